@@ -1,0 +1,683 @@
+/*
+ * a1mpc_oracle.c -- CPU ORACLE for the convex-MPC QP hot path.
+ *
+ * >>> TEST INFRASTRUCTURE ONLY. <<<
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker / the timed CPU baseline.  The product path
+ * (a1-qp-mpc-controller_amd/csrc) never links, loads or calls anything in oracle/.
+ *
+ * >>> PARITY UNPINNED. <<<
+ * The reference pins no expected values (S/test/test_mpc.cpp:157-161 only prints) and
+ * its arithmetic for the solve lives in third-party OSQP (oxfordcontrol/osqp, fetched
+ * UNPINNED at image build: docker/Dockerfile:77,91; install log shows
+ * libOsqpEigen.so.0.6.3, docker/Dockerfile:98 => OSQP 0.6.x) which is absent from
+ * /root/reference and from this machine, as are Eigen and ROS.  Nothing under
+ * /root/reference is compilable here (every file includes Eigen/OsqpEigen/ROS), so
+ * there is no oracle/_ref.  This file therefore
+ *   (1) restates the reference's own QP formation loop-for-loop in plain arrays
+ *       (S/ConvexMpc.cpp:7-58,110-156,181-245; S/A1RobotControl.cpp:11-48,377-413,
+ *        439-444,452-488,498-514,555-561; S/utils/Utils.cpp:35-41), and
+ *   (2) restates the published OSQP 0.6 algorithm (Stellato et al., "OSQP: an operator
+ *       splitting solver for quadratic programs", Math. Prog. Comp. 2020, and the 0.6.x
+ *       source layout: scaling.c scale_data, auxil.c set_rho_vec / update_xz_tilde /
+ *       update_x / update_z / update_y / compute_pri_res / compute_dua_res /
+ *       compute_rho_estimate / adapt_rho / check_termination / is_*_infeasible,
+ *       osqp.c osqp_solve) with OSQP's default settings.
+ * The one documented deviation: OSQP's default adaptive_rho_interval=0 derives the
+ * rho-update period from WALL-CLOCK setup time (osqp.c, PROFILING branch), i.e. the
+ * reference is not run-to-run reproducible.  The oracle uses a fixed iteration period
+ * (default 25 = the value OSQP's own rounding rule c_max(c_roundmultiple(iter,25),25)
+ * yields whenever 0.4*setup_time is worth < 38 iterations).
+ * The linear system is solved in its reduced form (P+sigma*I+A' diag(rho) A) by dense
+ * Cholesky -- algebraically what QDLDL's AMD ordering does to this KKT matrix (the
+ * degree-2 constraint rows are eliminated first); z_tilde is recovered through nu as
+ * OSQP does (solve_linsys_qdldl).
+ *
+ * Pinned instead (tests/test_oracle_*.py): KKT optimality of the tight mode, an
+ * independent scipy solve, analytic stand cases, and golden vectors in tests/golden/.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NS 13 /* MPC_STATE_DIM      S/A1Params.h:27 */
+#define NU 12 /* NUM_DOF            S/A1Params.h:34 */
+#define NC 20 /* MPC_CONSTRAINT_DIM S/A1Params.h:28 */
+#define NLEG 4
+
+/* OSQP 0.6 constants (include/constants.h) */
+#define OSQP_INFTY 1e30
+#define OSQP_RHO_MIN 1e-6
+#define OSQP_RHO_MAX 1e6
+#define OSQP_RHO_EQ_OVER_RHO_INEQ 1e3
+#define OSQP_RHO_TOL 1e-4
+#define OSQP_MIN_SCALING 1e-4
+#define OSQP_MAX_SCALING 1e4
+
+/* status values mirror OSQP's */
+#define ORC_SOLVED 1
+#define ORC_SOLVED_INACCURATE 2
+#define ORC_MAX_ITER_REACHED (-2)
+#define ORC_PRIMAL_INFEASIBLE (-3)
+#define ORC_DUAL_INFEASIBLE (-4)
+#define ORC_NON_CVX (-7)
+#define ORC_UNSOLVED (-10)
+
+typedef struct orc_settings {
+    double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, adaptive_rho_tolerance;
+    int32_t max_iter, scaling, check_termination, adaptive_rho, adaptive_rho_interval, warm_start;
+} orc_settings;
+
+typedef struct orc_info {
+    int32_t iters, status, rho_updates, nfact;
+    double pri_res, dua_res, rho_final;
+} orc_info;
+
+/* OSQP defaults (osqp/include/constants.h 0.6.x); warm_start as the MPC call site sets it. */
+void orc_default_settings(orc_settings *s) {
+    s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6;
+    s->eps_abs = 1e-3; s->eps_rel = 1e-3; s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
+    s->adaptive_rho_tolerance = 5.0;
+    s->max_iter = 4000; s->scaling = 10; s->check_termination = 25;
+    s->adaptive_rho = 1; s->adaptive_rho_interval = 25; s->warm_start = 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Generic OSQP-0.6 restatement: min 1/2 x'Px + q'x  s.t.  l <= Ax <= u
+ * P dense symmetric n*n (row-major), A in CSR.
+ * ---------------------------------------------------------------------------------------- */
+static double vmaxabs(const double *v, int n) {
+    double m = 0; for (int i = 0; i < n; ++i) { double a = fabs(v[i]); if (a > m) m = a; } return m;
+}
+static double limit_scaling1(double v) { /* scaling.c limit_scaling */
+    v = v < OSQP_MIN_SCALING ? 1.0 : v;
+    v = v > OSQP_MAX_SCALING ? OSQP_MAX_SCALING : v;
+    return v;
+}
+
+/* dense lower Cholesky in place (row-major, lower part used); returns 0 ok */
+static int chol_lower(double *K, int n) {
+    for (int j = 0; j < n; ++j) {
+        double d = K[j * n + j];
+        for (int k = 0; k < j; ++k) d -= K[j * n + k] * K[j * n + k];
+        if (!(d > 0.0)) return 1;
+        d = sqrt(d);
+        K[j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = K[i * n + j];
+            const double *ri = K + i * n, *rj = K + j * n;
+            for (int k = 0; k < j; ++k) s -= ri[k] * rj[k];
+            K[i * n + j] = s / d;
+        }
+    }
+    return 0;
+}
+static void chol_solve(const double *L, int n, double *b) {
+    for (int i = 0; i < n; ++i) {
+        double s = b[i]; const double *ri = L + i * n;
+        for (int k = 0; k < i; ++k) s -= ri[k] * b[k];
+        b[i] = s / ri[i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * b[k];
+        b[i] = s / L[i * n + i];
+    }
+}
+
+static void csr_mv(int m, const int32_t *rp, const int32_t *ci, const double *av, const double *x, double *y) {
+    for (int i = 0; i < m; ++i) { double s = 0; for (int k = rp[i]; k < rp[i + 1]; ++k) s += av[k] * x[ci[k]]; y[i] = s; }
+}
+static void csr_mtv(int m, int n, const int32_t *rp, const int32_t *ci, const double *av, const double *y, double *x) {
+    for (int j = 0; j < n; ++j) x[j] = 0;
+    for (int i = 0; i < m; ++i) for (int k = rp[i]; k < rp[i + 1]; ++k) x[ci[k]] += av[k] * y[i];
+}
+static void sym_mv(int n, const double *P, const double *x, double *y) {
+    for (int i = 0; i < n; ++i) { double s = 0; const double *r = P + i * n; for (int j = 0; j < n; ++j) s += r[j] * x[j]; y[i] = s; }
+}
+
+typedef struct {
+    int n, m, nnz;
+    const int32_t *rp, *ci;
+    double *P, *q, *av, *l, *u;           /* scaled data */
+    double *D, *Dinv, *E, *Einv, c, cinv; /* scaling */
+    double *rho_vec, *rho_inv_vec; int *ctype;
+    double *K;                            /* Cholesky factor of reduced KKT */
+    double *x, *z, *y, *x_prev, *z_prev, *xt, *zt, *delta_x, *delta_y;
+    double *Ax, *Px, *Aty, *tn, *tm;
+    double rho;
+    const orc_settings *st;
+    orc_info *info;
+} work_t;
+
+/* scaling.c scale_data */
+static void scale_data(work_t *w) {
+    int n = w->n, m = w->m;
+    double *Dt = w->tn, *Et = w->tm;
+    w->c = 1.0;
+    for (int i = 0; i < n; ++i) w->D[i] = 1.0;
+    for (int i = 0; i < m; ++i) w->E[i] = 1.0;
+    for (int it = 0; it < w->st->scaling; ++it) {
+        /* compute_inf_norm_cols_KKT */
+        for (int j = 0; j < n; ++j) Dt[j] = 0;
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double a = fabs(w->P[i * n + j]); if (a > Dt[j]) Dt[j] = a; }
+        for (int i = 0; i < m; ++i) {
+            double e = 0;
+            for (int k = w->rp[i]; k < w->rp[i + 1]; ++k) { double a = fabs(w->av[k]); if (a > e) e = a; if (a > Dt[w->ci[k]]) Dt[w->ci[k]] = a; }
+            Et[i] = e;
+        }
+        for (int j = 0; j < n; ++j) Dt[j] = 1.0 / sqrt(limit_scaling1(Dt[j]));
+        for (int i = 0; i < m; ++i) Et[i] = 1.0 / sqrt(limit_scaling1(Et[i]));
+        /* P <- D P D ; A <- E A D ; q <- D q */
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) w->P[i * n + j] *= Dt[i] * Dt[j];
+        for (int i = 0; i < m; ++i) for (int k = w->rp[i]; k < w->rp[i + 1]; ++k) w->av[k] *= Et[i] * Dt[w->ci[k]];
+        for (int j = 0; j < n; ++j) { w->q[j] *= Dt[j]; w->D[j] *= Dt[j]; }
+        for (int i = 0; i < m; ++i) w->E[i] *= Et[i];
+        /* cost normalisation */
+        double mean = 0;
+        for (int j = 0; j < n; ++j) { double cm = 0; for (int i = 0; i < n; ++i) { double a = fabs(w->P[i * n + j]); if (a > cm) cm = a; } mean += cm; }
+        mean /= n;
+        double nq = limit_scaling1(vmaxabs(w->q, n));
+        double ct = mean > nq ? mean : nq;
+        ct = 1.0 / limit_scaling1(ct);
+        for (int i = 0; i < n * n; ++i) w->P[i] *= ct;
+        for (int j = 0; j < n; ++j) w->q[j] *= ct;
+        w->c *= ct;
+    }
+    w->cinv = 1.0 / w->c;
+    for (int j = 0; j < n; ++j) w->Dinv[j] = 1.0 / w->D[j];
+    for (int i = 0; i < m; ++i) { w->Einv[i] = 1.0 / w->E[i]; w->l[i] *= w->E[i]; w->u[i] *= w->E[i]; }
+}
+
+/* auxil.c set_rho_vec */
+static void set_rho_vec(work_t *w) {
+    w->rho = fmin(fmax(w->rho, OSQP_RHO_MIN), OSQP_RHO_MAX);
+    for (int i = 0; i < w->m; ++i) {
+        if (w->l[i] < -OSQP_INFTY * OSQP_MIN_SCALING && w->u[i] > OSQP_INFTY * OSQP_MIN_SCALING) { w->ctype[i] = -1; w->rho_vec[i] = OSQP_RHO_MIN; }
+        else if (w->u[i] - w->l[i] < OSQP_RHO_TOL) { w->ctype[i] = 1; w->rho_vec[i] = OSQP_RHO_EQ_OVER_RHO_INEQ * w->rho; }
+        else { w->ctype[i] = 0; w->rho_vec[i] = w->rho; }
+        w->rho_inv_vec[i] = 1.0 / w->rho_vec[i];
+    }
+}
+
+/* reduced KKT: K = P + sigma I + A' diag(rho) A, Cholesky */
+static int factor(work_t *w) {
+    int n = w->n;
+    memcpy(w->K, w->P, sizeof(double) * n * n);
+    for (int j = 0; j < n; ++j) w->K[j * n + j] += w->st->sigma;
+    for (int i = 0; i < w->m; ++i)
+        for (int k = w->rp[i]; k < w->rp[i + 1]; ++k)
+            for (int k2 = w->rp[i]; k2 < w->rp[i + 1]; ++k2)
+                w->K[w->ci[k] * n + w->ci[k2]] += w->rho_vec[i] * w->av[k] * w->av[k2];
+    w->info->nfact++;
+    return chol_lower(w->K, n);
+}
+
+/* auxil.c compute_pri_res / compute_dua_res (unscaled norms, scaled vectors kept in z_prev/x_prev) */
+static double compute_pri_res(work_t *w) {
+    csr_mv(w->m, w->rp, w->ci, w->av, w->x, w->Ax);
+    double r = 0;
+    for (int i = 0; i < w->m; ++i) { w->z_prev[i] = w->Ax[i] - w->z[i]; double a = fabs(w->Einv[i] * w->z_prev[i]); if (a > r) r = a; }
+    return r;
+}
+static double compute_dua_res(work_t *w) {
+    sym_mv(w->n, w->P, w->x, w->Px);
+    csr_mtv(w->m, w->n, w->rp, w->ci, w->av, w->y, w->Aty);
+    double r = 0;
+    for (int j = 0; j < w->n; ++j) { w->x_prev[j] = w->q[j] + w->Px[j] + w->Aty[j]; double a = fabs(w->Dinv[j] * w->x_prev[j]); if (a > r) r = a; }
+    return w->cinv * r;
+}
+static double compute_pri_tol(work_t *w, double ea, double er) {
+    double a = 0, b = 0;
+    for (int i = 0; i < w->m; ++i) { double t = fabs(w->Einv[i] * w->z[i]); if (t > a) a = t; t = fabs(w->Einv[i] * w->Ax[i]); if (t > b) b = t; }
+    return ea + er * fmax(a, b);
+}
+static double compute_dua_tol(work_t *w, double ea, double er) {
+    double a = 0, b = 0, c = 0;
+    for (int j = 0; j < w->n; ++j) {
+        double t = fabs(w->Dinv[j] * w->q[j]); if (t > a) a = t;
+        t = fabs(w->Dinv[j] * w->Aty[j]); if (t > b) b = t;
+        t = fabs(w->Dinv[j] * w->Px[j]); if (t > c) c = t;
+    }
+    return ea + er * w->cinv * fmax(fmax(a, b), c);
+}
+static int is_primal_infeasible(work_t *w, double eps) {
+    double nd = 0, lhs = 0;
+    for (int i = 0; i < w->m; ++i) {
+        if (w->u[i] > OSQP_INFTY * OSQP_MIN_SCALING) {
+            if (w->l[i] < -OSQP_INFTY * OSQP_MIN_SCALING) w->delta_y[i] = 0.0; else w->delta_y[i] = fmin(w->delta_y[i], 0.0);
+        } else if (w->l[i] < -OSQP_INFTY * OSQP_MIN_SCALING) w->delta_y[i] = fmax(w->delta_y[i], 0.0);
+        double a = fabs(w->E[i] * w->delta_y[i]); if (a > nd) nd = a;
+    }
+    if (nd > eps) {
+        for (int i = 0; i < w->m; ++i) lhs += w->u[i] * fmax(w->delta_y[i], 0) + w->l[i] * fmin(w->delta_y[i], 0);
+        if (lhs < -eps * nd) {
+            csr_mtv(w->m, w->n, w->rp, w->ci, w->av, w->delta_y, w->tn);
+            double r = 0; for (int j = 0; j < w->n; ++j) { double a = fabs(w->Dinv[j] * w->tn[j]); if (a > r) r = a; }
+            return r < eps * nd;
+        }
+    }
+    return 0;
+}
+static int is_dual_infeasible(work_t *w, double eps) {
+    double nd = 0, qd = 0;
+    for (int j = 0; j < w->n; ++j) { double a = fabs(w->D[j] * w->delta_x[j]); if (a > nd) nd = a; qd += w->q[j] * w->delta_x[j]; }
+    if (nd > eps && qd < -w->c * eps * nd) {
+        sym_mv(w->n, w->P, w->delta_x, w->tn);
+        double r = 0; for (int j = 0; j < w->n; ++j) { double a = fabs(w->Dinv[j] * w->tn[j]); if (a > r) r = a; }
+        if (r < w->c * eps * nd) {
+            csr_mv(w->m, w->rp, w->ci, w->av, w->delta_x, w->tm);
+            for (int i = 0; i < w->m; ++i) {
+                double v = w->Einv[i] * w->tm[i];
+                if ((w->u[i] < OSQP_INFTY * OSQP_MIN_SCALING && v > eps * nd) || (w->l[i] > -OSQP_INFTY * OSQP_MIN_SCALING && v < -eps * nd)) return 0;
+            }
+            return 1;
+        }
+    }
+    return 0;
+}
+static int check_termination(work_t *w, int approximate) {
+    double ea = w->st->eps_abs, er = w->st->eps_rel, epi = w->st->eps_prim_inf, edi = w->st->eps_dual_inf;
+    int prc = 0, drc = 0, pic = 0, dic = 0;
+    if (w->info->pri_res > OSQP_INFTY || w->info->dua_res > OSQP_INFTY || isnan(w->info->pri_res) || isnan(w->info->dua_res)) { w->info->status = ORC_NON_CVX; return 1; }
+    if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+    if (w->m == 0) prc = 1;
+    else { if (w->info->pri_res < compute_pri_tol(w, ea, er)) prc = 1; else pic = is_primal_infeasible(w, epi); }
+    if (w->info->dua_res < compute_dua_tol(w, ea, er)) drc = 1; else dic = is_dual_infeasible(w, edi);
+    if (prc && drc) { w->info->status = approximate ? ORC_SOLVED_INACCURATE : ORC_SOLVED; return 1; }
+    if (pic) { w->info->status = ORC_PRIMAL_INFEASIBLE; return 1; }
+    if (dic) { w->info->status = ORC_DUAL_INFEASIBLE; return 1; }
+    return 0;
+}
+static void update_info(work_t *w) { w->info->pri_res = compute_pri_res(w); w->info->dua_res = compute_dua_res(w); }
+
+/* auxil.c compute_rho_estimate (all SCALED quantities) */
+static double compute_rho_estimate(work_t *w) {
+    double pr = vmaxabs(w->z_prev, w->m), dr = vmaxabs(w->x_prev, w->n);
+    double pn = fmax(vmaxabs(w->z, w->m), vmaxabs(w->Ax, w->m));
+    pr /= (pn + 1e-10);
+    double dn = fmax(fmax(vmaxabs(w->q, w->n), vmaxabs(w->Aty, w->n)), vmaxabs(w->Px, w->n));
+    dr /= (dn + 1e-10);
+    double re = w->rho * sqrt(pr / (dr + 1e-10));
+    return fmin(fmax(re, OSQP_RHO_MIN), OSQP_RHO_MAX);
+}
+static int adapt_rho(work_t *w) {
+    double rn = compute_rho_estimate(w);
+    if (rn > w->rho * w->st->adaptive_rho_tolerance || rn < w->rho / w->st->adaptive_rho_tolerance) {
+        w->rho = fmin(fmax(rn, OSQP_RHO_MIN), OSQP_RHO_MAX);
+        for (int i = 0; i < w->m; ++i) {
+            if (w->ctype[i] == 0) { w->rho_vec[i] = w->rho; w->rho_inv_vec[i] = 1.0 / w->rho; }
+            else if (w->ctype[i] == 1) { w->rho_vec[i] = OSQP_RHO_EQ_OVER_RHO_INEQ * w->rho; w->rho_inv_vec[i] = 1.0 / w->rho_vec[i]; }
+        }
+        w->info->rho_updates++;
+        return factor(w);
+    }
+    return 0;
+}
+
+/*
+ * x (n), y (m): unscaled; read as the warm start when settings->warm_start != 0 (osqp_warm_start
+ * semantics: x_s = Dinv x, z_s = A_s x_s, y_s = c Einv y), always written with the solution
+ * (store_solution: x = D x_s, y = cinv E y_s; NaN on infeasible status as OSQP does).
+ * rho_io: optional in/out carried rho (settings->rho persists across OSQP solves).
+ */
+int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
+                   const double *l, const double *u, const orc_settings *st, double *x, double *y, double *rho_io,
+                   orc_info *info) {
+    work_t w; memset(&w, 0, sizeof w);
+    int nnz = rp[m];
+    size_t tot = (size_t)2 * n * n + 16 * (size_t)n + 16 * (size_t)m + nnz + 64;
+    double *buf = (double *)calloc(tot, sizeof(double));
+    int *ctype = (int *)calloc(m + 1, sizeof(int));
+    if (!buf || !ctype) { free(buf); free(ctype); return -1; }
+    double *p = buf;
+#define TAKE(k) (p += (k), p - (k))
+    w.n = n; w.m = m; w.nnz = nnz; w.rp = rp; w.ci = ci; w.st = st; w.info = info; w.ctype = ctype;
+    w.P = TAKE(n * n); w.K = TAKE(n * n); w.q = TAKE(n); w.av = TAKE(nnz); w.l = TAKE(m); w.u = TAKE(m);
+    w.D = TAKE(n); w.Dinv = TAKE(n); w.E = TAKE(m); w.Einv = TAKE(m); w.rho_vec = TAKE(m); w.rho_inv_vec = TAKE(m);
+    w.x = TAKE(n); w.z = TAKE(m); w.y = TAKE(m); w.x_prev = TAKE(n); w.z_prev = TAKE(m); w.xt = TAKE(n); w.zt = TAKE(m);
+    w.delta_x = TAKE(n); w.delta_y = TAKE(m); w.Ax = TAKE(m); w.Px = TAKE(n); w.Aty = TAKE(n); w.tn = TAKE(n); w.tm = TAKE(m);
+#undef TAKE
+    memcpy(w.P, P, sizeof(double) * n * n); memcpy(w.q, q, sizeof(double) * n); memcpy(w.av, av, sizeof(double) * nnz);
+    memcpy(w.l, l, sizeof(double) * m); memcpy(w.u, u, sizeof(double) * m);
+    memset(info, 0, sizeof *info); info->status = ORC_UNSOLVED;
+    w.rho = (rho_io && st->warm_start && *rho_io > 0) ? *rho_io : st->rho;
+
+    /* osqp_setup */
+    if (st->scaling) scale_data(&w);
+    else { w.c = w.cinv = 1; for (int j = 0; j < n; ++j) w.D[j] = w.Dinv[j] = 1; for (int i = 0; i < m; ++i) w.E[i] = w.Einv[i] = 1; }
+    set_rho_vec(&w);
+    int rc = factor(&w);
+    if (rc) { info->status = ORC_NON_CVX; goto done; }
+
+    /* cold / warm start */
+    if (st->warm_start) {
+        for (int j = 0; j < n; ++j) w.x[j] = w.Dinv[j] * x[j];
+        csr_mv(m, rp, ci, w.av, w.x, w.z);
+        for (int i = 0; i < m; ++i) w.y[i] = w.c * w.Einv[i] * y[i];
+    }
+
+    {
+        int iter, can_check = 0;
+        const double alpha = st->alpha, sigma = st->sigma;
+        for (iter = 1; iter <= st->max_iter; ++iter) {
+            double *t;
+            t = w.x; w.x = w.x_prev; w.x_prev = t;
+            t = w.z; w.z = w.z_prev; w.z_prev = t;
+            /* update_xz_tilde: rhs, reduced solve, nu, z_tilde */
+            for (int i = 0; i < m; ++i) w.tm[i] = w.z_prev[i] - w.rho_inv_vec[i] * w.y[i]; /* rhs_z */
+            for (int j = 0; j < n; ++j) w.xt[j] = sigma * w.x_prev[j] - w.q[j];
+            for (int i = 0; i < m; ++i) { double s = w.rho_vec[i] * w.tm[i]; for (int k = rp[i]; k < rp[i + 1]; ++k) w.xt[ci[k]] += w.av[k] * s; }
+            chol_solve(w.K, n, w.xt);
+            csr_mv(m, rp, ci, w.av, w.xt, w.zt); /* A x_tilde */
+            for (int i = 0; i < m; ++i) {
+                double nu = w.rho_vec[i] * (w.zt[i] - w.tm[i]);
+                w.zt[i] = w.tm[i] + w.rho_inv_vec[i] * nu; /* b[n+j] += rho_inv*nu (solve_linsys_qdldl) */
+            }
+            /* update_x, update_z, update_y */
+            for (int j = 0; j < n; ++j) { w.x[j] = alpha * w.xt[j] + (1.0 - alpha) * w.x_prev[j]; w.delta_x[j] = w.x[j] - w.x_prev[j]; }
+            for (int i = 0; i < m; ++i) {
+                double v = alpha * w.zt[i] + (1.0 - alpha) * w.z_prev[i] + w.rho_inv_vec[i] * w.y[i];
+                w.z[i] = fmin(fmax(v, w.l[i]), w.u[i]);
+            }
+            for (int i = 0; i < m; ++i) {
+                w.delta_y[i] = w.rho_vec[i] * (alpha * w.zt[i] + (1.0 - alpha) * w.z_prev[i] - w.z[i]);
+                w.y[i] += w.delta_y[i];
+            }
+            can_check = st->check_termination && (iter % st->check_termination == 0);
+            if (can_check) { update_info(&w); if (check_termination(&w, 0)) break; }
+            if (st->adaptive_rho && st->adaptive_rho_interval && (iter % st->adaptive_rho_interval == 0)) {
+                if (!can_check) update_info(&w);
+                if (adapt_rho(&w)) { info->status = ORC_NON_CVX; break; }
+            }
+        }
+        if (iter > st->max_iter) iter = st->max_iter;
+        info->iters = iter;
+        if (info->status == ORC_UNSOLVED) {
+            if (!can_check) { update_info(&w); check_termination(&w, 0); }
+            if (info->status == ORC_UNSOLVED && !check_termination(&w, 1)) info->status = ORC_MAX_ITER_REACHED;
+        }
+    }
+done:
+    info->rho_final = w.rho;
+    if (rho_io) *rho_io = w.rho;
+    if (info->status == ORC_PRIMAL_INFEASIBLE || info->status == ORC_DUAL_INFEASIBLE || info->status == ORC_NON_CVX) {
+        for (int j = 0; j < n; ++j) x[j] = NAN;
+        for (int i = 0; i < m; ++i) y[i] = NAN;
+    } else {
+        for (int j = 0; j < n; ++j) x[j] = w.D[j] * w.x[j];
+        for (int i = 0; i < m; ++i) y[i] = w.cinv * w.E[i] * w.y[i];
+    }
+    free(buf); free(ctype);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Formation: MPC (S/ConvexMpc.cpp) -- literal restatement, runtime horizon
+ * ---------------------------------------------------------------------------------------- */
+typedef struct orc_mpc_params {
+    int32_t horizon;
+    double dt, mu, fz_min, fz_max;     /* S/ConvexMpc.cpp:8,223-224; S/A1RobotControl.cpp:462 */
+    double q[NS], r[NU];               /* S/A1CtrlStates.h:365-366 */
+    double mass, inertia[9];           /* S/A1CtrlStates.h:358-360, row-major 3x3 */
+} orc_mpc_params;
+
+static void mat3_mul(const double *a, const double *b, double *c) { /* row-major */
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += a[i * 3 + k] * b[k * 3 + j]; c[i * 3 + j] = s; }
+}
+static void mat3_inv(const double *a, double *inv) { /* cofactor formula, as Eigen's fixed 3x3 inverse */
+    double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+    double det = a[0] * c00 + a[1] * c01 + a[2] * c02, id = 1.0 / det;
+    inv[0] = c00 * id; inv[1] = (a[2] * a[7] - a[1] * a[8]) * id; inv[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    inv[3] = c01 * id; inv[4] = (a[0] * a[8] - a[2] * a[6]) * id; inv[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    inv[6] = c02 * id; inv[7] = (a[1] * a[6] - a[0] * a[7]) * id; inv[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+}
+static void skew3(const double *v, double *s) { /* S/utils/Utils.cpp:35-41 */
+    s[0] = 0; s[1] = -v[2]; s[2] = v[1]; s[3] = v[2]; s[4] = 0; s[5] = -v[0]; s[6] = -v[1]; s[7] = v[0]; s[8] = 0;
+}
+
+/* S/ConvexMpc.cpp:110-130  (A_c 13x13 row-major) */
+void orc_A_mat_c(double yaw, double *Ac) {
+    memset(Ac, 0, sizeof(double) * NS * NS);
+    double c = cos(yaw), s = sin(yaw);
+    Ac[0 * NS + 6] = c; Ac[0 * NS + 7] = s; Ac[1 * NS + 6] = -s; Ac[1 * NS + 7] = c; Ac[2 * NS + 8] = 1;
+    Ac[3 * NS + 9] = 1; Ac[4 * NS + 10] = 1; Ac[5 * NS + 11] = 1;
+    Ac[11 * NS + NU] = 1;
+}
+/* S/ConvexMpc.cpp:132-143  (B_c 13x12 row-major); foot: 3x4 column-major (Eigen), Rw row-major */
+void orc_B_mat_c(double mass, const double *Ib, const double *Rw, const double *foot, double *Bc) {
+    double Rt[9], t[9], Iw[9], Iwi[9], sk[9], blk[9];
+    memset(Bc, 0, sizeof(double) * NS * NU);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt[i * 3 + j] = Rw[j * 3 + i];
+    mat3_mul(Rw, Ib, t); mat3_mul(t, Rt, Iw);
+    for (int leg = 0; leg < NLEG; ++leg) {
+        mat3_inv(Iw, Iwi); skew3(foot + 3 * leg, sk); mat3_mul(Iwi, sk, blk);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Bc[(6 + i) * NU + 3 * leg + j] = blk[i * 3 + j];
+        for (int i = 0; i < 3; ++i) Bc[(9 + i) * NU + 3 * leg + i] = 1.0 / mass;
+    }
+}
+
+/*
+ * Full MPC QP data.  All outputs dense row-major; n = 12h, m = 20h.
+ *   x0[13], xref[13h], yaw (for A_c), Rw[9] row-major, foot: 3x4 col-major (stride 0 => same feet every
+ *   step, S/A1RobotControl.cpp:498-514; stride 12 => per-step feet as S/test/test_mpc.cpp:106-122),
+ *   contact[4] (+ stride 4 for per-step schedules; reference broadcasts, S/ConvexMpc.cpp:228-245).
+ * P (n*n), g (n), A CSR (rp[m+1], ci[36h], av[36h]), l (m), u (m).
+ */
+void orc_mpc_form(const orc_mpc_params *pr, const double *x0, const double *xref, double yaw, const double *Rw,
+                  const double *foot, int foot_stride, const uint8_t *contact, int contact_stride,
+                  double *P, double *g, int32_t *rp, int32_t *ci, double *av, double *l, double *u) {
+    const int h = pr->horizon, n = NU * h, ns = NS * h;
+    double Ac[NS * NS], Ad[NS * NS], Bc[NS * NU];
+    double *Bdl = (double *)calloc((size_t)ns * NU, sizeof(double));      /* B_mat_d_list */
+    double *Aqp = (double *)calloc((size_t)ns * NS, sizeof(double));
+    double *Bqp = (double *)calloc((size_t)ns * n, sizeof(double));
+    double *Qd = (double *)malloc(sizeof(double) * ns), *Rd = (double *)malloc(sizeof(double) * n);
+    double *tmp = (double *)malloc(sizeof(double) * ns);
+    /* ConvexMpc ctor :16-44 */
+    for (int i = 0; i < h; ++i) { for (int k = 0; k < NS; ++k) Qd[i * NS + k] = 2 * pr->q[k]; for (int k = 0; k < NU; ++k) Rd[i * NU + k] = 2 * pr->r[k]; }
+    orc_A_mat_c(yaw, Ac);
+    for (int i = 0; i < NS; ++i) for (int j = 0; j < NS; ++j) Ad[i * NS + j] = (i == j ? 1.0 : 0.0) + Ac[i * NS + j] * pr->dt; /* :150 */
+    for (int i = 0; i < h; ++i) {
+        orc_B_mat_c(pr->mass, pr->inertia, Rw, foot + (size_t)i * foot_stride, Bc);
+        for (int k = 0; k < NS * NU; ++k) Bdl[(size_t)i * NS * NU + k] = Bc[k] * pr->dt; /* :151, A1RobotControl.cpp:513 */
+    }
+    /* :184-202 */
+    for (int i = 0; i < h; ++i) {
+        double *Ai = Aqp + (size_t)i * NS * NS;
+        if (i == 0) memcpy(Ai, Ad, sizeof Ad);
+        else {
+            const double *Ap = Aqp + (size_t)(i - 1) * NS * NS;
+            for (int r = 0; r < NS; ++r) for (int c = 0; c < NS; ++c) { double s = 0; for (int k = 0; k < NS; ++k) s += Ap[r * NS + k] * Ad[k * NS + c]; Ai[r * NS + c] = s; }
+        }
+        for (int j = 0; j < i + 1; ++j) {
+            const double *Bj = Bdl + (size_t)j * NS * NU;
+            if (i - j == 0) {
+                for (int r = 0; r < NS; ++r) for (int c = 0; c < NU; ++c) Bqp[(size_t)(i * NS + r) * n + j * NU + c] = Bj[r * NU + c];
+            } else {
+                const double *Ap = Aqp + (size_t)(i - j - 1) * NS * NS;
+                for (int r = 0; r < NS; ++r) for (int c = 0; c < NU; ++c) { double s = 0; for (int k = 0; k < NS; ++k) s += Ap[r * NS + k] * Bj[k * NU + c]; Bqp[(size_t)(i * NS + r) * n + j * NU + c] = s; }
+            }
+        }
+    }
+    /* :207-210  dense_hessian = B_qp' Q B_qp + R */
+    for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) P[(size_t)a * n + b] = 0;
+    for (int k = 0; k < ns; ++k) {
+        const double *row = Bqp + (size_t)k * n; double qk = Qd[k];
+        if (qk == 0.0) continue;
+        for (int a = 0; a < n; ++a) { double v = row[a] * qk; if (v == 0.0) continue; double *Pa = P + (size_t)a * n; for (int b = 0; b < n; ++b) Pa[b] += v * row[b]; }
+    }
+    for (int a = 0; a < n; ++a) P[(size_t)a * n + a] += Rd[a];
+    /* :215-217 gradient */
+    for (int i = 0; i < h; ++i) for (int r = 0; r < NS; ++r) { double s = 0; for (int k = 0; k < NS; ++k) s += Aqp[(size_t)i * NS * NS + r * NS + k] * x0[k]; tmp[i * NS + r] = (s - xref[i * NS + r]) * Qd[i * NS + r]; }
+    for (int a = 0; a < n; ++a) { double s = 0; for (int k = 0; k < ns; ++k) s += Bqp[(size_t)k * n + a] * tmp[k]; g[a] = s; }
+    /* ctor :46-58 constraint stencil, and bounds :223-245 */
+    int nz = 0;
+    for (int i = 0; i < NLEG * h; ++i) {
+        const uint8_t *cs = contact + (size_t)(i / NLEG) * contact_stride;
+        double cf = cs[i % NLEG] ? 1.0 : 0.0;
+        int r0 = 5 * i, c0 = 3 * i;
+        rp[r0 + 0] = nz; ci[nz] = c0 + 0; av[nz++] = 1; ci[nz] = c0 + 2; av[nz++] = pr->mu;
+        rp[r0 + 1] = nz; ci[nz] = c0 + 0; av[nz++] = 1; ci[nz] = c0 + 2; av[nz++] = -pr->mu;
+        rp[r0 + 2] = nz; ci[nz] = c0 + 1; av[nz++] = 1; ci[nz] = c0 + 2; av[nz++] = pr->mu;
+        rp[r0 + 3] = nz; ci[nz] = c0 + 1; av[nz++] = 1; ci[nz] = c0 + 2; av[nz++] = -pr->mu;
+        rp[r0 + 4] = nz; ci[nz] = c0 + 2; av[nz++] = 1;
+        l[r0 + 0] = 0; u[r0 + 0] = OSQP_INFTY;
+        l[r0 + 1] = -OSQP_INFTY; u[r0 + 1] = 0;
+        l[r0 + 2] = 0; u[r0 + 2] = OSQP_INFTY;
+        l[r0 + 3] = -OSQP_INFTY; u[r0 + 3] = 0;
+        l[r0 + 4] = pr->fz_min * cf; u[r0 + 4] = pr->fz_max * cf;
+    }
+    rp[NC * h] = nz;
+    free(Bdl); free(Aqp); free(Bqp); free(Qd); free(Rd); free(tmp);
+}
+
+/* S/A1RobotControl.cpp:470-488 -- reference trajectory from the compact command */
+void orc_mpc_reference(int h, double dt, const double *euler, const double *pos, const double *Rw,
+                       const double *euler_d, const double *lin_vel_d_body, const double *ang_vel_d, double pos_z_d,
+                       double *xref) {
+    double vw[3];
+    for (int i = 0; i < 3; ++i) vw[i] = Rw[i * 3 + 0] * lin_vel_d_body[0] + Rw[i * 3 + 1] * lin_vel_d_body[1] + Rw[i * 3 + 2] * lin_vel_d_body[2];
+    for (int i = 0; i < h; ++i) {
+        double *x = xref + i * NS;
+        x[0] = euler_d[0]; x[1] = euler_d[1]; x[2] = euler[2] + ang_vel_d[2] * dt * (i + 1);
+        x[3] = pos[0] + vw[0] * dt * (i + 1); x[4] = pos[1] + vw[1] * dt * (i + 1); x[5] = pos_z_d;
+        x[6] = ang_vel_d[0]; x[7] = ang_vel_d[1]; x[8] = ang_vel_d[2];
+        x[9] = vw[0]; x[10] = vw[1]; x[11] = 0; x[12] = -9.8;
+    }
+}
+
+/*
+ * One MPC tick, S/A1RobotControl.cpp:446-562 minus ROS: form, OSQP solve, grf_body = R' f (Q9).
+ * u_full (12h, optional), warm x/y (optional, n and m), returns info.
+ * grf_out: 3x4 column-major.  NaN solution => zeros + status (replaces quirk Q8).
+ */
+int orc_mpc_solve(const orc_mpc_params *pr, const orc_settings *st, const double *x0, const double *xref, const double *Rw,
+                  const double *foot, int foot_stride, const uint8_t *contact, int contact_stride,
+                  double *grf_out, double *u_full, double *warm_x, double *warm_y, double *warm_rho, orc_info *info) {
+    const int h = pr->horizon, n = NU * h, m = NC * h;
+    double *P = (double *)malloc(sizeof(double) * ((size_t)n * n + n + 2 * m + 36 * h + n + m));
+    double *g = P + (size_t)n * n, *l = g + n, *u = l + m, *av = u + m, *x = av + 36 * h, *y = x + n;
+    int32_t *rp = (int32_t *)malloc(sizeof(int32_t) * (m + 1 + 36 * h)), *ci = rp + m + 1;
+    orc_mpc_form(pr, x0, xref, x0[2], Rw, foot, foot_stride, contact, contact_stride, P, g, rp, ci, av, l, u);
+    if (warm_x && st->warm_start) { memcpy(x, warm_x, sizeof(double) * n); memcpy(y, warm_y, sizeof(double) * m); }
+    else { memset(x, 0, sizeof(double) * n); memset(y, 0, sizeof(double) * m); }
+    int rc = orc_osqp_solve(n, m, P, g, rp, ci, av, l, u, st, x, y, warm_rho, info);
+    for (int leg = 0; leg < NLEG; ++leg) {
+        const double *f = x + 3 * leg;
+        int bad = isnan(f[0]) || isnan(f[1]) || isnan(f[2]);
+        for (int i = 0; i < 3; ++i) grf_out[3 * leg + i] = bad ? 0.0 : Rw[0 * 3 + i] * f[0] + Rw[1 * 3 + i] * f[1] + Rw[2 * 3 + i] * f[2];
+    }
+    if (u_full) memcpy(u_full, x, sizeof(double) * n);
+    if (warm_x) { memcpy(warm_x, x, sizeof(double) * n); memcpy(warm_y, y, sizeof(double) * m); }
+    free(P); free(rp);
+    return rc;
+}
+
+/* batch driver (CPU baseline): one problem per OpenMP thread, static partition */
+int orc_mpc_solve_batch(const orc_mpc_params *pr, const orc_settings *st, int nb, const double *x0, const double *xref,
+                        const double *Rw, const double *foot, const uint8_t *contact, double *grf_out, double *u_full,
+                        int32_t *iters, int32_t *status, int32_t *nfact, int nthreads) {
+    const int h = pr->horizon;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int b = 0; b < nb; ++b) {
+        orc_info info;
+        orc_mpc_solve(pr, st, x0 + (size_t)b * NS, xref + (size_t)b * NS * h, Rw + (size_t)b * 9, foot + (size_t)b * 12, 0,
+                      contact + (size_t)b * 4, 0, grf_out + (size_t)b * 12, u_full ? u_full + (size_t)b * NU * h : 0, 0, 0, 0, &info);
+        if (iters) iters[b] = info.iters;
+        if (status) status[b] = info.status;
+        if (nfact) nfact[b] = info.nfact;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Balance QP (S/A1RobotControl.cpp:11-48, 377-444)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct orc_qp_params {
+    double Qw[6];   /* :11  diag(1,1,1,400,400,100) */
+    double R;       /* :12  1e-3 */
+    double mu;      /* :13  0.7 */
+    double F_min, F_max; /* :14-15 */
+} orc_qp_params;
+
+void orc_default_qp_params(orc_qp_params *p) {
+    double q[6] = {1.0, 1.0, 1.0, 400.0, 400.0, 100.0};
+    memcpy(p->Qw, q, sizeof q); p->R = 1e-3; p->mu = 0.7; p->F_min = 0; p->F_max = 180;
+}
+
+/* :379-391  desired wrench from the PD law (all 3-vectors; Rw row-major) */
+void orc_balance_root_acc(const double *kp_lin, const double *kd_lin, const double *kp_ang, const double *kd_ang,
+                          const double *pos_d, const double *pos, const double *lin_vel_d_body, const double *lin_vel_world,
+                          const double *euler_d, const double *euler, const double *ang_vel_d_body, const double *ang_vel_world,
+                          const double *Rw, double mass, double *root_acc) {
+    double ee[3], t[3], t2[3];
+    for (int i = 0; i < 3; ++i) ee[i] = euler_d[i] - euler[i];
+    if (ee[2] > 3.1415926 * 1.5) ee[2] = euler_d[2] - 3.1415926 * 2 - euler[2];        /* :328-332 */
+    else if (ee[2] < -3.1415926 * 1.5) ee[2] = euler_d[2] + 3.1415926 * 2 - euler[2];
+    for (int i = 0; i < 3; ++i) root_acc[i] = kp_lin[i] * (pos_d[i] - pos[i]);
+    for (int i = 0; i < 3; ++i) t[i] = lin_vel_d_body[i] - (Rw[0 * 3 + i] * lin_vel_world[0] + Rw[1 * 3 + i] * lin_vel_world[1] + Rw[2 * 3 + i] * lin_vel_world[2]);
+    for (int i = 0; i < 3; ++i) t2[i] = kd_lin[i] * t[i];
+    for (int i = 0; i < 3; ++i) root_acc[i] += Rw[i * 3 + 0] * t2[0] + Rw[i * 3 + 1] * t2[1] + Rw[i * 3 + 2] * t2[2];
+    for (int i = 0; i < 3; ++i) root_acc[3 + i] = kp_ang[i] * ee[i];
+    for (int i = 0; i < 3; ++i) root_acc[3 + i] += kd_ang[i] * (ang_vel_d_body[i] - (Rw[0 * 3 + i] * ang_vel_world[0] + Rw[1 * 3 + i] * ang_vel_world[1] + Rw[2 * 3 + i] * ang_vel_world[2]));
+    root_acc[2] += mass * 9.8;
+}
+
+/* P (12x12), g(12), A CSR (20 rows, 36 nnz), l, u -- row order exactly as the ctor :28-48 */
+void orc_balance_form(const orc_qp_params *qp, const double *root_acc, const double *Rz, const double *foot,
+                      const uint8_t *contact, double *P, double *g, int32_t *rp, int32_t *ci, double *av, double *l, double *u) {
+    double M[6 * 12], sk[9];
+    memset(M, 0, sizeof M);
+    for (int leg = 0; leg < NLEG; ++leg) {
+        for (int i = 0; i < 3; ++i) M[i * 12 + 3 * leg + i] = 1.0;
+        skew3(foot + 3 * leg, sk);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += Rz[k * 3 + i] * sk[k * 3 + j]; M[(3 + i) * 12 + 3 * leg + j] = s; } /* Rz' * skew */
+    }
+    for (int a = 0; a < 12; ++a) for (int b = 0; b < 12; ++b) { double s = (a == b) ? qp->R : 0.0; for (int k = 0; k < 6; ++k) s += M[k * 12 + a] * qp->Qw[k] * M[k * 12 + b]; P[a * 12 + b] = s; }
+    for (int a = 0; a < 12; ++a) { double s = 0; for (int k = 0; k < 6; ++k) s += M[k * 12 + a] * qp->Qw[k] * root_acc[k]; g[a] = -s; }
+    int nz = 0;
+    for (int i = 0; i < NLEG; ++i) { rp[i] = nz; ci[nz] = 2 + 3 * i; av[nz++] = 1; double cf = contact[i] ? 1.0 : 0.0; l[i] = cf * qp->F_min; u[i] = cf * qp->F_max; }
+    for (int i = 0; i < NLEG; ++i) {
+        int r = NLEG + 4 * i;
+        rp[r + 0] = nz; ci[nz] = 3 * i; av[nz++] = 1; ci[nz] = 3 * i + 2; av[nz++] = -qp->mu;
+        rp[r + 1] = nz; ci[nz] = 3 * i; av[nz++] = -1; ci[nz] = 3 * i + 2; av[nz++] = -qp->mu;
+        rp[r + 2] = nz; ci[nz] = 3 * i + 1; av[nz++] = 1; ci[nz] = 3 * i + 2; av[nz++] = -qp->mu;
+        rp[r + 3] = nz; ci[nz] = 3 * i + 1; av[nz++] = -1; ci[nz] = 3 * i + 2; av[nz++] = -qp->mu;
+        for (int k = 0; k < 4; ++k) { l[r + k] = -OSQP_INFTY; u[r + k] = 0; }
+    }
+    rp[20] = nz;
+}
+
+/* one balance-QP tick: cold OSQP (warm start OFF, :419), grf_body = R' f (:439-444) */
+int orc_balance_solve(const orc_qp_params *qp, const orc_settings *st, const double *root_acc, const double *Rw, const double *Rz,
+                      const double *foot, const uint8_t *contact, double *grf_out, double *f_world, orc_info *info) {
+    double P[144], g[12], av[36], l[20], u[20], x[12], y[20];
+    int32_t rp[21], ci[36];
+    orc_balance_form(qp, root_acc, Rz, foot, contact, P, g, rp, ci, av, l, u);
+    memset(x, 0, sizeof x); memset(y, 0, sizeof y);
+    orc_settings s2 = *st; s2.warm_start = 0;
+    int rc = orc_osqp_solve(12, 20, P, g, rp, ci, av, l, u, &s2, x, y, 0, info);
+    for (int leg = 0; leg < NLEG; ++leg) {
+        const double *f = x + 3 * leg;
+        int bad = isnan(f[0]) || isnan(f[1]) || isnan(f[2]);
+        for (int i = 0; i < 3; ++i) grf_out[3 * leg + i] = bad ? 0.0 : Rw[0 * 3 + i] * f[0] + Rw[1 * 3 + i] * f[1] + Rw[2 * 3 + i] * f[2];
+    }
+    if (f_world) memcpy(f_world, x, sizeof x);
+    return rc;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,211 @@
+"""ctypes wrapper around oracle/liba1mpc_oracle.so  --  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see the header of a1mpc_oracle.c).  The product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liba1mpc_oracle.so")
+
+NS, NU, NC = 13, 12, 20
+
+STATUS = {1: "solved", 2: "solved_inaccurate", -2: "max_iter", -3: "primal_infeasible", -4: "dual_infeasible",
+          -7: "non_cvx", -10: "unsolved"}
+
+
+class Settings(C.Structure):
+    _fields_ = [("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double), ("eps_abs", C.c_double),
+                ("eps_rel", C.c_double), ("eps_prim_inf", C.c_double), ("eps_dual_inf", C.c_double),
+                ("adaptive_rho_tolerance", C.c_double), ("max_iter", C.c_int32), ("scaling", C.c_int32),
+                ("check_termination", C.c_int32), ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
+                ("warm_start", C.c_int32)]
+
+
+class Info(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("status", C.c_int32), ("rho_updates", C.c_int32), ("nfact", C.c_int32),
+                ("pri_res", C.c_double), ("dua_res", C.c_double), ("rho_final", C.c_double)]
+
+
+class MpcParams(C.Structure):
+    _fields_ = [("horizon", C.c_int32), ("dt", C.c_double), ("mu", C.c_double), ("fz_min", C.c_double),
+                ("fz_max", C.c_double), ("q", C.c_double * NS), ("r", C.c_double * NU), ("mass", C.c_double),
+                ("inertia", C.c_double * 9)]
+
+
+class QpParams(C.Structure):
+    _fields_ = [("Qw", C.c_double * 6), ("R", C.c_double), ("mu", C.c_double), ("F_min", C.c_double),
+                ("F_max", C.c_double)]
+
+
+def build(force=False):
+    """Compile the C restatement (gcc, a few seconds)."""
+    src = os.path.join(_HERE, "a1mpc_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liba1mpc_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a, t=C.c_double):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def default_settings(**over):
+    s = Settings()
+    lib().orc_default_settings(C.byref(s))
+    for k, v in over.items():
+        setattr(s, k, v)
+    return s
+
+
+def exact_settings(**over):
+    """'exact' mode: same algorithm driven to a tight tolerance (the truth the GPU and
+    the default-tolerance oracle are both measured against)."""
+    kw = dict(eps_abs=1e-10, eps_rel=1e-10, max_iter=100000)
+    kw.update(over)
+    return default_settings(**kw)
+
+
+def mpc_params(horizon, dt, mu, fz_min, fz_max, q, r, mass, inertia):
+    p = MpcParams()
+    p.horizon, p.dt, p.mu, p.fz_min, p.fz_max, p.mass = int(horizon), dt, mu, fz_min, fz_max, mass
+    p.q[:] = list(np.asarray(q, dtype=float))
+    p.r[:] = list(np.asarray(r, dtype=float))
+    p.inertia[:] = list(np.asarray(inertia, dtype=float).reshape(9))
+    return p
+
+
+def default_qp_params():
+    p = QpParams()
+    lib().orc_default_qp_params(C.byref(p))
+    return p
+
+
+def mpc_form(pr, x0, xref, Rw, foot, contact, yaw=None, foot_stride=0, contact_stride=0):
+    """Dense QP data of one problem: P (n,n), g, A (m,n dense, from CSR), l, u."""
+    h = pr.horizon
+    n, m = NU * h, NC * h
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    xref = np.ascontiguousarray(xref, dtype=np.float64)
+    Rw = np.ascontiguousarray(Rw, dtype=np.float64)
+    foot = np.ascontiguousarray(foot, dtype=np.float64)
+    contact = np.ascontiguousarray(contact, dtype=np.uint8)
+    P = np.zeros((n, n)); g = np.zeros(n); l = np.zeros(m); u = np.zeros(m)
+    rp = np.zeros(m + 1, dtype=np.int32); ci = np.zeros(36 * h, dtype=np.int32); av = np.zeros(36 * h)
+    lib().orc_mpc_form(C.byref(pr), _p(x0), _p(xref), C.c_double(float(x0[2] if yaw is None else yaw)), _p(Rw), _p(foot),
+                       C.c_int(foot_stride), _p(contact, C.c_uint8), C.c_int(contact_stride), _p(P), _p(g),
+                       _p(rp, C.c_int32), _p(ci, C.c_int32), _p(av), _p(l), _p(u))
+    A = np.zeros((m, n))
+    for i in range(m):
+        for k in range(rp[i], rp[i + 1]):
+            A[i, ci[k]] = av[k]
+    return P, g, A, l, u, (rp, ci, av)
+
+
+def osqp_solve(P, g, csr, l, u, st, x=None, y=None, rho=None):
+    rp, ci, av = csr
+    n, m = len(g), len(l)
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    x = np.zeros(n) if x is None else np.array(x, dtype=np.float64)
+    y = np.zeros(m) if y is None else np.array(y, dtype=np.float64)
+    info = Info()
+    rho_io = C.c_double(0.0 if rho is None else rho)
+    lib().orc_osqp_solve(C.c_int(n), C.c_int(m), _p(P), _p(np.ascontiguousarray(g)), _p(rp, C.c_int32), _p(ci, C.c_int32),
+                         _p(av), _p(np.ascontiguousarray(l)), _p(np.ascontiguousarray(u)), C.byref(st), _p(x), _p(y),
+                         C.byref(rho_io), C.byref(info))
+    return x, y, info, rho_io.value
+
+
+def mpc_solve_batch(pr, st, x0, xref, Rw, foot, contact, nthreads=0, want_u=False):
+    """Batch of independent ticks (S/A1RobotControl.cpp:446-562 each).  Arrays are (nb, ...)."""
+    h = pr.horizon
+    x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, NS)
+    nb = x0.shape[0]
+    xref = np.ascontiguousarray(xref, dtype=np.float64).reshape(nb, NS * h)
+    Rw = np.ascontiguousarray(Rw, dtype=np.float64).reshape(nb, 9)
+    foot = np.ascontiguousarray(foot, dtype=np.float64).reshape(nb, 12)
+    contact = np.ascontiguousarray(contact, dtype=np.uint8).reshape(nb, 4)
+    grf = np.zeros((nb, 12)); u = np.zeros((nb, NU * h)) if want_u else None
+    iters = np.zeros(nb, dtype=np.int32); status = np.zeros(nb, dtype=np.int32); nfact = np.zeros(nb, dtype=np.int32)
+    lib().orc_mpc_solve_batch(C.byref(pr), C.byref(st), C.c_int(nb), _p(x0), _p(xref), _p(Rw), _p(foot), _p(contact, C.c_uint8),
+                              _p(grf), _p(u), _p(iters, C.c_int32), _p(status, C.c_int32), _p(nfact, C.c_int32),
+                              C.c_int(nthreads))
+    return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
+
+
+def mpc_solve(pr, st, x0, xref, Rw, foot, contact, warm_x=None, warm_y=None, warm_rho=None, foot_stride=0,
+              contact_stride=0):
+    h = pr.horizon
+    n, m = NU * h, NC * h
+    grf = np.zeros(12); u = np.zeros(n)
+    info = Info()
+    wx = None if warm_x is None else np.array(warm_x, dtype=np.float64)
+    wy = None if warm_y is None else np.array(warm_y, dtype=np.float64)
+    rho = C.c_double(0.0 if warm_rho is None else warm_rho)
+    lib().orc_mpc_solve(C.byref(pr), C.byref(st), _p(np.ascontiguousarray(x0, dtype=np.float64)),
+                        _p(np.ascontiguousarray(xref, dtype=np.float64)), _p(np.ascontiguousarray(Rw, dtype=np.float64)),
+                        _p(np.ascontiguousarray(foot, dtype=np.float64)), C.c_int(foot_stride),
+                        _p(np.ascontiguousarray(contact, dtype=np.uint8), C.c_uint8), C.c_int(contact_stride), _p(grf), _p(u),
+                        _p(wx), _p(wy), C.byref(rho), C.byref(info))
+    return dict(grf=grf, u=u, info=info, warm_x=wx, warm_y=wy, rho=rho.value)
+
+
+def mpc_reference(h, dt, euler, pos, Rw, euler_d, lin_vel_d_body, ang_vel_d, pos_z_d):
+    xref = np.zeros(NS * h)
+    a = lambda v: _p(np.ascontiguousarray(v, dtype=np.float64))
+    lib().orc_mpc_reference(C.c_int(h), C.c_double(dt), a(euler), a(pos), a(Rw), a(euler_d), a(lin_vel_d_body), a(ang_vel_d),
+                            C.c_double(pos_z_d), _p(xref))
+    return xref
+
+
+def balance_form(qp, root_acc, Rz, foot, contact):
+    P = np.zeros((12, 12)); g = np.zeros(12); l = np.zeros(20); u = np.zeros(20)
+    rp = np.zeros(21, dtype=np.int32); ci = np.zeros(36, dtype=np.int32); av = np.zeros(36)
+    a = lambda v: _p(np.ascontiguousarray(v, dtype=np.float64))
+    lib().orc_balance_form(C.byref(qp), a(root_acc), a(Rz), a(foot), _p(np.ascontiguousarray(contact, dtype=np.uint8), C.c_uint8),
+                           _p(P), _p(g), _p(rp, C.c_int32), _p(ci, C.c_int32), _p(av), _p(l), _p(u))
+    A = np.zeros((20, 12))
+    for i in range(20):
+        for k in range(rp[i], rp[i + 1]):
+            A[i, ci[k]] = av[k]
+    return P, g, A, l, u, (rp, ci, av)
+
+
+def balance_solve(qp, st, root_acc, Rw, Rz, foot, contact):
+    grf = np.zeros(12); f = np.zeros(12); info = Info()
+    a = lambda v: _p(np.ascontiguousarray(v, dtype=np.float64))
+    lib().orc_balance_solve(C.byref(qp), C.byref(st), a(root_acc), a(Rw), a(Rz), a(foot),
+                            _p(np.ascontiguousarray(contact, dtype=np.uint8), C.c_uint8), _p(grf), _p(f), C.byref(info))
+    return dict(grf=grf, f_world=f, info=info)
+
+
+def balance_root_acc(kp_lin, kd_lin, kp_ang, kd_ang, pos_d, pos, lin_vel_d_body, lin_vel_world, euler_d, euler,
+                     ang_vel_d_body, ang_vel_world, Rw, mass):
+    out = np.zeros(6)
+    a = lambda v: _p(np.ascontiguousarray(v, dtype=np.float64))
+    lib().orc_balance_root_acc(a(kp_lin), a(kd_lin), a(kp_ang), a(kd_ang), a(pos_d), a(pos), a(lin_vel_d_body), a(lin_vel_world),
+                               a(euler_d), a(euler), a(ang_vel_d_body), a(ang_vel_world), a(Rw), C.c_double(mass), _p(out))
+    return out
+
+
+def num_threads():
+    return lib().orc_num_threads()
