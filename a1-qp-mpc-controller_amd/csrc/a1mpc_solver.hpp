@@ -1,0 +1,743 @@
+// a1mpc_solver.hpp -- one convex-MPC QP per DPP row (16 lanes), four QPs per wavefront.
+//
+// What it computes (reference behaviour, cited as S/ = src/a1_cpp/src/ of the reference tree):
+//   * QP formation of ConvexMpc (S/ConvexMpc.cpp:110-156 A_c/B_c/Euler discretisation, :181-245
+//     A_qp/B_qp, P = B_qp' Q B_qp + R, g = B_qp' Q (A_qp x0 - x_ref), friction-pyramid rows and bounds)
+//     as driven by A1RobotControl::compute_grf (S/A1RobotControl.cpp:446-562: same feet / rotation for
+//     every horizon step, contacts broadcast over the horizon, first-step forces rotated by R').
+//   * The OSQP 0.6 ADMM iteration the reference delegates to (call sites S/A1RobotControl.cpp:522-555):
+//     Ruiz equilibration (10 passes) + cost scaling, per-row rho (equality rows x1e3), over-relaxed
+//     ADMM (alpha 1.6), unscaled residual termination every 25 iterations, rho adaptation with
+//     re-factorisation -- the same iterates as oracle/a1mpc_oracle.c, to round-off.
+//
+// How (MI355X-first, nothing dense):
+//   * The horizon structure is exploited instead of materialised.  With the reference's step-invariant
+//     B_d and A_d = I + dt*A_c (A_c^2 B = 0) the Hessian is  P = alpha (x) U + beta (x) V + I (x) R  with two
+//     12x12 matrices U, V per problem and two H x H integer tables alpha, beta shared by everybody, so
+//     P is never formed: Ruiz column norms evaluate |gamma_st U_ab + V_ab| on the fly, P x and the
+//     gradient are one forward roll-out + one adjoint sweep, and the ADMM linear system
+//     (P + sigma I + A' rho A) x = b is an LQ problem solved by a Riccati recursion: per step a 12x12
+//     feedback K_t and a 12x12 S_t^{-1} (234 doubles) live in LDS, 18.7 KB per QP at H = 10.
+//   * Lane map inside a row: a 3-vector per quad.  Force layout: lane 4*leg+c holds f_{leg,c}; state
+//     layout: quads hold (rpy, pos, omega, vel).  12x12 mat-vecs are 12 x (row_newbcast DPP + v_fmac_f64)
+//     with the matrix row read from LDS; the same LDS image serves K x (row read) and K' r (column read).
+//   * ADMM vectors (x, z, y, D, E, q: 10 doubles per horizon step and lane) stay in VGPRs for the whole
+//     solve; all horizon loops over them are fully unrolled (template H), the Riccati factor loop is not.
+//
+// Everything is IEEE double, like the reference (Eigen double, OSQP c_float = double).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <type_traits>
+#include <utility>
+
+#include <a1mpc_rowops.hpp>  // csrc/gfx950/ (DPP) in the product build; tests/emu/ (host fibers) in the CPU test double
+
+namespace a1mpc {
+
+// ---- OSQP 0.6 constants (osqp/include/constants.h) ------------------------------------------------
+constexpr double kInfty = 1e30;
+constexpr double kRhoMin = 1e-6, kRhoMax = 1e6, kRhoEqOverIneq = 1e3, kRhoTol = 1e-4;
+constexpr double kMinScaling = 1e-4, kMaxScaling = 1e4;
+
+enum : int32_t {
+    A1MPC_SOLVED = 1,
+    A1MPC_SOLVED_INACCURATE = 2,
+    A1MPC_MAX_ITER_REACHED = -2,
+    A1MPC_NON_CVX = -7,
+    A1MPC_UNSOLVED = -10,
+};
+
+struct DeviceParams {
+    double dt, mu, fz_min, fz_max;
+    double q2[12];  // 2*q[0..11]   (S/ConvexMpc.cpp:20; q[12], the gravity state, never reaches P or g)
+    double r2[12];  // 2*r          (S/ConvexMpc.cpp:41)
+    double mass, inertia[9];
+    double rho0, sigma, alpha, eps_abs, eps_rel, adaptive_rho_tol;
+    int32_t max_iter, check_every, adaptive_rho, adaptive_rho_every, scaling_iters, warm_start;
+};
+
+struct ProblemIO {
+    const double* x0;        // 13
+    const double* xref;      // 13*H
+    const double* R;         // 9, row-major root_rot_mat
+    const double* foot;      // 12, 3x4 column-major foot_pos_abs (world-aligned, CoM-relative)
+    const uint8_t* contact;  // 4
+    double* grf;             // 12 out: 3x4 column-major body-frame GRFs
+    double* u_full;          // 12*H out (world frame, all steps) or null
+    double* warm_x;          // 12*H in/out or null   (unscaled primal, OSQP workspace x)
+    double* warm_y;          // 20*H in/out or null   (unscaled dual, reference row order)
+    double* rho_io;          // 1 in/out or null      (carried rho)
+    int32_t* iters;          // out or null
+    int32_t* status;         // out or null
+    int32_t* nfact;          // out or null
+};
+
+// ---- compile-time helpers ----------------------------------------------------------------------
+#define A1_CV(x) (std::remove_cv_t<std::remove_reference_t<decltype(x)>>::value)  // value of an integral_constant argument
+template <class F, int... I>
+A1_DEV void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+A1_DEV void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+constexpr int lane_of(int j) { return 4 * (j / 3) + (j % 3); }  // compact 0..11 -> lane in row
+template <int J>
+A1_DEV double bc(double v) {
+    return row_bcast<lane_of(J)>(v);
+}
+constexpr int alpha_diag(int s, int H) {  // sum_{i=s}^{H-1} (i-s)^2
+    int a = 0;
+    for (int i = s; i < H; ++i) a += (i - s) * (i - s);
+    return a;
+}
+
+A1_DEV double limit_scaling(double v) {  // osqp scaling.c limit_scaling
+    v = v < kMinScaling ? 1.0 : v;
+    v = v > kMaxScaling ? kMaxScaling : v;
+    return v;
+}
+A1_DEV double row_allmax(double v) {
+    v = fmax(v, row_ror<8>(v));
+    v = fmax(v, row_ror<4>(v));
+    v = fmax(v, row_ror<2>(v));
+    v = fmax(v, row_ror<1>(v));
+    return v;
+}
+A1_DEV double row_allsum(double v) {
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    v += row_ror<1>(v);
+    return v;
+}
+
+// ---- LDS image of one QP ------------------------------------------------------------------------
+template <int H>
+struct Layout {
+    static constexpr int KSTR = 13;          // padded row stride of K_t: conflict-free row and column reads
+    static constexpr int K_SZ = 12 * KSTR;   // 156
+    static constexpr int S_SZ = 78;          // packed lower triangle of S_t^{-1}
+    static constexpr int SLOT = K_SZ + S_SZ; // 234 doubles per horizon step
+    static constexpr int FAC = 0;
+    static constexpr int BL = H * SLOT;      // B~ (6x12): rows 0-2 = dt*Iw^-1*skew(r), rows 3-5 = dt/m*I
+    static constexpr int RAW = BL + 72;
+    // set-up-only aliases inside the factor region (the factor is written after Ruiz is finished)
+    static constexpr int TBL = 0;            // T*B~_omega (3x12)
+    static constexpr int DL = 36;            // D table of the current Ruiz pass, [t][12]
+    static_assert(DL + 12 * H <= H * SLOT, "alias");
+    // row stride == 3 (mod 32) doubles: the two QPs that share a 32-lane LDS phase hit disjoint banks
+    static constexpr int ROW_STRIDE = ((RAW + 28) / 32) * 32 + 3;
+    static_assert(ROW_STRIDE >= RAW, "stride");
+};
+
+// =================================================================================================
+// One QP, executed by the 16 lanes of a row.  `tab` = [s][t][2] = (alpha_st/beta_st, beta_st).
+// =================================================================================================
+template <int H>
+A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, const ProblemIO& io, double* __restrict__ lds) {
+    using L = Layout<H>;
+    const int ln = row_lane();
+    const int quad = ln >> 2, comp = ln & 3;
+    const bool act = comp < 3;
+    const int ci = act ? 3 * quad + comp : 0;  // compact index (safe 0 on pad lanes)
+    const int tri = ci * (ci + 1) / 2;
+    const double dt = P.dt, mu = P.mu;
+
+    // ---------------------------------------------------------------- inputs, B_d, per-lane constants
+    double Rm[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rm[i] = io.R[i];
+    const double yaw = io.x0[2];
+    const double cy = cos(yaw), sy = sin(yaw);  // S/ConvexMpc.cpp:115-116
+
+    double Bt[6];  // my column of B~ (force layout); zero on pad lanes
+    {
+        // I_world = R I_b R', inverse by cofactors (S/ConvexMpc.cpp:136-141)
+        double t9[9], Iw[9], Ii[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s += Rm[i * 3 + k] * P.inertia[k * 3 + j];
+                t9[i * 3 + j] = s;
+            }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) s += t9[i * 3 + k] * Rm[j * 3 + k];
+                Iw[i * 3 + j] = s;
+            }
+        const double c00 = Iw[4] * Iw[8] - Iw[5] * Iw[7], c01 = Iw[5] * Iw[6] - Iw[3] * Iw[8],
+                     c02 = Iw[3] * Iw[7] - Iw[4] * Iw[6];
+        const double idet = 1.0 / (Iw[0] * c00 + Iw[1] * c01 + Iw[2] * c02);
+        Ii[0] = c00 * idet; Ii[1] = (Iw[2] * Iw[7] - Iw[1] * Iw[8]) * idet; Ii[2] = (Iw[1] * Iw[5] - Iw[2] * Iw[4]) * idet;
+        Ii[3] = c01 * idet; Ii[4] = (Iw[0] * Iw[8] - Iw[2] * Iw[6]) * idet; Ii[5] = (Iw[2] * Iw[3] - Iw[0] * Iw[5]) * idet;
+        Ii[6] = c02 * idet; Ii[7] = (Iw[1] * Iw[6] - Iw[0] * Iw[7]) * idet; Ii[8] = (Iw[0] * Iw[4] - Iw[1] * Iw[3]) * idet;
+        const double rx = io.foot[3 * quad + 0], ry = io.foot[3 * quad + 1], rz = io.foot[3 * quad + 2];
+        // column `comp` of skew(r) (S/utils/Utils.cpp:35-41)
+        const double k0 = comp == 0 ? 0.0 : (comp == 1 ? -rz : ry);
+        const double k1 = comp == 0 ? rz : (comp == 1 ? 0.0 : -rx);
+        const double k2 = comp == 0 ? -ry : (comp == 1 ? rx : 0.0);
+        const double invm = 1.0 / P.mass;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            Bt[k] = act ? (Ii[k * 3 + 0] * k0 + Ii[k * 3 + 1] * k1 + Ii[k * 3 + 2] * k2) * dt : 0.0;  // :138,:151
+            Bt[3 + k] = (act && comp == k) ? invm * dt : 0.0;                                           // :139,:151
+        }
+    }
+    // T = A_c(0:3,6:9) = [[c,s,0],[-s,c,0],[0,0,1]] (S/ConvexMpc.cpp:123-125); my column of T*B~_omega
+    double TB[3];
+    TB[0] = cy * Bt[0] + sy * Bt[1];
+    TB[1] = -sy * Bt[0] + cy * Bt[1];
+    TB[2] = Bt[2];
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) lds[L::BL + k * 12 + ci] = Bt[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lds[L::TBL + k * 12 + ci] = TB[k];
+    }
+    row_sync();
+    // B~ row of the wrench lanes (state rows 6..11 = quads 2,3); zero elsewhere
+    double Brow[12];
+    {
+        const bool wl = act && quad >= 2;
+        const int k = wl ? ci - 6 : 0;
+#pragma unroll
+        for (int b = 0; b < 12; ++b) {
+            const double v = lds[L::BL + k * 12 + b];
+            Brow[b] = wl ? v : 0.0;
+        }
+    }
+    // A_d = I + dt*A_c and its transpose as row operators on a state-layout vector
+    const double fA = ln == 0 ? dt * cy : (ln == 1 ? -dt * sy : 0.0);
+    const double fB = ln == 0 ? dt * sy : (ln == 1 ? dt * cy : 0.0);
+    const double fC = ln == 2 ? dt : 0.0;
+    const double fP = (quad == 1 && act) ? dt : 0.0;
+    const double gA = ln == 8 ? dt * cy : (ln == 9 ? dt * sy : 0.0);
+    const double gB = ln == 8 ? -dt * sy : (ln == 9 ? dt * cy : 0.0);
+    const double gC = ln == 10 ? dt : 0.0;
+    const double gV = (quad == 3 && act) ? dt : 0.0;
+    auto opA = [&](double s) {  // (A_d s): rpy += dt*T*omega, pos += dt*vel
+        return s + fA * row_bcast<8>(s) + fB * row_bcast<9>(s) + fC * row_bcast<10>(s) + fP * row_ror<8>(s);
+    };
+    auto opAT = [&](double p) {  // (A_d' p): omega += dt*T'*rpy-part, vel += dt*pos-part
+        return p + gA * row_bcast<0>(p) + gB * row_bcast<1>(p) + gC * row_bcast<2>(p) + gV * row_ror<8>(p);
+    };
+    // adjoint of the roll-out: (B~' lambda_{omega,v}) in force layout
+    auto BtT = [&](double lam) {
+        double a0 = Bt[0] * bc<6>(lam), a1 = Bt[1] * bc<7>(lam);
+        a0 = fma(Bt[2], bc<8>(lam), a0);
+        a1 = fma(Bt[3], bc<9>(lam), a1);
+        a0 = fma(Bt[4], bc<10>(lam), a0);
+        a1 = fma(Bt[5], bc<11>(lam), a1);
+        return a0 + a1;
+    };
+    // (B~ u) scattered into the wrench lanes of a state-layout vector
+    auto Bu = [&](double u) {
+        double a0 = 0, a1 = 0;
+        static_for<6>([&](auto J) {
+            a0 = fma(Brow[2 * J], bc<2 * J>(u), a0);
+            a1 = fma(Brow[2 * J + 1], bc<2 * J + 1>(u), a1);
+        });
+        return a0 + a1;
+    };
+
+    const double q2s = act ? P.q2[ci] : 0.0;  // state-lane weight 2 q_i
+    const double r2a = act ? P.r2[ci] : 0.0;  // force-lane weight 2 r_a
+
+    // ---------------------------------------------------------------- gradient g = B_qp' Q (A_qp x0 - x_ref)
+    double g[H];
+    {
+        double w[H];
+        double xs = act ? io.x0[ci] : 0.0;
+        const double grav = io.x0[12];
+        static_for<H>([&](auto T) {
+            xs = opA(xs);
+            if (ln == 14) xs += dt * grav;  // A_c(11,12) = 1 (S/ConvexMpc.cpp:129)
+            const double xr = act ? io.xref[T * 13 + ci] : 0.0;
+            w[T] = q2s * (xs - xr);
+        });
+        double lam = 0.0;
+        static_for<H>([&](auto TT) {
+            constexpr int t = H - 1 - A1_CV(TT);
+            lam = w[t] + opAT(lam);
+            g[t] = BtT(lam);
+        });
+    }
+
+    // ---------------------------------------------------------------- U, V rows (P = alpha(x)U + beta(x)V + I(x)R)
+    double U[12], V[12], Ud = 0.0, Vd = 0.0;
+    static_for<12>([&](auto B) {
+        double u = 0.0, v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u += P.q2[k] * TB[k] * lds[L::TBL + k * 12 + B] + P.q2[3 + k] * Bt[3 + k] * lds[L::BL + (3 + k) * 12 + B];
+            v += P.q2[6 + k] * Bt[k] * lds[L::BL + k * 12 + B] + P.q2[9 + k] * Bt[3 + k] * lds[L::BL + (3 + k) * 12 + B];
+        }
+        U[B] = u * dt * dt;
+        V[B] = v;
+        if (act && ci == B) { Ud = U[B]; Vd = V[B]; }
+    });
+
+    // ---------------------------------------------------------------- Ruiz equilibration (osqp scaling.c scale_data)
+    double D[H], E0[H], E1[H];
+    double csc = 1.0;
+#pragma unroll
+    for (int t = 0; t < H; ++t) { D[t] = 1.0; E0[t] = act ? 1.0 : 0.0; E1[t] = (comp < 2) ? 1.0 : 0.0; }
+    if (P.scaling_iters > 0) {
+        double m[H];
+        // m[s] = max_{t,b} D_tb |P_(s,a),(t,b)|  for my rows (s, a): one pass over the implicit Hessian
+        auto sweep = [&](double(&mm)[H]) {
+            row_sync();
+            if (act) {
+#pragma unroll
+                for (int t = 0; t < H; ++t) lds[L::DL + t * 12 + ci] = D[t];
+            }
+            row_sync();
+#pragma unroll
+            for (int s = 0; s < H; ++s) mm[s] = 0.0;
+#pragma unroll 1
+            for (int t = 0; t < H; ++t) {
+                double Dt[12];
+#pragma unroll
+                for (int b = 0; b < 12; ++b) Dt[b] = lds[L::DL + t * 12 + b];
+                static_for<H>([&](auto S) {
+                    const double gam = tab[(S * H + t) * 2], bet = tab[(S * H + t) * 2 + 1];
+                    double a0 = 0.0, a1 = 0.0;
+                    static_for<6>([&](auto J) {
+                        a0 = fmax(a0, fabs(fma(gam, U[2 * J], V[2 * J])) * Dt[2 * J]);
+                        a1 = fmax(a1, fabs(fma(gam, U[2 * J + 1], V[2 * J + 1])) * Dt[2 * J + 1]);
+                    });
+                    mm[S] = fmax(mm[S], bet * fmax(a0, a1));
+                });
+            }
+            static_for<H>([&](auto S) {  // the true diagonal entry carries R
+                constexpr double ad = alpha_diag(A1_CV(S), H), bd = H - A1_CV(S);
+                mm[S] = fmax(mm[S], (ad * Ud + bd * Vd + r2a) * D[S]);
+            });
+        };
+        sweep(m);
+#pragma unroll 1
+        for (int pass = 0; pass < P.scaling_iters; ++pass) {
+            static_for<H>([&](auto T) {
+                const double Dz = quad_perm<2, 2, 2, 2>(D[T]);
+                const double mE = fmax(E0[T], E1[T]);
+                const double mEx = quad_perm<0, 0, 0, 0>(mE), mEy = quad_perm<1, 1, 1, 1>(mE);
+                const double colA = D[T] * (comp == 2 ? fmax(mu * fmax(mEx, mEy), E0[T]) : mE);
+                const double colP = csc * D[T] * m[T];
+                const double dtmp = 1.0 / sqrt(limit_scaling(fmax(colP, colA)));
+                const double rowf = comp == 2 ? D[T] : fmax(D[T], mu * Dz);
+                const double e0 = 1.0 / sqrt(limit_scaling(E0[T] * rowf));
+                const double e1 = 1.0 / sqrt(limit_scaling(E1[T] * rowf));
+                D[T] *= dtmp; E0[T] *= e0; E1[T] *= e1;
+            });
+            sweep(m);
+            double sum = 0.0, nq = 0.0;
+#pragma unroll
+            for (int t = 0; t < H; ++t) {
+                sum += csc * D[t] * m[t];
+                nq = fmax(nq, fabs(csc * D[t] * g[t]));
+            }
+            const double mean = row_allsum(sum) / double(12 * H);
+            nq = limit_scaling(row_allmax(nq));
+            const double ct = 1.0 / limit_scaling(fmax(mean, nq));
+            csc *= ct;
+        }
+    }
+    const double cinv = 1.0 / csc;
+    double Dinv[H], cg[H];
+#pragma unroll
+    for (int t = 0; t < H; ++t) { Dinv[t] = 1.0 / D[t]; cg[t] = csc * g[t]; }
+
+    // ---------------------------------------------------------------- bounds, row types (auxil.c set_rho_vec)
+    const double cf = (act && io.contact[quad]) ? 1.0 : 0.0;  // contacts broadcast over the horizon (S/ConvexMpc.cpp:228-245)
+    const double lo_u = P.fz_min * cf, hi_u = P.fz_max * cf;
+    unsigned eqmask = 0;  // bit t: my slot-0 row at step t is an equality row (swing leg: l = u = 0)
+#pragma unroll
+    for (int t = 0; t < H; ++t)
+        if (comp == 2 && (E0[t] * hi_u - E0[t] * lo_u < kRhoTol)) eqmask |= 1u << t;
+
+    // ---------------------------------------------------------------- ADMM state
+    double x[H], z0[H], z1[H], y0[H], y1[H];
+    double rho = P.rho0;
+    const bool warm = P.warm_start && io.warm_x != nullptr && io.warm_y != nullptr;
+    if (warm && io.rho_io != nullptr && *io.rho_io > 0.0) rho = *io.rho_io;
+    rho = fmin(fmax(rho, kRhoMin), kRhoMax);
+    {
+        // reference row order inside a (step, leg) block: [fx+mu fz, fx-mu fz, fy+mu fz, fy-mu fz, fz]
+        const int r0 = comp == 0 ? 0 : (comp == 1 ? 2 : 4), r1 = comp == 0 ? 1 : 3;
+        static_for<H>([&](auto T) {
+            double xw = 0.0, yw0 = 0.0, yw1 = 0.0;
+            if (warm && act) {
+                xw = io.warm_x[T * 12 + ci];
+                yw0 = io.warm_y[T * 20 + 5 * quad + r0];
+                if (comp < 2) yw1 = io.warm_y[T * 20 + 5 * quad + r1];
+            }
+            const double xz = quad_perm<2, 2, 2, 2>(xw);
+            x[T] = Dinv[T] * xw;                                          // x_s = D^-1 x
+            z0[T] = E0[T] * (comp == 2 ? xw : fma(mu, xz, xw));           // z = A_s x_s
+            z1[T] = E1[T] * fma(-mu, xz, xw);
+            y0[T] = E0[T] > 0.0 ? csc * yw0 / E0[T] : 0.0;                // y_s = c E^-1 y
+            y1[T] = E1[T] > 0.0 ? csc * yw1 / E1[T] : 0.0;
+        });
+    }
+
+    // ---------------------------------------------------------------- Riccati factorisation of
+    //   M = c P + sigma D^-2 + A' (E^2 rho) A      (K_s = D M D is OSQP's reduced KKT matrix)
+    const double qd = csc * q2s;
+    int nfact = 0;
+    bool fac_ok = true;
+    auto factorize = [&]() {
+        ++nfact;
+        const double rho_eq = kRhoEqOverIneq * rho;
+        // stage W_t = c R + sigma D^-2 + A_t' (E^2 rho) A_t  (block-diagonal, 3x3 per leg) into slot t
+        row_sync();
+        static_for<H>([&](auto T) {
+            const double rho0 = ((eqmask >> T) & 1u) ? rho_eq : rho;
+            const double a0 = E0[T] * E0[T] * rho0, a1 = E1[T] * E1[T] * rho;
+            const double sp = a0 + a1;
+            const double spx = quad_perm<0, 0, 0, 0>(sp), spy = quad_perm<1, 1, 1, 1>(sp);
+            const double base = csc * r2a + P.sigma * Dinv[T] * Dinv[T];
+            const double wd = comp == 2 ? base + a0 + mu * mu * (spx + spy) : base + sp;
+            const double wo = comp < 2 ? mu * (a0 - a1) : 0.0;
+            lds[L::FAC + T * L::SLOT + 2 * ln] = act ? wd : 0.0;
+            lds[L::FAC + T * L::SLOT + 2 * ln + 1] = wo;
+        });
+        row_sync();
+        double Pn[12];  // row of P_{t+1} (state layout); terminal value c Q
+#pragma unroll
+        for (int j = 0; j < 12; ++j) Pn[j] = (act && ci == j) ? qd : 0.0;
+#pragma unroll 1
+        for (int t = H - 1; t >= 0; --t) {
+            double* slot = lds + L::FAC + t * L::SLOT;
+            const double wd = slot[2 * ln], wo = slot[2 * ln + 1];
+            const double wox = quad_perm<0, 0, 0, 0>(wo), woy = quad_perm<1, 1, 1, 1>(wo);
+            row_sync();  // everybody holds W_t before the slot is overwritten
+            // G = A' P_{t+1}  (rows mixed across lanes), then GA = G A (columns, lane-local)
+            double G[12];
+            static_for<12>([&](auto J) { G[J] = opAT(Pn[J]); });
+            // F' = G(:,6:12) B~  (state row-owner)  and  Y = P_{t+1}(6:12,6:12) B~  (valid on the wrench lanes)
+            double Ft[12], Y[12];
+#pragma unroll
+            for (int b = 0; b < 12; ++b) { Ft[b] = 0.0; Y[b] = 0.0; }
+            static_for<6>([&](auto K) {
+#pragma unroll
+                for (int b = 0; b < 12; ++b) {
+                    const double bk = lds[L::BL + K * 12 + b];
+                    Ft[b] = fma(G[6 + K], bk, Ft[b]);
+                    Y[b] = fma(Pn[6 + K], bk, Y[b]);
+                }
+            });
+            G[6] += dt * (cy * G[0] - sy * G[1]);
+            G[7] += dt * (sy * G[0] + cy * G[1]);
+            G[8] += dt * G[2];
+            G[9] += dt * G[3];
+            G[10] += dt * G[4];
+            G[11] += dt * G[5];
+            // S = W_t + B~' Y   (force row-owner)
+            double S[12];
+            static_for<12>([&](auto B) {
+                double a0 = 0.0, a1 = 0.0;
+                a0 = fma(Bt[0], bc<6>(Y[B]), a0);
+                a1 = fma(Bt[1], bc<7>(Y[B]), a1);
+                a0 = fma(Bt[2], bc<8>(Y[B]), a0);
+                a1 = fma(Bt[3], bc<9>(Y[B]), a1);
+                a0 = fma(Bt[4], bc<10>(Y[B]), a0);
+                a1 = fma(Bt[5], bc<11>(Y[B]), a1);
+                double w = 0.0;
+                if (act) {
+                    if (B == ci) w = wd;
+                    else if (comp < 2 && B == 3 * quad + 2) w = wo;
+                    else if (comp == 2 && B == 3 * quad) w = wox;
+                    else if (comp == 2 && B == 3 * quad + 1) w = woy;
+                }
+                S[B] = a0 + a1 + w;
+            });
+            // in-place Gauss-Jordan inverse of the SPD 12x12 (row k broadcast, no pivoting)
+            static_for<12>([&](auto K) {
+                const double piv = bc<K>(S[K]);
+                if (!(piv > 0.0)) fac_ok = false;
+                const double pinv = 1.0 / piv;
+                const double f = S[K];
+                const bool mine = act && ci == K;
+                static_for<12>([&](auto J) {
+                    if constexpr (A1_CV(J) != A1_CV(K)) {
+                        const double rk = bc<K>(S[J]) * pinv;
+                        S[J] = mine ? rk : S[J] - f * rk;
+                    }
+                });
+                S[K] = mine ? pinv : -f * pinv;
+            });
+            if (act) {
+                static_for<12>([&](auto B) {
+                    if (B <= ci) slot[L::K_SZ + tri + B] = S[B];
+                });
+            }
+            row_sync();
+            // K' = F' S^-1  (state row-owner; S^-1 read row-uniformly from LDS)
+            double Kt[12];
+#pragma unroll
+            for (int a = 0; a < 12; ++a) Kt[a] = 0.0;
+            static_for<12>([&](auto B) {
+                static_for<12>([&](auto A_) {
+                    constexpr int aa = A1_CV(A_), bb = A1_CV(B);
+                    constexpr int hi = aa > bb ? aa : bb, lo = aa > bb ? bb : aa;
+                    Kt[A_] = fma(Ft[B], slot[L::K_SZ + hi * (hi + 1) / 2 + lo], Kt[A_]);
+                });
+            });
+            if (act) {
+#pragma unroll
+                for (int a = 0; a < 12; ++a) slot[a * L::KSTR + ci] = Kt[a];
+            }
+            row_sync();
+            // P_t = c Q + A' P_{t+1} A - F' K
+            if (t > 0) {
+                static_for<12>([&](auto J) {
+                    double a0 = G[J], a1 = 0.0;
+                    static_for<6>([&](auto A_) {
+                        a0 = fma(-Ft[2 * A_], slot[(2 * A_) * L::KSTR + J], a0);
+                        a1 = fma(-Ft[2 * A_ + 1], slot[(2 * A_ + 1) * L::KSTR + J], a1);
+                    });
+                    Pn[J] = a0 + a1 + ((act && ci == J) ? qd : 0.0);
+                });
+            }
+        }
+    };
+
+    // solve M v = b by the Riccati sweeps (b, v in force layout, all H steps in registers)
+    auto riccati_solve = [&](const double(&b)[H], double(&v)[H]) {
+        double d[H];
+        double pv = 0.0;  // costate p_{t+1}, state layout
+        static_for<H>([&](auto TT) {
+            constexpr int t = H - 1 - A1_CV(TT);
+            const double* slot = lds + L::FAC + t * L::SLOT;
+            const double r = b[t] - BtT(pv);
+            double a0 = 0.0, a1 = 0.0;
+            static_for<6>([&](auto J) {
+                constexpr int b0 = 2 * A1_CV(J), b1 = b0 + 1;
+                const double s0 = slot[L::K_SZ + (b0 <= ci ? tri + b0 : b0 * (b0 + 1) / 2 + ci)];
+                const double s1 = slot[L::K_SZ + (b1 <= ci ? tri + b1 : b1 * (b1 + 1) / 2 + ci)];
+                a0 = fma(s0, bc<b0>(r), a0);
+                a1 = fma(s1, bc<b1>(r), a1);
+            });
+            d[t] = act ? a0 + a1 : 0.0;
+            if constexpr (t > 0) {
+                double c0 = opAT(pv), c1 = 0.0;
+                static_for<6>([&](auto J) {
+                    c0 = fma(slot[(2 * J) * L::KSTR + ci], bc<2 * J>(r), c0);
+                    c1 = fma(slot[(2 * J + 1) * L::KSTR + ci], bc<2 * J + 1>(r), c1);
+                });
+                pv = act ? c0 + c1 : 0.0;
+            }
+        });
+        double s = 0.0;  // state x_t of the LQ roll-out (x_0 = 0)
+        static_for<H>([&](auto T) {
+            const double* slot = lds + L::FAC + T * L::SLOT;
+            double u = d[T];
+            if constexpr (T > 0) {
+                double a0 = 0.0, a1 = 0.0;
+                static_for<6>([&](auto J) {
+                    a0 = fma(slot[ci * L::KSTR + 2 * J], bc<2 * J>(s), a0);
+                    a1 = fma(slot[ci * L::KSTR + 2 * J + 1], bc<2 * J + 1>(s), a1);
+                });
+                u -= a0 + a1;
+            }
+            u = act ? u : 0.0;
+            v[T] = u;
+            if constexpr (T < H - 1) s = opA(s) + Bu(u);
+        });
+    };
+
+    // ---------------------------------------------------------------- residuals (auxil.c compute_pri_res/compute_dua_res/...)
+    struct Info {
+        double pri_res, dua_res, nEz, nEAx, nDq, nDAty, nDPx;  // unscaled
+        double s_pri, s_dua, s_z, s_Ax, s_q, s_Aty, s_Px;      // scaled (rho estimate)
+    } info;
+    auto update_info = [&]() {
+        double u[H], Pu[H];
+#pragma unroll
+        for (int t = 0; t < H; ++t) u[t] = D[t] * x[t];
+        {   // P u = B_qp' Q (B_qp u) + R u : roll-out, then adjoint
+            double sv[H];
+            double s = 0.0;
+            static_for<H>([&](auto T) {
+                s = opA(s) + Bu(u[T]);
+                sv[T] = q2s * s;
+            });
+            double lam = 0.0;
+            static_for<H>([&](auto TT) {
+                constexpr int t = H - 1 - A1_CV(TT);
+                lam = sv[t] + opAT(lam);
+                Pu[t] = fma(r2a, u[t], BtT(lam));
+            });
+        }
+        double m_pri = 0, m_upri = 0, m_z = 0, m_uz = 0, m_Ax = 0, m_uAx = 0;
+        double m_dua = 0, m_udua = 0, m_q = 0, m_uq = 0, m_Aty = 0, m_uAty = 0, m_Px = 0, m_uPx = 0;
+        static_for<H>([&](auto T) {
+            const double uz = quad_perm<2, 2, 2, 2>(u[T]);
+            const double ax0 = E0[T] * (comp == 2 ? u[T] : fma(mu, uz, u[T]));
+            const double ax1 = E1[T] * fma(-mu, uz, u[T]);
+            const double ie0 = E0[T] > 0.0 ? 1.0 / E0[T] : 0.0, ie1 = E1[T] > 0.0 ? 1.0 / E1[T] : 0.0;
+            const double rp0 = ax0 - z0[T], rp1 = ax1 - z1[T];
+            m_pri = fmax(m_pri, fmax(fabs(rp0), fabs(rp1)));
+            m_upri = fmax(m_upri, fmax(fabs(ie0 * rp0), fabs(ie1 * rp1)));
+            m_z = fmax(m_z, fmax(fabs(z0[T]), fabs(z1[T])));
+            m_uz = fmax(m_uz, fmax(fabs(ie0 * z0[T]), fabs(ie1 * z1[T])));
+            m_Ax = fmax(m_Ax, fmax(fabs(ax0), fabs(ax1)));
+            m_uAx = fmax(m_uAx, fmax(fabs(ie0 * ax0), fabs(ie1 * ax1)));
+            // A_s' y = D A' (E y)
+            const double w0 = E0[T] * y0[T], w1 = E1[T] * y1[T];
+            const double sm = w0 - w1;
+            const double smx = quad_perm<0, 0, 0, 0>(sm), smy = quad_perm<1, 1, 1, 1>(sm);
+            const double aty_u = comp == 2 ? fma(mu, smx + smy, w0) : w0 + w1;  // = D^-1 (A_s' y)
+            const double px_u = csc * Pu[T];                                    // = D^-1 (P_s x)
+            const double rd_u = px_u + cg[T] + aty_u;                           // = D^-1 (P_s x + q_s + A_s' y)
+            m_udua = fmax(m_udua, fabs(rd_u));
+            m_dua = fmax(m_dua, fabs(D[T] * rd_u));
+            m_uq = fmax(m_uq, fabs(cg[T]));
+            m_q = fmax(m_q, fabs(D[T] * cg[T]));
+            m_uAty = fmax(m_uAty, fabs(aty_u));
+            m_Aty = fmax(m_Aty, fabs(D[T] * aty_u));
+            m_uPx = fmax(m_uPx, fabs(px_u));
+            m_Px = fmax(m_Px, fabs(D[T] * px_u));
+        });
+        info.pri_res = row_allmax(act ? m_upri : 0.0);
+        info.nEz = row_allmax(act ? m_uz : 0.0);
+        info.nEAx = row_allmax(act ? m_uAx : 0.0);
+        info.s_pri = row_allmax(act ? m_pri : 0.0);
+        info.s_z = row_allmax(act ? m_z : 0.0);
+        info.s_Ax = row_allmax(act ? m_Ax : 0.0);
+        info.dua_res = cinv * row_allmax(act ? m_udua : 0.0);
+        info.nDq = row_allmax(act ? m_uq : 0.0);
+        info.nDAty = row_allmax(act ? m_uAty : 0.0);
+        info.nDPx = row_allmax(act ? m_uPx : 0.0);
+        info.s_dua = row_allmax(act ? m_dua : 0.0);
+        info.s_q = row_allmax(act ? m_q : 0.0);
+        info.s_Aty = row_allmax(act ? m_Aty : 0.0);
+        info.s_Px = row_allmax(act ? m_Px : 0.0);
+    };
+    int32_t status = A1MPC_UNSOLVED;
+    // auxil.c check_termination (feasibility certificates are not evaluated: u = 0 is always feasible and
+    // P > 0, so this QP family is never primal or dual infeasible)
+    auto check_termination = [&](bool approximate) -> bool {
+        double ea = P.eps_abs, er = P.eps_rel;
+        if (!(info.pri_res <= kInfty) || !(info.dua_res <= kInfty)) { status = A1MPC_NON_CVX; return true; }
+        if (approximate) { ea *= 10; er *= 10; }
+        const bool prc = info.pri_res < ea + er * fmax(info.nEz, info.nEAx);
+        const bool drc = info.dua_res < ea + er * cinv * fmax(fmax(info.nDq, info.nDAty), info.nDPx);
+        if (prc && drc) { status = approximate ? A1MPC_SOLVED_INACCURATE : A1MPC_SOLVED; return true; }
+        return false;
+    };
+
+    // ---------------------------------------------------------------- ADMM loop (osqp.c osqp_solve)
+    int iter = 0;
+    bool need_factor = true;
+    while (true) {
+        if (need_factor) {
+            factorize();
+            need_factor = false;
+            if (!fac_ok) { status = A1MPC_NON_CVX; break; }
+        }
+        ++iter;
+        {
+            const double rho_eq = kRhoEqOverIneq * rho;
+            const double rinv = 1.0 / rho, rinv_eq = 1.0 / rho_eq;
+            double b[H], v[H];
+            static_for<H>([&](auto T) {  // rhs of update_xz_tilde, premultiplied by D^-1
+                const bool eq = (eqmask >> T) & 1u;
+                const double rho0 = eq ? rho_eq : rho, ri0 = eq ? rinv_eq : rinv;
+                const double w0 = E0[T] * (rho0 * (z0[T] - ri0 * y0[T]));
+                const double w1 = E1[T] * (rho * (z1[T] - rinv * y1[T]));
+                const double sm = w0 - w1;
+                const double smx = quad_perm<0, 0, 0, 0>(sm), smy = quad_perm<1, 1, 1, 1>(sm);
+                const double at = comp == 2 ? fma(mu, smx + smy, w0) : w0 + w1;
+                b[T] = act ? fma(P.sigma * Dinv[T], x[T], at - cg[T]) : 0.0;
+            });
+            riccati_solve(b, v);
+            const double al = P.alpha, oma = 1.0 - P.alpha;
+            static_for<H>([&](auto T) {  // update_x, update_z, update_y
+                const bool eq = (eqmask >> T) & 1u;
+                const double rho0 = eq ? rho_eq : rho, ri0 = eq ? rinv_eq : rinv;
+                const double vz = quad_perm<2, 2, 2, 2>(v[T]);
+                const double zt0 = E0[T] * (comp == 2 ? v[T] : fma(mu, vz, v[T]));
+                const double zt1 = E1[T] * fma(-mu, vz, v[T]);
+                x[T] = al * (Dinv[T] * v[T]) + oma * x[T];
+                const double l0 = comp == 2 ? E0[T] * lo_u : 0.0;
+                const double u0 = comp == 2 ? E0[T] * hi_u : kInfty * E0[T];
+                const double zr0 = al * zt0 + oma * z0[T];
+                const double zn0 = fmin(fmax(zr0 + ri0 * y0[T], l0), u0);
+                y0[T] += rho0 * (zr0 - zn0);
+                z0[T] = zn0;
+                const double zr1 = al * zt1 + oma * z1[T];
+                const double zn1 = fmin(fmax(zr1 + rinv * y1[T], -kInfty * E1[T]), 0.0);
+                y1[T] += rho * (zr1 - zn1);
+                z1[T] = zn1;
+            });
+        }
+        const bool can_check = P.check_every > 0 && (iter % P.check_every) == 0;
+        const bool do_rho = P.adaptive_rho && P.adaptive_rho_every > 0 && (iter % P.adaptive_rho_every) == 0;
+        const bool last = iter >= P.max_iter;
+        if (can_check || do_rho || last) {
+            update_info();
+            if (can_check && check_termination(false)) break;
+            if (do_rho) {  // auxil.c compute_rho_estimate / adapt_rho
+                const double pr = info.s_pri / (fmax(info.s_z, info.s_Ax) + 1e-10);
+                const double dr = info.s_dua / (fmax(fmax(info.s_q, info.s_Aty), info.s_Px) + 1e-10);
+                const double rn = fmin(fmax(rho * sqrt(pr / (dr + 1e-10)), kRhoMin), kRhoMax);
+                if (rn > rho * P.adaptive_rho_tol || rn < rho / P.adaptive_rho_tol) {
+                    rho = rn;
+                    need_factor = true;
+                }
+            }
+            if (last) {
+                if (!can_check && check_termination(false)) break;
+                if (!check_termination(true)) status = A1MPC_MAX_ITER_REACHED;
+                if (need_factor) ++nfact;  // the reference refactors before it notices the iteration limit
+                break;
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- store_solution + first-step GRFs in the body frame
+    const bool nanout = status == A1MPC_NON_CVX;
+    const double nanv = nan("");
+    {
+        const double f = nanout ? nanv : D[0] * x[0];
+        const double f0 = quad_perm<0, 0, 0, 0>(f), f1 = quad_perm<1, 1, 1, 1>(f), f2 = quad_perm<2, 2, 2, 2>(f);
+        const bool bad = (f0 != f0) || (f1 != f1) || (f2 != f2);
+        if (act) {  // R' f (S/A1RobotControl.cpp:558-561); non-finite solution -> zeros + status
+            const double gb = Rm[0 * 3 + comp] * f0 + Rm[1 * 3 + comp] * f1 + Rm[2 * 3 + comp] * f2;
+            io.grf[3 * quad + comp] = bad ? 0.0 : gb;
+        }
+    }
+    {
+        const int r0 = comp == 0 ? 0 : (comp == 1 ? 2 : 4), r1 = comp == 0 ? 1 : 3;
+        static_for<H>([&](auto T) {
+            if (act) {
+                const double xu = nanout ? nanv : D[T] * x[T];
+                if (io.u_full) io.u_full[T * 12 + ci] = xu;
+                if (io.warm_x) io.warm_x[T * 12 + ci] = xu;
+                if (io.warm_y) {
+                    io.warm_y[T * 20 + 5 * quad + r0] = nanout ? nanv : cinv * E0[T] * y0[T];
+                    if (comp < 2) io.warm_y[T * 20 + 5 * quad + r1] = nanout ? nanv : cinv * E1[T] * y1[T];
+                }
+            }
+        });
+    }
+    if (ln == 0) {
+        if (io.iters) *io.iters = iter;
+        if (io.status) *io.status = status;
+        if (io.nfact) *io.nfact = nfact;
+        if (io.rho_io) *io.rho_io = rho;
+    }
+}
+
+}  // namespace a1mpc

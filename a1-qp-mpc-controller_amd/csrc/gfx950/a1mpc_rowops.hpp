@@ -1,0 +1,48 @@
+// a1mpc_rowops.hpp -- CDNA4 (gfx950) cross-lane primitives for the "one QP per DPP row" solver.
+//
+// A wavefront (64 lanes) is four DPP rows of 16 lanes; every QP lives in exactly one row, so all
+// cross-lane traffic of the solver is row-local DPP (no LDS crossbar, no __shfl):
+//   row_bcast<L>   v_mov_b64_dpp ... row_newbcast:L   (lane L of MY row -> every lane of the row)
+//   row_rorN       v_mov_b32_dpp x2 ... row_ror:N     (rotation inside the row; only used where
+//                                                      the direction does not matter: N=8 and the
+//                                                      8/4/2/1 all-reduce)
+//   quad_perm      v_mov_b32_dpp x2 ... quad_perm:[..] (a leg's fx,fy,fz live in one quad)
+// Rows never talk to each other, so rows of one wave may diverge (different ADMM iteration counts):
+// EXEC is then row-granular and every DPP source lane is still live.
+//
+// tests/emu/a1mpc_rowops.hpp provides the same names on top of host fibers so that the solver
+// source can be executed lane-for-lane on a CPU by the test-suite (test double, never shipped).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define A1_DEV __device__ __forceinline__
+
+namespace a1mpc {
+
+A1_DEV int row_lane() { return static_cast<int>(threadIdx.x) & 15; }
+
+template <int L>
+A1_DEV double row_bcast(double v) {
+    static_assert(L >= 0 && L < 16, "lane");
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + L, 0xF, 0xF, false);  // row_newbcast:L
+}
+template <int N>
+A1_DEV double row_ror(double v) {
+    static_assert(N >= 1 && N < 16, "rot");
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x120 + N, 0xF, 0xF, false);  // row_ror:N
+}
+template <int P0, int P1, int P2, int P3>
+A1_DEV double quad_perm(double v) {
+    return __builtin_amdgcn_update_dpp(0.0, v, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, false);
+}
+
+// Orders LDS traffic between the lanes of a row.  All lanes of a row are in one wavefront and the
+// LDS executes a wave's DS instructions in issue order, so this only has to stop the compiler from
+// moving DS accesses across it.
+A1_DEV void row_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace a1mpc

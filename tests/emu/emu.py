@@ -1,0 +1,76 @@
+"""ctypes front-end of tests/emu/liba1mpc_emu.so -- TEST INFRASTRUCTURE (CPU execution of the solver source
+on host fibers; see emu_harness.cpp).  Never imported by the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_CSRC = os.path.join(_ROOT, "a1-qp-mpc-controller_amd", "csrc")
+_LIB = os.path.join(_HERE, "liba1mpc_emu.so")
+
+
+class DeviceParams(C.Structure):  # mirrors a1mpc::DeviceParams (csrc/a1mpc_solver.hpp)
+    _fields_ = [("dt", C.c_double), ("mu", C.c_double), ("fz_min", C.c_double), ("fz_max", C.c_double),
+                ("q2", C.c_double * 12), ("r2", C.c_double * 12), ("mass", C.c_double), ("inertia", C.c_double * 9),
+                ("rho0", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double), ("eps_abs", C.c_double),
+                ("eps_rel", C.c_double), ("adaptive_rho_tol", C.c_double), ("max_iter", C.c_int32),
+                ("check_every", C.c_int32), ("adaptive_rho", C.c_int32), ("adaptive_rho_every", C.c_int32),
+                ("scaling_iters", C.c_int32), ("warm_start", C.c_int32)]
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_HERE, "a1mpc_rowops.hpp"),
+            os.path.join(_CSRC, "a1mpc_solver.hpp"), os.path.join(_CSRC, "a1mpc_tables.hpp")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", _HERE, "-I", _CSRC, srcs[0], "-o", _LIB])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        assert _lib.a1mpc_emu_sizeof_params() == C.sizeof(DeviceParams)
+    return _lib
+
+
+def make_params(params, settings=None, **over):
+    """params: scenario['params'] dict; settings: dict of OSQP settings (defaults = OSQP 0.6 defaults)."""
+    st = dict(rho0=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_tol=5.0, max_iter=4000,
+              check_every=25, adaptive_rho=1, adaptive_rho_every=25, scaling_iters=10, warm_start=0)
+    st.update(settings or {})
+    st.update(over)
+    p = DeviceParams()
+    p.dt, p.mu, p.fz_min, p.fz_max, p.mass = params["dt"], params["mu"], params["fz_min"], params["fz_max"], params["mass"]
+    p.q2[:] = [2.0 * v for v in params["q"][:12]]
+    p.r2[:] = [2.0 * v for v in params["r"]]
+    p.inertia[:] = list(np.asarray(params["inertia"], dtype=float).reshape(9))
+    for k, v in st.items():
+        setattr(p, k, v)
+    return p
+
+
+def _p(a, t=C.c_double):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def solve(sc, n=None, settings=None, warm=None, **over):
+    h = sc["horizon"]
+    n = len(sc["x0"]) if n is None else n
+    P = make_params(sc["params"], settings, **over)
+    grf = np.zeros((n, 12)); u = np.zeros((n, 12 * h))
+    iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32); nfact = np.zeros(n, np.int32)
+    wx = wy = rho = None
+    if warm is not None:
+        wx, wy, rho = warm
+    rc = lib().a1mpc_emu_solve(C.byref(P), h, n, _p(sc["x0"]), _p(sc["xref"]), _p(sc["R"]), _p(sc["foot"]),
+                               _p(sc["contact"], C.c_uint8), _p(grf), _p(u), _p(wx), _p(wy), _p(rho), _p(iters, C.c_int32),
+                               _p(status, C.c_int32), _p(nfact, C.c_int32))
+    assert rc == 0
+    return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)

@@ -1,0 +1,146 @@
+// tests/emu/emu_harness.cpp -- TEST INFRASTRUCTURE: runs csrc/a1mpc_solver.hpp on host fibers.
+// Built by tests/emu/build.py into tests/emu/liba1mpc_emu.so and used only by tests/test_emu_*.py to
+// validate the solver's algorithm, lane mapping and LDS synchronisation against the oracle without a GPU.
+#include <ucontext.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <a1mpc_rowops.hpp>  // the emulation flavour: -I tests/emu
+#include "a1mpc_solver.hpp"
+#include "a1mpc_tables.hpp"
+
+namespace a1mpc {
+
+thread_local int emu_lane = 0;
+
+namespace {
+constexpr int kLanes = 16;
+constexpr size_t kStack = 1 << 20;
+struct Sched {
+    ucontext_t main_ctx;
+    ucontext_t ctx[kLanes];
+    char* stacks[kLanes];
+    bool finished[kLanes];
+    double buf[2][kLanes];
+    int parity[kLanes];
+    long nxchg[kLanes];
+    void (*fn)(void*);
+    void* arg;
+};
+thread_local Sched* g_s = nullptr;
+
+void trampoline() {
+    Sched* s = g_s;
+    const int l = emu_lane;
+    s->fn(s->arg);
+    s->finished[l] = true;
+    swapcontext(&s->ctx[l], &s->main_ctx);
+}
+}  // namespace
+
+const double* emu_publish(double v) {
+    Sched* s = g_s;
+    const int l = emu_lane;
+    const int p = s->parity[l];
+    s->buf[p][l] = v;
+    s->parity[l] ^= 1;
+    s->nxchg[l]++;
+    swapcontext(&s->ctx[l], &s->main_ctx);  // resume after every other lane has published
+    emu_lane = l;
+    return s->buf[p];
+}
+
+static void run_row(void (*fn)(void*), void* arg) {
+    Sched s;
+    memset(&s, 0, sizeof s);
+    s.fn = fn;
+    s.arg = arg;
+    g_s = &s;
+    for (int l = 0; l < kLanes; ++l) {
+        s.stacks[l] = static_cast<char*>(malloc(kStack));
+        getcontext(&s.ctx[l]);
+        s.ctx[l].uc_stack.ss_sp = s.stacks[l];
+        s.ctx[l].uc_stack.ss_size = kStack;
+        s.ctx[l].uc_link = &s.main_ctx;
+        makecontext(&s.ctx[l], trampoline, 0);
+    }
+    for (;;) {
+        int alive = 0;
+        for (int l = 0; l < kLanes; ++l) {
+            if (s.finished[l]) continue;
+            emu_lane = l;
+            swapcontext(&s.main_ctx, &s.ctx[l]);
+            if (!s.finished[l]) ++alive;
+        }
+        bool any_fin = false, any_alive = false;
+        for (int l = 0; l < kLanes; ++l) (s.finished[l] ? any_fin : any_alive) = true;
+        if (any_fin && any_alive) { fprintf(stderr, "emu: row-divergent control flow (a lane finished early)\n"); abort(); }
+        for (int l = 1; l < kLanes; ++l)
+            if (s.nxchg[l] != s.nxchg[0]) { fprintf(stderr, "emu: lanes disagree on the number of cross-lane ops\n"); abort(); }
+        if (!alive) break;
+    }
+    for (int l = 0; l < kLanes; ++l) free(s.stacks[l]);
+    g_s = nullptr;
+}
+
+template <int H>
+struct Job {
+    const DeviceParams* P;
+    const double* tab;
+    ProblemIO io;
+    double* lds;
+};
+template <int H>
+static void job_entry(void* a) {
+    Job<H>* j = static_cast<Job<H>*>(a);
+    solve_row<H>(*j->P, j->tab, j->io, j->lds);
+}
+
+template <int H>
+static void run_batch(const DeviceParams* P, int n, const double* x0, const double* xref, const double* R, const double* foot,
+                      const uint8_t* contact, double* grf, double* u_full, double* warm_x, double* warm_y, double* rho,
+                      int32_t* iters, int32_t* status, int32_t* nfact) {
+    std::vector<double> tab(2 * H * H);
+    fill_gamma_beta_table(H, tab.data());
+    std::vector<double> lds(Layout<H>::ROW_STRIDE);
+    for (int b = 0; b < n; ++b) {
+        for (auto& v : lds) v = NAN;  // uninitialised LDS must never be consumed
+        Job<H> j;
+        j.P = P;
+        j.tab = tab.data();
+        j.lds = lds.data();
+        j.io.x0 = x0 + (size_t)b * 13;
+        j.io.xref = xref + (size_t)b * 13 * H;
+        j.io.R = R + (size_t)b * 9;
+        j.io.foot = foot + (size_t)b * 12;
+        j.io.contact = contact + (size_t)b * 4;
+        j.io.grf = grf + (size_t)b * 12;
+        j.io.u_full = u_full ? u_full + (size_t)b * 12 * H : nullptr;
+        j.io.warm_x = warm_x ? warm_x + (size_t)b * 12 * H : nullptr;
+        j.io.warm_y = warm_y ? warm_y + (size_t)b * 20 * H : nullptr;
+        j.io.rho_io = rho ? rho + b : nullptr;
+        j.io.iters = iters ? iters + b : nullptr;
+        j.io.status = status ? status + b : nullptr;
+        j.io.nfact = nfact ? nfact + b : nullptr;
+        run_row(job_entry<H>, &j);
+    }
+}
+
+}  // namespace a1mpc
+
+extern "C" int a1mpc_emu_solve(const a1mpc::DeviceParams* P, int horizon, int n, const double* x0, const double* xref, const double* R,
+                               const double* foot, const uint8_t* contact, double* grf, double* u_full, double* warm_x,
+                               double* warm_y, double* rho, int32_t* iters, int32_t* status, int32_t* nfact) {
+    switch (horizon) {
+        case 1: a1mpc::run_batch<1>(P, n, x0, xref, R, foot, contact, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
+        case 4: a1mpc::run_batch<4>(P, n, x0, xref, R, foot, contact, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
+        case 10: a1mpc::run_batch<10>(P, n, x0, xref, R, foot, contact, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
+        case 16: a1mpc::run_batch<16>(P, n, x0, xref, R, foot, contact, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
+        case 20: a1mpc::run_batch<20>(P, n, x0, xref, R, foot, contact, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
+    }
+    return -1;
+}
+extern "C" int a1mpc_emu_sizeof_params(void) { return (int)sizeof(a1mpc::DeviceParams); }
