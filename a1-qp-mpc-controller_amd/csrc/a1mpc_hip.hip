@@ -1,0 +1,412 @@
+// a1mpc_hip.hip -- gfx950 kernels + the C ABI of include/a1mpc.h (liba1mpc.so).
+//
+// One workgroup = one wavefront = four QPs (one per DPP row); dynamic LDS = 4 x Layout<H>::ROW_STRIDE
+// doubles (77.9 KB at H = 10 -> two workgroups per CU).  The QPs of a batch are independent, so the grid
+// is simply ceil(n / 4) workgroups and the hardware dispatcher load-balances rows that need more ADMM
+// iterations; nothing is shared between workgroups except the read-only (alpha/beta) table, so the
+// blockIdx -> XCD mapping is irrelevant for this kernel (no L2 reuse to localise).
+//
+// There is no CPU path in this file: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <a1mpc_rowops.hpp>
+
+#include "../../include/a1mpc.h"
+#include "a1mpc_solver.hpp"
+#include "a1mpc_tables.hpp"
+
+namespace a1mpc {
+
+struct KernelArgs {
+    DeviceParams P;
+    const double* tab;
+    int32_t n;
+    const double *root_acc, *Rz;  // balance mode only
+    const double *x0, *xref, *R, *foot;
+    const uint8_t* contact;
+    double *grf, *u_full, *warm_x, *warm_y, *rho;
+    int32_t *iters, *status, *nfact;
+};
+
+constexpr int kRowsPerWg = 4, kThreads = 64;
+
+template <int H, int MODE>
+__global__ __launch_bounds__(kThreads) void a1mpc_solve_kernel(const KernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
+    const int row = static_cast<int>(threadIdx.x) >> 4;
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * kRowsPerWg + row;
+    if (b >= a.n) return;  // row-uniform: the other rows of the wave keep all their DPP sources
+    ProblemIO io;
+    io.root_acc = MODE == kModeBalance ? a.root_acc + b * 6 : nullptr;
+    io.Rz = MODE == kModeBalance ? a.Rz + b * 9 : nullptr;
+    io.x0 = MODE == kModeMpc ? a.x0 + b * 13 : nullptr;
+    io.xref = MODE == kModeMpc ? a.xref + b * 13 * H : nullptr;
+    io.R = a.R + b * 9;
+    io.foot = a.foot + b * 12;
+    io.contact = a.contact + b * 4;
+    io.grf = a.grf + b * 12;
+    io.u_full = a.u_full ? a.u_full + b * 12 * H : nullptr;
+    io.warm_x = a.warm_x ? a.warm_x + b * 12 * H : nullptr;
+    io.warm_y = a.warm_y ? a.warm_y + b * 20 * H : nullptr;
+    io.rho_io = a.rho ? a.rho + b : nullptr;
+    io.iters = a.iters ? a.iters + b : nullptr;
+    io.status = a.status ? a.status + b : nullptr;
+    io.nfact = a.nfact ? a.nfact + b : nullptr;
+    solve_row<H, MODE>(a.P, a.tab, io, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+}
+
+template <int H>
+constexpr size_t lds_bytes() { return sizeof(double) * kRowsPerWg * Layout<H>::ROW_STRIDE; }
+
+thread_local std::string g_last_error;
+static a1mpc_status fail(a1mpc_status s, const std::string& msg) { g_last_error = msg; return s; }
+#define A1_HIP(call)                                                                                          \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess) return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <int H, int MODE>
+static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    A1_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes<H>())));
+        attr_set[dev] = true;
+    }
+    const unsigned grid = static_cast<unsigned>((a.n + kRowsPerWg - 1) / kRowsPerWg);
+    hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE>), dim3(grid), dim3(kThreads), lds_bytes<H>(), stream, a);
+    A1_HIP(hipGetLastError());
+    return A1MPC_OK;
+}
+
+static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, hipStream_t s) {
+    switch (horizon) {
+        case 1: return launch<1, kModeMpc>(a, s);
+        case 10: return launch<10, kModeMpc>(a, s);
+        case 16: return launch<16, kModeMpc>(a, s);
+        case 20: return launch<20, kModeMpc>(a, s);
+    }
+    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be 1, 10, 16 or 20");
+}
+static size_t lds_bytes_of(int horizon) {
+    switch (horizon) {
+        case 1: return lds_bytes<1>();
+        case 10: return lds_bytes<10>();
+        case 16: return lds_bytes<16>();
+        case 20: return lds_bytes<20>();
+    }
+    return 0;
+}
+
+static void to_device_params(const a1mpc_config& c, DeviceParams* p) {
+    std::memset(p, 0, sizeof *p);
+    p->dt = c.dt; p->mu = c.mu; p->fz_min = c.fz_min; p->fz_max = c.fz_max;
+    for (int i = 0; i < 12; ++i) { p->q2[i] = 2.0 * c.q[i]; p->r2[i] = 2.0 * c.r[i]; }  // S/ConvexMpc.cpp:20,41
+    p->mass = c.mass;
+    for (int i = 0; i < 9; ++i) p->inertia[i] = c.inertia_body[i];
+    p->rho0 = c.rho; p->sigma = c.sigma; p->alpha = c.alpha; p->eps_abs = c.eps_abs; p->eps_rel = c.eps_rel;
+    p->adaptive_rho_tol = c.adaptive_rho_tolerance;
+    p->max_iter = c.max_iter; p->check_every = c.check_termination; p->adaptive_rho = c.adaptive_rho;
+    p->adaptive_rho_every = c.adaptive_rho_interval; p->scaling_iters = c.scaling; p->warm_start = c.warm_start;
+}
+
+}  // namespace a1mpc
+
+using namespace a1mpc;
+
+struct a1mpc_handle_s {
+    a1mpc_config cfg;
+    DeviceParams dp;
+    int device = 0;
+    int max_batch = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    double* d_tab = nullptr;      // (alpha/beta, beta) table of cfg.horizon
+    double* d_tab1 = nullptr;     // the H = 1 table (balance QP)
+    // device staging for the host-pointer entry points
+    double *d_x0 = nullptr, *d_xref = nullptr, *d_R = nullptr, *d_foot = nullptr, *d_aux = nullptr, *d_Rz = nullptr;
+    uint8_t* d_contact = nullptr;
+    double *d_grf = nullptr, *d_u = nullptr;
+    int32_t *d_iters = nullptr, *d_status = nullptr, *d_nfact = nullptr;
+    hipStream_t last_stream = nullptr;
+    // carried OSQP workspace (warm start)
+    double *d_wx = nullptr, *d_wy = nullptr, *d_rho = nullptr;
+    // pinned host mirrors
+    char* h_pin = nullptr;
+    size_t h_pin_bytes = 0;
+};
+
+extern "C" {
+
+void a1mpc_default_config(a1mpc_config* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof *c);
+    c->horizon = 10;         // PLAN_HORIZON, S/A1Params.h:26
+    c->dt = 0.0025;          // S/A1RobotControl.cpp:462
+    c->mu = 0.3;             // S/ConvexMpc.cpp:8
+    c->fz_min = 0.0;         // S/ConvexMpc.cpp:223
+    c->fz_max = 180.0;       // S/ConvexMpc.cpp:224
+    c->rho = 0.1; c->sigma = 1e-6; c->alpha = 1.6; c->eps_abs = 1e-3; c->eps_rel = 1e-3;  // OSQP 0.6 defaults
+    c->adaptive_rho_tolerance = 5.0;
+    c->max_iter = 4000; c->check_termination = 25; c->adaptive_rho = 1; c->adaptive_rho_interval = 25; c->scaling = 10;
+    c->warm_start = 1;       // S/A1RobotControl.cpp:524
+}
+
+void a1mpc_default_balance_config(a1mpc_balance_config* q) {
+    if (!q) return;
+    const double Q[6] = {1.0, 1.0, 1.0, 400.0, 400.0, 100.0};  // S/A1RobotControl.cpp:11
+    std::memcpy(q->Q, Q, sizeof Q);
+    q->R = 1e-3; q->mu = 0.7; q->F_min = 0.0; q->F_max = 180.0;  // S/A1RobotControl.cpp:12-15
+}
+
+const char* a1mpc_status_string(a1mpc_status s) {
+    switch (s) {
+        case A1MPC_OK: return "ok";
+        case A1MPC_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case A1MPC_ERR_UNSUPPORTED_HORIZON: return "unsupported horizon";
+        case A1MPC_ERR_NO_DEVICE: return "no HIP device";
+        case A1MPC_ERR_HIP: return "HIP runtime error";
+        case A1MPC_ERR_BATCH_TOO_LARGE: return "batch larger than max_batch";
+    }
+    return "unknown";
+}
+const char* a1mpc_last_error(void) { return g_last_error.c_str(); }
+
+void a1mpc_destroy(a1mpc_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    void* ptrs[] = {h->d_tab, h->d_tab1, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_aux, h->d_Rz, h->d_contact, h->d_grf,
+                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t device, a1mpc_handle* out) {
+    if (!cfg || !out || max_batch <= 0 || device < 0) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null config/out or bad batch/device");
+    *out = nullptr;
+    if (lds_bytes_of(cfg->horizon) == 0) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be 1, 10, 16 or 20");
+    if (!(cfg->dt > 0) || !(cfg->mass > 0) || cfg->max_iter <= 0 || !(cfg->rho > 0) || !(cfg->sigma > 0))
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "dt, mass, rho, sigma and max_iter must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(A1MPC_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
+    if (device >= ndev) return fail(A1MPC_ERR_NO_DEVICE, "device ordinal out of range");
+    A1_HIP(hipSetDevice(device));
+    a1mpc_handle h = new (std::nothrow) a1mpc_handle_s();
+    if (!h) return fail(A1MPC_ERR_HIP, "out of host memory");
+    h->cfg = *cfg;
+    to_device_params(*cfg, &h->dp);
+    h->device = device;
+    h->max_batch = max_batch;
+    const int H = cfg->horizon;
+    const size_t n = static_cast<size_t>(max_batch);
+#define A1_TRY(call)                                  \
+    do {                                              \
+        hipError_t e_ = (call);                       \
+        if (e_ != hipSuccess) {                       \
+            a1mpc_destroy(h);                         \
+            return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        }                                             \
+    } while (0)
+    A1_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    A1_TRY(hipEventCreate(&h->ev0));
+    A1_TRY(hipEventCreate(&h->ev1));
+    std::vector<double> tab(2 * H * H), tab1(2);
+    fill_gamma_beta_table(H, tab.data());
+    fill_gamma_beta_table(1, tab1.data());
+    A1_TRY(hipMalloc(&h->d_tab, tab.size() * sizeof(double)));
+    A1_TRY(hipMalloc(&h->d_tab1, tab1.size() * sizeof(double)));
+    A1_TRY(hipMemcpy(h->d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    A1_TRY(hipMemcpy(h->d_tab1, tab1.data(), tab1.size() * sizeof(double), hipMemcpyHostToDevice));
+    A1_TRY(hipMalloc(&h->d_x0, n * 13 * sizeof(double)));
+    A1_TRY(hipMalloc(&h->d_xref, n * 13 * H * sizeof(double)));
+    A1_TRY(hipMalloc(&h->d_R, n * 9 * sizeof(double)));
+    A1_TRY(hipMalloc(&h->d_Rz, n * 9 * sizeof(double)));
+    A1_TRY(hipMalloc(&h->d_foot, n * 12 * sizeof(double)));
+    A1_TRY(hipMalloc(&h->d_aux, n * 6 * sizeof(double)));
+    A1_TRY(hipMalloc(&h->d_contact, n * 4));
+    A1_TRY(hipMalloc(&h->d_grf, n * 12 * sizeof(double)));
+    A1_TRY(hipMalloc(&h->d_u, n * 12 * H * sizeof(double)));
+    A1_TRY(hipMalloc(&h->d_iters, n * sizeof(int32_t)));
+    A1_TRY(hipMalloc(&h->d_status, n * sizeof(int32_t)));
+    A1_TRY(hipMalloc(&h->d_nfact, n * sizeof(int32_t)));
+    A1_TRY(hipMalloc(&h->d_wx, n * 12 * H * sizeof(double)));
+    A1_TRY(hipMalloc(&h->d_wy, n * 20 * H * sizeof(double)));
+    A1_TRY(hipMalloc(&h->d_rho, n * sizeof(double)));
+    A1_TRY(hipMemset(h->d_wx, 0, n * 12 * H * sizeof(double)));
+    A1_TRY(hipMemset(h->d_wy, 0, n * 20 * H * sizeof(double)));
+    A1_TRY(hipMemset(h->d_rho, 0, n * sizeof(double)));
+    // pinned mirror: inputs (x0, xref, R, Rz, foot, aux, contact) then outputs (grf, u, iters, status)
+    h->h_pin_bytes = n * ((13 + 13 * H + 9 + 9 + 12 + 6) * sizeof(double) + 8 + (12 + 12 * H) * sizeof(double) + 2 * sizeof(int32_t));
+    A1_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), h->h_pin_bytes, hipHostMallocDefault));
+#undef A1_TRY
+    *out = h;
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    A1_HIP(hipSetDevice(h->device));
+    const size_t n = h->max_batch, H = h->cfg.horizon;
+    A1_HIP(hipMemsetAsync(h->d_wx, 0, n * 12 * H * sizeof(double), h->stream));
+    A1_HIP(hipMemsetAsync(h->d_wy, 0, n * 20 * H * sizeof(double), h->stream));
+    A1_HIP(hipMemsetAsync(h->d_rho, 0, n * sizeof(double), h->stream));
+    A1_HIP(hipStreamSynchronize(h->stream));
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d_x0, const double* d_x_ref, const double* d_R_world,
+                                      const double* d_foot_abs, const uint8_t* d_contact, double* d_grf_body_out,
+                                      double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out, void* hip_stream) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !d_x0 || !d_x_ref || !d_R_world || !d_foot_abs || !d_contact || !d_grf_body_out)
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->stream;
+    KernelArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.P = h->dp; a.tab = h->d_tab; a.n = n;
+    a.x0 = d_x0; a.xref = d_x_ref; a.R = d_R_world; a.foot = d_foot_abs; a.contact = d_contact;
+    a.grf = d_grf_body_out; a.u_full = d_u_full_out; a.iters = d_iters_out; a.status = d_status_out; a.nfact = h->d_nfact;
+    h->last_stream = s;
+    if (h->cfg.warm_start) { a.warm_x = h->d_wx; a.warm_y = h->d_wy; a.rho = h->d_rho; }
+    A1_HIP(hipEventRecord(h->ev0, s));
+    a1mpc_status st = launch_mpc(h->cfg.horizon, a, s);
+    if (st != A1MPC_OK) return st;
+    A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = true;
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
+                               const double* foot_abs, const uint8_t* contact, double* grf_body_out, double* u_full_out,
+                               int32_t* iters_out, int32_t* status_out) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !grf_body_out)
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    const size_t N = n, H = h->cfg.horizon;
+    // snapshot the caller's arrays into pinned memory (the caller's program mutates them concurrently)
+    char* p = h->h_pin;
+    double* hx0 = reinterpret_cast<double*>(p); p += N * 13 * sizeof(double);
+    double* hxr = reinterpret_cast<double*>(p); p += N * 13 * H * sizeof(double);
+    double* hR = reinterpret_cast<double*>(p); p += N * 9 * sizeof(double);
+    double* hf = reinterpret_cast<double*>(p); p += N * 12 * sizeof(double);
+    double* hgrf = reinterpret_cast<double*>(p); p += N * 12 * sizeof(double);
+    double* hu = reinterpret_cast<double*>(p); p += N * 12 * H * sizeof(double);
+    int32_t* hit = reinterpret_cast<int32_t*>(p); p += N * sizeof(int32_t);
+    int32_t* hst = reinterpret_cast<int32_t*>(p); p += N * sizeof(int32_t);
+    uint8_t* hc = reinterpret_cast<uint8_t*>(p);
+    std::memcpy(hx0, x0, N * 13 * sizeof(double));
+    std::memcpy(hxr, x_ref, N * 13 * H * sizeof(double));
+    std::memcpy(hR, R_world, N * 9 * sizeof(double));
+    std::memcpy(hf, foot_abs, N * 12 * sizeof(double));
+    std::memcpy(hc, contact, N * 4);
+    hipStream_t s = h->stream;
+    A1_HIP(hipMemcpyAsync(h->d_x0, hx0, N * 13 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_xref, hxr, N * 13 * H * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_R, hR, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_foot, hf, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_contact, hc, N * 4, hipMemcpyHostToDevice, s));
+    a1mpc_status st = a1mpc_solve_batch_device(h, n, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_contact, h->d_grf,
+                                               u_full_out ? h->d_u : nullptr, h->d_iters, h->d_status, s);
+    if (st != A1MPC_OK) return st;
+    A1_HIP(hipMemcpyAsync(hgrf, h->d_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (u_full_out) A1_HIP(hipMemcpyAsync(hu, h->d_u, N * 12 * H * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (iters_out) A1_HIP(hipMemcpyAsync(hit, h->d_iters, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (status_out) A1_HIP(hipMemcpyAsync(hst, h->d_status, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipStreamSynchronize(s));
+    std::memcpy(grf_body_out, hgrf, N * 12 * sizeof(double));
+    if (u_full_out) std::memcpy(u_full_out, hu, N * 12 * H * sizeof(double));
+    if (iters_out) std::memcpy(iters_out, hit, N * sizeof(int32_t));
+    if (status_out) std::memcpy(status_out, hst, N * sizeof(int32_t));
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_config* qp, int32_t n, const double* root_acc,
+                                       const double* R_world, const double* R_z, const double* foot_abs, const uint8_t* contact,
+                                       double* grf_body_out, double* f_world_out, int32_t* iters_out, int32_t* status_out) {
+    if (!h || !qp) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle/config");
+    if (n < 0 || !root_acc || !R_world || !R_z || !foot_abs || !contact || !grf_body_out)
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    const size_t N = n;
+    hipStream_t s = h->stream;
+    // the transfers are small (344 B per QP); pageable copies on the stream are synchronous w.r.t. the host buffer
+    A1_HIP(hipMemcpyAsync(h->d_aux, root_acc, N * 6 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_R, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_Rz, R_z, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_foot, foot_abs, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_contact, contact, N * 4, hipMemcpyHostToDevice, s));
+    KernelArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.P = h->dp;
+    // the H = 1 member of the family: dt = 0, wrench weights (torque first) in q2[6:12], R on the diagonal
+    a.P.dt = 0.0; a.P.mu = qp->mu; a.P.fz_min = qp->F_min; a.P.fz_max = qp->F_max; a.P.warm_start = 0;
+    for (int i = 0; i < 12; ++i) { a.P.q2[i] = 0.0; a.P.r2[i] = qp->R; }
+    for (int k = 0; k < 3; ++k) { a.P.q2[6 + k] = qp->Q[3 + k]; a.P.q2[9 + k] = qp->Q[k]; }
+    a.tab = h->d_tab1; a.n = n;
+    a.root_acc = h->d_aux; a.Rz = h->d_Rz; a.R = h->d_R; a.foot = h->d_foot; a.contact = h->d_contact;
+    a.grf = h->d_grf; a.u_full = h->d_u; a.iters = h->d_iters; a.status = h->d_status; a.nfact = h->d_nfact;
+    h->last_stream = s;
+    A1_HIP(hipEventRecord(h->ev0, s));
+    a1mpc_status st = launch<1, kModeBalance>(a, s);
+    if (st != A1MPC_OK) return st;
+    A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = true;
+    A1_HIP(hipMemcpyAsync(grf_body_out, h->d_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (f_world_out) A1_HIP(hipMemcpyAsync(f_world_out, h->d_u, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (iters_out) A1_HIP(hipMemcpyAsync(iters_out, h->d_iters, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (status_out) A1_HIP(hipMemcpyAsync(status_out, h->d_status, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipStreamSynchronize(s));
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_last_kernel_ms(a1mpc_handle h, float* ms_out) {
+    if (!h || !ms_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle/out");
+    if (!h->timed) return fail(A1MPC_ERR_INVALID_ARGUMENT, "no kernel has been launched through this handle");
+    A1_HIP(hipSetDevice(h->device));
+    A1_HIP(hipEventSynchronize(h->ev1));
+    A1_HIP(hipEventElapsedTime(ms_out, h->ev0, h->ev1));
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_last_nfact(a1mpc_handle h, int32_t n, int32_t* nfact_out) {
+    if (!h || !nfact_out || n < 0 || n > h->max_batch) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle/out or bad n");
+    if (!h->timed) return fail(A1MPC_ERR_INVALID_ARGUMENT, "no kernel has been launched through this handle");
+    A1_HIP(hipSetDevice(h->device));
+    A1_HIP(hipStreamSynchronize(h->last_stream));
+    A1_HIP(hipMemcpy(nfact_out, h->d_nfact, static_cast<size_t>(n) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_kernel_info(a1mpc_handle h, int32_t* lds_bytes_per_workgroup, int32_t* qps_per_workgroup,
+                               int32_t* threads_per_workgroup) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (lds_bytes_per_workgroup) *lds_bytes_per_workgroup = static_cast<int32_t>(lds_bytes_of(h->cfg.horizon));
+    if (qps_per_workgroup) *qps_per_workgroup = kRowsPerWg;
+    if (threads_per_workgroup) *threads_per_workgroup = kThreads;
+    return A1MPC_OK;
+}
+
+}  // extern "C"

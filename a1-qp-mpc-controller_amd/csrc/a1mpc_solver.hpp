@@ -57,7 +57,11 @@ struct DeviceParams {
     int32_t max_iter, check_every, adaptive_rho, adaptive_rho_every, scaling_iters, warm_start;
 };
 
+enum : int { kModeMpc = 0, kModeBalance = 1 };
+
 struct ProblemIO {
+    const double* root_acc;  // balance mode only: 6, desired wrench (S/A1RobotControl.cpp:379-391)
+    const double* Rz;        // balance mode only: 9, row-major root_rot_mat_z
     const double* x0;        // 13
     const double* xref;      // 13*H
     const double* R;         // 9, row-major root_rot_mat
@@ -136,7 +140,12 @@ struct Layout {
 // =================================================================================================
 // One QP, executed by the 16 lanes of a row.  `tab` = [s][t][2] = (alpha_st/beta_st, beta_st).
 // =================================================================================================
-template <int H>
+//
+// MODE = kModeBalance (H = 1) is the 12-variable balance QP of compute_grf (S/A1RobotControl.cpp:377-444):
+// P = R I + M' Q M, q = -M' Q b with M = [I; Rz' skew(r_i)] is the H = 1 member of the same family
+// (alpha_00 = 0, beta_00 = 1, B~ := M with the torque rows first, dt := 0); its friction rows are the MPC
+// rows with two signs flipped, which leaves every ADMM iterate of x unchanged.
+template <int H, int MODE = kModeMpc>
 A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, const ProblemIO& io, double* __restrict__ lds) {
     using L = Layout<H>;
     const int ln = row_lane();
@@ -150,11 +159,25 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
     double Rm[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) Rm[i] = io.R[i];
-    const double yaw = io.x0[2];
-    const double cy = cos(yaw), sy = sin(yaw);  // S/ConvexMpc.cpp:115-116
+    double cy = 1.0, sy = 0.0;
+    if constexpr (MODE == kModeMpc) {
+        const double yaw = io.x0[2];
+        cy = cos(yaw); sy = sin(yaw);  // S/ConvexMpc.cpp:115-116
+    }
 
     double Bt[6];  // my column of B~ (force layout); zero on pad lanes
-    {
+    if constexpr (MODE == kModeBalance) {
+        static_assert(MODE != kModeBalance || H == 1, "the balance QP is the H = 1 case");
+        const double rx = io.foot[3 * quad + 0], ry = io.foot[3 * quad + 1], rz = io.foot[3 * quad + 2];
+        const double k0 = comp == 0 ? 0.0 : (comp == 1 ? -rz : ry);
+        const double k1 = comp == 0 ? rz : (comp == 1 ? 0.0 : -rx);
+        const double k2 = comp == 0 ? -ry : (comp == 1 ? rx : 0.0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {  // inertia_inv = [I; Rz' skew(r)] (S/A1RobotControl.cpp:394-399)
+            Bt[k] = act ? io.Rz[0 * 3 + k] * k0 + io.Rz[1 * 3 + k] * k1 + io.Rz[2 * 3 + k] * k2 : 0.0;
+            Bt[3 + k] = (act && comp == k) ? 1.0 : 0.0;
+        }
+    } else {
         // I_world = R I_b R', inverse by cofactors (S/ConvexMpc.cpp:136-141)
         double t9[9], Iw[9], Ii[9];
 #pragma unroll
@@ -255,7 +278,16 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
 
     // ---------------------------------------------------------------- gradient g = B_qp' Q (A_qp x0 - x_ref)
     double g[H];
-    {
+    if constexpr (MODE == kModeBalance) {
+        // q = -M' Q b (S/A1RobotControl.cpp:406); wrench order here: torque (root_acc[3:6]), force (root_acc[0:3])
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a += Bt[k] * P.q2[6 + k] * io.root_acc[3 + k];
+            a += Bt[3 + k] * P.q2[9 + k] * io.root_acc[k];
+        }
+        g[0] = -a;
+    } else {
         double w[H];
         double xs = act ? io.x0[ci] : 0.0;
         const double grav = io.x0[12];

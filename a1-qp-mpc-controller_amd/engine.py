@@ -1,0 +1,204 @@
+"""ctypes binding of liba1mpc.so -- the host-side mirror of the reference interface for the hot path.
+
+The reference is C++ (ConvexMpc + A1RobotControl::compute_grf); the C++ adapter with the reference's own
+class interface is include/a1mpc_convex_mpc.hpp.  This module is the Python plumbing the tests and
+bench.py use: numpy arrays in the C-ABI layouts in, GRFs out.  There is no fallback: if the HIP library is
+missing, or there is no GPU, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+NS, NU, NC = 13, 12, 20
+STATUS_NAMES = {1: "solved", 2: "solved_inaccurate", -2: "max_iter_reached", -7: "non_cvx", -10: "unsolved"}
+SUPPORTED_HORIZONS = (1, 10, 16, 20)
+
+
+class Config(C.Structure):  # a1mpc_config, include/a1mpc.h
+    _fields_ = [("horizon", C.c_int32), ("dt", C.c_double), ("mu", C.c_double), ("fz_min", C.c_double),
+                ("fz_max", C.c_double), ("q", C.c_double * NS), ("r", C.c_double * NU), ("mass", C.c_double),
+                ("inertia_body", C.c_double * 9), ("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
+                ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("adaptive_rho_tolerance", C.c_double),
+                ("max_iter", C.c_int32), ("check_termination", C.c_int32), ("adaptive_rho", C.c_int32),
+                ("adaptive_rho_interval", C.c_int32), ("scaling", C.c_int32), ("warm_start", C.c_int32)]
+
+
+class BalanceConfig(C.Structure):  # a1mpc_balance_config
+    _fields_ = [("Q", C.c_double * 6), ("R", C.c_double), ("mu", C.c_double), ("F_min", C.c_double), ("F_max", C.c_double)]
+
+
+EXPORTS = ["a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
+           "a1mpc_solve_batch_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
+           "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
+
+_lib = None
+
+
+class A1MpcError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen liba1mpc.so (no compute).  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or _build.LIB_PATH
+    if not os.path.exists(path):
+        raise A1MpcError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(there is no CPU fallback for the solver)")
+    lib = C.CDLL(path)
+    vp, i32, dp, u8p, i32p = C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    lib.a1mpc_default_config.argtypes = [C.POINTER(Config)]; lib.a1mpc_default_config.restype = None
+    lib.a1mpc_default_balance_config.argtypes = [C.POINTER(BalanceConfig)]; lib.a1mpc_default_balance_config.restype = None
+    lib.a1mpc_create.argtypes = [C.POINTER(Config), i32, i32, C.POINTER(vp)]; lib.a1mpc_create.restype = C.c_int
+    lib.a1mpc_destroy.argtypes = [vp]; lib.a1mpc_destroy.restype = None
+    lib.a1mpc_solve_batch.argtypes = [vp, i32, dp, dp, dp, dp, u8p, dp, dp, i32p, i32p]; lib.a1mpc_solve_batch.restype = C.c_int
+    lib.a1mpc_solve_batch_device.argtypes = [vp, i32] + [vp] * 9 + [vp]; lib.a1mpc_solve_batch_device.restype = C.c_int
+    lib.a1mpc_balance_solve_batch.argtypes = [vp, C.POINTER(BalanceConfig), i32, dp, dp, dp, dp, u8p, dp, dp, i32p, i32p]
+    lib.a1mpc_balance_solve_batch.restype = C.c_int
+    lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
+    lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int
+    lib.a1mpc_last_nfact.argtypes = [vp, i32, i32p]; lib.a1mpc_last_nfact.restype = C.c_int
+    lib.a1mpc_kernel_info.argtypes = [vp, i32p, i32p, i32p]; lib.a1mpc_kernel_info.restype = C.c_int
+    lib.a1mpc_status_string.argtypes = [C.c_int]; lib.a1mpc_status_string.restype = C.c_char_p
+    lib.a1mpc_last_error.argtypes = []; lib.a1mpc_last_error.restype = C.c_char_p
+    if path == _build.LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise A1MpcError(f"{what}: {lib.a1mpc_status_string(rc).decode()} ({lib.a1mpc_last_error().decode()})")
+
+
+def make_config(params, horizon, **osqp):
+    """params: dict with dt, mu, fz_min, fz_max, q(13), r(12), mass, inertia(9) -- e.g. scenarios.*()['params'].
+    osqp: overrides of the OSQP settings fields (rho, eps_abs, eps_rel, max_iter, warm_start, ...)."""
+    lib = load_library()
+    cfg = Config()
+    lib.a1mpc_default_config(C.byref(cfg))
+    cfg.horizon = int(horizon)
+    cfg.dt, cfg.mu, cfg.fz_min, cfg.fz_max, cfg.mass = params["dt"], params["mu"], params["fz_min"], params["fz_max"], params["mass"]
+    cfg.q[:] = [float(v) for v in params["q"]]
+    cfg.r[:] = [float(v) for v in params["r"]]
+    cfg.inertia_body[:] = [float(v) for v in np.asarray(params["inertia"], dtype=float).reshape(9)]
+    for k, v in osqp.items():
+        if not hasattr(cfg, k):
+            raise KeyError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _f64(a, shape):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a.reshape(shape)
+
+
+class Engine:
+    """One a1mpc handle: a fixed (robot constants, horizon, OSQP settings) configuration on one GPU."""
+
+    def __init__(self, cfg, max_batch, device=0):
+        self.lib = load_library()
+        self.cfg = cfg
+        self.horizon = int(cfg.horizon)
+        self.max_batch = int(max_batch)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        _check(self.lib, self.lib.a1mpc_create(C.byref(cfg), self.max_batch, self.device, C.byref(self._h)), "a1mpc_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.a1mpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- host arrays (the drop-in path: S/A1RobotControl.cpp:446-562 for n ticks) ----
+    def solve(self, x0, xref, R, foot, contact, want_u=False):
+        h = self.horizon
+        x0 = _f64(x0, (-1, NS)); n = x0.shape[0]
+        xref = _f64(xref, (n, NS * h)); R = _f64(R, (n, 9)); foot = _f64(foot, (n, 12))
+        contact = np.ascontiguousarray(contact, dtype=np.uint8).reshape(n, 4)
+        grf = np.zeros((n, 12)); u = np.zeros((n, NU * h)) if want_u else None
+        iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
+        rc = self.lib.a1mpc_solve_batch(self._h, n, _dp(x0), _dp(xref), _dp(R), _dp(foot),
+                                        contact.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(grf), _dp(u), _ip(iters), _ip(status))
+        _check(self.lib, rc, "a1mpc_solve_batch")
+        return dict(grf=grf, u=u, iters=iters, status=status)
+
+    # ---- device pointers (torch tensors already resident in HBM), asynchronous on `stream` ----
+    def solve_device(self, n, d_x0, d_xref, d_R, d_foot, d_contact, d_grf, d_u=None, d_iters=None, d_status=None, stream=None):
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+        rc = self.lib.a1mpc_solve_batch_device(self._h, int(n), ptr(d_x0), ptr(d_xref), ptr(d_R), ptr(d_foot), ptr(d_contact),
+                                               ptr(d_grf), ptr(d_u), ptr(d_iters), ptr(d_status),
+                                               C.c_void_p(int(stream)) if stream else None)
+        _check(self.lib, rc, "a1mpc_solve_batch_device")
+
+    def balance_solve(self, root_acc, R, Rz, foot, contact, qp=None):
+        if qp is None:
+            qp = BalanceConfig(); self.lib.a1mpc_default_balance_config(C.byref(qp))
+        root_acc = _f64(root_acc, (-1, 6)); n = root_acc.shape[0]
+        R = _f64(R, (n, 9)); Rz = _f64(Rz, (n, 9)); foot = _f64(foot, (n, 12))
+        contact = np.ascontiguousarray(contact, dtype=np.uint8).reshape(n, 4)
+        grf = np.zeros((n, 12)); f = np.zeros((n, 12)); iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
+        rc = self.lib.a1mpc_balance_solve_batch(self._h, C.byref(qp), n, _dp(root_acc), _dp(R), _dp(Rz), _dp(foot),
+                                                contact.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(grf), _dp(f), _ip(iters), _ip(status))
+        _check(self.lib, rc, "a1mpc_balance_solve_batch")
+        return dict(grf=grf, f_world=f, iters=iters, status=status)
+
+    def reset_warm_start(self):
+        _check(self.lib, self.lib.a1mpc_reset_warm_start(self._h), "a1mpc_reset_warm_start")
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _check(self.lib, self.lib.a1mpc_last_kernel_ms(self._h, C.byref(ms)), "a1mpc_last_kernel_ms")
+        return float(ms.value)
+
+    def last_nfact(self, n):
+        out = np.zeros(int(n), np.int32)
+        _check(self.lib, self.lib.a1mpc_last_nfact(self._h, int(n), _ip(out)), "a1mpc_last_nfact")
+        return out
+
+    def kernel_info(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(self.lib, self.lib.a1mpc_kernel_info(self._h, C.byref(a), C.byref(b), C.byref(c)), "a1mpc_kernel_info")
+        return dict(lds_bytes_per_workgroup=a.value, qps_per_workgroup=b.value, threads_per_workgroup=c.value)
+
+
+# ---- work model used for roofline.achieved (DESIGN.md "Measurement") --------------
+def algorithmic_flops(h, iters, nfact):
+    """F(h, iters, nfact) of the structured dense-condensed algorithm, per solve (numpy-broadcastable)."""
+    iters = np.asarray(iters, dtype=np.float64); nfact = np.asarray(nfact, dtype=np.float64)
+    f_cond = 3744.0 * h * (h + 1) * (h + 2) / 6.0 + 4056.0 * (h - 1) + 312.0 * h * h + 364.0 * h
+    f_fact = 576.0 * h ** 3
+    f_iter = 288.0 * h * h + 464.0 * h
+    f_chk = 288.0 * h * h + 336.0 * h
+    return f_cond + nfact * f_fact + iters * f_iter + np.ceil(iters / 25.0) * f_chk
+
+
+def algorithmic_bytes(h):
+    """Compulsory HBM bytes per solve: input record + 12 GRF doubles."""
+    return 8 * (38 + 13 * h) + 96

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC-QP solves/sec (horizon-10 SRBD) of the MI355X engine, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path (QP formation + OSQP-faithful ADMM solve, cold start) over one batch of
+synthetic input: BASELINE.json configs[2] -- 4096 randomized CoM states, flat terrain, horizon 10, per GPU
+(weak scaling: every rank gets its own 4096 QPs, generated from a rank-specific seed; the batch is
+embarrassingly parallel, so there is no data-path collective).  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (AMD spec; = 1/2 of the 157.3 TF FP32 rate in MI355X_MICROARCH.md)
+BATCH = 4096
+HORIZON = 10
+
+
+def cpu_baseline(pkg, sc, budget_s=15.0):
+    """The oracle (port of the reference path: dense formation + OSQP-0.6 ADMM) on this box's host cores, bounded sample."""
+    oracle = graft.load_oracle()
+    oracle.build()
+    p = sc["params"]
+    pr = oracle.mpc_params(sc["horizon"], p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"], p["inertia"])
+    st = oracle.default_settings()
+    cores = oracle.num_threads()
+    take = lambda n: (sc["x0"][:n], sc["xref"][:n], sc["R"][:n], sc["foot"][:n], sc["contact"][:n])
+    n0 = min(8 * cores, len(sc["x0"]))
+    t = time.perf_counter(); oracle.mpc_solve_batch(pr, st, *take(n0), nthreads=cores); t0 = time.perf_counter() - t
+    n = int(max(n0, min(len(sc["x0"]), budget_s / max(t0 / n0, 1e-9))))
+    t = time.perf_counter(); r = oracle.mpc_solve_batch(pr, st, *take(n), nthreads=cores); t1 = time.perf_counter() - t
+    t = time.perf_counter(); oracle.mpc_solve_batch(pr, st, *take(min(n, 64)), nthreads=1); ts = (time.perf_counter() - t) / min(n, 64)
+    return {"value": n / t1, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} QPs of the same workload (config3, h=10), OpenMP static over {cores} threads, {t1:.1f} s; "
+                      f"single-thread {1.0 / ts:.1f} solves/s; real OSQP/Eigen are not installable here (oracle/ restates them)",
+            "mean_iters": float(r["iters"].mean())}, r
+
+
+def latency_probe(pkg, nticks=1500):
+    """BASELINE configs[1]: batch 1, trot, warm-started sequential ticks through the host-pointer ABI (PCIe inclusive)."""
+    sc = pkg.scenarios.config2_trot_sequence(nticks)
+    cfg = pkg.make_config(sc["params"], sc["horizon"], warm_start=1)
+    lat = np.zeros(nticks)
+    with pkg.Engine(cfg, 1, int(os.environ.get("LOCAL_RANK", 0))) as eng:
+        for t in range(nticks):
+            a = time.perf_counter()
+            eng.solve(sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t])
+            lat[t] = time.perf_counter() - a
+    lat = lat[50:] * 1e3
+    return {"workload": "config2 trot, h=10, batch 1, warm start, host pointers in/out", "ticks": int(len(lat)),
+            "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "max_ms": float(lat.max())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="QPs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path for the solver)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    pkg = graft.load_package()
+    try:
+        pkg.load_library()
+    except Exception:
+        if rank == 0:
+            pkg.build.build()
+        if world > 1:
+            dist.barrier()
+        pkg.load_library()
+
+    n = args.batch
+    sc = pkg.scenarios.config3_random_flat(nb=n, seed=0xA1 + 3 + 1000 * rank)  # synthetic; rank 0 = the documented seed
+    cfg = pkg.make_config(sc["params"], HORIZON, warm_start=0)                   # cold start every step: no work is skipped
+    dev = torch.device("cuda", local)
+    d = {k: torch.from_numpy(sc[k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")}
+    grf = torch.zeros((n, 12), dtype=torch.float64, device=dev)
+    iters = torch.zeros(n, dtype=torch.int32, device=dev); status = torch.zeros(n, dtype=torch.int32, device=dev)
+    eng = pkg.Engine(cfg, n, local)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, iters, status, stream=stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record(stream)
+    for k in range(args.steps):
+        step()
+        evs[k + 1].record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps)])  # HIP events on the launch stream
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    it = iters.cpu().numpy(); stt = status.cpu().numpy()
+    if rank == 0:
+        h = HORIZON
+        nfact = eng.last_nfact(n)  # factorisations each QP really performed in the last launch
+        flops = float(pkg.algorithmic_flops(h, it, nfact).sum())
+        avg_ms = float(kern_ms.mean())
+        achieved = flops / (avg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "MPC QP solves/sec (horizon=10 SRBD)", "value": world * n * args.steps / elapsed, "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: batch=4096 randomized CoM states + flat terrain, horizon=10, cold-start "
+                                   "OSQP-default ADMM, per GPU", "batch_per_gpu": n, "horizon": h, "parallelism": f"batch-sharded x{world}",
+                       "mean_iters": float(it.mean()), "max_iters": int(it.max()), "solved_frac": float((stt == 1).mean())},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "a1mpc_solve_kernel<10,0>", "avg_kernel_ms": avg_ms, "algorithmic_flops_per_launch": flops,
+                         "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
+                         "note": "FP64 VALU-bound (no MFMA used); flops = SURVEY 8(d) F(h,iters,nfact) summed over the launch"},
+        }
+        if not args.no_latency:
+            out["latency"] = latency_probe(pkg)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"], _ = cpu_baseline(pkg, sc)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+/*
+ * a1mpc.h -- C ABI of the MI355X batched convex-MPC QP engine (liba1mpc.so).
+ *
+ * Drop-in boundary for the ONE hot path of ShuoYangRobotics/A1-QP-MPC-Controller: QP formation +
+ * OSQP solve inside A1RobotControl::compute_grf.  Citations are reference file:line with
+ * S/ = src/a1_cpp/src/.  The reference has no FFI; the C++ call sites this ABI replaces are
+ *
+ *   a1mpc_config                <- compile-time dims S/A1Params.h:26-34, ConvexMpc ctor constants
+ *                                  S/ConvexMpc.cpp:8-44,223-224, A1CtrlStates fields S/A1CtrlStates.h:358-366,
+ *                                  mpc_dt S/A1RobotControl.cpp:462, OSQP settings S/A1RobotControl.cpp:523-524
+ *   a1mpc_create / _destroy     <- `OsqpEigen::Solver solver` member (S/A1RobotControl.h:67) + per-tick
+ *                                  `ConvexMpc mpc_solver(q, r); reset()` (S/A1RobotControl.cpp:447-448)
+ *   a1mpc_solve_batch           <- MPC branch of compute_grf, S/A1RobotControl.cpp:446-562:
+ *                                  calculate_A_mat_c / calculate_B_mat_c / state_space_discretization /
+ *                                  calculate_qp_mats (S/ConvexMpc.cpp:110-260), solver.update*()/solve()
+ *                                  (:522-540), R' * solution[0:12] (:555-561)          -- n ticks at once
+ *   a1mpc_balance_solve_batch   <- balance-QP branch of compute_grf, S/A1RobotControl.cpp:377-444 (+ ctor :11-48)
+ *   a1mpc_reset_warm_start      <- destroying / re-creating the persistent OSQP workspace
+ *
+ * Plain pointers and sizes only.  All matrices use the reference's (Eigen) storage: 3x4 GRF / foot
+ * matrices are column-major (leg-major, 12 doubles), root_rot_mat is passed ROW-major (9 doubles).
+ * Caller owns every host array (pageable is fine; the library snapshots inputs at entry because the
+ * surrounding control program mutates A1CtrlStates without locks, S/MainGazebo.cpp:47-121).  A handle is
+ * used by one thread at a time (the reference's thread 1); different handles are independent.
+ * Nothing throws across this boundary.  There is NO CPU fallback: without a working HIP device every
+ * entry point returns an error.
+ */
+#ifndef A1MPC_H_
+#define A1MPC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A1MPC_STATE_DIM 13      /* MPC_STATE_DIM      S/A1Params.h:27 */
+#define A1MPC_NUM_DOF 12        /* NUM_DOF            S/A1Params.h:34 */
+#define A1MPC_CONSTRAINT_DIM 20 /* MPC_CONSTRAINT_DIM S/A1Params.h:28 */
+#define A1MPC_NUM_LEG 4         /* NUM_LEG            S/A1Params.h:31 */
+
+typedef enum a1mpc_status {
+    A1MPC_OK = 0,
+    A1MPC_ERR_INVALID_ARGUMENT = 1,
+    A1MPC_ERR_UNSUPPORTED_HORIZON = 2, /* horizons compiled in: 1, 10, 16, 20 */
+    A1MPC_ERR_NO_DEVICE = 3,
+    A1MPC_ERR_HIP = 4,
+    A1MPC_ERR_BATCH_TOO_LARGE = 5
+} a1mpc_status;
+
+/* per-problem solver status written to status_out[] -- OSQP's numbering, which the reference ignores
+ * (S/A1RobotControl.cpp:540); on A1MPC_QP_NON_CVX the GRFs are zeros (replaces the reference's
+ * uninitialised-matrix behaviour, S/A1RobotControl.cpp:322,559) */
+#define A1MPC_QP_SOLVED 1
+#define A1MPC_QP_SOLVED_INACCURATE 2
+#define A1MPC_QP_MAX_ITER_REACHED (-2)
+#define A1MPC_QP_NON_CVX (-7)
+
+typedef struct a1mpc_config {
+    int32_t horizon; /* PLAN_HORIZON (S/A1Params.h:26 fixes 10; a run-time value here) */
+    double dt;       /* mpc_dt, S/A1RobotControl.cpp:462 */
+    double mu;       /* S/ConvexMpc.cpp:8 */
+    double fz_min;   /* S/ConvexMpc.cpp:223 */
+    double fz_max;   /* S/ConvexMpc.cpp:224 */
+    double q[A1MPC_STATE_DIM]; /* q_weights, S/A1CtrlStates.h:365 */
+    double r[A1MPC_NUM_DOF];   /* r_weights, S/A1CtrlStates.h:366 */
+    double mass;               /* robot_mass, S/A1CtrlStates.h:358 */
+    double inertia_body[9];    /* a1_trunk_inertia, row-major, S/A1CtrlStates.h:359-360 */
+    /* OSQP 0.6 settings; the reference only sets verbosity and warm start, everything else is the default */
+    double rho, sigma, alpha, eps_abs, eps_rel, adaptive_rho_tolerance;
+    int32_t max_iter;
+    int32_t check_termination;     /* iterations between termination checks (25) */
+    int32_t adaptive_rho;          /* 1 */
+    int32_t adaptive_rho_interval; /* OSQP's default 0 means "wall-clock based"; this engine needs a fixed
+                                      iteration period so results are reproducible: 25 */
+    int32_t scaling;               /* Ruiz passes (10) */
+    int32_t warm_start;            /* 1 on the reference's MPC path, 0 on its balance-QP path */
+} a1mpc_config;
+
+/* balance-QP constants, A1RobotControl ctor S/A1RobotControl.cpp:11-15 */
+typedef struct a1mpc_balance_config {
+    double Q[6];         /* diag(1,1,1,400,400,100) */
+    double R;            /* 1e-3 */
+    double mu;           /* 0.7 */
+    double F_min, F_max; /* 0, 180 */
+} a1mpc_balance_config;
+
+typedef struct a1mpc_handle_s* a1mpc_handle;
+
+/* Reference constants (mu 0.3, fz in [0,180], dt 0.0025, horizon 10), OSQP defaults, warm start on;
+ * q, r, mass, inertia are left zero for the caller (they come from the rosparam YAML). */
+void a1mpc_default_config(a1mpc_config* cfg);
+void a1mpc_default_balance_config(a1mpc_balance_config* cfg);
+
+/* device: HIP device ordinal (>= 0).  max_batch: largest n any later call will pass. */
+a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t device, a1mpc_handle* out);
+void a1mpc_destroy(a1mpc_handle h);
+
+/*
+ * n independent MPC ticks.  Host pointers.
+ *   x0      n x 13   mpc_states                    (S/A1RobotControl.cpp:452-456)
+ *   x_ref   n x 13H  mpc_states_d                  (S/A1RobotControl.cpp:470-488)
+ *   R_world n x 9    root_rot_mat, row-major
+ *   foot    n x 12   foot_pos_abs, 3x4 column-major (same feet for all H steps, S/A1RobotControl.cpp:498-514)
+ *   contact n x 4    contacts[], broadcast over the horizon (S/ConvexMpc.cpp:228-245)
+ * out:
+ *   grf_body_out n x 12  3x4 column-major, body frame (the value compute_grf returns)
+ *   u_full_out   n x 12H world-frame forces of every horizon step, or NULL
+ *   iters_out, status_out  n each, or NULL
+ * With cfg.warm_start the handle keeps (x, y, rho) of problem i between calls, like the reference's
+ * persistent OSQP workspace.
+ */
+a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
+                               const double* foot_abs, const uint8_t* contact, double* grf_body_out, double* u_full_out,
+                               int32_t* iters_out, int32_t* status_out);
+
+/* Same, but every pointer is DEVICE memory of the handle's device and the launch is asynchronous on
+ * `hip_stream` (a hipStream_t, NULL = the handle's own stream).  No host synchronisation. */
+a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d_x0, const double* d_x_ref,
+                                      const double* d_R_world, const double* d_foot_abs, const uint8_t* d_contact,
+                                      double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out,
+                                      int32_t* d_status_out, void* hip_stream);
+
+/*
+ * n independent balance-QP ticks (12 variables, 20 constraints), cold-started like the reference.
+ *   root_acc n x 6   desired wrench incl. m*9.8 (S/A1RobotControl.cpp:379-391)
+ *   R_world  n x 9   root_rot_mat (output rotation), R_z n x 9 root_rot_mat_z (lever arms, :397), row-major
+ *   foot     n x 12, contact n x 4
+ * The handle's horizon is irrelevant for this call; its OSQP settings are used with warm_start forced off.
+ */
+a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_config* qp, int32_t n, const double* root_acc,
+                                       const double* R_world, const double* R_z, const double* foot_abs,
+                                       const uint8_t* contact, double* grf_body_out, double* f_world_out,
+                                       int32_t* iters_out, int32_t* status_out);
+
+/* forget the carried (x, y, rho) of every problem: next solve is a cold start */
+a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h);
+
+/* instrumentation: duration of the last kernel launched through this handle (HIP events on its stream;
+ * synchronises that stream), bytes of dynamic LDS per workgroup and QPs per workgroup of the horizon's kernel */
+a1mpc_status a1mpc_last_kernel_ms(a1mpc_handle h, float* ms_out);
+a1mpc_status a1mpc_kernel_info(a1mpc_handle h, int32_t* lds_bytes_per_workgroup, int32_t* qps_per_workgroup,
+                               int32_t* threads_per_workgroup);
+
+/* number of KKT (Riccati) factorisations each QP of the last MPC / balance launch performed (1 + rho updates);
+ * synchronises the handle's stream; instrumentation for the work model of bench.py */
+a1mpc_status a1mpc_last_nfact(a1mpc_handle h, int32_t n, int32_t* nfact_out);
+
+const char* a1mpc_status_string(a1mpc_status s);
+const char* a1mpc_last_error(void); /* thread-local detail of the last non-OK return (e.g. the HIP error string) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A1MPC_H_ */

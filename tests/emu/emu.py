@@ -74,3 +74,26 @@ def solve(sc, n=None, settings=None, warm=None, **over):
                                _p(status, C.c_int32), _p(nfact, C.c_int32))
     assert rc == 0
     return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
+
+
+def balance_params(qp=None, settings=None, **over):
+    """DeviceParams of the balance QP (S/A1RobotControl.cpp:11-15): the H = 1 member of the family with
+    dt = 0, wrench weights (torque first) in q2[6:12], R in r2."""
+    qp = qp or dict(Q=[1.0, 1.0, 1.0, 400.0, 400.0, 100.0], R=1e-3, mu=0.7, F_min=0.0, F_max=180.0)
+    prm = dict(dt=0.0, mu=qp["mu"], fz_min=qp["F_min"], fz_max=qp["F_max"], mass=1.0, inertia=np.eye(3).reshape(9),
+               q=[0.0] * 12, r=[0.0] * 12)
+    p = make_params(prm, settings, **over)
+    p.q2[:] = [0.0] * 6 + list(qp["Q"][3:6]) + list(qp["Q"][0:3])
+    p.r2[:] = [qp["R"]] * 12
+    p.warm_start = 0
+    return p
+
+
+def balance_solve(sc, n=None, settings=None, **over):
+    n = len(sc["root_acc"]) if n is None else n
+    P = balance_params(None, settings, **over)
+    grf = np.zeros((n, 12)); f = np.zeros((n, 12)); iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
+    rc = lib().a1mpc_emu_balance(C.byref(P), n, _p(sc["root_acc"]), _p(sc["R"]), _p(sc["Rz"]), _p(sc["foot"]),
+                                 _p(sc["contact"], C.c_uint8), _p(grf), _p(f), _p(iters, C.c_int32), _p(status, C.c_int32))
+    assert rc == 0
+    return dict(grf=grf, f_world=f, iters=iters, status=status)

@@ -109,6 +109,7 @@ static void run_batch(const DeviceParams* P, int n, const double* x0, const doub
     for (int b = 0; b < n; ++b) {
         for (auto& v : lds) v = NAN;  // uninitialised LDS must never be consumed
         Job<H> j;
+        memset(&j.io, 0, sizeof j.io);
         j.P = P;
         j.tab = tab.data();
         j.lds = lds.data();
@@ -142,5 +143,31 @@ extern "C" int a1mpc_emu_solve(const a1mpc::DeviceParams* P, int horizon, int n,
         case 20: a1mpc::run_batch<20>(P, n, x0, xref, R, foot, contact, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
     }
     return -1;
+}
+namespace a1mpc {
+static void balance_entry(void* a) {
+    Job<1>* j = static_cast<Job<1>*>(a);
+    solve_row<1, kModeBalance>(*j->P, j->tab, j->io, j->lds);
+}
+}  // namespace a1mpc
+extern "C" int a1mpc_emu_balance(const a1mpc::DeviceParams* P, int n, const double* root_acc, const double* R, const double* Rz,
+                                 const double* foot, const uint8_t* contact, double* grf, double* f_world, int32_t* iters,
+                                 int32_t* status) {
+    using namespace a1mpc;
+    double tab[2];
+    fill_gamma_beta_table(1, tab);
+    std::vector<double> lds(Layout<1>::ROW_STRIDE);
+    for (int b = 0; b < n; ++b) {
+        for (auto& v : lds) v = NAN;
+        Job<1> j;
+        memset(&j.io, 0, sizeof j.io);
+        j.P = P; j.tab = tab; j.lds = lds.data();
+        j.io.root_acc = root_acc + (size_t)b * 6; j.io.Rz = Rz + (size_t)b * 9; j.io.R = R + (size_t)b * 9;
+        j.io.foot = foot + (size_t)b * 12; j.io.contact = contact + (size_t)b * 4;
+        j.io.grf = grf + (size_t)b * 12; j.io.u_full = f_world ? f_world + (size_t)b * 12 : nullptr;
+        j.io.iters = iters ? iters + b : nullptr; j.io.status = status ? status + b : nullptr;
+        run_row(balance_entry, &j);
+    }
+    return 0;
 }
 extern "C" int a1mpc_emu_sizeof_params(void) { return (int)sizeof(a1mpc::DeviceParams); }

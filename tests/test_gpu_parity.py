@@ -1,0 +1,149 @@
+"""-m gpu: the HIP path, called through the C ABI (liba1mpc.so), against the oracle on identical inputs."""
+import numpy as np
+import pytest
+
+from helpers import TOL_FORCE_BALANCE_N, TOL_FORCE_N, compare, oracle_batch, take
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(pkg, sc, max_batch, **osqp):
+    cfg = pkg.make_config(sc["params"], sc["horizon"], **osqp)
+    return pkg.Engine(cfg, max_batch=max_batch, device=0)
+
+
+def test_fixture_T_default_and_exact(pkg, oracle, scen):
+    """S/test/test_mpc.cpp:18-60 inputs (stand, contacts FL+RL, cold start)."""
+    sc = scen.scenario_T()
+    with _engine(pkg, sc, 4, warm_start=0) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    ref = oracle_batch(oracle, sc)
+    compare(out, ref, min_same=1.0)
+    with _engine(pkg, sc, 4, warm_start=0, eps_abs=1e-10, eps_rel=1e-10, max_iter=100000) as eng:
+        oute = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    refe = oracle_batch(oracle, sc, settings=oracle.exact_settings())
+    compare(oute, refe, min_same=1.0)
+    f = oute["grf"].reshape(4, 3)
+    assert abs(f[0, 1]) == pytest.approx(0.3 * f[0, 2], rel=1e-6)  # friction row active: |fy| = mu fz
+    assert np.abs(f[1]).max() < 1e-6 and np.abs(f[3]).max() < 1e-6  # swing legs
+
+
+@pytest.mark.parametrize("name,gen,n", [("config3_h10", "config3_random_flat", 512), ("config4_h16", "config4_random_h16", 192),
+                                         ("config5_h20", "config5_divergent", 192)])
+def test_randomized_configs_default_settings(pkg, oracle, scen, name, gen, n):
+    sc = getattr(scen, gen)(nb=n)
+    with _engine(pkg, sc, n, warm_start=0) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    ref = oracle_batch(oracle, sc)
+    r = compare(out, ref)
+    print(name, r, "iters", np.unique(out["iters"], return_counts=True))
+
+
+def test_parameter_sets(pkg, oracle, scen):
+    for ps in ("hardware", "isaac", "ctrl_default"):
+        sc = scen.config3_random_flat(nb=64, param_set=ps)
+        with _engine(pkg, sc, 64, warm_start=0) as eng:
+            out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+        compare(out, oracle_batch(oracle, sc))
+
+
+def test_exact_mode_h10(pkg, oracle, scen):
+    sc = scen.config3_random_flat(nb=64)
+    with _engine(pkg, sc, 64, warm_start=0, eps_abs=1e-10, eps_rel=1e-10, max_iter=100000) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    ref = oracle_batch(oracle, sc, settings=oracle.exact_settings())
+    compare(out, ref, min_same=0.9)
+    # whatever the iteration count, both are the optimum
+    assert np.abs(out["u"] - ref["u"]).max() < 1e-5
+
+
+def test_ragged_and_edge_batches(pkg, oracle, scen):
+    """n not a multiple of the 4 QPs per workgroup, n = 1, n = 0, n > max_batch."""
+    sc = scen.config3_random_flat(nb=11)
+    ref = oracle_batch(oracle, sc)
+    with _engine(pkg, sc, 16, warm_start=0) as eng:
+        for n in (1, 2, 3, 5, 11):
+            s = take(sc, n)
+            out = eng.solve(s["x0"], s["xref"], s["R"], s["foot"], s["contact"], want_u=True)
+            r = {k: v[:n] for k, v in ref.items() if v is not None}
+            compare(out, r, min_same=1.0)
+        s = take(sc, 0)
+        out = eng.solve(np.zeros((0, 13)), np.zeros((0, 130)), np.zeros((0, 9)), np.zeros((0, 12)), np.zeros((0, 4), np.uint8))
+        assert out["grf"].shape == (0, 12)
+    with _engine(pkg, sc, 4, warm_start=0) as eng:
+        with pytest.raises(pkg.A1MpcError):
+            eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+
+
+def test_all_contact_patterns(pkg, oracle, scen):
+    """every one of the 16 contact patterns incl. 0000 (all rows equalities => zero forces)."""
+    sc = scen.config3_random_flat(nb=16)
+    sc["contact"] = ((np.arange(16)[:, None] >> np.arange(4)[None, :]) & 1).astype(np.uint8)
+    with _engine(pkg, sc, 16, warm_start=0) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    compare(out, oracle_batch(oracle, sc), min_same=1.0)
+    assert np.abs(out["grf"][0]).max() < 1e-3
+    assert (np.abs(out["u"].reshape(16, -1, 4, 3)[:, 0][sc["contact"] == 0]) < 1e-2).all()
+
+
+def test_warm_started_tick_sequence(pkg, oracle, scen):
+    """config 2: sequential ticks of one robot, warm start + carried rho (S/A1RobotControl.cpp:522-538)."""
+    nt = 40
+    sc = scen.config2_trot_sequence(nt)
+    pr = None
+    from helpers import oracle_params
+    pr = oracle_params(oracle, sc)
+    st = oracle.default_settings(warm_start=1)
+    h = sc["horizon"]
+    wx = np.zeros(12 * h); wy = np.zeros(20 * h); rho = None
+    with _engine(pkg, sc, 1, warm_start=1) as eng:
+        for t in range(nt):
+            out = eng.solve(sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t], want_u=True)
+            r = oracle.mpc_solve(pr, st, sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t], warm_x=wx, warm_y=wy,
+                                 warm_rho=rho)
+            wx, wy, rho = r["warm_x"], r["warm_y"], r["rho"]
+            assert out["iters"][0] == r["info"].iters, (t, out["iters"], r["info"].iters)
+            assert np.abs(out["u"][0] - r["u"]).max() < TOL_FORCE_N
+        eng.reset_warm_start()
+        out = eng.solve(sc["x0"][0], sc["xref"][0], sc["R"][0], sc["foot"][0], sc["contact"][0], want_u=True)
+        r0 = oracle.mpc_solve(pr, oracle.default_settings(), sc["x0"][0], sc["xref"][0], sc["R"][0], sc["foot"][0], sc["contact"][0])
+        assert out["iters"][0] == r0["info"].iters and np.abs(out["u"][0] - r0["u"]).max() < TOL_FORCE_N
+
+
+def test_balance_qp(pkg, oracle, scen):
+    """compute_grf's balance branch (S/A1RobotControl.cpp:377-444) = the H = 1 member of the kernel family."""
+    sc = scen.balance_random(256)
+    cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+    with pkg.Engine(cfg, 256, 0) as eng:
+        out = eng.balance_solve(sc["root_acc"], sc["R"], sc["Rz"], sc["foot"], sc["contact"])
+        qp, st = oracle.default_qp_params(), oracle.default_settings()
+        for b in range(256):
+            r = oracle.balance_solve(qp, st, sc["root_acc"][b], sc["R"][b], sc["Rz"][b], sc["foot"][b], sc["contact"][b])
+            assert out["iters"][b] == r["info"].iters and out["status"][b] == r["info"].status
+            assert np.abs(out["f_world"][b] - r["f_world"]).max() < TOL_FORCE_BALANCE_N
+            assert np.abs(out["grf"][b] - r["grf"]).max() < TOL_FORCE_BALANCE_N
+        s1 = scen.config1_balance_stand()
+        o1 = eng.balance_solve(s1["root_acc"], s1["R"], s1["Rz"], s1["foot"], s1["contact"])
+        assert np.allclose(o1["grf"].reshape(4, 3)[:, 2], 12.0 * 9.8 / 4, atol=0.02)  # ~ m g / 4 per leg
+
+
+def test_size_independent_properties_full_batch(pkg, scen):
+    """BASELINE config 3 at its full size (4096, h=10): properties that need no oracle."""
+    sc = scen.config3_random_flat()
+    n = len(sc["x0"])
+    with _engine(pkg, sc, n, warm_start=0) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+        # batch-order invariance: a permuted batch gives the permuted answer bit for bit
+        perm = np.random.default_rng(0).permutation(n)
+        outp = eng.solve(sc["x0"][perm], sc["xref"][perm], sc["R"][perm], sc["foot"][perm], sc["contact"][perm], want_u=True)
+    assert (outp["u"] == out["u"][perm]).all() and (outp["iters"] == out["iters"][perm]).all()
+    assert (out["status"] == 1).all()
+    u = out["u"].reshape(n, 10, 4, 3)
+    mu, tol = 0.3, 0.5  # OSQP's default 1e-3 tolerances leave O(0.1 N) constraint violation
+    assert (u[..., 2] >= -tol).all() and (u[..., 2] <= 180 + tol).all()
+    assert (np.abs(u[..., 0]) <= mu * u[..., 2] + tol).all() and (np.abs(u[..., 1]) <= mu * u[..., 2] + tol).all()
+    assert np.abs(u.transpose(0, 2, 1, 3)[sc["contact"] == 0]).max() < tol  # swing legs carry no force
+    # first-step GRF = R' u_0
+    R = sc["R"].reshape(n, 3, 3)
+    g = np.einsum("nji,nlj->nli", R, u[:, 0])
+    assert np.abs(g.reshape(n, 12) - out["grf"]).max() < 1e-9
