@@ -98,6 +98,7 @@ constexpr int alpha_diag(int s, int H) {  // sum_{i=s}^{H-1} (i-s)^2
     return a;
 }
 
+A1_DEV int imin(int a, int b) { return a < b ? a : b; }
 A1_DEV double limit_scaling(double v) {  // osqp scaling.c limit_scaling
     v = v < kMinScaling ? 1.0 : v;
     v = v > kMaxScaling ? kMaxScaling : v;
@@ -127,14 +128,22 @@ struct Layout {
     static constexpr int SLOT = K_SZ + S_SZ; // 234 doubles per horizon step
     static constexpr int FAC = 0;
     static constexpr int BL = H * SLOT;      // B~ (6x12): rows 0-2 = dt*Iw^-1*skew(r), rows 3-5 = dt/m*I
-    static constexpr int RAW = BL + 72;
+    static constexpr int CG = BL + 72;       // c*g = D^-1 q_s, [t][12]
+    static constexpr int RAW = CG + 12 * H;
     // set-up-only aliases inside the factor region (the factor is written after Ruiz is finished)
     static constexpr int TBL = 0;            // T*B~_omega (3x12)
     static constexpr int DL = 36;            // D table of the current Ruiz pass, [t][12]
     static_assert(DL + 12 * H <= H * SLOT, "alias");
-    // row stride == 3 (mod 32) doubles: the two QPs that share a 32-lane LDS phase hit disjoint banks
-    static constexpr int ROW_STRIDE = ((RAW + 28) / 32) * 32 + 3;
-    static_assert(ROW_STRIDE >= RAW, "stride");
+    // row stride mod 32 in {3,4,9,10,16,22,23,28,29}: the two QPs that share a 32-lane LDS phase then read the
+    // stride-13 rows of K_t from disjoint banks; even, so that 16-byte alignment survives.  H = 10: 2532 doubles,
+    // 4 x 2532 x 8 B = 81,024 B per workgroup -> two workgroups per CU (160 KiB).
+    static constexpr int stride_for(int raw) {
+        for (int s = raw;; ++s) {
+            const int m = s % 32;
+            if (s % 2 == 0 && (m == 4 || m == 10 || m == 16 || m == 22 || m == 28)) return s;
+        }
+    }
+    static constexpr int ROW_STRIDE = stride_for(RAW);
 };
 
 // =================================================================================================
@@ -228,17 +237,9 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
         for (int k = 0; k < 3; ++k) lds[L::TBL + k * 12 + ci] = TB[k];
     }
     row_sync();
-    // B~ row of the wrench lanes (state rows 6..11 = quads 2,3); zero elsewhere
-    double Brow[12];
-    {
-        const bool wl = act && quad >= 2;
-        const int k = wl ? ci - 6 : 0;
-#pragma unroll
-        for (int b = 0; b < 12; ++b) {
-            const double v = lds[L::BL + k * 12 + b];
-            Brow[b] = wl ? v : 0.0;
-        }
-    }
+    // B~ row of the wrench lanes (state rows 6..11 = quads 2,3) is re-read from LDS where it is needed
+    const bool wl = act && quad >= 2;
+    const double* brow = lds + L::BL + (wl ? ci - 6 : 0) * 12;
     // A_d = I + dt*A_c and its transpose as row operators on a state-layout vector
     const double fA = ln == 0 ? dt * cy : (ln == 1 ? -dt * sy : 0.0);
     const double fB = ln == 0 ? dt * sy : (ln == 1 ? dt * cy : 0.0);
@@ -267,10 +268,10 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
     auto Bu = [&](double u) {
         double a0 = 0, a1 = 0;
         static_for<6>([&](auto J) {
-            a0 = fma(Brow[2 * J], bc<2 * J>(u), a0);
-            a1 = fma(Brow[2 * J + 1], bc<2 * J + 1>(u), a1);
+            a0 = fma(brow[2 * J], bc<2 * J>(u), a0);
+            a1 = fma(brow[2 * J + 1], bc<2 * J + 1>(u), a1);
         });
-        return a0 + a1;
+        return wl ? a0 + a1 : 0.0;
     };
 
     const double q2s = act ? P.q2[ci] : 0.0;  // state-lane weight 2 q_i
@@ -385,42 +386,40 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
         }
     }
     const double cinv = 1.0 / csc;
-    double Dinv[H], cg[H];
-#pragma unroll
-    for (int t = 0; t < H; ++t) { Dinv[t] = 1.0 / D[t]; cg[t] = csc * g[t]; }
 
-    // ---------------------------------------------------------------- bounds, row types (auxil.c set_rho_vec)
+    // ---------------------------------------------------------------- hot state of the ADMM loop
+    // The iteration is carried in UNSCALED variables so that the Ruiz factors drop out of the hot loop:
+    //   xh = D x_s (world-frame forces), wh = w_s / E with w_s = z_s + y_s / rho.  OSQP's pair (z, y) is a function
+    //   of w alone after the first iteration:  z = Pi(w),  y = rho (w - z)  (update_z / update_y), and
+    //   w+ = w + alpha (z~ - Pi(w)).  In unscaled variables the projection uses the constant physical bounds, the
+    //   only scaling-dependent per-row datum is rr = E^2 rho_row, and the only per-variable one is sigma D^-2.
+    // Per horizon step and lane: xh, wh0, wh1, rr0, rr1, dI2 (6 doubles) in VGPRs; c*g lives in LDS.
+    double xh[H], wh0[H], wh1[H], rr0[H], rr1[H], dI2[H];
     const double cf = (act && io.contact[quad]) ? 1.0 : 0.0;  // contacts broadcast over the horizon (S/ConvexMpc.cpp:228-245)
     const double lo_u = P.fz_min * cf, hi_u = P.fz_max * cf;
-    unsigned eqmask = 0;  // bit t: my slot-0 row at step t is an equality row (swing leg: l = u = 0)
-#pragma unroll
-    for (int t = 0; t < H; ++t)
-        if (comp == 2 && (E0[t] * hi_u - E0[t] * lo_u < kRhoTol)) eqmask |= 1u << t;
-
-    // ---------------------------------------------------------------- ADMM state
-    double x[H], z0[H], z1[H], y0[H], y1[H];
+    // physical bounds of my two rows: slot 0 = [fx+mu fz >= 0 | fy+mu fz >= 0 | fz in [lo,hi]], slot 1 = [.. <= 0]
+    const double lb0 = comp == 2 ? lo_u : 0.0, ub0 = comp == 2 ? hi_u : kInfty;
+    unsigned eqmask = 0;  // bit t: my slot-0 row at step t is an equality row (swing leg: l = u = 0; auxil.c set_rho_vec)
     double rho = P.rho0;
     const bool warm = P.warm_start && io.warm_x != nullptr && io.warm_y != nullptr;
     if (warm && io.rho_io != nullptr && *io.rho_io > 0.0) rho = *io.rho_io;
     rho = fmin(fmax(rho, kRhoMin), kRhoMax);
-    {
-        // reference row order inside a (step, leg) block: [fx+mu fz, fx-mu fz, fy+mu fz, fy-mu fz, fz]
-        const int r0 = comp == 0 ? 0 : (comp == 1 ? 2 : 4), r1 = comp == 0 ? 1 : 3;
-        static_for<H>([&](auto T) {
-            double xw = 0.0, yw0 = 0.0, yw1 = 0.0;
-            if (warm && act) {
-                xw = io.warm_x[T * 12 + ci];
-                yw0 = io.warm_y[T * 20 + 5 * quad + r0];
-                if (comp < 2) yw1 = io.warm_y[T * 20 + 5 * quad + r1];
-            }
-            const double xz = quad_perm<2, 2, 2, 2>(xw);
-            x[T] = Dinv[T] * xw;                                          // x_s = D^-1 x
-            z0[T] = E0[T] * (comp == 2 ? xw : fma(mu, xz, xw));           // z = A_s x_s
-            z1[T] = E1[T] * fma(-mu, xz, xw);
-            y0[T] = E0[T] > 0.0 ? csc * yw0 / E0[T] : 0.0;                // y_s = c E^-1 y
-            y1[T] = E1[T] > 0.0 ? csc * yw1 / E1[T] : 0.0;
-        });
-    }
+    // reference row order inside a (step, leg) block: [fx+mu fz, fx-mu fz, fy+mu fz, fy-mu fz, fz]
+    const int r0 = comp == 0 ? 0 : (comp == 1 ? 2 : 4), r1 = comp == 0 ? 1 : 3;
+    row_sync();  // the Ruiz D table (aliased into the factor region) is dead from here on
+    static_for<H>([&](auto T) {
+        constexpr int t = A1_CV(T);
+        const bool eq = comp == 2 && (E0[t] * hi_u - E0[t] * lo_u < kRhoTol);
+        if (eq) eqmask |= 1u << t;
+        rr0[t] = E0[t] * E0[t] * (eq ? kRhoEqOverIneq * rho : rho);
+        rr1[t] = E1[t] * E1[t] * rho;
+        const double di = 1.0 / D[t];
+        dI2[t] = di * di;
+        xh[t] = (warm && act) ? io.warm_x[t * 12 + ci] : 0.0;  // x_s = D^-1 x  <=>  xh = x
+        wh0[t] = 0.0; wh1[t] = 0.0;                              // defined by the first iteration
+        if (act) lds[L::CG + t * 12 + ci] = csc * g[t];          // D^-1 q_s = c g
+    });
+    row_sync();
 
     // ---------------------------------------------------------------- Riccati factorisation of
     //   M = c P + sigma D^-2 + A' (E^2 rho) A      (K_s = D M D is OSQP's reduced KKT matrix)
@@ -429,15 +428,14 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
     bool fac_ok = true;
     auto factorize = [&]() {
         ++nfact;
-        const double rho_eq = kRhoEqOverIneq * rho;
+        const double sigma_f = row_opaque(P.sigma);
         // stage W_t = c R + sigma D^-2 + A_t' (E^2 rho) A_t  (block-diagonal, 3x3 per leg) into slot t
         row_sync();
         static_for<H>([&](auto T) {
-            const double rho0 = ((eqmask >> T) & 1u) ? rho_eq : rho;
-            const double a0 = E0[T] * E0[T] * rho0, a1 = E1[T] * E1[T] * rho;
+            const double a0 = rr0[T], a1 = rr1[T];
             const double sp = a0 + a1;
             const double spx = quad_perm<0, 0, 0, 0>(sp), spy = quad_perm<1, 1, 1, 1>(sp);
-            const double base = csc * r2a + P.sigma * Dinv[T] * Dinv[T];
+            const double base = csc * r2a + sigma_f * dI2[T];
             const double wd = comp == 2 ? base + a0 + mu * mu * (spx + spy) : base + sp;
             const double wo = comp < 2 ? mu * (a0 - a1) : 0.0;
             lds[L::FAC + T * L::SLOT + 2 * ln] = act ? wd : 0.0;
@@ -544,47 +542,98 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
         }
     };
 
-    // solve M v = b by the Riccati sweeps (b, v in force layout, all H steps in registers)
-    auto riccati_solve = [&](const double(&b)[H], double(&v)[H]) {
+    // per-lane LDS offsets of my row of the packed symmetric S_t^{-1} and of my row of K_t
+    const int krow = ci * L::KSTR;
+
+    // One ADMM iteration (osqp.c: update_xz_tilde, update_x, update_z, update_y).  The linear system M v = b is
+    // solved by the two Riccati sweeps; the right-hand side is formed inside the backward sweep and the x / w
+    // updates consume v_t inside the forward sweep, so only d_t crosses between the sweeps.
+    // FIRST: OSQP's iteration 1 starts from z0 = A x0 (not projected) and y0 (warm start) or zeros.
+    auto admm_iteration = [&](auto FIRST_) {
+        constexpr bool FIRST = A1_CV(FIRST_);
+        // Loop-invariant scalars are laundered through row_opaque() once per iteration: otherwise LICM hoists every
+        // per-step product that only depends on them out of the ADMM loop and the register file overflows.
+        const double sigma_l = row_opaque(P.sigma), lb0_l = row_opaque(lb0), ub0_l = row_opaque(ub0);
+        const double al = P.alpha, oma = 1.0 - P.alpha;
+        const double muz = comp == 2 ? mu : 0.0, mux = comp < 2 ? mu : 0.0, al1 = comp < 2 ? al : 0.0;  // selects folded into multipliers
         double d[H];
         double pv = 0.0;  // costate p_{t+1}, state layout
         static_for<H>([&](auto TT) {
             constexpr int t = H - 1 - A1_CV(TT);
             const double* slot = lds + L::FAC + t * L::SLOT;
-            const double r = b[t] - BtT(pv);
+            // rhs of update_xz_tilde premultiplied by D^-1:  b = sigma D^-2 xh - c g + A' [E (rho z_s - y_s)]
+            double t0, t1;
+            if constexpr (FIRST) {  // E (rho z_s - y_s) = rr (A x0) - c y0
+                const double xz = quad_perm<2, 2, 2, 2>(xh[t]);
+                double yw0 = 0.0, yw1 = 0.0;
+                if (warm && act) {
+                    yw0 = io.warm_y[t * 20 + 5 * quad + r0];
+                    if (comp < 2) yw1 = io.warm_y[t * 20 + 5 * quad + r1];
+                }
+                t0 = rr0[t] * (comp == 2 ? xh[t] : fma(mu, xz, xh[t])) - csc * yw0;
+                t1 = rr1[t] * fma(-mu, xz, xh[t]) - csc * yw1;
+            } else {                // E (rho z_s - y_s) = rr (2 Pi(wh) - wh)
+                const double z0 = fmin(fmax(wh0[t], lb0_l), ub0_l), z1 = fmin(wh1[t], 0.0);
+                t0 = rr0[t] * fma(2.0, z0, -wh0[t]);
+                t1 = rr1[t] * fma(2.0, z1, -wh1[t]);
+            }
+            const double sm = t0 - t1;
+            const double smx = quad_perm<0, 0, 0, 0>(sm), smy = quad_perm<1, 1, 1, 1>(sm);
+            const double at = fma(muz, smx + smy, t0 + t1);  // fz lanes: t1 == 0 (rr1 == 0); fx/fy lanes: muz == 0
+            const double cgt = lds[L::CG + t * 12 + ci];
+            const double bt = fma(sigma_l * dI2[t], xh[t], at - cgt);
+            const double r = bt - BtT(pv);
             double a0 = 0.0, a1 = 0.0;
             static_for<6>([&](auto J) {
                 constexpr int b0 = 2 * A1_CV(J), b1 = b0 + 1;
-                const double s0 = slot[L::K_SZ + (b0 <= ci ? tri + b0 : b0 * (b0 + 1) / 2 + ci)];
-                const double s1 = slot[L::K_SZ + (b1 <= ci ? tri + b1 : b1 * (b1 + 1) / 2 + ci)];
-                a0 = fma(s0, bc<b0>(r), a0);
-                a1 = fma(s1, bc<b1>(r), a1);
+                a0 = fma(slot[L::K_SZ + (b0 <= ci ? tri + b0 : b0 * (b0 + 1) / 2 + ci)], bc<b0>(r), a0);
+                a1 = fma(slot[L::K_SZ + (b1 <= ci ? tri + b1 : b1 * (b1 + 1) / 2 + ci)], bc<b1>(r), a1);
             });
-            d[t] = act ? a0 + a1 : 0.0;
+            d[t] = a0 + a1;
             if constexpr (t > 0) {
                 double c0 = opAT(pv), c1 = 0.0;
                 static_for<6>([&](auto J) {
                     c0 = fma(slot[(2 * J) * L::KSTR + ci], bc<2 * J>(r), c0);
                     c1 = fma(slot[(2 * J + 1) * L::KSTR + ci], bc<2 * J + 1>(r), c1);
                 });
-                pv = act ? c0 + c1 : 0.0;
+                pv = c0 + c1;
             }
         });
         double s = 0.0;  // state x_t of the LQ roll-out (x_0 = 0)
         static_for<H>([&](auto T) {
-            const double* slot = lds + L::FAC + T * L::SLOT;
-            double u = d[T];
-            if constexpr (T > 0) {
+            constexpr int t = A1_CV(T);
+            const double* slot = lds + L::FAC + t * L::SLOT;
+            double v = d[t];
+            if constexpr (t > 0) {
                 double a0 = 0.0, a1 = 0.0;
                 static_for<6>([&](auto J) {
-                    a0 = fma(slot[ci * L::KSTR + 2 * J], bc<2 * J>(s), a0);
-                    a1 = fma(slot[ci * L::KSTR + 2 * J + 1], bc<2 * J + 1>(s), a1);
+                    a0 = fma(slot[krow + 2 * J], bc<2 * J>(s), a0);
+                    a1 = fma(slot[krow + 2 * J + 1], bc<2 * J + 1>(s), a1);
                 });
-                u -= a0 + a1;
+                v -= a0 + a1;
             }
-            u = act ? u : 0.0;
-            v[T] = u;
-            if constexpr (T < H - 1) s = opA(s) + Bu(u);
+            v = act ? v : 0.0;  // pad lanes carry no force
+            if constexpr (t < H - 1) s = opA(s) + Bu(v);
+            // z~ = A v (unscaled), then update_x / update_z / update_y in the w form
+            const double vz = quad_perm<2, 2, 2, 2>(v);
+            const double av0 = fma(mux, vz, v);
+            const double av1 = fma(-mux, vz, v);
+            if constexpr (FIRST) {  // w1 = alpha z~ + (1 - alpha) z0 + y0 / rho,  z0 = A x0
+                const double xz = quad_perm<2, 2, 2, 2>(xh[t]);
+                double yw0 = 0.0, yw1 = 0.0;
+                if (warm && act) {
+                    yw0 = io.warm_y[t * 20 + 5 * quad + r0];
+                    if (comp < 2) yw1 = io.warm_y[t * 20 + 5 * quad + r1];
+                }
+                const double z00 = comp == 2 ? xh[t] : fma(mu, xz, xh[t]), z01 = fma(-mu, xz, xh[t]);
+                wh0[t] = al * av0 + oma * z00 + (rr0[t] > 0.0 ? csc * yw0 / rr0[t] : 0.0);
+                wh1[t] = comp < 2 ? al * av1 + oma * z01 + (rr1[t] > 0.0 ? csc * yw1 / rr1[t] : 0.0) : 0.0;
+            } else {                // w+ = w + alpha (z~ - Pi(w))
+                const double z0 = fmin(fmax(wh0[t], lb0_l), ub0_l), z1 = fmin(wh1[t], 0.0);
+                wh0[t] = fma(al, av0 - z0, wh0[t]);
+                wh1[t] = fma(al1, av1 - z1, wh1[t]);  // stays 0 on fz lanes
+            }
+            xh[t] = al * v + oma * xh[t];
         });
     };
 
@@ -594,52 +643,56 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
         double s_pri, s_dua, s_z, s_Ax, s_q, s_Aty, s_Px;      // scaled (rho estimate)
     } info;
     auto update_info = [&]() {
-        double u[H], Pu[H];
-#pragma unroll
-        for (int t = 0; t < H; ++t) u[t] = D[t] * x[t];
+        const double rho_c = row_opaque(rho), one_c = row_opaque(1.0);  // keep the cold path's invariants out of the hot loop's registers
+        double Pu[H];
         {   // P u = B_qp' Q (B_qp u) + R u : roll-out, then adjoint
             double sv[H];
             double s = 0.0;
             static_for<H>([&](auto T) {
-                s = opA(s) + Bu(u[T]);
+                s = opA(s) + Bu(xh[T]);
                 sv[T] = q2s * s;
             });
             double lam = 0.0;
             static_for<H>([&](auto TT) {
                 constexpr int t = H - 1 - A1_CV(TT);
                 lam = sv[t] + opAT(lam);
-                Pu[t] = fma(r2a, u[t], BtT(lam));
+                Pu[t] = fma(r2a, xh[t], BtT(lam));
             });
         }
         double m_pri = 0, m_upri = 0, m_z = 0, m_uz = 0, m_Ax = 0, m_uAx = 0;
         double m_dua = 0, m_udua = 0, m_q = 0, m_uq = 0, m_Aty = 0, m_uAty = 0, m_Px = 0, m_uPx = 0;
         static_for<H>([&](auto T) {
-            const double uz = quad_perm<2, 2, 2, 2>(u[T]);
-            const double ax0 = E0[T] * (comp == 2 ? u[T] : fma(mu, uz, u[T]));
-            const double ax1 = E1[T] * fma(-mu, uz, u[T]);
-            const double ie0 = E0[T] > 0.0 ? 1.0 / E0[T] : 0.0, ie1 = E1[T] > 0.0 ? 1.0 / E1[T] : 0.0;
-            const double rp0 = ax0 - z0[T], rp1 = ax1 - z1[T];
-            m_pri = fmax(m_pri, fmax(fabs(rp0), fabs(rp1)));
-            m_upri = fmax(m_upri, fmax(fabs(ie0 * rp0), fabs(ie1 * rp1)));
-            m_z = fmax(m_z, fmax(fabs(z0[T]), fabs(z1[T])));
-            m_uz = fmax(m_uz, fmax(fabs(ie0 * z0[T]), fabs(ie1 * z1[T])));
-            m_Ax = fmax(m_Ax, fmax(fabs(ax0), fabs(ax1)));
-            m_uAx = fmax(m_uAx, fmax(fabs(ie0 * ax0), fabs(ie1 * ax1)));
-            // A_s' y = D A' (E y)
-            const double w0 = E0[T] * y0[T], w1 = E1[T] * y1[T];
+            constexpr int t = A1_CV(T);
+            const double uz = quad_perm<2, 2, 2, 2>(xh[t]);
+            const double ax0 = comp == 2 ? xh[t] : fma(mu, uz, xh[t]);  // E^-1 (A_s x)
+            const double ax1 = comp < 2 ? fma(-mu, uz, xh[t]) : 0.0;
+            const double z0 = fmin(fmax(wh0[t], lb0), ub0), z1 = fmin(wh1[t], 0.0);  // E^-1 z
+            const double rp0 = ax0 - z0, rp1 = ax1 - z1;
+            const bool eq = (eqmask >> t) & 1u;
+            const double e0 = sqrt(rr0[t] / (eq ? kRhoEqOverIneq * rho_c : rho_c)), e1 = sqrt(rr1[t] / rho_c);  // E
+            m_upri = fmax(m_upri, fmax(fabs(rp0), fabs(rp1)));
+            m_pri = fmax(m_pri, fmax(fabs(e0 * rp0), fabs(e1 * rp1)));
+            m_uz = fmax(m_uz, fmax(fabs(z0), fabs(z1)));
+            m_z = fmax(m_z, fmax(fabs(e0 * z0), fabs(e1 * z1)));
+            m_uAx = fmax(m_uAx, fmax(fabs(ax0), fabs(ax1)));
+            m_Ax = fmax(m_Ax, fmax(fabs(e0 * ax0), fabs(e1 * ax1)));
+            // D^-1 (A_s' y_s) = A' (E y_s) = A' [rr (wh - Pi(wh))]
+            const double w0 = rr0[t] * (wh0[t] - z0), w1 = rr1[t] * (wh1[t] - z1);
             const double sm = w0 - w1;
             const double smx = quad_perm<0, 0, 0, 0>(sm), smy = quad_perm<1, 1, 1, 1>(sm);
-            const double aty_u = comp == 2 ? fma(mu, smx + smy, w0) : w0 + w1;  // = D^-1 (A_s' y)
-            const double px_u = csc * Pu[T];                                    // = D^-1 (P_s x)
-            const double rd_u = px_u + cg[T] + aty_u;                           // = D^-1 (P_s x + q_s + A_s' y)
+            const double aty_u = comp == 2 ? fma(mu, smx + smy, w0) : w0 + w1;
+            const double cgt = act ? lds[L::CG + t * 12 + ci] : 0.0;
+            const double px_u = csc * Pu[t];        // = D^-1 (P_s x_s)
+            const double rd_u = px_u + cgt + aty_u;  // = D^-1 (P_s x_s + q_s + A_s' y_s)
+            const double Dd = one_c / sqrt(dI2[t]);
             m_udua = fmax(m_udua, fabs(rd_u));
-            m_dua = fmax(m_dua, fabs(D[T] * rd_u));
-            m_uq = fmax(m_uq, fabs(cg[T]));
-            m_q = fmax(m_q, fabs(D[T] * cg[T]));
+            m_dua = fmax(m_dua, fabs(Dd * rd_u));
+            m_uq = fmax(m_uq, fabs(cgt));
+            m_q = fmax(m_q, fabs(Dd * cgt));
             m_uAty = fmax(m_uAty, fabs(aty_u));
-            m_Aty = fmax(m_Aty, fabs(D[T] * aty_u));
+            m_Aty = fmax(m_Aty, fabs(Dd * aty_u));
             m_uPx = fmax(m_uPx, fabs(px_u));
-            m_Px = fmax(m_Px, fabs(D[T] * px_u));
+            m_Px = fmax(m_Px, fabs(Dd * px_u));
         });
         info.pri_res = row_allmax(act ? m_upri : 0.0);
         info.nEz = row_allmax(act ? m_uz : 0.0);
@@ -670,100 +723,85 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
     };
 
     // ---------------------------------------------------------------- ADMM loop (osqp.c osqp_solve)
+    // Segment structure: the hot loop is a plain counted loop of admm_iteration() up to the next checkpoint
+    // (a multiple of check_termination / adaptive_rho_interval, or max_iter); the residual check, the rho
+    // update and the (rare) re-factorisation run between segments.  Every loop leaves through its latch only:
+    // rows of one wave finish at different iterations, and a divergent exit from the middle of a body would
+    // make the compiler copy every live-out vector on every iteration.
     int iter = 0;
-    bool need_factor = true;
-    while (true) {
+    bool done = false, need_factor = true;
+    do {
         if (need_factor) {
             factorize();
             need_factor = false;
-            if (!fac_ok) { status = A1MPC_NON_CVX; break; }
+            if (!fac_ok) { status = A1MPC_NON_CVX; done = true; }
         }
-        ++iter;
-        {
-            const double rho_eq = kRhoEqOverIneq * rho;
-            const double rinv = 1.0 / rho, rinv_eq = 1.0 / rho_eq;
-            double b[H], v[H];
-            static_for<H>([&](auto T) {  // rhs of update_xz_tilde, premultiplied by D^-1
-                const bool eq = (eqmask >> T) & 1u;
-                const double rho0 = eq ? rho_eq : rho, ri0 = eq ? rinv_eq : rinv;
-                const double w0 = E0[T] * (rho0 * (z0[T] - ri0 * y0[T]));
-                const double w1 = E1[T] * (rho * (z1[T] - rinv * y1[T]));
-                const double sm = w0 - w1;
-                const double smx = quad_perm<0, 0, 0, 0>(sm), smy = quad_perm<1, 1, 1, 1>(sm);
-                const double at = comp == 2 ? fma(mu, smx + smy, w0) : w0 + w1;
-                b[T] = act ? fma(P.sigma * Dinv[T], x[T], at - cg[T]) : 0.0;
-            });
-            riccati_solve(b, v);
-            const double al = P.alpha, oma = 1.0 - P.alpha;
-            static_for<H>([&](auto T) {  // update_x, update_z, update_y
-                const bool eq = (eqmask >> T) & 1u;
-                const double rho0 = eq ? rho_eq : rho, ri0 = eq ? rinv_eq : rinv;
-                const double vz = quad_perm<2, 2, 2, 2>(v[T]);
-                const double zt0 = E0[T] * (comp == 2 ? v[T] : fma(mu, vz, v[T]));
-                const double zt1 = E1[T] * fma(-mu, vz, v[T]);
-                x[T] = al * (Dinv[T] * v[T]) + oma * x[T];
-                const double l0 = comp == 2 ? E0[T] * lo_u : 0.0;
-                const double u0 = comp == 2 ? E0[T] * hi_u : kInfty * E0[T];
-                const double zr0 = al * zt0 + oma * z0[T];
-                const double zn0 = fmin(fmax(zr0 + ri0 * y0[T], l0), u0);
-                y0[T] += rho0 * (zr0 - zn0);
-                z0[T] = zn0;
-                const double zr1 = al * zt1 + oma * z1[T];
-                const double zn1 = fmin(fmax(zr1 + rinv * y1[T], -kInfty * E1[T]), 0.0);
-                y1[T] += rho * (zr1 - zn1);
-                z1[T] = zn1;
-            });
-        }
-        const bool can_check = P.check_every > 0 && (iter % P.check_every) == 0;
-        const bool do_rho = P.adaptive_rho && P.adaptive_rho_every > 0 && (iter % P.adaptive_rho_every) == 0;
-        const bool last = iter >= P.max_iter;
-        if (can_check || do_rho || last) {
+        if (!done) {
+            int next = P.max_iter;
+            if (P.check_every > 0) next = imin(next, (iter / P.check_every + 1) * P.check_every);
+            if (P.adaptive_rho && P.adaptive_rho_every > 0) next = imin(next, (iter / P.adaptive_rho_every + 1) * P.adaptive_rho_every);
+            if (iter == 0) { admm_iteration(std::true_type{}); iter = 1; }
+            for (int k = iter; k < next; ++k) admm_iteration(std::false_type{});
+            iter = next;
+            const bool can_check = P.check_every > 0 && (iter % P.check_every) == 0;
+            const bool do_rho = P.adaptive_rho && P.adaptive_rho_every > 0 && (iter % P.adaptive_rho_every) == 0;
+            const bool last = iter >= P.max_iter;
             update_info();
-            if (can_check && check_termination(false)) break;
-            if (do_rho) {  // auxil.c compute_rho_estimate / adapt_rho
-                const double pr = info.s_pri / (fmax(info.s_z, info.s_Ax) + 1e-10);
-                const double dr = info.s_dua / (fmax(fmax(info.s_q, info.s_Aty), info.s_Px) + 1e-10);
-                const double rn = fmin(fmax(rho * sqrt(pr / (dr + 1e-10)), kRhoMin), kRhoMax);
-                if (rn > rho * P.adaptive_rho_tol || rn < rho / P.adaptive_rho_tol) {
-                    rho = rn;
-                    need_factor = true;
+            if (can_check && check_termination(false)) {
+                done = true;
+            } else {
+                if (do_rho) {  // auxil.c compute_rho_estimate / adapt_rho
+                    const double pr = info.s_pri / (fmax(info.s_z, info.s_Ax) + 1e-10);
+                    const double dr = info.s_dua / (fmax(fmax(info.s_q, info.s_Aty), info.s_Px) + 1e-10);
+                    const double rn = fmin(fmax(rho * sqrt(pr / (dr + 1e-10)), kRhoMin), kRhoMax);
+                    if (rn > rho * P.adaptive_rho_tol || rn < rho / P.adaptive_rho_tol) {
+                        // y_s = rho E (wh - zh) is kept:  wh <- zh + (rho_old / rho_new) (wh - zh),  rr <- rr rho_new / rho_old
+                        const double up = rn / rho, dn = rho / rn;
+                        static_for<H>([&](auto T) {
+                            const double z0 = fmin(fmax(wh0[T], lb0), ub0), z1 = fmin(wh1[T], 0.0);
+                            wh0[T] = fma(dn, wh0[T] - z0, z0);
+                            wh1[T] = fma(dn, wh1[T] - z1, z1);
+                            rr0[T] *= up;
+                            rr1[T] *= up;
+                        });
+                        rho = rn;
+                        need_factor = true;
+                    }
+                }
+                if (last) {
+                    if (!(!can_check && check_termination(false)) && !check_termination(true)) status = A1MPC_MAX_ITER_REACHED;
+                    if (need_factor) ++nfact;  // the reference refactors before it notices the iteration limit
+                    done = true;
                 }
             }
-            if (last) {
-                if (!can_check && check_termination(false)) break;
-                if (!check_termination(true)) status = A1MPC_MAX_ITER_REACHED;
-                if (need_factor) ++nfact;  // the reference refactors before it notices the iteration limit
-                break;
-            }
         }
-    }
+    } while (!done);
 
     // ---------------------------------------------------------------- store_solution + first-step GRFs in the body frame
     const bool nanout = status == A1MPC_NON_CVX;
     const double nanv = nan("");
     {
-        const double f = nanout ? nanv : D[0] * x[0];
+        const double f = nanout ? nanv : xh[0];
         const double f0 = quad_perm<0, 0, 0, 0>(f), f1 = quad_perm<1, 1, 1, 1>(f), f2 = quad_perm<2, 2, 2, 2>(f);
         const bool bad = (f0 != f0) || (f1 != f1) || (f2 != f2);
         if (act) {  // R' f (S/A1RobotControl.cpp:558-561); non-finite solution -> zeros + status
-            const double gb = Rm[0 * 3 + comp] * f0 + Rm[1 * 3 + comp] * f1 + Rm[2 * 3 + comp] * f2;
+            const double gb = io.R[0 * 3 + comp] * f0 + io.R[1 * 3 + comp] * f1 + io.R[2 * 3 + comp] * f2;
             io.grf[3 * quad + comp] = bad ? 0.0 : gb;
         }
     }
-    {
-        const int r0 = comp == 0 ? 0 : (comp == 1 ? 2 : 4), r1 = comp == 0 ? 1 : 3;
-        static_for<H>([&](auto T) {
-            if (act) {
-                const double xu = nanout ? nanv : D[T] * x[T];
-                if (io.u_full) io.u_full[T * 12 + ci] = xu;
-                if (io.warm_x) io.warm_x[T * 12 + ci] = xu;
-                if (io.warm_y) {
-                    io.warm_y[T * 20 + 5 * quad + r0] = nanout ? nanv : cinv * E0[T] * y0[T];
-                    if (comp < 2) io.warm_y[T * 20 + 5 * quad + r1] = nanout ? nanv : cinv * E1[T] * y1[T];
-                }
+    static_for<H>([&](auto T) {
+        constexpr int t = A1_CV(T);
+        if (act) {
+            const double xu = nanout ? nanv : xh[t];
+            if (io.u_full) io.u_full[t * 12 + ci] = xu;
+            if (io.warm_x) io.warm_x[t * 12 + ci] = xu;
+            if (io.warm_y) {  // y = c^-1 E y_s = c^-1 rr (wh - Pi(wh))
+                const double z0 = fmin(fmax(wh0[t], lb0), ub0), z1 = fmin(wh1[t], 0.0);
+                io.warm_y[t * 20 + 5 * quad + r0] = nanout ? nanv : cinv * rr0[t] * (wh0[t] - z0);
+                if (comp < 2) io.warm_y[t * 20 + 5 * quad + r1] = nanout ? nanv : cinv * rr1[t] * (wh1[t] - z1);
             }
-        });
-    }
+        }
+    });
     if (ln == 0) {
         if (io.iters) *io.iters = iter;
         if (io.status) *io.status = status;

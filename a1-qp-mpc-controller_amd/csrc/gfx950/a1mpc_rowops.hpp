@@ -24,16 +24,16 @@ A1_DEV int row_lane() { return static_cast<int>(threadIdx.x) & 15; }
 template <int L>
 A1_DEV double row_bcast(double v) {
     static_assert(L >= 0 && L < 16, "lane");
-    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + L, 0xF, 0xF, false);  // row_newbcast:L
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + L, 0xF, 0xF, true);  // row_newbcast:L (bound_ctrl: no `old` operand to initialise)
 }
 template <int N>
 A1_DEV double row_ror(double v) {
     static_assert(N >= 1 && N < 16, "rot");
-    return __builtin_amdgcn_update_dpp(0.0, v, 0x120 + N, 0xF, 0xF, false);  // row_ror:N
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x120 + N, 0xF, 0xF, true);  // row_ror:N
 }
 template <int P0, int P1, int P2, int P3>
 A1_DEV double quad_perm(double v) {
-    return __builtin_amdgcn_update_dpp(0.0, v, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(0.0, v, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, true);
 }
 
 // Orders LDS traffic between the lanes of a row.  All lanes of a row are in one wavefront and the
@@ -43,6 +43,13 @@ A1_DEV void row_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
+// Optimisation barrier: the value becomes opaque to the compiler (no code is emitted).
+A1_DEV double row_opaque(double v) {
+    asm volatile("" : "+v"(v));
+    return v;
 }
 
 }  // namespace a1mpc

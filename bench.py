@@ -36,13 +36,18 @@ def cpu_baseline(pkg, sc, budget_s=15.0):
     st = oracle.default_settings()
     cores = oracle.num_threads()
     take = lambda n: (sc["x0"][:n], sc["xref"][:n], sc["R"][:n], sc["foot"][:n], sc["contact"][:n])
-    n0 = min(8 * cores, len(sc["x0"]))
+    nb = len(sc["x0"])
+    n0 = min(8 * cores, nb)
     t = time.perf_counter(); oracle.mpc_solve_batch(pr, st, *take(n0), nthreads=cores); t0 = time.perf_counter() - t
-    n = int(max(n0, min(len(sc["x0"]), budget_s / max(t0 / n0, 1e-9))))
-    t = time.perf_counter(); r = oracle.mpc_solve_batch(pr, st, *take(n), nthreads=cores); t1 = time.perf_counter() - t
+    reps = int(max(1, min(64, budget_s / max(t0 / n0 * nb, 1e-9))))  # whole passes over the workload, ~budget_s of CPU time
+    t = time.perf_counter()
+    for _ in range(reps):
+        r = oracle.mpc_solve_batch(pr, st, *take(nb), nthreads=cores)
+    t1 = time.perf_counter() - t
+    n = reps * nb
     t = time.perf_counter(); oracle.mpc_solve_batch(pr, st, *take(min(n, 64)), nthreads=1); ts = (time.perf_counter() - t) / min(n, 64)
     return {"value": n / t1, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} QPs of the same workload (config3, h=10), OpenMP static over {cores} threads, {t1:.1f} s; "
+            "sample": f"{reps} pass(es) over the same {nb} QPs (config3, h=10) = {n} solves, OpenMP static over {cores} threads, {t1:.1f} s; "
                       f"single-thread {1.0 / ts:.1f} solves/s; real OSQP/Eigen are not installable here (oracle/ restates them)",
             "mean_iters": float(r["iters"].mean())}, r
 
@@ -99,7 +104,8 @@ def main():
     grf = torch.zeros((n, 12), dtype=torch.float64, device=dev)
     iters = torch.zeros(n, dtype=torch.int32, device=dev); status = torch.zeros(n, dtype=torch.int32, device=dev)
     eng = pkg.Engine(cfg, n, local)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream: kernels and the timing events share it
+    torch.cuda.synchronize()
 
     def step():
         eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, iters, status, stream=stream.cuda_stream)

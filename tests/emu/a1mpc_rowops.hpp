@@ -30,4 +30,7 @@ inline double quad_perm(double v) {
 }
 inline void row_sync() { (void)emu_publish(0.0); }
 
+
+inline double row_opaque(double v) { return v; }
+
 }  // namespace a1mpc
