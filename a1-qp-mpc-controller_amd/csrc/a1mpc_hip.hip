@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -34,13 +35,13 @@ struct KernelArgs {
     int32_t *iters, *status, *nfact;
 };
 
-constexpr int kRowsPerWg = 4, kThreads = 64;
 
-template <int H, int MODE>
-__global__ __launch_bounds__(kThreads) void a1mpc_solve_kernel(const KernelArgs a) {
+// ROWS = QPs (DPP rows) per workgroup; the workgroup is one wavefront with 16*ROWS live lanes.
+template <int H, int MODE, int ROWS>
+__global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     const int row = static_cast<int>(threadIdx.x) >> 4;
-    const int64_t b = static_cast<int64_t>(blockIdx.x) * kRowsPerWg + row;
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
     if (b >= a.n) return;  // row-uniform: the other rows of the wave keep all their DPP sources
     ProblemIO io;
     io.root_acc = MODE == kModeBalance ? a.root_acc + b * 6 : nullptr;
@@ -62,7 +63,19 @@ __global__ __launch_bounds__(kThreads) void a1mpc_solve_kernel(const KernelArgs 
 }
 
 template <int H>
-constexpr size_t lds_bytes() { return sizeof(double) * kRowsPerWg * Layout<H>::ROW_STRIDE; }
+constexpr size_t lds_bytes(int rows) { return sizeof(double) * rows * Layout<H>::ROW_STRIDE; }
+
+// QPs per wavefront.  Rows of one wave run in lock-step until the slowest row has converged, so fewer rows per wave
+// waste fewer cycles on iteration-count divergence; LDS (not wave slots) bounds residency either way (8 QPs per CU
+// at H = 10).  Overridable for experiments with A1MPC_ROWS_PER_WG = 1 | 2 | 4.
+static int rows_per_wg() {
+    static int r = [] {
+        const char* e = getenv("A1MPC_ROWS_PER_WG");
+        const int v = e ? atoi(e) : 0;
+        return (v == 1 || v == 2 || v == 4) ? v : 4;
+    }();
+    return r;
+}
 
 thread_local std::string g_last_error;
 static a1mpc_status fail(a1mpc_status s, const std::string& msg) { g_last_error = msg; return s; }
@@ -72,20 +85,28 @@ static a1mpc_status fail(a1mpc_status s, const std::string& msg) { g_last_error 
         if (e_ != hipSuccess) return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-template <int H, int MODE>
-static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
+template <int H, int MODE, int ROWS>
+static a1mpc_status launch_rows(const KernelArgs& a, hipStream_t stream) {
     static bool attr_set[64] = {};
     int dev = 0;
     A1_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes<H>())));
+        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE, ROWS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes<H>(ROWS))));
         attr_set[dev] = true;
     }
-    const unsigned grid = static_cast<unsigned>((a.n + kRowsPerWg - 1) / kRowsPerWg);
-    hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE>), dim3(grid), dim3(kThreads), lds_bytes<H>(), stream, a);
+    const unsigned grid = static_cast<unsigned>((a.n + ROWS - 1) / ROWS);
+    hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE, ROWS>), dim3(grid), dim3(16 * ROWS), lds_bytes<H>(ROWS), stream, a);
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
+}
+template <int H, int MODE>
+static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
+    switch (rows_per_wg()) {
+        case 1: return launch_rows<H, MODE, 1>(a, stream);
+        case 2: return launch_rows<H, MODE, 2>(a, stream);
+    }
+    return launch_rows<H, MODE, 4>(a, stream);
 }
 
 static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, hipStream_t s) {
@@ -98,11 +119,12 @@ static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, hipStream_t s) 
     return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be 1, 10, 16 or 20");
 }
 static size_t lds_bytes_of(int horizon) {
+    const int r = rows_per_wg();
     switch (horizon) {
-        case 1: return lds_bytes<1>();
-        case 10: return lds_bytes<10>();
-        case 16: return lds_bytes<16>();
-        case 20: return lds_bytes<20>();
+        case 1: return lds_bytes<1>(r);
+        case 10: return lds_bytes<10>(r);
+        case 16: return lds_bytes<16>(r);
+        case 20: return lds_bytes<20>(r);
     }
     return 0;
 }
@@ -404,8 +426,8 @@ a1mpc_status a1mpc_kernel_info(a1mpc_handle h, int32_t* lds_bytes_per_workgroup,
                                int32_t* threads_per_workgroup) {
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
     if (lds_bytes_per_workgroup) *lds_bytes_per_workgroup = static_cast<int32_t>(lds_bytes_of(h->cfg.horizon));
-    if (qps_per_workgroup) *qps_per_workgroup = kRowsPerWg;
-    if (threads_per_workgroup) *threads_per_workgroup = kThreads;
+    if (qps_per_workgroup) *qps_per_workgroup = rows_per_wg();
+    if (threads_per_workgroup) *threads_per_workgroup = 16 * rows_per_wg();
     return A1MPC_OK;
 }
 

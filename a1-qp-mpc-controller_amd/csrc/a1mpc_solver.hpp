@@ -92,6 +92,10 @@ template <int J>
 A1_DEV double bc(double v) {
     return row_bcast<lane_of(J)>(v);
 }
+template <int J>
+A1_DEV void fbc(double& acc, double m, double x) {  // acc += m * x[compact index J]; x must be row_dpp_ready()
+    fma_bcast<lane_of(J)>(acc, m, x);
+}
 constexpr int alpha_diag(int s, int H) {  // sum_{i=s}^{H-1} (i-s)^2
     int a = 0;
     for (int i = s; i < H; ++i) a += (i - s) * (i - s);
@@ -250,26 +254,33 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
     const double gC = ln == 10 ? dt : 0.0;
     const double gV = (quad == 3 && act) ? dt : 0.0;
     auto opA = [&](double s) {  // (A_d s): rpy += dt*T*omega, pos += dt*vel
-        return s + fA * row_bcast<8>(s) + fB * row_bcast<9>(s) + fC * row_bcast<10>(s) + fP * row_ror<8>(s);
+        s = row_dpp_ready(s);
+        double a0 = s, a1 = fP * row_ror<8>(s);
+        fma_bcast<8>(a0, fA, s); fma_bcast<9>(a1, fB, s); fma_bcast<10>(a0, fC, s);
+        return a0 + a1;
     };
     auto opAT = [&](double p) {  // (A_d' p): omega += dt*T'*rpy-part, vel += dt*pos-part
-        return p + gA * row_bcast<0>(p) + gB * row_bcast<1>(p) + gC * row_bcast<2>(p) + gV * row_ror<8>(p);
+        p = row_dpp_ready(p);
+        double a0 = p, a1 = gV * row_ror<8>(p);
+        fma_bcast<0>(a0, gA, p); fma_bcast<1>(a1, gB, p); fma_bcast<2>(a0, gC, p);
+        return a0 + a1;
     };
     // adjoint of the roll-out: (B~' lambda_{omega,v}) in force layout
     auto BtT = [&](double lam) {
-        double a0 = Bt[0] * bc<6>(lam), a1 = Bt[1] * bc<7>(lam);
-        a0 = fma(Bt[2], bc<8>(lam), a0);
-        a1 = fma(Bt[3], bc<9>(lam), a1);
-        a0 = fma(Bt[4], bc<10>(lam), a0);
-        a1 = fma(Bt[5], bc<11>(lam), a1);
+        lam = row_dpp_ready(lam);
+        double a0 = 0.0, a1 = 0.0;
+        fbc<6>(a0, Bt[0], lam); fbc<7>(a1, Bt[1], lam);
+        fbc<8>(a0, Bt[2], lam); fbc<9>(a1, Bt[3], lam);
+        fbc<10>(a0, Bt[4], lam); fbc<11>(a1, Bt[5], lam);
         return a0 + a1;
     };
     // (B~ u) scattered into the wrench lanes of a state-layout vector
     auto Bu = [&](double u) {
+        u = row_dpp_ready(u);
         double a0 = 0, a1 = 0;
         static_for<6>([&](auto J) {
-            a0 = fma(brow[2 * J], bc<2 * J>(u), a0);
-            a1 = fma(brow[2 * J + 1], bc<2 * J + 1>(u), a1);
+            fbc<2 * J>(a0, brow[2 * J], u);
+            fbc<2 * J + 1>(a1, brow[2 * J + 1], u);
         });
         return wl ? a0 + a1 : 0.0;
     };
@@ -561,6 +572,14 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
         static_for<H>([&](auto TT) {
             constexpr int t = H - 1 - A1_CV(TT);
             const double* slot = lds + L::FAC + t * L::SLOT;
+            // issue this step's LDS reads first: their latency overlaps the right-hand-side arithmetic below
+            double Sr[12], Kc[12];
+            static_for<12>([&](auto B) {
+                constexpr int b = A1_CV(B);
+                Sr[b] = slot[L::K_SZ + (b <= ci ? tri + b : b * (b + 1) / 2 + ci)];
+                if constexpr (t > 0) Kc[b] = slot[b * L::KSTR + ci];
+            });
+            const double cgt = lds[L::CG + t * 12 + ci];
             // rhs of update_xz_tilde premultiplied by D^-1:  b = sigma D^-2 xh - c g + A' [E (rho z_s - y_s)]
             double t0, t1;
             if constexpr (FIRST) {  // E (rho z_s - y_s) = rr (A x0) - c y0
@@ -580,21 +599,20 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
             const double sm = t0 - t1;
             const double smx = quad_perm<0, 0, 0, 0>(sm), smy = quad_perm<1, 1, 1, 1>(sm);
             const double at = fma(muz, smx + smy, t0 + t1);  // fz lanes: t1 == 0 (rr1 == 0); fx/fy lanes: muz == 0
-            const double cgt = lds[L::CG + t * 12 + ci];
             const double bt = fma(sigma_l * dI2[t], xh[t], at - cgt);
-            const double r = bt - BtT(pv);
+            const double r = row_dpp_ready(bt - BtT(pv));
             double a0 = 0.0, a1 = 0.0;
             static_for<6>([&](auto J) {
                 constexpr int b0 = 2 * A1_CV(J), b1 = b0 + 1;
-                a0 = fma(slot[L::K_SZ + (b0 <= ci ? tri + b0 : b0 * (b0 + 1) / 2 + ci)], bc<b0>(r), a0);
-                a1 = fma(slot[L::K_SZ + (b1 <= ci ? tri + b1 : b1 * (b1 + 1) / 2 + ci)], bc<b1>(r), a1);
+                fbc<b0>(a0, Sr[b0], r);
+                fbc<b1>(a1, Sr[b1], r);
             });
             d[t] = a0 + a1;
             if constexpr (t > 0) {
                 double c0 = opAT(pv), c1 = 0.0;
                 static_for<6>([&](auto J) {
-                    c0 = fma(slot[(2 * J) * L::KSTR + ci], bc<2 * J>(r), c0);
-                    c1 = fma(slot[(2 * J + 1) * L::KSTR + ci], bc<2 * J + 1>(r), c1);
+                    fbc<2 * J>(c0, Kc[2 * J], r);
+                    fbc<2 * J + 1>(c1, Kc[2 * J + 1], r);
                 });
                 pv = c0 + c1;
             }
@@ -603,17 +621,32 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
             const double* slot = lds + L::FAC + t * L::SLOT;
+            // issue this step's LDS reads first (K_t row, my B~ row): they overlap the previous step's w / xh update
+            double Kr[12], Br[12];
+            static_for<12>([&](auto B) {
+                constexpr int b = A1_CV(B);
+                if constexpr (t > 0) Kr[b] = slot[krow + b];
+                if constexpr (t < H - 1) Br[b] = brow[b];
+            });
             double v = d[t];
             if constexpr (t > 0) {
                 double a0 = 0.0, a1 = 0.0;
                 static_for<6>([&](auto J) {
-                    a0 = fma(slot[krow + 2 * J], bc<2 * J>(s), a0);
-                    a1 = fma(slot[krow + 2 * J + 1], bc<2 * J + 1>(s), a1);
+                    fbc<2 * J>(a0, Kr[2 * J], s);
+                    fbc<2 * J + 1>(a1, Kr[2 * J + 1], s);
                 });
                 v -= a0 + a1;
             }
             v = act ? v : 0.0;  // pad lanes carry no force
-            if constexpr (t < H - 1) s = opA(s) + Bu(v);
+            if constexpr (t < H - 1) {
+                const double vr = row_dpp_ready(v);
+                double a0 = 0.0, a1 = 0.0;
+                static_for<6>([&](auto J) {
+                    fbc<2 * J>(a0, Br[2 * J], vr);
+                    fbc<2 * J + 1>(a1, Br[2 * J + 1], vr);
+                });
+                s = row_dpp_ready(opA(s) + (wl ? a0 + a1 : 0.0));
+            }
             // z~ = A v (unscaled), then update_x / update_z / update_y in the w form
             const double vz = quad_perm<2, 2, 2, 2>(v);
             const double av0 = fma(mux, vz, v);

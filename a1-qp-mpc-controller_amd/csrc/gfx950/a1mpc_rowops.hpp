@@ -46,6 +46,21 @@ A1_DEV void row_sync() {
 }
 
 
+// acc += m * (lane L of my row's x) as ONE instruction: v_fmac_f64 with a DPP row_newbcast source (gfx90a+: DP-ALU
+// DPP supports exactly this control).  hipcc emits v_mov_b64_dpp + v_fmac_f64 for the intrinsic form and does not
+// combine them, which doubles the instruction count and the dependency depth of every 12x12 mat-vec.
+// Hazard contract (hipcc pads nothing inside asm): a VGPR written by a VALU instruction needs 2 wait states before
+// a DPP instruction reads it -- pass x through row_dpp_ready() once after computing it and before its first fma_bcast.
+template <int L>
+A1_DEV void fma_bcast(double& acc, double m, double x) {
+    static_assert(L >= 0 && L < 16, "lane");
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(L));
+}
+A1_DEV double row_dpp_ready(double x) {
+    asm volatile("s_nop 1" : "+v"(x));
+    return x;
+}
+
 // Optimisation barrier: the value becomes opaque to the compiler (no code is emitted).
 A1_DEV double row_opaque(double v) {
     asm volatile("" : "+v"(v));

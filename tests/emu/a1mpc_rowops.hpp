@@ -28,6 +28,9 @@ inline double quad_perm(double v) {
     const int sel[4] = {P0, P1, P2, P3};
     return p[(emu_lane & ~3) + sel[emu_lane & 3]];
 }
+template <int L>
+inline void fma_bcast(double& acc, double m, double x) { acc = fma(m, emu_publish(x)[L], acc); }
+inline double row_dpp_ready(double x) { return x; }
 inline void row_sync() { (void)emu_publish(0.0); }
 
 

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Profiling target: a few launches of the hot kernel on BASELINE configs[2] (4096 QPs, h=10).  usage: prof_target.py [fixed_iters]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+import torch
+pkg = g.load_package()
+n = 4096
+sc = pkg.scenarios.config3_random_flat(nb=n)
+osqp = dict(warm_start=0)
+if len(sys.argv) > 1:
+    osqp.update(eps_abs=0.0, eps_rel=0.0, max_iter=int(sys.argv[1]), adaptive_rho=0)
+cfg = pkg.make_config(sc["params"], 10, **osqp)
+dev = torch.device("cuda", 0)
+d = {k: torch.from_numpy(sc[k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")}
+grf = torch.zeros((n, 12), dtype=torch.float64, device=dev)
+iters = torch.zeros(n, dtype=torch.int32, device=dev); status = torch.zeros(n, dtype=torch.int32, device=dev)
+eng = pkg.Engine(cfg, n, 0)
+st = torch.cuda.Stream(device=dev)
+for _ in range(5):
+    eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, iters, status, stream=st.cuda_stream)
+torch.cuda.synchronize()
+print("kernel ms", eng.last_kernel_ms(), "mean iters", iters.float().mean().item())
