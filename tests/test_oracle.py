@@ -1,0 +1,112 @@
+"""CPU: pins the oracle (oracle/a1mpc_oracle.c).  The reference pins nothing (S/test/test_mpc.cpp:157-161 only prints) and
+cannot be built here, so the oracle is pinned by (1) an independent numpy re-formation of the QP matrices after the
+reference's own formulas, (2) the KKT conditions of its tight-mode solutions on those matrices, (3) an independent scipy
+solve, (4) analytic stand cases, (5) the committed golden vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import ref_numpy as RN
+from helpers import oracle_batch, oracle_params
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _one(sc, b=0):
+    h = sc["horizon"]
+    return sc["x0"][b], sc["xref"][b], sc["R"][b].reshape(3, 3), sc["foot"][b].reshape(4, 3), sc["contact"][b]
+
+
+@pytest.mark.parametrize("gen,kw", [("scenario_T", {}), ("config3_random_flat", dict(nb=3)), ("config4_random_h16", dict(nb=2)),
+                                     ("config5_divergent", dict(nb=2)), ("config3_random_flat", dict(nb=2, param_set="hardware"))])
+def test_formation_matches_independent_numpy(oracle, scen, gen, kw):
+    sc = getattr(scen, gen)(**kw)
+    pr = oracle_params(oracle, sc)
+    for b in range(len(sc["x0"])):
+        x0, xref, R, foot, contact = _one(sc, b)
+        P, g, A, l, u, _ = oracle.mpc_form(pr, x0, xref, sc["R"][b], sc["foot"][b], contact)
+        P2, g2, A2, l2, u2 = RN.mpc_qp(sc["params"], sc["horizon"], x0, xref, R, foot, contact)
+        assert np.abs(P - P2).max() <= 1e-12 * np.abs(P2).max()
+        assert np.abs(g - g2).max() <= 1e-11 * max(1.0, np.abs(g2).max())
+        assert (A == A2).all() and (l == l2).all() and (u == u2).all()
+
+
+@pytest.mark.parametrize("name", ["T_test_mpc", "stand_gazebo", "config3_h10", "config4_h16", "config5_h20", "config3_hardware_weights"])
+def test_exact_mode_solutions_satisfy_kkt(scen, name):
+    """the `exact` golden solutions are the QP optimum: stationarity, feasibility, multiplier signs on numpy matrices"""
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    ps = "hardware" if "hardware" in name else ("test_mpc" if name.startswith("T_") else ("isaac" if "isaac" in name else "gazebo"))
+    params = dict(scen.PARAM_SETS[ps], **scen.MPC_CONSTANTS)
+    h = int(z["horizon"])
+    for b in range(min(4, len(z["x0"]))):
+        P, g, A, l, u = RN.mpc_qp(params, h, z["x0"][b], z["xref"][b], z["R"][b].reshape(3, 3), z["foot"][b].reshape(4, 3), z["contact"][b])
+        stat, viol, wrong = RN.kkt_violation(P, g, A, l, u, z["exact_u"][b], tol_active=1e-5)
+        scale = max(1.0, np.abs(g).max())
+        assert stat <= 1e-6 * scale and viol <= 1e-6 and wrong <= 1e-6 * scale, (name, b, stat, viol, wrong)
+
+
+def test_scipy_cross_check_fixture_T(oracle, scen):
+    """independent solver (scipy trust-constr) on the numpy matrices of fixture T agrees with the oracle's exact mode"""
+    from scipy.optimize import Bounds, LinearConstraint, minimize
+    sc = scen.scenario_T()
+    x0, xref, R, foot, contact = _one(sc)
+    P, g, A, l, u = RN.mpc_qp(sc["params"], 10, x0, xref, R, foot, contact)
+    lo = np.where(l < -1e20, -np.inf, l); hi = np.where(u > 1e20, np.inf, u)
+    res = minimize(lambda x: 0.5 * x @ P @ x + g @ x, np.zeros(120), jac=lambda x: P @ x + g, hess=lambda x: P, method="trust-constr",
+                   constraints=[LinearConstraint(A, lo, hi)], options=dict(gtol=1e-10, xtol=1e-12, maxiter=3000))
+    e = oracle_batch(oracle, sc, settings=oracle.exact_settings())
+    assert np.abs(res.x[:12] - e["u"][0][:12]).max() < 2e-2  # trust-constr's own accuracy; survey estimate (0,-12.837,42.790)
+    f = e["grf"][0].reshape(4, 3)
+    assert f[0, 2] == pytest.approx(42.790, abs=2e-3) and f[0, 1] == pytest.approx(-12.837, abs=2e-3)
+
+
+def test_analytic_stand_cases(oracle, scen):
+    for ps in ("gazebo", "isaac"):
+        sc = scen.scenario_stand(ps)
+        e = oracle_batch(oracle, sc, settings=oracle.exact_settings())
+        fz = e["grf"][0].reshape(4, 3)[:, 2]
+        assert fz.sum() == pytest.approx(sc["params"]["mass"] * 9.8, rel=2e-3)
+    s1 = scen.config1_balance_stand()
+    r = oracle.balance_solve(oracle.default_qp_params(), oracle.default_settings(), s1["root_acc"][0], s1["R"][0], s1["Rz"][0], s1["foot"][0], s1["contact"][0])
+    assert np.allclose(r["grf"].reshape(4, 3)[:, 2], 12 * 9.8 / 4, atol=0.02)
+
+
+def test_balance_formation_and_kkt(oracle, scen):
+    sc = scen.balance_random(6)
+    qp = oracle.default_qp_params()
+    for b in range(6):
+        P, g, A, l, u, _ = oracle.balance_form(qp, sc["root_acc"][b], sc["Rz"][b], sc["foot"][b], sc["contact"][b])
+        P2, g2, A2, l2, u2 = RN.balance_qp(sc["root_acc"][b], sc["Rz"][b].reshape(3, 3), sc["foot"][b].reshape(4, 3), sc["contact"][b])
+        assert np.abs(P - P2).max() < 1e-10 and np.abs(g - g2).max() < 1e-8 and (A == A2).all() and (l == l2).all() and (u == u2).all()
+        r = oracle.balance_solve(qp, oracle.exact_settings(), sc["root_acc"][b], sc["R"][b], sc["Rz"][b], sc["foot"][b], sc["contact"][b])
+        stat, viol, wrong = RN.kkt_violation(P2, g2, A2, l2, u2, r["f_world"], tol_active=1e-6)
+        assert stat < 1e-5 and viol < 1e-7 and wrong < 1e-5
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
+def test_oracle_reproduces_golden(oracle, scen, path):
+    z = np.load(path)
+    name = os.path.basename(path)[:-4]
+    if name == "balance_random":
+        qp, st = oracle.default_qp_params(), oracle.default_settings()
+        for b in range(len(z["root_acc"])):
+            r = oracle.balance_solve(qp, st, z["root_acc"][b], z["R"][b], z["Rz"][b], z["foot"][b], z["contact"][b])
+            assert r["info"].iters == z["default_iters"][b] and np.abs(r["f_world"] - z["default_f"][b]).max() < 1e-7
+        return
+    ps = "hardware" if "hardware" in name else ("test_mpc" if name.startswith("T_") else ("isaac" if "isaac" in name else "gazebo"))
+    sc = dict(params=dict(scen.PARAM_SETS[ps], **scen.MPC_CONSTANTS), horizon=int(z["horizon"]), x0=z["x0"], xref=z["xref"], R=z["R"], foot=z["foot"],
+              contact=z["contact"])
+    if name == "config2_warm_sequence":
+        pr = oracle_params(oracle, sc); st = oracle.default_settings(warm_start=1)
+        wx = np.zeros(120); wy = np.zeros(200); rho = None
+        for t in range(len(z["x0"])):
+            r = oracle.mpc_solve(pr, st, z["x0"][t], z["xref"][t], z["R"][t], z["foot"][t], z["contact"][t], warm_x=wx, warm_y=wy, warm_rho=rho)
+            wx, wy, rho = r["warm_x"], r["warm_y"], r["rho"]
+            assert r["info"].iters == z["iters"][t] and np.abs(r["u"] - z["u"][t]).max() < 1e-8
+        return
+    d = oracle_batch(oracle, sc)
+    assert (d["iters"] == z["default_iters"]).all() and np.abs(d["u"] - z["default_u"]).max() < 1e-8
+    e = oracle_batch(oracle, sc, settings=oracle.exact_settings())
+    assert np.abs(e["u"] - z["exact_u"]).max() < 1e-6
