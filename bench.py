@@ -138,6 +138,13 @@ def main():
         h = HORIZON
         nfact = eng.last_nfact(n)  # factorisations each QP really performed in the last launch
         flops = float(pkg.algorithmic_flops(h, it, nfact).sum())
+        traffic = None  # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), when a summary of this workload exists
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            if n == BATCH:
+                traffic = (pm["FETCH_SIZE"]["mean"] + pm["WRITE_SIZE"]["mean"]) * 1024.0
+        except Exception:
+            pass
         avg_ms = float(kern_ms.mean())
         achieved = flops / (avg_ms * 1e-3) / 1e12
         out = {
@@ -148,10 +155,11 @@ def main():
                                    "OSQP-default ADMM, per GPU", "batch_per_gpu": n, "horizon": h, "parallelism": f"batch-sharded x{world}",
                        "mean_iters": float(it.mean()), "max_iters": int(it.max()), "solved_frac": float((stt == 1).mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "a1mpc_solve_kernel<10,0>", "avg_kernel_ms": avg_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
-                         "note": "FP64 VALU-bound (no MFMA used); flops = SURVEY 8(d) F(h,iters,nfact) summed over the launch"},
+                         "note": "FP64 VALU issue/latency-bound (no MFMA used, DESIGN.md 3); flops = SURVEY 8(d) F(h,iters,nfact) summed over the launch; "
+                                 "traffic = FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_summary.json (same workload)"},
         }
         if not args.no_latency:
             out["latency"] = latency_probe(pkg)
