@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstring>
 #include <new>
 #include <string>
 #include <vector>
@@ -24,16 +25,7 @@
 
 namespace a1mpc {
 
-struct KernelArgs {
-    DeviceParams P;
-    const double* tab;
-    int32_t n;
-    const double *root_acc, *Rz;  // balance mode only
-    const double *x0, *xref, *R, *foot;
-    const uint8_t* contact;
-    double *grf, *u_full, *warm_x, *warm_y, *rho;
-    int32_t *iters, *status, *nfact;
-};
+using KernelArgs = BatchArgs;
 
 
 // ROWS = QPs (DPP rows) per workgroup; the workgroup is one wavefront with 16*ROWS live lanes.
@@ -43,23 +35,26 @@ __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
     const int row = static_cast<int>(threadIdx.x) >> 4;
     const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
     if (b >= a.n) return;  // row-uniform: the other rows of the wave keep all their DPP sources
-    ProblemIO io;
-    io.root_acc = MODE == kModeBalance ? a.root_acc + b * 6 : nullptr;
-    io.Rz = MODE == kModeBalance ? a.Rz + b * 9 : nullptr;
-    io.x0 = MODE == kModeMpc ? a.x0 + b * 13 : nullptr;
-    io.xref = MODE == kModeMpc ? a.xref + b * 13 * H : nullptr;
-    io.R = a.R + b * 9;
-    io.foot = a.foot + b * 12;
-    io.contact = a.contact + b * 4;
-    io.grf = a.grf + b * 12;
-    io.u_full = a.u_full ? a.u_full + b * 12 * H : nullptr;
-    io.warm_x = a.warm_x ? a.warm_x + b * 12 * H : nullptr;
-    io.warm_y = a.warm_y ? a.warm_y + b * 20 * H : nullptr;
-    io.rho_io = a.rho ? a.rho + b : nullptr;
-    io.iters = a.iters ? a.iters + b : nullptr;
-    io.status = a.status ? a.status + b : nullptr;
-    io.nfact = a.nfact ? a.nfact + b : nullptr;
+    const ProblemIO io = make_io<H, MODE>(a, b);
     solve_row<H, MODE>(a.P, a.tab, io, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+}
+
+// ---- split pipeline (large batches) -----------------------------------------------------------------------------
+// K1: formation + Ruiz, 4 QPs per wavefront, 2.8 KB of LDS per QP (H = 10) -> many waves per CU hide the sweep's latency.
+template <int H>
+__global__ __launch_bounds__(64, 2) void a1mpc_setup_kernel(const KernelArgs a, double* __restrict__ prep) {
+    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
+    const int row = static_cast<int>(threadIdx.x) >> 4;
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + row;
+    if (b >= a.n) return;
+    setup_row<H>(a, b, a1mpc_lds + row * LayoutSetup<H>::ROW_STRIDE, prep);
+}
+// K2: persistent rows; grid = resident workgroups; every row drains the queue of prepared QPs.
+template <int H, int ROWS>
+__global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
+    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
+    const int row = static_cast<int>(threadIdx.x) >> 4;
+    admm_rows<H>(a, prep, counter, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
 }
 
 template <int H>
@@ -85,6 +80,59 @@ static a1mpc_status fail(a1mpc_status s, const std::string& msg) { g_last_error 
         if (e_ != hipSuccess) return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// fused kernel for small batches (latency path), split pipeline from this batch size on; A1MPC_PIPELINE=fused|split overrides
+static int split_threshold() {
+    static int t = [] {
+        const char* e = getenv("A1MPC_PIPELINE");
+        if (e && !strcmp(e, "fused")) return 1 << 30;
+        if (e && !strcmp(e, "split")) return 1;
+        return 256;
+    }();
+    return t;
+}
+
+template <int H, int ROWS>
+static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* counter, hipStream_t stream) {
+    static int resident[64] = {};
+    int dev = 0;
+    A1_HIP(hipGetDevice(&dev));
+    const size_t lds2 = lds_bytes<H>(ROWS), lds1 = sizeof(double) * 4 * LayoutSetup<H>::ROW_STRIDE;
+    if (dev >= 0 && dev < 64 && !resident[dev]) {
+        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds2)));
+        int per_cu = 0, cus = 0;
+        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), 16 * ROWS, lds2));
+        A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        resident[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    }
+    A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
+    hipLaunchKernelGGL((a1mpc_setup_kernel<H>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
+    A1_HIP(hipGetLastError());
+    const int want = (a.n + ROWS - 1) / ROWS;
+    const int res = (dev >= 0 && dev < 64) ? resident[dev] : 512;
+    hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), dim3(static_cast<unsigned>(want < res ? want : res)), dim3(16 * ROWS), lds2, stream, a,
+                       static_cast<const double*>(prep), counter);
+    A1_HIP(hipGetLastError());
+    return A1MPC_OK;
+}
+template <int H>
+static a1mpc_status launch_split(const KernelArgs& a, double* prep, int* counter, hipStream_t stream) {
+    switch (rows_per_wg()) {
+        case 1: return launch_split_rows<H, 1>(a, prep, counter, stream);
+        case 2: return launch_split_rows<H, 2>(a, prep, counter, stream);
+    }
+    return launch_split_rows<H, 4>(a, prep, counter, stream);
+}
+static size_t prep_stride(int horizon) {
+    switch (horizon) {
+        case 1: return Prep<1>::STRIDE;
+        case 10: return Prep<10>::STRIDE;
+        case 16: return Prep<16>::STRIDE;
+        case 20: return Prep<20>::STRIDE;
+    }
+    return 0;
+}
+
 template <int H, int MODE, int ROWS>
 static a1mpc_status launch_rows(const KernelArgs& a, hipStream_t stream) {
     static bool attr_set[64] = {};
@@ -109,7 +157,15 @@ static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
     return launch_rows<H, MODE, 4>(a, stream);
 }
 
-static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, hipStream_t s) {
+static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s) {
+    if (a.n >= split_threshold() && prep && counter) {
+        switch (horizon) {
+            case 1: return launch_split<1>(a, prep, counter, s);
+            case 10: return launch_split<10>(a, prep, counter, s);
+            case 16: return launch_split<16>(a, prep, counter, s);
+            case 20: return launch_split<20>(a, prep, counter, s);
+        }
+    }
     switch (horizon) {
         case 1: return launch<1, kModeMpc>(a, s);
         case 10: return launch<10, kModeMpc>(a, s);
@@ -163,6 +219,9 @@ struct a1mpc_handle_s {
     hipStream_t last_stream = nullptr;
     // carried OSQP workspace (warm start)
     double *d_wx = nullptr, *d_wy = nullptr, *d_rho = nullptr;
+    // split pipeline: prepared state of every QP (set-up kernel -> ADMM kernel) and the work-queue counter
+    double* d_prep = nullptr;
+    int* d_counter = nullptr;
     // pinned host mirrors
     char* h_pin = nullptr;
     size_t h_pin_bytes = 0;
@@ -208,7 +267,7 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_tab, h->d_tab1, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_aux, h->d_Rz, h->d_contact, h->d_grf,
-                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho};
+                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -272,6 +331,8 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     A1_TRY(hipMemset(h->d_wx, 0, n * 12 * H * sizeof(double)));
     A1_TRY(hipMemset(h->d_wy, 0, n * 20 * H * sizeof(double)));
     A1_TRY(hipMemset(h->d_rho, 0, n * sizeof(double)));
+    if (max_batch >= split_threshold()) A1_TRY(hipMalloc(&h->d_prep, n * prep_stride(H) * sizeof(double)));
+    A1_TRY(hipMalloc(&h->d_counter, sizeof(int)));
     // pinned mirror: inputs (x0, xref, R, Rz, foot, aux, contact) then outputs (grf, u, iters, status)
     h->h_pin_bytes = n * ((13 + 13 * H + 9 + 9 + 12 + 6) * sizeof(double) + 8 + (12 + 12 * H) * sizeof(double) + 2 * sizeof(int32_t));
     A1_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), h->h_pin_bytes, hipHostMallocDefault));
@@ -309,7 +370,7 @@ a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d
     h->last_stream = s;
     if (h->cfg.warm_start) { a.warm_x = h->d_wx; a.warm_y = h->d_wy; a.rho = h->d_rho; }
     A1_HIP(hipEventRecord(h->ev0, s));
-    a1mpc_status st = launch_mpc(h->cfg.horizon, a, s);
+    a1mpc_status st = launch_mpc(h->cfg.horizon, a, h->d_prep, h->d_counter, s);
     if (st != A1MPC_OK) return st;
     A1_HIP(hipEventRecord(h->ev1, s));
     h->timed = true;

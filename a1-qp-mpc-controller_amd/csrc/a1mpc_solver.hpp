@@ -96,6 +96,18 @@ template <int J>
 A1_DEV void fbc(double& acc, double m, double x) {  // acc += m * x[compact index J]; x must be row_dpp_ready()
     fma_bcast<lane_of(J)>(acc, m, x);
 }
+// init + sum_{j<N} m[j] * x[compact index OFF + j]  (two interleaved accumulator chains; x must be row_dpp_ready())
+template <int OFF, int N>
+A1_DEV double dot_bc(const double (&m)[N], double x, double init = 0.0) {
+    static_assert(N >= 2 && N % 2 == 0, "even length");
+    double a0 = init, a1 = 0.0;
+    static_for<N / 2>([&](auto J) {
+        constexpr int j = 2 * A1_CV(J);
+        fma_bcast<lane_of(OFF + j)>(a0, m[j], x);
+        fma_bcast<lane_of(OFF + j + 1)>(a1, m[j + 1], x);
+    });
+    return a0 + a1;
+}
 constexpr int alpha_diag(int s, int H) {  // sum_{i=s}^{H-1} (i-s)^2
     int a = 0;
     for (int i = s; i < H; ++i) a += (i - s) * (i - s);
@@ -150,294 +162,395 @@ struct Layout {
     static constexpr int ROW_STRIDE = stride_for(RAW);
 };
 
+// LDS image of the set-up kernel (formation + Ruiz only: no factor): 348 doubles per QP at H = 10
+template <int H>
+struct LayoutSetup {
+    static constexpr int KSTR = 13, K_SZ = 12 * KSTR, S_SZ = 78, SLOT = K_SZ + S_SZ, FAC = 0;  // unused by the set-up code paths
+    static constexpr int TBL = 0;
+    static constexpr int DL = 36;
+    static constexpr int BL = DL + 12 * H;
+    static constexpr int CG = BL + 72;
+    static constexpr int RAW = CG + 12 * H;
+    static constexpr int ROW_STRIDE = RAW + (RAW % 2);
+};
+
+// prepared state handed from the set-up kernel to the ADMM kernel: [field][16 lanes] doubles per QP
+template <int H>
+struct Prep {
+    static constexpr int XH = 0, RR0 = H, RR1 = 2 * H, DI2 = 3 * H, CG = 4 * H, BT = 5 * H;  // per-lane fields
+    static constexpr int CSC = BT + 6, CY = CSC + 1, SY = CY + 1, RHO = SY + 1, LO = RHO + 1, HI = LO + 1, EQ = HI + 1, FLAGS = EQ + 1;
+    static constexpr int FIELDS = FLAGS + 1;
+    static constexpr int STRIDE = FIELDS * 16;  // doubles per QP
+};
+
 // =================================================================================================
-// One QP, executed by the 16 lanes of a row.  `tab` = [s][t][2] = (alpha_st/beta_st, beta_st).
-// =================================================================================================
+// One QP, executed by the 16 lanes of a DPP row.  `tab` = [s][t][2] = (alpha_st/beta_st, beta_st).
 //
 // MODE = kModeBalance (H = 1) is the 12-variable balance QP of compute_grf (S/A1RobotControl.cpp:377-444):
 // P = R I + M' Q M, q = -M' Q b with M = [I; Rz' skew(r_i)] is the H = 1 member of the same family
 // (alpha_00 = 0, beta_00 = 1, B~ := M with the torque rows first, dt := 0); its friction rows are the MPC
 // rows with two signs flipped, which leaves every ADMM iterate of x unchanged.
-template <int H, int MODE = kModeMpc>
-A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, const ProblemIO& io, double* __restrict__ lds) {
-    using L = Layout<H>;
-    const int ln = row_lane();
-    const int quad = ln >> 2, comp = ln & 3;
-    const bool act = comp < 3;
-    const int ci = act ? 3 * quad + comp : 0;  // compact index (safe 0 on pad lanes)
-    const int tri = ci * (ci + 1) / 2;
-    const double dt = P.dt, mu = P.mu;
-
-    // ---------------------------------------------------------------- inputs, B_d, per-lane constants
-    double Rm[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Rm[i] = io.R[i];
-    double cy = 1.0, sy = 0.0;
-    if constexpr (MODE == kModeMpc) {
-        const double yaw = io.x0[2];
-        cy = cos(yaw); sy = sin(yaw);  // S/ConvexMpc.cpp:115-116
-    }
-
+//
+// The object lives in registers (every array index is a compile-time constant after unrolling).  Two ways to drive it:
+//   fused   setup(io); solve(); write_outputs(io);                               one kernel, small batches / latency path
+//   split   K1: setup(io); save_prepared(p)        K2: load_prepared(p, io); { advance(); } ...; write_outputs(io)
+//           K2 rows pull the next prepared QP as soon as theirs has converged (advance() = one checkpoint-aligned segment).
+// =================================================================================================
+template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false>
+struct RowSolver {
+    using L = std::conditional_t<SETUP_ONLY, LayoutSetup<H>, Layout<H>>;
+    using PR = Prep<H>;
+    const DeviceParams& P;
+    const double* __restrict__ tab;
+    double* __restrict__ lds;
+    // lane identity
+    int ln, quad, comp, ci, tri, krow;
+    bool act, wl;
+    const double* brow;
+    double dt, mu;
+    // per-lane constants of the problem
     double Bt[6];  // my column of B~ (force layout); zero on pad lanes
-    if constexpr (MODE == kModeBalance) {
-        static_assert(MODE != kModeBalance || H == 1, "the balance QP is the H = 1 case");
-        const double rx = io.foot[3 * quad + 0], ry = io.foot[3 * quad + 1], rz = io.foot[3 * quad + 2];
-        const double k0 = comp == 0 ? 0.0 : (comp == 1 ? -rz : ry);
-        const double k1 = comp == 0 ? rz : (comp == 1 ? 0.0 : -rx);
-        const double k2 = comp == 0 ? -ry : (comp == 1 ? rx : 0.0);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {  // inertia_inv = [I; Rz' skew(r)] (S/A1RobotControl.cpp:394-399)
-            Bt[k] = act ? io.Rz[0 * 3 + k] * k0 + io.Rz[1 * 3 + k] * k1 + io.Rz[2 * 3 + k] * k2 : 0.0;
-            Bt[3 + k] = (act && comp == k) ? 1.0 : 0.0;
-        }
-    } else {
-        // I_world = R I_b R', inverse by cofactors (S/ConvexMpc.cpp:136-141)
-        double t9[9], Iw[9], Ii[9];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double s = 0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) s += Rm[i * 3 + k] * P.inertia[k * 3 + j];
-                t9[i * 3 + j] = s;
-            }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                double s = 0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) s += t9[i * 3 + k] * Rm[j * 3 + k];
-                Iw[i * 3 + j] = s;
-            }
-        const double c00 = Iw[4] * Iw[8] - Iw[5] * Iw[7], c01 = Iw[5] * Iw[6] - Iw[3] * Iw[8],
-                     c02 = Iw[3] * Iw[7] - Iw[4] * Iw[6];
-        const double idet = 1.0 / (Iw[0] * c00 + Iw[1] * c01 + Iw[2] * c02);
-        Ii[0] = c00 * idet; Ii[1] = (Iw[2] * Iw[7] - Iw[1] * Iw[8]) * idet; Ii[2] = (Iw[1] * Iw[5] - Iw[2] * Iw[4]) * idet;
-        Ii[3] = c01 * idet; Ii[4] = (Iw[0] * Iw[8] - Iw[2] * Iw[6]) * idet; Ii[5] = (Iw[2] * Iw[3] - Iw[0] * Iw[5]) * idet;
-        Ii[6] = c02 * idet; Ii[7] = (Iw[1] * Iw[6] - Iw[0] * Iw[7]) * idet; Ii[8] = (Iw[0] * Iw[4] - Iw[1] * Iw[3]) * idet;
-        const double rx = io.foot[3 * quad + 0], ry = io.foot[3 * quad + 1], rz = io.foot[3 * quad + 2];
-        // column `comp` of skew(r) (S/utils/Utils.cpp:35-41)
-        const double k0 = comp == 0 ? 0.0 : (comp == 1 ? -rz : ry);
-        const double k1 = comp == 0 ? rz : (comp == 1 ? 0.0 : -rx);
-        const double k2 = comp == 0 ? -ry : (comp == 1 ? rx : 0.0);
-        const double invm = 1.0 / P.mass;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            Bt[k] = act ? (Ii[k * 3 + 0] * k0 + Ii[k * 3 + 1] * k1 + Ii[k * 3 + 2] * k2) * dt : 0.0;  // :138,:151
-            Bt[3 + k] = (act && comp == k) ? invm * dt : 0.0;                                           // :139,:151
-        }
+    double cy, sy, fA, fB, fC, fP, gA, gB, gC, gV, q2s, r2a;
+    double csc, cinv, qd, lo_u, hi_u, lb0, ub0;
+    unsigned eqmask;  // bit t: my slot-0 row at step t is an equality row (swing leg: l = u = 0; auxil.c set_rho_vec)
+    int r0, r1;       // reference row numbers of my two rows inside a (step, leg) block
+    // hot state (see setup()): 6 doubles per horizon step and lane
+    double xh[H], wh0[H], wh1[H], rr0[H], rr1[H], dI2[H];
+    double rho;
+    bool warm, first_special;
+    const double* warm_y_in;
+    // bookkeeping
+    int iter, nfact;
+    int32_t status;
+    bool fac_ok, need_factor, done;
+    struct Info {
+        double pri_res, dua_res, nEz, nEAx, nDq, nDAty, nDPx;  // unscaled
+        double s_pri, s_dua, s_z, s_Ax, s_q, s_Aty, s_Px;      // scaled (rho estimate)
+    } info;
+
+    A1_DEV RowSolver(const DeviceParams& P_, const double* tab_, double* lds_) : P(P_), tab(tab_), lds(lds_) {
+        ln = row_lane();
+        quad = ln >> 2; comp = ln & 3;
+        act = comp < 3;
+        ci = act ? 3 * quad + comp : 0;  // compact index (safe 0 on pad lanes)
+        tri = ci * (ci + 1) / 2;
+        krow = ci * L::KSTR;
+        wl = act && quad >= 2;           // wrench lanes: state rows 6..11 = quads 2, 3
+        brow = lds + L::BL + (wl ? ci - 6 : 0) * 12;
+        dt = P.dt; mu = P.mu;
+        q2s = act ? P.q2[ci] : 0.0;      // state-lane weight 2 q_i
+        r2a = act ? P.r2[ci] : 0.0;      // force-lane weight 2 r_a
+        r0 = comp == 0 ? 0 : (comp == 1 ? 2 : 4); r1 = comp == 0 ? 1 : 3;
+        iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false;
+        warm = false; first_special = false; warm_y_in = nullptr; eqmask = 0;
     }
-    // T = A_c(0:3,6:9) = [[c,s,0],[-s,c,0],[0,0,1]] (S/ConvexMpc.cpp:123-125); my column of T*B~_omega
-    double TB[3];
-    TB[0] = cy * Bt[0] + sy * Bt[1];
-    TB[1] = -sy * Bt[0] + cy * Bt[1];
-    TB[2] = Bt[2];
-    if (act) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) lds[L::BL + k * 12 + ci] = Bt[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) lds[L::TBL + k * 12 + ci] = TB[k];
+
+    // A_d = I + dt*A_c and its transpose as row operators on a state-layout vector (T = A_c(0:3,6:9), S/ConvexMpc.cpp:123-125)
+    A1_DEV void set_rotation(double c, double s) {
+        cy = c; sy = s;
+        fA = ln == 0 ? dt * cy : (ln == 1 ? -dt * sy : 0.0);
+        fB = ln == 0 ? dt * sy : (ln == 1 ? dt * cy : 0.0);
+        fC = ln == 2 ? dt : 0.0;
+        fP = (quad == 1 && act) ? dt : 0.0;
+        gA = ln == 8 ? dt * cy : (ln == 9 ? dt * sy : 0.0);
+        gB = ln == 8 ? -dt * sy : (ln == 9 ? dt * cy : 0.0);
+        gC = ln == 10 ? dt : 0.0;
+        gV = (quad == 3 && act) ? dt : 0.0;
     }
-    row_sync();
-    // B~ row of the wrench lanes (state rows 6..11 = quads 2,3) is re-read from LDS where it is needed
-    const bool wl = act && quad >= 2;
-    const double* brow = lds + L::BL + (wl ? ci - 6 : 0) * 12;
-    // A_d = I + dt*A_c and its transpose as row operators on a state-layout vector
-    const double fA = ln == 0 ? dt * cy : (ln == 1 ? -dt * sy : 0.0);
-    const double fB = ln == 0 ? dt * sy : (ln == 1 ? dt * cy : 0.0);
-    const double fC = ln == 2 ? dt : 0.0;
-    const double fP = (quad == 1 && act) ? dt : 0.0;
-    const double gA = ln == 8 ? dt * cy : (ln == 9 ? dt * sy : 0.0);
-    const double gB = ln == 8 ? -dt * sy : (ln == 9 ? dt * cy : 0.0);
-    const double gC = ln == 10 ? dt : 0.0;
-    const double gV = (quad == 3 && act) ? dt : 0.0;
-    auto opA = [&](double s) {  // (A_d s): rpy += dt*T*omega, pos += dt*vel
-        s = row_dpp_ready(s);
+    // NOTE: opA, opAT, BtT, Bu read their argument through DPP: it must have passed row_dpp_ready()
+    A1_DEV double opA(double s) const {  // (A_d s): rpy += dt*T*omega, pos += dt*vel
         double a0 = s, a1 = fP * row_ror<8>(s);
         fma_bcast<8>(a0, fA, s); fma_bcast<9>(a1, fB, s); fma_bcast<10>(a0, fC, s);
         return a0 + a1;
-    };
-    auto opAT = [&](double p) {  // (A_d' p): omega += dt*T'*rpy-part, vel += dt*pos-part
-        p = row_dpp_ready(p);
+    }
+    A1_DEV double opAT(double p) const {  // (A_d' p): omega += dt*T'*rpy-part, vel += dt*pos-part
         double a0 = p, a1 = gV * row_ror<8>(p);
         fma_bcast<0>(a0, gA, p); fma_bcast<1>(a1, gB, p); fma_bcast<2>(a0, gC, p);
         return a0 + a1;
-    };
-    // adjoint of the roll-out: (B~' lambda_{omega,v}) in force layout
-    auto BtT = [&](double lam) {
-        lam = row_dpp_ready(lam);
-        double a0 = 0.0, a1 = 0.0;
-        fbc<6>(a0, Bt[0], lam); fbc<7>(a1, Bt[1], lam);
-        fbc<8>(a0, Bt[2], lam); fbc<9>(a1, Bt[3], lam);
-        fbc<10>(a0, Bt[4], lam); fbc<11>(a1, Bt[5], lam);
-        return a0 + a1;
-    };
-    // (B~ u) scattered into the wrench lanes of a state-layout vector
-    auto Bu = [&](double u) {
-        u = row_dpp_ready(u);
-        double a0 = 0, a1 = 0;
-        static_for<6>([&](auto J) {
-            fbc<2 * J>(a0, brow[2 * J], u);
-            fbc<2 * J + 1>(a1, brow[2 * J + 1], u);
-        });
-        return wl ? a0 + a1 : 0.0;
-    };
-
-    const double q2s = act ? P.q2[ci] : 0.0;  // state-lane weight 2 q_i
-    const double r2a = act ? P.r2[ci] : 0.0;  // force-lane weight 2 r_a
-
-    // ---------------------------------------------------------------- gradient g = B_qp' Q (A_qp x0 - x_ref)
-    double g[H];
-    if constexpr (MODE == kModeBalance) {
-        // q = -M' Q b (S/A1RobotControl.cpp:406); wrench order here: torque (root_acc[3:6]), force (root_acc[0:3])
-        double a = 0.0;
+    }
+    A1_DEV double BtT(double lam) const { return dot_bc<6>(Bt, lam); }  // (B~' lambda_{omega,v}) in force layout
+    A1_DEV double Bu(double u) const {                                  // (B~ u) on the wrench lanes of a state-layout vector
+        double Br[12];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            a += Bt[k] * P.q2[6 + k] * io.root_acc[3 + k];
-            a += Bt[3 + k] * P.q2[9 + k] * io.root_acc[k];
-        }
-        g[0] = -a;
-    } else {
-        double w[H];
-        double xs = act ? io.x0[ci] : 0.0;
-        const double grav = io.x0[12];
-        static_for<H>([&](auto T) {
-            xs = opA(xs);
-            if (ln == 14) xs += dt * grav;  // A_c(11,12) = 1 (S/ConvexMpc.cpp:129)
-            const double xr = act ? io.xref[T * 13 + ci] : 0.0;
-            w[T] = q2s * (xs - xr);
-        });
-        double lam = 0.0;
-        static_for<H>([&](auto TT) {
-            constexpr int t = H - 1 - A1_CV(TT);
-            lam = w[t] + opAT(lam);
-            g[t] = BtT(lam);
-        });
+        for (int b = 0; b < 12; ++b) Br[b] = brow[b];
+        const double r = dot_bc<0>(Br, u);
+        return wl ? r : 0.0;
+    }
+    A1_DEV void bounds_from_contact(double cf) {
+        lo_u = P.fz_min * cf; hi_u = P.fz_max * cf;
+        // physical bounds of my two rows: slot 0 = [fx+mu fz >= 0 | fy+mu fz >= 0 | fz in [lo,hi]], slot 1 = [.. <= 0]
+        lb0 = comp == 2 ? lo_u : 0.0; ub0 = comp == 2 ? hi_u : kInfty;
     }
 
-    // ---------------------------------------------------------------- U, V rows (P = alpha(x)U + beta(x)V + I(x)R)
-    double U[12], V[12], Ud = 0.0, Vd = 0.0;
-    static_for<12>([&](auto B) {
-        double u = 0.0, v = 0.0;
+    // ================================================================================ set-up: formation + Ruiz + hot state
+    A1_DEV void setup(const ProblemIO& io) {
+        double Rm[9];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            u += P.q2[k] * TB[k] * lds[L::TBL + k * 12 + B] + P.q2[3 + k] * Bt[3 + k] * lds[L::BL + (3 + k) * 12 + B];
-            v += P.q2[6 + k] * Bt[k] * lds[L::BL + k * 12 + B] + P.q2[9 + k] * Bt[3 + k] * lds[L::BL + (3 + k) * 12 + B];
+        for (int i = 0; i < 9; ++i) Rm[i] = io.R[i];
+        double c_ = 1.0, s_ = 0.0;
+        if constexpr (MODE == kModeMpc) {
+            const double yaw = io.x0[2];
+            c_ = cos(yaw); s_ = sin(yaw);  // S/ConvexMpc.cpp:115-116
         }
-        U[B] = u * dt * dt;
-        V[B] = v;
-        if (act && ci == B) { Ud = U[B]; Vd = V[B]; }
-    });
+        set_rotation(c_, s_);
+        if constexpr (MODE == kModeBalance) {
+            static_assert(MODE != kModeBalance || H == 1, "the balance QP is the H = 1 case");
+            const double rx = io.foot[3 * quad + 0], ry = io.foot[3 * quad + 1], rz = io.foot[3 * quad + 2];
+            const double k0 = comp == 0 ? 0.0 : (comp == 1 ? -rz : ry);
+            const double k1 = comp == 0 ? rz : (comp == 1 ? 0.0 : -rx);
+            const double k2 = comp == 0 ? -ry : (comp == 1 ? rx : 0.0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {  // inertia_inv = [I; Rz' skew(r)] (S/A1RobotControl.cpp:394-399)
+                Bt[k] = act ? io.Rz[0 * 3 + k] * k0 + io.Rz[1 * 3 + k] * k1 + io.Rz[2 * 3 + k] * k2 : 0.0;
+                Bt[3 + k] = (act && comp == k) ? 1.0 : 0.0;
+            }
+        } else {
+            // I_world = R I_b R', inverse by cofactors (S/ConvexMpc.cpp:136-141)
+            double t9[9], Iw[9], Ii[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) s += Rm[i * 3 + k] * P.inertia[k * 3 + j];
+                    t9[i * 3 + j] = s;
+                }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) s += t9[i * 3 + k] * Rm[j * 3 + k];
+                    Iw[i * 3 + j] = s;
+                }
+            const double c00 = Iw[4] * Iw[8] - Iw[5] * Iw[7], c01 = Iw[5] * Iw[6] - Iw[3] * Iw[8],
+                         c02 = Iw[3] * Iw[7] - Iw[4] * Iw[6];
+            const double idet = 1.0 / (Iw[0] * c00 + Iw[1] * c01 + Iw[2] * c02);
+            Ii[0] = c00 * idet; Ii[1] = (Iw[2] * Iw[7] - Iw[1] * Iw[8]) * idet; Ii[2] = (Iw[1] * Iw[5] - Iw[2] * Iw[4]) * idet;
+            Ii[3] = c01 * idet; Ii[4] = (Iw[0] * Iw[8] - Iw[2] * Iw[6]) * idet; Ii[5] = (Iw[2] * Iw[3] - Iw[0] * Iw[5]) * idet;
+            Ii[6] = c02 * idet; Ii[7] = (Iw[1] * Iw[6] - Iw[0] * Iw[7]) * idet; Ii[8] = (Iw[0] * Iw[4] - Iw[1] * Iw[3]) * idet;
+            const double rx = io.foot[3 * quad + 0], ry = io.foot[3 * quad + 1], rz = io.foot[3 * quad + 2];
+            // column `comp` of skew(r) (S/utils/Utils.cpp:35-41)
+            const double k0 = comp == 0 ? 0.0 : (comp == 1 ? -rz : ry);
+            const double k1 = comp == 0 ? rz : (comp == 1 ? 0.0 : -rx);
+            const double k2 = comp == 0 ? -ry : (comp == 1 ? rx : 0.0);
+            const double invm = 1.0 / P.mass;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Bt[k] = act ? (Ii[k * 3 + 0] * k0 + Ii[k * 3 + 1] * k1 + Ii[k * 3 + 2] * k2) * dt : 0.0;  // :138,:151
+                Bt[3 + k] = (act && comp == k) ? invm * dt : 0.0;                                           // :139,:151
+            }
+        }
+        // my column of T*B~_omega
+        double TB[3];
+        TB[0] = cy * Bt[0] + sy * Bt[1];
+        TB[1] = -sy * Bt[0] + cy * Bt[1];
+        TB[2] = Bt[2];
+        row_sync();
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) lds[L::BL + k * 12 + ci] = Bt[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lds[L::TBL + k * 12 + ci] = TB[k];
+        }
+        row_sync();
 
-    // ---------------------------------------------------------------- Ruiz equilibration (osqp scaling.c scale_data)
-    double D[H], E0[H], E1[H];
-    double csc = 1.0;
+        // ---------------------------------------------------------------- gradient g = B_qp' Q (A_qp x0 - x_ref)
+        double g[H];
+        if constexpr (MODE == kModeBalance) {
+            // q = -M' Q b (S/A1RobotControl.cpp:406); wrench order here: torque (root_acc[3:6]), force (root_acc[0:3])
+            double a = 0.0;
 #pragma unroll
-    for (int t = 0; t < H; ++t) { D[t] = 1.0; E0[t] = act ? 1.0 : 0.0; E1[t] = (comp < 2) ? 1.0 : 0.0; }
-    if (P.scaling_iters > 0) {
-        double m[H];
-        // m[s] = max_{t,b} D_tb |P_(s,a),(t,b)|  for my rows (s, a): one pass over the implicit Hessian
-        auto sweep = [&](double(&mm)[H]) {
-            row_sync();
-            if (act) {
-#pragma unroll
-                for (int t = 0; t < H; ++t) lds[L::DL + t * 12 + ci] = D[t];
+            for (int k = 0; k < 3; ++k) {
+                a += Bt[k] * P.q2[6 + k] * io.root_acc[3 + k];
+                a += Bt[3 + k] * P.q2[9 + k] * io.root_acc[k];
             }
-            row_sync();
-#pragma unroll
-            for (int s = 0; s < H; ++s) mm[s] = 0.0;
-#pragma unroll 1
-            for (int t = 0; t < H; ++t) {
-                double Dt[12];
-#pragma unroll
-                for (int b = 0; b < 12; ++b) Dt[b] = lds[L::DL + t * 12 + b];
-                static_for<H>([&](auto S) {
-                    const double gam = tab[(S * H + t) * 2], bet = tab[(S * H + t) * 2 + 1];
-                    double a0 = 0.0, a1 = 0.0;
-                    static_for<6>([&](auto J) {
-                        a0 = fmax(a0, fabs(fma(gam, U[2 * J], V[2 * J])) * Dt[2 * J]);
-                        a1 = fmax(a1, fabs(fma(gam, U[2 * J + 1], V[2 * J + 1])) * Dt[2 * J + 1]);
-                    });
-                    mm[S] = fmax(mm[S], bet * fmax(a0, a1));
-                });
-            }
-            static_for<H>([&](auto S) {  // the true diagonal entry carries R
-                constexpr double ad = alpha_diag(A1_CV(S), H), bd = H - A1_CV(S);
-                mm[S] = fmax(mm[S], (ad * Ud + bd * Vd + r2a) * D[S]);
-            });
-        };
-        sweep(m);
-#pragma unroll 1
-        for (int pass = 0; pass < P.scaling_iters; ++pass) {
+            g[0] = -a;
+        } else {
+            double w[H];
+            double xs = act ? io.x0[ci] : 0.0;
+            const double grav = io.x0[12];
             static_for<H>([&](auto T) {
-                const double Dz = quad_perm<2, 2, 2, 2>(D[T]);
-                const double mE = fmax(E0[T], E1[T]);
-                const double mEx = quad_perm<0, 0, 0, 0>(mE), mEy = quad_perm<1, 1, 1, 1>(mE);
-                const double colA = D[T] * (comp == 2 ? fmax(mu * fmax(mEx, mEy), E0[T]) : mE);
-                const double colP = csc * D[T] * m[T];
-                const double dtmp = 1.0 / sqrt(limit_scaling(fmax(colP, colA)));
-                const double rowf = comp == 2 ? D[T] : fmax(D[T], mu * Dz);
-                const double e0 = 1.0 / sqrt(limit_scaling(E0[T] * rowf));
-                const double e1 = 1.0 / sqrt(limit_scaling(E1[T] * rowf));
-                D[T] *= dtmp; E0[T] *= e0; E1[T] *= e1;
+                xs = opA(row_dpp_ready(xs));
+                if (ln == 14) xs += dt * grav;  // A_c(11,12) = 1 (S/ConvexMpc.cpp:129)
+                const double xr = act ? io.xref[T * 13 + ci] : 0.0;
+                w[T] = q2s * (xs - xr);
             });
-            sweep(m);
-            double sum = 0.0, nq = 0.0;
-#pragma unroll
-            for (int t = 0; t < H; ++t) {
-                sum += csc * D[t] * m[t];
-                nq = fmax(nq, fabs(csc * D[t] * g[t]));
-            }
-            const double mean = row_allsum(sum) / double(12 * H);
-            nq = limit_scaling(row_allmax(nq));
-            const double ct = 1.0 / limit_scaling(fmax(mean, nq));
-            csc *= ct;
+            double lam = row_dpp_ready(0.0);
+            static_for<H>([&](auto TT) {
+                constexpr int t = H - 1 - A1_CV(TT);
+                lam = row_dpp_ready(w[t] + opAT(lam));
+                g[t] = BtT(lam);
+            });
         }
+
+        // ---------------------------------------------------------------- U, V rows (P = alpha(x)U + beta(x)V + I(x)R)
+        double U[12], V[12], Ud = 0.0, Vd = 0.0;
+        static_for<12>([&](auto B) {
+            double u = 0.0, v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                u += P.q2[k] * TB[k] * lds[L::TBL + k * 12 + B] + P.q2[3 + k] * Bt[3 + k] * lds[L::BL + (3 + k) * 12 + B];
+                v += P.q2[6 + k] * Bt[k] * lds[L::BL + k * 12 + B] + P.q2[9 + k] * Bt[3 + k] * lds[L::BL + (3 + k) * 12 + B];
+            }
+            U[B] = u * dt * dt;
+            V[B] = v;
+            if (act && ci == B) { Ud = U[B]; Vd = V[B]; }
+        });
+
+        // ---------------------------------------------------------------- Ruiz equilibration (osqp scaling.c scale_data)
+        double D[H], E0[H], E1[H];
+        csc = 1.0;
+#pragma unroll
+        for (int t = 0; t < H; ++t) { D[t] = 1.0; E0[t] = act ? 1.0 : 0.0; E1[t] = (comp < 2) ? 1.0 : 0.0; }
+        if (P.scaling_iters > 0) {
+            double m[H];
+            // m[s] = max_{t,b} D_tb |P_(s,a),(t,b)|  for my rows (s, a): one pass over the implicit Hessian
+            auto sweep = [&](double(&mm)[H]) {
+                row_sync();
+                if (act) {
+#pragma unroll
+                    for (int t = 0; t < H; ++t) lds[L::DL + t * 12 + ci] = D[t];
+                }
+                row_sync();
+#pragma unroll
+                for (int s = 0; s < H; ++s) mm[s] = 0.0;
+#pragma unroll 1
+                for (int t = 0; t < H; ++t) {
+                    double Dt[12];
+#pragma unroll
+                    for (int b = 0; b < 12; ++b) Dt[b] = lds[L::DL + t * 12 + b];
+                    static_for<H>([&](auto S) {
+                        const double gam = tab[(S * H + t) * 2], bet = tab[(S * H + t) * 2 + 1];
+                        double a0 = 0.0, a1 = 0.0;
+                        static_for<6>([&](auto J) {
+                            a0 = fmax(a0, fabs(fma(gam, U[2 * J], V[2 * J])) * Dt[2 * J]);
+                            a1 = fmax(a1, fabs(fma(gam, U[2 * J + 1], V[2 * J + 1])) * Dt[2 * J + 1]);
+                        });
+                        mm[S] = fmax(mm[S], bet * fmax(a0, a1));
+                    });
+                }
+                static_for<H>([&](auto S) {  // the true diagonal entry carries R
+                    constexpr double ad = alpha_diag(A1_CV(S), H), bd = H - A1_CV(S);
+                    mm[S] = fmax(mm[S], (ad * Ud + bd * Vd + r2a) * D[S]);
+                });
+            };
+            sweep(m);
+#pragma unroll 1
+            for (int pass = 0; pass < P.scaling_iters; ++pass) {
+                static_for<H>([&](auto T) {
+                    const double Dz = quad_perm<2, 2, 2, 2>(D[T]);
+                    const double mE = fmax(E0[T], E1[T]);
+                    const double mEx = quad_perm<0, 0, 0, 0>(mE), mEy = quad_perm<1, 1, 1, 1>(mE);
+                    const double colA = D[T] * (comp == 2 ? fmax(mu * fmax(mEx, mEy), E0[T]) : mE);
+                    const double colP = csc * D[T] * m[T];
+                    const double dtmp = 1.0 / sqrt(limit_scaling(fmax(colP, colA)));
+                    const double rowf = comp == 2 ? D[T] : fmax(D[T], mu * Dz);
+                    const double e0 = 1.0 / sqrt(limit_scaling(E0[T] * rowf));
+                    const double e1 = 1.0 / sqrt(limit_scaling(E1[T] * rowf));
+                    D[T] *= dtmp; E0[T] *= e0; E1[T] *= e1;
+                });
+                sweep(m);
+                double sum = 0.0, nq = 0.0;
+#pragma unroll
+                for (int t = 0; t < H; ++t) {
+                    sum += csc * D[t] * m[t];
+                    nq = fmax(nq, fabs(csc * D[t] * g[t]));
+                }
+                const double mean = row_allsum(sum) / double(12 * H);
+                nq = limit_scaling(row_allmax(nq));
+                const double ct = 1.0 / limit_scaling(fmax(mean, nq));
+                csc *= ct;
+            }
+        }
+        cinv = 1.0 / csc;
+        qd = csc * q2s;
+
+        // ---------------------------------------------------------------- hot state of the ADMM loop
+        // The iteration is carried in UNSCALED variables so that the Ruiz factors drop out of the hot loop:
+        //   xh = D x_s (world-frame forces), wh = w_s / E with w_s = z_s + y_s / rho.  OSQP's pair (z, y) is a function
+        //   of w alone after the first iteration:  z = Pi(w),  y = rho (w - z)  (update_z / update_y), and
+        //   w+ = w + alpha (z~ - Pi(w)).  In unscaled variables the projection uses the constant physical bounds, the
+        //   only scaling-dependent per-row datum is rr = E^2 rho_row, and the only per-variable one is sigma D^-2.
+        // Per horizon step and lane: xh, wh0, wh1, rr0, rr1, dI2 (6 doubles) in VGPRs; c*g lives in LDS.
+        bounds_from_contact((act && io.contact[quad]) ? 1.0 : 0.0);  // contacts broadcast over the horizon (S/ConvexMpc.cpp:228-245)
+        rho = P.rho0;
+        warm = P.warm_start && io.warm_x != nullptr && io.warm_y != nullptr;
+        warm_y_in = io.warm_y;
+        if (warm && io.rho_io != nullptr && *io.rho_io > 0.0) rho = *io.rho_io;
+        rho = fmin(fmax(rho, kRhoMin), kRhoMax);
+        // OSQP's first iteration starts from z0 = A x0 (not projected) and y0; with x0 = y0 = 0 and 0 inside the bounds it
+        // coincides with the generic w-form iteration from w = 0
+        first_special = warm || !(P.fz_min <= 0.0 && P.fz_max >= 0.0);
+        eqmask = 0;
+        row_sync();  // the Ruiz D table (aliased into the factor region) is dead from here on
+        static_for<H>([&](auto T) {
+            constexpr int t = A1_CV(T);
+            const bool eq = comp == 2 && (E0[t] * hi_u - E0[t] * lo_u < kRhoTol);
+            if (eq) eqmask |= 1u << t;
+            rr0[t] = E0[t] * E0[t] * (eq ? kRhoEqOverIneq * rho : rho);
+            rr1[t] = E1[t] * E1[t] * rho;
+            const double di = 1.0 / D[t];
+            dI2[t] = di * di;
+            xh[t] = (warm && act) ? io.warm_x[t * 12 + ci] : 0.0;  // x_s = D^-1 x  <=>  xh = x
+            wh0[t] = 0.0; wh1[t] = 0.0;
+            if (act) lds[L::CG + t * 12 + ci] = csc * g[t];          // D^-1 q_s = c g
+        });
+        row_sync();
+        iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false;
     }
-    const double cinv = 1.0 / csc;
 
-    // ---------------------------------------------------------------- hot state of the ADMM loop
-    // The iteration is carried in UNSCALED variables so that the Ruiz factors drop out of the hot loop:
-    //   xh = D x_s (world-frame forces), wh = w_s / E with w_s = z_s + y_s / rho.  OSQP's pair (z, y) is a function
-    //   of w alone after the first iteration:  z = Pi(w),  y = rho (w - z)  (update_z / update_y), and
-    //   w+ = w + alpha (z~ - Pi(w)).  In unscaled variables the projection uses the constant physical bounds, the
-    //   only scaling-dependent per-row datum is rr = E^2 rho_row, and the only per-variable one is sigma D^-2.
-    // Per horizon step and lane: xh, wh0, wh1, rr0, rr1, dI2 (6 doubles) in VGPRs; c*g lives in LDS.
-    double xh[H], wh0[H], wh1[H], rr0[H], rr1[H], dI2[H];
-    const double cf = (act && io.contact[quad]) ? 1.0 : 0.0;  // contacts broadcast over the horizon (S/ConvexMpc.cpp:228-245)
-    const double lo_u = P.fz_min * cf, hi_u = P.fz_max * cf;
-    // physical bounds of my two rows: slot 0 = [fx+mu fz >= 0 | fy+mu fz >= 0 | fz in [lo,hi]], slot 1 = [.. <= 0]
-    const double lb0 = comp == 2 ? lo_u : 0.0, ub0 = comp == 2 ? hi_u : kInfty;
-    unsigned eqmask = 0;  // bit t: my slot-0 row at step t is an equality row (swing leg: l = u = 0; auxil.c set_rho_vec)
-    double rho = P.rho0;
-    const bool warm = P.warm_start && io.warm_x != nullptr && io.warm_y != nullptr;
-    if (warm && io.rho_io != nullptr && *io.rho_io > 0.0) rho = *io.rho_io;
-    rho = fmin(fmax(rho, kRhoMin), kRhoMax);
-    // reference row order inside a (step, leg) block: [fx+mu fz, fx-mu fz, fy+mu fz, fy-mu fz, fz]
-    const int r0 = comp == 0 ? 0 : (comp == 1 ? 2 : 4), r1 = comp == 0 ? 1 : 3;
-    row_sync();  // the Ruiz D table (aliased into the factor region) is dead from here on
-    static_for<H>([&](auto T) {
-        constexpr int t = A1_CV(T);
-        const bool eq = comp == 2 && (E0[t] * hi_u - E0[t] * lo_u < kRhoTol);
-        if (eq) eqmask |= 1u << t;
-        rr0[t] = E0[t] * E0[t] * (eq ? kRhoEqOverIneq * rho : rho);
-        rr1[t] = E1[t] * E1[t] * rho;
-        const double di = 1.0 / D[t];
-        dI2[t] = di * di;
-        xh[t] = (warm && act) ? io.warm_x[t * 12 + ci] : 0.0;  // x_s = D^-1 x  <=>  xh = x
-        wh0[t] = 0.0; wh1[t] = 0.0;                              // defined by the first iteration
-        if (act) lds[L::CG + t * 12 + ci] = csc * g[t];          // D^-1 q_s = c g
-    });
-    row_sync();
+    // ================================================================================ hand-off between the two kernels
+    A1_DEV void save_prepared(double* __restrict__ p) const {  // p: this QP's Prep<H>::STRIDE doubles
+        static_for<H>([&](auto T) {
+            constexpr int t = A1_CV(T);
+            p[(PR::XH + t) * 16 + ln] = xh[t];
+            p[(PR::RR0 + t) * 16 + ln] = rr0[t];
+            p[(PR::RR1 + t) * 16 + ln] = rr1[t];
+            p[(PR::DI2 + t) * 16 + ln] = dI2[t];
+            p[(PR::CG + t) * 16 + ln] = act ? lds[L::CG + t * 12 + ci] : 0.0;
+        });
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p[(PR::BT + k) * 16 + ln] = Bt[k];
+        p[PR::CSC * 16 + ln] = csc; p[PR::CY * 16 + ln] = cy; p[PR::SY * 16 + ln] = sy; p[PR::RHO * 16 + ln] = rho;
+        p[PR::LO * 16 + ln] = lo_u; p[PR::HI * 16 + ln] = hi_u;
+        p[PR::EQ * 16 + ln] = static_cast<double>(eqmask);
+        p[PR::FLAGS * 16 + ln] = (warm ? 1.0 : 0.0) + (first_special ? 2.0 : 0.0);
+    }
+    A1_DEV void load_prepared(const double* __restrict__ p, const ProblemIO& io) {
+        row_sync();  // the previous QP's LDS image is dead
+        static_for<H>([&](auto T) {
+            constexpr int t = A1_CV(T);
+            xh[t] = p[(PR::XH + t) * 16 + ln];
+            rr0[t] = p[(PR::RR0 + t) * 16 + ln];
+            rr1[t] = p[(PR::RR1 + t) * 16 + ln];
+            dI2[t] = p[(PR::DI2 + t) * 16 + ln];
+            wh0[t] = 0.0; wh1[t] = 0.0;
+            if (act) lds[L::CG + t * 12 + ci] = p[(PR::CG + t) * 16 + ln];
+        });
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            Bt[k] = p[(PR::BT + k) * 16 + ln];
+            if (act) lds[L::BL + k * 12 + ci] = Bt[k];
+        }
+        csc = p[PR::CSC * 16 + ln]; cinv = 1.0 / csc; qd = csc * q2s;
+        set_rotation(p[PR::CY * 16 + ln], p[PR::SY * 16 + ln]);
+        rho = p[PR::RHO * 16 + ln];
+        lo_u = p[PR::LO * 16 + ln]; hi_u = p[PR::HI * 16 + ln];
+        lb0 = comp == 2 ? lo_u : 0.0; ub0 = comp == 2 ? hi_u : kInfty;
+        eqmask = static_cast<unsigned>(p[PR::EQ * 16 + ln]);
+        const int fl = static_cast<int>(p[PR::FLAGS * 16 + ln]);
+        warm = fl & 1; first_special = (fl & 2) != 0;
+        warm_y_in = io.warm_y;
+        row_sync();
+        iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false;
+    }
 
-    // ---------------------------------------------------------------- Riccati factorisation of
+    // ================================================================================ Riccati factorisation of
     //   M = c P + sigma D^-2 + A' (E^2 rho) A      (K_s = D M D is OSQP's reduced KKT matrix)
-    const double qd = csc * q2s;
-    int nfact = 0;
-    bool fac_ok = true;
-    auto factorize = [&]() {
+    A1_DEV void factorize() {
         ++nfact;
         const double sigma_f = row_opaque(P.sigma);
         // stage W_t = c R + sigma D^-2 + A_t' (E^2 rho) A_t  (block-diagonal, 3x3 per leg) into slot t
@@ -464,17 +577,19 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
             row_sync();  // everybody holds W_t before the slot is overwritten
             // G = A' P_{t+1}  (rows mixed across lanes), then GA = G A (columns, lane-local)
             double G[12];
-            static_for<12>([&](auto J) { G[J] = opAT(Pn[J]); });
+            static_for<12>([&](auto J) { G[J] = opAT(row_dpp_ready(Pn[J])); });
             // F' = G(:,6:12) B~  (state row-owner)  and  Y = P_{t+1}(6:12,6:12) B~  (valid on the wrench lanes)
             double Ft[12], Y[12];
 #pragma unroll
             for (int b = 0; b < 12; ++b) { Ft[b] = 0.0; Y[b] = 0.0; }
             static_for<6>([&](auto K) {
+                double Bk[12];
+#pragma unroll
+                for (int b = 0; b < 12; ++b) Bk[b] = lds[L::BL + K * 12 + b];
 #pragma unroll
                 for (int b = 0; b < 12; ++b) {
-                    const double bk = lds[L::BL + K * 12 + b];
-                    Ft[b] = fma(G[6 + K], bk, Ft[b]);
-                    Y[b] = fma(Pn[6 + K], bk, Y[b]);
+                    Ft[b] = fma(G[6 + K], Bk[b], Ft[b]);
+                    Y[b] = fma(Pn[6 + K], Bk[b], Y[b]);
                 }
             });
             G[6] += dt * (cy * G[0] - sy * G[1]);
@@ -486,13 +601,6 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
             // S = W_t + B~' Y   (force row-owner)
             double S[12];
             static_for<12>([&](auto B) {
-                double a0 = 0.0, a1 = 0.0;
-                a0 = fma(Bt[0], bc<6>(Y[B]), a0);
-                a1 = fma(Bt[1], bc<7>(Y[B]), a1);
-                a0 = fma(Bt[2], bc<8>(Y[B]), a0);
-                a1 = fma(Bt[3], bc<9>(Y[B]), a1);
-                a0 = fma(Bt[4], bc<10>(Y[B]), a0);
-                a1 = fma(Bt[5], bc<11>(Y[B]), a1);
                 double w = 0.0;
                 if (act) {
                     if (B == ci) w = wd;
@@ -500,20 +608,20 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
                     else if (comp == 2 && B == 3 * quad) w = wox;
                     else if (comp == 2 && B == 3 * quad + 1) w = woy;
                 }
-                S[B] = a0 + a1 + w;
+                S[B] = dot_bc<6>(Bt, row_dpp_ready(Y[B])) + w;
             });
-            // in-place Gauss-Jordan inverse of the SPD 12x12 (row k broadcast, no pivoting)
+            // in-place Gauss-Jordan inverse of the SPD 12x12 (no pivoting).  Pivot k: row k is scaled by 1/p, every other row i
+            // subtracts S_ik/p times row k.  Both are  S_ij += m_i * S_kj  with m_k = 1/p - 1 and m_i = -S_ik/p, i.e. ONE
+            // v_fmac_f64_dpp per element whose DPP source is the element's own register read from lane k.
             static_for<12>([&](auto K) {
                 const double piv = bc<K>(S[K]);
                 if (!(piv > 0.0)) fac_ok = false;
                 const double pinv = 1.0 / piv;
                 const double f = S[K];
                 const bool mine = act && ci == K;
+                const double mlt = mine ? pinv - 1.0 : -f * pinv;
                 static_for<12>([&](auto J) {
-                    if constexpr (A1_CV(J) != A1_CV(K)) {
-                        const double rk = bc<K>(S[J]) * pinv;
-                        S[J] = mine ? rk : S[J] - f * rk;
-                    }
+                    if constexpr (A1_CV(J) != A1_CV(K)) fma_bcast<lane_of(A1_CV(K))>(S[J], mlt, S[J]);
                 });
                 S[K] = mine ? pinv : -f * pinv;
             });
@@ -528,11 +636,15 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
 #pragma unroll
             for (int a = 0; a < 12; ++a) Kt[a] = 0.0;
             static_for<12>([&](auto B) {
+                constexpr int bb = A1_CV(B);
+                double Sb[12];
                 static_for<12>([&](auto A_) {
-                    constexpr int aa = A1_CV(A_), bb = A1_CV(B);
+                    constexpr int aa = A1_CV(A_);
                     constexpr int hi = aa > bb ? aa : bb, lo = aa > bb ? bb : aa;
-                    Kt[A_] = fma(Ft[B], slot[L::K_SZ + hi * (hi + 1) / 2 + lo], Kt[A_]);
+                    Sb[aa] = slot[L::K_SZ + hi * (hi + 1) / 2 + lo];
                 });
+#pragma unroll
+                for (int a = 0; a < 12; ++a) Kt[a] = fma(Ft[bb], Sb[a], Kt[a]);
             });
             if (act) {
 #pragma unroll
@@ -542,33 +654,36 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
             // P_t = c Q + A' P_{t+1} A - F' K
             if (t > 0) {
                 static_for<12>([&](auto J) {
+                    double Kj[12];
+#pragma unroll
+                    for (int a = 0; a < 12; ++a) Kj[a] = slot[a * L::KSTR + J];
                     double a0 = G[J], a1 = 0.0;
                     static_for<6>([&](auto A_) {
-                        a0 = fma(-Ft[2 * A_], slot[(2 * A_) * L::KSTR + J], a0);
-                        a1 = fma(-Ft[2 * A_ + 1], slot[(2 * A_ + 1) * L::KSTR + J], a1);
+                        a0 = fma(-Ft[2 * A_], Kj[2 * A_], a0);
+                        a1 = fma(-Ft[2 * A_ + 1], Kj[2 * A_ + 1], a1);
                     });
                     Pn[J] = a0 + a1 + ((act && ci == J) ? qd : 0.0);
                 });
             }
         }
-    };
+        need_factor = false;
+        if (!fac_ok) { status = A1MPC_NON_CVX; done = true; }
+    }
 
-    // per-lane LDS offsets of my row of the packed symmetric S_t^{-1} and of my row of K_t
-    const int krow = ci * L::KSTR;
-
-    // One ADMM iteration (osqp.c: update_xz_tilde, update_x, update_z, update_y).  The linear system M v = b is
-    // solved by the two Riccati sweeps; the right-hand side is formed inside the backward sweep and the x / w
-    // updates consume v_t inside the forward sweep, so only d_t crosses between the sweeps.
-    // FIRST: OSQP's iteration 1 starts from z0 = A x0 (not projected) and y0 (warm start) or zeros.
-    auto admm_iteration = [&](auto FIRST_) {
-        constexpr bool FIRST = A1_CV(FIRST_);
+    // ================================================================================ one ADMM iteration
+    // (osqp.c: update_xz_tilde, update_x, update_z, update_y).  The linear system M v = b is solved by the two Riccati
+    // sweeps; the right-hand side is formed inside the backward sweep and the x / w updates consume v_t inside the
+    // forward sweep, so only d_t crosses between the sweeps.
+    // FIRST: OSQP's iteration 1 starts from z0 = A x0 (not projected) and y0 (warm start).
+    template <bool FIRST>
+    A1_DEV void admm_iteration() {
         // Loop-invariant scalars are laundered through row_opaque() once per iteration: otherwise LICM hoists every
         // per-step product that only depends on them out of the ADMM loop and the register file overflows.
         const double sigma_l = row_opaque(P.sigma), lb0_l = row_opaque(lb0), ub0_l = row_opaque(ub0);
         const double al = P.alpha, oma = 1.0 - P.alpha;
         const double muz = comp == 2 ? mu : 0.0, mux = comp < 2 ? mu : 0.0, al1 = comp < 2 ? al : 0.0;  // selects folded into multipliers
         double d[H];
-        double pv = 0.0;  // costate p_{t+1}, state layout
+        double pv = row_dpp_ready(0.0);  // costate p_{t+1}, state layout
         static_for<H>([&](auto TT) {
             constexpr int t = H - 1 - A1_CV(TT);
             const double* slot = lds + L::FAC + t * L::SLOT;
@@ -586,8 +701,8 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
                 const double xz = quad_perm<2, 2, 2, 2>(xh[t]);
                 double yw0 = 0.0, yw1 = 0.0;
                 if (warm && act) {
-                    yw0 = io.warm_y[t * 20 + 5 * quad + r0];
-                    if (comp < 2) yw1 = io.warm_y[t * 20 + 5 * quad + r1];
+                    yw0 = warm_y_in[t * 20 + 5 * quad + r0];
+                    if (comp < 2) yw1 = warm_y_in[t * 20 + 5 * quad + r1];
                 }
                 t0 = rr0[t] * (comp == 2 ? xh[t] : fma(mu, xz, xh[t])) - csc * yw0;
                 t1 = rr1[t] * fma(-mu, xz, xh[t]) - csc * yw1;
@@ -601,23 +716,10 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
             const double at = fma(muz, smx + smy, t0 + t1);  // fz lanes: t1 == 0 (rr1 == 0); fx/fy lanes: muz == 0
             const double bt = fma(sigma_l * dI2[t], xh[t], at - cgt);
             const double r = row_dpp_ready(bt - BtT(pv));
-            double a0 = 0.0, a1 = 0.0;
-            static_for<6>([&](auto J) {
-                constexpr int b0 = 2 * A1_CV(J), b1 = b0 + 1;
-                fbc<b0>(a0, Sr[b0], r);
-                fbc<b1>(a1, Sr[b1], r);
-            });
-            d[t] = a0 + a1;
-            if constexpr (t > 0) {
-                double c0 = opAT(pv), c1 = 0.0;
-                static_for<6>([&](auto J) {
-                    fbc<2 * J>(c0, Kc[2 * J], r);
-                    fbc<2 * J + 1>(c1, Kc[2 * J + 1], r);
-                });
-                pv = c0 + c1;
-            }
+            d[t] = dot_bc<0>(Sr, r);
+            if constexpr (t > 0) pv = row_dpp_ready(dot_bc<0>(Kc, r, opAT(pv)));
         });
-        double s = 0.0;  // state x_t of the LQ roll-out (x_0 = 0)
+        double s = row_dpp_ready(0.0);  // state x_t of the LQ roll-out (x_0 = 0)
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
             const double* slot = lds + L::FAC + t * L::SLOT;
@@ -629,23 +731,12 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
                 if constexpr (t < H - 1) Br[b] = brow[b];
             });
             double v = d[t];
-            if constexpr (t > 0) {
-                double a0 = 0.0, a1 = 0.0;
-                static_for<6>([&](auto J) {
-                    fbc<2 * J>(a0, Kr[2 * J], s);
-                    fbc<2 * J + 1>(a1, Kr[2 * J + 1], s);
-                });
-                v -= a0 + a1;
-            }
+            if constexpr (t > 0) v -= dot_bc<0>(Kr, s);
             v = act ? v : 0.0;  // pad lanes carry no force
             if constexpr (t < H - 1) {
-                const double vr = row_dpp_ready(v);
-                double a0 = 0.0, a1 = 0.0;
-                static_for<6>([&](auto J) {
-                    fbc<2 * J>(a0, Br[2 * J], vr);
-                    fbc<2 * J + 1>(a1, Br[2 * J + 1], vr);
-                });
-                s = row_dpp_ready(opA(s) + (wl ? a0 + a1 : 0.0));
+                const double as = opA(s);
+                const double asb = dot_bc<0>(Br, row_dpp_ready(v), as);
+                s = row_dpp_ready(wl ? asb : as);
             }
             // z~ = A v (unscaled), then update_x / update_z / update_y in the w form
             const double vz = quad_perm<2, 2, 2, 2>(v);
@@ -655,8 +746,8 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
                 const double xz = quad_perm<2, 2, 2, 2>(xh[t]);
                 double yw0 = 0.0, yw1 = 0.0;
                 if (warm && act) {
-                    yw0 = io.warm_y[t * 20 + 5 * quad + r0];
-                    if (comp < 2) yw1 = io.warm_y[t * 20 + 5 * quad + r1];
+                    yw0 = warm_y_in[t * 20 + 5 * quad + r0];
+                    if (comp < 2) yw1 = warm_y_in[t * 20 + 5 * quad + r1];
                 }
                 const double z00 = comp == 2 ? xh[t] : fma(mu, xz, xh[t]), z01 = fma(-mu, xz, xh[t]);
                 wh0[t] = al * av0 + oma * z00 + (rr0[t] > 0.0 ? csc * yw0 / rr0[t] : 0.0);
@@ -668,27 +759,23 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
             }
             xh[t] = al * v + oma * xh[t];
         });
-    };
+    }
 
-    // ---------------------------------------------------------------- residuals (auxil.c compute_pri_res/compute_dua_res/...)
-    struct Info {
-        double pri_res, dua_res, nEz, nEAx, nDq, nDAty, nDPx;  // unscaled
-        double s_pri, s_dua, s_z, s_Ax, s_q, s_Aty, s_Px;      // scaled (rho estimate)
-    } info;
-    auto update_info = [&]() {
+    // ================================================================================ residuals (auxil.c compute_pri_res / compute_dua_res / ...)
+    A1_DEV void update_info() {
         const double rho_c = row_opaque(rho), one_c = row_opaque(1.0);  // keep the cold path's invariants out of the hot loop's registers
         double Pu[H];
         {   // P u = B_qp' Q (B_qp u) + R u : roll-out, then adjoint
             double sv[H];
-            double s = 0.0;
+            double s = row_dpp_ready(0.0);
             static_for<H>([&](auto T) {
-                s = opA(s) + Bu(xh[T]);
+                s = row_dpp_ready(opA(s) + Bu(row_dpp_ready(xh[T])));
                 sv[T] = q2s * s;
             });
-            double lam = 0.0;
+            double lam = row_dpp_ready(0.0);
             static_for<H>([&](auto TT) {
                 constexpr int t = H - 1 - A1_CV(TT);
-                lam = sv[t] + opAT(lam);
+                lam = row_dpp_ready(sv[t] + opAT(lam));
                 Pu[t] = fma(r2a, xh[t], BtT(lam));
             });
         }
@@ -741,11 +828,10 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
         info.s_q = row_allmax(act ? m_q : 0.0);
         info.s_Aty = row_allmax(act ? m_Aty : 0.0);
         info.s_Px = row_allmax(act ? m_Px : 0.0);
-    };
-    int32_t status = A1MPC_UNSOLVED;
+    }
     // auxil.c check_termination (feasibility certificates are not evaluated: u = 0 is always feasible and
     // P > 0, so this QP family is never primal or dual infeasible)
-    auto check_termination = [&](bool approximate) -> bool {
+    A1_DEV bool check_termination(bool approximate) {
         double ea = P.eps_abs, er = P.eps_rel;
         if (!(info.pri_res <= kInfty) || !(info.dua_res <= kInfty)) { status = A1MPC_NON_CVX; return true; }
         if (approximate) { ea *= 10; er *= 10; }
@@ -753,28 +839,20 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
         const bool drc = info.dua_res < ea + er * cinv * fmax(fmax(info.nDq, info.nDAty), info.nDPx);
         if (prc && drc) { status = approximate ? A1MPC_SOLVED_INACCURATE : A1MPC_SOLVED; return true; }
         return false;
-    };
+    }
 
-    // ---------------------------------------------------------------- ADMM loop (osqp.c osqp_solve)
-    // Segment structure: the hot loop is a plain counted loop of admm_iteration() up to the next checkpoint
-    // (a multiple of check_termination / adaptive_rho_interval, or max_iter); the residual check, the rho
-    // update and the (rare) re-factorisation run between segments.  Every loop leaves through its latch only:
-    // rows of one wave finish at different iterations, and a divergent exit from the middle of a body would
-    // make the compiler copy every live-out vector on every iteration.
-    int iter = 0;
-    bool done = false, need_factor = true;
-    do {
-        if (need_factor) {
-            factorize();
-            need_factor = false;
-            if (!fac_ok) { status = A1MPC_NON_CVX; done = true; }
-        }
+    // ================================================================================ one segment of osqp_solve:
+    // (re-)factorise if needed, iterate up to the next checkpoint (a multiple of check_termination / adaptive_rho_interval, or
+    // max_iter), then the residual check and the rho update.  Everything that can differ between the rows of a wave
+    // (termination, rho update) happens at segment boundaries, so rows that run advance() in lock-step stay aligned.
+    A1_DEV void advance() {
+        if (need_factor) factorize();
         if (!done) {
             int next = P.max_iter;
             if (P.check_every > 0) next = imin(next, (iter / P.check_every + 1) * P.check_every);
             if (P.adaptive_rho && P.adaptive_rho_every > 0) next = imin(next, (iter / P.adaptive_rho_every + 1) * P.adaptive_rho_every);
-            if (iter == 0) { admm_iteration(std::true_type{}); iter = 1; }
-            for (int k = iter; k < next; ++k) admm_iteration(std::false_type{});
+            if (iter == 0 && first_special) { admm_iteration<true>(); iter = 1; }
+            for (int k = iter; k < next; ++k) admm_iteration<false>();
             iter = next;
             const bool can_check = P.check_every > 0 && (iter % P.check_every) == 0;
             const bool do_rho = P.adaptive_rho && P.adaptive_rho_every > 0 && (iter % P.adaptive_rho_every) == 0;
@@ -808,39 +886,124 @@ A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, con
                 }
             }
         }
-    } while (!done);
-
-    // ---------------------------------------------------------------- store_solution + first-step GRFs in the body frame
-    const bool nanout = status == A1MPC_NON_CVX;
-    const double nanv = nan("");
-    {
-        const double f = nanout ? nanv : xh[0];
-        const double f0 = quad_perm<0, 0, 0, 0>(f), f1 = quad_perm<1, 1, 1, 1>(f), f2 = quad_perm<2, 2, 2, 2>(f);
-        const bool bad = (f0 != f0) || (f1 != f1) || (f2 != f2);
-        if (act) {  // R' f (S/A1RobotControl.cpp:558-561); non-finite solution -> zeros + status
-            const double gb = io.R[0 * 3 + comp] * f0 + io.R[1 * 3 + comp] * f1 + io.R[2 * 3 + comp] * f2;
-            io.grf[3 * quad + comp] = bad ? 0.0 : gb;
-        }
     }
-    static_for<H>([&](auto T) {
-        constexpr int t = A1_CV(T);
-        if (act) {
-            const double xu = nanout ? nanv : xh[t];
-            if (io.u_full) io.u_full[t * 12 + ci] = xu;
-            if (io.warm_x) io.warm_x[t * 12 + ci] = xu;
-            if (io.warm_y) {  // y = c^-1 E y_s = c^-1 rr (wh - Pi(wh))
-                const double z0 = fmin(fmax(wh0[t], lb0), ub0), z1 = fmin(wh1[t], 0.0);
-                io.warm_y[t * 20 + 5 * quad + r0] = nanout ? nanv : cinv * rr0[t] * (wh0[t] - z0);
-                if (comp < 2) io.warm_y[t * 20 + 5 * quad + r1] = nanout ? nanv : cinv * rr1[t] * (wh1[t] - z1);
+    // fused driver: every loop leaves through its latch only (a divergent exit from the middle of a body makes the compiler
+    // copy every live-out vector on every iteration)
+    A1_DEV void solve() {
+        do { advance(); } while (!done);
+    }
+
+    // ================================================================================ store_solution + first-step GRFs in the body frame
+    A1_DEV void write_outputs(const ProblemIO& io) const {
+        const bool nanout = status == A1MPC_NON_CVX;
+        const double nanv = nan("");
+        {
+            const double f = nanout ? nanv : xh[0];
+            const double f0 = quad_perm<0, 0, 0, 0>(f), f1 = quad_perm<1, 1, 1, 1>(f), f2 = quad_perm<2, 2, 2, 2>(f);
+            const bool bad = (f0 != f0) || (f1 != f1) || (f2 != f2);
+            if (act) {  // R' f (S/A1RobotControl.cpp:558-561); non-finite solution -> zeros + status
+                const double gb = io.R[0 * 3 + comp] * f0 + io.R[1 * 3 + comp] * f1 + io.R[2 * 3 + comp] * f2;
+                io.grf[3 * quad + comp] = bad ? 0.0 : gb;
             }
         }
-    });
-    if (ln == 0) {
-        if (io.iters) *io.iters = iter;
-        if (io.status) *io.status = status;
-        if (io.nfact) *io.nfact = nfact;
-        if (io.rho_io) *io.rho_io = rho;
+        static_for<H>([&](auto T) {
+            constexpr int t = A1_CV(T);
+            if (act) {
+                const double xu = nanout ? nanv : xh[t];
+                if (io.u_full) io.u_full[t * 12 + ci] = xu;
+                if (io.warm_x) io.warm_x[t * 12 + ci] = xu;
+                if (io.warm_y) {  // y = c^-1 E y_s = c^-1 rr (wh - Pi(wh))
+                    const double z0 = fmin(fmax(wh0[t], lb0), ub0), z1 = fmin(wh1[t], 0.0);
+                    io.warm_y[t * 20 + 5 * quad + r0] = nanout ? nanv : cinv * rr0[t] * (wh0[t] - z0);
+                    if (comp < 2) io.warm_y[t * 20 + 5 * quad + r1] = nanout ? nanv : cinv * rr1[t] * (wh1[t] - z1);
+                }
+            }
+        });
+        if (ln == 0) {
+            if (io.iters) *io.iters = iter;
+            if (io.status) *io.status = status;
+            if (io.nfact) *io.nfact = nfact;
+            if (io.rho_io) *io.rho_io = rho;
+        }
     }
+};
+
+// arguments of a batch launch (device pointers; per-QP records are contiguous, QP b at base + b * record size)
+struct BatchArgs {
+    DeviceParams P;
+    const double* tab;
+    int32_t n;
+    const double *root_acc, *Rz;  // balance mode only
+    const double *x0, *xref, *R, *foot;
+    const uint8_t* contact;
+    double *grf, *u_full, *warm_x, *warm_y, *rho;
+    int32_t *iters, *status, *nfact;
+};
+template <int H, int MODE>
+A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
+    ProblemIO io;
+    io.root_acc = MODE == kModeBalance ? a.root_acc + b * 6 : nullptr;
+    io.Rz = MODE == kModeBalance ? a.Rz + b * 9 : nullptr;
+    io.x0 = MODE == kModeMpc ? a.x0 + b * 13 : nullptr;
+    io.xref = MODE == kModeMpc ? a.xref + b * 13 * H : nullptr;
+    io.R = a.R + b * 9;
+    io.foot = a.foot + b * 12;
+    io.contact = a.contact + b * 4;
+    io.grf = a.grf + b * 12;
+    io.u_full = a.u_full ? a.u_full + b * 12 * H : nullptr;
+    io.warm_x = a.warm_x ? a.warm_x + b * 12 * H : nullptr;
+    io.warm_y = a.warm_y ? a.warm_y + b * 20 * H : nullptr;
+    io.rho_io = a.rho ? a.rho + b : nullptr;
+    io.iters = a.iters ? a.iters + b : nullptr;
+    io.status = a.status ? a.status + b : nullptr;
+    io.nfact = a.nfact ? a.nfact + b : nullptr;
+    return io;
+}
+
+// split pipeline, kernel 1: formation + Ruiz for QP b, prepared state to global memory
+template <int H>
+A1_DEV void setup_row(const BatchArgs& a, int64_t b, double* __restrict__ lds, double* __restrict__ prep) {
+    RowSolver<H, kModeMpc, true> S(a.P, a.tab, lds);
+    S.setup(make_io<H, kModeMpc>(a, b));
+    S.save_prepared(prep + b * Prep<H>::STRIDE);
+}
+
+// split pipeline, kernel 2: a persistent row.  It pulls prepared QPs from a shared counter and advances them one
+// checkpoint-aligned segment per loop trip; a row whose QP has converged writes it out and pulls the next one at the next
+// trip, so the rows of a wave never wait for each other's iteration counts -- only for each other's (rare) re-factorisations.
+template <int H>
+A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* __restrict__ counter, double* __restrict__ lds) {
+    RowSolver<H, kModeMpc> S(a.P, a.tab, lds);
+    bool alive = true, need_new = true, have = false;
+    int64_t cur = 0;
+    while (alive) {
+        if (need_new) {
+            if (have) S.write_outputs(make_io<H, kModeMpc>(a, cur));
+            double v = 0.0;
+            if (S.ln == 0) v = static_cast<double>(row_atomic_inc(counter));
+            cur = static_cast<int64_t>(row_bcast<0>(v));
+            if (cur >= a.n) {
+                alive = false;
+            } else {
+                S.load_prepared(prep + cur * Prep<H>::STRIDE, make_io<H, kModeMpc>(a, cur));
+                have = true;
+                need_new = false;
+            }
+        }
+        if (alive) {
+            S.advance();
+            need_new = S.done;
+        }
+    }
+}
+
+// the fused path: one QP from inputs to outputs (small batches, the batch-1 latency path, the CPU test double)
+template <int H, int MODE = kModeMpc>
+A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, const ProblemIO& io, double* __restrict__ lds) {
+    RowSolver<H, MODE> S(P, tab, lds);
+    S.setup(io);
+    S.solve();
+    S.write_outputs(io);
 }
 
 }  // namespace a1mpc

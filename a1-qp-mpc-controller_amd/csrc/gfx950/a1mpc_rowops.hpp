@@ -49,6 +49,7 @@ A1_DEV void row_sync() {
 // acc += m * (lane L of my row's x) as ONE instruction: v_fmac_f64 with a DPP row_newbcast source (gfx90a+: DP-ALU
 // DPP supports exactly this control).  hipcc emits v_mov_b64_dpp + v_fmac_f64 for the intrinsic form and does not
 // combine them, which doubles the instruction count and the dependency depth of every 12x12 mat-vec.
+// (v_fmac_f64 is the only FP64 arithmetic op with a VOP2 encoding, hence the only one with a DPP form: no v_mul_f64_dpp.)
 // Hazard contract (hipcc pads nothing inside asm): a VGPR written by a VALU instruction needs 2 wait states before
 // a DPP instruction reads it -- pass x through row_dpp_ready() once after computing it and before its first fma_bcast.
 template <int L>
@@ -66,5 +67,9 @@ A1_DEV double row_opaque(double v) {
     asm volatile("" : "+v"(v));
     return v;
 }
+
+
+// returns the old value; called by one lane of a row (the work queue of the persistent ADMM rows)
+A1_DEV int row_atomic_inc(int* p) { return atomicAdd(p, 1); }
 
 }  // namespace a1mpc

@@ -67,6 +67,27 @@ def latency_probe(pkg, nticks=1500):
             "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "max_ms": float(lat.max())}
 
 
+def batch_sweep(pkg, local, sizes=(1024, 16384, 65536)):
+    """Extra information (not `value`): the same workload generator at other batch sizes of BASELINE's 1..65536 range."""
+    import torch
+    out = {}
+    dev = torch.device("cuda", local)
+    st = torch.cuda.Stream(device=dev)
+    for n in sizes:
+        sc = pkg.scenarios.config3_random_flat(nb=n)
+        cfg = pkg.make_config(sc["params"], HORIZON, warm_start=0)
+        d = {k: torch.from_numpy(sc[k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")}
+        grf = torch.zeros((n, 12), dtype=torch.float64, device=dev)
+        it = torch.zeros(n, dtype=torch.int32, device=dev); stt = torch.zeros(n, dtype=torch.int32, device=dev)
+        with pkg.Engine(cfg, n, local) as eng:
+            ms = []
+            for _ in range(4):
+                eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, it, stt, stream=st.cuda_stream)
+                ms.append(eng.last_kernel_ms())
+        out[str(n)] = {"kernel_ms": float(np.median(ms[1:])), "solves_per_s": n / (float(np.median(ms[1:])) * 1e-3)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,13 +177,14 @@ def main():
                        "mean_iters": float(it.mean()), "max_iters": int(it.max()), "solved_frac": float((stt == 1).mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "a1mpc_solve_kernel<10,0>", "avg_kernel_ms": avg_ms, "algorithmic_flops_per_launch": flops,
+                         "kernel": "a1mpc_setup_kernel<10> + a1mpc_admm_kernel<10,4> (one launch = both)", "avg_kernel_ms": avg_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
                          "note": "FP64 VALU issue/latency-bound (no MFMA used, DESIGN.md 3); flops = SURVEY 8(d) F(h,iters,nfact) summed over the launch; "
                                  "traffic = FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_summary.json (same workload)"},
         }
         if not args.no_latency:
             out["latency"] = latency_probe(pkg)
+            out["throughput_by_batch"] = batch_sweep(pkg, local)
         if not args.no_cpu_baseline:
             out["cpu_baseline"], _ = cpu_baseline(pkg, sc)
         print(json.dumps(out), flush=True)

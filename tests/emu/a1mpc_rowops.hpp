@@ -36,4 +36,7 @@ inline void row_sync() { (void)emu_publish(0.0); }
 
 inline double row_opaque(double v) { return v; }
 
+
+inline int row_atomic_inc(int* p) { return (*p)++; }
+
 }  // namespace a1mpc

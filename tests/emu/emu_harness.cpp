@@ -132,6 +132,50 @@ static void run_batch(const DeviceParams* P, int n, const double* x0, const doub
 
 }  // namespace a1mpc
 
+namespace a1mpc {
+template <int H>
+struct SplitJob { const BatchArgs* a; double* prep; int* counter; double* lds; int64_t b; };
+template <int H>
+static void split_setup_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); setup_row<H>(*j->a, j->b, j->lds, j->prep); }
+template <int H>
+static void split_admm_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); admm_rows<H>(*j->a, j->prep, j->counter, j->lds); }
+// the split pipeline on host fibers: K1 for every QP, then `nrows` persistent rows draining the queue one after another
+template <int H>
+static void run_split(const BatchArgs& a, int nrows) {
+    std::vector<double> tab(2 * H * H);
+    fill_gamma_beta_table(H, tab.data());
+    BatchArgs aa = a; aa.tab = tab.data();
+    std::vector<double> prep((size_t)a.n * Prep<H>::STRIDE, NAN);
+    std::vector<double> lds1(LayoutSetup<H>::ROW_STRIDE), lds2(Layout<H>::ROW_STRIDE);
+    int counter = 0;
+    SplitJob<H> j{&aa, prep.data(), &counter, nullptr, 0};
+    for (int64_t b = 0; b < a.n; ++b) {
+        for (auto& v : lds1) v = NAN;
+        j.b = b; j.lds = lds1.data();
+        run_row(split_setup_entry<H>, &j);
+    }
+    for (int r = 0; r < nrows; ++r) {
+        for (auto& v : lds2) v = NAN;
+        j.lds = lds2.data();
+        run_row(split_admm_entry<H>, &j);
+    }
+}
+}  // namespace a1mpc
+extern "C" int a1mpc_emu_solve_split(const a1mpc::DeviceParams* P, int horizon, int n, int nrows, const double* x0, const double* xref,
+                                     const double* R, const double* foot, const uint8_t* contact, double* grf, double* u_full,
+                                     double* warm_x, double* warm_y, double* rho, int32_t* iters, int32_t* status, int32_t* nfact) {
+    a1mpc::BatchArgs a;
+    memset(&a, 0, sizeof a);
+    a.P = *P; a.n = n; a.x0 = x0; a.xref = xref; a.R = R; a.foot = foot; a.contact = contact; a.grf = grf; a.u_full = u_full;
+    a.warm_x = warm_x; a.warm_y = warm_y; a.rho = rho; a.iters = iters; a.status = status; a.nfact = nfact;
+    switch (horizon) {
+        case 1: a1mpc::run_split<1>(a, nrows); return 0;
+        case 10: a1mpc::run_split<10>(a, nrows); return 0;
+        case 16: a1mpc::run_split<16>(a, nrows); return 0;
+        case 20: a1mpc::run_split<20>(a, nrows); return 0;
+    }
+    return -1;
+}
 extern "C" int a1mpc_emu_solve(const a1mpc::DeviceParams* P, int horizon, int n, const double* x0, const double* xref, const double* R,
                                const double* foot, const uint8_t* contact, double* grf, double* u_full, double* warm_x,
                                double* warm_y, double* rho, int32_t* iters, int32_t* status, int32_t* nfact) {
