@@ -163,7 +163,7 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
             if n == BATCH:
-                traffic = (pm["FETCH_SIZE"]["mean"] + pm["WRITE_SIZE"]["mean"]) * 1024.0
+                traffic = float(pm["_hbm_bytes_per_solve_batch_launch"])
         except Exception:
             pass
         avg_ms = float(kern_ms.mean())

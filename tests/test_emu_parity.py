@@ -59,3 +59,26 @@ def test_emulated_all_swing_and_max_iter(oracle, scen):
     out = emu.solve(sc, 1, max_iter=30, eps_abs=1e-12, eps_rel=1e-12)
     ref = oracle_batch(oracle, sc, 1, settings=oracle.default_settings(max_iter=30, eps_abs=1e-12, eps_rel=1e-12))
     assert out["iters"][0] == 30 and out["status"][0] == ref["status"][0] and np.abs(out["u"] - ref["u"]).max() < 1e-8
+
+
+@pytest.mark.parametrize("gen,kw,n,rows", [("config3_random_flat", dict(nb=8), 7, 2), ("config4_random_h16", dict(nb=4), 3, 1)])
+def test_emulated_split_pipeline(oracle, scen, gen, kw, n, rows):
+    """set-up kernel -> prepared state in memory -> persistent ADMM rows pulling QPs from the shared counter"""
+    sc = getattr(scen, gen)(**kw)
+    out = emu.solve(sc, n, split_rows=rows)
+    ref = oracle_batch(oracle, sc, n)
+    assert (out["nfact"] == ref["nfact"]).all()
+    compare(out, ref, tol=1e-8, min_same=1.0)
+
+
+def test_emulated_split_pipeline_warm_start(oracle, scen):
+    sc = scen.config2_trot_sequence(4)
+    pr = oracle_params(oracle, sc); st = oracle.default_settings(warm_start=1)
+    wx = np.zeros(120); wy = np.zeros(200); rho = None
+    ewx = np.zeros((1, 120)); ewy = np.zeros((1, 200)); erho = np.zeros(1)
+    for t in range(4):
+        r = oracle.mpc_solve(pr, st, sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t], warm_x=wx, warm_y=wy, warm_rho=rho)
+        wx, wy, rho = r["warm_x"], r["warm_y"], r["rho"]
+        one = {k: (sc[k][t:t + 1] if k in ("x0", "xref", "R", "foot", "contact") else sc[k]) for k in sc}
+        out = emu.solve(one, 1, warm=(ewx, ewy, erho), warm_start=1, split_rows=1)
+        assert out["iters"][0] == r["info"].iters and np.abs(out["u"][0] - r["u"]).max() < 1e-8

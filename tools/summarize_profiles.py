@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Copies the rocprofv3 summaries of gpurun_out/prof_final/ into profiles/ (tracked)."""
+import collections, csv, glob, json, os, shutil
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "prof_final"); dst = os.path.join(ROOT, "profiles")
+for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(dst, "r01_kernel_stats_bench_batch4096_h10.csv"))
+for f in glob.glob(os.path.join(src, "trace", "**", "*domain_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(dst, "r01_domain_stats.csv"))
+log = os.path.join(src, "bench_under_rocprof.log")
+if os.path.exists(log):
+    lines = [l for l in open(log) if l.startswith("{")]
+    if lines:
+        open(os.path.join(dst, "r01_bench_under_rocprof.json"), "w").write(lines[-1])
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")
+        if "a1mpc" in k:
+            short = "setup_kernel" if "setup" in k else ("admm_kernel" if "admm" in k else "solve_kernel(fused)")
+            acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summ = {k: {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in d.items()} for k, d in acc.items()}
+tot = sum(summ.get(k, {}).get(c, {}).get("mean_per_launch", 0.0) for k in summ for c in ("FETCH_SIZE", "WRITE_SIZE"))
+summ["_hbm_bytes_per_solve_batch_launch"] = tot * 1024.0
+summ["_note"] = ("rocprofv3 --pmc, one counter group per pass (tools/collect_profiles.sh), 4096 QPs h=10 default OSQP settings cold start "
+                 "(tools/prof_target.py); FETCH_SIZE / WRITE_SIZE in KiB per kernel launch; one solve_batch = setup_kernel + admm_kernel. "
+                 "Reads are 8-byte per-lane accesses of per-problem records (uncalibrated w.r.t. the guide's x2 rule for 16 B/lane streams).")
+json.dump(summ, open(os.path.join(dst, "r01_pmc_summary.json"), "w"), indent=1)
+print(json.dumps(summ, indent=1)[:3000])
