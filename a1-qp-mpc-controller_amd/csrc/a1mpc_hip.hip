@@ -46,8 +46,12 @@ __global__ __launch_bounds__(64, 2) void a1mpc_setup_kernel(const KernelArgs a, 
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     const int row = static_cast<int>(threadIdx.x) >> 4;
     const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + row;
+    // the (alpha/beta, beta) table is read H times per Ruiz sweep: stage it in LDS behind the four rows' regions
+    double* tabl = a1mpc_lds + 4 * LayoutSetup<H>::ROW_STRIDE;
+    for (int i = static_cast<int>(threadIdx.x); i < 2 * H * H; i += 64) tabl[i] = a.tab[i];
+    __syncthreads();
     if (b >= a.n) return;
-    setup_row<H>(a, b, a1mpc_lds + row * LayoutSetup<H>::ROW_STRIDE, prep);
+    setup_row<H>(a, tabl, b, a1mpc_lds + row * LayoutSetup<H>::ROW_STRIDE, prep);
 }
 // K2: persistent rows; grid = resident workgroups; every row drains the queue of prepared QPs.
 template <int H, int ROWS>
@@ -96,7 +100,7 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     static int resident[64] = {};
     int dev = 0;
     A1_HIP(hipGetDevice(&dev));
-    const size_t lds2 = lds_bytes<H>(ROWS), lds1 = sizeof(double) * 4 * LayoutSetup<H>::ROW_STRIDE;
+    const size_t lds2 = lds_bytes<H>(ROWS), lds1 = sizeof(double) * (4 * LayoutSetup<H>::ROW_STRIDE + 2 * H * H);
     if (dev >= 0 && dev < 64 && !resident[dev]) {
         A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(lds2)));

@@ -419,11 +419,14 @@ struct RowSolver {
                 for (int s = 0; s < H; ++s) mm[s] = 0.0;
 #pragma unroll 1
                 for (int t = 0; t < H; ++t) {
-                    double Dt[12];
+                    // all loads of this t first (table column + D row): one wait instead of one per block
+                    double gb[2 * H], Dt[12];
+#pragma unroll
+                    for (int s2 = 0; s2 < H; ++s2) { gb[2 * s2] = tab[(s2 * H + t) * 2]; gb[2 * s2 + 1] = tab[(s2 * H + t) * 2 + 1]; }
 #pragma unroll
                     for (int b = 0; b < 12; ++b) Dt[b] = lds[L::DL + t * 12 + b];
                     static_for<H>([&](auto S) {
-                        const double gam = tab[(S * H + t) * 2], bet = tab[(S * H + t) * 2 + 1];
+                        const double gam = gb[2 * A1_CV(S)], bet = gb[2 * A1_CV(S) + 1];
                         double a0 = 0.0, a1 = 0.0;
                         static_for<6>([&](auto J) {
                             a0 = fmax(a0, fabs(fma(gam, U[2 * J], V[2 * J])) * Dt[2 * J]);
@@ -962,8 +965,8 @@ A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
 
 // split pipeline, kernel 1: formation + Ruiz for QP b, prepared state to global memory
 template <int H>
-A1_DEV void setup_row(const BatchArgs& a, int64_t b, double* __restrict__ lds, double* __restrict__ prep) {
-    RowSolver<H, kModeMpc, true> S(a.P, a.tab, lds);
+A1_DEV void setup_row(const BatchArgs& a, const double* __restrict__ tab, int64_t b, double* __restrict__ lds, double* __restrict__ prep) {
+    RowSolver<H, kModeMpc, true> S(a.P, tab, lds);  // tab: the (alpha/beta, beta) table, staged in LDS by the kernel
     S.setup(make_io<H, kModeMpc>(a, b));
     S.save_prepared(prep + b * Prep<H>::STRIDE);
 }

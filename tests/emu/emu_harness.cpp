@@ -136,7 +136,7 @@ namespace a1mpc {
 template <int H>
 struct SplitJob { const BatchArgs* a; double* prep; int* counter; double* lds; int64_t b; };
 template <int H>
-static void split_setup_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); setup_row<H>(*j->a, j->b, j->lds, j->prep); }
+static void split_setup_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); setup_row<H>(*j->a, j->a->tab, j->b, j->lds, j->prep); }
 template <int H>
 static void split_admm_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); admm_rows<H>(*j->a, j->prep, j->counter, j->lds); }
 // the split pipeline on host fibers: K1 for every QP, then `nrows` persistent rows draining the queue one after another
