@@ -898,7 +898,13 @@ struct RowSolver {
 
     // ================================================================================ store_solution + first-step GRFs in the body frame
     A1_DEV void write_outputs(const ProblemIO& io) const {
-        const bool nanout = status == A1MPC_NON_CVX;
+        // a non-finite solution (NaN / Inf inputs) is reported as NON_CVX whatever the residual tests concluded: max-norms
+        // skip NaNs, so OSQP's own termination test can "converge" on a NaN iterate
+        double nf = 0.0;
+#pragma unroll
+        for (int t = 0; t < H; ++t) nf = (xh[t] - xh[t] == 0.0) ? nf : 1.0;
+        const int32_t status_out = row_allmax(nf) > 0.0 ? A1MPC_NON_CVX : status;
+        const bool nanout = status_out == A1MPC_NON_CVX;
         const double nanv = nan("");
         {
             const double f = nanout ? nanv : xh[0];
@@ -924,7 +930,7 @@ struct RowSolver {
         });
         if (ln == 0) {
             if (io.iters) *io.iters = iter;
-            if (io.status) *io.status = status;
+            if (io.status) *io.status = status_out;
             if (io.nfact) *io.nfact = nfact;
             if (io.rho_io) *io.rho_io = rho;
         }

@@ -82,3 +82,13 @@ def test_emulated_split_pipeline_warm_start(oracle, scen):
         one = {k: (sc[k][t:t + 1] if k in ("x0", "xref", "R", "foot", "contact") else sc[k]) for k in sc}
         out = emu.solve(one, 1, warm=(ewx, ewy, erho), warm_start=1, split_rows=1)
         assert out["iters"][0] == r["info"].iters and np.abs(out["u"][0] - r["u"]).max() < 1e-8
+
+
+def test_emulated_non_finite_input_returns_zeros_and_status(oracle, scen):
+    """a NaN state: the reference would return an uninitialised matrix (S/A1RobotControl.cpp:322,559); here zeros + status"""
+    sc = scen.config3_random_flat(nb=2)
+    sc["x0"][0, 4] = np.nan
+    out = emu.solve(sc, 2)
+    ref = oracle_batch(oracle, sc, 2)
+    assert out["status"][0] == -7 and (out["grf"][0] == 0).all() and np.isnan(out["u"][0]).all() and np.isnan(ref["u"][0]).all()
+    assert out["status"][1] == 1 and np.abs(out["u"][1] - ref["u"][1]).max() < 1e-8

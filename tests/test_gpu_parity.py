@@ -149,3 +149,39 @@ def test_size_independent_properties_full_batch(pkg, scen):
     R = sc["R"].reshape(n, 3, 3)
     g = np.einsum("nji,nlj->nli", R, u[:, 0])
     assert np.abs(g.reshape(n, 12) - out["grf"]).max() < 1e-9
+
+
+def test_non_finite_input_returns_zeros_and_status(pkg, oracle, scen):
+    """a NaN state must not poison its neighbours in the wave: zeros + status -7 for it, exact answers for the others"""
+    for n in (8, 512):  # fused kernel, split pipeline
+        sc = scen.config3_random_flat(nb=n)
+        sc["x0"][1, 4] = np.nan; sc["foot"][5, 2] = np.inf
+        with _engine(pkg, sc, n, warm_start=0) as eng:
+            out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+        bad = np.zeros(n, bool); bad[[1, 5]] = True
+        assert (out["status"][bad] == -7).all() and (out["grf"][bad] == 0).all()
+        ref = oracle_batch(oracle, take(sc, 16))
+        good = ~bad[:16]
+        assert (out["iters"][:16][good] == ref["iters"][good]).all()
+        assert np.abs(out["u"][:16][good] - ref["u"][good]).max() < TOL_FORCE_N
+
+
+@pytest.mark.parametrize("gen,n,h", [("config4_random_h16", 8192, 16), ("config5_divergent", 32768, 20)])
+def test_full_size_configs_4_and_5_properties(pkg, oracle, scen, gen, n, h):
+    """BASELINE configs[3] (65536 x h16 over 8 GPUs = 8192 per GPU) and configs[4] (32768 x h20) at full per-GPU size: the oracle
+    checks a strided sample, the whole batch is checked through size-independent properties."""
+    sc = getattr(scen, gen)(nb=n)
+    with _engine(pkg, sc, n, warm_start=0) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    assert (out["status"] == 1).all()
+    idx = np.arange(0, n, n // 48)
+    sub = {k: (sc[k][idx] if k in ("x0", "xref", "R", "foot", "contact") else sc[k]) for k in sc}
+    ref = oracle_batch(oracle, sub)
+    compare({k: (v[idx] if v is not None else None) for k, v in out.items()}, ref, min_same=1.0)
+    u = out["u"].reshape(n, h, 4, 3)
+    mu, tol = 0.3, 1.0  # OSQP-default accuracy
+    assert (u[..., 2] >= -tol).all() and (u[..., 2] <= 180 + tol).all()
+    assert (np.abs(u[..., 0]) <= mu * u[..., 2] + tol).all() and (np.abs(u[..., 1]) <= mu * u[..., 2] + tol).all()
+    assert np.abs(u.transpose(0, 2, 1, 3)[sc["contact"] == 0]).max() < tol
+    R = sc["R"].reshape(n, 3, 3)
+    assert np.abs(np.einsum("nji,nlj->nli", R, u[:, 0]).reshape(n, 12) - out["grf"]).max() < 1e-9
