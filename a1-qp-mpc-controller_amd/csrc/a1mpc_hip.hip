@@ -356,11 +356,12 @@ a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h) {
     return A1MPC_OK;
 }
 
-a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d_x0, const double* d_x_ref, const double* d_R_world,
-                                      const double* d_foot_abs, const uint8_t* d_contact, double* d_grf_body_out,
-                                      double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out, void* hip_stream) {
+static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d_tick, const double* d_x0, const double* d_x_ref,
+                                      const double* d_R_world, const double* d_foot_abs, const uint8_t* d_contact,
+                                      double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out,
+                                      void* hip_stream) {
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
-    if (n < 0 || !d_x0 || !d_x_ref || !d_R_world || !d_foot_abs || !d_contact || !d_grf_body_out)
+    if (n < 0 || (!d_tick && (!d_x0 || !d_x_ref)) || !d_R_world || !d_foot_abs || !d_contact || !d_grf_body_out)
         return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
     if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
     if (n == 0) return A1MPC_OK;
@@ -369,7 +370,7 @@ a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d
     KernelArgs a;
     std::memset(&a, 0, sizeof a);
     a.P = h->dp; a.tab = h->d_tab; a.n = n;
-    a.x0 = d_x0; a.xref = d_x_ref; a.R = d_R_world; a.foot = d_foot_abs; a.contact = d_contact;
+    a.tick = d_tick; a.x0 = d_x0; a.xref = d_x_ref; a.R = d_R_world; a.foot = d_foot_abs; a.contact = d_contact;
     a.grf = d_grf_body_out; a.u_full = d_u_full_out; a.iters = d_iters_out; a.status = d_status_out; a.nfact = h->d_nfact;
     h->last_stream = s;
     if (h->cfg.warm_start) { a.warm_x = h->d_wx; a.warm_y = h->d_wy; a.rho = h->d_rho; }
@@ -378,6 +379,49 @@ a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d
     if (st != A1MPC_OK) return st;
     A1_HIP(hipEventRecord(h->ev1, s));
     h->timed = true;
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d_x0, const double* d_x_ref, const double* d_R_world,
+                                      const double* d_foot_abs, const uint8_t* d_contact, double* d_grf_body_out,
+                                      double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out, void* hip_stream) {
+    if (!d_x0 || !d_x_ref) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    return solve_device_impl(h, n, nullptr, d_x0, d_x_ref, d_R_world, d_foot_abs, d_contact, d_grf_body_out, d_u_full_out, d_iters_out,
+                             d_status_out, hip_stream);
+}
+a1mpc_status a1mpc_solve_batch_ticks_device(a1mpc_handle h, int32_t n, const double* d_tick, const double* d_R_world,
+                                            const double* d_foot_abs, const uint8_t* d_contact, double* d_grf_body_out,
+                                            double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out, void* hip_stream) {
+    if (!d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    return solve_device_impl(h, n, d_tick, nullptr, nullptr, d_R_world, d_foot_abs, d_contact, d_grf_body_out, d_u_full_out, d_iters_out,
+                             d_status_out, hip_stream);
+}
+
+a1mpc_status a1mpc_solve_batch_ticks(a1mpc_handle h, int32_t n, const double* tick, const double* R_world, const double* foot_abs,
+                                     const uint8_t* contact, double* grf_body_out, double* u_full_out, int32_t* iters_out,
+                                     int32_t* status_out) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !tick || !R_world || !foot_abs || !contact || !grf_body_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    const size_t N = n, H = h->cfg.horizon;
+    hipStream_t s = h->stream;
+    // 22 + 9 + 12 doubles + 4 bytes per QP: the tick record rides in the x_ref staging buffer (13H >= 22 for H >= 2; H = 1 has its own room: 13 + 13)
+    double* d_tick = (H >= 2) ? h->d_xref : h->d_x0;
+    if (H < 2) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "tick records need horizon >= 2");
+    A1_HIP(hipMemcpyAsync(d_tick, tick, N * 22 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_R, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_foot, foot_abs, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_contact, contact, N * 4, hipMemcpyHostToDevice, s));
+    a1mpc_status st = solve_device_impl(h, n, d_tick, nullptr, nullptr, h->d_R, h->d_foot, h->d_contact, h->d_grf,
+                                        u_full_out ? h->d_u : nullptr, h->d_iters, h->d_status, s);
+    if (st != A1MPC_OK) return st;
+    A1_HIP(hipMemcpyAsync(grf_body_out, h->d_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (u_full_out) A1_HIP(hipMemcpyAsync(u_full_out, h->d_u, N * 12 * H * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (iters_out) A1_HIP(hipMemcpyAsync(iters_out, h->d_iters, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (status_out) A1_HIP(hipMemcpyAsync(status_out, h->d_status, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipStreamSynchronize(s));
     return A1MPC_OK;
 }
 

@@ -62,6 +62,7 @@ enum : int { kModeMpc = 0, kModeBalance = 1 };
 struct ProblemIO {
     const double* root_acc;  // balance mode only: 6, desired wrench (S/A1RobotControl.cpp:379-391)
     const double* Rz;        // balance mode only: 9, row-major root_rot_mat_z
+    const double* tick;      // 22 or null: compact tick record (N1) -- when set, x0 / xref are built on the device and the two pointers below are ignored
     const double* x0;        // 13
     const double* xref;      // 13*H
     const double* R;         // 9, row-major root_rot_mat
@@ -289,7 +290,7 @@ struct RowSolver {
         for (int i = 0; i < 9; ++i) Rm[i] = io.R[i];
         double c_ = 1.0, s_ = 0.0;
         if constexpr (MODE == kModeMpc) {
-            const double yaw = io.x0[2];
+            const double yaw = io.tick ? io.tick[2] : io.x0[2];
             c_ = cos(yaw); s_ = sin(yaw);  // S/ConvexMpc.cpp:115-116
         }
         set_rotation(c_, s_);
@@ -370,12 +371,33 @@ struct RowSolver {
             g[0] = -a;
         } else {
             double w[H];
-            double xs = act ? io.x0[ci] : 0.0;
-            const double grav = io.x0[12];
+            double xs, grav, xr_base = 0.0, xr_slope = 0.0;
+            if (io.tick) {
+                // N1: the tick record [euler, pos, ang_vel, lin_vel | euler_d, lin_vel_d (body), ang_vel_d, pos_z_d]; x0 and x_ref exactly as
+                // S/A1RobotControl.cpp:452-456 and :470-488 build them: x_ref_i = base + (slope * dt) * (i + 1)
+                const double* k = io.tick;
+                xs = act ? k[ci] : 0.0;
+                grav = -9.8;
+                const double vwx = Rm[0] * k[15] + Rm[1] * k[16] + Rm[2] * k[17], vwy = Rm[3] * k[15] + Rm[4] * k[16] + Rm[5] * k[17];
+                if (ci == 0) xr_base = k[12];
+                else if (ci == 1) xr_base = k[13];
+                else if (ci == 2) { xr_base = k[2]; xr_slope = k[20]; }
+                else if (ci == 3) { xr_base = k[3]; xr_slope = vwx; }
+                else if (ci == 4) { xr_base = k[4]; xr_slope = vwy; }
+                else if (ci == 5) xr_base = k[21];
+                else if (ci <= 8) xr_base = k[18 + ci - 6];
+                else if (ci == 9) xr_base = vwx;
+                else if (ci == 10) xr_base = vwy;
+                if (!act) { xr_base = 0.0; xr_slope = 0.0; }
+                xr_slope *= dt;
+            } else {
+                xs = act ? io.x0[ci] : 0.0;
+                grav = io.x0[12];
+            }
             static_for<H>([&](auto T) {
                 xs = opA(row_dpp_ready(xs));
                 if (ln == 14) xs += dt * grav;  // A_c(11,12) = 1 (S/ConvexMpc.cpp:129)
-                const double xr = act ? io.xref[T * 13 + ci] : 0.0;
+                const double xr = io.tick ? xr_base + xr_slope * double(A1_CV(T) + 1) : (act ? io.xref[T * 13 + ci] : 0.0);
                 w[T] = q2s * (xs - xr);
             });
             double lam = row_dpp_ready(0.0);
@@ -943,6 +965,7 @@ struct BatchArgs {
     const double* tab;
     int32_t n;
     const double *root_acc, *Rz;  // balance mode only
+    const double* tick;           // n x 22 compact tick records, or null (N1)
     const double *x0, *xref, *R, *foot;
     const uint8_t* contact;
     double *grf, *u_full, *warm_x, *warm_y, *rho;
@@ -953,8 +976,9 @@ A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
     ProblemIO io;
     io.root_acc = MODE == kModeBalance ? a.root_acc + b * 6 : nullptr;
     io.Rz = MODE == kModeBalance ? a.Rz + b * 9 : nullptr;
-    io.x0 = MODE == kModeMpc ? a.x0 + b * 13 : nullptr;
-    io.xref = MODE == kModeMpc ? a.xref + b * 13 * H : nullptr;
+    io.tick = (MODE == kModeMpc && a.tick) ? a.tick + b * 22 : nullptr;
+    io.x0 = (MODE == kModeMpc && a.x0) ? a.x0 + b * 13 : nullptr;
+    io.xref = (MODE == kModeMpc && a.xref) ? a.xref + b * 13 * H : nullptr;
     io.R = a.R + b * 9;
     io.foot = a.foot + b * 12;
     io.contact = a.contact + b * 4;

@@ -31,7 +31,7 @@ class BalanceConfig(C.Structure):  # a1mpc_balance_config
 
 
 EXPORTS = ["a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
-           "a1mpc_solve_batch_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
+           "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
 
 _lib = None
@@ -58,6 +58,8 @@ def load_library(path=None):
     lib.a1mpc_destroy.argtypes = [vp]; lib.a1mpc_destroy.restype = None
     lib.a1mpc_solve_batch.argtypes = [vp, i32, dp, dp, dp, dp, u8p, dp, dp, i32p, i32p]; lib.a1mpc_solve_batch.restype = C.c_int
     lib.a1mpc_solve_batch_device.argtypes = [vp, i32] + [vp] * 9 + [vp]; lib.a1mpc_solve_batch_device.restype = C.c_int
+    lib.a1mpc_solve_batch_ticks.argtypes = [vp, i32, dp, dp, dp, u8p, dp, dp, i32p, i32p]; lib.a1mpc_solve_batch_ticks.restype = C.c_int
+    lib.a1mpc_solve_batch_ticks_device.argtypes = [vp, i32] + [vp] * 8 + [vp]; lib.a1mpc_solve_batch_ticks_device.restype = C.c_int
     lib.a1mpc_balance_solve_batch.argtypes = [vp, C.POINTER(BalanceConfig), i32, dp, dp, dp, dp, u8p, dp, dp, i32p, i32p]
     lib.a1mpc_balance_solve_batch.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
@@ -147,6 +149,19 @@ class Engine:
         rc = self.lib.a1mpc_solve_batch(self._h, n, _dp(x0), _dp(xref), _dp(R), _dp(foot),
                                         contact.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(grf), _dp(u), _ip(iters), _ip(status))
         _check(self.lib, rc, "a1mpc_solve_batch")
+        return dict(grf=grf, u=u, iters=iters, status=status)
+
+    # ---- N1: compact tick records (x0 / x_ref built on the device, S/A1RobotControl.cpp:452-488) ----
+    def solve_ticks(self, tick, R, foot, contact, want_u=False):
+        h = self.horizon
+        tick = _f64(tick, (-1, 22)); n = tick.shape[0]
+        R = _f64(R, (n, 9)); foot = _f64(foot, (n, 12))
+        contact = np.ascontiguousarray(contact, dtype=np.uint8).reshape(n, 4)
+        grf = np.zeros((n, 12)); u = np.zeros((n, NU * h)) if want_u else None
+        iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
+        rc = self.lib.a1mpc_solve_batch_ticks(self._h, n, _dp(tick), _dp(R), _dp(foot), contact.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(grf),
+                                              _dp(u), _ip(iters), _ip(status))
+        _check(self.lib, rc, "a1mpc_solve_batch_ticks")
         return dict(grf=grf, u=u, iters=iters, status=status)
 
     # ---- device pointers (torch tensors already resident in HBM), asynchronous on `stream` ----

@@ -69,6 +69,13 @@ def pack_x0(euler, pos, ang_vel, lin_vel):
     return x0
 
 
+def pack_tick(euler, pos, ang_vel, lin_vel, euler_d, lin_vel_d_body, ang_vel_d, pos_z_d):
+    """The compact tick record of a1mpc_solve_batch_ticks (include/a1mpc.h): 22 doubles per QP."""
+    nb = euler.shape[0]
+    return np.ascontiguousarray(np.concatenate([euler, pos, ang_vel, lin_vel, euler_d, lin_vel_d_body, ang_vel_d,
+                                                np.asarray(pos_z_d, float).reshape(nb, 1)], axis=1))
+
+
 def _finish(params, horizon, x0, xref, R, foot, contact, **extra):
     out = dict(horizon=int(horizon), params=dict(params, **MPC_CONSTANTS),
                x0=np.ascontiguousarray(x0, dtype=np.float64), xref=np.ascontiguousarray(xref, dtype=np.float64),
@@ -125,6 +132,7 @@ def _random_states(rng, nb, params, horizon, rpy_lim, z_rng, w_sig, v_sig, vd_li
     nominal = np.array(params["foot"], dtype=float)  # body frame (4,3)
     foot_body = nominal[None] + rng.uniform(-foot_jitter, foot_jitter, (nb, 4, 3))
     foot = np.einsum("bij,blj->bli", R, foot_body)  # foot_pos_abs = R * foot_pos_rel
+    _random_states.last_tick = pack_tick(euler, pos, ang_vel, lin_vel, euler_d, vd, wd, np.full(nb, 0.3))
     return x0, xref, R, foot, contact
 
 
@@ -155,7 +163,7 @@ def config3_random_flat(nb=4096, seed=0xA1 + 3, horizon=10, param_set="gazebo"):
     sel = rng.choice(3, size=nb, p=[0.5, 0.25, 0.25])
     x0, xref, R, foot, contact = _random_states(rng, nb, p, horizon, (0.15, 0.15, np.pi), (0.25, 0.32), 0.3, 0.3,
                                                 (0.6, 0.3), pat[sel])
-    return _finish(p, horizon, x0, xref, R, foot, contact)
+    return _finish(p, horizon, x0, xref, R, foot, contact, tick=_random_states.last_tick)
 
 
 def config4_random_h16(nb=65536, seed=0xA1 + 4):
@@ -170,7 +178,7 @@ def config5_divergent(nb=32768, seed=0xA1 + 5, horizon=20, param_set="gazebo"):
     contact = ((code[:, None] >> np.arange(4)[None, :]) & 1).astype(np.uint8)
     x0, xref, R, foot, contact = _random_states(rng, nb, p, horizon, (0.15, 0.0, np.pi), (0.25, 0.32), 0.3, 0.0,
                                                 (0.6, 0.3), contact, pitch=(0.5, 0.05), v_zero=True)
-    return _finish(p, horizon, x0, xref, R, foot, contact)
+    return _finish(p, horizon, x0, xref, R, foot, contact, tick=_random_states.last_tick)
 
 
 def config1_balance_stand(param_set="gazebo"):

@@ -122,6 +122,20 @@ a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d
                                       int32_t* d_status_out, void* hip_stream);
 
 /*
+ * N1 (the caller side of the path, S/A1RobotControl.cpp:452-488): the same solve from the COMPACT tick record; x0 (mpc_states)
+ * and x_ref (mpc_states_d) are built on the device exactly as compute_grf builds them.  tick is n x 22 doubles:
+ *   [0:3] root_euler  [3:6] root_pos  [6:9] root_ang_vel  [9:12] root_lin_vel          (world frame, as in mpc_states)
+ *   [12:15] root_euler_d  [15:18] root_lin_vel_d (BODY frame; rotated by R_world as at :470)  [18:21] root_ang_vel_d  [21] root_pos_d[2]
+ * Input per QP drops from (13 + 13H) to 22 doubles.  Host pointers; a1mpc_solve_batch_ticks_device takes device pointers + a stream.
+ */
+a1mpc_status a1mpc_solve_batch_ticks(a1mpc_handle h, int32_t n, const double* tick, const double* R_world, const double* foot_abs,
+                                     const uint8_t* contact, double* grf_body_out, double* u_full_out, int32_t* iters_out,
+                                     int32_t* status_out);
+a1mpc_status a1mpc_solve_batch_ticks_device(a1mpc_handle h, int32_t n, const double* d_tick, const double* d_R_world,
+                                            const double* d_foot_abs, const uint8_t* d_contact, double* d_grf_body_out,
+                                            double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out, void* hip_stream);
+
+/*
  * n independent balance-QP ticks (12 variables, 20 constraints), cold-started like the reference.
  *   root_acc n x 6   desired wrench incl. m*9.8 (S/A1RobotControl.cpp:379-391)
  *   R_world  n x 9   root_rot_mat (output rotation), R_z n x 9 root_rot_mat_z (lever arms, :397), row-major

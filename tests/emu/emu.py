@@ -104,3 +104,14 @@ def balance_solve(sc, n=None, settings=None, **over):
                                  _p(sc["contact"], C.c_uint8), _p(grf), _p(f), _p(iters, C.c_int32), _p(status, C.c_int32))
     assert rc == 0
     return dict(grf=grf, f_world=f, iters=iters, status=status)
+
+
+def solve_ticks(sc, n=None, settings=None, **over):
+    """N1: compact tick records in, x0 / x_ref built by the solver source (horizon 10)."""
+    n = len(sc["tick"]) if n is None else n
+    P = make_params(sc["params"], settings, **over)
+    grf = np.zeros((n, 12)); u = np.zeros((n, 120)); iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
+    rc = lib().a1mpc_emu_solve_ticks(C.byref(P), 10, n, _p(sc["tick"]), _p(sc["R"]), _p(sc["foot"]), _p(sc["contact"], C.c_uint8), _p(grf), _p(u),
+                                     _p(iters, C.c_int32), _p(status, C.c_int32))
+    assert rc == 0
+    return dict(grf=grf, u=u, iters=iters, status=status)

@@ -176,6 +176,24 @@ extern "C" int a1mpc_emu_solve_split(const a1mpc::DeviceParams* P, int horizon, 
     }
     return -1;
 }
+extern "C" int a1mpc_emu_solve_ticks(const a1mpc::DeviceParams* P, int horizon, int n, const double* tick, const double* R,
+                                     const double* foot, const uint8_t* contact, double* grf, double* u_full, int32_t* iters, int32_t* status) {
+    using namespace a1mpc;
+    if (horizon != 10) return -1;
+    std::vector<double> tab(2 * 10 * 10);
+    fill_gamma_beta_table(10, tab.data());
+    std::vector<double> lds(Layout<10>::ROW_STRIDE);
+    for (int b = 0; b < n; ++b) {
+        for (auto& v : lds) v = NAN;
+        Job<10> j;
+        memset(&j.io, 0, sizeof j.io);
+        j.P = P; j.tab = tab.data(); j.lds = lds.data();
+        j.io.tick = tick + (size_t)b * 22; j.io.R = R + (size_t)b * 9; j.io.foot = foot + (size_t)b * 12; j.io.contact = contact + (size_t)b * 4;
+        j.io.grf = grf + (size_t)b * 12; j.io.u_full = u_full + (size_t)b * 120; j.io.iters = iters + b; j.io.status = status + b;
+        run_row(job_entry<10>, &j);
+    }
+    return 0;
+}
 extern "C" int a1mpc_emu_solve(const a1mpc::DeviceParams* P, int horizon, int n, const double* x0, const double* xref, const double* R,
                                const double* foot, const uint8_t* contact, double* grf, double* u_full, double* warm_x,
                                double* warm_y, double* rho, int32_t* iters, int32_t* status, int32_t* nfact) {

@@ -92,3 +92,16 @@ def test_emulated_non_finite_input_returns_zeros_and_status(oracle, scen):
     ref = oracle_batch(oracle, sc, 2)
     assert out["status"][0] == -7 and (out["grf"][0] == 0).all() and np.isnan(out["u"][0]).all() and np.isnan(ref["u"][0]).all()
     assert out["status"][1] == 1 and np.abs(out["u"][1] - ref["u"][1]).max() < 1e-8
+
+
+def test_emulated_tick_records_N1(oracle, scen):
+    """x0 / x_ref built on the device from the 22-number tick record == the reference's own builder
+    (S/A1RobotControl.cpp:452-488, restated by oracle.mpc_reference) followed by the same solve"""
+    sc = scen.config3_random_flat(nb=4)
+    out = emu.solve_ticks(sc, 4)
+    ref = oracle_batch(oracle, sc, 4)
+    compare(out, ref, tol=1e-8, min_same=1.0)
+    for b in range(4):  # the scenario's x_ref is what the oracle's restatement of :470-488 builds from the same tick
+        k = sc["tick"][b]
+        xr = oracle.mpc_reference(10, sc["params"]["dt"], k[0:3], k[3:6], sc["R"][b], k[12:15], k[15:18], k[18:21], k[21])
+        assert np.abs(xr - sc["xref"][b]).max() < 1e-12

@@ -185,3 +185,14 @@ def test_full_size_configs_4_and_5_properties(pkg, oracle, scen, gen, n, h):
     assert np.abs(u.transpose(0, 2, 1, 3)[sc["contact"] == 0]).max() < tol
     R = sc["R"].reshape(n, 3, 3)
     assert np.abs(np.einsum("nji,nlj->nli", R, u[:, 0]).reshape(n, 12) - out["grf"]).max() < 1e-9
+
+
+def test_tick_records_N1(pkg, oracle, scen):
+    """SURVEY 8(f) N1 through the C ABI: a1mpc_solve_batch_ticks == a1mpc_solve_batch on the x0 / x_ref the reference would build"""
+    for n in (64, 1024):
+        sc = scen.config3_random_flat(nb=n)
+        with _engine(pkg, sc, n, warm_start=0) as eng:
+            a = eng.solve_ticks(sc["tick"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+            b = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+        assert (a["iters"] == b["iters"]).all() and np.abs(a["u"] - b["u"]).max() < TOL_FORCE_N
+        compare({k: v[:32] if v is not None else None for k, v in a.items()}, oracle_batch(oracle, take(sc, 32)), min_same=1.0)
