@@ -93,10 +93,6 @@ template <int J>
 A1_DEV double bc(double v) {
     return row_bcast<lane_of(J)>(v);
 }
-template <int J>
-A1_DEV void fbc(double& acc, double m, double x) {  // acc += m * x[compact index J]; x must be row_dpp_ready()
-    fma_bcast<lane_of(J)>(acc, m, x);
-}
 // init + sum_{j<N} m[j] * x[compact index OFF + j]  (two interleaved accumulator chains; x must be row_dpp_ready())
 template <int OFF, int N>
 A1_DEV double dot_bc(const double (&m)[N], double x, double init = 0.0) {
@@ -655,41 +651,31 @@ struct RowSolver {
                     if (B <= ci) slot[L::K_SZ + tri + B] = S[B];
                 });
             }
-            row_sync();
-            // K' = F' S^-1  (state row-owner; S^-1 read row-uniformly from LDS)
+            // K' = F' S^-1  (state row-owner): K'[i][a] = sum_b F'[i][b] S^-1[b][a]; S^-1[b][a] = register a of force lane b, so every
+            // term is one v_fmac_f64_dpp (no LDS round trip)
             double Kt[12];
 #pragma unroll
             for (int a = 0; a < 12; ++a) Kt[a] = 0.0;
-            static_for<12>([&](auto B) {
-                constexpr int bb = A1_CV(B);
-                double Sb[12];
-                static_for<12>([&](auto A_) {
-                    constexpr int aa = A1_CV(A_);
-                    constexpr int hi = aa > bb ? aa : bb, lo = aa > bb ? bb : aa;
-                    Sb[aa] = slot[L::K_SZ + hi * (hi + 1) / 2 + lo];
-                });
-#pragma unroll
-                for (int a = 0; a < 12; ++a) Kt[a] = fma(Ft[bb], Sb[a], Kt[a]);
+            row_dpp_ready12(S);
+            static_for<12>([&](auto B) {  // twelve independent accumulator chains
+                static_for<12>([&](auto A_) { fma_bcast<lane_of(A1_CV(B))>(Kt[A_], Ft[B], S[A_]); });
             });
             if (act) {
 #pragma unroll
                 for (int a = 0; a < 12; ++a) slot[a * L::KSTR + ci] = Kt[a];
             }
-            row_sync();
-            // P_t = c Q + A' P_{t+1} A - F' K
+            // P_t = c Q + A' P_{t+1} A - F' K:  K[a][j] = register a of state lane j
             if (t > 0) {
-                static_for<12>([&](auto J) {
-                    double Kj[12];
+                double nFt[12];
 #pragma unroll
-                    for (int a = 0; a < 12; ++a) Kj[a] = slot[a * L::KSTR + J];
-                    double a0 = G[J], a1 = 0.0;
-                    static_for<6>([&](auto A_) {
-                        a0 = fma(-Ft[2 * A_], Kj[2 * A_], a0);
-                        a1 = fma(-Ft[2 * A_ + 1], Kj[2 * A_ + 1], a1);
-                    });
-                    Pn[J] = a0 + a1 + ((act && ci == J) ? qd : 0.0);
+                for (int a = 0; a < 12; ++a) nFt[a] = -Ft[a];
+                static_for<12>([&](auto J) { Pn[J] = G[J] + ((act && ci == J) ? qd : 0.0); });
+                row_dpp_ready12(Kt);
+                static_for<12>([&](auto A_) {
+                    static_for<12>([&](auto J) { fma_bcast<lane_of(A1_CV(J))>(Pn[J], nFt[A_], Kt[A_]); });
                 });
             }
+            row_sync();  // K_t and S_t^-1 of this step are in LDS before the next step reuses the registers' sources
         }
         need_factor = false;
         if (!fac_ok) { status = A1MPC_NON_CVX; done = true; }

@@ -62,6 +62,12 @@ A1_DEV double row_dpp_ready(double x) {
     return x;
 }
 
+// the same for twelve values at once (one wait instead of twelve)
+A1_DEV void row_dpp_ready12(double (&v)[12]) {
+    asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                 "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
+}
+
 // Optimisation barrier: the value becomes opaque to the compiler (no code is emitted).
 A1_DEV double row_opaque(double v) {
     asm volatile("" : "+v"(v));

@@ -31,6 +31,7 @@ inline double quad_perm(double v) {
 template <int L>
 inline void fma_bcast(double& acc, double m, double x) { acc = fma(m, emu_publish(x)[L], acc); }
 inline double row_dpp_ready(double x) { return x; }
+inline void row_dpp_ready12(double (&)[12]) {}
 inline void row_sync() { (void)emu_publish(0.0); }
 
 
