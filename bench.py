@@ -177,7 +177,7 @@ def main():
                        "mean_iters": float(it.mean()), "max_iters": int(it.max()), "solved_frac": float((stt == 1).mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "a1mpc_setup_kernel<10> + a1mpc_admm_kernel<10,4> (one launch = both)", "avg_kernel_ms": avg_ms, "algorithmic_flops_per_launch": flops,
+                         "kernel": "a1mpc_setup_kernel<10> + a1mpc_admm_kernel<10,2> (one launch = both)", "avg_kernel_ms": avg_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
                          "note": "FP64 VALU issue/latency-bound (no MFMA used, DESIGN.md 3); flops = SURVEY 8(d) F(h,iters,nfact) summed over the launch; "
                                  "traffic = FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_summary.json (same workload)"},

@@ -3,9 +3,16 @@
 import collections, csv, glob, json, os, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_final"); dst = os.path.join(ROOT, "profiles")
-for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+def newest(pattern):
+    fs = glob.glob(pattern, recursive=True)
+    return max(fs, key=os.path.getmtime) if fs else None
+
+
+f = newest(os.path.join(src, "trace", "**", "*kernel_stats.csv"))
+if f:
     shutil.copy(f, os.path.join(dst, "r01_kernel_stats_bench_batch4096_h10.csv"))
-for f in glob.glob(os.path.join(src, "trace", "**", "*domain_stats.csv"), recursive=True):
+f = newest(os.path.join(src, "trace", "**", "*domain_stats.csv"))
+if f:
     shutil.copy(f, os.path.join(dst, "r01_domain_stats.csv"))
 log = os.path.join(src, "bench_under_rocprof.log")
 if os.path.exists(log):
@@ -13,7 +20,12 @@ if os.path.exists(log):
     if lines:
         open(os.path.join(dst, "r01_bench_under_rocprof.json"), "w").write(lines[-1])
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
+pmc_files = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    d = f.split(os.sep)[-3]
+    if d not in pmc_files or os.path.getmtime(f) > os.path.getmtime(pmc_files[d]):
+        pmc_files[d] = f
+for f in pmc_files.values():
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
         if "a1mpc" in k:
