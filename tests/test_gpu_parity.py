@@ -196,3 +196,29 @@ def test_tick_records_N1(pkg, oracle, scen):
             b = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
         assert (a["iters"] == b["iters"]).all() and np.abs(a["u"] - b["u"]).max() < TOL_FORCE_N
         compare({k: v[:32] if v is not None else None for k, v in a.items()}, oracle_batch(oracle, take(sc, 32)), min_same=1.0)
+
+
+def test_device_pointer_entry_and_batched_warm_start(pkg, oracle, scen):
+    """a1mpc_solve_batch_device (asynchronous, caller's stream, torch tensors in HBM) == the host-pointer entry; and a batch of
+    300 robots ticked twice with warm start matches 300 sequentially warm-started oracle solvers"""
+    import torch
+    n = 300
+    sc = scen.config3_random_flat(nb=n)
+    dev = torch.device("cuda", 0)
+    d = {k: torch.from_numpy(sc[k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")}
+    grf = torch.zeros((n, 12), dtype=torch.float64, device=dev); u = torch.zeros((n, 120), dtype=torch.float64, device=dev)
+    it = torch.zeros(n, dtype=torch.int32, device=dev); stt = torch.zeros(n, dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    with _engine(pkg, sc, n, warm_start=1) as eng:
+        host1 = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)      # tick 1 (cold: zeros)
+        eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, u, it, stt, stream=st.cuda_stream)  # tick 2 (warm)
+        st.synchronize()
+    from helpers import oracle_params
+    pr = oracle_params(oracle, sc); so = oracle.default_settings(warm_start=1)
+    for b in range(0, n, 7):
+        r1 = oracle.mpc_solve(pr, so, sc["x0"][b], sc["xref"][b], sc["R"][b], sc["foot"][b], sc["contact"][b], warm_x=np.zeros(120), warm_y=np.zeros(200))
+        assert host1["iters"][b] == r1["info"].iters and np.abs(host1["u"][b] - r1["u"]).max() < TOL_FORCE_N
+        r2 = oracle.mpc_solve(pr, so, sc["x0"][b], sc["xref"][b], sc["R"][b], sc["foot"][b], sc["contact"][b], warm_x=r1["warm_x"], warm_y=r1["warm_y"],
+                              warm_rho=r1["rho"])
+        assert int(it[b]) == r2["info"].iters, (b, int(it[b]), r2["info"].iters)
+        assert np.abs(u[b].cpu().numpy() - r2["u"]).max() < TOL_FORCE_N
