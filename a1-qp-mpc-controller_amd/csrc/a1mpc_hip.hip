@@ -61,6 +61,8 @@ __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, cons
     admm_rows<H>(a, prep, counter, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
 }
 
+__global__ void a1mpc_noop_kernel() {}
+
 template <int H>
 constexpr size_t lds_bytes(int rows) { return sizeof(double) * rows * Layout<H>::ROW_STRIDE; }
 
@@ -341,6 +343,23 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     // pinned mirror: inputs (x0, xref, R, Rz, foot, aux, contact) then outputs (grf, u, iters, status)
     h->h_pin_bytes = n * ((13 + 13 * H + 9 + 9 + 12 + 6) * sizeof(double) + 8 + (12 + 12 * H) * sizeof(double) + 2 * sizeof(int32_t));
     A1_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), h->h_pin_bytes, hipHostMallocDefault));
+    // One-time, per process: the first launches / copies through a fresh HIP runtime cost milliseconds (code-object load, pool set-up);
+    // a 400 Hz loop should not pay that on its first tick (measured 5 ms -> 0.4 ms), so the tick's operation mix is exercised here.
+    static bool runtime_warmed = false;
+    if (!runtime_warmed) {
+        for (int i = 0; i < 256; ++i) {  // the operation mix of a tick: copies both ways from pinned memory, memset, launches, events
+            A1_TRY(hipMemcpyAsync(h->d_x0, h->h_pin, 8, hipMemcpyHostToDevice, h->stream));
+            A1_TRY(hipMemsetAsync(h->d_counter, 0, sizeof(int), h->stream));
+            A1_TRY(hipEventRecord(h->ev0, h->stream));
+            hipLaunchKernelGGL(a1mpc_noop_kernel, dim3(1), dim3(64), 0, h->stream);
+            hipLaunchKernelGGL(a1mpc_noop_kernel, dim3(1), dim3(64), 0, h->stream);
+            A1_TRY(hipEventRecord(h->ev1, h->stream));
+            A1_TRY(hipMemcpyAsync(h->h_pin + 64, h->d_x0, 8, hipMemcpyDeviceToHost, h->stream));
+            if ((i & 63) == 63) A1_TRY(hipStreamSynchronize(h->stream));
+        }
+        A1_TRY(hipStreamSynchronize(h->stream));
+        runtime_warmed = true;
+    }
 #undef A1_TRY
     *out = h;
     return A1MPC_OK;
