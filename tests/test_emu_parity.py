@@ -105,3 +105,20 @@ def test_emulated_tick_records_N1(oracle, scen):
         k = sc["tick"][b]
         xr = oracle.mpc_reference(10, sc["params"]["dt"], k[0:3], k[3:6], sc["R"][b], k[12:15], k[15:18], k[18:21], k[21])
         assert np.abs(xr - sc["xref"][b]).max() < 1e-12
+
+
+@pytest.mark.parametrize("over", [dict(scaling_iters=0), dict(alpha=1.0, check_every=10, adaptive_rho_every=35), dict(rho0=1.0, adaptive_rho=0)],
+                         ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_emulated_non_default_settings(oracle, scen, over):
+    names = dict(scaling_iters="scaling", check_every="check_termination", adaptive_rho_every="adaptive_rho_interval", rho0="rho")
+    sc = scen.config3_random_flat(nb=3)
+    out = emu.solve(sc, 3, **over)
+    ref = oracle_batch(oracle, sc, 3, settings=oracle.default_settings(**{names.get(k, k): v for k, v in over.items()}))
+    compare(out, ref, tol=1e-8, min_same=1.0)
+
+
+def test_emulated_positive_fz_min_first_iteration(oracle, scen):
+    sc = scen.config3_random_flat(nb=3)
+    sc["params"] = dict(sc["params"], fz_min=5.0)
+    out = emu.solve(sc, 3)
+    compare(out, oracle_batch(oracle, sc, 3), tol=1e-8, min_same=1.0)

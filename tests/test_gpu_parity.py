@@ -222,3 +222,36 @@ def test_device_pointer_entry_and_batched_warm_start(pkg, oracle, scen):
                               warm_rho=r1["rho"])
         assert int(it[b]) == r2["info"].iters, (b, int(it[b]), r2["info"].iters)
         assert np.abs(u[b].cpu().numpy() - r2["u"]).max() < TOL_FORCE_N
+
+
+SETTINGS_CASES = [dict(scaling=0), dict(scaling=3), dict(alpha=1.0), dict(alpha=1.8), dict(rho=1.0), dict(rho=0.01, adaptive_rho=0),
+                  dict(check_termination=10), dict(adaptive_rho_interval=50), dict(check_termination=10, adaptive_rho_interval=35),
+                  dict(max_iter=30), dict(sigma=1e-4), dict(eps_abs=1e-5, eps_rel=1e-5), dict(adaptive_rho_tolerance=2.0)]
+
+
+@pytest.mark.parametrize("over", SETTINGS_CASES, ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_non_default_osqp_settings(pkg, oracle, scen, over):
+    """every OSQP setting the ABI exposes, away from its default: same iterates as the oracle run with the same setting"""
+    sc = scen.config3_random_flat(nb=48)
+    with _engine(pkg, sc, 48, warm_start=0, **over) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    ref = oracle_batch(oracle, sc, settings=oracle.default_settings(**over))
+    compare(out, ref, min_same=1.0)
+
+
+@pytest.mark.parametrize("mu,fz_min,fz_max", [(0.6, 0.0, 120.0), (0.3, 5.0, 180.0), (0.15, 0.0, 60.0)])
+def test_other_friction_and_force_limits(pkg, oracle, scen, mu, fz_min, fz_max):
+    """fz_min > 0 excludes u = 0 from the box: OSQP's first iteration (z0 = 0 not projected) needs the dedicated code path"""
+    sc = scen.config3_random_flat(nb=48)
+    sc["params"] = dict(sc["params"], mu=mu, fz_min=fz_min, fz_max=fz_max)
+    with _engine(pkg, sc, 48, warm_start=0) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    compare(out, oracle_batch(oracle, sc), min_same=1.0)
+
+
+def test_horizon_1_mpc(pkg, oracle, scen):
+    """the MPC path at horizon 1 (n = 12, m = 20), the shape BASELINE's north star pairs with the balance QP"""
+    sc = scen.config3_random_flat(nb=64, horizon=1)
+    with _engine(pkg, sc, 64, warm_start=0) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    compare(out, oracle_batch(oracle, sc), min_same=1.0)
