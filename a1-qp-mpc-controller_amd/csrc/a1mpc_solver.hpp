@@ -425,7 +425,12 @@ struct RowSolver {
         for (int t = 0; t < H; ++t) { D[t] = 1.0; E0[t] = act ? 1.0 : 0.0; E1[t] = (comp < 2) ? 1.0 : 0.0; }
         if (P.scaling_iters > 0) {
             double m[H];
-            // m[s] = max_{t,b} D_tb |P_(s,a),(t,b)|  for my rows (s, a): one pass over the implicit Hessian
+            // m[s] = max_{t,b} D_tb |P_(s,a),(t,b)|  for my rows (s, a): one pass over the implicit Hessian.
+            // Exact pruning: block (s,t) cannot raise the maximum if  (gamma_st max_b|U_ab| + max_b|V_ab|) beta_st max_b D_tb  does not
+            // exceed it; starting from the diagonal entry this skips ~70 % of the blocks (wave-level) without changing a single result.
+            double Umax = 0.0, Vmax = 0.0;
+#pragma unroll
+            for (int b = 0; b < 12; ++b) { Umax = fmax(Umax, fabs(U[b])); Vmax = fmax(Vmax, fabs(V[b])); }
             auto sweep = [&](double(&mm)[H]) {
                 row_sync();
                 if (act) {
@@ -433,8 +438,10 @@ struct RowSolver {
                     for (int t = 0; t < H; ++t) lds[L::DL + t * 12 + ci] = D[t];
                 }
                 row_sync();
-#pragma unroll
-                for (int s = 0; s < H; ++s) mm[s] = 0.0;
+                static_for<H>([&](auto S) {  // the true diagonal entry carries R
+                    constexpr double ad = alpha_diag(A1_CV(S), H), bd = H - A1_CV(S);
+                    mm[S] = (ad * Ud + bd * Vd + r2a) * D[S];
+                });
 #pragma unroll 1
                 for (int t = 0; t < H; ++t) {
                     // all loads of this t first (table column + D row): one wait instead of one per block
@@ -443,20 +450,22 @@ struct RowSolver {
                     for (int s2 = 0; s2 < H; ++s2) { gb[2 * s2] = tab[(s2 * H + t) * 2]; gb[2 * s2 + 1] = tab[(s2 * H + t) * 2 + 1]; }
 #pragma unroll
                     for (int b = 0; b < 12; ++b) Dt[b] = lds[L::DL + t * 12 + b];
+                    double Dmax = 0.0;
+#pragma unroll
+                    for (int b = 0; b < 12; ++b) Dmax = fmax(Dmax, Dt[b]);
+                    Dmax *= 1.0 + 1e-12;  // the bound must dominate every rounded entry
                     static_for<H>([&](auto S) {
                         const double gam = gb[2 * A1_CV(S)], bet = gb[2 * A1_CV(S) + 1];
-                        double a0 = 0.0, a1 = 0.0;
-                        static_for<6>([&](auto J) {
-                            a0 = fmax(a0, fabs(fma(gam, U[2 * J], V[2 * J])) * Dt[2 * J]);
-                            a1 = fmax(a1, fabs(fma(gam, U[2 * J + 1], V[2 * J + 1])) * Dt[2 * J + 1]);
-                        });
-                        mm[S] = fmax(mm[S], bet * fmax(a0, a1));
+                        if (fma(gam, Umax, Vmax) * (bet * Dmax) > mm[S]) {
+                            double a0 = 0.0, a1 = 0.0;
+                            static_for<6>([&](auto J) {
+                                a0 = fmax(a0, fabs(fma(gam, U[2 * J], V[2 * J])) * Dt[2 * J]);
+                                a1 = fmax(a1, fabs(fma(gam, U[2 * J + 1], V[2 * J + 1])) * Dt[2 * J + 1]);
+                            });
+                            mm[S] = fmax(mm[S], bet * fmax(a0, a1));
+                        }
                     });
                 }
-                static_for<H>([&](auto S) {  // the true diagonal entry carries R
-                    constexpr double ad = alpha_diag(A1_CV(S), H), bd = H - A1_CV(S);
-                    mm[S] = fmax(mm[S], (ad * Ud + bd * Vd + r2a) * D[S]);
-                });
             };
             sweep(m);
 #pragma unroll 1
