@@ -171,13 +171,15 @@ struct LayoutSetup {
     static constexpr int ROW_STRIDE = RAW + (RAW % 2);
 };
 
-// prepared state handed from the set-up kernel to the ADMM kernel: [field][16 lanes] doubles per QP
+// prepared state handed from the set-up kernel to the ADMM kernel: [field][12 active lanes] doubles per QP (pad lanes hold nothing).
+// XH (the warm-start x) comes last and is only written / read when the solve is warm-started.
 template <int H>
 struct Prep {
-    static constexpr int XH = 0, RR0 = H, RR1 = 2 * H, DI2 = 3 * H, CG = 4 * H, BT = 5 * H;  // per-lane fields
+    static constexpr int RR0 = 0, RR1 = H, DI2 = 2 * H, CG = 3 * H, BT = 4 * H;  // per-lane fields
     static constexpr int CSC = BT + 6, CY = CSC + 1, SY = CY + 1, RHO = SY + 1, LO = RHO + 1, HI = LO + 1, EQ = HI + 1, FLAGS = EQ + 1;
-    static constexpr int FIELDS = FLAGS + 1;
-    static constexpr int STRIDE = FIELDS * 16;  // doubles per QP
+    static constexpr int XH = FLAGS + 1;
+    static constexpr int FIELDS = XH + H;
+    static constexpr int STRIDE = FIELDS * 12;  // doubles per QP: 5.2 KB cold / 6.1 KB warm at H = 10
 };
 
 // =================================================================================================
@@ -534,45 +536,47 @@ struct RowSolver {
 
     // ================================================================================ hand-off between the two kernels
     A1_DEV void save_prepared(double* __restrict__ p) const {  // p: this QP's Prep<H>::STRIDE doubles
+        if (!act) return;
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
-            p[(PR::XH + t) * 16 + ln] = xh[t];
-            p[(PR::RR0 + t) * 16 + ln] = rr0[t];
-            p[(PR::RR1 + t) * 16 + ln] = rr1[t];
-            p[(PR::DI2 + t) * 16 + ln] = dI2[t];
-            p[(PR::CG + t) * 16 + ln] = act ? lds[L::CG + t * 12 + ci] : 0.0;
+            p[(PR::RR0 + t) * 12 + ci] = rr0[t];
+            p[(PR::RR1 + t) * 12 + ci] = rr1[t];
+            p[(PR::DI2 + t) * 12 + ci] = dI2[t];
+            p[(PR::CG + t) * 12 + ci] = lds[L::CG + t * 12 + ci];
+            if (warm) p[(PR::XH + t) * 12 + ci] = xh[t];
         });
 #pragma unroll
-        for (int k = 0; k < 6; ++k) p[(PR::BT + k) * 16 + ln] = Bt[k];
-        p[PR::CSC * 16 + ln] = csc; p[PR::CY * 16 + ln] = cy; p[PR::SY * 16 + ln] = sy; p[PR::RHO * 16 + ln] = rho;
-        p[PR::LO * 16 + ln] = lo_u; p[PR::HI * 16 + ln] = hi_u;
-        p[PR::EQ * 16 + ln] = static_cast<double>(eqmask);
-        p[PR::FLAGS * 16 + ln] = (warm ? 1.0 : 0.0) + (first_special ? 2.0 : 0.0);
+        for (int k = 0; k < 6; ++k) p[(PR::BT + k) * 12 + ci] = Bt[k];
+        p[PR::CSC * 12 + ci] = csc; p[PR::CY * 12 + ci] = cy; p[PR::SY * 12 + ci] = sy; p[PR::RHO * 12 + ci] = rho;
+        p[PR::LO * 12 + ci] = lo_u; p[PR::HI * 12 + ci] = hi_u;
+        p[PR::EQ * 12 + ci] = static_cast<double>(eqmask);
+        p[PR::FLAGS * 12 + ci] = (warm ? 1.0 : 0.0) + (first_special ? 2.0 : 0.0);
     }
     A1_DEV void load_prepared(const double* __restrict__ p, const ProblemIO& io) {
         row_sync();  // the previous QP's LDS image is dead
+        const double am = act ? 1.0 : 0.0;  // pad lanes read lane 0's record (ci == 0) and zero what must be zero
+        const int fl = static_cast<int>(p[PR::FLAGS * 12 + ci]);
+        warm = fl & 1; first_special = (fl & 2) != 0;
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
-            xh[t] = p[(PR::XH + t) * 16 + ln];
-            rr0[t] = p[(PR::RR0 + t) * 16 + ln];
-            rr1[t] = p[(PR::RR1 + t) * 16 + ln];
-            dI2[t] = p[(PR::DI2 + t) * 16 + ln];
+            rr0[t] = am * p[(PR::RR0 + t) * 12 + ci];
+            rr1[t] = am * p[(PR::RR1 + t) * 12 + ci];
+            dI2[t] = p[(PR::DI2 + t) * 12 + ci];
+            xh[t] = warm ? am * p[(PR::XH + t) * 12 + ci] : 0.0;
             wh0[t] = 0.0; wh1[t] = 0.0;
-            if (act) lds[L::CG + t * 12 + ci] = p[(PR::CG + t) * 16 + ln];
+            if (act) lds[L::CG + t * 12 + ci] = p[(PR::CG + t) * 12 + ci];
         });
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            Bt[k] = p[(PR::BT + k) * 16 + ln];
+            Bt[k] = am * p[(PR::BT + k) * 12 + ci];
             if (act) lds[L::BL + k * 12 + ci] = Bt[k];
         }
-        csc = p[PR::CSC * 16 + ln]; cinv = 1.0 / csc; qd = csc * q2s;
-        set_rotation(p[PR::CY * 16 + ln], p[PR::SY * 16 + ln]);
-        rho = p[PR::RHO * 16 + ln];
-        lo_u = p[PR::LO * 16 + ln]; hi_u = p[PR::HI * 16 + ln];
+        csc = p[PR::CSC * 12 + ci]; cinv = 1.0 / csc; qd = csc * q2s;
+        set_rotation(p[PR::CY * 12 + ci], p[PR::SY * 12 + ci]);
+        rho = p[PR::RHO * 12 + ci];
+        lo_u = am * p[PR::LO * 12 + ci]; hi_u = am * p[PR::HI * 12 + ci];
         lb0 = comp == 2 ? lo_u : 0.0; ub0 = comp == 2 ? hi_u : kInfty;
-        eqmask = static_cast<unsigned>(p[PR::EQ * 16 + ln]);
-        const int fl = static_cast<int>(p[PR::FLAGS * 16 + ln]);
-        warm = fl & 1; first_special = (fl & 2) != 0;
+        eqmask = act ? static_cast<unsigned>(p[PR::EQ * 12 + ci]) : 0u;
         warm_y_in = io.warm_y;
         row_sync();
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false;
