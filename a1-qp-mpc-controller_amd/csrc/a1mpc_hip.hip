@@ -63,6 +63,59 @@ __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, cons
 
 __global__ void a1mpc_noop_kernel() {}
 
+// ---- N2a: update_plan (S/A1RobotControl.cpp:148-202), one lane per (robot, leg) ------------------------------------------------
+// Element-wise and HBM-bound: ~0.5 KB in + 0.3 KB out per robot.  The four lanes of a robot read the same robot-level words
+// (one transaction) and write consecutive 24-byte segments.  No FMA contraction: the results are bit-identical to the reference's
+// C++ arithmetic (and to the oracle, which is compiled the same way).
+struct PlanArgs {
+    a1mpc_gait_config g;
+    int32_t n;
+    const uint8_t* movement_mode;
+    double* gait_counter;
+    const double *gait_counter_speed, *root_lin_vel, *Rz, *Rw, *root_pos, *root_lin_vel_d;
+    uint8_t* plan_contacts;
+    double *rel, *abs_, *world;
+};
+__global__ __launch_bounds__(256) void a1mpc_plan_kernel(const PlanArgs a) {
+#pragma clang fp contract(off)
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t b = gid >> 2;
+    const int leg = static_cast<int>(gid & 3);
+    if (b >= a.n) return;
+    double gc = a.gait_counter[b * 4 + leg];
+    const double spd = a.gait_counter_speed[b * 4 + leg];
+    uint8_t pc;
+    if (!a.movement_mode[b]) {                                  // :150-153
+        pc = 1; gc = a.g.gait_counter_reset[leg];
+    } else {                                                    // :155-165
+        gc = gc + spd;
+        gc = fmod(gc, a.g.counter_per_gait);
+        pc = gc <= a.g.counter_per_swing ? 1 : 0;
+    }
+    a.gait_counter[b * 4 + leg] = gc;
+    a.plan_contacts[b * 4 + leg] = pc;
+    const double* Rz = a.Rz + b * 9; const double* Rw = a.Rw + b * 9;
+    const double* v = a.root_lin_vel + b * 3; const double* vd = a.root_lin_vel_d + b * 3; const double* pos = a.root_pos + b * 3;
+    const double vrx = Rz[0] * v[0] + Rz[3] * v[1] + Rz[6] * v[2];   // :168-169  Rz' v
+    const double vry = Rz[1] * v[0] + Rz[4] * v[1] + Rz[7] * v[2];
+    const double k = sqrt(fabs(a.g.default_foot_pos[2]) / 9.8);       // default_foot_pos(2): linear index 2 = z of leg 0
+    const double half_swing = ((a.g.counter_per_swing / spd) * a.g.control_dt) / 2.0;
+    double dx = k * (vrx - vd[0]) + half_swing * vd[0];              // :175-182
+    double dy = k * (vry - vd[1]) + half_swing * vd[1];
+    if (dx < -a.g.foot_delta_x_limit) dx = -a.g.foot_delta_x_limit;
+    if (dx > a.g.foot_delta_x_limit) dx = a.g.foot_delta_x_limit;
+    if (dy < -a.g.foot_delta_y_limit) dy = -a.g.foot_delta_y_limit;
+    if (dy > a.g.foot_delta_y_limit) dy = a.g.foot_delta_y_limit;
+    const double r0 = a.g.default_foot_pos[3 * leg + 0] + dx, r1 = a.g.default_foot_pos[3 * leg + 1] + dy, r2 = a.g.default_foot_pos[3 * leg + 2];
+    if (a.rel) { a.rel[b * 12 + 3 * leg + 0] = r0; a.rel[b * 12 + 3 * leg + 1] = r1; a.rel[b * 12 + 3 * leg + 2] = r2; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {                                    // :198-199
+        const double w = Rw[r * 3 + 0] * r0 + Rw[r * 3 + 1] * r1 + Rw[r * 3 + 2] * r2;
+        if (a.abs_) a.abs_[b * 12 + 3 * leg + r] = w;
+        if (a.world) a.world[b * 12 + 3 * leg + r] = w + pos[r];
+    }
+}
+
 template <int H>
 constexpr size_t lds_bytes(int rows) { return sizeof(double) * rows * Layout<H>::ROW_STRIDE; }
 
@@ -256,6 +309,64 @@ void a1mpc_default_balance_config(a1mpc_balance_config* q) {
     const double Q[6] = {1.0, 1.0, 1.0, 400.0, 400.0, 100.0};  // S/A1RobotControl.cpp:11
     std::memcpy(q->Q, Q, sizeof Q);
     q->R = 1e-3; q->mu = 0.7; q->F_min = 0.0; q->F_max = 180.0;  // S/A1RobotControl.cpp:12-15
+}
+
+void a1mpc_default_gait_config(a1mpc_gait_config* g) {
+    if (!g) return;
+    std::memset(g, 0, sizeof *g);
+    g->counter_per_gait = 240.0; g->counter_per_swing = 120.0;        // S/A1CtrlStates.h:24-25
+    g->control_dt = 0.0025;                                            // MAIN_UPDATE_FREQUENCY 2.5 ms, S/A1CtrlStates.h:332
+    g->foot_delta_x_limit = 0.1; g->foot_delta_y_limit = 0.1;          // S/A1Params.h:44-45
+    const double dfp[12] = {0.17, 0.15, -0.35, 0.17, -0.15, -0.35, -0.17, 0.15, -0.35, -0.17, -0.15, -0.35};  // S/A1CtrlStates.h:45-47
+    std::memcpy(g->default_foot_pos, dfp, sizeof dfp);
+    const double rs[4] = {0.0, 120.0, 120.0, 0.0};                     // S/A1CtrlStates.h:324
+    std::memcpy(g->gait_counter_reset, rs, sizeof rs);
+}
+
+a1mpc_status a1mpc_update_plan_batch(a1mpc_handle h, const a1mpc_gait_config* gait, int32_t n, const uint8_t* movement_mode,
+                                     double* gait_counter, const double* gait_counter_speed, const double* root_lin_vel,
+                                     const double* R_z, const double* R_world, const double* root_pos, const double* root_lin_vel_d,
+                                     uint8_t* plan_contacts_out, double* rel_out, double* abs_out, double* world_out) {
+    if (!h || !gait) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle/config");
+    if (n < 0 || !movement_mode || !gait_counter || !gait_counter_speed || !root_lin_vel || !R_z || !R_world || !root_pos || !root_lin_vel_d ||
+        !plan_contacts_out)
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    const size_t N = n;
+    hipStream_t s = h->stream;
+    // staging inside the MPC buffers of the handle (sized for max_batch): in  = d_xref [gc 4 | spd 4 | v 3 | vd 3 | pos 3 | Rz 9 | Rw 9] (35 <= 13H for H >= 3),
+    //                                                                  out = d_u    [rel 12 | abs 12 | world 12] (36 <= 12H for H >= 3)
+    if (h->cfg.horizon < 3) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "update_plan staging needs a handle with horizon >= 3");
+    double* din = h->d_xref;
+    double *d_gc = din, *d_spd = d_gc + 4 * N, *d_v = d_spd + 4 * N, *d_vd = d_v + 3 * N, *d_pos = d_vd + 3 * N, *d_Rz = d_pos + 3 * N, *d_Rw = d_Rz + 9 * N;
+    double *d_rel = h->d_u, *d_abs = d_rel + 12 * N, *d_world = d_abs + 12 * N;
+    uint8_t* d_mm = h->d_contact;                       // n bytes of the 4n
+    uint8_t* d_pc = reinterpret_cast<uint8_t*>(h->d_iters);  // 4n bytes
+    A1_HIP(hipMemcpyAsync(d_gc, gait_counter, N * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_spd, gait_counter_speed, N * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_v, root_lin_vel, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_vd, root_lin_vel_d, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_pos, root_pos, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_Rz, R_z, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_Rw, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_mm, movement_mode, N, hipMemcpyHostToDevice, s));
+    PlanArgs a;
+    a.g = *gait; a.n = n; a.movement_mode = d_mm; a.gait_counter = d_gc; a.gait_counter_speed = d_spd; a.root_lin_vel = d_v; a.Rz = d_Rz; a.Rw = d_Rw;
+    a.root_pos = d_pos; a.root_lin_vel_d = d_vd; a.plan_contacts = d_pc; a.rel = d_rel; a.abs_ = d_abs; a.world = d_world;
+    A1_HIP(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(a1mpc_plan_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    A1_HIP(hipGetLastError());
+    A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = true; h->last_stream = s;
+    A1_HIP(hipMemcpyAsync(gait_counter, d_gc, N * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipMemcpyAsync(plan_contacts_out, d_pc, N * 4, hipMemcpyDeviceToHost, s));
+    if (rel_out) A1_HIP(hipMemcpyAsync(rel_out, d_rel, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (abs_out) A1_HIP(hipMemcpyAsync(abs_out, d_abs, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (world_out) A1_HIP(hipMemcpyAsync(world_out, d_world, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipStreamSynchronize(s));
+    return A1MPC_OK;
 }
 
 const char* a1mpc_status_string(a1mpc_status s) {

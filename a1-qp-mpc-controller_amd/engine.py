@@ -30,7 +30,13 @@ class BalanceConfig(C.Structure):  # a1mpc_balance_config
     _fields_ = [("Q", C.c_double * 6), ("R", C.c_double), ("mu", C.c_double), ("F_min", C.c_double), ("F_max", C.c_double)]
 
 
-EXPORTS = ["a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
+class GaitConfig(C.Structure):  # a1mpc_gait_config
+    _fields_ = [("counter_per_gait", C.c_double), ("counter_per_swing", C.c_double), ("control_dt", C.c_double),
+                ("foot_delta_x_limit", C.c_double), ("foot_delta_y_limit", C.c_double), ("default_foot_pos", C.c_double * 12),
+                ("gait_counter_reset", C.c_double * 4)]
+
+
+EXPORTS = ["a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
 
@@ -62,6 +68,9 @@ def load_library(path=None):
     lib.a1mpc_solve_batch_ticks_device.argtypes = [vp, i32] + [vp] * 8 + [vp]; lib.a1mpc_solve_batch_ticks_device.restype = C.c_int
     lib.a1mpc_balance_solve_batch.argtypes = [vp, C.POINTER(BalanceConfig), i32, dp, dp, dp, dp, u8p, dp, dp, i32p, i32p]
     lib.a1mpc_balance_solve_batch.restype = C.c_int
+    lib.a1mpc_default_gait_config.argtypes = [C.POINTER(GaitConfig)]; lib.a1mpc_default_gait_config.restype = None
+    lib.a1mpc_update_plan_batch.argtypes = [vp, C.POINTER(GaitConfig), i32, u8p, dp, dp, dp, dp, dp, dp, dp, u8p, dp, dp, dp]
+    lib.a1mpc_update_plan_batch.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
     lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int
     lib.a1mpc_last_nfact.argtypes = [vp, i32, i32p]; lib.a1mpc_last_nfact.restype = C.c_int
@@ -183,6 +192,21 @@ class Engine:
                                                 contact.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(grf), _dp(f), _ip(iters), _ip(status))
         _check(self.lib, rc, "a1mpc_balance_solve_batch")
         return dict(grf=grf, f_world=f, iters=iters, status=status)
+
+    # ---- N2a: gait plan + Raibert foothold (S/A1RobotControl.cpp:148-202) ----
+    def update_plan(self, movement_mode, gait_counter, gait_counter_speed, root_lin_vel, Rz, R, root_pos, root_lin_vel_d, gait=None):
+        if gait is None:
+            gait = GaitConfig(); self.lib.a1mpc_default_gait_config(C.byref(gait))
+        gc = np.array(gait_counter, dtype=np.float64).reshape(-1, 4); n = gc.shape[0]
+        mm = np.ascontiguousarray(movement_mode, dtype=np.uint8).reshape(n)
+        spd = _f64(gait_counter_speed, (n, 4)); v = _f64(root_lin_vel, (n, 3)); Rz = _f64(Rz, (n, 9)); R = _f64(R, (n, 9))
+        pos = _f64(root_pos, (n, 3)); vd = _f64(root_lin_vel_d, (n, 3))
+        pc = np.zeros((n, 4), np.uint8); rel = np.zeros((n, 12)); ab = np.zeros((n, 12)); wo = np.zeros((n, 12))
+        u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+        rc = self.lib.a1mpc_update_plan_batch(self._h, C.byref(gait), n, u8(mm), _dp(gc), _dp(spd), _dp(v), _dp(Rz), _dp(R), _dp(pos), _dp(vd), u8(pc),
+                                              _dp(rel), _dp(ab), _dp(wo))
+        _check(self.lib, rc, "a1mpc_update_plan_batch")
+        return dict(gait_counter=gc, plan_contacts=pc, foot_pos_target_rel=rel, foot_pos_target_abs=ab, foot_pos_target_world=wo)
 
     def reset_warm_start(self):
         _check(self.lib, self.lib.a1mpc_reset_warm_start(self._h), "a1mpc_reset_warm_start")

@@ -147,6 +147,30 @@ a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_confi
                                        const uint8_t* contact, double* grf_body_out, double* f_world_out,
                                        int32_t* iters_out, int32_t* status_out);
 
+/*
+ * N2a (the caller side of the path): A1RobotControl::update_plan, S/A1RobotControl.cpp:148-202, for n robots -- gait counters,
+ * planned contacts and the Raibert foothold.  Element-wise, HBM-bound; results are bit-identical to the reference arithmetic.
+ *   movement_mode      n          0 = stand (all feet planned in contact, counters reset), 1 = walk
+ *   gait_counter       n x 4      in/out
+ *   gait_counter_speed n x 4
+ *   root_lin_vel n x 3 (world), R_z n x 9 (root_rot_mat_z), R_world n x 9 (root_rot_mat), root_pos n x 3, root_lin_vel_d n x 3 (body)
+ * out: plan_contacts n x 4, foot_pos_target_rel / _abs / _world n x 12 each (3x4 column-major); any of the three may be NULL.
+ * Host pointers.
+ */
+typedef struct a1mpc_gait_config {
+    double counter_per_gait, counter_per_swing; /* S/A1CtrlStates.h:24-25 */
+    double control_dt;                          /* S/A1CtrlStates.h:332 */
+    double foot_delta_x_limit, foot_delta_y_limit; /* S/A1Params.h:44-45 */
+    double default_foot_pos[12];                /* 3x4 column-major, S/A1CtrlStates.h:45 */
+    double gait_counter_reset[4];               /* S/A1CtrlStates.h:322-326 */
+} a1mpc_gait_config;
+void a1mpc_default_gait_config(a1mpc_gait_config* cfg);
+a1mpc_status a1mpc_update_plan_batch(a1mpc_handle h, const a1mpc_gait_config* gait, int32_t n, const uint8_t* movement_mode,
+                                     double* gait_counter, const double* gait_counter_speed, const double* root_lin_vel,
+                                     const double* R_z, const double* R_world, const double* root_pos, const double* root_lin_vel_d,
+                                     uint8_t* plan_contacts_out, double* foot_pos_target_rel_out, double* foot_pos_target_abs_out,
+                                     double* foot_pos_target_world_out);
+
 /* forget the carried (x, y, rho) of every problem: next solve is a cold start */
 a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h);
 

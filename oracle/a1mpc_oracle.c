@@ -674,6 +674,55 @@ int orc_balance_solve(const orc_qp_params *qp, const orc_settings *st, const dou
     return rc;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * N2a: A1RobotControl::update_plan, S/A1RobotControl.cpp:148-202 -- gait counters, planned contacts,
+ * Raibert foothold.  One robot; matrices 3x4 column-major (Eigen), rotation matrices row-major.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct orc_gait_params {
+    double counter_per_gait, counter_per_swing;   /* S/A1CtrlStates.h:24-25 */
+    double control_dt;                            /* S/A1CtrlStates.h:332 */
+    double foot_delta_x_limit, foot_delta_y_limit;/* S/A1Params.h:44-45 */
+    double default_foot_pos[12];                  /* 3x4 column-major, S/A1CtrlStates.h:45 */
+    double gait_counter_reset[4];                 /* S/A1CtrlStates.h:322-326 (gait_type 1: 0,120,120,0) */
+} orc_gait_params;
+
+void orc_update_plan(const orc_gait_params *gp, int movement_mode, double *gait_counter, const double *gait_counter_speed,
+                     const double *root_lin_vel, const double *Rz, const double *Rw, const double *root_pos,
+                     const double *root_lin_vel_d, uint8_t *plan_contacts, double *foot_pos_target_rel,
+                     double *foot_pos_target_abs, double *foot_pos_target_world) {
+    if (!movement_mode) {                                             /* :150-153 */
+        for (int i = 0; i < NLEG; ++i) { plan_contacts[i] = 1; gait_counter[i] = gp->gait_counter_reset[i]; }
+    } else {                                                          /* :155-165 */
+        for (int i = 0; i < NLEG; ++i) {
+            gait_counter[i] = gait_counter[i] + gait_counter_speed[i];
+            gait_counter[i] = fmod(gait_counter[i], gp->counter_per_gait);
+            plan_contacts[i] = gait_counter[i] <= gp->counter_per_swing ? 1 : 0;
+        }
+    }
+    double lin_vel_rel[3];                                            /* :168-169  Rz' * v_world */
+    for (int i = 0; i < 3; ++i) lin_vel_rel[i] = Rz[0 * 3 + i] * root_lin_vel[0] + Rz[1 * 3 + i] * root_lin_vel[1] + Rz[2 * 3 + i] * root_lin_vel[2];
+    for (int k = 0; k < 12; ++k) foot_pos_target_rel[k] = gp->default_foot_pos[k];   /* :172 */
+    for (int i = 0; i < NLEG; ++i) {                                  /* :173-201 */
+        /* default_foot_pos(2) in the reference is LINEAR index 2 of the 3x4 matrix = z of leg 0 */
+        double delta_x = sqrt(fabs(gp->default_foot_pos[2]) / 9.8) * (lin_vel_rel[0] - root_lin_vel_d[0]) +
+                         ((gp->counter_per_swing / gait_counter_speed[i]) * gp->control_dt) / 2.0 * root_lin_vel_d[0];
+        double delta_y = sqrt(fabs(gp->default_foot_pos[2]) / 9.8) * (lin_vel_rel[1] - root_lin_vel_d[1]) +
+                         ((gp->counter_per_swing / gait_counter_speed[i]) * gp->control_dt) / 2.0 * root_lin_vel_d[1];
+        if (delta_x < -gp->foot_delta_x_limit) delta_x = -gp->foot_delta_x_limit;
+        if (delta_x > gp->foot_delta_x_limit) delta_x = gp->foot_delta_x_limit;
+        if (delta_y < -gp->foot_delta_y_limit) delta_y = -gp->foot_delta_y_limit;
+        if (delta_y > gp->foot_delta_y_limit) delta_y = gp->foot_delta_y_limit;
+        foot_pos_target_rel[3 * i + 0] += delta_x;
+        foot_pos_target_rel[3 * i + 1] += delta_y;
+        for (int r = 0; r < 3; ++r) {
+            double a = Rw[r * 3 + 0] * foot_pos_target_rel[3 * i + 0] + Rw[r * 3 + 1] * foot_pos_target_rel[3 * i + 1] +
+                       Rw[r * 3 + 2] * foot_pos_target_rel[3 * i + 2];
+            foot_pos_target_abs[3 * i + r] = a;
+            foot_pos_target_world[3 * i + r] = a + root_pos[r];
+        }
+    }
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

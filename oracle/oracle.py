@@ -207,5 +207,30 @@ def balance_root_acc(kp_lin, kd_lin, kp_ang, kd_ang, pos_d, pos, lin_vel_d_body,
     return out
 
 
+class GaitParams(C.Structure):
+    _fields_ = [("counter_per_gait", C.c_double), ("counter_per_swing", C.c_double), ("control_dt", C.c_double),
+                ("foot_delta_x_limit", C.c_double), ("foot_delta_y_limit", C.c_double), ("default_foot_pos", C.c_double * 12),
+                ("gait_counter_reset", C.c_double * 4)]
+
+
+def gait_params(default_foot_pos, counter_per_gait=240.0, counter_per_swing=120.0, control_dt=0.0025, dx=0.1, dy=0.1,
+                reset=(0.0, 120.0, 120.0, 0.0)):
+    p = GaitParams()
+    p.counter_per_gait, p.counter_per_swing, p.control_dt, p.foot_delta_x_limit, p.foot_delta_y_limit = counter_per_gait, counter_per_swing, control_dt, dx, dy
+    p.default_foot_pos[:] = list(np.asarray(default_foot_pos, dtype=float).reshape(12))
+    p.gait_counter_reset[:] = list(reset)
+    return p
+
+
+def update_plan(gp, movement_mode, gait_counter, gait_counter_speed, root_lin_vel, Rz, Rw, root_pos, root_lin_vel_d):
+    """S/A1RobotControl.cpp:148-202 for one robot; returns (gait_counter, plan_contacts, target_rel, target_abs, target_world)."""
+    gc = np.array(gait_counter, dtype=np.float64)
+    pc = np.zeros(4, np.uint8); rel = np.zeros(12); ab = np.zeros(12); wo = np.zeros(12)
+    a = lambda v: _p(np.ascontiguousarray(v, dtype=np.float64))
+    lib().orc_update_plan(C.byref(gp), C.c_int(int(movement_mode)), _p(gc), a(gait_counter_speed), a(root_lin_vel), a(Rz), a(Rw), a(root_pos),
+                          a(root_lin_vel_d), _p(pc, C.c_uint8), _p(rel), _p(ab), _p(wo))
+    return gc, pc, rel, ab, wo
+
+
 def num_threads():
     return lib().orc_num_threads()

@@ -255,3 +255,27 @@ def test_horizon_1_mpc(pkg, oracle, scen):
     with _engine(pkg, sc, 64, warm_start=0) as eng:
         out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
     compare(out, oracle_batch(oracle, sc), min_same=1.0)
+
+
+def test_update_plan_N2a_bit_exact(pkg, oracle, scen):
+    """gait counters, planned contacts, Raibert foothold (S/A1RobotControl.cpp:148-202) -- element-wise arithmetic,
+    so the bar is BIT-exact against the oracle's restatement (both built without FMA contraction)."""
+    rng = np.random.default_rng(7)
+    n = 5000
+    yaw = rng.uniform(-np.pi, np.pi, n); roll = rng.uniform(-0.2, 0.2, n); pit = rng.uniform(-0.2, 0.2, n)
+    R = scen.rot_zyx(roll, pit, yaw).reshape(n, 9); Rz = scen.rot_zyx(0 * yaw, 0 * yaw, yaw).reshape(n, 9)
+    mm = (rng.random(n) < 0.8).astype(np.uint8)
+    gc = rng.uniform(0, 240, (n, 4)); gc[::7] = [0, 120, 120, 0]; gc[::11, 0] = 239.0  # wrap-around through fmod
+    spd = rng.choice([1.0, 1.5, 2.0, 3.0], size=(n, 4))
+    v = rng.normal(0, 0.6, (n, 3)); vd = rng.normal(0, 0.6, (n, 3)); vd[::5] *= 10  # saturates FOOT_DELTA_*_LIMIT
+    pos = rng.normal(0, 2.0, (n, 3))
+    cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+    with pkg.Engine(cfg, n, 0) as eng:
+        out = eng.update_plan(mm, gc, spd, v, Rz, R, pos, vd)
+    gp = oracle.gait_params([0.17, 0.15, -0.35, 0.17, -0.15, -0.35, -0.17, 0.15, -0.35, -0.17, -0.15, -0.35])
+    for b in range(0, n, 3):
+        g2, pc, rel, ab, wo = oracle.update_plan(gp, mm[b], gc[b], spd[b], v[b], Rz[b], R[b], pos[b], vd[b])
+        assert (out["gait_counter"][b] == g2).all() and (out["plan_contacts"][b] == pc).all()
+        assert (out["foot_pos_target_rel"][b] == rel).all() and (out["foot_pos_target_abs"][b] == ab).all()
+        assert (out["foot_pos_target_world"][b] == wo).all()
+    assert (out["plan_contacts"][mm == 0] == 1).all() and (np.abs(out["foot_pos_target_rel"].reshape(n, 4, 3)[:, :, 0] - [0.17, 0.17, -0.17, -0.17]) <= 0.1 + 1e-15).all()

@@ -110,3 +110,21 @@ def test_oracle_reproduces_golden(oracle, scen, path):
     assert (d["iters"] == z["default_iters"]).all() and np.abs(d["u"] - z["default_u"]).max() < 1e-8
     e = oracle_batch(oracle, sc, settings=oracle.exact_settings())
     assert np.abs(e["u"] - z["exact_u"]).max() < 1e-6
+
+
+def test_update_plan_restatement(oracle):
+    """N2a oracle vs a direct numpy transcription of S/A1RobotControl.cpp:148-202 on hand-picked cases"""
+    dfp = np.array([0.17, 0.15, -0.35, 0.17, -0.15, -0.35, -0.17, 0.15, -0.35, -0.17, -0.15, -0.35])
+    gp = oracle.gait_params(dfp)
+    Rz = np.eye(3).reshape(9); R = np.eye(3).reshape(9)
+    # stand: counters reset, all feet planned in contact, no velocity -> default footholds
+    gc, pc, rel, ab, wo = oracle.update_plan(gp, 0, [5, 6, 7, 8], [2, 2, 2, 2], [0, 0, 0], Rz, R, [1, 2, 3], [0, 0, 0])
+    assert list(gc) == [0, 120, 120, 0] and list(pc) == [1, 1, 1, 1] and (rel == dfp).all() and np.allclose(wo.reshape(4, 3), dfp.reshape(4, 3) + [1, 2, 3])
+    # walk: counter advance, wrap and swing threshold
+    gc, pc, rel, ab, wo = oracle.update_plan(gp, 1, [119, 120, 239, 0], [2, 2, 2, 2], [0.5, 0, 0], Rz, R, [0, 0, 0], [0.5, 0, 0])
+    assert list(gc) == [121, 122, 1, 2] and list(pc) == [0, 0, 1, 1]
+    dx = np.sqrt(0.35 / 9.8) * 0.0 + ((120 / 2.0) * 0.0025) / 2.0 * 0.5
+    assert np.allclose(rel.reshape(4, 3)[:, 0], dfp.reshape(4, 3)[:, 0] + dx, rtol=0, atol=1e-16)
+    # saturation of the foothold offsets
+    gc, pc, rel, ab, wo = oracle.update_plan(gp, 1, [0, 0, 0, 0], [2, 2, 2, 2], [5.0, -5.0, 0], Rz, R, [0, 0, 0], [0, 0, 0])
+    assert np.allclose(rel.reshape(4, 3)[:, 0] - dfp.reshape(4, 3)[:, 0], 0.1) and np.allclose(rel.reshape(4, 3)[:, 1] - dfp.reshape(4, 3)[:, 1], -0.1)
