@@ -177,11 +177,15 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
 }
 template <int H>
 static a1mpc_status launch_split(const KernelArgs& a, double* prep, int* counter, hipStream_t stream) {
+#ifdef A1MPC_DEV_SLIM  // kernel-tuning builds: one instantiation (H = 10, two rows), seconds instead of minutes to compile
+    return launch_split_rows<H, 2>(a, prep, counter, stream);
+#else
     switch (rows_per_wg()) {
         case 1: return launch_split_rows<H, 1>(a, prep, counter, stream);
         case 2: return launch_split_rows<H, 2>(a, prep, counter, stream);
     }
     return launch_split_rows<H, 4>(a, prep, counter, stream);
+#endif
 }
 static size_t prep_stride(int horizon) {
     switch (horizon) {
@@ -220,18 +224,22 @@ static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
 static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s) {
     if (a.n >= split_threshold() && prep && counter) {
         switch (horizon) {
-            case 1: return launch_split<1>(a, prep, counter, s);
             case 10: return launch_split<10>(a, prep, counter, s);
+#ifndef A1MPC_DEV_SLIM
+            case 1: return launch_split<1>(a, prep, counter, s);
             case 16: return launch_split<16>(a, prep, counter, s);
             case 20: return launch_split<20>(a, prep, counter, s);
+#endif
         }
     }
+#ifndef A1MPC_DEV_SLIM
     switch (horizon) {
         case 1: return launch<1, kModeMpc>(a, s);
         case 10: return launch<10, kModeMpc>(a, s);
         case 16: return launch<16, kModeMpc>(a, s);
         case 20: return launch<20, kModeMpc>(a, s);
     }
+#endif
     return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be 1, 10, 16 or 20");
 }
 static size_t lds_bytes_of(int horizon) {
@@ -631,7 +639,11 @@ a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_confi
     a.grf = h->d_grf; a.u_full = h->d_u; a.iters = h->d_iters; a.status = h->d_status; a.nfact = h->d_nfact;
     h->last_stream = s;
     A1_HIP(hipEventRecord(h->ev0, s));
+#ifdef A1MPC_DEV_SLIM
+    a1mpc_status st = fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "slim development build");
+#else
     a1mpc_status st = launch<1, kModeBalance>(a, s);
+#endif
     if (st != A1MPC_OK) return st;
     A1_HIP(hipEventRecord(h->ev1, s));
     h->timed = true;

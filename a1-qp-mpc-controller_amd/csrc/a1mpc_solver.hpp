@@ -141,7 +141,8 @@ struct Layout {
     static constexpr int SLOT = K_SZ + S_SZ; // 234 doubles per horizon step
     static constexpr int FAC = 0;
     static constexpr int BL = H * SLOT;      // B~ (6x12): rows 0-2 = dt*Iw^-1*skew(r), rows 3-5 = dt/m*I
-    static constexpr int CG = BL + 72;       // c*g = D^-1 q_s, [t][12]
+    static constexpr int ZROW = 6;           // a seventh, all-zero row of B~: the row of every lane that owns no wrench state
+    static constexpr int CG = BL + 84;       // c*g = D^-1 q_s, [t][12]
     static constexpr int RAW = CG + 12 * H;
     // set-up-only aliases inside the factor region (the factor is written after Ruiz is finished)
     static constexpr int TBL = 0;            // T*B~_omega (3x12)
@@ -166,7 +167,8 @@ struct LayoutSetup {
     static constexpr int TBL = 0;
     static constexpr int DL = 36;
     static constexpr int BL = DL + 12 * H;
-    static constexpr int CG = BL + 72;
+    static constexpr int ZROW = 6;
+    static constexpr int CG = BL + 84;
     static constexpr int RAW = CG + 12 * H;
     static constexpr int ROW_STRIDE = RAW + (RAW % 2);
 };
@@ -235,7 +237,7 @@ struct RowSolver {
         tri = ci * (ci + 1) / 2;
         krow = ci * L::KSTR;
         wl = act && quad >= 2;           // wrench lanes: state rows 6..11 = quads 2, 3
-        brow = lds + L::BL + (wl ? ci - 6 : 0) * 12;
+        brow = lds + L::BL + (wl ? ci - 6 : L::ZROW) * 12;
         dt = P.dt; mu = P.mu;
         q2s = act ? P.q2[ci] : 0.0;      // state-lane weight 2 q_i
         r2a = act ? P.r2[ci] : 0.0;      // force-lane weight 2 r_a
@@ -272,8 +274,7 @@ struct RowSolver {
         double Br[12];
 #pragma unroll
         for (int b = 0; b < 12; ++b) Br[b] = brow[b];
-        const double r = dot_bc<0>(Br, u);
-        return wl ? r : 0.0;
+        return dot_bc<0>(Br, u);  // lanes without a wrench state read the zero row
     }
     A1_DEV void bounds_from_contact(double cf) {
         lo_u = P.fz_min * cf; hi_u = P.fz_max * cf;
@@ -351,6 +352,7 @@ struct RowSolver {
         if (act) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) lds[L::BL + k * 12 + ci] = Bt[k];
+            lds[L::BL + L::ZROW * 12 + ci] = 0.0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) lds[L::TBL + k * 12 + ci] = TB[k];
         }
@@ -571,6 +573,7 @@ struct RowSolver {
             Bt[k] = am * p[(PR::BT + k) * 12 + ci];
             if (act) lds[L::BL + k * 12 + ci] = Bt[k];
         }
+        if (act) lds[L::BL + L::ZROW * 12 + ci] = 0.0;
         csc = p[PR::CSC * 12 + ci]; cinv = 1.0 / csc; qd = csc * q2s;
         set_rotation(p[PR::CY * 12 + ci], p[PR::SY * 12 + ci]);
         rho = p[PR::RHO * 12 + ci];
@@ -706,8 +709,11 @@ struct RowSolver {
         const double sigma_l = row_opaque(P.sigma), lb0_l = row_opaque(lb0), ub0_l = row_opaque(ub0);
         const double al = P.alpha, oma = 1.0 - P.alpha;
         const double muz = comp == 2 ? mu : 0.0, mux = comp < 2 ? mu : 0.0, al1 = comp < 2 ? al : 0.0;  // selects folded into multipliers
+        // One wave per SIMD: every instruction costs an issue slot, so the sweeps are written for instruction count --
+        // accumulator chains are seeded with values that have to be added anyway (no zero-initialised partners, no final
+        // adds), independent chains are interleaved by hand, subtraction rides on the NEG modifier of v_fmac_f64_dpp.
         double d[H];
-        double pv = row_dpp_ready(0.0);  // costate p_{t+1}, state layout
+        double pv = 0.0;  // costate p_{t+1}, state layout (dpp-ready at the top of every step)
         static_for<H>([&](auto TT) {
             constexpr int t = H - 1 - A1_CV(TT);
             const double* slot = lds + L::FAC + t * L::SLOT;
@@ -719,6 +725,7 @@ struct RowSolver {
                 if constexpr (t > 0) Kc[b] = slot[b * L::KSTR + ci];
             });
             const double cgt = lds[L::CG + t * 12 + ci];
+            row_sched_fence();
             // rhs of update_xz_tilde premultiplied by D^-1:  b = sigma D^-2 xh - c g + A' [E (rho z_s - y_s)]
             double t0, t1;
             if constexpr (FIRST) {  // E (rho z_s - y_s) = rr (A x0) - c y0
@@ -731,19 +738,45 @@ struct RowSolver {
                 t0 = rr0[t] * (comp == 2 ? xh[t] : fma(mu, xz, xh[t])) - csc * yw0;
                 t1 = rr1[t] * fma(-mu, xz, xh[t]) - csc * yw1;
             } else {                // E (rho z_s - y_s) = rr (2 Pi(wh) - wh)
-                const double z0 = fmin(fmax(wh0[t], lb0_l), ub0_l), z1 = fmin(wh1[t], 0.0);
+                const double z0 = min_f64(max_f64(wh0[t], lb0_l), ub0_l), z1 = min_f64(wh1[t], 0.0);
                 t0 = rr0[t] * fma(2.0, z0, -wh0[t]);
                 t1 = rr1[t] * fma(2.0, z1, -wh1[t]);
             }
             const double sm = t0 - t1;
             const double smx = quad_perm<0, 0, 0, 0>(sm), smy = quad_perm<1, 1, 1, 1>(sm);
             const double at = fma(muz, smx + smy, t0 + t1);  // fz lanes: t1 == 0 (rr1 == 0); fx/fy lanes: muz == 0
-            const double bt = fma(sigma_l * dI2[t], xh[t], at - cgt);
-            const double r = row_dpp_ready(bt - BtT(pv));
-            d[t] = dot_bc<0>(Sr, r);
-            if constexpr (t > 0) pv = row_dpp_ready(dot_bc<0>(Kc, r, opAT(pv)));
+            // r = b - B~' p_{t+1} as two partial sums; A' p_{t+1} seeds the two costate accumulators
+            double ra = at - cgt, rb = (sigma_l * dI2[t]) * xh[t];
+            double pa = 0.0, pb = 0.0;
+            if constexpr (t < H - 1) {
+                static_for<3>([&](auto J) {
+                    constexpr int j = 2 * A1_CV(J);
+                    fnma_bcast<lane_of(6 + j)>(ra, Bt[j], pv);
+                    fnma_bcast<lane_of(6 + j + 1)>(rb, Bt[j + 1], pv);
+                });
+                if constexpr (t > 0) {
+                    pa = pv; pb = gV * row_ror<8>(pv);
+                    fma_bcast<0>(pa, gA, pv); fma_bcast<1>(pb, gB, pv); fma_bcast<2>(pa, gC, pv);
+                }
+            }
+            const double r = row_dpp_ready(ra + rb);
+            // d_t = S_t^-1 r  interleaved with  p_t = A' p_{t+1} + K_t' r
+            double da = 0.0;
+            if constexpr (t > 0) {
+                static_for<6>([&](auto J) {
+                    constexpr int b = 2 * A1_CV(J);
+                    fma_bcast<lane_of(b)>(da, Sr[b], r);
+                    fma_bcast<lane_of(b)>(pa, Kc[b], r);
+                    fma_bcast<lane_of(b + 1)>(da, Sr[b + 1], r);
+                    fma_bcast<lane_of(b + 1)>(pb, Kc[b + 1], r);
+                });
+                d[t] = da;
+                pv = row_dpp_ready(pa + pb);
+            } else {
+                d[t] = dot_bc<0>(Sr, r);
+            }
         });
-        double s = row_dpp_ready(0.0);  // state x_t of the LQ roll-out (x_0 = 0)
+        double s = 0.0;  // state x_t of the LQ roll-out (x_0 = 0); dpp-ready at the top of every step
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
             const double* slot = lds + L::FAC + t * L::SLOT;
@@ -754,13 +787,30 @@ struct RowSolver {
                 if constexpr (t > 0) Kr[b] = slot[krow + b];
                 if constexpr (t < H - 1) Br[b] = brow[b];
             });
-            double v = d[t];
-            if constexpr (t > 0) v -= dot_bc<0>(Kr, s);
+            row_sched_fence();
+            // v_t = d_t - K_t x_t, and A x_t as the seed of x_{t+1} = A x_t + B~ v_t
+            double va = d[t], vb = 0.0, sa = 0.0, sb = 0.0;
+            if constexpr (t > 0) {
+                if constexpr (t < H - 1) {
+                    sa = s; sb = fP * row_ror<8>(s);
+                    fma_bcast<8>(sa, fA, s); fma_bcast<9>(sb, fB, s); fma_bcast<10>(sa, fC, s);
+                }
+                static_for<6>([&](auto J) {
+                    constexpr int b = 2 * A1_CV(J);
+                    fnma_bcast<lane_of(b)>(va, Kr[b], s);
+                    fnma_bcast<lane_of(b + 1)>(vb, Kr[b + 1], s);
+                });
+            }
+            double v = t > 0 ? va + vb : va;
             v = act ? v : 0.0;  // pad lanes carry no force
             if constexpr (t < H - 1) {
-                const double as = opA(s);
-                const double asb = dot_bc<0>(Br, row_dpp_ready(v), as);
-                s = row_dpp_ready(wl ? asb : as);
+                const double vr = row_dpp_ready(v);
+                static_for<6>([&](auto J) {
+                    constexpr int b = 2 * A1_CV(J);
+                    fma_bcast<lane_of(b)>(sa, Br[b], vr);
+                    fma_bcast<lane_of(b + 1)>(sb, Br[b + 1], vr);
+                });
+                s = row_dpp_ready(sa + sb);  // lanes without a wrench state read the zero row of B~
             }
             // z~ = A v (unscaled), then update_x / update_z / update_y in the w form
             const double vz = quad_perm<2, 2, 2, 2>(v);
@@ -777,7 +827,7 @@ struct RowSolver {
                 wh0[t] = al * av0 + oma * z00 + (rr0[t] > 0.0 ? csc * yw0 / rr0[t] : 0.0);
                 wh1[t] = comp < 2 ? al * av1 + oma * z01 + (rr1[t] > 0.0 ? csc * yw1 / rr1[t] : 0.0) : 0.0;
             } else {                // w+ = w + alpha (z~ - Pi(w))
-                const double z0 = fmin(fmax(wh0[t], lb0_l), ub0_l), z1 = fmin(wh1[t], 0.0);
+                const double z0 = min_f64(max_f64(wh0[t], lb0_l), ub0_l), z1 = min_f64(wh1[t], 0.0);
                 wh0[t] = fma(al, av0 - z0, wh0[t]);
                 wh1[t] = fma(al1, av1 - z1, wh1[t]);  // stays 0 on fz lanes
             }

@@ -57,6 +57,24 @@ A1_DEV void fma_bcast(double& acc, double m, double x) {
     static_assert(L >= 0 && L < 16, "lane");
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(L));
 }
+// acc -= m * (lane L of my row's x): the same instruction with the NEG source modifier
+template <int L>
+A1_DEV void fnma_bcast(double& acc, double m, double x) {
+    static_assert(L >= 0 && L < 16, "lane");
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(L));
+}
+// min / max as single instructions: fmin()/fmax() make hipcc canonicalise loop-carried operands first (v_max_f64 x, x, x),
+// one extra FP64 issue slot per operand in the projection of every ADMM row.  Operands here are never signalling NaNs.
+A1_DEV double max_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+A1_DEV double min_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 A1_DEV double row_dpp_ready(double x) {
     asm volatile("s_nop 1" : "+v"(x));
     return x;
@@ -67,6 +85,9 @@ A1_DEV void row_dpp_ready12(double (&v)[12]) {
     asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
                  "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
 }
+
+// Scheduling fence: the machine scheduler moves nothing across it (keeps a step's LDS reads ahead of the arithmetic that hides them).
+A1_DEV void row_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 // Optimisation barrier: the value becomes opaque to the compiler (no code is emitted).
 A1_DEV double row_opaque(double v) {

@@ -30,11 +30,16 @@ inline double quad_perm(double v) {
 }
 template <int L>
 inline void fma_bcast(double& acc, double m, double x) { acc = fma(m, emu_publish(x)[L], acc); }
+template <int L>
+inline void fnma_bcast(double& acc, double m, double x) { acc = fma(-m, emu_publish(x)[L], acc); }
+inline double max_f64(double a, double b) { return fmax(a, b); }
+inline double min_f64(double a, double b) { return fmin(a, b); }
 inline double row_dpp_ready(double x) { return x; }
 inline void row_dpp_ready12(double (&)[12]) {}
 inline void row_sync() { (void)emu_publish(0.0); }
 
 
+inline void row_sched_fence() {}
 inline double row_opaque(double v) { return v; }
 
 

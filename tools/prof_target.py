@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Profiling target: a few launches of the hot kernel on BASELINE configs[2] (4096 QPs, h=10).  usage: prof_target.py [fixed_iters]"""
+"""Profiling target: a few launches of the hot kernel on BASELINE configs[2] (4096 QPs, h=10).  usage: prof_target.py [fixed_iters [n]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 import torch
 pkg = g.load_package()
-n = 4096
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 sc = pkg.scenarios.config3_random_flat(nb=n)
 osqp = dict(warm_start=0)
 if len(sys.argv) > 1:
