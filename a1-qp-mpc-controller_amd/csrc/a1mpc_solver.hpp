@@ -211,6 +211,8 @@ struct RowSolver {
     double dt, mu;
     // per-lane constants of the problem
     double Bt[6];  // my column of B~ (force layout); zero on pad lanes
+    double Brw[12];  // my row of B~ (state layout; zeros on lanes without a wrench state): step-invariant, so it stays in registers --
+                     // an LDS read costs the wave ~12 issue cycles whatever its width (tools/ubench/issue_cost_ubench.hip)
     double cy, sy, fA, fB, fC, fP, gA, gB, gC, gV, q2s, r2a;
     double csc, cinv, qd, lo_u, hi_u, lb0, ub0;
     unsigned eqmask;  // bit t: my slot-0 row at step t is an equality row (swing leg: l = u = 0; auxil.c set_rho_vec)
@@ -693,6 +695,8 @@ struct RowSolver {
             }
             row_sync();  // K_t and S_t^-1 of this step are in LDS before the next step reuses the registers' sources
         }
+#pragma unroll
+        for (int b = 0; b < 12; ++b) Brw[b] = brow[b];
         need_factor = false;
         if (!fac_ok) { status = A1MPC_NON_CVX; done = true; }
     }
@@ -745,93 +749,75 @@ struct RowSolver {
             const double sm = t0 - t1;
             const double smx = quad_perm<0, 0, 0, 0>(sm), smy = quad_perm<1, 1, 1, 1>(sm);
             const double at = fma(muz, smx + smy, t0 + t1);  // fz lanes: t1 == 0 (rr1 == 0); fx/fy lanes: muz == 0
-            // r = b - B~' p_{t+1} as two partial sums; A' p_{t+1} seeds the two costate accumulators
-            double ra = at - cgt, rb = (sigma_l * dI2[t]) * xh[t];
-            double pa = 0.0, pb = 0.0;
+            // r = b - B~' p_{t+1};  d_t = S_t^-1 r  interleaved with  p_t = A' p_{t+1} + K_t' r   (instruction blocks, a1mpc_rowops.hpp)
+            const double sd = sigma_l * dI2[t];
+            double r, pa = 0.0, pb = 0.0;
             if constexpr (t < H - 1) {
-                static_for<3>([&](auto J) {
-                    constexpr int j = 2 * A1_CV(J);
-                    fnma_bcast<lane_of(6 + j)>(ra, Bt[j], pv);
-                    fnma_bcast<lane_of(6 + j + 1)>(rb, Bt[j + 1], pv);
-                });
-                if constexpr (t > 0) {
-                    pa = pv; pb = gV * row_ror<8>(pv);
-                    fma_bcast<0>(pa, gA, pv); fma_bcast<1>(pb, gB, pv); fma_bcast<2>(pa, gC, pv);
-                }
-            }
-            const double r = row_dpp_ready(ra + rb);
-            // d_t = S_t^-1 r  interleaved with  p_t = A' p_{t+1} + K_t' r
-            double da = 0.0;
-            if constexpr (t > 0) {
-                static_for<6>([&](auto J) {
-                    constexpr int b = 2 * A1_CV(J);
-                    fma_bcast<lane_of(b)>(da, Sr[b], r);
-                    fma_bcast<lane_of(b)>(pa, Kc[b], r);
-                    fma_bcast<lane_of(b + 1)>(da, Sr[b + 1], r);
-                    fma_bcast<lane_of(b + 1)>(pb, Kc[b + 1], r);
-                });
-                d[t] = da;
-                pv = row_dpp_ready(pa + pb);
+                if constexpr (t > 0) pb = gV * row_ror<8>(pv);
+                sweep_back_rhs(r, pa, pb, at, cgt, sd, xh[t], pv, Bt, gA, gB, gC);
             } else {
-                d[t] = dot_bc<0>(Sr, r);
+                r = row_dpp_ready(fma(sd, xh[t], at - cgt));  // p_H = 0
+            }
+            row_lds_landed();
+            if constexpr (t > 0) {
+                sweep_back_chains(d[t], pa, pb, r, Sr, Kc);
+                pv = pa;
+            } else {
+                d[t] = dot12_block(Sr, r);
             }
         });
         double s = 0.0;  // state x_t of the LQ roll-out (x_0 = 0); dpp-ready at the top of every step
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
             const double* slot = lds + L::FAC + t * L::SLOT;
-            // issue this step's LDS reads first (K_t row, my B~ row): they overlap the previous step's w / xh update
-            double Kr[12], Br[12];
+            // issue this step's LDS reads first (K_t row): they overlap the previous step's w update
+            double Kr[12];
             static_for<12>([&](auto B) {
                 constexpr int b = A1_CV(B);
                 if constexpr (t > 0) Kr[b] = slot[krow + b];
-                if constexpr (t < H - 1) Br[b] = brow[b];
             });
             row_sched_fence();
-            // v_t = d_t - K_t x_t, and A x_t as the seed of x_{t+1} = A x_t + B~ v_t
-            double va = d[t], vb = 0.0, sa = 0.0, sb = 0.0;
-            if constexpr (t > 0) {
-                if constexpr (t < H - 1) {
-                    sa = s; sb = fP * row_ror<8>(s);
-                    fma_bcast<8>(sa, fA, s); fma_bcast<9>(sb, fB, s); fma_bcast<10>(sa, fC, s);
-                }
-                static_for<6>([&](auto J) {
-                    constexpr int b = 2 * A1_CV(J);
-                    fnma_bcast<lane_of(b)>(va, Kr[b], s);
-                    fnma_bcast<lane_of(b + 1)>(vb, Kr[b + 1], s);
-                });
+            // v_t = d_t - K_t x_t,  xh <- alpha v + (1 - alpha) xh,  x_{t+1} = A x_t + B~ v_t   (instruction blocks)
+            const double am = act ? 1.0 : 0.0;  // pad lanes carry no force
+            double v = d[t], sa = 0.0, sb = 0.0, z0 = 0.0;
+            [[maybe_unused]] double xz_first = 0.0;
+            if constexpr (FIRST) xz_first = quad_perm<2, 2, 2, 2>(xh[t]);  // reads x0 before the block overwrites xh
+            const double xh_old = xh[t];
+            row_lds_landed();
+            if constexpr (t == 0) {
+                v = row_dpp_ready(am * v);  // x_0 = 0
+                xh[t] = fma(al, v, oma * xh[t]);
+            } else if constexpr (t < H - 1) {
+                sb = fP * row_ror<8>(s);
+                sweep_fwd_gain<true>(v, sa, sb, xh[t], s, Kr, fA, fB, fC, am, oma, al);
+            } else {
+                sweep_fwd_gain<false>(v, sa, sb, xh[t], s, Kr, fA, fB, fC, am, oma, al);
             }
-            double v = t > 0 ? va + vb : va;
-            v = act ? v : 0.0;  // pad lanes carry no force
             if constexpr (t < H - 1) {
-                const double vr = row_dpp_ready(v);
-                static_for<6>([&](auto J) {
-                    constexpr int b = 2 * A1_CV(J);
-                    fma_bcast<lane_of(b)>(sa, Br[b], vr);
-                    fma_bcast<lane_of(b + 1)>(sb, Br[b + 1], vr);
-                });
-                s = row_dpp_ready(sa + sb);  // lanes without a wrench state read the zero row of B~
+                sweep_fwd_input(sa, sb, z0, v, Brw, wh0[t], lb0_l, ub0_l);
+                s = sa;  // lanes without a wrench state read the zero row of B~
+            } else {
+                z0 = min_f64(max_f64(wh0[t], lb0_l), ub0_l);
             }
             // z~ = A v (unscaled), then update_x / update_z / update_y in the w form
             const double vz = quad_perm<2, 2, 2, 2>(v);
             const double av0 = fma(mux, vz, v);
             const double av1 = fma(-mux, vz, v);
             if constexpr (FIRST) {  // w1 = alpha z~ + (1 - alpha) z0 + y0 / rho,  z0 = A x0
-                const double xz = quad_perm<2, 2, 2, 2>(xh[t]);
+                const double xz = xz_first;
                 double yw0 = 0.0, yw1 = 0.0;
                 if (warm && act) {
                     yw0 = warm_y_in[t * 20 + 5 * quad + r0];
                     if (comp < 2) yw1 = warm_y_in[t * 20 + 5 * quad + r1];
                 }
-                const double z00 = comp == 2 ? xh[t] : fma(mu, xz, xh[t]), z01 = fma(-mu, xz, xh[t]);
+                const double z00 = comp == 2 ? xh_old : fma(mu, xz, xh_old), z01 = fma(-mu, xz, xh_old);
                 wh0[t] = al * av0 + oma * z00 + (rr0[t] > 0.0 ? csc * yw0 / rr0[t] : 0.0);
                 wh1[t] = comp < 2 ? al * av1 + oma * z01 + (rr1[t] > 0.0 ? csc * yw1 / rr1[t] : 0.0) : 0.0;
             } else {                // w+ = w + alpha (z~ - Pi(w))
-                const double z0 = min_f64(max_f64(wh0[t], lb0_l), ub0_l), z1 = min_f64(wh1[t], 0.0);
+                const double z1 = min_f64(wh1[t], 0.0);
                 wh0[t] = fma(al, av0 - z0, wh0[t]);
                 wh1[t] = fma(al1, av1 - z1, wh1[t]);  // stays 0 on fz lanes
             }
-            xh[t] = al * v + oma * xh[t];
         });
     }
 

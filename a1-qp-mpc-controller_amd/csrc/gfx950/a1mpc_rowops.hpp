@@ -86,8 +86,119 @@ A1_DEV void row_dpp_ready12(double (&v)[12]) {
                  "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
 }
 
+// ---- the Riccati sweeps of one ADMM iteration as monolithic instruction blocks -------------------------------------------------
+// One wave per SIMD means every instruction costs an issue slot.  Written as separate asm statements the chains pay for it
+// twice: hipcc counts an inline-asm statement as zero wait states, so it pads every dependent pair of them with s_nop, and it
+// cannot see the DPP read hazard, so each vector needed an explicit s_nop 1 before its first broadcast.  Inside one block the
+// order is ours: independent accumulators are interleaved, and the two instructions that must separate a VALU write from a
+// DPP read of the same register are instructions that have to be issued anyway (the hazard contract of every block: its
+// DPP-read inputs were written >= 2 instructions before the block ends / begins, as noted per block).
+// Compact index j = 0..11 -> lane 4*(j/3) + j%3 = 0,1,2,4,5,6,8,9,10,12,13,14.
+#define A1_FMAC(acc, x, m, L) "v_fmac_f64_dpp " acc ", " x ", " m " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n"
+#define A1_FNMA(acc, x, m, L) "v_fmac_f64_dpp " acc ", -" x ", " m " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n"
+
+// r = (at - cg) + sd*xh - B~' p   and the seeds of the costate accumulators  pa = p + gA p[0] + gC p[2],  pb += gB p[1]
+// (pb comes in as gV * ror8(p)).  p: written >= 2 instructions ago (sweep_back ends with two d-chain instructions after it);
+// r: followed by two instructions inside the block.
+A1_DEV void sweep_back_rhs(double& r, double& pa, double& pb, double at, double cg, double sd, double xh, double p, const double (&Bt)[6],
+                           double gA, double gB, double gC) {
+    double rb;
+    asm("v_add_f64 %0, %4, -%5\n"
+        "v_mul_f64 %1, %6, %7\n"
+        "v_mov_b64 %2, %8\n"
+        A1_FNMA("%0", "%8", "%9", 8) A1_FNMA("%1", "%8", "%10", 9) A1_FMAC("%2", "%8", "%15", 0)
+        A1_FNMA("%0", "%8", "%11", 10) A1_FNMA("%1", "%8", "%12", 12)
+        A1_FNMA("%0", "%8", "%13", 13) A1_FNMA("%1", "%8", "%14", 14)
+        "v_add_f64 %0, %0, %1\n"
+        A1_FMAC("%3", "%8", "%16", 1) A1_FMAC("%2", "%8", "%17", 2)
+        : "=&v"(r), "=&v"(rb), "=&v"(pa), "+v"(pb)
+        : "v"(at), "v"(cg), "v"(sd), "v"(xh), "v"(p), "v"(Bt[0]), "v"(Bt[1]), "v"(Bt[2]), "v"(Bt[3]), "v"(Bt[4]), "v"(Bt[5]), "v"(gA), "v"(gB), "v"(gC));
+}
+// d = S^-1 r (row Sr) interleaved with p_t = (pa + pb) + K' r (column Kc); the costate chain runs two terms ahead so that its
+// final add is followed by two d-chain instructions.  Returns p_t in pa.
+A1_DEV void sweep_back_chains(double& d, double& pa, double& pb, double r, const double (&Sr)[12], const double (&Kc)[12]) {
+    asm("v_mov_b64 %0, 0\n"
+        A1_FMAC("%1", "%3", "%16", 0) A1_FMAC("%2", "%3", "%17", 1)
+        A1_FMAC("%0", "%3", "%4", 0) A1_FMAC("%1", "%3", "%18", 2) A1_FMAC("%0", "%3", "%5", 1) A1_FMAC("%2", "%3", "%19", 4)
+        A1_FMAC("%0", "%3", "%6", 2) A1_FMAC("%1", "%3", "%20", 5) A1_FMAC("%0", "%3", "%7", 4) A1_FMAC("%2", "%3", "%21", 6)
+        A1_FMAC("%0", "%3", "%8", 5) A1_FMAC("%1", "%3", "%22", 8) A1_FMAC("%0", "%3", "%9", 6) A1_FMAC("%2", "%3", "%23", 9)
+        A1_FMAC("%0", "%3", "%10", 8) A1_FMAC("%1", "%3", "%24", 10) A1_FMAC("%0", "%3", "%11", 9) A1_FMAC("%2", "%3", "%25", 12)
+        A1_FMAC("%0", "%3", "%12", 10) A1_FMAC("%1", "%3", "%26", 13) A1_FMAC("%0", "%3", "%13", 12) A1_FMAC("%2", "%3", "%27", 14)
+        "v_add_f64 %1, %1, %2\n"
+        A1_FMAC("%0", "%3", "%14", 13) A1_FMAC("%0", "%3", "%15", 14)
+        : "=&v"(d), "+v"(pa), "+v"(pb)
+        : "v"(r), "v"(Sr[0]), "v"(Sr[1]), "v"(Sr[2]), "v"(Sr[3]), "v"(Sr[4]), "v"(Sr[5]), "v"(Sr[6]), "v"(Sr[7]), "v"(Sr[8]), "v"(Sr[9]), "v"(Sr[10]),
+          "v"(Sr[11]), "v"(Kc[0]), "v"(Kc[1]), "v"(Kc[2]), "v"(Kc[3]), "v"(Kc[4]), "v"(Kc[5]), "v"(Kc[6]), "v"(Kc[7]), "v"(Kc[8]), "v"(Kc[9]),
+          "v"(Kc[10]), "v"(Kc[11]));
+}
+// init + sum_j m[j] x[j] with two accumulators in one block (x written >= 2 instructions ago)
+A1_DEV double dot12_block(const double (&m)[12], double x) {
+    double a0, a1;
+    asm("v_mov_b64 %0, 0\n"
+        "v_mov_b64 %1, 0\n"
+        A1_FMAC("%0", "%2", "%3", 0) A1_FMAC("%1", "%2", "%4", 1) A1_FMAC("%0", "%2", "%5", 2) A1_FMAC("%1", "%2", "%6", 4)
+        A1_FMAC("%0", "%2", "%7", 5) A1_FMAC("%1", "%2", "%8", 6) A1_FMAC("%0", "%2", "%9", 8) A1_FMAC("%1", "%2", "%10", 9)
+        A1_FMAC("%0", "%2", "%11", 10) A1_FMAC("%1", "%2", "%12", 12) A1_FMAC("%0", "%2", "%13", 13) A1_FMAC("%1", "%2", "%14", 14)
+        "v_add_f64 %0, %0, %1\n"
+        : "=&v"(a0), "=&v"(a1)
+        : "v"(x), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]));
+    return a0;
+}
+// v = am * (v - K s) (row Kr),  xh = oma*xh + al*v,  and (SEED) the seeds of x_{t+1}: sa = s + fA s[8] + fC s[10], sb += fB s[9]
+// (sb comes in as fP * ror8(s)).  s: written >= 2 instructions ago (sweep_fwd_input ends with the two projection instructions);
+// v: followed by the two xh instructions.
+template <bool SEED>
+A1_DEV void sweep_fwd_gain(double& v, double& sa, double& sb, double& xh, double s, const double (&Kr)[12], double fA, double fB, double fC,
+                           double am, double oma, double al) {
+    double vb;
+    if constexpr (SEED) {
+        asm("v_mov_b64 %2, %5\n"
+            "v_mov_b64 %1, 0\n"
+            A1_FNMA("%0", "%5", "%6", 0) A1_FNMA("%1", "%5", "%7", 1) A1_FMAC("%2", "%5", "%18", 8)
+            A1_FNMA("%0", "%5", "%8", 2) A1_FNMA("%1", "%5", "%9", 4) A1_FMAC("%3", "%5", "%19", 9)
+            A1_FNMA("%0", "%5", "%10", 5) A1_FNMA("%1", "%5", "%11", 6) A1_FMAC("%2", "%5", "%20", 10)
+            A1_FNMA("%0", "%5", "%12", 8) A1_FNMA("%1", "%5", "%13", 9) A1_FNMA("%0", "%5", "%14", 10)
+            A1_FNMA("%1", "%5", "%15", 12) A1_FNMA("%0", "%5", "%16", 13) A1_FNMA("%1", "%5", "%17", 14)
+            "v_add_f64 %0, %0, %1\n"
+            "v_mul_f64 %0, %0, %21\n"
+            "v_mul_f64 %4, %22, %4\n"
+            "v_fmac_f64 %4, %23, %0\n"
+            : "+v"(v), "=&v"(vb), "=&v"(sa), "+v"(sb), "+v"(xh)
+            : "v"(s), "v"(Kr[0]), "v"(Kr[1]), "v"(Kr[2]), "v"(Kr[3]), "v"(Kr[4]), "v"(Kr[5]), "v"(Kr[6]), "v"(Kr[7]), "v"(Kr[8]), "v"(Kr[9]), "v"(Kr[10]),
+              "v"(Kr[11]), "v"(fA), "v"(fB), "v"(fC), "v"(am), "v"(oma), "v"(al));
+    } else {
+        asm("v_mov_b64 %1, 0\n"
+            A1_FNMA("%0", "%3", "%4", 0) A1_FNMA("%1", "%3", "%5", 1) A1_FNMA("%0", "%3", "%6", 2) A1_FNMA("%1", "%3", "%7", 4)
+            A1_FNMA("%0", "%3", "%8", 5) A1_FNMA("%1", "%3", "%9", 6) A1_FNMA("%0", "%3", "%10", 8) A1_FNMA("%1", "%3", "%11", 9)
+            A1_FNMA("%0", "%3", "%12", 10) A1_FNMA("%1", "%3", "%13", 12) A1_FNMA("%0", "%3", "%14", 13) A1_FNMA("%1", "%3", "%15", 14)
+            "v_add_f64 %0, %0, %1\n"
+            "v_mul_f64 %0, %0, %16\n"
+            "v_mul_f64 %2, %17, %2\n"
+            "v_fmac_f64 %2, %18, %0\n"
+            : "+v"(v), "=&v"(vb), "+v"(xh)
+            : "v"(s), "v"(Kr[0]), "v"(Kr[1]), "v"(Kr[2]), "v"(Kr[3]), "v"(Kr[4]), "v"(Kr[5]), "v"(Kr[6]), "v"(Kr[7]), "v"(Kr[8]), "v"(Kr[9]), "v"(Kr[10]),
+              "v"(Kr[11]), "v"(am), "v"(oma), "v"(al));
+    }
+}
+// x_{t+1} = (sa + sb) + B~ v (row Br), returned in sa; z0 = min(max(w0, lb), ub) rides behind it (the two instructions that
+// separate the new state from its first DPP read).  v: written >= 2 instructions ago (sweep_fwd_gain).
+A1_DEV void sweep_fwd_input(double& sa, double& sb, double& z0, double v, const double (&Br)[12], double w0, double lb, double ub) {
+    asm(A1_FMAC("%0", "%3", "%4", 0) A1_FMAC("%1", "%3", "%5", 1) A1_FMAC("%0", "%3", "%6", 2) A1_FMAC("%1", "%3", "%7", 4)
+        A1_FMAC("%0", "%3", "%8", 5) A1_FMAC("%1", "%3", "%9", 6) A1_FMAC("%0", "%3", "%10", 8) A1_FMAC("%1", "%3", "%11", 9)
+        A1_FMAC("%0", "%3", "%12", 10) A1_FMAC("%1", "%3", "%13", 12) A1_FMAC("%0", "%3", "%14", 13) A1_FMAC("%1", "%3", "%15", 14)
+        "v_add_f64 %0, %0, %1\n"
+        "v_max_f64 %2, %16, %17\n"
+        "v_min_f64 %2, %2, %18\n"
+        : "+v"(sa), "+v"(sb), "=&v"(z0)
+        : "v"(v), "v"(Br[0]), "v"(Br[1]), "v"(Br[2]), "v"(Br[3]), "v"(Br[4]), "v"(Br[5]), "v"(Br[6]), "v"(Br[7]), "v"(Br[8]), "v"(Br[9]), "v"(Br[10]),
+          "v"(Br[11]), "v"(w0), "v"(lb), "v"(ub));
+}
+
 // Scheduling fence: the machine scheduler moves nothing across it (keeps a step's LDS reads ahead of the arithmetic that hides them).
 A1_DEV void row_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+// All LDS reads issued so far have landed (s_waitcnt lgkmcnt(0)): one wait in front of a chain instead of one per operand.
+A1_DEV void row_lds_landed() { __builtin_amdgcn_s_waitcnt(0xc07f); }
 
 // Optimisation barrier: the value becomes opaque to the compiler (no code is emitted).
 A1_DEV double row_opaque(double v) {

@@ -39,7 +39,58 @@ inline void row_dpp_ready12(double (&)[12]) {}
 inline void row_sync() { (void)emu_publish(0.0); }
 
 
+
+// ---- the Riccati sweep blocks (same operation order as the gfx950 instruction blocks) ----
+namespace emu_detail {
+constexpr int LANE[12] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14};
+}
+inline void sweep_back_rhs(double& r, double& pa, double& pb, double at, double cg, double sd, double xh, double p, const double (&Bt)[6],
+                           double gA, double gB, double gC) {
+    const double* P_ = emu_publish(p);
+    double ra = at - cg, rb = sd * xh;
+    pa = p;
+    ra = fma(-P_[8], Bt[0], ra); rb = fma(-P_[9], Bt[1], rb); pa = fma(P_[0], gA, pa);
+    ra = fma(-P_[10], Bt[2], ra); rb = fma(-P_[12], Bt[3], rb);
+    ra = fma(-P_[13], Bt[4], ra); rb = fma(-P_[14], Bt[5], rb);
+    r = ra + rb;
+    pb = fma(P_[1], gB, pb); pa = fma(P_[2], gC, pa);
+}
+inline void sweep_back_chains(double& d, double& pa, double& pb, double r, const double (&Sr)[12], const double (&Kc)[12]) {
+    const double* R_ = emu_publish(r);
+    double da = 0.0;
+    for (int b = 0; b < 12; ++b) {
+        da = fma(R_[emu_detail::LANE[b]], Sr[b], da);
+        double& pacc = (b & 1) ? pb : pa;
+        pacc = fma(R_[emu_detail::LANE[b]], Kc[b], pacc);
+    }
+    pa = pa + pb;
+    d = da;
+}
+inline double dot12_block(const double (&m)[12], double x) {
+    const double* X_ = emu_publish(x);
+    double a0 = 0.0, a1 = 0.0;
+    for (int b = 0; b < 12; b += 2) { a0 = fma(X_[emu_detail::LANE[b]], m[b], a0); a1 = fma(X_[emu_detail::LANE[b + 1]], m[b + 1], a1); }
+    return a0 + a1;
+}
+template <bool SEED>
+inline void sweep_fwd_gain(double& v, double& sa, double& sb, double& xh, double s, const double (&Kr)[12], double fA, double fB, double fC,
+                           double am, double oma, double al) {
+    const double* S_ = emu_publish(s);
+    double va = v, vb = 0.0;
+    for (int b = 0; b < 12; b += 2) { va = fma(-S_[emu_detail::LANE[b]], Kr[b], va); vb = fma(-S_[emu_detail::LANE[b + 1]], Kr[b + 1], vb); }
+    if (SEED) { sa = s; sa = fma(S_[8], fA, sa); sb = fma(S_[9], fB, sb); sa = fma(S_[10], fC, sa); }
+    v = (va + vb) * am;
+    xh = fma(al, v, oma * xh);
+}
+inline void sweep_fwd_input(double& sa, double& sb, double& z0, double v, const double (&Br)[12], double w0, double lb, double ub) {
+    const double* V_ = emu_publish(v);
+    for (int b = 0; b < 12; b += 2) { sa = fma(V_[emu_detail::LANE[b]], Br[b], sa); sb = fma(V_[emu_detail::LANE[b + 1]], Br[b + 1], sb); }
+    sa = sa + sb;
+    z0 = fmin(fmax(w0, lb), ub);
+}
+
 inline void row_sched_fence() {}
+inline void row_lds_landed() {}
 inline double row_opaque(double v) { return v; }
 
 

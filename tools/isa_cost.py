@@ -10,7 +10,7 @@ blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
 best = None
 for b in blocks:
     name = b.split(":")[0]
-    ins = [l.split()[0:] for l in b.split("\n") if l.startswith("\t") and not l.startswith("\t.") and not l.startswith("\t;")]
+    ins = [l.split() for l in b.split("\n") if re.match(r"\s*(v_|s_|ds_|global_|buffer_|scratch_|flat_)", l)]  # also the lines of multi-instruction asm blocks
     if any(re.search(r"s_cbranch\S*\s+%s\b" % re.escape(name), " ".join(i)) for i in ins):
         if best is None or len(ins) > len(best[1]): best = (name, ins)
 name, ins = best
