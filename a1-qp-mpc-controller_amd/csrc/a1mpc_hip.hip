@@ -319,6 +319,105 @@ void a1mpc_default_balance_config(a1mpc_balance_config* q) {
     q->R = 1e-3; q->mu = 0.7; q->F_min = 0.0; q->F_max = 180.0;  // S/A1RobotControl.cpp:12-15
 }
 
+// ---- N3: compute_joint_torques (S/A1RobotControl.cpp:289-319), one lane per (robot, leg); no FMA contraction ---------------------
+struct TorqueArgs {
+    int32_t n;
+    const uint8_t *active, *contacts;
+    const double *Jb, *grf, *fkin, *tg;
+    double km[3];
+    double* tau;
+};
+__global__ __launch_bounds__(256) void a1mpc_torque_kernel(const TorqueArgs a) {
+#pragma clang fp contract(off)
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t b = gid >> 2;
+    const int leg = static_cast<int>(gid & 3);
+    if (b >= a.n) return;
+    double* out = a.tau + b * 12 + 3 * leg;
+    if (!a.active[b]) { out[0] = 0.0; out[1] = 0.0; out[2] = 0.0; return; }   // :294-295
+    const double* Jp = a.Jb + b * 36 + 9 * leg;
+    double J[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) J[k] = Jp[k];
+    double t0, t1, t2;
+    if (a.contacts[b * 4 + leg]) {                                             // :303  J' (-f)
+        const double f0 = -a.grf[b * 12 + 3 * leg + 0], f1 = -a.grf[b * 12 + 3 * leg + 1], f2 = -a.grf[b * 12 + 3 * leg + 2];
+        t0 = J[0] * f0 + J[1] * f1 + J[2] * f2;
+        t1 = J[3] * f0 + J[4] * f1 + J[5] * f2;
+        t2 = J[6] * f0 + J[7] * f1 + J[8] * f2;
+    } else {                                                                    // :306-307  PartialPivLU, Eigen's unblocked_lu order
+        double b0 = a.km[0] * a.fkin[b * 12 + 3 * leg + 0], b1 = a.km[1] * a.fkin[b * 12 + 3 * leg + 1], b2 = a.km[2] * a.fkin[b * 12 + 3 * leg + 2];
+        // k = 0: pivot = first largest |J(r,0)|
+        int r0 = 0; double big = fabs(J[0]);
+        if (fabs(J[1]) > big) { big = fabs(J[1]); r0 = 1; }
+        if (fabs(J[2]) > big) { big = fabs(J[2]); r0 = 2; }
+        if (big != 0.0) {
+            if (r0 == 1) { double t; t = J[0]; J[0] = J[1]; J[1] = t; t = J[3]; J[3] = J[4]; J[4] = t; t = J[6]; J[6] = J[7]; J[7] = t; }
+            if (r0 == 2) { double t; t = J[0]; J[0] = J[2]; J[2] = t; t = J[3]; J[3] = J[5]; J[5] = t; t = J[6]; J[6] = J[8]; J[8] = t; }
+            J[1] /= J[0]; J[2] /= J[0];
+        }
+        J[4] -= J[1] * J[3]; J[7] -= J[1] * J[6]; J[5] -= J[2] * J[3]; J[8] -= J[2] * J[6];
+        // k = 1
+        int r1 = 1; big = fabs(J[4]);
+        if (fabs(J[5]) > big) { big = fabs(J[5]); r1 = 2; }
+        if (big != 0.0) {
+            if (r1 == 2) { double t; t = J[1]; J[1] = J[2]; J[2] = t; t = J[4]; J[4] = J[5]; J[5] = t; t = J[7]; J[7] = J[8]; J[8] = t; }
+            J[5] /= J[4];
+        }
+        J[8] -= J[5] * J[7];
+        // P b, L y = P b, U x = y
+        if (r0 == 1) { const double t = b0; b0 = b1; b1 = t; }
+        if (r0 == 2) { const double t = b0; b0 = b2; b2 = t; }
+        if (r1 == 2) { const double t = b1; b1 = b2; b2 = t; }
+        b1 -= J[1] * b0;
+        b2 -= J[2] * b0 + J[5] * b1;
+        b2 /= J[8];
+        b1 -= J[7] * b2; b1 /= J[4];
+        b0 -= J[3] * b1 + J[6] * b2; b0 /= J[0];
+        t0 = b0; t1 = b1; t2 = b2;
+    }
+    const double* g = a.tg + b * 12 + 3 * leg;
+    const double v0 = t0 + g[0], v1 = t1 + g[1], v2 = t2 + g[2];                // :311
+    if (!isnan(v0)) out[0] = v0;                                                // :314-317
+    if (!isnan(v1)) out[1] = v1;
+    if (!isnan(v2)) out[2] = v2;
+}
+
+a1mpc_status a1mpc_joint_torques_batch(a1mpc_handle h, int32_t n, const uint8_t* active, const uint8_t* contacts, const double* j_foot_blocks,
+                                       const double* grf, const double* f_kin, const double* km_foot, const double* torques_gravity,
+                                       double* joint_torques) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !active || !contacts || !j_foot_blocks || !grf || !f_kin || !km_foot || !torques_gravity || !joint_torques)
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    if (h->cfg.horizon < 6) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "joint-torque staging needs a handle with horizon >= 6");
+    A1_HIP(hipSetDevice(h->device));
+    const size_t N = n;
+    hipStream_t s = h->stream;
+    // staging inside the handle's MPC buffers: d_xref [J 36 | grf 12 | f_kin 12] (60 <= 13 H), d_u [tg 12 | tau 12] (24 <= 12 H)
+    double *d_J = h->d_xref, *d_grf = d_J + 36 * N, *d_fk = d_grf + 12 * N, *d_tg = h->d_u, *d_tau = d_tg + 12 * N;
+    uint8_t *d_c = h->d_contact, *d_act = reinterpret_cast<uint8_t*>(h->d_iters);
+    A1_HIP(hipMemcpyAsync(d_J, j_foot_blocks, N * 36 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_grf, grf, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_fk, f_kin, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_tg, torques_gravity, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_tau, joint_torques, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_c, contacts, N * 4, hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_act, active, N, hipMemcpyHostToDevice, s));
+    TorqueArgs a;
+    a.n = n; a.active = d_act; a.contacts = d_c; a.Jb = d_J; a.grf = d_grf; a.fkin = d_fk; a.tg = d_tg; a.tau = d_tau;
+    a.km[0] = km_foot[0]; a.km[1] = km_foot[1]; a.km[2] = km_foot[2];
+    A1_HIP(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(a1mpc_torque_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    A1_HIP(hipGetLastError());
+    A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = true; h->last_stream = s;
+    A1_HIP(hipMemcpyAsync(joint_torques, d_tau, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipStreamSynchronize(s));
+    return A1MPC_OK;
+}
+
 void a1mpc_default_gait_config(a1mpc_gait_config* g) {
     if (!g) return;
     std::memset(g, 0, sizeof *g);

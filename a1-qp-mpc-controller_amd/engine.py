@@ -36,7 +36,7 @@ class GaitConfig(C.Structure):  # a1mpc_gait_config
                 ("gait_counter_reset", C.c_double * 4)]
 
 
-EXPORTS = ["a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
+EXPORTS = ["a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
 
@@ -71,6 +71,7 @@ def load_library(path=None):
     lib.a1mpc_default_gait_config.argtypes = [C.POINTER(GaitConfig)]; lib.a1mpc_default_gait_config.restype = None
     lib.a1mpc_update_plan_batch.argtypes = [vp, C.POINTER(GaitConfig), i32, u8p, dp, dp, dp, dp, dp, dp, dp, u8p, dp, dp, dp]
     lib.a1mpc_update_plan_batch.restype = C.c_int
+    lib.a1mpc_joint_torques_batch.argtypes = [vp, i32, u8p, u8p, dp, dp, dp, dp, dp, dp]; lib.a1mpc_joint_torques_batch.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
     lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int
     lib.a1mpc_last_nfact.argtypes = [vp, i32, i32p]; lib.a1mpc_last_nfact.restype = C.c_int
@@ -207,6 +208,16 @@ class Engine:
                                               _dp(rel), _dp(ab), _dp(wo))
         _check(self.lib, rc, "a1mpc_update_plan_batch")
         return dict(gait_counter=gc, plan_contacts=pc, foot_pos_target_rel=rel, foot_pos_target_abs=ab, foot_pos_target_world=wo)
+
+    # ---- N3: GRF -> joint torques (S/A1RobotControl.cpp:289-319) ----
+    def joint_torques(self, active, contacts, j_foot_blocks, grf, f_kin, km_foot, torques_gravity, joint_torques_prev):
+        tau = np.array(joint_torques_prev, dtype=np.float64).reshape(-1, 12); n = tau.shape[0]
+        act = np.ascontiguousarray(active, dtype=np.uint8).reshape(n); c = np.ascontiguousarray(contacts, dtype=np.uint8).reshape(n, 4)
+        Jb = _f64(j_foot_blocks, (n, 36)); g = _f64(grf, (n, 12)); fk = _f64(f_kin, (n, 12)); km = _f64(km_foot, (3,)); tg = _f64(torques_gravity, (n, 12))
+        u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+        rc = self.lib.a1mpc_joint_torques_batch(self._h, n, u8(act), u8(c), _dp(Jb), _dp(g), _dp(fk), _dp(km), _dp(tg), _dp(tau))
+        _check(self.lib, rc, "a1mpc_joint_torques_batch")
+        return tau
 
     def reset_warm_start(self):
         _check(self.lib, self.lib.a1mpc_reset_warm_start(self._h), "a1mpc_reset_warm_start")

@@ -171,6 +171,20 @@ a1mpc_status a1mpc_update_plan_batch(a1mpc_handle h, const a1mpc_gait_config* ga
                                      uint8_t* plan_contacts_out, double* foot_pos_target_rel_out, double* foot_pos_target_abs_out,
                                      double* foot_pos_target_world_out);
 
+/*
+ * N3 (the step right after the path): A1RobotControl::compute_joint_torques, S/A1RobotControl.cpp:289-319, for n robots.
+ *   active          n        0 while the reference's mpc_init_counter < 10 (:294): all torques zero
+ *   contacts        n x 4
+ *   j_foot_blocks   n x 4 x 9  the four diagonal 3x3 blocks of j_foot (S/A1CtrlStates.h), column-major each
+ *   grf, f_kin      n x 12     foot_forces_grf / foot_forces_kin, 3x4 column-major
+ *   km_foot         3, torques_gravity n x 12
+ *   joint_torques   n x 12     in/out: NaN results keep the previous value (:314-317)
+ * stance: tau = J'(-f_grf); swing: tau = J^-1 (km .* f_kin) by partial-pivot LU in Eigen's operation order.  Host pointers.
+ */
+a1mpc_status a1mpc_joint_torques_batch(a1mpc_handle h, int32_t n, const uint8_t* active, const uint8_t* contacts, const double* j_foot_blocks,
+                                       const double* grf, const double* f_kin, const double* km_foot, const double* torques_gravity,
+                                       double* joint_torques);
+
 /* forget the carried (x, y, rho) of every problem: next solve is a cold start */
 a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h);
 

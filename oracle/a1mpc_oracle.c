@@ -723,6 +723,54 @@ void orc_update_plan(const orc_gait_params *gp, int movement_mode, double *gait_
     }
 }
 
+/* ---- N3: A1RobotControl::compute_joint_torques, S/A1RobotControl.cpp:289-319 ------------------------------------------------
+ * stance leg: tau = J' (-f_grf)                     (:303)
+ * swing leg : tau = J^-1 (km .* f_kin)              (:306-307, Eigen jac.lu().solve(): PartialPivLU of a fixed 3x3 =
+ *             Eigen/src/LU/PartialPivLU.h unblocked_lu -- pivot = first largest |a_ik|, row swap, column scaled by 1/pivot through
+ *             a division per entry, rank-1 update -- then P b, unit-lower forward and upper backward substitution)
+ * then + torques_gravity (:311) and the NaN guard (:314-317); all zeros while mpc_init_counter < 10 (:294-295, `active` = 0).
+ * Jb: the four diagonal 3x3 blocks of j_foot, column-major each.  Eigen is not installed here: the LU order is restated from its
+ * published algorithm, bit-level parity with a live Eigen build is unpinned (agreement with LAPACK-style solves is tested). */
+void orc_joint_torques(int active, const uint8_t *contacts, const double *Jb, const double *grf, const double *f_kin, const double *km,
+                       const double *torques_gravity, double *joint_torques) {
+    if (!active) { for (int k = 0; k < 12; ++k) joint_torques[k] = 0.0; return; }
+    for (int i = 0; i < NLEG; ++i) {
+        const double *J = Jb + 9 * i;   /* J[r + 3 c] */
+        double tau[3];
+        if (contacts[i]) {
+            for (int c = 0; c < 3; ++c) {     /* row c of J' times (-f): sum_r J(r,c) * (-f_r), left to right */
+                tau[c] = J[0 + 3 * c] * -grf[3 * i + 0] + J[1 + 3 * c] * -grf[3 * i + 1] + J[2 + 3 * c] * -grf[3 * i + 2];
+            }
+        } else {
+            double a[9], b[3];
+            int perm[3];
+            for (int k = 0; k < 9; ++k) a[k] = J[k];
+            for (int k = 0; k < 3; ++k) b[k] = km[k] * f_kin[3 * i + k];
+            for (int k = 0; k < 3; ++k) {
+                int row = k; double big = fabs(a[k + 3 * k]);
+                for (int r = k + 1; r < 3; ++r) if (fabs(a[r + 3 * k]) > big) { big = fabs(a[r + 3 * k]); row = r; }
+                perm[k] = row;
+                if (big != 0.0) {
+                    if (row != k) for (int c = 0; c < 3; ++c) { double t = a[k + 3 * c]; a[k + 3 * c] = a[row + 3 * c]; a[row + 3 * c] = t; }
+                    for (int r = k + 1; r < 3; ++r) a[r + 3 * k] /= a[k + 3 * k];
+                }
+                for (int r = k + 1; r < 3; ++r) for (int c = k + 1; c < 3; ++c) a[r + 3 * c] -= a[r + 3 * k] * a[k + 3 * c];
+            }
+            for (int k = 0; k < 3; ++k) if (perm[k] != k) { double t = b[k]; b[k] = b[perm[k]]; b[perm[k]] = t; }   /* P b */
+            b[1] -= a[1 + 0] * b[0];                                   /* L y = P b, unit diagonal */
+            b[2] -= a[2 + 0] * b[0] + a[2 + 3] * b[1];
+            b[2] /= a[2 + 6];                                          /* U x = y */
+            b[1] -= a[1 + 6] * b[2]; b[1] /= a[1 + 3];
+            b[0] -= a[0 + 3] * b[1] + a[0 + 6] * b[2]; b[0] /= a[0];
+            for (int k = 0; k < 3; ++k) tau[k] = b[k];
+        }
+        for (int k = 0; k < 3; ++k) {
+            const double v = tau[k] + torques_gravity[3 * i + k];
+            if (!isnan(v)) joint_torques[3 * i + k] = v;               /* :314-317 */
+        }
+    }
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -232,5 +232,14 @@ def update_plan(gp, movement_mode, gait_counter, gait_counter_speed, root_lin_ve
     return gc, pc, rel, ab, wo
 
 
+def joint_torques(active, contacts, Jb, grf, f_kin, km, torques_gravity, joint_torques_prev):
+    """S/A1RobotControl.cpp:289-319 for one robot (Jb = the four diagonal 3x3 blocks of j_foot, column-major)."""
+    tau = np.array(joint_torques_prev, dtype=np.float64).reshape(12)
+    a = lambda v: _p(np.ascontiguousarray(v, dtype=np.float64))
+    c = np.ascontiguousarray(contacts, dtype=np.uint8)
+    lib().orc_joint_torques(C.c_int(int(active)), _p(c, C.c_uint8), a(Jb), a(grf), a(f_kin), a(km), a(torques_gravity), _p(tau))
+    return tau
+
+
 def num_threads():
     return lib().orc_num_threads()

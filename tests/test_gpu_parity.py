@@ -279,3 +279,25 @@ def test_update_plan_N2a_bit_exact(pkg, oracle, scen):
         assert (out["foot_pos_target_rel"][b] == rel).all() and (out["foot_pos_target_abs"][b] == ab).all()
         assert (out["foot_pos_target_world"][b] == wo).all()
     assert (out["plan_contacts"][mm == 0] == 1).all() and (np.abs(out["foot_pos_target_rel"].reshape(n, 4, 3)[:, :, 0] - [0.17, 0.17, -0.17, -0.17]) <= 0.1 + 1e-15).all()
+
+
+def test_joint_torques_N3_bit_exact(pkg, oracle, scen):
+    """tau = J'(-f) on stance legs, J^-1 (km .* f_kin) by partial-pivot LU on swing legs, gravity term, NaN guard
+    (S/A1RobotControl.cpp:289-319): bit-exact against the oracle's restatement."""
+    rng = np.random.default_rng(11)
+    n = 4000
+    Jb = rng.normal(0, 0.2, (n, 4, 9)); Jb[:, :, [0, 4, 8]] += rng.choice([-0.3, 0.3], size=(n, 4, 3))  # every pivot pattern occurs
+    Jb[5, 1] = 0.0  # singular block -> NaN -> previous torque kept
+    c = (rng.random((n, 4)) < 0.5).astype(np.uint8); act = (rng.random(n) < 0.9).astype(np.uint8)
+    grf = rng.normal(0, 40, (n, 12)); fk = rng.normal(0, 20, (n, 12)); tg = rng.normal(0, 1, (n, 12)); prev = rng.normal(0, 5, (n, 12))
+    km = np.array([0.1, 0.1, 0.04])
+    c[5, 1] = 0; act[5] = 1
+    cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+    with pkg.Engine(cfg, n, 0) as eng:
+        tau = eng.joint_torques(act, c, Jb.reshape(n, 36), grf, fk, km, tg, prev)
+    for b in range(0, n, 2):
+        ref = oracle.joint_torques(act[b], c[b], Jb[b].reshape(36), grf[b], fk[b], km, tg[b], prev[b])
+        assert (tau[b] == ref).all(), b
+    ref5 = oracle.joint_torques(1, c[5], Jb[5].reshape(36), grf[5], fk[5], km, tg[5], prev[5])
+    assert (tau[act == 0] == 0).all() and np.array_equal(tau[5], ref5)
+    assert (tau[5, 3:5] == prev[5, 3:5]).all() and np.isinf(tau[5, 5])  # 0*inf = NaN is guarded (:314-317), the infinity is not -- like the reference

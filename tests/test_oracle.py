@@ -128,3 +128,18 @@ def test_update_plan_restatement(oracle):
     # saturation of the foothold offsets
     gc, pc, rel, ab, wo = oracle.update_plan(gp, 1, [0, 0, 0, 0], [2, 2, 2, 2], [5.0, -5.0, 0], Rz, R, [0, 0, 0], [0, 0, 0])
     assert np.allclose(rel.reshape(4, 3)[:, 0] - dfp.reshape(4, 3)[:, 0], 0.1) and np.allclose(rel.reshape(4, 3)[:, 1] - dfp.reshape(4, 3)[:, 1], -0.1)
+
+
+def test_joint_torques_restatement(oracle):
+    """N3 oracle: stance = J'(-f), swing solves J tau = km .* f_kin (checked against numpy's LAPACK solve), inactive = zeros"""
+    rng = np.random.default_rng(3)
+    km = np.array([0.1, 0.1, 0.04])
+    for trial in range(200):
+        Jb = rng.normal(0, 0.3, (4, 3, 3))  # [leg][row][col]
+        Jcm = np.stack([Jb[i].T.reshape(9) for i in range(4)]).reshape(36)  # column-major blocks
+        c = (rng.random(4) < 0.5).astype(np.uint8); grf = rng.normal(0, 40, 12); fk = rng.normal(0, 20, 12); tg = rng.normal(0, 1, 12)
+        tau = oracle.joint_torques(1, c, Jcm, grf, fk, km, tg, np.zeros(12))
+        for i in range(4):
+            ref = Jb[i].T @ -grf[3 * i:3 * i + 3] if c[i] else np.linalg.solve(Jb[i], km * fk[3 * i:3 * i + 3])
+            assert np.allclose(tau[3 * i:3 * i + 3], ref + tg[3 * i:3 * i + 3], rtol=1e-9, atol=1e-9)
+    assert (oracle.joint_torques(0, c, Jcm, grf, fk, km, tg, np.ones(12)) == 0).all()

@@ -8,6 +8,7 @@ pkg = g.load_package()
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 sc = pkg.scenarios.config3_random_flat(nb=n)
 osqp = dict(warm_start=0)
+if os.environ.get('A1_SCALING'): osqp['scaling'] = int(os.environ['A1_SCALING'])
 if len(sys.argv) > 1:
     osqp.update(eps_abs=0.0, eps_rel=0.0, max_iter=int(sys.argv[1]), adaptive_rho=0)
 cfg = pkg.make_config(sc["params"], 10, **osqp)
