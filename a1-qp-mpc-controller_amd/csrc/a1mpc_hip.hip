@@ -12,7 +12,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <cstring>
 #include <new>
 #include <string>
 #include <vector>
@@ -59,6 +58,29 @@ __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, cons
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     const int row = static_cast<int>(threadIdx.x) >> 4;
     admm_rows<H>(a, prep, counter, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+}
+
+// K3: the next solve's queue order = this solve's QPs by decreasing cost (counting sort, one workgroup).  A batch of 1-4x the resident
+// rows is otherwise finished by whichever long QP happened to start last; longest-first makes the makespan max(longest, total / rows).
+__global__ __launch_bounds__(1024) void a1mpc_order_kernel(int n, const int32_t* __restrict__ cost, int32_t* __restrict__ order) {
+    __shared__ int hist[256];
+    const int tid = static_cast<int>(threadIdx.x);
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int c = cost[i] >> 3;
+        atomicAdd(&hist[c < 0 ? 0 : (c > 255 ? 255 : c)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int b = 255; b >= 0; --b) { const int c = hist[b]; hist[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int c = cost[i] >> 3;
+        order[atomicAdd(&hist[c < 0 ? 0 : (c > 255 ? 255 : c)], 1)] = i;
+    }
 }
 
 __global__ void a1mpc_noop_kernel() {}
@@ -221,6 +243,8 @@ static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
     return launch_rows<H, MODE, 4>(a, stream);
 }
 
+static constexpr int kScheduleMinBatch = 1024;  // below this every QP is resident at once and the order cannot matter
+
 static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s) {
     if (a.n >= split_threshold() && prep && counter) {
         switch (horizon) {
@@ -290,6 +314,10 @@ struct a1mpc_handle_s {
     // split pipeline: prepared state of every QP (set-up kernel -> ADMM kernel) and the work-queue counter
     double* d_prep = nullptr;
     int* d_counter = nullptr;
+    // queue order of the next solve (longest-first by the previous solve's per-QP cost) -- see a1mpc_set_schedule
+    int32_t *d_order = nullptr, *d_cost = nullptr;
+    int32_t hint_n = 0;  // batch size the order was built for (0 = none)
+    int schedule = 1;    // 1 = history (default), 0 = index order
     // packed device blocks + pinned host mirrors of the host-pointer MPC entry (one copy each way per call)
     char *d_in = nullptr, *d_out = nullptr;
     char* h_pin = nullptr;
@@ -493,7 +521,7 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_tab, h->d_tab1, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_aux, h->d_Rz, h->d_contact, h->d_grf,
-                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out};
+                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -559,6 +587,9 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     A1_TRY(hipMemset(h->d_rho, 0, n * sizeof(double)));
     if (max_batch >= split_threshold()) A1_TRY(hipMalloc(&h->d_prep, n * prep_stride(H) * sizeof(double)));
     A1_TRY(hipMalloc(&h->d_counter, sizeof(int)));
+    A1_TRY(hipMalloc(&h->d_order, n * sizeof(int32_t)));
+    A1_TRY(hipMalloc(&h->d_cost, n * sizeof(int32_t)));
+    if (const char* e = std::getenv("A1MPC_SCHEDULE")) h->schedule = std::strcmp(e, "index") != 0;
     // pinned mirror: inputs (x0, xref, R, Rz, foot, aux, contact) then outputs (grf, u, iters, status)
     h->h_pin_in_bytes = n * ((13 + 13 * H + 9 + 12) * sizeof(double) + 8);
     const size_t out_max = n * ((12 + 12 * H) * sizeof(double) + 2 * sizeof(int32_t));
@@ -596,6 +627,14 @@ a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h) {
     A1_HIP(hipMemsetAsync(h->d_wy, 0, n * 20 * H * sizeof(double), h->stream));
     A1_HIP(hipMemsetAsync(h->d_rho, 0, n * sizeof(double), h->stream));
     A1_HIP(hipStreamSynchronize(h->stream));
+    h->hint_n = 0;
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_set_schedule(a1mpc_handle h, int32_t history) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    h->schedule = history != 0;
+    h->hint_n = 0;
     return A1MPC_OK;
 }
 
@@ -617,9 +656,19 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     a.grf = d_grf_body_out; a.u_full = d_u_full_out; a.iters = d_iters_out; a.status = d_status_out; a.nfact = h->d_nfact;
     h->last_stream = s;
     if (h->cfg.warm_start) { a.warm_x = h->d_wx; a.warm_y = h->d_wy; a.rho = h->d_rho; }
+    // Straggler-aware queue order: batches beyond the resident rows are issued longest-first by the cost each QP had in the previous solve of
+    // this handle (the same robots tick after tick); the first solve of a batch size runs in index order.  Scheduling only.
+    const bool hints = h->schedule && h->d_prep && n >= kScheduleMinBatch;
+    a.order = (hints && h->hint_n == n) ? h->d_order : nullptr;
+    a.cost = hints ? h->d_cost : nullptr;
     A1_HIP(hipEventRecord(h->ev0, s));
     a1mpc_status st = launch_mpc(h->cfg.horizon, a, h->d_prep, h->d_counter, s);
     if (st != A1MPC_OK) return st;
+    if (hints) {
+        hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, s, n, static_cast<const int32_t*>(h->d_cost), h->d_order);
+        A1_HIP(hipGetLastError());
+        h->hint_n = n;
+    }
     A1_HIP(hipEventRecord(h->ev1, s));
     h->timed = true;
     return A1MPC_OK;

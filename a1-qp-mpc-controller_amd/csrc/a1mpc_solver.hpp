@@ -118,10 +118,10 @@ A1_DEV double limit_scaling(double v) {  // osqp scaling.c limit_scaling
     return v;
 }
 A1_DEV double row_allmax(double v) {
-    v = fmax(v, row_ror<8>(v));
-    v = fmax(v, row_ror<4>(v));
-    v = fmax(v, row_ror<2>(v));
-    v = fmax(v, row_ror<1>(v));
+    v = max_f64(v, row_ror<8>(v));
+    v = max_f64(v, row_ror<4>(v));
+    v = max_f64(v, row_ror<2>(v));
+    v = max_f64(v, row_ror<1>(v));
     return v;
 }
 A1_DEV double row_allsum(double v) {
@@ -839,23 +839,26 @@ struct RowSolver {
                 Pu[t] = fma(r2a, xh[t], BtT(lam));
             });
         }
+        // Norms of the scaled vectors (E r, D^-1 r: they only feed the rho estimate) are accumulated as squares -- E^2 = rr / rho_row and
+        // D^-2 = 1 / dI2 are at hand, E and D^-1 would cost a square root and a division per row and step -- and rooted once per norm.
         double m_pri = 0, m_upri = 0, m_z = 0, m_uz = 0, m_Ax = 0, m_uAx = 0;
         double m_dua = 0, m_udua = 0, m_q = 0, m_uq = 0, m_Aty = 0, m_uAty = 0, m_Px = 0, m_uPx = 0;
+        const double irho = one_c / rho_c, irho_eq = one_c / (kRhoEqOverIneq * rho_c);
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
             const double uz = quad_perm<2, 2, 2, 2>(xh[t]);
             const double ax0 = comp == 2 ? xh[t] : fma(mu, uz, xh[t]);  // E^-1 (A_s x)
             const double ax1 = comp < 2 ? fma(-mu, uz, xh[t]) : 0.0;
-            const double z0 = fmin(fmax(wh0[t], lb0), ub0), z1 = fmin(wh1[t], 0.0);  // E^-1 z
+            const double z0 = min_f64(max_f64(wh0[t], lb0), ub0), z1 = min_f64(wh1[t], 0.0);  // E^-1 z
             const double rp0 = ax0 - z0, rp1 = ax1 - z1;
             const bool eq = (eqmask >> t) & 1u;
-            const double e0 = sqrt(rr0[t] / (eq ? kRhoEqOverIneq * rho_c : rho_c)), e1 = sqrt(rr1[t] / rho_c);  // E
-            m_upri = fmax(m_upri, fmax(fabs(rp0), fabs(rp1)));
-            m_pri = fmax(m_pri, fmax(fabs(e0 * rp0), fabs(e1 * rp1)));
-            m_uz = fmax(m_uz, fmax(fabs(z0), fabs(z1)));
-            m_z = fmax(m_z, fmax(fabs(e0 * z0), fabs(e1 * z1)));
-            m_uAx = fmax(m_uAx, fmax(fabs(ax0), fabs(ax1)));
-            m_Ax = fmax(m_Ax, fmax(fabs(e0 * ax0), fabs(e1 * ax1)));
+            const double e0 = rr0[t] * (eq ? irho_eq : irho), e1 = rr1[t] * irho;  // E^2
+            m_upri = max_f64(m_upri, max_f64(fabs(rp0), fabs(rp1)));
+            m_pri = max_f64(m_pri, max_f64(e0 * (rp0 * rp0), e1 * (rp1 * rp1)));
+            m_uz = max_f64(m_uz, max_f64(fabs(z0), fabs(z1)));
+            m_z = max_f64(m_z, max_f64(e0 * (z0 * z0), e1 * (z1 * z1)));
+            m_uAx = max_f64(m_uAx, max_f64(fabs(ax0), fabs(ax1)));
+            m_Ax = max_f64(m_Ax, max_f64(e0 * (ax0 * ax0), e1 * (ax1 * ax1)));
             // D^-1 (A_s' y_s) = A' (E y_s) = A' [rr (wh - Pi(wh))]
             const double w0 = rr0[t] * (wh0[t] - z0), w1 = rr1[t] * (wh1[t] - z1);
             const double sm = w0 - w1;
@@ -864,30 +867,30 @@ struct RowSolver {
             const double cgt = act ? lds[L::CG + t * 12 + ci] : 0.0;
             const double px_u = csc * Pu[t];        // = D^-1 (P_s x_s)
             const double rd_u = px_u + cgt + aty_u;  // = D^-1 (P_s x_s + q_s + A_s' y_s)
-            const double Dd = one_c / sqrt(dI2[t]);
-            m_udua = fmax(m_udua, fabs(rd_u));
-            m_dua = fmax(m_dua, fabs(Dd * rd_u));
-            m_uq = fmax(m_uq, fabs(cgt));
-            m_q = fmax(m_q, fabs(Dd * cgt));
-            m_uAty = fmax(m_uAty, fabs(aty_u));
-            m_Aty = fmax(m_Aty, fabs(Dd * aty_u));
-            m_uPx = fmax(m_uPx, fabs(px_u));
-            m_Px = fmax(m_Px, fabs(Dd * px_u));
+            const double D2 = one_c / dI2[t];        // D^2
+            m_udua = max_f64(m_udua, fabs(rd_u));
+            m_dua = max_f64(m_dua, D2 * (rd_u * rd_u));
+            m_uq = max_f64(m_uq, fabs(cgt));
+            m_q = max_f64(m_q, D2 * (cgt * cgt));
+            m_uAty = max_f64(m_uAty, fabs(aty_u));
+            m_Aty = max_f64(m_Aty, D2 * (aty_u * aty_u));
+            m_uPx = max_f64(m_uPx, fabs(px_u));
+            m_Px = max_f64(m_Px, D2 * (px_u * px_u));
         });
         info.pri_res = row_allmax(act ? m_upri : 0.0);
         info.nEz = row_allmax(act ? m_uz : 0.0);
         info.nEAx = row_allmax(act ? m_uAx : 0.0);
-        info.s_pri = row_allmax(act ? m_pri : 0.0);
-        info.s_z = row_allmax(act ? m_z : 0.0);
-        info.s_Ax = row_allmax(act ? m_Ax : 0.0);
+        info.s_pri = sqrt(row_allmax(act ? m_pri : 0.0));
+        info.s_z = sqrt(row_allmax(act ? m_z : 0.0));
+        info.s_Ax = sqrt(row_allmax(act ? m_Ax : 0.0));
         info.dua_res = cinv * row_allmax(act ? m_udua : 0.0);
         info.nDq = row_allmax(act ? m_uq : 0.0);
         info.nDAty = row_allmax(act ? m_uAty : 0.0);
         info.nDPx = row_allmax(act ? m_uPx : 0.0);
-        info.s_dua = row_allmax(act ? m_dua : 0.0);
-        info.s_q = row_allmax(act ? m_q : 0.0);
-        info.s_Aty = row_allmax(act ? m_Aty : 0.0);
-        info.s_Px = row_allmax(act ? m_Px : 0.0);
+        info.s_dua = sqrt(row_allmax(act ? m_dua : 0.0));
+        info.s_q = sqrt(row_allmax(act ? m_q : 0.0));
+        info.s_Aty = sqrt(row_allmax(act ? m_Aty : 0.0));
+        info.s_Px = sqrt(row_allmax(act ? m_Px : 0.0));
     }
     // auxil.c check_termination (feasibility certificates are not evaluated: u = 0 is always feasible and
     // P > 0, so this QP family is never primal or dual infeasible)
@@ -1005,6 +1008,10 @@ struct BatchArgs {
     const uint8_t* contact;
     double *grf, *u_full, *warm_x, *warm_y, *rho;
     int32_t *iters, *status, *nfact;
+    // work-queue order of the persistent ADMM rows (null = index order) and the per-QP cost record that the next solve's order is
+    // built from (null = not recorded); scheduling only -- no result depends on either
+    const int32_t* order;
+    int32_t* cost;
 };
 template <int H, int MODE>
 A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
@@ -1046,9 +1053,15 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
     int64_t cur = 0;
     while (alive) {
         if (need_new) {
-            if (have) S.write_outputs(make_io<H, kModeMpc>(a, cur));
+            if (have) {
+                S.write_outputs(make_io<H, kModeMpc>(a, cur));
+                if (a.cost != nullptr && S.ln == 0) a.cost[cur] = S.iter + 10 * S.nfact;  // ~ ADMM-iteration equivalents (a factor pass ~ 10)
+            }
             double v = 0.0;
-            if (S.ln == 0) v = static_cast<double>(row_atomic_inc(counter));
+            if (S.ln == 0) {
+                const int q = row_atomic_inc(counter);
+                v = static_cast<double>((q < a.n && a.order != nullptr) ? a.order[q] : q);
+            }
             cur = static_cast<int64_t>(row_bcast<0>(v));
             if (cur >= a.n) {
                 alive = false;

@@ -36,7 +36,7 @@ class GaitConfig(C.Structure):  # a1mpc_gait_config
                 ("gait_counter_reset", C.c_double * 4)]
 
 
-EXPORTS = ["a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
+EXPORTS = ["a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
 
@@ -72,6 +72,7 @@ def load_library(path=None):
     lib.a1mpc_update_plan_batch.argtypes = [vp, C.POINTER(GaitConfig), i32, u8p, dp, dp, dp, dp, dp, dp, dp, u8p, dp, dp, dp]
     lib.a1mpc_update_plan_batch.restype = C.c_int
     lib.a1mpc_joint_torques_batch.argtypes = [vp, i32, u8p, u8p, dp, dp, dp, dp, dp, dp]; lib.a1mpc_joint_torques_batch.restype = C.c_int
+    lib.a1mpc_set_schedule.argtypes = [vp, i32]; lib.a1mpc_set_schedule.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
     lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int
     lib.a1mpc_last_nfact.argtypes = [vp, i32, i32p]; lib.a1mpc_last_nfact.restype = C.c_int
@@ -218,6 +219,10 @@ class Engine:
         rc = self.lib.a1mpc_joint_torques_batch(self._h, n, u8(act), u8(c), _dp(Jb), _dp(g), _dp(fk), _dp(km), _dp(tg), _dp(tau))
         _check(self.lib, rc, "a1mpc_joint_torques_batch")
         return tau
+
+    def set_schedule(self, history=True):
+        """queue order of batches beyond the resident set: previous solve's longest-first (default) or index order"""
+        _check(self.lib, self.lib.a1mpc_set_schedule(self._h, 1 if history else 0), "a1mpc_set_schedule")
 
     def reset_warm_start(self):
         _check(self.lib, self.lib.a1mpc_reset_warm_start(self._h), "a1mpc_reset_warm_start")

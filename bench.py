@@ -160,6 +160,17 @@ def main():
         elapsed = float(t.item())
 
     it = iters.cpu().numpy(); stt = status.cpu().numpy()
+    # the same steps in plain index order (what the first solve of a batch gets): reported beside `value`, never instead of it
+    eng.set_schedule(False)
+    step(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(args.steps):
+        step()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    index_ms = e0.elapsed_time(e1) / args.steps
+    eng.set_schedule(True)
     if rank == 0:
         h = HORIZON
         nfact = eng.last_nfact(n)  # factorisations each QP really performed in the last launch
@@ -182,11 +193,15 @@ def main():
                        "mean_iters": float(it.mean()), "max_iters": int(it.max()), "solved_frac": float((stt == 1).mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "a1mpc_setup_kernel<10> + a1mpc_admm_kernel<10,2> (one launch = both)", "avg_kernel_ms": avg_ms, "algorithmic_flops_per_launch": flops,
+                         "kernel": "a1mpc_setup_kernel<10> + a1mpc_admm_kernel<10,2> (+ a1mpc_order_kernel, ~5 us) = one solve", "avg_kernel_ms": avg_ms, "algorithmic_flops_per_launch": flops,
                          "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
                          "note": "FP64 VALU issue/latency-bound (no MFMA used, DESIGN.md 3); flops = SURVEY 8(d) F(h,iters,nfact) summed over the launch; "
                                  "traffic = FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_summary.json (same workload)"},
         }
+        out["scheduling"] = {
+            "mode": "history: the work queue of a batch beyond the resident rows is ordered longest-first by the per-QP cost of the previous "
+                    "solve of the handle (a1mpc_set_schedule); every QP is solved from scratch every step, results are independent of the order",
+            "index_order_ms_per_step": index_ms, "index_order_solves_per_s_per_gpu": n / (index_ms * 1e-3)}
         if not args.no_latency:
             out["latency"] = latency_probe(pkg)
             out["throughput_by_batch"] = batch_sweep(pkg, local)

@@ -301,3 +301,17 @@ def test_joint_torques_N3_bit_exact(pkg, oracle, scen):
     ref5 = oracle.joint_torques(1, c[5], Jb[5].reshape(36), grf[5], fk[5], km, tg[5], prev[5])
     assert (tau[act == 0] == 0).all() and np.array_equal(tau[5], ref5)
     assert (tau[5, 3:5] == prev[5, 3:5]).all() and np.isinf(tau[5, 5])  # 0*inf = NaN is guarded (:314-317), the infinity is not -- like the reference
+
+
+def test_queue_order_does_not_change_results(pkg, scen):
+    """a1mpc_set_schedule: longest-first by the previous solve's cost vs index order -- same QPs, bit-identical results, any order"""
+    sc = scen.config3_random_flat(nb=3000)
+    cfg = pkg.make_config(sc["params"], 10, warm_start=0)
+    args = (sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+    with pkg.Engine(cfg, 3000, 0) as eng:
+        first = eng.solve(*args)            # no history yet: index order
+        again = eng.solve(*args)            # ordered by the first solve's costs
+        eng.set_schedule(False)
+        plain = eng.solve(*args)
+    for k in ("grf", "iters", "status"):
+        assert np.array_equal(first[k], again[k]) and np.array_equal(first[k], plain[k]), k
