@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="QPs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-index-order", action="store_true", help="skip the extra index-order steps (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -161,16 +162,18 @@ def main():
 
     it = iters.cpu().numpy(); stt = status.cpu().numpy()
     # the same steps in plain index order (what the first solve of a batch gets): reported beside `value`, never instead of it
-    eng.set_schedule(False)
-    step(); torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(args.steps):
-        step()
-    e1.record(stream)
-    torch.cuda.synchronize()
-    index_ms = e0.elapsed_time(e1) / args.steps
-    eng.set_schedule(True)
+    index_ms = None
+    if not args.no_index_order:
+        eng.set_schedule(False)
+        step(); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.steps):
+            step()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        index_ms = e0.elapsed_time(e1) / args.steps
+        eng.set_schedule(True)
     if rank == 0:
         h = HORIZON
         nfact = eng.last_nfact(n)  # factorisations each QP really performed in the last launch
@@ -201,7 +204,7 @@ def main():
         out["scheduling"] = {
             "mode": "history: the work queue of a batch beyond the resident rows is ordered longest-first by the per-QP cost of the previous "
                     "solve of the handle (a1mpc_set_schedule); every QP is solved from scratch every step, results are independent of the order",
-            "index_order_ms_per_step": index_ms, "index_order_solves_per_s_per_gpu": n / (index_ms * 1e-3)}
+            "index_order_ms_per_step": index_ms, "index_order_solves_per_s_per_gpu": (n / (index_ms * 1e-3)) if index_ms else None}
         if not args.no_latency:
             out["latency"] = latency_probe(pkg)
             out["throughput_by_batch"] = batch_sweep(pkg, local)
