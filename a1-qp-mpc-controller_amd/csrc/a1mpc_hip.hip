@@ -161,25 +161,28 @@ static a1mpc_status fail(a1mpc_status s, const std::string& msg) { g_last_error 
         if (e_ != hipSuccess) return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-// the split pipeline serves every MPC batch size (it also wins at batch 1: p50 0.38 vs 0.43 ms); A1MPC_PIPELINE=fused selects the
-// single-kernel path for experiments -- the balance QP always uses it
-static int split_threshold() {
-    static int t = [] {
+// Pipeline choice.  A batch that fits the resident rows of the ADMM kernel runs the fused kernel (set-up + solve in one launch: every QP
+// starts at once, nothing to queue; measured 6 % faster than the split pair for 64 <= n <= 2048 at H = 10, equal at n = 1); larger batches
+// run the split pipeline (set-up kernel + persistent rows, +30 % at 4096).  A1MPC_PIPELINE=fused|split forces one.  The balance QP is always fused.
+static int pipeline_mode() {  // 0 = auto, 1 = always split, 2 = always fused
+    static int m = [] {
         const char* e = getenv("A1MPC_PIPELINE");
-        if (e && !strcmp(e, "fused")) return 1 << 30;
+        if (e && !strcmp(e, "fused")) return 2;
         if (e && !strcmp(e, "split")) return 1;
-        return 1;
+        return 0;
     }();
-    return t;
+    return m;
 }
 
+// workgroups of the persistent ADMM kernel that are resident at once on the current device (occupancy query, cached per device)
 template <int H, int ROWS>
-static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* counter, hipStream_t stream) {
+static a1mpc_status resident_workgroups(int* out) {
     static int resident[64] = {};
     int dev = 0;
     A1_HIP(hipGetDevice(&dev));
-    const size_t lds2 = lds_bytes<H>(ROWS), lds1 = sizeof(double) * (4 * LayoutSetup<H>::ROW_STRIDE + 2 * H * H);
-    if (dev >= 0 && dev < 64 && !resident[dev]) {
+    if (dev < 0 || dev >= 64) { *out = 512; return A1MPC_OK; }
+    if (!resident[dev]) {
+        const size_t lds2 = lds_bytes<H>(ROWS);
         A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(lds2)));
         int per_cu = 0, cus = 0;
@@ -187,11 +190,34 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
         A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         resident[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
     }
+    *out = resident[dev];
+    return A1MPC_OK;
+}
+template <int H>
+static a1mpc_status resident_rows(int* out) {
+    int wg = 0;
+    a1mpc_status st;
+#ifdef A1MPC_DEV_SLIM
+    st = resident_workgroups<H, 2>(&wg); *out = 2 * wg;
+#else
+    switch (rows_per_wg()) {
+        case 1: st = resident_workgroups<H, 1>(&wg); *out = wg; return st;
+        case 2: st = resident_workgroups<H, 2>(&wg); *out = 2 * wg; return st;
+    }
+    st = resident_workgroups<H, 4>(&wg); *out = 4 * wg;
+#endif
+    return st;
+}
+
+template <int H, int ROWS>
+static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* counter, hipStream_t stream) {
+    const size_t lds2 = lds_bytes<H>(ROWS), lds1 = sizeof(double) * (4 * LayoutSetup<H>::ROW_STRIDE + 2 * H * H);
+    int res = 0;
+    if (a1mpc_status st = resident_workgroups<H, ROWS>(&res); st != A1MPC_OK) return st;
     A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
     hipLaunchKernelGGL((a1mpc_setup_kernel<H>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
     A1_HIP(hipGetLastError());
     const int want = (a.n + ROWS - 1) / ROWS;
-    const int res = (dev >= 0 && dev < 64) ? resident[dev] : 512;
     hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), dim3(static_cast<unsigned>(want < res ? want : res)), dim3(16 * ROWS), lds2, stream, a,
                        static_cast<const double*>(prep), counter);
     A1_HIP(hipGetLastError());
@@ -245,8 +271,28 @@ static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
 
 static constexpr int kScheduleMinBatch = 1024;  // below this every QP is resident at once and the order cannot matter
 
-static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s) {
-    if (a.n >= split_threshold() && prep && counter) {
+// does a batch of n QPs go through the split pipeline?
+static a1mpc_status use_split_pipeline(int horizon, int n, bool have_prep, bool* split) {
+    *split = false;
+    if (!have_prep || pipeline_mode() == 2) return A1MPC_OK;
+    if (pipeline_mode() == 1) { *split = true; return A1MPC_OK; }
+    int rows = 0;
+    a1mpc_status st = A1MPC_OK;
+    switch (horizon) {
+        case 10: st = resident_rows<10>(&rows); break;
+#ifndef A1MPC_DEV_SLIM
+        case 1: st = resident_rows<1>(&rows); break;
+        case 16: st = resident_rows<16>(&rows); break;
+        case 20: st = resident_rows<20>(&rows); break;
+#endif
+        default: return A1MPC_OK;
+    }
+    *split = n > rows;
+    return st;
+}
+
+static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s, bool split) {
+    if (split && prep && counter) {
         switch (horizon) {
             case 10: return launch_split<10>(a, prep, counter, s);
 #ifndef A1MPC_DEV_SLIM
@@ -585,7 +631,7 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     A1_TRY(hipMemset(h->d_wx, 0, n * 12 * H * sizeof(double)));
     A1_TRY(hipMemset(h->d_wy, 0, n * 20 * H * sizeof(double)));
     A1_TRY(hipMemset(h->d_rho, 0, n * sizeof(double)));
-    if (max_batch >= split_threshold()) A1_TRY(hipMalloc(&h->d_prep, n * prep_stride(H) * sizeof(double)));
+    if (pipeline_mode() != 2) A1_TRY(hipMalloc(&h->d_prep, n * prep_stride(H) * sizeof(double)));
     A1_TRY(hipMalloc(&h->d_counter, sizeof(int)));
     A1_TRY(hipMalloc(&h->d_order, n * sizeof(int32_t)));
     A1_TRY(hipMalloc(&h->d_cost, n * sizeof(int32_t)));
@@ -658,11 +704,13 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     if (h->cfg.warm_start) { a.warm_x = h->d_wx; a.warm_y = h->d_wy; a.rho = h->d_rho; }
     // Straggler-aware queue order: batches beyond the resident rows are issued longest-first by the cost each QP had in the previous solve of
     // this handle (the same robots tick after tick); the first solve of a batch size runs in index order.  Scheduling only.
-    const bool hints = h->schedule && h->d_prep && n >= kScheduleMinBatch;
+    bool split = false;
+    if (a1mpc_status st0 = use_split_pipeline(h->cfg.horizon, n, h->d_prep != nullptr, &split); st0 != A1MPC_OK) return st0;
+    const bool hints = h->schedule && split && n >= kScheduleMinBatch;
     a.order = (hints && h->hint_n == n) ? h->d_order : nullptr;
     a.cost = hints ? h->d_cost : nullptr;
     A1_HIP(hipEventRecord(h->ev0, s));
-    a1mpc_status st = launch_mpc(h->cfg.horizon, a, h->d_prep, h->d_counter, s);
+    a1mpc_status st = launch_mpc(h->cfg.horizon, a, h->d_prep, h->d_counter, s, split);
     if (st != A1MPC_OK) return st;
     if (hints) {
         hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, s, n, static_cast<const int32_t*>(h->d_cost), h->d_order);
