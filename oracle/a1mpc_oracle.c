@@ -43,6 +43,13 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#ifdef ORC_EXTENDED
+/* Accuracy yardstick (tools/extended_check.py, make liba1mpc_oracle_x87.so): the same source with every `double` below widened to the
+ * x87 80-bit long double (64-bit significand) -- the OSQP iterate sequence with 2048x less rounding error, against which the
+ * double-precision oracle and the GPU engine are both measured.  Never used as the pass/fail checker. */
+#include <tgmath.h>
+#define double long double
+#endif
 
 #define NS 13 /* MPC_STATE_DIM      S/A1Params.h:27 */
 #define NU 12 /* NUM_DOF            S/A1Params.h:34 */

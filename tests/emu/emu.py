@@ -25,7 +25,7 @@ def build(force=False):
     srcs = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_HERE, "a1mpc_rowops.hpp"),
             os.path.join(_CSRC, "a1mpc_solver.hpp"), os.path.join(_CSRC, "a1mpc_tables.hpp")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", _HERE, "-I", _CSRC, srcs[0], "-o", _LIB])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", _HERE, "-I", _CSRC, srcs[0], "-o", _LIB] + os.environ.get("A1_EMU_FLAGS", "").split())
     return _LIB
 
 
