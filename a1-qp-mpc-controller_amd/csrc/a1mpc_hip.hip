@@ -362,6 +362,7 @@ struct a1mpc_handle_s {
     int* d_counter = nullptr;
     // queue order of the next solve (longest-first by the previous solve's per-QP cost) -- see a1mpc_set_schedule
     int32_t *d_order = nullptr, *d_cost = nullptr;
+    double* d_ct_state = nullptr;  // N2b filter state of every robot (allocated on first use)
     int32_t hint_n = 0;  // batch size the order was built for (0 = none)
     int schedule = 1;    // 1 = history (default), 0 = index order
     // packed device blocks + pinned host mirrors of the host-pointer MPC entry (one copy each way per call)
@@ -391,6 +392,174 @@ void a1mpc_default_balance_config(a1mpc_balance_config* q) {
     const double Q[6] = {1.0, 1.0, 1.0, 400.0, 400.0, 100.0};  // S/A1RobotControl.cpp:11
     std::memcpy(q->Q, Q, sizeof Q);
     q->R = 1e-3; q->mu = 0.7; q->F_min = 0.0; q->F_max = 180.0;  // S/A1RobotControl.cpp:12-15
+}
+
+// ---- N2b: contact logic + recent-contact filters, walking-surface fit, terrain pitch (S/A1RobotControl.cpp:256-282, 566-582, 335-376) --------
+// Device-resident state per robot: 13 moving-window filters x [count, head, sum, correction, ring[100]], early_contacts[4], recent[12].
+// K_a: one lane per (robot, leg) -- contact rules and the leg's three filters (window 60); K_b: one lane per robot -- plane fit,
+// terrain-angle filter (window 100), pitch rule.  HBM-bound: a tick touches one ring slot per active filter.  No FMA contraction.
+constexpr int kMwf = 104, kCtState = 13 * kMwf + 4 + 12;
+struct ContactArgs {
+    int32_t n;
+    double counter_per_swing, foot_force_low;
+    int32_t use_terrain_adapt;
+    double* state;
+    const double *gait_counter, *foot_force, *foot_pos_abs, *root_pos_z;
+    const uint8_t* plan_contacts;
+    double* pitch_d;
+    uint8_t* contacts;
+    double *recent_out, *terrain_out;
+};
+__device__ inline double mwf_update(double* f, int window, double v) {  // S/utils/filter.hpp:26-39,53-66
+#pragma clang fp contract(off)
+    int count = static_cast<int>(f[0]), head = static_cast<int>(f[1]);
+    double sum = f[2], corr = f[3];
+    double* ring = f + 4;
+    auto neumaier = [&](double val) {
+        const double ns = sum + val;
+        if (fabs(sum) >= fabs(val)) corr += (sum - ns) + val; else corr += (val - ns) + sum;
+        sum = ns;
+    };
+    if (count >= window) neumaier(-ring[head]); else count += 1;
+    neumaier(v);
+    ring[head] = v;
+    head = (head + 1) % window;
+    f[0] = count; f[1] = head; f[2] = sum; f[3] = corr;
+    return (sum + corr) / static_cast<double>(window);
+}
+__global__ __launch_bounds__(256) void a1mpc_contact_kernel(const ContactArgs a) {
+#pragma clang fp contract(off)
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t b = gid >> 2;
+    const int i = static_cast<int>(gid & 3);
+    if (b >= a.n) return;
+    double* st = a.state + b * kCtState;
+    double *early = st + 13 * kMwf, *recent = early + 4;
+    const double gc = a.gait_counter[b * 4 + i];
+    const bool plan = a.plan_contacts[b * 4 + i] != 0;
+    double e = early[i];
+    if (gc <= a.counter_per_swing * 1.5) e = 0.0;                                                                   // :260-262
+    if (!plan && gc > a.counter_per_swing * 1.5 && a.foot_force[b * 4 + i] > a.foot_force_low) e = 1.0;             // :263-267
+    early[i] = e;
+    const bool c = plan || e != 0.0;                                                                                // :271
+    a.contacts[b * 4 + i] = c ? 1 : 0;
+    if (c) {                                                                                                        // :274-281
+#pragma unroll
+        for (int k = 0; k < 3; ++k) recent[3 * i + k] = mwf_update(st + (3 * i + k) * kMwf, 60, a.foot_pos_abs[b * 12 + 3 * i + k]);
+    }
+}
+__device__ inline void sym3_pinv(const double* m, double* out) {  // pseudo-inverse of a symmetric PSD 3x3 by cyclic Jacobi (S/utils/Utils.cpp:44-52)
+#pragma clang fp contract(off)
+    double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; ++k) a[k] = m[k];
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            const double apq = a[3 * p + q];
+            if (apq == 0.0) continue;
+            const double th = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
+            const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+            for (int k = 0; k < 3; ++k) { const double akp = a[3 * k + p], akq = a[3 * k + q]; a[3 * k + p] = c * akp - sn * akq; a[3 * k + q] = sn * akp + c * akq; }
+            for (int k = 0; k < 3; ++k) { const double apk = a[3 * p + k], aqk = a[3 * q + k]; a[3 * p + k] = c * apk - sn * aqk; a[3 * q + k] = sn * apk + c * aqk; }
+            for (int k = 0; k < 3; ++k) { const double vkp = v[3 * k + p], vkq = v[3 * k + q]; v[3 * k + p] = c * vkp - sn * vkq; v[3 * k + q] = sn * vkp + c * vkq; }
+        }
+    }
+    double lmax = fabs(a[0]);
+    if (fabs(a[4]) > lmax) lmax = fabs(a[4]);
+    if (fabs(a[8]) > lmax) lmax = fabs(a[8]);
+    const double tol = 2.220446049250313e-16 * 3.0 * lmax;
+    double inv[3];
+    for (int k = 0; k < 3; ++k) inv[k] = fabs(a[4 * k]) > tol ? 1.0 / a[4 * k] : 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            out[3 * i + j] = v[3 * i + 0] * inv[0] * v[3 * j + 0] + v[3 * i + 1] * inv[1] * v[3 * j + 1] + v[3 * i + 2] * inv[2] * v[3 * j + 2];
+}
+__global__ __launch_bounds__(256) void a1mpc_terrain_kernel(const ContactArgs a) {
+#pragma clang fp contract(off)
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (b >= a.n) return;
+    double* st = a.state + b * kCtState;
+    const double* recent = st + 13 * kMwf + 4;
+    double rc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { rc[k] = recent[k]; a.recent_out[b * 12 + k] = rc[k]; }
+    double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, rhs[3] = {0, 0, 0}, P3[9], co[3];   // :566-582  a = pinv(W'W) W' z
+    for (int i = 0; i < 4; ++i) {
+        const double w[3] = {1.0, rc[3 * i + 0], rc[3 * i + 1]};
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) M[3 * r + c] += w[r] * w[c]; rhs[r] += w[r] * rc[3 * i + 2]; }
+    }
+    sym3_pinv(M, P3);
+    for (int r = 0; r < 3; ++r) co[r] = P3[3 * r + 0] * rhs[0] + P3[3 * r + 1] * rhs[1] + P3[3 * r + 2] * rhs[2];
+    const double s0 = co[1], s1 = co[2], s2 = -1.0;
+    double terrain_angle = 0.0;                                                             // :339-352
+    if (a.root_pos_z[b] > 0.1) {
+        const double angle_cos = fabs(0.0 * s0 + 0.0 * s1 + 1.0 * s2) / (sqrt(0.0 * 0.0 + 0.0 * 0.0 + 1.0 * 1.0) * sqrt(s0 * s0 + s1 * s1 + s2 * s2));
+        terrain_angle = mwf_update(st + 12 * kMwf, 100, acos(angle_cos));
+    }
+    if (terrain_angle > 0.5) terrain_angle = 0.5;
+    if (terrain_angle < -0.5) terrain_angle = -0.5;
+    const double F_R_diff = rc[2] + rc[5] - rc[8] - rc[11];                                // :355
+    if (a.use_terrain_adapt) a.pitch_d[b] = F_R_diff > 0.05 ? -terrain_angle : terrain_angle;  // :358-364
+    a.terrain_out[b] = terrain_angle;
+}
+
+void a1mpc_default_contact_config(a1mpc_contact_config* c) {
+    if (!c) return;
+    c->counter_per_swing = 120.0; c->foot_force_low = 30.0; c->use_terrain_adapt = 1;
+}
+a1mpc_status a1mpc_reset_contact_state(a1mpc_handle h) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (!h->d_ct_state) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double), h->stream));
+    A1_HIP(hipStreamSynchronize(h->stream));
+    return A1MPC_OK;
+}
+a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_config* cfg, int32_t n, const double* gait_counter,
+                                         const uint8_t* plan_contacts, const double* foot_force, const double* foot_pos_abs,
+                                         const double* root_pos_z, double* root_euler_d_pitch, uint8_t* contacts_out,
+                                         double* foot_pos_recent_contact_out, double* terrain_angle_out) {
+    if (!h || !cfg) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle/config");
+    if (n < 0 || !gait_counter || !plan_contacts || !foot_force || !foot_pos_abs || !root_pos_z || !root_euler_d_pitch || !contacts_out ||
+        !foot_pos_recent_contact_out || !terrain_angle_out)
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    if (h->cfg.horizon < 3) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "contact/terrain staging needs a handle with horizon >= 3");
+    A1_HIP(hipSetDevice(h->device));
+    const size_t N = n;
+    hipStream_t s = h->stream;
+    if (!h->d_ct_state) {
+        A1_HIP(hipMalloc(&h->d_ct_state, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double)));
+        A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double), s));
+    }
+    // staging inside the handle's MPC buffers: d_xref [gc 4 | ff 4 | foot 12 | z 1 | pitch 1] (22 <= 13 H), d_u [recent 12 | terrain 1]
+    double *d_gc = h->d_xref, *d_ff = d_gc + 4 * N, *d_fp = d_ff + 4 * N, *d_z = d_fp + 12 * N, *d_pd = d_z + N;
+    double *d_rec = h->d_u, *d_ta = d_rec + 12 * N;
+    uint8_t *d_pc = h->d_contact, *d_ct = reinterpret_cast<uint8_t*>(h->d_iters);
+    A1_HIP(hipMemcpyAsync(d_gc, gait_counter, N * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_ff, foot_force, N * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_fp, foot_pos_abs, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_z, root_pos_z, N * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_pd, root_euler_d_pitch, N * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_pc, plan_contacts, N * 4, hipMemcpyHostToDevice, s));
+    ContactArgs a;
+    a.n = n; a.counter_per_swing = cfg->counter_per_swing; a.foot_force_low = cfg->foot_force_low; a.use_terrain_adapt = cfg->use_terrain_adapt;
+    a.state = h->d_ct_state; a.gait_counter = d_gc; a.foot_force = d_ff; a.foot_pos_abs = d_fp; a.root_pos_z = d_z; a.plan_contacts = d_pc;
+    a.pitch_d = d_pd; a.contacts = d_ct; a.recent_out = d_rec; a.terrain_out = d_ta;
+    A1_HIP(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(a1mpc_contact_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(a1mpc_terrain_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+    A1_HIP(hipGetLastError());
+    A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = true; h->last_stream = s;
+    A1_HIP(hipMemcpyAsync(contacts_out, d_ct, N * 4, hipMemcpyDeviceToHost, s));
+    A1_HIP(hipMemcpyAsync(foot_pos_recent_contact_out, d_rec, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipMemcpyAsync(terrain_angle_out, d_ta, N * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipMemcpyAsync(root_euler_d_pitch, d_pd, N * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipStreamSynchronize(s));
+    return A1MPC_OK;
 }
 
 // ---- N3: compute_joint_torques (S/A1RobotControl.cpp:289-319), one lane per (robot, leg); no FMA contraction ---------------------
@@ -567,7 +736,7 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_tab, h->d_tab1, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_aux, h->d_Rz, h->d_contact, h->d_grf,
-                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost};
+                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);

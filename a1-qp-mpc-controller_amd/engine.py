@@ -36,7 +36,11 @@ class GaitConfig(C.Structure):  # a1mpc_gait_config
                 ("gait_counter_reset", C.c_double * 4)]
 
 
-EXPORTS = ["a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
+class ContactConfig(C.Structure):  # a1mpc_contact_config
+    _fields_ = [("counter_per_swing", C.c_double), ("foot_force_low", C.c_double), ("use_terrain_adapt", C.c_int32)]
+
+
+EXPORTS = ["a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
 
@@ -72,6 +76,10 @@ def load_library(path=None):
     lib.a1mpc_update_plan_batch.argtypes = [vp, C.POINTER(GaitConfig), i32, u8p, dp, dp, dp, dp, dp, dp, dp, u8p, dp, dp, dp]
     lib.a1mpc_update_plan_batch.restype = C.c_int
     lib.a1mpc_joint_torques_batch.argtypes = [vp, i32, u8p, u8p, dp, dp, dp, dp, dp, dp]; lib.a1mpc_joint_torques_batch.restype = C.c_int
+    lib.a1mpc_default_contact_config.argtypes = [C.POINTER(ContactConfig)]; lib.a1mpc_default_contact_config.restype = None
+    lib.a1mpc_contact_terrain_batch.argtypes = [vp, C.POINTER(ContactConfig), i32, dp, u8p, dp, dp, dp, dp, u8p, dp, dp]
+    lib.a1mpc_contact_terrain_batch.restype = C.c_int
+    lib.a1mpc_reset_contact_state.argtypes = [vp]; lib.a1mpc_reset_contact_state.restype = C.c_int
     lib.a1mpc_set_schedule.argtypes = [vp, i32]; lib.a1mpc_set_schedule.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
     lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int
@@ -219,6 +227,22 @@ class Engine:
         rc = self.lib.a1mpc_joint_torques_batch(self._h, n, u8(act), u8(c), _dp(Jb), _dp(g), _dp(fk), _dp(km), _dp(tg), _dp(tau))
         _check(self.lib, rc, "a1mpc_joint_torques_batch")
         return tau
+
+    # ---- N2b: contacts, recent-contact filters, terrain pitch (S/A1RobotControl.cpp:256-282, 566-582, 335-376); state lives on the device ----
+    def contact_terrain(self, gait_counter, plan_contacts, foot_force, foot_pos_abs, root_pos_z, root_euler_d_pitch, cfg=None):
+        if cfg is None:
+            cfg = ContactConfig(); self.lib.a1mpc_default_contact_config(C.byref(cfg))
+        gc = np.ascontiguousarray(gait_counter, dtype=np.float64).reshape(-1, 4); n = gc.shape[0]; pc = np.ascontiguousarray(plan_contacts, dtype=np.uint8).reshape(n, 4)
+        ff = _f64(foot_force, (n, 4)); fp = _f64(foot_pos_abs, (n, 12)); z = _f64(root_pos_z, (n,))
+        pd = np.array(root_euler_d_pitch, dtype=np.float64).reshape(n)
+        ct = np.zeros((n, 4), np.uint8); rec = np.zeros((n, 12)); ta = np.zeros(n)
+        u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+        rc = self.lib.a1mpc_contact_terrain_batch(self._h, C.byref(cfg), n, _dp(gc), u8(pc), _dp(ff), _dp(fp), _dp(z), _dp(pd), u8(ct), _dp(rec), _dp(ta))
+        _check(self.lib, rc, "a1mpc_contact_terrain_batch")
+        return dict(contacts=ct, foot_pos_recent_contact=rec, terrain_angle=ta, root_euler_d_pitch=pd)
+
+    def reset_contact_state(self):
+        _check(self.lib, self.lib.a1mpc_reset_contact_state(self._h), "a1mpc_reset_contact_state")
 
     def set_schedule(self, history=True):
         """queue order of batches beyond the resident set: previous solve's longest-first (default) or index order"""

@@ -185,6 +185,30 @@ a1mpc_status a1mpc_joint_torques_batch(a1mpc_handle h, int32_t n, const uint8_t*
                                        const double* grf, const double* f_kin, const double* km_foot, const double* torques_gravity,
                                        double* joint_torques);
 
+/*
+ * N2b (caller side of the path): actual contacts, recent-contact positions and terrain pitch for n robots, one tick --
+ * the contact block of generate_swing_legs_ctrl (S/A1RobotControl.cpp:256-282), compute_walking_surface (:566-582) and the
+ * terrain adaptation of compute_grf (:335-376), including their MovingWindowFilters (S/utils/filter.hpp; windows 60 / 100).
+ * The filter state of every robot (13 filters, early_contacts, foot_pos_recent_contact) lives on the device inside the handle,
+ * indexed by the robot's position in the batch; a1mpc_reset_contact_state zeroes it (= constructing A1RobotControl).
+ *   gait_counter n x 4, plan_contacts n x 4, foot_force n x 4, foot_pos_abs n x 12 (3x4 column-major), root_pos_z n
+ *   root_euler_d_pitch n   in/out: overwritten with +-terrain_angle when use_terrain_adapt (:358-364)
+ * out: contacts n x 4, foot_pos_recent_contact n x 12, terrain_angle n (= state.terrain_pitch_angle).  Host pointers.
+ * Filter arithmetic is bit-identical to the reference's; the plane fit uses a Jacobi eigen-decomposition in place of Eigen's
+ * JacobiSVD (same pseudo-inverse up to rounding), acos comes from the device math library.
+ */
+typedef struct a1mpc_contact_config {
+    double counter_per_swing;   /* S/A1CtrlStates.h:25 */
+    double foot_force_low;      /* FOOT_FORCE_LOW, S/A1Params.h:38 */
+    int32_t use_terrain_adapt;  /* S/A1CtrlStates.h:22 */
+} a1mpc_contact_config;
+void a1mpc_default_contact_config(a1mpc_contact_config* cfg);
+a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_config* cfg, int32_t n, const double* gait_counter,
+                                         const uint8_t* plan_contacts, const double* foot_force, const double* foot_pos_abs,
+                                         const double* root_pos_z, double* root_euler_d_pitch, uint8_t* contacts_out,
+                                         double* foot_pos_recent_contact_out, double* terrain_angle_out);
+a1mpc_status a1mpc_reset_contact_state(a1mpc_handle h);
+
 /* Work-queue order of batches larger than the resident set: history = 1 (default) issues the QPs longest-first by the cost
  * (iterations + factor passes) each one had in the previous solve of this handle with the same n -- the same robots tick after
  * tick; history = 0 is plain index order.  The first solve of a batch size, and the solve after a1mpc_reset_warm_start, run in

@@ -778,6 +778,89 @@ void orc_joint_torques(int active, const uint8_t *contacts, const double *Jb, co
     }
 }
 
+/* ---- N2b: contact logic + recent-contact filters (S/A1RobotControl.cpp:256-282), walking-surface fit (:566-582) and terrain pitch
+ * (:335-376), with the stateful MovingWindowFilters (S/utils/filter.hpp:14-66; windows 60 and 100, S/A1RobotControl.cpp:52-56) -------
+ * State of one robot = ORC_CT_STATE doubles: 13 filters (12 = [leg][x,y,z], 13th = terrain angle), each ORC_MWF doubles
+ * [count, head, sum, correction, ring[100]], then early_contacts[4], foot_pos_recent_contact[12] (3x4 column-major).
+ * The pseudo-inverse of the 3x3 SPD normal matrix (Utils::pseudo_inverse, S/utils/Utils.cpp:44-52, JacobiSVD + relative threshold) is
+ * restated through a cyclic Jacobi eigen-decomposition (SVD = EVD for a symmetric PSD matrix); agreement with numpy's SVD-based pinv is
+ * tested, bit parity with Eigen's JacobiSVD is not claimed. */
+#define ORC_MWF 104
+#define ORC_CT_STATE (13 * ORC_MWF + 4 + 12)
+static double mwf_update(double *f, int window, double v) {        /* filter.hpp:26-39,53-66 */
+    int count = (int)f[0], head = (int)f[1];
+    double sum = f[2], corr = f[3];
+    double *ring = f + 4;
+#define NEUMAIER(val) do { const double v_ = (val); const double ns = sum + v_; \
+        if (fabs(sum) >= fabs(v_)) corr += (sum - ns) + v_; else corr += (v_ - ns) + sum; sum = ns; } while (0)
+    if (count >= window) { NEUMAIER(-ring[head]); } else { count += 1; }
+    NEUMAIER(v);
+    ring[head] = v;                         /* with a full window the oldest slot is the one just vacated */
+    head = (head + 1) % window;
+    f[0] = count; f[1] = head; f[2] = sum; f[3] = corr;
+    return (sum + corr) / (double)window;
+}
+/* pinv of a symmetric PSD 3x3 (row-major m): V diag(1/l_i if l_i > eps*3*l_max else 0) V' */
+static void sym3_pinv(const double *m, double *out) {
+    double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; ++k) a[k] = m[k];
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            const double apq = a[3 * p + q];
+            if (apq == 0.0) continue;
+            const double th = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
+            const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+            for (int k = 0; k < 3; ++k) { const double akp = a[3 * k + p], akq = a[3 * k + q]; a[3 * k + p] = c * akp - sn * akq; a[3 * k + q] = sn * akp + c * akq; }
+            for (int k = 0; k < 3; ++k) { const double apk = a[3 * p + k], aqk = a[3 * q + k]; a[3 * p + k] = c * apk - sn * aqk; a[3 * q + k] = sn * apk + c * aqk; }
+            for (int k = 0; k < 3; ++k) { const double vkp = v[3 * k + p], vkq = v[3 * k + q]; v[3 * k + p] = c * vkp - sn * vkq; v[3 * k + q] = sn * vkp + c * vkq; }
+        }
+    }
+    double lmax = fabs(a[0]);
+    if (fabs(a[4]) > lmax) lmax = fabs(a[4]);
+    if (fabs(a[8]) > lmax) lmax = fabs(a[8]);
+    const double tol = 2.220446049250313e-16 * 3.0 * lmax;
+    double inv[3];
+    for (int k = 0; k < 3; ++k) inv[k] = fabs(a[4 * k]) > tol ? 1.0 / a[4 * k] : 0.0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+        out[3 * i + j] = v[3 * i + 0] * inv[0] * v[3 * j + 0] + v[3 * i + 1] * inv[1] * v[3 * j + 1] + v[3 * i + 2] * inv[2] * v[3 * j + 2];
+}
+void orc_contact_terrain_step(double counter_per_swing, double foot_force_low, int use_terrain_adapt, double *state,
+                              const double *gait_counter, const uint8_t *plan_contacts, const double *foot_force, const double *foot_pos_abs,
+                              double root_pos_z, uint8_t *contacts, double *foot_pos_recent_contact, double *terrain_angle_out,
+                              double *root_euler_d_pitch) {
+    double *early = state + 13 * ORC_MWF, *recent = early + 4;
+    for (int i = 0; i < NLEG; ++i) {                                              /* :259-282 */
+        if (gait_counter[i] <= counter_per_swing * 1.5) early[i] = 0.0;
+        if (!plan_contacts[i] && gait_counter[i] > counter_per_swing * 1.5 && foot_force[i] > foot_force_low) early[i] = 1.0;
+        contacts[i] = (plan_contacts[i] || early[i] != 0.0) ? 1 : 0;
+        if (contacts[i])
+            for (int k = 0; k < 3; ++k) recent[3 * i + k] = mwf_update(state + (3 * i + k) * ORC_MWF, 60, foot_pos_abs[3 * i + k]);
+    }
+    for (int k = 0; k < 12; ++k) foot_pos_recent_contact[k] = recent[k];
+    /* compute_walking_surface :566-582: a = pinv(W'W) W' z, W = [1 x y] */
+    double M[9] = {0}, rhs[3] = {0}, P3[9], a[3];
+    for (int i = 0; i < NLEG; ++i) {
+        const double w[3] = {1.0, recent[3 * i + 0], recent[3 * i + 1]};
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) M[3 * r + c] += w[r] * w[c]; rhs[r] += w[r] * recent[3 * i + 2]; }
+    }
+    sym3_pinv(M, P3);
+    for (int r = 0; r < 3; ++r) a[r] = P3[3 * r + 0] * rhs[0] + P3[3 * r + 1] * rhs[1] + P3[3 * r + 2] * rhs[2];
+    const double s0 = a[1], s1 = a[2], s2 = -1.0;                                 /* surf_coef :580 */
+    double terrain_angle = 0.0;                                                   /* :339-352 */
+    if (root_pos_z > 0.1) {
+        const double angle_cos = fabs(0.0 * s0 + 0.0 * s1 + 1.0 * s2) / (sqrt(0.0 * 0.0 + 0.0 * 0.0 + 1.0 * 1.0) * sqrt(s0 * s0 + s1 * s1 + s2 * s2));
+        terrain_angle = mwf_update(state + 12 * ORC_MWF, 100, acos(angle_cos));
+    }
+    if (terrain_angle > 0.5) terrain_angle = 0.5;
+    if (terrain_angle < -0.5) terrain_angle = -0.5;
+    const double F_R_diff = recent[2] + recent[5] - recent[8] - recent[11];       /* :355 */
+    if (use_terrain_adapt) *root_euler_d_pitch = F_R_diff > 0.05 ? -terrain_angle : terrain_angle;   /* :358-364 */
+    *terrain_angle_out = terrain_angle;
+}
+int orc_contact_state_doubles(void) { return ORC_CT_STATE; }
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

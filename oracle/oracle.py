@@ -241,5 +241,24 @@ def joint_torques(active, contacts, Jb, grf, f_kin, km, torques_gravity, joint_t
     return tau
 
 
+def contact_state():
+    """zeroed N2b state of one robot (13 moving-window filters, early contacts, recent contact positions)"""
+    lib().orc_contact_state_doubles.restype = C.c_int
+    return np.zeros(lib().orc_contact_state_doubles())
+
+
+def contact_terrain_step(state, gait_counter, plan_contacts, foot_force, foot_pos_abs, root_pos_z, pitch_d, counter_per_swing=120.0,
+                         foot_force_low=30.0, use_terrain_adapt=1):
+    """S/A1RobotControl.cpp:256-282, 566-582, 335-376 for one robot and one tick; state is updated in place.
+    returns (contacts, foot_pos_recent_contact, terrain_angle, root_euler_d_pitch)"""
+    a = lambda v: _p(np.ascontiguousarray(v, dtype=np.float64))
+    pc = np.ascontiguousarray(plan_contacts, dtype=np.uint8); ct = np.zeros(4, np.uint8); rec = np.zeros(12)
+    ang = C.c_double(0.0); pd = C.c_double(float(pitch_d))
+    lib().orc_contact_terrain_step(C.c_double(counter_per_swing), C.c_double(foot_force_low), C.c_int(int(use_terrain_adapt)), _p(state),
+                                   a(gait_counter), _p(pc, C.c_uint8), a(foot_force), a(foot_pos_abs), C.c_double(float(root_pos_z)),
+                                   _p(ct, C.c_uint8), _p(rec), C.byref(ang), C.byref(pd))
+    return ct, rec, ang.value, pd.value
+
+
 def num_threads():
     return lib().orc_num_threads()

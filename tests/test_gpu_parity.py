@@ -336,3 +336,34 @@ def test_random_batches_statistics(pkg, oracle, scen):
         assert np.median(d) < 1e-10 and np.percentile(d, 99.9) < 1e-5 and d.max() < TOL_FORCE_ANY_BATCH_N, (seed, np.median(d), d.max())
         worst = max(worst, d.max())
     assert worst < TOL_FORCE_ANY_BATCH_N
+
+
+def test_contact_terrain_N2b_sequence(pkg, oracle, scen):
+    """150 ticks of contact logic + moving-window filters + plane fit + terrain pitch for 300 robots, device-resident
+    filter state vs the oracle's per-robot state (S/A1RobotControl.cpp:256-282, 566-582, 335-376).  Contacts and the filtered contact
+    positions are bit-exact (same arithmetic, no contraction); the terrain angle goes through acos (device math library vs glibc)."""
+    rng = np.random.default_rng(21)
+    n, ticks = 300, 150
+    cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+    states = [oracle.contact_state() for _ in range(n)]
+    pitch_g = np.zeros(n); pitch_o = np.zeros(n)
+    base = np.outer([0.2, 0.2, -0.2, -0.2], [1.0, 0.0, 0.3]).reshape(12) + np.outer([1, -1, 1, -1], [0.0, 0.13, 0.0]).reshape(12)
+    gcs = rng.uniform(0, 240, (n, 4))
+    with pkg.Engine(cfg, n, 0) as eng:
+        for t in range(ticks):
+            gcs = np.fmod(gcs + 2.0, 240.0)
+            plan = (gcs <= 120).astype(np.uint8)
+            ff = rng.uniform(0, 80, (n, 4))
+            foot = base + rng.normal(0, 0.03, (n, 12)) + np.tile([0.0, 0.0, -0.3], 4)
+            z = np.where(rng.random(n) < 0.9, 0.3, 0.05)
+            out = eng.contact_terrain(gcs, plan, ff, foot, z, pitch_g)
+            pitch_g = out["root_euler_d_pitch"]
+            for b in range(0, n, 7):
+                ct, rec, ang, pitch_o[b] = oracle.contact_terrain_step(states[b], gcs[b], plan[b], ff[b], foot[b], z[b], pitch_o[b])
+                assert (out["contacts"][b] == ct).all() and (out["foot_pos_recent_contact"][b] == rec).all(), (t, b)
+                assert abs(out["terrain_angle"][b] - ang) <= 1e-13 and abs(pitch_g[b] - pitch_o[b]) <= 1e-13, (t, b)
+        eng.reset_contact_state()
+        out = eng.contact_terrain(gcs, plan, ff, foot, z, np.zeros(n))
+        fresh = oracle.contact_state()
+        ct, rec, ang, _ = oracle.contact_terrain_step(fresh, gcs[0], plan[0], ff[0], foot[0], z[0], 0.0)
+        assert (out["foot_pos_recent_contact"][0] == rec).all() and abs(out["terrain_angle"][0] - ang) <= 1e-13

@@ -143,3 +143,35 @@ def test_joint_torques_restatement(oracle):
             ref = Jb[i].T @ -grf[3 * i:3 * i + 3] if c[i] else np.linalg.solve(Jb[i], km * fk[3 * i:3 * i + 3])
             assert np.allclose(tau[3 * i:3 * i + 3], ref + tg[3 * i:3 * i + 3], rtol=1e-9, atol=1e-9)
     assert (oracle.joint_torques(0, c, Jcm, grf, fk, km, tg, np.ones(12)) == 0).all()
+
+
+def test_contact_terrain_restatement(oracle):
+    """N2b oracle: moving-window filters vs a plain deque mean, plane fit vs numpy's SVD pinv, early-contact / terrain rules"""
+    import collections
+    rng = np.random.default_rng(5)
+    st = oracle.contact_state()
+    dq = [collections.deque(maxlen=60) for _ in range(12)]; tq = collections.deque(maxlen=100)
+    rec_ref = np.zeros(12); early = np.zeros(4, bool); pitch = 0.0
+    for tick in range(400):
+        gc = rng.uniform(0, 240, 4); plan = (gc <= 120).astype(np.uint8); ff = rng.uniform(0, 80, 4)
+        foot = rng.normal(0, 0.05, 12) + np.tile([0.0, 0.0, -0.3 + 0.05 * np.sin(tick / 40)], 4) + np.outer([0.2, 0.2, -0.2, -0.2], [1.0, 0.0, 0.3]).reshape(12) \
+            + np.outer([1, -1, 1, -1], [0.0, 0.13, 0.0]).reshape(12)
+        z = 0.3 if tick % 50 else 0.05
+        ct, rec, ang, pitch = oracle.contact_terrain_step(st, gc, plan, ff, foot, z, pitch)
+        for i in range(4):
+            if gc[i] <= 180: early[i] = False
+            if (not plan[i]) and gc[i] > 180 and ff[i] > 30: early[i] = True
+            c = bool(plan[i]) or early[i]
+            assert ct[i] == c
+            if c:
+                for k in range(3):
+                    dq[3 * i + k].append(foot[3 * i + k]); rec_ref[3 * i + k] = sum(dq[3 * i + k]) / 60.0
+        assert np.allclose(rec, rec_ref, rtol=0, atol=1e-13)
+        W = np.stack([np.ones(4), rec_ref[0::3], rec_ref[1::3]], 1); a = np.linalg.pinv(W.T @ W) @ W.T @ rec_ref[2::3]
+        if z > 0.1:
+            tq.append(np.arccos(1.0 / np.sqrt(a[1] ** 2 + a[2] ** 2 + 1))); ang_ref = min(sum(tq) / 100.0, 0.5)
+        else:
+            ang_ref = 0.0
+        assert abs(ang - ang_ref) < 1e-9, (tick, ang, ang_ref)
+        fr = rec_ref[2] + rec_ref[5] - rec_ref[8] - rec_ref[11]
+        assert abs(pitch - (-ang_ref if fr > 0.05 else ang_ref)) < 1e-9
