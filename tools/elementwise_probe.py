@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""HBM roofline of the element-wise caller-side kernels (N2a update_plan, N3 joint torques, N2b contact/terrain) at 65536 robots:
+algorithmic bytes per robot / kernel time (HIP events inside the library, a1mpc_last_kernel_ms).  Prints one JSON line."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as g
+pkg = g.load_package(); scen = pkg.scenarios
+n = 65536
+rng = np.random.default_rng(0)
+cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+out = {}
+with pkg.Engine(cfg, n, 0) as eng:
+    yaw = rng.uniform(-3, 3, n); R = scen.rot_zyx(0 * yaw, 0 * yaw, yaw).reshape(n, 9)
+    args = ((rng.random(n) < 0.8).astype(np.uint8), rng.uniform(0, 240, (n, 4)), np.full((n, 4), 2.0), rng.normal(0, 0.5, (n, 3)), R, R, rng.normal(0, 1, (n, 3)), rng.normal(0, 0.5, (n, 3)))
+    ms = []
+    for _ in range(5):
+        eng.update_plan(*args); ms.append(eng.last_kernel_ms())
+    b = 8 * (4 + 4 + 3 + 9 + 9 + 3 + 3) + 1 + 8 * (4 + 36) + 4   # in + out per robot
+    out["N2a update_plan"] = {"kernel_ms": float(np.median(ms[1:])), "bytes_per_robot": b, "GB_per_s": n * b / (float(np.median(ms[1:])) * 1e-3) / 1e9}
+    Jb = rng.normal(0, 0.2, (n, 36)); Jb[:, [0, 4, 8, 9, 13, 17, 18, 22, 26, 27, 31, 35]] += 0.3
+    a3 = (np.ones(n, np.uint8), (rng.random((n, 4)) < 0.5).astype(np.uint8), Jb, rng.normal(0, 40, (n, 12)), rng.normal(0, 20, (n, 12)), np.array([0.1, 0.1, 0.04]),
+          rng.normal(0, 1, (n, 12)), np.zeros((n, 12)))
+    ms = []
+    for _ in range(5):
+        eng.joint_torques(*a3); ms.append(eng.last_kernel_ms())
+    b = 8 * (36 + 12 + 12 + 12 + 12) + 5 + 8 * 12
+    out["N3 joint_torques"] = {"kernel_ms": float(np.median(ms[1:])), "bytes_per_robot": b, "GB_per_s": n * b / (float(np.median(ms[1:])) * 1e-3) / 1e9}
+    ms = []
+    gcs = rng.uniform(0, 240, (n, 4)); pitch = np.zeros(n)
+    for t in range(70):
+        gcs = np.fmod(gcs + 2.0, 240.0)
+        o = eng.contact_terrain(gcs, (gcs <= 120).astype(np.uint8), rng.uniform(0, 80, (n, 4)), rng.normal(0, 0.2, (n, 12)), np.full(n, 0.3), pitch); pitch = o["root_euler_d_pitch"]
+        ms.append(eng.last_kernel_ms())
+    # per tick and robot: inputs 4+4+12+1+1 doubles + 4 bytes, outputs 12+1+1 doubles + 4 bytes, state: 4 header doubles r/w + 1 ring slot r/w per active filter (~7 of 13) + early/recent
+    b = 8 * 22 + 4 + 8 * 14 + 4 + 7 * (8 * 8 + 16) + 8 * 16 * 2
+    out["N2b contact_terrain (both kernels, steady state: full windows)"] = {"kernel_ms": float(np.median(ms[-5:])), "bytes_per_robot": b, "GB_per_s": n * b / (float(np.median(ms[-5:])) * 1e-3) / 1e9}
+print(json.dumps({"robots": n, "peak_GB_per_s": 8000, "kernels": out}))
