@@ -105,6 +105,8 @@ A1_DEV double dot_bc(const double (&m)[N], double x, double init = 0.0) {
     });
     return a0 + a1;
 }
+// below this rho the dual residual at a checkpoint is dominated by the x-update's backward error unless c P x + c g is carried (RowSolver::careful)
+constexpr double kRhoCareful = 1e-3;
 constexpr int alpha_diag(int s, int H) {  // sum_{i=s}^{H-1} (i-s)^2
     int a = 0;
     for (int i = s; i < H; ++i) a += (i - s) * (i - s);
@@ -140,6 +142,7 @@ struct Layout {
     static constexpr int S_SZ = 78;          // packed lower triangle of S_t^{-1}
     static constexpr int SLOT = K_SZ + S_SZ; // 234 doubles per horizon step
     static constexpr int FAC = 0;
+    static constexpr int GCOL = 12;          // the pad column of K_t's stride-13 rows carries G_t = (c P x + c g)_t, see RowSolver::careful
     static constexpr int BL = H * SLOT;      // B~ (6x12): rows 0-2 = dt*Iw^-1*skew(r), rows 3-5 = dt/m*I
     static constexpr int ZROW = 6;           // a seventh, all-zero row of B~: the row of every lane that owns no wrench state
     static constexpr int CG = BL + 84;       // c*g = D^-1 q_s, [t][12]
@@ -163,7 +166,7 @@ struct Layout {
 // LDS image of the set-up kernel (formation + Ruiz only: no factor): 348 doubles per QP at H = 10
 template <int H>
 struct LayoutSetup {
-    static constexpr int KSTR = 13, K_SZ = 12 * KSTR, S_SZ = 78, SLOT = K_SZ + S_SZ, FAC = 0;  // unused by the set-up code paths
+    static constexpr int KSTR = 13, K_SZ = 12 * KSTR, S_SZ = 78, SLOT = K_SZ + S_SZ, FAC = 0, GCOL = 12;  // unused by the set-up code paths
     static constexpr int TBL = 0;
     static constexpr int DL = 36;
     static constexpr int BL = DL + 12 * H;
@@ -221,6 +224,7 @@ struct RowSolver {
     double xh[H], wh0[H], wh1[H], rr0[H], rr1[H], dI2[H];
     double rho;
     bool warm, first_special;
+    bool careful;  // rho is small: c P x + c g is carried through the x-update identity (G in LDS) instead of re-evaluated at the checkpoints
     const double* warm_y_in;
     // bookkeeping
     int iter, nfact;
@@ -245,7 +249,7 @@ struct RowSolver {
         r2a = act ? P.r2[ci] : 0.0;      // force-lane weight 2 r_a
         r0 = comp == 0 ? 0 : (comp == 1 ? 2 : 4); r1 = comp == 0 ? 1 : 3;
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false;
-        warm = false; first_special = false; warm_y_in = nullptr; eqmask = 0;
+        warm = false; first_special = false; warm_y_in = nullptr; eqmask = 0; careful = false;
     }
 
     // A_d = I + dt*A_c and its transpose as row operators on a state-layout vector (T = A_c(0:3,6:9), S/ConvexMpc.cpp:123-125)
@@ -535,7 +539,7 @@ struct RowSolver {
             if (act) lds[L::CG + t * 12 + ci] = csc * g[t];          // D^-1 q_s = c g
         });
         row_sync();
-        iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false;
+        iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false; careful = false;
     }
 
     // ================================================================================ hand-off between the two kernels
@@ -584,7 +588,7 @@ struct RowSolver {
         eqmask = act ? static_cast<unsigned>(p[PR::EQ * 12 + ci]) : 0u;
         warm_y_in = io.warm_y;
         row_sync();
-        iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false;
+        iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false; careful = false;
     }
 
     // ================================================================================ Riccati factorisation of
@@ -601,8 +605,8 @@ struct RowSolver {
             const double base = csc * r2a + sigma_f * dI2[T];
             const double wd = comp == 2 ? base + a0 + mu * mu * (spx + spy) : base + sp;
             const double wo = comp < 2 ? mu * (a0 - a1) : 0.0;
-            lds[L::FAC + T * L::SLOT + 2 * ln] = act ? wd : 0.0;
-            lds[L::FAC + T * L::SLOT + 2 * ln + 1] = wo;
+            lds[L::FAC + T * L::SLOT + L::K_SZ + 2 * ln] = act ? wd : 0.0;  // staged in the S area of the slot (the K area's pad column carries G)
+            lds[L::FAC + T * L::SLOT + L::K_SZ + 2 * ln + 1] = wo;
         });
         row_sync();
         double Pn[12];  // row of P_{t+1} (state layout); terminal value c Q
@@ -611,7 +615,7 @@ struct RowSolver {
 #pragma unroll 1
         for (int t = H - 1; t >= 0; --t) {
             double* slot = lds + L::FAC + t * L::SLOT;
-            const double wd = slot[2 * ln], wo = slot[2 * ln + 1];
+            const double wd = slot[L::K_SZ + 2 * ln], wo = slot[L::K_SZ + 2 * ln + 1];
             const double wox = quad_perm<0, 0, 0, 0>(wo), woy = quad_perm<1, 1, 1, 1>(wo);
             row_sync();  // everybody holds W_t before the slot is overwritten
             // G = A' P_{t+1}  (rows mixed across lanes), then GA = G A (columns, lane-local)
@@ -678,7 +682,7 @@ struct RowSolver {
             static_for<12>([&](auto B) {  // twelve independent accumulator chains
                 static_for<12>([&](auto A_) { fma_bcast<lane_of(A1_CV(B))>(Kt[A_], Ft[B], S[A_]); });
             });
-            if (act) {
+            if (act && t > 0) {  // K_0 is never used (x_0 = 0)
 #pragma unroll
                 for (int a = 0; a < 12; ++a) slot[a * L::KSTR + ci] = Kt[a];
             }
@@ -706,7 +710,7 @@ struct RowSolver {
     // sweeps; the right-hand side is formed inside the backward sweep and the x / w updates consume v_t inside the
     // forward sweep, so only d_t crosses between the sweeps.
     // FIRST: OSQP's iteration 1 starts from z0 = A x0 (not projected) and y0 (warm start).
-    template <bool FIRST>
+    template <bool FIRST, bool CAREFUL = false>
     A1_DEV void admm_iteration() {
         // Loop-invariant scalars are laundered through row_opaque() once per iteration: otherwise LICM hoists every
         // per-step product that only depends on them out of the ADMM loop and the register file overflows.
@@ -783,6 +787,12 @@ struct RowSolver {
             [[maybe_unused]] double xz_first = 0.0;
             if constexpr (FIRST) xz_first = quad_perm<2, 2, 2, 2>(xh[t]);  // reads x0 before the block overwrites xh
             const double xh_old = xh[t];
+            [[maybe_unused]] double gt0 = 0.0, gt1 = 0.0;  // CAREFUL: rr (2 Pi(w) - w) of the state BEFORE this iteration's update
+            if constexpr (CAREFUL) {
+                const double zp0 = min_f64(max_f64(wh0[t], lb0_l), ub0_l), zp1 = min_f64(wh1[t], 0.0);
+                gt0 = rr0[t] * fma(2.0, zp0, -wh0[t]);
+                gt1 = rr1[t] * fma(2.0, zp1, -wh1[t]);
+            }
             row_lds_landed();
             if constexpr (t == 0) {
                 v = row_dpp_ready(am * v);  // x_0 = 0
@@ -803,6 +813,17 @@ struct RowSolver {
             const double vz = quad_perm<2, 2, 2, 2>(v);
             const double av0 = fma(mux, vz, v);
             const double av1 = fma(-mux, vz, v);
+            if constexpr (CAREFUL) {
+                // the x-update identity  c P x~ + c g = sigma D^-2 (x_prev - x~) + A' [rr (2 z_prev - w_prev - z~)]  holds for an exact solve and has no
+                // cancellation; G <- alpha (c P x~ + c g) + (1 - alpha) G follows x <- alpha x~ + (1 - alpha) x_prev.  Carried only while rho is small.
+                const double d0 = fma(-rr0[t], av0, gt0), d1 = fma(-rr1[t], av1, gt1);
+                const double sdm = d0 - d1;
+                const double sdx = quad_perm<0, 0, 0, 0>(sdm), sdy = quad_perm<1, 1, 1, 1>(sdm);
+                const double atd = fma(muz, sdx + sdy, d0 + d1);
+                const double T = fma(sigma_l * dI2[t], xh_old - v, atd);
+                double* G = lds + L::FAC + t * L::SLOT + ci * L::KSTR + L::GCOL;
+                if (act) *G = fma(al, T, oma * *G);
+            }
             if constexpr (FIRST) {  // w1 = alpha z~ + (1 - alpha) z0 + y0 / rho,  z0 = A x0
                 const double xz = xz_first;
                 double yw0 = 0.0, yw1 = 0.0;
@@ -866,7 +887,13 @@ struct RowSolver {
             const double aty_u = comp == 2 ? fma(mu, smx + smy, w0) : w0 + w1;
             const double cgt = act ? lds[L::CG + t * 12 + ci] : 0.0;
             const double px_u = csc * Pu[t];        // = D^-1 (P_s x_s)
-            const double rd_u = px_u + cgt + aty_u;  // = D^-1 (P_s x_s + q_s + A_s' y_s)
+            // D^-1 (P_s x_s + q_s) : re-evaluated here, or -- while rho is small and the re-evaluation would mostly measure the backward error
+            // of the Riccati solves -- the value carried through the x-update identity by the iterations (G, in the unused K_0 slot)
+            double* G = lds + L::FAC + t * L::SLOT + ci * L::KSTR + L::GCOL;
+            double pq_u = px_u + cgt;
+            if (careful) pq_u = act ? *G : 0.0;
+            else if (act) *G = pq_u;
+            const double rd_u = pq_u + aty_u;        // = D^-1 (P_s x_s + q_s + A_s' y_s)
             const double D2 = one_c / dI2[t];        // D^2
             m_udua = max_f64(m_udua, fabs(rd_u));
             m_dua = max_f64(m_dua, D2 * (rd_u * rd_u));
@@ -915,7 +942,12 @@ struct RowSolver {
             if (P.check_every > 0) next = imin(next, (iter / P.check_every + 1) * P.check_every);
             if (P.adaptive_rho && P.adaptive_rho_every > 0) next = imin(next, (iter / P.adaptive_rho_every + 1) * P.adaptive_rho_every);
             if (iter == 0 && first_special) { admm_iteration<true>(); iter = 1; }
-            for (int k = iter; k < next; ++k) admm_iteration<false>();
+            // the rows of a wave share one instruction stream: if any of them carries G, all run that variant (a harmless extra for the others)
+            if (row_wave_any(careful)) {
+                for (int k = iter; k < next; ++k) admm_iteration<false, true>();
+            } else {
+                for (int k = iter; k < next; ++k) admm_iteration<false, false>();
+            }
             iter = next;
             const bool can_check = P.check_every > 0 && (iter % P.check_every) == 0;
             const bool do_rho = P.adaptive_rho && P.adaptive_rho_every > 0 && (iter % P.adaptive_rho_every) == 0;
@@ -940,6 +972,7 @@ struct RowSolver {
                         });
                         rho = rn;
                         need_factor = true;
+                        careful = rho <= kRhoCareful;  // G holds this checkpoint's evaluation (written by update_info above) or the carried value
                     }
                 }
                 if (last) {

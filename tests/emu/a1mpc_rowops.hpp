@@ -94,6 +94,7 @@ inline void row_lds_landed() {}
 inline double row_opaque(double v) { return v; }
 
 
+inline bool row_wave_any(bool p) { return p; }  // one row per emulated wave
 inline int row_atomic_inc(int* p) { return (*p)++; }
 
 }  // namespace a1mpc

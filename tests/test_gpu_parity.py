@@ -319,8 +319,8 @@ def test_queue_order_does_not_change_results(pkg, scen):
 
 def test_random_batches_statistics(pkg, oracle, scen):
     """Arbitrary random batches (seeds that no other test uses): identical iteration counts and statuses, and the stated distribution of
-    ||u_gpu - u_oracle||_inf -- median at rounding level, 99.9 % below 1e-5 N, every QP below OSQP's own eps_abs (DESIGN.md 5 explains the
-    rare 1e-5..2e-4 N outliers: rho estimates taken at rho = RHO_MIN)."""
+    ||u_gpu - u_oracle||_inf -- median at rounding level, 99.9 % below 1e-7 N, every QP below 1e-5 N.  These batches contain the QPs whose rho
+    estimate is taken at rho = RHO_MIN, where the dual residual must be carried through the x-update identity."""
     from helpers import TOL_FORCE_ANY_BATCH_N
     worst = 0.0
     for seed in (1002, 1003, 1007, 2024):
@@ -333,7 +333,7 @@ def test_random_batches_statistics(pkg, oracle, scen):
         ref = oracle.mpc_solve_batch(pr, oracle.default_settings(), sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
         d = np.abs(out["grf"].reshape(n, 12) - ref["grf"].reshape(n, 12)).max(1)
         assert (out["iters"].ravel() == ref["iters"].ravel()).mean() >= 0.999 and (out["status"].ravel() == ref["status"].ravel()).all()
-        assert np.median(d) < 1e-10 and np.percentile(d, 99.9) < 1e-5 and d.max() < TOL_FORCE_ANY_BATCH_N, (seed, np.median(d), d.max())
+        assert np.median(d) < 1e-10 and np.percentile(d, 99.9) < 1e-7 and d.max() < TOL_FORCE_ANY_BATCH_N, (seed, np.median(d), d.max())
         worst = max(worst, d.max())
     assert worst < TOL_FORCE_ANY_BATCH_N
 
