@@ -363,6 +363,9 @@ struct a1mpc_handle_s {
     // queue order of the next solve (longest-first by the previous solve's per-QP cost) -- see a1mpc_set_schedule
     int32_t *d_order = nullptr, *d_cost = nullptr;
     double* d_ct_state = nullptr;  // N2b filter state of every robot (allocated on first use)
+    // staging of the element-wise entry points (N2a, N2b, N3), allocated on first use: 64 / 40 doubles and 16 bytes per robot
+    double *d_aux_in = nullptr, *d_aux_out = nullptr;
+    uint8_t* d_aux_u8 = nullptr;
     int32_t hint_n = 0;  // batch size the order was built for (0 = none)
     int schedule = 1;    // 1 = history (default), 0 = index order
     // packed device blocks + pinned host mirrors of the host-pointer MPC entry (one copy each way per call)
@@ -504,6 +507,15 @@ __global__ __launch_bounds__(256) void a1mpc_terrain_kernel(const ContactArgs a)
     a.terrain_out[b] = terrain_angle;
 }
 
+static a1mpc_status ensure_aux(a1mpc_handle h) {
+    if (h->d_aux_in) return A1MPC_OK;
+    const size_t n = static_cast<size_t>(h->max_batch);
+    A1_HIP(hipMalloc(&h->d_aux_in, n * 64 * sizeof(double)));
+    A1_HIP(hipMalloc(&h->d_aux_out, n * 40 * sizeof(double)));
+    A1_HIP(hipMalloc(&h->d_aux_u8, n * 16));
+    return A1MPC_OK;
+}
+
 void a1mpc_default_contact_config(a1mpc_contact_config* c) {
     if (!c) return;
     c->counter_per_swing = 120.0; c->foot_force_low = 30.0; c->use_terrain_adapt = 1;
@@ -526,18 +538,18 @@ a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_con
         return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
     if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
     if (n == 0) return A1MPC_OK;
-    if (h->cfg.horizon < 3) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "contact/terrain staging needs a handle with horizon >= 3");
     A1_HIP(hipSetDevice(h->device));
+    if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
     const size_t N = n;
     hipStream_t s = h->stream;
     if (!h->d_ct_state) {
         A1_HIP(hipMalloc(&h->d_ct_state, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double)));
         A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double), s));
     }
-    // staging inside the handle's MPC buffers: d_xref [gc 4 | ff 4 | foot 12 | z 1 | pitch 1] (22 <= 13 H), d_u [recent 12 | terrain 1]
-    double *d_gc = h->d_xref, *d_ff = d_gc + 4 * N, *d_fp = d_ff + 4 * N, *d_z = d_fp + 12 * N, *d_pd = d_z + N;
-    double *d_rec = h->d_u, *d_ta = d_rec + 12 * N;
-    uint8_t *d_pc = h->d_contact, *d_ct = reinterpret_cast<uint8_t*>(h->d_iters);
+    // staging: in [gc 4 | ff 4 | foot 12 | z 1 | pitch 1], out [recent 12 | terrain 1]
+    double *d_gc = h->d_aux_in, *d_ff = d_gc + 4 * N, *d_fp = d_ff + 4 * N, *d_z = d_fp + 12 * N, *d_pd = d_z + N;
+    double *d_rec = h->d_aux_out, *d_ta = d_rec + 12 * N;
+    uint8_t *d_pc = h->d_aux_u8, *d_ct = h->d_aux_u8 + 8 * N;
     A1_HIP(hipMemcpyAsync(d_gc, gait_counter, N * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(d_ff, foot_force, N * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(d_fp, foot_pos_abs, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
@@ -558,6 +570,102 @@ a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_con
     A1_HIP(hipMemcpyAsync(foot_pos_recent_contact_out, d_rec, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(terrain_angle_out, d_ta, N * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(root_euler_d_pitch, d_pd, N * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipStreamSynchronize(s));
+    return A1MPC_OK;
+}
+
+// ---- N4a: swing-leg targets + foot PD force (S/A1RobotControl.cpp:204-254, Bezier: S/utils/Utils.cpp:64-104), one lane per (robot, leg) ------
+struct SwingArgs {
+    int32_t n;
+    double counter_per_swing, dt, kp[3], kd[3];
+    const double *Rz, *foot_pos_abs, *gait_counter, *target_rel;
+    double *start, *rel_last, *target_last, *cur_out, *kin_out;
+};
+__global__ __launch_bounds__(256) void a1mpc_swing_kernel(const SwingArgs a) {
+#pragma clang fp contract(off)
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t b = gid >> 2;
+    const int i = static_cast<int>(gid & 3);
+    if (b >= a.n) return;
+    const double* Rz = a.Rz + b * 9;
+    const double* fa = a.foot_pos_abs + b * 12 + 3 * i;
+    const int64_t o = b * 12 + 3 * i;
+    double cur[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cur[r] = Rz[0 * 3 + r] * fa[0] + Rz[1 * 3 + r] * fa[1] + Rz[2 * 3 + r] * fa[2];   // :224
+    const double gc = a.gait_counter[b * 4 + i];
+    float spline_time = 0.0f;
+    double st[3];
+    if (gc <= a.counter_per_swing) {                                                                                  // :227-232
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { st[r] = cur[r]; a.start[o + r] = cur[r]; }
+    } else {                                                                                                          // :233-236
+        spline_time = static_cast<float>(gc - a.counter_per_swing) / static_cast<float>(a.counter_per_swing);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) st[r] = a.start[o + r];
+    }
+    const double t = spline_time, u = 1 - t;
+    const double t2 = t * t, t3 = t2 * t, t4 = t2 * t2, u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double fin = a.target_rel[o + r];
+        double P1 = st[r], P2 = fin;
+        if (r == 2) { P1 += 0.0f; P2 += 0.4f + 0.5 * 0.0; }                                                           // FOOT_SWING_CLEARANCE1 / 2
+        double y = 0;                                                                                                 // Utils.cpp:97-104
+        y += 1.0 * 1.0 * u4 * st[r];
+        y += 4.0 * t * u3 * P1;
+        y += 6.0 * t2 * u2 * P2;
+        y += 4.0 * t3 * u * fin;
+        y += 1.0 * t4 * 1.0 * fin;
+        const double vel_cur = (cur[r] - a.rel_last[o + r]) / a.dt;                                                   // :243-252
+        a.rel_last[o + r] = cur[r];
+        const double vel_tgt = (y - a.target_last[o + r]) / a.dt;
+        a.target_last[o + r] = y;
+        a.kin_out[o + r] = (y - cur[r]) * a.kp[r] + (vel_tgt - vel_cur) * a.kd[r];
+        a.cur_out[o + r] = cur[r];
+    }
+}
+
+a1mpc_status a1mpc_swing_legs_batch(a1mpc_handle h, int32_t n, double counter_per_swing, double dt, const double* R_z,
+                                    const double* foot_pos_abs, const double* gait_counter, const double* foot_pos_target_rel,
+                                    const double* kp_foot, const double* kd_foot, double* foot_pos_start, double* foot_pos_rel_last_time,
+                                    double* foot_pos_target_last_time, double* foot_pos_cur_out, double* foot_forces_kin_out) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !R_z || !foot_pos_abs || !gait_counter || !foot_pos_target_rel || !kp_foot || !kd_foot || !foot_pos_start || !foot_pos_rel_last_time ||
+        !foot_pos_target_last_time || !foot_pos_cur_out || !foot_forces_kin_out || !(dt > 0))
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer or dt <= 0");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
+    const size_t N = n;
+    hipStream_t s = h->stream;
+    // staging: in [Rz 9 | foot 12 | gc 4 | target_rel 12] = 37, in/out + out [start 12 | rel_last 12 | target_last 12] (aux_in tail, 36) and [cur 12 | kin 12]
+    double *d_Rz = h->d_aux_in, *d_fa = d_Rz + 9 * N, *d_gc = d_fa + 12 * N, *d_tr = d_gc + 4 * N;
+    double *d_st = h->d_aux_out, *d_rl = d_st + 12 * N, *d_tl = d_rl + 12 * N;
+    double *d_cur = d_tr + 12 * N, *d_kin = d_cur + 12 * N;   // aux_in has 64 doubles per robot: 37 + 24 = 61
+    A1_HIP(hipMemcpyAsync(d_Rz, R_z, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_fa, foot_pos_abs, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_gc, gait_counter, N * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_tr, foot_pos_target_rel, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_st, foot_pos_start, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_rl, foot_pos_rel_last_time, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_tl, foot_pos_target_last_time, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    SwingArgs a;
+    a.n = n; a.counter_per_swing = counter_per_swing; a.dt = dt;
+    for (int k = 0; k < 3; ++k) { a.kp[k] = kp_foot[k]; a.kd[k] = kd_foot[k]; }
+    a.Rz = d_Rz; a.foot_pos_abs = d_fa; a.gait_counter = d_gc; a.target_rel = d_tr; a.start = d_st; a.rel_last = d_rl; a.target_last = d_tl;
+    a.cur_out = d_cur; a.kin_out = d_kin;
+    A1_HIP(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(a1mpc_swing_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    A1_HIP(hipGetLastError());
+    A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = true; h->last_stream = s;
+    A1_HIP(hipMemcpyAsync(foot_pos_start, d_st, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipMemcpyAsync(foot_pos_rel_last_time, d_rl, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipMemcpyAsync(foot_pos_target_last_time, d_tl, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipMemcpyAsync(foot_pos_cur_out, d_cur, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipMemcpyAsync(foot_forces_kin_out, d_kin, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipStreamSynchronize(s));
     return A1MPC_OK;
 }
@@ -634,13 +742,13 @@ a1mpc_status a1mpc_joint_torques_batch(a1mpc_handle h, int32_t n, const uint8_t*
         return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
     if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
     if (n == 0) return A1MPC_OK;
-    if (h->cfg.horizon < 6) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "joint-torque staging needs a handle with horizon >= 6");
     A1_HIP(hipSetDevice(h->device));
+    if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
     const size_t N = n;
     hipStream_t s = h->stream;
-    // staging inside the handle's MPC buffers: d_xref [J 36 | grf 12 | f_kin 12] (60 <= 13 H), d_u [tg 12 | tau 12] (24 <= 12 H)
-    double *d_J = h->d_xref, *d_grf = d_J + 36 * N, *d_fk = d_grf + 12 * N, *d_tg = h->d_u, *d_tau = d_tg + 12 * N;
-    uint8_t *d_c = h->d_contact, *d_act = reinterpret_cast<uint8_t*>(h->d_iters);
+    // staging: in [J 36 | grf 12 | f_kin 12], out [tg 12 | tau 12]
+    double *d_J = h->d_aux_in, *d_grf = d_J + 36 * N, *d_fk = d_grf + 12 * N, *d_tg = h->d_aux_out, *d_tau = d_tg + 12 * N;
+    uint8_t *d_c = h->d_aux_u8, *d_act = h->d_aux_u8 + 8 * N;
     A1_HIP(hipMemcpyAsync(d_J, j_foot_blocks, N * 36 * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(d_grf, grf, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(d_fk, f_kin, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
@@ -684,16 +792,14 @@ a1mpc_status a1mpc_update_plan_batch(a1mpc_handle h, const a1mpc_gait_config* ga
     if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
     if (n == 0) return A1MPC_OK;
     A1_HIP(hipSetDevice(h->device));
+    if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
     const size_t N = n;
     hipStream_t s = h->stream;
-    // staging inside the MPC buffers of the handle (sized for max_batch): in  = d_xref [gc 4 | spd 4 | v 3 | vd 3 | pos 3 | Rz 9 | Rw 9] (35 <= 13H for H >= 3),
-    //                                                                  out = d_u    [rel 12 | abs 12 | world 12] (36 <= 12H for H >= 3)
-    if (h->cfg.horizon < 3) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "update_plan staging needs a handle with horizon >= 3");
-    double* din = h->d_xref;
+    // staging: in [gc 4 | spd 4 | v 3 | vd 3 | pos 3 | Rz 9 | Rw 9], out [rel 12 | abs 12 | world 12]
+    double* din = h->d_aux_in;
     double *d_gc = din, *d_spd = d_gc + 4 * N, *d_v = d_spd + 4 * N, *d_vd = d_v + 3 * N, *d_pos = d_vd + 3 * N, *d_Rz = d_pos + 3 * N, *d_Rw = d_Rz + 9 * N;
-    double *d_rel = h->d_u, *d_abs = d_rel + 12 * N, *d_world = d_abs + 12 * N;
-    uint8_t* d_mm = h->d_contact;                       // n bytes of the 4n
-    uint8_t* d_pc = reinterpret_cast<uint8_t*>(h->d_iters);  // 4n bytes
+    double *d_rel = h->d_aux_out, *d_abs = d_rel + 12 * N, *d_world = d_abs + 12 * N;
+    uint8_t *d_mm = h->d_aux_u8, *d_pc = h->d_aux_u8 + 8 * N;
     A1_HIP(hipMemcpyAsync(d_gc, gait_counter, N * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(d_spd, gait_counter_speed, N * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(d_v, root_lin_vel, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
@@ -736,7 +842,7 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_tab, h->d_tab1, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_aux, h->d_Rz, h->d_contact, h->d_grf,
-                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state};
+                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);

@@ -40,7 +40,7 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
     _fields_ = [("counter_per_swing", C.c_double), ("foot_force_low", C.c_double), ("use_terrain_adapt", C.c_int32)]
 
 
-EXPORTS = ["a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
+EXPORTS = ["a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
 
@@ -80,6 +80,8 @@ def load_library(path=None):
     lib.a1mpc_contact_terrain_batch.argtypes = [vp, C.POINTER(ContactConfig), i32, dp, u8p, dp, dp, dp, dp, u8p, dp, dp]
     lib.a1mpc_contact_terrain_batch.restype = C.c_int
     lib.a1mpc_reset_contact_state.argtypes = [vp]; lib.a1mpc_reset_contact_state.restype = C.c_int
+    lib.a1mpc_swing_legs_batch.argtypes = [vp, i32, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp]
+    lib.a1mpc_swing_legs_batch.restype = C.c_int
     lib.a1mpc_set_schedule.argtypes = [vp, i32]; lib.a1mpc_set_schedule.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
     lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int
@@ -240,6 +242,19 @@ class Engine:
         rc = self.lib.a1mpc_contact_terrain_batch(self._h, C.byref(cfg), n, _dp(gc), u8(pc), _dp(ff), _dp(fp), _dp(z), _dp(pd), u8(ct), _dp(rec), _dp(ta))
         _check(self.lib, rc, "a1mpc_contact_terrain_batch")
         return dict(contacts=ct, foot_pos_recent_contact=rec, terrain_angle=ta, root_euler_d_pitch=pd)
+
+    # ---- N4a: swing-leg targets + foot PD force (S/A1RobotControl.cpp:204-254); the three state arrays are updated in place ----
+    def swing_legs(self, Rz, foot_pos_abs, gait_counter, foot_pos_target_rel, foot_pos_start, rel_last, target_last, kp=(300.0, 400.0, 400.0),
+                   kd=(8.0, 8.0, 8.0), counter_per_swing=120.0, dt=0.0025):
+        n = foot_pos_start.shape[0]
+        for st in (foot_pos_start, rel_last, target_last):
+            assert st.dtype == np.float64 and st.flags["C_CONTIGUOUS"] and st.shape == (n, 12)
+        Rz = _f64(Rz, (n, 9)); fa = _f64(foot_pos_abs, (n, 12)); gc = _f64(gait_counter, (n, 4)); tr = _f64(foot_pos_target_rel, (n, 12))
+        kp = _f64(kp, (3,)); kd = _f64(kd, (3,)); cur = np.zeros((n, 12)); kin = np.zeros((n, 12))
+        rc = self.lib.a1mpc_swing_legs_batch(self._h, n, counter_per_swing, dt, _dp(Rz), _dp(fa), _dp(gc), _dp(tr), _dp(kp), _dp(kd), _dp(foot_pos_start),
+                                             _dp(rel_last), _dp(target_last), _dp(cur), _dp(kin))
+        _check(self.lib, rc, "a1mpc_swing_legs_batch")
+        return cur, kin
 
     def reset_contact_state(self):
         _check(self.lib, self.lib.a1mpc_reset_contact_state(self._h), "a1mpc_reset_contact_state")

@@ -209,6 +209,19 @@ a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_con
                                          double* foot_pos_recent_contact_out, double* terrain_angle_out);
 a1mpc_status a1mpc_reset_contact_state(a1mpc_handle h);
 
+/*
+ * N4a (caller side): swing-leg targets and the foot PD force -- the first block of generate_swing_legs_ctrl,
+ * S/A1RobotControl.cpp:204-254, with the Bezier curve of S/utils/Utils.cpp:64-104 -- for n robots.
+ *   R_z n x 9 (root_rot_mat_z), foot_pos_abs / foot_pos_target_rel n x 12, gait_counter n x 4, kp_foot / kd_foot 3 (per axis)
+ *   foot_pos_start, foot_pos_rel_last_time, foot_pos_target_last_time n x 12  in/out (state carried by the caller)
+ * out: foot_pos_cur n x 12, foot_forces_kin n x 12.  Host pointers.  Integer powers of the curve are products here (std::pow there):
+ * agreement to a few ulp, everything else bit-identical arithmetic.
+ */
+a1mpc_status a1mpc_swing_legs_batch(a1mpc_handle h, int32_t n, double counter_per_swing, double dt, const double* R_z,
+                                    const double* foot_pos_abs, const double* gait_counter, const double* foot_pos_target_rel,
+                                    const double* kp_foot, const double* kd_foot, double* foot_pos_start, double* foot_pos_rel_last_time,
+                                    double* foot_pos_target_last_time, double* foot_pos_cur_out, double* foot_forces_kin_out);
+
 /* Work-queue order of batches larger than the resident set: history = 1 (default) issues the QPs longest-first by the cost
  * (iterations + factor passes) each one had in the previous solve of this handle with the same n -- the same robots tick after
  * tick; history = 0 is plain index order.  The first solve of a batch size, and the solve after a1mpc_reset_warm_start, run in

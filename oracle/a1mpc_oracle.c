@@ -861,6 +861,48 @@ void orc_contact_terrain_step(double counter_per_swing, double foot_force_low, i
 }
 int orc_contact_state_doubles(void) { return ORC_CT_STATE; }
 
+/* ---- N4a: swing-leg targets and the foot PD force, the first block of generate_swing_legs_ctrl (S/A1RobotControl.cpp:204-254) with
+ * BezierUtils::get_foot_pos_curve / bezier_curve (S/utils/Utils.cpp:64-104; FOOT_SWING_CLEARANCE1/2 = 0.0f / 0.4f, S/A1Params.h:41-42).
+ * In/out per robot: foot_pos_start, foot_pos_rel_last_time, foot_pos_target_last_time (3x4 column-major each). */
+static double bezier_curve4(double t, const double *P) {                           /* Utils.cpp:97-104 */
+    static const double coefficients[5] = {1, 4, 6, 4, 1};
+    const float bezier_degree = 4;                                                 /* Utils.h:29,42 */
+    double y = 0;
+    for (int i = 0; i <= bezier_degree; i++) y += coefficients[i] * pow(t, i) * pow(1 - t, bezier_degree - i) * P[i];
+    return y;
+}
+void orc_swing_legs(double counter_per_swing, double dt, const double *Rz, const double *foot_pos_abs, const double *gait_counter,
+                    const double *foot_pos_target_rel, const double *kp_foot, const double *kd_foot, double *foot_pos_start,
+                    double *foot_pos_rel_last_time, double *foot_pos_target_last_time, double *foot_pos_cur_out, double *foot_forces_kin) {
+    for (int i = 0; i < NLEG; ++i) {
+        double cur[3], tgt[3];
+        for (int r = 0; r < 3; ++r)                                                /* :224  Rz' * foot_pos_abs */
+            cur[r] = Rz[0 * 3 + r] * foot_pos_abs[3 * i + 0] + Rz[1 * 3 + r] * foot_pos_abs[3 * i + 1] + Rz[2 * 3 + r] * foot_pos_abs[3 * i + 2];
+        float spline_time = 0.0f;
+        if (gait_counter[i] <= counter_per_swing) {                               /* :227-232 stance: keep refreshing the start point */
+            for (int r = 0; r < 3; ++r) foot_pos_start[3 * i + r] = cur[r];
+        } else {                                                                   /* :233-236 */
+            spline_time = (float)(gait_counter[i] - counter_per_swing) / (float)counter_per_swing;
+        }
+        for (int r = 0; r < 3; ++r) {                                              /* get_foot_pos_curve, terrain_pitch_angle = 0.0 (:238-241) */
+            double P[5] = {foot_pos_start[3 * i + r], foot_pos_start[3 * i + r], foot_pos_target_rel[3 * i + r], foot_pos_target_rel[3 * i + r],
+                           foot_pos_target_rel[3 * i + r]};
+            if (r == 2) { P[1] += 0.0f; P[2] += 0.4f + 0.5 * sin(0.0); }
+            tgt[r] = bezier_curve4(spline_time, P);
+        }
+        for (int r = 0; r < 3; ++r) {                                              /* :243-252 */
+            const int k = 3 * i + r;
+            const double vel_cur = (cur[r] - foot_pos_rel_last_time[k]) / dt;
+            foot_pos_rel_last_time[k] = cur[r];
+            const double vel_tgt = (tgt[r] - foot_pos_target_last_time[k]) / dt;
+            foot_pos_target_last_time[k] = tgt[r];
+            const double pos_err = tgt[r] - cur[r], vel_err = vel_tgt - vel_cur;
+            foot_forces_kin[k] = pos_err * kp_foot[r] + vel_err * kd_foot[r];
+            foot_pos_cur_out[k] = cur[r];
+        }
+    }
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -260,5 +260,15 @@ def contact_terrain_step(state, gait_counter, plan_contacts, foot_force, foot_po
     return ct, rec, ang.value, pd.value
 
 
+def swing_legs(Rz, foot_pos_abs, gait_counter, foot_pos_target_rel, foot_pos_start, rel_last, target_last, kp=(300.0, 400.0, 400.0),
+               kd=(8.0, 8.0, 8.0), counter_per_swing=120.0, dt=0.0025):
+    """S/A1RobotControl.cpp:204-254 for one robot; the three state arrays are updated in place.  returns (foot_pos_cur, foot_forces_kin)"""
+    a = lambda v: _p(np.ascontiguousarray(v, dtype=np.float64))
+    cur = np.zeros(12); kin = np.zeros(12)
+    lib().orc_swing_legs(C.c_double(counter_per_swing), C.c_double(dt), a(Rz), a(foot_pos_abs), a(gait_counter), a(foot_pos_target_rel), a(kp), a(kd),
+                         _p(foot_pos_start), _p(rel_last), _p(target_last), _p(cur), _p(kin))
+    return cur, kin
+
+
 def num_threads():
     return lib().orc_num_threads()

@@ -7,6 +7,7 @@ import numpy as np
 TOL_FORCE_N = 1e-5          # ||u_gpu - u_oracle||_inf, same settings, same iteration count; observed over 8 x 4096 random QPs: median 1.5e-12,
                             # 99.9 % < 5e-9, worst 1.4e-6 N (most of the worst-case gap is the double-precision oracle's own rounding: DESIGN.md 5)
 TOL_FORCE_ANY_BATCH_N = 1e-5   # the same bound for arbitrary random batches (seeds no other test uses)
+TOL_FORCE_BALANCE_N = 2e-4  # balance QP: P = 1e-3 I + M'QM, cond ~ 1e6 -- round-off is amplified more (observed <= 2e-5 N)
 MIN_SAME_ITERS = 0.995      # fraction of problems that must stop at the oracle's iteration (a termination test that
                             # lands within round-off of its threshold may flip; those problems are compared through
                             # the oracle's own default-vs-exact slack instead)

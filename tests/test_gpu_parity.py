@@ -367,3 +367,25 @@ def test_contact_terrain_N2b_sequence(pkg, oracle, scen):
         fresh = oracle.contact_state()
         ct, rec, ang, _ = oracle.contact_terrain_step(fresh, gcs[0], plan[0], ff[0], foot[0], z[0], 0.0)
         assert (out["foot_pos_recent_contact"][0] == rec).all() and abs(out["terrain_angle"][0] - ang) <= 1e-13
+
+
+def test_swing_legs_N4a_sequence(pkg, oracle, scen):
+    """swing-leg Bezier targets + foot PD force over 60 ticks for 500 robots (S/A1RobotControl.cpp:204-254).  The carried
+    state and foot_pos_cur are bit-exact; the curve uses products for the integer powers (std::pow in the reference): a few ulp."""
+    rng = np.random.default_rng(31)
+    n, ticks = 500, 60
+    cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+    st_g = [np.zeros((n, 12)) for _ in range(3)]; st_o = [np.zeros((n, 12)) for _ in range(3)]
+    gcs = rng.uniform(0, 240, (n, 4))
+    base = np.array([0.17, 0.15, -0.3, 0.17, -0.15, -0.3, -0.17, 0.15, -0.3, -0.17, -0.15, -0.3])
+    with pkg.Engine(cfg, n, 0) as eng:
+        for t in range(ticks):
+            gcs = np.fmod(gcs + 2.0, 240.0)
+            yaw = rng.uniform(-3, 3, n); Rz = scen.rot_zyx(0 * yaw, 0 * yaw, yaw).reshape(n, 9)
+            foot = base + rng.normal(0, 0.03, (n, 12)); tgt = base + rng.normal(0, 0.05, (n, 12))
+            cur, kin = eng.swing_legs(Rz, foot, gcs, tgt, *st_g)
+            for b in range(0, n, 11):
+                c_o, k_o = oracle.swing_legs(Rz[b], foot[b], gcs[b], tgt[b], st_o[0][b], st_o[1][b], st_o[2][b])
+                assert (cur[b] == c_o).all() and (st_g[0][b] == st_o[0][b]).all() and (st_g[1][b] == st_o[1][b]).all(), (t, b)
+                assert np.abs(st_g[2][b] - st_o[2][b]).max() <= 1e-15 and np.abs(kin[b] - k_o).max() <= 1e-9, (t, b, np.abs(kin[b] - k_o).max())
+                st_o[2][b] = st_g[2][b]  # keep the two state copies from drifting apart by the curve's ulp differences

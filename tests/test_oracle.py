@@ -175,3 +175,19 @@ def test_contact_terrain_restatement(oracle):
         assert abs(ang - ang_ref) < 1e-9, (tick, ang, ang_ref)
         fr = rec_ref[2] + rec_ref[5] - rec_ref[8] - rec_ref[11]
         assert abs(pitch - (-ang_ref if fr > 0.05 else ang_ref)) < 1e-9
+
+
+def test_swing_legs_restatement(oracle):
+    """N4a oracle: stance legs track their own position (zero position error, start point refreshed), swing legs follow the quartic
+    Bezier blend between start and target with 0.4 m * 6 t^2 (1-t)^2 of clearance, PD force = kp * pos error + kd * velocity error"""
+    Rz = np.eye(3).reshape(9)
+    foot = np.array([0.17, 0.15, -0.3, 0.17, -0.15, -0.3, -0.17, 0.15, -0.3, -0.17, -0.15, -0.3]); tgt = foot + np.tile([0.05, 0.0, 0.0], 4)
+    start = np.zeros(12); rl = foot.copy(); tl = foot.copy()
+    cur, kin = oracle.swing_legs(Rz, foot, [10, 10, 10, 10], tgt, start, rl, tl)
+    assert (cur == foot).all() and (start == foot).all() and np.allclose(kin, 0.0, atol=1e-9)
+    cur, kin = oracle.swing_legs(Rz, foot, [180, 10, 10, 180], tgt, start, rl, tl)   # legs 0, 3 at half swing: t = 0.5
+    t = 0.5
+    zc = 6 * t ** 2 * (1 - t) ** 2 * np.float32(0.4)
+    blend = 4 * t ** 3 * (1 - t) + t ** 4 + 6 * t ** 2 * (1 - t) ** 2
+    assert np.allclose(tl[0:3], [foot[0] + blend * 0.05, foot[1], foot[2] + zc], atol=1e-12)
+    assert np.allclose(kin[0], 300.0 * (tl[0] - foot[0]) + 8.0 * ((tl[0] - foot[0]) / 0.0025), rtol=1e-12)
