@@ -389,3 +389,52 @@ def test_swing_legs_N4a_sequence(pkg, oracle, scen):
                 assert (cur[b] == c_o).all() and (st_g[0][b] == st_o[0][b]).all() and (st_g[1][b] == st_o[1][b]).all(), (t, b)
                 assert np.abs(st_g[2][b] - st_o[2][b]).max() <= 1e-15 and np.abs(kin[b] - k_o).max() <= 1e-9, (t, b, np.abs(kin[b] - k_o).max())
                 st_o[2][b] = st_g[2][b]  # keep the two state copies from drifting apart by the curve's ulp differences
+
+
+def test_control_tick_chain(pkg, oracle, scen):
+    """The caller-side rows composed the way the reference's 400 Hz loop composes them (S/A1RobotControl.cpp: update_plan ->
+    generate_swing_legs_ctrl -> compute_grf [terrain pitch -> MPC] -> compute_joint_torques), 48 robots x 16 ticks with synthetic
+    sensor inputs, device entry points vs the oracle functions chained the same way: the joint torques at the end of every tick."""
+    rng = np.random.default_rng(77)
+    n, ticks, h = 48, 16, 10
+    P = scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS
+    cfg = pkg.make_config(P, h, warm_start=0)
+    pr = oracle.mpc_params(h, P["dt"], P["mu"], P["fz_min"], P["fz_max"], P["q"], P["r"], P["mass"], P["inertia"]); st = oracle.default_settings()
+    dfp = np.array([0.17, 0.15, -0.35, 0.17, -0.15, -0.35, -0.17, 0.15, -0.35, -0.17, -0.15, -0.35]); gp = oracle.gait_params(dfp)
+    km = np.array([0.1, 0.1, 0.04])
+    G = dict(gc=np.tile([0.0, 120.0, 120.0, 0.0], (n, 1)), start=np.zeros((n, 12)), rl=np.tile(dfp, (n, 1)), tl=np.tile(dfp, (n, 1)), pitch=np.zeros(n), tau=np.zeros((n, 12)))
+    O = dict(gc=G["gc"].copy(), start=np.zeros((n, 12)), rl=G["rl"].copy(), tl=G["tl"].copy(), pitch=np.zeros(n), tau=np.zeros((n, 12)),
+             ct=[oracle.contact_state() for _ in range(n)])
+    worst = 0.0
+    with pkg.Engine(cfg, n, 0) as eng:
+        for t in range(ticks):
+            # synthetic sensors of this tick
+            eul = rng.normal(0, 0.05, (n, 3)); eul[:, 2] = rng.uniform(-1, 1, n); pos = np.c_[rng.normal(0, 1, (n, 2)), 0.3 + rng.normal(0, 0.01, n)]
+            w = rng.normal(0, 0.3, (n, 3)); v = rng.normal(0, 0.3, (n, 3)); vd = np.c_[rng.uniform(-0.5, 0.5, (n, 2)), np.zeros(n)]; wd = np.c_[np.zeros((n, 2)), rng.uniform(-0.5, 0.5, n)]
+            R = scen.rot_zyx(eul[:, 0], eul[:, 1], eul[:, 2]).reshape(n, 9); Rz = scen.rot_zyx(0 * eul[:, 0], 0 * eul[:, 0], eul[:, 2]).reshape(n, 9)
+            foot_rel = dfp + rng.normal(0, 0.02, (n, 12))
+            foot_abs = np.einsum("nij,nlj->nli", R.reshape(n, 3, 3), foot_rel.reshape(n, 4, 3)).reshape(n, 12)
+            ff = rng.uniform(0, 80, (n, 4)); Jb = rng.normal(0, 0.2, (n, 36)); Jb[:, [0, 4, 8, 9, 13, 17, 18, 22, 26, 27, 31, 35]] += 0.3
+            tg = rng.normal(0, 0.5, (n, 12)); mm = np.ones(n, np.uint8); spd = np.full((n, 4), 2.0)
+            # ---- device chain
+            up = eng.update_plan(mm, G["gc"], spd, v, Rz, R, pos, vd); G["gc"] = up["gait_counter"]
+            cur, kin = eng.swing_legs(Rz, foot_abs, G["gc"], up["foot_pos_target_rel"], G["start"], G["rl"], G["tl"])
+            ctr = eng.contact_terrain(G["gc"], up["plan_contacts"], ff, foot_abs, pos[:, 2], G["pitch"]); G["pitch"] = ctr["root_euler_d_pitch"]
+            eul_d = np.c_[np.zeros(n), G["pitch"], eul[:, 2]]
+            tick = scen.pack_tick(eul, pos, w, v, eul_d, vd, wd, np.full(n, 0.3))
+            sol = eng.solve_ticks(tick, R, foot_abs, ctr["contacts"])
+            G["tau"] = eng.joint_torques(np.ones(n, np.uint8), ctr["contacts"], Jb, sol["grf"], kin, km, tg, G["tau"])
+            # ---- oracle chain
+            for b in range(n):
+                gc2, pc, rel, ab, wo = oracle.update_plan(gp, 1, O["gc"][b], spd[b], v[b], Rz[b], R[b], pos[b], vd[b]); O["gc"][b] = gc2
+                c_o, k_o = oracle.swing_legs(Rz[b], foot_abs[b], gc2, rel, O["start"][b], O["rl"][b], O["tl"][b])
+                ct, rec, ang, O["pitch"][b] = oracle.contact_terrain_step(O["ct"][b], gc2, pc, ff[b], foot_abs[b], pos[b, 2], O["pitch"][b])
+                ed = np.array([0.0, O["pitch"][b], eul[b, 2]])
+                xref = oracle.mpc_reference(h, P["dt"], eul[b], pos[b], R[b], ed, vd[b], wd[b], 0.3)
+                x0 = scen.pack_x0(eul[b:b + 1], pos[b:b + 1], w[b:b + 1], v[b:b + 1])[0]
+                grf = oracle.mpc_solve(pr, st, x0, xref, R[b], foot_abs[b], ct)["grf"]
+                O["tau"][b] = oracle.joint_torques(1, ct, Jb[b], grf, k_o, km, tg[b], O["tau"][b])
+                assert (ctr["contacts"][b] == ct).all() and (G["gc"][b] == gc2).all()
+            worst = max(worst, np.abs(G["tau"] - O["tau"]).max())
+            O["tl"][:] = G["tl"]  # the curve's ulp differences must not accumulate into the comparison (see test_swing_legs_N4a_sequence)
+    assert worst < 1e-5, worst
