@@ -109,10 +109,16 @@ def main():
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path for the solver)")
+    backend = os.environ.get("A1_BENCH_BACKEND", "nccl")  # "gloo" + A1_BENCH_SHARE_GPU=1: two ranks on ONE GPU, a smoke test of the N > 1 code path
+    if os.environ.get("A1_BENCH_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     pkg = graft.load_package()
     try:
         pkg.load_library()
@@ -156,7 +162,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps)])  # HIP events on the launch stream
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
