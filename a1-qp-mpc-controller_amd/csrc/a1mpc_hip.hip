@@ -363,7 +363,7 @@ struct a1mpc_handle_s {
     // queue order of the next solve (longest-first by the previous solve's per-QP cost) -- see a1mpc_set_schedule
     int32_t *d_order = nullptr, *d_cost = nullptr;
     double* d_ct_state = nullptr;  // N2b filter state of every robot (allocated on first use)
-    // staging of the element-wise entry points (N2a, N2b, N3), allocated on first use: 64 / 40 doubles and 16 bytes per robot
+    // staging of the element-wise entry points (N2a, N2b, N3), allocated on first use: 64 / 96 doubles and 16 bytes per robot
     double *d_aux_in = nullptr, *d_aux_out = nullptr;
     uint8_t* d_aux_u8 = nullptr;
     int32_t hint_n = 0;  // batch size the order was built for (0 = none)
@@ -511,7 +511,7 @@ static a1mpc_status ensure_aux(a1mpc_handle h) {
     if (h->d_aux_in) return A1MPC_OK;
     const size_t n = static_cast<size_t>(h->max_batch);
     A1_HIP(hipMalloc(&h->d_aux_in, n * 64 * sizeof(double)));
-    A1_HIP(hipMalloc(&h->d_aux_out, n * 40 * sizeof(double)));
+    A1_HIP(hipMalloc(&h->d_aux_out, n * 96 * sizeof(double)));
     A1_HIP(hipMalloc(&h->d_aux_u8, n * 16));
     return A1MPC_OK;
 }
@@ -666,6 +666,92 @@ a1mpc_status a1mpc_swing_legs_batch(a1mpc_handle h, int32_t n, double counter_pe
     A1_HIP(hipMemcpyAsync(foot_pos_target_last_time, d_tl, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(foot_pos_cur_out, d_cur, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(foot_forces_kin_out, d_kin, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipStreamSynchronize(s));
+    return A1MPC_OK;
+}
+
+// ---- N4b: leg kinematics (S/GazeboA1ROS.cpp:264-279, A1Kinematics fk / jac restated from the leg model), one lane per (robot, leg) -----------
+struct LegArgs {
+    int32_t n;
+    double rho_fix[20], rho_opt[12];
+    const double *q, *qd, *R, *pos, *vel;
+    double *rel, *Jb, *vrel, *pabs, *vabs, *pworld, *vworld;
+};
+__global__ __launch_bounds__(256) void a1mpc_leg_kernel(const LegArgs a) {
+#pragma clang fp contract(off)
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t b = gid >> 2;
+    const int i = static_cast<int>(gid & 3);
+    if (b >= a.n) return;
+    const double *q = a.q + b * 12 + 3 * i, *qd = a.qd + b * 12 + 3 * i, *f = a.rho_fix + 5 * i, *o = a.rho_opt + 3 * i;
+    const double ox = f[0], oy = f[1], L = f[2] + o[1], lt = f[3], al = f[4] - o[2], r0 = o[0];
+    const double s0 = sin(q[0]), c0 = cos(q[0]), s1 = sin(q[1]), c1 = cos(q[1]), s12 = sin(q[1] + q[2]), c12 = cos(q[1] + q[2]);
+    const double Xq = r0 * c12 - al * s12, Zq = -(al * c12) - r0 * s12;
+    const double Xr = Xq - lt * s1, Zp = Zq - lt * c1;
+    const double p[3] = {ox + Xr, oy + (L * c0 - Zp * s0), L * s0 + Zp * c0};
+    const double J[9] = {0.0, -p[2], p[1] - oy, Zp, s0 * Xr, -(c0 * Xr), Zq, s0 * Xq, -(c0 * Xq)};
+    const int64_t o12 = b * 12 + 3 * i;
+    double* Jo = a.Jb + b * 36 + 9 * i;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Jo[k] = J[k];
+    double v[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        v[r] = J[r] * qd[0] + J[3 + r] * qd[1] + J[6 + r] * qd[2];
+        a.rel[o12 + r] = p[r];
+        if (a.vrel) a.vrel[o12 + r] = v[r];
+    }
+    const double* R = a.R + b * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double pa = R[3 * r] * p[0] + R[3 * r + 1] * p[1] + R[3 * r + 2] * p[2];
+        const double va = R[3 * r] * v[0] + R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2];
+        if (a.pabs) a.pabs[o12 + r] = pa;
+        if (a.vabs) a.vabs[o12 + r] = va;
+        if (a.pworld) a.pworld[o12 + r] = pa + a.pos[b * 3 + r];
+        if (a.vworld) a.vworld[o12 + r] = va + a.vel[b * 3 + r];
+    }
+}
+
+a1mpc_status a1mpc_leg_state_batch(a1mpc_handle h, int32_t n, const double* joint_pos, const double* joint_vel, const double* R_world,
+                                   const double* root_pos, const double* root_lin_vel, const double* rho_fix, const double* rho_opt,
+                                   double* foot_pos_rel_out, double* j_foot_blocks_out, double* foot_vel_rel_out, double* foot_pos_abs_out,
+                                   double* foot_vel_abs_out, double* foot_pos_world_out, double* foot_vel_world_out) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !joint_pos || !joint_vel || !R_world || !root_pos || !root_lin_vel || !rho_fix || !rho_opt || !foot_pos_rel_out || !j_foot_blocks_out)
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
+    const size_t N = n;
+    hipStream_t s = h->stream;
+    // staging: aux_in [q 12 | qd 12 | R 9 | pos 3 | vel 3 | rel 12] = 51 of 64, aux_out [Jb 36 | vrel 12 | pabs 12 | vabs 12 | pworld 12 | vworld 12] = 96
+    double *d_q = h->d_aux_in, *d_qd = d_q + 12 * N, *d_R = d_qd + 12 * N, *d_pos = d_R + 9 * N, *d_vel = d_pos + 3 * N, *d_rel = d_vel + 3 * N;
+    double *d_Jb = h->d_aux_out, *d_vrel = d_Jb + 36 * N, *d_pabs = d_vrel + 12 * N, *d_vabs = d_pabs + 12 * N, *d_pw = d_vabs + 12 * N, *d_vw = d_pw + 12 * N;
+    A1_HIP(hipMemcpyAsync(d_q, joint_pos, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_qd, joint_vel, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_R, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_pos, root_pos, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_vel, root_lin_vel, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    LegArgs a;
+    a.n = n;
+    std::memcpy(a.rho_fix, rho_fix, sizeof a.rho_fix); std::memcpy(a.rho_opt, rho_opt, sizeof a.rho_opt);
+    a.q = d_q; a.qd = d_qd; a.R = d_R; a.pos = d_pos; a.vel = d_vel; a.rel = d_rel; a.Jb = d_Jb;
+    a.vrel = foot_vel_rel_out ? d_vrel : nullptr; a.pabs = foot_pos_abs_out ? d_pabs : nullptr; a.vabs = foot_vel_abs_out ? d_vabs : nullptr;
+    a.pworld = foot_pos_world_out ? d_pw : nullptr; a.vworld = foot_vel_world_out ? d_vw : nullptr;
+    A1_HIP(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(a1mpc_leg_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    A1_HIP(hipGetLastError());
+    A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = true; h->last_stream = s;
+    A1_HIP(hipMemcpyAsync(foot_pos_rel_out, d_rel, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipMemcpyAsync(j_foot_blocks_out, d_Jb, N * 36 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (foot_vel_rel_out) A1_HIP(hipMemcpyAsync(foot_vel_rel_out, d_vrel, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (foot_pos_abs_out) A1_HIP(hipMemcpyAsync(foot_pos_abs_out, d_pabs, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (foot_vel_abs_out) A1_HIP(hipMemcpyAsync(foot_vel_abs_out, d_vabs, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (foot_pos_world_out) A1_HIP(hipMemcpyAsync(foot_pos_world_out, d_pw, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (foot_vel_world_out) A1_HIP(hipMemcpyAsync(foot_vel_world_out, d_vw, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipStreamSynchronize(s));
     return A1MPC_OK;
 }

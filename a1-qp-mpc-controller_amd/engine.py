@@ -40,7 +40,7 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
     _fields_ = [("counter_per_swing", C.c_double), ("foot_force_low", C.c_double), ("use_terrain_adapt", C.c_int32)]
 
 
-EXPORTS = ["a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
+EXPORTS = ["a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
 
@@ -82,6 +82,7 @@ def load_library(path=None):
     lib.a1mpc_reset_contact_state.argtypes = [vp]; lib.a1mpc_reset_contact_state.restype = C.c_int
     lib.a1mpc_swing_legs_batch.argtypes = [vp, i32, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp]
     lib.a1mpc_swing_legs_batch.restype = C.c_int
+    lib.a1mpc_leg_state_batch.argtypes = [vp, i32] + [dp] * 14; lib.a1mpc_leg_state_batch.restype = C.c_int
     lib.a1mpc_set_schedule.argtypes = [vp, i32]; lib.a1mpc_set_schedule.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
     lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int
@@ -255,6 +256,20 @@ class Engine:
                                              _dp(rel_last), _dp(target_last), _dp(cur), _dp(kin))
         _check(self.lib, rc, "a1mpc_swing_legs_batch")
         return cur, kin
+
+    # ---- N4b: leg kinematics (S/GazeboA1ROS.cpp:264-279) ----
+    A1_RHO_FIX = np.array([[0.1805, 0.047, 0.0838, 0.21, 0.21], [0.1805, -0.047, -0.0838, 0.21, 0.21], [-0.1805, 0.047, 0.0838, 0.21, 0.21],
+                           [-0.1805, -0.047, -0.0838, 0.21, 0.21]])
+
+    def leg_state(self, joint_pos, joint_vel, R, root_pos, root_lin_vel, rho_fix=None, rho_opt=None):
+        q = _f64(joint_pos, (-1, 12)); n = q.shape[0]
+        qd = _f64(joint_vel, (n, 12)); R = _f64(R, (n, 9)); pos = _f64(root_pos, (n, 3)); vel = _f64(root_lin_vel, (n, 3))
+        fix = _f64(self.A1_RHO_FIX if rho_fix is None else rho_fix, (4, 5)); opt = _f64(np.zeros((4, 3)) if rho_opt is None else rho_opt, (4, 3))
+        names = ("foot_pos_rel", "Jb", "foot_vel_rel", "foot_pos_abs", "foot_vel_abs", "foot_pos_world", "foot_vel_world")
+        out = {k: np.zeros((n, 36 if k == "Jb" else 12)) for k in names}
+        rc = self.lib.a1mpc_leg_state_batch(self._h, n, _dp(q), _dp(qd), _dp(R), _dp(pos), _dp(vel), _dp(fix), _dp(opt), *[_dp(out[k]) for k in names])
+        _check(self.lib, rc, "a1mpc_leg_state_batch")
+        return out
 
     def reset_contact_state(self):
         _check(self.lib, self.lib.a1mpc_reset_contact_state(self._h), "a1mpc_reset_contact_state")

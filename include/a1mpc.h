@@ -222,6 +222,19 @@ a1mpc_status a1mpc_swing_legs_batch(a1mpc_handle h, int32_t n, double counter_pe
                                     const double* kp_foot, const double* kd_foot, double* foot_pos_start, double* foot_pos_rel_last_time,
                                     double* foot_pos_target_last_time, double* foot_pos_cur_out, double* foot_forces_kin_out);
 
+/*
+ * N4b (caller side): leg kinematics of n robots -- the per-leg block of the joint-state callback, S/GazeboA1ROS.cpp:264-279, with
+ * A1Kinematics::fk / jac (S/legKinematics/A1Kinematics.cpp) restated from the leg model (hip offset, abduction, thigh, calf).
+ *   joint_pos, joint_vel n x 12; R_world n x 9; root_pos, root_lin_vel n x 3; rho_fix 4 x 5 = [ox, oy, d, lt, lc] per leg, rho_opt 4 x 3
+ * out (each may be NULL except foot_pos_rel and j_foot_blocks): foot_pos_rel n x 12, j_foot_blocks n x 4 x 9 (column-major 3x3 per leg,
+ * the layout a1mpc_joint_torques_batch takes), foot_vel_rel, foot_pos_abs, foot_vel_abs, foot_pos_world, foot_vel_world n x 12.
+ * Host pointers.  sin / cos come from the device math library: agreement with the reference to a few ulp.
+ */
+a1mpc_status a1mpc_leg_state_batch(a1mpc_handle h, int32_t n, const double* joint_pos, const double* joint_vel, const double* R_world,
+                                   const double* root_pos, const double* root_lin_vel, const double* rho_fix, const double* rho_opt,
+                                   double* foot_pos_rel_out, double* j_foot_blocks_out, double* foot_vel_rel_out, double* foot_pos_abs_out,
+                                   double* foot_vel_abs_out, double* foot_pos_world_out, double* foot_vel_world_out);
+
 /* Work-queue order of batches larger than the resident set: history = 1 (default) issues the QPs longest-first by the cost
  * (iterations + factor passes) each one had in the previous solve of this handle with the same n -- the same robots tick after
  * tick; history = 0 is plain index order.  The first solve of a batch size, and the solve after a1mpc_reset_warm_start, run in

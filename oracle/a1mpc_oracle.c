@@ -903,6 +903,42 @@ void orc_swing_legs(double counter_per_swing, double dt, const double *Rz, const
     }
 }
 
+/* ---- N4b: leg kinematics of one robot, the per-leg block of the joint-state callback (S/GazeboA1ROS.cpp:264-279) with
+ * A1Kinematics::fk / jac (S/legKinematics/A1Kinematics.cpp:7-17; their bodies are MATLAB-generated trigonometric polynomials).
+ * Restated from the leg model those polynomials expand: hip at (ox, oy), abduction q0 about x with lateral offset L = d + rho1,
+ * thigh lt (q1) and calf lc (q2) in the sagittal plane, contact-point offsets rho0 (along the calf's x) and rho2 (shortening the calf):
+ *   X  = ox - lt sin q1 - (lc - rho2) sin(q1+q2) + rho0 cos(q1+q2)
+ *   Zp =    - lt cos q1 - (lc - rho2) cos(q1+q2) - rho0 sin(q1+q2)
+ *   y  = oy + L cos q0 - Zp sin q0,   z = L sin q0 + Zp cos q0
+ * (term-by-term identical to autoFunc_fk_derive after expanding the angle sums; the Jacobian is the analytic derivative = autoFunc_d_fk_dq).
+ * rho_fix = [ox, oy, d, lt, lc] (:92-93), rho_opt = [rho0, rho1, rho2] (:94-95), Jb column-major per leg. */
+void orc_leg_state(const double *joint_pos, const double *joint_vel, const double *Rw, const double *root_pos, const double *root_lin_vel,
+                   const double *rho_fix /* 4x5 */, const double *rho_opt /* 4x3 */, double *foot_pos_rel, double *Jb, double *foot_vel_rel,
+                   double *foot_pos_abs, double *foot_vel_abs, double *foot_pos_world, double *foot_vel_world) {
+    for (int i = 0; i < NLEG; ++i) {
+        const double *q = joint_pos + 3 * i, *qd = joint_vel + 3 * i, *f = rho_fix + 5 * i, *o = rho_opt + 3 * i;
+        const double ox = f[0], oy = f[1], L = f[2] + o[1], lt = f[3], a = f[4] - o[2], r0 = o[0];
+        const double s0 = sin(q[0]), c0 = cos(q[0]), s1 = sin(q[1]), c1 = cos(q[1]), s12 = sin(q[1] + q[2]), c12 = cos(q[1] + q[2]);
+        const double Xq = r0 * c12 - a * s12, Zq = -(a * c12) - r0 * s12;      /* calf part */
+        const double Xr = Xq - lt * s1, Zp = Zq - lt * c1;                      /* X - ox, Zp */
+        double p[3] = {ox + Xr, oy + (L * c0 - Zp * s0), L * s0 + Zp * c0};
+        double *J = Jb + 9 * i;
+        J[0] = 0.0;        J[1] = -p[2];       J[2] = p[1] - oy;                /* d/dq0 */
+        J[3] = Zp;         J[4] = s0 * Xr;     J[5] = -(c0 * Xr);               /* d/dq1 */
+        J[6] = Zq;         J[7] = s0 * Xq;     J[8] = -(c0 * Xq);               /* d/dq2 */
+        for (int r = 0; r < 3; ++r) {
+            foot_pos_rel[3 * i + r] = p[r];
+            foot_vel_rel[3 * i + r] = J[r] * qd[0] + J[3 + r] * qd[1] + J[6 + r] * qd[2];                         /* :273 */
+        }
+        for (int r = 0; r < 3; ++r) {                                                                            /* :275-279 */
+            const double pa = Rw[3 * r] * foot_pos_rel[3 * i] + Rw[3 * r + 1] * foot_pos_rel[3 * i + 1] + Rw[3 * r + 2] * foot_pos_rel[3 * i + 2];
+            const double va = Rw[3 * r] * foot_vel_rel[3 * i] + Rw[3 * r + 1] * foot_vel_rel[3 * i + 1] + Rw[3 * r + 2] * foot_vel_rel[3 * i + 2];
+            foot_pos_abs[3 * i + r] = pa; foot_vel_abs[3 * i + r] = va;
+            foot_pos_world[3 * i + r] = pa + root_pos[r]; foot_vel_world[3 * i + r] = va + root_lin_vel[r];
+        }
+    }
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -270,5 +270,19 @@ def swing_legs(Rz, foot_pos_abs, gait_counter, foot_pos_target_rel, foot_pos_sta
     return cur, kin
 
 
+A1_RHO_FIX = np.array([[0.1805, 0.047, 0.0838, 0.21, 0.21], [0.1805, -0.047, -0.0838, 0.21, 0.21], [-0.1805, 0.047, 0.0838, 0.21, 0.21],
+                       [-0.1805, -0.047, -0.0838, 0.21, 0.21]])  # S/GazeboA1ROS.cpp:76-93
+
+
+def leg_state(joint_pos, joint_vel, Rw, root_pos, root_lin_vel, rho_fix=A1_RHO_FIX, rho_opt=np.zeros((4, 3))):
+    """S/GazeboA1ROS.cpp:264-279 for one robot: dict of foot_pos_rel, Jb (4 blocks, column-major), foot_vel_rel, foot_pos_abs, foot_vel_abs,
+    foot_pos_world, foot_vel_world"""
+    a = lambda v: _p(np.ascontiguousarray(v, dtype=np.float64))
+    out = {k: np.zeros(36 if k == "Jb" else 12) for k in ("foot_pos_rel", "Jb", "foot_vel_rel", "foot_pos_abs", "foot_vel_abs", "foot_pos_world", "foot_vel_world")}
+    lib().orc_leg_state(a(joint_pos), a(joint_vel), a(Rw), a(root_pos), a(root_lin_vel), a(rho_fix), a(rho_opt), *[_p(out[k]) for k in
+                        ("foot_pos_rel", "Jb", "foot_vel_rel", "foot_pos_abs", "foot_vel_abs", "foot_pos_world", "foot_vel_world")])
+    return out
+
+
 def num_threads():
     return lib().orc_num_threads()

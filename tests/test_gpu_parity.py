@@ -438,3 +438,21 @@ def test_control_tick_chain(pkg, oracle, scen):
             worst = max(worst, np.abs(G["tau"] - O["tau"]).max())
             O["tl"][:] = G["tl"]  # the curve's ulp differences must not accumulate into the comparison (see test_swing_legs_N4a_sequence)
     assert worst < 1e-5, worst
+
+
+def test_leg_state_N4b(pkg, oracle, scen):
+    """leg forward kinematics, Jacobians and the frame chain of the joint-state callback (S/GazeboA1ROS.cpp:264-279) for
+    3000 robots vs the oracle; sin / cos come from the device math library, so the bar is a few ulp of the 0.4 m leg (1e-14)."""
+    rng = np.random.default_rng(41)
+    n = 3000
+    q = rng.uniform(-1.2, 1.2, (n, 12)); qd = rng.normal(0, 3, (n, 12)); opt = rng.normal(0, 0.01, (4, 3))
+    eul = rng.uniform(-0.5, 0.5, (n, 3)); eul[:, 2] = rng.uniform(-3, 3, n); R = scen.rot_zyx(eul[:, 0], eul[:, 1], eul[:, 2]).reshape(n, 9)
+    pos = rng.normal(0, 2, (n, 3)); vel = rng.normal(0, 1, (n, 3))
+    cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+    with pkg.Engine(cfg, n, 0) as eng:
+        out = eng.leg_state(q, qd, R, pos, vel, rho_opt=opt)
+    for b in range(0, n, 5):
+        ref = oracle.leg_state(q[b], qd[b], R[b], pos[b], vel[b], rho_opt=opt)
+        for k, tol in (("foot_pos_rel", 1e-14), ("Jb", 1e-14), ("foot_vel_rel", 1e-13), ("foot_pos_abs", 1e-14), ("foot_vel_abs", 1e-13),
+                       ("foot_pos_world", 1e-14), ("foot_vel_world", 1e-13)):
+            assert np.abs(out[k][b] - ref[k]).max() <= tol, (b, k, np.abs(out[k][b] - ref[k]).max())

@@ -191,3 +191,27 @@ def test_swing_legs_restatement(oracle):
     blend = 4 * t ** 3 * (1 - t) + t ** 4 + 6 * t ** 2 * (1 - t) ** 2
     assert np.allclose(tl[0:3], [foot[0] + blend * 0.05, foot[1], foot[2] + zc], atol=1e-12)
     assert np.allclose(kin[0], 300.0 * (tl[0] - foot[0]) + 8.0 * ((tl[0] - foot[0]) / 0.0025), rtol=1e-12)
+
+
+def test_leg_state_restatement(oracle):
+    """N4b oracle: zero pose = the A1 geometry, Jacobian = numerical derivative of the forward kinematics, frame chain"""
+    z = np.zeros(12); I = np.eye(3).reshape(9)
+    o = oracle.leg_state(z, z, I, [0, 0, 0], [0, 0, 0])
+    assert np.allclose(o["foot_pos_rel"].reshape(4, 3), [[0.1805, 0.047 + 0.0838, -0.42], [0.1805, -0.1308, -0.42], [-0.1805, 0.1308, -0.42], [-0.1805, -0.1308, -0.42]], atol=1e-15)
+    rng = np.random.default_rng(9)
+    for _ in range(50):
+        q = rng.uniform(-1, 1, 12); qd = rng.normal(0, 2, 12); opt = rng.normal(0, 0.01, (4, 3))
+        yaw, pit = rng.uniform(-3, 3), rng.uniform(-0.4, 0.4)
+        R = (np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]]) @ np.array([[np.cos(pit), 0, np.sin(pit)], [0, 1, 0], [-np.sin(pit), 0, np.cos(pit)]]))
+        pos, vel = rng.normal(0, 1, 3), rng.normal(0, 1, 3)
+        o = oracle.leg_state(q, qd, R.reshape(9), pos, vel, rho_opt=opt)
+        J = o["Jb"].reshape(4, 3, 3).transpose(0, 2, 1)  # [leg][row][col]
+        for k in range(3):
+            e = np.zeros(12); h = 1e-6
+            for leg in range(4):
+                e[:] = 0; e[3 * leg + k] = h
+                d = (oracle.leg_state(q + e, qd, R.reshape(9), pos, vel, rho_opt=opt)["foot_pos_rel"] - oracle.leg_state(q - e, qd, R.reshape(9), pos, vel, rho_opt=opt)["foot_pos_rel"]) / (2 * h)
+                assert np.allclose(d[3 * leg:3 * leg + 3], J[leg][:, k], atol=1e-8)
+        pr = o["foot_pos_rel"].reshape(4, 3); vr = np.einsum("lij,lj->li", J, qd.reshape(4, 3))
+        assert np.allclose(o["foot_vel_rel"].reshape(4, 3), vr, atol=1e-14) and np.allclose(o["foot_pos_world"].reshape(4, 3), pr @ R.T + pos, atol=1e-14)
+        assert np.allclose(o["foot_vel_world"].reshape(4, 3), vr @ R.T + vel, atol=1e-13)
