@@ -93,6 +93,29 @@ def batch_sweep(pkg, local, sizes=(1024, 16384, 65536)):
     return out
 
 
+def warm_tick_probe(pkg, local, n=4096, ticks=12):
+    """Extra information (not `value`): the closed-loop regime -- the same n robots tick after tick with warm start (the carried OSQP
+    workspace of the reference) and slowly moving states (two nearby batches alternate), queue order from the previous tick."""
+    import torch
+    dev = torch.device("cuda", local); st = torch.cuda.Stream(device=dev)
+    a = pkg.scenarios.config3_random_flat(nb=n)
+    rng = np.random.default_rng(5)
+    b = {k: a[k].copy() for k in ("x0", "xref", "R", "foot", "contact")}
+    b["x0"][:, :12] += rng.normal(0, 0.002, (n, 12)); b["foot"] += rng.normal(0, 0.001, (n, 12))
+    cfg = pkg.make_config(a["params"], HORIZON, warm_start=1)
+    da = {k: torch.from_numpy(a[k]).to(dev) for k in b}; db = {k: torch.from_numpy(b[k]).to(dev) for k in b}
+    grf = torch.zeros((n, 12), dtype=torch.float64, device=dev)
+    it = torch.zeros(n, dtype=torch.int32, device=dev); stt = torch.zeros(n, dtype=torch.int32, device=dev)
+    ms, iters = [], []
+    with pkg.Engine(cfg, n, local) as eng:
+        for t in range(ticks):
+            d = da if t % 2 == 0 else db
+            eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, it, stt, stream=st.cuda_stream)
+            ms.append(eng.last_kernel_ms()); iters.append(float(it.float().mean().item()))
+    return {"workload": "4096 robots, h=10, warm start, states move ~2 mm / 2 mrad between ticks", "kernel_ms_per_tick": float(np.median(ms[4:])),
+            "ticks_per_s_x_robots": n / (float(np.median(ms[4:])) * 1e-3), "mean_iters_cold_first_tick": iters[0], "mean_iters_warm": float(np.mean(iters[4:]))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +237,7 @@ def main():
         if not args.no_latency:
             out["latency"] = latency_probe(pkg)
             out["throughput_by_batch"] = batch_sweep(pkg, local)
+            out["warm_start_ticks"] = warm_tick_probe(pkg, local)
         if not args.no_cpu_baseline:
             out["cpu_baseline"], _ = cpu_baseline(pkg, sc)
         print(json.dumps(out), flush=True)
