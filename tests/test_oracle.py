@@ -48,16 +48,18 @@ def test_exact_mode_solutions_satisfy_kkt(scen, name):
 
 
 def test_scipy_cross_check_fixture_T(oracle, scen):
-    """independent solver (scipy trust-constr) on the numpy matrices of fixture T agrees with the oracle's exact mode"""
-    from scipy.optimize import Bounds, LinearConstraint, minimize
+    """independent solver (scipy SLSQP, a dense active-set SQP) on the numpy matrices of fixture T agrees with the oracle's exact mode"""
+    from scipy.optimize import minimize
     sc = scen.scenario_T()
     x0, xref, R, foot, contact = _one(sc)
     P, g, A, l, u = RN.mpc_qp(sc["params"], 10, x0, xref, R, foot, contact)
-    lo = np.where(l < -1e20, -np.inf, l); hi = np.where(u > 1e20, np.inf, u)
-    res = minimize(lambda x: 0.5 * x @ P @ x + g @ x, np.zeros(120), jac=lambda x: P @ x + g, hess=lambda x: P, method="trust-constr",
-                   constraints=[LinearConstraint(A, lo, hi)], options=dict(gtol=1e-10, xtol=1e-12, maxiter=3000))
+    fin_l = l > -1e20; fin_u = u < 1e20
+    Ai = np.vstack([A[fin_l], -A[fin_u]]); bi = np.concatenate([-l[fin_l], u[fin_u]])
+    res = minimize(lambda x: 0.5 * x @ P @ x + g @ x, np.zeros(120), jac=lambda x: P @ x + g, method="SLSQP",
+                   constraints=[dict(type="ineq", fun=lambda x: Ai @ x + bi, jac=lambda x: Ai)], options=dict(ftol=1e-14, maxiter=500))
+    assert res.status == 0
     e = oracle_batch(oracle, sc, settings=oracle.exact_settings())
-    assert np.abs(res.x[:12] - e["u"][0][:12]).max() < 2e-2  # trust-constr's own accuracy; survey estimate (0,-12.837,42.790)
+    assert np.abs(res.x[:12] - e["u"][0][:12]).max() < 5e-3  # SLSQP's own accuracy (observed 4e-4); survey estimate (0,-12.837,42.790)
     f = e["grf"][0].reshape(4, 3)
     assert f[0, 2] == pytest.approx(42.790, abs=2e-3) and f[0, 1] == pytest.approx(-12.837, abs=2e-3)
 
