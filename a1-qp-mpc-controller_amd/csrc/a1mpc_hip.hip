@@ -363,6 +363,7 @@ struct a1mpc_handle_s {
     // queue order of the next solve (longest-first by the previous solve's per-QP cost) -- see a1mpc_set_schedule
     int32_t *d_order = nullptr, *d_cost = nullptr;
     double* d_ct_state = nullptr;  // N2b filter state of every robot (allocated on first use)
+    double* d_ekf_state = nullptr;  // N4c Kalman filter state of every robot (allocated on first use)
     // staging of the element-wise entry points (N2a, N2b, N3), allocated on first use: 64 / 96 doubles and 16 bytes per robot
     double *d_aux_in = nullptr, *d_aux_out = nullptr;
     uint8_t* d_aux_u8 = nullptr;
@@ -756,6 +757,232 @@ a1mpc_status a1mpc_leg_state_batch(a1mpc_handle h, int32_t n, const double* join
     return A1MPC_OK;
 }
 
+// ---- N4c: A1BasicEKF (S/A1BasicEKF.cpp), 32 lanes per robot, two robots per wavefront -----------------------------------------------
+// Lane r owns row r of every matrix (18 state rows, 28 measurement rows); rows meet through the robot's LDS image (P, Pbar, S / S^-1 C, the
+// pivot row of the elimination).  The arithmetic follows the dense products of the reference term for term (inner index ascending, the
+// exact zeros of A, B, C dropped), no FMA contraction, so the result is bit-identical to the oracle's dense restatement.
+constexpr int kEkfState = 18 + 18 * 18 + 1;
+struct EkfArgs {
+    int32_t n;
+    double dt;
+    int32_t flat;
+    double* state;
+    const uint8_t* mode;
+    const double *ff, *R, *acc, *w, *fk, *fv;
+    double *pos_out, *vel_out;
+    uint8_t* ec_out;
+};
+__global__ __launch_bounds__(256) void a1mpc_ekf_init_kernel(const EkfArgs a) {  // init_state :54-68 for robots whose filter is new
+#pragma clang fp contract(off)
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (b >= a.n) return;
+    double* st = a.state + b * kEkfState;
+    if (st[18 + 324] != 0.0) return;
+    double *x = st, *P = st + 18;
+    for (int i = 0; i < 324; ++i) P[i] = 0.0;
+    for (int i = 0; i < 18; ++i) { P[i * 18 + i] = 1.0 * 3; x[i] = 0.0; }
+    x[2] = 0.09;
+    const double* R = a.R + b * 9; const double* fk = a.fk + b * 12;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 3; ++r) x[6 + i * 3 + r] = (R[3 * r] * fk[3 * i] + R[3 * r + 1] * fk[3 * i + 1] + R[3 * r + 2] * fk[3 * i + 2]) + x[r];
+    st[18 + 324] = 2.0;  // initialised in THIS call: the update kernel turns it into 1 and leaves the robot alone
+    for (int r = 0; r < 3; ++r) { a.pos_out[b * 3 + r] = x[r]; a.vel_out[b * 3 + r] = x[3 + r]; }
+    for (int i = 0; i < 4; ++i) a.ec_out[b * 4 + i] = 0;
+}
+__device__ inline void half_sync() {  // orders LDS traffic between the lanes of a wavefront (see row_sync)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// column list of C's row r: up to two (column, sign) pairs in ascending column order
+__device__ inline void ekf_c_row(int r, int& c0, double& s0, int& c1, double& s1) {
+    c1 = -1; s1 = 0.0;
+    if (r < 12) { c0 = r % 3; s0 = -1.0; c1 = 6 + r; s1 = 1.0; }            // -pos + foot
+    else if (r < 24) { c0 = 3 + (r - 12) % 3; s0 = 1.0; }                    // vel
+    else { c0 = 6 + (r - 24) * 3 + 2; s0 = 1.0; }                            // foot height
+}
+__global__ __launch_bounds__(64) void a1mpc_ekf_kernel(const EkfArgs a) {
+#pragma clang fp contract(off)
+    __shared__ double lds[2][1600];
+    const int g = static_cast<int>(threadIdx.x) >> 5, l = static_cast<int>(threadIdx.x) & 31;
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * 2 + g;
+    if (b >= a.n) return;
+    double* st = a.state + b * kEkfState;
+    const double flag = st[18 + 324];
+    if (flag != 1.0) { if (l == 0 && flag == 2.0) st[18 + 324] = 1.0; return; }
+    double *Pm = lds[g], *Pb = Pm + 324, *Sm = Pb + 324, *prow = Sm + 28 * 29, *xs = prow + 48, *xb = xs + 18, *zs = xb + 18;   // 324+324+812+48+18+18+28 = 1572
+    const double dt = a.dt;
+    for (int i = l; i < 324; i += 32) Pm[i] = st[18 + i];
+    if (l < 18) xs[l] = st[l];
+    const double* R = a.R + b * 9; const double *fk = a.fk + b * 12, *fv = a.fv + b * 12, *acc = a.acc + b * 3, *w = a.w + b * 3;
+    double ec[4];
+    for (int i = 0; i < 4; ++i) ec[i] = a.mode[b] == 0 ? 1.0 : fmin(fmax(a.ff[b * 4 + i] / (100.0 - 0.0), 0.0), 1.0);   // :79-86
+    const double PIMU = 0.01, VIMU = 0.01, PFOOT = 0.01, S_PIMU_REL = 0.001, S_VIMU_REL = 0.1, S_ZFOOT = 0.001;       // A1BasicEKF.h:15-20
+    half_sync();
+    // ---- process update (:72-112): xbar = A x + B u, Pbar = A P A' + Q; lane i < 18 owns row i
+    double Pr[18];
+    if (l < 18) {
+        double xbv;
+        if (l < 3) xbv = (xs[l] + dt * xs[3 + l]) + 0.0;
+        else if (l < 6) { const int c = l - 3; const double u = (R[3 * c] * acc[0] + R[3 * c + 1] * acc[1] + R[3 * c + 2] * acc[2]) + (c == 2 ? -9.81 : 0.0); xbv = xs[l] + dt * u; }
+        else xbv = xs[l] + 0.0;
+        xb[l] = xbv;
+        double T[18];
+        for (int j = 0; j < 18; ++j) T[j] = l < 3 ? Pm[l * 18 + j] + dt * Pm[(3 + l) * 18 + j] : Pm[l * 18 + j];
+        double q;
+        if (l < 3) q = PIMU * dt / 20.0; else if (l < 6) q = VIMU * dt * 9.8 / 20.0; else q = (1 + (1 - ec[(l - 6) / 3]) * 1e3) * dt * PFOOT;
+        for (int j = 0; j < 18; ++j) { Pr[j] = (j < 3 ? T[j] + T[3 + j] * dt : T[j]) + (j == l ? q : 0.0); Pb[l * 18 + j] = Pr[j]; }
+    }
+    half_sync();
+    // ---- innovation (:115-131): lane r < 28 owns row r of [S | error_y | C]
+    double M[47];
+    if (l < 28) {
+        const int r = l;
+        int c0, c1; double s0, s1;
+        ekf_c_row(r, c0, s0, c1, s1);
+        const double yhat = c1 >= 0 ? s0 * xb[c0] + s1 * xb[c1] : s0 * xb[c0];
+        double y, rd;
+        if (r < 24) {
+            const int i = (r % 12) / 3, c = r % 3;
+            const double* f = fk + 3 * i;
+            const double wgt = 1 + (1 - ec[i]) * 1e3;
+            if (r < 12) { y = R[3 * c] * f[0] + R[3 * c + 1] * f[1] + R[3 * c + 2] * f[2]; rd = wgt * S_PIMU_REL; }
+            else {
+                const double* v = fv + 3 * i;
+                const double wx = w[0], wy = w[1], wz = w[2];
+                const double sk0 = 0.0 * f[0] + -wz * f[1] + wy * f[2], sk1 = wz * f[0] + 0.0 * f[1] + -wx * f[2], sk2 = -wy * f[0] + wx * f[1] + 0.0 * f[2];
+                const double lv0 = -v[0] - sk0, lv1 = -v[1] - sk1, lv2 = -v[2] - sk2;
+                const double rl = R[3 * c] * lv0 + R[3 * c + 1] * lv1 + R[3 * c + 2] * lv2;
+                y = (1.0 - ec[i]) * xs[3 + c] + ec[i] * rl; rd = wgt * S_VIMU_REL;
+            }
+        } else {
+            const int i = r - 24;
+            y = (1.0 - ec[i]) * (xs[2] + fk[3 * i + 2]) + ec[i] * 0;
+            rd = a.flat ? (1 + (1 - ec[i]) * 1e3) * S_ZFOOT : 1e5;
+        }
+        double CP[18];
+        for (int j = 0; j < 18; ++j) CP[j] = c1 >= 0 ? s0 * Pb[c0 * 18 + j] + s1 * Pb[c1 * 18 + j] : s0 * Pb[c0 * 18 + j];
+        for (int c = 0; c < 28; ++c) {
+            int d0, d1; double t0, t1;
+            ekf_c_row(c, d0, t0, d1, t1);
+            const double v = d1 >= 0 ? CP[d0] * t0 + CP[d1] * t1 : CP[d0] * t0;
+            M[c] = v + (c == r ? rd : 0.0);
+            Sm[r * 29 + c] = M[c];
+        }
+        M[28] = y - yhat;
+        for (int j = 0; j < 18; ++j) M[29 + j] = (j == c0 ? s0 : 0.0) + (j == c1 ? s1 : 0.0);
+    }
+    half_sync();
+    if (l < 28)
+        for (int c = 0; c < 28; ++c) M[c] = c == l ? 0.5 * (M[c] + M[c]) : (c > l ? 0.5 * (M[c] + Sm[c * 29 + l]) : 0.5 * (Sm[c * 29 + l] + M[c]));   // :131
+    // ---- Gauss-Jordan elimination of [S | e | C] (:133-134, :138)
+#pragma unroll
+    for (int k = 0; k < 28; ++k) {
+        half_sync();
+        if (l == k) {
+            const double pinv = 1.0 / M[k];
+#pragma unroll
+            for (int j = 0; j < 47; ++j) { M[j] = M[j] * pinv; prow[j] = M[j]; }
+        }
+        half_sync();
+        if (l < 28 && l != k) {
+            const double f = M[k];
+#pragma unroll
+            for (int j = 0; j < 47; ++j) M[j] = M[j] - f * prow[j];
+        }
+    }
+    half_sync();
+    double* SC = Sm;  // S is consumed: the region now holds S^-1 C (28 x 18)
+    if (l < 28) { zs[l] = M[28]; for (int j = 0; j < 18; ++j) SC[l * 18 + j] = M[29 + j]; }
+    half_sync();
+    // ---- measurement update (:136-140)
+    double Tn[18];
+    if (l < 18) {
+        double G1[28];
+        for (int r = 0; r < 28; ++r) {
+            int c0, c1; double s0, s1;
+            ekf_c_row(r, c0, s0, c1, s1);
+            G1[r] = c1 >= 0 ? Pr[c0] * s0 + Pr[c1] * s1 : Pr[c0] * s0;
+        }
+        double acc_ = 0;
+        for (int r = 0; r < 28; ++r) acc_ += G1[r] * zs[r];
+        xs[l] = xb[l] + acc_;
+        double G2[18];
+        for (int j = 0; j < 18; ++j) { double s = 0; for (int r = 0; r < 28; ++r) s += G1[r] * SC[r * 18 + j]; G2[j] = s; }
+        for (int j = 0; j < 18; ++j) { double s = 0; for (int k = 0; k < 18; ++k) s += G2[k] * Pb[k * 18 + j]; Tn[j] = Pr[j] - s; Pm[l * 18 + j] = Tn[j]; }
+    }
+    half_sync();
+    if (l < 18) {
+        double Pn[18];
+        for (int j = 0; j < 18; ++j) Pn[j] = 0.5 * (Tn[j] + Pm[j * 18 + l]);                                       // :140
+        const double p00 = 0.5 * (Pm[0] + Pm[0]), p01 = 0.5 * (Pm[1] + Pm[18]), p10 = 0.5 * (Pm[18] + Pm[1]), p11 = 0.5 * (Pm[19] + Pm[19]);
+        if (p00 * p11 - p01 * p10 > 1e-6) {                                                                         // :143-147
+            for (int j = 0; j < 18; ++j) {
+                if (l < 2 && j >= 2) Pn[j] = 0.0;
+                if (l >= 2 && j < 2) Pn[j] = 0.0;
+                if (l < 2 && j < 2) Pn[j] /= 10.0;
+            }
+        }
+        for (int j = 0; j < 18; ++j) st[18 + l * 18 + j] = Pn[j];
+        st[l] = xs[l];
+        if (l < 3) a.pos_out[b * 3 + l] = xs[l]; else if (l < 6) a.vel_out[b * 3 + l - 3] = xs[l];
+    }
+    if (l < 4) a.ec_out[b * 4 + l] = ec[l] < 0.5 ? 0 : 1;                                                           // :151-157
+}
+
+a1mpc_status a1mpc_reset_ekf_state(a1mpc_handle h) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (!h->d_ekf_state) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    A1_HIP(hipMemsetAsync(h->d_ekf_state, 0, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double), h->stream));
+    A1_HIP(hipStreamSynchronize(h->stream));
+    return A1MPC_OK;
+}
+a1mpc_status a1mpc_ekf_update_batch(a1mpc_handle h, int32_t n, double dt, int32_t assume_flat_ground, const uint8_t* movement_mode,
+                                    const double* foot_force, const double* R_world, const double* imu_acc, const double* imu_ang_vel,
+                                    const double* foot_pos_rel, const double* foot_vel_rel, double* root_pos_out, double* root_lin_vel_out,
+                                    uint8_t* estimated_contacts_out) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !movement_mode || !foot_force || !R_world || !imu_acc || !imu_ang_vel || !foot_pos_rel || !foot_vel_rel || !root_pos_out ||
+        !root_lin_vel_out || !estimated_contacts_out || !(dt > 0))
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer or dt <= 0");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
+    const size_t N = n;
+    hipStream_t s = h->stream;
+    if (!h->d_ekf_state) {
+        A1_HIP(hipMalloc(&h->d_ekf_state, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double)));
+        A1_HIP(hipMemsetAsync(h->d_ekf_state, 0, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double), s));
+    }
+    // staging: aux_in [ff 4 | R 9 | acc 3 | w 3 | fk 12 | fv 12] = 43, aux_out [pos 3 | vel 3]
+    double *d_ff = h->d_aux_in, *d_R = d_ff + 4 * N, *d_acc = d_R + 9 * N, *d_w = d_acc + 3 * N, *d_fk = d_w + 3 * N, *d_fv = d_fk + 12 * N;
+    double *d_pos = h->d_aux_out, *d_vel = d_pos + 3 * N;
+    uint8_t *d_mm = h->d_aux_u8, *d_ec = h->d_aux_u8 + 8 * N;
+    A1_HIP(hipMemcpyAsync(d_ff, foot_force, N * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_R, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_acc, imu_acc, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_w, imu_ang_vel, N * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_fk, foot_pos_rel, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_fv, foot_vel_rel, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_mm, movement_mode, N, hipMemcpyHostToDevice, s));
+    EkfArgs a;
+    a.n = n; a.dt = dt; a.flat = assume_flat_ground; a.state = h->d_ekf_state; a.mode = d_mm; a.ff = d_ff; a.R = d_R; a.acc = d_acc; a.w = d_w;
+    a.fk = d_fk; a.fv = d_fv; a.pos_out = d_pos; a.vel_out = d_vel; a.ec_out = d_ec;
+    A1_HIP(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((N + 1) / 2)), dim3(64), 0, s, a);
+    A1_HIP(hipGetLastError());
+    A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = true; h->last_stream = s;
+    A1_HIP(hipMemcpyAsync(root_pos_out, d_pos, N * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipMemcpyAsync(root_lin_vel_out, d_vel, N * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipMemcpyAsync(estimated_contacts_out, d_ec, N * 4, hipMemcpyDeviceToHost, s));
+    A1_HIP(hipStreamSynchronize(s));
+    return A1MPC_OK;
+}
+
 // ---- N3: compute_joint_torques (S/A1RobotControl.cpp:289-319), one lane per (robot, leg); no FMA contraction ---------------------
 struct TorqueArgs {
     int32_t n;
@@ -928,7 +1155,7 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_tab, h->d_tab1, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_aux, h->d_Rz, h->d_contact, h->d_grf,
-                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8};
+                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_ekf_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);

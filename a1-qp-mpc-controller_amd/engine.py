@@ -40,7 +40,7 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
     _fields_ = [("counter_per_swing", C.c_double), ("foot_force_low", C.c_double), ("use_terrain_adapt", C.c_int32)]
 
 
-EXPORTS = ["a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
+EXPORTS = ["a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
 
@@ -83,6 +83,8 @@ def load_library(path=None):
     lib.a1mpc_swing_legs_batch.argtypes = [vp, i32, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp]
     lib.a1mpc_swing_legs_batch.restype = C.c_int
     lib.a1mpc_leg_state_batch.argtypes = [vp, i32] + [dp] * 14; lib.a1mpc_leg_state_batch.restype = C.c_int
+    lib.a1mpc_ekf_update_batch.argtypes = [vp, i32, C.c_double, i32, u8p, dp, dp, dp, dp, dp, dp, dp, dp, u8p]; lib.a1mpc_ekf_update_batch.restype = C.c_int
+    lib.a1mpc_reset_ekf_state.argtypes = [vp]; lib.a1mpc_reset_ekf_state.restype = C.c_int
     lib.a1mpc_set_schedule.argtypes = [vp, i32]; lib.a1mpc_set_schedule.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
     lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int
@@ -270,6 +272,21 @@ class Engine:
         rc = self.lib.a1mpc_leg_state_batch(self._h, n, _dp(q), _dp(qd), _dp(R), _dp(pos), _dp(vel), _dp(fix), _dp(opt), *[_dp(out[k]) for k in names])
         _check(self.lib, rc, "a1mpc_leg_state_batch")
         return out
+
+    # ---- N4c: A1BasicEKF (S/A1BasicEKF.cpp); filter state per robot on the device, first call = init_state ----
+    def ekf_update(self, dt, movement_mode, foot_force, R, imu_acc, imu_ang_vel, foot_pos_rel, foot_vel_rel, assume_flat_ground=1):
+        ff = _f64(foot_force, (-1, 4)); n = ff.shape[0]
+        mm = np.ascontiguousarray(movement_mode, dtype=np.uint8).reshape(n)
+        R = _f64(R, (n, 9)); acc = _f64(imu_acc, (n, 3)); w = _f64(imu_ang_vel, (n, 3)); fk = _f64(foot_pos_rel, (n, 12)); fv = _f64(foot_vel_rel, (n, 12))
+        pos = np.zeros((n, 3)); vel = np.zeros((n, 3)); ec = np.zeros((n, 4), np.uint8)
+        u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+        rc = self.lib.a1mpc_ekf_update_batch(self._h, n, float(dt), int(assume_flat_ground), u8(mm), _dp(ff), _dp(R), _dp(acc), _dp(w), _dp(fk), _dp(fv),
+                                             _dp(pos), _dp(vel), u8(ec))
+        _check(self.lib, rc, "a1mpc_ekf_update_batch")
+        return pos, vel, ec
+
+    def reset_ekf_state(self):
+        _check(self.lib, self.lib.a1mpc_reset_ekf_state(self._h), "a1mpc_reset_ekf_state")
 
     def reset_contact_state(self):
         _check(self.lib, self.lib.a1mpc_reset_contact_state(self._h), "a1mpc_reset_contact_state")

@@ -235,6 +235,21 @@ a1mpc_status a1mpc_leg_state_batch(a1mpc_handle h, int32_t n, const double* join
                                    double* foot_pos_rel_out, double* j_foot_blocks_out, double* foot_vel_rel_out, double* foot_pos_abs_out,
                                    double* foot_vel_abs_out, double* foot_pos_world_out, double* foot_vel_world_out);
 
+/*
+ * N4c (caller side, the step before the path): A1BasicEKF, S/A1BasicEKF.cpp:7-163 -- the 18-state / 28-measurement Kalman filter that
+ * provides root_pos and root_lin_vel -- for n robots, one tick.  The filter state of every robot (x 18, P 18x18, initialised flag) lives
+ * on the device inside the handle; the first call for a robot performs init_state (:54-68), later calls update_estimation (:70-163), like
+ * the reference's callers (S/GazeboA1ROS.cpp:194-198).  a1mpc_reset_ekf_state = constructing the filter anew.
+ *   movement_mode n, foot_force n x 4, R_world n x 9, imu_acc n x 3, imu_ang_vel n x 3, foot_pos_rel / foot_vel_rel n x 12
+ * out: root_pos n x 3, root_lin_vel n x 3, estimated_contacts n x 4.  Host pointers.
+ * The two fullPivHouseholderQr solves with S are one Gauss-Jordan elimination of [S | error_y | C] here (S is symmetric positive definite).
+ */
+a1mpc_status a1mpc_ekf_update_batch(a1mpc_handle h, int32_t n, double dt, int32_t assume_flat_ground, const uint8_t* movement_mode,
+                                    const double* foot_force, const double* R_world, const double* imu_acc, const double* imu_ang_vel,
+                                    const double* foot_pos_rel, const double* foot_vel_rel, double* root_pos_out, double* root_lin_vel_out,
+                                    uint8_t* estimated_contacts_out);
+a1mpc_status a1mpc_reset_ekf_state(a1mpc_handle h);
+
 /* Work-queue order of batches larger than the resident set: history = 1 (default) issues the QPs longest-first by the cost
  * (iterations + factor passes) each one had in the previous solve of this handle with the same n -- the same robots tick after
  * tick; history = 0 is plain index order.  The first solve of a batch size, and the solve after a1mpc_reset_warm_start, run in

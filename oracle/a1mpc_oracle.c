@@ -939,6 +939,126 @@ void orc_leg_state(const double *joint_pos, const double *joint_vel, const doubl
     }
 }
 
+/* ---- N4c: A1BasicEKF (S/A1BasicEKF.cpp:7-163), the 18-state / 28-measurement Kalman filter for base position and velocity -----------
+ * Dense restatement, matrix product by matrix product in the reference's evaluation order (left to right, inner index ascending).
+ * state = [x 18 | P 18x18 row-major | initialised flag] = ORC_EKF_STATE doubles.  The two S.fullPivHouseholderQr().solve() calls (:134,138)
+ * are restated as ONE Gauss-Jordan elimination of [S | error_y | C] without pivoting (S is symmetric positive definite): same solution,
+ * rounding differs from a Householder QR (agreement tested against LAPACK). */
+#define EKF_NS 18
+#define EKF_NM 28
+#define ORC_EKF_STATE (EKF_NS + EKF_NS * EKF_NS + 1)
+static void ekf_C(double *C) {                                       /* :10-17 */
+    memset(C, 0, sizeof(double) * EKF_NM * EKF_NS);
+    for (int i = 0; i < NLEG; ++i)
+        for (int k = 0; k < 3; ++k) {
+            C[(i * 3 + k) * EKF_NS + k] = -1.0;
+            C[(i * 3 + k) * EKF_NS + 6 + i * 3 + k] = 1.0;
+            C[(NLEG * 3 + i * 3 + k) * EKF_NS + 3 + k] = 1.0;
+        }
+    for (int i = 0; i < NLEG; ++i) C[(NLEG * 6 + i) * EKF_NS + 6 + i * 3 + 2] = 1.0;
+}
+void orc_ekf_step(double *state, double dt, int assume_flat_ground, int movement_mode, const double *foot_force, const double *Rw,
+                  const double *imu_acc, const double *imu_ang_vel, const double *foot_pos_rel, const double *foot_vel_rel,
+                  double *root_pos, double *root_lin_vel, uint8_t *estimated_contacts_out) {
+    double *x = state, *P = state + EKF_NS, *inited = state + EKF_NS + EKF_NS * EKF_NS;
+    if (*inited == 0.0) {                                            /* init_state :54-68 */
+        for (int i = 0; i < EKF_NS * EKF_NS; ++i) P[i] = 0.0;
+        for (int i = 0; i < EKF_NS; ++i) P[i * EKF_NS + i] = 1.0 * 3;
+        for (int i = 0; i < EKF_NS; ++i) x[i] = 0.0;
+        x[2] = 0.09;
+        for (int i = 0; i < NLEG; ++i)
+            for (int r = 0; r < 3; ++r)
+                x[6 + i * 3 + r] = (Rw[3 * r] * foot_pos_rel[3 * i] + Rw[3 * r + 1] * foot_pos_rel[3 * i + 1] + Rw[3 * r + 2] * foot_pos_rel[3 * i + 2]) + x[r];
+        *inited = 1.0;
+        for (int r = 0; r < 3; ++r) { root_pos[r] = x[r]; root_lin_vel[r] = x[3 + r]; }   /* the caller's state keeps its previous values in the reference; the filter state is returned here */
+        for (int i = 0; i < NLEG; ++i) estimated_contacts_out[i] = 0;
+        return;
+    }
+    static const double PIMU = 0.01, VIMU = 0.01, PFOOT = 0.01, S_PIMU_REL = 0.001, S_VIMU_REL = 0.1, S_ZFOOT = 0.001;   /* A1BasicEKF.h:15-20 */
+    double A[EKF_NS * EKF_NS] = {0}, B[EKF_NS * 3] = {0}, C[EKF_NM * EKF_NS], Q[EKF_NS] , Rd[EKF_NM], ec[NLEG];
+    for (int i = 0; i < EKF_NS; ++i) A[i * EKF_NS + i] = 1.0;
+    for (int k = 0; k < 3; ++k) { A[k * EKF_NS + 3 + k] = dt; B[(3 + k) * 3 + k] = dt; }            /* :72-73 */
+    ekf_C(C);
+    double u[3];                                                                                      /* :76 */
+    for (int r = 0; r < 3; ++r) u[r] = (Rw[3 * r] * imu_acc[0] + Rw[3 * r + 1] * imu_acc[1] + Rw[3 * r + 2] * imu_acc[2]) + (r == 2 ? -9.81 : 0.0);
+    for (int i = 0; i < NLEG; ++i)                                                                    /* :79-86 */
+        ec[i] = movement_mode == 0 ? 1.0 : fmin(fmax(foot_force[i] / (100.0 - 0.0), 0.0), 1.0);
+    for (int k = 0; k < 3; ++k) { Q[k] = PIMU * dt / 20.0; Q[3 + k] = VIMU * dt * 9.8 / 20.0; }     /* :88-89 */
+    for (int i = 0; i < EKF_NM; ++i) Rd[i] = 1.0;                                                     /* R.setIdentity(), blocks below overwrite every entry */
+    for (int i = 0; i < NLEG; ++i) {                                                                  /* :91-107 */
+        const double w = 1 + (1 - ec[i]) * 1e3;
+        for (int k = 0; k < 3; ++k) {
+            Q[6 + i * 3 + k] = w * dt * PFOOT;
+            Rd[i * 3 + k] = w * S_PIMU_REL;
+            Rd[NLEG * 3 + i * 3 + k] = w * S_VIMU_REL;
+        }
+        Rd[NLEG * 6 + i] = assume_flat_ground ? w * S_ZFOOT : 1e5;                                   /* :42-53, :103-106 */
+    }
+    double xbar[EKF_NS], T[EKF_NS * EKF_NS], Pbar[EKF_NS * EKF_NS];
+    for (int i = 0; i < EKF_NS; ++i) {                                                                /* :111 */
+        double a = 0, b = 0;
+        for (int k = 0; k < EKF_NS; ++k) a += A[i * EKF_NS + k] * x[k];
+        for (int k = 0; k < 3; ++k) b += B[i * 3 + k] * u[k];
+        xbar[i] = a + b;
+    }
+    for (int i = 0; i < EKF_NS; ++i) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int k = 0; k < EKF_NS; ++k) a += A[i * EKF_NS + k] * P[k * EKF_NS + j]; T[i * EKF_NS + j] = a; }
+    for (int i = 0; i < EKF_NS; ++i) for (int j = 0; j < EKF_NS; ++j) {                               /* :112 */
+        double a = 0; for (int k = 0; k < EKF_NS; ++k) a += T[i * EKF_NS + k] * A[j * EKF_NS + k];
+        Pbar[i * EKF_NS + j] = a + (i == j ? Q[i] : 0.0);
+    }
+    double yhat[EKF_NM], y[EKF_NM];
+    for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int k = 0; k < EKF_NS; ++k) a += C[r * EKF_NS + k] * xbar[k]; yhat[r] = a; }   /* :115 */
+    const double wx = imu_ang_vel[0], wy = imu_ang_vel[1], wz = imu_ang_vel[2];
+    for (int i = 0; i < NLEG; ++i) {                                                                  /* :119-128 */
+        const double *fk = foot_pos_rel + 3 * i, *fv = foot_vel_rel + 3 * i;
+        const double sk[3] = {0.0 * fk[0] + -wz * fk[1] + wy * fk[2], wz * fk[0] + 0.0 * fk[1] + -wx * fk[2], -wy * fk[0] + wx * fk[1] + 0.0 * fk[2]};  /* skew(w) fk */
+        const double lv[3] = {-fv[0] - sk[0], -fv[1] - sk[1], -fv[2] - sk[2]};
+        for (int r = 0; r < 3; ++r) {
+            y[i * 3 + r] = Rw[3 * r] * fk[0] + Rw[3 * r + 1] * fk[1] + Rw[3 * r + 2] * fk[2];
+            const double rl = Rw[3 * r] * lv[0] + Rw[3 * r + 1] * lv[1] + Rw[3 * r + 2] * lv[2];
+            y[NLEG * 3 + i * 3 + r] = (1.0 - ec[i]) * x[3 + r] + ec[i] * rl;
+        }
+        y[NLEG * 6 + i] = (1.0 - ec[i]) * (x[2] + fk[2]) + ec[i] * 0;
+    }
+    double CP[EKF_NM * EKF_NS], M[EKF_NM * 47];                       /* M = [S | error_y | C] */
+    for (int r = 0; r < EKF_NM; ++r) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int k = 0; k < EKF_NS; ++k) a += C[r * EKF_NS + k] * Pbar[k * EKF_NS + j]; CP[r * EKF_NS + j] = a; }
+    for (int r = 0; r < EKF_NM; ++r) for (int c = 0; c < EKF_NM; ++c) {                               /* :130 */
+        double a = 0; for (int k = 0; k < EKF_NS; ++k) a += CP[r * EKF_NS + k] * C[c * EKF_NS + k];
+        M[r * 47 + c] = a + (r == c ? Rd[r] : 0.0);
+    }
+    for (int r = 0; r < EKF_NM; ++r) for (int c = r + 1; c < EKF_NM; ++c) {                           /* :131 */
+        const double v = 0.5 * (M[r * 47 + c] + M[c * 47 + r]); M[r * 47 + c] = v; M[c * 47 + r] = v;
+    }
+    for (int r = 0; r < EKF_NM; ++r) { M[r * 47 + r] = 0.5 * (M[r * 47 + r] + M[r * 47 + r]); M[r * 47 + 28] = y[r] - yhat[r]; for (int j = 0; j < EKF_NS; ++j) M[r * 47 + 29 + j] = C[r * EKF_NS + j]; }
+    for (int k = 0; k < EKF_NM; ++k) {                                /* Gauss-Jordan, no pivoting (:133-134,138) */
+        const double pinv = 1.0 / M[k * 47 + k];
+        for (int j = 0; j < 47; ++j) M[k * 47 + j] = M[k * 47 + j] * pinv;
+        for (int i = 0; i < EKF_NM; ++i) if (i != k) {
+            const double f = M[i * 47 + k];
+            for (int j = 0; j < 47; ++j) M[i * 47 + j] = M[i * 47 + j] - f * M[k * 47 + j];
+        }
+    }
+    double G1[EKF_NS * EKF_NM], G2[EKF_NS * EKF_NS];
+    for (int a_ = 0; a_ < EKF_NS; ++a_) for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int k = 0; k < EKF_NS; ++k) a += Pbar[a_ * EKF_NS + k] * C[r * EKF_NS + k]; G1[a_ * EKF_NM + r] = a; }
+    for (int a_ = 0; a_ < EKF_NS; ++a_) {                                                             /* :136 */
+        double a = 0; for (int r = 0; r < EKF_NM; ++r) a += G1[a_ * EKF_NM + r] * M[r * 47 + 28];
+        x[a_] = xbar[a_] + a;
+    }
+    for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int r = 0; r < EKF_NM; ++r) a += G1[a_ * EKF_NM + r] * M[r * 47 + 29 + j]; G2[a_ * EKF_NS + j] = a; }
+    for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) {                            /* :139 */
+        double a = 0; for (int k = 0; k < EKF_NS; ++k) a += G2[a_ * EKF_NS + k] * Pbar[k * EKF_NS + j];
+        T[a_ * EKF_NS + j] = Pbar[a_ * EKF_NS + j] - a;
+    }
+    for (int i = 0; i < EKF_NS; ++i) for (int j = 0; j < EKF_NS; ++j) P[i * EKF_NS + j] = 0.5 * (T[i * EKF_NS + j] + T[j * EKF_NS + i]);   /* :140 */
+    if (P[0] * P[EKF_NS + 1] - P[1] * P[EKF_NS] > 1e-6) {                                             /* :143-147 */
+        for (int i = 0; i < 2; ++i) for (int j = 2; j < EKF_NS; ++j) { P[i * EKF_NS + j] = 0.0; P[j * EKF_NS + i] = 0.0; }
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) P[i * EKF_NS + j] /= 10.0;
+    }
+    for (int i = 0; i < NLEG; ++i) estimated_contacts_out[i] = ec[i] < 0.5 ? 0 : 1;                   /* :151-157 */
+    for (int r = 0; r < 3; ++r) { root_pos[r] = x[r]; root_lin_vel[r] = x[3 + r]; }                   /* :159-163 */
+}
+int orc_ekf_state_doubles(void) { return ORC_EKF_STATE; }
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -456,3 +456,23 @@ def test_leg_state_N4b(pkg, oracle, scen):
         for k, tol in (("foot_pos_rel", 1e-14), ("Jb", 1e-14), ("foot_vel_rel", 1e-13), ("foot_pos_abs", 1e-14), ("foot_vel_abs", 1e-13),
                        ("foot_pos_world", 1e-14), ("foot_vel_world", 1e-13)):
             assert np.abs(out[k][b] - ref[k]).max() <= tol, (b, k, np.abs(out[k][b] - ref[k]).max())
+
+
+def test_ekf_N4c_sequence(pkg, oracle, scen):
+    """A1BasicEKF for 200 robots over 80 ticks, device-resident filter state vs the oracle's dense restatement
+    (S/A1BasicEKF.cpp:54-163).  Same operation order and no contraction: the estimates are compared bit for bit."""
+    rng = np.random.default_rng(51)
+    n, ticks = 200, 80
+    cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+    states = [oracle.ekf_state() for _ in range(n)]
+    base = np.array([0.18, 0.13, -0.3, 0.18, -0.13, -0.3, -0.18, 0.13, -0.3, -0.18, -0.13, -0.3])
+    with pkg.Engine(cfg, n, 0) as eng:
+        for t in range(ticks):
+            mm = np.where(rng.random(n) < 0.8, 1, 0).astype(np.uint8) if t > 3 else np.zeros(n, np.uint8)
+            yaw = rng.uniform(-3, 3, n); eul = rng.normal(0, 0.05, (n, 2)); R = scen.rot_zyx(eul[:, 0], eul[:, 1], yaw).reshape(n, 9)
+            fk = base + rng.normal(0, 0.01, (n, 12)); fv = rng.normal(0, 0.3, (n, 12)); acc = np.array([0.0, 0.0, 9.81]) + rng.normal(0, 0.3, (n, 3))
+            w = rng.normal(0, 0.3, (n, 3)); ff = rng.uniform(0, 160, (n, 4))
+            pos, vel, ec = eng.ekf_update(0.0025, mm, ff, R, acc, w, fk, fv)
+            for b in range(0, n, 3):
+                p_o, v_o, e_o = oracle.ekf_step(states[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b])
+                assert np.array_equal(pos[b], p_o) and np.array_equal(vel[b], v_o) and (ec[b] == e_o).all(), (t, b, pos[b] - p_o, vel[b] - v_o)

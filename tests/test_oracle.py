@@ -217,3 +217,41 @@ def test_leg_state_restatement(oracle):
         pr = o["foot_pos_rel"].reshape(4, 3); vr = np.einsum("lij,lj->li", J, qd.reshape(4, 3))
         assert np.allclose(o["foot_vel_rel"].reshape(4, 3), vr, atol=1e-14) and np.allclose(o["foot_pos_world"].reshape(4, 3), pr @ R.T + pos, atol=1e-14)
         assert np.allclose(o["foot_vel_world"].reshape(4, 3), vr @ R.T + vel, atol=1e-13)
+
+
+def test_ekf_restatement(oracle):
+    """N4c oracle vs an independent numpy Kalman update (numpy.linalg.solve for the two S^-1 products) over a 120-tick sequence"""
+    rng = np.random.default_rng(13)
+    C_ = np.zeros((28, 18))
+    for i in range(4):
+        C_[3 * i:3 * i + 3, 0:3] = -np.eye(3); C_[3 * i:3 * i + 3, 6 + 3 * i:9 + 3 * i] = np.eye(3); C_[12 + 3 * i:15 + 3 * i, 3:6] = np.eye(3); C_[24 + i, 6 + 3 * i + 2] = 1
+    st = oracle.ekf_state(); x = None; P = None
+    for t in range(120):
+        dt = 0.0025; mm = 1 if t > 5 else 0
+        yaw = 0.3 * np.sin(t / 30); R = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1.0]])
+        fk = np.array([0.18, 0.13, -0.3, 0.18, -0.13, -0.3, -0.18, 0.13, -0.3, -0.18, -0.13, -0.3]) + rng.normal(0, 0.01, 12)
+        fv = rng.normal(0, 0.2, 12); acc = np.array([0.1, -0.2, 9.81]) + rng.normal(0, 0.05, 3); w = rng.normal(0, 0.2, 3); ff = rng.uniform(0, 150, 4)
+        pos, vel, ec = oracle.ekf_step(st, dt, mm, ff, R.reshape(9), acc, w, fk, fv)
+        if x is None:
+            x = np.zeros(18); x[2] = 0.09; P = 3 * np.eye(18)
+            for i in range(4): x[6 + 3 * i:9 + 3 * i] = R @ fk[3 * i:3 * i + 3] + x[0:3]
+        else:
+            A = np.eye(18); A[0:3, 3:6] = dt * np.eye(3); B = np.zeros((18, 3)); B[3:6] = dt * np.eye(3)
+            u = R @ acc + [0, 0, -9.81]; e = np.ones(4) if mm == 0 else np.clip(ff / 100.0, 0, 1)
+            Q = np.eye(18); Q[0:3, 0:3] *= 0.01 * dt / 20; Q[3:6, 3:6] *= 0.01 * dt * 9.8 / 20; Rm = np.eye(28)
+            for i in range(4):
+                k = 1 + (1 - e[i]) * 1e3
+                Q[6 + 3 * i:9 + 3 * i, 6 + 3 * i:9 + 3 * i] = k * dt * 0.01 * np.eye(3); Rm[3 * i:3 * i + 3, 3 * i:3 * i + 3] = k * 0.001 * np.eye(3)
+                Rm[12 + 3 * i:15 + 3 * i, 12 + 3 * i:15 + 3 * i] = k * 0.1 * np.eye(3); Rm[24 + i, 24 + i] = k * 0.001
+            xb = A @ x + B @ u; Pb = A @ P @ A.T + Q; y = np.zeros(28)
+            sk = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            for i in range(4):
+                f = fk[3 * i:3 * i + 3]; y[3 * i:3 * i + 3] = R @ f
+                y[12 + 3 * i:15 + 3 * i] = (1 - e[i]) * x[3:6] + e[i] * (R @ (-fv[3 * i:3 * i + 3] - sk @ f)); y[24 + i] = (1 - e[i]) * (x[2] + f[2])
+            S = C_ @ Pb @ C_.T + Rm; S = 0.5 * (S + S.T)
+            x = xb + Pb @ C_.T @ np.linalg.solve(S, y - C_ @ xb); P = Pb - Pb @ C_.T @ np.linalg.solve(S, C_) @ Pb; P = 0.5 * (P + P.T)
+            if np.linalg.det(P[0:2, 0:2]) > 1e-6:
+                P[0:2, 2:] = 0; P[2:, 0:2] = 0; P[0:2, 0:2] /= 10
+            assert (ec == (e >= 0.5)).all()
+        assert np.allclose(pos, x[0:3], atol=1e-10) and np.allclose(vel, x[3:6], atol=1e-10), (t, pos, x[0:3])
+        assert np.allclose(st[18:18 + 324].reshape(18, 18), P, rtol=1e-8, atol=1e-12)
