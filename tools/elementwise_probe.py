@@ -35,4 +35,24 @@ with pkg.Engine(cfg, n, 0) as eng:
     # per tick and robot: inputs 4+4+12+1+1 doubles + 4 bytes, outputs 12+1+1 doubles + 4 bytes, state: 4 header doubles r/w + 1 ring slot r/w per active filter (~7 of 13) + early/recent
     b = 8 * 22 + 4 + 8 * 14 + 4 + 7 * (8 * 8 + 16) + 8 * 16 * 2
     out["N2b contact_terrain (both kernels, steady state: full windows)"] = {"kernel_ms": float(np.median(ms[-5:])), "bytes_per_robot": b, "GB_per_s": n * b / (float(np.median(ms[-5:])) * 1e-3) / 1e9}
+    # N4b leg kinematics, N4a swing legs, N4c EKF
+    q = rng.uniform(-1, 1, (n, 12)); qd = rng.normal(0, 2, (n, 12)); pos = rng.normal(0, 1, (n, 3)); vel = rng.normal(0, 1, (n, 3))
+    ms = []
+    for _ in range(5):
+        leg = eng.leg_state(q, qd, R, pos, vel); ms.append(eng.last_kernel_ms())
+    b = 8 * (12 + 12 + 9 + 3 + 3) + 8 * (36 + 6 * 12)
+    out["N4b leg_state"] = {"kernel_ms": float(np.median(ms[1:])), "bytes_per_robot": b, "GB_per_s": n * b / (float(np.median(ms[1:])) * 1e-3) / 1e9}
+    stt = [np.zeros((n, 12)) for _ in range(3)]; ms = []
+    for _ in range(5):
+        eng.swing_legs(R, leg["foot_pos_abs"], rng.uniform(0, 240, (n, 4)), leg["foot_pos_rel"], *stt); ms.append(eng.last_kernel_ms())
+    b = 8 * (9 + 12 + 4 + 12 + 36) + 8 * (36 + 24)
+    out["N4a swing_legs"] = {"kernel_ms": float(np.median(ms[1:])), "bytes_per_robot": b, "GB_per_s": n * b / (float(np.median(ms[1:])) * 1e-3) / 1e9}
+    ms = []
+    for t in range(6):
+        eng.ekf_update(0.0025, np.ones(n, np.uint8), rng.uniform(0, 150, (n, 4)), R, rng.normal(0, 1, (n, 3)) + [0, 0, 9.81], rng.normal(0, 0.2, (n, 3)), leg["foot_pos_rel"], leg["foot_vel_rel"])
+        ms.append(eng.last_kernel_ms())
+    b = 8 * (4 + 9 + 3 + 3 + 12 + 12) + 1 + 2 * 8 * 343 + 8 * 6 + 4   # inputs + state read and written + outputs
+    fl = 2 * (18 * 18 * 2 + 28 * 18 * 2 + 28 * 28 * 47 + 18 * 28 + 18 * 28 * 18 + 18 * 18 * 18)  # products + elimination, flops per robot
+    out["N4c ekf (init + update kernels)"] = {"kernel_ms": float(np.median(ms[2:])), "bytes_per_robot": b, "GB_per_s": n * b / (float(np.median(ms[2:])) * 1e-3) / 1e9,
+                                              "flops_per_robot": fl, "TFLOP_per_s": n * fl / (float(np.median(ms[2:])) * 1e-3) / 1e12}
 print(json.dumps({"robots": n, "peak_GB_per_s": 8000, "kernels": out}))
