@@ -1138,6 +1138,117 @@ a1mpc_status a1mpc_update_plan_batch(a1mpc_handle h, const a1mpc_gait_config* ga
     return A1MPC_OK;
 }
 
+// ---- device-pointer variants of the caller-side entry points: every array is device-resident, the call is asynchronous on `hip_stream`
+// (NULL = the handle's stream), so a whole control tick -- leg state, EKF, plan, swing legs, contacts / terrain, MPC, joint torques --
+// chains on the GPU without a PCIe hop.  Same kernels as the host-pointer entries.
+#define A1_DEV_PROLOGUE(cond)                                                                               \
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");                                          \
+    if (n < 0 || !(cond)) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");              \
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");      \
+    if (n == 0) return A1MPC_OK;                                                                             \
+    A1_HIP(hipSetDevice(h->device));                                                                         \
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->stream;                           \
+    const size_t N = n;                                                                                      \
+    (void)N
+#define A1_DEV_EPILOGUE()              \
+    A1_HIP(hipGetLastError());         \
+    A1_HIP(hipEventRecord(h->ev1, s)); \
+    h->timed = true; h->last_stream = s; \
+    return A1MPC_OK
+
+a1mpc_status a1mpc_update_plan_batch_device(a1mpc_handle h, const a1mpc_gait_config* gait, int32_t n, const uint8_t* movement_mode,
+                                            double* gait_counter, const double* gait_counter_speed, const double* root_lin_vel, const double* R_z,
+                                            const double* R_world, const double* root_pos, const double* root_lin_vel_d, uint8_t* plan_contacts_out,
+                                            double* rel_out, double* abs_out, double* world_out, void* hip_stream) {
+    A1_DEV_PROLOGUE(gait && movement_mode && gait_counter && gait_counter_speed && root_lin_vel && R_z && R_world && root_pos && root_lin_vel_d && plan_contacts_out);
+    PlanArgs a;
+    a.g = *gait; a.n = n; a.movement_mode = movement_mode; a.gait_counter = gait_counter; a.gait_counter_speed = gait_counter_speed; a.root_lin_vel = root_lin_vel;
+    a.Rz = R_z; a.Rw = R_world; a.root_pos = root_pos; a.root_lin_vel_d = root_lin_vel_d; a.plan_contacts = plan_contacts_out; a.rel = rel_out; a.abs_ = abs_out;
+    a.world = world_out;
+    A1_HIP(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(a1mpc_plan_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    A1_DEV_EPILOGUE();
+}
+a1mpc_status a1mpc_swing_legs_batch_device(a1mpc_handle h, int32_t n, double counter_per_swing, double dt, const double* R_z, const double* foot_pos_abs,
+                                           const double* gait_counter, const double* foot_pos_target_rel, const double* kp_foot_host, const double* kd_foot_host,
+                                           double* foot_pos_start, double* foot_pos_rel_last_time, double* foot_pos_target_last_time, double* foot_pos_cur_out,
+                                           double* foot_forces_kin_out, void* hip_stream) {
+    A1_DEV_PROLOGUE(R_z && foot_pos_abs && gait_counter && foot_pos_target_rel && kp_foot_host && kd_foot_host && foot_pos_start && foot_pos_rel_last_time &&
+                    foot_pos_target_last_time && foot_pos_cur_out && foot_forces_kin_out && dt > 0);
+    SwingArgs a;
+    a.n = n; a.counter_per_swing = counter_per_swing; a.dt = dt;
+    for (int k = 0; k < 3; ++k) { a.kp[k] = kp_foot_host[k]; a.kd[k] = kd_foot_host[k]; }
+    a.Rz = R_z; a.foot_pos_abs = foot_pos_abs; a.gait_counter = gait_counter; a.target_rel = foot_pos_target_rel; a.start = foot_pos_start;
+    a.rel_last = foot_pos_rel_last_time; a.target_last = foot_pos_target_last_time; a.cur_out = foot_pos_cur_out; a.kin_out = foot_forces_kin_out;
+    A1_HIP(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(a1mpc_swing_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    A1_DEV_EPILOGUE();
+}
+a1mpc_status a1mpc_contact_terrain_batch_device(a1mpc_handle h, const a1mpc_contact_config* cfg, int32_t n, const double* gait_counter,
+                                                const uint8_t* plan_contacts, const double* foot_force, const double* foot_pos_abs, const double* root_pos_z,
+                                                double* root_euler_d_pitch, uint8_t* contacts_out, double* foot_pos_recent_contact_out, double* terrain_angle_out,
+                                                void* hip_stream) {
+    A1_DEV_PROLOGUE(cfg && gait_counter && plan_contacts && foot_force && foot_pos_abs && root_pos_z && root_euler_d_pitch && contacts_out &&
+                    foot_pos_recent_contact_out && terrain_angle_out);
+    if (!h->d_ct_state) {
+        A1_HIP(hipMalloc(&h->d_ct_state, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double)));
+        A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double), s));
+    }
+    ContactArgs a;
+    a.n = n; a.counter_per_swing = cfg->counter_per_swing; a.foot_force_low = cfg->foot_force_low; a.use_terrain_adapt = cfg->use_terrain_adapt;
+    a.state = h->d_ct_state; a.gait_counter = gait_counter; a.foot_force = foot_force; a.foot_pos_abs = foot_pos_abs; a.root_pos_z = root_pos_z;
+    a.plan_contacts = plan_contacts; a.pitch_d = root_euler_d_pitch; a.contacts = contacts_out; a.recent_out = foot_pos_recent_contact_out; a.terrain_out = terrain_angle_out;
+    A1_HIP(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(a1mpc_contact_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(a1mpc_terrain_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+    A1_DEV_EPILOGUE();
+}
+a1mpc_status a1mpc_leg_state_batch_device(a1mpc_handle h, int32_t n, const double* joint_pos, const double* joint_vel, const double* R_world,
+                                          const double* root_pos, const double* root_lin_vel, const double* rho_fix_host, const double* rho_opt_host,
+                                          double* foot_pos_rel_out, double* j_foot_blocks_out, double* foot_vel_rel_out, double* foot_pos_abs_out,
+                                          double* foot_vel_abs_out, double* foot_pos_world_out, double* foot_vel_world_out, void* hip_stream) {
+    A1_DEV_PROLOGUE(joint_pos && joint_vel && R_world && root_pos && root_lin_vel && rho_fix_host && rho_opt_host && foot_pos_rel_out && j_foot_blocks_out);
+    LegArgs a;
+    a.n = n;
+    std::memcpy(a.rho_fix, rho_fix_host, sizeof a.rho_fix); std::memcpy(a.rho_opt, rho_opt_host, sizeof a.rho_opt);
+    a.q = joint_pos; a.qd = joint_vel; a.R = R_world; a.pos = root_pos; a.vel = root_lin_vel; a.rel = foot_pos_rel_out; a.Jb = j_foot_blocks_out;
+    a.vrel = foot_vel_rel_out; a.pabs = foot_pos_abs_out; a.vabs = foot_vel_abs_out; a.pworld = foot_pos_world_out; a.vworld = foot_vel_world_out;
+    A1_HIP(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(a1mpc_leg_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    A1_DEV_EPILOGUE();
+}
+a1mpc_status a1mpc_ekf_update_batch_device(a1mpc_handle h, int32_t n, double dt, int32_t assume_flat_ground, const uint8_t* movement_mode,
+                                           const double* foot_force, const double* R_world, const double* imu_acc, const double* imu_ang_vel,
+                                           const double* foot_pos_rel, const double* foot_vel_rel, double* root_pos_out, double* root_lin_vel_out,
+                                           uint8_t* estimated_contacts_out, void* hip_stream) {
+    A1_DEV_PROLOGUE(movement_mode && foot_force && R_world && imu_acc && imu_ang_vel && foot_pos_rel && foot_vel_rel && root_pos_out && root_lin_vel_out &&
+                    estimated_contacts_out && dt > 0);
+    if (!h->d_ekf_state) {
+        A1_HIP(hipMalloc(&h->d_ekf_state, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double)));
+        A1_HIP(hipMemsetAsync(h->d_ekf_state, 0, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double), s));
+    }
+    EkfArgs a;
+    a.n = n; a.dt = dt; a.flat = assume_flat_ground; a.state = h->d_ekf_state; a.mode = movement_mode; a.ff = foot_force; a.R = R_world; a.acc = imu_acc;
+    a.w = imu_ang_vel; a.fk = foot_pos_rel; a.fv = foot_vel_rel; a.pos_out = root_pos_out; a.vel_out = root_lin_vel_out; a.ec_out = estimated_contacts_out;
+    A1_HIP(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((N + 1) / 2)), dim3(64), 0, s, a);
+    A1_DEV_EPILOGUE();
+}
+a1mpc_status a1mpc_joint_torques_batch_device(a1mpc_handle h, int32_t n, const uint8_t* active, const uint8_t* contacts, const double* j_foot_blocks,
+                                              const double* grf, const double* f_kin, const double* km_foot_host, const double* torques_gravity,
+                                              double* joint_torques, void* hip_stream) {
+    A1_DEV_PROLOGUE(active && contacts && j_foot_blocks && grf && f_kin && km_foot_host && torques_gravity && joint_torques);
+    TorqueArgs a;
+    a.n = n; a.active = active; a.contacts = contacts; a.Jb = j_foot_blocks; a.grf = grf; a.fkin = f_kin; a.tg = torques_gravity; a.tau = joint_torques;
+    a.km[0] = km_foot_host[0]; a.km[1] = km_foot_host[1]; a.km[2] = km_foot_host[2];
+    A1_HIP(hipEventRecord(h->ev0, s));
+    hipLaunchKernelGGL(a1mpc_torque_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    A1_DEV_EPILOGUE();
+}
+#undef A1_DEV_PROLOGUE
+#undef A1_DEV_EPILOGUE
+
 const char* a1mpc_status_string(a1mpc_status s) {
     switch (s) {
         case A1MPC_OK: return "ok";

@@ -40,7 +40,8 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
     _fields_ = [("counter_per_swing", C.c_double), ("foot_force_low", C.c_double), ("use_terrain_adapt", C.c_int32)]
 
 
-EXPORTS = ["a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
+EXPORTS = ["a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
+           "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
 
@@ -85,6 +86,13 @@ def load_library(path=None):
     lib.a1mpc_leg_state_batch.argtypes = [vp, i32] + [dp] * 14; lib.a1mpc_leg_state_batch.restype = C.c_int
     lib.a1mpc_ekf_update_batch.argtypes = [vp, i32, C.c_double, i32, u8p, dp, dp, dp, dp, dp, dp, dp, dp, u8p]; lib.a1mpc_ekf_update_batch.restype = C.c_int
     lib.a1mpc_reset_ekf_state.argtypes = [vp]; lib.a1mpc_reset_ekf_state.restype = C.c_int
+    vpp = C.c_void_p
+    lib.a1mpc_update_plan_batch_device.argtypes = [vp, C.POINTER(GaitConfig), i32] + [vpp] * 12 + [vpp]; lib.a1mpc_update_plan_batch_device.restype = C.c_int
+    lib.a1mpc_swing_legs_batch_device.argtypes = [vp, i32, C.c_double, C.c_double] + [vpp] * 4 + [dp, dp] + [vpp] * 5 + [vpp]; lib.a1mpc_swing_legs_batch_device.restype = C.c_int
+    lib.a1mpc_contact_terrain_batch_device.argtypes = [vp, C.POINTER(ContactConfig), i32] + [vpp] * 9 + [vpp]; lib.a1mpc_contact_terrain_batch_device.restype = C.c_int
+    lib.a1mpc_leg_state_batch_device.argtypes = [vp, i32] + [vpp] * 5 + [dp, dp] + [vpp] * 7 + [vpp]; lib.a1mpc_leg_state_batch_device.restype = C.c_int
+    lib.a1mpc_ekf_update_batch_device.argtypes = [vp, i32, C.c_double, i32] + [vpp] * 10 + [vpp]; lib.a1mpc_ekf_update_batch_device.restype = C.c_int
+    lib.a1mpc_joint_torques_batch_device.argtypes = [vp, i32] + [vpp] * 5 + [dp] + [vpp] * 2 + [vpp]; lib.a1mpc_joint_torques_batch_device.restype = C.c_int
     lib.a1mpc_set_schedule.argtypes = [vp, i32]; lib.a1mpc_set_schedule.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
     lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int

@@ -250,6 +250,35 @@ a1mpc_status a1mpc_ekf_update_batch(a1mpc_handle h, int32_t n, double dt, int32_
                                     uint8_t* estimated_contacts_out);
 a1mpc_status a1mpc_reset_ekf_state(a1mpc_handle h);
 
+/*
+ * Device-pointer variants of the caller-side entry points above: every array argument is a device pointer (the small per-call constant
+ * arrays kp / kd / km / rho_fix / rho_opt stay host pointers, they travel as kernel arguments), the call is asynchronous on `hip_stream`
+ * (NULL = the handle's stream).  Together with a1mpc_solve_batch_ticks_device a whole control tick chains on the GPU without a PCIe hop.
+ */
+a1mpc_status a1mpc_update_plan_batch_device(a1mpc_handle h, const a1mpc_gait_config* gait, int32_t n, const uint8_t* d_movement_mode,
+                                            double* d_gait_counter, const double* d_gait_counter_speed, const double* d_root_lin_vel,
+                                            const double* d_R_z, const double* d_R_world, const double* d_root_pos, const double* d_root_lin_vel_d,
+                                            uint8_t* d_plan_contacts_out, double* d_rel_out, double* d_abs_out, double* d_world_out, void* hip_stream);
+a1mpc_status a1mpc_swing_legs_batch_device(a1mpc_handle h, int32_t n, double counter_per_swing, double dt, const double* d_R_z,
+                                           const double* d_foot_pos_abs, const double* d_gait_counter, const double* d_foot_pos_target_rel,
+                                           const double* kp_foot, const double* kd_foot, double* d_foot_pos_start, double* d_foot_pos_rel_last_time,
+                                           double* d_foot_pos_target_last_time, double* d_foot_pos_cur_out, double* d_foot_forces_kin_out, void* hip_stream);
+a1mpc_status a1mpc_contact_terrain_batch_device(a1mpc_handle h, const a1mpc_contact_config* cfg, int32_t n, const double* d_gait_counter,
+                                                const uint8_t* d_plan_contacts, const double* d_foot_force, const double* d_foot_pos_abs,
+                                                const double* d_root_pos_z, double* d_root_euler_d_pitch, uint8_t* d_contacts_out,
+                                                double* d_foot_pos_recent_contact_out, double* d_terrain_angle_out, void* hip_stream);
+a1mpc_status a1mpc_leg_state_batch_device(a1mpc_handle h, int32_t n, const double* d_joint_pos, const double* d_joint_vel, const double* d_R_world,
+                                          const double* d_root_pos, const double* d_root_lin_vel, const double* rho_fix, const double* rho_opt,
+                                          double* d_foot_pos_rel_out, double* d_j_foot_blocks_out, double* d_foot_vel_rel_out, double* d_foot_pos_abs_out,
+                                          double* d_foot_vel_abs_out, double* d_foot_pos_world_out, double* d_foot_vel_world_out, void* hip_stream);
+a1mpc_status a1mpc_ekf_update_batch_device(a1mpc_handle h, int32_t n, double dt, int32_t assume_flat_ground, const uint8_t* d_movement_mode,
+                                           const double* d_foot_force, const double* d_R_world, const double* d_imu_acc, const double* d_imu_ang_vel,
+                                           const double* d_foot_pos_rel, const double* d_foot_vel_rel, double* d_root_pos_out, double* d_root_lin_vel_out,
+                                           uint8_t* d_estimated_contacts_out, void* hip_stream);
+a1mpc_status a1mpc_joint_torques_batch_device(a1mpc_handle h, int32_t n, const uint8_t* d_active, const uint8_t* d_contacts, const double* d_j_foot_blocks,
+                                              const double* d_grf, const double* d_f_kin, const double* km_foot, const double* d_torques_gravity,
+                                              double* d_joint_torques, void* hip_stream);
+
 /* Work-queue order of batches larger than the resident set: history = 1 (default) issues the QPs longest-first by the cost
  * (iterations + factor passes) each one had in the previous solve of this handle with the same n -- the same robots tick after
  * tick; history = 0 is plain index order.  The first solve of a batch size, and the solve after a1mpc_reset_warm_start, run in

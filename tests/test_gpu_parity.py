@@ -476,3 +476,66 @@ def test_ekf_N4c_sequence(pkg, oracle, scen):
             for b in range(0, n, 3):
                 p_o, v_o, e_o = oracle.ekf_step(states[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b])
                 assert np.array_equal(pos[b], p_o) and np.array_equal(vel[b], v_o) and (ec[b] == e_o).all(), (t, b, pos[b] - p_o, vel[b] - v_o)
+
+
+def test_device_pointer_tick_matches_host_pointer_tick(pkg, scen):
+    """The *_device variants of the caller-side entry points chained on the GPU (torch tensors, one stream, no host copies between the
+    stages) give bit for bit what the host-pointer entries give: leg state -> EKF -> plan -> swing legs -> contacts / terrain -> MPC
+    (tick records) -> joint torques, three ticks, 256 robots."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(99)
+    n, h = 256, 10
+    P = scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS
+    cfg = pkg.make_config(P, h, warm_start=0)
+    dev = torch.device("cuda", 0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    km = np.array([0.1, 0.1, 0.04]); kp = np.array([300.0, 400.0, 400.0]); kd = np.array([8.0, 8.0, 8.0]); dp_ = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    with pkg.Engine(cfg, n, 0) as eh, pkg.Engine(cfg, n, 0) as ed:
+        gait = pkg.engine.GaitConfig(); ed.lib.a1mpc_default_gait_config(C.byref(gait)); ccfg = pkg.engine.ContactConfig(); ed.lib.a1mpc_default_contact_config(C.byref(ccfg))
+        fix = np.ascontiguousarray(eh.A1_RHO_FIX); opt = np.zeros((4, 3))
+        st_h = dict(gc=np.tile([0.0, 120.0, 120.0, 0.0], (n, 1)), start=np.zeros((n, 12)), rl=np.zeros((n, 12)), tl=np.zeros((n, 12)), pitch=np.zeros(n), tau=np.zeros((n, 12)))
+        st_d = {k: T(v) for k, v in st_h.items()}
+        st = torch.cuda.Stream(device=dev); sp = C.c_void_p(st.cuda_stream)
+        for t in range(3):
+            q = rng.uniform(-0.8, 0.8, (n, 12)); qd = rng.normal(0, 1, (n, 12)); eul = rng.normal(0, 0.05, (n, 3)); eul[:, 2] = rng.uniform(-1, 1, n)
+            R = scen.rot_zyx(eul[:, 0], eul[:, 1], eul[:, 2]).reshape(n, 9); Rz = scen.rot_zyx(0 * eul[:, 0], 0 * eul[:, 0], eul[:, 2]).reshape(n, 9)
+            acc = np.array([0, 0, 9.81]) + rng.normal(0, 0.2, (n, 3)); w = rng.normal(0, 0.2, (n, 3)); ff = rng.uniform(0, 120, (n, 4)); mm = np.ones(n, np.uint8)
+            vd = np.c_[rng.uniform(-0.4, 0.4, (n, 2)), np.zeros(n)]; wd = np.c_[np.zeros((n, 2)), rng.uniform(-0.4, 0.4, n)]; spd = np.full((n, 4), 2.0); tg = rng.normal(0, 0.5, (n, 12))
+            act = np.ones(n, np.uint8)
+            # ---- host-pointer chain
+            leg = eh.leg_state(q, qd, R, np.zeros((n, 3)), np.zeros((n, 3)))
+            pos, vel, ec = eh.ekf_update(0.0025, mm, ff, R, acc, w, leg["foot_pos_rel"], leg["foot_vel_rel"])
+            up = eh.update_plan(mm, st_h["gc"], spd, vel, Rz, R, pos, vd); st_h["gc"] = up["gait_counter"]
+            cur, kin = eh.swing_legs(Rz, leg["foot_pos_abs"], st_h["gc"], up["foot_pos_target_rel"], st_h["start"], st_h["rl"], st_h["tl"])
+            ctr = eh.contact_terrain(st_h["gc"], up["plan_contacts"], ff, leg["foot_pos_abs"], pos[:, 2], st_h["pitch"]); st_h["pitch"] = ctr["root_euler_d_pitch"]
+            tick = scen.pack_tick(eul, pos, w, vel, np.c_[np.zeros(n), st_h["pitch"], eul[:, 2]], vd, wd, np.full(n, 0.3))
+            sol = eh.solve_ticks(tick, R, leg["foot_pos_abs"], ctr["contacts"])
+            st_h["tau"] = eh.joint_torques(act, ctr["contacts"], leg["Jb"], sol["grf"], kin, km, tg, st_h["tau"])
+            # ---- device-pointer chain (same inputs uploaded once per tick, everything else stays on the GPU)
+            with torch.cuda.stream(st):
+                d = {k: T(v) for k, v in dict(q=q, qd=qd, R=R, Rz=Rz, acc=acc, w=w, ff=ff, mm=mm, vd=vd, wd=wd, spd=spd, tg=tg, act=act, eul=eul, z0=np.zeros((n, 3))).items()}
+                o = {k: torch.zeros((n, m), dtype=torch.float64, device=dev) for k, m in dict(rel=12, Jb=36, vrel=12, pabs=12, vabs=12, pw=12, vw=12, pos=3, vel=3, trel=12, tabs=12,
+                                                                                             tworld=12, cur=12, kin=12, rec=12, grf=12).items()}
+                ec_d = torch.zeros((n, 4), dtype=torch.uint8, device=dev); pc_d = torch.zeros((n, 4), dtype=torch.uint8, device=dev); ct_d = torch.zeros((n, 4), dtype=torch.uint8, device=dev)
+                ta_d = torch.zeros(n, dtype=torch.float64, device=dev); it_d = torch.zeros(n, dtype=torch.int32, device=dev); stt_d = torch.zeros(n, dtype=torch.int32, device=dev)
+                L = ed.lib
+                assert L.a1mpc_leg_state_batch_device(ed._h, n, ptr(d["q"]), ptr(d["qd"]), ptr(d["R"]), ptr(d["z0"]), ptr(d["z0"]), dp_(fix), dp_(opt), ptr(o["rel"]), ptr(o["Jb"]),
+                                                      ptr(o["vrel"]), ptr(o["pabs"]), ptr(o["vabs"]), ptr(o["pw"]), ptr(o["vw"]), sp) == 0
+                assert L.a1mpc_ekf_update_batch_device(ed._h, n, 0.0025, 1, ptr(d["mm"]), ptr(d["ff"]), ptr(d["R"]), ptr(d["acc"]), ptr(d["w"]), ptr(o["rel"]), ptr(o["vrel"]),
+                                                       ptr(o["pos"]), ptr(o["vel"]), ptr(ec_d), sp) == 0
+                assert L.a1mpc_update_plan_batch_device(ed._h, C.byref(gait), n, ptr(d["mm"]), ptr(st_d["gc"]), ptr(d["spd"]), ptr(o["vel"]), ptr(d["Rz"]), ptr(d["R"]), ptr(o["pos"]),
+                                                        ptr(d["vd"]), ptr(pc_d), ptr(o["trel"]), ptr(o["tabs"]), ptr(o["tworld"]), sp) == 0
+                assert L.a1mpc_swing_legs_batch_device(ed._h, n, 120.0, 0.0025, ptr(d["Rz"]), ptr(o["pabs"]), ptr(st_d["gc"]), ptr(o["trel"]), dp_(kp), dp_(kd), ptr(st_d["start"]),
+                                                       ptr(st_d["rl"]), ptr(st_d["tl"]), ptr(o["cur"]), ptr(o["kin"]), sp) == 0
+                pz = o["pos"][:, 2].contiguous()
+                assert L.a1mpc_contact_terrain_batch_device(ed._h, C.byref(ccfg), n, ptr(st_d["gc"]), ptr(pc_d), ptr(d["ff"]), ptr(o["pabs"]), ptr(pz), ptr(st_d["pitch"]), ptr(ct_d),
+                                                            ptr(o["rec"]), ptr(ta_d), sp) == 0
+                zc = torch.zeros(n, dtype=torch.float64, device=dev)
+                tick_d = torch.cat([d["eul"], o["pos"], d["w"], o["vel"], torch.stack([zc, st_d["pitch"], d["eul"][:, 2]], 1), d["vd"], d["wd"], torch.full((n, 1), 0.3, dtype=torch.float64, device=dev)], 1).contiguous()
+                assert L.a1mpc_solve_batch_ticks_device(ed._h, n, ptr(tick_d), ptr(d["R"]), ptr(o["pabs"]), ptr(ct_d), ptr(o["grf"]), None, ptr(it_d), ptr(stt_d), sp) == 0
+                assert L.a1mpc_joint_torques_batch_device(ed._h, n, ptr(d["act"]), ptr(ct_d), ptr(o["Jb"]), ptr(o["grf"]), ptr(o["kin"]), dp_(km), ptr(d["tg"]), ptr(st_d["tau"]), sp) == 0
+            st.synchronize()
+            assert np.array_equal(st_d["tau"].cpu().numpy(), st_h["tau"]), (t, np.abs(st_d["tau"].cpu().numpy() - st_h["tau"]).max())
+            assert np.array_equal(o["pos"].cpu().numpy(), pos) and np.array_equal(ct_d.cpu().numpy(), ctr["contacts"]) and np.array_equal(it_d.cpu().numpy(), sol["iters"])
