@@ -38,6 +38,24 @@ __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
     solve_row<H, MODE>(a.P, a.tab, io, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
 }
 
+// Latency variant of the fused kernel for a handful of QPs: the four rows of a wavefront work on ONE QP during set-up (each takes every fourth
+// horizon step of the Ruiz sweeps; everything else is computed redundantly and written to the one shared LDS image), then rows 1-3 retire
+// and row 0 solves.  Same results bit for bit (the column maxima are exact and order-free).
+template <int H>
+__global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
+    const int row = static_cast<int>(threadIdx.x) >> 4;
+    const int64_t b = static_cast<int64_t>(blockIdx.x);
+    const ProblemIO io = make_io<H, kModeMpc>(a, b);
+    RowSolver<H, kModeMpc> S(a.P, a.tab, a1mpc_lds);
+    S.coop_id = row; S.coop_n = 4;
+    S.setup(io);
+    if (row != 0) return;
+    S.coop_id = 0; S.coop_n = 1;
+    S.solve();
+    S.write_outputs(io);
+}
+
 // ---- split pipeline (large batches) -----------------------------------------------------------------------------
 // K1: formation + Ruiz, 4 QPs per wavefront, 2.8 KB of LDS per QP (H = 10) -> many waves per CU hide the sweep's latency.
 template <int H>
@@ -260,8 +278,27 @@ static a1mpc_status launch_rows(const KernelArgs& a, hipStream_t stream) {
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
 }
+static constexpr int kCoopMaxBatch = 256;  // at most this many QPs: one wavefront per QP during set-up (the chip has 1024 SIMDs)
+template <int H>
+static a1mpc_status launch_coop(const KernelArgs& a, hipStream_t stream) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    A1_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_coop_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds_bytes<H>(1))));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((a1mpc_solve_coop_kernel<H>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds_bytes<H>(1), stream, a);
+    A1_HIP(hipGetLastError());
+    return A1MPC_OK;
+}
 template <int H, int MODE>
 static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
+    if constexpr (MODE == kModeMpc && H > 1) {
+        static const bool coop = [] { const char* e = getenv("A1MPC_COOP_SETUP"); return !(e && !strcmp(e, "0")); }();
+        if (coop && a.n <= kCoopMaxBatch) return launch_coop<H>(a, stream);
+    }
     switch (rows_per_wg()) {
         case 1: return launch_rows<H, MODE, 1>(a, stream);
         case 2: return launch_rows<H, MODE, 2>(a, stream);

@@ -150,7 +150,8 @@ struct Layout {
     // set-up-only aliases inside the factor region (the factor is written after Ruiz is finished)
     static constexpr int TBL = 0;            // T*B~_omega (3x12)
     static constexpr int DL = 36;            // D table of the current Ruiz pass, [t][12]
-    static_assert(DL + 12 * H <= H * SLOT, "alias");
+    static constexpr int COOP = DL + 12 * H;  // [row][s][16 lanes] partial column maxima of a set-up shared by the four rows of a wave (RowSolver::coop_n)
+    static_assert(COOP + 4 * H * 16 <= H * SLOT, "alias");
     // row stride mod 32 in {3,4,9,10,16,22,23,28,29}: the two QPs that share a 32-lane LDS phase then read the
     // stride-13 rows of K_t from disjoint banks; even, so that 16-byte alignment survives.  H = 10: 2532 doubles,
     // 4 x 2532 x 8 B = 81,024 B per workgroup -> two workgroups per CU (160 KiB).
@@ -169,6 +170,7 @@ struct LayoutSetup {
     static constexpr int KSTR = 13, K_SZ = 12 * KSTR, S_SZ = 78, SLOT = K_SZ + S_SZ, FAC = 0, GCOL = 12;  // unused by the set-up code paths
     static constexpr int TBL = 0;
     static constexpr int DL = 36;
+    static constexpr int COOP = 0;  // never used by the set-up kernel (one row per QP)
     static constexpr int BL = DL + 12 * H;
     static constexpr int ZROW = 6;
     static constexpr int CG = BL + 84;
@@ -224,6 +226,7 @@ struct RowSolver {
     double xh[H], wh0[H], wh1[H], rr0[H], rr1[H], dI2[H];
     double rho;
     bool warm, first_special;
+    int coop_id = 0, coop_n = 1;  // set-up only: row coop_id of coop_n rows of the wave that work on the SAME QP (batch-1 latency path), sharing its LDS image
     bool careful;  // rho is small: c P x + c g is carried through the x-update identity (G in LDS) instead of re-evaluated at the checkpoints
     const double* warm_y_in;
     // bookkeeping
@@ -453,7 +456,7 @@ struct RowSolver {
                     mm[S] = (ad * Ud + bd * Vd + r2a) * D[S];
                 });
 #pragma unroll 1
-                for (int t = 0; t < H; ++t) {
+                for (int t = coop_id; t < H; t += coop_n) {
                     // all loads of this t first (table column + D row): one wait instead of one per block
                     double gb[2 * H], Dt[12];
 #pragma unroll
@@ -475,6 +478,12 @@ struct RowSolver {
                             mm[S] = fmax(mm[S], bet * fmax(a0, a1));
                         }
                     });
+                }
+                if (coop_n > 1) {  // each row of the wave visited every coop_n-th t: the column maxima are the maxima over the rows (exact, order-free)
+                    static_for<H>([&](auto S) { lds[L::COOP + (coop_id * H + A1_CV(S)) * 16 + ln] = mm[S]; });
+                    row_sync();
+                    for (int r = 0; r < coop_n; ++r)
+                        static_for<H>([&](auto S) { mm[S] = fmax(mm[S], lds[L::COOP + (r * H + A1_CV(S)) * 16 + ln]); });
                 }
             };
             sweep(m);
