@@ -116,6 +116,71 @@ def warm_tick_probe(pkg, local, n=4096, ticks=12):
             "ticks_per_s_x_robots": n / (float(np.median(ms[4:])) * 1e-3), "mean_iters_cold_first_tick": iters[0], "mean_iters_warm": float(np.mean(iters[4:]))}
 
 
+def full_tick_probe(pkg, local, n=4096, ticks=10):
+    """Extra information (not `value`): one whole control tick per robot chained on the GPU through the *_device entry points -- leg state,
+    EKF, gait plan, swing legs, contacts / terrain, warm-started MPC (tick records), joint torques -- sensors resident in HBM, one stream."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", local); st = torch.cuda.Stream(device=dev); sp = C.c_void_p(st.cuda_stream)
+    rng = np.random.default_rng(7); scen = pkg.scenarios
+    P = scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS
+    cfg = pkg.make_config(P, HORIZON, warm_start=1)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    dp_ = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    km = np.array([0.1, 0.1, 0.04]); kp = np.array([300.0, 400.0, 400.0]); kd = np.array([8.0, 8.0, 8.0]); opt = np.zeros((4, 3))
+    eul = rng.normal(0, 0.03, (n, 3)); eul[:, 2] = rng.uniform(-1, 1, n)
+    q0 = np.tile([0.0, 0.8, -1.6], (n, 4)) + rng.normal(0, 0.05, (n, 12))
+    d = {k: T(v) for k, v in dict(q=q0, qd=rng.normal(0, 0.3, (n, 12)), R=scen.rot_zyx(eul[:, 0], eul[:, 1], eul[:, 2]).reshape(n, 9),
+                                  Rz=scen.rot_zyx(0 * eul[:, 0], 0 * eul[:, 0], eul[:, 2]).reshape(n, 9), acc=np.array([0, 0, 9.81]) + rng.normal(0, 0.1, (n, 3)),
+                                  w=rng.normal(0, 0.1, (n, 3)), ff=rng.uniform(20, 120, (n, 4)), mm=np.ones(n, np.uint8), vd=np.c_[rng.uniform(-0.3, 0.3, (n, 2)), np.zeros(n)],
+                                  wd=np.c_[np.zeros((n, 2)), rng.uniform(-0.3, 0.3, n)], spd=np.full((n, 4), 2.0), tg=rng.normal(0, 0.3, (n, 12)), act=np.ones(n, np.uint8),
+                                  eul=eul, z0=np.zeros((n, 3)), gc=np.tile([0.0, 120.0, 120.0, 0.0], (n, 1)), start=np.zeros((n, 12)), rl=np.zeros((n, 12)), tl=np.zeros((n, 12)),
+                                  pitch=np.zeros(n), tau=np.zeros((n, 12))).items()}
+    o = {k: torch.zeros((n, m), dtype=torch.float64, device=dev) for k, m in dict(rel=12, Jb=36, vrel=12, pabs=12, vabs=12, pw=12, vw=12, pos=3, vel=3, trel=12, tabs=12, tworld=12,
+                                                                                 cur=12, kin=12, rec=12, grf=12, tick=22).items()}
+    u8 = {k: torch.zeros((n, 4), dtype=torch.uint8, device=dev) for k in ("ec", "pc", "ct")}
+    ta = torch.zeros(n, dtype=torch.float64, device=dev); pz = torch.zeros(n, dtype=torch.float64, device=dev)
+    it = torch.zeros(n, dtype=torch.int32, device=dev); stt = torch.zeros(n, dtype=torch.int32, device=dev)
+    with pkg.Engine(cfg, n, local) as eng:
+        L, H_ = eng.lib, eng._h
+        gait = pkg.engine.GaitConfig(); L.a1mpc_default_gait_config(C.byref(gait)); cc = pkg.engine.ContactConfig(); L.a1mpc_default_contact_config(C.byref(cc))
+        fix = np.ascontiguousarray(eng.A1_RHO_FIX)
+
+        def tick():
+            rcs = [L.a1mpc_leg_state_batch_device(H_, n, ptr(d["q"]), ptr(d["qd"]), ptr(d["R"]), ptr(d["z0"]), ptr(d["z0"]), dp_(fix), dp_(opt), ptr(o["rel"]), ptr(o["Jb"]), ptr(o["vrel"]),
+                                                  ptr(o["pabs"]), ptr(o["vabs"]), ptr(o["pw"]), ptr(o["vw"]), sp),
+                   L.a1mpc_ekf_update_batch_device(H_, n, 0.0025, 1, ptr(d["mm"]), ptr(d["ff"]), ptr(d["R"]), ptr(d["acc"]), ptr(d["w"]), ptr(o["rel"]), ptr(o["vrel"]), ptr(o["pos"]),
+                                                   ptr(o["vel"]), ptr(u8["ec"]), sp),
+                   L.a1mpc_update_plan_batch_device(H_, C.byref(gait), n, ptr(d["mm"]), ptr(d["gc"]), ptr(d["spd"]), ptr(o["vel"]), ptr(d["Rz"]), ptr(d["R"]), ptr(o["pos"]), ptr(d["vd"]),
+                                                    ptr(u8["pc"]), ptr(o["trel"]), ptr(o["tabs"]), ptr(o["tworld"]), sp),
+                   L.a1mpc_swing_legs_batch_device(H_, n, 120.0, 0.0025, ptr(d["Rz"]), ptr(o["pabs"]), ptr(d["gc"]), ptr(o["trel"]), dp_(kp), dp_(kd), ptr(d["start"]), ptr(d["rl"]),
+                                                   ptr(d["tl"]), ptr(o["cur"]), ptr(o["kin"]), sp)]
+            with torch.cuda.stream(st):
+                pz.copy_(o["pos"][:, 2])
+            rcs.append(L.a1mpc_contact_terrain_batch_device(H_, C.byref(cc), n, ptr(d["gc"]), ptr(u8["pc"]), ptr(d["ff"]), ptr(o["pabs"]), ptr(pz), ptr(d["pitch"]), ptr(u8["ct"]),
+                                                            ptr(o["rec"]), ptr(ta), sp))
+            with torch.cuda.stream(st):  # the 22-number tick record of a1mpc_solve_batch_ticks, assembled on the device
+                o["tick"][:, 0:3] = d["eul"]; o["tick"][:, 3:6] = o["pos"]; o["tick"][:, 6:9] = d["w"]; o["tick"][:, 9:12] = o["vel"]
+                o["tick"][:, 12] = 0.0; o["tick"][:, 13] = d["pitch"]; o["tick"][:, 14] = d["eul"][:, 2]; o["tick"][:, 15:18] = d["vd"]; o["tick"][:, 18:21] = d["wd"]; o["tick"][:, 21] = 0.3
+            rcs.append(L.a1mpc_solve_batch_ticks_device(H_, n, ptr(o["tick"]), ptr(d["R"]), ptr(o["pabs"]), ptr(u8["ct"]), ptr(o["grf"]), None, ptr(it), ptr(stt), sp))
+            rcs.append(L.a1mpc_joint_torques_batch_device(H_, n, ptr(d["act"]), ptr(u8["ct"]), ptr(o["Jb"]), ptr(o["grf"]), ptr(o["kin"]), dp_(km), ptr(d["tg"]), ptr(d["tau"]), sp))
+            assert not any(rcs), rcs
+
+        for _ in range(4):
+            tick()
+        st.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(ticks):
+            tick()
+        e1.record(st)
+        st.synchronize()
+        ms = e0.elapsed_time(e1) / ticks
+    return {"workload": "4096 robots: leg state + EKF + gait plan + swing legs + contacts/terrain + warm-started MPC (h=10) + joint torques per tick, device-resident",
+            "ms_per_tick": ms, "robot_ticks_per_s": n / (ms * 1e-3), "mean_mpc_iters": float(it.float().mean().item())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +303,7 @@ def main():
             out["latency"] = latency_probe(pkg)
             out["throughput_by_batch"] = batch_sweep(pkg, local)
             out["warm_start_ticks"] = warm_tick_probe(pkg, local)
+            out["full_control_tick"] = full_tick_probe(pkg, local)
         if not args.no_cpu_baseline:
             out["cpu_baseline"], _ = cpu_baseline(pkg, sc)
         print(json.dumps(out), flush=True)
