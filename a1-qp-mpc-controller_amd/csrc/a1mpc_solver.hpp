@@ -151,7 +151,7 @@ struct Layout {
     static constexpr int TBL = 0;            // T*B~_omega (3x12)
     static constexpr int DL = 36;            // D table of the current Ruiz pass, [t][12]
     static constexpr int COOP = DL + 12 * H;  // [row][s][16 lanes] partial column maxima of a set-up shared by the four rows of a wave (RowSolver::coop_n)
-    static_assert(COOP + 4 * H * 16 <= H * SLOT, "alias");
+    static_assert(COOP + 8 * H * 16 <= H * SLOT || H == 1, "alias");  // + the D / E0 / E1 / m tables of the shared Ruiz update
     // row stride mod 32 in {3,4,9,10,16,22,23,28,29}: the two QPs that share a 32-lane LDS phase then read the
     // stride-13 rows of K_t from disjoint banks; even, so that 16-byte alignment survives.  H = 10: 2532 doubles,
     // 4 x 2532 x 8 B = 81,024 B per workgroup -> two workgroups per CU (160 KiB).
@@ -489,18 +489,41 @@ struct RowSolver {
             sweep(m);
 #pragma unroll 1
             for (int pass = 0; pass < P.scaling_iters; ++pass) {
-                static_for<H>([&](auto T) {
-                    const double Dz = quad_perm<2, 2, 2, 2>(D[T]);
-                    const double mE = fmax(E0[T], E1[T]);
+                // one Ruiz step of horizon step T (scaling.c scale_data: column norms of [P A'; A 0] -> D, row norms -> E)
+                auto ruiz_step = [&](double& Dt_, double& E0t, double& E1t, double mt) {
+                    const double Dz = quad_perm<2, 2, 2, 2>(Dt_);
+                    const double mE = fmax(E0t, E1t);
                     const double mEx = quad_perm<0, 0, 0, 0>(mE), mEy = quad_perm<1, 1, 1, 1>(mE);
-                    const double colA = D[T] * (comp == 2 ? fmax(mu * fmax(mEx, mEy), E0[T]) : mE);
-                    const double colP = csc * D[T] * m[T];
+                    const double colA = Dt_ * (comp == 2 ? fmax(mu * fmax(mEx, mEy), E0t) : mE);
+                    const double colP = csc * Dt_ * mt;
                     const double dtmp = 1.0 / sqrt(limit_scaling(fmax(colP, colA)));
-                    const double rowf = comp == 2 ? D[T] : fmax(D[T], mu * Dz);
-                    const double e0 = 1.0 / sqrt(limit_scaling(E0[T] * rowf));
-                    const double e1 = 1.0 / sqrt(limit_scaling(E1[T] * rowf));
-                    D[T] *= dtmp; E0[T] *= e0; E1[T] *= e1;
-                });
+                    const double rowf = comp == 2 ? Dt_ : fmax(Dt_, mu * Dz);
+                    const double e0 = 1.0 / sqrt(limit_scaling(E0t * rowf));
+                    const double e1 = 1.0 / sqrt(limit_scaling(E1t * rowf));
+                    Dt_ *= dtmp; E0t *= e0; E1t *= e1;
+                };
+                if (coop_n > 1) {
+                    // latency variant: the rows of the wave take every coop_n-th horizon step; the tables meet in the shared LDS image
+                    double* tb = lds + L::COOP + 4 * H * 16;  // [4 tables: D, E0, E1, m][H][16 lanes]
+                    static_for<H>([&](auto T) {
+                        constexpr int t = A1_CV(T);
+                        if (coop_id == 0) { tb[(0 * H + t) * 16 + ln] = D[t]; tb[(1 * H + t) * 16 + ln] = E0[t]; tb[(2 * H + t) * 16 + ln] = E1[t]; tb[(3 * H + t) * 16 + ln] = m[t]; }
+                    });
+                    row_sync();
+#pragma unroll 1
+                    for (int t = coop_id; t < H; t += coop_n) {
+                        double Dt_ = tb[(0 * H + t) * 16 + ln], E0t = tb[(1 * H + t) * 16 + ln], E1t = tb[(2 * H + t) * 16 + ln];
+                        ruiz_step(Dt_, E0t, E1t, tb[(3 * H + t) * 16 + ln]);
+                        tb[(0 * H + t) * 16 + ln] = Dt_; tb[(1 * H + t) * 16 + ln] = E0t; tb[(2 * H + t) * 16 + ln] = E1t;
+                    }
+                    row_sync();
+                    static_for<H>([&](auto T) {
+                        constexpr int t = A1_CV(T);
+                        D[t] = tb[(0 * H + t) * 16 + ln]; E0[t] = tb[(1 * H + t) * 16 + ln]; E1[t] = tb[(2 * H + t) * 16 + ln];
+                    });
+                } else {
+                    static_for<H>([&](auto T) { ruiz_step(D[T], E0[T], E1[T], m[T]); });
+                }
                 sweep(m);
                 double sum = 0.0, nq = 0.0;
 #pragma unroll
