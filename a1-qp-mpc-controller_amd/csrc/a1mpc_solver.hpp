@@ -1,4 +1,4 @@
-// a1mpc_solver.hpp -- one convex-MPC QP per DPP row (16 lanes), four QPs per wavefront.
+// a1mpc_solver.hpp -- one convex-MPC QP per DPP row (16 lanes), two (one, four) QPs per wavefront.
 //
 // What it computes (reference behaviour, cited as S/ = src/a1_cpp/src/ of the reference tree):
 //   * QP formation of ConvexMpc (S/ConvexMpc.cpp:110-156 A_c/B_c/Euler discretisation, :181-245
@@ -19,10 +19,16 @@
 //     (P + sigma I + A' rho A) x = b is an LQ problem solved by a Riccati recursion: per step a 12x12
 //     feedback K_t and a 12x12 S_t^{-1} (234 doubles) live in LDS, 18.7 KB per QP at H = 10.
 //   * Lane map inside a row: a 3-vector per quad.  Force layout: lane 4*leg+c holds f_{leg,c}; state
-//     layout: quads hold (rpy, pos, omega, vel).  12x12 mat-vecs are 12 x (row_newbcast DPP + v_fmac_f64)
-//     with the matrix row read from LDS; the same LDS image serves K x (row read) and K' r (column read).
-//   * ADMM vectors (x, z, y, D, E, q: 10 doubles per horizon step and lane) stay in VGPRs for the whole
-//     solve; all horizon loops over them are fully unrolled (template H), the Riccati factor loop is not.
+//     layout: quads hold (rpy, pos, omega, vel).  12x12 mat-vecs are 12 x v_fmac_f64_dpp row_newbcast (broadcast
+//     and FMA in one instruction) with the matrix row read from LDS; the same LDS image serves K x (row read)
+//     and K' r (column read).  The two Riccati sweeps of an ADMM iteration are monolithic instruction blocks
+//     (csrc/gfx950/a1mpc_rowops.hpp: sweep_back_rhs / sweep_back_chains / sweep_fwd_gain / sweep_fwd_input).
+//   * The ADMM state is carried unscaled in the w form (xh, wh0, wh1, rr0, rr1, sigma-term: 6 doubles per horizon
+//     step and lane, + d_t between the sweeps) in VGPRs for the whole solve; all horizon loops over them are fully
+//     unrolled (template H), the Riccati factor loop is not.  While rho is small the iterations also carry
+//     G = c P x + c g through the x-update identity (RowSolver::careful).
+//   * Drivers: solve_row (fused: set-up + solve, also the latency variant whose four rows share one QP's Ruiz
+//     passes, RowSolver::coop_n), setup_row + admm_rows (split pipeline: persistent rows drain a work queue).
 //
 // Everything is IEEE double, like the reference (Eigen double, OSQP c_float = double).
 #pragma once
@@ -152,9 +158,9 @@ struct Layout {
     static constexpr int DL = 36;            // D table of the current Ruiz pass, [t][12]
     static constexpr int COOP = DL + 12 * H;  // [row][s][16 lanes] partial column maxima of a set-up shared by the four rows of a wave (RowSolver::coop_n)
     static_assert(COOP + 8 * H * 16 <= H * SLOT || H == 1, "alias");  // + the D / E0 / E1 / m tables of the shared Ruiz update
-    // row stride mod 32 in {3,4,9,10,16,22,23,28,29}: the two QPs that share a 32-lane LDS phase then read the
-    // stride-13 rows of K_t from disjoint banks; even, so that 16-byte alignment survives.  H = 10: 2532 doubles,
-    // 4 x 2532 x 8 B = 81,024 B per workgroup -> two workgroups per CU (160 KiB).
+    // row stride mod 32 in {4,10,16,22,28}: the two QPs that share a 32-lane LDS phase then read the stride-13 rows of K_t
+    // from disjoint banks; even, so that 16-byte alignment survives.  H = 10: 2544 doubles = 20,352 B per QP -> eight QPs
+    // per CU (160 KiB): four workgroups of two rows.
     static constexpr int stride_for(int raw) {
         for (int s = raw;; ++s) {
             const int m = s % 32;
