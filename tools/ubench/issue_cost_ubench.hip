@@ -5,7 +5,7 @@
 #define REP 64
 #define ITER 256
 template <int MODE>
-__global__ __launch_bounds__(256) void k(double* out, long long* cyc, double seed, int live) {
+__global__ __launch_bounds__(1024) void k(double* out, long long* cyc, double seed, int live) {
     __shared__ double sm[2048];
     for (int i = threadIdx.x; i < 2048; i += blockDim.x) sm[i] = i;
     __syncthreads();
@@ -52,23 +52,25 @@ __global__ __launch_bounds__(256) void k(double* out, long long* cyc, double see
     double s = y + l0 + l1 + iw;
     for (int i = 0; i < 4; ++i) s += a[i];
     out[blockIdx.x * 64 + threadIdx.x] = s;
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) { cyc[2 * (threadIdx.x >> 6)] = t0; cyc[2 * (threadIdx.x >> 6) + 1] = t1; }
 }
 static int g_threads = 64, g_live = 64;
 template <int MODE>
 static double run(const char* name, double* d_out, long long* d_cyc, double base) {
     hipLaunchKernelGGL((k<MODE>), dim3(1), dim3(g_threads), 0, 0, d_out, d_cyc, 1.0, g_live);
     hipDeviceSynchronize();
-    long long c; hipMemcpy(&c, d_cyc, sizeof c, hipMemcpyDeviceToHost);
+    long long cc[32]; hipMemcpy(cc, d_cyc, sizeof(long long) * 2 * (g_threads / 64), hipMemcpyDeviceToHost);
+    long long lo = cc[0], hi = cc[1]; for (int w = 1; w < g_threads / 64; ++w) { if (cc[2 * w] < lo) lo = cc[2 * w]; if (cc[2 * w + 1] > hi) hi = cc[2 * w + 1]; }
+    long long c = hi - lo;  // span over all waves of the workgroup
     const double per = (double)c / (ITER * REP);
     printf("%-40s : %6.2f cycles per pair  (extra %5.2f)\n", name, per, per - base);
     return per;
 }
 int main() {
     double* d_out; long long* d_cyc;
-    hipMalloc(&d_out, 256 * sizeof(double)); hipMalloc(&d_cyc, sizeof(long long));
-  for (int cfg = 0; cfg < 4; ++cfg) {
-    g_threads = (cfg & 1) ? 256 : 64; g_live = (cfg & 2) ? 32 : 64;
+    hipMalloc(&d_out, 1024 * sizeof(double)); hipMalloc(&d_cyc, 64 * sizeof(long long));
+  for (int cfg = 0; cfg < 7; ++cfg) {
+    g_threads = cfg == 6 ? 1024 : (cfg >= 4 ? 512 : ((cfg & 1) ? 256 : 64)); g_live = ((cfg & 2) && cfg < 6) || cfg == 5 ? 32 : 64;
     printf("---- waves per CU %d, live lanes %d\n", g_threads / 64, g_live);
     double b = run<0>("v_fmac_f64 x4 chains alone", d_out, d_cyc, 0);
     run<1>("+ s_waitcnt lgkmcnt(0) (nothing pending)", d_out, d_cyc, b);
