@@ -436,7 +436,8 @@ void a1mpc_default_balance_config(a1mpc_balance_config* q) {
 }
 
 // ---- N2b: contact logic + recent-contact filters, walking-surface fit, terrain pitch (S/A1RobotControl.cpp:256-282, 566-582, 335-376) --------
-// Device-resident state per robot: 13 moving-window filters x [count, head, sum, correction, ring[100]], early_contacts[4], recent[12].
+// Device-resident state per robot: 13 moving-window filters x [count, head, sum, correction, ring[100]], early_contacts[4], recent[12],
+// stored field-major ([field][robot], stride = max_batch): robots whose filters are in phase touch neighbouring words.
 // K_a: one lane per (robot, leg) -- contact rules and the leg's three filters (window 60); K_b: one lane per robot -- plane fit,
 // terrain-angle filter (window 100), pitch rule.  HBM-bound: a tick touches one ring slot per active filter.  No FMA contraction.
 constexpr int kMwf = 104, kCtState = 13 * kMwf + 4 + 12;
@@ -445,27 +446,28 @@ struct ContactArgs {
     double counter_per_swing, foot_force_low;
     int32_t use_terrain_adapt;
     double* state;
+    int64_t stride;  // robots per field (= max_batch)
     const double *gait_counter, *foot_force, *foot_pos_abs, *root_pos_z;
     const uint8_t* plan_contacts;
     double* pitch_d;
     uint8_t* contacts;
     double *recent_out, *terrain_out;
 };
-__device__ inline double mwf_update(double* f, int window, double v) {  // S/utils/filter.hpp:26-39,53-66
+__device__ inline double mwf_update(double* f, int64_t fs, int window, double v) {  // S/utils/filter.hpp:26-39,53-66; f[k * fs] = field k of this filter
 #pragma clang fp contract(off)
-    int count = static_cast<int>(f[0]), head = static_cast<int>(f[1]);
-    double sum = f[2], corr = f[3];
-    double* ring = f + 4;
+    int count = static_cast<int>(f[0]), head = static_cast<int>(f[fs]);
+    double sum = f[2 * fs], corr = f[3 * fs];
+    double* ring = f + 4 * fs;
     auto neumaier = [&](double val) {
         const double ns = sum + val;
         if (fabs(sum) >= fabs(val)) corr += (sum - ns) + val; else corr += (val - ns) + sum;
         sum = ns;
     };
-    if (count >= window) neumaier(-ring[head]); else count += 1;
+    if (count >= window) neumaier(-ring[head * fs]); else count += 1;
     neumaier(v);
-    ring[head] = v;
+    ring[head * fs] = v;
     head = (head + 1) % window;
-    f[0] = count; f[1] = head; f[2] = sum; f[3] = corr;
+    f[0] = count; f[fs] = head; f[2 * fs] = sum; f[3 * fs] = corr;
     return (sum + corr) / static_cast<double>(window);
 }
 __global__ __launch_bounds__(256) void a1mpc_contact_kernel(const ContactArgs a) {
@@ -474,19 +476,20 @@ __global__ __launch_bounds__(256) void a1mpc_contact_kernel(const ContactArgs a)
     const int64_t b = gid >> 2;
     const int i = static_cast<int>(gid & 3);
     if (b >= a.n) return;
-    double* st = a.state + b * kCtState;
-    double *early = st + 13 * kMwf, *recent = early + 4;
+    double* st = a.state + b;
+    const int64_t fs = a.stride;
+    double *early = st + 13 * kMwf * fs, *recent = early + 4 * fs;
     const double gc = a.gait_counter[b * 4 + i];
     const bool plan = a.plan_contacts[b * 4 + i] != 0;
-    double e = early[i];
+    double e = early[i * fs];
     if (gc <= a.counter_per_swing * 1.5) e = 0.0;                                                                   // :260-262
     if (!plan && gc > a.counter_per_swing * 1.5 && a.foot_force[b * 4 + i] > a.foot_force_low) e = 1.0;             // :263-267
-    early[i] = e;
+    early[i * fs] = e;
     const bool c = plan || e != 0.0;                                                                                // :271
     a.contacts[b * 4 + i] = c ? 1 : 0;
     if (c) {                                                                                                        // :274-281
 #pragma unroll
-        for (int k = 0; k < 3; ++k) recent[3 * i + k] = mwf_update(st + (3 * i + k) * kMwf, 60, a.foot_pos_abs[b * 12 + 3 * i + k]);
+        for (int k = 0; k < 3; ++k) recent[(3 * i + k) * fs] = mwf_update(st + (3 * i + k) * kMwf * fs, fs, 60, a.foot_pos_abs[b * 12 + 3 * i + k]);
     }
 }
 __device__ inline void sym3_pinv(const double* m, double* out) {  // pseudo-inverse of a symmetric PSD 3x3 by cyclic Jacobi (S/utils/Utils.cpp:44-52)
@@ -520,11 +523,12 @@ __global__ __launch_bounds__(256) void a1mpc_terrain_kernel(const ContactArgs a)
 #pragma clang fp contract(off)
     const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (b >= a.n) return;
-    double* st = a.state + b * kCtState;
-    const double* recent = st + 13 * kMwf + 4;
+    double* st = a.state + b;
+    const int64_t fs = a.stride;
+    const double* recent = st + (13 * kMwf + 4) * fs;
     double rc[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) { rc[k] = recent[k]; a.recent_out[b * 12 + k] = rc[k]; }
+    for (int k = 0; k < 12; ++k) { rc[k] = recent[k * fs]; a.recent_out[b * 12 + k] = rc[k]; }
     double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, rhs[3] = {0, 0, 0}, P3[9], co[3];   // :566-582  a = pinv(W'W) W' z
     for (int i = 0; i < 4; ++i) {
         const double w[3] = {1.0, rc[3 * i + 0], rc[3 * i + 1]};
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(256) void a1mpc_terrain_kernel(const ContactArgs a)
     double terrain_angle = 0.0;                                                             // :339-352
     if (a.root_pos_z[b] > 0.1) {
         const double angle_cos = fabs(0.0 * s0 + 0.0 * s1 + 1.0 * s2) / (sqrt(0.0 * 0.0 + 0.0 * 0.0 + 1.0 * 1.0) * sqrt(s0 * s0 + s1 * s1 + s2 * s2));
-        terrain_angle = mwf_update(st + 12 * kMwf, 100, acos(angle_cos));
+        terrain_angle = mwf_update(st + 12 * kMwf * fs, fs, 100, acos(angle_cos));
     }
     if (terrain_angle > 0.5) terrain_angle = 0.5;
     if (terrain_angle < -0.5) terrain_angle = -0.5;
@@ -596,7 +600,7 @@ a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_con
     A1_HIP(hipMemcpyAsync(d_pc, plan_contacts, N * 4, hipMemcpyHostToDevice, s));
     ContactArgs a;
     a.n = n; a.counter_per_swing = cfg->counter_per_swing; a.foot_force_low = cfg->foot_force_low; a.use_terrain_adapt = cfg->use_terrain_adapt;
-    a.state = h->d_ct_state; a.gait_counter = d_gc; a.foot_force = d_ff; a.foot_pos_abs = d_fp; a.root_pos_z = d_z; a.plan_contacts = d_pc;
+    a.state = h->d_ct_state; a.stride = h->max_batch; a.gait_counter = d_gc; a.foot_force = d_ff; a.foot_pos_abs = d_fp; a.root_pos_z = d_z; a.plan_contacts = d_pc;
     a.pitch_d = d_pd; a.contacts = d_ct; a.recent_out = d_rec; a.terrain_out = d_ta;
     A1_HIP(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(a1mpc_contact_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
@@ -1233,7 +1237,7 @@ a1mpc_status a1mpc_contact_terrain_batch_device(a1mpc_handle h, const a1mpc_cont
     }
     ContactArgs a;
     a.n = n; a.counter_per_swing = cfg->counter_per_swing; a.foot_force_low = cfg->foot_force_low; a.use_terrain_adapt = cfg->use_terrain_adapt;
-    a.state = h->d_ct_state; a.gait_counter = gait_counter; a.foot_force = foot_force; a.foot_pos_abs = foot_pos_abs; a.root_pos_z = root_pos_z;
+    a.state = h->d_ct_state; a.stride = h->max_batch; a.gait_counter = gait_counter; a.foot_force = foot_force; a.foot_pos_abs = foot_pos_abs; a.root_pos_z = root_pos_z;
     a.plan_contacts = plan_contacts; a.pitch_d = root_euler_d_pitch; a.contacts = contacts_out; a.recent_out = foot_pos_recent_contact_out; a.terrain_out = terrain_angle_out;
     A1_HIP(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(a1mpc_contact_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
