@@ -44,7 +44,7 @@
 #include <omp.h>
 #endif
 #ifdef ORC_EXTENDED
-/* Accuracy yardstick (tools/extended_check.py, make liba1mpc_oracle_x87.so): the same source with every `double` below widened to the
+/* Accuracy yardstick (tests/tools/extended_check.py, make liba1mpc_oracle_x87.so): the same source with every `double` below widened to the
  * x87 80-bit long double (64-bit significand) -- the OSQP iterate sequence with 2048x less rounding error, against which the
  * double-precision oracle and the GPU engine are both measured.  Never used as the pass/fail checker. */
 #include <tgmath.h>

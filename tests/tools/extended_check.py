@@ -3,7 +3,7 @@
 sequence computed in x87 extended precision (oracle source built with -DORC_EXTENDED)?  Runs on the GPU box.  Prints one JSON line.
 TEST / ANALYSIS INFRASTRUCTURE: loads oracle/ like the tests do."""
 import ctypes as C, json, os, subprocess, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package(); orc = g.load_oracle()

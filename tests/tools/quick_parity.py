@@ -2,7 +2,7 @@
 """Kernel-tuning helper: solve BASELINE configs[2] (4096 QPs, h = 10) on the GPU, compare with the oracle, print the kernel time.
 usage: quick_parity.py [n]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package(); orc = g.load_oracle()
