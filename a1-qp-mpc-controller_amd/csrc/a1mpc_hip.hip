@@ -844,16 +844,16 @@ __device__ inline void ekf_c_row(int r, int& c0, double& s0, int& c1, double& s1
 }
 __global__ __launch_bounds__(64) void a1mpc_ekf_kernel(const EkfArgs a) {
 #pragma clang fp contract(off)
-    __shared__ double lds[2][1600];
+    __shared__ double lds[2][1280];
     const int g = static_cast<int>(threadIdx.x) >> 5, l = static_cast<int>(threadIdx.x) & 31;
     const int64_t b = static_cast<int64_t>(blockIdx.x) * 2 + g;
     if (b >= a.n) return;
     double* st = a.state + b * kEkfState;
     const double flag = st[18 + 324];
     if (flag != 1.0) { if (l == 0 && flag == 2.0) st[18 + 324] = 1.0; return; }
-    double *Pm = lds[g], *Pb = Pm + 324, *Sm = Pb + 324, *prow = Sm + 28 * 29, *xs = prow + 48, *xb = xs + 18, *zs = xb + 18;   // 324+324+812+48+18+18+28 = 1572
+    double *Pb = lds[g], *Sm = Pb + 324, *prow = Sm + 28 * 29, *xs = prow + 48, *xb = xs + 18, *zs = xb + 18;   // 324+812+48+18+18+28 = 1248 doubles = 10 KB per robot
     const double dt = a.dt;
-    for (int i = l; i < 324; i += 32) Pm[i] = st[18 + i];
+    const double* Pg = st + 18;  // P of the previous tick: every lane reads its own row(s) straight from global memory
     if (l < 18) xs[l] = st[l];
     const double* R = a.R + b * 9; const double *fk = a.fk + b * 12, *fv = a.fv + b * 12, *acc = a.acc + b * 3, *w = a.w + b * 3;
     double ec[4];
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(64) void a1mpc_ekf_kernel(const EkfArgs a) {
         else xbv = xs[l] + 0.0;
         xb[l] = xbv;
         double T[18];
-        for (int j = 0; j < 18; ++j) T[j] = l < 3 ? Pm[l * 18 + j] + dt * Pm[(3 + l) * 18 + j] : Pm[l * 18 + j];
+        for (int j = 0; j < 18; ++j) T[j] = l < 3 ? Pg[l * 18 + j] + dt * Pg[(3 + l) * 18 + j] : Pg[l * 18 + j];
         double q;
         if (l < 3) q = PIMU * dt / 20.0; else if (l < 6) q = VIMU * dt * 9.8 / 20.0; else q = (1 + (1 - ec[(l - 6) / 3]) * 1e3) * dt * PFOOT;
         for (int j = 0; j < 18; ++j) { Pr[j] = (j < 3 ? T[j] + T[3 + j] * dt : T[j]) + (j == l ? q : 0.0); Pb[l * 18 + j] = Pr[j]; }
@@ -950,8 +950,12 @@ __global__ __launch_bounds__(64) void a1mpc_ekf_kernel(const EkfArgs a) {
         xs[l] = xb[l] + acc_;
         double G2[18];
         for (int j = 0; j < 18; ++j) { double s = 0; for (int r = 0; r < 28; ++r) s += G1[r] * SC[r * 18 + j]; G2[j] = s; }
-        for (int j = 0; j < 18; ++j) { double s = 0; for (int k = 0; k < 18; ++k) s += G2[k] * Pb[k * 18 + j]; Tn[j] = Pr[j] - s; Pm[l * 18 + j] = Tn[j]; }
+        for (int j = 0; j < 18; ++j) { double s = 0; for (int k = 0; k < 18; ++k) s += G2[k] * Pb[k * 18 + j]; Tn[j] = Pr[j] - s; }
     }
+    half_sync();  // every lane is done reading Pbar: its region now stages the unsymmetrised update for the transposed read
+    double* Pm = Pb;
+    if (l < 18)
+        for (int j = 0; j < 18; ++j) Pm[l * 18 + j] = Tn[j];
     half_sync();
     if (l < 18) {
         double Pn[18];
