@@ -634,43 +634,55 @@ struct RowSolver {
     A1_DEV void factorize() {
         ++nfact;
         const double sigma_f = row_opaque(P.sigma);
-        // stage W_t = c R + sigma D^-2 + A_t' (E^2 rho) A_t  (block-diagonal, 3x3 per leg) into slot t
+        // stage W_t = c R + sigma D^-2 + A_t' (E^2 rho) A_t  (block-diagonal, 3x3 per leg) into slot t: my row of my leg's block
         row_sync();
         static_for<H>([&](auto T) {
             const double a0 = rr0[T], a1 = rr1[T];
             const double sp = a0 + a1;
             const double spx = quad_perm<0, 0, 0, 0>(sp), spy = quad_perm<1, 1, 1, 1>(sp);
             const double base = csc * r2a + sigma_f * dI2[T];
-            const double wd = comp == 2 ? base + a0 + mu * mu * (spx + spy) : base + sp;
+            const double wd = act ? (comp == 2 ? base + a0 + mu * mu * (spx + spy) : base + sp) : 0.0;
             const double wo = comp < 2 ? mu * (a0 - a1) : 0.0;
-            lds[L::FAC + T * L::SLOT + L::K_SZ + 2 * ln] = act ? wd : 0.0;  // staged in the S area of the slot (the K area's pad column carries G)
-            lds[L::FAC + T * L::SLOT + L::K_SZ + 2 * ln + 1] = wo;
+            const double wox = quad_perm<0, 0, 0, 0>(wo), woy = quad_perm<1, 1, 1, 1>(wo);
+            double* w = lds + L::FAC + T * L::SLOT + L::K_SZ + 3 * ln;  // staged in the S area of the slot (the K area's pad column carries G)
+            w[0] = comp == 0 ? wd : (comp == 2 ? wox : 0.0);
+            w[1] = comp == 1 ? wd : (comp == 2 ? woy : 0.0);
+            w[2] = comp == 2 ? wd : wo;
         });
         row_sync();
+        // lane constants of this pass: leg and component indicators (1.0 / 0.0) turn "add on my diagonal entry only" into one FMA
+        double mq[4], cm[3], qdc[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mq[q] = (act && quad == q) ? 1.0 : 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { cm[c] = comp == c ? 1.0 : 0.0; qdc[c] = comp == c ? qd : 0.0; }
         double Pn[12];  // row of P_{t+1} (state layout); terminal value c Q
 #pragma unroll
         for (int j = 0; j < 12; ++j) Pn[j] = (act && ci == j) ? qd : 0.0;
 #pragma unroll 1
         for (int t = H - 1; t >= 0; --t) {
             double* slot = lds + L::FAC + t * L::SLOT;
-            const double wd = slot[L::K_SZ + 2 * ln], wo = slot[L::K_SZ + 2 * ln + 1];
-            const double wox = quad_perm<0, 0, 0, 0>(wo), woy = quad_perm<1, 1, 1, 1>(wo);
+            const double wv[3] = {slot[L::K_SZ + 3 * ln], slot[L::K_SZ + 3 * ln + 1], slot[L::K_SZ + 3 * ln + 2]};
             row_sync();  // everybody holds W_t before the slot is overwritten
             // G = A' P_{t+1}  (rows mixed across lanes), then GA = G A (columns, lane-local)
             double G[12];
-            static_for<12>([&](auto J) { G[J] = opAT(row_dpp_ready(Pn[J])); });
+            row_dpp_ready12(Pn);
+            static_for<12>([&](auto J) { G[J] = opAT(Pn[J]); });
             // F' = G(:,6:12) B~  (state row-owner)  and  Y = P_{t+1}(6:12,6:12) B~  (valid on the wrench lanes)
             double Ft[12], Y[12];
-#pragma unroll
-            for (int b = 0; b < 12; ++b) { Ft[b] = 0.0; Y[b] = 0.0; }
             static_for<6>([&](auto K) {
                 double Bk[12];
 #pragma unroll
                 for (int b = 0; b < 12; ++b) Bk[b] = lds[L::BL + K * 12 + b];
 #pragma unroll
                 for (int b = 0; b < 12; ++b) {
-                    Ft[b] = fma(G[6 + K], Bk[b], Ft[b]);
-                    Y[b] = fma(Pn[6 + K], Bk[b], Y[b]);
+                    if constexpr (A1_CV(K) == 0) {
+                        Ft[b] = G[6] * Bk[b];
+                        Y[b] = Pn[6] * Bk[b];
+                    } else {
+                        Ft[b] = fma(G[6 + K], Bk[b], Ft[b]);
+                        Y[b] = fma(Pn[6 + K], Bk[b], Y[b]);
+                    }
                 }
             });
             G[6] += dt * (cy * G[0] - sy * G[1]);
@@ -679,32 +691,27 @@ struct RowSolver {
             G[9] += dt * G[3];
             G[10] += dt * G[4];
             G[11] += dt * G[5];
-            // S = W_t + B~' Y   (force row-owner)
+            // S = W_t + B~' Y   (force row-owner): twelve interleaved chains, each seeded with its W entry
             double S[12];
-            static_for<12>([&](auto B) {
-                double w = 0.0;
-                if (act) {
-                    if (B == ci) w = wd;
-                    else if (comp < 2 && B == 3 * quad + 2) w = wo;
-                    else if (comp == 2 && B == 3 * quad) w = wox;
-                    else if (comp == 2 && B == 3 * quad + 1) w = woy;
-                }
-                S[B] = dot_bc<6>(Bt, row_dpp_ready(Y[B])) + w;
+            static_for<12>([&](auto B) { S[B] = mq[A1_CV(B) / 3] * wv[A1_CV(B) % 3]; });
+            row_dpp_ready12(Y);
+            static_for<6>([&](auto K) {
+                static_for<12>([&](auto B) { fma_bcast<lane_of(6 + A1_CV(K))>(S[B], Bt[K], Y[B]); });
             });
             // in-place Gauss-Jordan inverse of the SPD 12x12 (no pivoting).  Pivot k: row k is scaled by 1/p, every other row i
             // subtracts S_ik/p times row k.  Both are  S_ij += m_i * S_kj  with m_k = 1/p - 1 and m_i = -S_ik/p, i.e. ONE
-            // v_fmac_f64_dpp per element whose DPP source is the element's own register read from lane k.
+            // v_fmac_f64_dpp per element whose DPP source is the element's own register read from lane k (gj_pivot); the
+            // reciprocal of the next pivot is computed inside the block, between the eliminations that do not feed it.
+            row_dpp_ready12(S);
+            double piv = bc<0>(S[0]);
+            double pinv = row_recip(piv);
             static_for<12>([&](auto K) {
-                const double piv = bc<K>(S[K]);
+                constexpr int k = A1_CV(K);
                 if (!(piv > 0.0)) fac_ok = false;
-                const double pinv = 1.0 / piv;
-                const double f = S[K];
-                const bool mine = act && ci == K;
-                const double mlt = mine ? pinv - 1.0 : -f * pinv;
-                static_for<12>([&](auto J) {
-                    if constexpr (A1_CV(J) != A1_CV(K)) fma_bcast<lane_of(A1_CV(K))>(S[J], mlt, S[J]);
-                });
-                S[K] = mine ? pinv : -f * pinv;
+                const double fm = fma(-mq[k / 3], cm[k % 3], S[k]);  // S_ik, minus one on the pivot's own row
+                const double mlt = -(fm * pinv);
+                S[k] = (act && ci == k) ? pinv : mlt;
+                gj_pivot<k>(S, mlt, piv, pinv);
             });
             if (act) {
                 static_for<12>([&](auto B) {
@@ -726,13 +733,10 @@ struct RowSolver {
             }
             // P_t = c Q + A' P_{t+1} A - F' K:  K[a][j] = register a of state lane j
             if (t > 0) {
-                double nFt[12];
-#pragma unroll
-                for (int a = 0; a < 12; ++a) nFt[a] = -Ft[a];
-                static_for<12>([&](auto J) { Pn[J] = G[J] + ((act && ci == J) ? qd : 0.0); });
+                static_for<12>([&](auto J) { Pn[J] = fma(mq[A1_CV(J) / 3], qdc[A1_CV(J) % 3], G[J]); });
                 row_dpp_ready12(Kt);
                 static_for<12>([&](auto A_) {
-                    static_for<12>([&](auto J) { fma_bcast<lane_of(A1_CV(J))>(Pn[J], nFt[A_], Kt[A_]); });
+                    static_for<12>([&](auto J) { fnma_bcast<lane_of(A1_CV(J))>(Pn[J], Ft[A_], Kt[A_]); });
                 });
             }
             row_sync();  // K_t and S_t^-1 of this step are in LDS before the next step reuses the registers' sources

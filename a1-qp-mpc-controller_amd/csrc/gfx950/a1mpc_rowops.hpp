@@ -195,6 +195,57 @@ A1_DEV void sweep_fwd_input(double& sa, double& sb, double& z0, double v, const 
 }
 
 // Scheduling fence: the machine scheduler moves nothing across it (keeps a step's LDS reads ahead of the arithmetic that hides them).
+// 1 / p for a well-scaled positive p (the Gauss-Jordan pivots): v_rcp_f64 + two Newton steps, ~1 ulp, without the scaling / fix-up
+// instructions of a correctly rounded division (12 dependent instructions shorter per pivot).
+A1_DEV double row_recip(double p) {
+    double x = __builtin_amdgcn_rcp(p);
+    double e = __builtin_fma(-p, x, 1.0);
+    x = __builtin_fma(x, e, x);
+    e = __builtin_fma(-p, x, 1.0);
+    return __builtin_fma(x, e, x);
+}
+
+// One Gauss-Jordan pivot of the row-distributed 12x12 (RowSolver::factorize): S[j] += mlt * (S[j] of lane K) for every j != K
+// (S[K] itself is set by the caller).  For K < 11 the block also returns the next pivot p = S[K+1] of lane K+1 and x = 1 / p
+// (row_recip's sequence): row K+1 is eliminated first, and the reciprocal's dependent chain is issued between the other ten
+// eliminations instead of after them.  Hazards: S[K+1] is read through DPP three instructions after its write; v_rcp_f64's
+// result is read two instructions later; every S[j] was written >= 2 instructions before the block (caller's glue code).
+#define A1_GJ(s) "v_fmac_f64_dpp " s ", " s ", %14 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n"
+#define A1_GJL(s) "v_fmac_f64_dpp " s ", " s ", %11 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n"
+template <int K>
+A1_DEV void gj_pivot(double (&S)[12], double mlt, double& p, double& x) {
+    static_assert(K >= 0 && K < 12, "pivot");
+    constexpr int LK = 4 * (K / 3) + K % 3;
+    if constexpr (K < 11) {
+        constexpr int N = K + 1, LN = 4 * (N / 3) + N % 3;
+        // the ten rows other than K and K+1, ascending
+        constexpr auto o = [](int i) { int j = i; if (j >= (K < N ? K : N)) ++j; if (j >= (K < N ? N : K)) ++j; return j; };
+        double e;
+        asm(A1_GJ("%0") A1_GJ("%1") A1_GJ("%2")
+            "v_mov_b64_dpp %11, %0 row_newbcast:%16 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            A1_GJ("%3")
+            "v_rcp_f64 %12, %11\n"
+            A1_GJ("%4") A1_GJ("%5")
+            "v_fma_f64 %13, -%11, %12, 1.0\n"
+            A1_GJ("%6")
+            "v_fmac_f64 %12, %12, %13\n"
+            A1_GJ("%7")
+            "v_fma_f64 %13, -%11, %12, 1.0\n"
+            A1_GJ("%8")
+            "v_fmac_f64 %12, %12, %13\n"
+            A1_GJ("%9") A1_GJ("%10")
+            : "+v"(S[N]), "+v"(S[o(0)]), "+v"(S[o(1)]), "+v"(S[o(2)]), "+v"(S[o(3)]), "+v"(S[o(4)]), "+v"(S[o(5)]), "+v"(S[o(6)]), "+v"(S[o(7)]),
+              "+v"(S[o(8)]), "+v"(S[o(9)]), "=&v"(p), "=&v"(x), "=&v"(e)
+            : "v"(mlt), "n"(LK), "n"(LN));
+    } else {
+        asm(A1_GJL("%0") A1_GJL("%1") A1_GJL("%2") A1_GJL("%3") A1_GJL("%4") A1_GJL("%5") A1_GJL("%6") A1_GJL("%7") A1_GJL("%8") A1_GJL("%9") A1_GJL("%10")
+            : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(S[4]), "+v"(S[5]), "+v"(S[6]), "+v"(S[7]), "+v"(S[8]), "+v"(S[9]), "+v"(S[10])
+            : "v"(mlt), "n"(LK));
+    }
+}
+#undef A1_GJL
+#undef A1_GJ
+
 A1_DEV void row_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 // All LDS reads issued so far have landed (s_waitcnt lgkmcnt(0)): one wait in front of a chain instead of one per operand.

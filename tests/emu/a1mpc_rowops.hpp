@@ -89,6 +89,20 @@ inline void sweep_fwd_input(double& sa, double& sb, double& z0, double v, const 
     z0 = fmin(fmax(w0, lb), ub);
 }
 
+inline double row_recip(double p) { return 1.0 / p; }  // the device sequence is accurate to ~1 ulp, this is the correctly rounded value
+template <int K>
+inline void gj_pivot(double (&S)[12], double mlt, double& p, double& x) {
+    constexpr int N = K + 1;
+    auto elim = [&](int j) { S[j] = fma(emu_publish(S[j])[emu_detail::LANE[K]], mlt, S[j]); };
+    if (N < 12) elim(N);
+    for (int j = 0; j < 12; ++j)
+        if (j != K && j != N) elim(j);
+    if (N < 12) {
+        p = emu_publish(S[N < 12 ? N : 0])[emu_detail::LANE[N < 12 ? N : 0]];
+        x = 1.0 / p;
+    }
+}
+
 inline void row_sched_fence() {}
 inline void row_lds_landed() {}
 inline double row_opaque(double v) { return v; }
