@@ -47,11 +47,19 @@ __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a
     const int row = static_cast<int>(threadIdx.x) >> 4;
     const int64_t b = static_cast<int64_t>(blockIdx.x);
     const ProblemIO io = make_io<H, kModeMpc>(a, b);
-    RowSolver<H, kModeMpc> S(a.P, a.tab, a1mpc_lds);
-    S.coop_id = row; S.coop_n = 4;
-    S.setup(io);
+    static_assert(Prep<H>::STRIDE <= H * Layout<H>::SLOT, "the hand-off record fits the (still empty) factor region");
+    {
+        RowSolver<H, kModeMpc> S(a.P, a.tab, a1mpc_lds);
+        S.coop_id = row; S.coop_n = 4;
+        S.setup(io);
+        row_sync();  // every row is done with the set-up scratch aliased into the factor region
+        if (row == 0) S.save_prepared(a1mpc_lds + Layout<H>::FAC);
+    }
     if (row != 0) return;
-    S.coop_id = 0; S.coop_n = 1;
+    // Row 0 continues exactly like a row of the split pipeline's second kernel: a fresh solver that reads the hand-off record
+    // (here through LDS).  Carrying the set-up's registers into the ADMM loop instead costs that loop its spill-free allocation.
+    RowSolver<H, kModeMpc> S(a.P, a.tab, a1mpc_lds);
+    S.load_prepared(a1mpc_lds + Layout<H>::FAC, io);
     S.solve();
     S.write_outputs(io);
 }

@@ -650,12 +650,13 @@ struct RowSolver {
             w[2] = comp == 2 ? wd : wo;
         });
         row_sync();
-        // lane constants of this pass: leg and component indicators (1.0 / 0.0) turn "add on my diagonal entry only" into one FMA
-        double mq[4], cm[3], qdc[3];
+        // lane constants of this pass: component indicators (1.0 / 0.0).  "Add on my diagonal entry only" is one v_fmac_f64_dpp with
+        // the leg's bank mask, the component indicator (times my own value) as the own-lane factor and 1.0 = cm[0] of lane 0 as the broadcast one.
+        // (built from opaque values: they must not be hoisted out of the ADMM loop, whose register file is full)
+        double cm[3], qdc[3];
+        const double one_f = row_opaque(1.0), qd_f = row_opaque(qd);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mq[q] = (act && quad == q) ? 1.0 : 0.0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { cm[c] = comp == c ? 1.0 : 0.0; qdc[c] = comp == c ? qd : 0.0; }
+        for (int c = 0; c < 3; ++c) { cm[c] = comp == c ? one_f : 0.0; qdc[c] = comp == c ? qd_f : 0.0; }
         double Pn[12];  // row of P_{t+1} (state layout); terminal value c Q
 #pragma unroll
         for (int j = 0; j < 12; ++j) Pn[j] = (act && ci == j) ? qd : 0.0;
@@ -693,11 +694,13 @@ struct RowSolver {
             G[11] += dt * G[5];
             // S = W_t + B~' Y   (force row-owner): twelve interleaved chains, each seeded with its W entry
             double S[12];
-            static_for<12>([&](auto B) { S[B] = mq[A1_CV(B) / 3] * wv[A1_CV(B) % 3]; });
+#pragma unroll
+            for (int b = 0; b < 12; ++b) S[b] = 0.0;
             row_dpp_ready12(Y);
             static_for<6>([&](auto K) {
                 static_for<12>([&](auto B) { fma_bcast<lane_of(6 + A1_CV(K))>(S[B], Bt[K], Y[B]); });
             });
+            static_for<12>([&](auto B) { fma_bcast_leg<0, A1_CV(B) / 3>(S[B], wv[A1_CV(B) % 3], cm[0]); });  // + W on my leg's block (cm[0] of lane 0 = 1)
             // in-place Gauss-Jordan inverse of the SPD 12x12 (no pivoting).  Pivot k: row k is scaled by 1/p, every other row i
             // subtracts S_ik/p times row k.  Both are  S_ij += m_i * S_kj  with m_k = 1/p - 1 and m_i = -S_ik/p, i.e. ONE
             // v_fmac_f64_dpp per element whose DPP source is the element's own register read from lane k (gj_pivot); the
@@ -708,8 +711,8 @@ struct RowSolver {
             static_for<12>([&](auto K) {
                 constexpr int k = A1_CV(K);
                 if (!(piv > 0.0)) fac_ok = false;
-                const double fm = fma(-mq[k / 3], cm[k % 3], S[k]);  // S_ik, minus one on the pivot's own row
-                const double mlt = -(fm * pinv);
+                fnma_bcast_leg<0, k / 3>(S[k], cm[k % 3], cm[0]);  // S_ik, minus one on the pivot's own row
+                const double mlt = -(S[k] * pinv);
                 S[k] = (act && ci == k) ? pinv : mlt;
                 gj_pivot<k>(S, mlt, piv, pinv);
             });
@@ -733,7 +736,10 @@ struct RowSolver {
             }
             // P_t = c Q + A' P_{t+1} A - F' K:  K[a][j] = register a of state lane j
             if (t > 0) {
-                static_for<12>([&](auto J) { Pn[J] = fma(mq[A1_CV(J) / 3], qdc[A1_CV(J) % 3], G[J]); });
+                static_for<12>([&](auto J) {
+                    Pn[J] = G[J];
+                    fma_bcast_leg<0, A1_CV(J) / 3>(Pn[J], qdc[A1_CV(J) % 3], cm[0]);
+                });
                 row_dpp_ready12(Kt);
                 static_for<12>([&](auto A_) {
                     static_for<12>([&](auto J) { fnma_bcast<lane_of(A1_CV(J))>(Pn[J], Ft[A_], Kt[A_]); });

@@ -63,6 +63,17 @@ A1_DEV void fnma_bcast(double& acc, double m, double x) {
     static_assert(L >= 0 && L < 16, "lane");
     asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(L));
 }
+// the same restricted to the four lanes of leg Q (DPP bank_mask: bit q enables lanes 4q..4q+3 of every row; the other lanes keep acc)
+template <int L, int Q>
+A1_DEV void fma_bcast_leg(double& acc, double m, double x) {
+    static_assert(L >= 0 && L < 16 && Q >= 0 && Q < 4, "lane / leg");
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:%4" : "+v"(acc) : "v"(x), "v"(m), "n"(L), "n"(1 << Q));
+}
+template <int L, int Q>
+A1_DEV void fnma_bcast_leg(double& acc, double m, double x) {
+    static_assert(L >= 0 && L < 16 && Q >= 0 && Q < 4, "lane / leg");
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:%4" : "+v"(acc) : "v"(x), "v"(m), "n"(L), "n"(1 << Q));
+}
 // min / max as single instructions: fmin()/fmax() make hipcc canonicalise loop-carried operands first (v_max_f64 x, x, x),
 // one extra FP64 issue slot per operand in the projection of every ADMM row.  Operands here are never signalling NaNs.
 A1_DEV double max_f64(double a, double b) {

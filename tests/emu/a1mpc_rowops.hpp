@@ -32,6 +32,16 @@ template <int L>
 inline void fma_bcast(double& acc, double m, double x) { acc = fma(m, emu_publish(x)[L], acc); }
 template <int L>
 inline void fnma_bcast(double& acc, double m, double x) { acc = fma(-m, emu_publish(x)[L], acc); }
+template <int L, int Q>
+inline void fma_bcast_leg(double& acc, double m, double x) {
+    const double v = emu_publish(x)[L];
+    if ((emu_lane >> 2) == Q) acc = fma(m, v, acc);
+}
+template <int L, int Q>
+inline void fnma_bcast_leg(double& acc, double m, double x) {
+    const double v = emu_publish(x)[L];
+    if ((emu_lane >> 2) == Q) acc = fma(-m, v, acc);
+}
 inline double max_f64(double a, double b) { return fmax(a, b); }
 inline double min_f64(double a, double b) { return fmin(a, b); }
 inline double row_dpp_ready(double x) { return x; }
