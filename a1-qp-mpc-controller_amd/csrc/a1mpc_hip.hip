@@ -34,8 +34,7 @@ __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
     const int row = static_cast<int>(threadIdx.x) >> 4;
     const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
     if (b >= a.n) return;  // row-uniform: the other rows of the wave keep all their DPP sources
-    const ProblemIO io = make_io<H, MODE>(a, b);
-    solve_row<H, MODE>(a.P, a.tab, io, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+    solve_row_with<H, MODE>(a.P, a.tab, [&]() { return make_io<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
 }
 
 // Latency variant of the fused kernel for a handful of QPs: the four rows of a wavefront work on ONE QP during set-up (each takes every fourth
@@ -59,9 +58,9 @@ __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a
     // Row 0 continues exactly like a row of the split pipeline's second kernel: a fresh solver that reads the hand-off record
     // (here through LDS).  Carrying the set-up's registers into the ADMM loop instead costs that loop its spill-free allocation.
     RowSolver<H, kModeMpc> S(a.P, a.tab, a1mpc_lds);
-    S.load_prepared(a1mpc_lds + Layout<H>::FAC, io);
+    S.load_prepared(a1mpc_lds + Layout<H>::FAC, make_io<H, kModeMpc>(a, b));
     S.solve();
-    S.write_outputs(io);
+    S.write_outputs(make_io<H, kModeMpc>(a, b));
 }
 
 // ---- split pipeline (large batches) -----------------------------------------------------------------------------

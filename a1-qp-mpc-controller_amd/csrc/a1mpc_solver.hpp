@@ -652,11 +652,12 @@ struct RowSolver {
         row_sync();
         // lane constants of this pass: component indicators (1.0 / 0.0).  "Add on my diagonal entry only" is one v_fmac_f64_dpp with
         // the leg's bank mask, the component indicator (times my own value) as the own-lane factor and 1.0 = cm[0] of lane 0 as the broadcast one.
-        // (built from opaque values: they must not be hoisted out of the ADMM loop, whose register file is full)
-        double cm[3], qdc[3];
-        const double one_f = row_opaque(1.0), qd_f = row_opaque(qd);
+                double cm[3], qdc[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { cm[c] = comp == c ? one_f : 0.0; qdc[c] = comp == c ? qd_f : 0.0; }
+        for (int c = 0; c < 3; ++c) { cm[c] = comp == c ? 1.0 : 0.0; qdc[c] = comp == c ? qd : 0.0; }
+        // the broadcast factor (1.0 on lane 0) is read through DPP: it must come out of row_dpp_ready(), which also keeps the
+        // compiler from re-materialising it right in front of a use (VALU write -> DPP read hazard)
+        const double one0 = row_dpp_ready(cm[0]);
         double Pn[12];  // row of P_{t+1} (state layout); terminal value c Q
 #pragma unroll
         for (int j = 0; j < 12; ++j) Pn[j] = (act && ci == j) ? qd : 0.0;
@@ -700,7 +701,7 @@ struct RowSolver {
             static_for<6>([&](auto K) {
                 static_for<12>([&](auto B) { fma_bcast<lane_of(6 + A1_CV(K))>(S[B], Bt[K], Y[B]); });
             });
-            static_for<12>([&](auto B) { fma_bcast_leg<0, A1_CV(B) / 3>(S[B], wv[A1_CV(B) % 3], cm[0]); });  // + W on my leg's block (cm[0] of lane 0 = 1)
+            static_for<12>([&](auto B) { fma_bcast_leg<0, A1_CV(B) / 3>(S[B], wv[A1_CV(B) % 3], one0); });  // + W on my leg's block (one0 of lane 0 = 1)
             // in-place Gauss-Jordan inverse of the SPD 12x12 (no pivoting).  Pivot k: row k is scaled by 1/p, every other row i
             // subtracts S_ik/p times row k.  Both are  S_ij += m_i * S_kj  with m_k = 1/p - 1 and m_i = -S_ik/p, i.e. ONE
             // v_fmac_f64_dpp per element whose DPP source is the element's own register read from lane k (gj_pivot); the
@@ -711,7 +712,7 @@ struct RowSolver {
             static_for<12>([&](auto K) {
                 constexpr int k = A1_CV(K);
                 if (!(piv > 0.0)) fac_ok = false;
-                fnma_bcast_leg<0, k / 3>(S[k], cm[k % 3], cm[0]);  // S_ik, minus one on the pivot's own row
+                fnma_bcast_leg<0, k / 3>(S[k], cm[k % 3], one0);  // S_ik, minus one on the pivot's own row
                 const double mlt = -(S[k] * pinv);
                 S[k] = (act && ci == k) ? pinv : mlt;
                 gj_pivot<k>(S, mlt, piv, pinv);
@@ -738,7 +739,7 @@ struct RowSolver {
             if (t > 0) {
                 static_for<12>([&](auto J) {
                     Pn[J] = G[J];
-                    fma_bcast_leg<0, A1_CV(J) / 3>(Pn[J], qdc[A1_CV(J) % 3], cm[0]);
+                    fma_bcast_leg<0, A1_CV(J) / 3>(Pn[J], qdc[A1_CV(J) % 3], one0);
                 });
                 row_dpp_ready12(Kt);
                 static_for<12>([&](auto A_) {
@@ -1159,13 +1160,35 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
     }
 }
 
-// the fused path: one QP from inputs to outputs (small batches, the batch-1 latency path, the CPU test double)
+// the fused path: one QP from inputs to outputs (small batches, the batch-1 latency path, the CPU test double).
+// make_io() is called where the pointers are needed (set-up, hand-off, outputs) instead of once: a ProblemIO of per-row pointers that
+// stays live across the ADMM loop costs that loop ~30 VGPRs it does not have.
+template <int H, int MODE, class MakeIO>
+A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab, MakeIO&& make_io_, double* __restrict__ lds) {
+    if constexpr (MODE == kModeMpc && Prep<H>::STRIDE <= H * Layout<H>::SLOT) {
+        // Set-up and iteration are two solver objects joined by the hand-off record of the split pipeline, staged in the (still
+        // empty) factor region: the ADMM loop then gets the register allocation of the persistent kernel instead of one that
+        // also carries the set-up's live values (scratch reloads inside the loop).  ~0.5 us per solve.
+        {
+            RowSolver<H, MODE> S0(P, tab, lds);
+            S0.setup(make_io_());
+            row_sync();
+            S0.save_prepared(lds + Layout<H>::FAC);
+        }
+        RowSolver<H, MODE> S(P, tab, lds);
+        S.load_prepared(lds + Layout<H>::FAC, make_io_());
+        S.solve();
+        S.write_outputs(make_io_());
+    } else {
+        RowSolver<H, MODE> S(P, tab, lds);
+        S.setup(make_io_());
+        S.solve();
+        S.write_outputs(make_io_());
+    }
+}
 template <int H, int MODE = kModeMpc>
 A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, const ProblemIO& io, double* __restrict__ lds) {
-    RowSolver<H, MODE> S(P, tab, lds);
-    S.setup(io);
-    S.solve();
-    S.write_outputs(io);
+    solve_row_with<H, MODE>(P, tab, [&]() -> const ProblemIO& { return io; }, lds);
 }
 
 }  // namespace a1mpc

@@ -267,6 +267,10 @@ A1_DEV double row_opaque(double v) {
     asm volatile("" : "+v"(v));
     return v;
 }
+A1_DEV int64_t row_opaque(int64_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 
 
 // true if the predicate holds on any live lane of the wavefront (= any row that is still running)

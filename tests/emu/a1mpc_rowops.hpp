@@ -116,6 +116,7 @@ inline void gj_pivot(double (&S)[12], double mlt, double& p, double& x) {
 inline void row_sched_fence() {}
 inline void row_lds_landed() {}
 inline double row_opaque(double v) { return v; }
+inline int64_t row_opaque(int64_t v) { return v; }
 
 
 inline bool row_wave_any(bool p) { return p; }  // one row per emulated wave
