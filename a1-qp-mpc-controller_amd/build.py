@@ -3,9 +3,11 @@
 hipcc cross-compiles without a GPU; the .so is written IN-TREE next to this file so it travels with the
 source snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
 """
+import glob
 import os
 import shutil
 import subprocess
+import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
@@ -30,13 +32,24 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """hipcc -> liba1mpc.so, then the DPP hazard check of the generated gfx950 assembly (isa_check.py): a library whose inline-asm
+    DPP chains read a register too early after a VALU write is deleted again and the build fails."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(CSRC, "gfx950"),
-           "-I", CSRC, os.path.join(CSRC, "a1mpc_hip.hip"), "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    from . import isa_check
+    with tempfile.TemporaryDirectory(prefix="a1mpc_build_") as tmp:  # -save-temps writes the listings into the working directory
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-save-temps", "-I", os.path.join(CSRC, "gfx950"),
+               "-I", CSRC, os.path.join(CSRC, "a1mpc_hip.hip"), "-o", LIB_PATH]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=tmp)
+        listings = glob.glob(os.path.join(tmp, f"*{ARCH}*.s"))
+        if not listings:
+            raise RuntimeError("hipcc -save-temps left no gfx950 listing to check")
+        bad = [h for l in listings for h in isa_check.dpp_hazards(l)]
+    if bad:
+        os.remove(LIB_PATH)
+        raise RuntimeError("DPP read hazards in the generated code (library removed):\n" + "\n".join(bad[:20]))
     return LIB_PATH
 
 

@@ -1,10 +1,11 @@
 // a1mpc_hip.hip -- gfx950 kernels + the C ABI of include/a1mpc.h (liba1mpc.so).
 //
-// One workgroup = one wavefront = four QPs (one per DPP row); dynamic LDS = 4 x Layout<H>::ROW_STRIDE
-// doubles (77.9 KB at H = 10 -> two workgroups per CU).  The QPs of a batch are independent, so the grid
-// is simply ceil(n / 4) workgroups and the hardware dispatcher load-balances rows that need more ADMM
-// iterations; nothing is shared between workgroups except the read-only (alpha/beta) table, so the
-// blockIdx -> XCD mapping is irrelevant for this kernel (no L2 reuse to localise).
+// One workgroup = one wavefront = ROWS QPs (one per 16-lane DPP row; ROWS = 2 by default, A1MPC_ROWS_PER_WG), dynamic LDS =
+// ROWS x Layout<H>::ROW_STRIDE doubles (20.4 KB per QP at H = 10 -> eight QPs = four workgroups per CU).  Three ways through a batch
+// (launch_mpc): the latency kernel (<= 256 QPs: the rows of a wave share one QP's set-up), the fused kernel (up to the resident rows:
+// one row = one QP from inputs to outputs) and the split pipeline (set-up kernel -> persistent ADMM rows that drain a queue in
+// longest-first order -> order kernel).  The QPs of a batch are independent; nothing is shared between workgroups except the read-only
+// (alpha/beta) table and the queue counter, so the blockIdx -> XCD mapping is irrelevant here (no L2 reuse to localise).
 //
 // There is no CPU path in this file: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>

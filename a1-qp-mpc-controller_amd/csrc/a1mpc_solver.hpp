@@ -661,6 +661,9 @@ struct RowSolver {
         double Pn[12];  // row of P_{t+1} (state layout); terminal value c Q
 #pragma unroll
         for (int j = 0; j < 12; ++j) Pn[j] = (act && ci == j) ? qd : 0.0;
+        double Btr[6];  // my column of B~, as a DPP source
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Btr[k] = row_dpp_ready(Bt[k]);
 #pragma unroll 1
         for (int t = H - 1; t >= 0; --t) {
             double* slot = lds + L::FAC + t * L::SLOT;
@@ -670,22 +673,16 @@ struct RowSolver {
             double G[12];
             row_dpp_ready12(Pn);
             static_for<12>([&](auto J) { G[J] = opAT(Pn[J]); });
-            // F' = G(:,6:12) B~  (state row-owner)  and  Y = P_{t+1}(6:12,6:12) B~  (valid on the wrench lanes)
+            // F' = G(:,6:12) B~  (state row-owner)  and  Y = P_{t+1}(6:12,6:12) B~  (valid on the wrench lanes).  B~[k][b] is register k
+            // of force lane b (Bt), so every term is a DPP broadcast: no LDS traffic, no staging registers for B~'s rows
             double Ft[12], Y[12];
+#pragma unroll
+            for (int b = 0; b < 12; ++b) { Ft[b] = 0.0; Y[b] = 0.0; }
             static_for<6>([&](auto K) {
-                double Bk[12];
-#pragma unroll
-                for (int b = 0; b < 12; ++b) Bk[b] = lds[L::BL + K * 12 + b];
-#pragma unroll
-                for (int b = 0; b < 12; ++b) {
-                    if constexpr (A1_CV(K) == 0) {
-                        Ft[b] = G[6] * Bk[b];
-                        Y[b] = Pn[6] * Bk[b];
-                    } else {
-                        Ft[b] = fma(G[6 + K], Bk[b], Ft[b]);
-                        Y[b] = fma(Pn[6 + K], Bk[b], Y[b]);
-                    }
-                }
+                static_for<12>([&](auto B) {
+                    fma_bcast<lane_of(A1_CV(B))>(Ft[B], G[6 + K], Btr[K]);
+                    fma_bcast<lane_of(A1_CV(B))>(Y[B], Pn[6 + K], Btr[K]);
+                });
             });
             G[6] += dt * (cy * G[0] - sy * G[1]);
             G[7] += dt * (sy * G[0] + cy * G[1]);

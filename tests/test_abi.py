@@ -57,3 +57,25 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hpp", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("oracle/a1mpc_oracle.c", "").replace("the oracle", "").lower() or f in ("scenarios.py",), (dp, f)
+
+
+def test_build_hazard_check_flags_early_dpp_reads(pkg, tmp_path):
+    """build() rejects a library whose inline-asm DPP chains read a VGPR fewer than two wait states after a VALU wrote it
+    (isa_check.py; the failure mode is a result that depends on what the row solved before)."""
+    from a1_qp_mpc_controller_amd import isa_check
+    head = "_ZN5a1mpc4testEv:\n.LBB0_1:\n"
+    dpp = "\tv_fmac_f64_dpp v[10:11], v[2:3], v[4:5] row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+    cases = {
+        "write_then_read": ("\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n" + dpp, True),
+        "one_between": ("\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n\tv_add_f64 v[20:21], v[6:7], v[8:9]\n" + dpp, True),
+        "two_between": ("\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n\tv_add_f64 v[20:21], v[6:7], v[8:9]\n\tv_add_f64 v[22:23], v[6:7], v[8:9]\n" + dpp, False),
+        "s_nop_1": ("\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n\ts_nop 1\n" + dpp, False),
+        "s_nop_0": ("\tv_cndmask_b32_e64 v3, 0, v9, s[0:1]\n\ts_nop 0\n" + dpp, True),
+        "other_register": ("\tv_mul_f64 v[12:13], v[6:7], v[8:9]\n" + dpp, False),
+        "own_lane_operand": ("\tv_mul_f64 v[4:5], v[6:7], v[8:9]\n" + dpp, False),  # src1 is not read through DPP
+        "lds_load_is_not_valu": ("\tds_read_b64 v[2:3], v9\n" + dpp, False),
+    }
+    for name, (body, bad) in cases.items():
+        f = tmp_path / (name + ".s")
+        f.write_text(head + body)
+        assert bool(isa_check.dpp_hazards(str(f))) == bad, name
