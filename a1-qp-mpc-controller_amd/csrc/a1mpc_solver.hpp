@@ -715,8 +715,11 @@ struct RowSolver {
                 gj_pivot<k>(S, mlt, piv, pinv);
             });
             if (act) {
-                static_for<12>([&](auto B) {
-                    if (B <= ci) slot[L::K_SZ + tri + B] = S[B];
+                // packed lower triangle, branch-free: entries right of my diagonal go to my own diagonal slot first, in descending
+                // column order, so that the diagonal entry itself is the last one written there (LDS stores of a wave stay in order)
+                static_for<12>([&](auto Bd) {
+                    constexpr int b = 11 - A1_CV(Bd);
+                    slot[L::K_SZ + tri + (b <= ci ? b : ci)] = S[b];
                 });
             }
             // K' = F' S^-1  (state row-owner): K'[i][a] = sum_b F'[i][b] S^-1[b][a]; S^-1[b][a] = register a of force lane b, so every
