@@ -29,7 +29,10 @@ for f in pmc_files.values():
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
         if "a1mpc" in k:
-            short = "setup_kernel" if "setup" in k else ("admm_kernel" if "admm" in k else "solve_kernel(fused)")
+            if "noop" in k:
+                continue  # the launch-latency filler of the batch-1 probe, not part of a solve
+            short = ("setup_kernel" if "setup" in k else "admm_kernel" if "admm" in k else "order_kernel" if "order" in k
+                     else "solve_kernel(fused)" if "solve" in k else k.split("(")[0].split("::")[-1])
             acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summ = {k: {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in d.items()} for k, d in acc.items()}
 tot = sum(summ.get(k, {}).get(c, {}).get("mean_per_launch", 0.0) for k in summ for c in ("FETCH_SIZE", "WRITE_SIZE"))
