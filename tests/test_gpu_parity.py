@@ -151,6 +151,29 @@ def test_size_independent_properties_full_batch(pkg, scen):
     assert np.abs(g.reshape(n, 12) - out["grf"]).max() < 1e-9
 
 
+@pytest.mark.parametrize("gen,n,history", [("config3_random_flat", 200, True),    # latency kernel (the rows of a wave share a set-up)
+                                           ("config3_random_flat", 1500, True),   # fused kernel, two QPs per wave
+                                           ("config3_random_flat", 3000, True),   # split pipeline, longest-first queue
+                                           ("config3_random_flat", 3000, False),  # split pipeline, index-order queue
+                                           ("config4_random_h16", 700, True), ("config5_divergent", 300, True)])
+def test_result_does_not_depend_on_position_or_history(pkg, scen, gen, n, history):
+    """Every kernel path: a QP's result is bit for bit the same wherever it sits in the batch, whatever its wave-mates are and
+    whatever the row solved before (another batch in between).  A violated DPP read hazard or a stale LDS word shows up here."""
+    sc = getattr(scen, gen)(nb=n)
+    args = lambda idx: (sc["x0"][idx], sc["xref"][idx], sc["R"][idx], sc["foot"][idx], sc["contact"][idx])
+    rng = np.random.default_rng(11)
+    with _engine(pkg, sc, n, warm_start=0) as eng:
+        eng.set_schedule(history)
+        out = eng.solve(*args(np.arange(n)), want_u=True)
+        perm = rng.permutation(n)
+        outp = eng.solve(*args(perm), want_u=True)
+        sub = np.sort(rng.choice(n, n // 3, replace=False))  # a different batch size: other wave-mates, other queue order
+        outs = eng.solve(*args(sub), want_u=True)
+        again = eng.solve(*args(np.arange(n)), want_u=True)
+    for o, idx in ((outp, perm), (outs, sub), (again, np.arange(n))):
+        assert (o["u"] == out["u"][idx]).all() and (o["iters"] == out["iters"][idx]).all() and (o["status"] == out["status"][idx]).all()
+
+
 def test_non_finite_input_returns_zeros_and_status(pkg, oracle, scen):
     """a NaN state must not poison its neighbours in the wave: zeros + status -7 for it, exact answers for the others"""
     for n in (8, 512):  # fused kernel, split pipeline

@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel-tuning aid: compiles ONLY the persistent ADMM kernel of one horizon (device code, no ABI) and prints its per-block ISA statistics.
 # usage: tools/one_kernel.sh H [extra hipcc flags]      (output in /tmp/onek)
-#        KERNEL=a1mpc_solve_coop_kernel tools/one_kernel.sh 10 ;  KERNEL=a1mpc_solve_kernel TARGS=', 0, 2' tools/one_kernel.sh 10
+#        KERNEL=a1mpc_solve_coop_kernel tools/one_kernel.sh 10 ;  KERNEL=a1mpc_solve_kernel TARGS=', 0, 2' tools/one_kernel.sh 10 ;  KERNEL=a1mpc_setup_kernel SIG=', double*' tools/one_kernel.sh 10
 set -e
 H=${1:-10}; shift || true
 R=$(cd "$(dirname "$0")/.." && pwd); P=$R/a1-qp-mpc-controller_amd
@@ -27,7 +27,7 @@ if [ -n "$KERNEL" ]; then  # KERNEL=a1mpc_solve_coop_kernel (or any kernel templ
 #include "a1mpc.h"
 #include "a1mpc_solver.hpp"
 #include "body.inc"
-template __global__ void a1mpc::$KERNEL<$H${TARGS}>(const a1mpc::BatchArgs);
+template __global__ void a1mpc::$KERNEL<$H${TARGS}>(const a1mpc::BatchArgs${SIG});
 }
 SRC
 fi
