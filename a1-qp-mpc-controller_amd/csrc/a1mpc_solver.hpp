@@ -234,7 +234,6 @@ struct RowSolver {
     bool warm, first_special;
     int coop_id = 0, coop_n = 1;  // set-up only: row coop_id of coop_n rows of the wave that work on the SAME QP (batch-1 latency path), sharing its LDS image
     bool careful;  // rho is small: c P x + c g is carried through the x-update identity (G in LDS) instead of re-evaluated at the checkpoints
-    const double* warm_y_in;
     // bookkeeping
     int iter, nfact;
     int32_t status;
@@ -258,7 +257,7 @@ struct RowSolver {
         r2a = act ? P.r2[ci] : 0.0;      // force-lane weight 2 r_a
         r0 = comp == 0 ? 0 : (comp == 1 ? 2 : 4); r1 = comp == 0 ? 1 : 3;
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false;
-        warm = false; first_special = false; warm_y_in = nullptr; eqmask = 0; careful = false;
+        warm = false; first_special = false; eqmask = 0; careful = false;
     }
 
     // A_d = I + dt*A_c and its transpose as row operators on a state-layout vector (T = A_c(0:3,6:9), S/ConvexMpc.cpp:123-125)
@@ -556,7 +555,6 @@ struct RowSolver {
         bounds_from_contact((act && io.contact[quad]) ? 1.0 : 0.0);  // contacts broadcast over the horizon (S/ConvexMpc.cpp:228-245)
         rho = P.rho0;
         warm = P.warm_start && io.warm_x != nullptr && io.warm_y != nullptr;
-        warm_y_in = io.warm_y;
         if (warm && io.rho_io != nullptr && *io.rho_io > 0.0) rho = *io.rho_io;
         rho = fmin(fmax(rho, kRhoMin), kRhoMax);
         // OSQP's first iteration starts from z0 = A x0 (not projected) and y0; with x0 = y0 = 0 and 0 inside the bounds it
@@ -573,11 +571,19 @@ struct RowSolver {
             const double di = 1.0 / D[t];
             dI2[t] = di * di;
             xh[t] = (warm && act) ? io.warm_x[t * 12 + ci] : 0.0;  // x_s = D^-1 x  <=>  xh = x
-            wh0[t] = 0.0; wh1[t] = 0.0;
+            park_warm_y(io, t);
             if (act) lds[L::CG + t * 12 + ci] = csc * g[t];          // D^-1 q_s = c g
         });
         row_sync();
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false; careful = false;
+    }
+
+    // OSQP's first iteration needs the warm-start dual y0 twice (both sweeps).  All its loads are issued here, back to back, into the
+    // w registers, which hold nothing before the first iteration (w = 0 when there is no warm start): no global-memory latency
+    // inside the sweeps.
+    A1_DEV void park_warm_y(const ProblemIO& io, int t) {
+        wh0[t] = (warm && act) ? io.warm_y[t * 20 + 5 * quad + r0] : 0.0;
+        wh1[t] = (warm && act && comp < 2) ? io.warm_y[t * 20 + 5 * quad + r1] : 0.0;
     }
 
     // ================================================================================ hand-off between the two kernels
@@ -609,7 +615,7 @@ struct RowSolver {
             rr1[t] = am * p[(PR::RR1 + t) * 12 + ci];
             dI2[t] = p[(PR::DI2 + t) * 12 + ci];
             xh[t] = warm ? am * p[(PR::XH + t) * 12 + ci] : 0.0;
-            wh0[t] = 0.0; wh1[t] = 0.0;
+            park_warm_y(io, t);
             if (act) lds[L::CG + t * 12 + ci] = p[(PR::CG + t) * 12 + ci];
         });
 #pragma unroll
@@ -624,7 +630,6 @@ struct RowSolver {
         lo_u = am * p[PR::LO * 12 + ci]; hi_u = am * p[PR::HI * 12 + ci];
         lb0 = comp == 2 ? lo_u : 0.0; ub0 = comp == 2 ? hi_u : kInfty;
         eqmask = act ? static_cast<unsigned>(p[PR::EQ * 12 + ci]) : 0u;
-        warm_y_in = io.warm_y;
         row_sync();
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false; careful = false;
     }
@@ -787,11 +792,7 @@ struct RowSolver {
             double t0, t1;
             if constexpr (FIRST) {  // E (rho z_s - y_s) = rr (A x0) - c y0
                 const double xz = quad_perm<2, 2, 2, 2>(xh[t]);
-                double yw0 = 0.0, yw1 = 0.0;
-                if (warm && act) {
-                    yw0 = warm_y_in[t * 20 + 5 * quad + r0];
-                    if (comp < 2) yw1 = warm_y_in[t * 20 + 5 * quad + r1];
-                }
+                const double yw0 = wh0[t], yw1 = wh1[t];  // y0 is parked in the (still unused) w registers, see park_warm_y()
                 t0 = rr0[t] * (comp == 2 ? xh[t] : fma(mu, xz, xh[t])) - csc * yw0;
                 t1 = rr1[t] * fma(-mu, xz, xh[t]) - csc * yw1;
             } else {                // E (rho z_s - y_s) = rr (2 Pi(wh) - wh)
@@ -875,11 +876,7 @@ struct RowSolver {
             }
             if constexpr (FIRST) {  // w1 = alpha z~ + (1 - alpha) z0 + y0 / rho,  z0 = A x0
                 const double xz = xz_first;
-                double yw0 = 0.0, yw1 = 0.0;
-                if (warm && act) {
-                    yw0 = warm_y_in[t * 20 + 5 * quad + r0];
-                    if (comp < 2) yw1 = warm_y_in[t * 20 + 5 * quad + r1];
-                }
+                const double yw0 = wh0[t], yw1 = wh1[t];
                 const double z00 = comp == 2 ? xh_old : fma(mu, xz, xh_old), z01 = fma(-mu, xz, xh_old);
                 wh0[t] = al * av0 + oma * z00 + (rr0[t] > 0.0 ? csc * yw0 / rr0[t] : 0.0);
                 wh1[t] = comp < 2 ? al * av1 + oma * z01 + (rr1[t] > 0.0 ? csc * yw1 / rr1[t] : 0.0) : 0.0;
