@@ -11,6 +11,8 @@ osqp = dict(warm_start=0)
 if os.environ.get('A1_SCALING'): osqp['scaling'] = int(os.environ['A1_SCALING'])
 if len(sys.argv) > 1:
     osqp.update(eps_abs=0.0, eps_rel=0.0, max_iter=int(sys.argv[1]), adaptive_rho=0)
+    if os.environ.get('A1_ADAPT'):  # a rho update (= one more factor pass) at every checkpoint
+        osqp.update(adaptive_rho=1, adaptive_rho_tolerance=1.0 + 1e-9)
 cfg = pkg.make_config(sc["params"], 10, **osqp)
 dev = torch.device("cuda", 0)
 d = {k: torch.from_numpy(sc[k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")}
@@ -21,4 +23,4 @@ st = torch.cuda.Stream(device=dev)
 for _ in range(5):
     eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, iters, status, stream=st.cuda_stream)
 torch.cuda.synchronize()
-print("kernel ms", eng.last_kernel_ms(), "mean iters", iters.float().mean().item())
+print("kernel ms", eng.last_kernel_ms(), "mean iters", iters.float().mean().item(), "mean factor passes", float(eng.last_nfact(n).mean()))
