@@ -3,7 +3,8 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, __graft_entry__ as g
 pkg = g.load_package(); orc = g.load_oracle()
 worst = 0; bad = 0; tot = 0
-for seed in range(3000, 3012):
+lo = int(sys.argv[1]) if len(sys.argv) > 1 else 3000; cnt = int(sys.argv[2]) if len(sys.argv) > 2 else 12  # usage: soak_parity.py [first_seed [count]]
+for seed in range(lo, lo + cnt):
     n = 4096
     sc = pkg.scenarios.config3_random_flat(nb=n, seed=seed, param_set=("gazebo", "hardware", "isaac")[seed % 3]); p = sc["params"]
     cfg = pkg.make_config(p, 10, warm_start=0)
