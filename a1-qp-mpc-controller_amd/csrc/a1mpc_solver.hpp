@@ -222,6 +222,7 @@ struct RowSolver {
     double dt, mu;
     // per-lane constants of the problem
     double Bt[6];  // my column of B~ (force layout); zero on pad lanes
+    static constexpr bool kBrowInRegs = H <= 10;  // beyond that the per-lane ADMM state alone (6H doubles) overflows the register file
     double Brw[12];  // my row of B~ (state layout; zeros on lanes without a wrench state): step-invariant, so it stays in registers --
                      // an LDS read costs the wave ~12 issue cycles whatever its width (tools/ubench/issue_cost_ubench.hip)
     double cy, sy, fA, fB, fC, fP, gA, gB, gC, gV, q2s, r2a;
@@ -754,7 +755,7 @@ struct RowSolver {
             row_sync();  // K_t and S_t^-1 of this step are in LDS before the next step reuses the registers' sources
         }
 #pragma unroll
-        for (int b = 0; b < 12; ++b) Brw[b] = brow[b];
+        for (int b = 0; b < 12; ++b) Brw[b] = kBrowInRegs ? brow[b] : 0.0;
         need_factor = false;
         if (!fac_ok) { status = A1MPC_NON_CVX; done = true; }
     }
@@ -830,6 +831,11 @@ struct RowSolver {
                 constexpr int b = A1_CV(B);
                 if constexpr (t > 0) Kr[b] = slot[krow + b];
             });
+            [[maybe_unused]] double Brl[12];  // H > 10: my row of B~ is re-read per step (the 24 registers are worth more than 6 LDS reads there)
+            if constexpr (!kBrowInRegs && t < H - 1) {
+#pragma unroll
+                for (int b = 0; b < 12; ++b) Brl[b] = brow[b];
+            }
             row_sched_fence();
             // v_t = d_t - K_t x_t,  xh <- alpha v + (1 - alpha) xh,  x_{t+1} = A x_t + B~ v_t   (instruction blocks)
             const double am = act ? 1.0 : 0.0;  // pad lanes carry no force
@@ -854,7 +860,8 @@ struct RowSolver {
                 sweep_fwd_gain<false>(v, sa, sb, xh[t], s, Kr, fA, fB, fC, am, oma, al);
             }
             if constexpr (t < H - 1) {
-                sweep_fwd_input(sa, sb, z0, v, Brw, wh0[t], lb0_l, ub0_l);
+                if constexpr (kBrowInRegs) sweep_fwd_input(sa, sb, z0, v, Brw, wh0[t], lb0_l, ub0_l);
+                else sweep_fwd_input(sa, sb, z0, v, Brl, wh0[t], lb0_l, ub0_l);
                 s = sa;  // lanes without a wrench state read the zero row of B~
             } else {
                 z0 = min_f64(max_f64(wh0[t], lb0_l), ub0_l);
@@ -896,7 +903,9 @@ struct RowSolver {
             double sv[H];
             double s = row_dpp_ready(0.0);
             static_for<H>([&](auto T) {
-                s = row_dpp_ready(opA(s) + Bu(row_dpp_ready(xh[T])));
+                // B~ u with my row of B~ from registers (loaded by factorize) where it is kept there
+                if constexpr (kBrowInRegs) s = row_dpp_ready(opA(s) + dot_bc<0>(Brw, row_dpp_ready(xh[T])));
+                else s = row_dpp_ready(opA(s) + Bu(row_dpp_ready(xh[T])));
                 sv[T] = q2s * s;
             });
             double lam = row_dpp_ready(0.0);
