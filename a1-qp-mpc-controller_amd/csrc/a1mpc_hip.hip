@@ -243,6 +243,11 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
     hipLaunchKernelGGL((a1mpc_setup_kernel<H>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
     A1_HIP(hipGetLastError());
+    if (a.predict && a.cost != nullptr && a.order != nullptr) {  // no history: the queue order comes from the set-up kernel's cost guesses
+        hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, static_cast<int>(a.n), static_cast<const int32_t*>(a.cost),
+                           const_cast<int32_t*>(a.order));
+        A1_HIP(hipGetLastError());
+    }
     const int want = (a.n + ROWS - 1) / ROWS;
     hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), dim3(static_cast<unsigned>(want < res ? want : res)), dim3(16 * ROWS), lds2, stream, a,
                        static_cast<const double*>(prep), counter);
@@ -1455,12 +1460,14 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     h->last_stream = s;
     if (h->cfg.warm_start) { a.warm_x = h->d_wx; a.warm_y = h->d_wy; a.rho = h->d_rho; }
     // Straggler-aware queue order: batches beyond the resident rows are issued longest-first by the cost each QP had in the previous solve of
-    // this handle (the same robots tick after tick); the first solve of a batch size runs in index order.  Scheduling only.
+    // this handle (the same robots tick after tick); the first solve of a batch size is ordered by the set-up kernel's cost guess
+    // (RowSolver::predict_cost).  Scheduling only.
     bool split = false;
     if (a1mpc_status st0 = use_split_pipeline(h->cfg.horizon, n, h->d_prep != nullptr, &split); st0 != A1MPC_OK) return st0;
     const bool hints = h->schedule && split && n >= kScheduleMinBatch;
-    a.order = (hints && h->hint_n == n) ? h->d_order : nullptr;
+    a.order = hints ? h->d_order : nullptr;
     a.cost = hints ? h->d_cost : nullptr;
+    a.predict = (hints && h->hint_n != n) ? 1 : 0;  // first solve of this batch size: order by the set-up kernel's guess instead
     A1_HIP(hipEventRecord(h->ev0, s));
     a1mpc_status st = launch_mpc(h->cfg.horizon, a, h->d_prep, h->d_counter, s, split);
     if (st != A1MPC_OK) return st;

@@ -239,6 +239,7 @@ struct RowSolver {
     int iter, nfact;
     int32_t status;
     bool fac_ok, need_factor, done;
+    int pred_cost = 0;  // set-up's guess of this QP's cost (queue order of a first solve, see predict_cost)
     struct Info {
         double pri_res, dua_res, nEz, nEAx, nDq, nDAty, nDPx;  // unscaled
         double s_pri, s_dua, s_z, s_Ax, s_q, s_Aty, s_Px;      // scaled (rho estimate)
@@ -409,12 +410,16 @@ struct RowSolver {
                 xs = act ? io.x0[ci] : 0.0;
                 grav = io.x0[12];
             }
+            const double x_now = xs;
+            double err0 = 0.0;  // first reference state minus the current state, my component
             static_for<H>([&](auto T) {
                 xs = opA(row_dpp_ready(xs));
                 if (ln == 14) xs += dt * grav;  // A_c(11,12) = 1 (S/ConvexMpc.cpp:129)
                 const double xr = io.tick ? xr_base + xr_slope * double(A1_CV(T) + 1) : (act ? io.xref[T * 13 + ci] : 0.0);
+                if constexpr (A1_CV(T) == 0) err0 = xr - x_now;
                 w[T] = q2s * (xs - xr);
             });
+            predict_cost(row_dpp_ready(err0), io);
             double lam = row_dpp_ready(0.0);
             static_for<H>([&](auto TT) {
                 constexpr int t = H - 1 - A1_CV(TT);
@@ -577,6 +582,19 @@ struct RowSolver {
         });
         row_sync();
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false; careful = false;
+    }
+
+    // Queue-order heuristic for a batch without history (scheduling only, no result depends on it): ADMM needs more iterations the more
+    // force the velocity error demands.  A linear fit of (iterations + 10 factor passes) on random SRBD states, 30 e_vz + 27 |e_vxy|, has
+    // rank correlation 0.4-0.6 with the true cost where states vary like that -- enough to start most long QPs early (tools/wave_sim.py,
+    // tools/first_solve_probe.py) -- and orders like chance where they do not.  (A stance-leg term raises the correlation on flat-ground
+    // batches and was dropped: on mixed-contact batches it sends the hardest, one- and two-leg QPs to the back of the queue.)
+    // Stored in 1/8 units of the real cost's scale, like the counting sort of a1mpc_order_kernel expects.
+    A1_DEV void predict_cost(double err0_ready, const ProblemIO&) {
+        const double evx = bc<9>(err0_ready), evy = bc<10>(err0_ready), evz = bc<11>(err0_ready);
+        const double hard = 30.0 * evz + 27.0 * sqrt(evx * evx + evy * evy);
+        const double c = 8.0 * hard + 400.0;
+        pred_cost = c > 0.0 ? (c < 2047.0 ? static_cast<int>(c) : 2047) : 0;  // (NaN -> 0)
     }
 
     // OSQP's first iteration needs the warm-start dual y0 twice (both sweeps).  All its loads are issued here, back to back, into the
@@ -1100,6 +1118,7 @@ struct BatchArgs {
     // built from (null = not recorded); scheduling only -- no result depends on either
     const int32_t* order;
     int32_t* cost;
+    int32_t predict;  // the set-up kernel writes its cost guess to `cost` (first solve of a batch: no history to order the queue by)
 };
 template <int H, int MODE>
 A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
@@ -1129,6 +1148,7 @@ A1_DEV void setup_row(const BatchArgs& a, const double* __restrict__ tab, int64_
     RowSolver<H, kModeMpc, true> S(a.P, tab, lds);  // tab: the (alpha/beta, beta) table, staged in LDS by the kernel
     S.setup(make_io<H, kModeMpc>(a, b));
     S.save_prepared(prep + b * Prep<H>::STRIDE);
+    if (a.predict && a.cost != nullptr && S.ln == 0) a.cost[b] = S.pred_cost;
 }
 
 // split pipeline, kernel 2: a persistent row.  It pulls prepared QPs from a shared counter and advances them one

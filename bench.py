@@ -256,7 +256,7 @@ def main():
 
     it = iters.cpu().numpy(); stt = status.cpu().numpy()
     # the same steps in plain index order (what the first solve of a batch gets): reported beside `value`, never instead of it
-    index_ms = None
+    index_ms = first_ms = None
     if not args.no_index_order:
         eng.set_schedule(False)
         step(); torch.cuda.synchronize()
@@ -267,6 +267,15 @@ def main():
         e1.record(stream)
         torch.cuda.synchronize()
         index_ms = e0.elapsed_time(e1) / args.steps
+        # ... and as a FIRST solve each time: a1mpc_set_schedule() drops the history, so the queue is ordered by the set-up kernel's cost guess
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.steps):
+            eng.set_schedule(True)
+            step()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        first_ms = e0.elapsed_time(e1) / args.steps
         eng.set_schedule(True)
     if rank == 0:
         h = HORIZON
@@ -298,7 +307,9 @@ def main():
         out["scheduling"] = {
             "mode": "history: the work queue of a batch beyond the resident rows is ordered longest-first by the per-QP cost of the previous "
                     "solve of the handle (a1mpc_set_schedule); every QP is solved from scratch every step, results are independent of the order",
-            "index_order_ms_per_step": index_ms, "index_order_solves_per_s_per_gpu": (n / (index_ms * 1e-3)) if index_ms else None}
+            "index_order_ms_per_step": index_ms, "index_order_solves_per_s_per_gpu": (n / (index_ms * 1e-3)) if index_ms else None,
+            "first_solve_ms_per_step": first_ms, "first_solve_solves_per_s_per_gpu": (n / (first_ms * 1e-3)) if first_ms else None,
+            "first_solve_note": "no history: queue ordered by the set-up kernel's per-QP cost guess (velocity error, rank correlation ~0.6 on this workload)"}
         if not args.no_latency:
             out["latency"] = latency_probe(pkg)
             out["throughput_by_batch"] = batch_sweep(pkg, local)

@@ -281,8 +281,9 @@ a1mpc_status a1mpc_joint_torques_batch_device(a1mpc_handle h, int32_t n, const u
 
 /* Work-queue order of batches larger than the resident set: history = 1 (default) issues the QPs longest-first by the cost
  * (iterations + factor passes) each one had in the previous solve of this handle with the same n -- the same robots tick after
- * tick; history = 0 is plain index order.  The first solve of a batch size, and the solve after a1mpc_reset_warm_start, run in
- * index order.  Scheduling only: no returned number depends on it.  Environment override at create: A1MPC_SCHEDULE=index. */
+ * tick; history = 0 is plain index order.  The first solve of a batch size, the solve after a1mpc_reset_warm_start and the solve after
+ * this call have no history: their queue is ordered by a cost guess the set-up kernel derives from each QP's velocity error.
+ * Scheduling only: no returned number depends on it.  Environment override at create: A1MPC_SCHEDULE=index. */
 a1mpc_status a1mpc_set_schedule(a1mpc_handle h, int32_t history);
 
 /* forget the carried (x, y, rho) of every problem: next solve is a cold start */
