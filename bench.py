@@ -255,7 +255,7 @@ def main():
         elapsed = float(t.item())
 
     it = iters.cpu().numpy(); stt = status.cpu().numpy()
-    # the same steps in plain index order (what the first solve of a batch gets): reported beside `value`, never instead of it
+    # the same steps in plain index order (a1mpc_set_schedule(0)) and as first solves (no history): reported beside `value`, never instead of it
     index_ms = first_ms = None
     if not args.no_index_order:
         eng.set_schedule(False)
