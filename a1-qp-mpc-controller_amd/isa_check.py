@@ -4,10 +4,15 @@ hipcc pads the hazards of the instructions it schedules itself, but not inside (
 v_fmac_f64_dpp chains are inline asm.  Rule (gfx90a+): a VGPR written by a VALU instruction needs 2 wait states before a DPP
 instruction reads it as its DPP source (src0); a VALU write of EXEC needs 5.  Every instruction in between counts as one wait
 state, `s_nop N` as N + 1.  A violated hazard reads the register's previous content: results that depend on which QP the row
-solved before.  The check is linear within a basic block and clears its history at a label (a hazard that spans a branch target is
-not seen: the solver's blocks begin with LDS reads, not with DPP reads).
+solved before.
+
+Control flow: the listing is split into basic blocks at labels; a block starts from the merged tails of ALL its predecessors (the
+fall-through one and every block that branches to its label, loop back-edges included), merged per age, so a write at the end of a
+loop body is seen by a DPP read at the loop head.
 """
 import re
+
+_DEPTH = 6  # wait states of history that matter (EXEC rule: 5)
 
 
 def _regs(tok):
@@ -19,42 +24,117 @@ def _regs(tok):
     return {int(m.group(1))} if m else set()
 
 
-def dpp_hazards(path, key=""):
-    """list of "file:line: kernel: message" strings, empty if the listing is clean"""
-    out = []
+def _parse(path, key):
+    """kernels -> list of blocks {label, instrs: [(line_no, text, op, ops)], targets: [labels], falls: bool}"""
+    kernels = {}
     kernel = None
-    hist = []  # (written VGPR set, writes_exec) of the previous instructions / wait states, newest last
+    cur = None
     with open(path) as f:
         for ln, l in enumerate(f, 1):
             m = re.match(r"^(_Z\w+):", l)
             if m:
-                kernel = m.group(1)
-                hist = []
+                kernel = m.group(1) if key in m.group(1) else None
+                if kernel:
+                    cur = dict(label=None, instrs=[], targets=[], falls=True)
+                    kernels[kernel] = [cur]
                 continue
-            if re.match(r"^\.LBB\d+_\d+:", l):
-                hist = []
+            if kernel is None:
+                continue
+            m = re.match(r"^(\.LBB\d+_\d+):", l)
+            if m:
+                cur = dict(label=m.group(1), instrs=[], targets=[], falls=True)
+                kernels[kernel].append(cur)
                 continue
             t = l.strip()
-            if not t or t[0] in ";.#" or kernel is None or key not in kernel:
+            if not t or t[0] in ";.#":
+                if t.startswith(".end_amdhsa_kernel") or t.startswith(".Lfunc_end"):
+                    kernel = None
                 continue
             mm = re.match(r"^([a-z][a-z0-9_]+)\s*(.*?)(\s*;.*)?$", t)
             if not mm:
                 continue
             op, rest = mm.group(1), mm.group(2)
             ops = [o.strip() for o in re.split(r",(?![^\[]*\])", rest)] if rest else []
-            if "_dpp" in op and len(ops) >= 2:
-                s0 = _regs(ops[1].split(" ")[0])
-                for age, (w, ex) in enumerate(reversed(hist[-5:]), 1):  # age - 1 = wait states between the write and this read
-                    if age <= 2 and (w & s0):
-                        out.append(f"{path}:{ln}: {kernel[:60]}: DPP source {ops[1].split(' ')[0]} written {age} instruction(s) earlier: {t}")
-                    if ex:
-                        out.append(f"{path}:{ln}: {kernel[:60]}: DPP {age} wait state(s) after a VALU write of EXEC: {t}")
-            if op == "s_nop":
-                hist += [(set(), False)] * (int(rest.split()[0], 0) + 1)
-            else:
-                w = set()
-                if op.startswith("v_") and ops and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
-                    w = _regs(ops[0].split(" ")[0])
-                hist.append((w, op.startswith("v_cmpx")))
-            hist = hist[-8:]
+            cur["instrs"].append((ln, t, op, ops))
+            b = re.match(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", t)
+            if b:
+                cur["targets"].append(b.group(1))
+            cur["falls"] = not (op in ("s_branch", "s_endpgm", "s_setpc_b64"))
+    return kernels
+
+
+def _step(hist, op, ops, rest_first):
+    """history after one instruction (list of (written VGPRs, writes EXEC), newest last)"""
+    if op == "s_nop":
+        hist = hist + [(frozenset(), False)] * (int(rest_first, 0) + 1)
+    else:
+        w = frozenset()
+        if op.startswith("v_") and ops and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+            w = frozenset(_regs(ops[0].split(" ")[0]))
+        hist = hist + [(w, op.startswith("v_cmpx"))]
+    return hist[-_DEPTH:]
+
+
+def _merge(tails):
+    """per-age union of several history tails (aligned at the newest entry)"""
+    out = []
+    for age in range(1, _DEPTH + 1):
+        w = set()
+        ex = False
+        for t in tails:
+            if len(t) >= age:
+                w |= t[-age][0]
+                ex = ex or t[-age][1]
+        out.append((frozenset(w), ex))
+    return list(reversed(out))
+
+
+def dpp_hazards(path, key=""):
+    """list of "file:line: kernel: message" strings, empty if the listing is clean"""
+    out = []
+    for kernel, blocks in _parse(path, key).items():
+        # pass 1: the tail every block leaves behind when entered with an empty history (a block of >= _DEPTH wait states forgets its entry)
+        tails = []
+        for b in blocks:
+            h = []
+            for _, _, op, ops in b["instrs"]:
+                h = _step(h, op, ops, ops[0].split()[0] if ops else "0")
+            tails.append(h)
+        by_label = {b["label"]: i for i, b in enumerate(blocks) if b["label"]}
+        preds = {i: [] for i in range(len(blocks))}
+        for i, b in enumerate(blocks):
+            if b["falls"] and i + 1 < len(blocks):
+                preds[i + 1].append(i)
+            for t in b["targets"]:
+                if t in by_label:
+                    preds[by_label[t]].append(i)
+        # short blocks pass their own entry history on: iterate the entry histories to a fixed point (bounded: the history is _DEPTH deep)
+        entry = [[] for _ in blocks]
+        for _ in range(_DEPTH + 1):
+            changed = False
+            for i, b in enumerate(blocks):
+                exits = []
+                for p in preds[i]:
+                    h = list(entry[p])
+                    for _, _, op, ops in blocks[p]["instrs"]:
+                        h = _step(h, op, ops, ops[0].split()[0] if ops else "0")
+                    exits.append(h)
+                new = _merge(exits) if exits else []
+                if new != entry[i]:
+                    entry[i] = new
+                    changed = True
+            if not changed:
+                break
+        # pass 2: check
+        for i, b in enumerate(blocks):
+            h = list(entry[i])
+            for ln, t, op, ops in b["instrs"]:
+                if "_dpp" in op and len(ops) >= 2:
+                    s0 = _regs(ops[1].split(" ")[0])
+                    for age, (w, ex) in enumerate(reversed(h[-5:]), 1):  # age - 1 = wait states between the write and this read
+                        if age <= 2 and (w & s0):
+                            out.append(f"{path}:{ln}: {kernel[:60]}: DPP source {ops[1].split(' ')[0]} written {age} instruction(s) earlier: {t}")
+                        if ex:
+                            out.append(f"{path}:{ln}: {kernel[:60]}: DPP {age} wait state(s) after a VALU write of EXEC: {t}")
+                h = _step(h, op, ops, ops[0].split()[0] if ops else "0")
     return out

@@ -75,6 +75,15 @@ def test_build_hazard_check_flags_early_dpp_reads(pkg, tmp_path):
         "own_lane_operand": ("\tv_mul_f64 v[4:5], v[6:7], v[8:9]\n" + dpp, False),  # src1 is not read through DPP
         "lds_load_is_not_valu": ("\tds_read_b64 v[2:3], v9\n" + dpp, False),
     }
+    filler = "\tv_add_f64 v[30:31], v[6:7], v[8:9]\n"
+    cases.update({
+        # control flow: the write is the last instruction of a loop body, the DPP read the first one at the loop head
+        "loop_back_edge": (dpp + filler * 3 + "\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n\ts_cbranch_scc1 .LBB0_1\n", True),
+        "loop_back_edge_padded": (dpp + filler * 3 + "\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n" + filler * 2 + "\ts_cbranch_scc1 .LBB0_1\n", False),
+        "fall_through_into_label": ("\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n.LBB0_2:\n" + dpp, True),
+        "branch_target": ("\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n\ts_branch .LBB0_3\n.LBB0_2:\n" + filler * 3 + "\ts_endpgm\n.LBB0_3:\n" + dpp, True),
+        "not_a_predecessor": ("\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n\ts_endpgm\n.LBB0_2:\n" + dpp, False),
+    })
     for name, (body, bad) in cases.items():
         f = tmp_path / (name + ".s")
         f.write_text(head + body)
