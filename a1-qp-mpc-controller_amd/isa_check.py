@@ -2,8 +2,9 @@
 
 hipcc pads the hazards of the instructions it schedules itself, but not inside (or between) inline-asm statements, and the solver's
 v_fmac_f64_dpp chains are inline asm.  Rule (gfx90a+): a VGPR written by a VALU instruction needs 2 wait states before a DPP
-instruction reads it as its DPP source (src0); a VALU write of EXEC needs 5.  Every instruction in between counts as one wait
-state, `s_nop N` as N + 1.  A violated hazard reads the register's previous content: results that depend on which QP the row
+instruction reads it as its DPP source (src0); a VALU write of EXEC needs 5; the result of a transcendental instruction
+(v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos) needs 1 before another VALU instruction reads it.  Every instruction in
+between counts as one wait state, `s_nop N` as N + 1.  A violated hazard reads the register's previous content: results that depend on which QP the row
 solved before.
 
 Control flow: the listing is split into basic blocks at labels; a block starts from the merged tails of ALL its predecessors (the
@@ -63,15 +64,18 @@ def _parse(path, key):
     return kernels
 
 
+_TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
+
+
 def _step(hist, op, ops, rest_first):
-    """history after one instruction (list of (written VGPRs, writes EXEC), newest last)"""
+    """history after one instruction (list of (written VGPRs, writes EXEC, is transcendental), newest last)"""
     if op == "s_nop":
-        hist = hist + [(frozenset(), False)] * (int(rest_first, 0) + 1)
+        hist = hist + [(frozenset(), False, False)] * (int(rest_first, 0) + 1)
     else:
         w = frozenset()
         if op.startswith("v_") and ops and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
             w = frozenset(_regs(ops[0].split(" ")[0]))
-        hist = hist + [(w, op.startswith("v_cmpx"))]
+        hist = hist + [(w, op.startswith("v_cmpx"), op.startswith(_TRANS))]
     return hist[-_DEPTH:]
 
 
@@ -80,12 +84,13 @@ def _merge(tails):
     out = []
     for age in range(1, _DEPTH + 1):
         w = set()
-        ex = False
+        ex = tr = False
         for t in tails:
             if len(t) >= age:
                 w |= t[-age][0]
                 ex = ex or t[-age][1]
-        out.append((frozenset(w), ex))
+                tr = tr or t[-age][2]  # conservative: "some predecessor's write at this age was transcendental"
+        out.append((frozenset(w), ex, tr))
     return list(reversed(out))
 
 
@@ -129,9 +134,13 @@ def dpp_hazards(path, key=""):
         for i, b in enumerate(blocks):
             h = list(entry[i])
             for ln, t, op, ops in b["instrs"]:
+                if op.startswith("v_") and not op.startswith(_TRANS) and h and h[-1][2]:
+                    srcs = set().union(*[_regs(o.split(" ")[0]) for o in (ops if op.startswith("v_fmac") else ops[1:])]) if ops else set()
+                    if h[-1][0] & srcs:
+                        out.append(f"{path}:{ln}: {kernel[:60]}: result of a transcendental instruction read by the next instruction: {t}")
                 if "_dpp" in op and len(ops) >= 2:
                     s0 = _regs(ops[1].split(" ")[0])
-                    for age, (w, ex) in enumerate(reversed(h[-5:]), 1):  # age - 1 = wait states between the write and this read
+                    for age, (w, ex, _tr) in enumerate(reversed(h[-5:]), 1):  # age - 1 = wait states between the write and this read
                         if age <= 2 and (w & s0):
                             out.append(f"{path}:{ln}: {kernel[:60]}: DPP source {ops[1].split(' ')[0]} written {age} instruction(s) earlier: {t}")
                         if ex:

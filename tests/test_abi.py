@@ -84,6 +84,11 @@ def test_build_hazard_check_flags_early_dpp_reads(pkg, tmp_path):
         "branch_target": ("\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n\ts_branch .LBB0_3\n.LBB0_2:\n" + filler * 3 + "\ts_endpgm\n.LBB0_3:\n" + dpp, True),
         "not_a_predecessor": ("\tv_mul_f64 v[2:3], v[6:7], v[8:9]\n\ts_endpgm\n.LBB0_2:\n" + dpp, False),
     })
+    cases.update({
+        "trans_result_next": ("\tv_rcp_f64 v[2:3], v[6:7]\n\tv_fma_f64 v[12:13], -v[6:7], v[2:3], 1.0\n", True),
+        "trans_result_after_one": ("\tv_rcp_f64 v[2:3], v[6:7]\n" + filler + "\tv_fma_f64 v[12:13], -v[6:7], v[2:3], 1.0\n", False),
+        "trans_then_unrelated": ("\tv_rcp_f64 v[2:3], v[6:7]\n\tv_fma_f64 v[12:13], -v[6:7], v[8:9], 1.0\n", False),
+    })
     for name, (body, bad) in cases.items():
         f = tmp_path / (name + ".s")
         f.write_text(head + body)

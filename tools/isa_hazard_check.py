@@ -10,5 +10,5 @@ mod = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(mod)
 bad = mod.dpp_hazards(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
 print("\n".join(bad[:50]))
-print(f"{'HAZARDS: %d' % len(bad) if bad else 'no DPP read hazards'} ({sys.argv[1]})")
+print(f"{'HAZARDS: %d' % len(bad) if bad else 'no DPP / transcendental read hazards'} ({sys.argv[1]})")
 sys.exit(1 if bad else 0)
