@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package(); scen = pkg.scenarios
-n = 65536
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 rng = np.random.default_rng(0)
 cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
 out = {}
