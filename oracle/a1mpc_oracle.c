@@ -6,14 +6,20 @@
  * library, and only as the checker / the timed CPU baseline.  The product path
  * (a1-qp-mpc-controller_amd/csrc) never links, loads or calls anything in oracle/.
  *
- * >>> PARITY UNPINNED. <<<
- * The reference pins no expected values (S/test/test_mpc.cpp:157-161 only prints) and
- * its arithmetic for the solve lives in third-party OSQP (oxfordcontrol/osqp, fetched
- * UNPINNED at image build: docker/Dockerfile:77,91; install log shows
- * libOsqpEigen.so.0.6.3, docker/Dockerfile:98 => OSQP 0.6.x) which is absent from
- * /root/reference and from this machine, as are Eigen and ROS.  Nothing under
- * /root/reference is compilable here (every file includes Eigen/OsqpEigen/ROS), so
- * there is no oracle/_ref.  This file therefore
+ * >>> PARITY: FORMATION AND CALLER-SIDE ROWS PINNED TO THE REFERENCE, THE OSQP SOLVE UNPINNED. <<<
+ * Pinned (round 2): `make -C oracle ref` compiles the reference's own sources -- S/ConvexMpc.cpp, S/A1RobotControl.cpp,
+ * S/A1BasicEKF.cpp, S/utils/Utils.cpp, S/utils/filter.hpp, S/legKinematics/A1Kinematics.cpp, S/test/test_mpc.cpp -- verbatim
+ * from /root/reference into oracle/_ref/liba1ref*.so over the stand-in headers of oracle/ref_shim/ (a mini-Eigen, no-op ROS
+ * names, an OsqpEigen::Solver that calls orc_osqp_solve below), and tests/test_ref_pin.py drives both with the same numbers:
+ * (P, g, A, l, u) equal to <= 1e-15 relative at h = 10 / 16 / 20 (the latter two through the one-macro PLAN_HORIZON edit) incl.
+ * per-step B_d; test_mpc.cpp as written; compute_grf's MPC branch over a warm-started sequence and its balance branch; the
+ * update_plan -> swing legs -> contacts / filters / terrain -> MPC -> joint torques chain over 150 ticks (element-wise rows bit for
+ * bit); leg kinematics; the EKF.  That pins the reference's SOURCE LOGIC.  It does not pin the rounding of Eigen's kernels (the
+ * stand-in's products are plain ascending-k sums; Eigen is not installed here).
+ * Unpinned: the SOLVE.  The reference pins no expected values (S/test/test_mpc.cpp:157-161 only prints) and its arithmetic for
+ * the solve lives in third-party OSQP (oxfordcontrol/osqp, fetched UNPINNED at image build: docker/Dockerfile:77,91; install log
+ * shows libOsqpEigen.so.0.6.3, docker/Dockerfile:98 => OSQP 0.6.x), absent from /root/reference and from this machine (no
+ * network, no wheel).  This file therefore
  *   (1) restates the reference's own QP formation loop-for-loop in plain arrays
  *       (S/ConvexMpc.cpp:7-58,110-156,181-245; S/A1RobotControl.cpp:11-48,377-413,
  *        439-444,452-488,498-514,555-561; S/utils/Utils.cpp:35-41), and
@@ -28,10 +34,12 @@
  * reference is not run-to-run reproducible.  The oracle uses a fixed iteration period
  * (default 25 = the value OSQP's own rounding rule c_max(c_roundmultiple(iter,25),25)
  * yields whenever 0.4*setup_time is worth < 38 iterations).
- * The linear system is solved in its reduced form (P+sigma*I+A' diag(rho) A) by dense
- * Cholesky -- algebraically what QDLDL's AMD ordering does to this KKT matrix (the
- * degree-2 constraint rows are eliminated first); z_tilde is recovered through nu as
- * OSQP does (solve_linsys_qdldl).
+ * Data handling follows OSQP's: only the upper triangle of P is used (mirrored), scaling multiplies rows first and then
+ * columns (mat_premult_diag / mat_postmult_diag).  The linear system has two back ends (settings->linsys): 0 = its reduced
+ * form (P+sigma*I+A' diag(rho) A) by dense Cholesky -- algebraically what QDLDL's AMD ordering does to this KKT matrix (the
+ * degree-2 constraint rows are eliminated first), z_tilde recovered through nu as solve_linsys_qdldl does; 1 = LDL' of the full
+ * quasi-definite KKT matrix in natural order.  Both give the same iteration count and status on every QP of the soak
+ * (profiles/r02_linsys_soak.json); their forces differ by up to ~1e-6 N, which is the resolution any "same answer as OSQP" claim has.
  *
  * Pinned instead (tests/test_oracle_*.py): KKT optimality of the tight mode, an
  * independent scipy solve, analytic stand cases, and golden vectors in tests/golden/.
@@ -65,24 +73,7 @@
 #define OSQP_MIN_SCALING 1e-4
 #define OSQP_MAX_SCALING 1e4
 
-/* status values mirror OSQP's */
-#define ORC_SOLVED 1
-#define ORC_SOLVED_INACCURATE 2
-#define ORC_MAX_ITER_REACHED (-2)
-#define ORC_PRIMAL_INFEASIBLE (-3)
-#define ORC_DUAL_INFEASIBLE (-4)
-#define ORC_NON_CVX (-7)
-#define ORC_UNSOLVED (-10)
-
-typedef struct orc_settings {
-    double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, adaptive_rho_tolerance;
-    int32_t max_iter, scaling, check_termination, adaptive_rho, adaptive_rho_interval, warm_start;
-} orc_settings;
-
-typedef struct orc_info {
-    int32_t iters, status, rho_updates, nfact;
-    double pri_res, dua_res, rho_final;
-} orc_info;
+#include "a1mpc_oracle_api.h" /* status codes, orc_settings, orc_info (shared with the oracle/_ref OsqpEigen stand-in) */
 
 /* OSQP defaults (osqp/include/constants.h 0.6.x); warm_start as the MPC call site sets it. */
 void orc_default_settings(orc_settings *s) {
@@ -90,7 +81,7 @@ void orc_default_settings(orc_settings *s) {
     s->eps_abs = 1e-3; s->eps_rel = 1e-3; s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
     s->adaptive_rho_tolerance = 5.0;
     s->max_iter = 4000; s->scaling = 10; s->check_termination = 25;
-    s->adaptive_rho = 1; s->adaptive_rho_interval = 25; s->warm_start = 0;
+    s->adaptive_rho = 1; s->adaptive_rho_interval = 25; s->warm_start = 0; s->linsys = 0; s->reserved_ = 0;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -154,6 +145,7 @@ typedef struct {
     double *D, *Dinv, *E, *Einv, c, cinv; /* scaling */
     double *rho_vec, *rho_inv_vec; int *ctype;
     double *K;                            /* Cholesky factor of reduced KKT */
+    double *KK, *KKd, *kb;                /* linsys = 1: LDL' of the full KKT (lower, row-major (n+m)^2), its D, a right-hand side */
     double *x, *z, *y, *x_prev, *z_prev, *xt, *zt, *delta_x, *delta_y;
     double *Ax, *Px, *Aty, *tn, *tm;
     double rho;
@@ -180,8 +172,10 @@ static void scale_data(work_t *w) {
         for (int j = 0; j < n; ++j) Dt[j] = 1.0 / sqrt(limit_scaling1(Dt[j]));
         for (int i = 0; i < m; ++i) Et[i] = 1.0 / sqrt(limit_scaling1(Et[i]));
         /* P <- D P D ; A <- E A D ; q <- D q */
-        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) w->P[i * n + j] *= Dt[i] * Dt[j];
-        for (int i = 0; i < m; ++i) for (int k = w->rp[i]; k < w->rp[i + 1]; ++k) w->av[k] *= Et[i] * Dt[w->ci[k]];
+        /* OSQP stores the upper triangle and scales it rows first, then columns (mat_premult_diag, mat_postmult_diag):
+         * P_ij <- (P_ij * D_i) * D_j for i <= j; the lower triangle is its mirror.  A likewise: (A_ij * E_i) * D_j. */
+        for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) { double v = (w->P[i * n + j] * Dt[i]) * Dt[j]; w->P[i * n + j] = v; w->P[j * n + i] = v; }
+        for (int i = 0; i < m; ++i) for (int k = w->rp[i]; k < w->rp[i + 1]; ++k) w->av[k] = (w->av[k] * Et[i]) * Dt[w->ci[k]];
         for (int j = 0; j < n; ++j) { w->q[j] *= Dt[j]; w->D[j] *= Dt[j]; }
         for (int i = 0; i < m; ++i) w->E[i] *= Et[i];
         /* cost normalisation */
@@ -211,9 +205,47 @@ static void set_rho_vec(work_t *w) {
     }
 }
 
+/* Second back end (settings->linsys = 1): LDL' of the full quasi-definite KKT matrix [P + sigma I, A'; A, -diag(1/rho)] as OSQP's
+ * QDLDL factors it, dense and in natural order (QDLDL's AMD permutation cannot be reproduced without AMD; a quasi-definite matrix
+ * has an LDL' factorisation under every symmetric permutation, so only the rounding differs).  It exists to show that iteration
+ * counts and statuses do not depend on which of the two algebraically equal solves is used (tests/tools/linsys_soak.py). */
+static int kkt_factor(work_t *w) {
+    const int n = w->n, m = w->m, N = n + m;
+    double *K = w->KK, *d = w->KKd;
+    memset(K, 0, sizeof(double) * (size_t)N * N);
+    for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) K[(size_t)i * N + j] = w->P[i * n + j];
+    for (int j = 0; j < n; ++j) K[(size_t)j * N + j] += w->st->sigma;
+    for (int i = 0; i < m; ++i) {
+        for (int k = w->rp[i]; k < w->rp[i + 1]; ++k) K[(size_t)(n + i) * N + w->ci[k]] = w->av[k];
+        K[(size_t)(n + i) * N + n + i] = -w->rho_inv_vec[i];
+    }
+    for (int j = 0; j < N; ++j) {          /* row-oriented LDL', lower triangle in place, unit diagonal implied */
+        double *rj = K + (size_t)j * N;
+        double dj = rj[j];
+        for (int k = 0; k < j; ++k) dj -= rj[k] * rj[k] * d[k];
+        if (dj == 0.0 || isnan(dj)) return 1;
+        d[j] = dj;
+        for (int i = j + 1; i < N; ++i) {
+            double *ri = K + (size_t)i * N;
+            double sv = ri[j];
+            for (int k = 0; k < j; ++k) sv -= ri[k] * rj[k] * d[k];
+            ri[j] = sv / dj;
+        }
+    }
+    for (int j = 0; j < n; ++j) if (!(d[j] > 0.0)) return 1;   /* OSQP: wrong number of positive pivots => non-convex */
+    return 0;
+}
+static void kkt_solve(const work_t *w, double *b) {
+    const int N = w->n + w->m; const double *K = w->KK, *d = w->KKd;
+    for (int i = 0; i < N; ++i) { double sv = b[i]; const double *ri = K + (size_t)i * N; for (int k = 0; k < i; ++k) sv -= ri[k] * b[k]; b[i] = sv; }
+    for (int i = 0; i < N; ++i) b[i] /= d[i];
+    for (int i = N - 1; i >= 0; --i) { double sv = b[i]; for (int k = i + 1; k < N; ++k) sv -= K[(size_t)k * N + i] * b[k]; b[i] = sv; }
+}
+
 /* reduced KKT: K = P + sigma I + A' diag(rho) A, Cholesky */
 static int factor(work_t *w) {
     int n = w->n;
+    if (w->st->linsys == 1) { w->info->nfact++; return kkt_factor(w); }
     memcpy(w->K, w->P, sizeof(double) * n * n);
     for (int j = 0; j < n; ++j) w->K[j * n + j] += w->st->sigma;
     for (int i = 0; i < w->m; ++i)
@@ -337,7 +369,7 @@ int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t
                    orc_info *info) {
     work_t w; memset(&w, 0, sizeof w);
     int nnz = rp[m];
-    size_t tot = (size_t)2 * n * n + 16 * (size_t)n + 16 * (size_t)m + nnz + 64;
+    size_t tot = (size_t)2 * n * n + 16 * (size_t)n + 16 * (size_t)m + nnz + 64 + (st->linsys == 1 ? (size_t)(n + m) * (n + m) + 2 * (size_t)(n + m) : 0);
     double *buf = (double *)calloc(tot, sizeof(double));
     int *ctype = (int *)calloc(m + 1, sizeof(int));
     if (!buf || !ctype) { free(buf); free(ctype); return -1; }
@@ -348,8 +380,12 @@ int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t
     w.D = TAKE(n); w.Dinv = TAKE(n); w.E = TAKE(m); w.Einv = TAKE(m); w.rho_vec = TAKE(m); w.rho_inv_vec = TAKE(m);
     w.x = TAKE(n); w.z = TAKE(m); w.y = TAKE(m); w.x_prev = TAKE(n); w.z_prev = TAKE(m); w.xt = TAKE(n); w.zt = TAKE(m);
     w.delta_x = TAKE(n); w.delta_y = TAKE(m); w.Ax = TAKE(m); w.Px = TAKE(n); w.Aty = TAKE(n); w.tn = TAKE(n); w.tm = TAKE(m);
+    if (st->linsys == 1) { w.KK = TAKE((n + m) * (n + m)); w.KKd = TAKE(n + m); w.kb = TAKE(n + m); }
 #undef TAKE
     memcpy(w.P, P, sizeof(double) * n * n); memcpy(w.q, q, sizeof(double) * n); memcpy(w.av, av, sizeof(double) * nnz);
+    /* OSQP is handed the UPPER triangle of P only (osqp-eigen: setHessianMatrix -> triangularView<Upper>); the reference's dense
+     * B_qp'QB_qp is symmetric only up to rounding, so mirror the upper triangle instead of trusting the lower one */
+    for (int i = 1; i < n; ++i) for (int j = 0; j < i; ++j) w.P[i * n + j] = w.P[j * n + i];
     memcpy(w.l, l, sizeof(double) * m); memcpy(w.u, u, sizeof(double) * m);
     memset(info, 0, sizeof *info); info->status = ORC_UNSOLVED;
     w.rho = (rho_io && st->warm_start && *rho_io > 0) ? *rho_io : st->rho;
@@ -379,11 +415,21 @@ int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t
             for (int i = 0; i < m; ++i) w.tm[i] = w.z_prev[i] - w.rho_inv_vec[i] * w.y[i]; /* rhs_z */
             for (int j = 0; j < n; ++j) w.xt[j] = sigma * w.x_prev[j] - w.q[j];
             for (int i = 0; i < m; ++i) { double s = w.rho_vec[i] * w.tm[i]; for (int k = rp[i]; k < rp[i + 1]; ++k) w.xt[ci[k]] += w.av[k] * s; }
+            if (st->linsys == 1) {
+                /* auxil.c update_xz_tilde + lin_sys/qdldl solve_linsys_qdldl: [x_tilde; nu] = K^-1 [sigma x_prev - q; z_prev - rho^-1 y],
+                 * z_tilde = rhs_z + rho^-1 nu  (rhs_z is what the solve was given in the lower block) */
+                for (int j = 0; j < n; ++j) w.kb[j] = sigma * w.x_prev[j] - w.q[j];
+                for (int i = 0; i < m; ++i) w.kb[n + i] = w.tm[i];
+                kkt_solve(&w, w.kb);
+                for (int j = 0; j < n; ++j) w.xt[j] = w.kb[j];
+                for (int i = 0; i < m; ++i) w.zt[i] = w.tm[i] + w.rho_inv_vec[i] * w.kb[n + i];
+            } else {
             chol_solve(w.K, n, w.xt);
             csr_mv(m, rp, ci, w.av, w.xt, w.zt); /* A x_tilde */
             for (int i = 0; i < m; ++i) {
                 double nu = w.rho_vec[i] * (w.zt[i] - w.tm[i]);
                 w.zt[i] = w.tm[i] + w.rho_inv_vec[i] * nu; /* b[n+j] += rho_inv*nu (solve_linsys_qdldl) */
+            }
             }
             /* update_x, update_z, update_y */
             for (int j = 0; j < n; ++j) { w.x[j] = alpha * w.xt[j] + (1.0 - alpha) * w.x_prev[j]; w.delta_x[j] = w.x[j] - w.x_prev[j]; }
@@ -580,7 +626,13 @@ int orc_mpc_solve(const orc_mpc_params *pr, const orc_settings *st, const double
         for (int i = 0; i < 3; ++i) grf_out[3 * leg + i] = bad ? 0.0 : Rw[0 * 3 + i] * f[0] + Rw[1 * 3 + i] * f[1] + Rw[2 * 3 + i] * f[2];
     }
     if (u_full) memcpy(u_full, x, sizeof(double) * n);
-    if (warm_x) { memcpy(warm_x, x, sizeof(double) * n); memcpy(warm_y, y, sizeof(double) * m); }
+    if (warm_x) {
+        /* A failed solve (NaN solution) must not poison the carried workspace: OSQP's store_solution() cold-starts the iterates in
+         * that case; here the next tick is a full cold start (x = y = 0, rho back to settings->rho). */
+        int failed = info->status == ORC_PRIMAL_INFEASIBLE || info->status == ORC_DUAL_INFEASIBLE || info->status == ORC_NON_CVX;
+        if (failed) { memset(warm_x, 0, sizeof(double) * n); memset(warm_y, 0, sizeof(double) * m); if (warm_rho) *warm_rho = 0; }
+        else { memcpy(warm_x, x, sizeof(double) * n); memcpy(warm_y, y, sizeof(double) * m); }
+    }
     free(P); free(rp);
     return rc;
 }

@@ -23,7 +23,7 @@ class Settings(C.Structure):
                 ("eps_rel", C.c_double), ("eps_prim_inf", C.c_double), ("eps_dual_inf", C.c_double),
                 ("adaptive_rho_tolerance", C.c_double), ("max_iter", C.c_int32), ("scaling", C.c_int32),
                 ("check_termination", C.c_int32), ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
-                ("warm_start", C.c_int32)]
+                ("warm_start", C.c_int32), ("linsys", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class Info(C.Structure):

@@ -1,0 +1,4 @@
+// TEST INFRASTRUCTURE (oracle/_ref build)
+#pragma once
+#include <vector>
+namespace std_msgs { struct Float64MultiArray { std::vector<double> data; }; }

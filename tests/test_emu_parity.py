@@ -37,7 +37,7 @@ def test_emulated_warm_start_sequence(oracle, scen):
         out = emu.solve(one, 1, warm=(ewx, ewy, erho), warm_start=1)
         assert out["iters"][0] == r["info"].iters, (t, out["iters"], r["info"].iters)
         assert np.abs(out["u"][0] - r["u"]).max() < 1e-8
-        assert np.abs(ewy[0] - wy).max() < 1e-6 and abs(erho[0] - rho) < 1e-12 * rho
+        assert np.abs(ewy[0] - wy).max() < 1e-6 and abs(erho[0] - rho) < 1e-11 * rho   # rho-estimate: a ratio of nearly cancelled residuals, sensitive to the last bits of P
 
 
 def test_emulated_balance_qp(oracle, scen):
