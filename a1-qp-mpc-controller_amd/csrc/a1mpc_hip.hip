@@ -38,6 +38,17 @@ __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
     solve_row_with<H, MODE>(a.P, a.tab, [&]() { return make_io<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
 }
 
+// General path (per-step feet / per-step contact schedules: S/ConvexMpc.h:74 B_mat_d_list, S/test/test_mpc.cpp:106-122): the fused kernel
+// over RowSolver<.., GEN = true>, whose LDS image also holds B~_t and the bounds of every horizon step.
+template <int H, int ROWS>
+__global__ __launch_bounds__(64) void a1mpc_solve_gen_kernel(const KernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
+    const int row = static_cast<int>(threadIdx.x) >> 4;
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
+    if (b >= a.n) return;
+    solve_row_with<H, kModeMpc, true>(a.P, a.tab, [&]() { return make_io<H, kModeMpc>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H, true>::ROW_STRIDE);
+}
+
 // Latency variant of the fused kernel for a handful of QPs: the four rows of a wavefront work on ONE QP during set-up (each takes every fourth
 // horizon step of the Ruiz sweeps; everything else is computed redundantly and written to the one shared LDS image), then rows 1-3 retire
 // and row 0 solves.  Same results bit for bit (the column maxima are exact and order-free).
@@ -291,6 +302,32 @@ static a1mpc_status launch_rows(const KernelArgs& a, hipStream_t stream) {
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
 }
+template <int H, int ROWS>
+static a1mpc_status launch_gen_rows(const KernelArgs& a, hipStream_t stream) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    A1_HIP(hipGetDevice(&dev));
+    const size_t lds = sizeof(double) * ROWS * Layout<H, true>::ROW_STRIDE;
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_gen_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds)));
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((a1mpc_solve_gen_kernel<H, ROWS>), dim3(static_cast<unsigned>((a.n + ROWS - 1) / ROWS)), dim3(16 * ROWS), lds, stream, a);
+    A1_HIP(hipGetLastError());
+    return A1MPC_OK;
+}
+// LDS per QP: 25.2 KB (H = 10: six QPs per CU), 39.9 KB (H = 16: four), 49.7 KB (H = 20: three, one row per workgroup)
+static a1mpc_status launch_gen(int horizon, const KernelArgs& a, hipStream_t s) {
+#ifndef A1MPC_DEV_SLIM
+    switch (horizon) {
+        case 10: return launch_gen_rows<10, 2>(a, s);
+        case 16: return launch_gen_rows<16, 2>(a, s);
+        case 20: return launch_gen_rows<20, 1>(a, s);
+    }
+#endif
+    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet / contact schedules need horizon 10, 16 or 20");
+}
 static constexpr int kCoopMaxBatch = 256;  // at most this many QPs: one wavefront per QP during set-up (the chip has 1024 SIMDs)
 template <int H>
 static a1mpc_status launch_coop(const KernelArgs& a, hipStream_t stream) {
@@ -405,6 +442,11 @@ struct a1mpc_handle_s {
     double *d_grf = nullptr, *d_u = nullptr;
     int32_t *d_iters = nullptr, *d_status = nullptr, *d_nfact = nullptr;
     hipStream_t last_stream = nullptr;
+    // Every launch touches handle-owned scratch (prepared-state records, queue counter / order / cost, nfact, the carried OSQP workspace,
+    // the filter states): a call on another stream than the previous call's first waits for that call's work (ev_order, recorded after
+    // every launch); the reset functions wait for it on the host.
+    hipEvent_t ev_order = nullptr;
+    bool busy = false;
     // carried OSQP workspace (warm start)
     double *d_wx = nullptr, *d_wy = nullptr, *d_rho = nullptr;
     // split pipeline: prepared state of every QP (set-up kernel -> ADMM kernel) and the work-queue counter
@@ -412,6 +454,8 @@ struct a1mpc_handle_s {
     int* d_counter = nullptr;
     // queue order of the next solve (longest-first by the previous solve's per-QP cost) -- see a1mpc_set_schedule
     int32_t *d_order = nullptr, *d_cost = nullptr;
+    double* d_foot_steps = nullptr;      // general path: n x 12H per-step feet (allocated on first use)
+    uint8_t* d_contact_steps = nullptr;  // general path: n x 4H per-step contacts
     double* d_ct_state = nullptr;  // N2b filter state of every robot (allocated on first use)
     double* d_ekf_state = nullptr;  // N4c Kalman filter state of every robot (allocated on first use)
     // staging of the element-wise entry points (N2a, N2b, N3), allocated on first use: 64 / 96 doubles and 16 bytes per robot
@@ -424,6 +468,18 @@ struct a1mpc_handle_s {
     char* h_pin = nullptr;
     size_t h_pin_bytes = 0, h_pin_in_bytes = 0;
 };
+
+static a1mpc_status order_streams(a1mpc_handle h, hipStream_t s) {
+    if (h->busy && h->last_stream != s) A1_HIP(hipStreamWaitEvent(s, h->ev_order, 0));
+    return A1MPC_OK;
+}
+static a1mpc_status mark_launched(a1mpc_handle h, hipStream_t s) {
+    A1_HIP(hipEventRecord(h->ev_order, s));
+    h->busy = true; h->last_stream = s;
+    return A1MPC_OK;
+}
+#define A1_ORDER(h, s) do { if (a1mpc_status so_ = order_streams(h, s); so_ != A1MPC_OK) return so_; } while (0)
+#define A1_MARK(h, s) do { if (a1mpc_status sm_ = mark_launched(h, s); sm_ != A1MPC_OK) return sm_; } while (0)
 
 extern "C" {
 
@@ -579,6 +635,7 @@ a1mpc_status a1mpc_reset_contact_state(a1mpc_handle h) {
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
     if (!h->d_ct_state) return A1MPC_OK;
     A1_HIP(hipSetDevice(h->device));
+    A1_ORDER(h, h->stream);  // the memsets below must not overtake a launch still running on a caller's stream
     A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double), h->stream));
     A1_HIP(hipStreamSynchronize(h->stream));
     return A1MPC_OK;
@@ -597,6 +654,7 @@ a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_con
     if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
     const size_t N = n;
     hipStream_t s = h->stream;
+    A1_ORDER(h, s);
     if (!h->d_ct_state) {
         A1_HIP(hipMalloc(&h->d_ct_state, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double)));
         A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double), s));
@@ -620,7 +678,7 @@ a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_con
     hipLaunchKernelGGL(a1mpc_terrain_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
     A1_HIP(hipGetLastError());
     A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true; h->last_stream = s;
+    h->timed = true; A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(contacts_out, d_ct, N * 4, hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(foot_pos_recent_contact_out, d_rec, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(terrain_angle_out, d_ta, N * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -695,6 +753,7 @@ a1mpc_status a1mpc_swing_legs_batch(a1mpc_handle h, int32_t n, double counter_pe
     if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
     const size_t N = n;
     hipStream_t s = h->stream;
+    A1_ORDER(h, s);
     // staging: in [Rz 9 | foot 12 | gc 4 | target_rel 12] = 37, in/out + out [start 12 | rel_last 12 | target_last 12] (aux_in tail, 36) and [cur 12 | kin 12]
     double *d_Rz = h->d_aux_in, *d_fa = d_Rz + 9 * N, *d_gc = d_fa + 12 * N, *d_tr = d_gc + 4 * N;
     double *d_st = h->d_aux_out, *d_rl = d_st + 12 * N, *d_tl = d_rl + 12 * N;
@@ -715,7 +774,7 @@ a1mpc_status a1mpc_swing_legs_batch(a1mpc_handle h, int32_t n, double counter_pe
     hipLaunchKernelGGL(a1mpc_swing_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
     A1_HIP(hipGetLastError());
     A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true; h->last_stream = s;
+    h->timed = true; A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(foot_pos_start, d_st, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(foot_pos_rel_last_time, d_rl, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(foot_pos_target_last_time, d_tl, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -781,6 +840,7 @@ a1mpc_status a1mpc_leg_state_batch(a1mpc_handle h, int32_t n, const double* join
     if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
     const size_t N = n;
     hipStream_t s = h->stream;
+    A1_ORDER(h, s);
     // staging: aux_in [q 12 | qd 12 | R 9 | pos 3 | vel 3 | rel 12] = 51 of 64, aux_out [Jb 36 | vrel 12 | pabs 12 | vabs 12 | pworld 12 | vworld 12] = 96
     double *d_q = h->d_aux_in, *d_qd = d_q + 12 * N, *d_R = d_qd + 12 * N, *d_pos = d_R + 9 * N, *d_vel = d_pos + 3 * N, *d_rel = d_vel + 3 * N;
     double *d_Jb = h->d_aux_out, *d_vrel = d_Jb + 36 * N, *d_pabs = d_vrel + 12 * N, *d_vabs = d_pabs + 12 * N, *d_pw = d_vabs + 12 * N, *d_vw = d_pw + 12 * N;
@@ -799,7 +859,7 @@ a1mpc_status a1mpc_leg_state_batch(a1mpc_handle h, int32_t n, const double* join
     hipLaunchKernelGGL(a1mpc_leg_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
     A1_HIP(hipGetLastError());
     A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true; h->last_stream = s;
+    h->timed = true; A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(foot_pos_rel_out, d_rel, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(j_foot_blocks_out, d_Jb, N * 36 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (foot_vel_rel_out) A1_HIP(hipMemcpyAsync(foot_vel_rel_out, d_vrel, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -992,6 +1052,7 @@ a1mpc_status a1mpc_reset_ekf_state(a1mpc_handle h) {
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
     if (!h->d_ekf_state) return A1MPC_OK;
     A1_HIP(hipSetDevice(h->device));
+    A1_ORDER(h, h->stream);  // the memsets below must not overtake a launch still running on a caller's stream
     A1_HIP(hipMemsetAsync(h->d_ekf_state, 0, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double), h->stream));
     A1_HIP(hipStreamSynchronize(h->stream));
     return A1MPC_OK;
@@ -1010,6 +1071,7 @@ a1mpc_status a1mpc_ekf_update_batch(a1mpc_handle h, int32_t n, double dt, int32_
     if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
     const size_t N = n;
     hipStream_t s = h->stream;
+    A1_ORDER(h, s);
     if (!h->d_ekf_state) {
         A1_HIP(hipMalloc(&h->d_ekf_state, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double)));
         A1_HIP(hipMemsetAsync(h->d_ekf_state, 0, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double), s));
@@ -1033,7 +1095,7 @@ a1mpc_status a1mpc_ekf_update_batch(a1mpc_handle h, int32_t n, double dt, int32_
     hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((N + 1) / 2)), dim3(64), 0, s, a);
     A1_HIP(hipGetLastError());
     A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true; h->last_stream = s;
+    h->timed = true; A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(root_pos_out, d_pos, N * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(root_lin_vel_out, d_vel, N * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(estimated_contacts_out, d_ec, N * 4, hipMemcpyDeviceToHost, s));
@@ -1117,6 +1179,7 @@ a1mpc_status a1mpc_joint_torques_batch(a1mpc_handle h, int32_t n, const uint8_t*
     if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
     const size_t N = n;
     hipStream_t s = h->stream;
+    A1_ORDER(h, s);
     // staging: in [J 36 | grf 12 | f_kin 12], out [tg 12 | tau 12]
     double *d_J = h->d_aux_in, *d_grf = d_J + 36 * N, *d_fk = d_grf + 12 * N, *d_tg = h->d_aux_out, *d_tau = d_tg + 12 * N;
     uint8_t *d_c = h->d_aux_u8, *d_act = h->d_aux_u8 + 8 * N;
@@ -1134,7 +1197,7 @@ a1mpc_status a1mpc_joint_torques_batch(a1mpc_handle h, int32_t n, const uint8_t*
     hipLaunchKernelGGL(a1mpc_torque_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
     A1_HIP(hipGetLastError());
     A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true; h->last_stream = s;
+    h->timed = true; A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(joint_torques, d_tau, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipStreamSynchronize(s));
     return A1MPC_OK;
@@ -1166,6 +1229,7 @@ a1mpc_status a1mpc_update_plan_batch(a1mpc_handle h, const a1mpc_gait_config* ga
     if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
     const size_t N = n;
     hipStream_t s = h->stream;
+    A1_ORDER(h, s);
     // staging: in [gc 4 | spd 4 | v 3 | vd 3 | pos 3 | Rz 9 | Rw 9], out [rel 12 | abs 12 | world 12]
     double* din = h->d_aux_in;
     double *d_gc = din, *d_spd = d_gc + 4 * N, *d_v = d_spd + 4 * N, *d_vd = d_v + 3 * N, *d_pos = d_vd + 3 * N, *d_Rz = d_pos + 3 * N, *d_Rw = d_Rz + 9 * N;
@@ -1186,7 +1250,7 @@ a1mpc_status a1mpc_update_plan_batch(a1mpc_handle h, const a1mpc_gait_config* ga
     hipLaunchKernelGGL(a1mpc_plan_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
     A1_HIP(hipGetLastError());
     A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true; h->last_stream = s;
+    h->timed = true; A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(gait_counter, d_gc, N * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(plan_contacts_out, d_pc, N * 4, hipMemcpyDeviceToHost, s));
     if (rel_out) A1_HIP(hipMemcpyAsync(rel_out, d_rel, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1206,12 +1270,13 @@ a1mpc_status a1mpc_update_plan_batch(a1mpc_handle h, const a1mpc_gait_config* ga
     if (n == 0) return A1MPC_OK;                                                                             \
     A1_HIP(hipSetDevice(h->device));                                                                         \
     hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->stream;                           \
+    A1_ORDER(h, s);                                                                                          \
     const size_t N = n;                                                                                      \
     (void)N
 #define A1_DEV_EPILOGUE()              \
     A1_HIP(hipGetLastError());         \
     A1_HIP(hipEventRecord(h->ev1, s)); \
-    h->timed = true; h->last_stream = s; \
+    h->timed = true; A1_MARK(h, s); \
     return A1MPC_OK
 
 a1mpc_status a1mpc_update_plan_batch_device(a1mpc_handle h, const a1mpc_gait_config* gait, int32_t n, const uint8_t* movement_mode,
@@ -1324,12 +1389,13 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_tab, h->d_tab1, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_aux, h->d_Rz, h->d_contact, h->d_grf,
-                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_ekf_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8};
+                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_ekf_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8, h->d_foot_steps, h->d_contact_steps};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_order) (void)hipEventDestroy(h->ev_order);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1363,6 +1429,7 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     A1_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     A1_TRY(hipEventCreate(&h->ev0));
     A1_TRY(hipEventCreate(&h->ev1));
+    A1_TRY(hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming));
     std::vector<double> tab(2 * H * H), tab1(2);
     fill_gamma_beta_table(H, tab.data());
     fill_gamma_beta_table(1, tab1.data());
@@ -1422,9 +1489,50 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     return A1MPC_OK;
 }
 
+a1mpc_status a1mpc_update_config(a1mpc_handle h, const a1mpc_config* cfg) {
+    if (!h || !cfg) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle/config");
+    if (cfg->horizon != h->cfg.horizon) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "the horizon of a handle is fixed at a1mpc_create");
+    if (!(cfg->dt > 0) || !(cfg->mass > 0) || cfg->max_iter <= 0 || !(cfg->rho > 0) || !(cfg->sigma > 0))
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "dt, mass, rho, sigma and max_iter must be positive");
+    // every constant travels to the kernels by value with each launch: nothing on the device has to change, launches already
+    // queued keep the values they were issued with, the carried warm start stays
+    h->cfg = *cfg;
+    to_device_params(*cfg, &h->dp);
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_warm_start(a1mpc_handle h, int32_t n, const double* x, const double* y, const double* rho) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0 || (!x && !y && !rho)) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    A1_ORDER(h, h->stream);
+    const size_t N = n, H = h->cfg.horizon;
+    if (x) A1_HIP(hipMemcpyAsync(h->d_wx, x, N * 12 * H * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (y) A1_HIP(hipMemcpyAsync(h->d_wy, y, N * 20 * H * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (rho) A1_HIP(hipMemcpyAsync(h->d_rho, rho, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    A1_HIP(hipStreamSynchronize(h->stream));
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_get_warm_start(a1mpc_handle h, int32_t n, double* x_out, double* y_out, double* rho_out) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    A1_ORDER(h, h->stream);
+    const size_t N = n, H = h->cfg.horizon;
+    if (x_out) A1_HIP(hipMemcpyAsync(x_out, h->d_wx, N * 12 * H * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (y_out) A1_HIP(hipMemcpyAsync(y_out, h->d_wy, N * 20 * H * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (rho_out) A1_HIP(hipMemcpyAsync(rho_out, h->d_rho, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    A1_HIP(hipStreamSynchronize(h->stream));
+    return A1MPC_OK;
+}
+
 a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h) {
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
     A1_HIP(hipSetDevice(h->device));
+    A1_ORDER(h, h->stream);  // the memsets below must not overtake a launch still running on a caller's stream
     const size_t n = h->max_batch, H = h->cfg.horizon;
     A1_HIP(hipMemsetAsync(h->d_wx, 0, n * 12 * H * sizeof(double), h->stream));
     A1_HIP(hipMemsetAsync(h->d_wy, 0, n * 20 * H * sizeof(double), h->stream));
@@ -1444,7 +1552,7 @@ a1mpc_status a1mpc_set_schedule(a1mpc_handle h, int32_t history) {
 static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d_tick, const double* d_x0, const double* d_x_ref,
                                       const double* d_R_world, const double* d_foot_abs, const uint8_t* d_contact,
                                       double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out,
-                                      void* hip_stream) {
+                                      void* hip_stream, int32_t foot_stride = 0, int32_t contact_stride = 0) {
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0 || (!d_tick && (!d_x0 || !d_x_ref)) || !d_R_world || !d_foot_abs || !d_contact || !d_grf_body_out)
         return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
@@ -1452,13 +1560,23 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     if (n == 0) return A1MPC_OK;
     A1_HIP(hipSetDevice(h->device));
     hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->stream;
+    A1_ORDER(h, s);
     KernelArgs a;
     std::memset(&a, 0, sizeof a);
     a.P = h->dp; a.tab = h->d_tab; a.n = n;
     a.tick = d_tick; a.x0 = d_x0; a.xref = d_x_ref; a.R = d_R_world; a.foot = d_foot_abs; a.contact = d_contact;
     a.grf = d_grf_body_out; a.u_full = d_u_full_out; a.iters = d_iters_out; a.status = d_status_out; a.nfact = h->d_nfact;
-    h->last_stream = s;
     if (h->cfg.warm_start) { a.warm_x = h->d_wx; a.warm_y = h->d_wy; a.rho = h->d_rho; }
+    if (foot_stride != 0 || contact_stride != 0) {  // general path: per-step B_d and / or a per-step contact schedule
+        if (d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "per-step feet / contacts are not combined with tick records");
+        a.foot_stride = foot_stride; a.contact_stride = contact_stride;
+        A1_HIP(hipEventRecord(h->ev0, s));
+        if (a1mpc_status stg = launch_gen(h->cfg.horizon, a, s); stg != A1MPC_OK) return stg;
+        A1_HIP(hipEventRecord(h->ev1, s));
+        h->timed = true;
+        A1_MARK(h, s);
+        return A1MPC_OK;
+    }
     // Straggler-aware queue order: batches beyond the resident rows are issued longest-first by the cost each QP had in the previous solve of
     // this handle (the same robots tick after tick); the first solve of a batch size is ordered by the set-up kernel's cost guess
     // (RowSolver::predict_cost).  Scheduling only.
@@ -1478,6 +1596,7 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     }
     A1_HIP(hipEventRecord(h->ev1, s));
     h->timed = true;
+    A1_MARK(h, s);
     return A1MPC_OK;
 }
 
@@ -1506,6 +1625,7 @@ a1mpc_status a1mpc_solve_batch_ticks(a1mpc_handle h, int32_t n, const double* ti
     A1_HIP(hipSetDevice(h->device));
     const size_t N = n, H = h->cfg.horizon;
     hipStream_t s = h->stream;
+    A1_ORDER(h, s);
     // 22 + 9 + 12 doubles + 4 bytes per QP: the tick record rides in the x_ref staging buffer (13H >= 22 for H >= 2; H = 1 has its own room: 13 + 13)
     double* d_tick = (H >= 2) ? h->d_xref : h->d_x0;
     if (H < 2) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "tick records need horizon >= 2");
@@ -1548,6 +1668,7 @@ a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, cons
     std::memcpy(hin + o_f, foot_abs, N * 12 * sizeof(double));
     std::memcpy(hin + o_c, contact, N * 4);
     hipStream_t s = h->stream;
+    A1_ORDER(h, s);
     A1_HIP(hipMemcpyAsync(h->d_in, hin, in_bytes, hipMemcpyHostToDevice, s));
     a1mpc_status st = a1mpc_solve_batch_device(
         h, n, reinterpret_cast<const double*>(h->d_in + o_x0), reinterpret_cast<const double*>(h->d_in + o_xr),
@@ -1565,6 +1686,54 @@ a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, cons
     return A1MPC_OK;
 }
 
+static bool strides_ok(int32_t foot_stride, int32_t contact_stride) {
+    return (foot_stride == 0 || foot_stride == 12) && (contact_stride == 0 || contact_stride == 4);
+}
+a1mpc_status a1mpc_solve_batch_strided_device(a1mpc_handle h, int32_t n, const double* d_x0, const double* d_x_ref, const double* d_R_world,
+                                              const double* d_foot_abs, int32_t foot_stride, const uint8_t* d_contact, int32_t contact_stride,
+                                              double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out,
+                                              void* hip_stream) {
+    if (!d_x0 || !d_x_ref) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (!strides_ok(foot_stride, contact_stride)) return fail(A1MPC_ERR_INVALID_ARGUMENT, "foot_stride must be 0 or 12, contact_stride 0 or 4");
+    return solve_device_impl(h, n, nullptr, d_x0, d_x_ref, d_R_world, d_foot_abs, d_contact, d_grf_body_out, d_u_full_out, d_iters_out,
+                             d_status_out, hip_stream, foot_stride, contact_stride);
+}
+a1mpc_status a1mpc_solve_batch_strided(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
+                                       const double* foot_abs, int32_t foot_stride, const uint8_t* contact, int32_t contact_stride,
+                                       double* grf_body_out, double* u_full_out, int32_t* iters_out, int32_t* status_out) {
+    if (!strides_ok(foot_stride, contact_stride)) return fail(A1MPC_ERR_INVALID_ARGUMENT, "foot_stride must be 0 or 12, contact_stride 0 or 4");
+    if (foot_stride == 0 && contact_stride == 0)  // the reference controller's case: the fast path, bit for bit
+        return a1mpc_solve_batch(h, n, x0, x_ref, R_world, foot_abs, contact, grf_body_out, u_full_out, iters_out, status_out);
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !grf_body_out)
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    const size_t N = n, H = h->cfg.horizon, nfoot = foot_stride ? 12 * H : 12, ncont = contact_stride ? 4 * H : 4;
+    hipStream_t s = h->stream;
+    A1_ORDER(h, s);
+    if (!h->d_foot_steps) {
+        A1_HIP(hipMalloc(&h->d_foot_steps, static_cast<size_t>(h->max_batch) * 12 * H * sizeof(double)));
+        A1_HIP(hipMalloc(&h->d_contact_steps, static_cast<size_t>(h->max_batch) * 4 * H));
+    }
+    // pageable copies on the stream are synchronous w.r.t. the host buffers: the caller's arrays are snapshotted when each call returns
+    A1_HIP(hipMemcpyAsync(h->d_x0, x0, N * 13 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_xref, x_ref, N * 13 * H * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_R, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_foot_steps, foot_abs, N * nfoot * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_contact_steps, contact, N * ncont, hipMemcpyHostToDevice, s));
+    a1mpc_status st = solve_device_impl(h, n, nullptr, h->d_x0, h->d_xref, h->d_R, h->d_foot_steps, h->d_contact_steps, h->d_grf,
+                                        u_full_out ? h->d_u : nullptr, h->d_iters, h->d_status, s, foot_stride, contact_stride);
+    if (st != A1MPC_OK) return st;
+    A1_HIP(hipMemcpyAsync(grf_body_out, h->d_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (u_full_out) A1_HIP(hipMemcpyAsync(u_full_out, h->d_u, N * 12 * H * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (iters_out) A1_HIP(hipMemcpyAsync(iters_out, h->d_iters, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (status_out) A1_HIP(hipMemcpyAsync(status_out, h->d_status, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipStreamSynchronize(s));
+    return A1MPC_OK;
+}
+
 a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_config* qp, int32_t n, const double* root_acc,
                                        const double* R_world, const double* R_z, const double* foot_abs, const uint8_t* contact,
                                        double* grf_body_out, double* f_world_out, int32_t* iters_out, int32_t* status_out) {
@@ -1576,6 +1745,7 @@ a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_confi
     A1_HIP(hipSetDevice(h->device));
     const size_t N = n;
     hipStream_t s = h->stream;
+    A1_ORDER(h, s);
     // the transfers are small (344 B per QP); pageable copies on the stream are synchronous w.r.t. the host buffer
     A1_HIP(hipMemcpyAsync(h->d_aux, root_acc, N * 6 * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(h->d_R, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1592,7 +1762,6 @@ a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_confi
     a.tab = h->d_tab1; a.n = n;
     a.root_acc = h->d_aux; a.Rz = h->d_Rz; a.R = h->d_R; a.foot = h->d_foot; a.contact = h->d_contact;
     a.grf = h->d_grf; a.u_full = h->d_u; a.iters = h->d_iters; a.status = h->d_status; a.nfact = h->d_nfact;
-    h->last_stream = s;
     A1_HIP(hipEventRecord(h->ev0, s));
 #ifdef A1MPC_DEV_SLIM
     a1mpc_status st = fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "slim development build");
@@ -1602,6 +1771,7 @@ a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_confi
     if (st != A1MPC_OK) return st;
     A1_HIP(hipEventRecord(h->ev1, s));
     h->timed = true;
+    A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(grf_body_out, h->d_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (f_world_out) A1_HIP(hipMemcpyAsync(f_world_out, h->d_u, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (iters_out) A1_HIP(hipMemcpyAsync(iters_out, h->d_iters, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));

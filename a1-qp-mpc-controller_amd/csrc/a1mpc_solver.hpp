@@ -72,8 +72,10 @@ struct ProblemIO {
     const double* x0;        // 13
     const double* xref;      // 13*H
     const double* R;         // 9, row-major root_rot_mat
-    const double* foot;      // 12, 3x4 column-major foot_pos_abs (world-aligned, CoM-relative)
-    const uint8_t* contact;  // 4
+    const double* foot;      // 12, 3x4 column-major foot_pos_abs (world-aligned, CoM-relative); GEN: + foot_stride doubles per horizon step
+    const uint8_t* contact;  // 4; GEN: + contact_stride bytes per horizon step
+    int32_t foot_stride;     // GEN only: 0 = the same feet at every step (S/A1RobotControl.cpp:498-514), 12 = per-step feet (S/test/test_mpc.cpp:106-122)
+    int32_t contact_stride;  // GEN only: 0 = contacts broadcast over the horizon (S/ConvexMpc.cpp:228-245), 4 = a per-step contact schedule
     double* grf;             // 12 out: 3x4 column-major body-frame GRFs
     double* u_full;          // 12*H out (world frame, all steps) or null
     double* warm_x;          // 12*H in/out or null   (unscaled primal, OSQP workspace x)
@@ -141,7 +143,9 @@ A1_DEV double row_allsum(double v) {
 }
 
 // ---- LDS image of one QP ------------------------------------------------------------------------
-template <int H>
+// GEN (per-step feet / per-step contact schedules, RowSolver<.., GEN = true>): three more tables per QP behind c*g --
+// the omega rows of B~_t for every step, and the slot-0 bounds of every step.
+template <int H, bool GEN = false>
 struct Layout {
     static constexpr int KSTR = 13;          // padded row stride of K_t: conflict-free row and column reads
     static constexpr int K_SZ = 12 * KSTR;   // 156
@@ -152,12 +156,17 @@ struct Layout {
     static constexpr int BL = H * SLOT;      // B~ (6x12): rows 0-2 = dt*Iw^-1*skew(r), rows 3-5 = dt/m*I
     static constexpr int ZROW = 6;           // a seventh, all-zero row of B~: the row of every lane that owns no wrench state
     static constexpr int CG = BL + 84;       // c*g = D^-1 q_s, [t][12]
-    static constexpr int RAW = CG + 12 * H;
+    static constexpr int BW = CG + 12 * H;   // GEN: [t][3][12] = dt*Iw^-1*skew(r_t), the omega rows of B~_t (rows 3-5 of B~ are step-invariant)
+    static constexpr int LBT = BW + (GEN ? 36 * H : 0);   // GEN: [t][12] lower bound of my slot-0 row at step t
+    static constexpr int UBT = LBT + (GEN ? 12 * H : 0);  // GEN: [t][12] upper bound
+    static constexpr int RAW = UBT + (GEN ? 12 * H : 0);
     // set-up-only aliases inside the factor region (the factor is written after Ruiz is finished)
     static constexpr int TBL = 0;            // T*B~_omega (3x12)
     static constexpr int DL = 36;            // D table of the current Ruiz pass, [t][12]
     static constexpr int COOP = DL + 12 * H;  // [row][s][16 lanes] partial column maxima of a set-up shared by the four rows of a wave (RowSolver::coop_n)
+    static constexpr int TBW = DL + 12 * H;  // GEN (never coop): [t][3][12] = T*B~_omega of step t
     static_assert(COOP + 8 * H * 16 <= H * SLOT || H == 1, "alias");  // + the D / E0 / E1 / m tables of the shared Ruiz update
+    static_assert(!GEN || TBW + 36 * H <= H * SLOT, "alias");
     // row stride mod 32 in {4,10,16,22,28}: the two QPs that share a 32-lane LDS phase then read the stride-13 rows of K_t
     // from disjoint banks; even, so that 16-byte alignment survives.  H = 10: 2544 doubles = 20,352 B per QP -> eight QPs
     // per CU (160 KiB): four workgroups of two rows.
@@ -177,6 +186,7 @@ struct LayoutSetup {
     static constexpr int TBL = 0;
     static constexpr int DL = 36;
     static constexpr int COOP = 0;  // never used by the set-up kernel (one row per QP)
+    static constexpr int BW = 0, TBW = 0, LBT = 0, UBT = 0;  // GEN never runs the split pipeline
     static constexpr int BL = DL + 12 * H;
     static constexpr int ZROW = 6;
     static constexpr int CG = BL + 84;
@@ -208,9 +218,15 @@ struct Prep {
 //   split   K1: setup(io); save_prepared(p)        K2: load_prepared(p, io); { advance(); } ...; write_outputs(io)
 //           K2 rows pull the next prepared QP as soon as theirs has converged (advance() = one checkpoint-aligned segment).
 // =================================================================================================
-template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false>
+// GEN = true is the general path of the reference's INTERFACE (S/ConvexMpc.h:74 B_mat_d_list, S/test/test_mpc.cpp:106-122): per-step
+// foot positions (a different B_d at every horizon step) and per-step contact schedules.  With step-dependent B~_t the Hessian block
+// (s,t) is still alpha_st U_st + beta_st V_st (A_c^2 B = 0 holds for every B_t), but U_st, V_st now depend on both steps: they are
+// evaluated on the fly from the per-step tables (6 FMAs per entry instead of 1), the Riccati sweeps read B~_t and the bounds per step
+// from LDS.  Same iterates as the oracle's strided formation; slower (bigger LDS image, more reads) and only in the fused kernel.
+template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false>
 struct RowSolver {
-    using L = std::conditional_t<SETUP_ONLY, LayoutSetup<H>, Layout<H>>;
+    static_assert(!GEN || (MODE == kModeMpc && !SETUP_ONLY && H > 1), "the general path is an MPC solve in the fused kernel");
+    using L = std::conditional_t<SETUP_ONLY, LayoutSetup<H>, Layout<H, GEN>>;
     using PR = Prep<H>;
     const DeviceParams& P;
     const double* __restrict__ tab;
@@ -222,7 +238,7 @@ struct RowSolver {
     double dt, mu;
     // per-lane constants of the problem
     double Bt[6];  // my column of B~ (force layout); zero on pad lanes
-    static constexpr bool kBrowInRegs = H <= 10;  // beyond that the per-lane ADMM state alone (6H doubles) overflows the register file
+    static constexpr bool kBrowInRegs = H <= 10 && !GEN;  // beyond that the per-lane ADMM state alone (6H doubles) overflows the register file
     double Brw[12];  // my row of B~ (state layout; zeros on lanes without a wrench state): step-invariant, so it stays in registers --
                      // an LDS read costs the wave ~12 issue cycles whatever its width (tools/ubench/issue_cost_ubench.hip)
     double cy, sy, fA, fB, fC, fP, gA, gB, gC, gV, q2s, r2a;
@@ -292,6 +308,21 @@ struct RowSolver {
         for (int b = 0; b < 12; ++b) Br[b] = brow[b];
         return dot_bc<0>(Br, u);  // lanes without a wrench state read the zero row
     }
+    // ---- per-step accessors (GEN: tables in LDS; otherwise the step-invariant registers)
+    A1_DEV double lb_at(int t) const { if constexpr (GEN) return lds[L::LBT + t * 12 + ci]; else return lb0; }
+    A1_DEV double ub_at(int t) const { if constexpr (GEN) return lds[L::UBT + t * 12 + ci]; else return ub0; }
+    A1_DEV void Bt_at(int t, double (&o)[6]) const {  // my column of B~_t (force layout)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = Bt[k];
+        if constexpr (GEN) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o[k] = act ? lds[L::BW + (t * 3 + k) * 12 + ci] : 0.0;
+        }
+    }
+    A1_DEV const double* brow_at(int t) const {   // my row of B~_t (state layout): omega lanes read the step's table
+        if constexpr (GEN) return (wl && quad == 2) ? lds + L::BW + (t * 3 + (ci - 6)) * 12 : brow;
+        else return brow;
+    }
     A1_DEV void bounds_from_contact(double cf) {
         lo_u = P.fz_min * cf; hi_u = P.fz_max * cf;
         // physical bounds of my two rows: slot 0 = [fx+mu fz >= 0 | fy+mu fz >= 0 | fz in [lo,hi]], slot 1 = [.. <= 0]
@@ -309,6 +340,7 @@ struct RowSolver {
             c_ = cos(yaw); s_ = sin(yaw);  // S/ConvexMpc.cpp:115-116
         }
         set_rotation(c_, s_);
+        [[maybe_unused]] double Ii[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // inverse world inertia (GEN re-uses it for every step's feet)
         if constexpr (MODE == kModeBalance) {
             static_assert(MODE != kModeBalance || H == 1, "the balance QP is the H = 1 case");
             const double rx = io.foot[3 * quad + 0], ry = io.foot[3 * quad + 1], rz = io.foot[3 * quad + 2];
@@ -322,7 +354,7 @@ struct RowSolver {
             }
         } else {
             // I_world = R I_b R', inverse by cofactors (S/ConvexMpc.cpp:136-141)
-            double t9[9], Iw[9], Ii[9];
+            double t9[9], Iw[9];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -371,6 +403,27 @@ struct RowSolver {
             lds[L::BL + L::ZROW * 12 + ci] = 0.0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) lds[L::TBL + k * 12 + ci] = TB[k];
+        }
+        if constexpr (GEN) {
+            // per-step feet: the omega rows of B~_t = dt * Iw^-1 * skew(r_t) (S/ConvexMpc.cpp:138,151 with the step's foot_pos) and T * them
+            static_for<H>([&](auto T) {
+                constexpr int t = A1_CV(T);
+                const double* fp = io.foot + static_cast<int64_t>(t) * io.foot_stride;
+                const double rx = fp[3 * quad + 0], ry = fp[3 * quad + 1], rz = fp[3 * quad + 2];
+                const double k0 = comp == 0 ? 0.0 : (comp == 1 ? -rz : ry);
+                const double k1 = comp == 0 ? rz : (comp == 1 ? 0.0 : -rx);
+                const double k2 = comp == 0 ? -ry : (comp == 1 ? rx : 0.0);
+                double bw[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) bw[k] = (Ii[k * 3 + 0] * k0 + Ii[k * 3 + 1] * k1 + Ii[k * 3 + 2] * k2) * dt;
+                if (act) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) lds[L::BW + (t * 3 + k) * 12 + ci] = bw[k];
+                    lds[L::TBW + (t * 3 + 0) * 12 + ci] = cy * bw[0] + sy * bw[1];
+                    lds[L::TBW + (t * 3 + 1) * 12 + ci] = -sy * bw[0] + cy * bw[1];
+                    lds[L::TBW + (t * 3 + 2) * 12 + ci] = bw[2];
+                }
+            });
         }
         row_sync();
 
@@ -424,7 +477,8 @@ struct RowSolver {
             static_for<H>([&](auto TT) {
                 constexpr int t = H - 1 - A1_CV(TT);
                 lam = row_dpp_ready(w[t] + opAT(lam));
-                g[t] = BtT(lam);
+                if constexpr (GEN) { double Bq[6]; Bt_at(t, Bq); g[t] = dot_bc<6>(Bq, lam); }
+                else g[t] = BtT(lam);
             });
         }
 
@@ -441,6 +495,29 @@ struct RowSolver {
             V[B] = v;
             if (act && ci == B) { Ud = U[B]; Vd = V[B]; }
         });
+        // GEN: block (s,t) of B_qp'QB_qp is beta_st (gamma_st U_st + V_st) with U_st[a][b] = dt^2 (sum_c q_c TB_s[c][a] TB_t[c][b] + q_{3+k} (dt/m)^2 [k = comp_a = comp_b]),
+        // V_st[a][b] = sum_c q_{6+c} B~w_s[c][a] B~w_t[c][b] + q_{9+k} (dt/m)^2 [..]: my row's step-s factors live in registers, the step-t tables in LDS
+        [[maybe_unused]] double cu[GEN ? H : 1][3], cv[GEN ? H : 1][3], Udg[GEN ? H : 1], Vdg[GEN ? H : 1], Ucs[3], Vcs[3];
+        [[maybe_unused]] const double dt2 = dt * dt;
+        if constexpr (GEN) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Ucs[k] = (act && comp == k) ? P.q2[3 + k] * Bt[3 + k] * Bt[3 + k] : 0.0;
+                Vcs[k] = (act && comp == k) ? P.q2[9 + k] * Bt[3 + k] * Bt[3 + k] : 0.0;
+            }
+            static_for<H>([&](auto S) {
+                constexpr int s = A1_CV(S);
+                double ud = 0.0, vd = 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double tb = act ? lds[L::TBW + (s * 3 + c) * 12 + ci] : 0.0, bwv = act ? lds[L::BW + (s * 3 + c) * 12 + ci] : 0.0;
+                    cu[s][c] = P.q2[c] * tb; cv[s][c] = P.q2[6 + c] * bwv;
+                    ud += cu[s][c] * tb; vd += cv[s][c] * bwv;
+                    if (comp == c) { ud += Ucs[c]; vd += Vcs[c]; }
+                }
+                Udg[s] = ud * dt2; Vdg[s] = vd;
+            });
+        }
 
         // ---------------------------------------------------------------- Ruiz equilibration (osqp scaling.c scale_data)
         double D[H], E0[H], E1[H];
@@ -464,10 +541,37 @@ struct RowSolver {
                 row_sync();
                 static_for<H>([&](auto S) {  // the true diagonal entry carries R
                     constexpr double ad = alpha_diag(A1_CV(S), H), bd = H - A1_CV(S);
-                    mm[S] = (ad * Ud + bd * Vd + r2a) * D[S];
+                    if constexpr (GEN) mm[S] = (ad * Udg[S] + bd * Vdg[S] + r2a) * D[S];
+                    else mm[S] = (ad * Ud + bd * Vd + r2a) * D[S];
                 });
+                if constexpr (GEN) {
 #pragma unroll 1
-                for (int t = coop_id; t < H; t += coop_n) {
+                    for (int t = 0; t < H; ++t) {  // every block is evaluated (no pruning bound for step-dependent U, V)
+                        double gb[2 * H], Dt[12], TBt[3][12], Bwt[3][12];
+#pragma unroll
+                        for (int s2 = 0; s2 < H; ++s2) { gb[2 * s2] = tab[(s2 * H + t) * 2]; gb[2 * s2 + 1] = tab[(s2 * H + t) * 2 + 1]; }
+#pragma unroll
+                        for (int b = 0; b < 12; ++b) {
+                            Dt[b] = lds[L::DL + t * 12 + b];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) { TBt[c][b] = lds[L::TBW + (t * 3 + c) * 12 + b]; Bwt[c][b] = lds[L::BW + (t * 3 + c) * 12 + b]; }
+                        }
+                        static_for<H>([&](auto S) {
+                            constexpr int s = A1_CV(S);
+                            const double gam = gb[2 * s], bet = gb[2 * s + 1];
+                            double a0 = 0.0;
+                            static_for<12>([&](auto B) {
+                                constexpr int b = A1_CV(B);
+                                const double u = fma(cu[s][2], TBt[2][b], fma(cu[s][1], TBt[1][b], fma(cu[s][0], TBt[0][b], Ucs[b % 3]))) * dt2;
+                                const double v = fma(cv[s][2], Bwt[2][b], fma(cv[s][1], Bwt[1][b], fma(cv[s][0], Bwt[0][b], Vcs[b % 3])));
+                                a0 = fmax(a0, fabs(fma(gam, u, v)) * Dt[b]);
+                            });
+                            mm[S] = fmax(mm[S], bet * a0);
+                        });
+                    }
+                }
+#pragma unroll 1
+                for (int t = GEN ? H : coop_id; t < H; t += coop_n) {
                     // all loads of this t first (table column + D row): one wait instead of one per block
                     double gb[2 * H], Dt[12];
 #pragma unroll
@@ -558,7 +662,7 @@ struct RowSolver {
         //   w+ = w + alpha (z~ - Pi(w)).  In unscaled variables the projection uses the constant physical bounds, the
         //   only scaling-dependent per-row datum is rr = E^2 rho_row, and the only per-variable one is sigma D^-2.
         // Per horizon step and lane: xh, wh0, wh1, rr0, rr1, dI2 (6 doubles) in VGPRs; c*g lives in LDS.
-        bounds_from_contact((act && io.contact[quad]) ? 1.0 : 0.0);  // contacts broadcast over the horizon (S/ConvexMpc.cpp:228-245)
+        bounds_from_contact((act && io.contact[quad]) ? 1.0 : 0.0);  // contacts broadcast over the horizon (S/ConvexMpc.cpp:228-245); GEN: step 0's
         rho = P.rho0;
         warm = P.warm_start && io.warm_x != nullptr && io.warm_y != nullptr;
         if (warm && io.rho_io != nullptr && *io.rho_io > 0.0) rho = *io.rho_io;
@@ -570,7 +674,13 @@ struct RowSolver {
         row_sync();  // the Ruiz D table (aliased into the factor region) is dead from here on
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
-            const bool eq = comp == 2 && (E0[t] * hi_u - E0[t] * lo_u < kRhoTol);
+            [[maybe_unused]] double lo_t = lo_u, hi_t = hi_u;
+            if constexpr (GEN) {  // the step's contact flags (a per-step schedule when contact_stride = 4): bounds of my slot-0 row at step t
+                const double cf = (act && io.contact[static_cast<int64_t>(t) * io.contact_stride + quad]) ? 1.0 : 0.0;
+                lo_t = P.fz_min * cf; hi_t = P.fz_max * cf;
+                if (act) { lds[L::LBT + t * 12 + ci] = comp == 2 ? lo_t : 0.0; lds[L::UBT + t * 12 + ci] = comp == 2 ? hi_t : kInfty; }
+            }
+            const bool eq = comp == 2 && (E0[t] * hi_t - E0[t] * lo_t < kRhoTol);
             if (eq) eqmask |= 1u << t;
             rr0[t] = E0[t] * E0[t] * (eq ? kRhoEqOverIneq * rho : rho);
             rr1[t] = E1[t] * E1[t] * rho;
@@ -692,6 +802,12 @@ struct RowSolver {
         for (int t = H - 1; t >= 0; --t) {
             double* slot = lds + L::FAC + t * L::SLOT;
             const double wv[3] = {slot[L::K_SZ + 3 * ln], slot[L::K_SZ + 3 * ln + 1], slot[L::K_SZ + 3 * ln + 2]};
+            [[maybe_unused]] double Btt[6];
+            if constexpr (GEN) {  // this step's B~_t
+                Bt_at(t, Btt);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) Btr[k] = row_dpp_ready(Btt[k]);
+            }
             row_sync();  // everybody holds W_t before the slot is overwritten
             // G = A' P_{t+1}  (rows mixed across lanes), then GA = G A (columns, lane-local)
             double G[12];
@@ -720,7 +836,10 @@ struct RowSolver {
             for (int b = 0; b < 12; ++b) S[b] = 0.0;
             row_dpp_ready12(Y);
             static_for<6>([&](auto K) {
-                static_for<12>([&](auto B) { fma_bcast<lane_of(6 + A1_CV(K))>(S[B], Bt[K], Y[B]); });
+                static_for<12>([&](auto B) {
+                    if constexpr (GEN) fma_bcast<lane_of(6 + A1_CV(K))>(S[B], Btt[K], Y[B]);
+                    else fma_bcast<lane_of(6 + A1_CV(K))>(S[B], Bt[K], Y[B]);
+                });
             });
             static_for<12>([&](auto B) { fma_bcast_leg<0, A1_CV(B) / 3>(S[B], wv[A1_CV(B) % 3], one0); });  // + W on my leg's block (one0 of lane 0 = 1)
             // in-place Gauss-Jordan inverse of the SPD 12x12 (no pivoting).  Pivot k: row k is scaled by 1/p, every other row i
@@ -806,6 +925,9 @@ struct RowSolver {
                 if constexpr (t > 0) Kc[b] = slot[b * L::KSTR + ci];
             });
             const double cgt = lds[L::CG + t * 12 + ci];
+            [[maybe_unused]] double Btl[6];
+            if constexpr (GEN) Bt_at(t, Btl);
+            const double lbt = GEN ? lb_at(t) : lb0_l, ubt = GEN ? ub_at(t) : ub0_l;
             row_sched_fence();
             // rhs of update_xz_tilde premultiplied by D^-1:  b = sigma D^-2 xh - c g + A' [E (rho z_s - y_s)]
             double t0, t1;
@@ -815,7 +937,7 @@ struct RowSolver {
                 t0 = rr0[t] * (comp == 2 ? xh[t] : fma(mu, xz, xh[t])) - csc * yw0;
                 t1 = rr1[t] * fma(-mu, xz, xh[t]) - csc * yw1;
             } else {                // E (rho z_s - y_s) = rr (2 Pi(wh) - wh)
-                const double z0 = min_f64(max_f64(wh0[t], lb0_l), ub0_l), z1 = min_f64(wh1[t], 0.0);
+                const double z0 = min_f64(max_f64(wh0[t], lbt), ubt), z1 = min_f64(wh1[t], 0.0);
                 t0 = rr0[t] * fma(2.0, z0, -wh0[t]);
                 t1 = rr1[t] * fma(2.0, z1, -wh1[t]);
             }
@@ -827,7 +949,8 @@ struct RowSolver {
             double r, pa = 0.0, pb = 0.0;
             if constexpr (t < H - 1) {
                 if constexpr (t > 0) pb = gV * row_ror<8>(pv);
-                sweep_back_rhs(r, pa, pb, at, cgt, sd, xh[t], pv, Bt, gA, gB, gC);
+                if constexpr (GEN) sweep_back_rhs(r, pa, pb, at, cgt, sd, xh[t], pv, Btl, gA, gB, gC);
+                else sweep_back_rhs(r, pa, pb, at, cgt, sd, xh[t], pv, Bt, gA, gB, gC);
             } else {
                 r = row_dpp_ready(fma(sd, xh[t], at - cgt));  // p_H = 0
             }
@@ -851,9 +974,11 @@ struct RowSolver {
             });
             [[maybe_unused]] double Brl[12];  // H > 10: my row of B~ is re-read per step (the 24 registers are worth more than 6 LDS reads there)
             if constexpr (!kBrowInRegs && t < H - 1) {
+                const double* br = brow_at(t);
 #pragma unroll
-                for (int b = 0; b < 12; ++b) Brl[b] = brow[b];
+                for (int b = 0; b < 12; ++b) Brl[b] = br[b];
             }
+            const double lbt = GEN ? lb_at(t) : lb0_l, ubt = GEN ? ub_at(t) : ub0_l;
             row_sched_fence();
             // v_t = d_t - K_t x_t,  xh <- alpha v + (1 - alpha) xh,  x_{t+1} = A x_t + B~ v_t   (instruction blocks)
             const double am = act ? 1.0 : 0.0;  // pad lanes carry no force
@@ -863,7 +988,7 @@ struct RowSolver {
             const double xh_old = xh[t];
             [[maybe_unused]] double gt0 = 0.0, gt1 = 0.0;  // CAREFUL: rr (2 Pi(w) - w) of the state BEFORE this iteration's update
             if constexpr (CAREFUL) {
-                const double zp0 = min_f64(max_f64(wh0[t], lb0_l), ub0_l), zp1 = min_f64(wh1[t], 0.0);
+                const double zp0 = min_f64(max_f64(wh0[t], lbt), ubt), zp1 = min_f64(wh1[t], 0.0);
                 gt0 = rr0[t] * fma(2.0, zp0, -wh0[t]);
                 gt1 = rr1[t] * fma(2.0, zp1, -wh1[t]);
             }
@@ -878,11 +1003,11 @@ struct RowSolver {
                 sweep_fwd_gain<false>(v, sa, sb, xh[t], s, Kr, fA, fB, fC, am, oma, al);
             }
             if constexpr (t < H - 1) {
-                if constexpr (kBrowInRegs) sweep_fwd_input(sa, sb, z0, v, Brw, wh0[t], lb0_l, ub0_l);
-                else sweep_fwd_input(sa, sb, z0, v, Brl, wh0[t], lb0_l, ub0_l);
+                if constexpr (kBrowInRegs) sweep_fwd_input(sa, sb, z0, v, Brw, wh0[t], lbt, ubt);
+                else sweep_fwd_input(sa, sb, z0, v, Brl, wh0[t], lbt, ubt);
                 s = sa;  // lanes without a wrench state read the zero row of B~
             } else {
-                z0 = min_f64(max_f64(wh0[t], lb0_l), ub0_l);
+                z0 = min_f64(max_f64(wh0[t], lbt), ubt);
             }
             // z~ = A v (unscaled), then update_x / update_z / update_y in the w form
             const double vz = quad_perm<2, 2, 2, 2>(v);
@@ -923,14 +1048,21 @@ struct RowSolver {
             static_for<H>([&](auto T) {
                 // B~ u with my row of B~ from registers (loaded by factorize) where it is kept there
                 if constexpr (kBrowInRegs) s = row_dpp_ready(opA(s) + dot_bc<0>(Brw, row_dpp_ready(xh[T])));
-                else s = row_dpp_ready(opA(s) + Bu(row_dpp_ready(xh[T])));
+                else if constexpr (GEN) {
+                    double Br[12];
+                    const double* br = brow_at(A1_CV(T));
+#pragma unroll
+                    for (int b = 0; b < 12; ++b) Br[b] = br[b];
+                    s = row_dpp_ready(opA(s) + dot_bc<0>(Br, row_dpp_ready(xh[T])));
+                } else s = row_dpp_ready(opA(s) + Bu(row_dpp_ready(xh[T])));
                 sv[T] = q2s * s;
             });
             double lam = row_dpp_ready(0.0);
             static_for<H>([&](auto TT) {
                 constexpr int t = H - 1 - A1_CV(TT);
                 lam = row_dpp_ready(sv[t] + opAT(lam));
-                Pu[t] = fma(r2a, xh[t], BtT(lam));
+                if constexpr (GEN) { double Bq[6]; Bt_at(t, Bq); Pu[t] = fma(r2a, xh[t], dot_bc<6>(Bq, lam)); }
+                else Pu[t] = fma(r2a, xh[t], BtT(lam));
             });
         }
         // Norms of the scaled vectors (E r, D^-1 r: they only feed the rho estimate) are accumulated as squares -- E^2 = rr / rho_row and
@@ -943,7 +1075,7 @@ struct RowSolver {
             const double uz = quad_perm<2, 2, 2, 2>(xh[t]);
             const double ax0 = comp == 2 ? xh[t] : fma(mu, uz, xh[t]);  // E^-1 (A_s x)
             const double ax1 = comp < 2 ? fma(-mu, uz, xh[t]) : 0.0;
-            const double z0 = min_f64(max_f64(wh0[t], lb0), ub0), z1 = min_f64(wh1[t], 0.0);  // E^-1 z
+            const double z0 = min_f64(max_f64(wh0[t], lb_at(t)), ub_at(t)), z1 = min_f64(wh1[t], 0.0);  // E^-1 z
             const double rp0 = ax0 - z0, rp1 = ax1 - z1;
             const bool eq = (eqmask >> t) & 1u;
             const double e0 = rr0[t] * (eq ? irho_eq : irho), e1 = rr1[t] * irho;  // E^2
@@ -1037,7 +1169,7 @@ struct RowSolver {
                         // y_s = rho E (wh - zh) is kept:  wh <- zh + (rho_old / rho_new) (wh - zh),  rr <- rr rho_new / rho_old
                         const double up = rn / rho, dn = rho / rn;
                         static_for<H>([&](auto T) {
-                            const double z0 = fmin(fmax(wh0[T], lb0), ub0), z1 = fmin(wh1[T], 0.0);
+                            const double z0 = fmin(fmax(wh0[T], lb_at(A1_CV(T))), ub_at(A1_CV(T))), z1 = fmin(wh1[T], 0.0);
                             wh0[T] = fma(dn, wh0[T] - z0, z0);
                             wh1[T] = fma(dn, wh1[T] - z1, z1);
                             rr0[T] *= up;
@@ -1086,11 +1218,14 @@ struct RowSolver {
             if (act) {
                 const double xu = nanout ? nanv : xh[t];
                 if (io.u_full) io.u_full[t * 12 + ci] = xu;
-                if (io.warm_x) io.warm_x[t * 12 + ci] = xu;
+                // A failed solve must not poison the carried workspace (every later tick of this robot would start from NaN): the next
+                // tick is a cold start -- x = y = 0 and, below, rho = 0 = "use settings.rho" (OSQP's store_solution() cold-starts its
+                // iterates after a failed solve)
+                if (io.warm_x) io.warm_x[t * 12 + ci] = nanout ? 0.0 : xu;
                 if (io.warm_y) {  // y = c^-1 E y_s = c^-1 rr (wh - Pi(wh))
-                    const double z0 = fmin(fmax(wh0[t], lb0), ub0), z1 = fmin(wh1[t], 0.0);
-                    io.warm_y[t * 20 + 5 * quad + r0] = nanout ? nanv : cinv * rr0[t] * (wh0[t] - z0);
-                    if (comp < 2) io.warm_y[t * 20 + 5 * quad + r1] = nanout ? nanv : cinv * rr1[t] * (wh1[t] - z1);
+                    const double z0 = fmin(fmax(wh0[t], lb_at(t)), ub_at(t)), z1 = fmin(wh1[t], 0.0);
+                    io.warm_y[t * 20 + 5 * quad + r0] = nanout ? 0.0 : cinv * rr0[t] * (wh0[t] - z0);
+                    if (comp < 2) io.warm_y[t * 20 + 5 * quad + r1] = nanout ? 0.0 : cinv * rr1[t] * (wh1[t] - z1);
                 }
             }
         });
@@ -1098,7 +1233,7 @@ struct RowSolver {
             if (io.iters) *io.iters = iter;
             if (io.status) *io.status = status_out;
             if (io.nfact) *io.nfact = nfact;
-            if (io.rho_io) *io.rho_io = rho;
+            if (io.rho_io) *io.rho_io = nanout ? 0.0 : rho;
         }
     }
 };
@@ -1112,6 +1247,7 @@ struct BatchArgs {
     const double* tick;           // n x 22 compact tick records, or null (N1)
     const double *x0, *xref, *R, *foot;
     const uint8_t* contact;
+    int32_t foot_stride, contact_stride;  // general path only (0 / 12 doubles and 0 / 4 bytes per horizon step): per-QP records are then 12H doubles / 4H bytes
     double *grf, *u_full, *warm_x, *warm_y, *rho;
     int32_t *iters, *status, *nfact;
     // work-queue order of the persistent ADMM rows (null = index order) and the per-QP cost record that the next solve's order is
@@ -1129,8 +1265,9 @@ A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
     io.x0 = (MODE == kModeMpc && a.x0) ? a.x0 + b * 13 : nullptr;
     io.xref = (MODE == kModeMpc && a.xref) ? a.xref + b * 13 * H : nullptr;
     io.R = a.R + b * 9;
-    io.foot = a.foot + b * 12;
-    io.contact = a.contact + b * 4;
+    io.foot = a.foot + b * (a.foot_stride ? 12 * H : 12);
+    io.contact = a.contact + b * (a.contact_stride ? 4 * H : 4);
+    io.foot_stride = a.foot_stride; io.contact_stride = a.contact_stride;
     io.grf = a.grf + b * 12;
     io.u_full = a.u_full ? a.u_full + b * 12 * H : nullptr;
     io.warm_x = a.warm_x ? a.warm_x + b * 12 * H : nullptr;
@@ -1189,9 +1326,15 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
 // the fused path: one QP from inputs to outputs (small batches, the batch-1 latency path, the CPU test double).
 // make_io() is called where the pointers are needed (set-up, hand-off, outputs) instead of once: a ProblemIO of per-row pointers that
 // stays live across the ADMM loop costs that loop ~30 VGPRs it does not have.
-template <int H, int MODE, class MakeIO>
+template <int H, int MODE, bool GEN = false, class MakeIO>
 A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab, MakeIO&& make_io_, double* __restrict__ lds) {
-    if constexpr (MODE == kModeMpc && Prep<H>::STRIDE <= H * Layout<H>::SLOT) {
+    if constexpr (GEN) {
+        // general path (per-step feet / contact schedules): one solver object from inputs to outputs
+        RowSolver<H, MODE, false, true> S(P, tab, lds);
+        S.setup(make_io_());
+        S.solve();
+        S.write_outputs(make_io_());
+    } else if constexpr (MODE == kModeMpc && Prep<H>::STRIDE <= H * Layout<H>::SLOT) {
         // Set-up and iteration are two solver objects joined by the hand-off record of the split pipeline, staged in the (still
         // empty) factor region: the ADMM loop then gets the register allocation of the persistent kernel instead of one that
         // also carries the set-up's live values (scratch reloads inside the loop).  ~0.5 us per solve.
@@ -1212,9 +1355,9 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
         S.write_outputs(make_io_());
     }
 }
-template <int H, int MODE = kModeMpc>
+template <int H, int MODE = kModeMpc, bool GEN = false>
 A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, const ProblemIO& io, double* __restrict__ lds) {
-    solve_row_with<H, MODE>(P, tab, [&]() -> const ProblemIO& { return io; }, lds);
+    solve_row_with<H, MODE, GEN>(P, tab, [&]() -> const ProblemIO& { return io; }, lds);
 }
 
 }  // namespace a1mpc

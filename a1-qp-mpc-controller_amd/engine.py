@@ -40,7 +40,7 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
     _fields_ = [("counter_per_swing", C.c_double), ("foot_force_low", C.c_double), ("use_terrain_adapt", C.c_int32)]
 
 
-EXPORTS = ["a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
+EXPORTS = ["a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
@@ -93,6 +93,11 @@ def load_library(path=None):
     lib.a1mpc_leg_state_batch_device.argtypes = [vp, i32] + [vpp] * 5 + [dp, dp] + [vpp] * 7 + [vpp]; lib.a1mpc_leg_state_batch_device.restype = C.c_int
     lib.a1mpc_ekf_update_batch_device.argtypes = [vp, i32, C.c_double, i32] + [vpp] * 10 + [vpp]; lib.a1mpc_ekf_update_batch_device.restype = C.c_int
     lib.a1mpc_joint_torques_batch_device.argtypes = [vp, i32] + [vpp] * 5 + [dp] + [vpp] * 2 + [vpp]; lib.a1mpc_joint_torques_batch_device.restype = C.c_int
+    lib.a1mpc_solve_batch_strided.argtypes = [vp, i32, dp, dp, dp, dp, i32, u8p, i32, dp, dp, i32p, i32p]; lib.a1mpc_solve_batch_strided.restype = C.c_int
+    lib.a1mpc_solve_batch_strided_device.argtypes = [vp, i32] + [vp] * 4 + [i32, vp, i32] + [vp] * 4 + [vp]; lib.a1mpc_solve_batch_strided_device.restype = C.c_int
+    lib.a1mpc_update_config.argtypes = [vp, C.POINTER(Config)]; lib.a1mpc_update_config.restype = C.c_int
+    lib.a1mpc_warm_start.argtypes = [vp, i32, dp, dp, dp]; lib.a1mpc_warm_start.restype = C.c_int
+    lib.a1mpc_get_warm_start.argtypes = [vp, i32, dp, dp, dp]; lib.a1mpc_get_warm_start.restype = C.c_int
     lib.a1mpc_set_schedule.argtypes = [vp, i32]; lib.a1mpc_set_schedule.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
     lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int
@@ -182,6 +187,35 @@ class Engine:
                                         contact.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(grf), _dp(u), _ip(iters), _ip(status))
         _check(self.lib, rc, "a1mpc_solve_batch")
         return dict(grf=grf, u=u, iters=iters, status=status)
+
+    # ---- the general case of the ConvexMpc interface: per-step feet (B_mat_d_list) and / or a per-step contact schedule ----
+    def solve_strided(self, x0, xref, R, foot, foot_stride, contact, contact_stride, want_u=False):
+        h = self.horizon
+        x0 = _f64(x0, (-1, NS)); n = x0.shape[0]
+        xref = _f64(xref, (n, NS * h)); R = _f64(R, (n, 9)); foot = _f64(foot, (n, 12 * h if foot_stride else 12))
+        contact = np.ascontiguousarray(contact, dtype=np.uint8).reshape(n, 4 * h if contact_stride else 4)
+        grf = np.zeros((n, 12)); u = np.zeros((n, NU * h)) if want_u else None
+        iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
+        rc = self.lib.a1mpc_solve_batch_strided(self._h, n, _dp(x0), _dp(xref), _dp(R), _dp(foot), int(foot_stride),
+                                                contact.ctypes.data_as(C.POINTER(C.c_uint8)), int(contact_stride), _dp(grf), _dp(u), _ip(iters), _ip(status))
+        _check(self.lib, rc, "a1mpc_solve_batch_strided")
+        return dict(grf=grf, u=u, iters=iters, status=status)
+
+    def update_config(self, cfg):
+        """replace everything but the horizon (dt, weights, mass / inertia, limits, OSQP settings); the warm start is kept"""
+        _check(self.lib, self.lib.a1mpc_update_config(self._h, C.byref(cfg)), "a1mpc_update_config")
+        self.cfg = cfg
+
+    def set_warm_start(self, x=None, y=None, rho=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, rho)]
+        n = next(a for a in arrs if a is not None).shape[0]
+        _check(self.lib, self.lib.a1mpc_warm_start(self._h, n, _dp(arrs[0]), _dp(arrs[1]), _dp(arrs[2])), "a1mpc_warm_start")
+
+    def get_warm_start(self, n):
+        h = self.horizon
+        x = np.zeros((n, NU * h)); y = np.zeros((n, 20 * h)); rho = np.zeros(n)
+        _check(self.lib, self.lib.a1mpc_get_warm_start(self._h, int(n), _dp(x), _dp(y), _dp(rho)), "a1mpc_get_warm_start")
+        return x, y, rho
 
     # ---- N1: compact tick records (x0 / x_ref built on the device, S/A1RobotControl.cpp:452-488) ----
     def solve_ticks(self, tick, R, foot, contact, want_u=False):

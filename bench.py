@@ -181,6 +181,34 @@ def full_tick_probe(pkg, local, n=4096, ticks=10):
             "ms_per_tick": ms, "robot_ticks_per_s": n / (ms * 1e-3), "mean_mpc_iters": float(it.float().mean().item())}
 
 
+def other_config_rooflines(pkg, local, steps=4):
+    """roofline blocks for the shapes of BASELINE configs[3] (h = 16, one GPU's share of 65536 / 8) and configs[4] (32768 x h = 20),
+    first solves, device-resident inputs (extra information, not `value`)."""
+    import torch
+    dev = torch.device("cuda", local); st = torch.cuda.Stream(device=dev)
+    res = []
+    for name, gen, n, h in (("configs[3] share: 8192 x h16", "config4_random_h16", 8192, 16), ("configs[4]: 32768 x h20 mixed contacts, 0.5 rad pitch", "config5_divergent", 32768, 20)):
+        sc = getattr(pkg.scenarios, gen)(nb=n)
+        cfg = pkg.make_config(sc["params"], h, warm_start=0)
+        d = {k: torch.from_numpy(sc[k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")}
+        grf = torch.zeros((n, 12), dtype=torch.float64, device=dev)
+        it = torch.zeros(n, dtype=torch.int32, device=dev); stt = torch.zeros(n, dtype=torch.int32, device=dev)
+        with pkg.Engine(cfg, n, local) as eng:
+            ms = []
+            for k in range(steps + 1):
+                eng.set_schedule(True)
+                eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, it, stt, stream=st.cuda_stream)
+                ms.append(eng.last_kernel_ms())
+            nf = eng.last_nfact(n)
+        avg = float(np.mean(ms[1:]))
+        fl = float(pkg.algorithmic_flops(h, it.cpu().numpy(), nf).sum())
+        ach = fl / (avg * 1e-3) / 1e12
+        res.append({"config": name, "batch": n, "horizon": h, "avg_kernel_ms": avg, "solves_per_s": n / (avg * 1e-3), "bound": "fp64-valu", "achieved": ach,
+                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "mean_iters": float(it.float().mean().item()),
+                    "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n, "solved_frac": float((stt == 1).float().mean().item())})
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,21 +246,29 @@ def main():
         pkg.load_library()
 
     n = args.batch
-    sc = pkg.scenarios.config3_random_flat(nb=n, seed=0xA1 + 3 + 1000 * rank)  # synthetic; rank 0 = the documented seed
+    # NB distinct batches, resident in HBM, cycled through the steps: no step re-solves the inputs of the step before it, and every step
+    # is a FIRST solve (a1mpc_set_schedule drops the handle's queue-order history before each launch) -- `value` cannot profit from
+    # having seen the same QPs before.  Rank 0 / batch 0 = the documented seed of BASELINE configs[2].
+    NB = 4
+    scs = [pkg.scenarios.config3_random_flat(nb=n, seed=0xA1 + 3 + 1000 * rank + 17 * k) for k in range(NB)]
+    sc = scs[0]
     cfg = pkg.make_config(sc["params"], HORIZON, warm_start=0)                   # cold start every step: no work is skipped
     dev = torch.device("cuda", local)
-    d = {k: torch.from_numpy(sc[k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")}
+    ds = [{k: torch.from_numpy(s_[k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")} for s_ in scs]
     grf = torch.zeros((n, 12), dtype=torch.float64, device=dev)
     iters = torch.zeros(n, dtype=torch.int32, device=dev); status = torch.zeros(n, dtype=torch.int32, device=dev)
     eng = pkg.Engine(cfg, n, local)
     stream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream: kernels and the timing events share it
     torch.cuda.synchronize()
 
-    def step():
+    def step(k=0, fresh=True):
+        d = ds[k % NB]
+        if fresh:
+            eng.set_schedule(True)   # forget the previous solve: the queue is ordered by the set-up kernel's own cost guess
         eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, iters, status, stream=stream.cuda_stream)
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -241,7 +277,7 @@ def main():
     t0 = time.perf_counter()
     evs[0].record(stream)
     for k in range(args.steps):
-        step()
+        step(k)
         evs[k + 1].record(stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -254,69 +290,78 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    it = iters.cpu().numpy(); stt = status.cpu().numpy()
-    # the same steps in plain index order (a1mpc_set_schedule(0)) and as first solves (no history): reported beside `value`, never instead of it
-    index_ms = first_ms = None
+    # per-batch work (iterations, factorisations: deterministic) for the flop model, collected outside the timed region
+    work = []
+    for k in range(NB):
+        step(k); torch.cuda.synchronize()
+        work.append((iters.cpu().numpy().copy(), status.cpu().numpy().copy(), eng.last_nfact(n).copy()))
+    gpu_grf0 = None
+    step(0); torch.cuda.synchronize(); gpu_grf0 = grf.cpu().numpy().copy()
+    it, stt = work[0][0], work[0][1]
+    # the same batches with the queue ordered by history (each batch re-solved right after itself) and in plain index order: reported beside `value`
+    index_ms = hist_ms = None
     if not args.no_index_order:
+        def timed(fn):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream); fn(); e1.record(stream); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / args.steps
         eng.set_schedule(False)
-        step(); torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(args.steps):
-            step()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        index_ms = e0.elapsed_time(e1) / args.steps
-        # ... and as a FIRST solve each time: a1mpc_set_schedule() drops the history, so the queue is ordered by the set-up kernel's cost guess
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(args.steps):
-            eng.set_schedule(True)
-            step()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        first_ms = e0.elapsed_time(e1) / args.steps
+        step(0, fresh=False); torch.cuda.synchronize()
+        index_ms = timed(lambda: [step(k, fresh=False) for k in range(args.steps)])
         eng.set_schedule(True)
+        step(0, fresh=False); torch.cuda.synchronize()
+        hist_ms = timed(lambda: [step(0, fresh=False) for _ in range(args.steps)])   # identical inputs again and again: hindsight order
     if rank == 0:
         h = HORIZON
-        nfact = eng.last_nfact(n)  # factorisations each QP really performed in the last launch
-        flops = float(pkg.algorithmic_flops(h, it, nfact).sum())
-        traffic = None  # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), when a summary of this workload exists
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            if n == BATCH:
-                traffic = float(pm["_hbm_bytes_per_solve_batch_launch"])
-        except Exception:
-            pass
+        flops_b = [float(pkg.algorithmic_flops(h, w[0], w[2]).sum()) for w in work]
+        flops = float(np.mean([flops_b[k % NB] for k in range(args.steps)]))   # mean algorithmic flops of a timed launch
         avg_ms = float(kern_ms.mean())
         achieved = flops / (avg_ms * 1e-3) / 1e12
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+        except Exception:
+            pass
+        traffic = float(pmc["hbm_bytes_per_launch"]) if (n == BATCH and "hbm_bytes_per_launch" in pmc) else None
         out = {
             "metric": "MPC QP solves/sec (horizon=10 SRBD)", "value": world * n * args.steps / elapsed, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: batch=4096 randomized CoM states + flat terrain, horizon=10, cold-start "
-                                   "OSQP-default ADMM, per GPU", "batch_per_gpu": n, "horizon": h, "parallelism": f"batch-sharded x{world}",
+                                   "OSQP-default ADMM, per GPU; 4 distinct batches cycled, every step a first solve (no queue-order history)",
+                       "batch_per_gpu": n, "horizon": h, "parallelism": f"batch-sharded x{world}",
                        "mean_iters": float(it.mean()), "max_iters": int(it.max()), "solved_frac": float((stt == 1).mean())},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "a1mpc_setup_kernel<10> + a1mpc_admm_kernel<10,2> (+ a1mpc_order_kernel, ~5 us) = one solve", "avg_kernel_ms": avg_ms, "algorithmic_flops_per_launch": flops,
-                         "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
-                         "note": "FP64 VALU issue/latency-bound (no MFMA used, DESIGN.md 3); flops = SURVEY 8(d) F(h,iters,nfact) summed over the launch; "
-                                 "traffic = FETCH_SIZE+WRITE_SIZE of profiles/r01_pmc_summary.json (same workload)"},
+                         "traffic_source": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r02_pmc_summary.json" if traffic else None,
+                         "kernel": "a1mpc_setup_kernel<10> + a1mpc_admm_kernel<10,2> (+ a1mpc_order_kernel, ~5 us) = one solve", "avg_kernel_ms": avg_ms,
+                         "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
+                         "executed_fp64_flops_per_launch": pmc.get("executed_fp64_flops_per_launch"),
+                         "executed_fp64_frac": (pmc["executed_fp64_flops_per_launch"] / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if pmc.get("executed_fp64_flops_per_launch") else None,
+                         "note": "bound: FP64 VALU issue / LDS latency (no MFMA in the kernel: profiles/r02_mfma_trial.md); the peak is the dense FP64 peak (vector = matrix "
+                                 "on MI355X); flops = SURVEY 8(d) F(h,iters,nfact) of the dense-condensed model summed over the launch; executed_fp64 = "
+                                 "SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 x live lanes from the static PMC profile"},
         }
         out["scheduling"] = {
-            "mode": "history: the work queue of a batch beyond the resident rows is ordered longest-first by the per-QP cost of the previous "
-                    "solve of the handle (a1mpc_set_schedule); every QP is solved from scratch every step, results are independent of the order",
+            "mode": "value: first solves (no history; queue ordered by the set-up kernel's per-QP cost guess).  Beside it: plain index order, and "
+                    "'history' = the same batch solved again right after itself with the queue in longest-first order of the previous solve "
+                    "(the closed-loop regime's order; hindsight for identical inputs, never `value`)",
             "index_order_ms_per_step": index_ms, "index_order_solves_per_s_per_gpu": (n / (index_ms * 1e-3)) if index_ms else None,
-            "first_solve_ms_per_step": first_ms, "first_solve_solves_per_s_per_gpu": (n / (first_ms * 1e-3)) if first_ms else None,
-            "first_solve_note": "no history: queue ordered by the set-up kernel's per-QP cost guess (velocity error, rank correlation ~0.6 on this workload)"}
+            "history_ms_per_step": hist_ms, "history_solves_per_s_per_gpu": (n / (hist_ms * 1e-3)) if hist_ms else None}
+        if not args.no_latency:
+            out["roofline_other_configs"] = other_config_rooflines(pkg, local)
         if not args.no_latency:
             out["latency"] = latency_probe(pkg)
             out["throughput_by_batch"] = batch_sweep(pkg, local)
             out["warm_start_ticks"] = warm_tick_probe(pkg, local)
             out["full_control_tick"] = full_tick_probe(pkg, local)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"], _ = cpu_baseline(pkg, sc)
+            out["cpu_baseline"], ref = cpu_baseline(pkg, sc)
+            # parity of the timed workload against the checker (same leg: the oracle is only ever the baseline / the checker)
+            dg = np.abs(gpu_grf0 - ref["grf"])
+            out["parity"] = {"checked_qps": int(n), "max_abs_dgrf_N": float(dg.max()), "iteration_mismatches": int((it != ref["iters"]).sum()),
+                             "status_mismatches": int((stt != ref["status"]).sum()), "tolerance_N": 1e-5,
+                             "against": "oracle/a1mpc_oracle.c (formation pinned to the reference's ConvexMpc.cpp by oracle/_ref; the OSQP solve restated, unpinned)"}
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -19,6 +19,10 @@
  *
  * Plain pointers and sizes only.  All matrices use the reference's (Eigen) storage: 3x4 GRF / foot
  * matrices are column-major (leg-major, 12 doubles), root_rot_mat is passed ROW-major (9 doubles).
+ * Streams: the *_device entry points launch on the stream the caller passes (NULL = the handle's own).  The handle owns scratch that
+ * every launch uses, so consecutive calls on DIFFERENT streams are ordered by the library (the later call waits on the device for the
+ * earlier one; calls on the same stream are ordered by the stream) -- a handle never runs two launches concurrently; use one handle
+ * per stream for that.
  * Caller owns every host array (pageable is fine; the library snapshots inputs at entry because the
  * surrounding control program mutates A1CtrlStates without locks, S/MainGazebo.cpp:47-121).  A handle is
  * used by one thread at a time (the reference's thread 1); different handles are independent.
@@ -120,6 +124,25 @@ a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d
                                       const double* d_R_world, const double* d_foot_abs, const uint8_t* d_contact,
                                       double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out,
                                       int32_t* d_status_out, void* hip_stream);
+
+/*
+ * The general case of the reference's ConvexMpc INTERFACE: a different B_d at every horizon step (public member B_mat_d_list,
+ * S/ConvexMpc.h:74, filled per step by S/test/test_mpc.cpp:106-122 -- feet shifted by root_lin_vel_d * dt -- and by the commented
+ * lines S/A1RobotControl.cpp:504-507) and a per-step contact schedule (a superset: calculate_qp_mats broadcasts the current contacts,
+ * S/ConvexMpc.cpp:228-245).
+ *   foot_stride    0: foot is n x 12, the same feet at every step       12: foot is n x 12H, step t of problem i at foot[(i*H + t)*12]
+ *   contact_stride 0: contact is n x 4, broadcast over the horizon       4: contact is n x 4H, step t of problem i at contact[(i*H + t)*4]
+ * Everything else as a1mpc_solve_batch.  (0, 0) IS a1mpc_solve_batch (same kernels, same bits).  Any other combination runs the
+ * general kernels: same OSQP iterates as the reference's formation with those inputs, with a bigger LDS image per QP (B~_t and the
+ * bounds of every step), i.e. fewer QPs in flight -- slower by design.  Horizons 10, 16, 20.
+ */
+a1mpc_status a1mpc_solve_batch_strided(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
+                                       const double* foot_abs, int32_t foot_stride, const uint8_t* contact, int32_t contact_stride,
+                                       double* grf_body_out, double* u_full_out, int32_t* iters_out, int32_t* status_out);
+a1mpc_status a1mpc_solve_batch_strided_device(a1mpc_handle h, int32_t n, const double* d_x0, const double* d_x_ref,
+                                              const double* d_R_world, const double* d_foot_abs, int32_t foot_stride,
+                                              const uint8_t* d_contact, int32_t contact_stride, double* d_grf_body_out,
+                                              double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out, void* hip_stream);
 
 /*
  * N1 (the caller side of the path, S/A1RobotControl.cpp:452-488): the same solve from the COMPACT tick record; x0 (mpc_states)
@@ -288,6 +311,20 @@ a1mpc_status a1mpc_set_schedule(a1mpc_handle h, int32_t history);
 
 /* forget the carried (x, y, rho) of every problem: next solve is a cold start */
 a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h);
+
+/* Read / write the carried OSQP workspace of problems 0..n-1 (the reference keeps it inside its persistent
+ * OsqpEigen::Solver member, S/A1RobotControl.h:67): x n x 12H (world-frame forces), y n x 20H (reference row order), rho n
+ * (0 = "start from settings.rho").  Any pointer may be NULL.  Host pointers; synchronises the handle's stream.  A solve whose
+ * solution is not finite leaves (0, 0, 0) behind, i.e. the next tick of that problem is a cold start (OSQP's store_solution()
+ * cold-starts its iterates after a failed solve), so one bad tick cannot poison the ticks after it. */
+a1mpc_status a1mpc_warm_start(a1mpc_handle h, int32_t n, const double* x, const double* y, const double* rho);
+a1mpc_status a1mpc_get_warm_start(a1mpc_handle h, int32_t n, double* x_out, double* y_out, double* rho_out);
+
+/* Replace the configuration of a live handle -- everything except the horizon: dt (the reference uses the measured loop dt when
+ * use_sim_time is "true", S/A1RobotControl.cpp:465), weights, mass / inertia, friction and force limits, OSQP settings.  The constants
+ * travel to the kernels by value with every launch, so this costs nothing, keeps the carried warm start and takes effect with the
+ * next call. */
+a1mpc_status a1mpc_update_config(a1mpc_handle h, const a1mpc_config* cfg);
 
 /* instrumentation: duration of the last kernel launched through this handle (HIP events on its stream;
  * synchronises that stream), bytes of dynamic LDS per workgroup and QPs per workgroup of the horizon's kernel */

@@ -456,6 +456,10 @@ int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t
         }
     }
 done:
+    /* A non-finite iterate (NaN / Inf inputs) is reported as NON_CVX whatever the residual tests concluded: OSQP's max-norms skip NaNs,
+     * so its own termination test can "converge" on a NaN iterate.  (Same rule as the engine's write_outputs; a deviation from OSQP that
+     * only concerns inputs the reference never produces.) */
+    for (int j = 0; j < n; ++j) if (!isfinite(w.x[j])) { info->status = ORC_NON_CVX; break; }
     info->rho_final = w.rho;
     if (rho_io) *rho_io = w.rho;
     if (info->status == ORC_PRIMAL_INFEASIBLE || info->status == ORC_DUAL_INFEASIBLE || info->status == ORC_NON_CVX) {

@@ -83,6 +83,24 @@ def solve(sc, n=None, settings=None, warm=None, split_rows=0, **over):
     return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
 
 
+def solve_gen(sc, foot, foot_stride, contact, contact_stride, n=None, settings=None, warm=None, **over):
+    """the general path: foot (n, 12) or (n, 12h) with foot_stride 0 / 12; contact (n, 4) or (n, 4h) with contact_stride 0 / 4"""
+    h = sc["horizon"]
+    n = len(sc["x0"]) if n is None else n
+    P = make_params(sc["params"], settings, **over)
+    foot = np.ascontiguousarray(foot, dtype=np.float64); contact = np.ascontiguousarray(contact, dtype=np.uint8)
+    grf = np.zeros((n, 12)); u = np.zeros((n, 12 * h))
+    iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32); nfact = np.zeros(n, np.int32)
+    wx = wy = rho = None
+    if warm is not None:
+        wx, wy, rho = warm
+    rc = lib().a1mpc_emu_solve_gen(C.byref(P), h, n, _p(sc["x0"]), _p(sc["xref"]), _p(sc["R"]), _p(foot), int(foot_stride), _p(contact, C.c_uint8),
+                                   int(contact_stride), _p(grf), _p(u), _p(wx), _p(wy), _p(rho), _p(iters, C.c_int32), _p(status, C.c_int32),
+                                   _p(nfact, C.c_int32))
+    assert rc == 0
+    return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
+
+
 def balance_params(qp=None, settings=None, **over):
     """DeviceParams of the balance QP (S/A1RobotControl.cpp:11-15): the H = 1 member of the family with
     dt = 0, wrench weights (torque first) in q2[6:12], R in r2."""

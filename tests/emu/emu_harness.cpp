@@ -232,4 +232,45 @@ extern "C" int a1mpc_emu_balance(const a1mpc::DeviceParams* P, int n, const doub
     }
     return 0;
 }
+namespace a1mpc {
+template <int H>
+static void gen_entry(void* a) {
+    Job<H>* j = static_cast<Job<H>*>(a);
+    solve_row<H, kModeMpc, true>(*j->P, j->tab, j->io, j->lds);
+}
+template <int H>
+static void run_gen(const DeviceParams* P, int n, const double* x0, const double* xref, const double* R, const double* foot, int foot_stride,
+                    const uint8_t* contact, int contact_stride, double* grf, double* u_full, double* warm_x, double* warm_y, double* rho,
+                    int32_t* iters, int32_t* status, int32_t* nfact) {
+    std::vector<double> tab(2 * H * H);
+    fill_gamma_beta_table(H, tab.data());
+    std::vector<double> lds(Layout<H, true>::ROW_STRIDE);
+    for (int b = 0; b < n; ++b) {
+        for (auto& v : lds) v = NAN;
+        Job<H> j;
+        memset(&j.io, 0, sizeof j.io);
+        j.P = P; j.tab = tab.data(); j.lds = lds.data();
+        j.io.x0 = x0 + (size_t)b * 13; j.io.xref = xref + (size_t)b * 13 * H; j.io.R = R + (size_t)b * 9;
+        j.io.foot = foot + (size_t)b * (foot_stride ? 12 * H : 12); j.io.contact = contact + (size_t)b * (contact_stride ? 4 * H : 4);
+        j.io.foot_stride = foot_stride; j.io.contact_stride = contact_stride;
+        j.io.grf = grf + (size_t)b * 12; j.io.u_full = u_full ? u_full + (size_t)b * 12 * H : nullptr;
+        j.io.warm_x = warm_x ? warm_x + (size_t)b * 12 * H : nullptr; j.io.warm_y = warm_y ? warm_y + (size_t)b * 20 * H : nullptr;
+        j.io.rho_io = rho ? rho + b : nullptr;
+        j.io.iters = iters ? iters + b : nullptr; j.io.status = status ? status + b : nullptr; j.io.nfact = nfact ? nfact + b : nullptr;
+        run_row(gen_entry<H>, &j);
+    }
+}
+}  // namespace a1mpc
+// the general path (per-step feet / per-step contact schedules, RowSolver<..., GEN = true>)
+extern "C" int a1mpc_emu_solve_gen(const a1mpc::DeviceParams* P, int horizon, int n, const double* x0, const double* xref, const double* R,
+                                   const double* foot, int foot_stride, const uint8_t* contact, int contact_stride, double* grf, double* u_full,
+                                   double* warm_x, double* warm_y, double* rho, int32_t* iters, int32_t* status, int32_t* nfact) {
+    switch (horizon) {
+        case 4: a1mpc::run_gen<4>(P, n, x0, xref, R, foot, foot_stride, contact, contact_stride, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
+        case 10: a1mpc::run_gen<10>(P, n, x0, xref, R, foot, foot_stride, contact, contact_stride, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
+        case 16: a1mpc::run_gen<16>(P, n, x0, xref, R, foot, foot_stride, contact, contact_stride, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
+        case 20: a1mpc::run_gen<20>(P, n, x0, xref, R, foot, foot_stride, contact, contact_stride, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
+    }
+    return -1;
+}
 extern "C" int a1mpc_emu_sizeof_params(void) { return (int)sizeof(a1mpc::DeviceParams); }

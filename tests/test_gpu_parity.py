@@ -562,3 +562,129 @@ def test_device_pointer_tick_matches_host_pointer_tick(pkg, scen):
             st.synchronize()
             assert np.array_equal(st_d["tau"].cpu().numpy(), st_h["tau"]), (t, np.abs(st_d["tau"].cpu().numpy() - st_h["tau"]).max())
             assert np.array_equal(o["pos"].cpu().numpy(), pos) and np.array_equal(ct_d.cpu().numpy(), ctr["contacts"]) and np.array_equal(it_d.cpu().numpy(), sol["iters"])
+
+
+# ------------------------------------------------------------------------------------------------------------ round 2
+def test_bench_batch_all_4096_qps_vs_oracle(pkg, oracle, scen):
+    """VERDICT r1 task 2: EVERY QP of the bench configuration (BASELINE configs[2]: 4096 x h10, the bench seed) against the oracle."""
+    sc = scen.config3_random_flat(nb=4096)
+    with _engine(pkg, sc, 4096, warm_start=0) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    r = compare(out, oracle_batch(oracle, sc), min_same=1.0)
+    print("4096 x h10:", r)
+
+
+@pytest.mark.parametrize("gen,n", [("config4_random_h16", 8192), ("config5_divergent", 8192)])
+def test_full_8192_h16_h20_vs_oracle(pkg, oracle, scen, gen, n):
+    """VERDICT r1 task 2: one full 8192 x h16 (configs[3] per-GPU share) and one 8192 x h20 (configs[4] shape) comparison, every QP."""
+    sc = getattr(scen, gen)(nb=n)
+    with _engine(pkg, sc, n, warm_start=0) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    r = compare(out, oracle_batch(oracle, sc), min_same=1.0)
+    print(gen, r)
+
+
+def _strided_inputs(scen, rng, h, nb, feet, cont):
+    sc = scen.config3_random_flat(nb=nb, horizon=h)
+    p = sc["params"]; foot = sc["foot"]; contact = sc["contact"]; fs = cs = 0
+    if feet:
+        vd = rng.uniform(-0.6, 0.6, (nb, 1, 1, 3))
+        foot = (sc["foot"].reshape(nb, 1, 4, 3) - vd * p["dt"] * np.arange(h).reshape(1, h, 1, 1) * 40.0).reshape(nb, h * 12); fs = 12
+    if cont:
+        sw = rng.integers(0, h + 1, (nb, 4)); first = rng.integers(0, 2, (nb, 4))
+        contact = np.where(np.arange(h).reshape(1, h, 1) < sw[:, None, :], first[:, None, :], 1 - first[:, None, :]).astype(np.uint8).reshape(nb, h * 4); cs = 4
+    return sc, np.ascontiguousarray(foot), fs, np.ascontiguousarray(contact), cs
+
+
+@pytest.mark.parametrize("h,nb,feet,cont", [(10, 300, True, True), (10, 128, True, False), (10, 128, False, True), (16, 96, True, True), (20, 64, True, True)])
+def test_per_step_feet_and_contact_schedules(pkg, oracle, scen, h, nb, feet, cont):
+    """b' (VERDICT r1): a1mpc_solve_batch_strided -- per-step B_d (S/ConvexMpc.h:74 B_mat_d_list, S/test/test_mpc.cpp:106-122) and per-step
+    contact schedules -- vs the oracle's strided formation (which oracle/_ref pins to the reference's ConvexMpc for per-step feet)."""
+    rng = np.random.default_rng(1000 + h + 2 * feet + cont)
+    sc, foot, fs, contact, cs = _strided_inputs(scen, rng, h, nb, feet, cont)
+    with _engine(pkg, sc, nb, warm_start=0) as eng:
+        out = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, fs, contact, cs, want_u=True)
+        bc = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], sc["foot"], 0, sc["contact"], 0, want_u=True)
+        fast = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    assert np.array_equal(bc["u"], fast["u"]) and np.array_equal(bc["iters"], fast["iters"])   # (0, 0) is the fast path, bit for bit
+    pr = oracle.mpc_params(h, **{k: sc["params"][k] for k in ("dt", "mu", "fz_min", "fz_max", "q", "r", "mass", "inertia")}); st = oracle.default_settings()
+    worst = 0.0
+    for b in range(0, nb, 3):
+        r = oracle.mpc_solve(pr, st, sc["x0"][b], sc["xref"][b], sc["R"][b], foot[b], contact[b], foot_stride=fs, contact_stride=cs)
+        assert out["iters"][b] == r["info"].iters and out["status"][b] == r["info"].status, (b, out["iters"][b], r["info"].iters)
+        worst = max(worst, np.abs(out["u"][b] - r["u"]).max(), np.abs(out["grf"][b] - r["grf"]).max())
+    assert worst <= TOL_FORCE_N, worst
+    if cont:   # a leg that is in swing at step t carries no force at step t
+        u = out["u"].reshape(nb, h, 4, 3); c = contact.reshape(nb, h, 4)
+        assert np.abs(u[c == 0]).max() < 1.0
+
+
+def test_failed_tick_leaves_a_cold_start_behind(pkg, oracle, scen):
+    """warm start ON, a NaN tick for some robots -> status -7 and zero GRFs for them at that tick, and at the NEXT tick
+    they are solved again (a cold start: same answer as a cold solve) instead of staying NaN for ever."""
+    n = 64
+    sc = scen.config3_random_flat(nb=n)
+    bad = np.zeros(n, bool); bad[[3, 17, 40]] = True
+    with _engine(pkg, sc, n, warm_start=1) as eng:
+        eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+        x0 = sc["x0"].copy(); x0[bad, 4] = np.nan
+        o1 = eng.solve(x0, sc["xref"], sc["R"], sc["foot"], sc["contact"])
+        assert (o1["status"][bad] == -7).all() and (o1["grf"][bad] == 0).all() and (o1["status"][~bad] == 1).all()
+        wx, wy, rho = eng.get_warm_start(n)
+        assert (wx[bad] == 0).all() and (wy[bad] == 0).all() and (rho[bad] == 0).all() and np.isfinite(wx).all() and np.isfinite(wy).all()
+        o2 = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    with _engine(pkg, sc, n, warm_start=0) as eng:
+        cold = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    assert (o2["status"] == 1).all()
+    assert np.array_equal(o2["u"][bad], cold["u"][bad]) and np.array_equal(o2["iters"][bad], cold["iters"][bad])
+
+
+def test_update_config_dt_and_warm_start_io(pkg, oracle, scen):
+    """dt (the reference passes the measured loop dt when use_sim_time is "true", S/A1RobotControl.cpp:465), weights
+    and mass can change on a live handle (a1mpc_update_config); a1mpc_warm_start / a1mpc_get_warm_start move the carried workspace."""
+    n = 32
+    sc = scen.config3_random_flat(nb=n)
+    p2 = dict(sc["params"], dt=0.004, mass=13.0)
+    xr2 = sc["xref"].copy()   # x_ref as the caller builds it with the other dt
+    tk = sc["tick"]
+    xr2 = scen.build_reference(10, 0.004, tk[:, 0:3], tk[:, 3:6], sc["R"].reshape(n, 3, 3), tk[:, 12:15], tk[:, 15:18], tk[:, 18:21], tk[:, 21])
+    with _engine(pkg, sc, n, warm_start=1) as eng:
+        a = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+        wx, wy, rho = eng.get_warm_start(n)
+        eng.update_config(pkg.make_config(p2, 10, warm_start=1))
+        b = eng.solve(sc["x0"], xr2, sc["R"], sc["foot"], sc["contact"], want_u=True)
+    pr = oracle.mpc_params(10, p2["dt"], p2["mu"], p2["fz_min"], p2["fz_max"], p2["q"], p2["r"], p2["mass"], p2["inertia"])
+    st = oracle.default_settings(warm_start=1)
+    for i in range(0, n, 4):
+        r = oracle.mpc_solve(pr, st, sc["x0"][i], xr2[i], sc["R"][i], sc["foot"][i], sc["contact"][i], warm_x=wx[i], warm_y=wy[i], warm_rho=rho[i])
+        assert b["iters"][i] == r["info"].iters and np.abs(b["u"][i] - r["u"]).max() <= TOL_FORCE_N, i
+    # a workspace written through the ABI is the one the next solve starts from
+    with _engine(pkg, sc, n, warm_start=1) as eng:
+        eng.set_warm_start(wx, wy, rho)
+        eng.update_config(pkg.make_config(p2, 10, warm_start=1))
+        c = eng.solve(sc["x0"], xr2, sc["R"], sc["foot"], sc["contact"], want_u=True)
+    assert np.array_equal(b["u"], c["u"]) and np.array_equal(b["iters"], c["iters"])
+    assert np.isfinite(a["u"]).all()
+
+
+def test_calls_on_different_streams_are_ordered(pkg, scen):
+    """two device-pointer solves of one handle issued on two different streams must not overlap on the handle's
+    scratch (prepared-state records, queue counter): results equal the same two solves issued on one stream."""
+    import torch
+    n = 4096
+    sc = scen.config3_random_flat(nb=n); sc2 = scen.config3_random_flat(nb=n, seed=77)
+    dev = torch.device("cuda:0")
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    ins = [[t(s["x0"]), t(s["xref"]), t(s["R"]), t(s["foot"]), t(s["contact"], torch.uint8)] for s in (sc, sc2)]
+    with _engine(pkg, sc, n, warm_start=0) as eng:
+        ref = []
+        for k in range(2):
+            g = torch.zeros(n, 12, dtype=torch.float64, device=dev)
+            eng.solve_device(n, *ins[k], g); torch.cuda.synchronize(); ref.append(g.cpu().numpy())
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        for rep in range(3):
+            g1 = torch.zeros(n, 12, dtype=torch.float64, device=dev); g2 = torch.zeros(n, 12, dtype=torch.float64, device=dev)
+            eng.solve_device(n, *ins[0], g1, stream=s1.cuda_stream)
+            eng.solve_device(n, *ins[1], g2, stream=s2.cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(g1.cpu().numpy(), ref[0]) and np.array_equal(g2.cpu().numpy(), ref[1]), rep
