@@ -120,6 +120,95 @@ __global__ __launch_bounds__(1024) void a1mpc_order_kernel(int n, const int32_t*
     }
 }
 
+// ---- debug / verification: the dense QP data the reference's ConvexMpc holds in its public members (hessian, gradient, lb, ub --
+// S/ConvexMpc.h:84-93, filled by calculate_qp_mats, S/ConvexMpc.cpp:158-245) materialised from the same inputs, per-step feet and
+// contacts included.  The solver never forms these (a1mpc_solver.hpp); this kernel exists so that callers which poke the members
+// (S/A1RobotControl.cpp:527-537, S/test/test_mpc.cpp:136-140) keep working and so that the implicit Hessian can be compared entry by
+// entry with the reference's dense product.  One workgroup per QP; not on the hot path.
+struct FormArgs {
+    DeviceParams P;
+    int32_t n, H, foot_stride, contact_stride;
+    const double *x0, *xref, *R, *foot;
+    const uint8_t* contact;
+    const double* yaw_A;
+    double *Pout, *gout, *lout, *uout;   // n x (12H)^2 row-major, n x 12H, n x 20H, n x 20H
+};
+__global__ __launch_bounds__(256) void a1mpc_form_kernel(const FormArgs a) {
+    __shared__ double Bw[20 * 36], TB[20 * 36], w[20 * 12], Ii[9];
+    const int64_t b = blockIdx.x;
+    const int tid = static_cast<int>(threadIdx.x), H = a.H, n = 12 * H;
+    const DeviceParams& P = a.P;
+    const double* R = a.R + b * 9;
+    const double* x0 = a.x0 + b * 13;
+    const double yaw = a.yaw_A ? a.yaw_A[b] : x0[2];
+    const double dt = P.dt, cy = cos(yaw), sy = sin(yaw), bv = dt / P.mass;
+    if (tid == 0) {  // I_world = R I_b R', inverse by cofactors (S/ConvexMpc.cpp:136-141)
+        double t9[9], Iw[9];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += R[i * 3 + k] * P.inertia[k * 3 + j]; t9[i * 3 + j] = s; }
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += t9[i * 3 + k] * R[j * 3 + k]; Iw[i * 3 + j] = s; }
+        const double c00 = Iw[4] * Iw[8] - Iw[5] * Iw[7], c01 = Iw[5] * Iw[6] - Iw[3] * Iw[8], c02 = Iw[3] * Iw[7] - Iw[4] * Iw[6];
+        const double id = 1.0 / (Iw[0] * c00 + Iw[1] * c01 + Iw[2] * c02);
+        Ii[0] = c00 * id; Ii[1] = (Iw[2] * Iw[7] - Iw[1] * Iw[8]) * id; Ii[2] = (Iw[1] * Iw[5] - Iw[2] * Iw[4]) * id;
+        Ii[3] = c01 * id; Ii[4] = (Iw[0] * Iw[8] - Iw[2] * Iw[6]) * id; Ii[5] = (Iw[2] * Iw[3] - Iw[0] * Iw[5]) * id;
+        Ii[6] = c02 * id; Ii[7] = (Iw[1] * Iw[6] - Iw[0] * Iw[7]) * id; Ii[8] = (Iw[0] * Iw[4] - Iw[1] * Iw[3]) * id;
+        // w_i = Q (A_d^{i+1} x0 - x_ref_i): roll-out with A_d = I + dt A_c (S/ConvexMpc.cpp:123-129,150)
+        double xs[12];
+        for (int k = 0; k < 12; ++k) xs[k] = x0[k];
+        const double* xr = a.xref + b * 13 * H;
+        for (int i = 0; i < H; ++i) {
+            const double o0 = xs[6], o1 = xs[7], o2 = xs[8];
+            xs[0] += dt * (cy * o0 + sy * o1); xs[1] += dt * (-sy * o0 + cy * o1); xs[2] += dt * o2;
+            xs[3] += dt * xs[9]; xs[4] += dt * xs[10]; xs[5] += dt * xs[11];
+            xs[11] += dt * x0[12];
+            for (int k = 0; k < 12; ++k) w[i * 12 + k] = P.q2[k] * (xs[k] - xr[i * 13 + k]);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < H * 12; e += 256) {  // B~w_t = dt Iw^-1 skew(r_t), T B~w_t
+        const int t = e / 12, c = e % 12, leg = c / 3, comp = c % 3;
+        const double* fp = a.foot + b * (a.foot_stride ? 12 * H : 12) + static_cast<int64_t>(t) * a.foot_stride + 3 * leg;
+        const double rx = fp[0], ry = fp[1], rz = fp[2];
+        const double k0 = comp == 0 ? 0.0 : (comp == 1 ? -rz : ry), k1 = comp == 0 ? rz : (comp == 1 ? 0.0 : -rx), k2 = comp == 0 ? -ry : (comp == 1 ? rx : 0.0);
+        double bw[3];
+        for (int k = 0; k < 3; ++k) bw[k] = (Ii[k * 3 + 0] * k0 + Ii[k * 3 + 1] * k1 + Ii[k * 3 + 2] * k2) * dt;
+        for (int k = 0; k < 3; ++k) Bw[(t * 3 + k) * 12 + c] = bw[k];
+        TB[(t * 3 + 0) * 12 + c] = cy * bw[0] + sy * bw[1]; TB[(t * 3 + 1) * 12 + c] = -sy * bw[0] + cy * bw[1]; TB[(t * 3 + 2) * 12 + c] = bw[2];
+    }
+    __syncthreads();
+    double* Po = a.Pout + b * static_cast<int64_t>(n) * n;
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e % n, s = i / 12, ca = i % 12, t = j / 12, cb = j % 12, m = s > t ? s : t;
+        double al = 0.0;
+        for (int k = m; k < H; ++k) al += static_cast<double>((k - s) * (k - t));
+        const double be = H - m;
+        double u = 0.0, v = 0.0;
+        for (int c = 0; c < 3; ++c) { u += P.q2[c] * TB[(s * 3 + c) * 12 + ca] * TB[(t * 3 + c) * 12 + cb]; v += P.q2[6 + c] * Bw[(s * 3 + c) * 12 + ca] * Bw[(t * 3 + c) * 12 + cb]; }
+        if (ca % 3 == cb % 3) { u += P.q2[3 + ca % 3] * bv * bv; v += P.q2[9 + ca % 3] * bv * bv; }
+        Po[e] = al * (u * dt * dt) + be * v + (i == j ? P.r2[ca] : 0.0);
+    }
+    for (int j = tid; j < n; j += 256) {
+        const int t = j / 12, cb = j % 12;
+        double g = 0.0;
+        for (int i = t; i < H; ++i) {
+            const double k = (i - t) * dt;
+            double lo = bv * w[i * 12 + 3 + cb % 3], hi = bv * w[i * 12 + 9 + cb % 3];
+            for (int c = 0; c < 3; ++c) { lo += TB[(t * 3 + c) * 12 + cb] * w[i * 12 + c]; hi += Bw[(t * 3 + c) * 12 + cb] * w[i * 12 + 6 + c]; }
+            g += k * lo + hi;
+        }
+        a.gout[b * n + j] = g;
+    }
+    for (int r = tid; r < 20 * H; r += 256) {  // S/ConvexMpc.cpp:223-245, per step
+        const int t = r / 20, leg = (r % 20) / 5, row = r % 5;
+        const uint8_t* cs = a.contact + b * (a.contact_stride ? 4 * H : 4) + static_cast<int64_t>(t) * a.contact_stride;
+        const double cf = cs[leg] ? 1.0 : 0.0;
+        double lo, hi;
+        if (row == 4) { lo = P.fz_min * cf; hi = P.fz_max * cf; }
+        else if (row == 0 || row == 2) { lo = 0.0; hi = kInfty; }
+        else { lo = -kInfty; hi = 0.0; }
+        a.lout[b * 20 * H + r] = lo; a.uout[b * 20 * H + r] = hi;
+    }
+}
+
 __global__ void a1mpc_noop_kernel() {}
 
 // ---- N2a: update_plan (S/A1RobotControl.cpp:148-202), one lane per (robot, leg) ------------------------------------------------
@@ -521,6 +610,7 @@ struct ContactArgs {
     double* pitch_d;
     uint8_t* contacts;
     double *recent_out, *terrain_out;
+    const double* recent_in;  // terrain-only entry: foot_pos_recent_contact comes from the caller instead of the handle's contact state
 };
 __device__ inline double mwf_update(double* f, int64_t fs, int window, double v) {  // S/utils/filter.hpp:26-39,53-66; f[k * fs] = field k of this filter
 #pragma clang fp contract(off)
@@ -597,7 +687,7 @@ __global__ __launch_bounds__(256) void a1mpc_terrain_kernel(const ContactArgs a)
     const double* recent = st + (13 * kMwf + 4) * fs;
     double rc[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) { rc[k] = recent[k * fs]; a.recent_out[b * 12 + k] = rc[k]; }
+    for (int k = 0; k < 12; ++k) { rc[k] = a.recent_in ? a.recent_in[b * 12 + k] : recent[k * fs]; if (a.recent_out) a.recent_out[b * 12 + k] = rc[k]; }
     double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, rhs[3] = {0, 0, 0}, P3[9], co[3];   // :566-582  a = pinv(W'W) W' z
     for (int i = 0; i < 4; ++i) {
         const double w[3] = {1.0, rc[3 * i + 0], rc[3 * i + 1]};
@@ -670,6 +760,7 @@ a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_con
     A1_HIP(hipMemcpyAsync(d_pd, root_euler_d_pitch, N * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(d_pc, plan_contacts, N * 4, hipMemcpyHostToDevice, s));
     ContactArgs a;
+    a.recent_in = nullptr;
     a.n = n; a.counter_per_swing = cfg->counter_per_swing; a.foot_force_low = cfg->foot_force_low; a.use_terrain_adapt = cfg->use_terrain_adapt;
     a.state = h->d_ct_state; a.stride = h->max_batch; a.gait_counter = d_gc; a.foot_force = d_ff; a.foot_pos_abs = d_fp; a.root_pos_z = d_z; a.plan_contacts = d_pc;
     a.pitch_d = d_pd; a.contacts = d_ct; a.recent_out = d_rec; a.terrain_out = d_ta;
@@ -1318,6 +1409,7 @@ a1mpc_status a1mpc_contact_terrain_batch_device(a1mpc_handle h, const a1mpc_cont
         A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double), s));
     }
     ContactArgs a;
+    a.recent_in = nullptr;
     a.n = n; a.counter_per_swing = cfg->counter_per_swing; a.foot_force_low = cfg->foot_force_low; a.use_terrain_adapt = cfg->use_terrain_adapt;
     a.state = h->d_ct_state; a.stride = h->max_batch; a.gait_counter = gait_counter; a.foot_force = foot_force; a.foot_pos_abs = foot_pos_abs; a.root_pos_z = root_pos_z;
     a.plan_contacts = plan_contacts; a.pitch_d = root_euler_d_pitch; a.contacts = contacts_out; a.recent_out = foot_pos_recent_contact_out; a.terrain_out = terrain_angle_out;
@@ -1552,7 +1644,7 @@ a1mpc_status a1mpc_set_schedule(a1mpc_handle h, int32_t history) {
 static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d_tick, const double* d_x0, const double* d_x_ref,
                                       const double* d_R_world, const double* d_foot_abs, const uint8_t* d_contact,
                                       double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out,
-                                      void* hip_stream, int32_t foot_stride = 0, int32_t contact_stride = 0) {
+                                      void* hip_stream, int32_t foot_stride = 0, int32_t contact_stride = 0, const double* d_yaw_A = nullptr) {
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0 || (!d_tick && (!d_x0 || !d_x_ref)) || !d_R_world || !d_foot_abs || !d_contact || !d_grf_body_out)
         return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
@@ -1567,9 +1659,9 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     a.tick = d_tick; a.x0 = d_x0; a.xref = d_x_ref; a.R = d_R_world; a.foot = d_foot_abs; a.contact = d_contact;
     a.grf = d_grf_body_out; a.u_full = d_u_full_out; a.iters = d_iters_out; a.status = d_status_out; a.nfact = h->d_nfact;
     if (h->cfg.warm_start) { a.warm_x = h->d_wx; a.warm_y = h->d_wy; a.rho = h->d_rho; }
-    if (foot_stride != 0 || contact_stride != 0) {  // general path: per-step B_d and / or a per-step contact schedule
+    if (foot_stride != 0 || contact_stride != 0 || d_yaw_A != nullptr) {  // general path: per-step B_d and / or a per-step contact schedule
         if (d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "per-step feet / contacts are not combined with tick records");
-        a.foot_stride = foot_stride; a.contact_stride = contact_stride;
+        a.foot_stride = foot_stride; a.contact_stride = contact_stride; a.yaw_A = d_yaw_A;
         A1_HIP(hipEventRecord(h->ev0, s));
         if (a1mpc_status stg = launch_gen(h->cfg.horizon, a, s); stg != A1MPC_OK) return stg;
         A1_HIP(hipEventRecord(h->ev1, s));
@@ -1686,23 +1778,104 @@ a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, cons
     return A1MPC_OK;
 }
 
+// ---- terrain block of compute_grf alone (S/A1RobotControl.cpp:335-376 + compute_walking_surface :566-582): foot_pos_recent_contact comes from
+// the caller's A1CtrlStates (the reference fills it in generate_swing_legs_ctrl); the terrain-angle filter of every robot lives in the handle
+a1mpc_status a1mpc_terrain_batch(a1mpc_handle h, int32_t use_terrain_adapt, int32_t n, const double* foot_pos_recent_contact, const double* root_pos_z,
+                                 double* root_euler_d_pitch, double* terrain_angle_out) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !foot_pos_recent_contact || !root_pos_z || !root_euler_d_pitch || !terrain_angle_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    if (a1mpc_status st = ensure_aux(h); st != A1MPC_OK) return st;
+    const size_t N = n;
+    hipStream_t s = h->stream;
+    A1_ORDER(h, s);
+    if (!h->d_ct_state) {
+        A1_HIP(hipMalloc(&h->d_ct_state, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double)));
+        A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double), s));
+    }
+    double *d_rec = h->d_aux_in, *d_z = d_rec + 12 * N, *d_pd = d_z + N, *d_ta = h->d_aux_out;
+    A1_HIP(hipMemcpyAsync(d_rec, foot_pos_recent_contact, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_z, root_pos_z, N * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(d_pd, root_euler_d_pitch, N * sizeof(double), hipMemcpyHostToDevice, s));
+    ContactArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.n = n; a.use_terrain_adapt = use_terrain_adapt; a.state = h->d_ct_state; a.stride = h->max_batch; a.root_pos_z = d_z; a.pitch_d = d_pd;
+    a.recent_in = d_rec; a.recent_out = nullptr; a.terrain_out = d_ta;
+    hipLaunchKernelGGL(a1mpc_terrain_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+    A1_HIP(hipGetLastError());
+    A1_MARK(h, s);
+    A1_HIP(hipMemcpyAsync(terrain_angle_out, d_ta, N * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipMemcpyAsync(root_euler_d_pitch, d_pd, N * sizeof(double), hipMemcpyDeviceToHost, s));
+    A1_HIP(hipStreamSynchronize(s));
+    return A1MPC_OK;
+}
+
+// ---- the dense QP the reference's ConvexMpc members hold (debug / verification; see a1mpc_form_kernel)
+a1mpc_status a1mpc_form_qp_batch(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world, const double* foot_abs,
+                                 int32_t foot_stride, const uint8_t* contact, int32_t contact_stride, const double* yaw_A, double* P_out, double* g_out,
+                                 double* l_out, double* u_out) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !P_out || !g_out || !l_out || !u_out)
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (!((foot_stride == 0 || foot_stride == 12) && (contact_stride == 0 || contact_stride == 4)))
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "foot_stride must be 0 or 12, contact_stride 0 or 4");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    const size_t N = n, H = h->cfg.horizon, nv = 12 * H, nc = 20 * H, nfoot = foot_stride ? 12 * H : 12, ncont = contact_stride ? 4 * H : 4;
+    hipStream_t s = h->stream;
+    A1_ORDER(h, s);
+    // own, call-scoped device buffers: this is a verification path, not a tick
+    double *d_in = nullptr, *d_out = nullptr;
+    uint8_t* d_c = nullptr;
+    const size_t in_d = N * (13 + 13 * H + 9 + nfoot + 1), out_d = N * (nv * nv + nv + 2 * nc);
+    A1_HIP(hipMalloc(&d_in, in_d * sizeof(double)));
+    hipError_t e1 = hipMalloc(&d_out, out_d * sizeof(double)), e2 = hipMalloc(&d_c, N * ncont);
+    if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_c); return fail(A1MPC_ERR_HIP, "hipMalloc (a1mpc_form_qp_batch)"); }
+    double *dx0 = d_in, *dxr = dx0 + N * 13, *dR = dxr + N * 13 * H, *df = dR + N * 9, *dyaw = df + N * nfoot;
+    double *dP = d_out, *dg = dP + N * nv * nv, *dl = dg + N * nv, *du = dl + N * nc;
+    hipError_t e = hipMemcpyAsync(dx0, x0, N * 13 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dxr, x_ref, N * 13 * H * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dR, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(df, foot_abs, N * nfoot * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_c, contact, N * ncont, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && yaw_A) e = hipMemcpyAsync(dyaw, yaw_A, N * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        FormArgs a;
+        a.P = h->dp; a.n = n; a.H = static_cast<int32_t>(H); a.foot_stride = foot_stride; a.contact_stride = contact_stride;
+        a.x0 = dx0; a.xref = dxr; a.R = dR; a.foot = df; a.contact = d_c; a.yaw_A = yaw_A ? dyaw : nullptr; a.Pout = dP; a.gout = dg; a.lout = dl; a.uout = du;
+        hipLaunchKernelGGL(a1mpc_form_kernel, dim3(static_cast<unsigned>(N)), dim3(256), 0, s, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(P_out, dP, N * nv * nv * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(g_out, dg, N * nv * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(l_out, dl, N * nc * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(u_out, du, N * nc * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_c);
+    if (e != hipSuccess) return fail(A1MPC_ERR_HIP, std::string("a1mpc_form_qp_batch: ") + hipGetErrorString(e));
+    return A1MPC_OK;
+}
+
 static bool strides_ok(int32_t foot_stride, int32_t contact_stride) {
     return (foot_stride == 0 || foot_stride == 12) && (contact_stride == 0 || contact_stride == 4);
 }
 a1mpc_status a1mpc_solve_batch_strided_device(a1mpc_handle h, int32_t n, const double* d_x0, const double* d_x_ref, const double* d_R_world,
                                               const double* d_foot_abs, int32_t foot_stride, const uint8_t* d_contact, int32_t contact_stride,
-                                              double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out,
-                                              void* hip_stream) {
+                                              const double* d_yaw_A, double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out,
+                                              int32_t* d_status_out, void* hip_stream) {
     if (!d_x0 || !d_x_ref) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
     if (!strides_ok(foot_stride, contact_stride)) return fail(A1MPC_ERR_INVALID_ARGUMENT, "foot_stride must be 0 or 12, contact_stride 0 or 4");
     return solve_device_impl(h, n, nullptr, d_x0, d_x_ref, d_R_world, d_foot_abs, d_contact, d_grf_body_out, d_u_full_out, d_iters_out,
-                             d_status_out, hip_stream, foot_stride, contact_stride);
+                             d_status_out, hip_stream, foot_stride, contact_stride, d_yaw_A);
 }
 a1mpc_status a1mpc_solve_batch_strided(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
                                        const double* foot_abs, int32_t foot_stride, const uint8_t* contact, int32_t contact_stride,
-                                       double* grf_body_out, double* u_full_out, int32_t* iters_out, int32_t* status_out) {
+                                       const double* yaw_A, double* grf_body_out, double* u_full_out, int32_t* iters_out, int32_t* status_out) {
     if (!strides_ok(foot_stride, contact_stride)) return fail(A1MPC_ERR_INVALID_ARGUMENT, "foot_stride must be 0 or 12, contact_stride 0 or 4");
-    if (foot_stride == 0 && contact_stride == 0)  // the reference controller's case: the fast path, bit for bit
+    if (foot_stride == 0 && contact_stride == 0 && !yaw_A)  // the reference controller's case: the fast path, bit for bit
         return a1mpc_solve_batch(h, n, x0, x_ref, R_world, foot_abs, contact, grf_body_out, u_full_out, iters_out, status_out);
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !grf_body_out)
@@ -1723,8 +1896,9 @@ a1mpc_status a1mpc_solve_batch_strided(a1mpc_handle h, int32_t n, const double* 
     A1_HIP(hipMemcpyAsync(h->d_R, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(h->d_foot_steps, foot_abs, N * nfoot * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(h->d_contact_steps, contact, N * ncont, hipMemcpyHostToDevice, s));
+    if (yaw_A) A1_HIP(hipMemcpyAsync(h->d_aux, yaw_A, N * sizeof(double), hipMemcpyHostToDevice, s));  // d_aux: n x 6 doubles of balance-QP staging, free here
     a1mpc_status st = solve_device_impl(h, n, nullptr, h->d_x0, h->d_xref, h->d_R, h->d_foot_steps, h->d_contact_steps, h->d_grf,
-                                        u_full_out ? h->d_u : nullptr, h->d_iters, h->d_status, s, foot_stride, contact_stride);
+                                        u_full_out ? h->d_u : nullptr, h->d_iters, h->d_status, s, foot_stride, contact_stride, yaw_A ? h->d_aux : nullptr);
     if (st != A1MPC_OK) return st;
     A1_HIP(hipMemcpyAsync(grf_body_out, h->d_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (u_full_out) A1_HIP(hipMemcpyAsync(u_full_out, h->d_u, N * 12 * H * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -75,6 +75,7 @@ struct ProblemIO {
     const double* foot;      // 12, 3x4 column-major foot_pos_abs (world-aligned, CoM-relative); GEN: + foot_stride doubles per horizon step
     const uint8_t* contact;  // 4; GEN: + contact_stride bytes per horizon step
     int32_t foot_stride;     // GEN only: 0 = the same feet at every step (S/A1RobotControl.cpp:498-514), 12 = per-step feet (S/test/test_mpc.cpp:106-122)
+    const double* yaw_A;     // GEN only, or null: the yaw A_c is built from when it is not mpc_states[2] (S/test/test_mpc.cpp:94-102 passes an average yaw)
     int32_t contact_stride;  // GEN only: 0 = contacts broadcast over the horizon (S/ConvexMpc.cpp:228-245), 4 = a per-step contact schedule
     double* grf;             // 12 out: 3x4 column-major body-frame GRFs
     double* u_full;          // 12*H out (world frame, all steps) or null
@@ -336,7 +337,8 @@ struct RowSolver {
         for (int i = 0; i < 9; ++i) Rm[i] = io.R[i];
         double c_ = 1.0, s_ = 0.0;
         if constexpr (MODE == kModeMpc) {
-            const double yaw = io.tick ? io.tick[2] : io.x0[2];
+            double yaw = io.tick ? io.tick[2] : io.x0[2];
+            if constexpr (GEN) { if (io.yaw_A) yaw = *io.yaw_A; }
             c_ = cos(yaw); s_ = sin(yaw);  // S/ConvexMpc.cpp:115-116
         }
         set_rotation(c_, s_);
@@ -1247,6 +1249,7 @@ struct BatchArgs {
     const double* tick;           // n x 22 compact tick records, or null (N1)
     const double *x0, *xref, *R, *foot;
     const uint8_t* contact;
+    const double* yaw_A;                  // general path only: n yaws for A_c, or null
     int32_t foot_stride, contact_stride;  // general path only (0 / 12 doubles and 0 / 4 bytes per horizon step): per-QP records are then 12H doubles / 4H bytes
     double *grf, *u_full, *warm_x, *warm_y, *rho;
     int32_t *iters, *status, *nfact;
@@ -1267,7 +1270,7 @@ A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
     io.R = a.R + b * 9;
     io.foot = a.foot + b * (a.foot_stride ? 12 * H : 12);
     io.contact = a.contact + b * (a.contact_stride ? 4 * H : 4);
-    io.foot_stride = a.foot_stride; io.contact_stride = a.contact_stride;
+    io.foot_stride = a.foot_stride; io.contact_stride = a.contact_stride; io.yaw_A = a.yaw_A ? a.yaw_A + b : nullptr;
     io.grf = a.grf + b * 12;
     io.u_full = a.u_full ? a.u_full + b * 12 * H : nullptr;
     io.warm_x = a.warm_x ? a.warm_x + b * 12 * H : nullptr;

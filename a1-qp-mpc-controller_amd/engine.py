@@ -40,7 +40,7 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
     _fields_ = [("counter_per_swing", C.c_double), ("foot_force_low", C.c_double), ("use_terrain_adapt", C.c_int32)]
 
 
-EXPORTS = ["a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
+EXPORTS = ["a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
@@ -93,8 +93,10 @@ def load_library(path=None):
     lib.a1mpc_leg_state_batch_device.argtypes = [vp, i32] + [vpp] * 5 + [dp, dp] + [vpp] * 7 + [vpp]; lib.a1mpc_leg_state_batch_device.restype = C.c_int
     lib.a1mpc_ekf_update_batch_device.argtypes = [vp, i32, C.c_double, i32] + [vpp] * 10 + [vpp]; lib.a1mpc_ekf_update_batch_device.restype = C.c_int
     lib.a1mpc_joint_torques_batch_device.argtypes = [vp, i32] + [vpp] * 5 + [dp] + [vpp] * 2 + [vpp]; lib.a1mpc_joint_torques_batch_device.restype = C.c_int
-    lib.a1mpc_solve_batch_strided.argtypes = [vp, i32, dp, dp, dp, dp, i32, u8p, i32, dp, dp, i32p, i32p]; lib.a1mpc_solve_batch_strided.restype = C.c_int
-    lib.a1mpc_solve_batch_strided_device.argtypes = [vp, i32] + [vp] * 4 + [i32, vp, i32] + [vp] * 4 + [vp]; lib.a1mpc_solve_batch_strided_device.restype = C.c_int
+    lib.a1mpc_solve_batch_strided.argtypes = [vp, i32, dp, dp, dp, dp, i32, u8p, i32, dp, dp, dp, i32p, i32p]; lib.a1mpc_solve_batch_strided.restype = C.c_int
+    lib.a1mpc_solve_batch_strided_device.argtypes = [vp, i32] + [vp] * 4 + [i32, vp, i32] + [vp] * 5 + [vp]; lib.a1mpc_solve_batch_strided_device.restype = C.c_int
+    lib.a1mpc_terrain_batch.argtypes = [vp, i32, i32, dp, dp, dp, dp]; lib.a1mpc_terrain_batch.restype = C.c_int
+    lib.a1mpc_form_qp_batch.argtypes = [vp, i32, dp, dp, dp, dp, i32, u8p, i32, dp, dp, dp, dp, dp]; lib.a1mpc_form_qp_batch.restype = C.c_int
     lib.a1mpc_update_config.argtypes = [vp, C.POINTER(Config)]; lib.a1mpc_update_config.restype = C.c_int
     lib.a1mpc_warm_start.argtypes = [vp, i32, dp, dp, dp]; lib.a1mpc_warm_start.restype = C.c_int
     lib.a1mpc_get_warm_start.argtypes = [vp, i32, dp, dp, dp]; lib.a1mpc_get_warm_start.restype = C.c_int
@@ -189,7 +191,7 @@ class Engine:
         return dict(grf=grf, u=u, iters=iters, status=status)
 
     # ---- the general case of the ConvexMpc interface: per-step feet (B_mat_d_list) and / or a per-step contact schedule ----
-    def solve_strided(self, x0, xref, R, foot, foot_stride, contact, contact_stride, want_u=False):
+    def solve_strided(self, x0, xref, R, foot, foot_stride, contact, contact_stride, want_u=False, yaw_A=None):
         h = self.horizon
         x0 = _f64(x0, (-1, NS)); n = x0.shape[0]
         xref = _f64(xref, (n, NS * h)); R = _f64(R, (n, 9)); foot = _f64(foot, (n, 12 * h if foot_stride else 12))
@@ -197,9 +199,28 @@ class Engine:
         grf = np.zeros((n, 12)); u = np.zeros((n, NU * h)) if want_u else None
         iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
         rc = self.lib.a1mpc_solve_batch_strided(self._h, n, _dp(x0), _dp(xref), _dp(R), _dp(foot), int(foot_stride),
-                                                contact.ctypes.data_as(C.POINTER(C.c_uint8)), int(contact_stride), _dp(grf), _dp(u), _ip(iters), _ip(status))
+                                                contact.ctypes.data_as(C.POINTER(C.c_uint8)), int(contact_stride),
+                                                None if yaw_A is None else _dp(np.ascontiguousarray(yaw_A, dtype=np.float64)), _dp(grf), _dp(u), _ip(iters), _ip(status))
         _check(self.lib, rc, "a1mpc_solve_batch_strided")
         return dict(grf=grf, u=u, iters=iters, status=status)
+
+    def form_qp(self, x0, xref, R, foot, contact, foot_stride=0, contact_stride=0, yaw_A=None):
+        """the dense (P, g, l, u) the reference's ConvexMpc members hold, formed on the GPU (debug / verification)"""
+        h = self.horizon
+        x0 = _f64(x0, (-1, NS)); n = x0.shape[0]
+        xref = _f64(xref, (n, NS * h)); R = _f64(R, (n, 9)); foot = _f64(foot, (n, 12 * h if foot_stride else 12))
+        contact = np.ascontiguousarray(contact, dtype=np.uint8).reshape(n, 4 * h if contact_stride else 4)
+        P = np.zeros((n, 12 * h, 12 * h)); g = np.zeros((n, 12 * h)); l = np.zeros((n, 20 * h)); u = np.zeros((n, 20 * h))
+        rc = self.lib.a1mpc_form_qp_batch(self._h, n, _dp(x0), _dp(xref), _dp(R), _dp(foot), int(foot_stride), contact.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                          int(contact_stride), None if yaw_A is None else _dp(np.ascontiguousarray(yaw_A, dtype=np.float64)), _dp(P), _dp(g), _dp(l), _dp(u))
+        _check(self.lib, rc, "a1mpc_form_qp_batch")
+        return dict(P=P, g=g, l=l, u=u)
+
+    def terrain(self, foot_pos_recent_contact, root_pos_z, root_euler_d_pitch, use_terrain_adapt=1):
+        rec = _f64(foot_pos_recent_contact, (-1, 12)); n = rec.shape[0]
+        z = _f64(root_pos_z, (n,)); pd = _f64(root_euler_d_pitch, (n,)).copy(); ta = np.zeros(n)
+        _check(self.lib, self.lib.a1mpc_terrain_batch(self._h, int(use_terrain_adapt), n, _dp(rec), _dp(z), _dp(pd), _dp(ta)), "a1mpc_terrain_batch")
+        return pd, ta
 
     def update_config(self, cfg):
         """replace everything but the horizon (dt, weights, mass / inertia, limits, OSQP settings); the warm start is kept"""

@@ -132,17 +132,21 @@ a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d
  * S/ConvexMpc.cpp:228-245).
  *   foot_stride    0: foot is n x 12, the same feet at every step       12: foot is n x 12H, step t of problem i at foot[(i*H + t)*12]
  *   contact_stride 0: contact is n x 4, broadcast over the horizon       4: contact is n x 4H, step t of problem i at contact[(i*H + t)*4]
- * Everything else as a1mpc_solve_batch.  (0, 0) IS a1mpc_solve_batch (same kernels, same bits).  Any other combination runs the
+ *   yaw_A          NULL: A_c is built from mpc_states[2] (S/A1RobotControl.cpp:452,492)      else n yaws, one per problem
+ *                  (calculate_A_mat_c takes its own euler argument, S/ConvexMpc.h:28; S/test/test_mpc.cpp:94-104 passes an average)
+ * Everything else as a1mpc_solve_batch.  (0, 0, NULL) IS a1mpc_solve_batch (same kernels, same bits).  Any other combination runs the
  * general kernels: same OSQP iterates as the reference's formation with those inputs, with a bigger LDS image per QP (B~_t and the
  * bounds of every step), i.e. fewer QPs in flight -- slower by design.  Horizons 10, 16, 20.
  */
 a1mpc_status a1mpc_solve_batch_strided(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
                                        const double* foot_abs, int32_t foot_stride, const uint8_t* contact, int32_t contact_stride,
-                                       double* grf_body_out, double* u_full_out, int32_t* iters_out, int32_t* status_out);
+                                       const double* yaw_A, double* grf_body_out, double* u_full_out, int32_t* iters_out,
+                                       int32_t* status_out);
 a1mpc_status a1mpc_solve_batch_strided_device(a1mpc_handle h, int32_t n, const double* d_x0, const double* d_x_ref,
                                               const double* d_R_world, const double* d_foot_abs, int32_t foot_stride,
-                                              const uint8_t* d_contact, int32_t contact_stride, double* d_grf_body_out,
-                                              double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out, void* hip_stream);
+                                              const uint8_t* d_contact, int32_t contact_stride, const double* d_yaw_A,
+                                              double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out,
+                                              int32_t* d_status_out, void* hip_stream);
 
 /*
  * N1 (the caller side of the path, S/A1RobotControl.cpp:452-488): the same solve from the COMPACT tick record; x0 (mpc_states)
@@ -231,6 +235,12 @@ a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_con
                                          const double* root_pos_z, double* root_euler_d_pitch, uint8_t* contacts_out,
                                          double* foot_pos_recent_contact_out, double* terrain_angle_out);
 a1mpc_status a1mpc_reset_contact_state(a1mpc_handle h);
+/* The terrain block of compute_grf on its own (S/A1RobotControl.cpp:335-376 with compute_walking_surface :566-582) for callers that keep
+ * the reference's generate_swing_legs_ctrl: foot_pos_recent_contact (n x 12, 3x4 column-major) comes from the caller's A1CtrlStates,
+ * the terrain-angle filter (window 100) of robot i lives in the handle (the same state a1mpc_contact_terrain_batch uses and
+ * a1mpc_reset_contact_state clears).  root_euler_d_pitch n in/out, terrain_angle_out n (= state.terrain_pitch_angle).  Host pointers. */
+a1mpc_status a1mpc_terrain_batch(a1mpc_handle h, int32_t use_terrain_adapt, int32_t n, const double* foot_pos_recent_contact,
+                                 const double* root_pos_z, double* root_euler_d_pitch, double* terrain_angle_out);
 
 /*
  * N4a (caller side): swing-leg targets and the foot PD force -- the first block of generate_swing_legs_ctrl,
@@ -301,6 +311,18 @@ a1mpc_status a1mpc_ekf_update_batch_device(a1mpc_handle h, int32_t n, double dt,
 a1mpc_status a1mpc_joint_torques_batch_device(a1mpc_handle h, int32_t n, const uint8_t* d_active, const uint8_t* d_contacts, const double* d_j_foot_blocks,
                                               const double* d_grf, const double* d_f_kin, const double* km_foot, const double* d_torques_gravity,
                                               double* d_joint_torques, void* hip_stream);
+
+/*
+ * Debug / verification: the dense QP data the reference's ConvexMpc keeps in its public members after calculate_qp_mats
+ * (hessian, gradient, lb, ub: S/ConvexMpc.h:84-93, S/ConvexMpc.cpp:158-245) for n problems, formed on the GPU from the same inputs as
+ * a1mpc_solve_batch_strided.  P_out n x (12H)^2 (row-major, symmetric), g_out n x 12H, l_out / u_out n x 20H (the constraint matrix is
+ * the constant stencil of S/ConvexMpc.cpp:46-58).  The solver itself never forms these; callers that poke the members
+ * (S/A1RobotControl.cpp:527-537, S/test/test_mpc.cpp:136-140) get them through include/a1mpc_dropin.hpp.  Host pointers; allocates
+ * and frees its own device buffers; not a per-tick call.
+ */
+a1mpc_status a1mpc_form_qp_batch(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
+                                 const double* foot_abs, int32_t foot_stride, const uint8_t* contact, int32_t contact_stride,
+                                 const double* yaw_A, double* P_out, double* g_out, double* l_out, double* u_out);
 
 /* Work-queue order of batches larger than the resident set: history = 1 (default) issues the QPs longest-first by the cost
  * (iterations + factor passes) each one had in the previous solve of this handle with the same n -- the same robots tick after

@@ -688,3 +688,48 @@ def test_calls_on_different_streams_are_ordered(pkg, scen):
             eng.solve_device(n, *ins[1], g2, stream=s2.cuda_stream)
             torch.cuda.synchronize()
             assert np.array_equal(g1.cpu().numpy(), ref[0]) and np.array_equal(g2.cpu().numpy(), ref[1]), rep
+
+
+@pytest.mark.parametrize("h", [10, 16, 20])
+def test_gpu_formed_dense_qp_equals_reference_ConvexMpc(pkg, oracle, scen, h):
+    """a1mpc_form_qp_batch (the GPU's implicit Hessian written out entry by entry) vs S/ConvexMpc.cpp compiled verbatim (oracle/_ref), and vs the
+    oracle: P, g, l, u for broadcast and per-step feet / contacts.  This compares the engine's formation with the REFERENCE directly,
+    not through iterates."""
+    import ref as REF
+    if not REF.build():
+        pytest.skip("oracle/_ref not available")
+    rng = np.random.default_rng(h)
+    nb = 6
+    sc, foot, fs, contact, cs = _strided_inputs(scen, rng, h, nb, True, True)
+    p = sc["params"]
+    pr = oracle.mpc_params(h, p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"], p["inertia"])
+    with _engine(pkg, sc, nb, warm_start=0) as eng:
+        bc = eng.form_qp(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+        ps = eng.form_qp(sc["x0"], sc["xref"], sc["R"], foot, sc["contact"], foot_stride=12)
+        pc = eng.form_qp(sc["x0"], sc["xref"], sc["R"], foot, contact, foot_stride=12, contact_stride=4)
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    for b in range(nb):
+        for out, f, fstr in ((bc, sc["foot"][b], 0), (ps, foot[b], 12)):
+            r = REF.convex_mpc_form(h, p["q"], p["r"], sc["x0"][b][:3], p["mass"], p["inertia"], sc["R"][b], f, sc["contact"][b], sc["x0"][b], sc["xref"][b], p["dt"],
+                                    foot_stride=fstr)
+            assert rel(out["P"][b], r["P"]) <= 1e-12 and rel(out["g"][b], r["g"]) <= 1e-10, (b, fstr, rel(out["P"][b], r["P"]), rel(out["g"][b], r["g"]))
+            assert np.array_equal(out["l"][b], r["l"]) and np.array_equal(out["u"][b], r["u"])
+        P, g, A, l, u, _ = oracle.mpc_form(pr, sc["x0"][b], sc["xref"][b], sc["R"][b], foot[b], contact[b], foot_stride=12, contact_stride=4)
+        assert rel(pc["P"][b], P) <= 1e-12 and rel(pc["g"][b], g) <= 1e-10 and np.array_equal(pc["l"][b], l) and np.array_equal(pc["u"][b], u)
+
+
+def test_terrain_block_alone(pkg, oracle, scen):
+    """a1mpc_terrain_batch (the terrain block of compute_grf with the caller's foot_pos_recent_contact) vs the full N2b entry fed the same way."""
+    rng = np.random.default_rng(3)
+    n = 200
+    cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+    base = np.outer([0.2, 0.2, -0.2, -0.2], [1.0, 0.0, 0.3]).reshape(12) + np.outer([1, -1, 1, -1], [0.0, 0.13, 0.0]).reshape(12)
+    pitch_a = np.zeros(n); pitch_b = np.zeros(n)
+    gcs = np.tile([0.0, 0.0, 0.0, 0.0], (n, 1)); plan = np.ones((n, 4), np.uint8)     # all feet in contact: every recent-contact filter updates
+    with pkg.Engine(cfg, n, 0) as full, pkg.Engine(cfg, n, 0) as only:
+        for t in range(130):
+            foot = base + rng.normal(0, 0.03, (n, 12)) + np.tile([0.0, 0.0, -0.3], 4); z = np.where(rng.random(n) < 0.9, 0.3, 0.05); ff = rng.uniform(0, 80, (n, 4))
+            o = full.contact_terrain(gcs, plan, ff, foot, z, pitch_a); pitch_a = o["root_euler_d_pitch"]
+            pitch_b, ta = only.terrain(o["foot_pos_recent_contact"], z, pitch_b)
+            assert np.array_equal(ta, o["terrain_angle"]) and np.array_equal(pitch_b, pitch_a), t
+    assert np.abs(pitch_a).max() > 0.05
