@@ -9,6 +9,8 @@
 //
 // There is no CPU path in this file: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen()ed by a1mpc_sharded_create(transport = 1), never linked
 
 #include <cstdio>
 #include <cstdlib>
@@ -1978,6 +1980,232 @@ a1mpc_status a1mpc_kernel_info(a1mpc_handle h, int32_t* lds_bytes_per_workgroup,
     if (lds_bytes_per_workgroup) *lds_bytes_per_workgroup = static_cast<int32_t>(lds_bytes_of(h->cfg.horizon));
     if (qps_per_workgroup) *qps_per_workgroup = rows_per_wg();
     if (threads_per_workgroup) *threads_per_workgroup = 16 * rows_per_wg();
+    return A1MPC_OK;
+}
+
+// ======================================================================================================================
+// Batch sharding across the GPUs of one node inside the C ABI (SURVEY 8b "device = -1 = all", 8e): one host thread, one handle and one
+// stream per device, the batch cut into contiguous shards (sizes differ by at most one, remainder to the low shards -- the QPs are
+// independent, there is no data-path collective).  Two transports for scatter-inputs / gather-GRFs:
+//   0  pinned host memory, one hipMemcpyAsync fan-out per device each way (no root hop; every GPU is fed over its own PCIe link)
+//   1  RCCL over xGMI: the whole batch goes to shard 0's GPU in one copy, grouped ncclSend / ncclRecv move the other shards' inputs
+//      out and their results back (the north_star's named path); librccl.so is dlopen()ed on first use
+// The same device may be listed twice (two shards on one GPU: how the single-GPU test box exercises transport 0).
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool load() {
+        if (lib) return true;
+        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return false;
+#define A1_SYM(n) n = reinterpret_cast<decltype(n)>(dlsym(lib, "nccl" #n))
+        A1_SYM(CommInitAll); A1_SYM(CommDestroy); A1_SYM(GroupStart); A1_SYM(GroupEnd); A1_SYM(Send); A1_SYM(Recv); A1_SYM(GetErrorString);
+#undef A1_SYM
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+    }
+};
+static RcclApi g_rccl;
+
+struct a1mpc_sharded_s {
+    int ndev = 0, transport = 0, max_batch = 0, horizon = 0;
+    std::vector<int> dev;
+    std::vector<a1mpc_handle> h;            // one engine handle per shard (its own stream, staging, warm start)
+    char* pin = nullptr;                    // pinned mirror of inputs + outputs (transport 0; transport 1 uses it for the two big copies)
+    size_t pin_bytes = 0;
+    // transport 1: the whole batch on shard 0's device + communicators
+    double *r_x0 = nullptr, *r_xref = nullptr, *r_R = nullptr, *r_foot = nullptr, *r_grf = nullptr;
+    uint8_t* r_contact = nullptr;
+    int32_t *r_iters = nullptr, *r_status = nullptr;
+    std::vector<ncclComm_t> comm;
+    std::vector<hipEvent_t> ev;             // per shard: "my part of this call is finished"
+};
+static void shard_range(int n, int g, int G, int* start, int* count) {
+    const int base = n / G, rem = n % G;
+    *count = base + (g < rem ? 1 : 0);
+    *start = g * base + (g < rem ? g : rem);
+}
+
+void a1mpc_sharded_destroy(a1mpc_sharded S) {
+    if (!S) return;
+    for (size_t g = 0; g < S->comm.size(); ++g) if (S->comm[g] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(S->comm[g]);
+    if (!S->dev.empty()) (void)hipSetDevice(S->dev[0]);
+    void* ptrs[] = {S->r_x0, S->r_xref, S->r_R, S->r_foot, S->r_grf, S->r_contact, S->r_iters, S->r_status};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (size_t g = 0; g < S->ev.size(); ++g) if (S->ev[g]) { (void)hipSetDevice(S->dev[g]); (void)hipEventDestroy(S->ev[g]); }
+    for (a1mpc_handle h : S->h) a1mpc_destroy(h);
+    if (S->pin) (void)hipHostFree(S->pin);
+    delete S;
+}
+
+a1mpc_status a1mpc_sharded_create(const a1mpc_config* cfg, int32_t max_batch, const int32_t* devices, int32_t n_devices, int32_t transport,
+                                  a1mpc_sharded* out) {
+    if (!cfg || !out || max_batch <= 0 || (transport != 0 && transport != 1)) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null config/out, bad batch or transport");
+    *out = nullptr;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return fail(A1MPC_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
+    a1mpc_sharded S = new (std::nothrow) a1mpc_sharded_s();
+    if (!S) return fail(A1MPC_ERR_HIP, "out of host memory");
+    if (n_devices <= 0 || !devices) { for (int d = 0; d < visible; ++d) S->dev.push_back(d); }   // -1 = all visible devices
+    else for (int g = 0; g < n_devices; ++g) {
+        if (devices[g] < 0 || devices[g] >= visible) { delete S; return fail(A1MPC_ERR_NO_DEVICE, "device ordinal out of range"); }
+        S->dev.push_back(devices[g]);
+    }
+    S->ndev = static_cast<int>(S->dev.size()); S->transport = transport; S->max_batch = max_batch; S->horizon = cfg->horizon;
+    const int per = (max_batch + S->ndev - 1) / S->ndev;
+    const size_t N = max_batch, H = cfg->horizon;
+    for (int g = 0; g < S->ndev; ++g) {
+        a1mpc_handle hg = nullptr;
+        const a1mpc_status st = a1mpc_create(cfg, per, S->dev[g], &hg);
+        if (st != A1MPC_OK) { a1mpc_sharded_destroy(S); return st; }
+        S->h.push_back(hg);
+        hipEvent_t e = nullptr;
+        if (hipSetDevice(S->dev[g]) != hipSuccess || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { a1mpc_sharded_destroy(S); return fail(A1MPC_ERR_HIP, "hipEventCreate"); }
+        S->ev.push_back(e);
+    }
+    S->pin_bytes = N * ((13 + 13 * H + 9 + 12 + 12) * sizeof(double) + 4 + 2 * sizeof(int32_t));
+    if (hipHostMalloc(reinterpret_cast<void**>(&S->pin), S->pin_bytes, hipHostMallocPortable) != hipSuccess) { a1mpc_sharded_destroy(S); return fail(A1MPC_ERR_HIP, "hipHostMalloc"); }
+    if (transport == 1) {
+        for (int a = 0; a < S->ndev; ++a) for (int b = a + 1; b < S->ndev; ++b)
+            if (S->dev[a] == S->dev[b]) { a1mpc_sharded_destroy(S); return fail(A1MPC_ERR_INVALID_ARGUMENT, "RCCL transport needs distinct devices"); }
+        if (!g_rccl.load()) { a1mpc_sharded_destroy(S); return fail(A1MPC_ERR_HIP, std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "missing symbols")); }
+        S->comm.assign(S->ndev, nullptr);
+        const ncclResult_t rc = g_rccl.CommInitAll(S->comm.data(), S->ndev, S->dev.data());
+        if (rc != ncclSuccess) { S->comm.clear(); a1mpc_sharded_destroy(S); return fail(A1MPC_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(rc)); }
+        bool ok = hipSetDevice(S->dev[0]) == hipSuccess;
+        ok = ok && hipMalloc(&S->r_x0, N * 13 * sizeof(double)) == hipSuccess && hipMalloc(&S->r_xref, N * 13 * H * sizeof(double)) == hipSuccess;
+        ok = ok && hipMalloc(&S->r_R, N * 9 * sizeof(double)) == hipSuccess && hipMalloc(&S->r_foot, N * 12 * sizeof(double)) == hipSuccess;
+        ok = ok && hipMalloc(&S->r_contact, N * 4) == hipSuccess && hipMalloc(&S->r_grf, N * 12 * sizeof(double)) == hipSuccess;
+        ok = ok && hipMalloc(&S->r_iters, N * sizeof(int32_t)) == hipSuccess && hipMalloc(&S->r_status, N * sizeof(int32_t)) == hipSuccess;
+        if (!ok) { a1mpc_sharded_destroy(S); return fail(A1MPC_ERR_HIP, "hipMalloc (root staging of the RCCL transport)"); }
+    }
+    *out = S;
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_sharded_info(a1mpc_sharded S, int32_t* n_shards, int32_t* devices_out, int32_t* transport) {
+    if (!S) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n_shards) *n_shards = S->ndev;
+    if (devices_out) for (int g = 0; g < S->ndev; ++g) devices_out[g] = S->dev[g];
+    if (transport) *transport = S->transport;
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double* x0, const double* x_ref, const double* R_world, const double* foot_abs,
+                                       const uint8_t* contact, double* grf_body_out, int32_t* iters_out, int32_t* status_out) {
+    if (!S) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !grf_body_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > S->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_sharded_create");
+    if (n == 0) return A1MPC_OK;
+    const size_t N = n, H = S->horizon, G = S->ndev;
+    // pinned snapshot (the caller's program mutates its arrays concurrently, see a1mpc.h), field after field like the device layout
+    char* p = S->pin;
+    double* p_x0 = reinterpret_cast<double*>(p); p += N * 13 * sizeof(double);
+    double* p_xr = reinterpret_cast<double*>(p); p += N * 13 * H * sizeof(double);
+    double* p_R = reinterpret_cast<double*>(p); p += N * 9 * sizeof(double);
+    double* p_f = reinterpret_cast<double*>(p); p += N * 12 * sizeof(double);
+    double* p_grf = reinterpret_cast<double*>(p); p += N * 12 * sizeof(double);
+    int32_t* p_it = reinterpret_cast<int32_t*>(p); p += N * sizeof(int32_t);
+    int32_t* p_st = reinterpret_cast<int32_t*>(p); p += N * sizeof(int32_t);
+    uint8_t* p_c = reinterpret_cast<uint8_t*>(p);
+    std::memcpy(p_x0, x0, N * 13 * sizeof(double)); std::memcpy(p_xr, x_ref, N * 13 * H * sizeof(double)); std::memcpy(p_R, R_world, N * 9 * sizeof(double));
+    std::memcpy(p_f, foot_abs, N * 12 * sizeof(double)); std::memcpy(p_c, contact, N * 4);
+    if (S->transport == 0) {
+        for (size_t g = 0; g < G; ++g) {   // everything asynchronous: the G devices copy and solve concurrently
+            int s0 = 0, c = 0;
+            shard_range(n, static_cast<int>(g), static_cast<int>(G), &s0, &c);
+            if (c == 0) continue;
+            a1mpc_handle h = S->h[g];
+            A1_HIP(hipSetDevice(h->device));
+            hipStream_t st = h->stream;
+            A1_ORDER(h, st);
+            const size_t o = s0, C = c;
+            A1_HIP(hipMemcpyAsync(h->d_x0, p_x0 + o * 13, C * 13 * sizeof(double), hipMemcpyHostToDevice, st));
+            A1_HIP(hipMemcpyAsync(h->d_xref, p_xr + o * 13 * H, C * 13 * H * sizeof(double), hipMemcpyHostToDevice, st));
+            A1_HIP(hipMemcpyAsync(h->d_R, p_R + o * 9, C * 9 * sizeof(double), hipMemcpyHostToDevice, st));
+            A1_HIP(hipMemcpyAsync(h->d_foot, p_f + o * 12, C * 12 * sizeof(double), hipMemcpyHostToDevice, st));
+            A1_HIP(hipMemcpyAsync(h->d_contact, p_c + o * 4, C * 4, hipMemcpyHostToDevice, st));
+            if (a1mpc_status rc = solve_device_impl(h, c, nullptr, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_contact, h->d_grf, nullptr, h->d_iters, h->d_status, st); rc != A1MPC_OK) return rc;
+            A1_HIP(hipMemcpyAsync(p_grf + o * 12, h->d_grf, C * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+            A1_HIP(hipMemcpyAsync(p_it + o, h->d_iters, C * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            A1_HIP(hipMemcpyAsync(p_st + o, h->d_status, C * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        }
+        for (size_t g = 0; g < G; ++g) { A1_HIP(hipSetDevice(S->h[g]->device)); A1_HIP(hipStreamSynchronize(S->h[g]->stream)); }
+    } else {
+#define A1_NCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); } while (0)
+        a1mpc_handle h0 = S->h[0];
+        A1_HIP(hipSetDevice(h0->device));
+        hipStream_t s0 = h0->stream;
+        A1_ORDER(h0, s0);
+        A1_HIP(hipMemcpyAsync(S->r_x0, p_x0, N * 13 * sizeof(double), hipMemcpyHostToDevice, s0));
+        A1_HIP(hipMemcpyAsync(S->r_xref, p_xr, N * 13 * H * sizeof(double), hipMemcpyHostToDevice, s0));
+        A1_HIP(hipMemcpyAsync(S->r_R, p_R, N * 9 * sizeof(double), hipMemcpyHostToDevice, s0));
+        A1_HIP(hipMemcpyAsync(S->r_foot, p_f, N * 12 * sizeof(double), hipMemcpyHostToDevice, s0));
+        A1_HIP(hipMemcpyAsync(S->r_contact, p_c, N * 4, hipMemcpyHostToDevice, s0));
+        // scatter: shard g > 0 receives its slice of every field from shard 0's device (root drives all its xGMI links concurrently)
+        A1_NCCL(g_rccl.GroupStart());
+        for (size_t g = 1; g < G; ++g) {
+            int st0 = 0, c = 0;
+            shard_range(n, static_cast<int>(g), static_cast<int>(G), &st0, &c);
+            if (c == 0) continue;
+            a1mpc_handle h = S->h[g];
+            const size_t o = st0, C = c;
+            A1_NCCL(g_rccl.Send(S->r_x0 + o * 13, C * 13, ncclFloat64, static_cast<int>(g), S->comm[0], s0));
+            A1_NCCL(g_rccl.Send(S->r_xref + o * 13 * H, C * 13 * H, ncclFloat64, static_cast<int>(g), S->comm[0], s0));
+            A1_NCCL(g_rccl.Send(S->r_R + o * 9, C * 9, ncclFloat64, static_cast<int>(g), S->comm[0], s0));
+            A1_NCCL(g_rccl.Send(S->r_foot + o * 12, C * 12, ncclFloat64, static_cast<int>(g), S->comm[0], s0));
+            A1_NCCL(g_rccl.Send(S->r_contact + o * 4, C * 4, ncclUint8, static_cast<int>(g), S->comm[0], s0));
+            A1_NCCL(g_rccl.Recv(h->d_x0, C * 13, ncclFloat64, 0, S->comm[g], h->stream));
+            A1_NCCL(g_rccl.Recv(h->d_xref, C * 13 * H, ncclFloat64, 0, S->comm[g], h->stream));
+            A1_NCCL(g_rccl.Recv(h->d_R, C * 9, ncclFloat64, 0, S->comm[g], h->stream));
+            A1_NCCL(g_rccl.Recv(h->d_foot, C * 12, ncclFloat64, 0, S->comm[g], h->stream));
+            A1_NCCL(g_rccl.Recv(h->d_contact, C * 4, ncclUint8, 0, S->comm[g], h->stream));
+        }
+        A1_NCCL(g_rccl.GroupEnd());
+        // every shard solves on its own stream (stream order: after its receives); shard 0 works in place on the root buffers
+        for (size_t g = 0; g < G; ++g) {
+            int st0 = 0, c = 0;
+            shard_range(n, static_cast<int>(g), static_cast<int>(G), &st0, &c);
+            if (c == 0) continue;
+            a1mpc_handle h = S->h[g];
+            A1_HIP(hipSetDevice(h->device));
+            a1mpc_status rc;
+            if (g == 0) rc = solve_device_impl(h, c, nullptr, S->r_x0, S->r_xref, S->r_R, S->r_foot, S->r_contact, S->r_grf, nullptr, S->r_iters, S->r_status, h->stream);
+            else rc = solve_device_impl(h, c, nullptr, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_contact, h->d_grf, nullptr, h->d_iters, h->d_status, h->stream);
+            if (rc != A1MPC_OK) return rc;
+        }
+        // gather: results of shard g > 0 back to their slice of the root buffers
+        A1_NCCL(g_rccl.GroupStart());
+        for (size_t g = 1; g < G; ++g) {
+            int st0 = 0, c = 0;
+            shard_range(n, static_cast<int>(g), static_cast<int>(G), &st0, &c);
+            if (c == 0) continue;
+            a1mpc_handle h = S->h[g];
+            const size_t o = st0, C = c;
+            A1_NCCL(g_rccl.Send(h->d_grf, C * 12, ncclFloat64, 0, S->comm[g], h->stream));
+            A1_NCCL(g_rccl.Send(h->d_iters, C, ncclInt32, 0, S->comm[g], h->stream));
+            A1_NCCL(g_rccl.Send(h->d_status, C, ncclInt32, 0, S->comm[g], h->stream));
+            A1_NCCL(g_rccl.Recv(S->r_grf + o * 12, C * 12, ncclFloat64, static_cast<int>(g), S->comm[0], s0));
+            A1_NCCL(g_rccl.Recv(S->r_iters + o, C, ncclInt32, static_cast<int>(g), S->comm[0], s0));
+            A1_NCCL(g_rccl.Recv(S->r_status + o, C, ncclInt32, static_cast<int>(g), S->comm[0], s0));
+        }
+        A1_NCCL(g_rccl.GroupEnd());
+        A1_HIP(hipSetDevice(h0->device));
+        A1_HIP(hipMemcpyAsync(p_grf, S->r_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s0));
+        A1_HIP(hipMemcpyAsync(p_it, S->r_iters, N * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
+        A1_HIP(hipMemcpyAsync(p_st, S->r_status, N * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
+        for (size_t g = 0; g < G; ++g) { A1_HIP(hipSetDevice(S->h[g]->device)); A1_HIP(hipStreamSynchronize(S->h[g]->stream)); }
+#undef A1_NCCL
+    }
+    std::memcpy(grf_body_out, p_grf, N * 12 * sizeof(double));
+    if (iters_out) std::memcpy(iters_out, p_it, N * sizeof(int32_t));
+    if (status_out) std::memcpy(status_out, p_st, N * sizeof(int32_t));
     return A1MPC_OK;
 }
 

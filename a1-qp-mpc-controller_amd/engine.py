@@ -40,7 +40,7 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
     _fields_ = [("counter_per_swing", C.c_double), ("foot_force_low", C.c_double), ("use_terrain_adapt", C.c_int32)]
 
 
-EXPORTS = ["a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
+EXPORTS = ["a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
@@ -95,6 +95,10 @@ def load_library(path=None):
     lib.a1mpc_joint_torques_batch_device.argtypes = [vp, i32] + [vpp] * 5 + [dp] + [vpp] * 2 + [vpp]; lib.a1mpc_joint_torques_batch_device.restype = C.c_int
     lib.a1mpc_solve_batch_strided.argtypes = [vp, i32, dp, dp, dp, dp, i32, u8p, i32, dp, dp, dp, i32p, i32p]; lib.a1mpc_solve_batch_strided.restype = C.c_int
     lib.a1mpc_solve_batch_strided_device.argtypes = [vp, i32] + [vp] * 4 + [i32, vp, i32] + [vp] * 5 + [vp]; lib.a1mpc_solve_batch_strided_device.restype = C.c_int
+    lib.a1mpc_sharded_create.argtypes = [C.POINTER(Config), i32, i32p, i32, i32, C.POINTER(vp)]; lib.a1mpc_sharded_create.restype = C.c_int
+    lib.a1mpc_sharded_solve_batch.argtypes = [vp, i32, dp, dp, dp, dp, u8p, dp, i32p, i32p]; lib.a1mpc_sharded_solve_batch.restype = C.c_int
+    lib.a1mpc_sharded_info.argtypes = [vp, i32p, i32p, i32p]; lib.a1mpc_sharded_info.restype = C.c_int
+    lib.a1mpc_sharded_destroy.argtypes = [vp]; lib.a1mpc_sharded_destroy.restype = None
     lib.a1mpc_terrain_batch.argtypes = [vp, i32, i32, dp, dp, dp, dp]; lib.a1mpc_terrain_batch.restype = C.c_int
     lib.a1mpc_form_qp_batch.argtypes = [vp, i32, dp, dp, dp, dp, i32, u8p, i32, dp, dp, dp, dp, dp]; lib.a1mpc_form_qp_batch.restype = C.c_int
     lib.a1mpc_update_config.argtypes = [vp, C.POINTER(Config)]; lib.a1mpc_update_config.restype = C.c_int
@@ -378,6 +382,45 @@ class Engine:
 
 
 # ---- work model used for roofline.achieved (DESIGN.md "Measurement") --------------
+class ShardedEngine:
+    """a1mpc_sharded_*: one handle, the batch cut into contiguous shards over `devices` (None = all visible), transport 0 = pinned copies, 1 = RCCL"""
+
+    def __init__(self, cfg, max_batch, devices=None, transport=0):
+        self.lib = load_library(); self.horizon = int(cfg.horizon); self._h = C.c_void_p()
+        dv = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        _check(self.lib, self.lib.a1mpc_sharded_create(C.byref(cfg), int(max_batch), _ip(dv), 0 if dv is None else len(dv), int(transport), C.byref(self._h)), "a1mpc_sharded_create")
+
+    def info(self):
+        n = C.c_int32(); t = C.c_int32(); d = np.zeros(64, np.int32)
+        _check(self.lib, self.lib.a1mpc_sharded_info(self._h, C.byref(n), _ip(d), C.byref(t)), "a1mpc_sharded_info")
+        return dict(n_shards=n.value, devices=d[:n.value].tolist(), transport=t.value)
+
+    def solve(self, x0, xref, R, foot, contact):
+        h = self.horizon
+        x0 = _f64(x0, (-1, NS)); n = x0.shape[0]
+        xref = _f64(xref, (n, NS * h)); R = _f64(R, (n, 9)); foot = _f64(foot, (n, 12)); contact = np.ascontiguousarray(contact, dtype=np.uint8).reshape(n, 4)
+        grf = np.zeros((n, 12)); iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
+        rc = self.lib.a1mpc_sharded_solve_batch(self._h, n, _dp(x0), _dp(xref), _dp(R), _dp(foot), contact.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(grf), _ip(iters), _ip(status))
+        _check(self.lib, rc, "a1mpc_sharded_solve_batch")
+        return dict(grf=grf, iters=iters, status=status)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.a1mpc_sharded_destroy(self._h); self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def algorithmic_flops(h, iters, nfact):
     """F(h, iters, nfact) of the structured dense-condensed algorithm, per solve (numpy-broadcastable)."""
     iters = np.asarray(iters, dtype=np.float64); nfact = np.asarray(nfact, dtype=np.float64)

@@ -53,7 +53,18 @@ def cpu_baseline(pkg, sc, budget_s=15.0):
 
 
 def latency_probe(pkg, nticks=1500):
-    """BASELINE configs[1]: batch 1, trot, warm-started sequential ticks through the host-pointer ABI (PCIe inclusive)."""
+    """BASELINE configs[1]: batch 1, trot, warm-started sequential ticks through the host-pointer ABI (PCIe inclusive).  10 000 ticks from the
+    C++ harness (tests/cpp/latency_harness, no Python in the loop) when it has been built; the Python loop below otherwise."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "latency_harness")
+    if os.path.exists(exe):
+        try:
+            env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("LOCAL_RANK", "0")) if os.environ.get("LOCAL_RANK") else None
+            r = subprocess.run([exe, "10000"], capture_output=True, text=True, timeout=120, env=env)
+            if r.returncode == 0:
+                return json.loads(r.stdout)
+        except Exception:
+            pass
     sc = pkg.scenarios.config2_trot_sequence(nticks)
     cfg = pkg.make_config(sc["params"], sc["horizon"], warm_start=1)
     import gc
@@ -209,12 +220,87 @@ def other_config_rooflines(pkg, local, steps=4):
     return res
 
 
+def strong_scaling_config4(pkg, args, rank, world, local, backend, dist):
+    """BASELINE configs[3]: 65536 QPs, horizon 16, the whole batch resident in rank 0's HBM; a step = scatter the shards' inputs (one group of
+    ncclSend / ncclRecv over xGMI), solve, gather GRFs + iterations + status back to rank 0 -- all inside the timed region.  Strong scaling."""
+    import torch
+    H = 16
+    N = args.batch if args.batch != BATCH else 65536
+    dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")      # gloo smoke test: communication through host tensors
+    sh = pkg.sharding
+    sc = pkg.scenarios.config4_random_h16(nb=N) if rank == 0 else None
+    params = (pkg.scenarios.PARAM_SETS["gazebo"] | pkg.scenarios.MPC_CONSTANTS)
+    cfg = pkg.make_config(params, H, warm_start=0)
+    rec, ct = sh.pack_inputs(sc, H, cdev) if rank == 0 else (None, None)
+    parts = sh.partition(N, world); cnt = parts[rank][1]
+    eng = pkg.Engine(cfg, max(cnt, 1), local)
+    stream = torch.cuda.Stream(device=dev)
+    grf = torch.zeros((cnt, 12), dtype=torch.float64, device=dev); meta = torch.zeros((cnt, 2), dtype=torch.int32, device=dev)
+    it = torch.zeros(cnt, dtype=torch.int32, device=dev); stt = torch.zeros(cnt, dtype=torch.int32, device=dev)
+    out_bufs = (torch.empty((N, 12), dtype=torch.float64, device=cdev), torch.empty((N, 2), dtype=torch.int32, device=cdev)) if rank == 0 else None
+    t_comm = [0.0]
+
+    def step():
+        a = time.perf_counter()
+        lrec, lct = sh.scatter(rec, ct, N, H, cdev, None, 0) if world > 1 else (rec, ct)
+        if cdev != dev:
+            lrec = lrec.to(dev); lct = lct.to(dev)
+        torch.cuda.synchronize(); b = time.perf_counter()
+        f = sh.unpack_record(lrec, H)
+        torch.cuda.current_stream().synchronize()
+        eng.set_schedule(True)
+        eng.solve_device(cnt, f["x0"], f["xref"], f["R"], f["foot"], lct.contiguous(), grf, None, it, stt, stream=stream.cuda_stream)
+        stream.synchronize()
+        meta[:, 0] = it; meta[:, 1] = stt
+        torch.cuda.synchronize(); c = time.perf_counter()
+        if world > 1:
+            sh.gather(grf.to(cdev), meta.to(cdev), N, cdev, None, 0, out_bufs)
+        else:
+            out_bufs[0].copy_(grf); out_bufs[1].copy_(meta)
+        torch.cuda.synchronize(); d = time.perf_counter()
+        t_comm[0] += (b - a) + (d - c)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t_comm[0] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res = None
+    if rank == 0:
+        iters = out_bufs[1][:, 0].cpu().numpy(); status = out_bufs[1][:, 1].cpu().numpy()
+        res = {"metric": "MPC QP solves/sec (horizon=16 SRBD), BASELINE configs[3]", "value": N * args.steps / elapsed, "unit": "solves/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[3]: batch=65536 randomized CoM states, horizon=16, the batch resident on rank 0, sharded contiguously over the "
+                                      "GPUs; scatter inputs + solve (cold start, first solve) + gather GRFs per step", "global_batch": N, "horizon": H,
+                          "parallelism": f"batch-sharded x{world}, {backend} grouped send/recv", "mean_iters": float(iters.mean()), "solved_frac": float((status == 1).mean())},
+               "scatter_gather_ms_per_step_rank0": t_comm[0] / args.steps * 1e3,
+               "scatter_bytes_per_step": int(N - parts[0][1]) * (sh.record_width(H) * 8 + 4), "gather_bytes_per_step": int(N - parts[0][1]) * (12 * 8 + 8)}
+    eng.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="QPs per GPU per step")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4), help="2 (default): BASELINE configs[2], 4096 x h10 per GPU, weak scaling (the `metric`); "
+                    "4: BASELINE configs[3], 65536 x h16 in total, sharded over the GPUs with scatter + gather inside the timed region (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-index-order", action="store_true", help="skip the extra index-order steps (profiling runs)")
@@ -244,6 +330,14 @@ def main():
         if world > 1:
             dist.barrier()
         pkg.load_library()
+
+    if args.config == 4:
+        out = strong_scaling_config4(pkg, args, rank, world, local, backend, dist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
 
     n = args.batch
     # NB distinct batches, resident in HBM, cycled through the steps: no step re-solves the inputs of the step before it, and every step
@@ -350,6 +444,27 @@ def main():
             "history_ms_per_step": hist_ms, "history_solves_per_s_per_gpu": (n / (hist_ms * 1e-3)) if hist_ms else None}
         if not args.no_latency:
             out["roofline_other_configs"] = other_config_rooflines(pkg, local)
+    if world > 1 and backend == "nccl":
+        # Extra information (not `value`, which needs no collective): what scattering this step's inputs from rank 0 and gathering the results
+        # back over RCCL / xGMI would cost -- the north_star's "scatter inputs / gather GRFs" -- one grouped send/recv each way.
+        sh = pkg.sharding
+        NT = n * world
+        rec = torch.zeros((NT if rank == 0 else 0, sh.record_width(HORIZON)), dtype=torch.float64, device=dev)
+        ctt = torch.zeros((NT if rank == 0 else 0, 4), dtype=torch.uint8, device=dev)
+        mg = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+        for _ in range(2):
+            sh.scatter(rec, ctt, NT, HORIZON, dev); sh.gather(grf, mg, NT, dev)
+        torch.cuda.synchronize(); dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            sh.scatter(rec, ctt, NT, HORIZON, dev); sh.gather(grf, mg, NT, dev)
+        torch.cuda.synchronize(); dist.barrier()
+        sg_ms = (time.perf_counter() - t1) / 10 * 1e3
+        if rank == 0:
+            out["scatter_gather"] = {"ms_per_step": sg_ms, "bytes_out_of_rank0": int(n * (world - 1) * (sh.record_width(HORIZON) * 8 + 4)),
+                                     "bytes_into_rank0": int(n * (world - 1) * (12 * 8 + 8)), "transport": "torch.distributed nccl (RCCL) batch_isend_irecv",
+                                     "note": "not part of `value`: ranks generate their own inputs in the weak-scaling metric; --config 4 puts scatter + gather inside the timed region"}
+    if rank == 0:
         if not args.no_latency:
             out["latency"] = latency_probe(pkg)
             out["throughput_by_batch"] = batch_sweep(pkg, local)

@@ -358,6 +358,26 @@ a1mpc_status a1mpc_kernel_info(a1mpc_handle h, int32_t* lds_bytes_per_workgroup,
  * synchronises the handle's stream; instrumentation for the work model of bench.py */
 a1mpc_status a1mpc_last_nfact(a1mpc_handle h, int32_t n, int32_t* nfact_out);
 
+/*
+ * The batch sharded over the GPUs of one node behind ONE handle and one host thread (SURVEY 8b "device = -1 = all", 8e): shard g solves a
+ * contiguous slice (sizes differ by at most one, remainder to the low shards) on devices[g] with its own engine handle and stream; the QPs
+ * are independent, so there is no data-path collective -- only scatter-inputs / gather-results, by one of two transports:
+ *   transport 0  pinned host memory, one asynchronous copy fan-out per device each way (every GPU over its own PCIe link)
+ *   transport 1  RCCL over xGMI: one copy of the whole batch to devices[0], grouped ncclSend / ncclRecv to the other devices and back
+ *                (librccl.so is dlopen()ed by this call; distinct devices required)
+ * devices NULL or n_devices <= 0 = every visible device.  A device may be listed twice with transport 0 (two shards on one GPU).
+ * max_batch is the TOTAL batch.  Warm start, if configured, is carried per shard, i.e. per position in the batch as long as n stays the same.
+ * Host pointers; layouts as a1mpc_solve_batch.
+ */
+typedef struct a1mpc_sharded_s* a1mpc_sharded;
+a1mpc_status a1mpc_sharded_create(const a1mpc_config* cfg, int32_t max_batch, const int32_t* devices, int32_t n_devices, int32_t transport,
+                                  a1mpc_sharded* out);
+a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded s, int32_t n, const double* x0, const double* x_ref, const double* R_world,
+                                       const double* foot_abs, const uint8_t* contact, double* grf_body_out, int32_t* iters_out,
+                                       int32_t* status_out);
+a1mpc_status a1mpc_sharded_info(a1mpc_sharded s, int32_t* n_shards, int32_t* devices_out, int32_t* transport);
+void a1mpc_sharded_destroy(a1mpc_sharded s);
+
 const char* a1mpc_status_string(a1mpc_status s);
 const char* a1mpc_last_error(void); /* thread-local detail of the last non-OK return (e.g. the HIP error string) */
 

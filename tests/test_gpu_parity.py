@@ -733,3 +733,27 @@ def test_terrain_block_alone(pkg, oracle, scen):
             pitch_b, ta = only.terrain(o["foot_pos_recent_contact"], z, pitch_b)
             assert np.array_equal(ta, o["terrain_angle"]) and np.array_equal(pitch_b, pitch_a), t
     assert np.abs(pitch_a).max() > 0.05
+
+
+def test_native_sharded_handle_two_shards_on_one_gpu(pkg, scen):
+    """a1mpc_sharded_* (SURVEY 8b device = -1, 8e): the batch cut into contiguous shards behind one handle.  The test box has one GPU, so the
+    pinned-copy transport runs two (three) shards on device 0 -- results must equal the single-handle solve bit for bit, ragged sizes included;
+    the RCCL transport is created on the one device (communicator set-up, root staging; no peer to talk to)."""
+    sc = scen.config3_random_flat(nb=4097)
+    cfg = pkg.make_config(sc["params"], 10, warm_start=0)
+    with pkg.Engine(cfg, 4097, 0) as eng:
+        ref = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+    for devs in ([0, 0], [0, 0, 0]):
+        with pkg.ShardedEngine(cfg, 4097, devices=devs, transport=0) as sh:
+            assert sh.info()["n_shards"] == len(devs)
+            for n in (4097, 5, 1):
+                out = sh.solve(sc["x0"][:n], sc["xref"][:n], sc["R"][:n], sc["foot"][:n], sc["contact"][:n])
+                assert np.array_equal(out["grf"], ref["grf"][:n]) and np.array_equal(out["iters"], ref["iters"][:n]) and np.array_equal(out["status"], ref["status"][:n]), (devs, n)
+    with pkg.ShardedEngine(cfg, 512, devices=None, transport=0) as sh:   # "all visible devices"
+        out = sh.solve(sc["x0"][:512], sc["xref"][:512], sc["R"][:512], sc["foot"][:512], sc["contact"][:512])
+        assert np.array_equal(out["grf"], ref["grf"][:512])
+    with pkg.ShardedEngine(cfg, 512, devices=[0], transport=1) as sh:    # RCCL transport, one rank
+        out = sh.solve(sc["x0"][:512], sc["xref"][:512], sc["R"][:512], sc["foot"][:512], sc["contact"][:512])
+        assert np.array_equal(out["grf"], ref["grf"][:512]) and sh.info()["transport"] == 1
+    with pytest.raises(pkg.A1MpcError):
+        pkg.ShardedEngine(cfg, 512, devices=[0, 0], transport=1)       # RCCL needs distinct devices
