@@ -47,6 +47,8 @@ def build(force=False, verbose=False):
         if not listings:
             raise RuntimeError("hipcc -save-temps left no gfx950 listing to check")
         bad = [h for l in listings for h in isa_check.dpp_hazards(l)]
+        if os.environ.get("A1MPC_SLIM") is None:
+            bad += isa_check.coverage_gaps(listings)   # the check must have seen the kernels it exists for (no fail-open)
     if bad:
         os.remove(LIB_PATH)
         raise RuntimeError("DPP read hazards in the generated code (library removed):\n" + "\n".join(bad[:20]))

@@ -338,7 +338,7 @@ static a1mpc_status resident_rows(int* out) {
 }
 
 template <int H, int ROWS>
-static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* counter, hipStream_t stream) {
+static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* counter, hipStream_t stream, hipEvent_t mid) {
     const size_t lds2 = lds_bytes<H>(ROWS), lds1 = sizeof(double) * (4 * LayoutSetup<H>::ROW_STRIDE + 2 * H * H);
     int res = 0;
     if (a1mpc_status st = resident_workgroups<H, ROWS>(&res); st != A1MPC_OK) return st;
@@ -350,6 +350,7 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
                            const_cast<int32_t*>(a.order));
         A1_HIP(hipGetLastError());
     }
+    if (mid) A1_HIP(hipEventRecord(mid, stream));  // stage split: formation + Ruiz (+ queue order) | factor + iterate
     const int want = (a.n + ROWS - 1) / ROWS;
     hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), dim3(static_cast<unsigned>(want < res ? want : res)), dim3(16 * ROWS), lds2, stream, a,
                        static_cast<const double*>(prep), counter);
@@ -357,15 +358,15 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     return A1MPC_OK;
 }
 template <int H>
-static a1mpc_status launch_split(const KernelArgs& a, double* prep, int* counter, hipStream_t stream) {
+static a1mpc_status launch_split(const KernelArgs& a, double* prep, int* counter, hipStream_t stream, hipEvent_t mid) {
 #ifdef A1MPC_DEV_SLIM  // kernel-tuning builds: one instantiation (H = 10, two rows), seconds instead of minutes to compile
-    return launch_split_rows<H, 2>(a, prep, counter, stream);
+    return launch_split_rows<H, 2>(a, prep, counter, stream, mid);
 #else
     switch (rows_per_wg()) {
-        case 1: return launch_split_rows<H, 1>(a, prep, counter, stream);
-        case 2: return launch_split_rows<H, 2>(a, prep, counter, stream);
+        case 1: return launch_split_rows<H, 1>(a, prep, counter, stream, mid);
+        case 2: return launch_split_rows<H, 2>(a, prep, counter, stream, mid);
     }
-    return launch_split_rows<H, 4>(a, prep, counter, stream);
+    return launch_split_rows<H, 4>(a, prep, counter, stream, mid);
 #endif
 }
 static size_t prep_stride(int horizon) {
@@ -469,14 +470,14 @@ static a1mpc_status use_split_pipeline(int horizon, int n, bool have_prep, bool*
     return st;
 }
 
-static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s, bool split) {
+static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s, bool split, hipEvent_t mid) {
     if (split && prep && counter) {
         switch (horizon) {
-            case 10: return launch_split<10>(a, prep, counter, s);
+            case 10: return launch_split<10>(a, prep, counter, s, mid);
 #ifndef A1MPC_DEV_SLIM
-            case 1: return launch_split<1>(a, prep, counter, s);
-            case 16: return launch_split<16>(a, prep, counter, s);
-            case 20: return launch_split<20>(a, prep, counter, s);
+            case 1: return launch_split<1>(a, prep, counter, s, mid);
+            case 16: return launch_split<16>(a, prep, counter, s, mid);
+            case 20: return launch_split<20>(a, prep, counter, s, mid);
 #endif
         }
     }
@@ -510,7 +511,13 @@ static void to_device_params(const a1mpc_config& c, DeviceParams* p) {
     p->rho0 = c.rho; p->sigma = c.sigma; p->alpha = c.alpha; p->eps_abs = c.eps_abs; p->eps_rel = c.eps_rel;
     p->adaptive_rho_tol = c.adaptive_rho_tolerance;
     p->max_iter = c.max_iter; p->check_every = c.check_termination; p->adaptive_rho = c.adaptive_rho;
-    p->adaptive_rho_every = c.adaptive_rho_interval; p->scaling_iters = c.scaling; p->warm_start = c.warm_start;
+    // adaptive_rho_interval = 0 is OSQP's default "automatic" (what the reference actually runs, S/A1RobotControl.cpp:523-524): OSQP fixes the
+    // interval in its first solve to c_max(c_roundmultiple(iter, check_termination), check_termination), iter = the iteration at which
+    // 0.4 x setup_time of WALL CLOCK has passed (osqp.c, PROFILING).  That rule is evaluated here with the outcome it has whenever 0.4 x setup_time
+    // is worth fewer than 1.5 x check_termination iterations (true for these QP sizes on the CPUs the reference runs on): check_termination.
+    // Its other possible outcomes (50, 75, ...) are selected by passing that number.
+    p->adaptive_rho_every = c.adaptive_rho_interval > 0 ? c.adaptive_rho_interval : (c.check_termination > 0 ? c.check_termination : 25);
+    p->scaling_iters = c.scaling; p->warm_start = c.warm_start;
 }
 
 }  // namespace a1mpc
@@ -537,6 +544,8 @@ struct a1mpc_handle_s {
     // the filter states): a call on another stream than the previous call's first waits for that call's work (ev_order, recorded after
     // every launch); the reset functions wait for it on the host.
     hipEvent_t ev_order = nullptr;
+    hipEvent_t ev_mid = nullptr;   // between the set-up kernel and the persistent ADMM kernel of the split pipeline (a1mpc_last_stage_ms)
+    bool staged = false;
     bool busy = false;
     // carried OSQP workspace (warm start)
     double *d_wx = nullptr, *d_wy = nullptr, *d_rho = nullptr;
@@ -1490,6 +1499,7 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_order) (void)hipEventDestroy(h->ev_order);
+    if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1524,6 +1534,7 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     A1_TRY(hipEventCreate(&h->ev0));
     A1_TRY(hipEventCreate(&h->ev1));
     A1_TRY(hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming));
+    A1_TRY(hipEventCreate(&h->ev_mid));
     std::vector<double> tab(2 * H * H), tab1(2);
     fill_gamma_beta_table(H, tab.data());
     fill_gamma_beta_table(1, tab1.data());
@@ -1664,6 +1675,7 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     if (foot_stride != 0 || contact_stride != 0 || d_yaw_A != nullptr) {  // general path: per-step B_d and / or a per-step contact schedule
         if (d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "per-step feet / contacts are not combined with tick records");
         a.foot_stride = foot_stride; a.contact_stride = contact_stride; a.yaw_A = d_yaw_A;
+        h->staged = false;
         A1_HIP(hipEventRecord(h->ev0, s));
         if (a1mpc_status stg = launch_gen(h->cfg.horizon, a, s); stg != A1MPC_OK) return stg;
         A1_HIP(hipEventRecord(h->ev1, s));
@@ -1681,7 +1693,8 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     a.cost = hints ? h->d_cost : nullptr;
     a.predict = (hints && h->hint_n != n) ? 1 : 0;  // first solve of this batch size: order by the set-up kernel's guess instead
     A1_HIP(hipEventRecord(h->ev0, s));
-    a1mpc_status st = launch_mpc(h->cfg.horizon, a, h->d_prep, h->d_counter, s, split);
+    h->staged = split;
+    a1mpc_status st = launch_mpc(h->cfg.horizon, a, h->d_prep, h->d_counter, s, split, h->ev_mid);
     if (st != A1MPC_OK) return st;
     if (hints) {
         hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, s, n, static_cast<const int32_t*>(h->d_cost), h->d_order);
@@ -1942,6 +1955,7 @@ a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_confi
 #ifdef A1MPC_DEV_SLIM
     a1mpc_status st = fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "slim development build");
 #else
+    h->staged = false;
     a1mpc_status st = launch<1, kModeBalance>(a, s);
 #endif
     if (st != A1MPC_OK) return st;
@@ -1962,6 +1976,21 @@ a1mpc_status a1mpc_last_kernel_ms(a1mpc_handle h, float* ms_out) {
     A1_HIP(hipSetDevice(h->device));
     A1_HIP(hipEventSynchronize(h->ev1));
     A1_HIP(hipEventElapsedTime(ms_out, h->ev0, h->ev1));
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_last_stage_ms(a1mpc_handle h, float* form_ms_out, float* solve_ms_out) {
+    if (!h || !form_ms_out || !solve_ms_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle/out");
+    if (!h->timed) return fail(A1MPC_ERR_INVALID_ARGUMENT, "no kernel has been launched through this handle");
+    A1_HIP(hipSetDevice(h->device));
+    A1_HIP(hipEventSynchronize(h->ev1));
+    if (h->staged) {
+        A1_HIP(hipEventElapsedTime(form_ms_out, h->ev0, h->ev_mid));
+        A1_HIP(hipEventElapsedTime(solve_ms_out, h->ev_mid, h->ev1));
+    } else {  // fused / latency kernel: one launch from inputs to outputs, the stages are not separable from outside
+        *form_ms_out = 0.0f;
+        A1_HIP(hipEventElapsedTime(solve_ms_out, h->ev0, h->ev1));
+    }
     return A1MPC_OK;
 }
 

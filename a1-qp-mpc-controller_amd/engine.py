@@ -40,7 +40,7 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
     _fields_ = [("counter_per_swing", C.c_double), ("foot_force_low", C.c_double), ("use_terrain_adapt", C.c_int32)]
 
 
-EXPORTS = ["a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
+EXPORTS = ["a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
@@ -107,6 +107,7 @@ def load_library(path=None):
     lib.a1mpc_set_schedule.argtypes = [vp, i32]; lib.a1mpc_set_schedule.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
     lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int
+    lib.a1mpc_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]; lib.a1mpc_last_stage_ms.restype = C.c_int
     lib.a1mpc_last_nfact.argtypes = [vp, i32, i32p]; lib.a1mpc_last_nfact.restype = C.c_int
     lib.a1mpc_kernel_info.argtypes = [vp, i32p, i32p, i32p]; lib.a1mpc_kernel_info.restype = C.c_int
     lib.a1mpc_status_string.argtypes = [C.c_int]; lib.a1mpc_status_string.restype = C.c_char_p
@@ -369,6 +370,11 @@ class Engine:
         ms = C.c_float()
         _check(self.lib, self.lib.a1mpc_last_kernel_ms(self._h, C.byref(ms)), "a1mpc_last_kernel_ms")
         return float(ms.value)
+
+    def last_stage_ms(self):
+        a = C.c_float(); b = C.c_float()
+        _check(self.lib, self.lib.a1mpc_last_stage_ms(self._h, C.byref(a), C.byref(b)), "a1mpc_last_stage_ms")
+        return float(a.value), float(b.value)
 
     def last_nfact(self, n):
         out = np.zeros(int(n), np.int32)

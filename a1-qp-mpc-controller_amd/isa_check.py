@@ -147,3 +147,31 @@ def dpp_hazards(path, key=""):
                             out.append(f"{path}:{ln}: {kernel[:60]}: DPP {age} wait state(s) after a VALU write of EXEC: {t}")
                 h = _step(h, op, ops, ops[0].split()[0] if ops else "0")
     return out
+
+
+# The check must not fail OPEN: if a change of listing format, name mangling or block labels made _parse() find nothing, dpp_hazards() would
+# return [] and every build would pass.  build() therefore also demands that the kernels made of inline-asm DPP chains were found and that a
+# plausible number of v_fmac_f64_dpp instructions was inspected in each.
+EXPECTED_DPP = {"a1mpc_admm_kernelILi10E": 1500, "a1mpc_admm_kernelILi16E": 2500, "a1mpc_admm_kernelILi20E": 3000, "a1mpc_setup_kernelILi10E": 60,
+                "a1mpc_solve_kernelILi10E": 1500, "a1mpc_solve_coop_kernelILi10E": 1500, "a1mpc_solve_gen_kernelILi10E": 1500}
+
+
+def dpp_coverage(path):
+    """{kernel: number of v_fmac_f64_dpp instructions the hazard check looked at}"""
+    return {k: sum(1 for b in blocks for (_, _, op, _) in b["instrs"] if "_dpp" in op and op.startswith("v_fmac_f64")) for k, blocks in _parse(path, "").items()}
+
+
+def coverage_gaps(paths, expected=None):
+    """list of messages: expected kernels that were not parsed, or parsed with too few DPP instructions"""
+    expected = EXPECTED_DPP if expected is None else expected
+    cov = {}
+    for p in paths:
+        cov.update(dpp_coverage(p))
+    out = []
+    for key, least in expected.items():
+        hits = [n for k, n in cov.items() if key in k]
+        if not hits:
+            out.append(f"hazard check saw no kernel matching {key} (listing format changed?)")
+        elif min(hits) < least:
+            out.append(f"hazard check inspected only {min(hits)} v_fmac_f64_dpp in {key} (expected >= {least})")
+    return out

@@ -75,8 +75,10 @@ typedef struct a1mpc_config {
     int32_t max_iter;
     int32_t check_termination;     /* iterations between termination checks (25) */
     int32_t adaptive_rho;          /* 1 */
-    int32_t adaptive_rho_interval; /* OSQP's default 0 means "wall-clock based"; this engine needs a fixed
-                                      iteration period so results are reproducible: 25 */
+    int32_t adaptive_rho_interval; /* > 0: rho is re-estimated every that many iterations.  0 = OSQP's default "automatic", the
+                                      setting the reference runs with: OSQP derives the period from measured wall-clock set-up time
+                                      (non-reproducible); here 0 resolves deterministically to the outcome of OSQP's rule for these QP
+                                      sizes, max(check_termination, 25-multiple) = check_termination (25).  a1mpc_default_config: 25 */
     int32_t scaling;               /* Ruiz passes (10) */
     int32_t warm_start;            /* 1 on the reference's MPC path, 0 on its balance-QP path */
 } a1mpc_config;
@@ -353,6 +355,13 @@ a1mpc_status a1mpc_update_config(a1mpc_handle h, const a1mpc_config* cfg);
 a1mpc_status a1mpc_last_kernel_ms(a1mpc_handle h, float* ms_out);
 a1mpc_status a1mpc_kernel_info(a1mpc_handle h, int32_t* lds_bytes_per_workgroup, int32_t* qps_per_workgroup,
                                int32_t* threads_per_workgroup);
+
+/* Stage split of the last MPC launch, the engine's counterpart of the reference's t1..t6 stopwatches (S/A1RobotControl.cpp:491-553;
+ * "form" = calculate_A/B_mat_c + discretisation + calculate_qp_mats + OSQP set-up, "solve" = solver.solve()): form_ms = the set-up kernel
+ * (formation + Ruiz equilibration, + the queue-order kernel), solve_ms = the persistent ADMM kernel (factorisations + iterations + output).
+ * Batches that run the fused / latency kernel are one launch: form_ms = 0, solve_ms = the whole launch.  Per-QP iteration counts come with
+ * every solve (iters_out), factorisation counts from a1mpc_last_nfact.  Synchronises the launch. */
+a1mpc_status a1mpc_last_stage_ms(a1mpc_handle h, float* form_ms_out, float* solve_ms_out);
 
 /* number of KKT (Riccati) factorisations each QP of the last MPC / balance launch performed (1 + rho updates);
  * synchronises the handle's stream; instrumentation for the work model of bench.py */

@@ -407,6 +407,9 @@ int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t
     {
         int iter, can_check = 0;
         const double alpha = st->alpha, sigma = st->sigma;
+        /* adaptive_rho_interval = 0 (OSQP's automatic, wall-clock based rule): resolved to the outcome the rule has for these QP sizes,
+         * c_max(c_roundmultiple(iter, check_termination), check_termination) = check_termination (see the header of this file) */
+        const int rho_every = st->adaptive_rho_interval > 0 ? st->adaptive_rho_interval : (st->check_termination > 0 ? st->check_termination : 25);
         for (iter = 1; iter <= st->max_iter; ++iter) {
             double *t;
             t = w.x; w.x = w.x_prev; w.x_prev = t;
@@ -443,7 +446,7 @@ int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t
             }
             can_check = st->check_termination && (iter % st->check_termination == 0);
             if (can_check) { update_info(&w); if (check_termination(&w, 0)) break; }
-            if (st->adaptive_rho && st->adaptive_rho_interval && (iter % st->adaptive_rho_interval == 0)) {
+            if (st->adaptive_rho && (iter % rho_every == 0)) {
                 if (!can_check) update_info(&w);
                 if (adapt_rho(&w)) { info->status = ORC_NON_CVX; break; }
             }

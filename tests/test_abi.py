@@ -93,3 +93,15 @@ def test_build_hazard_check_flags_early_dpp_reads(pkg, tmp_path):
         f = tmp_path / (name + ".s")
         f.write_text(head + body)
         assert bool(isa_check.dpp_hazards(str(f))) == bad, name
+
+
+def test_hazard_check_does_not_fail_open(pkg, tmp_path):
+    """a listing in which the parser finds none of the DPP kernels must FAIL the build's check, not pass it"""
+    from a1_qp_mpc_controller_amd import isa_check
+    f = tmp_path / "empty.s"
+    f.write_text("\t.text\n; nothing that looks like a kernel\n")
+    assert isa_check.dpp_hazards(str(f)) == [] and len(isa_check.coverage_gaps([str(f)])) == len(isa_check.EXPECTED_DPP)
+    g = tmp_path / "few.s"
+    g.write_text("_ZN5a1mpc17a1mpc_admm_kernelILi10ELi2EEEvNS_9BatchArgsEPKdPi:\n.LBB0_1:\n\tv_fmac_f64_dpp v[10:11], v[2:3], v[4:5] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\ts_endpgm\n")
+    gaps = isa_check.coverage_gaps([str(g)], {"a1mpc_admm_kernelILi10E": 1500})
+    assert len(gaps) == 1 and "only 1" in gaps[0]

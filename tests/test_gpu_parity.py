@@ -249,7 +249,7 @@ def test_device_pointer_entry_and_batched_warm_start(pkg, oracle, scen):
 
 SETTINGS_CASES = [dict(scaling=0), dict(scaling=3), dict(alpha=1.0), dict(alpha=1.8), dict(rho=1.0), dict(rho=0.01, adaptive_rho=0),
                   dict(check_termination=10), dict(adaptive_rho_interval=50), dict(check_termination=10, adaptive_rho_interval=35),
-                  dict(max_iter=30), dict(sigma=1e-4), dict(eps_abs=1e-5, eps_rel=1e-5), dict(adaptive_rho_tolerance=2.0)]
+                  dict(max_iter=30), dict(sigma=1e-4), dict(adaptive_rho_interval=0), dict(adaptive_rho_interval=0, check_termination=10), dict(eps_abs=1e-5, eps_rel=1e-5), dict(adaptive_rho_tolerance=2.0)]
 
 
 @pytest.mark.parametrize("over", SETTINGS_CASES, ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
@@ -757,3 +757,15 @@ def test_native_sharded_handle_two_shards_on_one_gpu(pkg, scen):
         assert np.array_equal(out["grf"], ref["grf"][:512]) and sh.info()["transport"] == 1
     with pytest.raises(pkg.A1MpcError):
         pkg.ShardedEngine(cfg, 512, devices=[0, 0], transport=1)       # RCCL needs distinct devices
+
+
+def test_stage_split_instrumentation(pkg, scen):
+    """SURVEY 5 "tracing": form | solve split of the last launch (the reference's t1..t6 stopwatches, S/A1RobotControl.cpp:491-553)"""
+    sc = scen.config3_random_flat(nb=8192)
+    with _engine(pkg, sc, 8192, warm_start=0) as eng:
+        eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+        form, solve = eng.last_stage_ms(); total = eng.last_kernel_ms()
+        assert form > 0.05 and solve > form and abs(form + solve - total) < 0.05 * total, (form, solve, total)
+        eng.solve(sc["x0"][:64], sc["xref"][:64], sc["R"][:64], sc["foot"][:64], sc["contact"][:64])   # fused kernel: not separable
+        form, solve = eng.last_stage_ms()
+        assert form == 0.0 and solve > 0.0

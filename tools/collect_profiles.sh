@@ -1,13 +1,15 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel trace of the default bench + PMC passes of the hot kernels.
-# Outputs under gpurun_out/prof_final/ ; tools/summarize_profiles.py copies the summaries into profiles/.
+# Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel trace of the default bench + PMC passes of the hot kernels (counters in their own
+# runs, one group per pass, never combined with trace domains).  usage: tools/collect_profiles.sh [round tag, default r02]
+# Outputs under gpurun_out/prof_<tag>/ ; tools/summarize_profiles.py <tag> copies the summaries into profiles/.
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/prof_final
+O=gpurun_out/prof_$TAG
 mkdir -p $O
-timeout 240 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-latency --no-index-order > $O/bench_under_rocprof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-latency --no-index-order > $O/bench_under_rocprof.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64"; do
   tag=$(echo $set | cut -d' ' -f1)
   timeout 150 rocprofv3 --pmc $set -d $O/pmc_$tag --output-format csv -- python tools/prof_target.py > /dev/null 2>&1
 done
-find $O -name "*kernel_stats.csv" -exec head -4 {} \;
+find $O -name "*kernel_stats.csv" -exec head -6 {} \;

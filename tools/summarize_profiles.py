@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Copies the rocprofv3 summaries of gpurun_out/prof_final/ into profiles/ (tracked)."""
-import collections, csv, glob, json, os, shutil
+import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "prof_final"); dst = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + TAG); dst = os.path.join(ROOT, "profiles")
 def newest(pattern):
     fs = glob.glob(pattern, recursive=True)
     return max(fs, key=os.path.getmtime) if fs else None
@@ -10,15 +11,15 @@ def newest(pattern):
 
 f = newest(os.path.join(src, "trace", "**", "*kernel_stats.csv"))
 if f:
-    shutil.copy(f, os.path.join(dst, "r01_kernel_stats_bench_batch4096_h10.csv"))
+    shutil.copy(f, os.path.join(dst, TAG + "_kernel_stats_bench_batch4096_h10.csv"))
 f = newest(os.path.join(src, "trace", "**", "*domain_stats.csv"))
 if f:
-    shutil.copy(f, os.path.join(dst, "r01_domain_stats.csv"))
+    shutil.copy(f, os.path.join(dst, TAG + "_domain_stats.csv"))
 log = os.path.join(src, "bench_under_rocprof.log")
 if os.path.exists(log):
     lines = [l for l in open(log) if l.startswith("{")]
     if lines:
-        open(os.path.join(dst, "r01_bench_under_rocprof.json"), "w").write(lines[-1])
+        open(os.path.join(dst, TAG + "_bench_under_rocprof.json"), "w").write(lines[-1])
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 pmc_files = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
@@ -37,8 +38,17 @@ for f in pmc_files.values():
 summ = {k: {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in d.items()} for k, d in acc.items()}
 tot = sum(summ.get(k, {}).get(c, {}).get("mean_per_launch", 0.0) for k in summ for c in ("FETCH_SIZE", "WRITE_SIZE"))
 summ["_hbm_bytes_per_solve_batch_launch"] = tot * 1024.0
+summ["hbm_bytes_per_launch"] = tot * 1024.0
+# executed FP64: wave-level instruction counts x the lanes that do useful work (set-up kernel: 4 rows x 12 lanes of 64; ADMM kernel: 2 x 12)
+live = {"setup_kernel": 48, "admm_kernel": 24}
+ex = 0.0
+for k, lanes in live.items():
+    c = summ.get(k, {})
+    g_ = lambda n: c.get(n, {}).get("mean_per_launch", 0.0)
+    ex += lanes * (2.0 * g_("SQ_INSTS_VALU_FMA_F64") + g_("SQ_INSTS_VALU_ADD_F64") + g_("SQ_INSTS_VALU_MUL_F64"))
+summ["executed_fp64_flops_per_launch"] = ex
 summ["_note"] = ("rocprofv3 --pmc, one counter group per pass (tools/collect_profiles.sh), 4096 QPs h=10 default OSQP settings cold start "
                  "(tools/prof_target.py); FETCH_SIZE / WRITE_SIZE in KiB per kernel launch; one solve_batch = setup_kernel + admm_kernel. "
                  "Reads are 8-byte per-lane accesses of per-problem records (uncalibrated w.r.t. the guide's x2 rule for 16 B/lane streams).")
-json.dump(summ, open(os.path.join(dst, "r01_pmc_summary.json"), "w"), indent=1)
+json.dump(summ, open(os.path.join(dst, TAG + "_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summ, indent=1)[:3000])
