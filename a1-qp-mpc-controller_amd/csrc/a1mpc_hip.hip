@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64) void a1mpc_solve_gen_kernel(const KernelArgs a)
     const int row = static_cast<int>(threadIdx.x) >> 4;
     const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
     if (b >= a.n) return;
-    solve_row_with<H, kModeMpc, true>(a.P, a.tab, [&]() { return make_io<H, kModeMpc>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H, true>::ROW_STRIDE);
+    solve_row_with<H, kModeMpc, true>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H, true>::ROW_STRIDE);
 }
 
 // Latency variant of the fused kernel for a handful of QPs: the four rows of a wavefront work on ONE QP during set-up (each takes every fourth

@@ -1268,9 +1268,9 @@ A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
     io.x0 = (MODE == kModeMpc && a.x0) ? a.x0 + b * 13 : nullptr;
     io.xref = (MODE == kModeMpc && a.xref) ? a.xref + b * 13 * H : nullptr;
     io.R = a.R + b * 9;
-    io.foot = a.foot + b * (a.foot_stride ? 12 * H : 12);
-    io.contact = a.contact + b * (a.contact_stride ? 4 * H : 4);
-    io.foot_stride = a.foot_stride; io.contact_stride = a.contact_stride; io.yaw_A = a.yaw_A ? a.yaw_A + b : nullptr;
+    io.foot = a.foot + b * 12;
+    io.contact = a.contact + b * 4;
+    // foot_stride / contact_stride / yaw_A are only read by RowSolver<..., GEN = true> and set by make_io_gen() below (deliberately not here)
     io.grf = a.grf + b * 12;
     io.u_full = a.u_full ? a.u_full + b * 12 * H : nullptr;
     io.warm_x = a.warm_x ? a.warm_x + b * 12 * H : nullptr;
@@ -1279,6 +1279,18 @@ A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
     io.iters = a.iters ? a.iters + b : nullptr;
     io.status = a.status ? a.status + b : nullptr;
     io.nfact = a.nfact ? a.nfact + b : nullptr;
+    return io;
+}
+
+// The general path's records (per-step feet / contacts, A_c yaw).  A separate function on purpose: make_io() is inlined into the persistent ADMM
+// kernel, whose register allocation is sensitive to every instruction around the hot loop -- with the stride selects inside make_io() the
+// same hot loop came out 7 % slower per iteration (tools/ab_kernels.sh: 10.3 -> 10.8 ms at 65 536 QPs).
+template <int H>
+A1_DEV ProblemIO make_io_gen(const BatchArgs& a, int64_t b) {
+    ProblemIO io = make_io<H, kModeMpc>(a, b);
+    io.foot = a.foot + b * (a.foot_stride ? 12 * H : 12);
+    io.contact = a.contact + b * (a.contact_stride ? 4 * H : 4);
+    io.foot_stride = a.foot_stride; io.contact_stride = a.contact_stride; io.yaw_A = a.yaw_A ? a.yaw_A + b : nullptr;
     return io;
 }
 
