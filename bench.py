@@ -470,7 +470,7 @@ def main():
             "history_ms_per_step": hist_ms, "history_solves_per_s_per_gpu": (n / (hist_ms * 1e-3)) if hist_ms else None}
         if not args.no_latency:
             out["roofline_other_configs"] = other_config_rooflines(pkg, local)
-    if world > 1 and backend == "nccl":
+    if world > 1 and backend == "nccl" and os.environ.get("A1_BENCH_SCATTER_GATHER") == "1":   # opt-in: an extra collective phase must not be able to take the metric's run down
         # Extra information (not `value`, which needs no collective): what scattering this step's inputs from rank 0 and gathering the results
         # back over RCCL / xGMI would cost -- the north_star's "scatter inputs / gather GRFs" -- one grouped send/recv each way.
         sh = pkg.sharding
