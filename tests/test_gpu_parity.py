@@ -769,3 +769,36 @@ def test_stage_split_instrumentation(pkg, scen):
         eng.solve(sc["x0"][:64], sc["xref"][:64], sc["R"][:64], sc["foot"][:64], sc["contact"][:64])   # fused kernel: not separable
         form, solve = eng.last_stage_ms()
         assert form == 0.0 and solve > 0.0
+
+
+def test_general_path_warm_started_sequence_and_device_pointers(pkg, oracle, scen):
+    """The general path carries the OSQP workspace like the fast path (warm-started ticks with per-step feet / contacts vs the oracle chained the
+    same way), and its device-pointer entry gives the host entry's numbers."""
+    import ctypes as C
+    import torch
+    h, nb, ticks = 10, 48, 5
+    rng = np.random.default_rng(77)
+    sc, foot, fs, contact, cs = _strided_inputs(scen, rng, h, nb, True, True)
+    p = sc["params"]
+    pr = oracle.mpc_params(h, p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"], p["inertia"]); st = oracle.default_settings(warm_start=1)
+    wx = np.zeros((nb, 12 * h)); wy = np.zeros((nb, 20 * h)); rho = np.zeros(nb)
+    with _engine(pkg, sc, nb, warm_start=1) as eng:
+        for t in range(ticks):
+            x0 = sc["x0"].copy(); x0[:, :12] += rng.normal(0, 0.002, (nb, 12)) * t
+            out = eng.solve_strided(x0, sc["xref"], sc["R"], foot, fs, contact, cs, want_u=True)
+            for b in range(0, nb, 5):
+                r = oracle.mpc_solve(pr, st, x0[b], sc["xref"][b], sc["R"][b], foot[b], contact[b], warm_x=wx[b], warm_y=wy[b], warm_rho=rho[b], foot_stride=fs, contact_stride=cs)
+                wx[b], wy[b], rho[b] = r["warm_x"], r["warm_y"], r["rho"]
+                assert out["iters"][b] == r["info"].iters, (t, b, out["iters"][b], r["info"].iters)
+                assert np.abs(out["u"][b] - r["u"]).max() <= TOL_FORCE_N
+    dev = torch.device("cuda:0")
+    T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    d = [T(sc["x0"]), T(sc["xref"]), T(sc["R"]), T(foot), T(contact, torch.uint8)]
+    g = torch.zeros(nb, 12, dtype=torch.float64, device=dev); it = torch.zeros(nb, dtype=torch.int32, device=dev); stt = torch.zeros(nb, dtype=torch.int32, device=dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    with _engine(pkg, sc, nb, warm_start=0) as eng:
+        host = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, fs, contact, cs)
+        rc = eng.lib.a1mpc_solve_batch_strided_device(eng._h, nb, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), fs, ptr(d[4]), cs, None, ptr(g), None, ptr(it), ptr(stt), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+    assert np.array_equal(g.cpu().numpy(), host["grf"]) and np.array_equal(it.cpu().numpy(), host["iters"])
