@@ -91,32 +91,34 @@ def _load_state(c, scen, ps, euler, pos, w, v, euler_d, vd, wd, pos_d, foot_abs,
     c.set("foot_pos_abs", foot_abs); c.set("contacts", contacts)
 
 
-def test_compute_grf_mpc_branch_warm_sequence(oracle, scen):
-    """A1RobotControl::compute_grf (stance_leg_control_type = 1) over a 40-tick warm-started trot sequence vs the oracle chained the
-    same way (state packing :452-456, x_ref :470-488, ConvexMpc, persistent warm-started solver :522-538, R'f :555-561).
-    Terrain adaptation off here (it is covered below): root_euler_d stays what the caller set."""
+@pytest.mark.parametrize("h,nt", [(10, 40), (16, 12), (20, 8)])
+def test_compute_grf_mpc_branch_warm_sequence(oracle, scen, h, nt):
+    """A1RobotControl::compute_grf (stance_leg_control_type = 1) over a warm-started trot sequence vs the oracle chained the
+    same way (state packing :452-456, x_ref :470-488, ConvexMpc, persistent warm-started solver :522-538, R'f :555-561), at the reference's
+    PLAN_HORIZON = 10 and with the one-macro edit to 16 / 20.  Terrain adaptation off here (it is covered below)."""
     ps = "gazebo"
-    sc = scen.config2_trot_sequence(40)
+    sc = scen.config2_trot_sequence(nt, horizon=h)
     p = sc["params"]
-    pr = oracle.mpc_params(10, p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"], p["inertia"])
+    pr = oracle.mpc_params(h, p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"], p["inertia"])
     st = oracle.default_settings(warm_start=1)
-    c = REF.Controller()
+    c = REF.Controller(h)
     c.set("stance_leg_control_type", [1]); c.set("use_terrain_adapt", [0])
-    wx = np.zeros(120); wy = np.zeros(200); rho = 0.0
-    for t in range(40):
+    wx = np.zeros(12 * h); wy = np.zeros(20 * h); rho = 0.0
+    for t in range(nt):
         x0 = sc["x0"][t]; R = sc["R"][t].reshape(3, 3)
         euler, pos, w, v = x0[0:3], x0[3:6], x0[6:9], x0[9:12]
         vd = np.array([0.3, 0.0, 0.0]); z3 = np.zeros(3)
         _load_state(c, scen, ps, euler, pos, w, v, z3, vd, z3, [0, 0, 0.3], sc["foot"][t], sc["contact"][t], R)
         grf = c.compute_grf(0.0025)
-        qp = REF.last_qp()
-        xref = oracle.mpc_reference(10, p["dt"], euler, pos, R.reshape(9), z3, vd, z3, 0.3)
+        qp = REF.last_qp(h)
+        xref = oracle.mpc_reference(h, p["dt"], euler, pos, R.reshape(9), z3, vd, z3, 0.3)
         assert np.array_equal(xref, sc["xref"][t]) or np.abs(xref - sc["xref"][t]).max() < 1e-15
-        assert np.array_equal(c.get("mpc_states_d", 130), xref) and np.array_equal(c.get("mpc_states", 13), x0)
+        assert np.array_equal(c.get("mpc_states_d", 13 * h), xref) and np.array_equal(c.get("mpc_states", 13), x0)
         o = oracle.mpc_solve(pr, st, x0, xref, R.reshape(9), sc["foot"][t], sc["contact"][t], warm_x=wx, warm_y=wy, warm_rho=rho)
         wx, wy, rho = o["warm_x"], o["warm_y"], o["rho"]
         assert o["info"].iters == qp["iters"] and o["info"].status == qp["status"], t
-        assert np.abs(o["grf"] - grf).max() <= 1e-9, (t, np.abs(o["grf"] - grf).max())
+        # same QP data to 1e-15, same iteration count; the forces then agree to the amplification of that last bit through ~50-100 ADMM iterations
+        assert np.abs(o["grf"] - grf).max() <= (1e-9 if h == 10 else 1e-7), (t, np.abs(o["grf"] - grf).max())
     c.close()
 
 
