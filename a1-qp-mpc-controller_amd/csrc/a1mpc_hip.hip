@@ -92,11 +92,23 @@ __global__ __launch_bounds__(64, 2) void a1mpc_setup_kernel(const KernelArgs a, 
     setup_row<H>(a, tabl, b, a1mpc_lds + row * LayoutSetup<H>::ROW_STRIDE, prep);
 }
 // K2: persistent rows; grid = resident workgroups; every row drains the queue of prepared QPs.
+#ifdef A1X_NOTWIN
+constexpr bool admm_twin_rows(int, int) { return false; }
+#else
+constexpr bool admm_twin_rows(int h, int rows) { return rows <= 2 && h > 1; }
+#endif  // the wavefront's spare rows run as twins (RowSolver<.., TWIN>)
 template <int H, int ROWS>
 __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
+    // ROWS <= 2: the wavefront's other rows run as twins of the QP rows (rows r and r + 2 share a QP and its LDS image, see row_is_twin)
+    constexpr bool kTwin = admm_twin_rows(H, ROWS);
     const int row = static_cast<int>(threadIdx.x) >> 4;
-    admm_rows<H>(a, prep, counter, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+    if constexpr (kTwin) {
+        if ((row & 1) >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
+        admm_rows<H, true>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H>::ROW_STRIDE);
+    } else {
+        admm_rows<H, false>(a, prep, counter, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+    }
 }
 
 // K3: the next solve's queue order = this solve's QPs by decreasing cost (counting sort, one workgroup).  A batch of 1-4x the resident
@@ -314,7 +326,7 @@ static a1mpc_status resident_workgroups(int* out) {
         A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(lds2)));
         int per_cu = 0, cus = 0;
-        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), 16 * ROWS, lds2));
+        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS, lds2));
         A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         resident[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
     }
@@ -352,7 +364,7 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     }
     if (mid) A1_HIP(hipEventRecord(mid, stream));  // stage split: formation + Ruiz (+ queue order) | factor + iterate
     const int want = (a.n + ROWS - 1) / ROWS;
-    hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), dim3(static_cast<unsigned>(want < res ? want : res)), dim3(16 * ROWS), lds2, stream, a,
+    hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), dim3(static_cast<unsigned>(want < res ? want : res)), dim3(admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS), lds2, stream, a,
                        static_cast<const double*>(prep), counter);
     A1_HIP(hipGetLastError());
     return A1MPC_OK;

@@ -224,9 +224,13 @@ struct Prep {
 // (s,t) is still alpha_st U_st + beta_st V_st (A_c^2 B = 0 holds for every B_t), but U_st, V_st now depend on both steps: they are
 // evaluated on the fly from the per-step tables (6 FMAs per entry instead of 1), the Riccati sweeps read B~_t and the bounds per step
 // from LDS.  Same iterates as the oracle's strided formation; slower (bigger LDS image, more reads) and only in the fused kernel.
-template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false>
+// TWIN = true (persistent ADMM kernel only): this row runs as one of a main / twin pair of DPP rows on the SAME QP (row_is_twin(),
+// a1mpc_rowops.hpp).  Both rows execute everything redundantly -- identical registers, identical control flow, only the main row stores --
+// except the two 12-term products of a backward-sweep step, which they split (admm_iteration).
+template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false, bool TWIN = false>
 struct RowSolver {
     static_assert(!GEN || (MODE == kModeMpc && !SETUP_ONLY && H > 1), "the general path is an MPC solve in the fused kernel");
+    static_assert(!TWIN || (MODE == kModeMpc && !SETUP_ONLY && !GEN && H > 1), "twin rows: the persistent ADMM kernel");
     using L = std::conditional_t<SETUP_ONLY, LayoutSetup<H>, Layout<H, GEN>>;
     using PR = Prep<H>;
     const DeviceParams& P;
@@ -235,6 +239,8 @@ struct RowSolver {
     // lane identity
     int ln, quad, comp, ci, tri, krow;
     bool act, wl;
+    bool twin, wr;    // TWIN: second row of the pair / this lane stores (act && !twin)
+    double hm, gAm, gBm, gCm, gVm;  // TWIN: 1 (main) / 0 (twin) and the costate-seed multipliers masked by it (sweep_back_rhs_twin)
     const double* brow;
     double dt, mu;
     // per-lane constants of the problem
@@ -256,6 +262,9 @@ struct RowSolver {
     int iter, nfact;
     int32_t status;
     bool fac_ok, need_factor, done;
+#ifdef A1X_CLK
+    long long clkB = 0, clkF = 0, clkT = 0, clkU = 0, clkX = 0;
+#endif
     int pred_cost = 0;  // set-up's guess of this QP's cost (queue order of a first solve, see predict_cost)
     struct Info {
         double pri_res, dua_res, nEz, nEAx, nDq, nDAty, nDPx;  // unscaled
@@ -266,6 +275,9 @@ struct RowSolver {
         ln = row_lane();
         quad = ln >> 2; comp = ln & 3;
         act = comp < 3;
+        twin = TWIN && row_is_twin();
+        wr = act && !twin;
+        hm = twin ? 0.0 : 1.0;
         ci = act ? 3 * quad + comp : 0;  // compact index (safe 0 on pad lanes)
         tri = ci * (ci + 1) / 2;
         krow = ci * L::KSTR;
@@ -290,6 +302,7 @@ struct RowSolver {
         gB = ln == 8 ? -dt * sy : (ln == 9 ? dt * cy : 0.0);
         gC = ln == 10 ? dt : 0.0;
         gV = (quad == 3 && act) ? dt : 0.0;
+        if constexpr (TWIN) { gAm = hm * gA; gBm = hm * gB; gCm = hm * gC; gVm = hm * gV; }
     }
     // NOTE: opA, opAT, BtT, Bu read their argument through DPP: it must have passed row_dpp_ready()
     A1_DEV double opA(double s) const {  // (A_d s): rpy += dt*T*omega, pos += dt*vel
@@ -748,14 +761,14 @@ struct RowSolver {
             dI2[t] = p[(PR::DI2 + t) * 12 + ci];
             xh[t] = warm ? am * p[(PR::XH + t) * 12 + ci] : 0.0;
             park_warm_y(io, t);
-            if (act) lds[L::CG + t * 12 + ci] = p[(PR::CG + t) * 12 + ci];
+            if (wr) lds[L::CG + t * 12 + ci] = p[(PR::CG + t) * 12 + ci];
         });
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             Bt[k] = am * p[(PR::BT + k) * 12 + ci];
-            if (act) lds[L::BL + k * 12 + ci] = Bt[k];
+            if (wr) lds[L::BL + k * 12 + ci] = Bt[k];
         }
-        if (act) lds[L::BL + L::ZROW * 12 + ci] = 0.0;
+        if (wr) lds[L::BL + L::ZROW * 12 + ci] = 0.0;
         csc = p[PR::CSC * 12 + ci]; cinv = 1.0 / csc; qd = csc * q2s;
         set_rotation(p[PR::CY * 12 + ci], p[PR::SY * 12 + ci]);
         rho = p[PR::RHO * 12 + ci];
@@ -764,6 +777,9 @@ struct RowSolver {
         eqmask = act ? static_cast<unsigned>(p[PR::EQ * 12 + ci]) : 0u;
         row_sync();
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false; careful = false;
+#ifdef A1X_CLK
+        clkB = clkF = clkT = clkU = clkX = 0;
+#endif
     }
 
     // ================================================================================ Riccati factorisation of
@@ -782,9 +798,11 @@ struct RowSolver {
             const double wo = comp < 2 ? mu * (a0 - a1) : 0.0;
             const double wox = quad_perm<0, 0, 0, 0>(wo), woy = quad_perm<1, 1, 1, 1>(wo);
             double* w = lds + L::FAC + T * L::SLOT + L::K_SZ + 3 * ln;  // staged in the S area of the slot (the K area's pad column carries G)
-            w[0] = comp == 0 ? wd : (comp == 2 ? wox : 0.0);
-            w[1] = comp == 1 ? wd : (comp == 2 ? woy : 0.0);
-            w[2] = comp == 2 ? wd : wo;
+            if (!twin) {
+                w[0] = comp == 0 ? wd : (comp == 2 ? wox : 0.0);
+                w[1] = comp == 1 ? wd : (comp == 2 ? woy : 0.0);
+                w[2] = comp == 2 ? wd : wo;
+            }
         });
         row_sync();
         // lane constants of this pass: component indicators (1.0 / 0.0).  "Add on my diagonal entry only" is one v_fmac_f64_dpp with
@@ -860,7 +878,7 @@ struct RowSolver {
                 S[k] = (act && ci == k) ? pinv : mlt;
                 gj_pivot<k>(S, mlt, piv, pinv);
             });
-            if (act) {
+            if (wr) {
                 // packed lower triangle, branch-free: entries right of my diagonal go to my own diagonal slot first, in descending
                 // column order, so that the diagonal entry itself is the last one written there (LDS stores of a wave stay in order)
                 static_for<12>([&](auto Bd) {
@@ -877,7 +895,7 @@ struct RowSolver {
             static_for<12>([&](auto B) {  // twelve independent accumulator chains
                 static_for<12>([&](auto A_) { fma_bcast<lane_of(A1_CV(B))>(Kt[A_], Ft[B], S[A_]); });
             });
-            if (act && t > 0) {  // K_0 is never used (x_0 = 0)
+            if (wr && t > 0) {  // K_0 is never used (x_0 = 0)
 #pragma unroll
                 for (int a = 0; a < 12; ++a) slot[a * L::KSTR + ci] = Kt[a];
             }
@@ -905,6 +923,19 @@ struct RowSolver {
     // sweeps; the right-hand side is formed inside the backward sweep and the x / w updates consume v_t inside the
     // forward sweep, so only d_t crosses between the sweeps.
     // FIRST: OSQP's iteration 1 starts from z0 = A x0 (not projected) and y0 (warm start).
+    // TWIN: the LDS reads of backward step t (one entry per term: the main row's K_t column, the twin's S_t^-1 row; and c g_t).
+    // (Carrying the reads of step H - 1 from one iteration into the next -- issued behind the last forward step -- was measured: the 26 loop-carried
+    // registers push ten loop invariants into scratch, 2.95 -> 3.56 us per iteration.)
+    struct SweepPre { double M[12]; double cg; };
+    template <int T_>
+    A1_DEV void issue_back_reads(SweepPre& q) const {
+        const double* slot = lds + L::FAC + T_ * L::SLOT;
+        static_for<12>([&](auto B) {
+            constexpr int b = A1_CV(B);
+            q.M[b] = slot[twin ? L::K_SZ + (b <= ci ? tri + b : b * (b + 1) / 2 + ci) : b * L::KSTR + ci];  // (t = 0: the main row's value is unused)
+        });
+        q.cg = lds[L::CG + T_ * 12 + ci];
+    }
     template <bool FIRST, bool CAREFUL = false>
     A1_DEV void admm_iteration() {
         // Loop-invariant scalars are laundered through row_opaque() once per iteration: otherwise LICM hoists every
@@ -917,17 +948,34 @@ struct RowSolver {
         // adds), independent chains are interleaved by hand, subtraction rides on the NEG modifier of v_fmac_f64_dpp.
         double d[H];
         double pv = 0.0;  // costate p_{t+1}, state layout (dpp-ready at the top of every step)
+#ifdef A1X_CLK
+        const long long c0_ = clock64();
+#endif
+        // TWIN: the LDS reads of a step are issued as soon as the block that consumed the previous step's has been issued (into the registers it
+        // frees): with one wave per SIMD nothing else hides an LDS round trip.
+        [[maybe_unused]] double Kq[1][12];
+        [[maybe_unused]] SweepPre pre;
+        if constexpr (TWIN) { issue_back_reads<H - 1>(pre); row_sched_fence(); }
+        [[maybe_unused]] auto issue_back = [&](auto TQ) { issue_back_reads<A1_CV(TQ)>(pre); };
+        [[maybe_unused]] auto issue_fwd = [&](auto TQ) {
+            constexpr int t = A1_CV(TQ);
+            const double* slot = lds + L::FAC + t * L::SLOT;
+            static_for<12>([&](auto B) { Kq[0][A1_CV(B)] = slot[krow + A1_CV(B)]; });
+        };
         static_for<H>([&](auto TT) {
             constexpr int t = H - 1 - A1_CV(TT);
             const double* slot = lds + L::FAC + t * L::SLOT;
             // issue this step's LDS reads first: their latency overlaps the right-hand-side arithmetic below
-            double Sr[12], Kc[12];
-            static_for<12>([&](auto B) {
-                constexpr int b = A1_CV(B);
-                Sr[b] = slot[L::K_SZ + (b <= ci ? tri + b : b * (b + 1) / 2 + ci)];
-                if constexpr (t > 0) Kc[b] = slot[b * L::KSTR + ci];
-            });
-            const double cgt = lds[L::CG + t * 12 + ci];
+            [[maybe_unused]] double Sr[12], Kc[12];
+            if constexpr (!TWIN) {
+                static_for<12>([&](auto B) {
+                    constexpr int b = A1_CV(B);
+                    Sr[b] = slot[L::K_SZ + (b <= ci ? tri + b : b * (b + 1) / 2 + ci)];
+                    if constexpr (t > 0) Kc[b] = slot[b * L::KSTR + ci];
+                });
+            }
+            double cgt;
+            if constexpr (TWIN) cgt = pre.cg; else cgt = lds[L::CG + t * 12 + ci];
             [[maybe_unused]] double Btl[6];
             if constexpr (GEN) Bt_at(t, Btl);
             const double lbt = GEN ? lb_at(t) : lb0_l, ubt = GEN ? ub_at(t) : ub0_l;
@@ -951,30 +999,55 @@ struct RowSolver {
             const double sd = sigma_l * dI2[t];
             double r, pa = 0.0, pb = 0.0;
             if constexpr (t < H - 1) {
-                if constexpr (t > 0) pb = gV * row_ror<8>(pv);
-                if constexpr (GEN) sweep_back_rhs(r, pa, pb, at, cgt, sd, xh[t], pv, Btl, gA, gB, gC);
-                else sweep_back_rhs(r, pa, pb, at, cgt, sd, xh[t], pv, Bt, gA, gB, gC);
+                if constexpr (TWIN) {
+                    if constexpr (t > 0) pb = gVm * row_ror<8>(pv);
+                    sweep_back_rhs_twin(r, pa, pb, at, cgt, sd, xh[t], pv, Bt, gAm, gBm, gCm, hm);
+                } else {
+                    if constexpr (t > 0) pb = gV * row_ror<8>(pv);
+                    if constexpr (GEN) sweep_back_rhs(r, pa, pb, at, cgt, sd, xh[t], pv, Btl, gA, gB, gC);
+                    else sweep_back_rhs(r, pa, pb, at, cgt, sd, xh[t], pv, Bt, gA, gB, gC);
+                }
             } else {
                 r = row_dpp_ready(fma(sd, xh[t], at - cgt));  // p_H = 0
             }
-            row_lds_landed();
-            if constexpr (t > 0) {
+            if constexpr (!TWIN) row_lds_landed();
+            if constexpr (TWIN) {
+                // main row: p_t = A' p_{t+1} + K_t' r;  twin: d_t = S_t^-1 r (same arithmetic as sweep_back_chains / dot12_block: even terms + odd terms);
+                // then the halves swap: both rows hold p_t and d_t again.  (hipcc places the s_waitcnt that lets the NEXT step's reads stay in flight)
+                sweep_back_chain_twin(pa, pb, r, pre.M);
+                row_sched_fence();
+                if constexpr (t > 0) issue_back(std::integral_constant<int, (t > 0 ? t - 1 : 0)>{});  // the next step's reads, into the registers the chain has just freed
+                else issue_fwd(std::integral_constant<int, 1>{});
+                row_sched_fence();
+                d[t] = twin_exchange(pa);
+                pv = pa;
+            } else if constexpr (t > 0) {
                 sweep_back_chains(d[t], pa, pb, r, Sr, Kc);
                 pv = pa;
             } else {
                 d[t] = dot12_block(Sr, r);
             }
         });
+#ifdef A1X_CLK
+        const long long c1_ = clock64();
+#endif
         double s = 0.0;  // state x_t of the LQ roll-out (x_0 = 0); dpp-ready at the top of every step
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
             const double* slot = lds + L::FAC + t * L::SLOT;
             // issue this step's LDS reads first (K_t row): they overlap the previous step's w update
             double Kr[12];
-            static_for<12>([&](auto B) {
-                constexpr int b = A1_CV(B);
-                if constexpr (t > 0) Kr[b] = slot[krow + b];
-            });
+            if constexpr (TWIN) {
+                if constexpr (t > 0) {
+#pragma unroll
+                    for (int b = 0; b < 12; ++b) Kr[b] = Kq[0][b];
+                }
+            } else {
+                static_for<12>([&](auto B) {
+                    constexpr int b = A1_CV(B);
+                    if constexpr (t > 0) Kr[b] = slot[krow + b];
+                });
+            }
             [[maybe_unused]] double Brl[12];  // H > 10: my row of B~ is re-read per step (the 24 registers are worth more than 6 LDS reads there)
             if constexpr (!kBrowInRegs && t < H - 1) {
                 const double* br = brow_at(t);
@@ -995,7 +1068,7 @@ struct RowSolver {
                 gt0 = rr0[t] * fma(2.0, zp0, -wh0[t]);
                 gt1 = rr1[t] * fma(2.0, zp1, -wh1[t]);
             }
-            row_lds_landed();
+            if constexpr (!TWIN) row_lds_landed();
             if constexpr (t == 0) {
                 v = row_dpp_ready(am * v);  // x_0 = 0
                 xh[t] = fma(al, v, oma * xh[t]);
@@ -1004,6 +1077,11 @@ struct RowSolver {
                 sweep_fwd_gain<true>(v, sa, sb, xh[t], s, Kr, fA, fB, fC, am, oma, al);
             } else {
                 sweep_fwd_gain<false>(v, sa, sb, xh[t], s, Kr, fA, fB, fC, am, oma, al);
+            }
+            if constexpr (TWIN) {  // the next step's K row, into the registers sweep_fwd_gain has just freed: the input chain and the w update hide the round trip
+                row_sched_fence();
+                if constexpr (t > 0 && t < H - 1) issue_fwd(std::integral_constant<int, (t < H - 1 ? t + 1 : 1)>{});
+                row_sched_fence();
             }
             if constexpr (t < H - 1) {
                 if constexpr (kBrowInRegs) sweep_fwd_input(sa, sb, z0, v, Brw, wh0[t], lbt, ubt);
@@ -1025,7 +1103,7 @@ struct RowSolver {
                 const double atd = fma(muz, sdx + sdy, d0 + d1);
                 const double T = fma(sigma_l * dI2[t], xh_old - v, atd);
                 double* G = lds + L::FAC + t * L::SLOT + ci * L::KSTR + L::GCOL;
-                if (act) *G = fma(al, T, oma * *G);
+                if (wr) *G = fma(al, T, oma * *G);
             }
             if constexpr (FIRST) {  // w1 = alpha z~ + (1 - alpha) z0 + y0 / rho,  z0 = A x0
                 const double xz = xz_first;
@@ -1039,6 +1117,10 @@ struct RowSolver {
                 wh1[t] = fma(al1, av1 - z1, wh1[t]);  // stays 0 on fz lanes
             }
         });
+#ifdef A1X_CLK
+        const long long c2_ = clock64();
+        clkB += c1_ - c0_; clkF += c2_ - c1_;
+#endif
     }
 
     // ================================================================================ residuals (auxil.c compute_pri_res / compute_dua_res / ...)
@@ -1100,7 +1182,7 @@ struct RowSolver {
             double* G = lds + L::FAC + t * L::SLOT + ci * L::KSTR + L::GCOL;
             double pq_u = px_u + cgt;
             if (careful) pq_u = act ? *G : 0.0;
-            else if (act) *G = pq_u;
+            else if (wr) *G = pq_u;
             const double rd_u = pq_u + aty_u;        // = D^-1 (P_s x_s + q_s + A_s' y_s)
             const double D2 = one_c / dI2[t];        // D^2
             m_udua = max_f64(m_udua, fabs(rd_u));
@@ -1151,16 +1233,28 @@ struct RowSolver {
             if (P.adaptive_rho && P.adaptive_rho_every > 0) next = imin(next, (iter / P.adaptive_rho_every + 1) * P.adaptive_rho_every);
             if (iter == 0 && first_special) { admm_iteration<true>(); iter = 1; }
             // the rows of a wave share one instruction stream: if any of them carries G, all run that variant (a harmless extra for the others)
+#ifdef A1X_CLK
+            const long long t0_ = clock64();
+#endif
             if (row_wave_any(careful)) {
                 for (int k = iter; k < next; ++k) admm_iteration<false, true>();
             } else {
                 for (int k = iter; k < next; ++k) admm_iteration<false, false>();
             }
+#ifdef A1X_CLK
+            clkT += clock64() - t0_;
+#endif
             iter = next;
             const bool can_check = P.check_every > 0 && (iter % P.check_every) == 0;
             const bool do_rho = P.adaptive_rho && P.adaptive_rho_every > 0 && (iter % P.adaptive_rho_every) == 0;
             const bool last = iter >= P.max_iter;
+#ifdef A1X_CLK
+            const long long t1_ = clock64();
+#endif
             update_info();
+#ifdef A1X_CLK
+            clkU += clock64() - t1_;
+#endif
             if (can_check && check_termination(false)) {
                 done = true;
             } else {
@@ -1211,14 +1305,14 @@ struct RowSolver {
             const double f = nanout ? nanv : xh[0];
             const double f0 = quad_perm<0, 0, 0, 0>(f), f1 = quad_perm<1, 1, 1, 1>(f), f2 = quad_perm<2, 2, 2, 2>(f);
             const bool bad = (f0 != f0) || (f1 != f1) || (f2 != f2);
-            if (act) {  // R' f (S/A1RobotControl.cpp:558-561); non-finite solution -> zeros + status
+            if (wr) {  // R' f (S/A1RobotControl.cpp:558-561); non-finite solution -> zeros + status
                 const double gb = io.R[0 * 3 + comp] * f0 + io.R[1 * 3 + comp] * f1 + io.R[2 * 3 + comp] * f2;
                 io.grf[3 * quad + comp] = bad ? 0.0 : gb;
             }
         }
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
-            if (act) {
+            if (wr) {
                 const double xu = nanout ? nanv : xh[t];
                 if (io.u_full) io.u_full[t * 12 + ci] = xu;
                 // A failed solve must not poison the carried workspace (every later tick of this robot would start from NaN): the next
@@ -1232,7 +1326,10 @@ struct RowSolver {
                 }
             }
         });
-        if (ln == 0) {
+#ifdef A1X_CLK
+        if (ln == 0 && !twin && io.u_full) { io.u_full[0] = double(clkB); io.u_full[12] = double(clkF); io.u_full[24] = double(clkT); io.u_full[36] = double(clkU); io.u_full[48] = double(clkX); }
+#endif
+        if (ln == 0 && !twin) {
             if (io.iters) *io.iters = iter;
             if (io.status) *io.status = status_out;
             if (io.nfact) *io.nfact = nfact;
@@ -1307,23 +1404,25 @@ A1_DEV void setup_row(const BatchArgs& a, const double* __restrict__ tab, int64_
 // split pipeline, kernel 2: a persistent row.  It pulls prepared QPs from a shared counter and advances them one
 // checkpoint-aligned segment per loop trip; a row whose QP has converged writes it out and pulls the next one at the next
 // trip, so the rows of a wave never wait for each other's iteration counts -- only for each other's (rare) re-factorisations.
-template <int H>
+template <int H, bool TWIN = false>
 A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* __restrict__ counter, double* __restrict__ lds) {
-    RowSolver<H, kModeMpc> S(a.P, a.tab, lds);
+    RowSolver<H, kModeMpc, false, false, TWIN> S(a.P, a.tab, lds);
     bool alive = true, need_new = true, have = false;
     int64_t cur = 0;
     while (alive) {
         if (need_new) {
             if (have) {
                 S.write_outputs(make_io<H, kModeMpc>(a, cur));
-                if (a.cost != nullptr && S.ln == 0) a.cost[cur] = S.iter + 10 * S.nfact;  // ~ ADMM-iteration equivalents (a factor pass ~ 10)
+                if (a.cost != nullptr && S.ln == 0 && !S.twin) a.cost[cur] = S.iter + 10 * S.nfact;  // ~ ADMM-iteration equivalents (a factor pass ~ 10)
             }
             double v = 0.0;
-            if (S.ln == 0) {
+            if (S.ln == 0 && !S.twin) {
                 const int q = row_atomic_inc(counter);
                 v = static_cast<double>((q < a.n && a.order != nullptr) ? a.order[q] : q);
             }
-            cur = static_cast<int64_t>(row_bcast<0>(v));
+            v = row_bcast<0>(v);
+            if constexpr (TWIN) v = twin_from_main(v);  // the twin row works on its main row's QP
+            cur = static_cast<int64_t>(v);
             if (cur >= a.n) {
                 alive = false;
             } else {

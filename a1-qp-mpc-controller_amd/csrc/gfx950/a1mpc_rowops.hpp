@@ -125,19 +125,50 @@ A1_DEV void sweep_back_rhs(double& r, double& pa, double& pb, double at, double 
         : "=&v"(r), "=&v"(rb), "=&v"(pa), "+v"(pb)
         : "v"(at), "v"(cg), "v"(sd), "v"(xh), "v"(p), "v"(Bt[0]), "v"(Bt[1]), "v"(Bt[2]), "v"(Bt[3]), "v"(Bt[4]), "v"(Bt[5]), "v"(gA), "v"(gB), "v"(gC));
 }
-// d = S^-1 r (row Sr) interleaved with p_t = (pa + pb) + K' r (column Kc); the costate chain runs two terms ahead so that its
-// final add is followed by two d-chain instructions.  Returns p_t in pa.
+// the same for a row that has a twin (persistent ADMM kernel, see twin_exchange): the costate seed is  pa = hm * p  with hm = 1 on the main
+// row and 0 on its twin (whose accumulators carry the d chain and must start from zero; gA, gB, gC and pb come in masked the same way)
+A1_DEV void sweep_back_rhs_twin(double& r, double& pa, double& pb, double at, double cg, double sd, double xh, double p, const double (&Bt)[6],
+                                double gA, double gB, double gC, double hm) {
+    double rb;
+    asm("v_add_f64 %0, %4, -%5\n"
+        "v_mul_f64 %1, %6, %7\n"
+        "v_mul_f64 %2, %8, %18\n"
+        A1_FNMA("%0", "%8", "%9", 8) A1_FNMA("%1", "%8", "%10", 9) A1_FMAC("%2", "%8", "%15", 0)
+        A1_FNMA("%0", "%8", "%11", 10) A1_FNMA("%1", "%8", "%12", 12)
+        A1_FNMA("%0", "%8", "%13", 13) A1_FNMA("%1", "%8", "%14", 14)
+        "v_add_f64 %0, %0, %1\n"
+        A1_FMAC("%3", "%8", "%16", 1) A1_FMAC("%2", "%8", "%17", 2)
+        : "=&v"(r), "=&v"(rb), "=&v"(pa), "+v"(pb)
+        : "v"(at), "v"(cg), "v"(sd), "v"(xh), "v"(p), "v"(Bt[0]), "v"(Bt[1]), "v"(Bt[2]), "v"(Bt[3]), "v"(Bt[4]), "v"(Bt[5]), "v"(gA), "v"(gB), "v"(gC),
+          "v"(hm));
+}
+// One chain pair for a row and its twin:  (pa, pb) += sum_b M[b] r[b]  (even b into pa, odd b into pb),  pa <- pa + pb.  On the main row M is
+// column `ci` of K_t and the pair arrives seeded with A' p_{t+1} (result: the costate p_t); on the twin M is row `ci` of S_t^-1 and the seeds are
+// zero (result: d_t = S_t^-1 r).  ONE instruction stream and ONE LDS read per term serve both products.  r: written >= 2 instructions ago.
+A1_DEV void sweep_back_chain_twin(double& pa, double& pb, double r, const double (&M)[12]) {
+    asm(A1_FMAC("%0", "%2", "%3", 0) A1_FMAC("%1", "%2", "%4", 1) A1_FMAC("%0", "%2", "%5", 2) A1_FMAC("%1", "%2", "%6", 4)
+        A1_FMAC("%0", "%2", "%7", 5) A1_FMAC("%1", "%2", "%8", 6) A1_FMAC("%0", "%2", "%9", 8) A1_FMAC("%1", "%2", "%10", 9)
+        A1_FMAC("%0", "%2", "%11", 10) A1_FMAC("%1", "%2", "%12", 12) A1_FMAC("%0", "%2", "%13", 13) A1_FMAC("%1", "%2", "%14", 14)
+        "v_add_f64 %0, %0, %1\n"
+        : "+v"(pa), "+v"(pb)
+        : "v"(r), "v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]), "v"(M[4]), "v"(M[5]), "v"(M[6]), "v"(M[7]), "v"(M[8]), "v"(M[9]), "v"(M[10]), "v"(M[11]));
+}
+// d = S^-1 r (row Sr; even terms + odd terms, two accumulators: the arithmetic of sweep_back_chain_twin) interleaved with
+// p_t = (pa + pb) + K' r (column Kc); the costate chain runs ahead so that its final add is followed by >= 2 instructions.  Returns p_t in pa.
 A1_DEV void sweep_back_chains(double& d, double& pa, double& pb, double r, const double (&Sr)[12], const double (&Kc)[12]) {
+    double db;
     asm("v_mov_b64 %0, 0\n"
-        A1_FMAC("%1", "%3", "%16", 0) A1_FMAC("%2", "%3", "%17", 1)
-        A1_FMAC("%0", "%3", "%4", 0) A1_FMAC("%1", "%3", "%18", 2) A1_FMAC("%0", "%3", "%5", 1) A1_FMAC("%2", "%3", "%19", 4)
-        A1_FMAC("%0", "%3", "%6", 2) A1_FMAC("%1", "%3", "%20", 5) A1_FMAC("%0", "%3", "%7", 4) A1_FMAC("%2", "%3", "%21", 6)
-        A1_FMAC("%0", "%3", "%8", 5) A1_FMAC("%1", "%3", "%22", 8) A1_FMAC("%0", "%3", "%9", 6) A1_FMAC("%2", "%3", "%23", 9)
-        A1_FMAC("%0", "%3", "%10", 8) A1_FMAC("%1", "%3", "%24", 10) A1_FMAC("%0", "%3", "%11", 9) A1_FMAC("%2", "%3", "%25", 12)
-        A1_FMAC("%0", "%3", "%12", 10) A1_FMAC("%1", "%3", "%26", 13) A1_FMAC("%0", "%3", "%13", 12) A1_FMAC("%2", "%3", "%27", 14)
+        "v_mov_b64 %3, 0\n"
+        A1_FMAC("%1", "%4", "%17", 0) A1_FMAC("%2", "%4", "%18", 1)
+        A1_FMAC("%0", "%4", "%5", 0) A1_FMAC("%1", "%4", "%19", 2) A1_FMAC("%3", "%4", "%6", 1) A1_FMAC("%2", "%4", "%20", 4)
+        A1_FMAC("%0", "%4", "%7", 2) A1_FMAC("%1", "%4", "%21", 5) A1_FMAC("%3", "%4", "%8", 4) A1_FMAC("%2", "%4", "%22", 6)
+        A1_FMAC("%0", "%4", "%9", 5) A1_FMAC("%1", "%4", "%23", 8) A1_FMAC("%3", "%4", "%10", 6) A1_FMAC("%2", "%4", "%24", 9)
+        A1_FMAC("%0", "%4", "%11", 8) A1_FMAC("%1", "%4", "%25", 10) A1_FMAC("%3", "%4", "%12", 9) A1_FMAC("%2", "%4", "%26", 12)
+        A1_FMAC("%0", "%4", "%13", 10) A1_FMAC("%1", "%4", "%27", 13) A1_FMAC("%3", "%4", "%14", 12) A1_FMAC("%2", "%4", "%28", 14)
         "v_add_f64 %1, %1, %2\n"
-        A1_FMAC("%0", "%3", "%14", 13) A1_FMAC("%0", "%3", "%15", 14)
-        : "=&v"(d), "+v"(pa), "+v"(pb)
+        A1_FMAC("%0", "%4", "%15", 13) A1_FMAC("%3", "%4", "%16", 14)
+        "v_add_f64 %0, %0, %3\n"
+        : "=&v"(d), "+v"(pa), "+v"(pb), "=&v"(db)
         : "v"(r), "v"(Sr[0]), "v"(Sr[1]), "v"(Sr[2]), "v"(Sr[3]), "v"(Sr[4]), "v"(Sr[5]), "v"(Sr[6]), "v"(Sr[7]), "v"(Sr[8]), "v"(Sr[9]), "v"(Sr[10]),
           "v"(Sr[11]), "v"(Kc[0]), "v"(Kc[1]), "v"(Kc[2]), "v"(Kc[3]), "v"(Kc[4]), "v"(Kc[5]), "v"(Kc[6]), "v"(Kc[7]), "v"(Kc[8]), "v"(Kc[9]),
           "v"(Kc[10]), "v"(Kc[11]));
@@ -272,6 +303,28 @@ A1_DEV int64_t row_opaque(int64_t v) {
     return v;
 }
 
+
+// ---- twin rows (persistent ADMM kernel) ------------------------------------------------------------------------------------------
+// A wavefront costs the same issue slots with 32 or 64 live lanes, and the LDS image bounds residency at two QPs per wavefront: rows 2 and 3
+// would idle.  In the persistent ADMM kernel they run as TWINS of rows 0 and 1 -- the same QP, the same instruction stream, bit-identical
+// state and control flow -- except in the backward Riccati sweep, where the two 12-term products of a step on the same right-hand side
+// (K_t' r on the main row, S_t^-1 r on the twin) share one chain of v_fmac_f64_dpp and one LDS read per term, and the halves then swap results.
+A1_DEV bool row_is_twin() { return (static_cast<int>(threadIdx.x) & 32) != 0; }
+// a = [x | y] on (main | twin)  ->  a = [x | x], returns [y | y]: v_permlane32_swap (lanes 32-63 of vdst <-> lanes 0-31 of src) on both dwords.
+// Builtin, not asm: hipcc places the 2 wait states the swap needs after the copies itself.
+A1_DEV double twin_exchange(double& a) {
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, a);
+    const unsigned lo = static_cast<unsigned>(bits), hi = static_cast<unsigned>(bits >> 32);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    a = __builtin_bit_cast(double, static_cast<unsigned long long>(r0[0]) | (static_cast<unsigned long long>(r1[0]) << 32));
+    return __builtin_bit_cast(double, static_cast<unsigned long long>(r0[1]) | (static_cast<unsigned long long>(r1[1]) << 32));
+}
+// the twin takes its main row's value
+A1_DEV double twin_from_main(double v) {
+    (void)twin_exchange(v);
+    return v;
+}
 
 // true if the predicate holds on any live lane of the wavefront (= any row that is still running)
 A1_DEV bool row_wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }

@@ -2,7 +2,7 @@
 
 hipcc pads the hazards of the instructions it schedules itself, but not inside (or between) inline-asm statements, and the solver's
 v_fmac_f64_dpp chains are inline asm.  Rule (gfx90a+): a VGPR written by a VALU instruction needs 2 wait states before a DPP
-instruction reads it as its DPP source (src0); a VALU write of EXEC needs 5; the result of a transcendental instruction
+instruction reads it as its DPP source (src0), and the same before v_permlane16/32_swap reads either operand; a VALU write of EXEC needs 5; the result of a transcendental instruction
 (v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos) needs 1 before another VALU instruction reads it.  Every instruction in
 between counts as one wait state, `s_nop N` as N + 1.  A violated hazard reads the register's previous content: results that depend on which QP the row
 solved before.
@@ -75,6 +75,8 @@ def _step(hist, op, ops, rest_first):
         w = frozenset()
         if op.startswith("v_") and ops and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
             w = frozenset(_regs(ops[0].split(" ")[0]))
+            if op.startswith(("v_permlane16_swap", "v_permlane32_swap", "v_swap_")) and len(ops) >= 2:  # both operands are written
+                w = w | frozenset(_regs(ops[1].split(" ")[0]))
         hist = hist + [(w, op.startswith("v_cmpx"), op.startswith(_TRANS))]
     return hist[-_DEPTH:]
 
@@ -138,6 +140,11 @@ def dpp_hazards(path, key=""):
                     srcs = set().union(*[_regs(o.split(" ")[0]) for o in (ops if op.startswith("v_fmac") else ops[1:])]) if ops else set()
                     if h[-1][0] & srcs:
                         out.append(f"{path}:{ln}: {kernel[:60]}: result of a transcendental instruction read by the next instruction: {t}")
+                if op.startswith(("v_permlane16_swap", "v_permlane32_swap")) and len(ops) >= 2:  # twin_exchange: both operands are read, 2 wait states after a VALU write
+                    rd = _regs(ops[0].split(" ")[0]) | _regs(ops[1].split(" ")[0])
+                    for age, (w, _ex, _tr) in enumerate(reversed(h[-2:]), 1):
+                        if w & rd:
+                            out.append(f"{path}:{ln}: {kernel[:60]}: v_permlane*_swap operand written {age} instruction(s) earlier: {t}")
                 if "_dpp" in op and len(ops) >= 2:
                     s0 = _regs(ops[1].split(" ")[0])
                     for age, (w, ex, _tr) in enumerate(reversed(h[-5:]), 1):  # age - 1 = wait states between the write and this read

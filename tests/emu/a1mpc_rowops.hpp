@@ -67,15 +67,22 @@ inline void sweep_back_rhs(double& r, double& pa, double& pb, double at, double 
 }
 inline void sweep_back_chains(double& d, double& pa, double& pb, double r, const double (&Sr)[12], const double (&Kc)[12]) {
     const double* R_ = emu_publish(r);
-    double da = 0.0;
+    double da = 0.0, db = 0.0;  // even / odd terms, like the gfx950 block
     for (int b = 0; b < 12; ++b) {
-        da = fma(R_[emu_detail::LANE[b]], Sr[b], da);
+        double& dacc = (b & 1) ? db : da;
+        dacc = fma(R_[emu_detail::LANE[b]], Sr[b], dacc);
         double& pacc = (b & 1) ? pb : pa;
         pacc = fma(R_[emu_detail::LANE[b]], Kc[b], pacc);
     }
     pa = pa + pb;
-    d = da;
+    d = da + db;
 }
+// twin rows exist only in the persistent ADMM kernel of the device build (RowSolver<.., TWIN = true> is never instantiated here)
+inline bool row_is_twin() { return false; }
+inline double twin_exchange(double& a) { return a; }
+inline double twin_from_main(double v) { return v; }
+inline void sweep_back_rhs_twin(double&, double&, double&, double, double, double, double, double, const double (&)[6], double, double, double, double) {}
+inline void sweep_back_chain_twin(double&, double&, double, const double (&)[12]) {}
 inline double dot12_block(const double (&m)[12], double x) {
     const double* X_ = emu_publish(x);
     double a0 = 0.0, a1 = 0.0;

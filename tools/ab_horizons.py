@@ -9,7 +9,7 @@ if "--child" not in sys.argv:
     sys.exit(0)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
-pkg = g.load_package(); pkg.engine._lib = None; pkg.engine.load_library(sys.argv[1])
+pkg = g.load_package(); pkg.engine._lib = pkg.engine.load_library(sys.argv[1])  # (load_library only caches the in-tree path)
 res = {}
 for gen, n, h in (("config4_random_h16", 8192, 16), ("config5_divergent", 16384, 20)):
     sc = getattr(pkg.scenarios, gen)(nb=n)

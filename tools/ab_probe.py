@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """A/B of two builds of liba1mpc.so on the same box: kernel ms at a few batch sizes (history order = the steadiest measurement).
-usage: ab_probe.py libA.so libB.so"""
+usage: ab_probe.py libA.so libB.so [libC.so ...] [--only n] [--fixed k]"""
 import ctypes as C, os, sys, subprocess, json
 import numpy as np
 if "--child" not in sys.argv:
     res = {}
-    for lib in sys.argv[1:3]:
-        out = subprocess.run([sys.executable, __file__, lib, "--child"] + [a for a in sys.argv[3:]], capture_output=True, text=True, timeout=150)
+    libs = [a for a in sys.argv[1:] if a.endswith(".so")]
+    rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
+    for lib in libs:
+        out = subprocess.run([sys.executable, __file__, lib, "--child"] + rest, capture_output=True, text=True, timeout=90)
         res[os.path.basename(lib)] = json.loads(out.stdout.strip().splitlines()[-1])
     print(json.dumps(res, indent=1))
     sys.exit(0)
@@ -14,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
 pkg.engine._lib = None
-pkg.engine.load_library(sys.argv[1]) if "r01" not in sys.argv[1] else None
+pkg.engine._lib = pkg.engine.load_library(sys.argv[1]) if "r01" not in sys.argv[1] else None  # (load_library only caches the in-tree path)
 if "r01" in sys.argv[1]:   # the round-1 library exports fewer symbols: bind by hand what the probe needs
     lib = C.CDLL(sys.argv[1]); pkg.engine._lib = None
     real = pkg.engine.load_library
