@@ -225,8 +225,9 @@ struct Prep {
 // evaluated on the fly from the per-step tables (6 FMAs per entry instead of 1), the Riccati sweeps read B~_t and the bounds per step
 // from LDS.  Same iterates as the oracle's strided formation; slower (bigger LDS image, more reads) and only in the fused kernel.
 // TWIN = true (persistent ADMM kernel only): this row runs as one of a main / twin pair of DPP rows on the SAME QP (row_is_twin(),
-// a1mpc_rowops.hpp).  Both rows execute everything redundantly -- identical registers, identical control flow, only the main row stores --
-// except the two 12-term products of a backward-sweep step, which they split (admm_iteration).
+// a1mpc_rowops.hpp).  The pair shares the control flow (every decision is taken on values both rows hold) and the LDS image; it splits the
+// per-lane ADMM state by horizon step (main row: even steps, twin: odd steps) and the two products of a backward-sweep step
+// (admm_iteration_twin); everything sequential over the steps is computed redundantly by both rows.
 template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false, bool TWIN = false>
 struct RowSolver {
     static_assert(!GEN || (MODE == kModeMpc && !SETUP_ONLY && H > 1), "the general path is an MPC solve in the fused kernel");
@@ -239,13 +240,15 @@ struct RowSolver {
     // lane identity
     int ln, quad, comp, ci, tri, krow;
     bool act, wl;
-    bool twin, wr;    // TWIN: second row of the pair / this lane stores (act && !twin)
+    bool twin, wr;    // TWIN: second row of the pair / this lane stores what both rows hold (act && !twin)
+    int tw;           // 0 / 1: my steps are 2k + tw
     double hm, gAm, gBm, gCm, gVm;  // TWIN: 1 (main) / 0 (twin) and the costate-seed multipliers masked by it (sweep_back_rhs_twin)
     const double* brow;
     double dt, mu;
     // per-lane constants of the problem
     double Bt[6];  // my column of B~ (force layout); zero on pad lanes
-    static constexpr bool kBrowInRegs = H <= 10 && !GEN;  // beyond that the per-lane ADMM state alone (6H doubles) overflows the register file
+    static constexpr bool kBrowInRegs = (H <= 10 && !GEN) || TWIN;  // beyond that the per-lane ADMM state alone (6H doubles; 3H for a twin pair) overflows the register file
+    static constexpr int HS = TWIN ? H / 2 : H;  // slots of the per-lane state: slot k = step k, or step 2k + tw of a twin pair
     double Brw[12];  // my row of B~ (state layout; zeros on lanes without a wrench state): step-invariant, so it stays in registers --
                      // an LDS read costs the wave ~12 issue cycles whatever its width (tools/ubench/issue_cost_ubench.hip)
     double cy, sy, fA, fB, fC, fP, gA, gB, gC, gV, q2s, r2a;
@@ -253,7 +256,7 @@ struct RowSolver {
     unsigned eqmask;  // bit t: my slot-0 row at step t is an equality row (swing leg: l = u = 0; auxil.c set_rho_vec)
     int r0, r1;       // reference row numbers of my two rows inside a (step, leg) block
     // hot state (see setup()): 6 doubles per horizon step and lane
-    double xh[H], wh0[H], wh1[H], rr0[H], rr1[H], dI2[H];
+    double xh[HS], wh0[HS], wh1[HS], rr0[HS], rr1[HS], dI2[HS];
     double rho;
     bool warm, first_special;
     int coop_id = 0, coop_n = 1;  // set-up only: row coop_id of coop_n rows of the wave that work on the SAME QP (batch-1 latency path), sharing its LDS image
@@ -276,6 +279,7 @@ struct RowSolver {
         quad = ln >> 2; comp = ln & 3;
         act = comp < 3;
         twin = TWIN && row_is_twin();
+        tw = twin ? 1 : 0;
         wr = act && !twin;
         hm = twin ? 0.0 : 1.0;
         ci = act ? 3 * quad + comp : 0;  // compact index (safe 0 on pad lanes)
@@ -754,15 +758,30 @@ struct RowSolver {
         const double am = act ? 1.0 : 0.0;  // pad lanes read lane 0's record (ci == 0) and zero what must be zero
         const int fl = static_cast<int>(p[PR::FLAGS * 12 + ci]);
         warm = fl & 1; first_special = (fl & 2) != 0;
-        static_for<H>([&](auto T) {
-            constexpr int t = A1_CV(T);
-            rr0[t] = am * p[(PR::RR0 + t) * 12 + ci];
-            rr1[t] = am * p[(PR::RR1 + t) * 12 + ci];
-            dI2[t] = p[(PR::DI2 + t) * 12 + ci];
-            xh[t] = warm ? am * p[(PR::XH + t) * 12 + ci] : 0.0;
-            park_warm_y(io, t);
-            if (wr) lds[L::CG + t * 12 + ci] = p[(PR::CG + t) * 12 + ci];
-        });
+        if constexpr (TWIN) {
+            const int to = tw * 12;  // my step of slot k is 2k + tw: one record row further on the twin
+            static_for<HS>([&](auto K) {
+                constexpr int k = A1_CV(K);
+                rr0[k] = am * p[(PR::RR0 + 2 * k) * 12 + ci + to];
+                rr1[k] = am * p[(PR::RR1 + 2 * k) * 12 + ci + to];
+                dI2[k] = p[(PR::DI2 + 2 * k) * 12 + ci + to];
+                xh[k] = warm ? am * p[(PR::XH + 2 * k) * 12 + ci + to] : 0.0;
+                const int t = 2 * k + tw;
+                wh0[k] = (warm && act) ? io.warm_y[t * 20 + 5 * quad + r0] : 0.0;  // park_warm_y()
+                wh1[k] = (warm && act && comp < 2) ? io.warm_y[t * 20 + 5 * quad + r1] : 0.0;
+                if (act) lds[L::CG + 2 * k * 12 + ci + to] = p[(PR::CG + 2 * k) * 12 + ci + to];
+            });
+        } else {
+            static_for<H>([&](auto T) {
+                constexpr int t = A1_CV(T);
+                rr0[t] = am * p[(PR::RR0 + t) * 12 + ci];
+                rr1[t] = am * p[(PR::RR1 + t) * 12 + ci];
+                dI2[t] = p[(PR::DI2 + t) * 12 + ci];
+                xh[t] = warm ? am * p[(PR::XH + t) * 12 + ci] : 0.0;
+                park_warm_y(io, t);
+                if (act) lds[L::CG + t * 12 + ci] = p[(PR::CG + t) * 12 + ci];
+            });
+        }
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             Bt[k] = am * p[(PR::BT + k) * 12 + ci];
@@ -789,7 +808,7 @@ struct RowSolver {
         const double sigma_f = row_opaque(P.sigma);
         // stage W_t = c R + sigma D^-2 + A_t' (E^2 rho) A_t  (block-diagonal, 3x3 per leg) into slot t: my row of my leg's block
         row_sync();
-        static_for<H>([&](auto T) {
+        static_for<HS>([&](auto T) {  // (a twin pair: each row stages the W_t of its own steps)
             const double a0 = rr0[T], a1 = rr1[T];
             const double sp = a0 + a1;
             const double spx = quad_perm<0, 0, 0, 0>(sp), spy = quad_perm<1, 1, 1, 1>(sp);
@@ -797,12 +816,10 @@ struct RowSolver {
             const double wd = act ? (comp == 2 ? base + a0 + mu * mu * (spx + spy) : base + sp) : 0.0;
             const double wo = comp < 2 ? mu * (a0 - a1) : 0.0;
             const double wox = quad_perm<0, 0, 0, 0>(wo), woy = quad_perm<1, 1, 1, 1>(wo);
-            double* w = lds + L::FAC + T * L::SLOT + L::K_SZ + 3 * ln;  // staged in the S area of the slot (the K area's pad column carries G)
-            if (!twin) {
-                w[0] = comp == 0 ? wd : (comp == 2 ? wox : 0.0);
-                w[1] = comp == 1 ? wd : (comp == 2 ? woy : 0.0);
-                w[2] = comp == 2 ? wd : wo;
-            }
+            double* w = lds + L::FAC + (TWIN ? 2 * A1_CV(T) + tw : A1_CV(T)) * L::SLOT + L::K_SZ + 3 * ln;  // staged in the S area of the slot (the K area's pad column carries G)
+            w[0] = comp == 0 ? wd : (comp == 2 ? wox : 0.0);
+            w[1] = comp == 1 ? wd : (comp == 2 ? woy : 0.0);
+            w[2] = comp == 2 ? wd : wo;
         });
         row_sync();
         // lane constants of this pass: component indicators (1.0 / 0.0).  "Add on my diagonal entry only" is one v_fmac_f64_dpp with
@@ -923,21 +940,13 @@ struct RowSolver {
     // sweeps; the right-hand side is formed inside the backward sweep and the x / w updates consume v_t inside the
     // forward sweep, so only d_t crosses between the sweeps.
     // FIRST: OSQP's iteration 1 starts from z0 = A x0 (not projected) and y0 (warm start).
-    // TWIN: the LDS reads of backward step t (one entry per term: the main row's K_t column, the twin's S_t^-1 row; and c g_t).
-    // (Carrying the reads of step H - 1 from one iteration into the next -- issued behind the last forward step -- was measured: the 26 loop-carried
-    // registers push ten loop invariants into scratch, 2.95 -> 3.56 us per iteration.)
-    struct SweepPre { double M[12]; double cg; };
-    template <int T_>
-    A1_DEV void issue_back_reads(SweepPre& q) const {
-        const double* slot = lds + L::FAC + T_ * L::SLOT;
-        static_for<12>([&](auto B) {
-            constexpr int b = A1_CV(B);
-            q.M[b] = slot[twin ? L::K_SZ + (b <= ci ? tri + b : b * (b + 1) / 2 + ci) : b * L::KSTR + ci];  // (t = 0: the main row's value is unused)
-        });
-        q.cg = lds[L::CG + T_ * 12 + ci];
-    }
     template <bool FIRST, bool CAREFUL = false>
     A1_DEV void admm_iteration() {
+        if constexpr (TWIN) admm_iteration_twin<FIRST, CAREFUL>();
+        else admm_iteration_single<FIRST, CAREFUL>();
+    }
+    template <bool FIRST, bool CAREFUL>
+    A1_DEV void admm_iteration_single() {
         // Loop-invariant scalars are laundered through row_opaque() once per iteration: otherwise LICM hoists every
         // per-step product that only depends on them out of the ADMM loop and the register file overflows.
         const double sigma_l = row_opaque(P.sigma), lb0_l = row_opaque(lb0), ub0_l = row_opaque(ub0);
@@ -948,34 +957,17 @@ struct RowSolver {
         // adds), independent chains are interleaved by hand, subtraction rides on the NEG modifier of v_fmac_f64_dpp.
         double d[H];
         double pv = 0.0;  // costate p_{t+1}, state layout (dpp-ready at the top of every step)
-#ifdef A1X_CLK
-        const long long c0_ = clock64();
-#endif
-        // TWIN: the LDS reads of a step are issued as soon as the block that consumed the previous step's has been issued (into the registers it
-        // frees): with one wave per SIMD nothing else hides an LDS round trip.
-        [[maybe_unused]] double Kq[1][12];
-        [[maybe_unused]] SweepPre pre;
-        if constexpr (TWIN) { issue_back_reads<H - 1>(pre); row_sched_fence(); }
-        [[maybe_unused]] auto issue_back = [&](auto TQ) { issue_back_reads<A1_CV(TQ)>(pre); };
-        [[maybe_unused]] auto issue_fwd = [&](auto TQ) {
-            constexpr int t = A1_CV(TQ);
-            const double* slot = lds + L::FAC + t * L::SLOT;
-            static_for<12>([&](auto B) { Kq[0][A1_CV(B)] = slot[krow + A1_CV(B)]; });
-        };
         static_for<H>([&](auto TT) {
             constexpr int t = H - 1 - A1_CV(TT);
             const double* slot = lds + L::FAC + t * L::SLOT;
             // issue this step's LDS reads first: their latency overlaps the right-hand-side arithmetic below
-            [[maybe_unused]] double Sr[12], Kc[12];
-            if constexpr (!TWIN) {
-                static_for<12>([&](auto B) {
-                    constexpr int b = A1_CV(B);
-                    Sr[b] = slot[L::K_SZ + (b <= ci ? tri + b : b * (b + 1) / 2 + ci)];
-                    if constexpr (t > 0) Kc[b] = slot[b * L::KSTR + ci];
-                });
-            }
-            double cgt;
-            if constexpr (TWIN) cgt = pre.cg; else cgt = lds[L::CG + t * 12 + ci];
+            double Sr[12], Kc[12];
+            static_for<12>([&](auto B) {
+                constexpr int b = A1_CV(B);
+                Sr[b] = slot[L::K_SZ + (b <= ci ? tri + b : b * (b + 1) / 2 + ci)];
+                if constexpr (t > 0) Kc[b] = slot[b * L::KSTR + ci];
+            });
+            const double cgt = lds[L::CG + t * 12 + ci];
             [[maybe_unused]] double Btl[6];
             if constexpr (GEN) Bt_at(t, Btl);
             const double lbt = GEN ? lb_at(t) : lb0_l, ubt = GEN ? ub_at(t) : ub0_l;
@@ -999,55 +991,30 @@ struct RowSolver {
             const double sd = sigma_l * dI2[t];
             double r, pa = 0.0, pb = 0.0;
             if constexpr (t < H - 1) {
-                if constexpr (TWIN) {
-                    if constexpr (t > 0) pb = gVm * row_ror<8>(pv);
-                    sweep_back_rhs_twin(r, pa, pb, at, cgt, sd, xh[t], pv, Bt, gAm, gBm, gCm, hm);
-                } else {
-                    if constexpr (t > 0) pb = gV * row_ror<8>(pv);
-                    if constexpr (GEN) sweep_back_rhs(r, pa, pb, at, cgt, sd, xh[t], pv, Btl, gA, gB, gC);
-                    else sweep_back_rhs(r, pa, pb, at, cgt, sd, xh[t], pv, Bt, gA, gB, gC);
-                }
+                if constexpr (t > 0) pb = gV * row_ror<8>(pv);
+                if constexpr (GEN) sweep_back_rhs(r, pa, pb, at, cgt, sd, xh[t], pv, Btl, gA, gB, gC);
+                else sweep_back_rhs(r, pa, pb, at, cgt, sd, xh[t], pv, Bt, gA, gB, gC);
             } else {
                 r = row_dpp_ready(fma(sd, xh[t], at - cgt));  // p_H = 0
             }
-            if constexpr (!TWIN) row_lds_landed();
-            if constexpr (TWIN) {
-                // main row: p_t = A' p_{t+1} + K_t' r;  twin: d_t = S_t^-1 r (same arithmetic as sweep_back_chains / dot12_block: even terms + odd terms);
-                // then the halves swap: both rows hold p_t and d_t again.  (hipcc places the s_waitcnt that lets the NEXT step's reads stay in flight)
-                sweep_back_chain_twin(pa, pb, r, pre.M);
-                row_sched_fence();
-                if constexpr (t > 0) issue_back(std::integral_constant<int, (t > 0 ? t - 1 : 0)>{});  // the next step's reads, into the registers the chain has just freed
-                else issue_fwd(std::integral_constant<int, 1>{});
-                row_sched_fence();
-                d[t] = twin_exchange(pa);
-                pv = pa;
-            } else if constexpr (t > 0) {
+            row_lds_landed();
+            if constexpr (t > 0) {
                 sweep_back_chains(d[t], pa, pb, r, Sr, Kc);
                 pv = pa;
             } else {
                 d[t] = dot12_block(Sr, r);
             }
         });
-#ifdef A1X_CLK
-        const long long c1_ = clock64();
-#endif
         double s = 0.0;  // state x_t of the LQ roll-out (x_0 = 0); dpp-ready at the top of every step
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
             const double* slot = lds + L::FAC + t * L::SLOT;
             // issue this step's LDS reads first (K_t row): they overlap the previous step's w update
             double Kr[12];
-            if constexpr (TWIN) {
-                if constexpr (t > 0) {
-#pragma unroll
-                    for (int b = 0; b < 12; ++b) Kr[b] = Kq[0][b];
-                }
-            } else {
-                static_for<12>([&](auto B) {
-                    constexpr int b = A1_CV(B);
-                    if constexpr (t > 0) Kr[b] = slot[krow + b];
-                });
-            }
+            static_for<12>([&](auto B) {
+                constexpr int b = A1_CV(B);
+                if constexpr (t > 0) Kr[b] = slot[krow + b];
+            });
             [[maybe_unused]] double Brl[12];  // H > 10: my row of B~ is re-read per step (the 24 registers are worth more than 6 LDS reads there)
             if constexpr (!kBrowInRegs && t < H - 1) {
                 const double* br = brow_at(t);
@@ -1068,7 +1035,7 @@ struct RowSolver {
                 gt0 = rr0[t] * fma(2.0, zp0, -wh0[t]);
                 gt1 = rr1[t] * fma(2.0, zp1, -wh1[t]);
             }
-            if constexpr (!TWIN) row_lds_landed();
+            row_lds_landed();
             if constexpr (t == 0) {
                 v = row_dpp_ready(am * v);  // x_0 = 0
                 xh[t] = fma(al, v, oma * xh[t]);
@@ -1077,11 +1044,6 @@ struct RowSolver {
                 sweep_fwd_gain<true>(v, sa, sb, xh[t], s, Kr, fA, fB, fC, am, oma, al);
             } else {
                 sweep_fwd_gain<false>(v, sa, sb, xh[t], s, Kr, fA, fB, fC, am, oma, al);
-            }
-            if constexpr (TWIN) {  // the next step's K row, into the registers sweep_fwd_gain has just freed: the input chain and the w update hide the round trip
-                row_sched_fence();
-                if constexpr (t > 0 && t < H - 1) issue_fwd(std::integral_constant<int, (t < H - 1 ? t + 1 : 1)>{});
-                row_sched_fence();
             }
             if constexpr (t < H - 1) {
                 if constexpr (kBrowInRegs) sweep_fwd_input(sa, sb, z0, v, Brw, wh0[t], lbt, ubt);
@@ -1103,7 +1065,7 @@ struct RowSolver {
                 const double atd = fma(muz, sdx + sdy, d0 + d1);
                 const double T = fma(sigma_l * dI2[t], xh_old - v, atd);
                 double* G = lds + L::FAC + t * L::SLOT + ci * L::KSTR + L::GCOL;
-                if (wr) *G = fma(al, T, oma * *G);
+                if (act) *G = fma(al, T, oma * *G);
             }
             if constexpr (FIRST) {  // w1 = alpha z~ + (1 - alpha) z0 + y0 / rho,  z0 = A x0
                 const double xz = xz_first;
@@ -1117,17 +1079,201 @@ struct RowSolver {
                 wh1[t] = fma(al1, av1 - z1, wh1[t]);  // stays 0 on fz lanes
             }
         });
+    }
+
+    // ---------------------------------------------------------------- the same iteration for a main / twin pair of rows (TWIN)
+    // The pair splits (a) the per-lane state: slot k of xh / wh / rr / dI2 is horizon step 2k on the main row and 2k + 1 on the twin, so all
+    // element-wise work (projection, right-hand side, x / w update) is issued once per PAIR of steps and the register file holds half the
+    // state; and (b) the two 12-term products of a backward step on the same right-hand side: one chain of v_fmac_f64_dpp and one LDS read
+    // per term compute K_t' r on the main row and S_t^-1 r on the twin.  Everything that is sequential over the steps (the costate, the
+    // roll-out) is computed redundantly and bit-identically by both rows; twin_exchange() moves the per-step values the other row needs
+    // (the right-hand-side data e_t, then p_t / d_t).  Every value is formed by the same operations in the same order as in the
+    // single-row code above: the two kernels agree bit for bit.
+    // LDS reads are issued as soon as the block that consumed the previous step's has been issued (into the registers it frees): with one
+    // wave per SIMD nothing else hides an LDS round trip.  (Carrying the first reads of the next iteration across the loop back-edge was
+    // measured: the loop-carried registers push loop invariants into scratch, 2.95 -> 3.56 us per iteration.)
+    template <int T_>
+    A1_DEV void issue_back_reads(double (&M)[12]) const {
+        const double* slot = lds + L::FAC + T_ * L::SLOT;
+        static_for<12>([&](auto B) {  // one read serves both rows: the main row's K_t column entry, the twin's S_t^-1 row entry (t = 0: the main row's value is unused)
+            constexpr int b = A1_CV(B);
+            M[b] = slot[twin ? L::K_SZ + (b <= ci ? tri + b : b * (b + 1) / 2 + ci) : b * L::KSTR + ci];
+        });
+    }
+    template <bool FIRST, bool CAREFUL>
+    A1_DEV void admm_iteration_twin() {
+        static_assert(H % 2 == 0, "twin rows split the horizon steps in pairs");
+        const double sigma_l = row_opaque(P.sigma), lb0_l = row_opaque(lb0), ub0_l = row_opaque(ub0);
+        const double al = P.alpha, oma = 1.0 - P.alpha;
+        const double muz = comp == 2 ? mu : 0.0, mux = comp < 2 ? mu : 0.0, al1 = comp < 2 ? al : 0.0;
+        const double am = act ? 1.0 : 0.0;  // pad lanes carry no force
+        const double* cgp = lds + L::CG + tw * 12 + ci;  // c g of my step of slot k: cgp[24 k]
+        double d[H];
+        double pv = 0.0;  // costate p_{t+1}, state layout
+        double M[12], Kq[12];
+        issue_back_reads<H - 1>(M);
+        double cgv = cgp[24 * (HS - 1)];
+        row_sched_fence();
+#ifdef A1X_CLK
+        const long long c0_ = clock64();
+#endif
+        // one step of the backward sweep: r = e_t - B~' p_{t+1};  main row: p_t = A' p_{t+1} + K_t' r,  twin: d_t = S_t^-1 r;  then the rows swap
+        auto back_step = [&](auto TQ, double e_t) {
+            constexpr int t = A1_CV(TQ);
+            double r = e_t, pa = 0.0, pb = 0.0;
+            if constexpr (t < H - 1) {
+                if constexpr (t > 0) pb = gVm * row_ror<8>(pv);
+                sweep_back_rhs_twin(r, pa, pb, pv, Bt, gAm, gBm, gCm, hm);
+            } else {
+                r = row_dpp_ready(r);  // p_H = 0
+            }
+            sweep_back_chain_twin(pa, pb, r, M);
+            row_sched_fence();
+            if constexpr (t > 0) issue_back_reads<(t > 0 ? t - 1 : 0)>(M);  // the next step's reads, into the registers the chain has just freed
+            else {
+                const double* slot1 = lds + L::FAC + 1 * L::SLOT;           // ... or the forward sweep's first K row
+                static_for<12>([&](auto B) { Kq[A1_CV(B)] = slot1[krow + A1_CV(B)]; });
+            }
+            row_sched_fence();
+            d[t] = twin_exchange(pa);
+            pv = pa;
+        };
+        static_for<HS>([&](auto KK) {
+            constexpr int k = HS - 1 - A1_CV(KK);
+            // my step's right-hand-side data  e = sigma D^-2 xh - c g + A' [E (rho z_s - y_s)]  (see the single-row code)
+            double t0, t1;
+            if constexpr (FIRST) {
+                const double xz = quad_perm<2, 2, 2, 2>(xh[k]);
+                const double yw0 = wh0[k], yw1 = wh1[k];
+                t0 = rr0[k] * (comp == 2 ? xh[k] : fma(mu, xz, xh[k])) - csc * yw0;
+                t1 = rr1[k] * fma(-mu, xz, xh[k]) - csc * yw1;
+            } else {
+                const double z0 = min_f64(max_f64(wh0[k], lb0_l), ub0_l), z1 = min_f64(wh1[k], 0.0);
+                t0 = rr0[k] * fma(2.0, z0, -wh0[k]);
+                t1 = rr1[k] * fma(2.0, z1, -wh1[k]);
+            }
+            const double sm = t0 - t1;
+            const double smx = quad_perm<0, 0, 0, 0>(sm), smy = quad_perm<1, 1, 1, 1>(sm);
+            const double at = fma(muz, smx + smy, t0 + t1);
+            double e = fma(sigma_l * dI2[k], xh[k], at - cgv);
+            if constexpr (k > 0) cgv = cgp[24 * (k > 0 ? k - 1 : 0)];
+            const double eo = twin_exchange(e);  // e: step 2k (the main row's) on both rows, eo: step 2k + 1 (the twin's)
+            back_step(std::integral_constant<int, 2 * k + 1>{}, eo);
+            back_step(std::integral_constant<int, 2 * k>{}, e);
+        });
+#ifdef A1X_CLK
+        const long long c1_ = clock64();
+#endif
+        double s = 0.0;  // state x_t of the LQ roll-out (x_0 = 0)
+        // one step of the forward sweep: v_t = d_t - K_t x_t,  x_{t+1} = A x_t + B~ v_t
+        auto fwd_step = [&](auto TQ) {
+            constexpr int t = A1_CV(TQ);
+            double v = d[t], sa = 0.0, sb = 0.0;
+            if constexpr (t == 0) {
+                v = row_dpp_ready(am * v);  // x_0 = 0
+            } else if constexpr (t < H - 1) {
+                sb = fP * row_ror<8>(s);
+                sweep_fwd_gain_twin<true>(v, sa, sb, s, Kq, fA, fB, fC, am);
+            } else {
+                sweep_fwd_gain_twin<false>(v, sa, sb, s, Kq, fA, fB, fC, am);
+            }
+            row_sched_fence();
+            if constexpr (t > 0 && t < H - 1) {  // the next step's K row, into the registers the gain block has just freed
+                const double* slotn = lds + L::FAC + (t + 1) * L::SLOT;
+                static_for<12>([&](auto B) { Kq[A1_CV(B)] = slotn[krow + A1_CV(B)]; });
+            }
+            row_sched_fence();
+            if constexpr (t < H - 1) {
+                sweep_fwd_input_twin(sa, sb, v, Brw);
+                s = row_dpp_ready(sa);  // lanes without a wrench state read the zero row of B~
+            }
+            return v;
+        };
+        static_for<HS>([&](auto K) {
+            constexpr int k = A1_CV(K);
+            const double va = fwd_step(std::integral_constant<int, 2 * k>{});
+            const double vb = fwd_step(std::integral_constant<int, 2 * k + 1>{});
+            const double v = twin ? vb : va;  // my step's v
+            // update_x / update_z / update_y of my step in the w form (see the single-row code)
+            [[maybe_unused]] double xz_first = 0.0;
+            if constexpr (FIRST) xz_first = quad_perm<2, 2, 2, 2>(xh[k]);
+            const double xh_old = xh[k];
+            [[maybe_unused]] double gt0 = 0.0, gt1 = 0.0;
+            if constexpr (CAREFUL) {
+                const double zp0 = min_f64(max_f64(wh0[k], lb0_l), ub0_l), zp1 = min_f64(wh1[k], 0.0);
+                gt0 = rr0[k] * fma(2.0, zp0, -wh0[k]);
+                gt1 = rr1[k] * fma(2.0, zp1, -wh1[k]);
+            }
+            const double z0 = min_f64(max_f64(wh0[k], lb0_l), ub0_l);
+            xh[k] = fma(al, v, oma * xh[k]);
+            const double vz = quad_perm<2, 2, 2, 2>(v);
+            const double av0 = fma(mux, vz, v);
+            const double av1 = fma(-mux, vz, v);
+            if constexpr (CAREFUL) {
+                const double d0 = fma(-rr0[k], av0, gt0), d1 = fma(-rr1[k], av1, gt1);
+                const double sdm = d0 - d1;
+                const double sdx = quad_perm<0, 0, 0, 0>(sdm), sdy = quad_perm<1, 1, 1, 1>(sdm);
+                const double atd = fma(muz, sdx + sdy, d0 + d1);
+                const double T = fma(sigma_l * dI2[k], xh_old - v, atd);
+                double* G = lds + L::FAC + (2 * k + tw) * L::SLOT + ci * L::KSTR + L::GCOL;
+                if (act) *G = fma(al, T, oma * *G);
+            }
+            if constexpr (FIRST) {
+                const double xz = xz_first;
+                const double yw0 = wh0[k], yw1 = wh1[k];
+                const double z00 = comp == 2 ? xh_old : fma(mu, xz, xh_old), z01 = fma(-mu, xz, xh_old);
+                wh0[k] = al * av0 + oma * z00 + (rr0[k] > 0.0 ? csc * yw0 / rr0[k] : 0.0);
+                wh1[k] = comp < 2 ? al * av1 + oma * z01 + (rr1[k] > 0.0 ? csc * yw1 / rr1[k] : 0.0) : 0.0;
+            } else {
+                const double z1 = min_f64(wh1[k], 0.0);
+                wh0[k] = fma(al, av0 - z0, wh0[k]);
+                wh1[k] = fma(al1, av1 - z1, wh1[k]);
+            }
+        });
 #ifdef A1X_CLK
         const long long c2_ = clock64();
         clkB += c1_ - c0_; clkF += c2_ - c1_;
 #endif
     }
 
+
     // ================================================================================ residuals (auxil.c compute_pri_res / compute_dua_res / ...)
+    // maximum over the lanes of my row -- and, for a twin pair, of both rows (the pair's norms run over all horizon steps)
+    A1_DEV double pair_allmax(double v) const {
+        v = row_allmax(v);
+        if constexpr (TWIN) {
+            const double o = twin_exchange(v);
+            v = max_f64(v, o);
+        }
+        return v;
+    }
     A1_DEV void update_info() {
         const double rho_c = row_opaque(rho), one_c = row_opaque(1.0);  // keep the cold path's invariants out of the hot loop's registers
-        double Pu[H];
-        {   // P u = B_qp' Q (B_qp u) + R u : roll-out, then adjoint
+        double Pu[HS];
+        if constexpr (TWIN) {
+            // a twin pair: both rows run the roll-out and the adjoint sweep over all steps (the rows swap their xh of every step pair);
+            // each keeps the (P u) of its own steps
+            double sv[H];
+            double s = row_dpp_ready(0.0);
+            static_for<HS>([&](auto K) {
+                constexpr int k = A1_CV(K);
+                double xa = xh[k];
+                const double xb = twin_exchange(xa);  // xa: step 2k (the main row's) on both rows, xb: step 2k + 1
+                s = row_dpp_ready(opA(s) + dot_bc<0>(Brw, row_dpp_ready(xa)));
+                sv[2 * k] = q2s * s;
+                s = row_dpp_ready(opA(s) + dot_bc<0>(Brw, row_dpp_ready(xb)));
+                sv[2 * k + 1] = q2s * s;
+            });
+            double lam = row_dpp_ready(0.0);
+            static_for<HS>([&](auto KK) {
+                constexpr int k = HS - 1 - A1_CV(KK);
+                lam = row_dpp_ready(sv[2 * k + 1] + opAT(lam));
+                const double b1 = BtT(lam);
+                lam = row_dpp_ready(sv[2 * k] + opAT(lam));
+                const double b0 = BtT(lam);
+                Pu[k] = fma(r2a, xh[k], twin ? b1 : b0);
+            });
+        } else {   // P u = B_qp' Q (B_qp u) + R u : roll-out, then adjoint
             double sv[H];
             double s = row_dpp_ready(0.0);
             static_for<H>([&](auto T) {
@@ -1155,15 +1301,16 @@ struct RowSolver {
         double m_pri = 0, m_upri = 0, m_z = 0, m_uz = 0, m_Ax = 0, m_uAx = 0;
         double m_dua = 0, m_udua = 0, m_q = 0, m_uq = 0, m_Aty = 0, m_uAty = 0, m_Px = 0, m_uPx = 0;
         const double irho = one_c / rho_c, irho_eq = one_c / (kRhoEqOverIneq * rho_c);
-        static_for<H>([&](auto T) {
-            constexpr int t = A1_CV(T);
-            const double uz = quad_perm<2, 2, 2, 2>(xh[t]);
-            const double ax0 = comp == 2 ? xh[t] : fma(mu, uz, xh[t]);  // E^-1 (A_s x)
-            const double ax1 = comp < 2 ? fma(-mu, uz, xh[t]) : 0.0;
-            const double z0 = min_f64(max_f64(wh0[t], lb_at(t)), ub_at(t)), z1 = min_f64(wh1[t], 0.0);  // E^-1 z
+        static_for<HS>([&](auto T) {
+            constexpr int k = A1_CV(T);            // slot
+            const int t = TWIN ? 2 * k + tw : k;   // its horizon step
+            const double uz = quad_perm<2, 2, 2, 2>(xh[k]);
+            const double ax0 = comp == 2 ? xh[k] : fma(mu, uz, xh[k]);  // E^-1 (A_s x)
+            const double ax1 = comp < 2 ? fma(-mu, uz, xh[k]) : 0.0;
+            const double z0 = min_f64(max_f64(wh0[k], lb_at(t)), ub_at(t)), z1 = min_f64(wh1[k], 0.0);  // E^-1 z
             const double rp0 = ax0 - z0, rp1 = ax1 - z1;
             const bool eq = (eqmask >> t) & 1u;
-            const double e0 = rr0[t] * (eq ? irho_eq : irho), e1 = rr1[t] * irho;  // E^2
+            const double e0 = rr0[k] * (eq ? irho_eq : irho), e1 = rr1[k] * irho;  // E^2
             m_upri = max_f64(m_upri, max_f64(fabs(rp0), fabs(rp1)));
             m_pri = max_f64(m_pri, max_f64(e0 * (rp0 * rp0), e1 * (rp1 * rp1)));
             m_uz = max_f64(m_uz, max_f64(fabs(z0), fabs(z1)));
@@ -1171,20 +1318,20 @@ struct RowSolver {
             m_uAx = max_f64(m_uAx, max_f64(fabs(ax0), fabs(ax1)));
             m_Ax = max_f64(m_Ax, max_f64(e0 * (ax0 * ax0), e1 * (ax1 * ax1)));
             // D^-1 (A_s' y_s) = A' (E y_s) = A' [rr (wh - Pi(wh))]
-            const double w0 = rr0[t] * (wh0[t] - z0), w1 = rr1[t] * (wh1[t] - z1);
+            const double w0 = rr0[k] * (wh0[k] - z0), w1 = rr1[k] * (wh1[k] - z1);
             const double sm = w0 - w1;
             const double smx = quad_perm<0, 0, 0, 0>(sm), smy = quad_perm<1, 1, 1, 1>(sm);
             const double aty_u = comp == 2 ? fma(mu, smx + smy, w0) : w0 + w1;
             const double cgt = act ? lds[L::CG + t * 12 + ci] : 0.0;
-            const double px_u = csc * Pu[t];        // = D^-1 (P_s x_s)
+            const double px_u = csc * Pu[k];        // = D^-1 (P_s x_s)
             // D^-1 (P_s x_s + q_s) : re-evaluated here, or -- while rho is small and the re-evaluation would mostly measure the backward error
             // of the Riccati solves -- the value carried through the x-update identity by the iterations (G, in the unused K_0 slot)
             double* G = lds + L::FAC + t * L::SLOT + ci * L::KSTR + L::GCOL;
             double pq_u = px_u + cgt;
             if (careful) pq_u = act ? *G : 0.0;
-            else if (wr) *G = pq_u;
+            else if (act) *G = pq_u;
             const double rd_u = pq_u + aty_u;        // = D^-1 (P_s x_s + q_s + A_s' y_s)
-            const double D2 = one_c / dI2[t];        // D^2
+            const double D2 = one_c / dI2[k];        // D^2
             m_udua = max_f64(m_udua, fabs(rd_u));
             m_dua = max_f64(m_dua, D2 * (rd_u * rd_u));
             m_uq = max_f64(m_uq, fabs(cgt));
@@ -1194,20 +1341,20 @@ struct RowSolver {
             m_uPx = max_f64(m_uPx, fabs(px_u));
             m_Px = max_f64(m_Px, D2 * (px_u * px_u));
         });
-        info.pri_res = row_allmax(act ? m_upri : 0.0);
-        info.nEz = row_allmax(act ? m_uz : 0.0);
-        info.nEAx = row_allmax(act ? m_uAx : 0.0);
-        info.s_pri = sqrt(row_allmax(act ? m_pri : 0.0));
-        info.s_z = sqrt(row_allmax(act ? m_z : 0.0));
-        info.s_Ax = sqrt(row_allmax(act ? m_Ax : 0.0));
-        info.dua_res = cinv * row_allmax(act ? m_udua : 0.0);
-        info.nDq = row_allmax(act ? m_uq : 0.0);
-        info.nDAty = row_allmax(act ? m_uAty : 0.0);
-        info.nDPx = row_allmax(act ? m_uPx : 0.0);
-        info.s_dua = sqrt(row_allmax(act ? m_dua : 0.0));
-        info.s_q = sqrt(row_allmax(act ? m_q : 0.0));
-        info.s_Aty = sqrt(row_allmax(act ? m_Aty : 0.0));
-        info.s_Px = sqrt(row_allmax(act ? m_Px : 0.0));
+        info.pri_res = pair_allmax(act ? m_upri : 0.0);
+        info.nEz = pair_allmax(act ? m_uz : 0.0);
+        info.nEAx = pair_allmax(act ? m_uAx : 0.0);
+        info.s_pri = sqrt(pair_allmax(act ? m_pri : 0.0));
+        info.s_z = sqrt(pair_allmax(act ? m_z : 0.0));
+        info.s_Ax = sqrt(pair_allmax(act ? m_Ax : 0.0));
+        info.dua_res = cinv * pair_allmax(act ? m_udua : 0.0);
+        info.nDq = pair_allmax(act ? m_uq : 0.0);
+        info.nDAty = pair_allmax(act ? m_uAty : 0.0);
+        info.nDPx = pair_allmax(act ? m_uPx : 0.0);
+        info.s_dua = sqrt(pair_allmax(act ? m_dua : 0.0));
+        info.s_q = sqrt(pair_allmax(act ? m_q : 0.0));
+        info.s_Aty = sqrt(pair_allmax(act ? m_Aty : 0.0));
+        info.s_Px = sqrt(pair_allmax(act ? m_Px : 0.0));
     }
     // auxil.c check_termination (feasibility certificates are not evaluated: u = 0 is always feasible and
     // P > 0, so this QP family is never primal or dual infeasible)
@@ -1265,7 +1412,7 @@ struct RowSolver {
                     if (rn > rho * P.adaptive_rho_tol || rn < rho / P.adaptive_rho_tol) {
                         // y_s = rho E (wh - zh) is kept:  wh <- zh + (rho_old / rho_new) (wh - zh),  rr <- rr rho_new / rho_old
                         const double up = rn / rho, dn = rho / rn;
-                        static_for<H>([&](auto T) {
+                        static_for<HS>([&](auto T) {  // (bounds: only the general path's depend on the step, and it has no twin rows)
                             const double z0 = fmin(fmax(wh0[T], lb_at(A1_CV(T))), ub_at(A1_CV(T))), z1 = fmin(wh1[T], 0.0);
                             wh0[T] = fma(dn, wh0[T] - z0, z0);
                             wh1[T] = fma(dn, wh1[T] - z1, z1);
@@ -1297,8 +1444,8 @@ struct RowSolver {
         // skip NaNs, so OSQP's own termination test can "converge" on a NaN iterate
         double nf = 0.0;
 #pragma unroll
-        for (int t = 0; t < H; ++t) nf = (xh[t] - xh[t] == 0.0) ? nf : 1.0;
-        const int32_t status_out = row_allmax(nf) > 0.0 ? A1MPC_NON_CVX : status;
+        for (int t = 0; t < HS; ++t) nf = (xh[t] - xh[t] == 0.0) ? nf : 1.0;
+        const int32_t status_out = pair_allmax(nf) > 0.0 ? A1MPC_NON_CVX : status;
         const bool nanout = status_out == A1MPC_NON_CVX;
         const double nanv = nan("");
         {
@@ -1310,19 +1457,20 @@ struct RowSolver {
                 io.grf[3 * quad + comp] = bad ? 0.0 : gb;
             }
         }
-        static_for<H>([&](auto T) {
-            constexpr int t = A1_CV(T);
-            if (wr) {
-                const double xu = nanout ? nanv : xh[t];
+        static_for<HS>([&](auto T) {
+            constexpr int k = A1_CV(T);
+            const int t = TWIN ? 2 * k + tw : k;  // (a twin pair: each row writes its own steps)
+            if (act) {
+                const double xu = nanout ? nanv : xh[k];
                 if (io.u_full) io.u_full[t * 12 + ci] = xu;
                 // A failed solve must not poison the carried workspace (every later tick of this robot would start from NaN): the next
                 // tick is a cold start -- x = y = 0 and, below, rho = 0 = "use settings.rho" (OSQP's store_solution() cold-starts its
                 // iterates after a failed solve)
                 if (io.warm_x) io.warm_x[t * 12 + ci] = nanout ? 0.0 : xu;
                 if (io.warm_y) {  // y = c^-1 E y_s = c^-1 rr (wh - Pi(wh))
-                    const double z0 = fmin(fmax(wh0[t], lb_at(t)), ub_at(t)), z1 = fmin(wh1[t], 0.0);
-                    io.warm_y[t * 20 + 5 * quad + r0] = nanout ? 0.0 : cinv * rr0[t] * (wh0[t] - z0);
-                    if (comp < 2) io.warm_y[t * 20 + 5 * quad + r1] = nanout ? 0.0 : cinv * rr1[t] * (wh1[t] - z1);
+                    const double z0 = fmin(fmax(wh0[k], lb_at(t)), ub_at(t)), z1 = fmin(wh1[k], 0.0);
+                    io.warm_y[t * 20 + 5 * quad + r0] = nanout ? 0.0 : cinv * rr0[k] * (wh0[k] - z0);
+                    if (comp < 2) io.warm_y[t * 20 + 5 * quad + r1] = nanout ? 0.0 : cinv * rr1[k] * (wh1[k] - z1);
                 }
             }
         });

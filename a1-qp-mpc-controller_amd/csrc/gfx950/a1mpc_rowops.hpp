@@ -108,14 +108,16 @@ A1_DEV void row_dpp_ready12(double (&v)[12]) {
 #define A1_FMAC(acc, x, m, L) "v_fmac_f64_dpp " acc ", " x ", " m " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n"
 #define A1_FNMA(acc, x, m, L) "v_fmac_f64_dpp " acc ", -" x ", " m " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n"
 
-// r = (at - cg) + sd*xh - B~' p   and the seeds of the costate accumulators  pa = p + gA p[0] + gC p[2],  pb += gB p[1]
+// r = e - B~' p  with  e = sd*xh + (at - cg)  (even terms into e, odd terms into a second accumulator that starts from zero: the arithmetic
+// of sweep_back_rhs_twin)  and the seeds of the costate accumulators  pa = p + gA p[0] + gC p[2],  pb += gB p[1]
 // (pb comes in as gV * ror8(p)).  p: written >= 2 instructions ago (sweep_back ends with two d-chain instructions after it);
 // r: followed by two instructions inside the block.
 A1_DEV void sweep_back_rhs(double& r, double& pa, double& pb, double at, double cg, double sd, double xh, double p, const double (&Bt)[6],
                            double gA, double gB, double gC) {
     double rb;
     asm("v_add_f64 %0, %4, -%5\n"
-        "v_mul_f64 %1, %6, %7\n"
+        "v_mov_b64 %1, 0\n"
+        "v_fmac_f64 %0, %6, %7\n"
         "v_mov_b64 %2, %8\n"
         A1_FNMA("%0", "%8", "%9", 8) A1_FNMA("%1", "%8", "%10", 9) A1_FMAC("%2", "%8", "%15", 0)
         A1_FNMA("%0", "%8", "%11", 10) A1_FNMA("%1", "%8", "%12", 12)
@@ -125,22 +127,20 @@ A1_DEV void sweep_back_rhs(double& r, double& pa, double& pb, double at, double 
         : "=&v"(r), "=&v"(rb), "=&v"(pa), "+v"(pb)
         : "v"(at), "v"(cg), "v"(sd), "v"(xh), "v"(p), "v"(Bt[0]), "v"(Bt[1]), "v"(Bt[2]), "v"(Bt[3]), "v"(Bt[4]), "v"(Bt[5]), "v"(gA), "v"(gB), "v"(gC));
 }
-// the same for a row that has a twin (persistent ADMM kernel, see twin_exchange): the costate seed is  pa = hm * p  with hm = 1 on the main
-// row and 0 on its twin (whose accumulators carry the d chain and must start from zero; gA, gB, gC and pb come in masked the same way)
-A1_DEV void sweep_back_rhs_twin(double& r, double& pa, double& pb, double at, double cg, double sd, double xh, double p, const double (&Bt)[6],
-                                double gA, double gB, double gC, double hm) {
+// the same for a row of a twin pair (persistent ADMM kernel, see twin_exchange): r comes in as e (formed by the row that owns the step and
+// swapped over), and the costate seed is  pa = hm * p  with hm = 1 on the main row and 0 on its twin (whose accumulators carry the d chain
+// and must start from zero; gA, gB, gC and pb come in masked the same way).
+A1_DEV void sweep_back_rhs_twin(double& r, double& pa, double& pb, double p, const double (&Bt)[6], double gA, double gB, double gC, double hm) {
     double rb;
-    asm("v_add_f64 %0, %4, -%5\n"
-        "v_mul_f64 %1, %6, %7\n"
-        "v_mul_f64 %2, %8, %18\n"
-        A1_FNMA("%0", "%8", "%9", 8) A1_FNMA("%1", "%8", "%10", 9) A1_FMAC("%2", "%8", "%15", 0)
-        A1_FNMA("%0", "%8", "%11", 10) A1_FNMA("%1", "%8", "%12", 12)
-        A1_FNMA("%0", "%8", "%13", 13) A1_FNMA("%1", "%8", "%14", 14)
+    asm("v_mov_b64 %1, 0\n"
+        "v_mul_f64 %2, %4, %14\n"
+        A1_FNMA("%0", "%4", "%5", 8) A1_FNMA("%1", "%4", "%6", 9) A1_FMAC("%2", "%4", "%11", 0)
+        A1_FNMA("%0", "%4", "%7", 10) A1_FNMA("%1", "%4", "%8", 12)
+        A1_FNMA("%0", "%4", "%9", 13) A1_FNMA("%1", "%4", "%10", 14)
         "v_add_f64 %0, %0, %1\n"
-        A1_FMAC("%3", "%8", "%16", 1) A1_FMAC("%2", "%8", "%17", 2)
-        : "=&v"(r), "=&v"(rb), "=&v"(pa), "+v"(pb)
-        : "v"(at), "v"(cg), "v"(sd), "v"(xh), "v"(p), "v"(Bt[0]), "v"(Bt[1]), "v"(Bt[2]), "v"(Bt[3]), "v"(Bt[4]), "v"(Bt[5]), "v"(gA), "v"(gB), "v"(gC),
-          "v"(hm));
+        A1_FMAC("%3", "%4", "%12", 1) A1_FMAC("%2", "%4", "%13", 2)
+        : "+v"(r), "=&v"(rb), "=&v"(pa), "+v"(pb)
+        : "v"(p), "v"(Bt[0]), "v"(Bt[1]), "v"(Bt[2]), "v"(Bt[3]), "v"(Bt[4]), "v"(Bt[5]), "v"(gA), "v"(gB), "v"(gC), "v"(hm));
 }
 // One chain pair for a row and its twin:  (pa, pb) += sum_b M[b] r[b]  (even b into pa, odd b into pb),  pa <- pa + pb.  On the main row M is
 // column `ci` of K_t and the pair arrives seeded with A' p_{t+1} (result: the costate p_t); on the twin M is row `ci` of S_t^-1 and the seeds are
@@ -234,6 +234,47 @@ A1_DEV void sweep_fwd_input(double& sa, double& sb, double& z0, double v, const 
         : "+v"(sa), "+v"(sb), "=&v"(z0)
         : "v"(v), "v"(Br[0]), "v"(Br[1]), "v"(Br[2]), "v"(Br[3]), "v"(Br[4]), "v"(Br[5]), "v"(Br[6]), "v"(Br[7]), "v"(Br[8]), "v"(Br[9]), "v"(Br[10]),
           "v"(Br[11]), "v"(w0), "v"(lb), "v"(ub));
+}
+
+// The forward blocks of a twin pair: the x / w updates of a step belong to ONE row of the pair (RowSolver::admm_iteration_twin), so the blocks
+// only carry the roll-out.  v = am * (v - K s) (row Kr) and (SEED) the seeds of x_{t+1}: sa = s + fA s[8] + fC s[10], sb += fB s[9]; the seed
+// terms come last so that v is followed by >= 2 instructions before sweep_fwd_input_twin reads it through DPP.  s: written >= 2 instructions ago.
+template <bool SEED>
+A1_DEV void sweep_fwd_gain_twin(double& v, double& sa, double& sb, double s, const double (&Kr)[12], double fA, double fB, double fC, double am) {
+    double vb;
+    if constexpr (SEED) {
+        asm("v_mov_b64 %2, %4\n"
+            "v_mov_b64 %1, 0\n"
+            A1_FNMA("%0", "%4", "%5", 0) A1_FNMA("%1", "%4", "%6", 1) A1_FNMA("%0", "%4", "%7", 2) A1_FNMA("%1", "%4", "%8", 4)
+            A1_FNMA("%0", "%4", "%9", 5) A1_FNMA("%1", "%4", "%10", 6) A1_FNMA("%0", "%4", "%11", 8) A1_FNMA("%1", "%4", "%12", 9)
+            A1_FNMA("%0", "%4", "%13", 10) A1_FNMA("%1", "%4", "%14", 12) A1_FNMA("%0", "%4", "%15", 13) A1_FNMA("%1", "%4", "%16", 14)
+            "v_add_f64 %0, %0, %1\n"
+            "v_mul_f64 %0, %0, %20\n"
+            A1_FMAC("%2", "%4", "%17", 8) A1_FMAC("%3", "%4", "%18", 9) A1_FMAC("%2", "%4", "%19", 10)
+            : "+v"(v), "=&v"(vb), "=&v"(sa), "+v"(sb)
+            : "v"(s), "v"(Kr[0]), "v"(Kr[1]), "v"(Kr[2]), "v"(Kr[3]), "v"(Kr[4]), "v"(Kr[5]), "v"(Kr[6]), "v"(Kr[7]), "v"(Kr[8]), "v"(Kr[9]), "v"(Kr[10]),
+              "v"(Kr[11]), "v"(fA), "v"(fB), "v"(fC), "v"(am));
+    } else {
+        asm("v_mov_b64 %1, 0\n"
+            A1_FNMA("%0", "%2", "%3", 0) A1_FNMA("%1", "%2", "%4", 1) A1_FNMA("%0", "%2", "%5", 2) A1_FNMA("%1", "%2", "%6", 4)
+            A1_FNMA("%0", "%2", "%7", 5) A1_FNMA("%1", "%2", "%8", 6) A1_FNMA("%0", "%2", "%9", 8) A1_FNMA("%1", "%2", "%10", 9)
+            A1_FNMA("%0", "%2", "%11", 10) A1_FNMA("%1", "%2", "%12", 12) A1_FNMA("%0", "%2", "%13", 13) A1_FNMA("%1", "%2", "%14", 14)
+            "v_add_f64 %0, %0, %1\n"
+            "v_mul_f64 %0, %0, %15\n"
+            : "+v"(v), "=&v"(vb)
+            : "v"(s), "v"(Kr[0]), "v"(Kr[1]), "v"(Kr[2]), "v"(Kr[3]), "v"(Kr[4]), "v"(Kr[5]), "v"(Kr[6]), "v"(Kr[7]), "v"(Kr[8]), "v"(Kr[9]), "v"(Kr[10]),
+              "v"(Kr[11]), "v"(am));
+    }
+}
+// x_{t+1} = (sa + sb) + B~ v (row Br), returned in sa.  v: written >= 2 instructions ago.  The caller passes sa through row_dpp_ready().
+A1_DEV void sweep_fwd_input_twin(double& sa, double& sb, double v, const double (&Br)[12]) {
+    asm(A1_FMAC("%0", "%2", "%3", 0) A1_FMAC("%1", "%2", "%4", 1) A1_FMAC("%0", "%2", "%5", 2) A1_FMAC("%1", "%2", "%6", 4)
+        A1_FMAC("%0", "%2", "%7", 5) A1_FMAC("%1", "%2", "%8", 6) A1_FMAC("%0", "%2", "%9", 8) A1_FMAC("%1", "%2", "%10", 9)
+        A1_FMAC("%0", "%2", "%11", 10) A1_FMAC("%1", "%2", "%12", 12) A1_FMAC("%0", "%2", "%13", 13) A1_FMAC("%1", "%2", "%14", 14)
+        "v_add_f64 %0, %0, %1\n"
+        : "+v"(sa), "+v"(sb)
+        : "v"(v), "v"(Br[0]), "v"(Br[1]), "v"(Br[2]), "v"(Br[3]), "v"(Br[4]), "v"(Br[5]), "v"(Br[6]), "v"(Br[7]), "v"(Br[8]), "v"(Br[9]), "v"(Br[10]),
+          "v"(Br[11]));
 }
 
 // Scheduling fence: the machine scheduler moves nothing across it (keeps a step's LDS reads ahead of the arithmetic that hides them).

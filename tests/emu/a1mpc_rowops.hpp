@@ -57,7 +57,7 @@ constexpr int LANE[12] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14};
 inline void sweep_back_rhs(double& r, double& pa, double& pb, double at, double cg, double sd, double xh, double p, const double (&Bt)[6],
                            double gA, double gB, double gC) {
     const double* P_ = emu_publish(p);
-    double ra = at - cg, rb = sd * xh;
+    double ra = fma(sd, xh, at - cg), rb = 0.0;  // e in the first accumulator, the second starts from zero (like the gfx950 block)
     pa = p;
     ra = fma(-P_[8], Bt[0], ra); rb = fma(-P_[9], Bt[1], rb); pa = fma(P_[0], gA, pa);
     ra = fma(-P_[10], Bt[2], ra); rb = fma(-P_[12], Bt[3], rb);
@@ -81,7 +81,10 @@ inline void sweep_back_chains(double& d, double& pa, double& pb, double r, const
 inline bool row_is_twin() { return false; }
 inline double twin_exchange(double& a) { return a; }
 inline double twin_from_main(double v) { return v; }
-inline void sweep_back_rhs_twin(double&, double&, double&, double, double, double, double, double, const double (&)[6], double, double, double, double) {}
+inline void sweep_back_rhs_twin(double&, double&, double&, double, const double (&)[6], double, double, double, double) {}
+template <bool SEED>
+inline void sweep_fwd_gain_twin(double&, double&, double&, double, const double (&)[12], double, double, double, double) {}
+inline void sweep_fwd_input_twin(double&, double&, double, const double (&)[12]) {}
 inline void sweep_back_chain_twin(double&, double&, double, const double (&)[12]) {}
 inline double dot12_block(const double (&m)[12], double x) {
     const double* X_ = emu_publish(x);
