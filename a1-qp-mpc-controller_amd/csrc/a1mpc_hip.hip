@@ -30,14 +30,19 @@ namespace a1mpc {
 using KernelArgs = BatchArgs;
 
 
-// ROWS = QPs (DPP rows) per workgroup; the workgroup is one wavefront with 16*ROWS live lanes.
+// The MPC kernels with at most two QPs per wavefront run the wavefront's other rows as twins of the QP rows: rows r and r + 2 share a QP and its
+// LDS image (row_is_twin(), RowSolver<.., TWIN>); the workgroup is then a full wavefront.
+constexpr bool twin_rows(int h, int mode, int rows) { return rows <= 2 && h > 1 && mode == kModeMpc; }
+// ROWS = QPs (DPP rows) per workgroup; the workgroup is one wavefront with 16*ROWS live lanes (64 with twin rows).
 template <int H, int MODE, int ROWS>
 __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    const int row = static_cast<int>(threadIdx.x) >> 4;
+    constexpr bool kTwin = twin_rows(H, MODE, ROWS);
+    const int row = kTwin ? (static_cast<int>(threadIdx.x) >> 4) & 1 : static_cast<int>(threadIdx.x) >> 4;
+    if (kTwin && row >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
     const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
-    if (b >= a.n) return;  // row-uniform: the other rows of the wave keep all their DPP sources
-    solve_row_with<H, MODE>(a.P, a.tab, [&]() { return make_io<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+    if (b >= a.n) return;  // row-uniform (a twin leaves with its main row): the other rows of the wave keep all their DPP sources
+    solve_row_with<H, MODE, false, kTwin>(a.P, a.tab, [&]() { return make_io<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
 }
 
 // General path (per-step feet / per-step contact schedules: S/ConvexMpc.h:74 B_mat_d_list, S/test/test_mpc.cpp:106-122): the fused kernel
@@ -68,10 +73,10 @@ __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a
         row_sync();  // every row is done with the set-up scratch aliased into the factor region
         if (row == 0) S.save_prepared(a1mpc_lds + Layout<H>::FAC);
     }
-    if (row != 0) return;
-    // Row 0 continues exactly like a row of the split pipeline's second kernel: a fresh solver that reads the hand-off record
+    if (row & 1) return;
+    // Rows 0 and 2 continue exactly like a main / twin pair of the split pipeline's second kernel: a fresh solver that reads the hand-off record
     // (here through LDS).  Carrying the set-up's registers into the ADMM loop instead costs that loop its spill-free allocation.
-    RowSolver<H, kModeMpc> S(a.P, a.tab, a1mpc_lds);
+    RowSolver<H, kModeMpc, false, false, true> S(a.P, a.tab, a1mpc_lds);
     S.load_prepared(a1mpc_lds + Layout<H>::FAC, make_io<H, kModeMpc>(a, b));
     S.solve();
     S.write_outputs(make_io<H, kModeMpc>(a, b));
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(64, 2) void a1mpc_setup_kernel(const KernelArgs a, 
 #ifdef A1X_NOTWIN
 constexpr bool admm_twin_rows(int, int) { return false; }
 #else
-constexpr bool admm_twin_rows(int h, int rows) { return rows <= 2 && h > 1; }
+constexpr bool admm_twin_rows(int h, int rows) { return twin_rows(h, kModeMpc, rows); }
 #endif  // the wavefront's spare rows run as twins (RowSolver<.., TWIN>)
 template <int H, int ROWS>
 __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
@@ -402,7 +407,7 @@ static a1mpc_status launch_rows(const KernelArgs& a, hipStream_t stream) {
         attr_set[dev] = true;
     }
     const unsigned grid = static_cast<unsigned>((a.n + ROWS - 1) / ROWS);
-    hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE, ROWS>), dim3(grid), dim3(16 * ROWS), lds_bytes<H>(ROWS), stream, a);
+    hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE, ROWS>), dim3(grid), dim3(twin_rows(H, MODE, ROWS) ? 64 : 16 * ROWS), lds_bytes<H>(ROWS), stream, a);
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
 }

@@ -1589,8 +1589,11 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
 // the fused path: one QP from inputs to outputs (small batches, the batch-1 latency path, the CPU test double).
 // make_io() is called where the pointers are needed (set-up, hand-off, outputs) instead of once: a ProblemIO of per-row pointers that
 // stays live across the ADMM loop costs that loop ~30 VGPRs it does not have.
-template <int H, int MODE, bool GEN = false, class MakeIO>
+// TWIN: the calling row is one of a main / twin pair (rows r and r + 2 of the wavefront, see RowSolver<.., TWIN>): the main row sets the QP up alone,
+// both iterate.
+template <int H, int MODE, bool GEN = false, bool TWIN = false, class MakeIO>
 A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab, MakeIO&& make_io_, double* __restrict__ lds) {
+    static_assert(!TWIN || (!GEN && MODE == kModeMpc && Prep<H>::STRIDE <= H * Layout<H>::SLOT), "twin rows: the MPC solve with the set-up | iteration hand-off");
     if constexpr (GEN) {
         // general path (per-step feet / contact schedules): the same set-up | iteration hand-off as below (its per-step tables live behind c*g
         // in the LDS image and survive it; the T*B~w table aliased into the factor region is dead once the Ruiz passes are done)
@@ -1609,13 +1612,13 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
         // Set-up and iteration are two solver objects joined by the hand-off record of the split pipeline, staged in the (still
         // empty) factor region: the ADMM loop then gets the register allocation of the persistent kernel instead of one that
         // also carries the set-up's live values (scratch reloads inside the loop).  ~0.5 us per solve.
-        {
+        if (!TWIN || !row_is_twin()) {
             RowSolver<H, MODE> S0(P, tab, lds);
             S0.setup(make_io_());
             row_sync();
             S0.save_prepared(lds + Layout<H>::FAC);
         }
-        RowSolver<H, MODE> S(P, tab, lds);
+        RowSolver<H, MODE, false, false, TWIN> S(P, tab, lds);
         S.load_prepared(lds + Layout<H>::FAC, make_io_());
         S.solve();
         S.write_outputs(make_io_());
@@ -1628,7 +1631,7 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
 }
 template <int H, int MODE = kModeMpc, bool GEN = false>
 A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, const ProblemIO& io, double* __restrict__ lds) {
-    solve_row_with<H, MODE, GEN>(P, tab, [&]() -> const ProblemIO& { return io; }, lds);
+    solve_row_with<H, MODE, GEN, false>(P, tab, [&]() -> const ProblemIO& { return io; }, lds);
 }
 
 }  // namespace a1mpc
