@@ -295,6 +295,11 @@ struct RowSolver {
         warm = false; first_special = false; eqmask = 0; careful = false;
     }
 
+    // orders LDS traffic between the lanes that work on this QP: my row, or both rows of a twin pair
+    A1_DEV void sync() const {
+        if constexpr (TWIN) pair_sync();
+        else row_sync();
+    }
     // A_d = I + dt*A_c and its transpose as row operators on a state-layout vector (T = A_c(0:3,6:9), S/ConvexMpc.cpp:123-125)
     A1_DEV void set_rotation(double c, double s) {
         cy = c; sy = s;
@@ -631,10 +636,10 @@ struct RowSolver {
                     const double mEx = quad_perm<0, 0, 0, 0>(mE), mEy = quad_perm<1, 1, 1, 1>(mE);
                     const double colA = Dt_ * (comp == 2 ? fmax(mu * fmax(mEx, mEy), E0t) : mE);
                     const double colP = csc * Dt_ * mt;
-                    const double dtmp = 1.0 / sqrt(limit_scaling(fmax(colP, colA)));
+                    const double dtmp = row_rsqrt(limit_scaling(fmax(colP, colA)));
                     const double rowf = comp == 2 ? Dt_ : fmax(Dt_, mu * Dz);
-                    const double e0 = 1.0 / sqrt(limit_scaling(E0t * rowf));
-                    const double e1 = 1.0 / sqrt(limit_scaling(E1t * rowf));
+                    const double e0 = row_rsqrt(limit_scaling(E0t * rowf));
+                    const double e1 = row_rsqrt(limit_scaling(E1t * rowf));
                     Dt_ *= dtmp; E0t *= e0; E1t *= e1;
                 };
                 if (coop_n > 1) {
@@ -754,7 +759,7 @@ struct RowSolver {
         p[PR::FLAGS * 12 + ci] = (warm ? 1.0 : 0.0) + (first_special ? 2.0 : 0.0);
     }
     A1_DEV void load_prepared(const double* __restrict__ p, const ProblemIO& io) {
-        row_sync();  // the previous QP's LDS image is dead
+        sync();  // the previous QP's LDS image is dead
         const double am = act ? 1.0 : 0.0;  // pad lanes read lane 0's record (ci == 0) and zero what must be zero
         const int fl = static_cast<int>(p[PR::FLAGS * 12 + ci]);
         warm = fl & 1; first_special = (fl & 2) != 0;
@@ -794,7 +799,7 @@ struct RowSolver {
         lo_u = am * p[PR::LO * 12 + ci]; hi_u = am * p[PR::HI * 12 + ci];
         lb0 = comp == 2 ? lo_u : 0.0; ub0 = comp == 2 ? hi_u : kInfty;
         eqmask = act ? static_cast<unsigned>(p[PR::EQ * 12 + ci]) : 0u;
-        row_sync();
+        sync();
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false; careful = false;
 #ifdef A1X_CLK
         clkB = clkF = clkT = clkU = clkX = 0;
@@ -807,7 +812,7 @@ struct RowSolver {
         ++nfact;
         const double sigma_f = row_opaque(P.sigma);
         // stage W_t = c R + sigma D^-2 + A_t' (E^2 rho) A_t  (block-diagonal, 3x3 per leg) into slot t: my row of my leg's block
-        row_sync();
+        sync();
         static_for<HS>([&](auto T) {  // (a twin pair: each row stages the W_t of its own steps)
             const double a0 = rr0[T], a1 = rr1[T];
             const double sp = a0 + a1;
@@ -821,7 +826,7 @@ struct RowSolver {
             w[1] = comp == 1 ? wd : (comp == 2 ? woy : 0.0);
             w[2] = comp == 2 ? wd : wo;
         });
-        row_sync();
+        sync();
         // lane constants of this pass: component indicators (1.0 / 0.0).  "Add on my diagonal entry only" is one v_fmac_f64_dpp with
         // the leg's bank mask, the component indicator (times my own value) as the own-lane factor and 1.0 = cm[0] of lane 0 as the broadcast one.
                 double cm[3], qdc[3];
@@ -846,7 +851,7 @@ struct RowSolver {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) Btr[k] = row_dpp_ready(Btt[k]);
             }
-            row_sync();  // everybody holds W_t before the slot is overwritten
+            sync();  // everybody holds W_t before the slot is overwritten
             // G = A' P_{t+1}  (rows mixed across lanes), then GA = G A (columns, lane-local)
             double G[12];
             row_dpp_ready12(Pn);
@@ -927,7 +932,7 @@ struct RowSolver {
                     static_for<12>([&](auto J) { fnma_bcast<lane_of(A1_CV(J))>(Pn[J], Ft[A_], Kt[A_]); });
                 });
             }
-            row_sync();  // K_t and S_t^-1 of this step are in LDS before the next step reuses the registers' sources
+            sync();  // K_t and S_t^-1 of this step are in LDS before the next step reuses the registers' sources
         }
 #pragma unroll
         for (int b = 0; b < 12; ++b) Brw[b] = kBrowInRegs ? brow[b] : 0.0;
@@ -1090,8 +1095,9 @@ struct RowSolver {
     // (the right-hand-side data e_t, then p_t / d_t).  Every value is formed by the same operations in the same order as in the
     // single-row code above: the two kernels agree bit for bit.
     // LDS reads are issued as soon as the block that consumed the previous step's has been issued (into the registers it frees): with one
-    // wave per SIMD nothing else hides an LDS round trip.  (Carrying the first reads of the next iteration across the loop back-edge was
-    // measured: the loop-carried registers push loop invariants into scratch, 2.95 -> 3.56 us per iteration.)
+    // wave per SIMD nothing else hides an LDS round trip.  (Measured and not kept: carrying the first reads of the next iteration across the
+    // loop back-edge -- the loop-carried registers push loop invariants into scratch, 2.95 -> 3.56 us per iteration; double-buffering the
+    // backward reads a whole step ahead -- 36 more AGPR moves per iteration, 2.77 -> 2.88 us.)
     template <int T_>
     A1_DEV void issue_back_reads(double (&M)[12]) const {
         const double* slot = lds + L::FAC + T_ * L::SLOT;
@@ -1373,7 +1379,13 @@ struct RowSolver {
     // max_iter), then the residual check and the rho update.  Everything that can differ between the rows of a wave
     // (termination, rho update) happens at segment boundaries, so rows that run advance() in lock-step stay aligned.
     A1_DEV void advance() {
+#ifdef A1X_CLK
+        const long long tf_ = clock64();
+#endif
         if (need_factor) factorize();
+#ifdef A1X_CLK
+        clkX += clock64() - tf_;
+#endif
         if (!done) {
             int next = P.max_iter;
             if (P.check_every > 0) next = imin(next, (iter / P.check_every + 1) * P.check_every);
@@ -1618,6 +1630,7 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
             row_sync();
             S0.save_prepared(lds + Layout<H>::FAC);
         }
+        if constexpr (TWIN) pair_sync();  // the twin reads the hand-off record its main row wrote
         RowSolver<H, MODE, false, false, TWIN> S(P, tab, lds);
         S.load_prepared(lds + Layout<H>::FAC, make_io_());
         S.solve();

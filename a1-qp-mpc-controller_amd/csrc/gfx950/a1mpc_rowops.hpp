@@ -288,6 +288,19 @@ A1_DEV double row_recip(double p) {
     return __builtin_fma(x, e, x);
 }
 
+// 1 / sqrt(p) for a positive, well-scaled p (the Ruiz factors: 1e-4 <= p <= 1e4 after limit_scaling): v_rsq_f64 + two Goldschmidt steps, ~1 ulp,
+// ~9 instructions against ~35 for a correctly rounded sqrt followed by a correctly rounded division (thirty of them per Ruiz pass and QP).
+A1_DEV double row_rsqrt(double p) {
+    const double y = __builtin_amdgcn_rsq(p);
+    double g = p * y, h = 0.5 * y;          // g -> sqrt(p), h -> 1 / (2 sqrt(p))
+    double r = __builtin_fma(-g, h, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-g, h, 0.5);
+    h = __builtin_fma(h, r, h);
+    return h + h;
+}
+
 // One Gauss-Jordan pivot of the row-distributed 12x12 (RowSolver::factorize): S[j] += mlt * (S[j] of lane K) for every j != K
 // (S[K] itself is set by the caller).  For K < 11 the block also returns the next pivot p = S[K+1] of lane K+1 and x = 1 / p
 // (row_recip's sequence): row K+1 is eliminated first, and the reciprocal's dependent chain is issued between the other ten
@@ -361,6 +374,8 @@ A1_DEV double twin_exchange(double& a) {
     a = __builtin_bit_cast(double, static_cast<unsigned long long>(r0[0]) | (static_cast<unsigned long long>(r1[0]) << 32));
     return __builtin_bit_cast(double, static_cast<unsigned long long>(r0[1]) | (static_cast<unsigned long long>(r1[1]) << 32));
 }
+// LDS ordering between the two rows of a pair (one wavefront: the same as row_sync(); the CPU test double needs the distinction)
+A1_DEV void pair_sync() { row_sync(); }
 // the twin takes its main row's value
 A1_DEV double twin_from_main(double v) {
     (void)twin_exchange(v);

@@ -14,10 +14,11 @@
 namespace a1mpc {
 
 struct EmuRow;
-extern thread_local int emu_lane;
-const double* emu_publish(double v);  // returns the 16 published values of this exchange
+extern thread_local int emu_lane;        // 0..15, or 0..31 when a main / twin pair of rows is emulated (16..31 = the twin)
+const double* emu_publish(double v);     // returns the 16 published values of MY row of this exchange
+double emu_twin_exchange(double& a);     // a = [x | y] on (main | twin) -> a = [x | x], returns [y | y]
 
-inline int row_lane() { return emu_lane; }
+inline int row_lane() { return emu_lane & 15; }
 template <int L>
 inline double row_bcast(double v) { return emu_publish(v)[L]; }
 template <int N>
@@ -26,7 +27,7 @@ template <int P0, int P1, int P2, int P3>
 inline double quad_perm(double v) {
     const double* p = emu_publish(v);
     const int sel[4] = {P0, P1, P2, P3};
-    return p[(emu_lane & ~3) + sel[emu_lane & 3]];
+    return p[((emu_lane & 15) & ~3) + sel[emu_lane & 3]];
 }
 template <int L>
 inline void fma_bcast(double& acc, double m, double x) { acc = fma(m, emu_publish(x)[L], acc); }
@@ -35,13 +36,14 @@ inline void fnma_bcast(double& acc, double m, double x) { acc = fma(-m, emu_publ
 template <int L, int Q>
 inline void fma_bcast_leg(double& acc, double m, double x) {
     const double v = emu_publish(x)[L];
-    if ((emu_lane >> 2) == Q) acc = fma(m, v, acc);
+    if (((emu_lane & 15) >> 2) == Q) acc = fma(m, v, acc);
 }
 template <int L, int Q>
 inline void fnma_bcast_leg(double& acc, double m, double x) {
     const double v = emu_publish(x)[L];
-    if ((emu_lane >> 2) == Q) acc = fma(-m, v, acc);
+    if (((emu_lane & 15) >> 2) == Q) acc = fma(-m, v, acc);
 }
+inline double row_rsqrt(double p) { return 1.0 / sqrt(p); }
 inline double max_f64(double a, double b) { return fmax(a, b); }
 inline double min_f64(double a, double b) { return fmin(a, b); }
 inline double row_dpp_ready(double x) { return x; }
@@ -77,15 +79,42 @@ inline void sweep_back_chains(double& d, double& pa, double& pb, double r, const
     pa = pa + pb;
     d = da + db;
 }
-// twin rows exist only in the persistent ADMM kernel of the device build (RowSolver<.., TWIN = true> is never instantiated here)
-inline bool row_is_twin() { return false; }
-inline double twin_exchange(double& a) { return a; }
-inline double twin_from_main(double v) { return v; }
-inline void sweep_back_rhs_twin(double&, double&, double&, double, const double (&)[6], double, double, double, double) {}
+// ---- a main / twin pair of rows (RowSolver<.., TWIN>): the same operation order as the gfx950 blocks
+inline bool row_is_twin() { return emu_lane >= 16; }
+inline double twin_exchange(double& a) { return emu_twin_exchange(a); }
+inline double twin_from_main(double v) { (void)emu_twin_exchange(v); return v; }
+inline void pair_sync() { double z = 0.0; (void)emu_twin_exchange(z); }  // both rows of the pair arrive before either goes on
+inline void sweep_back_rhs_twin(double& r, double& pa, double& pb, double p, const double (&Bt)[6], double gA, double gB, double gC, double hm) {
+    const double* P_ = emu_publish(p);
+    double ra = r, rb = 0.0;
+    pa = p * hm;
+    ra = fma(-P_[8], Bt[0], ra); rb = fma(-P_[9], Bt[1], rb); pa = fma(P_[0], gA, pa);
+    ra = fma(-P_[10], Bt[2], ra); rb = fma(-P_[12], Bt[3], rb);
+    ra = fma(-P_[13], Bt[4], ra); rb = fma(-P_[14], Bt[5], rb);
+    r = ra + rb;
+    pb = fma(P_[1], gB, pb); pa = fma(P_[2], gC, pa);
+}
+inline void sweep_back_chain_twin(double& pa, double& pb, double r, const double (&M)[12]) {
+    const double* R_ = emu_publish(r);
+    for (int b = 0; b < 12; ++b) {
+        double& acc = (b & 1) ? pb : pa;
+        acc = fma(R_[emu_detail::LANE[b]], M[b], acc);
+    }
+    pa = pa + pb;
+}
 template <bool SEED>
-inline void sweep_fwd_gain_twin(double&, double&, double&, double, const double (&)[12], double, double, double, double) {}
-inline void sweep_fwd_input_twin(double&, double&, double, const double (&)[12]) {}
-inline void sweep_back_chain_twin(double&, double&, double, const double (&)[12]) {}
+inline void sweep_fwd_gain_twin(double& v, double& sa, double& sb, double s, const double (&Kr)[12], double fA, double fB, double fC, double am) {
+    const double* S_ = emu_publish(s);
+    double va = v, vb = 0.0;
+    for (int b = 0; b < 12; b += 2) { va = fma(-S_[emu_detail::LANE[b]], Kr[b], va); vb = fma(-S_[emu_detail::LANE[b + 1]], Kr[b + 1], vb); }
+    v = (va + vb) * am;
+    if (SEED) { sa = s; sa = fma(S_[8], fA, sa); sb = fma(S_[9], fB, sb); sa = fma(S_[10], fC, sa); }
+}
+inline void sweep_fwd_input_twin(double& sa, double& sb, double v, const double (&Br)[12]) {
+    const double* V_ = emu_publish(v);
+    for (int b = 0; b < 12; b += 2) { sa = fma(V_[emu_detail::LANE[b]], Br[b], sa); sb = fma(V_[emu_detail::LANE[b + 1]], Br[b + 1], sb); }
+    sa = sa + sb;
+}
 inline double dot12_block(const double (&m)[12], double x) {
     const double* X_ = emu_publish(x);
     double a0 = 0.0, a1 = 0.0;

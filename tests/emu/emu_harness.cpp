@@ -17,16 +17,16 @@ namespace a1mpc {
 thread_local int emu_lane = 0;
 
 namespace {
-constexpr int kLanes = 16;
+constexpr int kLanes = 32;  // a DPP row, or a main / twin pair of rows (lanes 16-31 = the twin: RowSolver<.., TWIN>)
 constexpr size_t kStack = 1 << 20;
 struct Sched {
+    int lanes;
     ucontext_t main_ctx;
     ucontext_t ctx[kLanes];
     char* stacks[kLanes];
     bool finished[kLanes];
-    double buf[2][kLanes];
-    int parity[kLanes];
-    long nxchg[kLanes];
+    double buf[2][kLanes], xbuf[2][kLanes];  // row-local exchanges / exchanges between the rows of a pair
+    long gen[kLanes], xgen[kLanes];          // how many of each this lane has published
     void (*fn)(void*);
     void* arg;
 };
@@ -39,27 +39,53 @@ void trampoline() {
     s->finished[l] = true;
     swapcontext(&s->ctx[l], &s->main_ctx);
 }
+// yield until every lane lo..hi-1 has published exchange number g (counters cnt)
+void wait_for(Sched* s, int l, const long* cnt, long g, int lo, int hi) {
+    for (;;) {
+        bool all = true;
+        for (int x = lo; x < hi; ++x) {
+            if (s->finished[x] && cnt[x] < g) { fprintf(stderr, "emu: divergent control flow (lane %d finished while lane %d waits for it)\n", x, l); abort(); }
+            all = all && cnt[x] >= g;
+        }
+        if (all) return;
+        swapcontext(&s->ctx[l], &s->main_ctx);
+        emu_lane = l;
+    }
+}
 }  // namespace
 
+// Row-local exchange: the caller resumes when the 16 lanes of ITS row have published (the rows of a pair may be at different points --
+// e.g. the twin skips the set-up); returns the row's 16 values.
 const double* emu_publish(double v) {
     Sched* s = g_s;
+    const int l = emu_lane, lo = l & ~15;
+    const long g = ++s->gen[l];
+    s->buf[g & 1][l] = v;
+    wait_for(s, l, s->gen, g, lo, lo + 16);
+    return s->buf[g & 1] + lo;
+}
+// a = [x | y] on (main | twin)  ->  a = [x | x], returns [y | y]   (v_permlane32_swap on the device): waits for the partner lane's k-th exchange
+double emu_twin_exchange(double& a) {
+    Sched* s = g_s;
     const int l = emu_lane;
-    const int p = s->parity[l];
-    s->buf[p][l] = v;
-    s->parity[l] ^= 1;
-    s->nxchg[l]++;
-    swapcontext(&s->ctx[l], &s->main_ctx);  // resume after every other lane has published
-    emu_lane = l;
-    return s->buf[p];
+    const long g = ++s->xgen[l];
+    const double mine = a;
+    s->xbuf[g & 1][l] = a;
+    wait_for(s, l, s->xgen, g, 0, 32);
+    const double other = s->xbuf[g & 1][l ^ 16];
+    if (l < 16) return other;
+    a = other;
+    return mine;
 }
 
-static void run_row(void (*fn)(void*), void* arg) {
+static void run_row(void (*fn)(void*), void* arg, int lanes = 16) {
     Sched s;
     memset(&s, 0, sizeof s);
+    s.lanes = lanes;
     s.fn = fn;
     s.arg = arg;
     g_s = &s;
-    for (int l = 0; l < kLanes; ++l) {
+    for (int l = 0; l < lanes; ++l) {
         s.stacks[l] = static_cast<char*>(malloc(kStack));
         getcontext(&s.ctx[l]);
         s.ctx[l].uc_stack.ss_sp = s.stacks[l];
@@ -69,20 +95,18 @@ static void run_row(void (*fn)(void*), void* arg) {
     }
     for (;;) {
         int alive = 0;
-        for (int l = 0; l < kLanes; ++l) {
+        for (int l = 0; l < lanes; ++l) {
             if (s.finished[l]) continue;
             emu_lane = l;
             swapcontext(&s.main_ctx, &s.ctx[l]);
             if (!s.finished[l]) ++alive;
         }
-        bool any_fin = false, any_alive = false;
-        for (int l = 0; l < kLanes; ++l) (s.finished[l] ? any_fin : any_alive) = true;
-        if (any_fin && any_alive) { fprintf(stderr, "emu: row-divergent control flow (a lane finished early)\n"); abort(); }
-        for (int l = 1; l < kLanes; ++l)
-            if (s.nxchg[l] != s.nxchg[0]) { fprintf(stderr, "emu: lanes disagree on the number of cross-lane ops\n"); abort(); }
         if (!alive) break;
     }
-    for (int l = 0; l < kLanes; ++l) free(s.stacks[l]);
+    for (int r = 0; r < lanes; r += 16)
+        for (int l = r + 1; l < r + 16; ++l)
+            if (s.gen[l] != s.gen[r]) { fprintf(stderr, "emu: the lanes of a row disagree on the number of cross-lane ops\n"); abort(); }
+    for (int l = 0; l < lanes; ++l) free(s.stacks[l]);
     g_s = nullptr;
 }
 
@@ -99,6 +123,12 @@ static void job_entry(void* a) {
     solve_row<H>(*j->P, j->tab, j->io, j->lds);
 }
 
+template <int H>
+static void job_twin_entry(void* a) {  // the fused kernel on a main / twin pair of rows
+    Job<H>* j = static_cast<Job<H>*>(a);
+    if constexpr (H > 1 && H % 2 == 0) solve_row_with<H, kModeMpc, false, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+}
+static bool g_emu_twin = false;  // a1mpc_emu_set_twin(): the fused entry points run main / twin pairs
 template <int H>
 static void run_batch(const DeviceParams* P, int n, const double* x0, const double* xref, const double* R, const double* foot,
                       const uint8_t* contact, double* grf, double* u_full, double* warm_x, double* warm_y, double* rho,
@@ -126,11 +156,13 @@ static void run_batch(const DeviceParams* P, int n, const double* x0, const doub
         j.io.iters = iters ? iters + b : nullptr;
         j.io.status = status ? status + b : nullptr;
         j.io.nfact = nfact ? nfact + b : nullptr;
-        run_row(job_entry<H>, &j);
+        if (g_emu_twin && H > 1 && H % 2 == 0) run_row(job_twin_entry<H>, &j, 32);
+        else run_row(job_entry<H>, &j);
     }
 }
 
 }  // namespace a1mpc
+extern "C" void a1mpc_emu_set_twin(int on) { a1mpc::g_emu_twin = on != 0; }
 
 namespace a1mpc {
 template <int H>
@@ -139,9 +171,11 @@ template <int H>
 static void split_setup_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); setup_row<H>(*j->a, j->a->tab, j->b, j->lds, j->prep); }
 template <int H>
 static void split_admm_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); admm_rows<H>(*j->a, j->prep, j->counter, j->lds); }
+template <int H>
+static void split_admm_twin_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); admm_rows<H, true>(*j->a, j->prep, j->counter, j->lds); }
 // the split pipeline on host fibers: K1 for every QP, then `nrows` persistent rows draining the queue one after another
 template <int H>
-static void run_split(const BatchArgs& a, int nrows) {
+static void run_split(const BatchArgs& a, int nrows, bool twin = false) {
     std::vector<double> tab(2 * H * H);
     fill_gamma_beta_table(H, tab.data());
     BatchArgs aa = a; aa.tab = tab.data();
@@ -157,6 +191,7 @@ static void run_split(const BatchArgs& a, int nrows) {
     for (int r = 0; r < nrows; ++r) {
         for (auto& v : lds2) v = NAN;
         j.lds = lds2.data();
+        if constexpr (H > 1) { if (twin) { run_row(split_admm_twin_entry<H>, &j, 32); continue; } }
         run_row(split_admm_entry<H>, &j);
     }
 }
@@ -168,11 +203,13 @@ extern "C" int a1mpc_emu_solve_split(const a1mpc::DeviceParams* P, int horizon, 
     memset(&a, 0, sizeof a);
     a.P = *P; a.n = n; a.x0 = x0; a.xref = xref; a.R = R; a.foot = foot; a.contact = contact; a.grf = grf; a.u_full = u_full;
     a.warm_x = warm_x; a.warm_y = warm_y; a.rho = rho; a.iters = iters; a.status = status; a.nfact = nfact;
+    const bool twin = nrows < 0;  // nrows < 0: -nrows persistent main / twin PAIRS of rows (the device's persistent kernel)
+    if (twin) nrows = -nrows;
     switch (horizon) {
         case 1: a1mpc::run_split<1>(a, nrows); return 0;
-        case 10: a1mpc::run_split<10>(a, nrows); return 0;
-        case 16: a1mpc::run_split<16>(a, nrows); return 0;
-        case 20: a1mpc::run_split<20>(a, nrows); return 0;
+        case 10: a1mpc::run_split<10>(a, nrows, twin); return 0;
+        case 16: a1mpc::run_split<16>(a, nrows, twin); return 0;
+        case 20: a1mpc::run_split<20>(a, nrows, twin); return 0;
     }
     return -1;
 }

@@ -89,6 +89,15 @@ def test_build_hazard_check_flags_early_dpp_reads(pkg, tmp_path):
         "trans_result_after_one": ("\tv_rcp_f64 v[2:3], v[6:7]\n" + filler + "\tv_fma_f64 v[12:13], -v[6:7], v[2:3], 1.0\n", False),
         "trans_then_unrelated": ("\tv_rcp_f64 v[2:3], v[6:7]\n\tv_fma_f64 v[12:13], -v[6:7], v[8:9], 1.0\n", False),
     })
+    swap = "\tv_permlane32_swap_b32_e32 v2, v40\n"
+    cases.update({
+        # twin_exchange(): v_permlane32_swap reads BOTH operands 2 wait states after a VALU write at the earliest, and writes both
+        "swap_after_copy": ("\tv_mov_b32_e32 v40, v2\n" + swap, True),
+        "swap_after_write_of_vdst": ("\tv_add_f64 v[2:3], v[6:7], v[8:9]\n" + filler + swap, True),
+        "swap_padded": ("\tv_mov_b32_e32 v40, v2\n\ts_nop 1\n" + swap, False),
+        "swap_writes_its_source": (swap + "\tv_fmac_f64_dpp v[10:11], v[40:41], v[4:5] row_newbcast:0 row_mask:0xf bank_mask:0xf\n", True),
+        "swap_then_dpp_padded": (swap + filler * 2 + "\tv_fmac_f64_dpp v[10:11], v[40:41], v[4:5] row_newbcast:0 row_mask:0xf bank_mask:0xf\n", False),
+    })
     for name, (body, bad) in cases.items():
         f = tmp_path / (name + ".s")
         f.write_text(head + body)

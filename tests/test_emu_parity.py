@@ -178,3 +178,53 @@ def test_emulated_failed_tick_does_not_poison_warm_start(oracle, scen):
         if t == 2:
             cold = emu.solve(one, 1)
             assert cold["iters"][0] == out["iters"][0] and np.abs(cold["u"] - out["u"]).max() < 1e-12
+
+
+# ---- main / twin pairs of rows (RowSolver<.., TWIN>: what every device kernel with H > 1 runs) ------------------------------------------------
+@pytest.mark.parametrize("gen,kw,n", [("config3_random_flat", dict(nb=8), 5), ("config4_random_h16", dict(nb=4), 2), ("config5_divergent", dict(nb=4), 2)])
+def test_emulated_twin_rows_match_the_single_row_code_bit_for_bit(oracle, scen, gen, kw, n):
+    """the pair splits the per-lane state by horizon step and the two products of a backward step, and swaps values between the rows
+    (twin_exchange); every value is formed by the same operations in the same order as in the single-row code"""
+    sc = getattr(scen, gen)(**kw)
+    one = emu.solve(sc, n)
+    two = emu.solve(sc, n, twin=True)
+    assert np.array_equal(one["u"], two["u"]) and np.array_equal(one["grf"], two["grf"])
+    assert (one["iters"] == two["iters"]).all() and (one["status"] == two["status"]).all() and (one["nfact"] == two["nfact"]).all()
+    compare(two, oracle_batch(oracle, sc, n), tol=1e-8, min_same=1.0)
+
+
+def test_emulated_twin_rows_in_the_persistent_kernel(oracle, scen):
+    """set-up kernel -> persistent main / twin pairs pulling QPs from the shared counter (the queue index travels from the main row to its twin)"""
+    sc = scen.config3_random_flat(nb=8)
+    out = emu.solve(sc, 7, split_rows=2, twin=True)
+    ref = oracle_batch(oracle, sc, 7)
+    assert (out["nfact"] == ref["nfact"]).all()
+    compare(out, ref, tol=1e-8, min_same=1.0)
+    assert np.array_equal(out["u"], emu.solve(sc, 7)["u"])
+
+
+def test_emulated_twin_rows_warm_start_first_iteration_and_small_rho(oracle, scen):
+    """the FIRST-iteration variant (warm start: y0 parked in the w registers of the row that owns the step) and the variant that carries
+    G = c P x + c g through the iterations while rho is small (each row updates the G of its own steps)"""
+    sc = scen.config2_trot_sequence(4)
+    pr = oracle_params(oracle, sc); st = oracle.default_settings(warm_start=1)
+    wx = np.zeros(120); wy = np.zeros(200); rho = None
+    ewx = np.zeros((1, 120)); ewy = np.zeros((1, 200)); erho = np.zeros(1)
+    for t in range(4):
+        r = oracle.mpc_solve(pr, st, sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t], warm_x=wx, warm_y=wy, warm_rho=rho)
+        wx, wy, rho = r["warm_x"], r["warm_y"], r["rho"]
+        one = {k: (sc[k][t:t + 1] if k in ("x0", "xref", "R", "foot", "contact") else sc[k]) for k in sc}
+        out = emu.solve(one, 1, warm=(ewx, ewy, erho), warm_start=1, twin=True)
+        assert out["iters"][0] == r["info"].iters and np.abs(out["u"][0] - r["u"]).max() < 1e-8
+    sc = scen.config3_random_flat(nb=3)
+    over = dict(rho0=1e-5, adaptive_rho=0, max_iter=60)   # rho <= kRhoCareful from the start
+    a = emu.solve(sc, 3, **over); b = emu.solve(sc, 3, twin=True, **over)
+    assert np.array_equal(a["u"], b["u"]) and (a["iters"] == b["iters"]).all()
+
+
+def test_emulated_twin_rows_non_finite_input(oracle, scen):
+    sc = scen.config3_random_flat(nb=2)
+    sc["x0"][0, 4] = np.nan
+    out = emu.solve(sc, 2, twin=True)
+    assert out["status"][0] == -7 and (out["grf"][0] == 0).all() and np.isnan(out["u"][0]).all()
+    assert out["status"][1] == 1
