@@ -39,8 +39,9 @@ summ = {k: {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v
 tot = sum(summ.get(k, {}).get(c, {}).get("mean_per_launch", 0.0) for k in summ for c in ("FETCH_SIZE", "WRITE_SIZE"))
 summ["_hbm_bytes_per_solve_batch_launch"] = tot * 1024.0
 summ["hbm_bytes_per_launch"] = tot * 1024.0
-# executed FP64: wave-level instruction counts x the lanes that do useful work (set-up kernel: 4 rows x 12 lanes of 64; ADMM kernel: 2 x 12)
-live = {"setup_kernel": 48, "admm_kernel": 24}
+# executed FP64: wave-level instruction counts x the live lanes (set-up kernel: 4 rows x 12 lanes of 64; ADMM kernel: 2 QPs x (main + twin row) x 12 --
+# the twin row's share of the work that it computes redundantly with its main row, the costate / roll-out recurrences, is counted: it is executed)
+live = {"setup_kernel": 48, "admm_kernel": 48}
 ex = 0.0
 for k, lanes in live.items():
     c = summ.get(k, {})
