@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
     if (kTwin && row >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
     const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
     if (b >= a.n) return;  // row-uniform (a twin leaves with its main row): the other rows of the wave keep all their DPP sources
-    solve_row_with<H, MODE, false, kTwin>(a.P, a.tab, [&]() { return make_io<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+    solve_row_with<H, MODE, false, kTwin>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
 }
 
 // General path (per-step feet / per-step contact schedules: S/ConvexMpc.h:74 B_mat_d_list, S/test/test_mpc.cpp:106-122): the fused kernel
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     const int row = static_cast<int>(threadIdx.x) >> 4;
     const int64_t b = static_cast<int64_t>(blockIdx.x);
-    const ProblemIO io = make_io<H, kModeMpc>(a, b);
+    const ProblemIO io = make_io_sched<H, kModeMpc>(a, b);
     static_assert(Prep<H>::STRIDE <= H * Layout<H>::SLOT, "the hand-off record fits the (still empty) factor region");
     {
         RowSolver<H, kModeMpc> S(a.P, a.tab, a1mpc_lds);
@@ -83,9 +83,12 @@ __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a
 }
 
 // ---- split pipeline (large batches) -----------------------------------------------------------------------------
-// K1: formation + Ruiz, 4 QPs per wavefront, 2.8 KB of LDS per QP (H = 10) -> many waves per CU hide the sweep's latency.
-template <int H>
-__global__ __launch_bounds__(64, 2) void a1mpc_setup_kernel(const KernelArgs a, double* __restrict__ prep) {
+// K1: formation + Ruiz, 4 QPs per wavefront, 2.8 KB of LDS per QP (H = 10).  WAVES = 2: two waves per SIMD hide each other's latencies (256 registers
+// each: 35 doubles per lane spill at H = 10, 137 at H = 20).  WAVES = 1: all 512 registers, nothing spills -- faster when the batch is one round of
+// waves anyway (4096 QPs at H = 10: 0.157 -> 0.139 ms) and at H = 20, where the spills cost more than the second wave hides (16 384 QPs: 1.84 -> 1.32 ms);
+// slower otherwise (65 536 x h10: 1.48 -> 1.91 ms).  launch_split_rows() picks.
+template <int H, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void a1mpc_setup_kernel(const KernelArgs a, double* __restrict__ prep) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     const int row = static_cast<int>(threadIdx.x) >> 4;
     const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + row;
@@ -360,7 +363,11 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     int res = 0;
     if (a1mpc_status st = resident_workgroups<H, ROWS>(&res); st != A1MPC_OK) return st;
     A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
-    hipLaunchKernelGGL((a1mpc_setup_kernel<H>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
+    // `res` workgroups of the ADMM kernel are resident = one per SIMD: a batch of at most that many set-up waves is a single round
+    if (H >= 20 || (a.n + 3) / 4 <= res)
+        hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
+    else
+        hipLaunchKernelGGL((a1mpc_setup_kernel<H, 2>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
     A1_HIP(hipGetLastError());
     if (a.predict && a.cost != nullptr && a.order != nullptr) {  // no history: the queue order comes from the set-up kernel's cost guesses
         hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, static_cast<int>(a.n), static_cast<const int32_t*>(a.cost),
@@ -1689,7 +1696,8 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     a.tick = d_tick; a.x0 = d_x0; a.xref = d_x_ref; a.R = d_R_world; a.foot = d_foot_abs; a.contact = d_contact;
     a.grf = d_grf_body_out; a.u_full = d_u_full_out; a.iters = d_iters_out; a.status = d_status_out; a.nfact = h->d_nfact;
     if (h->cfg.warm_start) { a.warm_x = h->d_wx; a.warm_y = h->d_wy; a.rho = h->d_rho; }
-    if (foot_stride != 0 || contact_stride != 0 || d_yaw_A != nullptr) {  // general path: per-step B_d and / or a per-step contact schedule
+    a.contact_stride = contact_stride;  // a per-step contact schedule alone (feet step-invariant) stays on the fast path: contacts only change bounds and equality rows
+    if (foot_stride != 0 || d_yaw_A != nullptr) {  // general path: per-step B_d (and / or its own A_c yaw), with or without a contact schedule
         if (d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "per-step feet / contacts are not combined with tick records");
         a.foot_stride = foot_stride; a.contact_stride = contact_stride; a.yaw_A = d_yaw_A;
         h->staged = false;

@@ -73,10 +73,10 @@ struct ProblemIO {
     const double* xref;      // 13*H
     const double* R;         // 9, row-major root_rot_mat
     const double* foot;      // 12, 3x4 column-major foot_pos_abs (world-aligned, CoM-relative); GEN: + foot_stride doubles per horizon step
-    const uint8_t* contact;  // 4; GEN: + contact_stride bytes per horizon step
+    const uint8_t* contact;  // 4; + contact_stride bytes per horizon step
     int32_t foot_stride;     // GEN only: 0 = the same feet at every step (S/A1RobotControl.cpp:498-514), 12 = per-step feet (S/test/test_mpc.cpp:106-122)
     const double* yaw_A;     // GEN only, or null: the yaw A_c is built from when it is not mpc_states[2] (S/test/test_mpc.cpp:94-102 passes an average yaw)
-    int32_t contact_stride;  // GEN only: 0 = contacts broadcast over the horizon (S/ConvexMpc.cpp:228-245), 4 = a per-step contact schedule
+    int32_t contact_stride;  // 0 = contacts broadcast over the horizon (S/ConvexMpc.cpp:228-245), 4 = a per-step contact schedule (read by every set-up: make_io_sched / make_io_gen)
     double* grf;             // 12 out: 3x4 column-major body-frame GRFs
     double* u_full;          // 12*H out (world frame, all steps) or null
     double* warm_x;          // 12*H in/out or null   (unscaled primal, OSQP workspace x)
@@ -200,7 +200,7 @@ struct LayoutSetup {
 template <int H>
 struct Prep {
     static constexpr int RR0 = 0, RR1 = H, DI2 = 2 * H, CG = 3 * H, BT = 4 * H;  // per-lane fields
-    static constexpr int CSC = BT + 6, CY = CSC + 1, SY = CY + 1, RHO = SY + 1, LO = RHO + 1, HI = LO + 1, EQ = HI + 1, FLAGS = EQ + 1;
+    static constexpr int CSC = BT + 6, CY = CSC + 1, SY = CY + 1, RHO = SY + 1, CM = RHO + 1, HI = CM + 1, EQ = HI + 1, FLAGS = EQ + 1;  // CM: contact bit of my leg per step (HI: spare)
     static constexpr int XH = FLAGS + 1;
     static constexpr int FIELDS = XH + H;
     static constexpr int STRIDE = FIELDS * 12;  // doubles per QP: 5.2 KB cold / 6.1 KB warm at H = 10
@@ -252,8 +252,10 @@ struct RowSolver {
     double Brw[12];  // my row of B~ (state layout; zeros on lanes without a wrench state): step-invariant, so it stays in registers --
                      // an LDS read costs the wave ~12 issue cycles whatever its width (tools/ubench/issue_cost_ubench.hip)
     double cy, sy, fA, fB, fC, fP, gA, gB, gC, gV, q2s, r2a;
-    double csc, cinv, qd, lo_u, hi_u, lb0, ub0;
+    double csc, cinv, qd, lo_u, hi_u, lb0, ub0;   // (lo_u .. ub0: step 0's)
+    double lbk[HS], ubk[HS];  // bounds of my slot-0 row per slot: contacts may follow a per-step schedule (contact_stride = 4); the general path keeps them in LDS
     unsigned eqmask;  // bit t: my slot-0 row at step t is an equality row (swing leg: l = u = 0; auxil.c set_rho_vec)
+    unsigned cmask;   // bit t: my leg is in contact at step t
     int r0, r1;       // reference row numbers of my two rows inside a (step, leg) block
     // hot state (see setup()): 6 doubles per horizon step and lane
     double xh[HS], wh0[HS], wh1[HS], rr0[HS], rr1[HS], dI2[HS];
@@ -332,8 +334,17 @@ struct RowSolver {
         return dot_bc<0>(Br, u);  // lanes without a wrench state read the zero row
     }
     // ---- per-step accessors (GEN: tables in LDS; otherwise the step-invariant registers)
-    A1_DEV double lb_at(int t) const { if constexpr (GEN) return lds[L::LBT + t * 12 + ci]; else return lb0; }
+    A1_DEV double lb_at(int t) const { if constexpr (GEN) return lds[L::LBT + t * 12 + ci]; else return lb0; }  // (GEN callers only)
     A1_DEV double ub_at(int t) const { if constexpr (GEN) return lds[L::UBT + t * 12 + ci]; else return ub0; }
+    template <int K>
+    A1_DEV double lbs(int t) const { if constexpr (GEN) return lds[L::LBT + t * 12 + ci]; else return lbk[K]; }  // slot K = horizon step t
+    template <int K>
+    A1_DEV double ubs(int t) const { if constexpr (GEN) return lds[L::UBT + t * 12 + ci]; else return ubk[K]; }
+    A1_DEV void slot_bounds(int k, int t) {  // from the contact bit of step t
+        const double cf = (cmask >> t) & 1u ? 1.0 : 0.0;
+        lbk[k] = comp == 2 ? P.fz_min * cf : 0.0;
+        ubk[k] = comp == 2 ? P.fz_max * cf : kInfty;
+    }
     A1_DEV void Bt_at(int t, double (&o)[6]) const {  // my column of B~_t (force layout)
 #pragma unroll
         for (int k = 0; k < 6; ++k) o[k] = Bt[k];
@@ -695,15 +706,19 @@ struct RowSolver {
         // OSQP's first iteration starts from z0 = A x0 (not projected) and y0; with x0 = y0 = 0 and 0 inside the bounds it
         // coincides with the generic w-form iteration from w = 0
         first_special = warm || !(P.fz_min <= 0.0 && P.fz_max >= 0.0);
-        eqmask = 0;
+        eqmask = 0; cmask = 0;
         row_sync();  // the Ruiz D table (aliased into the factor region) is dead from here on
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
-            [[maybe_unused]] double lo_t = lo_u, hi_t = hi_u;
-            if constexpr (GEN) {  // the step's contact flags (a per-step schedule when contact_stride = 4): bounds of my slot-0 row at step t
-                const double cf = (act && io.contact[static_cast<int64_t>(t) * io.contact_stride + quad]) ? 1.0 : 0.0;
-                lo_t = P.fz_min * cf; hi_t = P.fz_max * cf;
+            // the step's contact flags (a per-step schedule when contact_stride = 4): bounds of my slot-0 row at step t
+            const bool ct = act && io.contact[static_cast<int64_t>(t) * io.contact_stride + quad];
+            const double cf = ct ? 1.0 : 0.0;
+            const double lo_t = P.fz_min * cf, hi_t = P.fz_max * cf;
+            if (ct) cmask |= 1u << t;
+            if constexpr (GEN) {
                 if (act) { lds[L::LBT + t * 12 + ci] = comp == 2 ? lo_t : 0.0; lds[L::UBT + t * 12 + ci] = comp == 2 ? hi_t : kInfty; }
+            } else if constexpr (!TWIN) {
+                lbk[t] = comp == 2 ? lo_t : 0.0; ubk[t] = comp == 2 ? hi_t : kInfty;
             }
             const bool eq = comp == 2 && (E0[t] * hi_t - E0[t] * lo_t < kRhoTol);
             if (eq) eqmask |= 1u << t;
@@ -754,7 +769,7 @@ struct RowSolver {
 #pragma unroll
         for (int k = 0; k < 6; ++k) p[(PR::BT + k) * 12 + ci] = Bt[k];
         p[PR::CSC * 12 + ci] = csc; p[PR::CY * 12 + ci] = cy; p[PR::SY * 12 + ci] = sy; p[PR::RHO * 12 + ci] = rho;
-        p[PR::LO * 12 + ci] = lo_u; p[PR::HI * 12 + ci] = hi_u;
+        p[PR::CM * 12 + ci] = static_cast<double>(cmask); p[PR::HI * 12 + ci] = 0.0;
         p[PR::EQ * 12 + ci] = static_cast<double>(eqmask);
         p[PR::FLAGS * 12 + ci] = (warm ? 1.0 : 0.0) + (first_special ? 2.0 : 0.0);
     }
@@ -796,7 +811,10 @@ struct RowSolver {
         csc = p[PR::CSC * 12 + ci]; cinv = 1.0 / csc; qd = csc * q2s;
         set_rotation(p[PR::CY * 12 + ci], p[PR::SY * 12 + ci]);
         rho = p[PR::RHO * 12 + ci];
-        lo_u = am * p[PR::LO * 12 + ci]; hi_u = am * p[PR::HI * 12 + ci];
+        cmask = act ? static_cast<unsigned>(p[PR::CM * 12 + ci]) : 0u;
+#pragma unroll
+        for (int k = 0; k < HS; ++k) slot_bounds(k, TWIN ? 2 * k + tw : k);
+        lo_u = P.fz_min * (cmask & 1u ? 1.0 : 0.0); hi_u = P.fz_max * (cmask & 1u ? 1.0 : 0.0);
         lb0 = comp == 2 ? lo_u : 0.0; ub0 = comp == 2 ? hi_u : kInfty;
         eqmask = act ? static_cast<unsigned>(p[PR::EQ * 12 + ci]) : 0u;
         sync();
@@ -954,7 +972,7 @@ struct RowSolver {
     A1_DEV void admm_iteration_single() {
         // Loop-invariant scalars are laundered through row_opaque() once per iteration: otherwise LICM hoists every
         // per-step product that only depends on them out of the ADMM loop and the register file overflows.
-        const double sigma_l = row_opaque(P.sigma), lb0_l = row_opaque(lb0), ub0_l = row_opaque(ub0);
+        const double sigma_l = row_opaque(P.sigma);
         const double al = P.alpha, oma = 1.0 - P.alpha;
         const double muz = comp == 2 ? mu : 0.0, mux = comp < 2 ? mu : 0.0, al1 = comp < 2 ? al : 0.0;  // selects folded into multipliers
         // One wave per SIMD: every instruction costs an issue slot, so the sweeps are written for instruction count --
@@ -975,7 +993,7 @@ struct RowSolver {
             const double cgt = lds[L::CG + t * 12 + ci];
             [[maybe_unused]] double Btl[6];
             if constexpr (GEN) Bt_at(t, Btl);
-            const double lbt = GEN ? lb_at(t) : lb0_l, ubt = GEN ? ub_at(t) : ub0_l;
+            const double lbt = lbs<t>(t), ubt = ubs<t>(t);
             row_sched_fence();
             // rhs of update_xz_tilde premultiplied by D^-1:  b = sigma D^-2 xh - c g + A' [E (rho z_s - y_s)]
             double t0, t1;
@@ -1026,7 +1044,7 @@ struct RowSolver {
 #pragma unroll
                 for (int b = 0; b < 12; ++b) Brl[b] = br[b];
             }
-            const double lbt = GEN ? lb_at(t) : lb0_l, ubt = GEN ? ub_at(t) : ub0_l;
+            const double lbt = lbs<t>(t), ubt = ubs<t>(t);
             row_sched_fence();
             // v_t = d_t - K_t x_t,  xh <- alpha v + (1 - alpha) xh,  x_{t+1} = A x_t + B~ v_t   (instruction blocks)
             const double am = act ? 1.0 : 0.0;  // pad lanes carry no force
@@ -1109,7 +1127,7 @@ struct RowSolver {
     template <bool FIRST, bool CAREFUL>
     A1_DEV void admm_iteration_twin() {
         static_assert(H % 2 == 0, "twin rows split the horizon steps in pairs");
-        const double sigma_l = row_opaque(P.sigma), lb0_l = row_opaque(lb0), ub0_l = row_opaque(ub0);
+        const double sigma_l = row_opaque(P.sigma);
         const double al = P.alpha, oma = 1.0 - P.alpha;
         const double muz = comp == 2 ? mu : 0.0, mux = comp < 2 ? mu : 0.0, al1 = comp < 2 ? al : 0.0;
         const double am = act ? 1.0 : 0.0;  // pad lanes carry no force
@@ -1154,7 +1172,7 @@ struct RowSolver {
                 t0 = rr0[k] * (comp == 2 ? xh[k] : fma(mu, xz, xh[k])) - csc * yw0;
                 t1 = rr1[k] * fma(-mu, xz, xh[k]) - csc * yw1;
             } else {
-                const double z0 = min_f64(max_f64(wh0[k], lb0_l), ub0_l), z1 = min_f64(wh1[k], 0.0);
+                const double z0 = min_f64(max_f64(wh0[k], lbk[k]), ubk[k]), z1 = min_f64(wh1[k], 0.0);
                 t0 = rr0[k] * fma(2.0, z0, -wh0[k]);
                 t1 = rr1[k] * fma(2.0, z1, -wh1[k]);
             }
@@ -1206,11 +1224,11 @@ struct RowSolver {
             const double xh_old = xh[k];
             [[maybe_unused]] double gt0 = 0.0, gt1 = 0.0;
             if constexpr (CAREFUL) {
-                const double zp0 = min_f64(max_f64(wh0[k], lb0_l), ub0_l), zp1 = min_f64(wh1[k], 0.0);
+                const double zp0 = min_f64(max_f64(wh0[k], lbk[k]), ubk[k]), zp1 = min_f64(wh1[k], 0.0);
                 gt0 = rr0[k] * fma(2.0, zp0, -wh0[k]);
                 gt1 = rr1[k] * fma(2.0, zp1, -wh1[k]);
             }
-            const double z0 = min_f64(max_f64(wh0[k], lb0_l), ub0_l);
+            const double z0 = min_f64(max_f64(wh0[k], lbk[k]), ubk[k]);
             xh[k] = fma(al, v, oma * xh[k]);
             const double vz = quad_perm<2, 2, 2, 2>(v);
             const double av0 = fma(mux, vz, v);
@@ -1313,7 +1331,7 @@ struct RowSolver {
             const double uz = quad_perm<2, 2, 2, 2>(xh[k]);
             const double ax0 = comp == 2 ? xh[k] : fma(mu, uz, xh[k]);  // E^-1 (A_s x)
             const double ax1 = comp < 2 ? fma(-mu, uz, xh[k]) : 0.0;
-            const double z0 = min_f64(max_f64(wh0[k], lb_at(t)), ub_at(t)), z1 = min_f64(wh1[k], 0.0);  // E^-1 z
+            const double z0 = min_f64(max_f64(wh0[k], lbs<k>(t)), ubs<k>(t)), z1 = min_f64(wh1[k], 0.0);  // E^-1 z
             const double rp0 = ax0 - z0, rp1 = ax1 - z1;
             const bool eq = (eqmask >> t) & 1u;
             const double e0 = rr0[k] * (eq ? irho_eq : irho), e1 = rr1[k] * irho;  // E^2
@@ -1424,8 +1442,8 @@ struct RowSolver {
                     if (rn > rho * P.adaptive_rho_tol || rn < rho / P.adaptive_rho_tol) {
                         // y_s = rho E (wh - zh) is kept:  wh <- zh + (rho_old / rho_new) (wh - zh),  rr <- rr rho_new / rho_old
                         const double up = rn / rho, dn = rho / rn;
-                        static_for<HS>([&](auto T) {  // (bounds: only the general path's depend on the step, and it has no twin rows)
-                            const double z0 = fmin(fmax(wh0[T], lb_at(A1_CV(T))), ub_at(A1_CV(T))), z1 = fmin(wh1[T], 0.0);
+                        static_for<HS>([&](auto T) {  // (the general path has no twin rows: its slot is its step)
+                            const double z0 = fmin(fmax(wh0[T], lbs<A1_CV(T)>(A1_CV(T))), ubs<A1_CV(T)>(A1_CV(T))), z1 = fmin(wh1[T], 0.0);
                             wh0[T] = fma(dn, wh0[T] - z0, z0);
                             wh1[T] = fma(dn, wh1[T] - z1, z1);
                             rr0[T] *= up;
@@ -1480,7 +1498,7 @@ struct RowSolver {
                 // iterates after a failed solve)
                 if (io.warm_x) io.warm_x[t * 12 + ci] = nanout ? 0.0 : xu;
                 if (io.warm_y) {  // y = c^-1 E y_s = c^-1 rr (wh - Pi(wh))
-                    const double z0 = fmin(fmax(wh0[k], lb_at(t)), ub_at(t)), z1 = fmin(wh1[k], 0.0);
+                    const double z0 = fmin(fmax(wh0[k], lbs<k>(t)), ubs<k>(t)), z1 = fmin(wh1[k], 0.0);
                     io.warm_y[t * 20 + 5 * quad + r0] = nanout ? 0.0 : cinv * rr0[k] * (wh0[k] - z0);
                     if (comp < 2) io.warm_y[t * 20 + 5 * quad + r1] = nanout ? 0.0 : cinv * rr1[k] * (wh1[k] - z1);
                 }
@@ -1540,6 +1558,16 @@ A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
     return io;
 }
 
+// The fast path with a per-step contact schedule (contact_stride = 4; feet step-invariant): contacts only change the bounds and which rows are
+// equalities, so every kernel of the fast path takes them -- the set-ups read the schedule, the hand-off record carries the contact bits.
+template <int H, int MODE>
+A1_DEV ProblemIO make_io_sched(const BatchArgs& a, int64_t b) {
+    ProblemIO io = make_io<H, MODE>(a, b);
+    io.contact = a.contact + b * (a.contact_stride ? 4 * H : 4);
+    io.foot_stride = 0; io.contact_stride = a.contact_stride; io.yaw_A = nullptr;
+    return io;
+}
+
 // The general path's records (per-step feet / contacts, A_c yaw).  A separate function on purpose: make_io() is inlined into the persistent ADMM
 // kernel, whose register allocation is sensitive to every instruction around the hot loop -- with the stride selects inside make_io() the
 // same hot loop came out 7 % slower per iteration (tools/ab_kernels.sh: 10.3 -> 10.8 ms at 65 536 QPs).
@@ -1556,7 +1584,7 @@ A1_DEV ProblemIO make_io_gen(const BatchArgs& a, int64_t b) {
 template <int H>
 A1_DEV void setup_row(const BatchArgs& a, const double* __restrict__ tab, int64_t b, double* __restrict__ lds, double* __restrict__ prep) {
     RowSolver<H, kModeMpc, true> S(a.P, tab, lds);  // tab: the (alpha/beta, beta) table, staged in LDS by the kernel
-    S.setup(make_io<H, kModeMpc>(a, b));
+    S.setup(make_io_sched<H, kModeMpc>(a, b));
     S.save_prepared(prep + b * Prep<H>::STRIDE);
     if (a.predict && a.cost != nullptr && S.ln == 0) a.cost[b] = S.pred_cost;
 }

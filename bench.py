@@ -454,7 +454,7 @@ def main():
             "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r02_pmc_summary.json" if traffic else None,
-                         "kernel": "a1mpc_setup_kernel<10> + a1mpc_admm_kernel<10,2> (+ a1mpc_order_kernel, ~5 us) = one solve", "avg_kernel_ms": avg_ms,
+                         "kernel": "a1mpc_setup_kernel<10,1> + a1mpc_admm_kernel<10,2> (+ a1mpc_order_kernel, ~5 us) = one solve", "avg_kernel_ms": avg_ms,
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
                          "executed_fp64_flops_per_launch": pmc.get("executed_fp64_flops_per_launch"),
                          "executed_fp64_frac": (pmc["executed_fp64_flops_per_launch"] / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if pmc.get("executed_fp64_flops_per_launch") else None,

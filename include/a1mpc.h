@@ -136,9 +136,11 @@ a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d
  *   contact_stride 0: contact is n x 4, broadcast over the horizon       4: contact is n x 4H, step t of problem i at contact[(i*H + t)*4]
  *   yaw_A          NULL: A_c is built from mpc_states[2] (S/A1RobotControl.cpp:452,492)      else n yaws, one per problem
  *                  (calculate_A_mat_c takes its own euler argument, S/ConvexMpc.h:28; S/test/test_mpc.cpp:94-104 passes an average)
- * Everything else as a1mpc_solve_batch.  (0, 0, NULL) IS a1mpc_solve_batch (same kernels, same bits).  Any other combination runs the
- * general kernels: same OSQP iterates as the reference's formation with those inputs, with a bigger LDS image per QP (B~_t and the
- * bounds of every step), i.e. fewer QPs in flight -- slower by design.  Horizons 10, 16, 20.
+ * Everything else as a1mpc_solve_batch.  (0, 0, NULL) IS a1mpc_solve_batch (same kernels, same bits).  (0, 4, NULL) -- a gait schedule over the
+ * horizon with step-invariant feet, the case a controller with a contact plan has -- also runs the fast kernels at their speed: contacts only
+ * change the bounds and which rows are equalities (any horizon a1mpc_create accepts).  Per-step feet and / or a yaw_A run the general kernels:
+ * same OSQP iterates as the reference's formation with those inputs, with a bigger LDS image per QP (B~_t and the bounds of every step), i.e.
+ * fewer QPs in flight -- 3-6x slower by design.  Horizons 10, 16, 20.
  */
 a1mpc_status a1mpc_solve_batch_strided(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
                                        const double* foot_abs, int32_t foot_stride, const uint8_t* contact, int32_t contact_stride,

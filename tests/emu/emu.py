@@ -60,9 +60,10 @@ def _p(a, t=C.c_double):
     return None if a is None else a.ctypes.data_as(C.POINTER(t))
 
 
-def solve(sc, n=None, settings=None, warm=None, split_rows=0, twin=False, **over):
+def solve(sc, n=None, settings=None, warm=None, split_rows=0, twin=False, contact_schedule=None, **over):
     """split_rows > 0: run the two-kernel pipeline (set-up kernel, then `split_rows` persistent ADMM rows) instead of the fused path;
-    twin: the iterations run on main / twin PAIRS of rows (RowSolver<.., TWIN>: what the device kernels do for H > 1)"""
+    twin: the iterations run on main / twin PAIRS of rows (RowSolver<.., TWIN>: what the device kernels do for H > 1);
+    contact_schedule: (n, 4h) per-step contacts on the FAST path (feet step-invariant) instead of sc["contact"]"""
     h = sc["horizon"]
     n = len(sc["x0"]) if n is None else n
     P = make_params(sc["params"], settings, **over)
@@ -71,16 +72,27 @@ def solve(sc, n=None, settings=None, warm=None, split_rows=0, twin=False, **over
     wx = wy = rho = None
     if warm is not None:
         wx, wy, rho = warm
+    contact = sc["contact"]
+    if contact_schedule is not None:
+        contact = np.ascontiguousarray(contact_schedule, dtype=np.uint8).reshape(-1, 4 * h)
+    lib().a1mpc_emu_set_contact_stride(4 if contact_schedule is not None else 0)
+    try:
+        return _solve(sc, n, h, P, grf, u, iters, status, nfact, wx, wy, rho, contact, split_rows, twin)
+    finally:
+        lib().a1mpc_emu_set_contact_stride(0)
+
+
+def _solve(sc, n, h, P, grf, u, iters, status, nfact, wx, wy, rho, contact, split_rows, twin):
     if split_rows:
         rc = lib().a1mpc_emu_solve_split(C.byref(P), h, n, -int(split_rows) if twin else int(split_rows), _p(sc["x0"]), _p(sc["xref"]), _p(sc["R"]), _p(sc["foot"]),
-                                         _p(sc["contact"], C.c_uint8), _p(grf), _p(u), _p(wx), _p(wy), _p(rho), _p(iters, C.c_int32),
+                                         _p(contact, C.c_uint8), _p(grf), _p(u), _p(wx), _p(wy), _p(rho), _p(iters, C.c_int32),
                                          _p(status, C.c_int32), _p(nfact, C.c_int32))
         assert rc == 0
         return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
     lib().a1mpc_emu_set_twin(1 if twin else 0)
     try:
         rc = lib().a1mpc_emu_solve(C.byref(P), h, n, _p(sc["x0"]), _p(sc["xref"]), _p(sc["R"]), _p(sc["foot"]),
-                                   _p(sc["contact"], C.c_uint8), _p(grf), _p(u), _p(wx), _p(wy), _p(rho), _p(iters, C.c_int32),
+                                   _p(contact, C.c_uint8), _p(grf), _p(u), _p(wx), _p(wy), _p(rho), _p(iters, C.c_int32),
                                    _p(status, C.c_int32), _p(nfact, C.c_int32))
     finally:
         lib().a1mpc_emu_set_twin(0)

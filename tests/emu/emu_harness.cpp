@@ -129,6 +129,7 @@ static void job_twin_entry(void* a) {  // the fused kernel on a main / twin pair
     if constexpr (H > 1 && H % 2 == 0) solve_row_with<H, kModeMpc, false, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
 }
 static bool g_emu_twin = false;  // a1mpc_emu_set_twin(): the fused entry points run main / twin pairs
+static int g_emu_contact_stride = 0;  // a1mpc_emu_set_contact_stride(): 4 = `contact` is an n x 4H per-step schedule (fast path, feet step-invariant)
 template <int H>
 static void run_batch(const DeviceParams* P, int n, const double* x0, const double* xref, const double* R, const double* foot,
                       const uint8_t* contact, double* grf, double* u_full, double* warm_x, double* warm_y, double* rho,
@@ -147,7 +148,8 @@ static void run_batch(const DeviceParams* P, int n, const double* x0, const doub
         j.io.xref = xref + (size_t)b * 13 * H;
         j.io.R = R + (size_t)b * 9;
         j.io.foot = foot + (size_t)b * 12;
-        j.io.contact = contact + (size_t)b * 4;
+        j.io.contact = contact + (size_t)b * (g_emu_contact_stride ? 4 * H : 4);
+        j.io.contact_stride = g_emu_contact_stride;
         j.io.grf = grf + (size_t)b * 12;
         j.io.u_full = u_full ? u_full + (size_t)b * 12 * H : nullptr;
         j.io.warm_x = warm_x ? warm_x + (size_t)b * 12 * H : nullptr;
@@ -163,6 +165,7 @@ static void run_batch(const DeviceParams* P, int n, const double* x0, const doub
 
 }  // namespace a1mpc
 extern "C" void a1mpc_emu_set_twin(int on) { a1mpc::g_emu_twin = on != 0; }
+extern "C" void a1mpc_emu_set_contact_stride(int stride) { a1mpc::g_emu_contact_stride = stride; }
 
 namespace a1mpc {
 template <int H>
@@ -203,6 +206,7 @@ extern "C" int a1mpc_emu_solve_split(const a1mpc::DeviceParams* P, int horizon, 
     memset(&a, 0, sizeof a);
     a.P = *P; a.n = n; a.x0 = x0; a.xref = xref; a.R = R; a.foot = foot; a.contact = contact; a.grf = grf; a.u_full = u_full;
     a.warm_x = warm_x; a.warm_y = warm_y; a.rho = rho; a.iters = iters; a.status = status; a.nfact = nfact;
+    a.contact_stride = a1mpc::g_emu_contact_stride;
     const bool twin = nrows < 0;  // nrows < 0: -nrows persistent main / twin PAIRS of rows (the device's persistent kernel)
     if (twin) nrows = -nrows;
     switch (horizon) {

@@ -228,3 +228,20 @@ def test_emulated_twin_rows_non_finite_input(oracle, scen):
     out = emu.solve(sc, 2, twin=True)
     assert out["status"][0] == -7 and (out["grf"][0] == 0).all() and np.isnan(out["u"][0]).all()
     assert out["status"][1] == 1
+
+
+@pytest.mark.parametrize("h,twin,split", [(10, False, 0), (10, True, 0), (10, True, 2), (16, True, 0), (20, True, 1)])
+def test_emulated_contact_schedule_on_the_fast_path(oracle, scen, h, twin, split):
+    """a per-step contact schedule with step-invariant feet (contact_stride = 4, foot_stride = 0) stays on the fast kernels: contacts only change
+    the bounds and which rows are equalities; vs the oracle's strided formation, and vs the general path (which solves the same QP)"""
+    rng = np.random.default_rng(700 + h)
+    nb = 3 if h <= 10 else 2
+    sc, foot, fs, contact, cs = _strided_case(scen, rng, h, nb, False, True)
+    out = emu.solve(sc, nb, twin=twin, split_rows=split, contact_schedule=contact)
+    pr = oracle_params(oracle, sc); st = oracle.default_settings()
+    for b in range(nb):
+        r = oracle.mpc_solve(pr, st, sc["x0"][b], sc["xref"][b], sc["R"][b], sc["foot"][b], contact[b], foot_stride=0, contact_stride=4)
+        assert out["iters"][b] == r["info"].iters and out["status"][b] == r["info"].status and out["nfact"][b] == r["info"].nfact, (b, out["iters"][b], r["info"].iters)
+        assert np.abs(out["u"][b] - r["u"]).max() < 1e-8 and np.abs(out["grf"][b] - r["grf"]).max() < 1e-8
+    gen = emu.solve_gen(sc, sc["foot"], 0, contact, 4)
+    assert (gen["iters"] == out["iters"]).all() and np.abs(gen["u"] - out["u"]).max() < 1e-9

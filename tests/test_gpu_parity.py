@@ -619,6 +619,29 @@ def test_per_step_feet_and_contact_schedules(pkg, oracle, scen, h, nb, feet, con
         assert np.abs(u[c == 0]).max() < 1.0
 
 
+@pytest.mark.parametrize("h,nb", [(10, 4500), (10, 700), (10, 1), (16, 1200), (20, 2300)])
+def test_contact_schedule_alone_stays_on_the_fast_kernels(pkg, oracle, scen, h, nb):
+    """a per-step contact schedule with step-invariant feet (contact_stride = 4, foot_stride = 0, no yaw_A): the fast kernels take it (set-up
+    kernel + persistent twin rows, fused kernel, latency kernel by batch size) -- vs the oracle's strided formation on a sample, and vs the
+    general path on every QP (a yaw_A equal to the state's yaw forces the general path onto the same QP)."""
+    rng = np.random.default_rng(4000 + h + nb)
+    sc, foot, fs, contact, cs = _strided_inputs(scen, rng, h, nb, False, True)
+    with _engine(pkg, sc, nb, warm_start=0) as eng:
+        out = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], sc["foot"], 0, contact, 4, want_u=True)
+        gen = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], sc["foot"], 0, contact, 4, want_u=True, yaw_A=sc["x0"][:, 2].copy())
+        ms_fast = None
+    assert (out["status"] == 1).all() and np.array_equal(out["iters"], gen["iters"]) and np.abs(out["u"] - gen["u"]).max() <= 1e-7
+    pr = oracle.mpc_params(h, **{k: sc["params"][k] for k in ("dt", "mu", "fz_min", "fz_max", "q", "r", "mass", "inertia")}); st = oracle.default_settings()
+    worst = 0.0
+    for b in range(0, nb, max(1, nb // 40)):
+        r = oracle.mpc_solve(pr, st, sc["x0"][b], sc["xref"][b], sc["R"][b], sc["foot"][b], contact[b], foot_stride=0, contact_stride=4)
+        assert out["iters"][b] == r["info"].iters and out["status"][b] == r["info"].status, (b, out["iters"][b], r["info"].iters)
+        worst = max(worst, np.abs(out["u"][b] - r["u"]).max(), np.abs(out["grf"][b] - r["grf"]).max())
+    assert worst <= TOL_FORCE_N, worst
+    u = out["u"].reshape(nb, h, 4, 3); c = contact.reshape(nb, h, 4)
+    assert np.abs(u[c == 0]).max() < 1.0   # a leg in swing at step t carries no force at step t
+
+
 def test_failed_tick_leaves_a_cold_start_behind(pkg, oracle, scen):
     """warm start ON, a NaN tick for some robots -> status -7 and zero GRFs for them at that tick, and at the NEXT tick
     they are solved again (a cold start: same answer as a cold solve) instead of staying NaN for ever."""

@@ -16,14 +16,17 @@ for h, n in ((10, 4096), (10, 16384), (16, 8192), (20, 8192)):
     contact = np.ascontiguousarray(np.where(np.arange(h).reshape(1, h, 1) < sw[:, None, :], first[:, None, :], 1 - first[:, None, :]).astype(np.uint8).reshape(n, h * 4))
     cfg = pkg.make_config(sc["params"], h, warm_start=0)
     with pkg.Engine(cfg, n, 0) as eng:
-        ms_f, ms_g = [], []
+        ms_f, ms_g, ms_s = [], [], []
         for _ in range(3):
             eng.set_schedule(True)
             a = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"]); ms_f.append(eng.last_kernel_ms())
             b = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, 12, contact, 4); ms_g.append(eng.last_kernel_ms())
+            eng.set_schedule(True)   # contact schedule alone (feet step-invariant): the fast kernels
+            c = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], sc["foot"], 0, contact, 4); ms_s.append(eng.last_kernel_ms())
     out.append(dict(horizon=h, batch=n, fast_path_kernel_ms=float(np.median(ms_f)), general_path_kernel_ms=float(np.median(ms_g)),
                     fast_solves_per_s=n / (float(np.median(ms_f)) * 1e-3), general_solves_per_s=n / (float(np.median(ms_g)) * 1e-3),
-                    mean_iters_fast=float(a["iters"].mean()), mean_iters_general=float(b["iters"].mean()), solved_general=float((b["status"] == 1).mean())))
+                    schedule_only_kernel_ms=float(np.median(ms_s)), schedule_only_solves_per_s=n / (float(np.median(ms_s)) * 1e-3), mean_iters_schedule_only=float(c["iters"].mean()),
+                    solved_schedule_only=float((c["status"] == 1).mean()), mean_iters_fast=float(a["iters"].mean()), mean_iters_general=float(b["iters"].mean()), solved_general=float((b["status"] == 1).mean())))
     print(out[-1], flush=True)
 os.makedirs("gpurun_out/r02", exist_ok=True)
 json.dump(out, open("gpurun_out/r02/general_path_probe.json", "w"), indent=1)
