@@ -551,6 +551,9 @@ struct RowSolver {
                     if (comp == c) { ud += Ucs[c]; vd += Vcs[c]; }
                 }
                 Udg[s] = ud * dt2; Vdg[s] = vd;
+                // T B~w_t = T (B~w_t): fold the yaw rotation into my step-s factors once, so that a sweep entry needs the B~w_t table only
+                const double c0 = cu[s][0], c1 = cu[s][1];
+                cu[s][0] = (c0 * cy - c1 * sy) * dt2; cu[s][1] = (c0 * sy + c1 * cy) * dt2; cu[s][2] *= dt2;
             });
         }
 
@@ -583,24 +586,27 @@ struct RowSolver {
 #pragma unroll 1
                     for (int t = 0; t < H; ++t) {  // every block is evaluated: a per-block pruning bound like the fast path's was tried and measured slower here
                                                    // (3.11 -> 3.35 ms at 4096 x h10: per-lane skips do not skip at wave level and cost registers)
-                        double gb[2 * H], Dt[12], TBt[3][12], Bwt[3][12];
+                        // entry (s,a),(t,b) = beta_st (y . B~w_t[:,b] + k_{b%3})  with  y = gamma_st dt^2 T'(q T B~w_s[:,a]) + q_w B~w_s[:,a]  and the
+                        // velocity-row constants k: 3 FMAs per entry and one table (round 2; it was 6 FMAs and two tables)
+                        double gb[2 * H], Dt[12], Bwt[3][12];
 #pragma unroll
                         for (int s2 = 0; s2 < H; ++s2) { gb[2 * s2] = tab[(s2 * H + t) * 2]; gb[2 * s2 + 1] = tab[(s2 * H + t) * 2 + 1]; }
 #pragma unroll
                         for (int b = 0; b < 12; ++b) {
                             Dt[b] = lds[L::DL + t * 12 + b];
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) { TBt[c][b] = lds[L::TBW + (t * 3 + c) * 12 + b]; Bwt[c][b] = lds[L::BW + (t * 3 + c) * 12 + b]; }
+                            for (int c = 0; c < 3; ++c) Bwt[c][b] = lds[L::BW + (t * 3 + c) * 12 + b];
                         }
                         static_for<H>([&](auto S) {
                             constexpr int s = A1_CV(S);
                             const double gam = gb[2 * s], bet = gb[2 * s + 1];
+                            const double y0 = fma(gam, cu[s][0], cv[s][0]), y1 = fma(gam, cu[s][1], cv[s][1]), y2 = fma(gam, cu[s][2], cv[s][2]);
+                            const double gd = gam * dt2;
+                            const double k3[3] = {fma(gd, Ucs[0], Vcs[0]), fma(gd, Ucs[1], Vcs[1]), fma(gd, Ucs[2], Vcs[2])};
                             double a0 = 0.0;
                             static_for<12>([&](auto B) {
                                 constexpr int b = A1_CV(B);
-                                const double u = fma(cu[s][2], TBt[2][b], fma(cu[s][1], TBt[1][b], fma(cu[s][0], TBt[0][b], Ucs[b % 3]))) * dt2;
-                                const double v = fma(cv[s][2], Bwt[2][b], fma(cv[s][1], Bwt[1][b], fma(cv[s][0], Bwt[0][b], Vcs[b % 3])));
-                                a0 = fmax(a0, fabs(fma(gam, u, v)) * Dt[b]);
+                                a0 = fmax(a0, fabs(fma(y2, Bwt[2][b], fma(y1, Bwt[1][b], fma(y0, Bwt[0][b], k3[b % 3])))) * Dt[b]);
                             });
                             mm[S] = fmax(mm[S], bet * a0);
                         });
