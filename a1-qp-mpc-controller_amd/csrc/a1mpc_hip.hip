@@ -50,10 +50,12 @@ __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
 template <int H, int ROWS>
 __global__ __launch_bounds__(64) void a1mpc_solve_gen_kernel(const KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    const int row = static_cast<int>(threadIdx.x) >> 4;
+    static_assert(ROWS <= 2, "rows r and r + 2 of the wavefront share a QP (twin rows)");
+    const int row = (static_cast<int>(threadIdx.x) >> 4) & 1;
+    if (row >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
     const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
     if (b >= a.n) return;
-    solve_row_with<H, kModeMpc, true>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H, true>::ROW_STRIDE);
+    solve_row_with<H, kModeMpc, true, true>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H, true>::ROW_STRIDE);
 }
 
 // Latency variant of the fused kernel for a handful of QPs: the four rows of a wavefront work on ONE QP during set-up (each takes every fourth
@@ -429,7 +431,7 @@ static a1mpc_status launch_gen_rows(const KernelArgs& a, hipStream_t stream) {
                                    static_cast<int>(lds)));
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((a1mpc_solve_gen_kernel<H, ROWS>), dim3(static_cast<unsigned>((a.n + ROWS - 1) / ROWS)), dim3(16 * ROWS), lds, stream, a);
+    hipLaunchKernelGGL((a1mpc_solve_gen_kernel<H, ROWS>), dim3(static_cast<unsigned>((a.n + ROWS - 1) / ROWS)), dim3(64), lds, stream, a);
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
 }

@@ -231,7 +231,7 @@ struct Prep {
 template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false, bool TWIN = false>
 struct RowSolver {
     static_assert(!GEN || (MODE == kModeMpc && !SETUP_ONLY && H > 1), "the general path is an MPC solve in the fused kernel");
-    static_assert(!TWIN || (MODE == kModeMpc && !SETUP_ONLY && !GEN && H > 1), "twin rows: the persistent ADMM kernel");
+    static_assert(!TWIN || (MODE == kModeMpc && !SETUP_ONLY && H > 1), "twin rows: the iterations of an MPC solve");
     using L = std::conditional_t<SETUP_ONLY, LayoutSetup<H>, Layout<H, GEN>>;
     using PR = Prep<H>;
     const DeviceParams& P;
@@ -247,7 +247,7 @@ struct RowSolver {
     double dt, mu;
     // per-lane constants of the problem
     double Bt[6];  // my column of B~ (force layout); zero on pad lanes
-    static constexpr bool kBrowInRegs = (H <= 10 && !GEN) || TWIN;  // beyond that the per-lane ADMM state alone (6H doubles; 3H for a twin pair) overflows the register file
+    static constexpr bool kBrowInRegs = ((H <= 10) || TWIN) && !GEN;  // beyond that the per-lane ADMM state alone (6H doubles; 3H for a twin pair) overflows the register file
     static constexpr int HS = TWIN ? H / 2 : H;  // slots of the per-lane state: slot k = step k, or step 2k + tw of a twin pair
     double Brw[12];  // my row of B~ (state layout; zeros on lanes without a wrench state): step-invariant, so it stays in registers --
                      // an LDS read costs the wave ~12 issue cycles whatever its width (tools/ubench/issue_cost_ubench.hip)
@@ -819,7 +819,7 @@ struct RowSolver {
         rho = p[PR::RHO * 12 + ci];
         cmask = act ? static_cast<unsigned>(p[PR::CM * 12 + ci]) : 0u;
 #pragma unroll
-        for (int k = 0; k < HS; ++k) slot_bounds(k, TWIN ? 2 * k + tw : k);
+        for (int k = 0; k < HS; ++k) { if constexpr (!GEN) slot_bounds(k, TWIN ? 2 * k + tw : k); }
         lo_u = P.fz_min * (cmask & 1u ? 1.0 : 0.0); hi_u = P.fz_max * (cmask & 1u ? 1.0 : 0.0);
         lb0 = comp == 2 ? lo_u : 0.0; ub0 = comp == 2 ? hi_u : kInfty;
         eqmask = act ? static_cast<unsigned>(p[PR::EQ * 12 + ci]) : 0u;
@@ -1153,7 +1153,13 @@ struct RowSolver {
             double r = e_t, pa = 0.0, pb = 0.0;
             if constexpr (t < H - 1) {
                 if constexpr (t > 0) pb = gVm * row_ror<8>(pv);
-                sweep_back_rhs_twin(r, pa, pb, pv, Bt, gAm, gBm, gCm, hm);
+                if constexpr (GEN) {
+                    double Btl[6];
+                    Bt_at(t, Btl);  // my column of this step's B~_t
+                    sweep_back_rhs_twin(r, pa, pb, pv, Btl, gAm, gBm, gCm, hm);
+                } else {
+                    sweep_back_rhs_twin(r, pa, pb, pv, Bt, gAm, gBm, gCm, hm);
+                }
             } else {
                 r = row_dpp_ready(r);  // p_H = 0
             }
@@ -1178,7 +1184,7 @@ struct RowSolver {
                 t0 = rr0[k] * (comp == 2 ? xh[k] : fma(mu, xz, xh[k])) - csc * yw0;
                 t1 = rr1[k] * fma(-mu, xz, xh[k]) - csc * yw1;
             } else {
-                const double z0 = min_f64(max_f64(wh0[k], lbk[k]), ubk[k]), z1 = min_f64(wh1[k], 0.0);
+                const double z0 = min_f64(max_f64(wh0[k], lbs<k>(2 * k + tw)), ubs<k>(2 * k + tw)), z1 = min_f64(wh1[k], 0.0);
                 t0 = rr0[k] * fma(2.0, z0, -wh0[k]);
                 t1 = rr1[k] * fma(2.0, z1, -wh1[k]);
             }
@@ -1208,13 +1214,20 @@ struct RowSolver {
                 sweep_fwd_gain_twin<false>(v, sa, sb, s, Kq, fA, fB, fC, am);
             }
             row_sched_fence();
+            [[maybe_unused]] double Brl[12];
+            if constexpr (GEN && t < H - 1) {  // my row of this step's B~_t
+                const double* br = brow_at(t);
+#pragma unroll
+                for (int b = 0; b < 12; ++b) Brl[b] = br[b];
+            }
             if constexpr (t > 0 && t < H - 1) {  // the next step's K row, into the registers the gain block has just freed
                 const double* slotn = lds + L::FAC + (t + 1) * L::SLOT;
                 static_for<12>([&](auto B) { Kq[A1_CV(B)] = slotn[krow + A1_CV(B)]; });
             }
             row_sched_fence();
             if constexpr (t < H - 1) {
-                sweep_fwd_input_twin(sa, sb, v, Brw);
+                if constexpr (GEN) sweep_fwd_input_twin(sa, sb, v, Brl);
+                else sweep_fwd_input_twin(sa, sb, v, Brw);
                 s = row_dpp_ready(sa);  // lanes without a wrench state read the zero row of B~
             }
             return v;
@@ -1230,11 +1243,11 @@ struct RowSolver {
             const double xh_old = xh[k];
             [[maybe_unused]] double gt0 = 0.0, gt1 = 0.0;
             if constexpr (CAREFUL) {
-                const double zp0 = min_f64(max_f64(wh0[k], lbk[k]), ubk[k]), zp1 = min_f64(wh1[k], 0.0);
+                const double zp0 = min_f64(max_f64(wh0[k], lbs<k>(2 * k + tw)), ubs<k>(2 * k + tw)), zp1 = min_f64(wh1[k], 0.0);
                 gt0 = rr0[k] * fma(2.0, zp0, -wh0[k]);
                 gt1 = rr1[k] * fma(2.0, zp1, -wh1[k]);
             }
-            const double z0 = min_f64(max_f64(wh0[k], lbk[k]), ubk[k]);
+            const double z0 = min_f64(max_f64(wh0[k], lbs<k>(2 * k + tw)), ubs<k>(2 * k + tw));
             xh[k] = fma(al, v, oma * xh[k]);
             const double vz = quad_perm<2, 2, 2, 2>(v);
             const double av0 = fma(mux, vz, v);
@@ -1289,18 +1302,33 @@ struct RowSolver {
                 constexpr int k = A1_CV(K);
                 double xa = xh[k];
                 const double xb = twin_exchange(xa);  // xa: step 2k (the main row's) on both rows, xb: step 2k + 1
-                s = row_dpp_ready(opA(s) + dot_bc<0>(Brw, row_dpp_ready(xa)));
+                auto Bx = [&](int t, double x_ready) {  // (B~_t x) on the wrench lanes
+                    if constexpr (GEN) {
+                        double Br[12];
+                        const double* br = brow_at(t);
+#pragma unroll
+                        for (int b = 0; b < 12; ++b) Br[b] = br[b];
+                        return dot_bc<0>(Br, x_ready);
+                    } else {
+                        return dot_bc<0>(Brw, x_ready);
+                    }
+                };
+                s = row_dpp_ready(opA(s) + Bx(2 * k, row_dpp_ready(xa)));
                 sv[2 * k] = q2s * s;
-                s = row_dpp_ready(opA(s) + dot_bc<0>(Brw, row_dpp_ready(xb)));
+                s = row_dpp_ready(opA(s) + Bx(2 * k + 1, row_dpp_ready(xb)));
                 sv[2 * k + 1] = q2s * s;
             });
             double lam = row_dpp_ready(0.0);
             static_for<HS>([&](auto KK) {
                 constexpr int k = HS - 1 - A1_CV(KK);
+                auto Btl_ = [&](int t, double lam_ready) {  // (B~_t' lambda) in force layout
+                    if constexpr (GEN) { double Bq[6]; Bt_at(t, Bq); return dot_bc<6>(Bq, lam_ready); }
+                    else return BtT(lam_ready);
+                };
                 lam = row_dpp_ready(sv[2 * k + 1] + opAT(lam));
-                const double b1 = BtT(lam);
+                const double b1 = Btl_(2 * k + 1, lam);
                 lam = row_dpp_ready(sv[2 * k] + opAT(lam));
-                const double b0 = BtT(lam);
+                const double b0 = Btl_(2 * k, lam);
                 Pu[k] = fma(r2a, xh[k], twin ? b1 : b0);
             });
         } else {   // P u = B_qp' Q (B_qp u) + R u : roll-out, then adjoint
@@ -1448,8 +1476,9 @@ struct RowSolver {
                     if (rn > rho * P.adaptive_rho_tol || rn < rho / P.adaptive_rho_tol) {
                         // y_s = rho E (wh - zh) is kept:  wh <- zh + (rho_old / rho_new) (wh - zh),  rr <- rr rho_new / rho_old
                         const double up = rn / rho, dn = rho / rn;
-                        static_for<HS>([&](auto T) {  // (the general path has no twin rows: its slot is its step)
-                            const double z0 = fmin(fmax(wh0[T], lbs<A1_CV(T)>(A1_CV(T))), ubs<A1_CV(T)>(A1_CV(T))), z1 = fmin(wh1[T], 0.0);
+                        static_for<HS>([&](auto T) {
+                            const int t_ = TWIN ? 2 * A1_CV(T) + tw : A1_CV(T);
+                            const double z0 = fmin(fmax(wh0[T], lbs<A1_CV(T)>(t_)), ubs<A1_CV(T)>(t_)), z1 = fmin(wh1[T], 0.0);
                             wh0[T] = fma(dn, wh0[T] - z0, z0);
                             wh1[T] = fma(dn, wh1[T] - z1, z1);
                             rr0[T] *= up;
@@ -1639,18 +1668,19 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
 // both iterate.
 template <int H, int MODE, bool GEN = false, bool TWIN = false, class MakeIO>
 A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab, MakeIO&& make_io_, double* __restrict__ lds) {
-    static_assert(!TWIN || (!GEN && MODE == kModeMpc && Prep<H>::STRIDE <= H * Layout<H>::SLOT), "twin rows: the MPC solve with the set-up | iteration hand-off");
+    static_assert(!TWIN || (MODE == kModeMpc && Prep<H>::STRIDE <= H * Layout<H>::SLOT), "twin rows: the MPC solve with the set-up | iteration hand-off");
     if constexpr (GEN) {
         // general path (per-step feet / contact schedules): the same set-up | iteration hand-off as below (its per-step tables live behind c*g
         // in the LDS image and survive it; the T*B~w table aliased into the factor region is dead once the Ruiz passes are done)
         static_assert(Prep<H>::STRIDE <= H * Layout<H, true>::SLOT, "the hand-off record fits the (still empty) factor region");
-        {
+        if (!TWIN || !row_is_twin()) {
             RowSolver<H, MODE, false, true> S0(P, tab, lds);
             S0.setup(make_io_());
             row_sync();
             S0.save_prepared(lds + Layout<H, true>::FAC);
         }
-        RowSolver<H, MODE, false, true> S(P, tab, lds);
+        if constexpr (TWIN) pair_sync();  // the twin reads the hand-off record and the per-step tables its main row wrote
+        RowSolver<H, MODE, false, true, TWIN> S(P, tab, lds);
         S.load_prepared(lds + Layout<H, true>::FAC, make_io_());
         S.solve();
         S.write_outputs(make_io_());

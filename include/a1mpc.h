@@ -140,7 +140,7 @@ a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d
  * horizon with step-invariant feet, the case a controller with a contact plan has -- also runs the fast kernels at their speed: contacts only
  * change the bounds and which rows are equalities (any horizon a1mpc_create accepts).  Per-step feet and / or a yaw_A run the general kernels:
  * same OSQP iterates as the reference's formation with those inputs, with a bigger LDS image per QP (B~_t and the bounds of every step), i.e.
- * fewer QPs in flight -- 3-6x slower by design.  Horizons 10, 16, 20.
+ * fewer QPs in flight -- 2-3x slower by design.  Horizons 10, 16, 20.
  */
 a1mpc_status a1mpc_solve_batch_strided(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
                                        const double* foot_abs, int32_t foot_stride, const uint8_t* contact, int32_t contact_stride,

@@ -100,7 +100,7 @@ def _solve(sc, n, h, P, grf, u, iters, status, nfact, wx, wy, rho, contact, spli
     return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
 
 
-def solve_gen(sc, foot, foot_stride, contact, contact_stride, n=None, settings=None, warm=None, **over):
+def solve_gen(sc, foot, foot_stride, contact, contact_stride, n=None, settings=None, warm=None, twin=False, **over):
     """the general path: foot (n, 12) or (n, 12h) with foot_stride 0 / 12; contact (n, 4) or (n, 4h) with contact_stride 0 / 4"""
     h = sc["horizon"]
     n = len(sc["x0"]) if n is None else n
@@ -111,9 +111,11 @@ def solve_gen(sc, foot, foot_stride, contact, contact_stride, n=None, settings=N
     wx = wy = rho = None
     if warm is not None:
         wx, wy, rho = warm
+    lib().a1mpc_emu_set_twin(1 if twin else 0)
     rc = lib().a1mpc_emu_solve_gen(C.byref(P), h, n, _p(sc["x0"]), _p(sc["xref"]), _p(sc["R"]), _p(foot), int(foot_stride), _p(contact, C.c_uint8),
                                    int(contact_stride), _p(grf), _p(u), _p(wx), _p(wy), _p(rho), _p(iters, C.c_int32), _p(status, C.c_int32),
                                    _p(nfact, C.c_int32))
+    lib().a1mpc_emu_set_twin(0)
     assert rc == 0
     return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
 

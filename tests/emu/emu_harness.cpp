@@ -280,6 +280,11 @@ static void gen_entry(void* a) {
     solve_row<H, kModeMpc, true>(*j->P, j->tab, j->io, j->lds);
 }
 template <int H>
+static void gen_twin_entry(void* a) {
+    Job<H>* j = static_cast<Job<H>*>(a);
+    if constexpr (H % 2 == 0) solve_row_with<H, kModeMpc, true, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+}
+template <int H>
 static void run_gen(const DeviceParams* P, int n, const double* x0, const double* xref, const double* R, const double* foot, int foot_stride,
                     const uint8_t* contact, int contact_stride, double* grf, double* u_full, double* warm_x, double* warm_y, double* rho,
                     int32_t* iters, int32_t* status, int32_t* nfact) {
@@ -298,7 +303,8 @@ static void run_gen(const DeviceParams* P, int n, const double* x0, const double
         j.io.warm_x = warm_x ? warm_x + (size_t)b * 12 * H : nullptr; j.io.warm_y = warm_y ? warm_y + (size_t)b * 20 * H : nullptr;
         j.io.rho_io = rho ? rho + b : nullptr;
         j.io.iters = iters ? iters + b : nullptr; j.io.status = status ? status + b : nullptr; j.io.nfact = nfact ? nfact + b : nullptr;
-        run_row(gen_entry<H>, &j);
+        if (g_emu_twin && H % 2 == 0) run_row(gen_twin_entry<H>, &j, 32);
+        else run_row(gen_entry<H>, &j);
     }
 }
 }  // namespace a1mpc

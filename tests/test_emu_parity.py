@@ -151,6 +151,8 @@ def test_emulated_general_path_matches_strided_oracle(oracle, scen, h, feet, con
         r = oracle.mpc_solve(pr, st, sc["x0"][b], sc["xref"][b], sc["R"][b], foot[b], contact[b], foot_stride=fs, contact_stride=cs)
         assert out["iters"][b] == r["info"].iters and out["status"][b] == r["info"].status and out["nfact"][b] == r["info"].nfact, (b, out["iters"][b], r["info"].iters)
         assert np.abs(out["u"][b] - r["u"]).max() < 1e-8 and np.abs(out["grf"][b] - r["grf"]).max() < 1e-8
+    two = emu.solve_gen(sc, foot, fs, contact, cs, twin=True)   # the device runs the general path's iterations on main / twin pairs of rows too
+    assert np.array_equal(two["u"], out["u"]) and (two["iters"] == out["iters"]).all() and (two["status"] == out["status"]).all()
     if not feet and not cont:   # with broadcast inputs the general path must reproduce the fast path's numbers
         fast = emu.solve(sc, nb)
         assert (fast["iters"] == out["iters"]).all() and np.abs(fast["u"] - out["u"]).max() < 1e-9
