@@ -85,10 +85,10 @@ __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a
 }
 
 // ---- split pipeline (large batches) -----------------------------------------------------------------------------
-// K1: formation + Ruiz, 4 QPs per wavefront, 2.8 KB of LDS per QP (H = 10).  WAVES = 2: two waves per SIMD hide each other's latencies (256 registers
-// each: 35 doubles per lane spill at H = 10, 137 at H = 20).  WAVES = 1: all 512 registers, nothing spills -- faster when the batch is one round of
-// waves anyway (4096 QPs at H = 10: 0.157 -> 0.139 ms) and at H = 20, where the spills cost more than the second wave hides (16 384 QPs: 1.84 -> 1.32 ms);
-// slower otherwise (65 536 x h10: 1.48 -> 1.91 ms).  launch_split_rows() picks.
+// K1: formation + Ruiz, 4 QPs per wavefront, 2.8 KB of LDS per QP (H = 10), ONE wave per SIMD (WAVES = 1: all 512 registers, nothing spills).
+// Until the Ruiz sweep became a short column loop (RowSolver::setup) a second wave per SIMD (256 registers each, 35-137 doubles per lane spilled) paid off
+// for multi-round batches at H = 10 / 16; with the column loop it loses everywhere (65 536 x h10: 1.27 vs 1.16 ms, 32 768 x h16: 2.12 vs 1.25 ms,
+// 16 384 x h20: 2.14 vs 0.75 ms; profiles/r02_setup_waves_probe.txt) and is no longer built.
 template <int H, int WAVES>
 __global__ __launch_bounds__(64, WAVES) void a1mpc_setup_kernel(const KernelArgs a, double* __restrict__ prep) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
@@ -365,11 +365,7 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     int res = 0;
     if (a1mpc_status st = resident_workgroups<H, ROWS>(&res); st != A1MPC_OK) return st;
     A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
-    // `res` workgroups of the ADMM kernel are resident = one per SIMD: a batch of at most that many set-up waves is a single round
-    if (H >= 20 || (a.n + 3) / 4 <= res)
-        hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
-    else
-        hipLaunchKernelGGL((a1mpc_setup_kernel<H, 2>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
+    hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
     A1_HIP(hipGetLastError());
     if (a.predict && a.cost != nullptr && a.order != nullptr) {  // no history: the queue order comes from the set-up kernel's cost guesses
         hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, static_cast<int>(a.n), static_cast<const int32_t*>(a.cost),

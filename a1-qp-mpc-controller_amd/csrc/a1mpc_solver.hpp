@@ -116,6 +116,22 @@ A1_DEV double dot_bc(const double (&m)[N], double x, double init = 0.0) {
 }
 // below this rho the dual residual at a checkpoint is dominated by the x-update's backward error unless c P x + c g is carried (RowSolver::careful)
 constexpr double kRhoCareful = 1e-3;
+// gamma_st = alpha_st / beta_st and beta_st = H - max(s,t) never grow with t for fixed s (csrc/a1mpc_tables.hpp; the quotients are compared as integers,
+// rounding them to double is monotone)
+constexpr bool gamma_beta_monotone(int H) {
+    for (int s = 0; s < H; ++s) {
+        long ap = 0, bp = 0;
+        for (int t = 0; t < H; ++t) {
+            const int m = s > t ? s : t;
+            long a = 0;
+            for (int i = m; i < H; ++i) a += static_cast<long>(i - s) * (i - t);
+            const long b = H - m;
+            if (t > 0 && (b > bp || a * bp > ap * b)) return false;  // beta grew, or alpha / beta > alpha' / beta'
+            ap = a; bp = b;
+        }
+    }
+    return true;
+}
 constexpr int alpha_diag(int s, int H) {  // sum_{i=s}^{H-1} (i-s)^2
     int a = 0;
     for (int i = s; i < H; ++i) a += (i - s) * (i - s);
@@ -565,8 +581,7 @@ struct RowSolver {
         if (P.scaling_iters > 0) {
             double m[H];
             // m[s] = max_{t,b} D_tb |P_(s,a),(t,b)|  for my rows (s, a): one pass over the implicit Hessian.
-            // Exact pruning: block (s,t) cannot raise the maximum if  (gamma_st max_b|U_ab| + max_b|V_ab|) beta_st max_b D_tb  does not
-            // exceed it; starting from the diagonal entry this skips ~70 % of the blocks (wave-level) without changing a single result.
+            // Exact pruning (see the column loop below): starting from the diagonal entry, 60-75 % of the blocks provably cannot raise a maximum.
             double Umax = 0.0, Vmax = 0.0;
 #pragma unroll
             for (int b = 0; b < 12; ++b) { Umax = fmax(Umax, fabs(U[b])); Vmax = fmax(Vmax, fabs(V[b])); }
@@ -577,6 +592,11 @@ struct RowSolver {
                     for (int t = 0; t < H; ++t) lds[L::DL + t * 12 + ci] = D[t];
                 }
                 row_sync();
+                // the largest D of the whole QP (pad lanes hold 1.0 and do not count)
+                double Dall = 0.0;
+#pragma unroll
+                for (int t = 0; t < H; ++t) Dall = max_f64(Dall, D[t]);
+                Dall = row_allmax(act ? Dall : 0.0);
                 static_for<H>([&](auto S) {  // the true diagonal entry carries R
                     constexpr double ad = alpha_diag(A1_CV(S), H), bd = H - A1_CV(S);
                     if constexpr (GEN) mm[S] = (ad * Udg[S] + bd * Vdg[S] + r2a) * D[S];
@@ -612,29 +632,42 @@ struct RowSolver {
                         });
                     }
                 }
+                // Blocks are visited column by column (t ascending; a row of a shared set-up takes every coop_n-th) and only while some block still to
+                // come could raise a maximum.  Inside a column every s is evaluated, branch-free, on the column's pre-scaled rows u_b = U_ab D_tb,
+                // v_b = V_ab D_tb: entry = |fma(gamma_st, u_b, v_b)| beta_st, 2 instructions per entry.  The bound of block (s,t),
+                //     B_st = fma(gamma_st, Umax Dall, Vmax Dall) beta_st        (Umax = max_b |U_ab|, Dall = max over the whole D table),
+                // is the SAME operation sequence on operands that dominate the entry's one by one, so by the monotonicity of IEEE rounding it dominates
+                // every rounded entry of the block exactly -- no safety margin, ties prune (they are structural: with the reference's weights the
+                // columns of A set D, the same at every step).  For fixed s both gamma_st and beta_st never grow with t (gamma_beta_monotone<H>, asserted),
+                // hence neither does B_st: once B_st <= m[s] for every s, no later column can change a bit of the result.  Random SRBD states stop after
+                // 2-4 of 10 columns (5 of 20 at H = 20).
+                static_assert(gamma_beta_monotone(H), "the column loop of the Ruiz sweep stops early on the strength of this");
+                const double UDall = Umax * Dall, VDall = Vmax * Dall;
+                {
+                    int t = GEN ? H : coop_id;
 #pragma unroll 1
-                for (int t = GEN ? H : coop_id; t < H; t += coop_n) {
-                    // all loads of this t first (table column + D row): one wait instead of one per block
-                    double gb[2 * H], Dt[12];
+                    while (true) {
+                        const int tc = t < H ? t : H - 1;  // (rows of a shared set-up run out of columns at different times; they re-visit a real block, which is harmless)
+                        double gb[2 * H];
 #pragma unroll
-                    for (int s2 = 0; s2 < H; ++s2) { gb[2 * s2] = tab[(s2 * H + t) * 2]; gb[2 * s2 + 1] = tab[(s2 * H + t) * 2 + 1]; }
+                        for (int s2 = 0; s2 < H; ++s2) { gb[2 * s2] = tab[(s2 * H + tc) * 2]; gb[2 * s2 + 1] = tab[(s2 * H + tc) * 2 + 1]; }
+                        bool need = false;
+                        static_for<H>([&](auto S) { need |= fma(gb[2 * A1_CV(S)], UDall, VDall) * gb[2 * A1_CV(S) + 1] > mm[S]; });
+                        if (!row_wave_any(need && t < H)) break;
+                        double UD[12], VD[12];
 #pragma unroll
-                    for (int b = 0; b < 12; ++b) Dt[b] = lds[L::DL + t * 12 + b];
-                    double Dmax = 0.0;
-#pragma unroll
-                    for (int b = 0; b < 12; ++b) Dmax = fmax(Dmax, Dt[b]);
-                    Dmax *= 1.0 + 1e-12;  // the bound must dominate every rounded entry
-                    static_for<H>([&](auto S) {
-                        const double gam = gb[2 * A1_CV(S)], bet = gb[2 * A1_CV(S) + 1];
-                        if (fma(gam, Umax, Vmax) * (bet * Dmax) > mm[S]) {
-                            double a0 = 0.0, a1 = 0.0;
-                            static_for<6>([&](auto J) {
-                                a0 = fmax(a0, fabs(fma(gam, U[2 * J], V[2 * J])) * Dt[2 * J]);
-                                a1 = fmax(a1, fabs(fma(gam, U[2 * J + 1], V[2 * J + 1])) * Dt[2 * J + 1]);
+                        for (int b = 0; b < 12; ++b) { const double db = lds[L::DL + tc * 12 + b]; UD[b] = U[b] * db; VD[b] = V[b] * db; }
+                        static_for<H>([&](auto S) {
+                            const double gam = gb[2 * A1_CV(S)], bet = gb[2 * A1_CV(S) + 1];
+                            double a0 = fabs(fma(gam, UD[0], VD[0])), a1 = fabs(fma(gam, UD[1], VD[1]));
+                            static_for<5>([&](auto J) {
+                                a0 = max_abs_f64(a0, fma(gam, UD[2 * J + 2], VD[2 * J + 2]));
+                                a1 = max_abs_f64(a1, fma(gam, UD[2 * J + 3], VD[2 * J + 3]));
                             });
-                            mm[S] = fmax(mm[S], bet * fmax(a0, a1));
-                        }
-                    });
+                            mm[S] = max_f64(mm[S], bet * max_f64(a0, a1));
+                        });
+                        t += coop_n;
+                    }
                 }
                 if (coop_n > 1) {  // each row of the wave visited every coop_n-th t: the column maxima are the maxima over the rows (exact, order-free)
                     static_for<H>([&](auto S) { lds[L::COOP + (coop_id * H + A1_CV(S)) * 16 + ln] = mm[S]; });

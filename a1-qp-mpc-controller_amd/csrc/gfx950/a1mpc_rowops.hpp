@@ -81,6 +81,12 @@ A1_DEV double max_f64(double a, double b) {
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// max(a, |x|): the absolute value rides on the source modifier
+A1_DEV double max_abs_f64(double a, double x) {
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(x));
+    return r;
+}
 A1_DEV double min_f64(double a, double b) {
     double r;
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));

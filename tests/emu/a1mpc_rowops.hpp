@@ -46,6 +46,7 @@ inline void fnma_bcast_leg(double& acc, double m, double x) {
 inline double row_rsqrt(double p) { return 1.0 / sqrt(p); }
 inline double max_f64(double a, double b) { return fmax(a, b); }
 inline double min_f64(double a, double b) { return fmin(a, b); }
+inline double max_abs_f64(double a, double x) { return fmax(a, fabs(x)); }
 inline double row_dpp_ready(double x) { return x; }
 inline void row_dpp_ready12(double (&)[12]) {}
 inline void row_sync() { (void)emu_publish(0.0); }
