@@ -606,6 +606,8 @@ struct RowSolver {
 #pragma unroll 1
                     for (int t = 0; t < H; ++t) {  // every block is evaluated: a per-block pruning bound like the fast path's was tried and measured slower here
                                                    // (3.11 -> 3.35 ms at 4096 x h10: per-lane skips do not skip at wave level and cost registers)
+                                                   // and so was the fast path's column loop (below) with the bound gamma (sum_c |cu_c| max|B~w_c| + ..) + ..:
+                                                   // the triangle inequality over the three omega rows is too loose to stop early (1.86 -> 1.80 M solves/s)
                         // entry (s,a),(t,b) = beta_st (y . B~w_t[:,b] + k_{b%3})  with  y = gamma_st dt^2 T'(q T B~w_s[:,a]) + q_w B~w_s[:,a]  and the
                         // velocity-row constants k: 3 FMAs per entry and one table (round 2; it was 6 FMAs and two tables)
                         double gb[2 * H], Dt[12], Bwt[3][12];

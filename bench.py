@@ -468,7 +468,7 @@ def main():
                     "(the closed-loop regime's order; hindsight for identical inputs, never `value`)",
             "index_order_ms_per_step": index_ms, "index_order_solves_per_s_per_gpu": (n / (index_ms * 1e-3)) if index_ms else None,
             "history_ms_per_step": hist_ms, "history_solves_per_s_per_gpu": (n / (hist_ms * 1e-3)) if hist_ms else None}
-        if not args.no_latency:
+        if not args.no_latency and world == 1:
             out["roofline_other_configs"] = other_config_rooflines(pkg, local)
     if world > 1 and backend == "nccl" and os.environ.get("A1_BENCH_SCATTER_GATHER") == "1":   # opt-in: an extra collective phase must not be able to take the metric's run down
         # Extra information (not `value`, which needs no collective): what scattering this step's inputs from rank 0 and gathering the results
@@ -491,6 +491,10 @@ def main():
                                      "bytes_into_rank0": int(n * (world - 1) * (12 * 8 + 8)), "transport": "torch.distributed nccl (RCCL) batch_isend_irecv",
                                      "note": "not part of `value`: ranks generate their own inputs in the weak-scaling metric; --config 4 puts scatter + gather inside the timed region"}
     if rank == 0:
+        # everything below is extra information measured on ONE GPU / the host; N > 1 runs (the scaling curve) print the metric's line only,
+        # the other ranks are not kept waiting in the final barrier for a minute of single-GPU probes
+        if world > 1:
+            args.no_latency = args.no_cpu_baseline = True
         if not args.no_latency:
             out["latency"] = latency_probe(pkg)
             out["throughput_by_batch"] = batch_sweep(pkg, local)
