@@ -29,6 +29,33 @@ def build(force=False):
     return _LIB
 
 
+def variant(flags, tag):
+    """a second build of the test double with extra compiler flags (e.g. -DA1X_FULL_SWEEP), as its own library; use it with `using()`"""
+    path = os.path.join(_HERE, f"liba1mpc_emu_{tag}.so")
+    srcs = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_HERE, "a1mpc_rowops.hpp"), os.path.join(_CSRC, "a1mpc_solver.hpp"), os.path.join(_CSRC, "a1mpc_tables.hpp")]
+    if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", _HERE, "-I", _CSRC, srcs[0], "-o", path] + list(flags))
+    v = C.CDLL(path)
+    assert v.a1mpc_emu_sizeof_params() == C.sizeof(DeviceParams)
+    return v
+
+
+class using:
+    """with emu.using(emu.variant(...)): the solve functions of this module run the given build"""
+    def __init__(self, v):
+        self.v = v
+
+    def __enter__(self):
+        global _lib
+        lib()
+        self.old, _lib = _lib, self.v
+        return self.v
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self.old
+
+
 _lib = None
 
 

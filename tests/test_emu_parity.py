@@ -247,3 +247,18 @@ def test_emulated_contact_schedule_on_the_fast_path(oracle, scen, h, twin, split
         assert np.abs(out["u"][b] - r["u"]).max() < 1e-8 and np.abs(out["grf"][b] - r["grf"]).max() < 1e-8
     gen = emu.solve_gen(sc, sc["foot"], 0, contact, 4)
     assert (gen["iters"] == out["iters"]).all() and np.abs(gen["u"] - out["u"]).max() < 1e-9
+
+
+# ---- the Ruiz sweep's early stop (RowSolver::setup, column loop) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("gen,kw,n,split", [("config3_random_flat", dict(nb=8), 6, 0), ("config3_random_flat", dict(nb=8, param_set="hardware"), 4, 2),
+                                            ("config5_divergent", dict(nb=4), 2, 1)])
+def test_emulated_ruiz_sweep_early_stop_is_exact(scen, gen, kw, n, split):
+    """The column loop of the Ruiz sweep stops as soon as a rounding-exact bound rules out every later column of the implicit Hessian.  A build that
+    visits every column (-DA1X_FULL_SWEEP) must produce the same bits: same scaling, hence same iterates, iteration counts and forces -- in the fused
+    kernel (one row per QP), in the latency variant's shared set-up (four rows take every fourth column) and in the set-up kernel of the split pipeline."""
+    sc = getattr(scen, gen)(**kw)
+    fast = emu.solve(sc, n, split_rows=split, twin=split > 0)
+    with emu.using(emu.variant(["-DA1X_FULL_SWEEP"], "fullsweep")):
+        full = emu.solve(sc, n, split_rows=split, twin=split > 0)
+    assert np.array_equal(fast["u"], full["u"]) and np.array_equal(fast["grf"], full["grf"])
+    assert (fast["iters"] == full["iters"]).all() and (fast["status"] == full["status"]).all() and (fast["nfact"] == full["nfact"]).all()
