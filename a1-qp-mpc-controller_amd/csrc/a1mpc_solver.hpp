@@ -180,10 +180,9 @@ struct Layout {
     // set-up-only aliases inside the factor region (the factor is written after Ruiz is finished)
     static constexpr int TBL = 0;            // T*B~_omega (3x12)
     static constexpr int DL = 36;            // D table of the current Ruiz pass, [t][12]
-    static constexpr int COOP = DL + 12 * H;  // [row][s][16 lanes] partial column maxima of a set-up shared by the four rows of a wave (RowSolver::coop_n)
-    static constexpr int TBW = DL + 12 * H;  // GEN (never coop): [t][3][12] = T*B~_omega of step t
+    static constexpr int TBW = DL + 12 * H;  // GEN: [t][3][12] = T*B~_omega of step t
+    static constexpr int COOP = TBW + (GEN ? 36 * H : 0);  // [row][s][16 lanes] partial column maxima of a set-up shared by several rows of a wave (RowSolver::coop_n)
     static_assert(COOP + 8 * H * 16 <= H * SLOT || H == 1, "alias");  // + the D / E0 / E1 / m tables of the shared Ruiz update
-    static_assert(!GEN || TBW + 36 * H <= H * SLOT, "alias");
     // row stride mod 32 in {4,10,16,22,28}: the two QPs that share a 32-lane LDS phase then read the stride-13 rows of K_t
     // from disjoint banks; even, so that 16-byte alignment survives.  H = 10: 2544 doubles = 20,352 B per QP -> eight QPs
     // per CU (160 KiB): four workgroups of two rows.
@@ -318,6 +317,12 @@ struct RowSolver {
         if constexpr (TWIN) pair_sync();
         else row_sync();
     }
+    // set-up: orders LDS traffic between the lanes that work on this QP's set-up -- my row, or every row that shares it (coop_n > 1: the rows of
+    // the wavefront run in lock-step; the CPU test double has to be told)
+    A1_DEV void set_sync() const {
+        if (coop_n > 1) coop_sync();
+        else row_sync();
+    }
     // A_d = I + dt*A_c and its transpose as row operators on a state-layout vector (T = A_c(0:3,6:9), S/ConvexMpc.cpp:123-125)
     A1_DEV void set_rotation(double c, double s) {
         cy = c; sy = s;
@@ -447,7 +452,7 @@ struct RowSolver {
         TB[0] = cy * Bt[0] + sy * Bt[1];
         TB[1] = -sy * Bt[0] + cy * Bt[1];
         TB[2] = Bt[2];
-        row_sync();
+        set_sync();
         if (act) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) lds[L::BL + k * 12 + ci] = Bt[k];
@@ -476,7 +481,7 @@ struct RowSolver {
                 }
             });
         }
-        row_sync();
+        set_sync();
 
         // ---------------------------------------------------------------- gradient g = B_qp' Q (A_qp x0 - x_ref)
         double g[H];
@@ -586,12 +591,12 @@ struct RowSolver {
 #pragma unroll
             for (int b = 0; b < 12; ++b) { Umax = fmax(Umax, fabs(U[b])); Vmax = fmax(Vmax, fabs(V[b])); }
             auto sweep = [&](double(&mm)[H]) {
-                row_sync();
+                set_sync();
                 if (act) {
 #pragma unroll
                     for (int t = 0; t < H; ++t) lds[L::DL + t * 12 + ci] = D[t];
                 }
-                row_sync();
+                set_sync();
                 // the largest D of the whole QP (pad lanes hold 1.0 and do not count)
                 double Dall = 0.0;
 #pragma unroll
@@ -604,7 +609,7 @@ struct RowSolver {
                 });
                 if constexpr (GEN) {
 #pragma unroll 1
-                    for (int t = 0; t < H; ++t) {  // every block is evaluated: a per-block pruning bound like the fast path's was tried and measured slower here
+                    for (int t = coop_id; t < H; t += coop_n) {  // every block is evaluated: a per-block pruning bound like the fast path's was tried and measured slower here
                                                    // (3.11 -> 3.35 ms at 4096 x h10: per-lane skips do not skip at wave level and cost registers)
                                                    // and so was the fast path's column loop (below) with the bound gamma (sum_c |cu_c| max|B~w_c| + ..) + ..:
                                                    // the triangle inequality over the three omega rows is too loose to stop early (1.86 -> 1.80 M solves/s)
@@ -676,7 +681,7 @@ struct RowSolver {
                 }
                 if (coop_n > 1) {  // each row of the wave visited every coop_n-th t: the column maxima are the maxima over the rows (exact, order-free)
                     static_for<H>([&](auto S) { lds[L::COOP + (coop_id * H + A1_CV(S)) * 16 + ln] = mm[S]; });
-                    row_sync();
+                    set_sync();
                     for (int r = 0; r < coop_n; ++r)
                         static_for<H>([&](auto S) { mm[S] = fmax(mm[S], lds[L::COOP + (r * H + A1_CV(S)) * 16 + ln]); });
                 }
@@ -704,14 +709,14 @@ struct RowSolver {
                         constexpr int t = A1_CV(T);
                         if (coop_id == 0) { tb[(0 * H + t) * 16 + ln] = D[t]; tb[(1 * H + t) * 16 + ln] = E0[t]; tb[(2 * H + t) * 16 + ln] = E1[t]; tb[(3 * H + t) * 16 + ln] = m[t]; }
                     });
-                    row_sync();
+                    set_sync();
 #pragma unroll 1
                     for (int t = coop_id; t < H; t += coop_n) {
                         double Dt_ = tb[(0 * H + t) * 16 + ln], E0t = tb[(1 * H + t) * 16 + ln], E1t = tb[(2 * H + t) * 16 + ln];
                         ruiz_step(Dt_, E0t, E1t, tb[(3 * H + t) * 16 + ln]);
                         tb[(0 * H + t) * 16 + ln] = Dt_; tb[(1 * H + t) * 16 + ln] = E0t; tb[(2 * H + t) * 16 + ln] = E1t;
                     }
-                    row_sync();
+                    set_sync();
                     static_for<H>([&](auto T) {
                         constexpr int t = A1_CV(T);
                         D[t] = tb[(0 * H + t) * 16 + ln]; E0[t] = tb[(1 * H + t) * 16 + ln]; E1[t] = tb[(2 * H + t) * 16 + ln];
@@ -751,7 +756,7 @@ struct RowSolver {
         // coincides with the generic w-form iteration from w = 0
         first_special = warm || !(P.fz_min <= 0.0 && P.fz_max >= 0.0);
         eqmask = 0; cmask = 0;
-        row_sync();  // the Ruiz D table (aliased into the factor region) is dead from here on
+        set_sync();  // the Ruiz D table (aliased into the factor region) is dead from here on
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
             // the step's contact flags (a per-step schedule when contact_stride = 4): bounds of my slot-0 row at step t
@@ -774,7 +779,7 @@ struct RowSolver {
             park_warm_y(io, t);
             if (act) lds[L::CG + t * 12 + ci] = csc * g[t];          // D^-1 q_s = c g
         });
-        row_sync();
+        set_sync();
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false; careful = false;
     }
 
@@ -1711,11 +1716,13 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
         // general path (per-step feet / contact schedules): the same set-up | iteration hand-off as below (its per-step tables live behind c*g
         // in the LDS image and survive it; the T*B~w table aliased into the factor region is dead once the Ruiz passes are done)
         static_assert(Prep<H>::STRIDE <= H * Layout<H, true>::SLOT, "the hand-off record fits the (still empty) factor region");
-        if (!TWIN || !row_is_twin()) {
+        {   // a main / twin pair shares the set-up like the rows of the latency kernel do: each takes every other column of the Ruiz sweeps and every
+            // other horizon step of the D / E updates, everything else is computed redundantly (same values, same LDS image)
             RowSolver<H, MODE, false, true> S0(P, tab, lds);
+            if constexpr (TWIN) { S0.coop_id = row_is_twin() ? 1 : 0; S0.coop_n = 2; }
             S0.setup(make_io_());
-            row_sync();
-            S0.save_prepared(lds + Layout<H, true>::FAC);
+            if constexpr (TWIN) pair_sync(); else row_sync();  // everybody is done with the set-up scratch aliased into the factor region
+            if (!TWIN || !row_is_twin()) S0.save_prepared(lds + Layout<H, true>::FAC);
         }
         if constexpr (TWIN) pair_sync();  // the twin reads the hand-off record and the per-step tables its main row wrote
         RowSolver<H, MODE, false, true, TWIN> S(P, tab, lds);
@@ -1726,11 +1733,12 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
         // Set-up and iteration are two solver objects joined by the hand-off record of the split pipeline, staged in the (still
         // empty) factor region: the ADMM loop then gets the register allocation of the persistent kernel instead of one that
         // also carries the set-up's live values (scratch reloads inside the loop).  ~0.5 us per solve.
-        if (!TWIN || !row_is_twin()) {
+        {   // (a main / twin pair shares the set-up: see the general path above)
             RowSolver<H, MODE> S0(P, tab, lds);
+            if constexpr (TWIN) { S0.coop_id = row_is_twin() ? 1 : 0; S0.coop_n = 2; }
             S0.setup(make_io_());
-            row_sync();
-            S0.save_prepared(lds + Layout<H>::FAC);
+            if constexpr (TWIN) pair_sync(); else row_sync();
+            if (!TWIN || !row_is_twin()) S0.save_prepared(lds + Layout<H>::FAC);
         }
         if constexpr (TWIN) pair_sync();  // the twin reads the hand-off record its main row wrote
         RowSolver<H, MODE, false, false, TWIN> S(P, tab, lds);

@@ -382,6 +382,8 @@ A1_DEV double twin_exchange(double& a) {
 }
 // LDS ordering between the two rows of a pair (one wavefront: the same as row_sync(); the CPU test double needs the distinction)
 A1_DEV void pair_sync() { row_sync(); }
+// rows of one wavefront that share a QP's set-up (RowSolver::coop_n): the same wave-level ordering
+A1_DEV void coop_sync() { row_sync(); }
 // the twin takes its main row's value
 A1_DEV double twin_from_main(double v) {
     (void)twin_exchange(v);

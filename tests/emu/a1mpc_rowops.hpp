@@ -85,6 +85,7 @@ inline bool row_is_twin() { return emu_lane >= 16; }
 inline double twin_exchange(double& a) { return emu_twin_exchange(a); }
 inline double twin_from_main(double v) { (void)emu_twin_exchange(v); return v; }
 inline void pair_sync() { double z = 0.0; (void)emu_twin_exchange(z); }  // both rows of the pair arrive before either goes on
+inline void coop_sync() { pair_sync(); }  // a set-up shared by the two rows of a pair (the four-row variant of the latency kernel is not emulated)
 inline void sweep_back_rhs_twin(double& r, double& pa, double& pb, double p, const double (&Bt)[6], double gA, double gB, double gC, double hm) {
     const double* P_ = emu_publish(p);
     double ra = r, rb = 0.0;
