@@ -293,14 +293,16 @@ constexpr size_t lds_bytes(int rows) { return sizeof(double) * rows * Layout<H>:
 
 // QPs per wavefront.  LDS (not wave slots) bounds residency at 8 QPs per CU (H = 10) whatever the split, and a wave costs the same
 // issue slots with 2 or 4 live rows, so 2 rows x 4 waves per CU loses nothing and each row waits for only one neighbour's
-// factorisation passes (measured: +5 % at 4096 QPs, +4 % at 32768).  A1MPC_ROWS_PER_WG = 1 | 2 | 4 overrides.
-static int rows_per_wg() {
+// factorisation passes (measured: +5 % at 4096 QPs, +4 % at 32768).  From H = 16 on LDS allows four QPs per CU at most: one QP (a main / twin pair of rows) per
+// wavefront then puts them on four SIMDs instead of two -- no more QPs in flight, but no row waits for a wave-mate's hand-over or factor pass any more and the LDS
+// conflicts between the two images go (8192 x h16 first solve 4.62 -> 4.41 ms, 16 384 x h20 10.35 -> 10.04 ms).  A1MPC_ROWS_PER_WG = 1 | 2 | 4 overrides.
+static int rows_per_wg(int horizon) {
     static int r = [] {
         const char* e = getenv("A1MPC_ROWS_PER_WG");
         const int v = e ? atoi(e) : 0;
-        return (v == 1 || v == 2 || v == 4) ? v : 2;
+        return (v == 1 || v == 2 || v == 4) ? v : 0;
     }();
-    return r;
+    return r ? r : (horizon >= 16 ? 1 : 2);
 }
 
 thread_local std::string g_last_error;
@@ -350,7 +352,7 @@ static a1mpc_status resident_rows(int* out) {
 #ifdef A1MPC_DEV_SLIM
     st = resident_workgroups<H, 2>(&wg); *out = 2 * wg;
 #else
-    switch (rows_per_wg()) {
+    switch (rows_per_wg(H)) {
         case 1: st = resident_workgroups<H, 1>(&wg); *out = wg; return st;
         case 2: st = resident_workgroups<H, 2>(&wg); *out = 2 * wg; return st;
     }
@@ -384,7 +386,7 @@ static a1mpc_status launch_split(const KernelArgs& a, double* prep, int* counter
 #ifdef A1MPC_DEV_SLIM  // kernel-tuning builds: one instantiation (H = 10, two rows), seconds instead of minutes to compile
     return launch_split_rows<H, 2>(a, prep, counter, stream, mid);
 #else
-    switch (rows_per_wg()) {
+    switch (rows_per_wg(H)) {
         case 1: return launch_split_rows<H, 1>(a, prep, counter, stream, mid);
         case 2: return launch_split_rows<H, 2>(a, prep, counter, stream, mid);
     }
@@ -431,12 +433,12 @@ static a1mpc_status launch_gen_rows(const KernelArgs& a, hipStream_t stream) {
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
 }
-// LDS per QP: 25.2 KB (H = 10: six QPs per CU), 39.9 KB (H = 16: four), 49.7 KB (H = 20: three, one row per workgroup)
+// LDS per QP: 25.2 KB (H = 10: six QPs per CU), 39.9 KB (H = 16: four, one per wavefront like the fast path's), 49.7 KB (H = 20: three, one row per workgroup)
 static a1mpc_status launch_gen(int horizon, const KernelArgs& a, hipStream_t s) {
 #ifndef A1MPC_DEV_SLIM
     switch (horizon) {
         case 10: return launch_gen_rows<10, 2>(a, s);
-        case 16: return launch_gen_rows<16, 2>(a, s);
+        case 16: return launch_gen_rows<16, 1>(a, s);
         case 20: return launch_gen_rows<20, 1>(a, s);
     }
 #endif
@@ -463,7 +465,7 @@ static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
         static const bool coop = [] { const char* e = getenv("A1MPC_COOP_SETUP"); return !(e && !strcmp(e, "0")); }();
         if (coop && a.n <= kCoopMaxBatch) return launch_coop<H>(a, stream);
     }
-    switch (rows_per_wg()) {
+    switch (rows_per_wg(H)) {
         case 1: return launch_rows<H, MODE, 1>(a, stream);
         case 2: return launch_rows<H, MODE, 2>(a, stream);
     }
@@ -514,7 +516,7 @@ static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, i
     return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be 1, 10, 16 or 20");
 }
 static size_t lds_bytes_of(int horizon) {
-    const int r = rows_per_wg();
+    const int r = rows_per_wg(horizon);
     switch (horizon) {
         case 1: return lds_bytes<1>(r);
         case 10: return lds_bytes<10>(r);
@@ -2030,8 +2032,8 @@ a1mpc_status a1mpc_kernel_info(a1mpc_handle h, int32_t* lds_bytes_per_workgroup,
                                int32_t* threads_per_workgroup) {
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
     if (lds_bytes_per_workgroup) *lds_bytes_per_workgroup = static_cast<int32_t>(lds_bytes_of(h->cfg.horizon));
-    if (qps_per_workgroup) *qps_per_workgroup = rows_per_wg();
-    if (threads_per_workgroup) *threads_per_workgroup = 16 * rows_per_wg();
+    if (qps_per_workgroup) *qps_per_workgroup = rows_per_wg(h->cfg.horizon);
+    if (threads_per_workgroup) *threads_per_workgroup = h->cfg.horizon > 1 && rows_per_wg(h->cfg.horizon) <= 2 ? 64 : 16 * rows_per_wg(h->cfg.horizon);  // (twin rows: a full wavefront)
     return A1MPC_OK;
 }
 
