@@ -121,6 +121,28 @@ __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, cons
     }
 }
 
+// The general path's own split pipeline (round 2, last step): the same two kernels over RowSolver<.., GEN = true>.  K1 holds the per-step tables B~w_t and
+// T B~w_t of four QPs (8.5 KB each at H = 10); its record carries B~w_t to K2, whose rows rebuild the per-step tables of their LDS image from it.
+template <int H>
+__global__ __launch_bounds__(64, 1) void a1mpc_setup_gen_kernel(const KernelArgs a, double* __restrict__ prep) {
+    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
+    const int row = static_cast<int>(threadIdx.x) >> 4;
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + row;
+    double* tabl = a1mpc_lds + 4 * LayoutSetup<H, true>::ROW_STRIDE;
+    for (int i = static_cast<int>(threadIdx.x); i < 2 * H * H; i += 64) tabl[i] = a.tab[i];
+    __syncthreads();
+    if (b >= a.n) return;
+    setup_row<H, true>(a, tabl, b, a1mpc_lds + row * LayoutSetup<H, true>::ROW_STRIDE, prep);
+}
+template <int H, int ROWS>
+__global__ __launch_bounds__(64) void a1mpc_admm_gen_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
+    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
+    static_assert(ROWS <= 2, "rows r and r + 2 of the wavefront share a QP (twin rows)");
+    const int row = static_cast<int>(threadIdx.x) >> 4;
+    if ((row & 1) >= ROWS) return;
+    admm_rows<H, true, true>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H, true>::ROW_STRIDE);
+}
+
 // K3: the next solve's queue order = this solve's QPs by decreasing cost (counting sort, one workgroup).  A batch of 1-4x the resident
 // rows is otherwise finished by whichever long QP happened to start last; longest-first makes the makespan max(longest, total / rows).
 __global__ __launch_bounds__(1024) void a1mpc_order_kernel(int n, const int32_t* __restrict__ cost, int32_t* __restrict__ order) {
@@ -433,6 +455,81 @@ static a1mpc_status launch_gen_rows(const KernelArgs& a, hipStream_t stream) {
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
 }
+// resident workgroups of the general path's ADMM kernel (occupancy query, cached per device)
+template <int H, int ROWS>
+static a1mpc_status resident_workgroups_gen(int* out) {
+    static int resident[64] = {};
+    int dev = 0;
+    A1_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(A1MPC_ERR_HIP, "device index out of range");
+    if (!resident[dev]) {
+        const size_t lds = sizeof(double) * ROWS * Layout<H, true>::ROW_STRIDE;
+        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_gen_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        int per_cu = 0, cus = 0;
+        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_gen_kernel<H, ROWS>), 64, lds));
+        A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        resident[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    }
+    *out = resident[dev];
+    return A1MPC_OK;
+}
+// a batch beyond the resident rows: the general path's set-up kernel, the queue-order kernel, its persistent ADMM kernel
+template <int H, int ROWS>
+static a1mpc_status launch_gen_split_rows(const KernelArgs& a, double* prep, int* counter, hipStream_t stream, hipEvent_t mid, int res) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    A1_HIP(hipGetDevice(&dev));
+    const size_t lds1 = sizeof(double) * (4 * LayoutSetup<H, true>::ROW_STRIDE + 2 * H * H), lds2 = sizeof(double) * ROWS * Layout<H, true>::ROW_STRIDE;
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_setup_gen_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds1)));
+        attr_set[dev] = true;
+    }
+    A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
+    hipLaunchKernelGGL((a1mpc_setup_gen_kernel<H>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
+    A1_HIP(hipGetLastError());
+    if (a.predict && a.cost != nullptr && a.order != nullptr) {
+        hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, static_cast<int>(a.n), static_cast<const int32_t*>(a.cost), const_cast<int32_t*>(a.order));
+        A1_HIP(hipGetLastError());
+    }
+    if (mid) A1_HIP(hipEventRecord(mid, stream));
+    const int want = (a.n + ROWS - 1) / ROWS;
+    hipLaunchKernelGGL((a1mpc_admm_gen_kernel<H, ROWS>), dim3(static_cast<unsigned>(want < res ? want : res)), dim3(64), lds2, stream, a, static_cast<const double*>(prep), counter);
+    A1_HIP(hipGetLastError());
+    return A1MPC_OK;
+}
+static size_t prep_stride_gen(int horizon) {
+    switch (horizon) {
+        case 10: return Prep<10>::STRIDE_GEN;
+        case 16: return Prep<16>::STRIDE_GEN;
+        case 20: return Prep<20>::STRIDE_GEN;
+    }
+    return 0;
+}
+// rows of the general path's ADMM kernel that are resident at once (0: horizon without a general path)
+static a1mpc_status resident_rows_gen(int horizon, int* rows) {
+    int wg = 0;
+    a1mpc_status st = A1MPC_OK;
+    *rows = 0;
+#ifndef A1MPC_DEV_SLIM
+    switch (horizon) {
+        case 10: st = resident_workgroups_gen<10, 2>(&wg); *rows = 2 * wg; break;
+        case 16: st = resident_workgroups_gen<16, 1>(&wg); *rows = wg; break;
+        case 20: st = resident_workgroups_gen<20, 1>(&wg); *rows = wg; break;
+    }
+#endif
+    return st;
+}
+static a1mpc_status launch_gen_split(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s, hipEvent_t mid) {
+    int wg = 0;
+#ifndef A1MPC_DEV_SLIM
+    switch (horizon) {
+        case 10: if (a1mpc_status st = resident_workgroups_gen<10, 2>(&wg); st != A1MPC_OK) return st; return launch_gen_split_rows<10, 2>(a, prep, counter, s, mid, wg);
+        case 16: if (a1mpc_status st = resident_workgroups_gen<16, 1>(&wg); st != A1MPC_OK) return st; return launch_gen_split_rows<16, 1>(a, prep, counter, s, mid, wg);
+        case 20: if (a1mpc_status st = resident_workgroups_gen<20, 1>(&wg); st != A1MPC_OK) return st; return launch_gen_split_rows<20, 1>(a, prep, counter, s, mid, wg);
+    }
+#endif
+    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet / contact schedules need horizon 10, 16 or 20");
+}
 // LDS per QP: 25.2 KB (H = 10: six QPs per CU), 39.9 KB (H = 16: four, one per wavefront like the fast path's), 49.7 KB (H = 20: three, one row per workgroup)
 static a1mpc_status launch_gen(int horizon, const KernelArgs& a, hipStream_t s) {
 #ifndef A1MPC_DEV_SLIM
@@ -575,6 +672,7 @@ struct a1mpc_handle_s {
     double *d_wx = nullptr, *d_wy = nullptr, *d_rho = nullptr;
     // split pipeline: prepared state of every QP (set-up kernel -> ADMM kernel) and the work-queue counter
     double* d_prep = nullptr;
+    double* d_prep_gen = nullptr;  // the general path's records (B~w_t of every step included), allocated on first use
     int* d_counter = nullptr;
     // queue order of the next solve (longest-first by the previous solve's per-QP cost) -- see a1mpc_set_schedule
     int32_t *d_order = nullptr, *d_cost = nullptr;
@@ -1516,7 +1614,7 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_tab, h->d_tab1, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_aux, h->d_Rz, h->d_contact, h->d_grf,
-                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_ekf_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8, h->d_foot_steps, h->d_contact_steps};
+                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_ekf_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8, h->d_foot_steps, h->d_contact_steps, h->d_prep_gen};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -1700,9 +1798,30 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     if (foot_stride != 0 || d_yaw_A != nullptr) {  // general path: per-step B_d (and / or its own A_c yaw), with or without a contact schedule
         if (d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "per-step feet / contacts are not combined with tick records");
         a.foot_stride = foot_stride; a.contact_stride = contact_stride; a.yaw_A = d_yaw_A;
-        h->staged = false;
+        // a batch beyond the resident rows of the general path's ADMM kernel runs its split pipeline (set-up kernel + persistent rows on a queue, like the
+        // fast path); its hand-off records (B~w_t of every step included) live in a buffer of their own, allocated on first use
+        int rows_gen = 0;
+        if (a1mpc_status st0 = resident_rows_gen(h->cfg.horizon, &rows_gen); st0 != A1MPC_OK) return st0;
+        const bool split_gen = pipeline_mode() != 2 && rows_gen > 0 && (pipeline_mode() == 1 || n > rows_gen) && h->d_counter != nullptr;
+        if (split_gen && !h->d_prep_gen) {
+            A1_HIP(hipMalloc(&h->d_prep_gen, static_cast<size_t>(h->max_batch) * prep_stride_gen(h->cfg.horizon) * sizeof(double)));
+        }
+        const bool hints_gen = h->schedule && split_gen && n >= kScheduleMinBatch && h->d_order != nullptr && h->d_cost != nullptr;
+        a.order = hints_gen ? h->d_order : nullptr;
+        a.cost = hints_gen ? h->d_cost : nullptr;
+        a.predict = (hints_gen && h->hint_n != -n) ? 1 : 0;  // (the history of a general-path batch is remembered as -n: never mixed up with a fast-path batch of the same size)
+        h->staged = split_gen;
         A1_HIP(hipEventRecord(h->ev0, s));
-        if (a1mpc_status stg = launch_gen(h->cfg.horizon, a, s); stg != A1MPC_OK) return stg;
+        if (split_gen) {
+            if (a1mpc_status stg = launch_gen_split(h->cfg.horizon, a, h->d_prep_gen, h->d_counter, s, h->ev_mid); stg != A1MPC_OK) return stg;
+            if (hints_gen) {
+                hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, s, n, static_cast<const int32_t*>(h->d_cost), h->d_order);
+                A1_HIP(hipGetLastError());
+                h->hint_n = -n;
+            }
+        } else {
+            if (a1mpc_status stg = launch_gen(h->cfg.horizon, a, s); stg != A1MPC_OK) return stg;
+        }
         A1_HIP(hipEventRecord(h->ev1, s));
         h->timed = true;
         A1_MARK(h, s);

@@ -195,18 +195,21 @@ struct Layout {
     static constexpr int ROW_STRIDE = stride_for(RAW);
 };
 
-// LDS image of the set-up kernel (formation + Ruiz only: no factor): 348 doubles per QP at H = 10
-template <int H>
+// LDS image of the set-up kernel (formation + Ruiz only: no factor): 348 doubles per QP at H = 10; GEN (the general path's own set-up kernel): + the per-step
+// tables B~w_t and T B~w_t, 1068 doubles = 8.5 KB per QP at H = 10 (the per-step bounds are rebuilt from the contact bits by the ADMM kernel)
+template <int H, bool GEN = false>
 struct LayoutSetup {
     static constexpr int KSTR = 13, K_SZ = 12 * KSTR, S_SZ = 78, SLOT = K_SZ + S_SZ, FAC = 0, GCOL = 12;  // unused by the set-up code paths
     static constexpr int TBL = 0;
     static constexpr int DL = 36;
-    static constexpr int COOP = 0;  // never used by the set-up kernel (one row per QP)
-    static constexpr int BW = 0, TBW = 0, LBT = 0, UBT = 0;  // GEN never runs the split pipeline
-    static constexpr int BL = DL + 12 * H;
+    static constexpr int TBW = DL + 12 * H;                  // GEN: [t][3][12] = T*B~_omega of step t
+    static constexpr int COOP = 0;  // never used by the set-up kernels (one row per QP)
+    static constexpr int CUV = 0, LBT = 0, UBT = 0;          // (not written by a set-up-only solver)
+    static constexpr int BL = TBW + (GEN ? 36 * H : 0);
     static constexpr int ZROW = 6;
     static constexpr int CG = BL + 84;
-    static constexpr int RAW = CG + 12 * H;
+    static constexpr int BW = CG + 12 * H;                   // GEN: [t][3][12] = the omega rows of B~_t
+    static constexpr int RAW = BW + (GEN ? 36 * H : 0);
     static constexpr int ROW_STRIDE = RAW + (RAW % 2);
 };
 
@@ -219,6 +222,9 @@ struct Prep {
     static constexpr int XH = FLAGS + 1;
     static constexpr int FIELDS = XH + H;
     static constexpr int STRIDE = FIELDS * 12;  // doubles per QP: 5.2 KB cold / 6.1 KB warm at H = 10
+    // general path, split pipeline: + my column of the omega rows of B~_t for every step, [t][3] (the record of a QP is then STRIDE_GEN doubles)
+    static constexpr int BWF = FIELDS;
+    static constexpr int STRIDE_GEN = (FIELDS + 3 * H) * 12;
 };
 
 // =================================================================================================
@@ -245,9 +251,9 @@ struct Prep {
 // (admm_iteration_twin); everything sequential over the steps is computed redundantly by both rows.
 template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false, bool TWIN = false>
 struct RowSolver {
-    static_assert(!GEN || (MODE == kModeMpc && !SETUP_ONLY && H > 1), "the general path is an MPC solve in the fused kernel");
+    static_assert(!GEN || (MODE == kModeMpc && H > 1), "the general path is an MPC solve");
     static_assert(!TWIN || (MODE == kModeMpc && !SETUP_ONLY && H > 1), "twin rows: the iterations of an MPC solve");
-    using L = std::conditional_t<SETUP_ONLY, LayoutSetup<H>, Layout<H, GEN>>;
+    using L = std::conditional_t<SETUP_ONLY, LayoutSetup<H, GEN>, Layout<H, GEN>>;
     using PR = Prep<H>;
     const DeviceParams& P;
     const double* __restrict__ tab;
@@ -765,7 +771,7 @@ struct RowSolver {
             const double lo_t = P.fz_min * cf, hi_t = P.fz_max * cf;
             if (ct) cmask |= 1u << t;
             if constexpr (GEN) {
-                if (act) { lds[L::LBT + t * 12 + ci] = comp == 2 ? lo_t : 0.0; lds[L::UBT + t * 12 + ci] = comp == 2 ? hi_t : kInfty; }
+                if constexpr (!SETUP_ONLY) { if (act) { lds[L::LBT + t * 12 + ci] = comp == 2 ? lo_t : 0.0; lds[L::UBT + t * 12 + ci] = comp == 2 ? hi_t : kInfty; } }  // (the ADMM kernel of the split pipeline rebuilds them from the contact bits)
             } else if constexpr (!TWIN) {
                 lbk[t] = comp == 2 ? lo_t : 0.0; ubk[t] = comp == 2 ? hi_t : kInfty;
             }
@@ -825,8 +831,16 @@ struct RowSolver {
         p[PR::CM * 12 + ci] = static_cast<double>(cmask); p[PR::HI * 12 + ci] = 0.0;
         p[PR::EQ * 12 + ci] = static_cast<double>(eqmask);
         p[PR::FLAGS * 12 + ci] = (warm ? 1.0 : 0.0) + (first_special ? 2.0 : 0.0);
+        if constexpr (GEN && SETUP_ONLY) {  // the general path's own set-up kernel: the per-step omega rows of B~_t travel with the record
+            static_for<H>([&](auto T) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p[(PR::BWF + 3 * A1_CV(T) + c) * 12 + ci] = lds[L::BW + (A1_CV(T) * 3 + c) * 12 + ci];
+            });
+        }
     }
-    A1_DEV void load_prepared(const double* __restrict__ p, const ProblemIO& io) {
+    // tables (GEN): the record comes from the general path's set-up kernel -- B~w_t and the per-step bounds are rebuilt in this LDS image (in the fused
+    // kernel they are still where the set-up wrote them)
+    A1_DEV void load_prepared(const double* __restrict__ p, const ProblemIO& io, [[maybe_unused]] bool tables = false) {
         sync();  // the previous QP's LDS image is dead
         const double am = act ? 1.0 : 0.0;  // pad lanes read lane 0's record (ci == 0) and zero what must be zero
         const int fl = static_cast<int>(p[PR::FLAGS * 12 + ci]);
@@ -870,6 +884,18 @@ struct RowSolver {
         lo_u = P.fz_min * (cmask & 1u ? 1.0 : 0.0); hi_u = P.fz_max * (cmask & 1u ? 1.0 : 0.0);
         lb0 = comp == 2 ? lo_u : 0.0; ub0 = comp == 2 ? hi_u : kInfty;
         eqmask = act ? static_cast<unsigned>(p[PR::EQ * 12 + ci]) : 0u;
+        if constexpr (GEN) {
+            if (tables && wr) {
+                static_for<H>([&](auto T) {
+                    constexpr int t = A1_CV(T);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) lds[L::BW + (t * 3 + c) * 12 + ci] = p[(PR::BWF + 3 * t + c) * 12 + ci];
+                    const double cf = (cmask >> t) & 1u ? 1.0 : 0.0;
+                    lds[L::LBT + t * 12 + ci] = comp == 2 ? P.fz_min * cf : 0.0;
+                    lds[L::UBT + t * 12 + ci] = comp == 2 ? P.fz_max * cf : kInfty;
+                });
+            }
+        }
         sync();
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false; careful = false;
 #ifdef A1X_CLK
@@ -1663,20 +1689,25 @@ A1_DEV ProblemIO make_io_gen(const BatchArgs& a, int64_t b) {
 }
 
 // split pipeline, kernel 1: formation + Ruiz for QP b, prepared state to global memory
-template <int H>
+template <int H, bool GEN = false>
 A1_DEV void setup_row(const BatchArgs& a, const double* __restrict__ tab, int64_t b, double* __restrict__ lds, double* __restrict__ prep) {
-    RowSolver<H, kModeMpc, true> S(a.P, tab, lds);  // tab: the (alpha/beta, beta) table, staged in LDS by the kernel
-    S.setup(make_io_sched<H, kModeMpc>(a, b));
-    S.save_prepared(prep + b * Prep<H>::STRIDE);
+    RowSolver<H, kModeMpc, true, GEN> S(a.P, tab, lds);  // tab: the (alpha/beta, beta) table, staged in LDS by the kernel
+    if constexpr (GEN) {
+        S.setup(make_io_gen<H>(a, b));
+        S.save_prepared(prep + b * Prep<H>::STRIDE_GEN);
+    } else {
+        S.setup(make_io_sched<H, kModeMpc>(a, b));
+        S.save_prepared(prep + b * Prep<H>::STRIDE);
+    }
     if (a.predict && a.cost != nullptr && S.ln == 0) a.cost[b] = S.pred_cost;
 }
 
 // split pipeline, kernel 2: a persistent row.  It pulls prepared QPs from a shared counter and advances them one
 // checkpoint-aligned segment per loop trip; a row whose QP has converged writes it out and pulls the next one at the next
 // trip, so the rows of a wave never wait for each other's iteration counts -- only for each other's (rare) re-factorisations.
-template <int H, bool TWIN = false>
+template <int H, bool TWIN = false, bool GEN = false>
 A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* __restrict__ counter, double* __restrict__ lds) {
-    RowSolver<H, kModeMpc, false, false, TWIN> S(a.P, a.tab, lds);
+    RowSolver<H, kModeMpc, false, GEN, TWIN> S(a.P, a.tab, lds);
     bool alive = true, need_new = true, have = false;
     int64_t cur = 0;
     while (alive) {
@@ -1696,7 +1727,8 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
             if (cur >= a.n) {
                 alive = false;
             } else {
-                S.load_prepared(prep + cur * Prep<H>::STRIDE, make_io<H, kModeMpc>(a, cur));
+                if constexpr (GEN) S.load_prepared(prep + cur * Prep<H>::STRIDE_GEN, make_io<H, kModeMpc>(a, cur), true);
+                else S.load_prepared(prep + cur * Prep<H>::STRIDE, make_io<H, kModeMpc>(a, cur));
                 have = true;
                 need_new = false;
             }

@@ -147,6 +147,20 @@ def solve_gen(sc, foot, foot_stride, contact, contact_stride, n=None, settings=N
     return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
 
 
+def solve_gen_split(sc, foot, foot_stride, contact, contact_stride, rows=2, n=None, settings=None, **over):
+    """the general path's split pipeline: its own set-up kernel, then `rows` persistent main / twin pairs draining the queue"""
+    h = sc["horizon"]
+    n = len(sc["x0"]) if n is None else n
+    P = make_params(sc["params"], settings, **over)
+    foot = np.ascontiguousarray(foot, dtype=np.float64); contact = np.ascontiguousarray(contact, dtype=np.uint8)
+    grf = np.zeros((n, 12)); u = np.zeros((n, 12 * h))
+    iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32); nfact = np.zeros(n, np.int32)
+    rc = lib().a1mpc_emu_solve_gen_split(C.byref(P), h, n, int(rows), _p(sc["x0"]), _p(sc["xref"]), _p(sc["R"]), _p(foot), int(foot_stride), _p(contact, C.c_uint8),
+                                         int(contact_stride), _p(grf), _p(u), _p(iters, C.c_int32), _p(status, C.c_int32), _p(nfact, C.c_int32))
+    assert rc == 0
+    return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
+
+
 def balance_params(qp=None, settings=None, **over):
     """DeviceParams of the balance QP (S/A1RobotControl.cpp:11-15): the H = 1 member of the family with
     dt = 0, wrench weights (torque first) in q2[6:12], R in r2."""

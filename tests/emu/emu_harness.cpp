@@ -217,6 +217,47 @@ extern "C" int a1mpc_emu_solve_split(const a1mpc::DeviceParams* P, int horizon, 
     }
     return -1;
 }
+namespace a1mpc {
+template <int H>
+static void split_setup_gen_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); setup_row<H, true>(*j->a, j->a->tab, j->b, j->lds, j->prep); }
+template <int H>
+static void split_admm_gen_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); admm_rows<H, true, true>(*j->a, j->prep, j->counter, j->lds); }
+// the general path's split pipeline: its set-up kernel for every QP, then `nrows` persistent main / twin pairs
+template <int H>
+static void run_split_gen(const BatchArgs& a, int nrows) {
+    std::vector<double> tab(2 * H * H);
+    fill_gamma_beta_table(H, tab.data());
+    BatchArgs aa = a; aa.tab = tab.data();
+    std::vector<double> prep((size_t)a.n * Prep<H>::STRIDE_GEN, NAN);
+    std::vector<double> lds1(LayoutSetup<H, true>::ROW_STRIDE), lds2(Layout<H, true>::ROW_STRIDE);
+    int counter = 0;
+    SplitJob<H> j{&aa, prep.data(), &counter, nullptr, 0};
+    for (int64_t b = 0; b < a.n; ++b) {
+        for (auto& v : lds1) v = NAN;
+        j.b = b; j.lds = lds1.data();
+        run_row(split_setup_gen_entry<H>, &j);
+    }
+    for (int r = 0; r < nrows; ++r) {
+        for (auto& v : lds2) v = NAN;
+        j.lds = lds2.data();
+        run_row(split_admm_gen_entry<H>, &j, 32);
+    }
+}
+}  // namespace a1mpc
+extern "C" int a1mpc_emu_solve_gen_split(const a1mpc::DeviceParams* P, int horizon, int n, int nrows, const double* x0, const double* xref, const double* R,
+                                         const double* foot, int foot_stride, const uint8_t* contact, int contact_stride, double* grf, double* u_full,
+                                         int32_t* iters, int32_t* status, int32_t* nfact) {
+    a1mpc::BatchArgs a;
+    memset(&a, 0, sizeof a);
+    a.P = *P; a.n = n; a.x0 = x0; a.xref = xref; a.R = R; a.foot = foot; a.contact = contact; a.grf = grf; a.u_full = u_full;
+    a.iters = iters; a.status = status; a.nfact = nfact; a.foot_stride = foot_stride; a.contact_stride = contact_stride;
+    switch (horizon) {
+        case 10: a1mpc::run_split_gen<10>(a, nrows); return 0;
+        case 16: a1mpc::run_split_gen<16>(a, nrows); return 0;
+        case 20: a1mpc::run_split_gen<20>(a, nrows); return 0;
+    }
+    return -1;
+}
 extern "C" int a1mpc_emu_solve_ticks(const a1mpc::DeviceParams* P, int horizon, int n, const double* tick, const double* R,
                                      const double* foot, const uint8_t* contact, double* grf, double* u_full, int32_t* iters, int32_t* status) {
     using namespace a1mpc;

@@ -262,3 +262,16 @@ def test_emulated_ruiz_sweep_early_stop_is_exact(scen, gen, kw, n, split):
         full = emu.solve(sc, n, split_rows=split, twin=split > 0)
     assert np.array_equal(fast["u"], full["u"]) and np.array_equal(fast["grf"], full["grf"])
     assert (fast["iters"] == full["iters"]).all() and (fast["status"] == full["status"]).all() and (fast["nfact"] == full["nfact"]).all()
+
+
+@pytest.mark.parametrize("h,feet,cont,rows", [(10, True, True, 2), (10, True, False, 1), (16, True, True, 1), (20, False, True, 1)])
+def test_emulated_general_path_split_pipeline(scen, h, feet, cont, rows):
+    """the general path's own set-up kernel + persistent main / twin pairs (the hand-off record carries B~w_t of every step; the ADMM rows rebuild the
+    per-step tables of their LDS image from it): bit for bit the fused general-path kernel"""
+    rng = np.random.default_rng(900 + h)
+    nb = 5 if h <= 10 else 3
+    sc, foot, fs, contact, cs = _strided_case(scen, rng, h, nb, feet, cont)
+    fused = emu.solve_gen(sc, foot, fs, contact, cs, twin=True)
+    split = emu.solve_gen_split(sc, foot, fs, contact, cs, rows=rows)
+    assert np.array_equal(fused["u"], split["u"]) and np.array_equal(fused["grf"], split["grf"])
+    assert (fused["iters"] == split["iters"]).all() and (fused["status"] == split["status"]).all() and (fused["nfact"] == split["nfact"]).all()

@@ -619,6 +619,28 @@ def test_per_step_feet_and_contact_schedules(pkg, oracle, scen, h, nb, feet, con
         assert np.abs(u[c == 0]).max() < 1.0
 
 
+@pytest.mark.parametrize("h,nb", [(10, 4000), (16, 2100), (20, 1700)])
+def test_general_path_split_pipeline(pkg, oracle, scen, h, nb):
+    """a general-path batch beyond its resident rows runs the general path's own set-up kernel + persistent main / twin pairs on a queue (the hand-off
+    record carries B~w_t of every step): bit for bit the fused general-path kernel (the first 200 QPs solved alone), the oracle's strided formation on a
+    sample, and a re-solve in history order"""
+    rng = np.random.default_rng(5000 + h)
+    sc, foot, fs, contact, cs = _strided_inputs(scen, rng, h, nb, True, True)
+    with _engine(pkg, sc, nb, warm_start=0) as eng:
+        out = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, fs, contact, cs, want_u=True)
+        again = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, fs, contact, cs, want_u=True)   # queue now ordered by the first solve's costs
+        small = eng.solve_strided(sc["x0"][:200], sc["xref"][:200], sc["R"][:200], foot[:200], fs, contact[:200], cs, want_u=True)
+    assert np.array_equal(out["u"], again["u"]) and np.array_equal(out["iters"], again["iters"])
+    assert np.array_equal(out["u"][:200], small["u"]) and np.array_equal(out["iters"][:200], small["iters"]) and np.array_equal(out["grf"][:200], small["grf"])
+    pr = oracle.mpc_params(h, **{k: sc["params"][k] for k in ("dt", "mu", "fz_min", "fz_max", "q", "r", "mass", "inertia")}); st = oracle.default_settings()
+    worst = 0.0
+    for b in range(0, nb, nb // 50):
+        r = oracle.mpc_solve(pr, st, sc["x0"][b], sc["xref"][b], sc["R"][b], foot[b], contact[b], foot_stride=fs, contact_stride=cs)
+        assert out["iters"][b] == r["info"].iters and out["status"][b] == r["info"].status, (b, out["iters"][b], r["info"].iters)
+        worst = max(worst, np.abs(out["u"][b] - r["u"]).max(), np.abs(out["grf"][b] - r["grf"]).max())
+    assert worst <= TOL_FORCE_N, worst
+
+
 @pytest.mark.parametrize("h,nb", [(10, 4500), (10, 700), (10, 1), (16, 1200), (20, 2300)])
 def test_contact_schedule_alone_stays_on_the_fast_kernels(pkg, oracle, scen, h, nb):
     """a per-step contact schedule with step-invariant feet (contact_stride = 4, foot_stride = 0, no yaw_A): the fast kernels take it (set-up
