@@ -2382,4 +2382,104 @@ a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double*
     return A1MPC_OK;
 }
 
+
+// ======================================================================================================================
+// Batch pipeline: `depth` engine handles on `depth` HIP streams of ONE device, batches submitted round-robin.  A launch of a few thousand QPs
+// ends in a tail (its few 150-225-iteration QPs keep a handful of wavefronts busy, the rest of the chip idles); with a second batch in flight
+// on another stream the hardware dispatches that batch's set-up kernel and persistent rows onto the SIMDs the tail has left.  Every slot is a
+// complete handle (its own prepared-state records, queue, warm start), so batches in flight share nothing and results are bit-identical to a
+// lone handle's.  One host thread per pipeline (like a handle).
+struct a1mpc_pipeline_s {
+    int device = 0, depth = 0, next = 0;
+    std::vector<a1mpc_handle> h;
+    std::vector<hipEvent_t> ready, done;   // per slot: "the caller's inputs are ready" (recorded on the caller's stream), "this slot's last submit has finished"
+    std::vector<char> used;
+};
+
+void a1mpc_pipeline_destroy(a1mpc_pipeline p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (hipEvent_t e : p->ready) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->done) if (e) (void)hipEventDestroy(e);
+    for (a1mpc_handle h : p->h) a1mpc_destroy(h);
+    delete p;
+}
+
+a1mpc_status a1mpc_pipeline_create(const a1mpc_config* cfg, int32_t max_batch, int32_t device, int32_t depth, a1mpc_pipeline* out) {
+    if (!cfg || !out || max_batch <= 0 || device < 0 || depth < 0 || depth > 8) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null config/out, bad batch/device or depth > 8");
+    *out = nullptr;
+    a1mpc_pipeline p = new (std::nothrow) a1mpc_pipeline_s();
+    if (!p) return fail(A1MPC_ERR_HIP, "out of host memory");
+    p->device = device; p->depth = depth == 0 ? 2 : depth;
+    for (int k = 0; k < p->depth; ++k) {
+        a1mpc_handle hk = nullptr;
+        const a1mpc_status st = a1mpc_create(cfg, max_batch, device, &hk);
+        if (st != A1MPC_OK) { a1mpc_pipeline_destroy(p); return st; }
+        p->h.push_back(hk);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
+            if (e0) (void)hipEventDestroy(e0);
+            a1mpc_pipeline_destroy(p);
+            return fail(A1MPC_ERR_HIP, "hipEventCreate (pipeline)");
+        }
+        p->ready.push_back(e0); p->done.push_back(e1); p->used.push_back(0);
+    }
+    *out = p;
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_pipeline_depth(a1mpc_pipeline p, int32_t* depth_out) {
+    if (!p || !depth_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null pipeline/out");
+    *depth_out = p->depth;
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_pipeline_handle(a1mpc_pipeline p, int32_t slot, a1mpc_handle* out) {
+    if (!p || !out || slot < 0 || slot >= p->depth) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null pipeline/out or slot out of range");
+    *out = p->h[slot];
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_pipeline_submit_device(a1mpc_pipeline p, int32_t slot, int32_t fresh_batch, int32_t n, const double* d_x0, const double* d_x_ref,
+                                          const double* d_R_world, const double* d_foot_abs, const uint8_t* d_contact, double* d_grf_body_out,
+                                          double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out, void* inputs_ready_stream, int32_t* slot_out) {
+    if (!p) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (slot >= p->depth) return fail(A1MPC_ERR_INVALID_ARGUMENT, "slot out of range");
+    if (!d_x0 || !d_x_ref) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    const int k = slot >= 0 ? slot : p->next;
+    a1mpc_handle h = p->h[k];
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_pipeline_create");
+    A1_HIP(hipSetDevice(p->device));
+    if (inputs_ready_stream) {   // the slot's stream starts after everything the caller has queued on that stream so far
+        A1_HIP(hipEventRecord(p->ready[k], static_cast<hipStream_t>(inputs_ready_stream)));
+        A1_HIP(hipStreamWaitEvent(h->stream, p->ready[k], 0));
+    }
+    if (fresh_batch) {           // QPs this slot has not seen before: queue ordered by the set-up kernel's cost guess, not by the slot's previous batch
+        if (a1mpc_status st = a1mpc_set_schedule(h, 1); st != A1MPC_OK) return st;
+    }
+    if (a1mpc_status st = solve_device_impl(h, n, nullptr, d_x0, d_x_ref, d_R_world, d_foot_abs, d_contact, d_grf_body_out, d_u_full_out, d_iters_out,
+                                            d_status_out, h->stream); st != A1MPC_OK) return st;
+    A1_HIP(hipEventRecord(p->done[k], h->stream));
+    p->used[k] = 1;
+    if (slot < 0) p->next = (p->next + 1) % p->depth;
+    if (slot_out) *slot_out = k;
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_pipeline_wait(a1mpc_pipeline p, int32_t slot) {
+    if (!p || slot >= p->depth) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null pipeline or slot out of range");
+    A1_HIP(hipSetDevice(p->device));
+    for (int k = 0; k < p->depth; ++k)
+        if ((slot < 0 || slot == k) && p->used[k]) A1_HIP(hipEventSynchronize(p->done[k]));
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_pipeline_join(a1mpc_pipeline p, int32_t slot, void* hip_stream) {
+    if (!p || slot >= p->depth) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null pipeline or slot out of range");
+    A1_HIP(hipSetDevice(p->device));
+    for (int k = 0; k < p->depth; ++k)
+        if ((slot < 0 || slot == k) && p->used[k]) A1_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), p->done[k], 0));
+    return A1MPC_OK;
+}
+
 }  // extern "C"

@@ -43,7 +43,8 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
 EXPORTS = ["a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
-           "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error"]
+           "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error", "a1mpc_pipeline_create", "a1mpc_pipeline_submit_device",
+           "a1mpc_pipeline_wait", "a1mpc_pipeline_join", "a1mpc_pipeline_handle", "a1mpc_pipeline_depth", "a1mpc_pipeline_destroy"]
 
 _lib = None
 
@@ -99,6 +100,13 @@ def load_library(path=None):
     lib.a1mpc_sharded_solve_batch.argtypes = [vp, i32, dp, dp, dp, dp, u8p, dp, i32p, i32p]; lib.a1mpc_sharded_solve_batch.restype = C.c_int
     lib.a1mpc_sharded_info.argtypes = [vp, i32p, i32p, i32p]; lib.a1mpc_sharded_info.restype = C.c_int
     lib.a1mpc_sharded_destroy.argtypes = [vp]; lib.a1mpc_sharded_destroy.restype = None
+    lib.a1mpc_pipeline_create.argtypes = [C.POINTER(Config), i32, i32, i32, C.POINTER(vp)]; lib.a1mpc_pipeline_create.restype = C.c_int
+    lib.a1mpc_pipeline_submit_device.argtypes = [vp, i32, i32, i32] + [vp] * 9 + [vp, i32p]; lib.a1mpc_pipeline_submit_device.restype = C.c_int
+    lib.a1mpc_pipeline_wait.argtypes = [vp, i32]; lib.a1mpc_pipeline_wait.restype = C.c_int
+    lib.a1mpc_pipeline_join.argtypes = [vp, i32, vp]; lib.a1mpc_pipeline_join.restype = C.c_int
+    lib.a1mpc_pipeline_handle.argtypes = [vp, i32, C.POINTER(vp)]; lib.a1mpc_pipeline_handle.restype = C.c_int
+    lib.a1mpc_pipeline_depth.argtypes = [vp, i32p]; lib.a1mpc_pipeline_depth.restype = C.c_int
+    lib.a1mpc_pipeline_destroy.argtypes = [vp]; lib.a1mpc_pipeline_destroy.restype = None
     lib.a1mpc_terrain_batch.argtypes = [vp, i32, i32, dp, dp, dp, dp]; lib.a1mpc_terrain_batch.restype = C.c_int
     lib.a1mpc_form_qp_batch.argtypes = [vp, i32, dp, dp, dp, dp, i32, u8p, i32, dp, dp, dp, dp, dp]; lib.a1mpc_form_qp_batch.restype = C.c_int
     lib.a1mpc_update_config.argtypes = [vp, C.POINTER(Config)]; lib.a1mpc_update_config.restype = C.c_int
@@ -388,6 +396,62 @@ class Engine:
 
 
 # ---- work model used for roofline.achieved (DESIGN.md "Measurement") --------------
+class Pipeline:
+    """a1mpc_pipeline: `depth` engine handles on `depth` HIP streams of one GPU, batches submitted round-robin so that the next batch's
+    set-up kernel and persistent rows fill the tail of the one before (include/a1mpc.h).  Device pointers (torch tensors) only."""
+
+    def __init__(self, cfg, max_batch, device=0, depth=2):
+        self.lib = load_library()
+        self.cfg = cfg; self.horizon = int(cfg.horizon); self.max_batch = int(max_batch); self.device = int(device)
+        self._p = C.c_void_p()
+        _check(self.lib, self.lib.a1mpc_pipeline_create(C.byref(cfg), self.max_batch, self.device, int(depth), C.byref(self._p)), "a1mpc_pipeline_create")
+        d = C.c_int32(0)
+        _check(self.lib, self.lib.a1mpc_pipeline_depth(self._p, C.byref(d)), "a1mpc_pipeline_depth")
+        self.depth = int(d.value)
+
+    def submit_device(self, n, d_x0, d_xref, d_R, d_foot, d_contact, d_grf, d_u=None, d_iters=None, d_status=None, slot=-1, fresh=True, after_stream=None):
+        """returns the slot the batch went to; outputs are valid after wait(slot) / join(slot, stream)"""
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+        k = C.c_int32(-1)
+        rc = self.lib.a1mpc_pipeline_submit_device(self._p, int(slot), 1 if fresh else 0, int(n), ptr(d_x0), ptr(d_xref), ptr(d_R), ptr(d_foot), ptr(d_contact),
+                                                   ptr(d_grf), ptr(d_u), ptr(d_iters), ptr(d_status), C.c_void_p(int(after_stream)) if after_stream else None, C.byref(k))
+        _check(self.lib, rc, "a1mpc_pipeline_submit_device")
+        return int(k.value)
+
+    def wait(self, slot=-1):
+        _check(self.lib, self.lib.a1mpc_pipeline_wait(self._p, int(slot)), "a1mpc_pipeline_wait")
+
+    def join(self, stream, slot=-1):
+        _check(self.lib, self.lib.a1mpc_pipeline_join(self._p, int(slot), C.c_void_p(int(stream)) if stream else None), "a1mpc_pipeline_join")
+
+    def handle(self, slot):
+        h = C.c_void_p()
+        _check(self.lib, self.lib.a1mpc_pipeline_handle(self._p, int(slot), C.byref(h)), "a1mpc_pipeline_handle")
+        return h
+
+    def last_nfact(self, slot, n):
+        out = np.zeros(int(n), np.int32)
+        _check(self.lib, self.lib.a1mpc_last_nfact(self.handle(slot), int(n), _ip(out)), "a1mpc_last_nfact")
+        return out
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p:
+            self.lib.a1mpc_pipeline_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 class ShardedEngine:
     """a1mpc_sharded_*: one handle, the batch cut into contiguous shards over `devices` (None = all visible), transport 0 = pinned copies, 1 = RCCL"""
 

@@ -322,11 +322,13 @@ def strong_scaling_config4(pkg, args, rank, world, local, backend, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=BATCH, help="QPs per GPU per step")
     ap.add_argument("--config", type=int, default=2, choices=(2, 4), help="2 (default): BASELINE configs[2], 4096 x h10 per GPU, weak scaling (the `metric`); "
                     "4: BASELINE configs[3], 65536 x h16 in total, sharded over the GPUs with scatter + gather inside the timed region (strong scaling)")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight (a1mpc_pipeline: one engine handle + HIP stream each, submitted round-robin); "
+                    "1 = one handle, launches serialised on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-index-order", action="store_true", help="skip the extra index-order steps (profiling runs)")
@@ -377,38 +379,61 @@ def main():
     ds = [{k: torch.from_numpy(s_[k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")} for s_ in scs]
     grf = torch.zeros((n, 12), dtype=torch.float64, device=dev)
     iters = torch.zeros(n, dtype=torch.int32, device=dev); status = torch.zeros(n, dtype=torch.int32, device=dev)
-    eng = pkg.Engine(cfg, n, local)
+    outs = [(torch.zeros((n, 12), dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev))
+            for _ in range(NB)]           # one output set per resident batch: a batch in flight never shares its outputs with the next one
+    depth = max(1, min(args.depth, NB))
+    eng = pkg.Engine(cfg, n, local)       # the lone handle: single-stream figures, index / history order, work collection
+    pipe = pkg.Pipeline(cfg, n, local, depth=depth)   # `value`: `depth` batches in flight, the next batch fills the tail of the one before
     stream = torch.cuda.Stream(device=dev)  # a real (non-null) HIP stream: kernels and the timing events share it
     torch.cuda.synchronize()
 
-    def step(k=0, fresh=True):
+    def step(k=0, fresh=True):            # the lone handle, one stream
         d = ds[k % NB]
         if fresh:
             eng.set_schedule(True)   # forget the previous solve: the queue is ordered by the set-up kernel's own cost guess
         eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, iters, status, stream=stream.cuda_stream)
 
+    def submit(k, after=None):            # the pipeline: every batch a first solve (fresh: the slot's history is dropped), round-robin over the slots
+        d = ds[k % NB]; o = outs[k % NB]
+        return pipe.submit_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], o[0], None, o[1], o[2], fresh=True, after_stream=after)
+
     for k in range(args.warmup):
-        step(k)
+        submit(k)
+    pipe.wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    evs[0].record(stream)
+    e0.record(stream)
     for k in range(args.steps):
-        step(k)
-        evs[k + 1].record(stream)
+        submit(k, after=stream.cuda_stream if k < depth else None)   # the first launch of every slot starts behind e0
+    pipe.join(stream.cuda_stream)         # ... and e1 sits behind the last launch of every slot: HIP events around the timed region
+    e1.record(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms = np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps)])  # HIP events on the launch stream
+    pipe_ms = e0.elapsed_time(e1) / args.steps   # device time per batch with `depth` batches in flight
+    pipe_out0 = tuple(t_.cpu().numpy().copy() for t_ in outs[0])   # what the timed region left for batch 0 (GRFs, iterations, status): the parity block checks THESE
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # the same steps through the lone handle on one stream (launches serialised): per-launch durations by HIP events, what a kernel trace shows
+    for k in range(2):
+        step(k)
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    evs[0].record(stream)
+    for k in range(args.steps):
+        step(k)
+        evs[k + 1].record(stream)
+    torch.cuda.synchronize()
+    kern_ms = np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps)])  # HIP events on the launch stream
 
     # per-batch work (iterations, factorisations: deterministic) for the flop model, collected outside the timed region
     work = []
@@ -418,6 +443,7 @@ def main():
     gpu_grf0 = None
     step(0); torch.cuda.synchronize(); gpu_grf0 = grf.cpu().numpy().copy()
     it, stt = work[0][0], work[0][1]
+    pipe_same = bool(np.array_equal(pipe_out0[0], gpu_grf0) and np.array_equal(pipe_out0[1], it) and np.array_equal(pipe_out0[2], stt))
     # the same batches with the queue ordered by history (each batch re-solved right after itself) and in plain index order: reported beside `value`
     index_ms = hist_ms = None
     if not args.no_index_order:
@@ -435,7 +461,8 @@ def main():
         h = HORIZON
         flops_b = [float(pkg.algorithmic_flops(h, w[0], w[2]).sum()) for w in work]
         flops = float(np.mean([flops_b[k % NB] for k in range(args.steps)]))   # mean algorithmic flops of a timed launch
-        avg_ms = float(kern_ms.mean())
+        single_ms = float(kern_ms.mean())          # one launch alone on one stream (what a kernel trace shows per launch: set-up + order + ADMM kernel)
+        avg_ms = float(pipe_ms)                    # device time per launch over the timed region (HIP events), `depth` launches in flight
         achieved = flops / (avg_ms * 1e-3) / 1e12
         pmc = {}
         try:
@@ -448,13 +475,20 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: batch=4096 randomized CoM states + flat terrain, horizon=10, cold-start "
-                                   "OSQP-default ADMM, per GPU; 4 distinct batches cycled, every step a first solve (no queue-order history)",
-                       "batch_per_gpu": n, "horizon": h, "parallelism": f"batch-sharded x{world}",
+                                   "OSQP-default ADMM, per GPU; 4 distinct batches cycled, every step a first solve (no queue-order history); "
+                                   f"{depth} batch(es) in flight (a1mpc_pipeline: one engine handle + HIP stream per slot, round-robin)",
+                       "batch_per_gpu": n, "horizon": h, "parallelism": f"batch-sharded x{world}", "batches_in_flight": depth,
                        "mean_iters": float(it.mean()), "max_iters": int(it.max()), "solved_frac": float((stt == 1).mean())},
             "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r02_pmc_summary.json" if traffic else None,
                          "kernel": "a1mpc_setup_kernel<10,1> + a1mpc_admm_kernel<10,2> (+ a1mpc_order_kernel, ~5 us) = one solve", "avg_kernel_ms": avg_ms,
+                         "avg_kernel_ms_is": f"timed region (HIP events on the launch stream, behind the first and after the last launch of every slot) / launches, {depth} launches in flight: "
+                                             "with overlapping launches this is the rate a launch completes at, not the span of one launch",
+                         "single_stream": {"avg_kernel_ms": single_ms, "achieved": flops / (single_ms * 1e-3) / 1e12, "frac": flops / (single_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                           "solves_per_s": n / (single_ms * 1e-3),
+                                           "what": "the same first solves through ONE handle on one stream, launches serialised: the sum of the three kernels' durations in a kernel trace "
+                                                   "(profiles/r02_kernel_stats_bench_depth1_batch4096_h10.csv)"},
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
                          "executed_fp64_flops_per_launch": pmc.get("executed_fp64_flops_per_launch"),
                          "executed_fp64_frac": (pmc["executed_fp64_flops_per_launch"] / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if pmc.get("executed_fp64_flops_per_launch") else None,
@@ -503,12 +537,13 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"], ref = cpu_baseline(pkg, sc)
             # parity of the timed workload against the checker (same leg: the oracle is only ever the baseline / the checker)
-            dg = np.abs(gpu_grf0 - ref["grf"])
-            out["parity"] = {"checked_qps": int(n), "max_abs_dgrf_N": float(dg.max()), "iteration_mismatches": int((it != ref["iters"]).sum()),
-                             "status_mismatches": int((stt != ref["status"]).sum()), "tolerance_N": 1e-5,
+            dg = np.abs(pipe_out0[0] - ref["grf"])
+            out["parity"] = {"checked_qps": int(n), "max_abs_dgrf_N": float(dg.max()), "iteration_mismatches": int((pipe_out0[1] != ref["iters"]).sum()),
+                             "status_mismatches": int((pipe_out0[2] != ref["status"]).sum()), "tolerance_N": 1e-5,
+                             "checked": "the outputs the timed region left for batch 0 (pipelined launches)", "pipelined_outputs_bit_identical_to_lone_handle": pipe_same,
                              "against": "oracle/a1mpc_oracle.c (formation pinned to the reference's ConvexMpc.cpp by oracle/_ref; the OSQP solve restated, unpinned)"}
         print(json.dumps(out), flush=True)
-    eng.close()
+    eng.close(); pipe.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -389,6 +389,38 @@ a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded s, int32_t n, const double*
 a1mpc_status a1mpc_sharded_info(a1mpc_sharded s, int32_t* n_shards, int32_t* devices_out, int32_t* transport);
 void a1mpc_sharded_destroy(a1mpc_sharded s);
 
+/*
+ * Batch pipeline: consecutive batches in flight together on ONE device (north_star: "HIP streams"; the reference has no counterpart -- it
+ * solves one QP per tick on one thread, S/MainGazebo.cpp:57-68).  A launch of a few thousand QPs ends in a tail: its few 150-225-iteration
+ * QPs keep a handful of wavefronts busy while the rest of the chip idles (the last 0.15-0.25 ms of a 0.85 ms launch at 4096 x h10).  The
+ * pipeline owns `depth` complete engine handles (0 = the default, 2) on `depth` HIP streams and hands batches to them round-robin, so the
+ * next batch's set-up kernel and persistent rows are dispatched onto the SIMDs the tail has left.  Batches in flight share nothing
+ * (prepared-state records, queue, warm start are per slot): results are bit-identical to a lone handle's.  Measured on one MI355X, first
+ * solves of distinct batches (profiles/r02_overlap_probe.json): 2048 x h10 3.4 -> 6.3 M solves/s (depth 3), 4096 x h10 4.8 -> 6.1 M,
+ * 8192 x h16 1.92 -> 2.07 M, 8192 x h20 1.43 -> 1.61 M; batches of >= 16 384 QPs fill the chip on their own and lose 7 % when pipelined --
+ * submit those through a plain handle.
+ *   submit   device pointers, layouts of a1mpc_solve_batch_device.  slot = -1: next slot round-robin (returned in *slot_out), or a fixed
+ *            slot (a robot population that is warm-started must stay on its slot: the carried OSQP workspace lives there).
+ *            fresh_batch != 0: these QPs are new to the slot, order its queue by the set-up kernel's cost guess instead of the slot's
+ *            previous batch (a1mpc_set_schedule).  inputs_ready_stream: the slot starts after everything queued on that stream so far
+ *            (NULL = the inputs are ready now).  Returns at once; the outputs of a slot are valid after a1mpc_pipeline_wait / _join, and
+ *            its output buffers must not be handed to another submit before that.
+ *   wait     the host waits for the slot's last submit (slot -1 = every slot);  join: a caller's stream waits for it instead.
+ *   handle   the slot's engine handle, for warm-start I/O, a1mpc_update_config and the instrumentation calls.
+ * One host thread per pipeline.
+ */
+typedef struct a1mpc_pipeline_s* a1mpc_pipeline;
+a1mpc_status a1mpc_pipeline_create(const a1mpc_config* cfg, int32_t max_batch, int32_t device, int32_t depth, a1mpc_pipeline* out);
+a1mpc_status a1mpc_pipeline_submit_device(a1mpc_pipeline p, int32_t slot, int32_t fresh_batch, int32_t n, const double* d_x0,
+                                          const double* d_x_ref, const double* d_R_world, const double* d_foot_abs, const uint8_t* d_contact,
+                                          double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out,
+                                          void* inputs_ready_stream, int32_t* slot_out);
+a1mpc_status a1mpc_pipeline_wait(a1mpc_pipeline p, int32_t slot);
+a1mpc_status a1mpc_pipeline_join(a1mpc_pipeline p, int32_t slot, void* hip_stream);
+a1mpc_status a1mpc_pipeline_handle(a1mpc_pipeline p, int32_t slot, a1mpc_handle* out);
+a1mpc_status a1mpc_pipeline_depth(a1mpc_pipeline p, int32_t* depth_out);
+void a1mpc_pipeline_destroy(a1mpc_pipeline p);
+
 const char* a1mpc_status_string(a1mpc_status s);
 const char* a1mpc_last_error(void); /* thread-local detail of the last non-OK return (e.g. the HIP error string) */
 

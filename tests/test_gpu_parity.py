@@ -847,3 +847,91 @@ def test_general_path_warm_started_sequence_and_device_pointers(pkg, oracle, sce
         assert rc == 0
         torch.cuda.synchronize()
     assert np.array_equal(g.cpu().numpy(), host["grf"]) and np.array_equal(it.cpu().numpy(), host["iters"])
+
+
+def test_batch_pipeline_overlaps_batches_and_changes_no_bit(pkg, oracle, scen):
+    """a1mpc_pipeline_*: consecutive batches in flight on `depth` handles / HIP streams.  Every batch comes back bit-identical to a lone handle's
+    solve (and the first one is oracle-checked), slots go round-robin, a fixed slot keeps its warm start, wait / join deliver the outputs, and at
+    4096 x h10 two batches in flight are faster per batch than one (the next batch runs in the tail of the one before)."""
+    import time
+    import torch
+    n, NB = 4096, 4
+    dev = torch.device("cuda:0")
+    scs = [scen.config3_random_flat(nb=n, seed=500 + k) for k in range(NB)]
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    ins = [[t(s["x0"]), t(s["xref"]), t(s["R"]), t(s["foot"]), t(s["contact"], torch.uint8)] for s in scs]
+    cfg = pkg.make_config(scs[0]["params"], 10, warm_start=0)
+    ref = []
+    with pkg.Engine(cfg, n, 0) as eng:
+        for k in range(NB):
+            g = torch.zeros(n, 12, dtype=torch.float64, device=dev); it = torch.zeros(n, dtype=torch.int32, device=dev)
+            eng.set_schedule(True)
+            eng.solve_device(n, *ins[k], g, None, it); torch.cuda.synchronize()
+            ref.append((g.cpu().numpy(), it.cpu().numpy()))
+    o = oracle_batch(oracle, scs[0])
+    assert np.abs(ref[0][0] - o["grf"]).max() <= TOL_FORCE_N and (ref[0][1] == o["iters"]).all()
+
+    def run(depth, steps):
+        outs = [(torch.zeros(n, 12, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(NB)]
+        with pkg.Pipeline(cfg, n, 0, depth=depth) as pipe:
+            assert pipe.depth == depth
+            slots = [pipe.submit_device(n, *ins[k % NB], outs[k % NB][0], None, outs[k % NB][1]) for k in range(NB)]
+            assert slots == [k % depth for k in range(NB)]
+            pipe.wait()
+            for k in range(NB):
+                assert np.array_equal(outs[k][0].cpu().numpy(), ref[k][0]) and np.array_equal(outs[k][1].cpu().numpy(), ref[k][1]), (depth, k)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for k in range(steps):
+                pipe.submit_device(n, *ins[k % NB], outs[k % NB][0], None, outs[k % NB][1])
+            pipe.wait()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            # join: a caller's stream sees the outputs of a submit that waited for that stream's inputs
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                x0 = ins[1][0].clone()
+            g = torch.zeros(n, 12, dtype=torch.float64, device=dev)
+            k = pipe.submit_device(n, x0, *ins[1][1:], g, after_stream=s.cuda_stream)
+            pipe.join(s.cuda_stream, k)
+            with torch.cuda.stream(s):
+                gsum = g.clone()
+            s.synchronize()
+            assert np.array_equal(gsum.cpu().numpy(), ref[1][0])
+        return ms
+    ms1 = min(run(1, 24) for _ in range(2)); ms2 = min(run(2, 24) for _ in range(2))
+    print(f"4096 x h10 first solves: {ms1:.3f} ms per batch alone, {ms2:.3f} ms with two in flight")
+    assert ms2 < 0.95 * ms1, (ms1, ms2)
+
+    # a warm-started population stays on its slot: slot 1 alone carries its own OSQP workspace from tick to tick
+    sc = scen.config3_random_flat(nb=256, seed=9)
+    cfgw = pkg.make_config(sc["params"], 10, warm_start=1)
+    a = [t(sc["x0"]), t(sc["xref"]), t(sc["R"]), t(sc["foot"]), t(sc["contact"], torch.uint8)]
+    with pkg.Engine(cfgw, 256, 0) as eng, pkg.Pipeline(cfgw, 256, 0, depth=2) as pipe:
+        for tick in range(3):
+            g0 = torch.zeros(256, 12, dtype=torch.float64, device=dev); i0 = torch.zeros(256, dtype=torch.int32, device=dev)
+            g1 = torch.zeros(256, 12, dtype=torch.float64, device=dev); i1 = torch.zeros(256, dtype=torch.int32, device=dev)
+            eng.solve_device(256, *a, g0, None, i0)
+            assert pipe.submit_device(256, *a, g1, None, i1, slot=1, fresh=False) == 1
+            pipe.wait(1); torch.cuda.synchronize()
+            assert np.array_equal(g0.cpu().numpy(), g1.cpu().numpy()) and np.array_equal(i0.cpu().numpy(), i1.cpu().numpy()), tick
+        assert i1.float().mean().item() < 40   # warm: 25 iterations for nearly every QP
+
+
+def test_batch_pipeline_argument_errors(pkg, scen):
+    import ctypes as C
+    sc = scen.config3_random_flat(nb=8)
+    cfg = pkg.make_config(sc["params"], 10, warm_start=0)
+    lib = pkg.load_library()
+    p = C.c_void_p()
+    assert lib.a1mpc_pipeline_create(C.byref(cfg), 8, 0, 9, C.byref(p)) != 0 and not p          # depth > 8
+    assert lib.a1mpc_pipeline_create(C.byref(cfg), 0, 0, 2, C.byref(p)) != 0
+    bad = pkg.make_config(sc["params"], 7)
+    assert lib.a1mpc_pipeline_create(C.byref(bad), 8, 0, 2, C.byref(p)) != 0 and not p          # unsupported horizon, nothing leaked
+    with pkg.Pipeline(cfg, 8, 0, depth=0) as pipe:
+        assert pipe.depth == 2
+        with pytest.raises(pkg.A1MpcError):
+            pipe.submit_device(8, None, None, None, None, None, None)
+        with pytest.raises(pkg.A1MpcError):
+            pipe.wait(5)
+        pipe.wait()   # nothing submitted yet: returns at once
+        assert lib.a1mpc_pipeline_wait(None, -1) != 0
+    lib.a1mpc_pipeline_destroy(None)

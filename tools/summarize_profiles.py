@@ -20,6 +20,40 @@ if os.path.exists(log):
     lines = [l for l in open(log) if l.startswith("{")]
     if lines:
         open(os.path.join(dst, TAG + "_bench_under_rocprof.json"), "w").write(lines[-1])
+f = newest(os.path.join(src, "trace_depth1", "**", "*kernel_stats.csv"))
+if f:
+    shutil.copy(f, os.path.join(dst, TAG + "_kernel_stats_bench_depth1_batch4096_h10.csv"))
+log = os.path.join(src, "bench_depth1_under_rocprof.log")
+if os.path.exists(log):
+    lines = [l for l in open(log) if l.startswith("{")]
+    if lines:
+        open(os.path.join(dst, TAG + "_bench_depth1_under_rocprof.json"), "w").write(lines[-1])
+
+
+def overlap_summary(trace_dir):
+    """from the kernel trace's timestamps: how the launches of the PIPELINED timed region (the first 2 + 10 ADMM launches of the process: warm-up, timed) sit on the time axis --
+    span per launch (the rate launches complete at) against the mean duration of one launch's kernels (longer than the span when launches overlap)"""
+    f = newest(os.path.join(trace_dir, "**", "*kernel_trace.csv"))
+    if not f:
+        return None
+    rows = [r for r in csv.DictReader(open(f)) if "a1mpc" in r.get("Kernel_Name", "") and "noop" not in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    admm = [r for r in rows if "admm_kernel" in r["Kernel_Name"]]
+    setup = [r for r in rows if "setup_kernel" in r["Kernel_Name"]]
+    if len(admm) < 12 or len(setup) < 12:
+        return None
+    timed_a, timed_s = admm[2:12], setup[2:12]
+    t0 = min(int(r["Start_Timestamp"]) for r in timed_s); t1 = max(int(r["End_Timestamp"]) for r in timed_a)
+    dur = lambda rs: float(sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs)) / len(rs) * 1e-6
+    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in timed_a)
+    return {"timed_launches": 10, "span_ms_per_launch": (t1 - t0) * 1e-6 / 10, "mean_admm_kernel_ms": dur(timed_a), "mean_setup_kernel_ms": dur(timed_s),
+            "admm_kernels_in_flight_mean": busy / float(t1 - t0), "streams": sorted({r.get("Stream_Id", r.get("Queue_Id", "?")) for r in timed_a})}
+
+
+ov = {"depth2_default": overlap_summary(os.path.join(src, "trace")), "depth1": overlap_summary(os.path.join(src, "trace_depth1"))}
+if any(ov.values()):
+    json.dump(ov, open(os.path.join(dst, TAG + "_kernel_trace_overlap.json"), "w"), indent=1)
+    print(json.dumps(ov, indent=1))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 pmc_files = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
