@@ -391,7 +391,11 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
     hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
     A1_HIP(hipGetLastError());
-    if (a.predict && a.cost != nullptr && a.order != nullptr) {  // no history: the queue order comes from the set-up kernel's cost guesses
+    // queue order of THIS solve, longest first: by the set-up kernel's cost guesses (predict: no history) or by the cost each QP had in the handle's previous
+    // solve of this batch size (the cost buffer still holds it; the ADMM kernel below overwrites it with this solve's).  Sorted here, in front of the kernel
+    // that needs it, not behind the solve that produced the costs: a one-workgroup kernel of 1024 threads behind a persistent kernel waits for a free CU, and
+    // with a second batch in flight on another stream (a1mpc_pipeline) that wait was ~0.5 ms per launch (kernel trace, profiles/r02_kernel_trace_overlap.json)
+    if (a.cost != nullptr && a.order != nullptr) {
         hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, static_cast<int>(a.n), static_cast<const int32_t*>(a.cost),
                            const_cast<int32_t*>(a.order));
         A1_HIP(hipGetLastError());
@@ -487,7 +491,7 @@ static a1mpc_status launch_gen_split_rows(const KernelArgs& a, double* prep, int
     A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
     hipLaunchKernelGGL((a1mpc_setup_gen_kernel<H>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
     A1_HIP(hipGetLastError());
-    if (a.predict && a.cost != nullptr && a.order != nullptr) {
+    if (a.cost != nullptr && a.order != nullptr) {   // (predicted or the previous solve's costs: see launch_split_rows)
         hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, static_cast<int>(a.n), static_cast<const int32_t*>(a.cost), const_cast<int32_t*>(a.order));
         A1_HIP(hipGetLastError());
     }
@@ -1814,11 +1818,7 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
         A1_HIP(hipEventRecord(h->ev0, s));
         if (split_gen) {
             if (a1mpc_status stg = launch_gen_split(h->cfg.horizon, a, h->d_prep_gen, h->d_counter, s, h->ev_mid); stg != A1MPC_OK) return stg;
-            if (hints_gen) {
-                hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, s, n, static_cast<const int32_t*>(h->d_cost), h->d_order);
-                A1_HIP(hipGetLastError());
-                h->hint_n = -n;
-            }
+            if (hints_gen) h->hint_n = -n;   // the cost buffer now holds this batch's costs: the next general-path solve of this size is ordered by them
         } else {
             if (a1mpc_status stg = launch_gen(h->cfg.horizon, a, s); stg != A1MPC_OK) return stg;
         }
@@ -1840,11 +1840,7 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     h->staged = split;
     a1mpc_status st = launch_mpc(h->cfg.horizon, a, h->d_prep, h->d_counter, s, split, h->ev_mid);
     if (st != A1MPC_OK) return st;
-    if (hints) {
-        hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, s, n, static_cast<const int32_t*>(h->d_cost), h->d_order);
-        A1_HIP(hipGetLastError());
-        h->hint_n = n;
-    }
+    if (hints) h->hint_n = n;   // the cost buffer now holds this batch's costs: the next solve of this size is ordered by them (sorted in front of its ADMM kernel)
     A1_HIP(hipEventRecord(h->ev1, s));
     h->timed = true;
     A1_MARK(h, s);

@@ -10,6 +10,7 @@ mkdir -p $O
 # the default bench (two batches in flight) and the same steps through one handle on one stream (--depth 1: launches serialised, per-kernel durations add up to a step)
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-latency --no-index-order > $O/bench_under_rocprof.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_depth1 --output-format csv -- python bench.py --depth 1 --steps 10 --warmup 2 --no-cpu-baseline --no-latency --no-index-order > $O/bench_depth1_under_rocprof.log 2>&1
+[ -n "$SKIP_PMC" ] && { find $O -name "*kernel_stats.csv" -exec head -6 {} \; ; exit 0; }   # kernels unchanged since the last PMC passes: traces only
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64"; do
   tag=$(echo $set | cut -d' ' -f1)
   timeout 150 rocprofv3 --pmc $set -d $O/pmc_$tag --output-format csv -- python tools/prof_target.py > /dev/null 2>&1
