@@ -69,6 +69,9 @@ for f in pmc_files.values():
             short = ("setup_kernel" if "setup" in k else "admm_kernel" if "admm" in k else "order_kernel" if "order" in k
                      else "solve_kernel(fused)" if "solve" in k else k.split("(")[0].split("::")[-1])
             acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if not pmc_files:
+    print("no PMC passes in", src, "-- profiles/%s_pmc_summary.json left as it is" % TAG)
+    sys.exit(0)
 summ = {k: {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in d.items()} for k, d in acc.items()}
 tot = sum(summ.get(k, {}).get(c, {}).get("mean_per_launch", 0.0) for k in summ for c in ("FETCH_SIZE", "WRITE_SIZE"))
 summ["_hbm_bytes_per_solve_batch_launch"] = tot * 1024.0
