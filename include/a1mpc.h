@@ -396,9 +396,9 @@ void a1mpc_sharded_destroy(a1mpc_sharded s);
  * pipeline owns `depth` complete engine handles (0 = the default, 2) on `depth` HIP streams and hands batches to them round-robin, so the
  * next batch's set-up kernel and persistent rows are dispatched onto the SIMDs the tail has left.  Batches in flight share nothing
  * (prepared-state records, queue, warm start are per slot): results are bit-identical to a lone handle's.  Measured on one MI355X, first
- * solves of distinct batches (profiles/r02_overlap_probe.json): 2048 x h10 3.4 -> 6.3 M solves/s (depth 3), 4096 x h10 4.8 -> 6.1 M,
- * 8192 x h16 1.92 -> 2.07 M, 8192 x h20 1.43 -> 1.61 M; batches of >= 16 384 QPs fill the chip on their own and lose 7 % when pipelined --
- * submit those through a plain handle.
+ * solves of distinct batches (profiles/r02_overlap_probe.json): 2048 x h10 3.4 -> 6.1 M solves/s (depth 3), 4096 x h10 4.8 -> 6.45 M,
+ * 8192 x h16 1.92 -> 2.08 M, 8192 x h20 1.45 -> 1.6 M; 16 384 x h10 neutral; a batch of 65 536 QPs fills the chip on its own and loses 7 %
+ * when pipelined -- submit those through a plain handle.
  *   submit   device pointers, layouts of a1mpc_solve_batch_device.  slot = -1: next slot round-robin (returned in *slot_out), or a fixed
  *            slot (a robot population that is warm-started must stay on its slot: the carried OSQP workspace lives there).
  *            fresh_batch != 0: these QPs are new to the slot, order its queue by the set-up kernel's cost guess instead of the slot's
