@@ -1700,7 +1700,8 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     A1_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), h->h_pin_bytes, hipHostMallocDefault));
     // One-time, per process: the first launches / copies through a fresh HIP runtime cost milliseconds (code-object load, pool set-up);
     // a 400 Hz loop should not pay that on its first tick (measured 5 ms -> 0.4 ms), so the tick's operation mix is exercised here.
-    static bool runtime_warmed = false;
+    static bool runtime_warmed_dev[64] = {};   // per device: a sharded handle (a1mpc_sharded_*) creates one engine handle on every GPU of the node
+    bool& runtime_warmed = runtime_warmed_dev[device < 64 ? device : 63];
     if (!runtime_warmed) {
         for (int i = 0; i < 256; ++i) {  // the operation mix of a tick: copies both ways from pinned memory, memset, launches, events
             A1_TRY(hipMemcpyAsync(h->d_x0, h->h_pin, 8, hipMemcpyHostToDevice, h->stream));
@@ -2450,9 +2451,8 @@ a1mpc_status a1mpc_pipeline_submit_device(a1mpc_pipeline p, int32_t slot, int32_
         A1_HIP(hipEventRecord(p->ready[k], static_cast<hipStream_t>(inputs_ready_stream)));
         A1_HIP(hipStreamWaitEvent(h->stream, p->ready[k], 0));
     }
-    if (fresh_batch) {           // QPs this slot has not seen before: queue ordered by the set-up kernel's cost guess, not by the slot's previous batch
-        if (a1mpc_status st = a1mpc_set_schedule(h, 1); st != A1MPC_OK) return st;
-    }
+    if (fresh_batch) h->hint_n = 0;   // QPs this slot has not seen before: queue ordered by the set-up kernel's cost guess, not by the costs of the slot's previous
+                                      // batch (what a1mpc_set_schedule does, without touching the handle's index-order / history setting)
     if (a1mpc_status st = solve_device_impl(h, n, nullptr, d_x0, d_x_ref, d_R_world, d_foot_abs, d_contact, d_grf_body_out, d_u_full_out, d_iters_out,
                                             d_status_out, h->stream); st != A1MPC_OK) return st;
     A1_HIP(hipEventRecord(p->done[k], h->stream));

@@ -364,9 +364,40 @@ static int adapt_rho(work_t *w) {
  * (store_solution: x = D x_s, y = cinv E y_s; NaN on infeasible status as OSQP does).
  * rho_io: optional in/out carried rho (settings->rho persists across OSQP solves).
  */
-int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
+/* auxil.c update_rho_vec: constraint types after a bound update; returns 1 when a type (and with it rho_vec) changed, i.e. when OSQP refactors */
+static int update_rho_vec(work_t *w) {
+    int changed = 0;
+    for (int i = 0; i < w->m; ++i) {
+        int t = (w->l[i] < -OSQP_INFTY * OSQP_MIN_SCALING && w->u[i] > OSQP_INFTY * OSQP_MIN_SCALING) ? -1 : (w->u[i] - w->l[i] < OSQP_RHO_TOL ? 1 : 0);
+        if (t != w->ctype[i]) {
+            w->ctype[i] = t;
+            w->rho_vec[i] = t == -1 ? OSQP_RHO_MIN : (t == 1 ? OSQP_RHO_EQ_OVER_RHO_INEQ * w->rho : w->rho);
+            w->rho_inv_vec[i] = 1.0 / w->rho_vec[i];
+            changed = 1;
+        }
+    }
+    return changed;
+}
+
+/*
+ * carry (optional): the persistent OSQP workspace of the reference's `OsqpEigen::Solver solver` member between ticks, for the UPDATE PATH the
+ * reference takes on every tick after the first (S/A1RobotControl.cpp:533-538: updateHessianMatrix, updateGradient, updateLowerBound,
+ * updateUpperBound, then solve() with warm start) -- restated from OSQP 0.6 (osqp.c osqp_update_P / osqp_update_lin_cost / osqp_update_lower_bound /
+ * osqp_update_upper_bound, auxil.c update_rho_vec), unpinned like the rest of the solve:
+ *   osqp_update_P        unscale_data, new P, scale_data AGAIN FROM D = E = c = 1 -- with the PREVIOUS tick's q, l, u still in the workspace (the gradient
+ *                        is only replaced by the next call), so the cost scaling c sees the old gradient --, refactor with the carried rho_vec
+ *   osqp_update_lin_cost q = c (D q_new)
+ *   osqp_update_*_bound  l = E l_new, then u = E u_new; after each, update_rho_vec: a constraint whose type changed gets its rho and the KKT matrix is refactored
+ *   osqp_solve           warm start: the SCALED iterates (x, z, y) of the previous solve are used as they are (they were scaled with the previous tick's D, E, c),
+ *                        rho = the previous solve's adapted value
+ * Layout: carry[0] = valid flag, [1] = rho, then x_s (n), z_s (m), y_s (m), q_prev (n), l_prev (m), u_prev (m): 2 + 2n + 4m doubles, zero-initialised by the caller.
+ * A first tick (valid = 0) is osqp_setup + a cold solve (the workspace's iterates are zero whatever warm_start says).
+ */
+static int osqp_solve_impl(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
                    const double *l, const double *u, const orc_settings *st, double *x, double *y, double *rho_io,
-                   orc_info *info) {
+                   orc_info *info, double *carry) {
+    const int upd = carry && carry[0] != 0.0;
+    double *c_xs = carry ? carry + 2 : 0, *c_zs = carry ? c_xs + n : 0, *c_ys = carry ? c_zs + m : 0, *c_q = carry ? c_ys + m : 0, *c_l = carry ? c_q + n : 0, *c_u = carry ? c_l + m : 0;
     work_t w; memset(&w, 0, sizeof w);
     int nnz = rp[m];
     size_t tot = (size_t)2 * n * n + 16 * (size_t)n + 16 * (size_t)m + nnz + 64 + (st->linsys == 1 ? (size_t)(n + m) * (n + m) + 2 * (size_t)(n + m) : 0);
@@ -389,6 +420,10 @@ int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t
     memcpy(w.l, l, sizeof(double) * m); memcpy(w.u, u, sizeof(double) * m);
     memset(info, 0, sizeof *info); info->status = ORC_UNSOLVED;
     w.rho = (rho_io && st->warm_start && *rho_io > 0) ? *rho_io : st->rho;
+    if (upd) {  /* osqp_update_P re-scales with the previous tick's q, l, u in the workspace; settings->rho is the previous solve's */
+        memcpy(w.q, c_q, sizeof(double) * n); memcpy(w.l, c_l, sizeof(double) * m); memcpy(w.u, c_u, sizeof(double) * m);
+        w.rho = carry[1];
+    } else if (carry) w.rho = st->rho;
 
     /* osqp_setup */
     if (st->scaling) scale_data(&w);
@@ -397,8 +432,16 @@ int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t
     int rc = factor(&w);
     if (rc) { info->status = ORC_NON_CVX; goto done; }
 
+    if (upd) {
+        for (int j = 0; j < n; ++j) w.q[j] = (w.D[j] * q[j]) * w.c;                 /* osqp_update_lin_cost: vec_ew_prod(D, q), vec_mult_scalar(q, c) */
+        for (int i = 0; i < m; ++i) w.l[i] = w.E[i] * l[i];                        /* osqp_update_lower_bound */
+        if (update_rho_vec(&w)) { rc = factor(&w); if (rc) { info->status = ORC_NON_CVX; goto done; } }
+        for (int i = 0; i < m; ++i) w.u[i] = w.E[i] * u[i];                        /* osqp_update_upper_bound */
+        if (update_rho_vec(&w)) { rc = factor(&w); if (rc) { info->status = ORC_NON_CVX; goto done; } }
+        memcpy(w.x, c_xs, sizeof(double) * n); memcpy(w.z, c_zs, sizeof(double) * m); memcpy(w.y, c_ys, sizeof(double) * m);
+    }
     /* cold / warm start */
-    if (st->warm_start) {
+    if (st->warm_start && !carry) {
         for (int j = 0; j < n; ++j) w.x[j] = w.Dinv[j] * x[j];
         csr_mv(m, rp, ci, w.av, w.x, w.z);
         for (int i = 0; i < m; ++i) w.y[i] = w.c * w.Einv[i] * y[i];
@@ -465,6 +508,13 @@ done:
     for (int j = 0; j < n; ++j) if (!isfinite(w.x[j])) { info->status = ORC_NON_CVX; break; }
     info->rho_final = w.rho;
     if (rho_io) *rho_io = w.rho;
+    if (carry) {  /* what stays in the reference's workspace for the next tick's update calls */
+        const int failed = info->status == ORC_PRIMAL_INFEASIBLE || info->status == ORC_DUAL_INFEASIBLE || info->status == ORC_NON_CVX;
+        carry[0] = 1.0; carry[1] = w.rho;
+        for (int j = 0; j < n; ++j) c_xs[j] = failed ? 0.0 : w.x[j];               /* store_solution: cold_start after a failed solve */
+        for (int i = 0; i < m; ++i) { c_zs[i] = failed ? 0.0 : w.z[i]; c_ys[i] = failed ? 0.0 : w.y[i]; }
+        memcpy(c_q, q, sizeof(double) * n); memcpy(c_l, l, sizeof(double) * m); memcpy(c_u, u, sizeof(double) * m);
+    }
     if (info->status == ORC_PRIMAL_INFEASIBLE || info->status == ORC_DUAL_INFEASIBLE || info->status == ORC_NON_CVX) {
         for (int j = 0; j < n; ++j) x[j] = NAN;
         for (int i = 0; i < m; ++i) y[i] = NAN;
@@ -474,6 +524,15 @@ done:
     }
     free(buf); free(ctype);
     return 0;
+}
+int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
+                   const double *l, const double *u, const orc_settings *st, double *x, double *y, double *rho_io,
+                   orc_info *info) {
+    return osqp_solve_impl(n, m, P, q, rp, ci, av, l, u, st, x, y, rho_io, info, 0);
+}
+int orc_osqp_solve_update(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
+                          const double *l, const double *u, const orc_settings *st, double *x, double *y, double *carry, orc_info *info) {
+    return osqp_solve_impl(n, m, P, q, rp, ci, av, l, u, st, x, y, 0, info, carry);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -640,6 +699,26 @@ int orc_mpc_solve(const orc_mpc_params *pr, const orc_settings *st, const double
         if (failed) { memset(warm_x, 0, sizeof(double) * n); memset(warm_y, 0, sizeof(double) * m); if (warm_rho) *warm_rho = 0; }
         else { memcpy(warm_x, x, sizeof(double) * n); memcpy(warm_y, y, sizeof(double) * m); }
     }
+    free(P); free(rp);
+    return rc;
+}
+
+/* One MPC tick on the reference's UPDATE PATH (see osqp_solve_impl): carry = 2 + 2n + 4m doubles, zero before the first tick of a robot. */
+int orc_mpc_solve_update(const orc_mpc_params *pr, const orc_settings *st, const double *x0, const double *xref, const double *Rw,
+                         const double *foot, const uint8_t *contact, double *grf_out, double *u_full, double *carry, orc_info *info) {
+    const int h = pr->horizon, n = NU * h, m = NC * h;
+    double *P = (double *)malloc(sizeof(double) * ((size_t)n * n + n + 2 * m + 36 * h + n + m));
+    double *g = P + (size_t)n * n, *l = g + n, *u = l + m, *av = u + m, *x = av + 36 * h, *y = x + n;
+    int32_t *rp = (int32_t *)malloc(sizeof(int32_t) * (m + 1 + 36 * h)), *ci = rp + m + 1;
+    orc_mpc_form(pr, x0, xref, x0[2], Rw, foot, 0, contact, 0, P, g, rp, ci, av, l, u);
+    memset(x, 0, sizeof(double) * n); memset(y, 0, sizeof(double) * m);
+    int rc = orc_osqp_solve_update(n, m, P, g, rp, ci, av, l, u, st, x, y, carry, info);
+    for (int leg = 0; leg < NLEG; ++leg) {
+        const double *f = x + 3 * leg;
+        int bad = isnan(f[0]) || isnan(f[1]) || isnan(f[2]);
+        for (int i = 0; i < 3; ++i) grf_out[3 * leg + i] = bad ? 0.0 : Rw[0 * 3 + i] * f[0] + Rw[1 * 3 + i] * f[1] + Rw[2 * 3 + i] * f[2];
+    }
+    if (u_full) memcpy(u_full, x, sizeof(double) * n);
     free(P); free(rp);
     return rc;
 }

@@ -169,6 +169,23 @@ def mpc_solve(pr, st, x0, xref, Rw, foot, contact, warm_x=None, warm_y=None, war
     return dict(grf=grf, u=u, info=info, warm_x=wx, warm_y=wy, rho=rho.value)
 
 
+def update_carry(horizon):
+    """zeroed workspace carry of mpc_solve_update for one robot (2 + 2n + 4m doubles)"""
+    return np.zeros(2 + 2 * NU * horizon + 4 * NC * horizon)
+
+
+def mpc_solve_update(pr, st, x0, xref, Rw, foot, contact, carry):
+    """one tick on the reference's UPDATE PATH (updateHessianMatrix / updateGradient / update*Bound on a persistent OSQP workspace,
+    S/A1RobotControl.cpp:533-538; see osqp_solve_impl in a1mpc_oracle.c).  `carry` is updated in place."""
+    h = pr.horizon
+    grf = np.zeros(12); u = np.zeros(NU * h); info = Info()
+    assert carry.dtype == np.float64 and carry.size == 2 + 2 * NU * h + 4 * NC * h and carry.flags.c_contiguous
+    lib().orc_mpc_solve_update(C.byref(pr), C.byref(st), _p(np.ascontiguousarray(x0, dtype=np.float64)), _p(np.ascontiguousarray(xref, dtype=np.float64)),
+                               _p(np.ascontiguousarray(Rw, dtype=np.float64)), _p(np.ascontiguousarray(foot, dtype=np.float64)),
+                               _p(np.ascontiguousarray(contact, dtype=np.uint8), C.c_uint8), _p(grf), _p(u), _p(carry), C.byref(info))
+    return dict(grf=grf, u=u, info=info)
+
+
 def mpc_reference(h, dt, euler, pos, Rw, euler_d, lin_vel_d_body, ang_vel_d, pos_z_d):
     xref = np.zeros(NS * h)
     a = lambda v: _p(np.ascontiguousarray(v, dtype=np.float64))

@@ -267,3 +267,46 @@ def test_two_linear_system_back_ends_agree(oracle, scen):
         a = oracle_batch(oracle, sc); b = oracle_batch(oracle, sc, settings=oracle.default_settings(linsys=1))
         assert (a["iters"] == b["iters"]).all() and (a["status"] == b["status"]).all() and (a["nfact"] == b["nfact"]).all()
         assert np.abs(a["u"] - b["u"]).max() <= 1e-5
+
+
+def test_update_path_restatement(oracle, scen):
+    """The reference's tick >= 2 path (updateHessianMatrix / updateGradient / update*Bound on the persistent OsqpEigen workspace,
+    S/A1RobotControl.cpp:533-538) restated from OSQP 0.6's update functions (osqp_solve_impl with a carry): mechanics only --
+    the first tick is the cold solve bit for bit; a tick that repeats the previous tick's QP re-derives the same scaling, starts at the previous
+    solution and stops at the first check with (nearly) the same forces; a contact switch changes constraint types and costs a
+    factorisation; a failed tick leaves a usable workspace behind; over a slowly moving trot the path stays within OSQP's own slack of the
+    "fresh set-up + osqp_warm_start" restatement the engine implements (tests/tools/update_path_probe.py has the 4000-tick figures)."""
+    seq = scen.config2_trot_sequence(130)
+    p = seq["params"]
+    pr = oracle.mpc_params(10, p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"], p["inertia"])
+    st = oracle.default_settings(warm_start=1)
+    args = lambda k: (seq["x0"][k], seq["xref"][k], seq["R"][k], seq["foot"][k], seq["contact"][k])
+    carry = oracle.update_carry(10)
+    a = oracle.mpc_solve_update(pr, st, *args(0), carry)
+    cold = oracle.mpc_solve(pr, oracle.default_settings(warm_start=0), *args(0))
+    assert np.array_equal(a["grf"], cold["grf"]) and a["info"].iters == cold["info"].iters and carry[0] == 1.0
+    b = oracle.mpc_solve_update(pr, st, *args(0), carry)          # the same QP again: same scaling, start = the previous solution
+    opt = oracle.mpc_solve(pr, oracle.exact_settings(), *args(0))["grf"]   # (a default-tolerance answer is N's away from the optimum: 25 more iterations move it closer)
+    assert b["info"].iters == 25 and b["info"].nfact == 1 and np.abs(b["grf"] - opt).max() < np.abs(a["grf"] - opt).max()
+    # contact switch at tick 60 (1001 -> 0110): eight rows change type, OSQP refactors once more inside updateUpperBound
+    for k in range(1, 60):
+        r = oracle.mpc_solve_update(pr, st, *args(k), carry)
+    assert r["info"].status in (1, 2)
+    sw = oracle.mpc_solve_update(pr, st, *args(60), carry)
+    assert sw["info"].nfact >= 2 and sw["info"].status in (1, 2) and np.abs(sw["grf"].reshape(4, 3)[[0, 3]]).max() < 0.5   # legs 0 and 3 now swing (to the solver's tolerance)
+    # a non-finite tick: zeros out, cold iterates left in the workspace, the next tick is solved
+    bad = seq["x0"][61].copy(); bad[3] = np.nan
+    nf = oracle.mpc_solve_update(pr, st, bad, *args(61)[1:], carry)
+    assert nf["info"].status == -7 and not nf["grf"].any() and not carry[2:2 + 120].any()
+    ok = oracle.mpc_solve_update(pr, st, *args(62), carry)
+    assert ok["info"].status in (1, 2) and np.isfinite(ok["grf"]).all()
+    # distance to the engine's semantics over a slowly moving state (same QP data tick by tick, two warm starts of it)
+    rng = np.random.default_rng(3)
+    x0 = seq["x0"][0].copy(); wx = np.zeros(120); wy = np.zeros(200); rho = 0.0; carry = oracle.update_carry(10); d = []; same = 0
+    for k in range(120):
+        x0[:12] += rng.normal(0, 5e-4, 12)
+        fresh = oracle.mpc_solve(pr, st, x0, seq["xref"][0], seq["R"][0], seq["foot"][0], seq["contact"][0], warm_x=wx, warm_y=wy, warm_rho=rho)
+        wx, wy, rho = fresh["warm_x"], fresh["warm_y"], fresh["rho"]
+        upd = oracle.mpc_solve_update(pr, st, x0, seq["xref"][0], seq["R"][0], seq["foot"][0], seq["contact"][0], carry)
+        d.append(np.abs(fresh["grf"] - upd["grf"]).max()); same += fresh["info"].iters == upd["info"].iters
+    assert d[0] == 0.0 and np.median(d) < 1.0 and max(d) < 20.0 and same >= 100, (np.median(d), max(d), same)
