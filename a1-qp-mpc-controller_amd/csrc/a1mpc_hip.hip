@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include <a1mpc_rowops.hpp>
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a
     RowSolver<H, kModeMpc, false, false, true> S(a.P, a.tab, a1mpc_lds);
     S.load_prepared(a1mpc_lds + Layout<H>::FAC, make_io<H, kModeMpc>(a, b));
     S.solve();
-    S.write_outputs(make_io<H, kModeMpc>(a, b));
+    S.write_outputs(make_io<H, kModeMpc>(a, b), carry_of<H>(a, b));
 }
 
 // ---- split pipeline (large batches) -----------------------------------------------------------------------------
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a
 // Until the Ruiz sweep became a short column loop (RowSolver::setup) a second wave per SIMD (256 registers each, 35-137 doubles per lane spilled) paid off
 // for multi-round batches at H = 10 / 16; with the column loop it loses everywhere (65 536 x h10: 1.27 vs 1.16 ms, 32 768 x h16: 2.12 vs 1.25 ms,
 // 16 384 x h20: 2.14 vs 0.75 ms; profiles/r02_setup_waves_probe.txt) and is no longer built.
-template <int H, int WAVES>
+template <int H, int WAVES, bool UPD = false>   // UPD: the instantiation that also serves warm_start = 2 (see a1mpc_admm_kernel)
 __global__ __launch_bounds__(64, WAVES) void a1mpc_setup_kernel(const KernelArgs a, double* __restrict__ prep) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     const int row = static_cast<int>(threadIdx.x) >> 4;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(64, WAVES) void a1mpc_setup_kernel(const KernelArgs
     for (int i = static_cast<int>(threadIdx.x); i < 2 * H * H; i += 64) tabl[i] = a.tab[i];
     __syncthreads();
     if (b >= a.n) return;
-    setup_row<H>(a, tabl, b, a1mpc_lds + row * LayoutSetup<H>::ROW_STRIDE, prep);
+    setup_row<H, false, UPD>(a, tabl, b, a1mpc_lds + row * LayoutSetup<H>::ROW_STRIDE, prep);
 }
 // K2: persistent rows; grid = resident workgroups; every row drains the queue of prepared QPs.
 #ifdef A1X_NOTWIN
@@ -107,7 +108,9 @@ constexpr bool admm_twin_rows(int, int) { return false; }
 #else
 constexpr bool admm_twin_rows(int h, int rows) { return twin_rows(h, kModeMpc, rows); }
 #endif  // the wavefront's spare rows run as twins (RowSolver<.., TWIN>)
-template <int H, int ROWS>
+// UPD: the instantiation that also serves warm_start = 2 (the reference's update path); every other mode runs UPD = false, whose code is what it was before
+// the update path existed (the allocation of the hot loop is sensitive to anything around it: a1mpc_solver.hpp, load_prepared)
+template <int H, int ROWS, bool UPD = false>
 __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     // ROWS <= 2: the wavefront's other rows run as twins of the QP rows (rows r and r + 2 share a QP and its LDS image, see row_is_twin)
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, cons
     const int row = static_cast<int>(threadIdx.x) >> 4;
     if constexpr (kTwin) {
         if ((row & 1) >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
-        admm_rows<H, true>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H>::ROW_STRIDE);
+        admm_rows<H, true, false, UPD>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H>::ROW_STRIDE);
     } else {
-        admm_rows<H, false>(a, prep, counter, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+        admm_rows<H, false, false, UPD>(a, prep, counter, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
     }
 }
 
@@ -367,6 +370,16 @@ static a1mpc_status resident_workgroups(int* out) {
     *out = resident[dev];
     return A1MPC_OK;
 }
+// dynamic-LDS limit of a kernel, once per device and kernel
+static a1mpc_status set_lds_attr(const void* fn, size_t bytes) {
+    static std::vector<std::pair<const void*, int>> done;
+    int dev = 0;
+    A1_HIP(hipGetDevice(&dev));
+    for (const auto& d : done) if (d.first == fn && d.second == dev) return A1MPC_OK;
+    A1_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+    done.emplace_back(fn, dev);
+    return A1MPC_OK;
+}
 template <int H>
 static a1mpc_status resident_rows(int* out) {
     int wg = 0;
@@ -389,7 +402,8 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     int res = 0;
     if (a1mpc_status st = resident_workgroups<H, ROWS>(&res); st != A1MPC_OK) return st;
     A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
-    hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
+    if (H > 1 && a.carry != nullptr) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1, true>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
+    else hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
     A1_HIP(hipGetLastError());
     // queue order of THIS solve, longest first: by the set-up kernel's cost guesses (predict: no history) or by the cost each QP had in the handle's previous
     // solve of this batch size (the cost buffer still holds it; the ADMM kernel below overwrites it with this solve's).  Sorted here, in front of the kernel
@@ -402,8 +416,13 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     }
     if (mid) A1_HIP(hipEventRecord(mid, stream));  // stage split: formation + Ruiz (+ queue order) | factor + iterate
     const int want = (a.n + ROWS - 1) / ROWS;
-    hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), dim3(static_cast<unsigned>(want < res ? want : res)), dim3(admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS), lds2, stream, a,
-                       static_cast<const double*>(prep), counter);
+    const dim3 grid(static_cast<unsigned>(want < res ? want : res)), block(admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS);
+    if (H > 1 && a.carry != nullptr) {  // warm_start = 2: the update-path instantiation (same resources: it differs in a few instructions around the first iteration)
+        if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, true>), lds2); st != A1MPC_OK) return st;
+        hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
+    } else {
+        hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
+    }
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
 }
@@ -418,6 +437,14 @@ static a1mpc_status launch_split(const KernelArgs& a, double* prep, int* counter
     }
     return launch_split_rows<H, 4>(a, prep, counter, stream, mid);
 #endif
+}
+static size_t carry_stride(int horizon) {
+    switch (horizon) {
+        case 10: return Carry<10>::STRIDE;
+        case 16: return Carry<16>::STRIDE;
+        case 20: return Carry<20>::STRIDE;
+    }
+    return 0;  // (horizon 1: the update path does not apply -- warm_start = 2 behaves like 1)
 }
 static size_t prep_stride(int horizon) {
     switch (horizon) {
@@ -668,6 +695,7 @@ struct a1mpc_handle_s {
     // Every launch touches handle-owned scratch (prepared-state records, queue counter / order / cost, nfact, the carried OSQP workspace,
     // the filter states): a call on another stream than the previous call's first waits for that call's work (ev_order, recorded after
     // every launch); the reset functions wait for it on the host.
+    double* d_carry = nullptr;     // warm_start = 2 (the reference's update path): n x Carry<H>::STRIDE, allocated on first use
     hipEvent_t ev_order = nullptr;
     hipEvent_t ev_mid = nullptr;   // between the set-up kernel and the persistent ADMM kernel of the split pipeline (a1mpc_last_stage_ms)
     bool staged = false;
@@ -1618,7 +1646,7 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_tab, h->d_tab1, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_aux, h->d_Rz, h->d_contact, h->d_grf,
-                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_ekf_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8, h->d_foot_steps, h->d_contact_steps, h->d_prep_gen};
+                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_ekf_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8, h->d_foot_steps, h->d_contact_steps, h->d_prep_gen, h->d_carry};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -1743,6 +1771,8 @@ a1mpc_status a1mpc_warm_start(a1mpc_handle h, int32_t n, const double* x, const 
     if (x) A1_HIP(hipMemcpyAsync(h->d_wx, x, N * 12 * H * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (y) A1_HIP(hipMemcpyAsync(h->d_wy, y, N * 20 * H * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (rho) A1_HIP(hipMemcpyAsync(h->d_rho, rho, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // warm_start = 2: an injected (x, y, rho) is not what the update path left behind -- the next tick of these problems is a fresh set-up warm-started from it
+    if (h->d_carry) A1_HIP(hipMemsetAsync(h->d_carry, 0, N * carry_stride(h->cfg.horizon) * sizeof(double), h->stream));
     A1_HIP(hipStreamSynchronize(h->stream));
     return A1MPC_OK;
 }
@@ -1769,6 +1799,7 @@ a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h) {
     A1_HIP(hipMemsetAsync(h->d_wx, 0, n * 12 * H * sizeof(double), h->stream));
     A1_HIP(hipMemsetAsync(h->d_wy, 0, n * 20 * H * sizeof(double), h->stream));
     A1_HIP(hipMemsetAsync(h->d_rho, 0, n * sizeof(double), h->stream));
+    if (h->d_carry) A1_HIP(hipMemsetAsync(h->d_carry, 0, n * carry_stride(h->cfg.horizon) * sizeof(double), h->stream));
     A1_HIP(hipStreamSynchronize(h->stream));
     h->hint_n = 0;
     return A1MPC_OK;
@@ -1799,6 +1830,14 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     a.tick = d_tick; a.x0 = d_x0; a.xref = d_x_ref; a.R = d_R_world; a.foot = d_foot_abs; a.contact = d_contact;
     a.grf = d_grf_body_out; a.u_full = d_u_full_out; a.iters = d_iters_out; a.status = d_status_out; a.nfact = h->d_nfact;
     if (h->cfg.warm_start) { a.warm_x = h->d_wx; a.warm_y = h->d_wy; a.rho = h->d_rho; }
+    if (h->cfg.warm_start == 2 && carry_stride(h->cfg.horizon) != 0) {   // the reference's update path on ticks >= 2 (a1mpc.h): what its persistent OSQP workspace carries
+        if (!h->d_carry) {
+            const size_t bytes = static_cast<size_t>(h->max_batch) * carry_stride(h->cfg.horizon) * sizeof(double);
+            A1_HIP(hipMalloc(&h->d_carry, bytes));
+            A1_HIP(hipMemsetAsync(h->d_carry, 0, bytes, s));
+        }
+        a.carry = h->d_carry;
+    }
     a.contact_stride = contact_stride;  // a per-step contact schedule alone (feet step-invariant) stays on the fast path: contacts only change bounds and equality rows
     if (foot_stride != 0 || d_yaw_A != nullptr) {  // general path: per-step B_d (and / or its own A_c yaw), with or without a contact schedule
         if (d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "per-step feet / contacts are not combined with tick records");

@@ -85,6 +85,7 @@ struct ProblemIO {
     int32_t* iters;          // out or null
     int32_t* status;         // out or null
     int32_t* nfact;          // out or null
+    double* carry;           // Carry<H>::STRIDE in/out or null: what the reference's persistent OSQP workspace still holds of the previous tick (warm_start = 2, the UPDATE path)
 };
 
 // ---- compile-time helpers ----------------------------------------------------------------------
@@ -213,6 +214,17 @@ struct LayoutSetup {
     static constexpr int ROW_STRIDE = RAW + (RAW % 2);
 };
 
+// warm_start = 2 -- the reference's UPDATE path on ticks >= 2 (S/A1RobotControl.cpp:533-538: updateHessianMatrix / updateGradient / update*Bound on the persistent
+// OsqpEigen workspace, then solve() with warm start).  OSQP 0.6 then (osqp_update_P) re-equilibrates from D = E = c = 1 with the PREVIOUS tick's gradient still in
+// the workspace, (osqp_update_lin_cost / _bounds) scales the new q, l, u with the new D, E, c, and (osqp_solve, warm) starts from the previous solve's SCALED iterates
+// as they are.  Per problem the engine therefore carries, next to the unscaled (x, y, rho) of warm_start = 1: the previous scalings, the previous unscaled gradient
+// and the previous unscaled z = Pi(w).  Per-lane fields are [t][12 lanes] like the hand-off record; C = 0 marks "no previous tick".
+template <int H>
+struct Carry {
+    static constexpr int C = 0, D = 1, E0 = D + 12 * H, E1 = E0 + 12 * H, G = E1 + 12 * H, Z0 = G + 12 * H, Z1 = Z0 + 12 * H;
+    static constexpr int STRIDE = Z1 + 12 * H + 1;  // (even)
+};
+
 // prepared state handed from the set-up kernel to the ADMM kernel: [field][12 active lanes] doubles per QP (pad lanes hold nothing).
 // XH (the warm-start x) comes last and is only written / read when the solve is warm-started.
 template <int H>
@@ -220,7 +232,9 @@ struct Prep {
     static constexpr int RR0 = 0, RR1 = H, DI2 = 2 * H, CG = 3 * H, BT = 4 * H;  // per-lane fields
     static constexpr int CSC = BT + 6, CY = CSC + 1, SY = CY + 1, RHO = SY + 1, CM = RHO + 1, HI = CM + 1, EQ = HI + 1, FLAGS = EQ + 1;  // CM: contact bit of my leg per step (HI: spare)
     static constexpr int XH = FLAGS + 1;
-    static constexpr int FIELDS = XH + H;
+    // update path only (FLAGS bit 2; H > 1): the first iteration's y-hat of my two rows and its c g - A'[(2 - alpha) rr delta] (RowSolver::setup, "update path")
+    static constexpr int YW0 = XH + H, YW1 = YW0 + H, CGE = YW1 + H;
+    static constexpr int FIELDS = XH + H + (H > 1 ? 3 * H : 0);
     static constexpr int STRIDE = FIELDS * 12;  // doubles per QP: 5.2 KB cold / 6.1 KB warm at H = 10
     // general path, split pipeline: + my column of the omega rows of B~_t for every step, [t][3] (the record of a QP is then STRIDE_GEN doubles)
     static constexpr int BWF = FIELDS;
@@ -282,6 +296,8 @@ struct RowSolver {
     double xh[HS], wh0[HS], wh1[HS], rr0[HS], rr1[HS], dI2[HS];
     double rho;
     bool warm, first_special;
+    bool upd;         // warm_start = 2 and a previous tick in the carry: this solve follows the reference's update path
+    double epsv[HS];  // set-up, update path: A'[(2 - alpha) rr delta] of my lane (the first iteration's correction of c g)
     int coop_id = 0, coop_n = 1;  // set-up only: row coop_id of coop_n rows of the wave that work on the SAME QP (batch-1 latency path), sharing its LDS image
     bool careful;  // rho is small: c P x + c g is carried through the x-update identity (G in LDS) instead of re-evaluated at the checkpoints
     // bookkeeping
@@ -315,7 +331,7 @@ struct RowSolver {
         r2a = act ? P.r2[ci] : 0.0;      // force-lane weight 2 r_a
         r0 = comp == 0 ? 0 : (comp == 1 ? 2 : 4); r1 = comp == 0 ? 1 : 3;
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false;
-        warm = false; first_special = false; eqmask = 0; careful = false;
+        warm = false; first_special = false; eqmask = 0; careful = false; upd = false;
     }
 
     // orders LDS traffic between the lanes that work on this QP: my row, or both rows of a twin pair
@@ -391,6 +407,9 @@ struct RowSolver {
     }
 
     // ================================================================================ set-up: formation + Ruiz + hot state
+    // UPD = false: an instantiation without the update path (warm_start = 2 never reaches it) -- the split pipeline's set-up kernel of every other mode keeps the
+    // code it had before the update path existed (with it in: +9 % on that kernel, measured)
+    template <bool UPD = true>
     A1_DEV void setup(const ProblemIO& io) {
         double Rm[9];
 #pragma unroll
@@ -585,6 +604,11 @@ struct RowSolver {
         }
 
         // ---------------------------------------------------------------- Ruiz equilibration (osqp scaling.c scale_data)
+        // update path (warm_start = 2, a previous tick in the carry): osqp_update_P re-equilibrates while the workspace still holds the PREVIOUS tick's
+        // gradient -- the only place the gradient enters scale_data is the cost normalisation below
+        using CR = Carry<H>;
+        upd = false;
+        if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) upd = P.warm_start == 2 && io.carry != nullptr && io.warm_x != nullptr && io.warm_y != nullptr && io.carry[CR::C] > 0.0;
         double D[H], E0[H], E1[H];
         csc = 1.0;
 #pragma unroll
@@ -735,7 +759,8 @@ struct RowSolver {
 #pragma unroll
                 for (int t = 0; t < H; ++t) {
                     sum += csc * D[t] * m[t];
-                    nq = fmax(nq, fabs(csc * D[t] * g[t]));
+                    if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) nq = fmax(nq, fabs(csc * D[t] * ((upd && act) ? io.carry[CR::G + t * 12 + ci] : (upd ? 0.0 : g[t]))));
+                    else nq = fmax(nq, fabs(csc * D[t] * g[t]));
                 }
                 const double mean = row_allsum(sum) / double(12 * H);
                 nq = limit_scaling(row_allmax(nq));
@@ -784,8 +809,51 @@ struct RowSolver {
             xh[t] = (warm && act) ? io.warm_x[t * 12 + ci] : 0.0;  // x_s = D^-1 x  <=>  xh = x
             park_warm_y(io, t);
             if (act) lds[L::CG + t * 12 + ci] = csc * g[t];          // D^-1 q_s = c g
+            if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) {
+                if (upd) {
+                    // The carried SCALED iterates (x_s, z_s, y_s) are used as they are, i.e. read in the NEW scaling:  x0 = D (x / D'), z0 = (E' / E) z,
+                    // y0 = (c' / c)(E / E') y  with the previous scalings D', E', c' and the previous unscaled x, z, y.  OSQP's first iteration uses z0 twice:
+                    // E (rho z0 - y0) in the right-hand side and (1 - alpha) z0 + y0 / rho in the w update.  The kernels compute z0 = A x0 in both places
+                    // (osqp_warm_start semantics); with delta = z0 - A x0 both are reproduced exactly by parking  y^ = y0 + (1 - alpha) rr delta / c  in the w
+                    // registers and by handing the first iteration  c g - A'[(2 - alpha) rr delta]  in the slot of c g (admm_iteration<FIRST> is not touched;
+                    // the true c g comes back after iteration 1, see load_prepared / advance).
+                    const double* cr = io.carry;
+                    const double cp = cr[CR::C];
+                    const double Dp = act ? cr[CR::D + t * 12 + ci] : 1.0, E0p = act ? cr[CR::E0 + t * 12 + ci] : 1.0, E1p = (act && comp < 2) ? cr[CR::E1 + t * 12 + ci] : 1.0;
+                    const double zp0 = act ? cr[CR::Z0 + t * 12 + ci] : 0.0, zp1 = (act && comp < 2) ? cr[CR::Z1 + t * 12 + ci] : 0.0;
+                    xh[t] = act ? D[t] * (xh[t] / Dp) : 0.0;
+                    const double cr_c = cp / csc;
+                    const double y0 = act ? cr_c * (E0[t] / E0p) * wh0[t] : 0.0, y1 = (act && comp < 2) ? cr_c * (E1[t] / E1p) * wh1[t] : 0.0;
+                    const double zc0 = act ? (E0p / E0[t]) * zp0 : 0.0, zc1 = (act && comp < 2) ? (E1p / E1[t]) * zp1 : 0.0;
+                    const double xz = quad_perm<2, 2, 2, 2>(xh[t]);
+                    const double z00 = comp == 2 ? xh[t] : fma(mu, xz, xh[t]), z01 = fma(-mu, xz, xh[t]);
+                    const double d0 = act ? zc0 - z00 : 0.0, d1 = (act && comp < 2) ? zc1 - z01 : 0.0;
+                    const double oma = 1.0 - P.alpha;
+                    wh0[t] = y0 + oma * rr0[t] * d0 / csc;
+                    wh1[t] = y1 + oma * rr1[t] * d1 / csc;
+                    const double s0 = (1.0 + oma) * rr0[t] * d0, s1 = (1.0 + oma) * rr1[t] * d1;
+                    const double sm = s0 - s1;
+                    const double smx = quad_perm<0, 0, 0, 0>(sm), smy = quad_perm<1, 1, 1, 1>(sm);
+                    epsv[t] = fma(comp == 2 ? mu : 0.0, smx + smy, s0 + s1);
+                }
+            }
         });
         set_sync();
+        if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) {
+            // what the next tick's update calls will find in the workspace: this tick's scalings and unscaled gradient (z follows in write_outputs).
+            // Every row that shares this set-up holds the same values; the reads of the previous tick's fields above are complete (set_sync)
+            if (P.warm_start == 2 && io.carry != nullptr && coop_id == 0) {
+                double* cw = io.carry;
+                if (act) {
+                    static_for<H>([&](auto T) {
+                        constexpr int t = A1_CV(T);
+                        cw[CR::D + t * 12 + ci] = D[t]; cw[CR::E0 + t * 12 + ci] = E0[t]; cw[CR::G + t * 12 + ci] = g[t];
+                        if (comp < 2) cw[CR::E1 + t * 12 + ci] = E1[t];
+                    });
+                }
+                if (ln == 0) cw[CR::C] = csc;
+            }
+        }
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false; careful = false;
     }
 
@@ -815,6 +883,7 @@ struct RowSolver {
     }
 
     // ================================================================================ hand-off between the two kernels
+    template <bool UPD = true>
     A1_DEV void save_prepared(double* __restrict__ p) const {  // p: this QP's Prep<H>::STRIDE doubles
         if (!act) return;
         static_for<H>([&](auto T) {
@@ -824,13 +893,20 @@ struct RowSolver {
             p[(PR::DI2 + t) * 12 + ci] = dI2[t];
             p[(PR::CG + t) * 12 + ci] = lds[L::CG + t * 12 + ci];
             if (warm) p[(PR::XH + t) * 12 + ci] = xh[t];
+            if constexpr (UPD && H > 1 && !TWIN) {
+                if (upd) {  // update path: y^ of my two rows and the first iteration's c g (see setup)
+                    p[(PR::YW0 + t) * 12 + ci] = wh0[t]; p[(PR::YW1 + t) * 12 + ci] = wh1[t];
+                    p[(PR::CGE + t) * 12 + ci] = lds[L::CG + t * 12 + ci] - epsv[t];
+                }
+            }
         });
 #pragma unroll
         for (int k = 0; k < 6; ++k) p[(PR::BT + k) * 12 + ci] = Bt[k];
         p[PR::CSC * 12 + ci] = csc; p[PR::CY * 12 + ci] = cy; p[PR::SY * 12 + ci] = sy; p[PR::RHO * 12 + ci] = rho;
         p[PR::CM * 12 + ci] = static_cast<double>(cmask); p[PR::HI * 12 + ci] = 0.0;
         p[PR::EQ * 12 + ci] = static_cast<double>(eqmask);
-        p[PR::FLAGS * 12 + ci] = (warm ? 1.0 : 0.0) + (first_special ? 2.0 : 0.0);
+        if constexpr (UPD) p[PR::FLAGS * 12 + ci] = (warm ? 1.0 : 0.0) + (first_special ? 2.0 : 0.0) + (upd ? 4.0 : 0.0);
+        else p[PR::FLAGS * 12 + ci] = (warm ? 1.0 : 0.0) + (first_special ? 2.0 : 0.0);
         if constexpr (GEN && SETUP_ONLY) {  // the general path's own set-up kernel: the per-step omega rows of B~_t travel with the record
             static_for<H>([&](auto T) {
 #pragma unroll
@@ -840,11 +916,16 @@ struct RowSolver {
     }
     // tables (GEN): the record comes from the general path's set-up kernel -- B~w_t and the per-step bounds are rebuilt in this LDS image (in the fused
     // kernel they are still where the set-up wrote them)
+    // UPD = false: an instantiation without the update path's hand-off (warm_start = 2 never reaches it): the persistent ADMM kernel of every other mode keeps
+    // the code -- and with it the register allocation of its hot loop -- it had before the update path existed (with it: 4 more AGPR moves per iteration, +1 %)
+    template <bool UPD = true>
     A1_DEV void load_prepared(const double* __restrict__ p, const ProblemIO& io, [[maybe_unused]] bool tables = false) {
         sync();  // the previous QP's LDS image is dead
         const double am = act ? 1.0 : 0.0;  // pad lanes read lane 0's record (ci == 0) and zero what must be zero
         const int fl = static_cast<int>(p[PR::FLAGS * 12 + ci]);
         warm = fl & 1; first_special = (fl & 2) != 0;
+        [[maybe_unused]] const bool upd_ = UPD && (fl & 4) != 0;
+        [[maybe_unused]] double cgk[HS];  // update path: the true c g of my steps, parked in the pad column of K_t until the first iteration is done
         if constexpr (TWIN) {
             const int to = tw * 12;  // my step of slot k is 2k + tw: one record row further on the twin
             static_for<HS>([&](auto K) {
@@ -856,7 +937,16 @@ struct RowSolver {
                 const int t = 2 * k + tw;
                 wh0[k] = (warm && act) ? io.warm_y[t * 20 + 5 * quad + r0] : 0.0;  // park_warm_y()
                 wh1[k] = (warm && act && comp < 2) ? io.warm_y[t * 20 + 5 * quad + r1] : 0.0;
-                if (act) lds[L::CG + 2 * k * 12 + ci + to] = p[(PR::CG + 2 * k) * 12 + ci + to];
+                if constexpr (UPD && H > 1) {
+                    cgk[k] = p[(PR::CG + 2 * k) * 12 + ci + to];
+                    if (upd_) {  // update path: y^ and the first iteration's c g come from the set-up (see setup)
+                        wh0[k] = am * p[(PR::YW0 + 2 * k) * 12 + ci + to]; wh1[k] = am * p[(PR::YW1 + 2 * k) * 12 + ci + to];
+                        if (act) lds[L::CG + 2 * k * 12 + ci + to] = p[(PR::CGE + 2 * k) * 12 + ci + to];
+                    }
+                    if (act && !upd_) lds[L::CG + 2 * k * 12 + ci + to] = cgk[k];
+                } else {
+                    if (act) lds[L::CG + 2 * k * 12 + ci + to] = p[(PR::CG + 2 * k) * 12 + ci + to];
+                }
             });
         } else {
             static_for<H>([&](auto T) {
@@ -866,7 +956,16 @@ struct RowSolver {
                 dI2[t] = p[(PR::DI2 + t) * 12 + ci];
                 xh[t] = warm ? am * p[(PR::XH + t) * 12 + ci] : 0.0;
                 park_warm_y(io, t);
-                if (act) lds[L::CG + t * 12 + ci] = p[(PR::CG + t) * 12 + ci];
+                if constexpr (UPD && H > 1) {
+                    cgk[t] = p[(PR::CG + t) * 12 + ci];
+                    if (upd_) {
+                        wh0[t] = am * p[(PR::YW0 + t) * 12 + ci]; wh1[t] = am * p[(PR::YW1 + t) * 12 + ci];
+                        if (act) lds[L::CG + t * 12 + ci] = p[(PR::CGE + t) * 12 + ci];
+                    }
+                    if (act && !upd_) lds[L::CG + t * 12 + ci] = cgk[t];
+                } else {
+                    if (act) lds[L::CG + t * 12 + ci] = p[(PR::CG + t) * 12 + ci];
+                }
             });
         }
 #pragma unroll
@@ -897,10 +996,32 @@ struct RowSolver {
             }
         }
         sync();
+        if constexpr (UPD && H > 1 && !GEN) {
+            if (first_special) {  // the true c g waits in the pad column of K_t until iteration 1 is done (restore_cg; the update path's first iteration runs on a corrected one).
+                                  // After the sync: in the fused kernels the record is staged in the factor region, which holds the pad columns
+                if (act) {
+#pragma unroll
+                    for (int k = 0; k < HS; ++k) lds[L::FAC + (TWIN ? 2 * k + tw : k) * L::SLOT + ci * L::KSTR + L::GCOL] = cgk[k];
+                }
+                sync();
+            }
+        }
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false; careful = false;
 #ifdef A1X_CLK
         clkB = clkF = clkT = clkU = clkX = 0;
 #endif
+    }
+    // update path: iteration 1 is done -- the true c g (parked in the pad column of K_t by load_prepared) replaces the first iteration's corrected one
+    A1_DEV void restore_cg() {
+        sync();
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < HS; ++k) {
+                const int t = TWIN ? 2 * k + tw : k;
+                lds[L::CG + t * 12 + ci] = lds[L::FAC + t * L::SLOT + ci * L::KSTR + L::GCOL];
+            }
+        }
+        sync();
     }
 
     // ================================================================================ Riccati factorisation of
@@ -1503,6 +1624,7 @@ struct RowSolver {
     // (re-)factorise if needed, iterate up to the next checkpoint (a multiple of check_termination / adaptive_rho_interval, or
     // max_iter), then the residual check and the rho update.  Everything that can differ between the rows of a wave
     // (termination, rho update) happens at segment boundaries, so rows that run advance() in lock-step stay aligned.
+    template <bool UPD = true>
     A1_DEV void advance() {
 #ifdef A1X_CLK
         const long long tf_ = clock64();
@@ -1515,7 +1637,10 @@ struct RowSolver {
             int next = P.max_iter;
             if (P.check_every > 0) next = imin(next, (iter / P.check_every + 1) * P.check_every);
             if (P.adaptive_rho && P.adaptive_rho_every > 0) next = imin(next, (iter / P.adaptive_rho_every + 1) * P.adaptive_rho_every);
-            if (iter == 0 && first_special) { admm_iteration<true>(); iter = 1; }
+            if (iter == 0 && first_special) {
+                admm_iteration<true>(); iter = 1;
+                if constexpr (UPD && H > 1 && !GEN && !SETUP_ONLY && MODE == kModeMpc) restore_cg();  // (unconditional in the UPD instantiations: a flag would have to live across the ADMM loop)
+            }
             // the rows of a wave share one instruction stream: if any of them carries G, all run that variant (a harmless extra for the others)
 #ifdef A1X_CLK
             const long long t0_ = clock64();
@@ -1577,7 +1702,8 @@ struct RowSolver {
     }
 
     // ================================================================================ store_solution + first-step GRFs in the body frame
-    A1_DEV void write_outputs(const ProblemIO& io) const {
+    // carry (update path, warm_start = 2): this QP's Carry<H> record, or null -- the unscaled z = Pi(w) of the solve goes there
+    A1_DEV void write_outputs(const ProblemIO& io, double* __restrict__ carry = nullptr) const {
         // a non-finite solution (NaN / Inf inputs) is reported as NON_CVX whatever the residual tests concluded: max-norms
         // skip NaNs, so OSQP's own termination test can "converge" on a NaN iterate
         double nf = 0.0;
@@ -1609,6 +1735,12 @@ struct RowSolver {
                     const double z0 = fmin(fmax(wh0[k], lbs<k>(t)), ubs<k>(t)), z1 = fmin(wh1[k], 0.0);
                     io.warm_y[t * 20 + 5 * quad + r0] = nanout ? 0.0 : cinv * rr0[k] * (wh0[k] - z0);
                     if (comp < 2) io.warm_y[t * 20 + 5 * quad + r1] = nanout ? 0.0 : cinv * rr1[k] * (wh1[k] - z1);
+                    if constexpr (H > 1 && MODE == kModeMpc && !GEN) {
+                        if (carry) {  // z_s / E = Pi(w / E): what OSQP leaves in work->z (zeros after a failed solve: cold_start)
+                            carry[Carry<H>::Z0 + t * 12 + ci] = nanout ? 0.0 : z0;
+                            if (comp < 2) carry[Carry<H>::Z1 + t * 12 + ci] = nanout ? 0.0 : z1;
+                        }
+                    }
                 }
             }
         });
@@ -1642,6 +1774,7 @@ struct BatchArgs {
     const int32_t* order;
     int32_t* cost;
     int32_t predict;  // the set-up kernel writes its cost guess to `cost` (first solve of a batch: no history to order the queue by)
+    double* carry;    // warm_start = 2 (update path): n x Carry<H>::STRIDE, or null
 };
 template <int H, int MODE>
 A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
@@ -1663,8 +1796,11 @@ A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
     io.iters = a.iters ? a.iters + b : nullptr;
     io.status = a.status ? a.status + b : nullptr;
     io.nfact = a.nfact ? a.nfact + b : nullptr;
+    io.carry = nullptr;  // (set by make_io_sched for the set-ups; the ADMM side gets the pointer where it writes, see carry_of)
     return io;
 }
+template <int H>
+A1_DEV double* carry_of(const BatchArgs& a, int64_t b) { return a.carry ? a.carry + b * Carry<H>::STRIDE : nullptr; }
 
 // The fast path with a per-step contact schedule (contact_stride = 4; feet step-invariant): contacts only change the bounds and which rows are
 // equalities, so every kernel of the fast path takes them -- the set-ups read the schedule, the hand-off record carries the contact bits.
@@ -1673,6 +1809,7 @@ A1_DEV ProblemIO make_io_sched(const BatchArgs& a, int64_t b) {
     ProblemIO io = make_io<H, MODE>(a, b);
     io.contact = a.contact + b * (a.contact_stride ? 4 * H : 4);
     io.foot_stride = 0; io.contact_stride = a.contact_stride; io.yaw_A = nullptr;
+    io.carry = carry_of<H>(a, b);
     return io;
 }
 
@@ -1689,15 +1826,15 @@ A1_DEV ProblemIO make_io_gen(const BatchArgs& a, int64_t b) {
 }
 
 // split pipeline, kernel 1: formation + Ruiz for QP b, prepared state to global memory
-template <int H, bool GEN = false>
+template <int H, bool GEN = false, bool UPD = false>
 A1_DEV void setup_row(const BatchArgs& a, const double* __restrict__ tab, int64_t b, double* __restrict__ lds, double* __restrict__ prep) {
     RowSolver<H, kModeMpc, true, GEN> S(a.P, tab, lds);  // tab: the (alpha/beta, beta) table, staged in LDS by the kernel
     if constexpr (GEN) {
-        S.setup(make_io_gen<H>(a, b));
-        S.save_prepared(prep + b * Prep<H>::STRIDE_GEN);
+        S.template setup<false>(make_io_gen<H>(a, b));
+        S.template save_prepared<false>(prep + b * Prep<H>::STRIDE_GEN);
     } else {
-        S.setup(make_io_sched<H, kModeMpc>(a, b));
-        S.save_prepared(prep + b * Prep<H>::STRIDE);
+        S.template setup<UPD>(make_io_sched<H, kModeMpc>(a, b));
+        S.template save_prepared<UPD>(prep + b * Prep<H>::STRIDE);
     }
     if (a.predict && a.cost != nullptr && S.ln == 0) a.cost[b] = S.pred_cost;
 }
@@ -1705,7 +1842,7 @@ A1_DEV void setup_row(const BatchArgs& a, const double* __restrict__ tab, int64_
 // split pipeline, kernel 2: a persistent row.  It pulls prepared QPs from a shared counter and advances them one
 // checkpoint-aligned segment per loop trip; a row whose QP has converged writes it out and pulls the next one at the next
 // trip, so the rows of a wave never wait for each other's iteration counts -- only for each other's (rare) re-factorisations.
-template <int H, bool TWIN = false, bool GEN = false>
+template <int H, bool TWIN = false, bool GEN = false, bool UPD = false>
 A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* __restrict__ counter, double* __restrict__ lds) {
     RowSolver<H, kModeMpc, false, GEN, TWIN> S(a.P, a.tab, lds);
     bool alive = true, need_new = true, have = false;
@@ -1713,7 +1850,8 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
     while (alive) {
         if (need_new) {
             if (have) {
-                S.write_outputs(make_io<H, kModeMpc>(a, cur));
+                if constexpr (UPD) S.write_outputs(make_io<H, kModeMpc>(a, cur), carry_of<H>(a, cur));
+                else S.write_outputs(make_io<H, kModeMpc>(a, cur));
                 if (a.cost != nullptr && S.ln == 0 && !S.twin) a.cost[cur] = S.iter + 10 * S.nfact;  // ~ ADMM-iteration equivalents (a factor pass ~ 10)
             }
             double v = 0.0;
@@ -1727,14 +1865,14 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
             if (cur >= a.n) {
                 alive = false;
             } else {
-                if constexpr (GEN) S.load_prepared(prep + cur * Prep<H>::STRIDE_GEN, make_io<H, kModeMpc>(a, cur), true);
-                else S.load_prepared(prep + cur * Prep<H>::STRIDE, make_io<H, kModeMpc>(a, cur));
+                if constexpr (GEN) S.template load_prepared<false>(prep + cur * Prep<H>::STRIDE_GEN, make_io<H, kModeMpc>(a, cur), true);
+                else S.template load_prepared<UPD>(prep + cur * Prep<H>::STRIDE, make_io<H, kModeMpc>(a, cur));
                 have = true;
                 need_new = false;
             }
         }
         if (alive) {
-            S.advance();
+            S.template advance<UPD>();
             need_new = S.done;
         }
     }
@@ -1780,7 +1918,7 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
         RowSolver<H, MODE, false, false, TWIN> S(P, tab, lds);
         S.load_prepared(lds + Layout<H>::FAC, make_io_());
         S.solve();
-        S.write_outputs(make_io_());
+        { const ProblemIO& io_ = make_io_(); S.write_outputs(io_, io_.carry); }
     } else {
         RowSolver<H, MODE> S(P, tab, lds);
         S.setup(make_io_());

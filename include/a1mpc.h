@@ -80,7 +80,13 @@ typedef struct a1mpc_config {
                                       (non-reproducible); here 0 resolves deterministically to the outcome of OSQP's rule for these QP
                                       sizes, max(check_termination, 25-multiple) = check_termination (25).  a1mpc_default_config: 25 */
     int32_t scaling;               /* Ruiz passes (10) */
-    int32_t warm_start;            /* 1 on the reference's MPC path, 0 on its balance-QP path */
+    int32_t warm_start;            /* 0: cold start every solve (the reference's balance-QP path and S/test/test_mpc.cpp).
+                                      1: every tick is a fresh OSQP set-up warm-started from the previous tick's (x, y, rho) as osqp_warm_start defines it.
+                                      2: the reference's UPDATE path on ticks >= 2 (S/A1RobotControl.cpp:533-538: updateHessianMatrix / updateGradient /
+                                         update*Bound on the persistent OsqpEigen workspace, then solve()): OSQP re-equilibrates with the PREVIOUS tick's
+                                         gradient still in the workspace and starts from the previous solve's SCALED (x, z, y) as they are.  The handle then
+                                         also carries the previous scalings, gradient and z of every problem.  Restated from OSQP 0.6's update functions
+                                         (oracle: orc_mpc_solve_update); horizons 10 / 16 / 20, fast path (per-step feet and horizon 1 behave like 1). */
 } a1mpc_config;
 
 /* balance-QP constants, A1RobotControl ctor S/A1RobotControl.cpp:11-15 */

@@ -510,7 +510,7 @@ done:
     if (rho_io) *rho_io = w.rho;
     if (carry) {  /* what stays in the reference's workspace for the next tick's update calls */
         const int failed = info->status == ORC_PRIMAL_INFEASIBLE || info->status == ORC_DUAL_INFEASIBLE || info->status == ORC_NON_CVX;
-        carry[0] = 1.0; carry[1] = w.rho;
+        carry[0] = 1.0; carry[1] = failed ? st->rho : w.rho;   /* (a failed solve: the next tick starts from settings->rho, like the engine's cold start after a failure) */
         for (int j = 0; j < n; ++j) c_xs[j] = failed ? 0.0 : w.x[j];               /* store_solution: cold_start after a failed solve */
         for (int i = 0; i < m; ++i) { c_zs[i] = failed ? 0.0 : w.z[i]; c_ys[i] = failed ? 0.0 : w.y[i]; }
         memcpy(c_q, q, sizeof(double) * n); memcpy(c_l, l, sizeof(double) * m); memcpy(c_u, u, sizeof(double) * m);

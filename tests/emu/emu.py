@@ -87,7 +87,12 @@ def _p(a, t=C.c_double):
     return None if a is None else a.ctypes.data_as(C.POINTER(t))
 
 
-def solve(sc, n=None, settings=None, warm=None, split_rows=0, twin=False, contact_schedule=None, **over):
+def carry_buffer(horizon, n):
+    """zeroed Carry<H> records of n problems (the update path, warm_start = 2)"""
+    return np.zeros((n, int(lib().a1mpc_emu_carry_stride(int(horizon)))))
+
+
+def solve(sc, n=None, settings=None, warm=None, split_rows=0, twin=False, contact_schedule=None, carry=None, **over):
     """split_rows > 0: run the two-kernel pipeline (set-up kernel, then `split_rows` persistent ADMM rows) instead of the fused path;
     twin: the iterations run on main / twin PAIRS of rows (RowSolver<.., TWIN>: what the device kernels do for H > 1);
     contact_schedule: (n, 4h) per-step contacts on the FAST path (feet step-invariant) instead of sc["contact"]"""
@@ -103,10 +108,12 @@ def solve(sc, n=None, settings=None, warm=None, split_rows=0, twin=False, contac
     if contact_schedule is not None:
         contact = np.ascontiguousarray(contact_schedule, dtype=np.uint8).reshape(-1, 4 * h)
     lib().a1mpc_emu_set_contact_stride(4 if contact_schedule is not None else 0)
+    lib().a1mpc_emu_set_carry.argtypes = [C.c_void_p]
+    lib().a1mpc_emu_set_carry(None if carry is None else carry.ctypes.data)   # update path (warm_start = 2): carried in place
     try:
         return _solve(sc, n, h, P, grf, u, iters, status, nfact, wx, wy, rho, contact, split_rows, twin)
     finally:
-        lib().a1mpc_emu_set_contact_stride(0)
+        lib().a1mpc_emu_set_contact_stride(0); lib().a1mpc_emu_set_carry(None)
 
 
 def _solve(sc, n, h, P, grf, u, iters, status, nfact, wx, wy, rho, contact, split_rows, twin):

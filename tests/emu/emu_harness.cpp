@@ -129,6 +129,7 @@ static void job_twin_entry(void* a) {  // the fused kernel on a main / twin pair
     if constexpr (H > 1 && H % 2 == 0) solve_row_with<H, kModeMpc, false, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
 }
 static bool g_emu_twin = false;  // a1mpc_emu_set_twin(): the fused entry points run main / twin pairs
+static double* g_emu_carry = nullptr;  // a1mpc_emu_set_carry(): n x Carry<H>::STRIDE doubles of the update path (warm_start = 2), or null
 static int g_emu_contact_stride = 0;  // a1mpc_emu_set_contact_stride(): 4 = `contact` is an n x 4H per-step schedule (fast path, feet step-invariant)
 template <int H>
 static void run_batch(const DeviceParams* P, int n, const double* x0, const double* xref, const double* R, const double* foot,
@@ -158,6 +159,7 @@ static void run_batch(const DeviceParams* P, int n, const double* x0, const doub
         j.io.iters = iters ? iters + b : nullptr;
         j.io.status = status ? status + b : nullptr;
         j.io.nfact = nfact ? nfact + b : nullptr;
+        j.io.carry = g_emu_carry ? g_emu_carry + (size_t)b * Carry<H>::STRIDE : nullptr;
         if (g_emu_twin && H > 1 && H % 2 == 0) run_row(job_twin_entry<H>, &j, 32);
         else run_row(job_entry<H>, &j);
     }
@@ -166,16 +168,31 @@ static void run_batch(const DeviceParams* P, int n, const double* x0, const doub
 }  // namespace a1mpc
 extern "C" void a1mpc_emu_set_twin(int on) { a1mpc::g_emu_twin = on != 0; }
 extern "C" void a1mpc_emu_set_contact_stride(int stride) { a1mpc::g_emu_contact_stride = stride; }
+extern "C" void a1mpc_emu_set_carry(double* carry) { a1mpc::g_emu_carry = carry; }
+extern "C" int a1mpc_emu_carry_stride(int horizon) {
+    switch (horizon) { case 10: return a1mpc::Carry<10>::STRIDE; case 16: return a1mpc::Carry<16>::STRIDE; case 20: return a1mpc::Carry<20>::STRIDE; case 4: return a1mpc::Carry<4>::STRIDE; }
+    return 0;
+}
 
 namespace a1mpc {
 template <int H>
 struct SplitJob { const BatchArgs* a; double* prep; int* counter; double* lds; int64_t b; };
+// (like the host: the update-path instantiations of the two kernels when a carry is given -- warm_start = 2 --, the plain ones otherwise)
 template <int H>
-static void split_setup_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); setup_row<H>(*j->a, j->a->tab, j->b, j->lds, j->prep); }
+static void split_setup_entry(void* p) {
+    auto* j = static_cast<SplitJob<H>*>(p);
+    if (j->a->carry) setup_row<H, false, true>(*j->a, j->a->tab, j->b, j->lds, j->prep); else setup_row<H>(*j->a, j->a->tab, j->b, j->lds, j->prep);
+}
 template <int H>
-static void split_admm_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); admm_rows<H>(*j->a, j->prep, j->counter, j->lds); }
+static void split_admm_entry(void* p) {
+    auto* j = static_cast<SplitJob<H>*>(p);
+    if (j->a->carry) admm_rows<H, false, false, true>(*j->a, j->prep, j->counter, j->lds); else admm_rows<H>(*j->a, j->prep, j->counter, j->lds);
+}
 template <int H>
-static void split_admm_twin_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); admm_rows<H, true>(*j->a, j->prep, j->counter, j->lds); }
+static void split_admm_twin_entry(void* p) {
+    auto* j = static_cast<SplitJob<H>*>(p);
+    if (j->a->carry) admm_rows<H, true, false, true>(*j->a, j->prep, j->counter, j->lds); else admm_rows<H, true>(*j->a, j->prep, j->counter, j->lds);
+}
 // the split pipeline on host fibers: K1 for every QP, then `nrows` persistent rows draining the queue one after another
 template <int H>
 static void run_split(const BatchArgs& a, int nrows, bool twin = false) {
@@ -206,7 +223,7 @@ extern "C" int a1mpc_emu_solve_split(const a1mpc::DeviceParams* P, int horizon, 
     memset(&a, 0, sizeof a);
     a.P = *P; a.n = n; a.x0 = x0; a.xref = xref; a.R = R; a.foot = foot; a.contact = contact; a.grf = grf; a.u_full = u_full;
     a.warm_x = warm_x; a.warm_y = warm_y; a.rho = rho; a.iters = iters; a.status = status; a.nfact = nfact;
-    a.contact_stride = a1mpc::g_emu_contact_stride;
+    a.contact_stride = a1mpc::g_emu_contact_stride; a.carry = a1mpc::g_emu_carry;
     const bool twin = nrows < 0;  // nrows < 0: -nrows persistent main / twin PAIRS of rows (the device's persistent kernel)
     if (twin) nrows = -nrows;
     switch (horizon) {

@@ -275,3 +275,30 @@ def test_emulated_general_path_split_pipeline(scen, h, feet, cont, rows):
     split = emu.solve_gen_split(sc, foot, fs, contact, cs, rows=rows)
     assert np.array_equal(fused["u"], split["u"]) and np.array_equal(fused["grf"], split["grf"])
     assert (fused["iters"] == split["iters"]).all() and (fused["status"] == split["status"]).all() and (fused["nfact"] == split["nfact"]).all()
+
+
+@pytest.mark.parametrize("path", ["fused_twin", "split_twin", "single_row"])
+def test_emulated_update_path_matches_oracle(oracle, scen, path):
+    """warm_start = 2, the reference's tick >= 2 UPDATE path (S/A1RobotControl.cpp:533-538): previous gradient in the Ruiz cost normalisation, carried iterates
+    read in the new scaling, first iteration from the carried z -- the solver source, lane for lane, against the oracle's restatement of OSQP's update
+    functions (orc_mpc_solve_update): same iteration count every tick, forces to 1e-8 N, through a contact switch and a failed tick."""
+    seq = scen.config2_trot_sequence(70)
+    pr = oracle_params(oracle, seq); st = oracle.default_settings(warm_start=1)
+    kw = dict(fused_twin=dict(twin=True), split_twin=dict(split_rows=1, twin=True), single_row=dict())[path]
+    carry_o = oracle.update_carry(10)
+    wx = np.zeros((1, 120)); wy = np.zeros((1, 200)); rho = np.zeros(1); carry = emu.carry_buffer(10, 1)
+    ticks = list(range(0, 6)) + list(range(57, 64))      # (the contacts switch 1001 -> 0110 at tick 60; jumping from tick 5 to 57 is one more big change of the state)
+    for i, k in enumerate(ticks):
+        x0 = seq["x0"][k].copy()
+        if i == 9:
+            x0[4] = np.nan                             # a failed tick: zeros out, the next tick starts from cold iterates on the update path
+        o = oracle.mpc_solve_update(pr, st, x0, seq["xref"][k], seq["R"][k], seq["foot"][k], seq["contact"][k], carry_o)
+        one = {kk: (seq[kk][k:k + 1] if kk in ("x0", "xref", "R", "foot", "contact") else seq[kk]) for kk in seq}
+        one["x0"] = x0[None]
+        e = emu.solve(one, n=1, warm=(wx, wy, rho), carry=carry, warm_start=2, **kw)
+        assert e["iters"][0] == o["info"].iters and e["status"][0] == o["info"].status, (path, k, e["iters"], o["info"].iters)
+        assert np.abs(e["grf"][0] - o["grf"]).max() < 1e-8, (path, k)
+        if i == 9:
+            assert o["info"].status == -7 and not e["grf"].any()
+        elif i > 0:
+            assert abs(rho[0] - carry_o[1]) <= 1e-9 * carry_o[1]

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import TOL_FORCE_BALANCE_N, TOL_FORCE_N, compare, oracle_batch, take
+from helpers import TOL_FORCE_BALANCE_N, TOL_FORCE_N, compare, oracle_batch, oracle_params, take
 
 pytestmark = pytest.mark.gpu
 
@@ -935,3 +935,43 @@ def test_batch_pipeline_argument_errors(pkg, scen):
         pipe.wait()   # nothing submitted yet: returns at once
         assert lib.a1mpc_pipeline_wait(None, -1) != 0
     lib.a1mpc_pipeline_destroy(None)
+
+
+def _oracle_update_ticks(oracle, pr, st, scs, carries):
+    """one update-path tick of every robot b (its own carry) on the oracle"""
+    n = len(scs["x0"])
+    grf = np.zeros((n, 12)); it = np.zeros(n, np.int32); stt = np.zeros(n, np.int32)
+    for b in range(n):
+        o = oracle.mpc_solve_update(pr, st, scs["x0"][b], scs["xref"][b], scs["R"][b], scs["foot"][b], scs["contact"][b], carries[b])
+        grf[b] = o["grf"]; it[b] = o["info"].iters; stt[b] = o["info"].status
+    return grf, it, stt
+
+
+@pytest.mark.parametrize("n", [1, 300, 2600])
+def test_update_path_warm_start_2_matches_oracle(pkg, oracle, scen, n):
+    """warm_start = 2: the reference's tick >= 2 UPDATE path on the latency kernel (n = 1), the fused kernel (300) and the split pipeline (2600 > the resident
+    rows) against the oracle's restatement of OSQP's update functions (orc_mpc_solve_update): every robot carries its own workspace through a sequence of
+    slowly moving states with a contact switch; same iteration count and status on every QP of every tick, forces within the parity tolerance."""
+    rng = np.random.default_rng(100 + n)
+    sc = scen.config3_random_flat(nb=n, seed=900 + n)
+    pr = oracle_params(oracle, sc); st = oracle.default_settings(warm_start=1)
+    carries = [oracle.update_carry(10) for _ in range(n)]
+    ticks = 8 if n == 1 else (5 if n == 300 else 3)
+    with _engine(pkg, sc, n, warm_start=2) as eng:
+        for t in range(ticks):
+            if t > 0:
+                sc["x0"][:, :12] += rng.normal(0, 2e-3, (n, 12)); sc["foot"] += rng.normal(0, 1e-3, (n, 12))
+            if t == 2:
+                sc["contact"][:] = 1 - sc["contact"]      # every leg changes role: constraint types change, the carried z / y meet other bounds
+                sc["contact"][sc["contact"].sum(1) == 0] = [1, 0, 0, 1]
+            out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+            grf, it, stt = _oracle_update_ticks(oracle, pr, st, sc, carries)
+            assert (out["iters"] == it).all() and (out["status"] == stt).all(), (n, t, int((out["iters"] != it).sum()))
+            assert np.abs(out["grf"] - grf).max() <= TOL_FORCE_N, (n, t, np.abs(out["grf"] - grf).max())
+    # the first tick of a handle and the tick after a1mpc_reset_warm_start are cold solves whatever the mode
+    with _engine(pkg, sc, n, warm_start=2) as eng, _engine(pkg, sc, n, warm_start=0) as cold:
+        a = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"]); c = cold.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+        assert np.array_equal(a["grf"], c["grf"]) and np.array_equal(a["iters"], c["iters"])
+        eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"]); eng.reset_warm_start()
+        a = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+        assert np.array_equal(a["grf"], c["grf"]) and np.array_equal(a["iters"], c["iters"])
