@@ -210,7 +210,10 @@ template <class State, int H = 10>
 class ComputeGrfGpu {
   public:
     static constexpr int NLEG = A1MPC_NUM_LEG;
-    explicit ComputeGrfGpu(int device = 0) : device_(device) { a1mpc_default_config(&cfg_); cfg_.horizon = H; a1mpc_default_balance_config(&qp_); }
+    explicit ComputeGrfGpu(int device = 0) : device_(device) {
+        a1mpc_default_config(&cfg_); cfg_.horizon = H; a1mpc_default_balance_config(&qp_);
+        cfg_.warm_start = 2;   // the reference's persistent `solver` member: initSolver once, then update*() + solve() every tick = OSQP's update path (S/A1RobotControl.cpp:522-538)
+    }
     ~ComputeGrfGpu() { if (h_) a1mpc_destroy(h_); }
     ComputeGrfGpu(const ComputeGrfGpu&) = delete;
     ComputeGrfGpu& operator=(const ComputeGrfGpu&) = delete;

@@ -36,6 +36,9 @@ void orc_default_settings(orc_settings *s);
 int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
                    const double *l, const double *u, const orc_settings *st, double *x, double *y, double *rho_io,
                    orc_info *info);
+/* the same solve on OSQP's UPDATE path (a persistent workspace between ticks): carry = 2 + 2n + 4m doubles, zero before the first tick (a1mpc_oracle.c, osqp_solve_impl) */
+int orc_osqp_solve_update(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
+                          const double *l, const double *u, const orc_settings *st, double *x, double *y, double *carry, orc_info *info);
 #ifdef __cplusplus
 }
 #endif

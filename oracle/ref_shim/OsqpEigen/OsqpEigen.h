@@ -63,7 +63,9 @@ class Solver {
     std::unique_ptr<Settings> s_{new Settings};
     std::unique_ptr<Data> d_{new Data};
     bool init_ = false;
-    std::vector<double> x_, y_; double rho_ = 0;   // the persistent OSQP workspace: last (x, y) and the current rho
+    std::vector<double> x_, y_; double rho_ = 0;   // last (x, y) and rho (cold / one-off solves)
+    std::vector<double> carry_;                    // the persistent OSQP workspace of a warm-started solver between ticks: update*() + solve() follow OSQP's UPDATE path
+                                                   // (orc_osqp_solve_update: osqp_update_P re-equilibrating with the previous gradient, carried scaled iterates)
     Eigen::VectorXd sol_;
   public:
     const std::unique_ptr<Settings> &settings() const { return s_; }
@@ -72,6 +74,7 @@ class Solver {
     bool initSolver() {
         if (!(d_->hasP && d_->hasq && d_->hasA && d_->hasl && d_->hasu)) return false;
         init_ = true; x_.assign((size_t)d_->n, 0.0); y_.assign((size_t)d_->m, 0.0); rho_ = 0; shim_last().inits++;
+        carry_.assign((size_t)(2 + 2 * d_->n + 4 * d_->m), 0.0);
         return true;
     }
     void clearSolver() { init_ = false; }
@@ -90,8 +93,15 @@ class Solver {
         if (!st.warm_start) { x_.assign((size_t)n, 0.0); y_.assign((size_t)m, 0.0); rho_ = 0; }
         ShimRecord &rec = shim_last();
         rec.n = n; rec.m = m; rec.P = d_->P; rec.q = d_->q; rec.A = d_->A; rec.l = d_->l; rec.u = d_->u;
-        int rc = orc_osqp_solve(n, m, d_->P.data(), d_->q.data(), rp.data(), ci.data(), av.data(), d_->l.data(), d_->u.data(), &st,
+        int rc;
+        if (st.warm_start) {   // the reference's MPC solver: initSolver once, then updateHessianMatrix / updateGradient / update*Bound + solve every tick
+            x_.assign((size_t)n, 0.0); y_.assign((size_t)m, 0.0);
+            rc = orc_osqp_solve_update(n, m, d_->P.data(), d_->q.data(), rp.data(), ci.data(), av.data(), d_->l.data(), d_->u.data(), &st,
+                                       x_.data(), y_.data(), carry_.data(), &rec.info);
+        } else {
+            rc = orc_osqp_solve(n, m, d_->P.data(), d_->q.data(), rp.data(), ci.data(), av.data(), d_->l.data(), d_->u.data(), &st,
                                 x_.data(), y_.data(), &rho_, &rec.info);
+        }
         rec.x = x_; rec.y = y_; rec.solves++;
         sol_.resize(n); for (int j = 0; j < n; ++j) sol_(j) = x_[(size_t)j];
         // OSQP cold-starts its iterates after a failed solve (osqp_solve -> store_solution -> cold_start); like orc_mpc_solve the next

@@ -103,7 +103,7 @@ def test_compute_grf_mpc_branch_warm_sequence(oracle, scen, h, nt):
     st = oracle.default_settings(warm_start=1)
     c = REF.Controller(h)
     c.set("stance_leg_control_type", [1]); c.set("use_terrain_adapt", [0])
-    wx = np.zeros(12 * h); wy = np.zeros(20 * h); rho = 0.0
+    carry = oracle.update_carry(h)   # the persistent OsqpEigen solver of the reference: ticks >= 2 take OSQP's update path (S/A1RobotControl.cpp:533-538)
     for t in range(nt):
         x0 = sc["x0"][t]; R = sc["R"][t].reshape(3, 3)
         euler, pos, w, v = x0[0:3], x0[3:6], x0[6:9], x0[9:12]
@@ -114,8 +114,7 @@ def test_compute_grf_mpc_branch_warm_sequence(oracle, scen, h, nt):
         xref = oracle.mpc_reference(h, p["dt"], euler, pos, R.reshape(9), z3, vd, z3, 0.3)
         assert np.array_equal(xref, sc["xref"][t]) or np.abs(xref - sc["xref"][t]).max() < 1e-15
         assert np.array_equal(c.get("mpc_states_d", 13 * h), xref) and np.array_equal(c.get("mpc_states", 13), x0)
-        o = oracle.mpc_solve(pr, st, x0, xref, R.reshape(9), sc["foot"][t], sc["contact"][t], warm_x=wx, warm_y=wy, warm_rho=rho)
-        wx, wy, rho = o["warm_x"], o["warm_y"], o["rho"]
+        o = oracle.mpc_solve_update(pr, st, x0, xref, R.reshape(9), sc["foot"][t], sc["contact"][t], carry)
         assert o["info"].iters == qp["iters"] and o["info"].status == qp["status"], t
         # same QP data to 1e-15, same iteration count; the forces then agree to the amplification of that last bit through ~50-100 ADMM iterations
         assert np.abs(o["grf"] - grf).max() <= (1e-9 if h == 10 else 1e-7), (t, np.abs(o["grf"] - grf).max())
@@ -196,6 +195,7 @@ def test_caller_side_tick_chain_equals_reference(oracle, scen):
     pitch_d = 0.0; tau_prev = np.zeros(12); grf_prev = np.zeros(12)
     km = np.array([0.1, 0.1, 0.1]); tg = np.array([0.8, 0, 0, -0.8, 0, 0, 0.8, 0, 0, -0.8, 0, 0])
     slope = 0.25
+    carry_mpc = oracle.update_carry(10)
     for t in range(150):
         euler = np.array([rng.normal(0, 0.02), 0.2 + rng.normal(0, 0.02), 0.3 + 0.001 * t])
         R = scen.rot_zyx(*euler); Rz = scen.rot_zyx(0.0, 0.0, euler[2])
@@ -235,8 +235,7 @@ def test_caller_side_tick_chain_equals_reference(oracle, scen):
         xref = oracle.mpc_reference(10, p["dt"], euler, pos, R.reshape(9), [0.0, pitch_d, 0.0], vd, wd, 0.3)
         assert np.array_equal(xref, c.get("mpc_states_d", 130)), t
         x0 = np.concatenate([euler, pos, w, v, [-9.8]])
-        o = oracle.mpc_solve(pr, st, x0, xref, R.reshape(9), foot_abs, ct, warm_x=wx, warm_y=wy, warm_rho=rho)
-        wx, wy, rho = o["warm_x"], o["warm_y"], o["rho"]
+        o = oracle.mpc_solve_update(pr, st, x0, xref, R.reshape(9), foot_abs, ct, carry_mpc)   # (the reference's persistent solver: OSQP's update path from tick 2 on)
         assert o["info"].iters == qp["iters"] and o["info"].status == qp["status"], t
         assert np.abs(o["grf"] - grf_r).max() <= 1e-6, (t, np.abs(o["grf"] - grf_r).max())
         tau = oracle.joint_torques(1 if t >= 9 else 0, ct, Jb.reshape(36), grf_r, kin, km, tg, tau_prev)
