@@ -21,13 +21,14 @@ static void rot_zyx(double r, double p, double y, double* R) {
 
 int main(int argc, char** argv) {
     const int ticks = argc > 1 ? atoi(argv[1]) : 10000, pace_us = argc > 2 ? atoi(argv[2]) : 0, H = 10;
+    const int warm_mode = argc > 3 ? atoi(argv[3]) : 1;   // 1 = fresh set-up + warm start, 2 = the reference's update path (a1mpc.h)
     a1mpc_config cfg;
     a1mpc_default_config(&cfg);
     const double q[13] = {20, 10, 1, 0, 0, 420, .05, .05, .05, 30, 30, 10, 0};   // config/gazebo_a1_mpc.yaml:40-72
     for (int i = 0; i < 13; ++i) cfg.q[i] = q[i];
     for (int i = 0; i < 12; ++i) cfg.r[i] = 1e-7;
     cfg.mass = 12.0; cfg.inertia_body[0] = 0.0158533; cfg.inertia_body[4] = 0.0377999; cfg.inertia_body[8] = 0.0456542;
-    cfg.horizon = H; cfg.warm_start = 1;
+    cfg.horizon = H; cfg.warm_start = warm_mode;
     a1mpc_handle h = nullptr;
     if (a1mpc_create(&cfg, 1, 0, &h) != A1MPC_OK) { std::fprintf(stderr, "a1mpc_create: %s\n", a1mpc_last_error()); return 2; }
     std::mt19937_64 rng(0xA1 + 2);
@@ -71,8 +72,8 @@ int main(int argc, char** argv) {
     int over = 0, worst_t = skip;
     for (int t = skip; t < ticks; ++t) { over += lat[t] > 2.5; if (lat[t] > lat[worst_t]) worst_t = t; }
     double mean_it = 0; for (int t = skip; t < ticks; ++t) mean_it += iters[t]; mean_it /= (ticks - skip);
-    std::printf("{\"workload\": \"config2 trot, h=10, batch 1, warm start, host pointers in/out, C++ caller, %s\", \"ticks\": %zu, \"p50_ms\": %.4f, \"p99_ms\": %.4f, "
+    std::printf("{\"warm_start\": %d, \"workload\": \"config2 trot, h=10, batch 1, warm start, host pointers in/out, C++ caller, %s\", \"ticks\": %zu, \"p50_ms\": %.4f, \"p99_ms\": %.4f, "
                 "\"p999_ms\": %.4f, \"max_ms\": %.4f, \"ticks_over_2p5_ms\": %d, \"worst_tick_index\": %d, \"worst_tick_iters\": %d, \"mean_iters\": %.1f, \"not_solved\": %d}\n",
-                pace_us > 0 ? "paced" : "back to back", v.size(), pct(0.50), pct(0.99), pct(0.999), s.back(), over, worst_t, iters[worst_t], mean_it, bad_status);
+                warm_mode, pace_us > 0 ? "paced" : "back to back", v.size(), pct(0.50), pct(0.99), pct(0.999), s.back(), over, worst_t, iters[worst_t], mean_it, bad_status);
     return 0;
 }
