@@ -130,7 +130,7 @@ def batch_sweep(pkg, local, sizes=(1024, 16384, 65536)):
     return out
 
 
-def warm_tick_probe(pkg, local, n=4096, ticks=12):
+def warm_tick_probe(pkg, local, n=4096, ticks=12, mode=1):
     """Extra information (not `value`): the closed-loop regime -- the same n robots tick after tick with warm start (the carried OSQP
     workspace of the reference) and slowly moving states (two nearby batches alternate), queue order from the previous tick."""
     import torch
@@ -139,7 +139,7 @@ def warm_tick_probe(pkg, local, n=4096, ticks=12):
     rng = np.random.default_rng(5)
     b = {k: a[k].copy() for k in ("x0", "xref", "R", "foot", "contact")}
     b["x0"][:, :12] += rng.normal(0, 0.002, (n, 12)); b["foot"] += rng.normal(0, 0.001, (n, 12))
-    cfg = pkg.make_config(a["params"], HORIZON, warm_start=1)
+    cfg = pkg.make_config(a["params"], HORIZON, warm_start=mode)   # 1: fresh set-up + warm start; 2: the reference's per-tick OSQP update path (include/a1mpc.h)
     da = {k: torch.from_numpy(a[k]).to(dev) for k in b}; db = {k: torch.from_numpy(b[k]).to(dev) for k in b}
     grf = torch.zeros((n, 12), dtype=torch.float64, device=dev)
     it = torch.zeros(n, dtype=torch.int32, device=dev); stt = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -149,7 +149,7 @@ def warm_tick_probe(pkg, local, n=4096, ticks=12):
             d = da if t % 2 == 0 else db
             eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, it, stt, stream=st.cuda_stream)
             ms.append(eng.last_kernel_ms()); iters.append(float(it.float().mean().item()))
-    return {"workload": "4096 robots, h=10, warm start, states move ~2 mm / 2 mrad between ticks", "kernel_ms_per_tick": float(np.median(ms[4:])),
+    return {"workload": "4096 robots, h=10, warm start, states move ~2 mm / 2 mrad between ticks", "warm_start_mode": mode, "kernel_ms_per_tick": float(np.median(ms[4:])),
             "ticks_per_s_x_robots": n / (float(np.median(ms[4:])) * 1e-3), "mean_iters_cold_first_tick": iters[0], "mean_iters_warm": float(np.mean(iters[4:]))}
 
 
@@ -240,9 +240,24 @@ def other_config_rooflines(pkg, local, steps=4):
         avg = float(np.mean(ms[1:]))
         fl = float(pkg.algorithmic_flops(h, it.cpu().numpy(), nf).sum())
         ach = fl / (avg * 1e-3) / 1e12
-        res.append({"config": name, "batch": n, "horizon": h, "avg_kernel_ms": avg, "solves_per_s": n / (avg * 1e-3), "bound": "fp64-valu", "achieved": ach,
-                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "mean_iters": float(it.float().mean().item()),
-                    "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n, "solved_frac": float((stt == 1).float().mean().item())})
+        entry = {"config": name, "batch": n, "horizon": h, "avg_kernel_ms": avg, "solves_per_s": n / (avg * 1e-3), "bound": "fp64-valu", "achieved": ach,
+                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "mean_iters": float(it.float().mean().item()),
+                 "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n, "solved_frac": float((stt == 1).float().mean().item())}
+        if n <= 8192:   # a batch of this size leaves a tail: the same first solves with two batches in flight (a1mpc_pipeline; batches of tens of thousands fill the chip alone)
+            outs = [(torch.zeros((n, 12), dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(2)]
+            with pkg.Pipeline(cfg, n, local, depth=2) as pipe:
+                sub = lambda k, after=None: pipe.submit_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], outs[k % 2][0], None, outs[k % 2][1], outs[k % 2][2], fresh=True, after_stream=after)
+                for k in range(2):
+                    sub(k)
+                pipe.wait(); torch.cuda.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                for k in range(2 * steps):
+                    sub(k, st.cuda_stream if k < 2 else None)
+                pipe.join(st.cuda_stream); e1.record(st); torch.cuda.synchronize()
+                pms = e0.elapsed_time(e1) / (2 * steps)
+            entry["two_in_flight"] = {"ms_per_batch": pms, "solves_per_s": n / (pms * 1e-3), "frac": fl / (pms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+        res.append(entry)
     return res
 
 
@@ -533,6 +548,7 @@ def main():
             out["latency"] = latency_probe(pkg)
             out["throughput_by_batch"] = batch_sweep(pkg, local)
             out["warm_start_ticks"] = warm_tick_probe(pkg, local)
+            out["warm_start_ticks_update_path"] = warm_tick_probe(pkg, local, mode=2)
             out["full_control_tick"] = full_tick_probe(pkg, local)
         if not args.no_cpu_baseline:
             out["cpu_baseline"], ref = cpu_baseline(pkg, sc)
