@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -373,6 +374,8 @@ static a1mpc_status resident_workgroups(int* out) {
 // dynamic-LDS limit of a kernel, once per device and kernel
 static a1mpc_status set_lds_attr(const void* fn, size_t bytes) {
     static std::vector<std::pair<const void*, int>> done;
+    static std::mutex mu;   // handles of different threads may launch at the same time
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     A1_HIP(hipGetDevice(&dev));
     for (const auto& d : done) if (d.first == fn && d.second == dev) return A1MPC_OK;
@@ -402,8 +405,10 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     int res = 0;
     if (a1mpc_status st = resident_workgroups<H, ROWS>(&res); st != A1MPC_OK) return st;
     A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
-    if (H > 1 && a.carry != nullptr) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1, true>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
-    else hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
+    bool upd_kernels = false;   // warm_start = 2: the update-path instantiations of the two kernels (H > 1 only; same resources, a few more instructions around set-up and iteration 1)
+    if constexpr (H > 1) upd_kernels = a.carry != nullptr;
+    if constexpr (H > 1) { if (upd_kernels) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1, true>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep); }
+    if (!upd_kernels) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
     A1_HIP(hipGetLastError());
     // queue order of THIS solve, longest first: by the set-up kernel's cost guesses (predict: no history) or by the cost each QP had in the handle's previous
     // solve of this batch size (the cost buffer still holds it; the ADMM kernel below overwrites it with this solve's).  Sorted here, in front of the kernel
@@ -417,12 +422,13 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     if (mid) A1_HIP(hipEventRecord(mid, stream));  // stage split: formation + Ruiz (+ queue order) | factor + iterate
     const int want = (a.n + ROWS - 1) / ROWS;
     const dim3 grid(static_cast<unsigned>(want < res ? want : res)), block(admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS);
-    if (H > 1 && a.carry != nullptr) {  // warm_start = 2: the update-path instantiation (same resources: it differs in a few instructions around the first iteration)
-        if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, true>), lds2); st != A1MPC_OK) return st;
-        hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
-    } else {
-        hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
+    if constexpr (H > 1) {
+        if (upd_kernels) {
+            if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, true>), lds2); st != A1MPC_OK) return st;
+            hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
+        }
     }
+    if (!upd_kernels) hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
 }
