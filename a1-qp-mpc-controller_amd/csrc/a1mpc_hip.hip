@@ -36,7 +36,8 @@ using KernelArgs = BatchArgs;
 // LDS image (row_is_twin(), RowSolver<.., TWIN>); the workgroup is then a full wavefront.
 constexpr bool twin_rows(int h, int mode, int rows) { return rows <= 2 && h > 1 && mode == kModeMpc; }
 // ROWS = QPs (DPP rows) per workgroup; the workgroup is one wavefront with 16*ROWS live lanes (64 with twin rows).
-template <int H, int MODE, int ROWS>
+// UPD: the instantiation that also serves warm_start = 2 (the reference's update path; built for the default ROWS of a horizon only)
+template <int H, int MODE, int ROWS, bool UPD = false>
 __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     constexpr bool kTwin = twin_rows(H, MODE, ROWS);
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
     if (kTwin && row >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
     const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
     if (b >= a.n) return;  // row-uniform (a twin leaves with its main row): the other rows of the wave keep all their DPP sources
-    solve_row_with<H, MODE, false, kTwin>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+    solve_row_with<H, MODE, false, kTwin, UPD>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
 }
 
 // General path (per-step feet / per-step contact schedules: S/ConvexMpc.h:74 B_mat_d_list, S/test/test_mpc.cpp:106-122): the fused kernel
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(64) void a1mpc_solve_gen_kernel(const KernelArgs a)
 // Latency variant of the fused kernel for a handful of QPs: the four rows of a wavefront work on ONE QP during set-up (each takes every fourth
 // horizon step of the Ruiz sweeps; everything else is computed redundantly and written to the one shared LDS image), then rows 1-3 retire
 // and row 0 solves.  Same results bit for bit (the column maxima are exact and order-free).
-template <int H>
+template <int H, bool UPD = false>
 __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     const int row = static_cast<int>(threadIdx.x) >> 4;
@@ -73,17 +74,18 @@ __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a
     {
         RowSolver<H, kModeMpc> S(a.P, a.tab, a1mpc_lds);
         S.coop_id = row; S.coop_n = 4;
-        S.setup(io);
+        S.template setup<UPD>(io);
         row_sync();  // every row is done with the set-up scratch aliased into the factor region
-        if (row == 0) S.save_prepared(a1mpc_lds + Layout<H>::FAC);
+        if (row == 0) S.template save_prepared<UPD>(a1mpc_lds + Layout<H>::FAC);
     }
     if (row & 1) return;
     // Rows 0 and 2 continue exactly like a main / twin pair of the split pipeline's second kernel: a fresh solver that reads the hand-off record
     // (here through LDS).  Carrying the set-up's registers into the ADMM loop instead costs that loop its spill-free allocation.
     RowSolver<H, kModeMpc, false, false, true> S(a.P, a.tab, a1mpc_lds);
-    S.load_prepared(a1mpc_lds + Layout<H>::FAC, make_io<H, kModeMpc>(a, b));
-    S.solve();
-    S.write_outputs(make_io<H, kModeMpc>(a, b), carry_of<H>(a, b));
+    S.template load_prepared<UPD>(a1mpc_lds + Layout<H>::FAC, make_io<H, kModeMpc>(a, b));
+    S.template solve<UPD>();
+    if constexpr (UPD) S.write_outputs(make_io<H, kModeMpc>(a, b), carry_of<H>(a, b));
+    else S.write_outputs(make_io<H, kModeMpc>(a, b));
 }
 
 // ---- split pipeline (large batches) -----------------------------------------------------------------------------
@@ -322,13 +324,19 @@ constexpr size_t lds_bytes(int rows) { return sizeof(double) * rows * Layout<H>:
 // factorisation passes (measured: +5 % at 4096 QPs, +4 % at 32768).  From H = 16 on LDS allows four QPs per CU at most: one QP (a main / twin pair of rows) per
 // wavefront then puts them on four SIMDs instead of two -- no more QPs in flight, but no row waits for a wave-mate's hand-over or factor pass any more and the LDS
 // conflicts between the two images go (8192 x h16 first solve 4.62 -> 4.41 ms, 16 384 x h20 10.35 -> 10.04 ms).  A1MPC_ROWS_PER_WG = 1 | 2 | 4 overrides.
+constexpr int default_rows_per_wg(int horizon) { return horizon >= 16 ? 1 : 2; }
+// The shipped build instantiates the kernels for the default rows per workgroup only (the other two layouts were measured and lost, above; every extra layout of
+// the H = 16 / 20 kernels costs a minute of compile time): the override is honoured by -DA1MPC_ALL_ROWS tuning builds.
 static int rows_per_wg(int horizon) {
+#ifndef A1MPC_ALL_ROWS
+    return default_rows_per_wg(horizon);
+#endif
     static int r = [] {
         const char* e = getenv("A1MPC_ROWS_PER_WG");
         const int v = e ? atoi(e) : 0;
         return (v == 1 || v == 2 || v == 4) ? v : 0;
     }();
-    return r ? r : (horizon >= 16 ? 1 : 2);
+    return r ? r : default_rows_per_wg(horizon);
 }
 
 thread_local std::string g_last_error;
@@ -390,11 +398,15 @@ static a1mpc_status resident_rows(int* out) {
 #ifdef A1MPC_DEV_SLIM
     st = resident_workgroups<H, 2>(&wg); *out = 2 * wg;
 #else
+#ifdef A1MPC_ALL_ROWS
     switch (rows_per_wg(H)) {
         case 1: st = resident_workgroups<H, 1>(&wg); *out = wg; return st;
         case 2: st = resident_workgroups<H, 2>(&wg); *out = 2 * wg; return st;
     }
     st = resident_workgroups<H, 4>(&wg); *out = 4 * wg;
+#else
+    st = resident_workgroups<H, default_rows_per_wg(H)>(&wg); *out = default_rows_per_wg(H) * wg;
+#endif
 #endif
     return st;
 }
@@ -405,9 +417,10 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     int res = 0;
     if (a1mpc_status st = resident_workgroups<H, ROWS>(&res); st != A1MPC_OK) return st;
     A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
-    bool upd_kernels = false;   // warm_start = 2: the update-path instantiations of the two kernels (H > 1 only; same resources, a few more instructions around set-up and iteration 1)
-    if constexpr (H > 1) upd_kernels = a.carry != nullptr;
-    if constexpr (H > 1) { if (upd_kernels) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1, true>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep); }
+    bool upd_kernels = false;   // warm_start = 2: the update-path instantiations of the two kernels (H > 1, default rows per workgroup; same resources, a few more instructions around set-up and iteration 1)
+    constexpr bool kHasUpd = H > 1 && ROWS == default_rows_per_wg(H);
+    if constexpr (kHasUpd) upd_kernels = a.carry != nullptr;
+    if constexpr (kHasUpd) { if (upd_kernels) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1, true>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep); }
     if (!upd_kernels) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
     A1_HIP(hipGetLastError());
     // queue order of THIS solve, longest first: by the set-up kernel's cost guesses (predict: no history) or by the cost each QP had in the handle's previous
@@ -422,7 +435,7 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     if (mid) A1_HIP(hipEventRecord(mid, stream));  // stage split: formation + Ruiz (+ queue order) | factor + iterate
     const int want = (a.n + ROWS - 1) / ROWS;
     const dim3 grid(static_cast<unsigned>(want < res ? want : res)), block(admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS);
-    if constexpr (H > 1) {
+    if constexpr (kHasUpd) {
         if (upd_kernels) {
             if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, true>), lds2); st != A1MPC_OK) return st;
             hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
@@ -437,11 +450,16 @@ static a1mpc_status launch_split(const KernelArgs& a, double* prep, int* counter
 #ifdef A1MPC_DEV_SLIM  // kernel-tuning builds: one instantiation (H = 10, two rows), seconds instead of minutes to compile
     return launch_split_rows<H, 2>(a, prep, counter, stream, mid);
 #else
-    switch (rows_per_wg(H)) {
-        case 1: return launch_split_rows<H, 1>(a, prep, counter, stream, mid);
-        case 2: return launch_split_rows<H, 2>(a, prep, counter, stream, mid);
+#ifdef A1MPC_ALL_ROWS
+    if (a.carry == nullptr) {   // (the update-path kernels exist for the default rows per workgroup only)
+        switch (rows_per_wg(H)) {
+            case 1: return launch_split_rows<H, 1>(a, prep, counter, stream, mid);
+            case 2: return launch_split_rows<H, 2>(a, prep, counter, stream, mid);
+        }
+        return launch_split_rows<H, 4>(a, prep, counter, stream, mid);
     }
-    return launch_split_rows<H, 4>(a, prep, counter, stream, mid);
+#endif
+    return launch_split_rows<H, default_rows_per_wg(H)>(a, prep, counter, stream, mid);
 #endif
 }
 static size_t carry_stride(int horizon) {
@@ -473,6 +491,14 @@ static a1mpc_status launch_rows(const KernelArgs& a, hipStream_t stream) {
         attr_set[dev] = true;
     }
     const unsigned grid = static_cast<unsigned>((a.n + ROWS - 1) / ROWS);
+    if constexpr (MODE == kModeMpc && H > 1 && ROWS == default_rows_per_wg(H)) {
+        if (a.carry != nullptr) {   // warm_start = 2: the update-path instantiation
+            if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE, ROWS, true>), lds_bytes<H>(ROWS)); st != A1MPC_OK) return st;
+            hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE, ROWS, true>), dim3(grid), dim3(twin_rows(H, MODE, ROWS) ? 64 : 16 * ROWS), lds_bytes<H>(ROWS), stream, a);
+            A1_HIP(hipGetLastError());
+            return A1MPC_OK;
+        }
+    }
     hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE, ROWS>), dim3(grid), dim3(twin_rows(H, MODE, ROWS) ? 64 : 16 * ROWS), lds_bytes<H>(ROWS), stream, a);
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
@@ -589,6 +615,12 @@ static a1mpc_status launch_coop(const KernelArgs& a, hipStream_t stream) {
                                    static_cast<int>(lds_bytes<H>(1))));
         attr_set[dev] = true;
     }
+    if (a.carry != nullptr) {   // warm_start = 2: the update-path instantiation
+        if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_coop_kernel<H, true>), lds_bytes<H>(1)); st != A1MPC_OK) return st;
+        hipLaunchKernelGGL((a1mpc_solve_coop_kernel<H, true>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds_bytes<H>(1), stream, a);
+        A1_HIP(hipGetLastError());
+        return A1MPC_OK;
+    }
     hipLaunchKernelGGL((a1mpc_solve_coop_kernel<H>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds_bytes<H>(1), stream, a);
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
@@ -599,11 +631,16 @@ static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
         static const bool coop = [] { const char* e = getenv("A1MPC_COOP_SETUP"); return !(e && !strcmp(e, "0")); }();
         if (coop && a.n <= kCoopMaxBatch) return launch_coop<H>(a, stream);
     }
-    switch (rows_per_wg(H)) {
-        case 1: return launch_rows<H, MODE, 1>(a, stream);
-        case 2: return launch_rows<H, MODE, 2>(a, stream);
+#ifdef A1MPC_ALL_ROWS
+    if (a.carry == nullptr) {   // (the update-path kernels exist for the default rows per workgroup only)
+        switch (rows_per_wg(H)) {
+            case 1: return launch_rows<H, MODE, 1>(a, stream);
+            case 2: return launch_rows<H, MODE, 2>(a, stream);
+        }
+        return launch_rows<H, MODE, 4>(a, stream);
     }
-    return launch_rows<H, MODE, 4>(a, stream);
+#endif
+    return launch_rows<H, MODE, default_rows_per_wg(H)>(a, stream);
 }
 
 static constexpr int kScheduleMinBatch = 1024;  // below this every QP is resident at once and the order cannot matter

@@ -409,7 +409,7 @@ struct RowSolver {
     // ================================================================================ set-up: formation + Ruiz + hot state
     // UPD = false: an instantiation without the update path (warm_start = 2 never reaches it) -- the split pipeline's set-up kernel of every other mode keeps the
     // code it had before the update path existed (with it in: +9 % on that kernel, measured)
-    template <bool UPD = true>
+    template <bool UPD = false>
     A1_DEV void setup(const ProblemIO& io) {
         double Rm[9];
 #pragma unroll
@@ -883,7 +883,7 @@ struct RowSolver {
     }
 
     // ================================================================================ hand-off between the two kernels
-    template <bool UPD = true>
+    template <bool UPD = false>
     A1_DEV void save_prepared(double* __restrict__ p) const {  // p: this QP's Prep<H>::STRIDE doubles
         if (!act) return;
         static_for<H>([&](auto T) {
@@ -918,7 +918,7 @@ struct RowSolver {
     // kernel they are still where the set-up wrote them)
     // UPD = false: an instantiation without the update path's hand-off (warm_start = 2 never reaches it): the persistent ADMM kernel of every other mode keeps
     // the code -- and with it the register allocation of its hot loop -- it had before the update path existed (with it: 4 more AGPR moves per iteration, +1 %)
-    template <bool UPD = true>
+    template <bool UPD = false>
     A1_DEV void load_prepared(const double* __restrict__ p, const ProblemIO& io, [[maybe_unused]] bool tables = false) {
         sync();  // the previous QP's LDS image is dead
         const double am = act ? 1.0 : 0.0;  // pad lanes read lane 0's record (ci == 0) and zero what must be zero
@@ -1624,7 +1624,7 @@ struct RowSolver {
     // (re-)factorise if needed, iterate up to the next checkpoint (a multiple of check_termination / adaptive_rho_interval, or
     // max_iter), then the residual check and the rho update.  Everything that can differ between the rows of a wave
     // (termination, rho update) happens at segment boundaries, so rows that run advance() in lock-step stay aligned.
-    template <bool UPD = true>
+    template <bool UPD = false>
     A1_DEV void advance() {
 #ifdef A1X_CLK
         const long long tf_ = clock64();
@@ -1697,8 +1697,9 @@ struct RowSolver {
     }
     // fused driver: every loop leaves through its latch only (a divergent exit from the middle of a body makes the compiler
     // copy every live-out vector on every iteration)
+    template <bool UPD = false>
     A1_DEV void solve() {
-        do { advance(); } while (!done);
+        do { advance<UPD>(); } while (!done);
     }
 
     // ================================================================================ store_solution + first-step GRFs in the body frame
@@ -1883,7 +1884,8 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
 // stays live across the ADMM loop costs that loop ~30 VGPRs it does not have.
 // TWIN: the calling row is one of a main / twin pair (rows r and r + 2 of the wavefront, see RowSolver<.., TWIN>): the main row sets the QP up alone,
 // both iterate.
-template <int H, int MODE, bool GEN = false, bool TWIN = false, class MakeIO>
+// UPD: the instantiation that also serves warm_start = 2 (the reference's update path); UPD = false is the code of every other mode, as it was before that path existed
+template <int H, int MODE, bool GEN = false, bool TWIN = false, bool UPD = false, class MakeIO>
 A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab, MakeIO&& make_io_, double* __restrict__ lds) {
     static_assert(!TWIN || (MODE == kModeMpc && Prep<H>::STRIDE <= H * Layout<H>::SLOT), "twin rows: the MPC solve with the set-up | iteration hand-off");
     if constexpr (GEN) {
@@ -1910,15 +1912,16 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
         {   // (a main / twin pair shares the set-up: see the general path above)
             RowSolver<H, MODE> S0(P, tab, lds);
             if constexpr (TWIN) { S0.coop_id = row_is_twin() ? 1 : 0; S0.coop_n = 2; }
-            S0.setup(make_io_());
+            S0.template setup<UPD>(make_io_());
             if constexpr (TWIN) pair_sync(); else row_sync();
-            if (!TWIN || !row_is_twin()) S0.save_prepared(lds + Layout<H>::FAC);
+            if (!TWIN || !row_is_twin()) S0.template save_prepared<UPD>(lds + Layout<H>::FAC);
         }
         if constexpr (TWIN) pair_sync();  // the twin reads the hand-off record its main row wrote
         RowSolver<H, MODE, false, false, TWIN> S(P, tab, lds);
-        S.load_prepared(lds + Layout<H>::FAC, make_io_());
-        S.solve();
-        { const ProblemIO& io_ = make_io_(); S.write_outputs(io_, io_.carry); }
+        S.template load_prepared<UPD>(lds + Layout<H>::FAC, make_io_());
+        S.template solve<UPD>();
+        if constexpr (UPD) { const ProblemIO& io_ = make_io_(); S.write_outputs(io_, io_.carry); }
+        else S.write_outputs(make_io_());
     } else {
         RowSolver<H, MODE> S(P, tab, lds);
         S.setup(make_io_());
@@ -1926,9 +1929,9 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
         S.write_outputs(make_io_());
     }
 }
-template <int H, int MODE = kModeMpc, bool GEN = false>
+template <int H, int MODE = kModeMpc, bool GEN = false, bool UPD = false>
 A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, const ProblemIO& io, double* __restrict__ lds) {
-    solve_row_with<H, MODE, GEN, false>(P, tab, [&]() -> const ProblemIO& { return io; }, lds);
+    solve_row_with<H, MODE, GEN, false, UPD>(P, tab, [&]() -> const ProblemIO& { return io; }, lds);
 }
 
 }  // namespace a1mpc

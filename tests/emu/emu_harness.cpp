@@ -120,13 +120,17 @@ struct Job {
 template <int H>
 static void job_entry(void* a) {
     Job<H>* j = static_cast<Job<H>*>(a);
+    if constexpr (H > 1) { if (j->io.carry) { solve_row<H, kModeMpc, false, true>(*j->P, j->tab, j->io, j->lds); return; } }   // (like the host: the update-path instantiation for warm_start = 2)
     solve_row<H>(*j->P, j->tab, j->io, j->lds);
 }
 
 template <int H>
 static void job_twin_entry(void* a) {  // the fused kernel on a main / twin pair of rows
     Job<H>* j = static_cast<Job<H>*>(a);
-    if constexpr (H > 1 && H % 2 == 0) solve_row_with<H, kModeMpc, false, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+    if constexpr (H > 1 && H % 2 == 0) {
+        if (j->io.carry) solve_row_with<H, kModeMpc, false, true, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+        else solve_row_with<H, kModeMpc, false, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+    }
 }
 static bool g_emu_twin = false;  // a1mpc_emu_set_twin(): the fused entry points run main / twin pairs
 static double* g_emu_carry = nullptr;  // a1mpc_emu_set_carry(): n x Carry<H>::STRIDE doubles of the update path (warm_start = 2), or null
