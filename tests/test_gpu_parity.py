@@ -975,3 +975,30 @@ def test_update_path_warm_start_2_matches_oracle(pkg, oracle, scen, n):
         eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"]); eng.reset_warm_start()
         a = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
         assert np.array_equal(a["grf"], c["grf"]) and np.array_equal(a["iters"], c["iters"])
+
+
+def test_pipeline_slots_carry_their_own_update_path_workspace(pkg, scen):
+    """two robot fleets on the two slots of a pipeline with warm_start = 2: each slot carries its own OSQP workspace (x, y, rho AND the update path's scalings /
+    gradient / z), so every tick of a fleet equals the tick of a lone handle that solved the same sequence -- bit for bit, while the two fleets' launches overlap."""
+    import torch
+    n = 2600
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    fleets = [scen.config3_random_flat(nb=n, seed=70 + f) for f in range(2)]
+    cfg = pkg.make_config(fleets[0]["params"], 10, warm_start=2)
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    with pkg.Engine(cfg, n, 0) as e0, pkg.Engine(cfg, n, 0) as e1, pkg.Pipeline(cfg, n, 0, depth=2) as pipe:
+        for tick in range(4):
+            ins = []
+            for f in range(2):
+                if tick > 0:
+                    fleets[f]["x0"][:, :12] += rng.normal(0, 2e-3, (n, 12))
+                ins.append([t(fleets[f]["x0"]), t(fleets[f]["xref"]), t(fleets[f]["R"]), t(fleets[f]["foot"]), t(fleets[f]["contact"], torch.uint8)])
+            outs = [(torch.zeros(n, 12, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(4)]
+            assert pipe.submit_device(n, *ins[0], outs[0][0], None, outs[0][1], slot=0, fresh=False) == 0
+            assert pipe.submit_device(n, *ins[1], outs[1][0], None, outs[1][1], slot=1, fresh=False) == 1
+            e0.solve_device(n, *ins[0], outs[2][0], None, outs[2][1]); e1.solve_device(n, *ins[1], outs[3][0], None, outs[3][1])
+            pipe.wait(); torch.cuda.synchronize()
+            for f in range(2):
+                assert np.array_equal(outs[f][0].cpu().numpy(), outs[2 + f][0].cpu().numpy()) and np.array_equal(outs[f][1].cpu().numpy(), outs[2 + f][1].cpu().numpy()), (tick, f)
+        assert outs[0][1].float().mean().item() < 40   # warm ticks
