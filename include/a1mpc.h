@@ -348,7 +348,8 @@ a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h);
  * OsqpEigen::Solver member, S/A1RobotControl.h:67): x n x 12H (world-frame forces), y n x 20H (reference row order), rho n
  * (0 = "start from settings.rho").  Any pointer may be NULL.  Host pointers; synchronises the handle's stream.  A solve whose
  * solution is not finite leaves (0, 0, 0) behind, i.e. the next tick of that problem is a cold start (OSQP's store_solution()
- * cold-starts its iterates after a failed solve), so one bad tick cannot poison the ticks after it. */
+ * cold-starts its iterates after a failed solve), so one bad tick cannot poison the ticks after it.  With warm_start = 2 an injected state also clears the
+ * update path's carry of these problems: their next tick is a fresh set-up warm-started from (x, y, rho), the ticks after it follow the update path again. */
 a1mpc_status a1mpc_warm_start(a1mpc_handle h, int32_t n, const double* x, const double* y, const double* rho);
 a1mpc_status a1mpc_get_warm_start(a1mpc_handle h, int32_t n, double* x_out, double* y_out, double* rho_out);
 
