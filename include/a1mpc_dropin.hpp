@@ -56,6 +56,7 @@ class ConvexMpcGpu {
         mu = 0.3; fz_min = 0.0; fz_max = 0.0;                             // S/ConvexMpc.cpp:8-10
         a1mpc_default_config(&cfg_);
         cfg_.horizon = H;
+        cfg_.warm_start = 2;   // a persistent solver that is updated and re-solved every tick = OSQP's update path (S/A1RobotControl.cpp:533-538); config().warm_start = 0 for one-off solves
         for (int i = 0; i < NS; ++i) cfg_.q[i] = q_weights_(i);
         for (int i = 0; i < NU; ++i) cfg_.r[i] = r_weights_(i);
         linear_constraints.resize(NC * H, NU * H);                        // S/ConvexMpc.cpp:46-58
