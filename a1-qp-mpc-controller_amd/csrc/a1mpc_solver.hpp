@@ -609,6 +609,11 @@ struct RowSolver {
         using CR = Carry<H>;
         upd = false;
         if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) upd = P.warm_start == 2 && io.carry != nullptr && io.warm_x != nullptr && io.warm_y != nullptr && io.carry[CR::C] > 0.0;
+        [[maybe_unused]] double gq[(UPD && MODE == kModeMpc && H > 1 && !GEN) ? H : 1];   // the gradient the cost normalisation sees: the previous tick's on the update path
+        if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) {
+#pragma unroll
+            for (int t = 0; t < H; ++t) gq[t] = upd ? (act ? io.carry[CR::G + t * 12 + ci] : 0.0) : g[t];
+        }
         double D[H], E0[H], E1[H];
         csc = 1.0;
 #pragma unroll
@@ -759,7 +764,7 @@ struct RowSolver {
 #pragma unroll
                 for (int t = 0; t < H; ++t) {
                     sum += csc * D[t] * m[t];
-                    if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) nq = fmax(nq, fabs(csc * D[t] * ((upd && act) ? io.carry[CR::G + t * 12 + ci] : (upd ? 0.0 : g[t]))));
+                    if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) nq = fmax(nq, fabs(csc * D[t] * gq[t]));
                     else nq = fmax(nq, fabs(csc * D[t] * g[t]));
                 }
                 const double mean = row_allsum(sum) / double(12 * H);
