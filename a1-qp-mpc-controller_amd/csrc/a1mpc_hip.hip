@@ -2489,7 +2489,12 @@ a1mpc_status a1mpc_pipeline_create(const a1mpc_config* cfg, int32_t max_batch, i
     *out = nullptr;
     a1mpc_pipeline p = new (std::nothrow) a1mpc_pipeline_s();
     if (!p) return fail(A1MPC_ERR_HIP, "out of host memory");
-    p->device = device; p->depth = depth == 0 ? 2 : depth;
+    p->device = device; p->depth = depth;
+    if (depth == 0) {   // default: two batches in flight; three when max_batch runs the fused kernel (no set-up kernel to wait for: 2048 x h10 5.7 M solves/s at depth 2, 6.1-6.3 M at 3)
+        bool split = true;
+        if (hipSetDevice(device) == hipSuccess) (void)use_split_pipeline(cfg->horizon, max_batch, true, &split);
+        p->depth = split ? 2 : 3;
+    }
     for (int k = 0; k < p->depth; ++k) {
         a1mpc_handle hk = nullptr;
         const a1mpc_status st = a1mpc_create(cfg, max_batch, device, &hk);
