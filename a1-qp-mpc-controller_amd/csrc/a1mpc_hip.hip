@@ -27,6 +27,9 @@
 #include "a1mpc_solver.hpp"
 #include "a1mpc_tables.hpp"
 
+#ifdef A1MPC_DEV_SLIM
+#define A1_SLIM_H ((A1MPC_DEV_SLIM + 0) >= 10 ? (A1MPC_DEV_SLIM + 0) : 10)   // the one horizon a kernel-tuning build serves (split pipeline only)
+#endif
 namespace a1mpc {
 
 using KernelArgs = BatchArgs;
@@ -113,7 +116,8 @@ constexpr bool admm_twin_rows(int h, int rows) { return twin_rows(h, kModeMpc, r
 #endif  // the wavefront's spare rows run as twins (RowSolver<.., TWIN>)
 // UPD: the instantiation that also serves warm_start = 2 (the reference's update path); every other mode runs UPD = false, whose code is what it was before
 // the update path existed (the allocation of the hot loop is sensitive to anything around it: a1mpc_solver.hpp, load_prepared)
-template <int H, int ROWS, bool UPD = false>
+// UNI: contacts broadcast over the horizon (contact_stride = 0): one pair of bounds for every slot (RowSolver<.., UNI>; built for H >= 16, where the registers matter)
+template <int H, int ROWS, bool UPD = false, bool UNI = false>
 __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     // ROWS <= 2: the wavefront's other rows run as twins of the QP rows (rows r and r + 2 share a QP and its LDS image, see row_is_twin)
@@ -121,9 +125,9 @@ __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, cons
     const int row = static_cast<int>(threadIdx.x) >> 4;
     if constexpr (kTwin) {
         if ((row & 1) >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
-        admm_rows<H, true, false, UPD>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H>::ROW_STRIDE);
+        admm_rows<H, true, false, UPD, UNI>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H>::ROW_STRIDE);
     } else {
-        admm_rows<H, false, false, UPD>(a, prep, counter, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+        admm_rows<H, false, false, UPD, UNI>(a, prep, counter, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
     }
 }
 
@@ -360,25 +364,8 @@ static int pipeline_mode() {  // 0 = auto, 1 = always split, 2 = always fused
     return m;
 }
 
-// workgroups of the persistent ADMM kernel that are resident at once on the current device (occupancy query, cached per device)
-template <int H, int ROWS>
-static a1mpc_status resident_workgroups(int* out) {
-    static int resident[64] = {};
-    int dev = 0;
-    A1_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) { *out = 512; return A1MPC_OK; }
-    if (!resident[dev]) {
-        const size_t lds2 = lds_bytes<H>(ROWS);
-        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(lds2)));
-        int per_cu = 0, cus = 0;
-        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS, lds2));
-        A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        resident[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
-    }
-    *out = resident[dev];
-    return A1MPC_OK;
-}
+// per-device caches below (occupancy, attribute-set flags) are shared by every handle of the process: handles of different threads are independent (a1mpc.h), so they are guarded
+static std::mutex g_cache_mu;
 // dynamic-LDS limit of a kernel, once per device and kernel
 static a1mpc_status set_lds_attr(const void* fn, size_t bytes) {
     static std::vector<std::pair<const void*, int>> done;
@@ -391,12 +378,32 @@ static a1mpc_status set_lds_attr(const void* fn, size_t bytes) {
     done.emplace_back(fn, dev);
     return A1MPC_OK;
 }
+// workgroups of the persistent ADMM kernel that are resident at once on the current device (occupancy query, cached per device)
+template <int H, int ROWS>
+static a1mpc_status resident_workgroups(int* out) {
+    static int resident[64] = {};
+    int dev = 0;
+    A1_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { *out = 512; return A1MPC_OK; }
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    if (!resident[dev]) {
+        const size_t lds2 = lds_bytes<H>(ROWS);
+        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds2)));
+        int per_cu = 0, cus = 0;
+        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS, lds2));
+        A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        resident[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    }
+    *out = resident[dev];
+    return A1MPC_OK;
+}
 template <int H>
 static a1mpc_status resident_rows(int* out) {
     int wg = 0;
     a1mpc_status st;
 #ifdef A1MPC_DEV_SLIM
-    st = resident_workgroups<H, 2>(&wg); *out = 2 * wg;
+    st = resident_workgroups<H, default_rows_per_wg(H)>(&wg); *out = default_rows_per_wg(H) * wg;
 #else
 #ifdef A1MPC_ALL_ROWS
     switch (rows_per_wg(H)) {
@@ -441,14 +448,23 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
             hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
         }
     }
-    if (!upd_kernels) hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
+    bool uni_kernel = false;   // broadcast contacts at H >= 16: the instantiation with one pair of bounds for all slots
+    constexpr bool kHasUni = H >= 16 && ROWS == default_rows_per_wg(H) && admm_twin_rows(H, ROWS);
+    if constexpr (kHasUni) {
+        uni_kernel = !upd_kernels && a.contact_stride == 0;
+        if (uni_kernel) {
+            if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, true>), lds2); st != A1MPC_OK) return st;
+            hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
+        }
+    }
+    if (!upd_kernels && !uni_kernel) hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
 }
 template <int H>
 static a1mpc_status launch_split(const KernelArgs& a, double* prep, int* counter, hipStream_t stream, hipEvent_t mid) {
-#ifdef A1MPC_DEV_SLIM  // kernel-tuning builds: one instantiation (H = 10, two rows), seconds instead of minutes to compile
-    return launch_split_rows<H, 2>(a, prep, counter, stream, mid);
+#ifdef A1MPC_DEV_SLIM  // kernel-tuning builds: the split pipeline of ONE horizon (-DA1MPC_DEV_SLIM: 10; -DA1MPC_DEV_SLIM=16 / =20), a minute or two instead of five to compile
+    return launch_split_rows<H, default_rows_per_wg(H)>(a, prep, counter, stream, mid);
 #else
 #ifdef A1MPC_ALL_ROWS
     if (a.carry == nullptr) {   // (the update-path kernels exist for the default rows per workgroup only)
@@ -485,10 +501,13 @@ static a1mpc_status launch_rows(const KernelArgs& a, hipStream_t stream) {
     static bool attr_set[64] = {};
     int dev = 0;
     A1_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE, ROWS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes<H>(ROWS))));
-        attr_set[dev] = true;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE, ROWS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes<H>(ROWS))));
+            attr_set[dev] = true;
+        }
     }
     const unsigned grid = static_cast<unsigned>((a.n + ROWS - 1) / ROWS);
     if constexpr (MODE == kModeMpc && H > 1 && ROWS == default_rows_per_wg(H)) {
@@ -509,10 +528,13 @@ static a1mpc_status launch_gen_rows(const KernelArgs& a, hipStream_t stream) {
     int dev = 0;
     A1_HIP(hipGetDevice(&dev));
     const size_t lds = sizeof(double) * ROWS * Layout<H, true>::ROW_STRIDE;
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_gen_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(lds)));
-        attr_set[dev] = true;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_gen_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds)));
+            attr_set[dev] = true;
+        }
     }
     hipLaunchKernelGGL((a1mpc_solve_gen_kernel<H, ROWS>), dim3(static_cast<unsigned>((a.n + ROWS - 1) / ROWS)), dim3(64), lds, stream, a);
     A1_HIP(hipGetLastError());
@@ -525,6 +547,7 @@ static a1mpc_status resident_workgroups_gen(int* out) {
     int dev = 0;
     A1_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(A1MPC_ERR_HIP, "device index out of range");
+    std::lock_guard<std::mutex> lock(g_cache_mu);
     if (!resident[dev]) {
         const size_t lds = sizeof(double) * ROWS * Layout<H, true>::ROW_STRIDE;
         A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_gen_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
@@ -543,9 +566,12 @@ static a1mpc_status launch_gen_split_rows(const KernelArgs& a, double* prep, int
     int dev = 0;
     A1_HIP(hipGetDevice(&dev));
     const size_t lds1 = sizeof(double) * (4 * LayoutSetup<H, true>::ROW_STRIDE + 2 * H * H), lds2 = sizeof(double) * ROWS * Layout<H, true>::ROW_STRIDE;
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_setup_gen_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds1)));
-        attr_set[dev] = true;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_setup_gen_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds1)));
+            attr_set[dev] = true;
+        }
     }
     A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
     hipLaunchKernelGGL((a1mpc_setup_gen_kernel<H>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
@@ -610,10 +636,13 @@ static a1mpc_status launch_coop(const KernelArgs& a, hipStream_t stream) {
     static bool attr_set[64] = {};
     int dev = 0;
     A1_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_coop_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(lds_bytes<H>(1))));
-        attr_set[dev] = true;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_coop_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes<H>(1))));
+            attr_set[dev] = true;
+        }
     }
     if (a.carry != nullptr) {   // warm_start = 2: the update-path instantiation
         if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_coop_kernel<H, true>), lds_bytes<H>(1)); st != A1MPC_OK) return st;
@@ -653,8 +682,10 @@ static a1mpc_status use_split_pipeline(int horizon, int n, bool have_prep, bool*
     int rows = 0;
     a1mpc_status st = A1MPC_OK;
     switch (horizon) {
+#ifdef A1MPC_DEV_SLIM
+        case A1_SLIM_H: st = resident_rows<A1_SLIM_H>(&rows); break;
+#else
         case 10: st = resident_rows<10>(&rows); break;
-#ifndef A1MPC_DEV_SLIM
         case 1: st = resident_rows<1>(&rows); break;
         case 16: st = resident_rows<16>(&rows); break;
         case 20: st = resident_rows<20>(&rows); break;
@@ -668,8 +699,10 @@ static a1mpc_status use_split_pipeline(int horizon, int n, bool have_prep, bool*
 static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s, bool split, hipEvent_t mid) {
     if (split && prep && counter) {
         switch (horizon) {
+#ifdef A1MPC_DEV_SLIM
+            case A1_SLIM_H: return launch_split<A1_SLIM_H>(a, prep, counter, s, mid);
+#else
             case 10: return launch_split<10>(a, prep, counter, s, mid);
-#ifndef A1MPC_DEV_SLIM
             case 1: return launch_split<1>(a, prep, counter, s, mid);
             case 16: return launch_split<16>(a, prep, counter, s, mid);
             case 20: return launch_split<20>(a, prep, counter, s, mid);
@@ -1772,6 +1805,7 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     // One-time, per process: the first launches / copies through a fresh HIP runtime cost milliseconds (code-object load, pool set-up);
     // a 400 Hz loop should not pay that on its first tick (measured 5 ms -> 0.4 ms), so the tick's operation mix is exercised here.
     static bool runtime_warmed_dev[64] = {};   // per device: a sharded handle (a1mpc_sharded_*) creates one engine handle on every GPU of the node
+    std::unique_lock<std::mutex> warm_lock(g_cache_mu);   // (handles may be created from several threads)
     bool& runtime_warmed = runtime_warmed_dev[device < 64 ? device : 63];
     if (!runtime_warmed) {
         for (int i = 0; i < 256; ++i) {  // the operation mix of a tick: copies both ways from pinned memory, memset, launches, events
@@ -1787,6 +1821,7 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
         A1_TRY(hipStreamSynchronize(h->stream));
         runtime_warmed = true;
     }
+    warm_lock.unlock();
 #undef A1_TRY
     *out = h;
     return A1MPC_OK;
@@ -1799,6 +1834,13 @@ a1mpc_status a1mpc_update_config(a1mpc_handle h, const a1mpc_config* cfg) {
         return fail(A1MPC_ERR_INVALID_ARGUMENT, "dt, mass, rho, sigma and max_iter must be positive");
     // every constant travels to the kernels by value with each launch: nothing on the device has to change, launches already
     // queued keep the values they were issued with, the carried warm start stays
+    if (cfg->warm_start != h->cfg.warm_start && h->d_carry) {
+        // leaving or entering the update path: ticks solved in another mode do not refresh its carry (previous scalings / gradient / z), so what is there is stale
+        A1_HIP(hipSetDevice(h->device));
+        A1_ORDER(h, h->stream);
+        A1_HIP(hipMemsetAsync(h->d_carry, 0, static_cast<size_t>(h->max_batch) * carry_stride(h->cfg.horizon) * sizeof(double), h->stream));
+        A1_MARK(h, h->stream);
+    }
     h->cfg = *cfg;
     to_device_params(*cfg, &h->dp);
     return A1MPC_OK;
@@ -1885,6 +1927,13 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     if (foot_stride != 0 || d_yaw_A != nullptr) {  // general path: per-step B_d (and / or its own A_c yaw), with or without a contact schedule
         if (d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "per-step feet / contacts are not combined with tick records");
         a.foot_stride = foot_stride; a.contact_stride = contact_stride; a.yaw_A = d_yaw_A;
+        // The general kernels solve on warm_start = 1 semantics: they rewrite the carried (x, y, rho) of these problems but neither read nor refresh the update
+        // path's carry (previous scalings, gradient, z).  A carry left standing would pair tick k - 2's scalings with tick k - 1's iterates on the next
+        // fast-path tick: mark "no previous tick" (field C of every record) instead -- that tick is then a fresh set-up warm-started from (x, y, rho).
+        if (a.carry != nullptr) {
+            A1_HIP(hipMemset2DAsync(h->d_carry, carry_stride(h->cfg.horizon) * sizeof(double), 0, sizeof(double), static_cast<size_t>(n), s));
+            a.carry = nullptr;
+        }
         // a batch beyond the resident rows of the general path's ADMM kernel runs its split pipeline (set-up kernel + persistent rows on a queue, like the
         // fast path); its hand-off records (B~w_t of every step included) live in a buffer of their own, allocated on first use
         int rows_gen = 0;
@@ -1974,22 +2023,25 @@ a1mpc_status a1mpc_solve_batch_ticks(a1mpc_handle h, int32_t n, const double* ti
     return A1MPC_OK;
 }
 
-a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
-                               const double* foot_abs, const uint8_t* contact, double* grf_body_out, double* u_full_out,
-                               int32_t* iters_out, int32_t* status_out) {
-    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
-    if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !grf_body_out)
-        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
-    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
-    if (n == 0) return A1MPC_OK;
+// The host-pointer MPC entry in two halves, so that a pipeline slot can leave a batch in flight (a1mpc_pipeline_submit):
+//   host_submit   snapshot the caller's arrays into ONE pinned block (the caller's program mutates them concurrently) laid out exactly like the device
+//                 block, one H2D copy, the launches, one D2H copy into the pinned mirror -- all queued on the handle's stream, nothing waited for
+//                 (a tick is one H2D copy, one memset, two launches and one D2H copy -- API calls, not bytes, set batch-1 latency);
+//   host_collect  (after the stream has drained) the pinned mirror into the caller's output arrays.
+struct HostOut { size_t q_grf, q_it, q_st, q_u; };
+static HostOut host_out_layout(size_t N) {
+    HostOut o;
+    o.q_grf = 0; o.q_it = o.q_grf + N * 12 * sizeof(double); o.q_st = o.q_it + N * sizeof(int32_t); o.q_u = o.q_st + N * sizeof(int32_t);
+    return o;
+}
+static a1mpc_status host_submit(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world, const double* foot_abs,
+                                const uint8_t* contact, bool want_u) {
     A1_HIP(hipSetDevice(h->device));
     const size_t N = n, H = h->cfg.horizon;
-    // snapshot the caller's arrays into ONE pinned block (the caller's program mutates them concurrently) laid out exactly like the
-    // device block, so a tick is one H2D copy, one memset, two launches and one D2H copy -- API calls, not bytes, set batch-1 latency
     const size_t o_x0 = 0, o_xr = o_x0 + N * 13 * sizeof(double), o_R = o_xr + N * 13 * H * sizeof(double),
                  o_f = o_R + N * 9 * sizeof(double), o_c = o_f + N * 12 * sizeof(double), in_bytes = o_c + N * 4;
-    const size_t q_grf = 0, q_it = q_grf + N * 12 * sizeof(double), q_st = q_it + N * sizeof(int32_t), q_u = q_st + N * sizeof(int32_t),
-                 out_bytes = u_full_out ? q_u + N * 12 * H * sizeof(double) : q_u;
+    const HostOut q = host_out_layout(N);
+    const size_t out_bytes = want_u ? q.q_u + N * 12 * H * sizeof(double) : q.q_u;
     char* hin = h->h_pin;
     char* hout = h->h_pin + h->h_pin_in_bytes;
     std::memcpy(hin + o_x0, x0, N * 13 * sizeof(double));
@@ -2003,16 +2055,34 @@ a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, cons
     a1mpc_status st = a1mpc_solve_batch_device(
         h, n, reinterpret_cast<const double*>(h->d_in + o_x0), reinterpret_cast<const double*>(h->d_in + o_xr),
         reinterpret_cast<const double*>(h->d_in + o_R), reinterpret_cast<const double*>(h->d_in + o_f),
-        reinterpret_cast<const uint8_t*>(h->d_in + o_c), reinterpret_cast<double*>(h->d_out + q_grf),
-        u_full_out ? reinterpret_cast<double*>(h->d_out + q_u) : nullptr, reinterpret_cast<int32_t*>(h->d_out + q_it),
-        reinterpret_cast<int32_t*>(h->d_out + q_st), s);
+        reinterpret_cast<const uint8_t*>(h->d_in + o_c), reinterpret_cast<double*>(h->d_out + q.q_grf),
+        want_u ? reinterpret_cast<double*>(h->d_out + q.q_u) : nullptr, reinterpret_cast<int32_t*>(h->d_out + q.q_it),
+        reinterpret_cast<int32_t*>(h->d_out + q.q_st), s);
     if (st != A1MPC_OK) return st;
     A1_HIP(hipMemcpyAsync(hout, h->d_out, out_bytes, hipMemcpyDeviceToHost, s));
-    A1_HIP(hipStreamSynchronize(s));
-    std::memcpy(grf_body_out, hout + q_grf, N * 12 * sizeof(double));
-    if (u_full_out) std::memcpy(u_full_out, hout + q_u, N * 12 * H * sizeof(double));
-    if (iters_out) std::memcpy(iters_out, hout + q_it, N * sizeof(int32_t));
-    if (status_out) std::memcpy(status_out, hout + q_st, N * sizeof(int32_t));
+    return A1MPC_OK;
+}
+static void host_collect(a1mpc_handle h, int32_t n, double* grf_body_out, double* u_full_out, int32_t* iters_out, int32_t* status_out) {
+    const size_t N = n, H = h->cfg.horizon;
+    const HostOut q = host_out_layout(N);
+    const char* hout = h->h_pin + h->h_pin_in_bytes;
+    std::memcpy(grf_body_out, hout + q.q_grf, N * 12 * sizeof(double));
+    if (u_full_out) std::memcpy(u_full_out, hout + q.q_u, N * 12 * H * sizeof(double));
+    if (iters_out) std::memcpy(iters_out, hout + q.q_it, N * sizeof(int32_t));
+    if (status_out) std::memcpy(status_out, hout + q.q_st, N * sizeof(int32_t));
+}
+
+a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
+                               const double* foot_abs, const uint8_t* contact, double* grf_body_out, double* u_full_out,
+                               int32_t* iters_out, int32_t* status_out) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !grf_body_out)
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    if (a1mpc_status st = host_submit(h, n, x0, x_ref, R_world, foot_abs, contact, u_full_out != nullptr); st != A1MPC_OK) return st;
+    A1_HIP(hipStreamSynchronize(h->stream));
+    host_collect(h, n, grf_body_out, u_full_out, iters_out, status_out);
     return A1MPC_OK;
 }
 
@@ -2368,93 +2438,112 @@ a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double*
     uint8_t* p_c = reinterpret_cast<uint8_t*>(p);
     std::memcpy(p_x0, x0, N * 13 * sizeof(double)); std::memcpy(p_xr, x_ref, N * 13 * H * sizeof(double)); std::memcpy(p_R, R_world, N * 9 * sizeof(double));
     std::memcpy(p_f, foot_abs, N * 12 * sizeof(double)); std::memcpy(p_c, contact, N * 4);
+    // Error handling of a multi-device call: nothing may be left behind -- an open RCCL group is closed and every shard's stream is drained (their async copies
+    // target the shared pinned mirror, which the next call overwrites) before the status goes back to the caller.
+    bool group_open = false;
+    auto drain = [&]() {
+        if (group_open && g_rccl.GroupEnd) { (void)g_rccl.GroupEnd(); group_open = false; }
+        for (size_t g = 0; g < G; ++g) { if (hipSetDevice(S->h[g]->device) == hipSuccess) (void)hipStreamSynchronize(S->h[g]->stream); }
+    };
+#define A1_SH_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { drain(); return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
+#define A1_SH_ST(call) do { a1mpc_status s_ = (call); if (s_ != A1MPC_OK) { drain(); return s_; } } while (0)
     if (S->transport == 0) {
         for (size_t g = 0; g < G; ++g) {   // everything asynchronous: the G devices copy and solve concurrently
             int s0 = 0, c = 0;
             shard_range(n, static_cast<int>(g), static_cast<int>(G), &s0, &c);
             if (c == 0) continue;
             a1mpc_handle h = S->h[g];
-            A1_HIP(hipSetDevice(h->device));
+            A1_SH_HIP(hipSetDevice(h->device));
             hipStream_t st = h->stream;
-            A1_ORDER(h, st);
+            A1_SH_ST(order_streams(h, st));
             const size_t o = s0, C = c;
-            A1_HIP(hipMemcpyAsync(h->d_x0, p_x0 + o * 13, C * 13 * sizeof(double), hipMemcpyHostToDevice, st));
-            A1_HIP(hipMemcpyAsync(h->d_xref, p_xr + o * 13 * H, C * 13 * H * sizeof(double), hipMemcpyHostToDevice, st));
-            A1_HIP(hipMemcpyAsync(h->d_R, p_R + o * 9, C * 9 * sizeof(double), hipMemcpyHostToDevice, st));
-            A1_HIP(hipMemcpyAsync(h->d_foot, p_f + o * 12, C * 12 * sizeof(double), hipMemcpyHostToDevice, st));
-            A1_HIP(hipMemcpyAsync(h->d_contact, p_c + o * 4, C * 4, hipMemcpyHostToDevice, st));
-            if (a1mpc_status rc = solve_device_impl(h, c, nullptr, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_contact, h->d_grf, nullptr, h->d_iters, h->d_status, st); rc != A1MPC_OK) return rc;
-            A1_HIP(hipMemcpyAsync(p_grf + o * 12, h->d_grf, C * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
-            A1_HIP(hipMemcpyAsync(p_it + o, h->d_iters, C * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            A1_HIP(hipMemcpyAsync(p_st + o, h->d_status, C * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            A1_SH_HIP(hipMemcpyAsync(h->d_x0, p_x0 + o * 13, C * 13 * sizeof(double), hipMemcpyHostToDevice, st));
+            A1_SH_HIP(hipMemcpyAsync(h->d_xref, p_xr + o * 13 * H, C * 13 * H * sizeof(double), hipMemcpyHostToDevice, st));
+            A1_SH_HIP(hipMemcpyAsync(h->d_R, p_R + o * 9, C * 9 * sizeof(double), hipMemcpyHostToDevice, st));
+            A1_SH_HIP(hipMemcpyAsync(h->d_foot, p_f + o * 12, C * 12 * sizeof(double), hipMemcpyHostToDevice, st));
+            A1_SH_HIP(hipMemcpyAsync(h->d_contact, p_c + o * 4, C * 4, hipMemcpyHostToDevice, st));
+            A1_SH_ST(solve_device_impl(h, c, nullptr, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_contact, h->d_grf, nullptr, h->d_iters, h->d_status, st));
+            A1_SH_HIP(hipMemcpyAsync(p_grf + o * 12, h->d_grf, C * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+            A1_SH_HIP(hipMemcpyAsync(p_it + o, h->d_iters, C * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            A1_SH_HIP(hipMemcpyAsync(p_st + o, h->d_status, C * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         }
-        for (size_t g = 0; g < G; ++g) { A1_HIP(hipSetDevice(S->h[g]->device)); A1_HIP(hipStreamSynchronize(S->h[g]->stream)); }
+        for (size_t g = 0; g < G; ++g) { A1_SH_HIP(hipSetDevice(S->h[g]->device)); A1_SH_HIP(hipStreamSynchronize(S->h[g]->stream)); }
     } else {
-#define A1_NCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); } while (0)
+        // every RCCL call is issued with the device of ITS communicator current (one thread drives all the communicators of ncclCommInitAll: the stream
+        // handed to a call belongs to that device)
+#define A1_NCCL(dev, call) do { A1_SH_HIP(hipSetDevice(dev)); ncclResult_t r_ = (call); if (r_ != ncclSuccess) { drain(); return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); } } while (0)
         a1mpc_handle h0 = S->h[0];
-        A1_HIP(hipSetDevice(h0->device));
+        const int dev0 = h0->device;
+        A1_SH_HIP(hipSetDevice(dev0));
         hipStream_t s0 = h0->stream;
-        A1_ORDER(h0, s0);
-        A1_HIP(hipMemcpyAsync(S->r_x0, p_x0, N * 13 * sizeof(double), hipMemcpyHostToDevice, s0));
-        A1_HIP(hipMemcpyAsync(S->r_xref, p_xr, N * 13 * H * sizeof(double), hipMemcpyHostToDevice, s0));
-        A1_HIP(hipMemcpyAsync(S->r_R, p_R, N * 9 * sizeof(double), hipMemcpyHostToDevice, s0));
-        A1_HIP(hipMemcpyAsync(S->r_foot, p_f, N * 12 * sizeof(double), hipMemcpyHostToDevice, s0));
-        A1_HIP(hipMemcpyAsync(S->r_contact, p_c, N * 4, hipMemcpyHostToDevice, s0));
+        A1_SH_ST(order_streams(h0, s0));
+        A1_SH_HIP(hipMemcpyAsync(S->r_x0, p_x0, N * 13 * sizeof(double), hipMemcpyHostToDevice, s0));
+        A1_SH_HIP(hipMemcpyAsync(S->r_xref, p_xr, N * 13 * H * sizeof(double), hipMemcpyHostToDevice, s0));
+        A1_SH_HIP(hipMemcpyAsync(S->r_R, p_R, N * 9 * sizeof(double), hipMemcpyHostToDevice, s0));
+        A1_SH_HIP(hipMemcpyAsync(S->r_foot, p_f, N * 12 * sizeof(double), hipMemcpyHostToDevice, s0));
+        A1_SH_HIP(hipMemcpyAsync(S->r_contact, p_c, N * 4, hipMemcpyHostToDevice, s0));
+        for (size_t g = 1; g < G; ++g) { A1_SH_HIP(hipSetDevice(S->h[g]->device)); A1_SH_ST(order_streams(S->h[g], S->h[g]->stream)); }
         // scatter: shard g > 0 receives its slice of every field from shard 0's device (root drives all its xGMI links concurrently)
-        A1_NCCL(g_rccl.GroupStart());
+        A1_NCCL(dev0, g_rccl.GroupStart()); group_open = true;
         for (size_t g = 1; g < G; ++g) {
             int st0 = 0, c = 0;
             shard_range(n, static_cast<int>(g), static_cast<int>(G), &st0, &c);
             if (c == 0) continue;
             a1mpc_handle h = S->h[g];
             const size_t o = st0, C = c;
-            A1_NCCL(g_rccl.Send(S->r_x0 + o * 13, C * 13, ncclFloat64, static_cast<int>(g), S->comm[0], s0));
-            A1_NCCL(g_rccl.Send(S->r_xref + o * 13 * H, C * 13 * H, ncclFloat64, static_cast<int>(g), S->comm[0], s0));
-            A1_NCCL(g_rccl.Send(S->r_R + o * 9, C * 9, ncclFloat64, static_cast<int>(g), S->comm[0], s0));
-            A1_NCCL(g_rccl.Send(S->r_foot + o * 12, C * 12, ncclFloat64, static_cast<int>(g), S->comm[0], s0));
-            A1_NCCL(g_rccl.Send(S->r_contact + o * 4, C * 4, ncclUint8, static_cast<int>(g), S->comm[0], s0));
-            A1_NCCL(g_rccl.Recv(h->d_x0, C * 13, ncclFloat64, 0, S->comm[g], h->stream));
-            A1_NCCL(g_rccl.Recv(h->d_xref, C * 13 * H, ncclFloat64, 0, S->comm[g], h->stream));
-            A1_NCCL(g_rccl.Recv(h->d_R, C * 9, ncclFloat64, 0, S->comm[g], h->stream));
-            A1_NCCL(g_rccl.Recv(h->d_foot, C * 12, ncclFloat64, 0, S->comm[g], h->stream));
-            A1_NCCL(g_rccl.Recv(h->d_contact, C * 4, ncclUint8, 0, S->comm[g], h->stream));
+            const int gi = static_cast<int>(g);
+            A1_NCCL(dev0, g_rccl.Send(S->r_x0 + o * 13, C * 13, ncclFloat64, gi, S->comm[0], s0));
+            A1_NCCL(dev0, g_rccl.Send(S->r_xref + o * 13 * H, C * 13 * H, ncclFloat64, gi, S->comm[0], s0));
+            A1_NCCL(dev0, g_rccl.Send(S->r_R + o * 9, C * 9, ncclFloat64, gi, S->comm[0], s0));
+            A1_NCCL(dev0, g_rccl.Send(S->r_foot + o * 12, C * 12, ncclFloat64, gi, S->comm[0], s0));
+            A1_NCCL(dev0, g_rccl.Send(S->r_contact + o * 4, C * 4, ncclUint8, gi, S->comm[0], s0));
+            A1_NCCL(h->device, g_rccl.Recv(h->d_x0, C * 13, ncclFloat64, 0, S->comm[g], h->stream));
+            A1_NCCL(h->device, g_rccl.Recv(h->d_xref, C * 13 * H, ncclFloat64, 0, S->comm[g], h->stream));
+            A1_NCCL(h->device, g_rccl.Recv(h->d_R, C * 9, ncclFloat64, 0, S->comm[g], h->stream));
+            A1_NCCL(h->device, g_rccl.Recv(h->d_foot, C * 12, ncclFloat64, 0, S->comm[g], h->stream));
+            A1_NCCL(h->device, g_rccl.Recv(h->d_contact, C * 4, ncclUint8, 0, S->comm[g], h->stream));
         }
-        A1_NCCL(g_rccl.GroupEnd());
+        group_open = false;
+        A1_NCCL(dev0, g_rccl.GroupEnd());
         // every shard solves on its own stream (stream order: after its receives); shard 0 works in place on the root buffers
         for (size_t g = 0; g < G; ++g) {
             int st0 = 0, c = 0;
             shard_range(n, static_cast<int>(g), static_cast<int>(G), &st0, &c);
             if (c == 0) continue;
             a1mpc_handle h = S->h[g];
-            A1_HIP(hipSetDevice(h->device));
-            a1mpc_status rc;
-            if (g == 0) rc = solve_device_impl(h, c, nullptr, S->r_x0, S->r_xref, S->r_R, S->r_foot, S->r_contact, S->r_grf, nullptr, S->r_iters, S->r_status, h->stream);
-            else rc = solve_device_impl(h, c, nullptr, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_contact, h->d_grf, nullptr, h->d_iters, h->d_status, h->stream);
-            if (rc != A1MPC_OK) return rc;
+            A1_SH_HIP(hipSetDevice(h->device));
+            if (g == 0) A1_SH_ST(solve_device_impl(h, c, nullptr, S->r_x0, S->r_xref, S->r_R, S->r_foot, S->r_contact, S->r_grf, nullptr, S->r_iters, S->r_status, h->stream));
+            else A1_SH_ST(solve_device_impl(h, c, nullptr, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_contact, h->d_grf, nullptr, h->d_iters, h->d_status, h->stream));
         }
         // gather: results of shard g > 0 back to their slice of the root buffers
-        A1_NCCL(g_rccl.GroupStart());
+        A1_NCCL(dev0, g_rccl.GroupStart()); group_open = true;
         for (size_t g = 1; g < G; ++g) {
             int st0 = 0, c = 0;
             shard_range(n, static_cast<int>(g), static_cast<int>(G), &st0, &c);
             if (c == 0) continue;
             a1mpc_handle h = S->h[g];
             const size_t o = st0, C = c;
-            A1_NCCL(g_rccl.Send(h->d_grf, C * 12, ncclFloat64, 0, S->comm[g], h->stream));
-            A1_NCCL(g_rccl.Send(h->d_iters, C, ncclInt32, 0, S->comm[g], h->stream));
-            A1_NCCL(g_rccl.Send(h->d_status, C, ncclInt32, 0, S->comm[g], h->stream));
-            A1_NCCL(g_rccl.Recv(S->r_grf + o * 12, C * 12, ncclFloat64, static_cast<int>(g), S->comm[0], s0));
-            A1_NCCL(g_rccl.Recv(S->r_iters + o, C, ncclInt32, static_cast<int>(g), S->comm[0], s0));
-            A1_NCCL(g_rccl.Recv(S->r_status + o, C, ncclInt32, static_cast<int>(g), S->comm[0], s0));
+            const int gi = static_cast<int>(g);
+            A1_NCCL(h->device, g_rccl.Send(h->d_grf, C * 12, ncclFloat64, 0, S->comm[g], h->stream));
+            A1_NCCL(h->device, g_rccl.Send(h->d_iters, C, ncclInt32, 0, S->comm[g], h->stream));
+            A1_NCCL(h->device, g_rccl.Send(h->d_status, C, ncclInt32, 0, S->comm[g], h->stream));
+            A1_NCCL(dev0, g_rccl.Recv(S->r_grf + o * 12, C * 12, ncclFloat64, gi, S->comm[0], s0));
+            A1_NCCL(dev0, g_rccl.Recv(S->r_iters + o, C, ncclInt32, gi, S->comm[0], s0));
+            A1_NCCL(dev0, g_rccl.Recv(S->r_status + o, C, ncclInt32, gi, S->comm[0], s0));
         }
-        A1_NCCL(g_rccl.GroupEnd());
-        A1_HIP(hipSetDevice(h0->device));
-        A1_HIP(hipMemcpyAsync(p_grf, S->r_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s0));
-        A1_HIP(hipMemcpyAsync(p_it, S->r_iters, N * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
-        A1_HIP(hipMemcpyAsync(p_st, S->r_status, N * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
-        for (size_t g = 0; g < G; ++g) { A1_HIP(hipSetDevice(S->h[g]->device)); A1_HIP(hipStreamSynchronize(S->h[g]->stream)); }
+        group_open = false;
+        A1_NCCL(dev0, g_rccl.GroupEnd());
+        // the RCCL operations ran on the handles' streams behind their solves: the handles' "last launch" events move with them
+        for (size_t g = 0; g < G; ++g) { A1_SH_HIP(hipSetDevice(S->h[g]->device)); A1_SH_ST(mark_launched(S->h[g], S->h[g]->stream)); }
+        A1_SH_HIP(hipSetDevice(dev0));
+        A1_SH_HIP(hipMemcpyAsync(p_grf, S->r_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s0));
+        A1_SH_HIP(hipMemcpyAsync(p_it, S->r_iters, N * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
+        A1_SH_HIP(hipMemcpyAsync(p_st, S->r_status, N * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
+        for (size_t g = 0; g < G; ++g) { A1_SH_HIP(hipSetDevice(S->h[g]->device)); A1_SH_HIP(hipStreamSynchronize(S->h[g]->stream)); }
 #undef A1_NCCL
     }
+#undef A1_SH_HIP
+#undef A1_SH_ST
     std::memcpy(grf_body_out, p_grf, N * 12 * sizeof(double));
     if (iters_out) std::memcpy(iters_out, p_it, N * sizeof(int32_t));
     if (status_out) std::memcpy(status_out, p_st, N * sizeof(int32_t));
@@ -2473,7 +2562,18 @@ struct a1mpc_pipeline_s {
     std::vector<a1mpc_handle> h;
     std::vector<hipEvent_t> ready, done;   // per slot: "the caller's inputs are ready" (recorded on the caller's stream), "this slot's last submit has finished"
     std::vector<char> used;
+    struct HostPending { int32_t n = 0; double *grf = nullptr, *u = nullptr; int32_t *iters = nullptr, *status = nullptr; };
+    std::vector<HostPending> pending;      // per slot: a host-pointer submit whose outputs are still in the slot's pinned mirror (n = 0: none)
 };
+// a slot's host-pointer batch has to be handed to its caller before the slot's pinned mirror is reused
+static a1mpc_status pipeline_deliver(a1mpc_pipeline p, int k) {
+    a1mpc_pipeline_s::HostPending& q = p->pending[k];
+    if (q.n == 0) return A1MPC_OK;
+    A1_HIP(hipStreamSynchronize(p->h[k]->stream));   // (the slot's stream carries nothing but this batch; the wait a1mpc_solve_batch uses)
+    host_collect(p->h[k], q.n, q.grf, q.u, q.iters, q.status);
+    q = a1mpc_pipeline_s::HostPending();
+    return A1MPC_OK;
+}
 
 void a1mpc_pipeline_destroy(a1mpc_pipeline p) {
     if (!p) return;
@@ -2506,7 +2606,7 @@ a1mpc_status a1mpc_pipeline_create(const a1mpc_config* cfg, int32_t max_batch, i
             a1mpc_pipeline_destroy(p);
             return fail(A1MPC_ERR_HIP, "hipEventCreate (pipeline)");
         }
-        p->ready.push_back(e0); p->done.push_back(e1); p->used.push_back(0);
+        p->ready.push_back(e0); p->done.push_back(e1); p->used.push_back(0); p->pending.emplace_back();
     }
     *out = p;
     return A1MPC_OK;
@@ -2534,6 +2634,7 @@ a1mpc_status a1mpc_pipeline_submit_device(a1mpc_pipeline p, int32_t slot, int32_
     a1mpc_handle h = p->h[k];
     if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_pipeline_create");
     A1_HIP(hipSetDevice(p->device));
+    if (a1mpc_status sd = pipeline_deliver(p, k); sd != A1MPC_OK) return sd;
     if (inputs_ready_stream) {   // the slot's stream starts after everything the caller has queued on that stream so far
         A1_HIP(hipEventRecord(p->ready[k], static_cast<hipStream_t>(inputs_ready_stream)));
         A1_HIP(hipStreamWaitEvent(h->stream, p->ready[k], 0));
@@ -2549,11 +2650,41 @@ a1mpc_status a1mpc_pipeline_submit_device(a1mpc_pipeline p, int32_t slot, int32_
     return A1MPC_OK;
 }
 
+// Host pointers in, host pointers out, and still more than one batch in flight (the reference's boundary is host-side: A1CtrlStates in, a 3x4 matrix
+// out, S/A1RobotControl.h:44): the call snapshots the inputs into the slot's pinned block, queues H2D copy + launches + D2H copy on the slot's stream
+// and returns; a1mpc_pipeline_wait() hands the results to the output arrays given here.  While the GPU solves batch k the caller's thread snapshots
+// batch k + 1 and the copy engines move it.
+a1mpc_status a1mpc_pipeline_submit(a1mpc_pipeline p, int32_t slot, int32_t fresh_batch, int32_t n, const double* x0, const double* x_ref,
+                                   const double* R_world, const double* foot_abs, const uint8_t* contact, double* grf_body_out, double* u_full_out,
+                                   int32_t* iters_out, int32_t* status_out, int32_t* slot_out) {
+    if (!p) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (slot >= p->depth) return fail(A1MPC_ERR_INVALID_ARGUMENT, "slot out of range");
+    if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !grf_body_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    const int k = slot >= 0 ? slot : p->next;
+    a1mpc_handle h = p->h[k];
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_pipeline_create");
+    A1_HIP(hipSetDevice(p->device));
+    if (a1mpc_status sd = pipeline_deliver(p, k); sd != A1MPC_OK) return sd;   // the slot's previous batch leaves its pinned mirror first
+    if (slot_out) *slot_out = k;
+    if (slot < 0) p->next = (p->next + 1) % p->depth;
+    if (n == 0) return A1MPC_OK;
+    if (fresh_batch) h->hint_n = 0;
+    if (a1mpc_status st = host_submit(h, n, x0, x_ref, R_world, foot_abs, contact, u_full_out != nullptr); st != A1MPC_OK) return st;
+    A1_HIP(hipEventRecord(p->done[k], h->stream));
+    p->used[k] = 1;
+    a1mpc_pipeline_s::HostPending& q = p->pending[k];
+    q.n = n; q.grf = grf_body_out; q.u = u_full_out; q.iters = iters_out; q.status = status_out;
+    return A1MPC_OK;
+}
+
 a1mpc_status a1mpc_pipeline_wait(a1mpc_pipeline p, int32_t slot) {
     if (!p || slot >= p->depth) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null pipeline or slot out of range");
     A1_HIP(hipSetDevice(p->device));
     for (int k = 0; k < p->depth; ++k)
-        if ((slot < 0 || slot == k) && p->used[k]) A1_HIP(hipEventSynchronize(p->done[k]));
+        if ((slot < 0 || slot == k) && p->used[k]) {
+            A1_HIP(hipEventSynchronize(p->done[k]));
+            if (a1mpc_status sd = pipeline_deliver(p, k); sd != A1MPC_OK) return sd;
+        }
     return A1MPC_OK;
 }
 

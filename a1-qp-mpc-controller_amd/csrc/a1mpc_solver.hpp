@@ -160,6 +160,55 @@ A1_DEV double row_allsum(double v) {
     return v;
 }
 
+// ---- packed S_t^-1: which of the 78 doubles of a step's S area holds entry (i, j), i >= j ------------------------------------
+// Not row-major triangular: the backward sweep of a twin pair reads "cross" b -- lane ci takes entry (max(ci, b), min(ci, b)) -- with one
+// ds_read_b64, which the LDS serves in two 32-lane groups on 64 dword banks (32 doubles), and the lane group of the twin rows holds TWO QPs
+// whose images lie 16 doubles (mod 32) apart.  With the twelve entries of every cross on twelve different residues mod 16 the 24 reads of a
+// group never share a bank (row-major packing: 21 LDS cycles per 12 reads; SQ_LDS_BANK_CONFLICT was 11.7 % of the ADMM kernel's LDS cycles).
+// Found by tools/sinv_layout_search.py (which also minimises the clashes of the factor pass's stores); checked below at compile time.
+constexpr unsigned char kSinvSlot[78] = {
+    57,
+    49, 15,
+    66,  9, 74,
+     7, 54, 75, 14,
+    76, 26, 30, 50, 36,
+    45, 11, 44, 19, 24,  0,
+     6, 62, 47, 65, 59, 58, 56,
+    42, 55, 64, 52, 38, 41, 77, 21,
+     8, 48, 20, 69, 13, 22, 28, 67, 71,
+    63,  4, 70, 40,  5, 39, 51, 17,  2, 29,
+    68, 72,  3, 12, 16, 34, 53, 31, 25, 27, 33,
+    46, 61,  1, 32, 35, 37, 23, 60, 43, 73, 10, 18,
+};
+constexpr int sinv_slot_ce(int i, int j) { return i >= j ? kSinvSlot[i * (i + 1) / 2 + j] : kSinvSlot[j * (j + 1) / 2 + i]; }
+constexpr bool sinv_slots_ok() {
+    bool used[78] = {};
+    for (int k = 0; k < 78; ++k) {  // a bijection onto the S area
+        if (kSinvSlot[k] >= 78 || used[kSinvSlot[k]]) return false;
+        used[kSinvSlot[k]] = true;
+    }
+    for (int b = 0; b < 12; ++b) {  // every cross on twelve different residues mod 16
+        bool bank[16] = {};
+        for (int c = 0; c < 12; ++c) {
+            const int r = sinv_slot_ce(c, b) % 16;
+            if (bank[r]) return false;
+            bank[r] = true;
+        }
+    }
+    return true;
+}
+static_assert(sinv_slots_ok(), "packed S^-1 slot table");
+// Slot of entry (max(ci, B), min(ci, B)) for a compile-time B and a lane's ci (B = -1: the diagonal entry (ci, ci)): the twelve slots of cross B are
+// packed into two immediates and picked by shifts -- plain arithmetic on ci that the compiler computes once per kernel and keeps in the twelve address
+// registers the triangular formula used to occupy (a table in memory put a load and a branch into every use).
+template <int B>
+A1_DEV int sinv_slot(int ci) {
+    constexpr auto at = [](int c) { return static_cast<unsigned long long>(B < 0 ? sinv_slot_ce(c, c) : sinv_slot_ce(c, B)); };
+    constexpr unsigned long long lo = at(0) | at(1) << 8 | at(2) << 16 | at(3) << 24 | at(4) << 32 | at(5) << 40 | at(6) << 48 | at(7) << 56;
+    constexpr unsigned hi = static_cast<unsigned>(at(8) | at(9) << 8 | at(10) << 16 | at(11) << 24);
+    return ci < 8 ? static_cast<int>((lo >> (8 * ci)) & 0xff) : static_cast<int>((hi >> (8 * (ci - 8))) & 0xff);
+}
+
 // ---- LDS image of one QP ------------------------------------------------------------------------
 // GEN (per-step feet / per-step contact schedules, RowSolver<.., GEN = true>): three more tables per QP behind c*g --
 // the omega rows of B~_t for every step, and the slot-0 bounds of every step.
@@ -167,7 +216,7 @@ template <int H, bool GEN = false>
 struct Layout {
     static constexpr int KSTR = 13;          // padded row stride of K_t: conflict-free row and column reads
     static constexpr int K_SZ = 12 * KSTR;   // 156
-    static constexpr int S_SZ = 78;          // packed lower triangle of S_t^{-1}
+    static constexpr int S_SZ = 78;          // packed S_t^{-1}: the 78 entries i >= j, placed by kSinvSlot
     static constexpr int SLOT = K_SZ + S_SZ; // 234 doubles per horizon step
     static constexpr int FAC = 0;
     static constexpr int GCOL = 12;          // the pad column of K_t's stride-13 rows carries G_t = (c P x + c g)_t, see RowSolver::careful
@@ -263,8 +312,12 @@ struct Prep {
 // a1mpc_rowops.hpp).  The pair shares the control flow (every decision is taken on values both rows hold) and the LDS image; it splits the
 // per-lane ADMM state by horizon step (main row: even steps, twin: odd steps) and the two products of a backward-sweep step
 // (admm_iteration_twin); everything sequential over the steps is computed redundantly by both rows.
-template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false, bool TWIN = false>
+// UNI = true (persistent ADMM kernel, H >= 16): the caller guarantees contacts broadcast over the horizon (contact_stride = 0, what the reference's controller
+// does, S/ConvexMpc.cpp:228-245), so ONE pair of bounds serves every slot and the per-slot pairs (2 HS doubles per lane) leave the register file -- at H = 16
+// the hot loop loses its 8 scratch reloads and 14 of 72 AGPR moves per iteration (8192 x h16 first solve 3.93 -> 3.73 ms).  Same values, same bits.
+template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false, bool TWIN = false, bool UNI = false>
 struct RowSolver {
+    static_assert(!UNI || (!GEN && MODE == kModeMpc), "uniform bounds: the fast path with broadcast contacts");
     static_assert(!GEN || (MODE == kModeMpc && H > 1), "the general path is an MPC solve");
     static_assert(!TWIN || (MODE == kModeMpc && !SETUP_ONLY && H > 1), "twin rows: the iterations of an MPC solve");
     using L = std::conditional_t<SETUP_ONLY, LayoutSetup<H, GEN>, Layout<H, GEN>>;
@@ -273,7 +326,8 @@ struct RowSolver {
     const double* __restrict__ tab;
     double* __restrict__ lds;
     // lane identity
-    int ln, quad, comp, ci, tri, krow;
+    int ln, quad, comp, ci, krow;
+    int mofs[12];     // TWIN: element b of my backward-sweep read inside a step's slot -- K_t[b][ci] on a main row, entry (ci, b) of the packed S_t^-1 on a twin
     bool act, wl;
     bool twin, wr;    // TWIN: second row of the pair / this lane stores what both rows hold (act && !twin)
     int tw;           // 0 / 1: my steps are 2k + tw
@@ -322,8 +376,10 @@ struct RowSolver {
         wr = act && !twin;
         hm = twin ? 0.0 : 1.0;
         ci = act ? 3 * quad + comp : 0;  // compact index (safe 0 on pad lanes)
-        tri = ci * (ci + 1) / 2;
         krow = ci * L::KSTR;
+        // (opaque: twelve loop-invariant address registers with the horizon step in the read's immediate -- left to fold the selects the compiler re-derives
+        // one of them per step, ten registers for one, and the hot loop pays for them in AGPR moves)
+        static_for<12>([&](auto B) { constexpr int b = A1_CV(B); mofs[b] = TWIN ? row_opaque(twin ? L::K_SZ + sinv_slot<b>(ci) : b * L::KSTR + ci) : 0; });
         wl = act && quad >= 2;           // wrench lanes: state rows 6..11 = quads 2, 3
         brow = lds + L::BL + (wl ? ci - 6 : L::ZROW) * 12;
         dt = P.dt; mu = P.mu;
@@ -380,9 +436,9 @@ struct RowSolver {
     A1_DEV double lb_at(int t) const { if constexpr (GEN) return lds[L::LBT + t * 12 + ci]; else return lb0; }  // (GEN callers only)
     A1_DEV double ub_at(int t) const { if constexpr (GEN) return lds[L::UBT + t * 12 + ci]; else return ub0; }
     template <int K>
-    A1_DEV double lbs(int t) const { if constexpr (GEN) return lds[L::LBT + t * 12 + ci]; else return lbk[K]; }  // slot K = horizon step t
+    A1_DEV double lbs(int t) const { if constexpr (GEN) return lds[L::LBT + t * 12 + ci]; else return lbk[UNI ? 0 : K]; }  // slot K = horizon step t
     template <int K>
-    A1_DEV double ubs(int t) const { if constexpr (GEN) return lds[L::UBT + t * 12 + ci]; else return ubk[K]; }
+    A1_DEV double ubs(int t) const { if constexpr (GEN) return lds[L::UBT + t * 12 + ci]; else return ubk[UNI ? 0 : K]; }
     A1_DEV void slot_bounds(int k, int t) {  // from the contact bit of step t
         const double cf = (cmask >> t) & 1u ? 1.0 : 0.0;
         lbk[k] = comp == 2 ? P.fz_min * cf : 0.0;
@@ -1128,7 +1184,7 @@ struct RowSolver {
                 // column order, so that the diagonal entry itself is the last one written there (LDS stores of a wave stay in order)
                 static_for<12>([&](auto Bd) {
                     constexpr int b = 11 - A1_CV(Bd);
-                    slot[L::K_SZ + tri + (b <= ci ? b : ci)] = S[b];
+                    slot[L::K_SZ + (b <= ci ? sinv_slot<b>(ci) : sinv_slot<-1>(ci))] = S[b];
                 });
             }
             // K' = F' S^-1  (state row-owner): K'[i][a] = sum_b F'[i][b] S^-1[b][a]; S^-1[b][a] = register a of force lane b, so every
@@ -1192,7 +1248,7 @@ struct RowSolver {
             double Sr[12], Kc[12];
             static_for<12>([&](auto B) {
                 constexpr int b = A1_CV(B);
-                Sr[b] = slot[L::K_SZ + (b <= ci ? tri + b : b * (b + 1) / 2 + ci)];
+                Sr[b] = slot[L::K_SZ + sinv_slot<b>(ci)];
                 if constexpr (t > 0) Kc[b] = slot[b * L::KSTR + ci];
             });
             const double cgt = lds[L::CG + t * 12 + ci];
@@ -1208,7 +1264,7 @@ struct RowSolver {
                 t0 = rr0[t] * (comp == 2 ? xh[t] : fma(mu, xz, xh[t])) - csc * yw0;
                 t1 = rr1[t] * fma(-mu, xz, xh[t]) - csc * yw1;
             } else {                // E (rho z_s - y_s) = rr (2 Pi(wh) - wh)
-                const double z0 = min_f64(max_f64(wh0[t], lbt), ubt), z1 = min_f64(wh1[t], 0.0);
+                const double z0 = clamp_f64(wh0[t], lbt, ubt), z1 = min_f64(wh1[t], 0.0);
                 t0 = rr0[t] * fma(2.0, z0, -wh0[t]);
                 t1 = rr1[t] * fma(2.0, z1, -wh1[t]);
             }
@@ -1259,7 +1315,7 @@ struct RowSolver {
             const double xh_old = xh[t];
             [[maybe_unused]] double gt0 = 0.0, gt1 = 0.0;  // CAREFUL: rr (2 Pi(w) - w) of the state BEFORE this iteration's update
             if constexpr (CAREFUL) {
-                const double zp0 = min_f64(max_f64(wh0[t], lbt), ubt), zp1 = min_f64(wh1[t], 0.0);
+                const double zp0 = clamp_f64(wh0[t], lbt, ubt), zp1 = min_f64(wh1[t], 0.0);
                 gt0 = rr0[t] * fma(2.0, zp0, -wh0[t]);
                 gt1 = rr1[t] * fma(2.0, zp1, -wh1[t]);
             }
@@ -1278,7 +1334,7 @@ struct RowSolver {
                 else sweep_fwd_input(sa, sb, z0, v, Brl, wh0[t], lbt, ubt);
                 s = sa;  // lanes without a wrench state read the zero row of B~
             } else {
-                z0 = min_f64(max_f64(wh0[t], lbt), ubt);
+                z0 = clamp_f64(wh0[t], lbt, ubt);
             }
             // z~ = A v (unscaled), then update_x / update_z / update_y in the w form
             const double vz = quad_perm<2, 2, 2, 2>(v);
@@ -1320,13 +1376,14 @@ struct RowSolver {
     // LDS reads are issued as soon as the block that consumed the previous step's has been issued (into the registers it frees): with one
     // wave per SIMD nothing else hides an LDS round trip.  (Measured and not kept: carrying the first reads of the next iteration across the
     // loop back-edge -- the loop-carried registers push loop invariants into scratch, 2.95 -> 3.56 us per iteration; double-buffering the
-    // backward reads a whole step ahead -- 36 more AGPR moves per iteration, 2.77 -> 2.88 us.)
+    // backward reads a whole step ahead -- 36 more AGPR moves per iteration, 2.77 -> 2.88 us; again in round 3 with both sweeps' reads two steps ahead in a second
+    // register set, after the loop had lost its AGPR traffic: 44 AGPR moves per iteration come back, +6 ... 10 % per iteration.)
     template <int T_>
     A1_DEV void issue_back_reads(double (&M)[12]) const {
         const double* slot = lds + L::FAC + T_ * L::SLOT;
         static_for<12>([&](auto B) {  // one read serves both rows: the main row's K_t column entry, the twin's S_t^-1 row entry (t = 0: the main row's value is unused)
             constexpr int b = A1_CV(B);
-            M[b] = slot[twin ? L::K_SZ + (b <= ci ? tri + b : b * (b + 1) / 2 + ci) : b * L::KSTR + ci];
+            M[b] = slot[mofs[b]];
         });
     }
     template <bool FIRST, bool CAREFUL>
@@ -1340,6 +1397,7 @@ struct RowSolver {
         double d[H];
         double pv = 0.0;  // costate p_{t+1}, state layout
         double M[12], Kq[12];
+        double pbn = 0.0;  // gV ror8(p_{t+1}) on the main row, 0 on the twin
         issue_back_reads<H - 1>(M);
         double cgv = cgp[24 * (HS - 1)];
         row_sched_fence();
@@ -1351,7 +1409,7 @@ struct RowSolver {
             constexpr int t = A1_CV(TQ);
             double r = e_t, pa = 0.0, pb = 0.0;
             if constexpr (t < H - 1) {
-                if constexpr (t > 0) pb = gVm * row_ror<8>(pv);
+                if constexpr (t > 0) pb = pbn;
                 if constexpr (GEN) {
                     double Btl[6];
                     Bt_at(t, Btl);  // my column of this step's B~_t
@@ -1366,11 +1424,14 @@ struct RowSolver {
             row_sched_fence();
             if constexpr (t > 0) issue_back_reads<(t > 0 ? t - 1 : 0)>(M);  // the next step's reads, into the registers the chain has just freed
             else {
-                const double* slot1 = lds + L::FAC + 1 * L::SLOT;           // ... or the forward sweep's first K row
-                static_for<12>([&](auto B) { Kq[A1_CV(B)] = slot1[krow + A1_CV(B)]; });
+                const auto kr1 = row_lds_at<1 * L::SLOT>(lds + L::FAC + krow);  // ... or the forward sweep's first K row
+                static_for<12>([&](auto B) { Kq[A1_CV(B)] = kr1[A1_CV(B)]; });
             }
             row_sched_fence();
-            d[t] = twin_exchange(pa);
+            // the seed gV ror8(p_t) of the next step's costate, taken BEFORE the swap: the main row already holds p_t, and on the twin (which holds d_t
+            // there) the multiplier is zero -- behind the swap the rotate would wait two states for it
+            if constexpr (t > 1) pbn = gVm * row_ror<8>(pa);
+            d[t] = twin_exchange_copied(pa, pb);  // (pb: the chain block's copy of pa)
             pv = pa;
         };
         static_for<HS>([&](auto KK) {
@@ -1383,7 +1444,7 @@ struct RowSolver {
                 t0 = rr0[k] * (comp == 2 ? xh[k] : fma(mu, xz, xh[k])) - csc * yw0;
                 t1 = rr1[k] * fma(-mu, xz, xh[k]) - csc * yw1;
             } else {
-                const double z0 = min_f64(max_f64(wh0[k], lbs<k>(2 * k + tw)), ubs<k>(2 * k + tw)), z1 = min_f64(wh1[k], 0.0);
+                const double z0 = clamp_f64(wh0[k], lbs<k>(2 * k + tw), ubs<k>(2 * k + tw)), z1 = min_f64(wh1[k], 0.0);
                 t0 = rr0[k] * fma(2.0, z0, -wh0[k]);
                 t1 = rr1[k] * fma(2.0, z1, -wh1[k]);
             }
@@ -1403,14 +1464,17 @@ struct RowSolver {
         // one step of the forward sweep: v_t = d_t - K_t x_t,  x_{t+1} = A x_t + B~ v_t
         auto fwd_step = [&](auto TQ) {
             constexpr int t = A1_CV(TQ);
-            double v = d[t], sa = 0.0, sb = 0.0;
+            double v = d[t], sb = 0.0;
+            // (one address register per step: the reads are base + immediate; formed ahead of the gain block -- hipcc pads an asm statement that follows another)
+            [[maybe_unused]] lds_cptr krn = nullptr;
+            if constexpr (t > 0 && t < H - 1) krn = row_lds_at<(t + 1) * L::SLOT>(lds + L::FAC + krow);
             if constexpr (t == 0) {
                 v = row_dpp_ready(am * v);  // x_0 = 0
             } else if constexpr (t < H - 1) {
                 sb = fP * row_ror<8>(s);
-                sweep_fwd_gain_twin<true>(v, sa, sb, s, Kq, fA, fB, fC, am);
+                sweep_fwd_gain_twin<true>(v, s, sb, Kq, fA, fB, fC, am);
             } else {
-                sweep_fwd_gain_twin<false>(v, sa, sb, s, Kq, fA, fB, fC, am);
+                sweep_fwd_gain_twin<false>(v, s, sb, Kq, fA, fB, fC, am);
             }
             row_sched_fence();
             [[maybe_unused]] double Brl[12];
@@ -1420,14 +1484,14 @@ struct RowSolver {
                 for (int b = 0; b < 12; ++b) Brl[b] = br[b];
             }
             if constexpr (t > 0 && t < H - 1) {  // the next step's K row, into the registers the gain block has just freed
-                const double* slotn = lds + L::FAC + (t + 1) * L::SLOT;
-                static_for<12>([&](auto B) { Kq[A1_CV(B)] = slotn[krow + A1_CV(B)]; });
+                static_for<12>([&](auto B) { Kq[A1_CV(B)] = krn[A1_CV(B)]; });
             }
             row_sched_fence();
-            if constexpr (t < H - 1) {
-                if constexpr (GEN) sweep_fwd_input_twin(sa, sb, v, Brl);
-                else sweep_fwd_input_twin(sa, sb, v, Brw);
-                s = row_dpp_ready(sa);  // lanes without a wrench state read the zero row of B~
+            if constexpr (t < H - 1) {  // (s: zero at t = 0, x_t with the seeds of x_{t+1} on top after the gain block)
+                if constexpr (GEN) sweep_fwd_input_twin(s, sb, v, Brl);
+                else sweep_fwd_input_twin(s, sb, v, Brw);  // lanes without a wrench state read the zero row of B~
+                // the next step's first DPP read of s: behind the row_ror<8> of its seed (hipcc pads that one itself), or -- last step -- right at the top of its block
+                if constexpr (t == H - 2) s = row_dpp_ready(s);
             }
             return v;
         };
@@ -1442,11 +1506,11 @@ struct RowSolver {
             const double xh_old = xh[k];
             [[maybe_unused]] double gt0 = 0.0, gt1 = 0.0;
             if constexpr (CAREFUL) {
-                const double zp0 = min_f64(max_f64(wh0[k], lbs<k>(2 * k + tw)), ubs<k>(2 * k + tw)), zp1 = min_f64(wh1[k], 0.0);
+                const double zp0 = clamp_f64(wh0[k], lbs<k>(2 * k + tw), ubs<k>(2 * k + tw)), zp1 = min_f64(wh1[k], 0.0);
                 gt0 = rr0[k] * fma(2.0, zp0, -wh0[k]);
                 gt1 = rr1[k] * fma(2.0, zp1, -wh1[k]);
             }
-            const double z0 = min_f64(max_f64(wh0[k], lbs<k>(2 * k + tw)), ubs<k>(2 * k + tw));
+            const double z0 = clamp_f64(wh0[k], lbs<k>(2 * k + tw), ubs<k>(2 * k + tw));
             xh[k] = fma(al, v, oma * xh[k]);
             const double vz = quad_perm<2, 2, 2, 2>(v);
             const double av0 = fma(mux, vz, v);
@@ -1564,7 +1628,7 @@ struct RowSolver {
             const double uz = quad_perm<2, 2, 2, 2>(xh[k]);
             const double ax0 = comp == 2 ? xh[k] : fma(mu, uz, xh[k]);  // E^-1 (A_s x)
             const double ax1 = comp < 2 ? fma(-mu, uz, xh[k]) : 0.0;
-            const double z0 = min_f64(max_f64(wh0[k], lbs<k>(t)), ubs<k>(t)), z1 = min_f64(wh1[k], 0.0);  // E^-1 z
+            const double z0 = clamp_f64(wh0[k], lbs<k>(t), ubs<k>(t)), z1 = min_f64(wh1[k], 0.0);  // E^-1 z
             const double rp0 = ax0 - z0, rp1 = ax1 - z1;
             const bool eq = (eqmask >> t) & 1u;
             const double e0 = rr0[k] * (eq ? irho_eq : irho), e1 = rr1[k] * irho;  // E^2
@@ -1848,9 +1912,9 @@ A1_DEV void setup_row(const BatchArgs& a, const double* __restrict__ tab, int64_
 // split pipeline, kernel 2: a persistent row.  It pulls prepared QPs from a shared counter and advances them one
 // checkpoint-aligned segment per loop trip; a row whose QP has converged writes it out and pulls the next one at the next
 // trip, so the rows of a wave never wait for each other's iteration counts -- only for each other's (rare) re-factorisations.
-template <int H, bool TWIN = false, bool GEN = false, bool UPD = false>
+template <int H, bool TWIN = false, bool GEN = false, bool UPD = false, bool UNI = false>
 A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* __restrict__ counter, double* __restrict__ lds) {
-    RowSolver<H, kModeMpc, false, GEN, TWIN> S(a.P, a.tab, lds);
+    RowSolver<H, kModeMpc, false, GEN, TWIN, UNI> S(a.P, a.tab, lds);
     bool alive = true, need_new = true, have = false;
     int64_t cur = 0;
     while (alive) {

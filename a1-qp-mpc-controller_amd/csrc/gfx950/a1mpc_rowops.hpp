@@ -92,6 +92,13 @@ A1_DEV double min_f64(double a, double b) {
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// min(max(w, lb), ub) as one statement: hipcc pads a dependent pair of asm statements with an s_nop
+A1_DEV double clamp_f64(double w, double lb, double ub) {
+    double r;
+    asm("v_max_f64 %0, %1, %2\n"
+        "v_min_f64 %0, %0, %3" : "=&v"(r) : "v"(w), "v"(lb), "v"(ub));
+    return r;
+}
 A1_DEV double row_dpp_ready(double x) {
     asm volatile("s_nop 1" : "+v"(x));
     return x;
@@ -151,11 +158,14 @@ A1_DEV void sweep_back_rhs_twin(double& r, double& pa, double& pb, double p, con
 // One chain pair for a row and its twin:  (pa, pb) += sum_b M[b] r[b]  (even b into pa, odd b into pb),  pa <- pa + pb.  On the main row M is
 // column `ci` of K_t and the pair arrives seeded with A' p_{t+1} (result: the costate p_t); on the twin M is row `ci` of S_t^-1 and the seeds are
 // zero (result: d_t = S_t^-1 r).  ONE instruction stream and ONE LDS read per term serve both products.  r: written >= 2 instructions ago.
+// The block ends with the copy of the result that twin_exchange_copied() swaps with (pb := pa): the swap reads it >= 2 instructions later -- the next
+// step's LDS reads are issued in between -- where a copy made next to the swap costs a second v_mov and an s_nop.
 A1_DEV void sweep_back_chain_twin(double& pa, double& pb, double r, const double (&M)[12]) {
     asm(A1_FMAC("%0", "%2", "%3", 0) A1_FMAC("%1", "%2", "%4", 1) A1_FMAC("%0", "%2", "%5", 2) A1_FMAC("%1", "%2", "%6", 4)
         A1_FMAC("%0", "%2", "%7", 5) A1_FMAC("%1", "%2", "%8", 6) A1_FMAC("%0", "%2", "%9", 8) A1_FMAC("%1", "%2", "%10", 9)
         A1_FMAC("%0", "%2", "%11", 10) A1_FMAC("%1", "%2", "%12", 12) A1_FMAC("%0", "%2", "%13", 13) A1_FMAC("%1", "%2", "%14", 14)
         "v_add_f64 %0, %0, %1\n"
+        "v_mov_b64 %1, %0\n"
         : "+v"(pa), "+v"(pb)
         : "v"(r), "v"(M[0]), "v"(M[1]), "v"(M[2]), "v"(M[3]), "v"(M[4]), "v"(M[5]), "v"(M[6]), "v"(M[7]), "v"(M[8]), "v"(M[9]), "v"(M[10]), "v"(M[11]));
 }
@@ -243,22 +253,24 @@ A1_DEV void sweep_fwd_input(double& sa, double& sb, double& z0, double v, const 
 }
 
 // The forward blocks of a twin pair: the x / w updates of a step belong to ONE row of the pair (RowSolver::admm_iteration_twin), so the blocks
-// only carry the roll-out.  v = am * (v - K s) (row Kr) and (SEED) the seeds of x_{t+1}: sa = s + fA s[8] + fC s[10], sb += fB s[9]; the seed
+// only carry the roll-out.  v = am * (v - K s) (row Kr) and (SEED) the seeds of x_{t+1}: s += fA s[8] + fC s[10], sb += fB s[9]; the seed
 // terms come last so that v is followed by >= 2 instructions before sweep_fwd_input_twin reads it through DPP.  s: written >= 2 instructions ago.
 template <bool SEED>
-A1_DEV void sweep_fwd_gain_twin(double& v, double& sa, double& sb, double s, const double (&Kr)[12], double fA, double fB, double fC, double am) {
+A1_DEV void sweep_fwd_gain_twin(double& v, double& s, double& sb, const double (&Kr)[12], double fA, double fB, double fC, double am) {
     double vb;
     if constexpr (SEED) {
-        asm("v_mov_b64 %2, %4\n"
-            "v_mov_b64 %1, 0\n"
-            A1_FNMA("%0", "%4", "%5", 0) A1_FNMA("%1", "%4", "%6", 1) A1_FNMA("%0", "%4", "%7", 2) A1_FNMA("%1", "%4", "%8", 4)
-            A1_FNMA("%0", "%4", "%9", 5) A1_FNMA("%1", "%4", "%10", 6) A1_FNMA("%0", "%4", "%11", 8) A1_FNMA("%1", "%4", "%12", 9)
-            A1_FNMA("%0", "%4", "%13", 10) A1_FNMA("%1", "%4", "%14", 12) A1_FNMA("%0", "%4", "%15", 13) A1_FNMA("%1", "%4", "%16", 14)
+        // the seeds accumulate onto s IN PLACE (no copy): they come after the last term that reads s as it was, they only change lanes 0, 1 (fA) and 2 (fC)
+        // and read lanes 8, 9, 10; each write of s is two instructions away from the next DPP read of s
+        asm("v_mov_b64 %1, 0\n"
+            A1_FNMA("%0", "%2", "%4", 0) A1_FNMA("%1", "%2", "%5", 1) A1_FNMA("%0", "%2", "%6", 2) A1_FNMA("%1", "%2", "%7", 4)
+            A1_FNMA("%0", "%2", "%8", 5) A1_FNMA("%1", "%2", "%9", 6) A1_FNMA("%0", "%2", "%10", 8) A1_FNMA("%1", "%2", "%11", 9)
+            A1_FNMA("%0", "%2", "%12", 10) A1_FNMA("%1", "%2", "%13", 12) A1_FNMA("%0", "%2", "%14", 13) A1_FNMA("%1", "%2", "%15", 14)
+            A1_FMAC("%2", "%2", "%16", 8)
             "v_add_f64 %0, %0, %1\n"
-            "v_mul_f64 %0, %0, %20\n"
-            A1_FMAC("%2", "%4", "%17", 8) A1_FMAC("%3", "%4", "%18", 9) A1_FMAC("%2", "%4", "%19", 10)
-            : "+v"(v), "=&v"(vb), "=&v"(sa), "+v"(sb)
-            : "v"(s), "v"(Kr[0]), "v"(Kr[1]), "v"(Kr[2]), "v"(Kr[3]), "v"(Kr[4]), "v"(Kr[5]), "v"(Kr[6]), "v"(Kr[7]), "v"(Kr[8]), "v"(Kr[9]), "v"(Kr[10]),
+            "v_mul_f64 %0, %0, %19\n"
+            A1_FMAC("%3", "%2", "%17", 9) A1_FMAC("%2", "%2", "%18", 10)
+            : "+v"(v), "=&v"(vb), "+v"(s), "+v"(sb)
+            : "v"(Kr[0]), "v"(Kr[1]), "v"(Kr[2]), "v"(Kr[3]), "v"(Kr[4]), "v"(Kr[5]), "v"(Kr[6]), "v"(Kr[7]), "v"(Kr[8]), "v"(Kr[9]), "v"(Kr[10]),
               "v"(Kr[11]), "v"(fA), "v"(fB), "v"(fC), "v"(am));
     } else {
         asm("v_mov_b64 %1, 0\n"
@@ -362,6 +374,21 @@ A1_DEV int64_t row_opaque(int64_t v) {
     asm volatile("" : "+v"(v));
     return v;
 }
+A1_DEV int row_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// p + OFF doubles as an LDS address in a register of its own, formed by ONE v_add_u32 where it is used: the reads that follow become base + immediate.
+// Left to itself hipcc folds a step's constant into every read of the step, and ds_read2_b64's 8-bit offsets do not reach it -- one v_add_u32 per read
+// instruction instead of one per step; an opaque copy of the sum gets hoisted out of the ADMM loop instead (one more loop-carried register per step).
+using lds_cptr = const __attribute__((address_space(3))) double*;
+template <int OFF>
+A1_DEV lds_cptr row_lds_at(const double* p) {
+    const unsigned b = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_cptr)p));
+    unsigned a;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(a) : "n"(OFF * 8), "v"(b));
+    return reinterpret_cast<lds_cptr>(static_cast<uintptr_t>(a));
+}
 
 
 // ---- twin rows (persistent ADMM kernel) ------------------------------------------------------------------------------------------
@@ -372,13 +399,22 @@ A1_DEV int64_t row_opaque(int64_t v) {
 A1_DEV bool row_is_twin() { return (static_cast<int>(threadIdx.x) & 32) != 0; }
 // a = [x | y] on (main | twin)  ->  a = [x | x], returns [y | y]: v_permlane32_swap (lanes 32-63 of vdst <-> lanes 0-31 of src) on both dwords.
 // Builtin, not asm: hipcc places the 2 wait states the swap needs after the copies itself.
-A1_DEV double twin_exchange(double& a) {
-    const unsigned long long bits = __builtin_bit_cast(unsigned long long, a);
+A1_DEV double twin_exchange_copied(double& a, double c) {  // c: a copy of a, made >= 2 instructions ago (VALU write -> v_permlane32_swap read: 2 wait states)
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, a), cbits = __builtin_bit_cast(unsigned long long, c);
     const unsigned lo = static_cast<unsigned>(bits), hi = static_cast<unsigned>(bits >> 32);
-    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const unsigned clo = static_cast<unsigned>(cbits), chi = static_cast<unsigned>(cbits >> 32);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, clo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, chi, false, false);
     a = __builtin_bit_cast(double, static_cast<unsigned long long>(r0[0]) | (static_cast<unsigned long long>(r1[0]) << 32));
     return __builtin_bit_cast(double, static_cast<unsigned long long>(r0[1]) | (static_cast<unsigned long long>(r1[1]) << 32));
+}
+A1_DEV double twin_exchange(double& a) {
+    // the swap rewrites both of its operands, so it needs a copy of `a`: ONE v_mov_b64 (hipcc makes two v_mov_b32 of it) and the two wait states
+    // the swap needs after a VALU write, which hipcc cannot see behind an asm statement
+    double c;
+    asm("v_mov_b64 %0, %1\n"
+        "s_nop 1\n" : "=v"(c) : "v"(a));
+    return twin_exchange_copied(a, c);
 }
 // LDS ordering between the two rows of a pair (one wavefront: the same as row_sync(); the CPU test double needs the distinction)
 A1_DEV void pair_sync() { row_sync(); }

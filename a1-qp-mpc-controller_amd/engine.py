@@ -43,7 +43,7 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
 EXPORTS = ["a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
-           "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error", "a1mpc_pipeline_create", "a1mpc_pipeline_submit_device",
+           "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error", "a1mpc_pipeline_create", "a1mpc_pipeline_submit_device", "a1mpc_pipeline_submit",
            "a1mpc_pipeline_wait", "a1mpc_pipeline_join", "a1mpc_pipeline_handle", "a1mpc_pipeline_depth", "a1mpc_pipeline_destroy"]
 
 _lib = None
@@ -102,6 +102,8 @@ def load_library(path=None):
     lib.a1mpc_sharded_destroy.argtypes = [vp]; lib.a1mpc_sharded_destroy.restype = None
     lib.a1mpc_pipeline_create.argtypes = [C.POINTER(Config), i32, i32, i32, C.POINTER(vp)]; lib.a1mpc_pipeline_create.restype = C.c_int
     lib.a1mpc_pipeline_submit_device.argtypes = [vp, i32, i32, i32] + [vp] * 9 + [vp, i32p]; lib.a1mpc_pipeline_submit_device.restype = C.c_int
+    if path == _build.LIB_PATH or hasattr(lib, "a1mpc_pipeline_submit"):  # (an older build bound by hand for an A/B, tools/ab_probe.py, may lack the round-3 entries)
+        lib.a1mpc_pipeline_submit.argtypes = [vp, i32, i32, i32, dp, dp, dp, dp, u8p, dp, dp, i32p, i32p, i32p]; lib.a1mpc_pipeline_submit.restype = C.c_int
     lib.a1mpc_pipeline_wait.argtypes = [vp, i32]; lib.a1mpc_pipeline_wait.restype = C.c_int
     lib.a1mpc_pipeline_join.argtypes = [vp, i32, vp]; lib.a1mpc_pipeline_join.restype = C.c_int
     lib.a1mpc_pipeline_handle.argtypes = [vp, i32, C.POINTER(vp)]; lib.a1mpc_pipeline_handle.restype = C.c_int
@@ -154,6 +156,10 @@ def _dp(a):
 
 def _ip(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _u8p(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint8))
 
 
 def _f64(a, shape):
@@ -398,7 +404,7 @@ class Engine:
 # ---- work model used for roofline.achieved (DESIGN.md "Measurement") --------------
 class Pipeline:
     """a1mpc_pipeline: `depth` engine handles on `depth` HIP streams of one GPU, batches submitted round-robin so that the next batch's
-    set-up kernel and persistent rows fill the tail of the one before (include/a1mpc.h).  Device pointers (torch tensors) only."""
+    set-up kernel and persistent rows fill the tail of the one before (include/a1mpc.h).  Device pointers (torch tensors) or host arrays."""
 
     def __init__(self, cfg, max_batch, device=0, depth=2):
         self.lib = load_library()
@@ -416,6 +422,22 @@ class Pipeline:
         rc = self.lib.a1mpc_pipeline_submit_device(self._p, int(slot), 1 if fresh else 0, int(n), ptr(d_x0), ptr(d_xref), ptr(d_R), ptr(d_foot), ptr(d_contact),
                                                    ptr(d_grf), ptr(d_u), ptr(d_iters), ptr(d_status), C.c_void_p(int(after_stream)) if after_stream else None, C.byref(k))
         _check(self.lib, rc, "a1mpc_pipeline_submit_device")
+        return int(k.value)
+
+    def submit(self, x0, xref, R, foot, contact, out, slot=-1, fresh=True):
+        """host arrays in (a1mpc_solve_batch's layouts; snapshotted before the call returns), host arrays out: `out` = dict(grf=, [u=], [iters=], [status=]) of
+        preallocated C-contiguous numpy arrays that wait(slot) -- or the next submit to the slot -- fills.  Returns the slot."""
+        n = int(x0.shape[0])
+        x0 = np.ascontiguousarray(x0, np.float64); xref = np.ascontiguousarray(xref, np.float64); R = np.ascontiguousarray(R, np.float64)
+        foot = np.ascontiguousarray(foot, np.float64); contact = np.ascontiguousarray(contact, np.uint8)
+        for k_, a_ in out.items():
+            assert a_.flags["C_CONTIGUOUS"] and a_.shape[0] >= n, k_
+        k = C.c_int32(-1)
+        rc = self.lib.a1mpc_pipeline_submit(self._p, int(slot), 1 if fresh else 0, n, _dp(x0), _dp(xref), _dp(R), _dp(foot), _u8p(contact), _dp(out["grf"]),
+                                            _dp(out["u"]) if out.get("u") is not None else None, _ip(out["iters"]) if out.get("iters") is not None else None,
+                                            _ip(out["status"]) if out.get("status") is not None else None, C.byref(k))
+        _check(self.lib, rc, "a1mpc_pipeline_submit")
+        self._keep = getattr(self, "_keep", {}); self._keep[int(k.value)] = out   # the output arrays must outlive the slot's batch
         return int(k.value)
 
     def wait(self, slot=-1):

@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
+PMC_SUMMARY = "r03_pmc_summary.json"   # static rocprofv3 --pmc summary of this round (tools/collect_profiles.sh + summarize_profiles.py)
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (AMD spec; = 1/2 of the 157.3 TF FP32 rate in MI355X_MICROARCH.md)
 BATCH = 4096
 HORIZON = 10
@@ -64,17 +65,34 @@ def cpu_baseline(pkg, sc, budget_s=15.0):
     oracle.mpc_solve_batch(pr, st, *take(min(nb, 8)), nthreads=1)
     t = time.perf_counter(); oracle.mpc_solve_batch(pr, st, *take(min(nb, 96)), nthreads=1); ts = (time.perf_counter() - t) / min(nb, 96)
     single = single_thread_ticks(pkg, oracle, pr, sc["horizon"])
-    n0 = min(8 * cores, nb)
-    t = time.perf_counter(); oracle.mpc_solve_batch(pr, st, *take(n0), nthreads=cores); t0 = time.perf_counter() - t
-    reps = int(max(1, min(64, budget_s / max(t0 / n0 * nb, 1e-9))))  # whole passes over the workload, ~budget_s of CPU time
+    # How many cores does this process really have?  omp_get_max_threads() counts the box's hardware threads; the affinity mask and the cgroup quota say what is usable.
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    # thread-count sweep on a bounded sample (one problem per thread, static partition): the best count is the baseline's -- 128 SMT threads of a shared box are not 128 cores
+    cand = sorted({t_ for t_ in (1, 8, 16, 32, 64, 96, 128, usable, cores) if 1 <= t_ <= max(cores, usable)})
+    sweep = {}
+    for t_ in cand:
+        m = min(nb, max(64, 16 * t_))
+        oracle.mpc_solve_batch(pr, st, *take(min(nb, 2 * t_)), nthreads=t_)
+        t = time.perf_counter(); oracle.mpc_solve_batch(pr, st, *take(m), nthreads=t_); sweep[t_] = m / (time.perf_counter() - t)
+    best = max(sweep, key=sweep.get)
+    t0 = nb / sweep[best]
+    reps = int(max(1, min(64, budget_s / max(t0, 1e-9))))  # whole passes over the workload, ~budget_s of CPU time
     t = time.perf_counter()
     for _ in range(reps):
-        r = oracle.mpc_solve_batch(pr, st, *take(nb), nthreads=cores)
+        r = oracle.mpc_solve_batch(pr, st, *take(nb), nthreads=best)
     t1 = time.perf_counter() - t
     n = reps * nb
-    return {"value": n / t1, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} pass(es) over the same {nb} QPs (config3, h=10) = {n} solves, OpenMP static over {cores} threads, {t1:.1f} s; "
+    return {"value": n / t1, "unit": "solves/s", "cores": best, "kind": "port",
+            "sample": f"{reps} pass(es) over the same {nb} QPs (config3, h=10) = {n} solves, OpenMP static over {best} threads (the best of the sweep), {t1:.1f} s; "
                       f"single-thread cold {1.0 / ts:.1f} solves/s (measured before the threaded passes); real OSQP/Eigen are not installable here (oracle/ restates them)",
+            "host": {"hardware_threads_omp": cores, "sched_getaffinity": usable, "cgroup_cpu_max_cores": quota},
+            "thread_sweep_solves_per_s": {str(k): float(v) for k, v in sweep.items()}, "speedup_over_one_thread": float(n / t1 * ts),
             "mean_iters": float(r["iters"].mean()), "single_thread_cold_solves_per_s": 1.0 / ts, "single_thread_warm_ticks": single}, r
 
 
@@ -107,6 +125,52 @@ def latency_probe(pkg, nticks=1500):
     lat = lat[50:] * 1e3
     return {"workload": "config2 trot, h=10, batch 1, warm start, host pointers in/out", "ticks": int(len(lat)),
             "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "max_ms": float(lat.max())}
+
+
+def pcie_inclusive_probe(pkg, scs, cfg, n, local, steps=24):
+    """Extra information (never `value`): the same first solves for a caller that owns HOST arrays (the reference's boundary is host-side, S/A1RobotControl.h:44) --
+    a1mpc_solve_batch (synchronous) and a1mpc_pipeline_submit / _wait with two batches in flight (the caller's thread snapshots batch k + 1 into the slot's pinned
+    block while the GPU solves batch k).  Wall clock of the calling thread; outputs checked bit for bit against the synchronous entry."""
+    import gc
+    NB = len(scs)
+    gc.collect(); gc.disable()   # wall-clock loops of a few tens of ms: one Python gen-2 collection (~40 ms, observed) would double the figure; the reference's caller is C++
+    try:
+        return _pcie_inclusive(pkg, scs, cfg, n, local, steps, NB)
+    finally:
+        gc.enable()
+
+
+def _pcie_inclusive(pkg, scs, cfg, n, local, steps, NB):
+    with pkg.Engine(cfg, n, local) as eng:
+        ref = []
+        for k in range(NB + 2):
+            s_ = scs[k % NB]; eng.set_schedule(True); o = eng.solve(s_["x0"], s_["xref"], s_["R"], s_["foot"], s_["contact"])
+            if k < NB: ref.append(o)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            s_ = scs[k % NB]; eng.set_schedule(True); eng.solve(s_["x0"], s_["xref"], s_["R"], s_["foot"], s_["contact"])
+        sync_ms = (time.perf_counter() - t0) / steps * 1e3
+    depth = 2
+    outs = [dict(grf=np.zeros((n, 12)), iters=np.zeros(n, np.int32), status=np.zeros(n, np.int32)) for _ in range(depth)]
+    same = True
+    with pkg.Pipeline(cfg, n, local, depth=depth) as pipe:
+        def run(count, check):
+            nonlocal same
+            held = [None] * depth
+            for k in range(count):
+                j = k % depth; s_ = scs[k % NB]
+                if held[j] is not None:
+                    pipe.wait(j)
+                    if check:
+                        r = ref[held[j]]; same = same and np.array_equal(outs[j]["grf"], r["grf"]) and np.array_equal(outs[j]["iters"], r["iters"])
+                pipe.submit(s_["x0"], s_["xref"], s_["R"], s_["foot"], s_["contact"], outs[j], slot=j, fresh=True); held[j] = k % NB
+            pipe.wait()
+        run(2 * depth + NB, True)
+        t0 = time.perf_counter(); run(steps, False); pipe_ms = (time.perf_counter() - t0) / steps * 1e3
+    h = int(cfg.horizon)
+    return {"workload": f"{n} x h{h} first solves, host arrays in and out every batch", "bytes_in_per_batch": n * ((13 + 13 * h + 9 + 12) * 8 + 4), "bytes_out_per_batch": n * (12 * 8 + 8),
+            "synchronous_a1mpc_solve_batch": {"ms_per_batch": sync_ms, "solves_per_s": n / sync_ms * 1e3},
+            "a1mpc_pipeline_submit_depth2": {"ms_per_batch": pipe_ms, "solves_per_s": n / pipe_ms * 1e3, "bit_identical_to_synchronous": bool(same)}}
 
 
 def batch_sweep(pkg, local, sizes=(1024, 16384, 65536)):
@@ -224,7 +288,13 @@ def other_config_rooflines(pkg, local, steps=4):
     import torch
     dev = torch.device("cuda", local); st = torch.cuda.Stream(device=dev)
     res = []
-    for name, gen, n, h in (("configs[3] share: 8192 x h16", "config4_random_h16", 8192, 16), ("configs[4]: 32768 x h20 mixed contacts, 0.5 rad pitch", "config5_divergent", 32768, 20)):
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY))).get("executed_fp64_flops_per_launch_by_config", {})
+    except Exception:
+        pass
+    for name, gen, n, h in (("BASELINE's upper batch: 65536 x h10 (configs[2]'s generator)", "config3_random_flat", 65536, 10), ("configs[3] share: 8192 x h16", "config4_random_h16", 8192, 16),
+                            ("configs[4]: 32768 x h20 mixed contacts, 0.5 rad pitch", "config5_divergent", 32768, 20)):
         sc = getattr(pkg.scenarios, gen)(nb=n)
         cfg = pkg.make_config(sc["params"], h, warm_start=0)
         d = {k: torch.from_numpy(sc[k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")}
@@ -243,6 +313,9 @@ def other_config_rooflines(pkg, local, steps=4):
         entry = {"config": name, "batch": n, "horizon": h, "avg_kernel_ms": avg, "solves_per_s": n / (avg * 1e-3), "bound": "fp64-valu", "achieved": ach,
                  "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "mean_iters": float(it.float().mean().item()),
                  "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n, "solved_frac": float((stt == 1).float().mean().item())}
+        ex = pmc.get(f"{n}x{h}")   # SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 x live lanes of a first solve of this batch (static: profiles/, rocprofv3 --pmc of tools/prof_shapes.py)
+        if ex:
+            entry["executed_fp64_flops_per_launch"] = ex; entry["executed_fp64_frac"] = ex / (avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
         if n <= 8192:   # a batch of this size leaves a tail: the same first solves with two batches in flight (a1mpc_pipeline; batches of tens of thousands fill the chip alone)
             outs = [(torch.zeros((n, 12), dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(2)]
             with pkg.Pipeline(cfg, n, local, depth=2) as pipe:
@@ -281,12 +354,36 @@ def strong_scaling_config4(pkg, args, rank, world, local, backend, dist):
     it = torch.zeros(cnt, dtype=torch.int32, device=dev); stt = torch.zeros(cnt, dtype=torch.int32, device=dev)
     out_bufs = (torch.empty((N, 12), dtype=torch.float64, device=cdev), torch.empty((N, 2), dtype=torch.int32, device=cdev)) if rank == 0 else None
     t_comm = [0.0]
+    on_device = cdev == dev   # nccl: scatter, solve and gather are queued on ONE stream (torch's current stream; RCCL orders its own stream against it), no host
+                              # synchronisation and no staging hop inside a step; the communication share is read from HIP events after the loop.
+                              # gloo (the CPU smoke test of this code path): host tensors, host clocks, a synchronisation per phase.
+    torch.cuda.synchronize()
+    if on_device:
+        torch.cuda.set_stream(stream)   # a real (non-null) stream becomes torch's current stream: tensor ops, RCCL's stream dependencies and the engine's launches share it
+    cur = stream
+    evs = []
 
     def step():
+        if on_device:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record(cur)
+            lrec, lct = sh.scatter(rec, ct, N, H, cdev, None, 0) if world > 1 else (rec, ct)
+            e[1].record(cur)
+            f = sh.unpack_record(lrec, H)
+            eng.set_schedule(True)
+            eng.solve_device(cnt, f["x0"], f["xref"], f["R"], f["foot"], lct, grf, None, it, stt, stream=cur.cuda_stream)
+            meta[:, 0] = it; meta[:, 1] = stt
+            e[2].record(cur)
+            if world > 1:
+                sh.gather(grf, meta, N, cdev, None, 0, out_bufs)
+            else:
+                out_bufs[0].copy_(grf); out_bufs[1].copy_(meta)
+            e[3].record(cur)
+            evs.append(e)
+            return
         a = time.perf_counter()
         lrec, lct = sh.scatter(rec, ct, N, H, cdev, None, 0) if world > 1 else (rec, ct)
-        if cdev != dev:
-            lrec = lrec.to(dev); lct = lct.to(dev)
+        lrec = lrec.to(dev); lct = lct.to(dev)
         torch.cuda.synchronize(); b = time.perf_counter()
         f = sh.unpack_record(lrec, H)
         torch.cuda.current_stream().synchronize()
@@ -307,7 +404,7 @@ def strong_scaling_config4(pkg, args, rank, world, local, backend, dist):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    t_comm[0] = 0.0
+    t_comm[0] = 0.0; evs.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -315,6 +412,8 @@ def strong_scaling_config4(pkg, args, rank, world, local, backend, dist):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if on_device:
+        t_comm[0] = sum(e[0].elapsed_time(e[1]) + e[2].elapsed_time(e[3]) for e in evs) * 1e-3
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -334,6 +433,71 @@ def strong_scaling_config4(pkg, args, rank, world, local, backend, dist):
     return res
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks here (one process per GPU through torch.distributed.run, the way the driver launches
+    N > 1) and hand their JSON line through.  A box with fewer than N GPUs runs the N ranks on the GPUs it has over gloo (A1_BENCH_SHARE_GPU: a smoke test of the
+    N > 1 code path, said so in config.parallelism) -- the line still says n_gpus = N ranks, never a scaling claim."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if have < args.gpus:
+        env["A1_BENCH_SHARE_GPU"] = "1"; env["A1_BENCH_BACKEND"] = "gloo"
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
+def native_sharded(args):
+    """One process, all GPUs: the C ABI's own sharding (a1mpc_sharded_*, SURVEY 8b `device = -1`, 8e "measure both transports").  Host arrays in, host arrays out -- the
+    PCIe-inclusive rate of a caller on the reference's side of the boundary, both transports side by side over the same batches.  On a box with fewer GPUs than --gpus
+    the shards of transport 0 share the GPUs that exist (a plumbing run); transport 1 needs distinct devices and is run over the devices that exist."""
+    import torch
+    pkg = graft.load_package()
+    pkg.load_library()
+    have = torch.cuda.device_count()
+    cfg4 = args.config == 4
+    h = 16 if cfg4 else HORIZON
+    n = (args.batch if args.batch != BATCH else 65536) if cfg4 else args.batch * args.gpus
+    gen = pkg.scenarios.config4_random_h16 if cfg4 else pkg.scenarios.config3_random_flat
+    NB = 2 if cfg4 else 4
+    scs = [gen(nb=n, seed=0xA1 + 3 + 17 * k) for k in range(NB)]
+    cfg = pkg.make_config(scs[0]["params"], h, warm_start=0)
+    res = {}
+    for transport in (0, 1):
+        devs = [g % have for g in range(args.gpus)] if transport == 0 else list(range(min(args.gpus, have)))
+        try:
+            with pkg.engine.ShardedEngine(cfg, n, devices=devs, transport=transport) as sh:
+                for k in range(max(1, args.warmup // 2)):
+                    s = scs[k % NB]; o = sh.solve(s["x0"], s["xref"], s["R"], s["foot"], s["contact"])
+                t0 = time.perf_counter()
+                for k in range(args.steps):
+                    s = scs[k % NB]; o = sh.solve(s["x0"], s["xref"], s["R"], s["foot"], s["contact"])
+                el = time.perf_counter() - t0
+                res[transport] = {"transport": "pinned fan-out, one hipMemcpyAsync per device each way" if transport == 0 else "RCCL grouped ncclSend / ncclRecv through shard 0's GPU",
+                                  "devices": devs, "solves_per_s": n * args.steps / el, "ms_per_step": el / args.steps * 1e3, "mean_iters": float(o["iters"].mean()),
+                                  "solved_frac": float((o["status"] == 1).mean())}
+        except Exception as e:   # (e.g. RCCL not loadable: reported, the other transport still counts)
+            res[transport] = {"error": str(e)[:300], "devices": devs}
+    pick = res[args.native]
+    if "error" in pick:
+        raise SystemExit(f"--native {args.native}: {pick['error']}")
+    out = {"metric": f"MPC QP solves/sec (horizon={h} SRBD), host arrays in / out through a1mpc_sharded_* (PCIe inclusive)", "value": pick["solves_per_s"], "unit": "solves/s",
+           "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": pick["ms_per_step"], "higher_is_better": True, "scaling": "strong" if cfg4 else "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": ("BASELINE configs[3]: 65536 x h16" if cfg4 else f"BASELINE configs[2]: {args.batch} x h10 per GPU") + ", one process, batch sharded contiguously over the devices inside the C ABI, "
+                                  "cold-start first solves of distinct batches, host arrays in and out every step", "global_batch": n, "horizon": h,
+                      "parallelism": f"a1mpc_sharded x{args.gpus} ({have} physical GPU(s) on this box)", "transport": args.native},
+           "transports": {"0": res[0], "1": res[1]}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -347,13 +511,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-index-order", action="store_true", help="skip the extra index-order steps (profiling runs)")
+    ap.add_argument("--native", type=int, default=-1, choices=(-1, 0, 1), help="one process, all --gpus GPUs through the C ABI's own sharding (a1mpc_sharded_*, host arrays in / out): "
+                    "0 = pinned fan-out (one hipMemcpyAsync per device each way), 1 = RCCL grouped send / recv through shard 0's GPU; both are measured, the chosen one is `value`")
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path for the solver)")
+    if args.native >= 0:
+        return native_sharded(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     backend = os.environ.get("A1_BENCH_BACKEND", "nccl")  # "gloo" + A1_BENCH_SHARE_GPU=1: two ranks on ONE GPU, a smoke test of the N > 1 code path
     if os.environ.get("A1_BENCH_SHARE_GPU"):
         local = 0
@@ -482,7 +652,7 @@ def main():
         achieved = flops / (avg_ms * 1e-3) / 1e12
         pmc = {}
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_SUMMARY)))
         except Exception:
             pass
         traffic = float(pmc["hbm_bytes_per_launch"]) if (n == BATCH and "hbm_bytes_per_launch" in pmc) else None
@@ -493,18 +663,20 @@ def main():
             "config": {"workload": "BASELINE configs[2]: batch=4096 randomized CoM states + flat terrain, horizon=10, cold-start "
                                    "OSQP-default ADMM, per GPU; 4 distinct batches cycled, every step a first solve (no queue-order history); "
                                    f"{depth} batch(es) in flight (a1mpc_pipeline: one engine handle + HIP stream per slot, round-robin)",
-                       "batch_per_gpu": n, "horizon": h, "parallelism": f"batch-sharded x{world}", "batches_in_flight": depth, "untimed_launches_before_timing": spin_up + args.warmup,
+                       "batch_per_gpu": n, "horizon": h, "parallelism": f"batch-sharded x{world}" + (f" ({backend}, ranks SHARING {torch.cuda.device_count()} physical GPU(s): a smoke "
+                                                                                                 "test of the N > 1 path, not a scaling point)" if os.environ.get("A1_BENCH_SHARE_GPU") else ""),
+                       "batches_in_flight": depth, "untimed_launches_before_timing": spin_up + args.warmup,
                        "mean_iters": float(it.mean()), "max_iters": int(it.max()), "solved_frac": float((stt == 1).mean())},
             "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_source": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r02_pmc_summary.json" if traffic else None,
+                         "traffic_source": f"static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/{PMC_SUMMARY}" if traffic else None,
                          "kernel": "a1mpc_setup_kernel<10,1> + a1mpc_admm_kernel<10,2> (+ a1mpc_order_kernel, ~5 us) = one solve", "avg_kernel_ms": avg_ms,
                          "avg_kernel_ms_is": f"timed region (HIP events on the launch stream, behind the first and after the last launch of every slot) / launches, {depth} launches in flight: "
                                              "with overlapping launches this is the rate a launch completes at, not the span of one launch",
                          "single_stream": {"avg_kernel_ms": single_ms, "achieved": flops / (single_ms * 1e-3) / 1e12, "frac": flops / (single_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                            "solves_per_s": n / (single_ms * 1e-3),
                                            "what": "the same first solves through ONE handle on one stream, launches serialised: the sum of the three kernels' durations in a kernel trace "
-                                                   "(profiles/r02_kernel_stats_bench_depth1_batch4096_h10.csv)"},
+                                                   "(profiles/r03_kernel_stats_bench_depth1_batch4096_h10.csv)"},
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
                          "executed_fp64_flops_per_launch": pmc.get("executed_fp64_flops_per_launch"),
                          "executed_fp64_frac": (pmc["executed_fp64_flops_per_launch"] / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if pmc.get("executed_fp64_flops_per_launch") else None,
@@ -546,6 +718,7 @@ def main():
         if world > 1:
             args.no_latency = args.no_cpu_baseline = True
         if not args.no_latency:
+            out["pcie_inclusive"] = pcie_inclusive_probe(pkg, scs, cfg, n, local)
             out["latency"] = latency_probe(pkg)
             out["throughput_by_batch"] = batch_sweep(pkg, local)
             out["warm_start_ticks"] = warm_tick_probe(pkg, local)

@@ -412,7 +412,13 @@ void a1mpc_sharded_destroy(a1mpc_sharded s);
  *            previous batch (a1mpc_set_schedule).  inputs_ready_stream: the slot starts after everything queued on that stream so far
  *            (NULL = the inputs are ready now).  Returns at once; the outputs of a slot are valid after a1mpc_pipeline_wait / _join, and
  *            its output buffers must not be handed to another submit before that.
- *   wait     the host waits for the slot's last submit (slot -1 = every slot);  join: a caller's stream waits for it instead.
+ *   submit (host pointers)  a1mpc_pipeline_submit: the arrays of a1mpc_solve_batch -- what a caller on the reference's side of the boundary has
+ *            (S/A1RobotControl.h:44: A1CtrlStates in, a 3x4 matrix out).  Inputs are snapshotted into the slot's pinned block before the call
+ *            returns (the caller may overwrite them at once); H2D copy, launches and D2H copy are queued on the slot's stream.  The OUTPUT arrays
+ *            are written by the a1mpc_pipeline_wait (or by the next submit) that retires the slot: they must stay valid until then.  The
+ *            caller's thread snapshots batch k + 1 while the GPU solves batch k.
+ *   wait     the host waits for the slot's last submit (slot -1 = every slot) and hands a host-pointer batch to its output arrays;
+ *            join: a caller's stream waits for it instead (device-pointer submits only).
  *   handle   the slot's engine handle, for warm-start I/O, a1mpc_update_config and the instrumentation calls.
  * One host thread per pipeline.
  */
@@ -422,6 +428,9 @@ a1mpc_status a1mpc_pipeline_submit_device(a1mpc_pipeline p, int32_t slot, int32_
                                           const double* d_x_ref, const double* d_R_world, const double* d_foot_abs, const uint8_t* d_contact,
                                           double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out,
                                           void* inputs_ready_stream, int32_t* slot_out);
+a1mpc_status a1mpc_pipeline_submit(a1mpc_pipeline p, int32_t slot, int32_t fresh_batch, int32_t n, const double* x0, const double* x_ref,
+                                   const double* R_world, const double* foot_abs, const uint8_t* contact, double* grf_body_out,
+                                   double* u_full_out, int32_t* iters_out, int32_t* status_out, int32_t* slot_out);
 a1mpc_status a1mpc_pipeline_wait(a1mpc_pipeline p, int32_t slot);
 a1mpc_status a1mpc_pipeline_join(a1mpc_pipeline p, int32_t slot, void* hip_stream);
 a1mpc_status a1mpc_pipeline_handle(a1mpc_pipeline p, int32_t slot, a1mpc_handle* out);

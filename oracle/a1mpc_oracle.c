@@ -379,6 +379,17 @@ static int update_rho_vec(work_t *w) {
     return changed;
 }
 
+/* Per-thread scratch, reused from solve to solve.  Every solve used to calloc / malloc ~0.5 MB in pieces above glibc's mmap threshold: each one a fresh mapping,
+ * page faults and the process-wide mmap lock -- the 128 OpenMP threads of the CPU baseline ran 9.8x one thread.  Buffers live as long as their thread. */
+typedef struct { void *p; size_t cap; } orc_scratch;
+static __thread orc_scratch tl_scratch[8];
+static void *scratch_get(int slot, size_t bytes, int zero) {
+    orc_scratch *sc = &tl_scratch[slot];
+    if (sc->cap < bytes) { free(sc->p); sc->p = malloc(bytes); sc->cap = sc->p ? bytes : 0; }
+    if (sc->p && zero) memset(sc->p, 0, bytes);
+    return sc->p;
+}
+
 /*
  * carry (optional): the persistent OSQP workspace of the reference's `OsqpEigen::Solver solver` member between ticks, for the UPDATE PATH the
  * reference takes on every tick after the first (S/A1RobotControl.cpp:533-538: updateHessianMatrix, updateGradient, updateLowerBound,
@@ -401,9 +412,9 @@ static int osqp_solve_impl(int n, int m, const double *P, const double *q, const
     work_t w; memset(&w, 0, sizeof w);
     int nnz = rp[m];
     size_t tot = (size_t)2 * n * n + 16 * (size_t)n + 16 * (size_t)m + nnz + 64 + (st->linsys == 1 ? (size_t)(n + m) * (n + m) + 2 * (size_t)(n + m) : 0);
-    double *buf = (double *)calloc(tot, sizeof(double));
-    int *ctype = (int *)calloc(m + 1, sizeof(int));
-    if (!buf || !ctype) { free(buf); free(ctype); return -1; }
+    double *buf = (double *)scratch_get(0, tot * sizeof(double), 1);
+    int *ctype = (int *)scratch_get(1, (size_t)(m + 1) * sizeof(int), 1);
+    if (!buf || !ctype) return -1;
     double *p = buf;
 #define TAKE(k) (p += (k), p - (k))
     w.n = n; w.m = m; w.nnz = nnz; w.rp = rp; w.ci = ci; w.st = st; w.info = info; w.ctype = ctype;
@@ -522,7 +533,6 @@ done:
         for (int j = 0; j < n; ++j) x[j] = w.D[j] * w.x[j];
         for (int i = 0; i < m; ++i) y[i] = w.cinv * w.E[i] * w.y[i];
     }
-    free(buf); free(ctype);
     return 0;
 }
 int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
@@ -592,11 +602,11 @@ void orc_mpc_form(const orc_mpc_params *pr, const double *x0, const double *xref
                   double *P, double *g, int32_t *rp, int32_t *ci, double *av, double *l, double *u) {
     const int h = pr->horizon, n = NU * h, ns = NS * h;
     double Ac[NS * NS], Ad[NS * NS], Bc[NS * NU];
-    double *Bdl = (double *)calloc((size_t)ns * NU, sizeof(double));      /* B_mat_d_list */
-    double *Aqp = (double *)calloc((size_t)ns * NS, sizeof(double));
-    double *Bqp = (double *)calloc((size_t)ns * n, sizeof(double));
-    double *Qd = (double *)malloc(sizeof(double) * ns), *Rd = (double *)malloc(sizeof(double) * n);
-    double *tmp = (double *)malloc(sizeof(double) * ns);
+    double *Bdl = (double *)scratch_get(2, sizeof(double) * (size_t)ns * NU, 1);      /* B_mat_d_list */
+    double *Aqp = (double *)scratch_get(3, sizeof(double) * (size_t)ns * NS, 1);
+    double *Bqp = (double *)scratch_get(4, sizeof(double) * (size_t)ns * n, 1);
+    double *Qd = (double *)scratch_get(5, sizeof(double) * (size_t)(2 * ns + n), 0), *Rd = Qd + ns;
+    double *tmp = Rd + n;
     /* ConvexMpc ctor :16-44 */
     for (int i = 0; i < h; ++i) { for (int k = 0; k < NS; ++k) Qd[i * NS + k] = 2 * pr->q[k]; for (int k = 0; k < NU; ++k) Rd[i * NU + k] = 2 * pr->r[k]; }
     orc_A_mat_c(yaw, Ac);
@@ -652,7 +662,6 @@ void orc_mpc_form(const orc_mpc_params *pr, const double *x0, const double *xref
         l[r0 + 4] = pr->fz_min * cf; u[r0 + 4] = pr->fz_max * cf;
     }
     rp[NC * h] = nz;
-    free(Bdl); free(Aqp); free(Bqp); free(Qd); free(Rd); free(tmp);
 }
 
 /* S/A1RobotControl.cpp:470-488 -- reference trajectory from the compact command */
@@ -679,9 +688,9 @@ int orc_mpc_solve(const orc_mpc_params *pr, const orc_settings *st, const double
                   const double *foot, int foot_stride, const uint8_t *contact, int contact_stride,
                   double *grf_out, double *u_full, double *warm_x, double *warm_y, double *warm_rho, orc_info *info) {
     const int h = pr->horizon, n = NU * h, m = NC * h;
-    double *P = (double *)malloc(sizeof(double) * ((size_t)n * n + n + 2 * m + 36 * h + n + m));
+    double *P = (double *)scratch_get(6, sizeof(double) * ((size_t)n * n + n + 2 * m + 36 * h + n + m), 0);
     double *g = P + (size_t)n * n, *l = g + n, *u = l + m, *av = u + m, *x = av + 36 * h, *y = x + n;
-    int32_t *rp = (int32_t *)malloc(sizeof(int32_t) * (m + 1 + 36 * h)), *ci = rp + m + 1;
+    int32_t *rp = (int32_t *)scratch_get(7, sizeof(int32_t) * (m + 1 + 36 * h), 0), *ci = rp + m + 1;
     orc_mpc_form(pr, x0, xref, x0[2], Rw, foot, foot_stride, contact, contact_stride, P, g, rp, ci, av, l, u);
     if (warm_x && st->warm_start) { memcpy(x, warm_x, sizeof(double) * n); memcpy(y, warm_y, sizeof(double) * m); }
     else { memset(x, 0, sizeof(double) * n); memset(y, 0, sizeof(double) * m); }
@@ -699,7 +708,6 @@ int orc_mpc_solve(const orc_mpc_params *pr, const orc_settings *st, const double
         if (failed) { memset(warm_x, 0, sizeof(double) * n); memset(warm_y, 0, sizeof(double) * m); if (warm_rho) *warm_rho = 0; }
         else { memcpy(warm_x, x, sizeof(double) * n); memcpy(warm_y, y, sizeof(double) * m); }
     }
-    free(P); free(rp);
     return rc;
 }
 
@@ -707,9 +715,9 @@ int orc_mpc_solve(const orc_mpc_params *pr, const orc_settings *st, const double
 int orc_mpc_solve_update(const orc_mpc_params *pr, const orc_settings *st, const double *x0, const double *xref, const double *Rw,
                          const double *foot, const uint8_t *contact, double *grf_out, double *u_full, double *carry, orc_info *info) {
     const int h = pr->horizon, n = NU * h, m = NC * h;
-    double *P = (double *)malloc(sizeof(double) * ((size_t)n * n + n + 2 * m + 36 * h + n + m));
+    double *P = (double *)scratch_get(6, sizeof(double) * ((size_t)n * n + n + 2 * m + 36 * h + n + m), 0);
     double *g = P + (size_t)n * n, *l = g + n, *u = l + m, *av = u + m, *x = av + 36 * h, *y = x + n;
-    int32_t *rp = (int32_t *)malloc(sizeof(int32_t) * (m + 1 + 36 * h)), *ci = rp + m + 1;
+    int32_t *rp = (int32_t *)scratch_get(7, sizeof(int32_t) * (m + 1 + 36 * h), 0), *ci = rp + m + 1;
     orc_mpc_form(pr, x0, xref, x0[2], Rw, foot, 0, contact, 0, P, g, rp, ci, av, l, u);
     memset(x, 0, sizeof(double) * n); memset(y, 0, sizeof(double) * m);
     int rc = orc_osqp_solve_update(n, m, P, g, rp, ci, av, l, u, st, x, y, carry, info);
@@ -719,7 +727,6 @@ int orc_mpc_solve_update(const orc_mpc_params *pr, const orc_settings *st, const
         for (int i = 0; i < 3; ++i) grf_out[3 * leg + i] = bad ? 0.0 : Rw[0 * 3 + i] * f[0] + Rw[1 * 3 + i] * f[1] + Rw[2 * 3 + i] * f[2];
     }
     if (u_full) memcpy(u_full, x, sizeof(double) * n);
-    free(P); free(rp);
     return rc;
 }
 

@@ -46,6 +46,7 @@ inline void fnma_bcast_leg(double& acc, double m, double x) {
 inline double row_rsqrt(double p) { return 1.0 / sqrt(p); }
 inline double max_f64(double a, double b) { return fmax(a, b); }
 inline double min_f64(double a, double b) { return fmin(a, b); }
+inline double clamp_f64(double w, double lb, double ub) { return fmin(fmax(w, lb), ub); }
 inline double max_abs_f64(double a, double x) { return fmax(a, fabs(x)); }
 inline double row_dpp_ready(double x) { return x; }
 inline void row_dpp_ready12(double (&)[12]) {}
@@ -83,6 +84,7 @@ inline void sweep_back_chains(double& d, double& pa, double& pb, double r, const
 // ---- a main / twin pair of rows (RowSolver<.., TWIN>): the same operation order as the gfx950 blocks
 inline bool row_is_twin() { return emu_lane >= 16; }
 inline double twin_exchange(double& a) { return emu_twin_exchange(a); }
+inline double twin_exchange_copied(double& a, double /*copy of a (the device block's hazard spacing)*/) { return emu_twin_exchange(a); }
 inline double twin_from_main(double v) { (void)emu_twin_exchange(v); return v; }
 inline void pair_sync() { double z = 0.0; (void)emu_twin_exchange(z); }  // both rows of the pair arrive before either goes on
 inline void coop_sync() { pair_sync(); }  // a set-up shared by the two rows of a pair (the four-row variant of the latency kernel is not emulated)
@@ -103,14 +105,15 @@ inline void sweep_back_chain_twin(double& pa, double& pb, double r, const double
         acc = fma(R_[emu_detail::LANE[b]], M[b], acc);
     }
     pa = pa + pb;
+    pb = pa;  // (the device block leaves the copy that twin_exchange_copied() swaps with)
 }
 template <bool SEED>
-inline void sweep_fwd_gain_twin(double& v, double& sa, double& sb, double s, const double (&Kr)[12], double fA, double fB, double fC, double am) {
+inline void sweep_fwd_gain_twin(double& v, double& s, double& sb, const double (&Kr)[12], double fA, double fB, double fC, double am) {
     const double* S_ = emu_publish(s);
     double va = v, vb = 0.0;
     for (int b = 0; b < 12; b += 2) { va = fma(-S_[emu_detail::LANE[b]], Kr[b], va); vb = fma(-S_[emu_detail::LANE[b + 1]], Kr[b + 1], vb); }
     v = (va + vb) * am;
-    if (SEED) { sa = s; sa = fma(S_[8], fA, sa); sb = fma(S_[9], fB, sb); sa = fma(S_[10], fC, sa); }
+    if (SEED) { s = fma(S_[8], fA, s); sb = fma(S_[9], fB, sb); s = fma(S_[10], fC, s); }  // (the device block accumulates the seeds onto s in place)
 }
 inline void sweep_fwd_input_twin(double& sa, double& sb, double v, const double (&Br)[12]) {
     const double* V_ = emu_publish(v);
@@ -158,6 +161,10 @@ inline void row_sched_fence() {}
 inline void row_lds_landed() {}
 inline double row_opaque(double v) { return v; }
 inline int64_t row_opaque(int64_t v) { return v; }
+inline int row_opaque(int v) { return v; }
+using lds_cptr = const double*;
+template <int OFF>
+inline const double* row_lds_at(const double* p) { return p + OFF; }
 
 
 inline bool row_wave_any(bool p) { return p; }  // one row per emulated wave

@@ -1004,3 +1004,98 @@ def test_pipeline_slots_carry_their_own_update_path_workspace(pkg, scen):
             for f in range(2):
                 assert np.array_equal(outs[f][0].cpu().numpy(), outs[2 + f][0].cpu().numpy()) and np.array_equal(outs[f][1].cpu().numpy(), outs[2 + f][1].cpu().numpy()), (tick, f)
         assert outs[0][1].float().mean().item() < 40   # warm ticks
+
+
+def test_host_pointer_pipeline_matches_the_synchronous_entry(pkg, scen):
+    """a1mpc_pipeline_submit / _wait: host arrays in, host arrays out (the reference's side of the boundary, S/A1RobotControl.h:44), two or three batches in flight.
+    The inputs are snapshotted before submit returns (they are overwritten right behind it here); every batch comes back bit-identical to a1mpc_solve_batch,
+    u_full / iters / status included; a slot that is resubmitted first delivers its previous batch; n = 0 and ragged sizes work."""
+    n, NB = 3000, 5   # beyond the resident rows: the split pipeline
+    scs = [scen.config3_random_flat(nb=n, seed=800 + k) for k in range(NB)]
+    cfg = pkg.make_config(scs[0]["params"], 10, warm_start=0)
+    ref = []
+    with pkg.Engine(cfg, n, 0) as eng:
+        for s in scs:
+            eng.set_schedule(True)
+            ref.append(eng.solve(s["x0"], s["xref"], s["R"], s["foot"], s["contact"], want_u=True))
+    for depth in (2, 3):
+        with pkg.Pipeline(cfg, n, 0, depth=depth) as pipe:
+            outs = [dict(grf=np.full((n, 12), np.nan), u=np.full((n, 120), np.nan), iters=np.full(n, -1, np.int32), status=np.full(n, -99, np.int32)) for _ in range(NB)]
+            for k, s in enumerate(scs):
+                ins = [np.array(s[f]) for f in ("x0", "xref", "R", "foot", "contact")]
+                slot = pipe.submit(*ins, outs[k], fresh=True)   # round-robin: a slot that still holds batch k - depth delivers it first
+                assert slot == k % depth
+                for a in ins:
+                    a[...] = 0            # the caller's arrays are free again as soon as submit returns
+                if k >= depth:            # batch k - depth was delivered by this submit
+                    j = k - depth
+                    assert np.array_equal(outs[j]["grf"], ref[j]["grf"]) and np.array_equal(outs[j]["iters"], ref[j]["iters"]), (depth, j)
+            pipe.wait()
+            for k in range(NB):
+                assert np.array_equal(outs[k]["grf"], ref[k]["grf"]) and np.array_equal(outs[k]["u"], ref[k]["u"]), (depth, k)
+                assert np.array_equal(outs[k]["iters"], ref[k]["iters"]) and np.array_equal(outs[k]["status"], ref[k]["status"]), (depth, k)
+            # ragged: fewer QPs than max_batch, outputs optional, and an empty batch
+            m = 37
+            o = dict(grf=np.zeros((m, 12)))
+            pipe.submit(scs[1]["x0"][:m], scs[1]["xref"][:m], scs[1]["R"][:m], scs[1]["foot"][:m], scs[1]["contact"][:m], o, slot=0)
+            pipe.wait(0)
+            with pkg.Engine(cfg, m, 0) as small:
+                r = small.solve(scs[1]["x0"][:m], scs[1]["xref"][:m], scs[1]["R"][:m], scs[1]["foot"][:m], scs[1]["contact"][:m])
+            assert np.array_equal(o["grf"], r["grf"])
+            e = dict(grf=np.zeros((0, 12)))
+            pipe.submit(scs[1]["x0"][:0], scs[1]["xref"][:0], scs[1]["R"][:0], scs[1]["foot"][:0], scs[1]["contact"][:0], e, slot=1)
+            pipe.wait()
+            with pytest.raises(pkg.A1MpcError):
+                pipe.submit(np.zeros((n + 1, 13)), np.zeros((n + 1, 130)), np.zeros((n + 1, 9)), np.zeros((n + 1, 12)), np.zeros((n + 1, 4), np.uint8), dict(grf=np.zeros((n + 1, 12))))
+
+
+def test_update_path_carry_is_dropped_by_ticks_that_do_not_refresh_it(pkg, oracle, scen):
+    """warm_start = 2: a general-path tick (per-step feet) and a stretch in warm_start = 1 rewrite the carried (x, y, rho) but not the update
+    path's carry.  The fast-path tick that follows must NOT pair the stale scalings / gradient / z with the fresh iterates: it is a fresh set-up warm-started
+    from (x, y, rho) -- exactly what a warm_start = 1 handle that saw the same sequence does, bit for bit."""
+    n = 64
+    rng = np.random.default_rng(77)
+    sc = scen.config3_random_flat(nb=n, seed=4242)
+    seq = []
+    for t in range(6):
+        if t > 0:
+            sc["x0"][:, :12] += rng.normal(0, 2e-3, (n, 12))
+        seq.append({k: np.array(v) if isinstance(v, np.ndarray) else v for k, v in sc.items()})
+    feet_steps = lambda s: np.repeat(s["foot"][:, None, :], 10, axis=1) + rng.normal(0, 1e-3, (n, 10, 12))
+    f2 = feet_steps(seq[2]); c2 = np.repeat(seq[2]["contact"][:, None, :], 10, axis=1)
+    with _engine(pkg, sc, n, warm_start=2) as e2, _engine(pkg, sc, n, warm_start=1) as e1:
+        # ticks 0, 1 on the update path (e1 runs them in mode 1: different numbers from tick 1 on, not compared)
+        for t in (0, 1):
+            e2.solve(seq[t]["x0"], seq[t]["xref"], seq[t]["R"], seq[t]["foot"], seq[t]["contact"])
+        # align the two handles' carried (x, y, rho), then a general-path tick on both
+        x, y, rho = e2.get_warm_start(n)
+        e1.set_warm_start(x, y, rho)
+        e2.set_warm_start(x, y, rho)   # (also clears e2's carry: the documented effect of an injected state)
+        a = e2.solve_strided(seq[2]["x0"], seq[2]["xref"], seq[2]["R"], f2, 12, c2, 4)
+        b = e1.solve_strided(seq[2]["x0"], seq[2]["xref"], seq[2]["R"], f2, 12, c2, 4)
+        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"])
+        # a fast-path tick on the update path first (fills the carry again), then the general path, then the fast path: the last one must equal mode 1
+        a = e2.solve(seq[3]["x0"], seq[3]["xref"], seq[3]["R"], seq[3]["foot"], seq[3]["contact"])
+        b = e1.solve(seq[3]["x0"], seq[3]["xref"], seq[3]["R"], seq[3]["foot"], seq[3]["contact"])
+        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"])   # (tick after a cleared carry = mode 1)
+        x, y, rho = e2.get_warm_start(n); e1.set_warm_start(x, y, rho)
+        a = e2.solve_strided(seq[4]["x0"], seq[4]["xref"], seq[4]["R"], f2, 12, c2, 4)
+        b = e1.solve_strided(seq[4]["x0"], seq[4]["xref"], seq[4]["R"], f2, 12, c2, 4)
+        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"])
+        a = e2.solve(seq[5]["x0"], seq[5]["xref"], seq[5]["R"], seq[5]["foot"], seq[5]["contact"])
+        b = e1.solve(seq[5]["x0"], seq[5]["xref"], seq[5]["R"], seq[5]["foot"], seq[5]["contact"])
+        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"]), "stale update-path carry used after a general-path tick"
+    # the same through a1mpc_update_config: 2 -> 1 -> 2 leaves no stale carry behind
+    with _engine(pkg, sc, n, warm_start=2) as e2, _engine(pkg, sc, n, warm_start=1) as e1:
+        for t in (0, 1):
+            e2.solve(seq[t]["x0"], seq[t]["xref"], seq[t]["R"], seq[t]["foot"], seq[t]["contact"])
+        x, y, rho = e2.get_warm_start(n); e1.set_warm_start(x, y, rho)
+        e2.update_config(pkg.make_config(sc["params"], 10, warm_start=1))
+        for t in (2, 3):
+            a = e2.solve(seq[t]["x0"], seq[t]["xref"], seq[t]["R"], seq[t]["foot"], seq[t]["contact"])
+            b = e1.solve(seq[t]["x0"], seq[t]["xref"], seq[t]["R"], seq[t]["foot"], seq[t]["contact"])
+            assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"])
+        e2.update_config(pkg.make_config(sc["params"], 10, warm_start=2))
+        a = e2.solve(seq[4]["x0"], seq[4]["xref"], seq[4]["R"], seq[4]["foot"], seq[4]["contact"])
+        b = e1.solve(seq[4]["x0"], seq[4]["xref"], seq[4]["R"], seq[4]["foot"], seq[4]["contact"])
+        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"]), "stale update-path carry used after a1mpc_update_config"

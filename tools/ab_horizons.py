@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package(); pkg.engine._lib = pkg.engine.load_library(sys.argv[1])  # (load_library only caches the in-tree path)
 res = {}
-for gen, n, h in (("config4_random_h16", 8192, 16), ("config5_divergent", 16384, 20)):
+for gen, n, h in [c for c in (("config4_random_h16", 8192, 16), ("config5_divergent", 16384, 20)) if os.environ.get("A1_AB_H") in (None, str(c[2]))]:  # A1_AB_H=16: a slim build of one horizon
     sc = getattr(pkg.scenarios, gen)(nb=n)
     with pkg.Engine(pkg.make_config(sc["params"], h, warm_start=0), n, 0) as eng:
         ms = []

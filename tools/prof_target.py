@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 import torch
 pkg = g.load_package()
+if os.environ.get("A1_LIB"):  # profile another build of the library (the engine's loader only caches the in-tree path)
+    pkg.engine._lib = pkg.engine.load_library(os.environ["A1_LIB"])
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 sc = pkg.scenarios.config3_random_flat(nb=n)
 osqp = dict(warm_start=0)
