@@ -23,22 +23,49 @@ def hipcc():
     raise RuntimeError("hipcc not found (ROCm toolchain required to build liba1mpc.so)")
 
 
-def needs_build():
+def source_hash():
+    """sha256 (16 hex digits) over the library's sources: compiled into the library (a1mpc_build_info) so that a shipped liba1mpc.so can be matched to the sources
+    beside it -- file times do not survive a snapshot"""
+    import hashlib
+    h = hashlib.sha256()
+    for d in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(_HERE), "include", "a1mpc.h")]:
+        h.update(open(d, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def library_hash():
+    """the source hash the existing library was compiled from, or None (missing library / a build from before the hash existed)"""
+    import ctypes
     if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(_HERE), "include", "a1mpc.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+        return None
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.a1mpc_build_info.restype = ctypes.c_char_p
+        info = lib.a1mpc_build_info().decode()
+        return info.split("sources ")[1].split()[0]
+    except Exception:
+        return None
+
+
+def needs_build():
+    return library_hash() != source_hash()
+
+
+last_build = {}   # what the last build() call did: {"compiled": bool, "source_hash": ..., "seconds": ...} (reported by __graft_entry__.build)
 
 
 def build(force=False, verbose=False):
     """hipcc -> liba1mpc.so, then the DPP hazard check of the generated gfx950 assembly (isa_check.py): a library whose inline-asm
     DPP chains read a register too early after a VALU write is deleted again and the build fails."""
-    if not force and not needs_build():
+    import time
+    sh = source_hash()
+    if not force and os.environ.get("A1MPC_FORCE_BUILD") is None and library_hash() == sh:
+        last_build.update(compiled=False, source_hash=sh, seconds=0.0)   # the library IS the compilation of these sources (hash compiled in), hazard-checked when it was built
         return LIB_PATH
+    t_start = time.time()
     from . import isa_check
     with tempfile.TemporaryDirectory(prefix="a1mpc_build_") as tmp:  # -save-temps writes the listings into the working directory
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-save-temps", "-I", os.path.join(CSRC, "gfx950"),
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-save-temps", f'-DA1MPC_SOURCE_HASH="{sh}"', "-I", os.path.join(CSRC, "gfx950"),
                "-I", CSRC, os.path.join(CSRC, "a1mpc_hip.hip"), "-o", LIB_PATH]
         if verbose:
             print(" ".join(cmd))
@@ -52,6 +79,7 @@ def build(force=False, verbose=False):
     if bad:
         os.remove(LIB_PATH)
         raise RuntimeError("DPP read hazards in the generated code (library removed):\n" + "\n".join(bad[:20]))
+    last_build.update(compiled=True, source_hash=sh, seconds=time.time() - t_start)
     return LIB_PATH
 
 

@@ -1718,6 +1718,12 @@ const char* a1mpc_status_string(a1mpc_status s) {
 }
 const char* a1mpc_last_error(void) { return g_last_error.c_str(); }
 
+#ifndef A1MPC_SOURCE_HASH
+#define A1MPC_SOURCE_HASH "unknown"
+#endif
+// which sources this library is the compilation of (build.py: sha256 over csrc/ + include/a1mpc.h) -- a shipped .so is matched against the sources beside it
+const char* a1mpc_build_info(void) { return "sources " A1MPC_SOURCE_HASH " arch gfx950"; }
+
 void a1mpc_destroy(a1mpc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);

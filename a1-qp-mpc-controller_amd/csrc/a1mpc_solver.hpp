@@ -271,7 +271,10 @@ struct LayoutSetup {
 template <int H>
 struct Carry {
     static constexpr int C = 0, D = 1, E0 = D + 12 * H, E1 = E0 + 12 * H, G = E1 + 12 * H, Z0 = G + 12 * H, Z1 = Z0 + 12 * H;
-    static constexpr int STRIDE = Z1 + 12 * H + 1;  // (even)
+    // SIG [12 lanes]: which entries of my rows of U and V were non-zero -- the sparsity pattern of the previous tick's Hessian as osqp-eigen's updateHessianMatrix
+    // compares it (the reference's hessian is dense.sparseView(), S/ConvexMpc.cpp:211: exact zeros are not stored); see RowSolver::setup, "pattern change"
+    static constexpr int SIG = Z1 + 12 * H;
+    static constexpr int STRIDE = SIG + 12 + 1;  // (even)
 };
 
 // prepared state handed from the set-up kernel to the ADMM kernel: [field][12 active lanes] doubles per QP (pad lanes hold nothing).
@@ -665,10 +668,26 @@ struct RowSolver {
         using CR = Carry<H>;
         upd = false;
         if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) upd = P.warm_start == 2 && io.carry != nullptr && io.warm_x != nullptr && io.warm_y != nullptr && io.carry[CR::C] > 0.0;
+        // Pattern change.  osqp-eigen's updateHessianMatrix takes osqp_update_P only while the upper-triangular triplets of hessian.sparseView() keep their pattern; when
+        // exact zeros of the reference's dense B_qp'QB_qp appear or vanish it reads the workspace iterates, clears the solver, initialises it again (fresh scaling with
+        // the CURRENT data, rho back to settings.rho) and warm-starts it with those iterates through osqp_warm_start_x / _y -- which scale what they are given, and
+        // what they are given are the previous solve's SCALED iterates (oracle/a1mpc_oracle.c osqp_solve_impl, `reinit`).  Block (s,t) of the Hessian is alpha_st U + beta_st V with
+        // alpha_st = 0 exactly where max(s,t) = H - 1, so the pattern of P is a function of the zero patterns of U and V: my rows' 24 flags are the signature.
+        [[maybe_unused]] bool reinit = false;
+        [[maybe_unused]] double sig = 0.0;
+        if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) {
+            unsigned bits = 0;
+            static_for<12>([&](auto B) { bits |= (U[B] != 0.0 ? 1u : 0u) << A1_CV(B); bits |= (V[B] != 0.0 ? 1u : 0u) << (12 + A1_CV(B)); });
+            sig = act ? static_cast<double>(bits) : 0.0;
+            if (upd) {
+                const double prev = act ? io.carry[CR::SIG + ci] : 0.0;
+                reinit = row_allmax(prev != sig ? 1.0 : 0.0) > 0.0;
+            }
+        }
         [[maybe_unused]] double gq[(UPD && MODE == kModeMpc && H > 1 && !GEN) ? H : 1];   // the gradient the cost normalisation sees: the previous tick's on the update path
         if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) {
 #pragma unroll
-            for (int t = 0; t < H; ++t) gq[t] = upd ? (act ? io.carry[CR::G + t * 12 + ci] : 0.0) : g[t];
+            for (int t = 0; t < H; ++t) gq[t] = (upd && !reinit) ? (act ? io.carry[CR::G + t * 12 + ci] : 0.0) : g[t];
         }
         double D[H], E0[H], E1[H];
         csc = 1.0;
@@ -843,6 +862,7 @@ struct RowSolver {
         rho = P.rho0;
         warm = P.warm_start && io.warm_x != nullptr && io.warm_y != nullptr;
         if (warm && io.rho_io != nullptr && *io.rho_io > 0.0) rho = *io.rho_io;
+        if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) { if (reinit) rho = P.rho0; }   // a re-initialised solver starts from its settings' rho
         rho = fmin(fmax(rho, kRhoMin), kRhoMax);
         // OSQP's first iteration starts from z0 = A x0 (not projected) and y0; with x0 = y0 = 0 and 0 inside the bounds it
         // coincides with the generic w-form iteration from w = 0
@@ -871,7 +891,17 @@ struct RowSolver {
             park_warm_y(io, t);
             if (act) lds[L::CG + t * 12 + ci] = csc * g[t];          // D^-1 q_s = c g
             if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) {
-                if (upd) {
+                if (upd && reinit) {
+                    // pattern change: the previous solve's SCALED x_s = x / D', y_s = c' y / E' go through osqp_warm_start_x / _y as if they were unscaled -- a plain
+                    // warm start (the code of warm_start = 1 below and in the first iteration) from those values
+                    const double* cr = io.carry;
+                    const double cp = cr[CR::C];
+                    const double Dp = act ? cr[CR::D + t * 12 + ci] : 1.0, E0p = act ? cr[CR::E0 + t * 12 + ci] : 1.0, E1p = (act && comp < 2) ? cr[CR::E1 + t * 12 + ci] : 1.0;
+                    xh[t] = act ? xh[t] / Dp : 0.0;
+                    wh0[t] = act ? (cp / E0p) * wh0[t] : 0.0;
+                    wh1[t] = (act && comp < 2) ? (cp / E1p) * wh1[t] : 0.0;
+                    epsv[t] = 0.0;   // (they travel like the update path's y^: through the hand-off record, with an uncorrected c g)
+                } else if (upd) {
                     // The carried SCALED iterates (x_s, z_s, y_s) are used as they are, i.e. read in the NEW scaling:  x0 = D (x / D'), z0 = (E' / E) z,
                     // y0 = (c' / c)(E / E') y  with the previous scalings D', E', c' and the previous unscaled x, z, y.  OSQP's first iteration uses z0 twice:
                     // E (rho z0 - y0) in the right-hand side and (1 - alpha) z0 + y0 / rho in the w update.  The kernels compute z0 = A x0 in both places
@@ -911,6 +941,7 @@ struct RowSolver {
                         cw[CR::D + t * 12 + ci] = D[t]; cw[CR::E0 + t * 12 + ci] = E0[t]; cw[CR::G + t * 12 + ci] = g[t];
                         if (comp < 2) cw[CR::E1 + t * 12 + ci] = E1[t];
                     });
+                    cw[CR::SIG + ci] = sig;
                 }
                 if (ln == 0) cw[CR::C] = csc;
             }

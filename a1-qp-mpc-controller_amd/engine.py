@@ -43,7 +43,7 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
 EXPORTS = ["a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
-           "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error", "a1mpc_pipeline_create", "a1mpc_pipeline_submit_device", "a1mpc_pipeline_submit",
+           "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error", "a1mpc_build_info", "a1mpc_pipeline_create", "a1mpc_pipeline_submit_device", "a1mpc_pipeline_submit",
            "a1mpc_pipeline_wait", "a1mpc_pipeline_join", "a1mpc_pipeline_handle", "a1mpc_pipeline_depth", "a1mpc_pipeline_destroy"]
 
 _lib = None

@@ -132,6 +132,7 @@ class ConvexMpcGpu {
                     throw std::logic_error("a1mpc::ConvexMpcGpu: B_mat_d_list was edited by other means than storing B_mat_d after each calculate_B_mat_c / "
                                            "state_space_discretization call; arbitrary B_d blocks cannot be passed to the GPU path (it takes foot positions)");
         if (static_cast<int>(feet_.size()) > 12 * H) feet_.erase(feet_.begin(), feet_.end() - 12 * H);   // the last H recorded calls = the H blocks of B_mat_d_list
+        if (static_cast<int>(recorded_B_.size()) > H) recorded_B_.erase(recorded_B_.begin(), recorded_B_.end() - H);   // (a persistent instance that is never reset() would grow by H matrices per tick)
         per_step_feet_ = false;
         for (int i = 1; i < H && !per_step_feet_; ++i) per_step_feet_ = std::memcmp(&feet_[12 * i], &feet_[0], 12 * sizeof(double)) != 0;
         fz_min = 0; fz_max = 180;                                         // S/ConvexMpc.cpp:223-224
@@ -283,6 +284,10 @@ class ComputeGrfGpu {
     // robot constants and weights are read from the state every tick, like the reference's per-tick ConvexMpc construction (:447)
     void sync_config(State& state, double mpc_dt) {
         a1mpc_config c = cfg_;
+        // use_sim_time == "true" hands the caller's dt over (S/A1RobotControl.cpp:465), and the first simulated tick may carry dt <= 0: the reference then solves a
+        // degenerate QP (B_d = 0) and returns its matrix; the library rejects a non-positive dt, and an exception out of the control thread is worse than either --
+        // such a tick runs on the last valid dt (0.0025 before there was one)
+        if (!(mpc_dt > 0.0)) mpc_dt = cfg_.dt > 0.0 ? cfg_.dt : 0.0025;
         c.dt = mpc_dt; c.mass = state.robot_mass;
         for (int i = 0; i < A1MPC_STATE_DIM; ++i) c.q[i] = state.q_weights(i);
         for (int i = 0; i < A1MPC_NUM_DOF; ++i) c.r[i] = state.r_weights(i);

@@ -406,8 +406,9 @@ static void *scratch_get(int slot, size_t bytes, int zero) {
  */
 static int osqp_solve_impl(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
                    const double *l, const double *u, const orc_settings *st, double *x, double *y, double *rho_io,
-                   orc_info *info, double *carry) {
+                   orc_info *info, double *carry, int pattern_changed) {
     const int upd = carry && carry[0] != 0.0;
+    const int reinit = upd && pattern_changed;   /* osqp-eigen's updateHessianMatrix with a changed sparsity pattern: see below */
     double *c_xs = carry ? carry + 2 : 0, *c_zs = carry ? c_xs + n : 0, *c_ys = carry ? c_zs + m : 0, *c_q = carry ? c_ys + m : 0, *c_l = carry ? c_q + n : 0, *c_u = carry ? c_l + m : 0;
     work_t w; memset(&w, 0, sizeof w);
     int nnz = rp[m];
@@ -431,10 +432,10 @@ static int osqp_solve_impl(int n, int m, const double *P, const double *q, const
     memcpy(w.l, l, sizeof(double) * m); memcpy(w.u, u, sizeof(double) * m);
     memset(info, 0, sizeof *info); info->status = ORC_UNSOLVED;
     w.rho = (rho_io && st->warm_start && *rho_io > 0) ? *rho_io : st->rho;
-    if (upd) {  /* osqp_update_P re-scales with the previous tick's q, l, u in the workspace; settings->rho is the previous solve's */
+    if (upd && !reinit) {  /* osqp_update_P re-scales with the previous tick's q, l, u in the workspace; settings->rho is the previous solve's */
         memcpy(w.q, c_q, sizeof(double) * n); memcpy(w.l, c_l, sizeof(double) * m); memcpy(w.u, c_u, sizeof(double) * m);
         w.rho = carry[1];
-    } else if (carry) w.rho = st->rho;
+    } else if (carry) w.rho = st->rho;   /* first tick, or reinit: osqp_setup with the solver's own settings (rho back to settings->rho) and the current q, l, u */
 
     /* osqp_setup */
     if (st->scaling) scale_data(&w);
@@ -443,7 +444,19 @@ static int osqp_solve_impl(int n, int m, const double *P, const double *q, const
     int rc = factor(&w);
     if (rc) { info->status = ORC_NON_CVX; goto done; }
 
-    if (upd) {
+    if (reinit) {
+        /* osqp-eigen 0.6.3, Solver::updateHessianMatrix when the triplets of hessian.sparseView() no longer match the workspace's P (the reference's dense
+         * B_qp'QB_qp gains or loses exact zeros, S/ConvexMpc.cpp:211; level stance, yaw = 0, symmetric feet -- fixture T is such a state): osqp_update_P cannot
+         * change a pattern, so osqp-eigen does  getPrimalVariable / getDualVariable -- which map the WORKSPACE iterates work->x, work->y, i.e. the previous solve's
+         * SCALED x_s = D'^-1 x, y_s = c' E'^-1 y --, clearSolver, initSolver (= the osqp_setup above: fresh scaling with the current data, rho = settings->rho),
+         * setPrimalVariable / setDualVariable = osqp_warm_start_x / _y, which treat what they are given as unscaled:  x <- D^-1 x_s,  z <- A x,  y <- c E^-1 y_s.
+         * The updateGradient / update*Bound calls that follow in compute_grf hand over the data osqp_setup has just seen: nothing changes.  (Restated from memory of
+         * osqp-eigen's Solver.tpp, unpinned like the rest of the solve.  initSolver re-reads q, l, u through the pointers setGradient / set*Bound stored at the first
+         * tick -- the members of that tick's local ConvexMpc object; every tick's object lives at the same stack address, so it finds the current tick's values.) */
+        for (int j = 0; j < n; ++j) w.x[j] = w.Dinv[j] * c_xs[j];
+        csr_mv(m, rp, ci, w.av, w.x, w.z);
+        for (int i = 0; i < m; ++i) w.y[i] = w.c * w.Einv[i] * c_ys[i];
+    } else if (upd) {
         for (int j = 0; j < n; ++j) w.q[j] = (w.D[j] * q[j]) * w.c;                 /* osqp_update_lin_cost: vec_ew_prod(D, q), vec_mult_scalar(q, c) */
         for (int i = 0; i < m; ++i) w.l[i] = w.E[i] * l[i];                        /* osqp_update_lower_bound */
         if (update_rho_vec(&w)) { rc = factor(&w); if (rc) { info->status = ORC_NON_CVX; goto done; } }
@@ -538,11 +551,26 @@ done:
 int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
                    const double *l, const double *u, const orc_settings *st, double *x, double *y, double *rho_io,
                    orc_info *info) {
-    return osqp_solve_impl(n, m, P, q, rp, ci, av, l, u, st, x, y, rho_io, info, 0);
+    return osqp_solve_impl(n, m, P, q, rp, ci, av, l, u, st, x, y, rho_io, info, 0, 0);
 }
 int orc_osqp_solve_update(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
                           const double *l, const double *u, const orc_settings *st, double *x, double *y, double *carry, orc_info *info) {
-    return osqp_solve_impl(n, m, P, q, rp, ci, av, l, u, st, x, y, 0, info, carry);
+    return osqp_solve_impl(n, m, P, q, rp, ci, av, l, u, st, x, y, 0, info, carry, 0);
+}
+/* the same when the caller (osqp-eigen's updateHessianMatrix) has found the sparsity pattern of P changed since the previous tick: re-initialisation + warm start */
+int orc_osqp_solve_update_ex(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
+                             const double *l, const double *u, const orc_settings *st, double *x, double *y, double *carry, int pattern_changed, orc_info *info) {
+    return osqp_solve_impl(n, m, P, q, rp, ci, av, l, u, st, x, y, 0, info, carry, pattern_changed);
+}
+/* sparsity pattern of the upper triangle of a dense symmetric P as hessian.sparseView() sees it (exact zeros dropped): FNV-1a over the non-zero flags, plus the count */
+void orc_pattern_signature(int n, const double *P, double *sig2) {
+    uint64_t hsh = 1469598103934665603ULL; int64_t nnz = 0;
+    for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) {
+        const int nz = P[(size_t)i * n + j] != 0.0;
+        nnz += nz; hsh = (hsh ^ (uint64_t)nz) * 1099511628211ULL;
+    }
+    sig2[0] = (double)(hsh >> 12);   /* 52 bits: exact in a double */
+    sig2[1] = (double)nnz;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -711,7 +739,8 @@ int orc_mpc_solve(const orc_mpc_params *pr, const orc_settings *st, const double
     return rc;
 }
 
-/* One MPC tick on the reference's UPDATE PATH (see osqp_solve_impl): carry = 2 + 2n + 4m doubles, zero before the first tick of a robot. */
+/* One MPC tick on the reference's UPDATE PATH (see osqp_solve_impl): carry = 2 + 2n + 4m doubles + 2 for the sparsity pattern of the previous tick's P
+ * (osqp-eigen compares it in updateHessianMatrix), zero before the first tick of a robot. */
 int orc_mpc_solve_update(const orc_mpc_params *pr, const orc_settings *st, const double *x0, const double *xref, const double *Rw,
                          const double *foot, const uint8_t *contact, double *grf_out, double *u_full, double *carry, orc_info *info) {
     const int h = pr->horizon, n = NU * h, m = NC * h;
@@ -720,7 +749,12 @@ int orc_mpc_solve_update(const orc_mpc_params *pr, const orc_settings *st, const
     int32_t *rp = (int32_t *)scratch_get(7, sizeof(int32_t) * (m + 1 + 36 * h), 0), *ci = rp + m + 1;
     orc_mpc_form(pr, x0, xref, x0[2], Rw, foot, 0, contact, 0, P, g, rp, ci, av, l, u);
     memset(x, 0, sizeof(double) * n); memset(y, 0, sizeof(double) * m);
-    int rc = orc_osqp_solve_update(n, m, P, g, rp, ci, av, l, u, st, x, y, carry, info);
+    double sig[2], *csig = carry + 2 + 2 * n + 4 * m;
+    orc_pattern_signature(n, P, sig);
+    const int changed = carry[0] != 0.0 && (sig[0] != csig[0] || sig[1] != csig[1]);
+    csig[0] = sig[0]; csig[1] = sig[1];
+    int rc = orc_osqp_solve_update_ex(n, m, P, g, rp, ci, av, l, u, st, x, y, carry, changed, info);
+    info->reinit = changed;
     for (int leg = 0; leg < NLEG; ++leg) {
         const double *f = x + 3 * leg;
         int bad = isnan(f[0]) || isnan(f[1]) || isnan(f[2]);

@@ -30,6 +30,7 @@ typedef struct orc_settings {
 typedef struct orc_info {
     int32_t iters, status, rho_updates, nfact;
     double pri_res, dua_res, rho_final;
+    int32_t reinit, pad_;   /* update path: this tick re-initialised the solver (osqp-eigen: the sparsity pattern of P changed) */
 } orc_info;
 
 void orc_default_settings(orc_settings *s);
@@ -39,6 +40,9 @@ int orc_osqp_solve(int n, int m, const double *P, const double *q, const int32_t
 /* the same solve on OSQP's UPDATE path (a persistent workspace between ticks): carry = 2 + 2n + 4m doubles, zero before the first tick (a1mpc_oracle.c, osqp_solve_impl) */
 int orc_osqp_solve_update(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
                           const double *l, const double *u, const orc_settings *st, double *x, double *y, double *carry, orc_info *info);
+/* ... when the caller has found the sparsity pattern of P changed since the previous tick (osqp-eigen's updateHessianMatrix): re-initialisation + warm start */
+int orc_osqp_solve_update_ex(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
+                             const double *l, const double *u, const orc_settings *st, double *x, double *y, double *carry, int pattern_changed, orc_info *info);
 #ifdef __cplusplus
 }
 #endif

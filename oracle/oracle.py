@@ -28,7 +28,7 @@ class Settings(C.Structure):
 
 class Info(C.Structure):
     _fields_ = [("iters", C.c_int32), ("status", C.c_int32), ("rho_updates", C.c_int32), ("nfact", C.c_int32),
-                ("pri_res", C.c_double), ("dua_res", C.c_double), ("rho_final", C.c_double)]
+                ("pri_res", C.c_double), ("dua_res", C.c_double), ("rho_final", C.c_double), ("reinit", C.c_int32), ("pad_", C.c_int32)]
 
 
 class MpcParams(C.Structure):
@@ -170,8 +170,8 @@ def mpc_solve(pr, st, x0, xref, Rw, foot, contact, warm_x=None, warm_y=None, war
 
 
 def update_carry(horizon):
-    """zeroed workspace carry of mpc_solve_update for one robot (2 + 2n + 4m doubles)"""
-    return np.zeros(2 + 2 * NU * horizon + 4 * NC * horizon)
+    """zeroed workspace carry of mpc_solve_update for one robot (2 + 2n + 4m doubles + 2 for the sparsity pattern of the previous tick's P)"""
+    return np.zeros(4 + 2 * NU * horizon + 4 * NC * horizon)
 
 
 def mpc_solve_update(pr, st, x0, xref, Rw, foot, contact, carry):
@@ -179,7 +179,7 @@ def mpc_solve_update(pr, st, x0, xref, Rw, foot, contact, carry):
     S/A1RobotControl.cpp:533-538; see osqp_solve_impl in a1mpc_oracle.c).  `carry` is updated in place."""
     h = pr.horizon
     grf = np.zeros(12); u = np.zeros(NU * h); info = Info()
-    assert carry.dtype == np.float64 and carry.size == 2 + 2 * NU * h + 4 * NC * h and carry.flags.c_contiguous
+    assert carry.dtype == np.float64 and carry.size == 4 + 2 * NU * h + 4 * NC * h and carry.flags.c_contiguous
     lib().orc_mpc_solve_update(C.byref(pr), C.byref(st), _p(np.ascontiguousarray(x0, dtype=np.float64)), _p(np.ascontiguousarray(xref, dtype=np.float64)),
                                _p(np.ascontiguousarray(Rw, dtype=np.float64)), _p(np.ascontiguousarray(foot, dtype=np.float64)),
                                _p(np.ascontiguousarray(contact, dtype=np.uint8), C.c_uint8), _p(grf), _p(u), _p(carry), C.byref(info))

@@ -73,7 +73,8 @@ def last_qp(horizon=10):
     L.ref_last_qp(_p(P), _p(q), _p(A), _p(l), _p(u), _p(x), _p(y))
     it, st, nf = C.c_int(), C.c_int(), C.c_int(); rho = C.c_double()
     L.ref_last_info(C.byref(it), C.byref(st), C.byref(nf), C.byref(rho))
-    return dict(P=P, q=q, A=A, l=l, u=u, x=x, y=y, iters=it.value, status=st.value, nfact=nf.value, rho=rho.value, solves=solves)
+    re = C.c_int(); reinits = L.ref_last_reinit(C.byref(re))
+    return dict(P=P, q=q, A=A, l=l, u=u, x=x, y=y, iters=it.value, status=st.value, nfact=nf.value, rho=rho.value, solves=solves, reinit=re.value, reinits=reinits)
 
 
 def run_test_mpc(horizon=10):

@@ -99,6 +99,8 @@ void ref_last_qp(double *P, double *q, double *A, double *l, double *u, double *
     if (x) std::memcpy(x, r.x.data(), sizeof(double) * r.x.size());
     if (y) std::memcpy(y, r.y.data(), sizeof(double) * r.y.size());
 }
+// did the most recent solve() re-initialise the solver (updateHessianMatrix found another sparsity pattern)?  returns the total count of such updates so far
+int ref_last_reinit(int *this_solve) { auto &r = OsqpEigen::shim_last(); *this_solve = r.info.reinit; return r.reinits; }
 void ref_last_info(int *iters, int *status, int *nfact, double *rho_final) {
     auto &r = OsqpEigen::shim_last(); *iters = r.info.iters; *status = r.info.status; *nfact = r.info.nfact; *rho_final = r.info.rho_final;
 }

@@ -16,7 +16,7 @@ const double INFTY = 1e30;   // OSQP's OSQP_INFTY
 
 // what the last solve() of any Solver saw and produced (read by oracle/ref_harness.cpp)
 struct ShimRecord {
-    int n = 0, m = 0, solves = 0, inits = 0;
+    int n = 0, m = 0, solves = 0, inits = 0, reinits = 0;   // reinits: updateHessianMatrix calls that found another sparsity pattern
     std::vector<double> P, q, A, l, u, x, y;   // P n*n row-major (full symmetric), A m*n row-major
     orc_info info{};
 };
@@ -66,6 +66,14 @@ class Solver {
     std::vector<double> x_, y_; double rho_ = 0;   // last (x, y) and rho (cold / one-off solves)
     std::vector<double> carry_;                    // the persistent OSQP workspace of a warm-started solver between ticks: update*() + solve() follow OSQP's UPDATE path
                                                    // (orc_osqp_solve_update: osqp_update_P re-equilibrating with the previous gradient, carried scaled iterates)
+    std::vector<unsigned char> pattern_;           // non-zero flags of the upper triangle of the Hessian the workspace was set up / last updated with
+    bool pattern_changed_ = false;                 // updateHessianMatrix found another pattern: the next solve() re-initialises (osqp-eigen 0.6.3, see updateHessianMatrix)
+    static std::vector<unsigned char> pattern_of(const Eigen::SparseMatrix<double> &H) {
+        // what osqp-eigen compares: the triplets of the upper triangle of H (H comes from dense.sparseView(): exact zeros are not stored)
+        std::vector<unsigned char> p; const int n = H.rows();
+        for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) p.push_back(H.stored(i, j) && H.coeff(i, j) != 0.0 ? 1 : 0);
+        return p;
+    }
     Eigen::VectorXd sol_;
   public:
     const std::unique_ptr<Settings> &settings() const { return s_; }
@@ -75,10 +83,24 @@ class Solver {
         if (!(d_->hasP && d_->hasq && d_->hasA && d_->hasl && d_->hasu)) return false;
         init_ = true; x_.assign((size_t)d_->n, 0.0); y_.assign((size_t)d_->m, 0.0); rho_ = 0; shim_last().inits++;
         carry_.assign((size_t)(2 + 2 * d_->n + 4 * d_->m), 0.0);
+        pattern_.clear(); pattern_changed_ = false;
+        {   // the pattern the workspace is set up with (Data keeps the full symmetric matrix)
+            const int n = d_->n;
+            for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) pattern_.push_back(d_->P[(size_t)i * n + j] != 0.0 ? 1 : 0);
+        }
         return true;
     }
     void clearSolver() { init_ = false; }
-    bool updateHessianMatrix(const Eigen::SparseMatrix<double> &H) { return init_ && d_->setHessianMatrix(H); }
+    // osqp-eigen 0.6.3 Solver::updateHessianMatrix: the new upper-triangular triplets are compared with those of the workspace's P.  Same pattern: osqp_update_P
+    // (the UPDATE path).  Another pattern -- the reference's dense B_qp'QB_qp gained or lost exact zeros (S/ConvexMpc.cpp:211 sparseView) --: the primal / dual
+    // workspace iterates are read, the solver is cleared and initialised again with the new Hessian, and the iterates go back in through osqp_warm_start_x / _y
+    // (orc_osqp_solve_update_ex with pattern_changed = 1 restates exactly that on the carried workspace).
+    bool updateHessianMatrix(const Eigen::SparseMatrix<double> &H) {
+        if (!init_ || !d_->setHessianMatrix(H)) return false;
+        std::vector<unsigned char> p = pattern_of(H);
+        if (p != pattern_) { pattern_changed_ = true; pattern_ = p; shim_last().reinits++; }
+        return true;
+    }
     bool updateGradient(const Eigen::Dyn<double> &g) { return init_ && d_->setGradient(g); }
     bool updateLowerBound(const Eigen::Dyn<double> &v) { return init_ && d_->setLowerBound(v); }
     bool updateUpperBound(const Eigen::Dyn<double> &v) { return init_ && d_->setUpperBound(v); }
@@ -96,8 +118,10 @@ class Solver {
         int rc;
         if (st.warm_start) {   // the reference's MPC solver: initSolver once, then updateHessianMatrix / updateGradient / update*Bound + solve every tick
             x_.assign((size_t)n, 0.0); y_.assign((size_t)m, 0.0);
-            rc = orc_osqp_solve_update(n, m, d_->P.data(), d_->q.data(), rp.data(), ci.data(), av.data(), d_->l.data(), d_->u.data(), &st,
-                                       x_.data(), y_.data(), carry_.data(), &rec.info);
+            rc = orc_osqp_solve_update_ex(n, m, d_->P.data(), d_->q.data(), rp.data(), ci.data(), av.data(), d_->l.data(), d_->u.data(), &st,
+                                          x_.data(), y_.data(), carry_.data(), pattern_changed_ ? 1 : 0, &rec.info);
+            rec.info.reinit = pattern_changed_ ? 1 : 0;
+            pattern_changed_ = false;
         } else {
             rc = orc_osqp_solve(n, m, d_->P.data(), d_->q.data(), rp.data(), ci.data(), av.data(), d_->l.data(), d_->u.data(), &st,
                                 x_.data(), y_.data(), &rho_, &rec.info);

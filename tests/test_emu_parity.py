@@ -302,3 +302,36 @@ def test_emulated_update_path_matches_oracle(oracle, scen, path):
             assert o["info"].status == -7 and not e["grf"].any()
         elif i > 0:
             assert abs(rho[0] - carry_o[1]) <= 1e-9 * carry_o[1]
+
+
+@pytest.mark.parametrize("path", ["fused_twin", "split_twin"])
+def test_emulated_update_path_reinitialises_on_a_pattern_change(oracle, scen, path):
+    """warm_start = 2 when exact zeros of the reference's Hessian appear / vanish (fixture T's weights: level <-> pitched): osqp-eigen's updateHessianMatrix
+    re-initialises the solver and warm-starts it with the workspace's scaled iterates.  The kernels detect the change from the zero patterns of U and V (the
+    pattern of P = alpha (x) U + beta (x) V is a function of them), the oracle from the dense P it forms like the reference: same ticks, same iterates."""
+    T = scen.scenario_T(); p = T["params"]; h = 10
+    pr = oracle_params(oracle, T); st = oracle.default_settings(warm_start=1)
+    kw = dict(fused_twin=dict(twin=True), split_twin=dict(split_rows=1, twin=True))[path]
+    carry_o = oracle.update_carry(h)
+    wx = np.zeros((1, 120)); wy = np.zeros((1, 200)); rho = np.zeros(1); carry = emu.carry_buffer(h, 1)
+    nominal = np.array([0.17, 0.15, -0.35, 0.17, -0.15, -0.35, -0.17, 0.15, -0.35, -0.17, -0.15, -0.35]).reshape(4, 3)
+    # Two re-initialisations, no more: the doubly scaled warm start the reference's path produces is a poor starting point on fixture T's ill-conditioned QP (r = 1e-6),
+    # and every re-initialised solve amplifies rounding differences ~1000x -- the ORACLE's own two linear-system back ends (mathematically identical) are 2e-7 N apart
+    # after the second one, 9e-2 N after the third, and 250 vs 4000 iterations after the fourth on this very sequence.  (Nothing to do with the kernels: mode 1 and
+    # the pattern-preserving update path agree to 1e-12 N along it.)
+    pitches = [0.0, 0.0, 0.02, 0.03, 0.0, 0.0]
+    seen = []
+    for t, pitch in enumerate(pitches):
+        R = scen.rot_zyx(0.0, pitch, 0.0)
+        foot = (R @ nominal.T).T.reshape(12) if pitch else nominal.reshape(12)
+        x0 = np.array([0.0, pitch, 0.0, 0.0, 0.0, 0.15 + 0.001 * t, 0, 0, 0, 0, 0, 0, -9.8])
+        xref = oracle.mpc_reference(h, p["dt"], x0[0:3], x0[3:6], R.reshape(9), np.zeros(3), np.zeros(3), np.zeros(3), 0.15)
+        contact = np.array([1, 0, 1, 0], np.uint8)
+        o = oracle.mpc_solve_update(pr, st, x0, xref, R.reshape(9), foot, contact, carry_o)
+        one = dict(T); one.update(x0=x0[None], xref=xref[None], R=R.reshape(1, 9), foot=foot[None], contact=contact[None])
+        e = emu.solve(one, n=1, warm=(wx, wy, rho), carry=carry, warm_start=2, **kw)
+        seen.append(int(o["info"].reinit))
+        assert e["iters"][0] == o["info"].iters and e["status"][0] == o["info"].status, (path, t, e["iters"], o["info"].iters, seen)
+        assert np.abs(e["grf"][0] - o["grf"]).max() < 1e-7, (path, t)
+        assert abs(rho[0] - carry_o[1]) <= 1e-6 * carry_o[1]
+    assert seen == [0, 0, 1, 0, 1, 0]

@@ -106,3 +106,40 @@ def test_two_ranks_share_the_gpu_and_run_the_engine():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert same_grf and same_it and solved
+
+
+def _run_bench(*flags, timeout=420):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):   # no launcher around it: bench.py starts its own ranks
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]      # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts two ranks itself and prints n_gpus = 2 -- on the one-GPU test box the two ranks
+    share the GPU over gloo (said so in config.parallelism); both the weak-scaling metric and --config 4 (scatter + solve + gather in the timed region) run end to end."""
+    out = _run_bench("--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-latency", "--no-index-order")
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["solved_frac"] == 1.0
+    assert "roofline" in out and out["unit"] == "solves/s"
+    out4 = _run_bench("--gpus", "2", "--config", "4", "--batch", "4000", "--steps", "2", "--warmup", "1")
+    assert out4["n_gpus"] == 2 and out4["scaling"] == "strong" and out4["config"]["global_batch"] == 4000 and out4["config"]["solved_frac"] > 0.99
+    one = _run_bench("--config", "4", "--batch", "4000", "--steps", "2", "--warmup", "1")   # N = 1: the device-resident path without host synchronisation in the step
+    assert one["n_gpus"] == 1 and one["config"]["mean_iters"] == out4["config"]["mean_iters"]
+
+
+@pytest.mark.gpu
+def test_bench_native_runs_both_transports():
+    """`bench.py --native t --gpus N`: one process, the batch sharded inside the C ABI (a1mpc_sharded_*), both transports measured side by side.  On the one-GPU box
+    transport 0 runs its shards on the same GPU and the RCCL transport runs over the one device there is (communicator, root staging, no peer)."""
+    out = _run_bench("--native", "0", "--gpus", "2", "--batch", "1000", "--steps", "3", "--warmup", "2")
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2000 and out["value"] > 0
+    t0, t1 = out["transports"]["0"], out["transports"]["1"]
+    assert t0["devices"] == [0, 0] and t0["solved_frac"] == 1.0
+    assert "error" in t1 or (t1["solved_frac"] == 1.0 and t1["mean_iters"] == t0["mean_iters"]), t1

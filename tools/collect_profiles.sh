@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel trace of the default bench + PMC passes of the hot kernels (counters in their own
 # runs, one group per pass, never combined with trace domains).  usage: tools/collect_profiles.sh [round tag, default r02]
 # Outputs under gpurun_out/prof_<tag>/ ; tools/summarize_profiles.py <tag> copies the summaries into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$TAG
@@ -10,9 +10,25 @@ mkdir -p $O
 # the default bench (two batches in flight) and the same steps through one handle on one stream (--depth 1: launches serialised, per-kernel durations add up to a step)
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-latency --no-index-order > $O/bench_under_rocprof.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_depth1 --output-format csv -- python bench.py --depth 1 --steps 10 --warmup 2 --no-cpu-baseline --no-latency --no-index-order > $O/bench_depth1_under_rocprof.log 2>&1
-[ -n "$SKIP_PMC" ] && { find $O -name "*kernel_stats.csv" -exec head -6 {} \; ; exit 0; }   # kernels unchanged since the last PMC passes: traces only
+[ -n "$SKIP_PMC" ] && { # the other shapes of BASELINE: executed FP64 (+ issue counters) of a first solve each -> executed_fp64_flops_per_launch_by_config of the summary
+for shape in "65536,10" "8192,16" "32768,20"; do
+  for set in "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE FETCH_SIZE WRITE_SIZE"; do
+    tag=$(echo $set | cut -d' ' -f1)
+    A1_SHAPE=$shape timeout 200 rocprofv3 --pmc $set -d $O/shape_${shape/,/x}_$tag --output-format csv -- python tools/prof_target.py > /dev/null 2>&1
+  done
+  A1_SHAPE=$shape timeout 200 rocprofv3 --kernel-trace --stats -d $O/shape_${shape/,/x}_trace --output-format csv -- python tools/prof_target.py > $O/shape_${shape/,/x}_trace.log 2>&1
+done
+find $O -name "*kernel_stats.csv" -exec head -6 {} \; ; exit 0; }   # kernels unchanged since the last PMC passes: traces only
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64"; do
   tag=$(echo $set | cut -d' ' -f1)
   timeout 150 rocprofv3 --pmc $set -d $O/pmc_$tag --output-format csv -- python tools/prof_target.py > /dev/null 2>&1
+done
+# the other shapes of BASELINE: executed FP64 (+ issue counters) of a first solve each -> executed_fp64_flops_per_launch_by_config of the summary
+for shape in "65536,10" "8192,16" "32768,20"; do
+  for set in "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE FETCH_SIZE WRITE_SIZE"; do
+    tag=$(echo $set | cut -d' ' -f1)
+    A1_SHAPE=$shape timeout 200 rocprofv3 --pmc $set -d $O/shape_${shape/,/x}_$tag --output-format csv -- python tools/prof_target.py > /dev/null 2>&1
+  done
+  A1_SHAPE=$shape timeout 200 rocprofv3 --kernel-trace --stats -d $O/shape_${shape/,/x}_trace --output-format csv -- python tools/prof_target.py > $O/shape_${shape/,/x}_trace.log 2>&1
 done
 find $O -name "*kernel_stats.csv" -exec head -6 {} \;

@@ -1,11 +1,25 @@
-cd "$GRAFT_REPO_ROOT"
+# Runs ON THE GPU BOX (gpurun): the round's evidence in one call -- rocprofv3 kernel traces + PMC passes, the default bench, the C++ latency harness, --config 4,
+# the self-spawned 2-rank run, the native sharded harness, the host-pointer pipeline probe, A/B of this round's library against the previous round's.
+# usage: tools/evidence_run.sh [tag, default r03]     -> gpurun_out/<tag>/..., gpurun_out/prof_<tag>/...
+TAG=${1:-r03}
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p $O
 timeout 100 python -c "import torch"
-timeout 600 bash tools/collect_profiles.sh r02 > gpurun_out/collect_r02.log 2>&1   # (SKIP_PMC=1 in the environment: kernel traces only)
-python tools/summarize_profiles.py r02 > /dev/null 2>&1   # the bench line's roofline.traffic / executed-FP64 figures are read from this run's PMC summary
-timeout 400 python bench.py > gpurun_out/bench_default_r02.json 2> gpurun_out/bench_default_r02.err
-timeout 100 tests/cpp/latency_harness 10000 > gpurun_out/latency_10000.json 2>/dev/null
-timeout 100 tests/cpp/latency_harness 4000 2000 > gpurun_out/latency_paced.json 2>/dev/null
-timeout 200 python bench.py --config 4 --steps 5 --warmup 2 > gpurun_out/bench_config4_n1.json 2>/dev/null
-timeout 200 python tools/general_path_probe.py > gpurun_out/general_path_probe.log 2>&1
-timeout 200 python tools/stage_probe.py > gpurun_out/stage_probe.json 2>/dev/null
-tail -c 300 gpurun_out/bench_default_r02.json; echo; cat gpurun_out/latency_10000.json; tail -3 gpurun_out/collect_r02.log
+timeout 1500 bash tools/collect_profiles.sh $TAG > $O/collect.log 2>&1
+python tools/summarize_profiles.py $TAG > $O/summarize.log 2>&1   # the bench line's roofline.traffic / executed-FP64 figures are read from this run's PMC summary
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 300 python bench.py --depth 1 --no-cpu-baseline --no-latency > $O/bench_depth1.json 2> /dev/null
+timeout 100 tests/cpp/latency_harness 10000 > $O/latency_10000.json 2>/dev/null
+timeout 100 tests/cpp/latency_harness 4000 2000 > $O/latency_paced.json 2>/dev/null
+timeout 200 python bench.py --config 4 --steps 5 --warmup 2 > $O/bench_config4_n1.json 2>/dev/null
+timeout 300 python bench.py --gpus 2 --steps 10 --warmup 4 --no-cpu-baseline --no-latency --no-index-order > $O/bench_gpus2_shared_gpu_gloo.json 2>/dev/null
+timeout 300 python bench.py --gpus 2 --config 4 --steps 3 --warmup 1 > $O/bench_config4_2ranks_shared_gpu_gloo.json 2>/dev/null
+timeout 300 python bench.py --native 0 --gpus 2 --steps 10 --warmup 4 > $O/bench_native_2shards_one_gpu.json 2>/dev/null
+timeout 200 python tools/pcie_probe.py 4096 10 60 > $O/pcie_probe_4096_h10.json 2>/dev/null
+timeout 200 python tools/pcie_probe.py 8192 16 20 > $O/pcie_probe_8192_h16.json 2>/dev/null
+[ -f _ab/r02_final.so ] && timeout 300 python tools/ab_probe.py _ab/r02_final.so a1-qp-mpc-controller_amd/liba1mpc.so > $O/ab_r02_vs_r03.json 2>&1
+[ -f _ab/r02_final.so ] && timeout 300 python tools/ab_horizons.py _ab/r02_final.so a1-qp-mpc-controller_amd/liba1mpc.so > $O/ab_horizons_r02_vs_r03.txt 2>&1
+[ -f _ab/r02_final.so ] && timeout 400 python tools/ab_slope.py _ab/r02_final.so a1-qp-mpc-controller_amd/liba1mpc.so --reps 5 --rounds 3 > $O/ab_slope_r02_vs_r03.json 2>&1
+timeout 200 python tools/general_path_probe.py > $O/general_path_probe.log 2>&1
+timeout 200 python tools/stage_probe.py > $O/stage_probe.json 2>/dev/null
+timeout 200 python tools/elementwise_probe.py > $O/elementwise_probe.log 2>&1
+tail -c 400 $O/bench_default.json; echo; cat $O/latency_10000.json; tail -3 $O/collect.log

@@ -2,7 +2,7 @@
 """Copies the rocprofv3 summaries of gpurun_out/prof_final/ into profiles/ (tracked)."""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + TAG); dst = os.path.join(ROOT, "profiles")
 def newest(pattern):
     fs = glob.glob(pattern, recursive=True)
@@ -85,6 +85,40 @@ for k, lanes in live.items():
     g_ = lambda n: c.get(n, {}).get("mean_per_launch", 0.0)
     ex += lanes * (2.0 * g_("SQ_INSTS_VALU_FMA_F64") + g_("SQ_INSTS_VALU_ADD_F64") + g_("SQ_INSTS_VALU_MUL_F64"))
 summ["executed_fp64_flops_per_launch"] = ex
+# the other shapes (collect_profiles.sh: A1_SHAPE passes of tools/prof_target.py): per kernel and launch, counters + kernel durations
+by_cfg, shapes = {}, {}
+for d in sorted(glob.glob(os.path.join(src, "shape_*_SQ_INSTS_VALU_FMA_F64"))) + sorted(glob.glob(os.path.join(src, "shape_*_SQ_LDS_BANK_CONFLICT"))):
+    shape = os.path.basename(d).split("_")[1]
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        a2 = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            k = r.get("Kernel_Name", "")
+            if "a1mpc" in k and "noop" not in k:
+                short = "setup_kernel" if "setup" in k else "admm_kernel" if "admm" in k else "order_kernel" if "order" in k else k.split("(")[0].split("::")[-1]
+                a2[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, dd in a2.items():
+            shapes.setdefault(shape, {}).setdefault(k, {}).update({c: sum(v) / len(v) for c, v in dd.items()})
+for shape, ks in shapes.items():
+    h_ = int(shape.split("x")[1])
+    lanes = {"setup_kernel": 48, "admm_kernel": 48 if h_ == 10 else 24}   # ADMM kernel: two QPs per wavefront at h = 10, one (a main / twin pair of rows) from h = 16 on
+    e_ = 0.0
+    for k, ln_ in lanes.items():
+        c = ks.get(k, {})
+        e_ += ln_ * (2.0 * c.get("SQ_INSTS_VALU_FMA_F64", 0.0) + c.get("SQ_INSTS_VALU_ADD_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0))
+    by_cfg[shape] = e_
+    for k, c in ks.items():
+        if c.get("SQ_LDS_IDX_ACTIVE"): c["lds_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+        if c.get("SQ_WAVE_CYCLES"): c["wait_any_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+    f = newest(os.path.join(src, "shape_%s_trace" % shape, "**", "*kernel_stats.csv"))
+    if f:
+        shutil.copy(f, os.path.join(dst, TAG + "_kernel_stats_first_solves_%s.csv" % shape.replace("x", "_h")))
+summ["executed_fp64_flops_per_launch_by_config"] = by_cfg
+summ["other_shapes_per_launch"] = shapes
+for k in ("admm_kernel", "setup_kernel"):
+    c = summ.get(k, {})
+    g_ = lambda n: c.get(n, {}).get("mean_per_launch", 0.0)
+    if g_("SQ_LDS_IDX_ACTIVE"): summ.setdefault("_derived", {})[k + "_lds_conflict_frac"] = g_("SQ_LDS_BANK_CONFLICT") / g_("SQ_LDS_IDX_ACTIVE")
+    if g_("SQ_WAVE_CYCLES"): summ.setdefault("_derived", {})[k + "_wait_any_frac"] = g_("SQ_WAIT_ANY") / g_("SQ_WAVE_CYCLES")
 summ["_note"] = ("rocprofv3 --pmc, one counter group per pass (tools/collect_profiles.sh), 4096 QPs h=10 default OSQP settings cold start "
                  "(tools/prof_target.py); FETCH_SIZE / WRITE_SIZE in KiB per kernel launch; one solve_batch = setup_kernel + admm_kernel. "
                  "Reads are 8-byte per-lane accesses of per-problem records (uncalibrated w.r.t. the guide's x2 rule for 16 B/lane streams).")
