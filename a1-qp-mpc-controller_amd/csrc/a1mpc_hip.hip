@@ -2596,11 +2596,8 @@ a1mpc_status a1mpc_pipeline_create(const a1mpc_config* cfg, int32_t max_batch, i
     a1mpc_pipeline p = new (std::nothrow) a1mpc_pipeline_s();
     if (!p) return fail(A1MPC_ERR_HIP, "out of host memory");
     p->device = device; p->depth = depth;
-    if (depth == 0) {   // default: two batches in flight; three when max_batch runs the fused kernel (no set-up kernel to wait for: 2048 x h10 5.7 M solves/s at depth 2, 6.1-6.3 M at 3)
-        bool split = true;
-        if (hipSetDevice(device) == hipSuccess) (void)use_split_pipeline(cfg->horizon, max_batch, true, &split);
-        p->depth = split ? 2 : 3;
-    }
+    if (depth == 0) p->depth = 2;   // default: two batches in flight.  (Round 2 took three for batches small enough for the fused kernel; with this round's kernels two win at every
+                                    // size measured -- 512 / 1024 / 2048 / 4096 x h10: 0.28 / 0.30 / 0.35 / 0.61 ms per batch at depth 2, 0.35 / 0.40 / 0.43 / 0.69 at depth 3.)
     for (int k = 0; k < p->depth; ++k) {
         a1mpc_handle hk = nullptr;
         const a1mpc_status st = a1mpc_create(cfg, max_batch, device, &hk);

@@ -1266,7 +1266,7 @@ struct RowSolver {
         // per-step product that only depends on them out of the ADMM loop and the register file overflows.
         const double sigma_l = row_opaque(P.sigma);
         const double al = P.alpha, oma = 1.0 - P.alpha;
-        const double muz = comp == 2 ? mu : 0.0, mux = comp < 2 ? mu : 0.0, al1 = comp < 2 ? al : 0.0;  // selects folded into multipliers
+        const double muz = comp == 2 ? mu : 0.0, mux = comp < 2 ? mu : 0.0;  // selects folded into multipliers
         // One wave per SIMD: every instruction costs an issue slot, so the sweeps are written for instruction count --
         // accumulator chains are seeded with values that have to be added anyway (no zero-initialised partners, no final
         // adds), independent chains are interleaved by hand, subtraction rides on the NEG modifier of v_fmac_f64_dpp.
@@ -1391,7 +1391,7 @@ struct RowSolver {
             } else {                // w+ = w + alpha (z~ - Pi(w))
                 const double z1 = min_f64(wh1[t], 0.0);
                 wh0[t] = fma(al, av0 - z0, wh0[t]);
-                wh1[t] = fma(al1, av1 - z1, wh1[t]);  // stays 0 on fz lanes
+                wh1[t] = fma(al, av1 - z1, wh1[t]);   // (fz lanes have no second row: see the twin-row code)
             }
         });
     }
@@ -1422,7 +1422,7 @@ struct RowSolver {
         static_assert(H % 2 == 0, "twin rows split the horizon steps in pairs");
         const double sigma_l = row_opaque(P.sigma);
         const double al = P.alpha, oma = 1.0 - P.alpha;
-        const double muz = comp == 2 ? mu : 0.0, mux = comp < 2 ? mu : 0.0, al1 = comp < 2 ? al : 0.0;
+        const double muz = comp == 2 ? mu : 0.0, mux = comp < 2 ? mu : 0.0;
         const double am = act ? 1.0 : 0.0;  // pad lanes carry no force
         const double* cgp = lds + L::CG + tw * 12 + ci;  // c g of my step of slot k: cgp[24 k]
         double d[H];
@@ -1564,7 +1564,10 @@ struct RowSolver {
             } else {
                 const double z1 = min_f64(wh1[k], 0.0);
                 wh0[k] = fma(al, av0 - z0, wh0[k]);
-                wh1[k] = fma(al1, av1 - z1, wh1[k]);
+                // fz lanes own no second constraint row: their wh1 is never read where it matters (rr1 = E1^2 rho = 0 there, so every product with it vanishes; the residual
+                // norms, the outputs and the carry test comp < 2), so it need not be held at zero by a per-lane multiplier -- at h = 20 that multiplier was reloaded
+                // from scratch once per step pair (ten scratch loads per iteration)
+                wh1[k] = fma(al, av1 - z1, wh1[k]);
             }
         });
 #ifdef A1X_CLK
@@ -1659,7 +1662,7 @@ struct RowSolver {
             const double uz = quad_perm<2, 2, 2, 2>(xh[k]);
             const double ax0 = comp == 2 ? xh[k] : fma(mu, uz, xh[k]);  // E^-1 (A_s x)
             const double ax1 = comp < 2 ? fma(-mu, uz, xh[k]) : 0.0;
-            const double z0 = clamp_f64(wh0[k], lbs<k>(t), ubs<k>(t)), z1 = min_f64(wh1[k], 0.0);  // E^-1 z
+            const double z0 = clamp_f64(wh0[k], lbs<k>(t), ubs<k>(t)), z1 = comp < 2 ? min_f64(wh1[k], 0.0) : 0.0;  // E^-1 z (fz lanes: no second row, wh1 is a don't-care there)
             const double rp0 = ax0 - z0, rp1 = ax1 - z1;
             const bool eq = (eqmask >> t) & 1u;
             const double e0 = rr0[k] * (eq ? irho_eq : irho), e1 = rr1[k] * irho;  // E^2

@@ -406,7 +406,7 @@ void a1mpc_sharded_destroy(a1mpc_sharded s);
  * Batch pipeline: consecutive batches in flight together on ONE device (north_star: "HIP streams"; the reference has no counterpart -- it
  * solves one QP per tick on one thread, S/MainGazebo.cpp:57-68).  A launch of a few thousand QPs ends in a tail: its few 150-225-iteration
  * QPs keep a handful of wavefronts busy while the rest of the chip idles (the last 0.15-0.25 ms of a 0.85 ms launch at 4096 x h10).  The
- * pipeline owns `depth` complete engine handles (0 = the default: 2, or 3 when max_batch is small enough for the fused kernel) on `depth` HIP streams and hands batches to them round-robin, so the
+ * pipeline owns `depth` complete engine handles (0 = the default: 2) on `depth` HIP streams and hands batches to them round-robin, so the
  * next batch's set-up kernel and persistent rows are dispatched onto the SIMDs the tail has left.  Batches in flight share nothing
  * (prepared-state records, queue, warm start are per slot): results are bit-identical to a lone handle's.  Measured on one MI355X, first
  * solves of distinct batches (profiles/r02_overlap_probe.json): 2048 x h10 3.4 -> 6.1 M solves/s (depth 3), 4096 x h10 4.8 -> 6.45 M,

@@ -927,7 +927,7 @@ def test_batch_pipeline_argument_errors(pkg, scen):
     bad = pkg.make_config(sc["params"], 7)
     assert lib.a1mpc_pipeline_create(C.byref(bad), 8, 0, 2, C.byref(p)) != 0 and not p          # unsupported horizon, nothing leaked
     with pkg.Pipeline(cfg, 8, 0, depth=0) as pipe:
-        assert pipe.depth == 3   # default: 3 for batches that run the fused kernel, 2 beyond the resident rows
+        assert pipe.depth == 2   # default: two batches in flight at every size
         with pkg.Pipeline(cfg, 4096, 0, depth=0) as big:
             assert big.depth == 2
         with pytest.raises(pkg.A1MpcError):
