@@ -1423,7 +1423,6 @@ struct RowSolver {
         const double sigma_l = row_opaque(P.sigma);
         const double al = P.alpha, oma = 1.0 - P.alpha;
         const double muz = comp == 2 ? mu : 0.0, mux = comp < 2 ? mu : 0.0;
-        const double am = act ? 1.0 : 0.0;  // pad lanes carry no force
         const double* cgp = lds + L::CG + tw * 12 + ci;  // c g of my step of slot k: cgp[24 k]
         double d[H];
         double pv = 0.0;  // costate p_{t+1}, state layout
@@ -1499,13 +1498,15 @@ struct RowSolver {
             // (one address register per step: the reads are base + immediate; formed ahead of the gain block -- hipcc pads an asm statement that follows another)
             [[maybe_unused]] lds_cptr krn = nullptr;
             if constexpr (t > 0 && t < H - 1) krn = row_lds_at<(t + 1) * L::SLOT>(lds + L::FAC + krow);
+            // (no `am` multiply: a pad lane carries a copy of lane 0's v -- its matrix rows are lane 0's -- that no DPP read, no store and no norm ever looks at;
+            // on the lanes that matter v * 1.0 is v)
             if constexpr (t == 0) {
-                v = row_dpp_ready(am * v);  // x_0 = 0
+                v = row_dpp_ready(v);  // x_0 = 0
             } else if constexpr (t < H - 1) {
                 sb = fP * row_ror<8>(s);
-                sweep_fwd_gain_twin<true>(v, s, sb, Kq, fA, fB, fC, am);
+                sweep_fwd_gain_twin<true>(v, s, Kq, fA);
             } else {
-                sweep_fwd_gain_twin<false>(v, s, sb, Kq, fA, fB, fC, am);
+                sweep_fwd_gain_twin<false>(v, s, Kq, fA);
             }
             row_sched_fence();
             [[maybe_unused]] double Brl[12];
@@ -1519,8 +1520,8 @@ struct RowSolver {
             }
             row_sched_fence();
             if constexpr (t < H - 1) {  // (s: zero at t = 0, x_t with the seeds of x_{t+1} on top after the gain block)
-                if constexpr (GEN) sweep_fwd_input_twin(s, sb, v, Brl);
-                else sweep_fwd_input_twin(s, sb, v, Brw);  // lanes without a wrench state read the zero row of B~
+                if constexpr (GEN) sweep_fwd_input_twin<(t > 0)>(s, sb, v, Brl, fB, fC);
+                else sweep_fwd_input_twin<(t > 0)>(s, sb, v, Brw, fB, fC);  // lanes without a wrench state read the zero row of B~
                 // the next step's first DPP read of s: behind the row_ror<8> of its seed (hipcc pads that one itself), or -- last step -- right at the top of its block
                 if constexpr (t == H - 2) s = row_dpp_ready(s);
             }

@@ -253,46 +253,57 @@ A1_DEV void sweep_fwd_input(double& sa, double& sb, double& z0, double v, const 
 }
 
 // The forward blocks of a twin pair: the x / w updates of a step belong to ONE row of the pair (RowSolver::admm_iteration_twin), so the blocks
-// only carry the roll-out.  v = am * (v - K s) (row Kr) and (SEED) the seeds of x_{t+1}: s += fA s[8] + fC s[10], sb += fB s[9]; the seed
+// only carry the roll-out.  v = v - K s (row Kr; the pad lanes' copy of lane 0's value is never read: no `am` multiply) and (SEED) the first seed of x_{t+1}: s += fA s[8]; the seed
 // terms come last so that v is followed by >= 2 instructions before sweep_fwd_input_twin reads it through DPP.  s: written >= 2 instructions ago.
 template <bool SEED>
-A1_DEV void sweep_fwd_gain_twin(double& v, double& s, double& sb, const double (&Kr)[12], double fA, double fB, double fC, double am) {
+A1_DEV void sweep_fwd_gain_twin(double& v, double& s, const double (&Kr)[12], double fA) {
     double vb;
     if constexpr (SEED) {
-        // the seeds accumulate onto s IN PLACE (no copy): they come after the last term that reads s as it was, they only change lanes 0, 1 (fA) and 2 (fC)
-        // and read lanes 8, 9, 10; each write of s is two instructions away from the next DPP read of s
+        // the first seed of x_{t+1} accumulates onto s IN PLACE (no copy): it comes after the last term that reads s as it was, changes lanes 0 and 1 only and
+        // reads lane 8; the other two seeds open the input block (each write of s is two instructions away from the next DPP read of s)
         asm("v_mov_b64 %1, 0\n"
-            A1_FNMA("%0", "%2", "%4", 0) A1_FNMA("%1", "%2", "%5", 1) A1_FNMA("%0", "%2", "%6", 2) A1_FNMA("%1", "%2", "%7", 4)
-            A1_FNMA("%0", "%2", "%8", 5) A1_FNMA("%1", "%2", "%9", 6) A1_FNMA("%0", "%2", "%10", 8) A1_FNMA("%1", "%2", "%11", 9)
-            A1_FNMA("%0", "%2", "%12", 10) A1_FNMA("%1", "%2", "%13", 12) A1_FNMA("%0", "%2", "%14", 13) A1_FNMA("%1", "%2", "%15", 14)
-            A1_FMAC("%2", "%2", "%16", 8)
+            A1_FNMA("%0", "%2", "%3", 0) A1_FNMA("%1", "%2", "%4", 1) A1_FNMA("%0", "%2", "%5", 2) A1_FNMA("%1", "%2", "%6", 4)
+            A1_FNMA("%0", "%2", "%7", 5) A1_FNMA("%1", "%2", "%8", 6) A1_FNMA("%0", "%2", "%9", 8) A1_FNMA("%1", "%2", "%10", 9)
+            A1_FNMA("%0", "%2", "%11", 10) A1_FNMA("%1", "%2", "%12", 12) A1_FNMA("%0", "%2", "%13", 13) A1_FNMA("%1", "%2", "%14", 14)
+            A1_FMAC("%2", "%2", "%15", 8)
             "v_add_f64 %0, %0, %1\n"
-            "v_mul_f64 %0, %0, %19\n"
-            A1_FMAC("%3", "%2", "%17", 9) A1_FMAC("%2", "%2", "%18", 10)
-            : "+v"(v), "=&v"(vb), "+v"(s), "+v"(sb)
+            : "+v"(v), "=&v"(vb), "+v"(s)
             : "v"(Kr[0]), "v"(Kr[1]), "v"(Kr[2]), "v"(Kr[3]), "v"(Kr[4]), "v"(Kr[5]), "v"(Kr[6]), "v"(Kr[7]), "v"(Kr[8]), "v"(Kr[9]), "v"(Kr[10]),
-              "v"(Kr[11]), "v"(fA), "v"(fB), "v"(fC), "v"(am));
+              "v"(Kr[11]), "v"(fA));
     } else {
         asm("v_mov_b64 %1, 0\n"
             A1_FNMA("%0", "%2", "%3", 0) A1_FNMA("%1", "%2", "%4", 1) A1_FNMA("%0", "%2", "%5", 2) A1_FNMA("%1", "%2", "%6", 4)
             A1_FNMA("%0", "%2", "%7", 5) A1_FNMA("%1", "%2", "%8", 6) A1_FNMA("%0", "%2", "%9", 8) A1_FNMA("%1", "%2", "%10", 9)
             A1_FNMA("%0", "%2", "%11", 10) A1_FNMA("%1", "%2", "%12", 12) A1_FNMA("%0", "%2", "%13", 13) A1_FNMA("%1", "%2", "%14", 14)
             "v_add_f64 %0, %0, %1\n"
-            "v_mul_f64 %0, %0, %15\n"
             : "+v"(v), "=&v"(vb)
             : "v"(s), "v"(Kr[0]), "v"(Kr[1]), "v"(Kr[2]), "v"(Kr[3]), "v"(Kr[4]), "v"(Kr[5]), "v"(Kr[6]), "v"(Kr[7]), "v"(Kr[8]), "v"(Kr[9]), "v"(Kr[10]),
-              "v"(Kr[11]), "v"(am));
+              "v"(Kr[11]));
     }
 }
-// x_{t+1} = (sa + sb) + B~ v (row Br), returned in sa.  v: written >= 2 instructions ago.  The caller passes sa through row_dpp_ready().
-A1_DEV void sweep_fwd_input_twin(double& sa, double& sb, double v, const double (&Br)[12]) {
-    asm(A1_FMAC("%0", "%2", "%3", 0) A1_FMAC("%1", "%2", "%4", 1) A1_FMAC("%0", "%2", "%5", 2) A1_FMAC("%1", "%2", "%6", 4)
-        A1_FMAC("%0", "%2", "%7", 5) A1_FMAC("%1", "%2", "%8", 6) A1_FMAC("%0", "%2", "%9", 8) A1_FMAC("%1", "%2", "%10", 9)
-        A1_FMAC("%0", "%2", "%11", 10) A1_FMAC("%1", "%2", "%12", 12) A1_FMAC("%0", "%2", "%13", 13) A1_FMAC("%1", "%2", "%14", 14)
-        "v_add_f64 %0, %0, %1\n"
-        : "+v"(sa), "+v"(sb)
-        : "v"(v), "v"(Br[0]), "v"(Br[1]), "v"(Br[2]), "v"(Br[3]), "v"(Br[4]), "v"(Br[5]), "v"(Br[6]), "v"(Br[7]), "v"(Br[8]), "v"(Br[9]), "v"(Br[10]),
-          "v"(Br[11]));
+// x_{t+1} = (sa + sb) + B~ v (row Br), returned in sa.  SEED: sa arrives as x_t + fA x_t[8] (sweep_fwd_gain_twin) and the block opens with the other two seeds,
+// sb += fB sa[9], sa += fC sa[10] (they read the omega lanes before the B~ v terms change them).  v: written >= 2 instructions ago (the step's LDS reads and, with SEED,
+// the two seed instructions lie in between).  The next DPP read of sa is two instructions away or more (row_dpp_ready / the row_ror of the next seed).
+template <bool SEED>
+A1_DEV void sweep_fwd_input_twin(double& sa, double& sb, double v, const double (&Br)[12], double fB, double fC) {
+    if constexpr (SEED) {
+        asm(A1_FMAC("%1", "%0", "%15", 9) A1_FMAC("%0", "%0", "%16", 10)
+            A1_FMAC("%0", "%2", "%3", 0) A1_FMAC("%1", "%2", "%4", 1) A1_FMAC("%0", "%2", "%5", 2) A1_FMAC("%1", "%2", "%6", 4)
+            A1_FMAC("%0", "%2", "%7", 5) A1_FMAC("%1", "%2", "%8", 6) A1_FMAC("%0", "%2", "%9", 8) A1_FMAC("%1", "%2", "%10", 9)
+            A1_FMAC("%0", "%2", "%11", 10) A1_FMAC("%1", "%2", "%12", 12) A1_FMAC("%0", "%2", "%13", 13) A1_FMAC("%1", "%2", "%14", 14)
+            "v_add_f64 %0, %0, %1\n"
+            : "+v"(sa), "+v"(sb)
+            : "v"(v), "v"(Br[0]), "v"(Br[1]), "v"(Br[2]), "v"(Br[3]), "v"(Br[4]), "v"(Br[5]), "v"(Br[6]), "v"(Br[7]), "v"(Br[8]), "v"(Br[9]), "v"(Br[10]),
+              "v"(Br[11]), "v"(fB), "v"(fC));
+    } else {
+        asm(A1_FMAC("%0", "%2", "%3", 0) A1_FMAC("%1", "%2", "%4", 1) A1_FMAC("%0", "%2", "%5", 2) A1_FMAC("%1", "%2", "%6", 4)
+            A1_FMAC("%0", "%2", "%7", 5) A1_FMAC("%1", "%2", "%8", 6) A1_FMAC("%0", "%2", "%9", 8) A1_FMAC("%1", "%2", "%10", 9)
+            A1_FMAC("%0", "%2", "%11", 10) A1_FMAC("%1", "%2", "%12", 12) A1_FMAC("%0", "%2", "%13", 13) A1_FMAC("%1", "%2", "%14", 14)
+            "v_add_f64 %0, %0, %1\n"
+            : "+v"(sa), "+v"(sb)
+            : "v"(v), "v"(Br[0]), "v"(Br[1]), "v"(Br[2]), "v"(Br[3]), "v"(Br[4]), "v"(Br[5]), "v"(Br[6]), "v"(Br[7]), "v"(Br[8]), "v"(Br[9]), "v"(Br[10]),
+              "v"(Br[11]));
+    }
 }
 
 // Scheduling fence: the machine scheduler moves nothing across it (keeps a step's LDS reads ahead of the arithmetic that hides them).

@@ -108,14 +108,16 @@ inline void sweep_back_chain_twin(double& pa, double& pb, double r, const double
     pb = pa;  // (the device block leaves the copy that twin_exchange_copied() swaps with)
 }
 template <bool SEED>
-inline void sweep_fwd_gain_twin(double& v, double& s, double& sb, const double (&Kr)[12], double fA, double fB, double fC, double am) {
+inline void sweep_fwd_gain_twin(double& v, double& s, const double (&Kr)[12], double fA) {
     const double* S_ = emu_publish(s);
     double va = v, vb = 0.0;
     for (int b = 0; b < 12; b += 2) { va = fma(-S_[emu_detail::LANE[b]], Kr[b], va); vb = fma(-S_[emu_detail::LANE[b + 1]], Kr[b + 1], vb); }
-    v = (va + vb) * am;
-    if (SEED) { s = fma(S_[8], fA, s); sb = fma(S_[9], fB, sb); s = fma(S_[10], fC, s); }  // (the device block accumulates the seeds onto s in place)
+    v = va + vb;   // (pad lanes keep a copy of lane 0's value that nothing reads)
+    if (SEED) s = fma(S_[8], fA, s);  // (the device block accumulates the first seed onto s in place; the other two open the input block)
 }
-inline void sweep_fwd_input_twin(double& sa, double& sb, double v, const double (&Br)[12]) {
+template <bool SEED>
+inline void sweep_fwd_input_twin(double& sa, double& sb, double v, const double (&Br)[12], double fB, double fC) {
+    if (SEED) { const double* S_ = emu_publish(sa); const double s9 = S_[9], s10 = S_[10]; sb = fma(s9, fB, sb); sa = fma(s10, fC, sa); }
     const double* V_ = emu_publish(v);
     for (int b = 0; b < 12; b += 2) { sa = fma(V_[emu_detail::LANE[b]], Br[b], sa); sb = fma(V_[emu_detail::LANE[b + 1]], Br[b + 1], sb); }
     sa = sa + sb;
