@@ -1280,8 +1280,9 @@ __global__ __launch_bounds__(64) void a1mpc_ekf_kernel(const EkfArgs a) {
         for (int j = 0; j < 18; ++j) { Pr[j] = (j < 3 ? T[j] + T[3 + j] * dt : T[j]) + (j == l ? q : 0.0); Pb[l * 18 + j] = Pr[j]; }
     }
     half_sync();
-    // ---- innovation (:115-131): lane r < 28 owns row r of [S | error_y | C]
-    double M[47];
+    // ---- innovation (:115-131): lane r < 28 owns row r of S (and its error_y entry)
+    double M[28];
+    double err = 0.0;
     if (l < 28) {
         const int r = l;
         int c0, c1; double s0, s1;
@@ -1315,31 +1316,45 @@ __global__ __launch_bounds__(64) void a1mpc_ekf_kernel(const EkfArgs a) {
             M[c] = v + (c == r ? rd : 0.0);
             Sm[r * 29 + c] = M[c];
         }
-        M[28] = y - yhat;
-        for (int j = 0; j < 18; ++j) M[29 + j] = (j == c0 ? s0 : 0.0) + (j == c1 ? s1 : 0.0);
+        err = y - yhat;
+        zs[r] = err;   // error_y, read by every row in the product S^-1 error_y below
     }
     half_sync();
     if (l < 28)
         for (int c = 0; c < 28; ++c) M[c] = c == l ? 0.5 * (M[c] + M[c]) : (c > l ? 0.5 * (M[c] + Sm[c * 29 + l]) : 0.5 * (Sm[c * 29 + l] + M[c]));   // :131
-    // ---- Gauss-Jordan elimination of [S | e | C] (:133-134, :138)
+    // ---- S^-1 by in-place Gauss-Jordan elimination, no pivoting (S is symmetric positive definite); the two solves (:134, :138) are then products with it.
+    // Pivot k: row k is scaled by 1 / p and its own entry becomes 1 / p; every other row i subtracts f = a_ik times row k and its k-th entry becomes -f / p.
+    // (Until round 3 the 47-wide tableau [S | error_y | C] was eliminated: 47 instead of 28 entries per row and pivot for the same two solutions.)
 #pragma unroll
     for (int k = 0; k < 28; ++k) {
         half_sync();
         if (l == k) {
             const double pinv = 1.0 / M[k];
 #pragma unroll
-            for (int j = 0; j < 47; ++j) { M[j] = M[j] * pinv; prow[j] = M[j]; }
+            for (int j = 0; j < 28; ++j) { M[j] = j == k ? pinv : M[j] * pinv; prow[j] = M[j]; }
         }
         half_sync();
         if (l < 28 && l != k) {
             const double f = M[k];
 #pragma unroll
-            for (int j = 0; j < 47; ++j) M[j] = M[j] - f * prow[j];
+            for (int j = 0; j < 28; ++j) M[j] = j == k ? -(f * prow[j]) : M[j] - f * prow[j];
         }
     }
     half_sync();
     double* SC = Sm;  // S is consumed: the region now holds S^-1 C (28 x 18)
-    if (l < 28) { zs[l] = M[28]; for (int j = 0; j < 18; ++j) SC[l * 18 + j] = M[29 + j]; }
+    double serr = 0.0;
+    if (l < 28) {
+        // S^-1 error_y (:134): dense product, inner index ascending
+        for (int c = 0; c < 28; ++c) serr += M[c] * zs[c];
+        // S^-1 C (:138): the dense product with C's exact zeros dropped (C[c][j] is 0 or +-1, a zero term leaves the running sum as it is): per column j the
+        // rows c with an entry, ascending -- j < 3: c = j, 3 + j, 6 + j, 9 + j (-1); j = 3..5: c = 12 + (j - 3), 15 + .., 18 + .., 21 + .. (+1); j = 6 + m: c = m (+1)
+        // and, for the z column of a foot, c = 24 + m / 3 (+1)
+        for (int j = 0; j < 3; ++j) SC[l * 18 + j] = (((0.0 + M[j] * -1.0) + M[3 + j] * -1.0) + M[6 + j] * -1.0) + M[9 + j] * -1.0;
+        for (int j = 0; j < 3; ++j) SC[l * 18 + 3 + j] = (((0.0 + M[12 + j] * 1.0) + M[15 + j] * 1.0) + M[18 + j] * 1.0) + M[21 + j] * 1.0;
+        for (int m = 0; m < 12; ++m) SC[l * 18 + 6 + m] = m % 3 == 2 ? (0.0 + M[m] * 1.0) + M[24 + m / 3] * 1.0 : 0.0 + M[m] * 1.0;
+    }
+    half_sync();   // every row has read error_y: its place now takes S^-1 error_y
+    if (l < 28) zs[l] = serr;
     half_sync();
     // ---- measurement update (:136-140)
     double Tn[18];

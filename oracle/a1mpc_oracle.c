@@ -1121,8 +1121,9 @@ void orc_leg_state(const double *joint_pos, const double *joint_vel, const doubl
 /* ---- N4c: A1BasicEKF (S/A1BasicEKF.cpp:7-163), the 18-state / 28-measurement Kalman filter for base position and velocity -----------
  * Dense restatement, matrix product by matrix product in the reference's evaluation order (left to right, inner index ascending).
  * state = [x 18 | P 18x18 row-major | initialised flag] = ORC_EKF_STATE doubles.  The two S.fullPivHouseholderQr().solve() calls (:134,138)
- * are restated as ONE Gauss-Jordan elimination of [S | error_y | C] without pivoting (S is symmetric positive definite): same solution,
- * rounding differs from a Householder QR (agreement tested against LAPACK). */
+ * are restated as products with S^-1, computed ONCE by an in-place Gauss-Jordan elimination without pivoting (S is symmetric positive definite; until round 3
+ * the 47-wide tableau [S | error_y | C] was eliminated instead: 40 % more work for the same two solutions): same solution, rounding differs from a
+ * Householder QR (agreement tested against LAPACK and against the reference's own source, 1e-9). */
 #define EKF_NS 18
 #define EKF_NM 28
 #define ORC_EKF_STATE (EKF_NS + EKF_NS * EKF_NS + 1)
@@ -1199,31 +1200,35 @@ void orc_ekf_step(double *state, double dt, int assume_flat_ground, int movement
         }
         y[NLEG * 6 + i] = (1.0 - ec[i]) * (x[2] + fk[2]) + ec[i] * 0;
     }
-    double CP[EKF_NM * EKF_NS], M[EKF_NM * 47];                       /* M = [S | error_y | C] */
+    double CP[EKF_NM * EKF_NS], M[EKF_NM * EKF_NM], err[EKF_NM], Serr[EKF_NM], SC[EKF_NM * EKF_NS];
     for (int r = 0; r < EKF_NM; ++r) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int k = 0; k < EKF_NS; ++k) a += C[r * EKF_NS + k] * Pbar[k * EKF_NS + j]; CP[r * EKF_NS + j] = a; }
     for (int r = 0; r < EKF_NM; ++r) for (int c = 0; c < EKF_NM; ++c) {                               /* :130 */
         double a = 0; for (int k = 0; k < EKF_NS; ++k) a += CP[r * EKF_NS + k] * C[c * EKF_NS + k];
-        M[r * 47 + c] = a + (r == c ? Rd[r] : 0.0);
+        M[r * EKF_NM + c] = a + (r == c ? Rd[r] : 0.0);
     }
     for (int r = 0; r < EKF_NM; ++r) for (int c = r + 1; c < EKF_NM; ++c) {                           /* :131 */
-        const double v = 0.5 * (M[r * 47 + c] + M[c * 47 + r]); M[r * 47 + c] = v; M[c * 47 + r] = v;
+        const double v = 0.5 * (M[r * EKF_NM + c] + M[c * EKF_NM + r]); M[r * EKF_NM + c] = v; M[c * EKF_NM + r] = v;
     }
-    for (int r = 0; r < EKF_NM; ++r) { M[r * 47 + r] = 0.5 * (M[r * 47 + r] + M[r * 47 + r]); M[r * 47 + 28] = y[r] - yhat[r]; for (int j = 0; j < EKF_NS; ++j) M[r * 47 + 29 + j] = C[r * EKF_NS + j]; }
-    for (int k = 0; k < EKF_NM; ++k) {                                /* Gauss-Jordan, no pivoting (:133-134,138) */
-        const double pinv = 1.0 / M[k * 47 + k];
-        for (int j = 0; j < 47; ++j) M[k * 47 + j] = M[k * 47 + j] * pinv;
+    for (int r = 0; r < EKF_NM; ++r) { M[r * EKF_NM + r] = 0.5 * (M[r * EKF_NM + r] + M[r * EKF_NM + r]); err[r] = y[r] - yhat[r]; }   /* :133 */
+    /* S^-1 by in-place Gauss-Jordan, no pivoting (S is symmetric positive definite); the two solves (:134, :138) are then products with it.
+     * Pivot k: row k is scaled by 1 / p and its own entry becomes 1 / p; every other row i subtracts f = a_ik times row k and its k-th entry becomes -f / p. */
+    for (int k = 0; k < EKF_NM; ++k) {
+        const double pinv = 1.0 / M[k * EKF_NM + k];
+        for (int j = 0; j < EKF_NM; ++j) M[k * EKF_NM + j] = j == k ? pinv : M[k * EKF_NM + j] * pinv;
         for (int i = 0; i < EKF_NM; ++i) if (i != k) {
-            const double f = M[i * 47 + k];
-            for (int j = 0; j < 47; ++j) M[i * 47 + j] = M[i * 47 + j] - f * M[k * 47 + j];
+            const double f = M[i * EKF_NM + k];
+            for (int j = 0; j < EKF_NM; ++j) M[i * EKF_NM + j] = j == k ? -(f * pinv) : M[i * EKF_NM + j] - f * M[k * EKF_NM + j];
         }
     }
+    for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a += M[r * EKF_NM + c] * err[c]; Serr[r] = a; }                                    /* :134 */
+    for (int r = 0; r < EKF_NM; ++r) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a += M[r * EKF_NM + c] * C[c * EKF_NS + j]; SC[r * EKF_NS + j] = a; }   /* :138 */
     double G1[EKF_NS * EKF_NM], G2[EKF_NS * EKF_NS];
     for (int a_ = 0; a_ < EKF_NS; ++a_) for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int k = 0; k < EKF_NS; ++k) a += Pbar[a_ * EKF_NS + k] * C[r * EKF_NS + k]; G1[a_ * EKF_NM + r] = a; }
     for (int a_ = 0; a_ < EKF_NS; ++a_) {                                                             /* :136 */
-        double a = 0; for (int r = 0; r < EKF_NM; ++r) a += G1[a_ * EKF_NM + r] * M[r * 47 + 28];
+        double a = 0; for (int r = 0; r < EKF_NM; ++r) a += G1[a_ * EKF_NM + r] * Serr[r];
         x[a_] = xbar[a_] + a;
     }
-    for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int r = 0; r < EKF_NM; ++r) a += G1[a_ * EKF_NM + r] * M[r * 47 + 29 + j]; G2[a_ * EKF_NS + j] = a; }
+    for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int r = 0; r < EKF_NM; ++r) a += G1[a_ * EKF_NM + r] * SC[r * EKF_NS + j]; G2[a_ * EKF_NS + j] = a; }
     for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) {                            /* :139 */
         double a = 0; for (int k = 0; k < EKF_NS; ++k) a += G2[a_ * EKF_NS + k] * Pbar[k * EKF_NS + j];
         T[a_ * EKF_NS + j] = Pbar[a_ * EKF_NS + j] - a;

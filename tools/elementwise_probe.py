@@ -52,7 +52,7 @@ with pkg.Engine(cfg, n, 0) as eng:
         eng.ekf_update(0.0025, np.ones(n, np.uint8), rng.uniform(0, 150, (n, 4)), R, rng.normal(0, 1, (n, 3)) + [0, 0, 9.81], rng.normal(0, 0.2, (n, 3)), leg["foot_pos_rel"], leg["foot_vel_rel"])
         ms.append(eng.last_kernel_ms())
     b = 8 * (4 + 9 + 3 + 3 + 12 + 12) + 1 + 2 * 8 * 343 + 8 * 6 + 4   # inputs + state read and written + outputs
-    fl = 2 * (18 * 18 * 2 + 28 * 18 * 2 + 28 * 28 * 47 + 18 * 28 + 18 * 28 * 18 + 18 * 18 * 18)  # products + elimination, flops per robot
+    fl = 2 * (18 * 18 * 2 + 28 * 18 * 2 + 28 * 28 * 28 + 28 * 28 + 28 * 4 + 18 * 28 + 18 * 28 * 18 + 18 * 18 * 18)  # products + the in-place 28 x 28 inverse (round 3; the 47-wide tableau until then: 28 * 28 * 47) + S^-1 e, S^-1 C: flops per robot
     out["N4c ekf (init + update kernels)"] = {"kernel_ms": float(np.median(ms[2:])), "bytes_per_robot": b, "GB_per_s": n * b / (float(np.median(ms[2:])) * 1e-3) / 1e9,
                                               "flops_per_robot": fl, "TFLOP_per_s": n * fl / (float(np.median(ms[2:])) * 1e-3) / 1e12}
 print(json.dumps({"robots": n, "peak_GB_per_s": 8000, "kernels": out}))

@@ -22,4 +22,5 @@ timeout 200 python tools/pcie_probe.py 8192 16 20 > $O/pcie_probe_8192_h16.json 
 timeout 200 python tools/general_path_probe.py > $O/general_path_probe.log 2>&1
 timeout 200 python tools/stage_probe.py > $O/stage_probe.json 2>/dev/null
 timeout 200 python tools/elementwise_probe.py > $O/elementwise_probe.log 2>&1
+( cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; timeout 200 rocprofv3 --kernel-trace --stats -d $O/elementwise_trace --output-format csv -- python tools/elementwise_probe.py > /dev/null 2>&1 )
 tail -c 400 $O/bench_default.json; echo; cat $O/latency_10000.json; tail -3 $O/collect.log
