@@ -354,7 +354,11 @@ a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h);
  * OsqpEigen::Solver member, S/A1RobotControl.h:67): x n x 12H (world-frame forces), y n x 20H (reference row order), rho n
  * (0 = "start from settings.rho").  Any pointer may be NULL.  Host pointers; synchronises the handle's stream.  A solve whose
  * solution is not finite leaves (0, 0, 0) behind, i.e. the next tick of that problem is a cold start (OSQP's store_solution()
- * cold-starts its iterates after a failed solve), so one bad tick cannot poison the ticks after it.  With warm_start = 2 an injected state also clears the
+ * cold-starts its iterates after a failed solve), so one bad tick cannot poison the ticks after it.  One deliberate difference: OSQP's
+ * cold_start() zeroes x, y, z but leaves the rho it had adapted in settings->rho, so the real solver's next tick starts from that rho;
+ * this library (and the oracle) restart from the configured rho, because a rho adapted on the way to a non-finite point is not worth
+ * keeping.  A status without a solution is the only place the two differ, and the reference's QP (bounded forces, convex cost) never
+ * produced one in any parity run.  With warm_start = 2 an injected state also clears the
  * update path's carry of these problems: their next tick is a fresh set-up warm-started from (x, y, rho), the ticks after it follow the update path again. */
 a1mpc_status a1mpc_warm_start(a1mpc_handle h, int32_t n, const double* x, const double* y, const double* rho);
 a1mpc_status a1mpc_get_warm_start(a1mpc_handle h, int32_t n, double* x_out, double* y_out, double* rho_out);
@@ -409,9 +413,9 @@ void a1mpc_sharded_destroy(a1mpc_sharded s);
  * pipeline owns `depth` complete engine handles (0 = the default: 2) on `depth` HIP streams and hands batches to them round-robin, so the
  * next batch's set-up kernel and persistent rows are dispatched onto the SIMDs the tail has left.  Batches in flight share nothing
  * (prepared-state records, queue, warm start are per slot): results are bit-identical to a lone handle's.  Measured on one MI355X, first
- * solves of distinct batches (profiles/r02_overlap_probe.json): 2048 x h10 3.4 -> 6.1 M solves/s (depth 3), 4096 x h10 4.8 -> 6.45 M,
- * 8192 x h16 1.92 -> 2.08 M, 8192 x h20 1.45 -> 1.6 M; 16 384 x h10 neutral; a batch of 65 536 QPs fills the chip on its own and loses 7 %
- * when pipelined -- submit those through a plain handle.
+ * solves of distinct batches (profiles/r03_bench_default_run.json, r03_bench_depth1_run.json): 4096 x h10 4.2-5.0 M -> 6.35-6.44 M solves/s,
+ * 8192 x h16 2.23 -> 2.47 M; depth 3 no longer pays (profiles/r03_pcie_probe_4096_h10.json); 16 384 x h10 neutral; a batch of 65 536 QPs
+ * fills the chip on its own and loses 7 % when pipelined -- submit those through a plain handle.
  *   submit   device pointers, layouts of a1mpc_solve_batch_device.  slot = -1: next slot round-robin (returned in *slot_out), or a fixed
  *            slot (a robot population that is warm-started must stay on its slot: the carried OSQP workspace lives there).
  *            fresh_batch != 0: these QPs are new to the slot, order its queue by the set-up kernel's cost guess instead of the slot's
