@@ -835,17 +835,28 @@ void a1mpc_default_balance_config(a1mpc_balance_config* q) {
 }
 
 // ---- N2b: contact logic + recent-contact filters, walking-surface fit, terrain pitch (S/A1RobotControl.cpp:256-282, 566-582, 335-376) --------
-// Device-resident state per robot: 13 moving-window filters x [count, head, sum, correction, ring[100]], early_contacts[4], recent[12],
-// stored field-major ([field][robot], stride = max_batch): robots whose filters are in phase touch neighbouring words.
-// K_a: one lane per (robot, leg) -- contact rules and the leg's three filters (window 60); K_b: one lane per robot -- plane fit,
-// terrain-angle filter (window 100), pitch rule.  HBM-bound: a tick touches one ring slot per active filter.  No FMA contraction.
-constexpr int kMwf = 104, kCtState = 13 * kMwf + 4 + 12;
+// Device-resident state per robot, laid out so that one tick touches whole cache lines whatever phase the robots' filters are in (round 3; until then
+// every field was its own [robot] array, which coalesces only while all robots' ring cursors agree -- they part with the first early contact):
+//   record, 384 B, 128-aligned: 4 x CtLeg (64 B: the leg's window count and cursor -- its three position filters are always updated together, so they
+//           share them --, the early-contact flag, 3 x Neumaier sum / correction) + CtRobot (128 B: foot_pos_recent_contact, the terrain-angle filter's header);
+//   leg rings  [robot][leg][60 slots][4 doubles] (x, y, z of one tick in one 32-byte sector; the 4th is padding);
+//   terrain ring [100 slots][robot]: this filter advances on every tick of a robot that stands (root height > 0.1 m), so the robots' cursors agree unless one of them
+//           has been lying down -- neighbouring robots then touch neighbouring words (the leg rings cannot have that: early contacts part their cursors for good).
+// One lane per robot: 3 lines of record + one sector per leg in contact + one word of the terrain ring, read and written once.  No FMA contraction.
+constexpr int kLegWindow = 60, kTerrainWindow = 100;
+struct CtLeg { int32_t count, head; double early, sum[3], corr[3]; };
+struct CtRobot { double recent[12]; int32_t count, head; double sum, corr, pad_; };
+struct CtRecord { CtLeg leg[4]; CtRobot rb; };   // (no alignas: the records start a hipMalloc block, which is 256-byte aligned, and their LDS image below is not 128-aligned)
+static_assert(sizeof(CtLeg) == 64 && sizeof(CtRobot) == 128 && sizeof(CtRecord) == 384, "contact-state record: three 128-byte lines");
+constexpr size_t kCtLegRing = 4 * kLegWindow * 4;  // doubles per robot
+constexpr size_t kCtBytesPerRobot = sizeof(CtRecord) + (kCtLegRing + kTerrainWindow) * sizeof(double);
 struct ContactArgs {
     int32_t n;
     double counter_per_swing, foot_force_low;
     int32_t use_terrain_adapt;
-    double* state;
-    int64_t stride;  // robots per field (= max_batch)
+    CtRecord* rec;
+    double *leg_ring, *terrain_ring;
+    int64_t stride;  // robots per terrain-ring slot (= max_batch)
     const double *gait_counter, *foot_force, *foot_pos_abs, *root_pos_z;
     const uint8_t* plan_contacts;
     double* pitch_d;
@@ -853,45 +864,15 @@ struct ContactArgs {
     double *recent_out, *terrain_out;
     const double* recent_in;  // terrain-only entry: foot_pos_recent_contact comes from the caller instead of the handle's contact state
 };
-__device__ inline double mwf_update(double* f, int64_t fs, int window, double v) {  // S/utils/filter.hpp:26-39,53-66; f[k * fs] = field k of this filter
+struct Neumaier {  // S/utils/filter.hpp:26-39,53-66: the moving-window sum with its running compensation
+    double sum, corr;
+    __device__ inline void add(double val) {
 #pragma clang fp contract(off)
-    int count = static_cast<int>(f[0]), head = static_cast<int>(f[fs]);
-    double sum = f[2 * fs], corr = f[3 * fs];
-    double* ring = f + 4 * fs;
-    auto neumaier = [&](double val) {
         const double ns = sum + val;
         if (fabs(sum) >= fabs(val)) corr += (sum - ns) + val; else corr += (val - ns) + sum;
         sum = ns;
-    };
-    if (count >= window) neumaier(-ring[head * fs]); else count += 1;
-    neumaier(v);
-    ring[head * fs] = v;
-    head = (head + 1) % window;
-    f[0] = count; f[fs] = head; f[2 * fs] = sum; f[3 * fs] = corr;
-    return (sum + corr) / static_cast<double>(window);
-}
-__global__ __launch_bounds__(256) void a1mpc_contact_kernel(const ContactArgs a) {
-#pragma clang fp contract(off)
-    const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    const int64_t b = gid >> 2;
-    const int i = static_cast<int>(gid & 3);
-    if (b >= a.n) return;
-    double* st = a.state + b;
-    const int64_t fs = a.stride;
-    double *early = st + 13 * kMwf * fs, *recent = early + 4 * fs;
-    const double gc = a.gait_counter[b * 4 + i];
-    const bool plan = a.plan_contacts[b * 4 + i] != 0;
-    double e = early[i * fs];
-    if (gc <= a.counter_per_swing * 1.5) e = 0.0;                                                                   // :260-262
-    if (!plan && gc > a.counter_per_swing * 1.5 && a.foot_force[b * 4 + i] > a.foot_force_low) e = 1.0;             // :263-267
-    early[i * fs] = e;
-    const bool c = plan || e != 0.0;                                                                                // :271
-    a.contacts[b * 4 + i] = c ? 1 : 0;
-    if (c) {                                                                                                        // :274-281
-#pragma unroll
-        for (int k = 0; k < 3; ++k) recent[(3 * i + k) * fs] = mwf_update(st + (3 * i + k) * kMwf * fs, fs, 60, a.foot_pos_abs[b * 12 + 3 * i + k]);
     }
-}
+};
 __device__ inline void sym3_pinv(const double* m, double* out) {  // pseudo-inverse of a symmetric PSD 3x3 by cyclic Jacobi (S/utils/Utils.cpp:44-52)
 #pragma clang fp contract(off)
     double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -919,20 +900,68 @@ __device__ inline void sym3_pinv(const double* m, double* out) {  // pseudo-inve
         for (int j = 0; j < 3; ++j)
             out[3 * i + j] = v[3 * i + 0] * inv[0] * v[3 * j + 0] + v[3 * i + 1] * inv[1] * v[3 * j + 1] + v[3 * i + 2] * inv[2] * v[3 * j + 2];
 }
-__global__ __launch_bounds__(256) void a1mpc_terrain_kernel(const ContactArgs a) {
+// one robot's tick on its record `st` (the kernel hands in the record's LDS image; the terrain-only entry and the host-compiled test double the record itself)
+__device__ __forceinline__ void contact_terrain_robot(const ContactArgs& a, const int64_t b, CtRecord* st) {
 #pragma clang fp contract(off)
-    const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (b >= a.n) return;
-    double* st = a.state + b;
-    const int64_t fs = a.stride;
-    const double* recent = st + (13 * kMwf + 4) * fs;
     double rc[12];
+    if (a.recent_in) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) { rc[k] = a.recent_in ? a.recent_in[b * 12 + k] : recent[k * fs]; if (a.recent_out) a.recent_out[b * 12 + k] = rc[k]; }
+        for (int k = 0; k < 12; ++k) rc[k] = a.recent_in[b * 12 + k];
+    } else {
+        CtLeg L[4];
+        double slot[4][3], gc[4], ff[4], fp[12];
+        uint8_t plan[4];
+        bool c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { L[i] = st->leg[i]; gc[i] = a.gait_counter[b * 4 + i]; ff[i] = a.foot_force[b * 4 + i]; plan[i] = a.plan_contacts[b * 4 + i]; }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { rc[k] = st->rb.recent[k]; fp[k] = a.foot_pos_abs[b * 12 + k]; }
+        double* ring = a.leg_ring + b * kCtLegRing;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double e = L[i].early;
+            if (gc[i] <= a.counter_per_swing * 1.5) e = 0.0;                                                        // :260-262
+            if (!plan[i] && gc[i] > a.counter_per_swing * 1.5 && ff[i] > a.foot_force_low) e = 1.0;                 // :263-267
+            c[i] = plan[i] != 0 || e != 0.0;                                                                        // :271
+            if (e != L[i].early) st->leg[i].early = e;
+            a.contacts[b * 4 + i] = c[i] ? 1 : 0;
+            const double* sl = ring + (i * kLegWindow + L[i].head) * 4;
+            const bool full = c[i] && L[i].count >= kLegWindow;   // only then does the slot under the cursor hold a sample to retire
+#pragma unroll
+            for (int k = 0; k < 3; ++k) slot[i][k] = full ? sl[k] : 0.0;
+        }
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!c[i]) continue;                                                                                    // :274-281
+            any = true;
+            const bool full = L[i].count >= kLegWindow;
+            double* sl = ring + (i * kLegWindow + L[i].head) * 4;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Neumaier f{L[i].sum[k], L[i].corr[k]};
+                if (full) f.add(-slot[i][k]);
+                f.add(fp[3 * i + k]);
+                sl[k] = fp[3 * i + k];
+                st->leg[i].sum[k] = f.sum; st->leg[i].corr[k] = f.corr;
+                rc[3 * i + k] = (f.sum + f.corr) / static_cast<double>(kLegWindow);
+            }
+            st->leg[i].count = full ? L[i].count : L[i].count + 1;
+            st->leg[i].head = (L[i].head + 1) % kLegWindow;
+        }
+        if (any) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) st->rb.recent[k] = rc[k];
+        }
+    }
+    if (a.recent_out) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) a.recent_out[b * 12 + k] = rc[k];
+    }
     double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, rhs[3] = {0, 0, 0}, P3[9], co[3];   // :566-582  a = pinv(W'W) W' z
     for (int i = 0; i < 4; ++i) {
         const double w[3] = {1.0, rc[3 * i + 0], rc[3 * i + 1]};
-        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) M[3 * r + c] += w[r] * w[c]; rhs[r] += w[r] * rc[3 * i + 2]; }
+        for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) M[3 * r + cc] += w[r] * w[cc]; rhs[r] += w[r] * rc[3 * i + 2]; }
     }
     sym3_pinv(M, P3);
     for (int r = 0; r < 3; ++r) co[r] = P3[3 * r + 0] * rhs[0] + P3[3 * r + 1] * rhs[1] + P3[3 * r + 2] * rhs[2];
@@ -940,13 +969,65 @@ __global__ __launch_bounds__(256) void a1mpc_terrain_kernel(const ContactArgs a)
     double terrain_angle = 0.0;                                                             // :339-352
     if (a.root_pos_z[b] > 0.1) {
         const double angle_cos = fabs(0.0 * s0 + 0.0 * s1 + 1.0 * s2) / (sqrt(0.0 * 0.0 + 0.0 * 0.0 + 1.0 * 1.0) * sqrt(s0 * s0 + s1 * s1 + s2 * s2));
-        terrain_angle = mwf_update(st + 12 * kMwf * fs, fs, 100, acos(angle_cos));
+        const double v = acos(angle_cos);
+        const int count = st->rb.count, head = st->rb.head;
+        Neumaier f{st->rb.sum, st->rb.corr};
+        double* tr = a.terrain_ring + head * a.stride + b;
+        if (count >= kTerrainWindow) f.add(-*tr); else st->rb.count = count + 1;
+        f.add(v);
+        *tr = v;
+        st->rb.head = (head + 1) % kTerrainWindow; st->rb.sum = f.sum; st->rb.corr = f.corr;
+        terrain_angle = (f.sum + f.corr) / static_cast<double>(kTerrainWindow);
     }
     if (terrain_angle > 0.5) terrain_angle = 0.5;
     if (terrain_angle < -0.5) terrain_angle = -0.5;
     const double F_R_diff = rc[2] + rc[5] - rc[8] - rc[11];                                // :355
     if (a.use_terrain_adapt) a.pitch_d[b] = F_R_diff > 0.05 ? -terrain_angle : terrain_angle;  // :358-364
     a.terrain_out[b] = terrain_angle;
+}
+// One wavefront = 64 robots.  A lane that walks its own 384-byte record in HBM makes every load instruction touch 64 different lines (measured: 2.5 TB/s of algorithmic
+// bytes at 524 288 robots whether the plane fit runs or not).  The wavefront therefore moves its 24 KB of records as 24 fully coalesced 16-byte-per-lane loads into LDS,
+// every lane works on the LDS image of its record (stride 400 B = 25 x 16 B: the 16 lanes of a ds_read_b128 phase hit 16 different quad-banks), and the image goes back
+// the same way -- whole lines in, whole lines out.  Only the ring sectors are touched in place (one 32-byte sector per leg in contact, wherever that robot's cursor is).
+constexpr int kCtLdsStride = 400, kCtUnits = sizeof(CtRecord) / 16;   // bytes per record image; 16-byte units per record
+__global__ __launch_bounds__(64) void a1mpc_contact_terrain_kernel(const ContactArgs a) {
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * 64;
+    const int lane = threadIdx.x;
+    const int64_t b = base + lane;
+    if (a.recent_in) {   // terrain-only entry: 24 bytes of the record matter
+        if (b < a.n) contact_terrain_robot(a, b, a.rec + b);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) unsigned char img[64 * kCtLdsStride];
+    const int cnt = a.n - base < 64 ? static_cast<int>(a.n - base) : 64;
+    const uint4* src = reinterpret_cast<const uint4*>(a.rec + base);
+    uint4 v[kCtUnits];
+#pragma unroll
+    for (int i = 0; i < kCtUnits; ++i) { const int o = i * 64 + lane; v[i] = o < cnt * kCtUnits ? src[o] : uint4{0, 0, 0, 0}; }
+#pragma unroll
+    for (int i = 0; i < kCtUnits; ++i) { const int o = i * 64 + lane, r = o / kCtUnits, w = o - r * kCtUnits; *reinterpret_cast<uint4*>(img + r * kCtLdsStride + w * 16) = v[i]; }
+    __syncthreads();
+    if (b < a.n) contact_terrain_robot(a, b, reinterpret_cast<CtRecord*>(img + lane * kCtLdsStride));
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(a.rec + base);
+#pragma unroll
+    for (int i = 0; i < kCtUnits; ++i) { const int o = i * 64 + lane, r = o / kCtUnits, w = o - r * kCtUnits; if (o < cnt * kCtUnits) dst[o] = *reinterpret_cast<const uint4*>(img + r * kCtLdsStride + w * 16); }
+}
+// the handle's contact state: records, then the leg rings, then the terrain rings (zero = every filter empty)
+static a1mpc_status ensure_contact_state(a1mpc_handle h, hipStream_t s) {
+    if (h->d_ct_state) return A1MPC_OK;
+    A1_HIP(hipMalloc(&h->d_ct_state, static_cast<size_t>(h->max_batch) * kCtBytesPerRobot));
+    A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtBytesPerRobot, s));
+    return A1MPC_OK;
+}
+static void contact_state_pointers(a1mpc_handle h, ContactArgs& a) {
+    a.rec = reinterpret_cast<CtRecord*>(h->d_ct_state);
+    a.leg_ring = reinterpret_cast<double*>(a.rec + h->max_batch);
+    a.terrain_ring = a.leg_ring + static_cast<size_t>(h->max_batch) * kCtLegRing;
+    a.stride = h->max_batch;
+}
+static void launch_contact_terrain(const ContactArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(a1mpc_contact_terrain_kernel, dim3(static_cast<unsigned>((a.n + 63) / 64)), dim3(64), 0, s, a);
 }
 
 static a1mpc_status ensure_aux(a1mpc_handle h) {
@@ -967,7 +1048,7 @@ a1mpc_status a1mpc_reset_contact_state(a1mpc_handle h) {
     if (!h->d_ct_state) return A1MPC_OK;
     A1_HIP(hipSetDevice(h->device));
     A1_ORDER(h, h->stream);  // the memsets below must not overtake a launch still running on a caller's stream
-    A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double), h->stream));
+    A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtBytesPerRobot, h->stream));
     A1_HIP(hipStreamSynchronize(h->stream));
     return A1MPC_OK;
 }
@@ -986,10 +1067,7 @@ a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_con
     const size_t N = n;
     hipStream_t s = h->stream;
     A1_ORDER(h, s);
-    if (!h->d_ct_state) {
-        A1_HIP(hipMalloc(&h->d_ct_state, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double)));
-        A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double), s));
-    }
+    if (a1mpc_status st = ensure_contact_state(h, s); st != A1MPC_OK) return st;
     // staging: in [gc 4 | ff 4 | foot 12 | z 1 | pitch 1], out [recent 12 | terrain 1]
     double *d_gc = h->d_aux_in, *d_ff = d_gc + 4 * N, *d_fp = d_ff + 4 * N, *d_z = d_fp + 12 * N, *d_pd = d_z + N;
     double *d_rec = h->d_aux_out, *d_ta = d_rec + 12 * N;
@@ -1003,11 +1081,10 @@ a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_con
     ContactArgs a;
     a.recent_in = nullptr;
     a.n = n; a.counter_per_swing = cfg->counter_per_swing; a.foot_force_low = cfg->foot_force_low; a.use_terrain_adapt = cfg->use_terrain_adapt;
-    a.state = h->d_ct_state; a.stride = h->max_batch; a.gait_counter = d_gc; a.foot_force = d_ff; a.foot_pos_abs = d_fp; a.root_pos_z = d_z; a.plan_contacts = d_pc;
+    contact_state_pointers(h, a); a.gait_counter = d_gc; a.foot_force = d_ff; a.foot_pos_abs = d_fp; a.root_pos_z = d_z; a.plan_contacts = d_pc;
     a.pitch_d = d_pd; a.contacts = d_ct; a.recent_out = d_rec; a.terrain_out = d_ta;
     A1_HIP(hipEventRecord(h->ev0, s));
-    hipLaunchKernelGGL(a1mpc_contact_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(a1mpc_terrain_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+    launch_contact_terrain(a, s);
     A1_HIP(hipGetLastError());
     A1_HIP(hipEventRecord(h->ev1, s));
     h->timed = true; A1_MARK(h, s);
@@ -1249,7 +1326,7 @@ __device__ inline void ekf_c_row(int r, int& c0, double& s0, int& c1, double& s1
 }
 __global__ __launch_bounds__(64) void a1mpc_ekf_kernel(const EkfArgs a) {
 #pragma clang fp contract(off)
-    __shared__ double lds[2][1280];
+    __shared__ __attribute__((aligned(16))) double lds[2][1280];
     const int g = static_cast<int>(threadIdx.x) >> 5, l = static_cast<int>(threadIdx.x) & 31;
     const int64_t b = static_cast<int64_t>(blockIdx.x) * 2 + g;
     if (b >= a.n) return;
@@ -1322,23 +1399,31 @@ __global__ __launch_bounds__(64) void a1mpc_ekf_kernel(const EkfArgs a) {
     half_sync();
     if (l < 28)
         for (int c = 0; c < 28; ++c) M[c] = c == l ? 0.5 * (M[c] + M[c]) : (c > l ? 0.5 * (M[c] + Sm[c * 29 + l]) : 0.5 * (Sm[c * 29 + l] + M[c]));   // :131
-    // ---- S^-1 by in-place Gauss-Jordan elimination, no pivoting (S is symmetric positive definite); the two solves (:134, :138) are then products with it.
-    // Pivot k: row k is scaled by 1 / p and its own entry becomes 1 / p; every other row i subtracts f = a_ik times row k and its k-th entry becomes -f / p.
-    // (Until round 3 the 47-wide tableau [S | error_y | C] was eliminated: 47 instead of 28 entries per row and pivot for the same two solutions.)
+    // ---- S^-1 by the symmetric sweep operator (in-place Gauss-Jordan without pivoting; S is symmetric positive definite); the two solves (:134, :138) are then
+    // products with it.  Sweep k, p = a_kk:  a_ij -= (a_ik / p) a_kj,  a_ik = a_ik / p,  a_kj = a_kj / p,  a_kk = -1 / p  -- the matrix stays symmetric and ends as -S^-1.
+    // Lane i takes the pivot row from COLUMN k as the other lanes hold it (a_jk for a_kj): a sweep exchanges ONE word per lane (28 lanes write, everyone reads the 28
+    // back).  Exact, because the update is fma(-(a_ik a_jk), 1/p, a_ij): the product commutes, lanes i and j compute the same bits for a_ij and a_ji.  (Until round 3
+    // lane k scaled its row first and published all of it: 28 LDS writes with one lane of 32 active per sweep.  The oracle does the same, oracle/a1mpc_oracle.c.)
 #pragma unroll
     for (int k = 0; k < 28; ++k) {
+        half_sync();   // the previous sweep's reads of the column are complete
+        if (l < 28) prow[l] = M[k];
         half_sync();
-        if (l == k) {
-            const double pinv = 1.0 / M[k];
+        if (l < 28) {
+            const double pinv = 1.0 / prow[k];
+            if (l == k) {
 #pragma unroll
-            for (int j = 0; j < 28; ++j) { M[j] = j == k ? pinv : M[j] * pinv; prow[j] = M[j]; }
-        }
-        half_sync();
-        if (l < 28 && l != k) {
-            const double f = M[k];
+                for (int j = 0; j < 28; ++j) M[j] = j == k ? -pinv : M[j] * pinv;
+            } else {
+                const double aik = M[k];
 #pragma unroll
-            for (int j = 0; j < 28; ++j) M[j] = j == k ? -(f * prow[j]) : M[j] - f * prow[j];
+                for (int j = 0; j < 28; ++j) M[j] = j == k ? aik * pinv : __builtin_fma(-(aik * prow[j]), pinv, M[j]);
+            }
         }
+    }
+    if (l < 28) {
+#pragma unroll
+        for (int j = 0; j < 28; ++j) M[j] = -M[j];
     }
     half_sync();
     double* SC = Sm;  // S is consumed: the region now holds S^-1 C (28 x 18)
@@ -1660,18 +1745,14 @@ a1mpc_status a1mpc_contact_terrain_batch_device(a1mpc_handle h, const a1mpc_cont
                                                 void* hip_stream) {
     A1_DEV_PROLOGUE(cfg && gait_counter && plan_contacts && foot_force && foot_pos_abs && root_pos_z && root_euler_d_pitch && contacts_out &&
                     foot_pos_recent_contact_out && terrain_angle_out);
-    if (!h->d_ct_state) {
-        A1_HIP(hipMalloc(&h->d_ct_state, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double)));
-        A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double), s));
-    }
+    if (a1mpc_status st = ensure_contact_state(h, s); st != A1MPC_OK) return st;
     ContactArgs a;
     a.recent_in = nullptr;
     a.n = n; a.counter_per_swing = cfg->counter_per_swing; a.foot_force_low = cfg->foot_force_low; a.use_terrain_adapt = cfg->use_terrain_adapt;
-    a.state = h->d_ct_state; a.stride = h->max_batch; a.gait_counter = gait_counter; a.foot_force = foot_force; a.foot_pos_abs = foot_pos_abs; a.root_pos_z = root_pos_z;
+    contact_state_pointers(h, a); a.gait_counter = gait_counter; a.foot_force = foot_force; a.foot_pos_abs = foot_pos_abs; a.root_pos_z = root_pos_z;
     a.plan_contacts = plan_contacts; a.pitch_d = root_euler_d_pitch; a.contacts = contacts_out; a.recent_out = foot_pos_recent_contact_out; a.terrain_out = terrain_angle_out;
     A1_HIP(hipEventRecord(h->ev0, s));
-    hipLaunchKernelGGL(a1mpc_contact_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(a1mpc_terrain_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+    launch_contact_terrain(a, s);
     A1_DEV_EPILOGUE();
 }
 a1mpc_status a1mpc_leg_state_batch_device(a1mpc_handle h, int32_t n, const double* joint_pos, const double* joint_vel, const double* R_world,
@@ -2120,19 +2201,16 @@ a1mpc_status a1mpc_terrain_batch(a1mpc_handle h, int32_t use_terrain_adapt, int3
     const size_t N = n;
     hipStream_t s = h->stream;
     A1_ORDER(h, s);
-    if (!h->d_ct_state) {
-        A1_HIP(hipMalloc(&h->d_ct_state, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double)));
-        A1_HIP(hipMemsetAsync(h->d_ct_state, 0, static_cast<size_t>(h->max_batch) * kCtState * sizeof(double), s));
-    }
+    if (a1mpc_status st = ensure_contact_state(h, s); st != A1MPC_OK) return st;
     double *d_rec = h->d_aux_in, *d_z = d_rec + 12 * N, *d_pd = d_z + N, *d_ta = h->d_aux_out;
     A1_HIP(hipMemcpyAsync(d_rec, foot_pos_recent_contact, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(d_z, root_pos_z, N * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(d_pd, root_euler_d_pitch, N * sizeof(double), hipMemcpyHostToDevice, s));
     ContactArgs a;
     std::memset(&a, 0, sizeof a);
-    a.n = n; a.use_terrain_adapt = use_terrain_adapt; a.state = h->d_ct_state; a.stride = h->max_batch; a.root_pos_z = d_z; a.pitch_d = d_pd;
+    a.n = n; a.use_terrain_adapt = use_terrain_adapt; contact_state_pointers(h, a); a.root_pos_z = d_z; a.pitch_d = d_pd;
     a.recent_in = d_rec; a.recent_out = nullptr; a.terrain_out = d_ta;
-    hipLaunchKernelGGL(a1mpc_terrain_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+    launch_contact_terrain(a, s);
     A1_HIP(hipGetLastError());
     A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(terrain_angle_out, d_ta, N * sizeof(double), hipMemcpyDeviceToHost, s));

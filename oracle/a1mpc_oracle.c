@@ -1121,7 +1121,7 @@ void orc_leg_state(const double *joint_pos, const double *joint_vel, const doubl
 /* ---- N4c: A1BasicEKF (S/A1BasicEKF.cpp:7-163), the 18-state / 28-measurement Kalman filter for base position and velocity -----------
  * Dense restatement, matrix product by matrix product in the reference's evaluation order (left to right, inner index ascending).
  * state = [x 18 | P 18x18 row-major | initialised flag] = ORC_EKF_STATE doubles.  The two S.fullPivHouseholderQr().solve() calls (:134,138)
- * are restated as products with S^-1, computed ONCE by an in-place Gauss-Jordan elimination without pivoting (S is symmetric positive definite; until round 3
+ * are restated as products with S^-1, computed ONCE by symmetric sweeps (in-place Gauss-Jordan without pivoting; S is symmetric positive definite; until round 3
  * the 47-wide tableau [S | error_y | C] was eliminated instead: 40 % more work for the same two solutions): same solution, rounding differs from a
  * Householder QR (agreement tested against LAPACK and against the reference's own source, 1e-9). */
 #define EKF_NS 18
@@ -1210,16 +1210,23 @@ void orc_ekf_step(double *state, double dt, int assume_flat_ground, int movement
         const double v = 0.5 * (M[r * EKF_NM + c] + M[c * EKF_NM + r]); M[r * EKF_NM + c] = v; M[c * EKF_NM + r] = v;
     }
     for (int r = 0; r < EKF_NM; ++r) { M[r * EKF_NM + r] = 0.5 * (M[r * EKF_NM + r] + M[r * EKF_NM + r]); err[r] = y[r] - yhat[r]; }   /* :133 */
-    /* S^-1 by in-place Gauss-Jordan, no pivoting (S is symmetric positive definite); the two solves (:134, :138) are then products with it.
-     * Pivot k: row k is scaled by 1 / p and its own entry becomes 1 / p; every other row i subtracts f = a_ik times row k and its k-th entry becomes -f / p. */
+    /* S^-1 by the symmetric sweep operator (in-place Gauss-Jordan without pivoting; S is symmetric positive definite); the two solves (:134, :138) are then
+     * products with it.  Sweep k with p = a_kk:  a_ij -= (a_ik / p) a_kj,  a_ik = a_ik / p,  a_kj = a_kj / p,  a_kk = -1 / p; the matrix stays symmetric and ends
+     * as -S^-1.  Row i takes the pivot row from COLUMN k as the other rows hold it (a_jk for a_kj): on the device row i lives in lane i, and one word per lane is
+     * all a sweep has to exchange.  That is exact because the update is evaluated as fma(-(a_ik a_jk), 1/p, a_ij): the product commutes, rows i and j compute
+     * the same bits for a_ij and a_ji, and the matrix stays symmetric to the last bit.  (With f = a_ik / p first -- one operation fewer -- a_ij and a_ji drift
+     * apart by a rounding per sweep and the inverse loses a digit and a half componentwise: tried, 8.6e-13 against 2.8e-14 on the filter's graded S.) */
     for (int k = 0; k < EKF_NM; ++k) {
-        const double pinv = 1.0 / M[k * EKF_NM + k];
-        for (int j = 0; j < EKF_NM; ++j) M[k * EKF_NM + j] = j == k ? pinv : M[k * EKF_NM + j] * pinv;
-        for (int i = 0; i < EKF_NM; ++i) if (i != k) {
-            const double f = M[i * EKF_NM + k];
-            for (int j = 0; j < EKF_NM; ++j) M[i * EKF_NM + j] = j == k ? -(f * pinv) : M[i * EKF_NM + j] - f * M[k * EKF_NM + j];
+        double col[EKF_NM];
+        for (int j = 0; j < EKF_NM; ++j) col[j] = M[j * EKF_NM + k];
+        const double pinv = 1.0 / col[k];
+        for (int i = 0; i < EKF_NM; ++i) {
+            if (i == k) { for (int j = 0; j < EKF_NM; ++j) M[k * EKF_NM + j] = j == k ? -pinv : M[k * EKF_NM + j] * pinv; continue; }
+            const double aik = M[i * EKF_NM + k];
+            for (int j = 0; j < EKF_NM; ++j) M[i * EKF_NM + j] = j == k ? aik * pinv : fma(-(aik * col[j]), pinv, M[i * EKF_NM + j]);
         }
     }
+    for (int i = 0; i < EKF_NM * EKF_NM; ++i) M[i] = -M[i];
     for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a += M[r * EKF_NM + c] * err[c]; Serr[r] = a; }                                    /* :134 */
     for (int r = 0; r < EKF_NM; ++r) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a += M[r * EKF_NM + c] * C[c * EKF_NS + j]; SC[r * EKF_NS + j] = a; }   /* :138 */
     double G1[EKF_NS * EKF_NM], G2[EKF_NS * EKF_NS];
