@@ -1403,7 +1403,7 @@ __global__ __launch_bounds__(64) void a1mpc_ekf_kernel(const EkfArgs a) {
     // products with it.  Sweep k, p = a_kk:  a_ij -= (a_ik / p) a_kj,  a_ik = a_ik / p,  a_kj = a_kj / p,  a_kk = -1 / p  -- the matrix stays symmetric and ends as -S^-1.
     // Lane i takes the pivot row from COLUMN k as the other lanes hold it (a_jk for a_kj): a sweep exchanges ONE word per lane (28 lanes write, everyone reads the 28
     // back).  Exact, because the update is fma(-(a_ik a_jk), 1/p, a_ij): the product commutes, lanes i and j compute the same bits for a_ij and a_ji.  (Until round 3
-    // lane k scaled its row first and published all of it: 28 LDS writes with one lane of 32 active per sweep.  The oracle does the same, oracle/a1mpc_oracle.c.)
+    // lane k scaled its row first and published all of it: 28 LDS writes with one lane of 32 active per sweep.  oracle/a1mpc_oracle.c does the same.)
 #pragma unroll
     for (int k = 0; k < 28; ++k) {
         half_sync();   // the previous sweep's reads of the column are complete
