@@ -67,7 +67,7 @@ int main() {
     int clk = 0; hipDeviceGetAttribute(&clk, hipDeviceAttributeWallClockRate, 0);
     printf("wall clock rate (kHz, clock64 tick): %d\n", clk);
     run<0, 1>("v_fmac_f64 dependent", d_out, d_cyc); run<0, 2>("v_fmac_f64", d_out, d_cyc); run<0, 4>("v_fmac_f64", d_out, d_cyc); run<0, 8>("v_fmac_f64", d_out, d_cyc);
-    run<1, 1>("v_fmac_f64_dpp dependent", d_out, d_cyc); run<1, 2>("v_fmac_f64_dpp", d_out, d_cyc); run<1, 4>("v_fmac_f64_dpp", d_out, d_cyc); run<1, 8>("v_fmac_f64_dpp", d_out, d_cyc);
+    run<1, 1>("v_fmac_f64_dpp dependent", d_out, d_cyc); run<1, 2>("v_fmac_f64_dpp", d_out, d_cyc); run<1, 3>("v_fmac_f64_dpp", d_out, d_cyc); run<1, 4>("v_fmac_f64_dpp", d_out, d_cyc); run<1, 8>("v_fmac_f64_dpp", d_out, d_cyc);
     run<2, 1>("v_mov_b64_dpp(acc)+v_fmac dependent", d_out, d_cyc); run<2, 2>("v_mov_b64_dpp+v_fmac", d_out, d_cyc); run<2, 4>("v_mov_b64_dpp+v_fmac", d_out, d_cyc);
     run<3, 1>("v_mov_b64_dpp", d_out, d_cyc); run<3, 4>("v_mov_b64_dpp", d_out, d_cyc);
     run<4, 1>("v_add_f64 dependent", d_out, d_cyc); run<4, 4>("v_add_f64", d_out, d_cyc);
