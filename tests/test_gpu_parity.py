@@ -392,6 +392,26 @@ def test_contact_terrain_N2b_sequence(pkg, oracle, scen):
         assert (out["foot_pos_recent_contact"][0] == rec).all() and abs(out["terrain_angle"][0] - ang) <= 1e-13
 
 
+def test_contact_terrain_N2b_partial_wavefront_and_spare_capacity(pkg, oracle, scen):
+    """N2b with n = 70 robots on a handle created for 200: the second wavefront of the launch stages 6 records (the record copy is cut at n, the ring regions start
+    behind max_batch records) -- every robot against the oracle over a leg-window wrap."""
+    rng = np.random.default_rng(77)
+    n, cap, ticks = 70, 200, 90
+    cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+    states = [oracle.contact_state() for _ in range(n)]
+    pitch_g = np.zeros(n); pitch_o = np.zeros(n)
+    gcs = rng.uniform(0, 240, (n, 4))
+    with pkg.Engine(cfg, cap, 0) as eng:
+        for t in range(ticks):
+            gcs = np.fmod(gcs + 2.0, 240.0)
+            plan = (gcs <= 150).astype(np.uint8); ff = rng.uniform(0, 80, (n, 4)); foot = rng.normal(0, 0.2, (n, 12)); z = np.full(n, 0.3)
+            out = eng.contact_terrain(gcs, plan, ff, foot, z, pitch_g); pitch_g = out["root_euler_d_pitch"]
+            for b in range(n):
+                ct, rec, ang, pitch_o[b] = oracle.contact_terrain_step(states[b], gcs[b], plan[b], ff[b], foot[b], z[b], pitch_o[b])
+                assert (out["contacts"][b] == ct).all() and (out["foot_pos_recent_contact"][b] == rec).all(), (t, b)
+                assert abs(out["terrain_angle"][b] - ang) <= 1e-13 and abs(pitch_g[b] - pitch_o[b]) <= 1e-13, (t, b)
+
+
 def test_swing_legs_N4a_sequence(pkg, oracle, scen):
     """swing-leg Bezier targets + foot PD force over 60 ticks for 500 robots (S/A1RobotControl.cpp:204-254).  The carried
     state and foot_pos_cur are bit-exact; the curve uses products for the integer powers (std::pow in the reference): a few ulp."""
