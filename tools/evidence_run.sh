@@ -24,5 +24,6 @@ timeout 200 python tools/stage_probe.py > $O/stage_probe.json 2>/dev/null
 timeout 200 python tools/elementwise_probe.py > $O/elementwise_probe.log 2>&1
 ( cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; timeout 200 rocprofv3 --kernel-trace --stats -d $O/elementwise_trace --output-format csv -- python tools/elementwise_probe.py > /dev/null 2>&1 )
 ( python tests/tools/soak_parity.py 9000 48 10; python tests/tools/soak_parity.py 9100 12 16; python tests/tools/soak_parity.py 9200 12 20 ) 2>&1 | grep -v amdgpu.ids > $O/parity_soak.txt
+python tests/tools/soak_settings.py 100 200 256 2>&1 | grep -v amdgpu.ids > $O/settings_soak.txt
 [ -x tools/ubench/n2b_bench ] && ( for b in n2b_bench n2b_bench_nofit; do [ -x tools/ubench/$b ] && for n in 65536 524288; do echo $b; timeout 100 tools/ubench/$b $n 72; done; done ) > $O/n2b_bench.txt 2>&1
 tail -c 400 $O/bench_default.json; echo; cat $O/latency_10000.json; tail -3 $O/collect.log
