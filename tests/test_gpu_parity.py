@@ -262,6 +262,26 @@ def test_non_default_osqp_settings(pkg, oracle, scen, over):
     compare(out, ref, min_same=1.0)
 
 
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_random_setting_combinations(pkg, oracle, scen, seed):
+    """several knobs away from their defaults at once (the draws of tests/tools/soak_settings.py, seeds 100-111: OSQP settings x friction / force limits x horizon),
+    64 QPs each: same iteration count and status on every QP, forces within the bar.  (The soak's 660 combinations are in profiles/r03_settings_soak*.txt; the handful
+    that exceed the bar are combinations on which the oracle's own two linear-system back ends part by more, profiles/r03_settings_soaks_second_round.txt.)"""
+    rng = np.random.default_rng(seed)
+    H = int(rng.choice([10, 10, 16, 20]))
+    over = dict(scaling=int(rng.choice([0, 2, 10, 10, 15])), alpha=float(rng.choice([1.0, 1.6, 1.6, rng.uniform(1.05, 1.9)])), rho=float(10 ** rng.uniform(-2, 0.3)),
+                sigma=float(10 ** rng.uniform(-7, -4)), check_termination=int(rng.choice([5, 10, 25, 25, 40])), adaptive_rho=int(rng.choice([0, 1, 1, 1])),
+                adaptive_rho_interval=int(rng.choice([0, 10, 25, 35, 50, 100])), adaptive_rho_tolerance=float(rng.choice([1.5, 2.0, 5.0, 5.0])),
+                eps_abs=float(rng.choice([1e-3, 1e-3, 1e-4, 1e-5])), max_iter=int(rng.choice([60, 400, 4000, 4000])))
+    over["eps_rel"] = over["eps_abs"]
+    gen = {10: scen.config3_random_flat, 16: scen.config4_random_h16, 20: scen.config5_divergent}[H]
+    sc = gen(nb=64, seed=7000 + seed)
+    sc["params"] = dict(sc["params"], mu=float(rng.choice([0.3, 0.3, 0.6, 0.15])), fz_min=float(rng.choice([0.0, 0.0, 0.0, 5.0])), fz_max=float(rng.choice([180.0, 180.0, 120.0, 60.0])))
+    with _engine(pkg, sc, 64, warm_start=0, **over) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+    compare(out, oracle_batch(oracle, sc, settings=oracle.default_settings(**over)), min_same=1.0)
+
+
 @pytest.mark.parametrize("mu,fz_min,fz_max", [(0.6, 0.0, 120.0), (0.3, 5.0, 180.0), (0.15, 0.0, 60.0)])
 def test_other_friction_and_force_limits(pkg, oracle, scen, mu, fz_min, fz_max):
     """fz_min > 0 excludes u = 0 from the box: OSQP's first iteration (z0 = 0 not projected) needs the dedicated code path"""
