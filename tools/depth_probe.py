@@ -14,7 +14,7 @@ cfg = pkg.make_config(scs[0]["params"], h, warm_start=0)
 ds = [{k: torch.from_numpy(s[k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")} for s in scs]
 with pkg.Engine(cfg, n, 0) as eng:
     ref = [eng.solve(s["x0"], s["xref"], s["R"], s["foot"], s["contact"]) for s in scs]
-res = {"early_setup_env": os.environ.get("A1MPC_PIPELINE_EARLY_SETUP", "")}
+res = {}
 for variant in ("free_running", "one_event_start"):
     for E in (2, 3, 4):
         pipe = pkg.Pipeline(cfg, n, 0, depth=E)
