@@ -34,16 +34,17 @@ def source_hash():
 
 
 def library_hash():
-    """the source hash the existing library was compiled from, or None (missing library / a build from before the hash existed)"""
-    import ctypes
+    """the source hash the existing library was compiled from, or None (missing library / a build from before the hash existed).
+    Read from the file's bytes (the string a1mpc_build_info() returns), NOT by loading the library: glibc matches loaded libraries by name, so a
+    CDLL here would pin the old mapping and a later CDLL of the rebuilt file at the same path would silently return the pre-build code."""
+    import re
     if not os.path.exists(LIB_PATH):
         return None
     try:
-        lib = ctypes.CDLL(LIB_PATH)
-        lib.a1mpc_build_info.restype = ctypes.c_char_p
-        info = lib.a1mpc_build_info().decode()
-        return info.split("sources ")[1].split()[0]
-    except Exception:
+        with open(LIB_PATH, "rb") as f:
+            m = re.search(rb"sources ([0-9a-f]{16}) arch " + ARCH.encode(), f.read())
+        return m.group(1).decode() if m else None
+    except OSError:
         return None
 
 

@@ -131,6 +131,22 @@ __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, cons
     }
 }
 
+// K2, CU-wide (round 4): ONE workgroup of four wavefronts owns a CU's whole LDS.  At H = 16 an image is 32.2 KB: five fit in 160 KB, but an ADMM wave needs a
+// whole SIMD's register file, so with one-wave workgroups of one QP each the fifth image has no wave to serve it and rows 1 and 3 of every wave idle.  Here
+// wave 0 carries TWO QPs (main / twin pairs on rows (0,2) and (1,3), exactly the H = 10 arrangement) and waves 1-3 one each: five QPs per CU instead of four.
+// Rows still refill from the queue independently and nothing is shared between the waves (no workgroup barrier anywhere in admm_rows): the only coupling is
+// that wave 0's two QPs wait for each other's factor passes, as every pair of H = 10 does.
+constexpr int cu_wide_qps(int h) { return h == 16 ? 5 : 0; }   // QPs of a CU-wide workgroup (0: this horizon has no such kernel -- H = 20: 40 KB per image, four per CU)
+template <int H, bool UPD = false, bool UNI = false>
+__global__ __launch_bounds__(256) void a1mpc_admm_cu_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
+    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
+    static_assert(cu_wide_qps(H) == 5 && admm_twin_rows(H, 1), "five images: two on wave 0, one on each of waves 1-3");
+    const int wave = static_cast<int>(threadIdx.x) >> 6, row = (static_cast<int>(threadIdx.x) >> 4) & 3;
+    if (wave != 0 && (row & 1)) return;  // waves 1-3: rows 1 and 3 have no QP
+    const int image = wave == 0 ? (row & 1) : wave + 1;
+    admm_rows<H, true, false, UPD, UNI>(a, prep, counter, a1mpc_lds + image * Layout<H>::ROW_STRIDE);
+}
+
 // The general path's own split pipeline (round 2, last step): the same two kernels over RowSolver<.., GEN = true>.  K1 holds the per-step tables B~w_t and
 // T B~w_t of four QPs (8.5 KB each at H = 10); its record carries B~w_t to K2, whose rows rebuild the per-step tables of their LDS image from it.
 template <int H>
@@ -398,6 +414,29 @@ static a1mpc_status resident_workgroups(int* out) {
     *out = resident[dev];
     return A1MPC_OK;
 }
+// the CU-wide ADMM kernel (a1mpc_admm_cu_kernel; H = 16): one workgroup of 256 threads and five images per CU.  A1MPC_CU_WIDE=0 falls back to the one-wave kernels (A/B runs)
+static bool cu_wide_enabled() {
+    static const bool on = [] { const char* e = getenv("A1MPC_CU_WIDE"); return !(e && !strcmp(e, "0")); }();
+    return on;
+}
+template <int H>
+static a1mpc_status resident_cu_workgroups(int* out) {
+    static int resident[64] = {};
+    int dev = 0;
+    A1_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { *out = 256; return A1MPC_OK; }
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    if (!resident[dev]) {
+        const size_t lds2 = lds_bytes<H>(cu_wide_qps(H));
+        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2)));
+        int per_cu = 0, cus = 0;
+        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H>), 256, lds2));
+        A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        resident[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    }
+    *out = resident[dev];
+    return A1MPC_OK;
+}
 template <int H>
 static a1mpc_status resident_rows(int* out) {
     int wg = 0;
@@ -440,6 +479,27 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
         A1_HIP(hipGetLastError());
     }
     if (mid) A1_HIP(hipEventRecord(mid, stream));  // stage split: formation + Ruiz (+ queue order) | factor + iterate
+    if constexpr (cu_wide_qps(H) > 0 && ROWS == default_rows_per_wg(H)) {
+        if (cu_wide_enabled()) {   // five QPs per CU: one 256-thread workgroup per CU (a1mpc_admm_cu_kernel)
+            constexpr int Q = cu_wide_qps(H);
+            const size_t ldsq = lds_bytes<H>(Q);
+            int resq = 0;
+            if (a1mpc_status st = resident_cu_workgroups<H>(&resq); st != A1MPC_OK) return st;
+            const int wantq = (a.n + Q - 1) / Q;
+            const dim3 gridq(static_cast<unsigned>(wantq < resq ? wantq : resq)), blockq(256);
+            if (a.carry != nullptr) {
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, true>), ldsq); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
+            } else if (a.contact_stride == 0) {
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, true>), ldsq); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
+            } else {
+                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
+            }
+            A1_HIP(hipGetLastError());
+            return A1MPC_OK;
+        }
+    }
     const int want = (a.n + ROWS - 1) / ROWS;
     const dim3 grid(static_cast<unsigned>(want < res ? want : res)), block(admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS);
     if constexpr (kHasUpd) {

@@ -159,7 +159,7 @@ def dpp_hazards(path, key=""):
 # The check must not fail OPEN: if a change of listing format, name mangling or block labels made _parse() find nothing, dpp_hazards() would
 # return [] and every build would pass.  build() therefore also demands that the kernels made of inline-asm DPP chains were found and that a
 # plausible number of v_fmac_f64_dpp instructions was inspected in each.
-EXPECTED_DPP = {"a1mpc_admm_kernelILi10E": 1500, "a1mpc_admm_kernelILi16E": 2500, "a1mpc_admm_kernelILi20E": 3000, "a1mpc_setup_kernelILi10E": 60,
+EXPECTED_DPP = {"a1mpc_admm_kernelILi10E": 1500, "a1mpc_admm_kernelILi16E": 2500, "a1mpc_admm_kernelILi20E": 3000, "a1mpc_admm_cu_kernelILi16E": 2500, "a1mpc_setup_kernelILi10E": 60,
                 "a1mpc_solve_kernelILi10E": 1500, "a1mpc_solve_coop_kernelILi10E": 1500, "a1mpc_solve_gen_kernelILi10E": 1500}
 
 
