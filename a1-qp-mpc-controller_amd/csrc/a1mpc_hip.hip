@@ -380,6 +380,33 @@ static int pipeline_mode() {  // 0 = auto, 1 = always split, 2 = always fused
     return m;
 }
 
+// Profiler ranges (the reference brackets its tick with stopwatches t1..t6, S/A1RobotControl.cpp:491-553).  With A1MPC_ROCTX=1 the launches of a solve are
+// bracketed by roctx ranges ("a1mpc set-up", "a1mpc order", "a1mpc admm", "a1mpc solve (fused)"; rocprofv3 --marker-trace shows them beside the kernel trace).
+// The roctx library is dlopen()ed on first use, never linked; without the variable, or without the library, a range is a no-op.
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi() {
+        const char* e = getenv("A1MPC_ROCTX");
+        if (!(e && !strcmp(e, "1"))) return;
+        void* lib = nullptr;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+        if (!lib) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+static const RoctxApi& roctx() { static const RoctxApi api; return api; }
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~RoctxRange() { if (on) roctx().pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 // per-device caches below (occupancy, attribute-set flags) are shared by every handle of the process: handles of different threads are independent (a1mpc.h), so they are guarded
 static std::mutex g_cache_mu;
 // dynamic-LDS limit of a kernel, once per device and kernel
@@ -466,19 +493,24 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     bool upd_kernels = false;   // warm_start = 2: the update-path instantiations of the two kernels (H > 1, default rows per workgroup; same resources, a few more instructions around set-up and iteration 1)
     constexpr bool kHasUpd = H > 1 && ROWS == default_rows_per_wg(H);
     if constexpr (kHasUpd) upd_kernels = a.carry != nullptr;
-    if constexpr (kHasUpd) { if (upd_kernels) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1, true>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep); }
-    if (!upd_kernels) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
+    {
+        RoctxRange range("a1mpc set-up");
+        if constexpr (kHasUpd) { if (upd_kernels) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1, true>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep); }
+        if (!upd_kernels) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
+    }
     A1_HIP(hipGetLastError());
     // queue order of THIS solve, longest first: by the set-up kernel's cost guesses (predict: no history) or by the cost each QP had in the handle's previous
     // solve of this batch size (the cost buffer still holds it; the ADMM kernel below overwrites it with this solve's).  Sorted here, in front of the kernel
     // that needs it, not behind the solve that produced the costs: a one-workgroup kernel of 1024 threads behind a persistent kernel waits for a free CU, and
     // with a second batch in flight on another stream (a1mpc_pipeline) that wait was ~0.5 ms per launch (kernel trace, profiles/r02_kernel_trace_overlap.json)
     if (a.cost != nullptr && a.order != nullptr) {
+        RoctxRange range("a1mpc order");
         hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, static_cast<int>(a.n), static_cast<const int32_t*>(a.cost),
                            const_cast<int32_t*>(a.order));
         A1_HIP(hipGetLastError());
     }
     if (mid) A1_HIP(hipEventRecord(mid, stream));  // stage split: formation + Ruiz (+ queue order) | factor + iterate
+    RoctxRange range_admm("a1mpc admm");
     if constexpr (cu_wide_qps(H) > 0 && ROWS == default_rows_per_wg(H)) {
         if (cu_wide_enabled()) {   // five QPs per CU: one 256-thread workgroup per CU (a1mpc_admm_cu_kernel)
             constexpr int Q = cu_wide_qps(H);
@@ -732,6 +764,16 @@ static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
     return launch_rows<H, MODE, default_rows_per_wg(H)>(a, stream);
 }
 
+static bool warm_fused_enabled() {
+    static const bool on = [] { const char* e = getenv("A1MPC_WARM_FUSED"); return !(e && !strcmp(e, "0")); }();
+    return on;
+}
+// largest warm-started batch that runs the fused kernel (see solve_device_impl): measured crossovers, in QPs
+static int warm_fused_max(int horizon) {
+    static const int over = [] { const char* e = getenv("A1MPC_WARM_FUSED_MAX"); return e ? atoi(e) : 0; }();
+    if (over > 0) return over;
+    return horizon == 10 ? 8192 : 0;
+}
 static constexpr int kScheduleMinBatch = 1024;  // below this every QP is resident at once and the order cannot matter
 
 // does a batch of n QPs go through the split pipeline?
@@ -757,6 +799,7 @@ static a1mpc_status use_split_pipeline(int horizon, int n, bool have_prep, bool*
 }
 
 static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s, bool split, hipEvent_t mid) {
+    RoctxRange range(split ? "a1mpc solve (split pipeline)" : "a1mpc solve (fused)");
     if (split && prep && counter) {
         switch (horizon) {
 #ifdef A1MPC_DEV_SLIM
@@ -852,6 +895,7 @@ struct a1mpc_handle_s {
     double *d_aux_in = nullptr, *d_aux_out = nullptr;
     uint8_t* d_aux_u8 = nullptr;
     int32_t hint_n = 0;  // batch size the order was built for (0 = none)
+    int32_t last_ws_mode = -1;  // warm-start semantics the last MPC solve ran (a1mpc_last_warm_start_mode): the configured mode, or 1 where mode 2 does not exist
     int schedule = 1;    // 1 = history (default), 0 = index order
     // packed device blocks + pinned host mirrors of the host-pointer MPC entry (one copy each way per call)
     char *d_in = nullptr, *d_out = nullptr;
@@ -2038,6 +2082,76 @@ a1mpc_status a1mpc_get_warm_start(a1mpc_handle h, int32_t n, double* x_out, doub
     return A1MPC_OK;
 }
 
+a1mpc_status a1mpc_last_warm_start_mode(a1mpc_handle h, int32_t* mode_out) {
+    if (!h || !mode_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle / output");
+    *mode_out = h->last_ws_mode;
+    return A1MPC_OK;
+}
+
+// one Carry<H> record -> 20H rows: lane (leg, comp) holds rows r0 (Z0) and, for fx / fy, r1 (Z1) of its leg's block
+static void unpack_carry_z(int H, const double* rec, double* z) {
+    const int Z0 = 1 + 48 * H, Z1 = 1 + 60 * H;
+    static_assert(Carry<10>::Z0 == 1 + 48 * 10 && Carry<10>::Z1 == 1 + 60 * 10 && Carry<20>::Z0 == 1 + 48 * 20 && Carry<20>::Z1 == 1 + 60 * 20, "Carry<H> layout");
+    for (int t = 0; t < H; ++t)
+        for (int ci = 0; ci < 12; ++ci) {
+            const int leg = ci / 3, comp = ci % 3;
+            const int r0 = comp == 0 ? 0 : (comp == 1 ? 2 : 4), r1 = comp == 0 ? 1 : 3;
+            z[t * 20 + 5 * leg + r0] = rec[Z0 + t * 12 + ci];
+            if (comp < 2) z[t * 20 + 5 * leg + r1] = rec[Z1 + t * 12 + ci];
+        }
+}
+a1mpc_status a1mpc_get_workspace_z(a1mpc_handle h, int32_t n, double* z_out) {
+    if (!h || !z_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle / output");
+    if (n < 0 || n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    const size_t cs = carry_stride(h->cfg.horizon);
+    if (h->cfg.warm_start != 2 || cs == 0 || !h->d_carry) return fail(A1MPC_ERR_INVALID_ARGUMENT, "no update-path carry (warm_start = 2, horizon > 1, after the first tick)");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    A1_ORDER(h, h->stream);
+    std::vector<double> rec(static_cast<size_t>(n) * cs);
+    A1_HIP(hipMemcpyAsync(rec.data(), h->d_carry, rec.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    A1_HIP(hipStreamSynchronize(h->stream));
+    const size_t H = h->cfg.horizon;
+    for (int b = 0; b < n; ++b) {
+        const double* r = rec.data() + static_cast<size_t>(b) * cs;
+        double* z = z_out + static_cast<size_t>(b) * 20 * H;
+        unpack_carry_z(h->cfg.horizon, r, z);
+    }
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_get_workspace_scaling(a1mpc_handle h, int32_t n, double* D_out, double* E_out, double* c_out) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    const size_t cs = carry_stride(h->cfg.horizon);
+    if (h->cfg.warm_start != 2 || cs == 0 || !h->d_carry) return fail(A1MPC_ERR_INVALID_ARGUMENT, "no update-path carry (warm_start = 2, horizon > 1, after the first tick)");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    A1_ORDER(h, h->stream);
+    std::vector<double> rec(static_cast<size_t>(n) * cs);
+    A1_HIP(hipMemcpyAsync(rec.data(), h->d_carry, rec.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    A1_HIP(hipStreamSynchronize(h->stream));
+    const int H = h->cfg.horizon;
+    const int oD = 1, oE0 = 1 + 12 * H, oE1 = 1 + 24 * H;   // Carry<H>::D, E0, E1
+    static_assert(Carry<10>::D == 1 && Carry<10>::E0 == 1 + 120 && Carry<10>::E1 == 1 + 240 && Carry<16>::E1 == 1 + 24 * 16, "Carry<H> layout");
+    for (int b = 0; b < n; ++b) {
+        const double* r = rec.data() + static_cast<size_t>(b) * cs;
+        if (c_out) c_out[b] = r[0];
+        for (int t = 0; t < H; ++t)
+            for (int ci = 0; ci < 12; ++ci) {
+                const int leg = ci / 3, comp = ci % 3;
+                const int r0 = comp == 0 ? 0 : (comp == 1 ? 2 : 4), r1 = comp == 0 ? 1 : 3;
+                if (D_out) D_out[(static_cast<size_t>(b) * H + t) * 12 + ci] = r[oD + t * 12 + ci];
+                if (E_out) {
+                    double* e = E_out + (static_cast<size_t>(b) * H + t) * 20 + 5 * leg;
+                    e[r0] = r[oE0 + t * 12 + ci];
+                    if (comp < 2) e[r1] = r[oE1 + t * 12 + ci];
+                }
+            }
+    }
+    return A1MPC_OK;
+}
+
 a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h) {
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
     A1_HIP(hipSetDevice(h->device));
@@ -2085,6 +2199,7 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
         }
         a.carry = h->d_carry;
     }
+    h->last_ws_mode = (h->cfg.warm_start == 2 && (a.carry == nullptr || foot_stride != 0 || d_yaw_A != nullptr)) ? 1 : h->cfg.warm_start;
     a.contact_stride = contact_stride;  // a per-step contact schedule alone (feet step-invariant) stays on the fast path: contacts only change bounds and equality rows
     if (foot_stride != 0 || d_yaw_A != nullptr) {  // general path: per-step B_d (and / or its own A_c yaw), with or without a contact schedule
         if (d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "per-step feet / contacts are not combined with tick records");
@@ -2126,6 +2241,11 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     // (RowSolver::predict_cost).  Scheduling only.
     bool split = false;
     if (a1mpc_status st0 = use_split_pipeline(h->cfg.horizon, n, h->d_prep != nullptr, &split); st0 != A1MPC_OK) return st0;
+    // Warm-started ticks of the same robots (the closed-loop regime: second and later ticks of a batch size) take ~25 iterations each, all alike: nothing is left
+    // for the queue to balance, and the fused kernel -- set-up and solve in one launch, no hand-off through memory, no kernel boundary for the rows to idle at --
+    // wins up to a few rounds of the resident rows (4096 x h10: 0.397 -> 0.350 ms per tick, 8192: 0.665 -> 0.652; profiles/r04_warm_ticks_fused_vs_split.txt).
+    // Same results bit for bit (the pipelines are tested against each other).  A1MPC_WARM_FUSED=0 keeps the split pipeline (A/B runs).
+    if (split && h->cfg.warm_start != 0 && h->hint_n == n && pipeline_mode() == 0 && warm_fused_enabled() && n <= warm_fused_max(h->cfg.horizon)) split = false;
     const bool hints = h->schedule && split && n >= kScheduleMinBatch;
     a.order = hints ? h->d_order : nullptr;
     a.cost = hints ? h->d_cost : nullptr;
@@ -2476,6 +2596,7 @@ struct RcclApi {
     void* lib = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -2487,9 +2608,9 @@ struct RcclApi {
         if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!lib) return false;
 #define A1_SYM(n) n = reinterpret_cast<decltype(n)>(dlsym(lib, "nccl" #n))
-        A1_SYM(CommInitAll); A1_SYM(CommDestroy); A1_SYM(GroupStart); A1_SYM(GroupEnd); A1_SYM(Send); A1_SYM(Recv); A1_SYM(GetErrorString);
+        A1_SYM(CommInitAll); A1_SYM(CommDestroy); A1_SYM(CommAbort); A1_SYM(GroupStart); A1_SYM(GroupEnd); A1_SYM(Send); A1_SYM(Recv); A1_SYM(GetErrorString);
 #undef A1_SYM
-        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+        return CommInitAll && CommDestroy && CommAbort && GroupStart && GroupEnd && Send && Recv && GetErrorString;
     }
 };
 static RcclApi g_rccl;
@@ -2506,6 +2627,7 @@ struct a1mpc_sharded_s {
     int32_t *r_iters = nullptr, *r_status = nullptr;
     std::vector<ncclComm_t> comm;
     std::vector<hipEvent_t> ev;             // per shard: "my part of this call is finished"
+    bool broken = false;                    // an error inside an open RCCL group: the communicators were aborted, the handle only accepts a1mpc_sharded_destroy
 };
 static void shard_range(int n, int g, int G, int* start, int* count) {
     const int base = n / G, rem = n % G;
@@ -2583,6 +2705,7 @@ a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double*
     if (!S) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !grf_body_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
     if (n > S->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_sharded_create");
+    if (S->broken) return fail(A1MPC_ERR_HIP, "an earlier call failed inside an RCCL group and the communicators were aborted: destroy this handle and create a new one");
     if (n == 0) return A1MPC_OK;
     const size_t N = n, H = S->horizon, G = S->ndev;
     // pinned snapshot (the caller's program mutates its arrays concurrently, see a1mpc.h), field after field like the device layout
@@ -2601,7 +2724,15 @@ a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double*
     // target the shared pinned mirror, which the next call overwrites) before the status goes back to the caller.
     bool group_open = false;
     auto drain = [&]() {
-        if (group_open && g_rccl.GroupEnd) { (void)g_rccl.GroupEnd(); group_open = false; }
+        if (group_open && g_rccl.GroupEnd) {
+            // A failure between paired ncclSend / ncclRecv calls leaves point-to-point operations without their partner: GroupEnd submits them and a stream
+            // synchronise would then wait for ever.  Close the group, ABORT every communicator -- that terminates the operations in flight -- and only
+            // then drain the streams; the handle is unusable afterwards (a1mpc_sharded_solve_batch refuses, a1mpc_sharded_destroy frees it).
+            (void)g_rccl.GroupEnd(); group_open = false;
+            for (size_t g = 0; g < S->comm.size(); ++g)
+                if (S->comm[g]) { if (hipSetDevice(S->dev[g]) == hipSuccess) (void)g_rccl.CommAbort(S->comm[g]); S->comm[g] = nullptr; }
+            S->broken = true;
+        }
         for (size_t g = 0; g < G; ++g) { if (hipSetDevice(S->h[g]->device) == hipSuccess) (void)hipStreamSynchronize(S->h[g]->stream); }
     };
 #define A1_SH_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { drain(); return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
@@ -2737,6 +2868,7 @@ static a1mpc_status pipeline_deliver(a1mpc_pipeline p, int k) {
 void a1mpc_pipeline_destroy(a1mpc_pipeline p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
+    for (int k = 0; k < static_cast<int>(p->pending.size()); ++k) (void)pipeline_deliver(p, k);   // batches still in flight reach their callers' arrays before the slots go
     for (hipEvent_t e : p->ready) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->done) if (e) (void)hipEventDestroy(e);
     for (a1mpc_handle h : p->h) a1mpc_destroy(h);
@@ -2776,6 +2908,10 @@ a1mpc_status a1mpc_pipeline_depth(a1mpc_pipeline p, int32_t* depth_out) {
 
 a1mpc_status a1mpc_pipeline_handle(a1mpc_pipeline p, int32_t slot, a1mpc_handle* out) {
     if (!p || !out || slot < 0 || slot >= p->depth) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null pipeline/out or slot out of range");
+    // A host-pointer batch still in flight on this slot keeps its results in the handle's ONE pinned mirror: any host-pointer call the caller makes on the handle
+    // would overwrite them.  Hand the batch to its caller's arrays first -- the handle that leaves here carries nothing pending.
+    A1_HIP(hipSetDevice(p->device));
+    if (a1mpc_status sd = pipeline_deliver(p, slot); sd != A1MPC_OK) return sd;
     *out = p->h[slot];
     return A1MPC_OK;
 }

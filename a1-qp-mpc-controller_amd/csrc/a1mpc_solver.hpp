@@ -279,15 +279,20 @@ struct Carry {
 
 // prepared state handed from the set-up kernel to the ADMM kernel: [field][12 active lanes] doubles per QP (pad lanes hold nothing).
 // XH (the warm-start x) comes last and is only written / read when the solve is warm-started.
+// Round 4: rr1 = E1^2 rho is not stored.  On the fx / fy lanes the Ruiz passes update E0 and E1 by the same operations on the same operands (the rows
+// [f + mu fz] and [f - mu fz] have the same absolute entries: RowSolver::setup, ruiz_step), so E1 == E0 bit for bit, those lanes' first row is never an equality
+// (eq: fz lanes only), hence rr1 == rr0 there; fz and pad lanes have no second row (E1 = 0: rr1 = 0).  The contact bits, the equality bits and the flags share
+// one word (PK = cmask + 2^20 eqmask + 2^40 flags: integers below 2^43, exact in a double).  54 -> 41 fields at H = 10.
 template <int H>
 struct Prep {
-    static constexpr int RR0 = 0, RR1 = H, DI2 = 2 * H, CG = 3 * H, BT = 4 * H;  // per-lane fields
-    static constexpr int CSC = BT + 6, CY = CSC + 1, SY = CY + 1, RHO = SY + 1, CM = RHO + 1, HI = CM + 1, EQ = HI + 1, FLAGS = EQ + 1;  // CM: contact bit of my leg per step (HI: spare)
-    static constexpr int XH = FLAGS + 1;
+    static_assert(H <= 20, "PK packs one bit per horizon step into 20-bit fields");
+    static constexpr int RR0 = 0, DI2 = H, CG = 2 * H, BT = 3 * H;  // per-lane fields
+    static constexpr int CSC = BT + 6, CY = CSC + 1, SY = CY + 1, RHO = SY + 1, PK = RHO + 1;
+    static constexpr int XH = PK + 1;
     // update path only (FLAGS bit 2; H > 1): the first iteration's y-hat of my two rows and its c g - A'[(2 - alpha) rr delta] (RowSolver::setup, "update path")
     static constexpr int YW0 = XH + H, YW1 = YW0 + H, CGE = YW1 + H;
     static constexpr int FIELDS = XH + H + (H > 1 ? 3 * H : 0);
-    static constexpr int STRIDE = FIELDS * 12;  // doubles per QP: 5.2 KB cold / 6.1 KB warm at H = 10
+    static constexpr int STRIDE = FIELDS * 12;  // doubles per QP: 3.9 KB cold / 4.9 KB warm at H = 10 are written (round 3: 5.2 / 6.1)
     // general path, split pipeline: + my column of the omega rows of B~_t for every step, [t][3] (the record of a QP is then STRIDE_GEN doubles)
     static constexpr int BWF = FIELDS;
     static constexpr int STRIDE_GEN = (FIELDS + 3 * H) * 12;
@@ -980,8 +985,7 @@ struct RowSolver {
         if (!act) return;
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
-            p[(PR::RR0 + t) * 12 + ci] = rr0[t];
-            p[(PR::RR1 + t) * 12 + ci] = rr1[t];
+            p[(PR::RR0 + t) * 12 + ci] = rr0[t];   // (rr1: rr0 again on the fx / fy lanes, zero elsewhere -- see Prep)
             p[(PR::DI2 + t) * 12 + ci] = dI2[t];
             p[(PR::CG + t) * 12 + ci] = lds[L::CG + t * 12 + ci];
             if (warm) p[(PR::XH + t) * 12 + ci] = xh[t];
@@ -995,10 +999,9 @@ struct RowSolver {
 #pragma unroll
         for (int k = 0; k < 6; ++k) p[(PR::BT + k) * 12 + ci] = Bt[k];
         p[PR::CSC * 12 + ci] = csc; p[PR::CY * 12 + ci] = cy; p[PR::SY * 12 + ci] = sy; p[PR::RHO * 12 + ci] = rho;
-        p[PR::CM * 12 + ci] = static_cast<double>(cmask); p[PR::HI * 12 + ci] = 0.0;
-        p[PR::EQ * 12 + ci] = static_cast<double>(eqmask);
-        if constexpr (UPD) p[PR::FLAGS * 12 + ci] = (warm ? 1.0 : 0.0) + (first_special ? 2.0 : 0.0) + (upd ? 4.0 : 0.0);
-        else p[PR::FLAGS * 12 + ci] = (warm ? 1.0 : 0.0) + (first_special ? 2.0 : 0.0);
+        unsigned fl = (warm ? 1u : 0u) + (first_special ? 2u : 0u);
+        if constexpr (UPD) fl += upd ? 4u : 0u;
+        p[PR::PK * 12 + ci] = static_cast<double>(static_cast<unsigned long long>(cmask) | static_cast<unsigned long long>(eqmask) << 20 | static_cast<unsigned long long>(fl) << 40);
         if constexpr (GEN && SETUP_ONLY) {  // the general path's own set-up kernel: the per-step omega rows of B~_t travel with the record
             static_for<H>([&](auto T) {
 #pragma unroll
@@ -1014,7 +1017,9 @@ struct RowSolver {
     A1_DEV void load_prepared(const double* __restrict__ p, const ProblemIO& io, [[maybe_unused]] bool tables = false) {
         sync();  // the previous QP's LDS image is dead
         const double am = act ? 1.0 : 0.0;  // pad lanes read lane 0's record (ci == 0) and zero what must be zero
-        const int fl = static_cast<int>(p[PR::FLAGS * 12 + ci]);
+        const unsigned long long pk = static_cast<unsigned long long>(p[PR::PK * 12 + ci]);
+        const int fl = static_cast<int>(pk >> 40);
+        const bool two = act && comp < 2;   // lanes with a second constraint row
         warm = fl & 1; first_special = (fl & 2) != 0;
         [[maybe_unused]] const bool upd_ = UPD && (fl & 4) != 0;
         [[maybe_unused]] double cgk[HS];  // update path: the true c g of my steps, parked in the pad column of K_t until the first iteration is done
@@ -1023,7 +1028,7 @@ struct RowSolver {
             static_for<HS>([&](auto K) {
                 constexpr int k = A1_CV(K);
                 rr0[k] = am * p[(PR::RR0 + 2 * k) * 12 + ci + to];
-                rr1[k] = am * p[(PR::RR1 + 2 * k) * 12 + ci + to];
+                rr1[k] = two ? p[(PR::RR0 + 2 * k) * 12 + ci + to] : 0.0;
                 dI2[k] = p[(PR::DI2 + 2 * k) * 12 + ci + to];
                 xh[k] = warm ? am * p[(PR::XH + 2 * k) * 12 + ci + to] : 0.0;
                 const int t = 2 * k + tw;
@@ -1044,7 +1049,7 @@ struct RowSolver {
             static_for<H>([&](auto T) {
                 constexpr int t = A1_CV(T);
                 rr0[t] = am * p[(PR::RR0 + t) * 12 + ci];
-                rr1[t] = am * p[(PR::RR1 + t) * 12 + ci];
+                rr1[t] = two ? p[(PR::RR0 + t) * 12 + ci] : 0.0;
                 dI2[t] = p[(PR::DI2 + t) * 12 + ci];
                 xh[t] = warm ? am * p[(PR::XH + t) * 12 + ci] : 0.0;
                 park_warm_y(io, t);
@@ -1069,12 +1074,12 @@ struct RowSolver {
         csc = p[PR::CSC * 12 + ci]; cinv = 1.0 / csc; qd = csc * q2s;
         set_rotation(p[PR::CY * 12 + ci], p[PR::SY * 12 + ci]);
         rho = p[PR::RHO * 12 + ci];
-        cmask = act ? static_cast<unsigned>(p[PR::CM * 12 + ci]) : 0u;
+        cmask = act ? static_cast<unsigned>(pk & 0xfffffu) : 0u;
 #pragma unroll
         for (int k = 0; k < HS; ++k) { if constexpr (!GEN) slot_bounds(k, TWIN ? 2 * k + tw : k); }
         lo_u = P.fz_min * (cmask & 1u ? 1.0 : 0.0); hi_u = P.fz_max * (cmask & 1u ? 1.0 : 0.0);
         lb0 = comp == 2 ? lo_u : 0.0; ub0 = comp == 2 ? hi_u : kInfty;
-        eqmask = act ? static_cast<unsigned>(p[PR::EQ * 12 + ci]) : 0u;
+        eqmask = act ? static_cast<unsigned>((pk >> 20) & 0xfffffu) : 0u;
         if constexpr (GEN) {
             if (tables && wr) {
                 static_for<H>([&](auto T) {
@@ -1745,6 +1750,13 @@ struct RowSolver {
                 admm_iteration<true>(); iter = 1;
                 if constexpr (UPD && H > 1 && !GEN && !SETUP_ONLY && MODE == kModeMpc) restore_cg();  // (unconditional in the UPD instantiations: a flag would have to live across the ADMM loop)
             }
+#ifdef A1X_POISON  // test build (tests/test_emu_parity.py): the values nothing may depend on -- wh1 of the fz lanes (no second constraint row: any FINITE value), every
+                   // per-step register of the pad lanes (anything) -- are overwritten at every segment start; not one output bit may change
+            static_for<HS>([&](auto K) {
+                if (act && comp == 2) wh1[K] = (A1_CV(K) & 1) ? 1e300 : -1e300;
+                if (!act) { xh[K] = nan(""); wh0[K] = nan(""); wh1[K] = nan(""); }
+            });
+#endif
             // the rows of a wave share one instruction stream: if any of them carries G, all run that variant (a harmless extra for the others)
 #ifdef A1X_CLK
             const long long t0_ = clock64();
@@ -1814,7 +1826,7 @@ struct RowSolver {
         double nf = 0.0;
 #pragma unroll
         for (int t = 0; t < HS; ++t) nf = (xh[t] - xh[t] == 0.0) ? nf : 1.0;
-        const int32_t status_out = pair_allmax(nf) > 0.0 ? A1MPC_NON_CVX : status;
+        const int32_t status_out = pair_allmax(act ? nf : 0.0) > 0.0 ? A1MPC_NON_CVX : status;   // (pad lanes hold no force: what they carry is nobody's business)
         const bool nanout = status_out == A1MPC_NON_CVX;
         const double nanv = nan("");
         {

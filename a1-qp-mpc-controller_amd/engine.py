@@ -40,7 +40,7 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
     _fields_ = [("counter_per_swing", C.c_double), ("foot_force_low", C.c_double), ("use_terrain_adapt", C.c_int32)]
 
 
-EXPORTS = ["a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
+EXPORTS = ["a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_get_workspace_z", "a1mpc_get_workspace_scaling", "a1mpc_last_warm_start_mode", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error", "a1mpc_build_info", "a1mpc_pipeline_create", "a1mpc_pipeline_submit_device", "a1mpc_pipeline_submit",
@@ -114,6 +114,9 @@ def load_library(path=None):
     lib.a1mpc_update_config.argtypes = [vp, C.POINTER(Config)]; lib.a1mpc_update_config.restype = C.c_int
     lib.a1mpc_warm_start.argtypes = [vp, i32, dp, dp, dp]; lib.a1mpc_warm_start.restype = C.c_int
     lib.a1mpc_get_warm_start.argtypes = [vp, i32, dp, dp, dp]; lib.a1mpc_get_warm_start.restype = C.c_int
+    lib.a1mpc_get_workspace_z.argtypes = [vp, i32, dp]; lib.a1mpc_get_workspace_z.restype = C.c_int
+    lib.a1mpc_get_workspace_scaling.argtypes = [vp, i32, dp, dp, dp]; lib.a1mpc_get_workspace_scaling.restype = C.c_int
+    lib.a1mpc_last_warm_start_mode.argtypes = [vp, C.POINTER(C.c_int32)]; lib.a1mpc_last_warm_start_mode.restype = C.c_int
     lib.a1mpc_set_schedule.argtypes = [vp, i32]; lib.a1mpc_set_schedule.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
     lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int
@@ -256,6 +259,24 @@ class Engine:
         x = np.zeros((n, NU * h)); y = np.zeros((n, 20 * h)); rho = np.zeros(n)
         _check(self.lib, self.lib.a1mpc_get_warm_start(self._h, int(n), _dp(x), _dp(y), _dp(rho)), "a1mpc_get_warm_start")
         return x, y, rho
+
+    def last_warm_start_mode(self):
+        m = C.c_int32(-9)
+        _check(self.lib, self.lib.a1mpc_last_warm_start_mode(self._h, C.byref(m)), "a1mpc_last_warm_start_mode")
+        return int(m.value)
+
+    def get_workspace_scaling(self, n):
+        """warm_start = 2: (D (n, 12 h), E (n, 20 h), c (n)) of the last update-path tick (a1mpc_get_workspace_scaling)"""
+        h = self.horizon
+        D = np.zeros((n, NU * h)); E = np.zeros((n, 20 * h)); c = np.zeros(n)
+        _check(self.lib, self.lib.a1mpc_get_workspace_scaling(self._h, int(n), _dp(D), _dp(E), _dp(c)), "a1mpc_get_workspace_scaling")
+        return D, E, c
+
+    def get_workspace_z(self, n):
+        """warm_start = 2: the unscaled z the update path keeps beside (x, y, rho), (n, 20 h) in the reference's row order (a1mpc_get_workspace_z)"""
+        z = np.zeros((n, 20 * self.horizon))
+        _check(self.lib, self.lib.a1mpc_get_workspace_z(self._h, int(n), _dp(z)), "a1mpc_get_workspace_z")
+        return z
 
     # ---- N1: compact tick records (x0 / x_ref built on the device, S/A1RobotControl.cpp:452-488) ----
     def solve_ticks(self, tick, R, foot, contact, want_u=False):
@@ -430,8 +451,19 @@ class Pipeline:
         n = int(x0.shape[0])
         x0 = np.ascontiguousarray(x0, np.float64); xref = np.ascontiguousarray(xref, np.float64); R = np.ascontiguousarray(R, np.float64)
         foot = np.ascontiguousarray(foot, np.float64); contact = np.ascontiguousarray(contact, np.uint8)
+        # the C side memcpys n*12 (grf) / n*12*H (u) doubles and n int32 (iters, status) into these arrays LATER (wait / the next submit): a wrong dtype or a short
+        # array would be a deferred heap overflow, so dtype and total size are checked here, before the call
+        need = {"grf": (np.float64, n * NU), "u": (np.float64, n * NU * self.horizon), "iters": (np.int32, n), "status": (np.int32, n)}
         for k_, a_ in out.items():
-            assert a_.flags["C_CONTIGUOUS"] and a_.shape[0] >= n, k_
+            if a_ is None:
+                continue
+            if k_ not in need:
+                raise ValueError(f"unknown output array {k_!r}")
+            dt_, size_ = need[k_]
+            if not (isinstance(a_, np.ndarray) and a_.flags["C_CONTIGUOUS"] and a_.dtype == dt_ and a_.size >= size_):
+                raise ValueError(f"output array {k_!r} must be a C-contiguous numpy array of {np.dtype(dt_).name} with at least {size_} elements")
+        if out.get("grf") is None:
+            raise ValueError("output array 'grf' is required")
         k = C.c_int32(-1)
         rc = self.lib.a1mpc_pipeline_submit(self._p, int(slot), 1 if fresh else 0, n, _dp(x0), _dp(xref), _dp(R), _dp(foot), _u8p(contact), _dp(out["grf"]),
                                             _dp(out["u"]) if out.get("u") is not None else None, _ip(out["iters"]) if out.get("iters") is not None else None,

@@ -102,21 +102,23 @@ def cpu_baseline(pkg, sc, budget_s=15.0):
             "mean_iters": float(r["iters"].mean()), "single_thread_cold_solves_per_s": 1.0 / ts, "single_thread_warm_ticks": single}, r
 
 
-def latency_probe(pkg, nticks=1500):
+def latency_probe(pkg, nticks=1500, mode=1):
     """BASELINE configs[1]: batch 1, trot, warm-started sequential ticks through the host-pointer ABI (PCIe inclusive).  10 000 ticks from the
-    C++ harness (tests/cpp/latency_harness, no Python in the loop) when it has been built; the Python loop below otherwise."""
+    C++ harness (tests/cpp/latency_harness, no Python in the loop) when it has been built; the Python loop below otherwise.
+    mode 1: fresh set-up + osqp_warm_start every tick; mode 2: the reference's per-tick OSQP update path on its persistent solver (S/A1RobotControl.cpp:533-540:
+    what the reference's control loop -- and the drop-in ComputeGrfGpu -- actually runs)."""
     import subprocess
     exe = os.path.join(ROOT, "tests", "cpp", "latency_harness")
     if os.path.exists(exe):
         try:
             env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("LOCAL_RANK", "0")) if os.environ.get("LOCAL_RANK") else None
-            r = subprocess.run([exe, "10000"], capture_output=True, text=True, timeout=120, env=env)
+            r = subprocess.run([exe, "10000", "0", str(mode)], capture_output=True, text=True, timeout=120, env=env)
             if r.returncode == 0:
                 return json.loads(r.stdout)
         except Exception:
             pass
     sc = pkg.scenarios.config2_trot_sequence(nticks)
-    cfg = pkg.make_config(sc["params"], sc["horizon"], warm_start=1)
+    cfg = pkg.make_config(sc["params"], sc["horizon"], warm_start=mode)
     import gc
     lat = np.zeros(nticks)
     with pkg.Engine(cfg, 1, int(os.environ.get("LOCAL_RANK", 0))) as eng:
@@ -129,7 +131,7 @@ def latency_probe(pkg, nticks=1500):
         finally:
             gc.enable()
     lat = lat[50:] * 1e3
-    return {"workload": "config2 trot, h=10, batch 1, warm start, host pointers in/out", "ticks": int(len(lat)),
+    return {"warm_start": mode, "workload": "config2 trot, h=10, batch 1, warm start, host pointers in/out", "ticks": int(len(lat)),
             "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "max_ms": float(lat.max())}
 
 
@@ -319,6 +321,8 @@ def other_config_rooflines(pkg, local, steps=4):
         entry = {"config": name, "batch": n, "horizon": h, "avg_kernel_ms": avg, "solves_per_s": n / (avg * 1e-3), "bound": "fp64-valu", "achieved": ach,
                  "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "mean_iters": float(it.float().mean().item()),
                  "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n, "solved_frac": float((stt == 1).float().mean().item())}
+        entry["lanes_live"] = {10: "48 of 64 (two QPs per wavefront)", 16: "28.8 of 64 on average: a CU-wide workgroup of four wavefronts carries five QPs (wave 0 two = 48 lanes, waves 1-3 one = 24 lanes each)",
+                               20: "24 of 64 (one QP per wavefront: 40 KB of LDS per QP, four per CU)"}[h]
         ex = pmc.get(f"{n}x{h}")   # SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 x live lanes of a first solve of this batch (static: profiles/, rocprofv3 --pmc of tools/prof_shapes.py)
         if ex:
             entry["executed_fp64_flops_per_launch"] = ex; entry["executed_fp64_frac"] = ex / (avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
@@ -679,16 +683,19 @@ def main():
                          "kernel": "a1mpc_setup_kernel<10,1> + a1mpc_admm_kernel<10,2> (+ a1mpc_order_kernel, ~5 us) = one solve", "avg_kernel_ms": avg_ms,
                          "avg_kernel_ms_is": f"timed region (HIP events on the launch stream, behind the first and after the last launch of every slot) / launches, {depth} launches in flight: "
                                              "with overlapping launches this is the rate a launch completes at, not the span of one launch",
+                         "lanes_live": "48 of 64 (two QPs per wavefront, each on a main / twin pair of 16-lane rows with 12 live lanes)",
                          "single_stream": {"avg_kernel_ms": single_ms, "achieved": flops / (single_ms * 1e-3) / 1e12, "frac": flops / (single_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                            "solves_per_s": n / (single_ms * 1e-3),
+                                           "executed_fp64_frac": (pmc["executed_fp64_flops_per_launch"] / (single_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if pmc.get("executed_fp64_flops_per_launch") else None,
                                            "what": "the same first solves through ONE handle on one stream, launches serialised: the sum of the three kernels' durations in a kernel trace "
                                                    "(profiles/r03_kernel_stats_bench_depth1_batch4096_h10.csv)"},
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
                          "executed_fp64_flops_per_launch": pmc.get("executed_fp64_flops_per_launch"),
                          "executed_fp64_frac": (pmc["executed_fp64_flops_per_launch"] / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if pmc.get("executed_fp64_flops_per_launch") else None,
                          "note": "bound: FP64 VALU issue / LDS latency (no MFMA in the kernel: profiles/r02_mfma_trial.md); the peak is the dense FP64 peak (vector = matrix "
-                                 "on MI355X); flops = SURVEY 8(d) F(h,iters,nfact) of the dense-condensed model summed over the launch; executed_fp64 = "
-                                 "SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 x live lanes from the static PMC profile"},
+                                 "on MI355X).  TWO fractions, always side by side: `frac` prices the SURVEY 8(d) dense-condensed flop model F(h,iters,nfact) (what a dense solver "
+                                 "would execute; the structured Riccati solve executes 1.5x / 2.8x / 3.9x fewer flops at h = 10 / 16 / 20), `executed_fp64_frac` prices the FP64 flops "
+                                 "the kernels really issue (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 x live lanes from the static PMC profile) -- the hardware fraction"},
         }
         out["scheduling"] = {
             "mode": "value: first solves (no history; queue ordered by the set-up kernel's per-QP cost guess).  Beside it: plain index order, and "
@@ -726,6 +733,7 @@ def main():
         if not args.no_latency:
             out["pcie_inclusive"] = pcie_inclusive_probe(pkg, scs, cfg, n, local)
             out["latency"] = latency_probe(pkg)
+            out["latency_update_path"] = latency_probe(pkg, mode=2)   # warm_start = 2: the reference's operating point (its persistent OsqpEigen solver, update calls + solve per tick)
             out["throughput_by_batch"] = batch_sweep(pkg, local)
             out["warm_start_ticks"] = warm_tick_probe(pkg, local)
             out["warm_start_ticks_update_path"] = warm_tick_probe(pkg, local, mode=2)

@@ -362,6 +362,22 @@ a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h);
  * update path's carry of these problems: their next tick is a fresh set-up warm-started from (x, y, rho), the ticks after it follow the update path again. */
 a1mpc_status a1mpc_warm_start(a1mpc_handle h, int32_t n, const double* x, const double* y, const double* rho);
 a1mpc_status a1mpc_get_warm_start(a1mpc_handle h, int32_t n, double* x_out, double* y_out, double* rho_out);
+/* warm_start = 2 only: the unscaled z = Pi(w) of problems 0..n-1 that the update path keeps beside (x, y, rho) -- what OSQP leaves in work->z, n x 20H in the
+ * reference's row order (S/ConvexMpc.cpp:46-58).  With x and y it is everything OSQP's own termination test reads (auxil.c check_termination: ||Ax - z||,
+ * ||Px + q + A'y||), so a caller -- the parity tests do, on the ticks where engine and oracle stop at different iterations -- can verify that a returned point is
+ * one OSQP would have stopped at.  A1MPC_ERR_INVALID_ARGUMENT when the handle has no update-path carry (another warm-start mode, horizon 1, no tick yet).
+ * Host pointer; synchronises the handle's stream.  Problems without a previous update-path tick read as zeros. */
+a1mpc_status a1mpc_get_workspace_z(a1mpc_handle h, int32_t n, double* z_out);
+/* warm_start = 2 only: the equilibration of the handle's last update-path tick as OSQP's workspace holds it -- D (n x 12H, variable scaling), E (n x 20H,
+ * constraint scaling, reference row order) and the cost scaling c (n; 0 = no previous tick).  Together with a1mpc_get_warm_start (unscaled x, y, rho) and
+ * a1mpc_get_workspace_z this is the complete state the reference's persistent OsqpEigen solver carries from tick to tick (scaled iterates x_s = x / D,
+ * z_s = E z, y_s = c y / E): a second implementation of the update path can be started from it (the parity tests re-seed the oracle that way).
+ * Any pointer may be NULL.  Host pointers; synchronises the handle's stream. */
+a1mpc_status a1mpc_get_workspace_scaling(a1mpc_handle h, int32_t n, double* D_out, double* E_out, double* c_out);
+/* Which warm-start semantics the handle's last MPC solve actually ran: 0 (cold), 1 (fresh set-up + osqp_warm_start) or 2 (the reference's update path).
+ * warm_start = 2 exists on the fast path at horizons 10 / 16 / 20; a solve through the general path (per-step feet, a separate A_c yaw) or at horizon 1
+ * runs mode 1 instead (documented at a1mpc_config.warm_start) -- this call makes that visible to the caller.  -1 before the first solve. */
+a1mpc_status a1mpc_last_warm_start_mode(a1mpc_handle h, int32_t* mode_out);
 
 /* Replace the configuration of a live handle -- everything except the horizon: dt (the reference uses the measured loop dt when
  * use_sim_time is "true", S/A1RobotControl.cpp:465), weights, mass / inertia, friction and force limits, OSQP settings.  The constants
@@ -443,6 +459,9 @@ a1mpc_status a1mpc_pipeline_submit(a1mpc_pipeline p, int32_t slot, int32_t fresh
                                    double* u_full_out, int32_t* iters_out, int32_t* status_out, int32_t* slot_out);
 a1mpc_status a1mpc_pipeline_wait(a1mpc_pipeline p, int32_t slot);
 a1mpc_status a1mpc_pipeline_join(a1mpc_pipeline p, int32_t slot, void* hip_stream);
+/* a1mpc_pipeline_handle: a host-pointer batch still in flight on the slot is waited for and handed to its caller's output arrays first (its results live in
+ * the handle's one pinned mirror, which any host-pointer call on the handle would overwrite).  a1mpc_pipeline_destroy does the same for every slot: the output
+ * arrays of submitted batches must stay valid until wait / the next submit to the slot / destroy has returned. */
 a1mpc_status a1mpc_pipeline_handle(a1mpc_pipeline p, int32_t slot, a1mpc_handle* out);
 a1mpc_status a1mpc_pipeline_depth(a1mpc_pipeline p, int32_t* depth_out);
 void a1mpc_pipeline_destroy(a1mpc_pipeline p);

@@ -532,6 +532,10 @@ done:
     for (int j = 0; j < n; ++j) if (!isfinite(w.x[j])) { info->status = ORC_NON_CVX; break; }
     info->rho_final = w.rho;
     if (rho_io) *rho_io = w.rho;
+    {   /* the unscaled z = Einv z_s of this solve, for orc_last_z() (tests: OSQP's termination test needs it beside x and y) */
+        double *lz = (double *)scratch_get(2, (size_t)(m + 1) * sizeof(double), 0);
+        if (lz) { lz[0] = (double)m; for (int i = 0; i < m; ++i) lz[1 + i] = w.Einv[i] * w.z[i]; }
+    }
     if (carry) {  /* what stays in the reference's workspace for the next tick's update calls */
         const int failed = info->status == ORC_PRIMAL_INFEASIBLE || info->status == ORC_DUAL_INFEASIBLE || info->status == ORC_NON_CVX;
         carry[0] = 1.0; carry[1] = failed ? st->rho : w.rho;   /* (a failed solve: the next tick starts from settings->rho, like the engine's cold start after a failure) */
@@ -561,6 +565,43 @@ int orc_osqp_solve_update(int n, int m, const double *P, const double *q, const 
 int orc_osqp_solve_update_ex(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
                              const double *l, const double *u, const orc_settings *st, double *x, double *y, double *carry, int pattern_changed, orc_info *info) {
     return osqp_solve_impl(n, m, P, q, rp, ci, av, l, u, st, x, y, 0, info, carry, pattern_changed);
+}
+/* unscaled z of the calling thread's most recent solve (m doubles); returns m, or -1 when there was none or the size differs */
+int orc_last_z(int m, double *z_out) {
+    const double *lz = (const double *)tl_scratch[2].p;
+    if (!lz || (int)lz[0] != m) return -1;
+    for (int i = 0; i < m; ++i) z_out[i] = lz[1 + i];
+    return m;
+}
+/* OSQP's termination test (auxil.c check_termination, scaled_termination = 0) evaluated on a GIVEN unscaled iterate (x, z, y): is this a point OSQP itself would
+ * have stopped at?  Test infrastructure for the ticks where the engine and this oracle stop at different iterations (tests/test_gpu_parity.py, the 10 000-tick
+ * update-path test).  The unscaled norms need no scaling data:  Einv (A_s x_s - z_s) = A x - z  and  cinv Dinv (P_s x_s + q_s + A_s' y_s) = P x + q + A' y,
+ * likewise the norms of the tolerances (compute_pri_tol / compute_dua_tol above).  P: the upper triangle is used (what OSQP is handed).
+ * out[0..3] = pri_res, pri_tol, dua_res, dua_tol.  Returns 1 when both tests pass (strict inequalities, as OSQP's). */
+int orc_check_termination(int n, int m, const double *P, const double *q, const int32_t *rp, const int32_t *ci, const double *av,
+                          const double *x, const double *z, const double *y, double eps_abs, double eps_rel, double *out) {
+    double pri = 0, nz = 0, nAx = 0, dua = 0, nq = 0, nAty = 0, nPx = 0;
+    double *Aty = (double *)calloc((size_t)n, sizeof(double));
+    if (!Aty) return -1;
+    for (int i = 0; i < m; ++i) {
+        double ax = 0;
+        for (int k = rp[i]; k < rp[i + 1]; ++k) { ax += av[k] * x[ci[k]]; Aty[ci[k]] += av[k] * y[i]; }
+        double a = fabs(ax - z[i]); if (a > pri) pri = a;
+        a = fabs(z[i]); if (a > nz) nz = a;
+        a = fabs(ax); if (a > nAx) nAx = a;
+    }
+    for (int j = 0; j < n; ++j) {
+        double px = 0;
+        for (int k = 0; k < n; ++k) px += (k >= j ? P[(size_t)j * n + k] : P[(size_t)k * n + j]) * x[k];
+        double a = fabs(px + q[j] + Aty[j]); if (a > dua) dua = a;
+        a = fabs(q[j]); if (a > nq) nq = a;
+        a = fabs(Aty[j]); if (a > nAty) nAty = a;
+        a = fabs(px); if (a > nPx) nPx = a;
+    }
+    free(Aty);
+    const double ptol = eps_abs + eps_rel * fmax(nz, nAx), dtol = eps_abs + eps_rel * fmax(fmax(nq, nAty), nPx);
+    if (out) { out[0] = pri; out[1] = ptol; out[2] = dua; out[3] = dtol; }
+    return pri < ptol && dua < dtol;
 }
 /* sparsity pattern of the upper triangle of a dense symmetric P as hessian.sparseView() sees it (exact zeros dropped): FNV-1a over the non-zero flags, plus the count */
 void orc_pattern_signature(int n, const double *P, double *sig2) {

@@ -135,6 +135,26 @@ def osqp_solve(P, g, csr, l, u, st, x=None, y=None, rho=None):
     return x, y, info, rho_io.value
 
 
+def last_z(m):
+    """unscaled z of this thread's most recent single solve (mpc_solve / mpc_solve_update / osqp_solve), reference row order"""
+    z = np.zeros(m)
+    assert lib().orc_last_z(C.c_int(m), _p(z)) == m
+    return z
+
+
+def check_termination(P, g, csr, x, z, y, eps_abs=1e-3, eps_rel=1e-3):
+    """OSQP's termination test on a GIVEN unscaled iterate (x, z, y) of the QP (P, g, A = csr): dict(ok, pri_res, pri_tol, dua_res, dua_tol).
+    For the ticks where engine and oracle stop at different iterations: is the engine's point one OSQP itself would have stopped at?"""
+    rp, ci, av = csr
+    n, m = len(g), len(rp) - 1
+    out = np.zeros(4)
+    ok = lib().orc_check_termination(C.c_int(n), C.c_int(m), _p(np.ascontiguousarray(P, dtype=np.float64)), _p(np.ascontiguousarray(g, dtype=np.float64)),
+                                     _p(rp, C.c_int32), _p(ci, C.c_int32), _p(av), _p(np.ascontiguousarray(x, dtype=np.float64)),
+                                     _p(np.ascontiguousarray(z, dtype=np.float64)), _p(np.ascontiguousarray(y, dtype=np.float64)),
+                                     C.c_double(eps_abs), C.c_double(eps_rel), _p(out))
+    return dict(ok=bool(ok == 1), pri_res=float(out[0]), pri_tol=float(out[1]), dua_res=float(out[2]), dua_tol=float(out[3]))
+
+
 def mpc_solve_batch(pr, st, x0, xref, Rw, foot, contact, nthreads=0, want_u=False):
     """Batch of independent ticks (S/A1RobotControl.cpp:446-562 each).  Arrays are (nb, ...)."""
     h = pr.horizon
@@ -172,6 +192,26 @@ def mpc_solve(pr, st, x0, xref, Rw, foot, contact, warm_x=None, warm_y=None, war
 def update_carry(horizon):
     """zeroed workspace carry of mpc_solve_update for one robot (2 + 2n + 4m doubles + 2 for the sparsity pattern of the previous tick's P)"""
     return np.zeros(4 + 2 * NU * horizon + 4 * NC * horizon)
+
+
+def carry_from_workspace(h, x, y, z, rho, D, E, c, P_prev, g_prev, l_prev, u_prev):
+    """the workspace carry of mpc_solve_update (osqp_solve_impl's layout: valid, rho, x_s, z_s, y_s, q_prev, l_prev, u_prev, pattern signature of the previous P)
+    built from an UNSCALED state (x, y, z, rho) and the equilibration (D, E, c) it was reached under -- x_s = x / D, z_s = E z, y_s = c y / E -- plus the previous
+    tick's QP data.  How the tests start this oracle from the engine's workspace (a1mpc_get_warm_start / _workspace_z / _workspace_scaling)."""
+    n, m = NU * h, NC * h
+    carry = update_carry(h)
+    carry[0] = 1.0; carry[1] = rho
+    o = 2
+    carry[o:o + n] = np.asarray(x) / np.asarray(D); o += n
+    carry[o:o + m] = np.asarray(E) * np.asarray(z); o += m
+    carry[o:o + m] = c * np.asarray(y) / np.asarray(E); o += m
+    carry[o:o + n] = g_prev; o += n
+    carry[o:o + m] = l_prev; o += m
+    carry[o:o + m] = u_prev; o += m
+    sig = np.zeros(2)
+    lib().orc_pattern_signature(C.c_int(n), _p(np.ascontiguousarray(P_prev, dtype=np.float64)), _p(sig))
+    carry[o:o + 2] = sig
+    return carry
 
 
 def mpc_solve_update(pr, st, x0, xref, Rw, foot, contact, carry):

@@ -32,7 +32,23 @@ def take(sc, n):
     return out
 
 
-def compare(out, ref, tol=TOL_FORCE_N, min_same=MIN_SAME_ITERS):
+def exact_resolver(O, sc, settings=None):
+    """for compare(): solves the given QPs of `sc` with the oracle in exact mode (eps 1e-10) and in the default mode -> (u_exact, u_default), each (k, 12 h)"""
+    def resolve(idx):
+        sub = dict(sc)
+        for k in ("x0", "xref", "R", "foot", "contact"):
+            sub[k] = sc[k][idx]
+        over = {} if settings is None else {k: getattr(settings, k) for k in ("rho", "sigma", "alpha", "scaling", "adaptive_rho", "adaptive_rho_interval", "adaptive_rho_tolerance", "check_termination")}
+        ex = oracle_batch(O, sub, settings=O.exact_settings(**over))
+        return ex["u"]
+    return resolve
+
+
+def compare(out, ref, tol=TOL_FORCE_N, min_same=MIN_SAME_ITERS, resolve=None):
+    """GPU vs oracle on the same QPs.  QPs that stopped at the oracle's iteration: same status, forces within `tol`.  QPs with ANOTHER iteration count (a termination
+    test within round-off of its threshold may flip; at most 1 - min_same of the batch) are not dropped: with `resolve` (exact_resolver) each is compared against the
+    oracle's exact-mode optimum and must lie within 3 x the distance the default-tolerance oracle itself keeps from it on the same QP (the flip is one
+    25-iteration checkpoint earlier or later) -- OSQP's own slack at its default tolerances, SURVEY 7.2(1).  Without `resolve` any such QP fails the comparison."""
     same = out["iters"] == ref["iters"]
     frac = same.mean()
     assert frac >= min_same, f"only {frac:.4f} of the problems stopped at the oracle's iteration"
@@ -40,4 +56,15 @@ def compare(out, ref, tol=TOL_FORCE_N, min_same=MIN_SAME_ITERS):
     du = np.abs(out["u"] - ref["u"])[same].max() if out.get("u") is not None else 0.0
     dg = np.abs(out["grf"] - ref["grf"])[same].max()
     assert du <= tol and dg <= tol, (du, dg)
-    return dict(same_frac=float(frac), du=float(du), dgrf=float(dg))
+    worst_ratio = 0.0
+    if not same.all():
+        idx = np.flatnonzero(~same)
+        assert resolve is not None, f"{len(idx)} QP(s) with another iteration count than the oracle's and no exact-mode resolver to check them against: {idx[:8]}"
+        assert out.get("u") is not None and ref.get("u") is not None, "resolving iteration mismatches needs the full-horizon forces (want_u)"
+        ue = resolve(idx)
+        for j, i in enumerate(idx):
+            slack = np.abs(ref["u"][i] - ue[j]).max()     # what the default tolerances leave open on this QP (oracle default vs oracle exact)
+            d = np.abs(out["u"][i] - ue[j]).max()
+            assert d <= 3.0 * slack + tol, f"QP {i}: iterations {out['iters'][i]} vs {ref['iters'][i]}; {d:.3e} N from the exact optimum, the oracle's own default-mode slack is {slack:.3e} N"
+            worst_ratio = max(worst_ratio, d / max(slack, 1e-300))
+    return dict(same_frac=float(frac), du=float(du), dgrf=float(dg), resolved=int((~same).sum()), worst_resolved_ratio=float(worst_ratio))

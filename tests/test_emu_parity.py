@@ -335,3 +335,34 @@ def test_emulated_update_path_reinitialises_on_a_pattern_change(oracle, scen, pa
         assert np.abs(e["grf"][0] - o["grf"]).max() < 1e-7, (path, t)
         assert abs(rho[0] - carry_o[1]) <= 1e-6 * carry_o[1]
     assert seen == [0, 0, 1, 0, 1, 0]
+
+
+@pytest.mark.parametrize("gen,kw,n,twin,split", [("config3_random_flat", {}, 3, True, 0), ("config5_divergent", {"horizon": 10}, 4, True, 2)])
+def test_emulated_dont_care_lanes_are_dont_cares(scen, gen, kw, n, twin, split):
+    """the hot loop no longer holds the fz lanes' (non-existent) second-row variable wh1 at zero, nor the pad lanes' state -- correctness rests on every
+    reader masking them.  A build that overwrites them at every segment start (fz-lane wh1 = +-1e300, pad-lane xh / wh0 / wh1 = NaN; -DA1X_POISON) must return the
+    same bits: forces, iteration counts, status, factor passes, and the carried warm start."""
+    sc = getattr(scen, gen)(nb=n, **kw)
+    for ws in (0, 1):
+        warm = None
+        if ws:
+            h = sc["horizon"]
+            first = emu.solve(sc, n, warm=(np.zeros((n, 12 * h)), np.zeros((n, 20 * h)), np.zeros(n)), warm_start=1, twin=twin, split_rows=split)
+            assert (first["status"] == 1).all()
+        def run():
+            w = None
+            if ws:
+                h = sc["horizon"]
+                w = (np.zeros((n, 12 * h)), np.zeros((n, 20 * h)), np.zeros(n))
+                emu.solve(sc, n, warm=w, warm_start=1, twin=twin, split_rows=split)      # tick 1 fills the workspace ...
+            out = emu.solve(sc, n, warm=w, warm_start=ws, twin=twin, split_rows=split)     # ... tick 2 starts from it (OSQP's first-iteration code path)
+            return out, w
+        a, wa = run()
+        with emu.using(emu.variant(["-DA1X_POISON"], "poison")):
+            b, wb = run()
+        for k in ("grf", "u", "iters", "status", "nfact"):
+            assert np.array_equal(a[k], b[k]), (ws, k)
+        if ws:
+            for x, y in zip(wa, wb):
+                assert np.array_equal(x, y)
+        assert (a["status"] == 1).all()

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import TOL_FORCE_BALANCE_N, TOL_FORCE_N, compare, oracle_batch, oracle_params, take
+from helpers import TOL_FORCE_BALANCE_N, TOL_FORCE_N, compare, exact_resolver, oracle_batch, oracle_params, take
 
 pytestmark = pytest.mark.gpu
 
@@ -35,7 +35,7 @@ def test_randomized_configs_default_settings(pkg, oracle, scen, name, gen, n):
     with _engine(pkg, sc, n, warm_start=0) as eng:
         out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
     ref = oracle_batch(oracle, sc)
-    r = compare(out, ref)
+    r = compare(out, ref, resolve=exact_resolver(oracle, sc))   # (a QP with another iteration count is checked against the exact-mode optimum, not dropped)
     print(name, r, "iters", np.unique(out["iters"], return_counts=True))
 
 
@@ -44,7 +44,7 @@ def test_parameter_sets(pkg, oracle, scen):
         sc = scen.config3_random_flat(nb=64, param_set=ps)
         with _engine(pkg, sc, 64, warm_start=0) as eng:
             out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
-        compare(out, oracle_batch(oracle, sc))
+        compare(out, oracle_batch(oracle, sc), resolve=exact_resolver(oracle, sc))
 
 
 def test_exact_mode_h10(pkg, oracle, scen):
@@ -1189,15 +1189,27 @@ def test_full_size_batches_every_qp_vs_oracle(pkg, oracle, scen, gen, n, h):
 def test_ten_thousand_warm_started_ticks_batch_1(pkg, oracle, scen, mode):
     """VERDICT r2 item 6 / BASELINE configs[1]: 10 000 sequential warm-started trot ticks of ONE robot (the reference's operating point, S/A1RobotControl.cpp:522-538)
     through the host-pointer entry, in both warm-start semantics -- 1: fresh set-up + osqp_warm_start, 2: the reference's per-tick OSQP update path -- against the oracle
-    chained the same way.  Mode 1: the same iteration count and status and forces within the parity tolerance on EVERY tick.  Mode 2: the same between the (counted, rare)
-    ticks where the chaotic update-path sequence parts ways -- see the comment in the loop."""
+    chained the same way.  Mode 1: the same iteration count and status and forces within the parity tolerance on EVERY tick.
+    Mode 2 asserts something on every tick as well.  The update path makes this tick sequence a chaotic map (independent 2 cm / 0.02 rad noise on
+    every tick: each solve starts from iterates scaled for another problem), so last-bit differences between two implementations grow from tick to tick until they
+    exceed the tolerance -- the oracle's OWN two back ends, Cholesky of the reduced system vs LDL' of the KKT matrix, are 0.5 N apart from tick 3354 on.  Between those
+    (counted, rare) PARTINGS every tick is within the parity tolerance with the same iteration count.  ON a parting tick the engine's answer is checked on its own:
+      (i)  OSQP's termination test (auxil.c check_termination: unscaled residuals against eps_abs + eps_rel x norms) evaluated on the ENGINE's (x, z, y) of that tick
+           passes -- the engine stopped at a point OSQP itself accepts;
+      (ii) the oracle is then RE-SEEDED from the engine's workspace (a1mpc_get_warm_start / _workspace_z / _workspace_scaling: everything the reference's persistent
+           solver carries) instead of both sides restarting cold, and the next tick -- engine, double-precision oracle and the x87 extended-precision build of the
+           oracle (tests/x87.py), all three from that one state -- must agree tick-for-tick again: engine vs oracle within 1e-7 N with the same iteration count (a
+           parting is accumulated chaos, not a per-tick discrepancy), and the engine no further from the extended-precision answer than the double oracle is (+ 1e-10 N)."""
+    import x87
     nt = 10000
     sc = scen.config2_trot_sequence(nt)
     pr = oracle_params(oracle, sc); st = oracle.default_settings(warm_start=1)
     h = sc["horizon"]
     wx = np.zeros(12 * h); wy = np.zeros(20 * h); rho = None
     carry = oracle.update_carry(h)
-    errs = np.zeros(nt); its = 0; diverged = []
+    errs = np.zeros(nt); its = 0; diverged = []; partings = []
+    xpr = x87.params(sc["params"], h) if mode == 2 else None
+    seeded = None     # mode 2: the workspace the oracle was re-seeded with at the previous (parting) tick
     with _engine(pkg, sc, 1, warm_start=mode) as eng:
         for t in range(nt):
             out = eng.solve(sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t])
@@ -1210,19 +1222,32 @@ def test_ten_thousand_warm_started_ticks_batch_1(pkg, oracle, scen, mode):
             errs[t] = float(np.abs(out["grf"][0] - r["grf"]).max()); its += int(out["iters"][0])
             if mode == 1:
                 assert same, (mode, t, out["iters"], r["info"].iters)
-            elif not same or errs[t] > TOL_FORCE_N:
-                # The update path makes the tick sequence a chaotic map on this input (independent 2 cm / 0.02 rad noise on every tick: each solve starts from iterates
-                # scaled for another problem): last-bit differences of the two linear solvers grow from tick to tick until a termination test flips, after which the
-                # two workspaces hold different (both legitimate) histories.  The oracle's OWN two back ends -- Cholesky of the reduced system vs LDL' of the KKT
-                # matrix -- part ways at tick 3354 of this sequence and are 0.5 N apart in the median from then on (mode 1: 1e-7 N apart over all 10 000 ticks, no
-                # flip).  So: a tick beyond the parity tolerance (or with another iteration count) is counted as a parting, both sides start again from a cold
-                # workspace, and the run goes on.
+                continue
+            if seeded is not None:   # (ii) the tick after a parting: all three from ONE state
+                xr = x87.mpc_solve_update(xpr, x87.settings(warm_start=1), sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t], seeded)
+                d_eng = float(np.abs(out["grf"][0] - xr["grf"]).max()); d_orc = float(np.abs(r["grf"] - xr["grf"]).max())
+                partings[-1].update(next_tick=dict(iters=(int(out["iters"][0]), int(r["info"].iters), xr["iters"]), engine_vs_oracle_N=errs[t], engine_vs_x87_N=d_eng, oracle_vs_x87_N=d_orc))
+                assert same and errs[t] <= 1e-7, (t, partings[-1])
+                assert d_eng <= d_orc + 1e-10, (t, partings[-1])   # (observed: the engine is the CLOSER one on every parting, 1e-13 against 1e-11 N)
+                seeded = None
+            if not same or errs[t] > TOL_FORCE_N:
+                assert eng.last_warm_start_mode() == 2
+                ex, ey, erho = eng.get_warm_start(1); ez = eng.get_workspace_z(1); eD, eE, ec = eng.get_workspace_scaling(1)
+                P, g, _, l, u, csr = oracle.mpc_form(pr, sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t])
+                k = 10.0 if out["status"][0] == 2 else 1.0     # (SOLVED_INACCURATE: OSQP's approximate test, 10 x the tolerances)
+                ct = oracle.check_termination(P, g, csr, ex[0], ez[0], ey[0], eps_abs=k * st.eps_abs, eps_rel=k * st.eps_rel)
+                assert out["status"][0] in (1, 2) and ct["ok"], (t, int(out["status"][0]), ct)   # (i) a point OSQP's own termination test accepts
+                partings.append(dict(tick=t, iters=(int(out["iters"][0]), int(r["info"].iters)), engine_vs_oracle_N=errs[t], pri=(ct["pri_res"], ct["pri_tol"]), dua=(ct["dua_res"], ct["dua_tol"])))
                 diverged.append(t); errs[t] = 0.0
-                eng.reset_warm_start(); carry = oracle.update_carry(h)
+                carry = oracle.carry_from_workspace(h, ex[0], ey[0], ez[0], erho[0], eD[0], eE[0], ec[0], P, g, l, u)   # the oracle goes on from the ENGINE's workspace
+                seeded = carry.copy()
     worst = float(errs.max())
     print(f"warm_start = {mode}: 10000 ticks, |dGRF| median {np.median(errs):.1e}, 99.9 % {np.quantile(errs, 0.999):.1e}, worst {worst:.2e} N (tick {int(errs.argmax())}), "
-          f"ticks above 1e-6 N: {int((errs > 1e-6).sum())}, partings (both sides restarted cold): {diverged}, mean iterations {its / nt:.1f}")
+          f"ticks above 1e-6 N: {int((errs > 1e-6).sum())}, partings (oracle re-seeded from the engine's workspace): {diverged}, mean iterations {its / nt:.1f}")
+    for pt in partings:
+        print("  parting", pt)
     if mode == 1:    # fresh set-up + osqp_warm_start: the parity tolerance on every one of the 10 000 ticks
         assert worst <= TOL_FORCE_N, (mode, int(errs.argmax()), worst)
     else:            # the update path: at most a handful of partings in 10 000 ticks, every other tick within the tolerance (by construction of the count)
-        assert len(diverged) <= 10 and worst <= TOL_FORCE_N, (mode, diverged, int(errs.argmax()), worst)   # (observed on MI355X: 5 partings, at ticks 3201, 5599, 6253, 7180, 8687)
+        assert len(diverged) <= 10 and worst <= TOL_FORCE_N, (mode, diverged, int(errs.argmax()), worst)
+        assert seeded is None or diverged[-1] == nt - 1

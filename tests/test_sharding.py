@@ -143,3 +143,31 @@ def test_bench_native_runs_both_transports():
     t0, t1 = out["transports"]["0"], out["transports"]["1"]
     assert t0["devices"] == [0, 0] and t0["solved_frac"] == 1.0
     assert "error" in t1 or (t1["solved_frac"] == 1.0 and t1["mean_iters"] == t0["mean_iters"]), t1
+
+
+@pytest.mark.gpu
+def test_eight_ranks_first_contact_on_the_shared_gpu():
+    """VERDICT r3 item 8 (insurance for the first 8-GPU run; no scaling claim): the 8-rank case has never been started on real hardware, so everything about it that
+    does not need eight devices is run here -- eight ranks x (engine handle + two-slot pipeline) on the one test GPU over gloo, self-spawned like the driver's command
+    minus the launcher, for the weak-scaling metric and for --config 4 (scatter + solve + gather in the timed region), and eight shards through the native handle.
+    Asserted: n_gpus = 8, every QP solved, the scatter / gather byte counts of the contiguous partition, and a wall-clock ceiling per call (rendezvous, eight torch
+    imports and eight engine creations included)."""
+    import time
+    t0 = time.time()
+    out = _run_bench("--gpus", "8", "--batch", "1024", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-latency", "--no-index-order", timeout=600)
+    t_weak = time.time() - t0
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["solved_frac"] == 1.0 and out["config"]["batch_per_gpu"] == 1024
+    N, H = 8192, 16
+    t0 = time.time()
+    out4 = _run_bench("--gpus", "8", "--config", "4", "--batch", str(N), "--steps", "2", "--warmup", "1", timeout=600)
+    t_strong = time.time() - t0
+    assert out4["n_gpus"] == 8 and out4["scaling"] == "strong" and out4["config"]["global_batch"] == N and out4["config"]["solved_frac"] == 1.0
+    rec_bytes = (13 + 13 * H + 9 + 12) * 8 + 4     # x0, x_ref, R, feet as doubles + four contact bytes per QP (1 940 B at h = 16)
+    away = N - N // 8                              # QPs that leave rank 0
+    assert out4["scatter_bytes_per_step"] == away * rec_bytes and out4["gather_bytes_per_step"] == away * (12 * 8 + 8), (out4["scatter_bytes_per_step"], out4["gather_bytes_per_step"])
+    t0 = time.time()
+    nat = _run_bench("--native", "0", "--gpus", "8", "--batch", "512", "--steps", "3", "--warmup", "2", timeout=600)
+    t_nat = time.time() - t0
+    assert nat["n_gpus"] == 8 and nat["config"]["global_batch"] == 8 * 512 and nat["transports"]["0"]["devices"] == [0] * 8 and nat["transports"]["0"]["solved_frac"] == 1.0
+    print(f"8 ranks on one GPU: weak {t_weak:.0f} s, config 4 {t_strong:.0f} s, native 8 shards {t_nat:.0f} s wall clock")
+    assert max(t_weak, t_strong) < 420 and t_nat < 180, (t_weak, t_strong, t_nat)
