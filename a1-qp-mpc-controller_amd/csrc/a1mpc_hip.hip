@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen()ed by a1mpc_sharded_create(transport = 1), never linked
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -117,7 +118,8 @@ constexpr bool admm_twin_rows(int h, int rows) { return twin_rows(h, kModeMpc, r
 // UPD: the instantiation that also serves warm_start = 2 (the reference's update path); every other mode runs UPD = false, whose code is what it was before
 // the update path existed (the allocation of the hot loop is sensitive to anything around it: a1mpc_solver.hpp, load_prepared)
 // UNI: contacts broadcast over the horizon (contact_stride = 0): one pair of bounds for every slot (RowSolver<.., UNI>; built for H >= 16, where the registers matter)
-template <int H, int ROWS, bool UPD = false, bool UNI = false>
+// CLK: the profiling instantiation (a1mpc_set_profiling): shader-clock stamps around factor passes / iteration segments / residual checks, outside the hot loop
+template <int H, int ROWS, bool UPD = false, bool UNI = false, bool CLK = false>
 __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     // ROWS <= 2: the wavefront's other rows run as twins of the QP rows (rows r and r + 2 share a QP and its LDS image, see row_is_twin)
@@ -125,9 +127,9 @@ __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, cons
     const int row = static_cast<int>(threadIdx.x) >> 4;
     if constexpr (kTwin) {
         if ((row & 1) >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
-        admm_rows<H, true, false, UPD, UNI>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H>::ROW_STRIDE);
+        admm_rows<H, true, false, UPD, UNI, CLK>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H>::ROW_STRIDE);
     } else {
-        admm_rows<H, false, false, UPD, UNI>(a, prep, counter, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+        admm_rows<H, false, false, UPD, UNI, CLK>(a, prep, counter, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
     }
 }
 
@@ -137,14 +139,14 @@ __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, cons
 // Rows still refill from the queue independently and nothing is shared between the waves (no workgroup barrier anywhere in admm_rows): the only coupling is
 // that wave 0's two QPs wait for each other's factor passes, as every pair of H = 10 does.
 constexpr int cu_wide_qps(int h) { return h == 16 ? 5 : 0; }   // QPs of a CU-wide workgroup (0: this horizon has no such kernel -- H = 20: 40 KB per image, four per CU)
-template <int H, bool UPD = false, bool UNI = false>
+template <int H, bool UPD = false, bool UNI = false, bool CLK = false>
 __global__ __launch_bounds__(256) void a1mpc_admm_cu_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     static_assert(cu_wide_qps(H) == 5 && admm_twin_rows(H, 1), "five images: two on wave 0, one on each of waves 1-3");
     const int wave = static_cast<int>(threadIdx.x) >> 6, row = (static_cast<int>(threadIdx.x) >> 4) & 3;
     if (wave != 0 && (row & 1)) return;  // waves 1-3: rows 1 and 3 have no QP
     const int image = wave == 0 ? (row & 1) : wave + 1;
-    admm_rows<H, true, false, UPD, UNI>(a, prep, counter, a1mpc_lds + image * Layout<H>::ROW_STRIDE);
+    admm_rows<H, true, false, UPD, UNI, CLK>(a, prep, counter, a1mpc_lds + image * Layout<H>::ROW_STRIDE);
 }
 
 // The general path's own split pipeline (round 2, last step): the same two kernels over RowSolver<.., GEN = true>.  K1 holds the per-step tables B~w_t and
@@ -519,7 +521,10 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
             if (a1mpc_status st = resident_cu_workgroups<H>(&resq); st != A1MPC_OK) return st;
             const int wantq = (a.n + Q - 1) / Q;
             const dim3 gridq(static_cast<unsigned>(wantq < resq ? wantq : resq)), blockq(256);
-            if (a.carry != nullptr) {
+            if (a.clk != nullptr && a.carry == nullptr && a.contact_stride == 0) {   // profiling instantiation (of the kernel broadcast contacts run)
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, true, true>), ldsq); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, true, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
+            } else if (a.carry != nullptr) {
                 if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, true>), ldsq); st != A1MPC_OK) return st;
                 hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
             } else if (a.contact_stride == 0) {
@@ -538,6 +543,16 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
         if (upd_kernels) {
             if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, true>), lds2); st != A1MPC_OK) return st;
             hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
+        }
+    }
+    // profiling instantiation (a1mpc_set_profiling; H > 1, default rows, no update path, broadcast contacts): the kernel of the default batches with clock stamps
+    if constexpr (H > 1 && ROWS == default_rows_per_wg(H) && admm_twin_rows(H, ROWS) && cu_wide_qps(H) == 0) {
+        if (a.clk != nullptr && !upd_kernels && a.contact_stride == 0) {
+            constexpr bool kUni = H >= 16;
+            if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, kUni, true>), lds2); st != A1MPC_OK) return st;
+            hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, kUni, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
+            A1_HIP(hipGetLastError());
+            return A1MPC_OK;
         }
     }
     bool uni_kernel = false;   // broadcast contacts at H >= 16: the instantiation with one pair of bounds for all slots
@@ -895,6 +910,9 @@ struct a1mpc_handle_s {
     double *d_aux_in = nullptr, *d_aux_out = nullptr;
     uint8_t* d_aux_u8 = nullptr;
     int32_t hint_n = 0;  // batch size the order was built for (0 = none)
+    bool profiling = false;        // a1mpc_set_profiling: split-pipeline solves run the clock-stamped instantiation of the ADMM kernel
+    long long* d_clk = nullptr;    // n x 3 cycles per QP (allocated on first use)
+    int32_t clk_n = 0;             // QPs of the last profiled solve (0: the last solve was not profiled)
     int32_t last_ws_mode = -1;  // warm-start semantics the last MPC solve ran (a1mpc_last_warm_start_mode): the configured mode, or 1 where mode 2 does not exist
     int schedule = 1;    // 1 = history (default), 0 = index order
     // packed device blocks + pinned host mirrors of the host-pointer MPC entry (one copy each way per call)
@@ -1928,7 +1946,7 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_tab, h->d_tab1, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_aux, h->d_Rz, h->d_contact, h->d_grf,
-                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_ekf_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8, h->d_foot_steps, h->d_contact_steps, h->d_prep_gen, h->d_carry};
+                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_ekf_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8, h->d_foot_steps, h->d_contact_steps, h->d_prep_gen, h->d_carry, h->d_clk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -2062,8 +2080,25 @@ a1mpc_status a1mpc_warm_start(a1mpc_handle h, int32_t n, const double* x, const 
     if (x) A1_HIP(hipMemcpyAsync(h->d_wx, x, N * 12 * H * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (y) A1_HIP(hipMemcpyAsync(h->d_wy, y, N * 20 * H * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (rho) A1_HIP(hipMemcpyAsync(h->d_rho, rho, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    // warm_start = 2: an injected (x, y, rho) is not what the update path left behind -- the next tick of these problems is a fresh set-up warm-started from it
-    if (h->d_carry) A1_HIP(hipMemsetAsync(h->d_carry, 0, N * carry_stride(h->cfg.horizon) * sizeof(double), h->stream));
+    // warm_start = 2: the injected state is re-expressed on the update path's workspace the way osqp_warm_start_x / _y do it on the reference's persistent solver:
+    // x and y replace the carried (unscaled) iterates above, z becomes A x (osqp_warm_start_x: z = A x), the previous tick's scalings, gradient and pattern stay --
+    // the next tick follows the update path from there.  (Until round 4 the carry was cleared: that tick was a fresh set-up.)
+    std::vector<double> zbuf;
+    if (h->d_carry && x) {
+        const size_t cs = carry_stride(h->cfg.horizon);
+        const double mu = h->cfg.mu;
+        zbuf.resize(N * 24 * H);
+        for (size_t b = 0; b < N; ++b)
+            for (size_t t = 0; t < H; ++t)
+                for (int leg = 0; leg < 4; ++leg) {
+                    const double* f = x + (b * H + t) * 12 + 3 * leg;
+                    double* z0 = zbuf.data() + b * 24 * H + t * 12 + 3 * leg;   // [Z0: 12H | Z1: 12H] of Carry<H>, per lane (leg, comp)
+                    double* z1 = z0 + 12 * H;
+                    z0[0] = std::fma(mu, f[2], f[0]); z0[1] = std::fma(mu, f[2], f[1]); z0[2] = f[2];
+                    z1[0] = std::fma(-mu, f[2], f[0]); z1[1] = std::fma(-mu, f[2], f[1]); z1[2] = 0.0;
+                }
+        A1_HIP(hipMemcpy2DAsync(h->d_carry + (1 + 48 * H), cs * sizeof(double), zbuf.data(), 24 * H * sizeof(double), 24 * H * sizeof(double), N, hipMemcpyHostToDevice, h->stream));
+    }
     A1_HIP(hipStreamSynchronize(h->stream));
     return A1MPC_OK;
 }
@@ -2079,6 +2114,25 @@ a1mpc_status a1mpc_get_warm_start(a1mpc_handle h, int32_t n, double* x_out, doub
     if (y_out) A1_HIP(hipMemcpyAsync(y_out, h->d_wy, N * 20 * H * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (rho_out) A1_HIP(hipMemcpyAsync(rho_out, h->d_rho, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     A1_HIP(hipStreamSynchronize(h->stream));
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_set_profiling(a1mpc_handle h, int32_t on) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    h->profiling = on != 0;
+    return A1MPC_OK;
+}
+a1mpc_status a1mpc_last_stage_cycles(a1mpc_handle h, double* cycles3_out, int32_t* qps_out) {
+    if (!h || !cycles3_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle / output");
+    cycles3_out[0] = cycles3_out[1] = cycles3_out[2] = 0.0;
+    if (qps_out) *qps_out = h->clk_n;
+    if (h->clk_n == 0 || !h->d_clk) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    A1_ORDER(h, h->stream);
+    std::vector<long long> c(static_cast<size_t>(h->clk_n) * 3);
+    A1_HIP(hipMemcpyAsync(c.data(), h->d_clk, c.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    A1_HIP(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < h->clk_n; ++b) for (int k = 0; k < 3; ++k) cycles3_out[k] += static_cast<double>(c[static_cast<size_t>(b) * 3 + k]);
     return A1MPC_OK;
 }
 
@@ -2252,6 +2306,11 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     a.predict = (hints && h->hint_n != n) ? 1 : 0;  // first solve of this batch size: order by the set-up kernel's guess instead
     A1_HIP(hipEventRecord(h->ev0, s));
     h->staged = split;
+    h->clk_n = 0;
+    if (h->profiling && split && h->cfg.horizon > 1 && a.carry == nullptr && a.contact_stride == 0) {
+        if (!h->d_clk) A1_HIP(hipMalloc(&h->d_clk, static_cast<size_t>(h->max_batch) * 3 * sizeof(long long)));
+        a.clk = h->d_clk; h->clk_n = n;
+    }
     a1mpc_status st = launch_mpc(h->cfg.horizon, a, h->d_prep, h->d_counter, s, split, h->ev_mid);
     if (st != A1MPC_OK) return st;
     if (hints) h->hint_n = n;   // the cost buffer now holds this batch's costs: the next solve of this size is ordered by them (sorted in front of its ADMM kernel)

@@ -323,7 +323,9 @@ struct Prep {
 // UNI = true (persistent ADMM kernel, H >= 16): the caller guarantees contacts broadcast over the horizon (contact_stride = 0, what the reference's controller
 // does, S/ConvexMpc.cpp:228-245), so ONE pair of bounds serves every slot and the per-slot pairs (2 HS doubles per lane) leave the register file -- at H = 16
 // the hot loop loses its 8 scratch reloads and 14 of 72 AGPR moves per iteration (8192 x h16 first solve 3.93 -> 3.73 ms).  Same values, same bits.
-template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false, bool TWIN = false, bool UNI = false>
+// CLK = true (persistent ADMM kernel, profiling instantiation: a1mpc_set_profiling): shader-clock stamps around the factor passes, the iteration segments and the
+// residual checks of a QP -- outside the hot loop; the numbers behind a1mpc_last_stage_cycles (the reference's t1..t6 stopwatches, S/A1RobotControl.cpp:491-553)
+template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false, bool TWIN = false, bool UNI = false, bool CLK = false>
 struct RowSolver {
     static_assert(!UNI || (!GEN && MODE == kModeMpc), "uniform bounds: the fast path with broadcast contacts");
     static_assert(!GEN || (MODE == kModeMpc && H > 1), "the general path is an MPC solve");
@@ -369,6 +371,7 @@ struct RowSolver {
 #ifdef A1X_CLK
     long long clkB = 0, clkF = 0, clkT = 0, clkU = 0, clkX = 0;
 #endif
+    long long pfX = 0, pfT = 0, pfU = 0;  // CLK: shader-clock cycles this QP spent in factor passes / iteration segments / residual checks (wave-mates' stalls included)
     int pred_cost = 0;  // set-up's guess of this QP's cost (queue order of a first solve, see predict_cost)
     struct Info {
         double pri_res, dua_res, nEz, nEAx, nDq, nDAty, nDPx;  // unscaled
@@ -1104,6 +1107,7 @@ struct RowSolver {
             }
         }
         iter = 0; nfact = 0; status = A1MPC_UNSOLVED; fac_ok = true; need_factor = true; done = false; careful = false;
+        pfX = pfT = pfU = 0;
 #ifdef A1X_CLK
         clkB = clkF = clkT = clkU = clkX = 0;
 #endif
@@ -1738,7 +1742,10 @@ struct RowSolver {
 #ifdef A1X_CLK
         const long long tf_ = clock64();
 #endif
+        [[maybe_unused]] long long pf0_ = 0;
+        if constexpr (CLK) pf0_ = row_clock();
         if (need_factor) factorize();
+        if constexpr (CLK) pfX += row_clock() - pf0_;
 #ifdef A1X_CLK
         clkX += clock64() - tf_;
 #endif
@@ -1761,6 +1768,8 @@ struct RowSolver {
 #ifdef A1X_CLK
             const long long t0_ = clock64();
 #endif
+            [[maybe_unused]] long long pf1_ = 0;
+            if constexpr (CLK) pf1_ = row_clock();
             if (row_wave_any(careful)) {
                 for (int k = iter; k < next; ++k) admm_iteration<false, true>();
             } else {
@@ -1769,6 +1778,7 @@ struct RowSolver {
 #ifdef A1X_CLK
             clkT += clock64() - t0_;
 #endif
+            if constexpr (CLK) pfT += row_clock() - pf1_;
             iter = next;
             const bool can_check = P.check_every > 0 && (iter % P.check_every) == 0;
             const bool do_rho = P.adaptive_rho && P.adaptive_rho_every > 0 && (iter % P.adaptive_rho_every) == 0;
@@ -1776,7 +1786,10 @@ struct RowSolver {
 #ifdef A1X_CLK
             const long long t1_ = clock64();
 #endif
+            [[maybe_unused]] long long pf2_ = 0;
+            if constexpr (CLK) pf2_ = row_clock();
             update_info();
+            if constexpr (CLK) pfU += row_clock() - pf2_;
 #ifdef A1X_CLK
             clkU += clock64() - t1_;
 #endif
@@ -1845,8 +1858,8 @@ struct RowSolver {
                 const double xu = nanout ? nanv : xh[k];
                 if (io.u_full) io.u_full[t * 12 + ci] = xu;
                 // A failed solve must not poison the carried workspace (every later tick of this robot would start from NaN): the next
-                // tick is a cold start -- x = y = 0 and, below, rho = 0 = "use settings.rho" (OSQP's store_solution() cold-starts its
-                // iterates after a failed solve)
+                // tick starts from cold iterates -- x = y = 0 (OSQP's store_solution() cold-starts its iterates after a failed solve) -- with the rho
+                // the solver had reached, like OSQP (below)
                 if (io.warm_x) io.warm_x[t * 12 + ci] = nanout ? 0.0 : xu;
                 if (io.warm_y) {  // y = c^-1 E y_s = c^-1 rr (wh - Pi(wh))
                     const double z0 = fmin(fmax(wh0[k], lbs<k>(t)), ubs<k>(t)), z1 = fmin(wh1[k], 0.0);
@@ -1868,7 +1881,7 @@ struct RowSolver {
             if (io.iters) *io.iters = iter;
             if (io.status) *io.status = status_out;
             if (io.nfact) *io.nfact = nfact;
-            if (io.rho_io) *io.rho_io = nanout ? 0.0 : rho;
+            if (io.rho_io) *io.rho_io = rho;   // also after a failed solve: OSQP's cold_start() zeroes x, z, y and leaves the rho it had adapted in settings->rho (round 4; until then 0 = "settings.rho")
         }
     }
 };
@@ -1892,6 +1905,7 @@ struct BatchArgs {
     int32_t* cost;
     int32_t predict;  // the set-up kernel writes its cost guess to `cost` (first solve of a batch: no history to order the queue by)
     double* carry;    // warm_start = 2 (update path): n x Carry<H>::STRIDE, or null
+    long long* clk;   // profiling instantiation (a1mpc_set_profiling): n x 3 shader-clock cycles per QP [factor passes, iteration segments, residual checks], or null
 };
 template <int H, int MODE>
 A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
@@ -1959,9 +1973,9 @@ A1_DEV void setup_row(const BatchArgs& a, const double* __restrict__ tab, int64_
 // split pipeline, kernel 2: a persistent row.  It pulls prepared QPs from a shared counter and advances them one
 // checkpoint-aligned segment per loop trip; a row whose QP has converged writes it out and pulls the next one at the next
 // trip, so the rows of a wave never wait for each other's iteration counts -- only for each other's (rare) re-factorisations.
-template <int H, bool TWIN = false, bool GEN = false, bool UPD = false, bool UNI = false>
+template <int H, bool TWIN = false, bool GEN = false, bool UPD = false, bool UNI = false, bool CLK = false>
 A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* __restrict__ counter, double* __restrict__ lds) {
-    RowSolver<H, kModeMpc, false, GEN, TWIN, UNI> S(a.P, a.tab, lds);
+    RowSolver<H, kModeMpc, false, GEN, TWIN, UNI, CLK> S(a.P, a.tab, lds);
     bool alive = true, need_new = true, have = false;
     int64_t cur = 0;
     while (alive) {
@@ -1970,6 +1984,7 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
                 if constexpr (UPD) S.write_outputs(make_io<H, kModeMpc>(a, cur), carry_of<H>(a, cur));
                 else S.write_outputs(make_io<H, kModeMpc>(a, cur));
                 if (a.cost != nullptr && S.ln == 0 && !S.twin) a.cost[cur] = S.iter + 10 * S.nfact;  // ~ ADMM-iteration equivalents (a factor pass ~ 10)
+                if constexpr (CLK) { if (a.clk != nullptr && S.ln == 0 && !S.twin) { a.clk[cur * 3 + 0] = S.pfX; a.clk[cur * 3 + 1] = S.pfT; a.clk[cur * 3 + 2] = S.pfU; } }
             }
             double v = 0.0;
             if (S.ln == 0 && !S.twin) {

@@ -440,6 +440,9 @@ A1_DEV double twin_from_main(double v) {
 // true if the predicate holds on any live lane of the wavefront (= any row that is still running)
 A1_DEV bool row_wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 
+// shader clock (s_memtime); the profiling instantiation of the persistent ADMM kernel stamps its stages with it (RowSolver<.., CLK>)
+A1_DEV long long row_clock() { return clock64(); }
+
 // returns the old value; called by one lane of a row (the work queue of the persistent ADMM rows)
 A1_DEV int row_atomic_inc(int* p) { return atomicAdd(p, 1); }
 

@@ -593,21 +593,31 @@ def main():
         return pipe.submit_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], o[0], None, o[1], o[2], fresh=True, after_stream=after)
 
     spin_up = max(0, 8 - args.warmup)     # (untimed, like the warm-up steps: with fewer than ~8 launches behind it the first timed steps run on a GPU that has not clocked up yet -- measured
-    for k in range(spin_up + args.warmup):  #  0.72 vs 0.68 ms per step with --warmup 3; reported as config.untimed_launches_before_timing)
-        submit(k)
+                                          #  0.72 vs 0.68 ms per step with --warmup 3; reported as config.untimed_launches_before_timing)
+
+    def region(steps):
+        """`steps` batches through the pipeline exactly the way the timed region issues them: the first launch of every slot starts behind an event on `stream`, an
+        event sits behind the last launch of every slot.  The warm-up runs through here too: the first use of the cross-stream waits and of the events costs the
+        HIP runtime ~0.7 ms on the GPU timeline and several ms on the host (tools/pipe_start_probe.py: first region 0.66 ms per batch, every later one 0.625) --
+        a one-off of the process, not of a step, so it belongs to the warm-up."""
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for k in range(steps):
+            submit(k, after=stream.cuda_stream if k < depth else None)   # the first launch of every slot starts behind e0
+        pipe.join(stream.cuda_stream)     # ... and e1 sits behind the last launch of every slot: HIP events around the region
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0, e1
+
+    if spin_up + args.warmup > 0:
+        region(spin_up + args.warmup)     # W untimed warm-up steps (+ the spin-up launches)
     pipe.wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    e0.record(stream)
-    for k in range(args.steps):
-        submit(k, after=stream.cuda_stream if k < depth else None)   # the first launch of every slot starts behind e0
-    pipe.join(stream.cuda_stream)         # ... and e1 sits behind the last launch of every slot: HIP events around the timed region
-    e1.record(stream)
-    torch.cuda.synchronize()
+    e0, e1 = region(args.steps)           # EXACTLY K timed steps, bracketed by a barrier + synchronize on both sides
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

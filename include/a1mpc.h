@@ -353,13 +353,14 @@ a1mpc_status a1mpc_reset_warm_start(a1mpc_handle h);
 /* Read / write the carried OSQP workspace of problems 0..n-1 (the reference keeps it inside its persistent
  * OsqpEigen::Solver member, S/A1RobotControl.h:67): x n x 12H (world-frame forces), y n x 20H (reference row order), rho n
  * (0 = "start from settings.rho").  Any pointer may be NULL.  Host pointers; synchronises the handle's stream.  A solve whose
- * solution is not finite leaves (0, 0, 0) behind, i.e. the next tick of that problem is a cold start (OSQP's store_solution()
- * cold-starts its iterates after a failed solve), so one bad tick cannot poison the ticks after it.  One deliberate difference: OSQP's
- * cold_start() zeroes x, y, z but leaves the rho it had adapted in settings->rho, so the real solver's next tick starts from that rho;
- * this library (and the oracle) restart from the configured rho, because a rho adapted on the way to a non-finite point is not worth
- * keeping.  A status without a solution is the only place the two differ, and the reference's QP (bounded forces, convex cost) never
- * produced one in any parity run.  With warm_start = 2 an injected state also clears the
- * update path's carry of these problems: their next tick is a fresh set-up warm-started from (x, y, rho), the ticks after it follow the update path again. */
+ * solution is not finite leaves x = y = 0 behind, i.e. the next tick of that problem starts from cold iterates (OSQP's store_solution()
+ * cold-starts its iterates after a failed solve), so one bad tick cannot poison the ticks after it -- and, since round 4, the rho the
+ * solver had reached, exactly as OSQP's cold_start() leaves the adapted rho in settings->rho (the reference ignores the solver's return
+ * code, S/A1RobotControl.cpp:540, so its next tick does run with that rho; engine and oracle used to restart from the configured rho).
+ * With warm_start = 2 an injected state is re-expressed on the update path's workspace the way osqp_warm_start_x / _y do it on the
+ * reference's persistent solver (round 4): x and y replace the carried iterates, z becomes A x, the previous tick's scalings and gradient
+ * stay, and the next tick follows the update path from there (until round 4 an injected state cleared the carry and the next tick was a
+ * fresh set-up). */
 a1mpc_status a1mpc_warm_start(a1mpc_handle h, int32_t n, const double* x, const double* y, const double* rho);
 a1mpc_status a1mpc_get_warm_start(a1mpc_handle h, int32_t n, double* x_out, double* y_out, double* rho_out);
 /* warm_start = 2 only: the unscaled z = Pi(w) of problems 0..n-1 that the update path keeps beside (x, y, rho) -- what OSQP leaves in work->z, n x 20H in the
@@ -374,6 +375,15 @@ a1mpc_status a1mpc_get_workspace_z(a1mpc_handle h, int32_t n, double* z_out);
  * z_s = E z, y_s = c y / E): a second implementation of the update path can be started from it (the parity tests re-seed the oracle that way).
  * Any pointer may be NULL.  Host pointers; synchronises the handle's stream. */
 a1mpc_status a1mpc_get_workspace_scaling(a1mpc_handle h, int32_t n, double* D_out, double* E_out, double* c_out);
+/* Stage counters of the solve (the reference brackets its tick with stopwatches t1..t6, S/A1RobotControl.cpp:491-553; a1mpc_last_stage_ms gives
+ * set-up | solve by HIP events).  a1mpc_set_profiling(h, 1): batches that go through the split pipeline (more QPs than the resident rows; horizon > 1,
+ * warm_start != 2, contacts broadcast) run a clock-stamped instantiation of the persistent ADMM kernel -- the same arithmetic, the same results bit for bit,
+ * shader-clock stamps around every factor pass, iteration segment and residual check (outside the hot loop).  a1mpc_last_stage_cycles then returns the cycles
+ * summed over the QPs of the last profiled solve: [0] Riccati factor passes, [1] ADMM iterations, [2] residual checks + rho updates; *qps_out = the number of
+ * QPs summed (0: the last solve was not profiled).  A QP's cycles include the time its wavefront spent on its wave-mate's divergent stages; the three sums'
+ * ratio splits a1mpc_last_stage_ms' solve stage.  Host call; synchronises the handle's stream. */
+a1mpc_status a1mpc_set_profiling(a1mpc_handle h, int32_t on);
+a1mpc_status a1mpc_last_stage_cycles(a1mpc_handle h, double* cycles3_out, int32_t* qps_out);
 /* Which warm-start semantics the handle's last MPC solve actually ran: 0 (cold), 1 (fresh set-up + osqp_warm_start) or 2 (the reference's update path).
  * warm_start = 2 exists on the fast path at horizons 10 / 16 / 20; a solve through the general path (per-step feet, a separate A_c yaw) or at horizon 1
  * runs mode 1 instead (documented at a1mpc_config.warm_start) -- this call makes that visible to the caller.  -1 before the first solve. */

@@ -538,7 +538,7 @@ done:
     }
     if (carry) {  /* what stays in the reference's workspace for the next tick's update calls */
         const int failed = info->status == ORC_PRIMAL_INFEASIBLE || info->status == ORC_DUAL_INFEASIBLE || info->status == ORC_NON_CVX;
-        carry[0] = 1.0; carry[1] = failed ? st->rho : w.rho;   /* (a failed solve: the next tick starts from settings->rho, like the engine's cold start after a failure) */
+        carry[0] = 1.0; carry[1] = w.rho;   /* (also after a failed solve: cold_start() zeroes the iterates, settings->rho keeps what adapt_rho left there) */
         for (int j = 0; j < n; ++j) c_xs[j] = failed ? 0.0 : w.x[j];               /* store_solution: cold_start after a failed solve */
         for (int i = 0; i < m; ++i) { c_zs[i] = failed ? 0.0 : w.z[i]; c_ys[i] = failed ? 0.0 : w.y[i]; }
         memcpy(c_q, q, sizeof(double) * n); memcpy(c_l, l, sizeof(double) * m); memcpy(c_u, u, sizeof(double) * m);
@@ -772,9 +772,9 @@ int orc_mpc_solve(const orc_mpc_params *pr, const orc_settings *st, const double
     if (u_full) memcpy(u_full, x, sizeof(double) * n);
     if (warm_x) {
         /* A failed solve (NaN solution) must not poison the carried workspace: OSQP's store_solution() cold-starts the iterates in
-         * that case; here the next tick is a full cold start (x = y = 0, rho back to settings->rho). */
+         * that case (x = y = 0); the rho the solver had reached stays, as OSQP leaves it in settings->rho (round 4). */
         int failed = info->status == ORC_PRIMAL_INFEASIBLE || info->status == ORC_DUAL_INFEASIBLE || info->status == ORC_NON_CVX;
-        if (failed) { memset(warm_x, 0, sizeof(double) * n); memset(warm_y, 0, sizeof(double) * m); if (warm_rho) *warm_rho = 0; }
+        if (failed) { memset(warm_x, 0, sizeof(double) * n); memset(warm_y, 0, sizeof(double) * m); }   /* (warm_rho: what the solve left, like OSQP's settings->rho) */
         else { memcpy(warm_x, x, sizeof(double) * n); memcpy(warm_y, y, sizeof(double) * m); }
     }
     return rc;

@@ -170,6 +170,7 @@ inline const double* row_lds_at(const double* p) { return p + OFF; }
 
 
 inline bool row_wave_any(bool p) { return p; }  // one row per emulated wave
+inline long long row_clock() { return 0; }   // (no clock on the host fibers: the profiling instantiation is never emulated)
 inline int row_atomic_inc(int* p) { return (*p)++; }
 
 }  // namespace a1mpc

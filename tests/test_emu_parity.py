@@ -159,8 +159,8 @@ def test_emulated_general_path_matches_strided_oracle(oracle, scen, h, feet, con
 
 
 def test_emulated_failed_tick_does_not_poison_warm_start(oracle, scen):
-    """a NaN tick with warm start on must leave a cold start behind, not NaN -- tick k+1 equals a cold solve, in the
-    solver source and in the oracle alike."""
+    """a NaN tick with warm start on must leave cold iterates behind, not NaN -- tick k+1 starts from x = y = 0 with the rho the solver had (OSQP's
+    store_solution() -> cold_start()), in the solver source and in the oracle alike."""
     sc = scen.config2_trot_sequence(3)
     pr = oracle_params(oracle, sc); st = oracle.default_settings(warm_start=1)
     ewx = np.zeros((1, 120)); ewy = np.zeros((1, 200)); erho = np.zeros(1)
@@ -174,12 +174,11 @@ def test_emulated_failed_tick_does_not_poison_warm_start(oracle, scen):
         wx, wy, rho = r["warm_x"], r["warm_y"], r["rho"]
         if t == 1:
             assert out["status"][0] == -7 == r["info"].status and (out["grf"] == 0).all() and (r["grf"] == 0).all()
-            assert (ewx == 0).all() and (ewy == 0).all() and erho[0] == 0 and (wx == 0).all() and (wy == 0).all() and rho == 0
+            assert (ewx == 0).all() and (ewy == 0).all() and (wx == 0).all() and (wy == 0).all()
+            assert erho[0] == rho_before[0] and rho == rho_before[1] and rho_before[0] > 0    # the rho each solver had stays (OSQP's cold_start() keeps settings->rho), round 4
         else:
             assert out["status"][0] == 1 and out["iters"][0] == r["info"].iters and np.abs(out["u"][0] - r["u"]).max() < 1e-8
-        if t == 2:
-            cold = emu.solve(one, 1)
-            assert cold["iters"][0] == out["iters"][0] and np.abs(cold["u"] - out["u"]).max() < 1e-12
+        rho_before = (float(erho[0]), float(rho))
 
 
 # ---- main / twin pairs of rows (RowSolver<.., TWIN>: what every device kernel with H > 1 runs) ------------------------------------------------
@@ -281,7 +280,7 @@ def test_emulated_general_path_split_pipeline(scen, h, feet, cont, rows):
 def test_emulated_update_path_matches_oracle(oracle, scen, path):
     """warm_start = 2, the reference's tick >= 2 UPDATE path (S/A1RobotControl.cpp:533-538): previous gradient in the Ruiz cost normalisation, carried iterates
     read in the new scaling, first iteration from the carried z -- the solver source, lane for lane, against the oracle's restatement of OSQP's update
-    functions (orc_mpc_solve_update): same iteration count every tick, forces to 1e-8 N, through a contact switch and a failed tick."""
+    functions (orc_mpc_solve_update): same iteration count every tick, forces to 1e-8 N (1e-7 N after the failed tick), through a contact switch and a failed tick."""
     seq = scen.config2_trot_sequence(70)
     pr = oracle_params(oracle, seq); st = oracle.default_settings(warm_start=1)
     kw = dict(fused_twin=dict(twin=True), split_twin=dict(split_rows=1, twin=True), single_row=dict())[path]
@@ -297,11 +296,11 @@ def test_emulated_update_path_matches_oracle(oracle, scen, path):
         one["x0"] = x0[None]
         e = emu.solve(one, n=1, warm=(wx, wy, rho), carry=carry, warm_start=2, **kw)
         assert e["iters"][0] == o["info"].iters and e["status"][0] == o["info"].status, (path, k, e["iters"], o["info"].iters)
-        assert np.abs(e["grf"][0] - o["grf"]).max() < 1e-8, (path, k)
+        assert np.abs(e["grf"][0] - o["grf"]).max() < (1e-8 if i <= 9 else 1e-7), (path, k)   # (after the failed tick both go on from the rho THEY had reached, equal to ~1e-8 relative: round 4)
         if i == 9:
             assert o["info"].status == -7 and not e["grf"].any()
         elif i > 0:
-            assert abs(rho[0] - carry_o[1]) <= 1e-9 * carry_o[1]
+            assert abs(rho[0] - carry_o[1]) <= 1e-7 * carry_o[1]   # (the adapted rho is a quotient of residual norms: round-off level differences between two implementations are amplified ~1e3 x)
 
 
 @pytest.mark.parametrize("path", ["fused_twin", "split_twin"])

@@ -706,22 +706,26 @@ def test_contact_schedule_alone_stays_on_the_fast_kernels(pkg, oracle, scen, h, 
 
 def test_failed_tick_leaves_a_cold_start_behind(pkg, oracle, scen):
     """warm start ON, a NaN tick for some robots -> status -7 and zero GRFs for them at that tick, and at the NEXT tick
-    they are solved again (a cold start: same answer as a cold solve) instead of staying NaN for ever."""
+    they are solved again from cold iterates (x = y = 0) instead of staying NaN for ever -- with the rho the solver had reached, as OSQP's
+    store_solution() -> cold_start() leaves it (the reference ignores the return code, its next tick runs with that rho)."""
     n = 64
     sc = scen.config3_random_flat(nb=n)
     bad = np.zeros(n, bool); bad[[3, 17, 40]] = True
     with _engine(pkg, sc, n, warm_start=1) as eng:
         eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+        _, _, rho0 = eng.get_warm_start(n)
         x0 = sc["x0"].copy(); x0[bad, 4] = np.nan
         o1 = eng.solve(x0, sc["xref"], sc["R"], sc["foot"], sc["contact"])
         assert (o1["status"][bad] == -7).all() and (o1["grf"][bad] == 0).all() and (o1["status"][~bad] == 1).all()
         wx, wy, rho = eng.get_warm_start(n)
-        assert (wx[bad] == 0).all() and (wy[bad] == 0).all() and (rho[bad] == 0).all() and np.isfinite(wx).all() and np.isfinite(wy).all()
+        assert (wx[bad] == 0).all() and (wy[bad] == 0).all() and np.isfinite(wx).all() and np.isfinite(wy).all()
+        assert np.array_equal(rho[bad], rho0[bad]) and (rho0[bad] > 0).all()    # the failed solve never got to adapt: the rho it was started with stays
         o2 = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
-    with _engine(pkg, sc, n, warm_start=0) as eng:
-        cold = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
     assert (o2["status"] == 1).all()
-    assert np.array_equal(o2["u"][bad], cold["u"][bad]) and np.array_equal(o2["iters"][bad], cold["iters"][bad])
+    pr = oracle_params(oracle, sc); st = oracle.default_settings(warm_start=1)
+    for i in np.flatnonzero(bad):   # cold iterates + the carried rho: the oracle started the same way
+        r = oracle.mpc_solve(pr, st, sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i], warm_x=np.zeros(120), warm_y=np.zeros(200), warm_rho=rho[i])
+        assert o2["iters"][i] == r["info"].iters and np.abs(o2["u"][i] - r["u"]).max() <= TOL_FORCE_N, i
 
 
 def test_update_config_dt_and_warm_start_io(pkg, oracle, scen):
@@ -1110,7 +1114,7 @@ def test_update_path_carry_is_dropped_by_ticks_that_do_not_refresh_it(pkg, oracl
         # align the two handles' carried (x, y, rho), then a general-path tick on both
         x, y, rho = e2.get_warm_start(n)
         e1.set_warm_start(x, y, rho)
-        e2.set_warm_start(x, y, rho)   # (also clears e2's carry: the documented effect of an injected state)
+        e2.set_warm_start(x, y, rho)   # (the same values it holds: a no-op on the iterates; the general-path tick below is what drops the carry)
         a = e2.solve_strided(seq[2]["x0"], seq[2]["xref"], seq[2]["R"], f2, 12, c2, 4)
         b = e1.solve_strided(seq[2]["x0"], seq[2]["xref"], seq[2]["R"], f2, 12, c2, 4)
         assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"])
@@ -1139,6 +1143,48 @@ def test_update_path_carry_is_dropped_by_ticks_that_do_not_refresh_it(pkg, oracl
         a = e2.solve(seq[4]["x0"], seq[4]["xref"], seq[4]["R"], seq[4]["foot"], seq[4]["contact"])
         b = e1.solve(seq[4]["x0"], seq[4]["xref"], seq[4]["R"], seq[4]["foot"], seq[4]["contact"])
         assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"]), "stale update-path carry used after a1mpc_update_config"
+
+
+def test_update_path_injected_warm_start_is_reexpressed_on_the_workspace(pkg, oracle, scen):
+    """with warm_start = 2 an a1mpc_warm_start(x, y, rho) no longer clears the update path's carry; it does what osqp_warm_start_x / _y do on the
+    reference's persistent solver -- x and y replace the iterates, z becomes A x, the previous tick's scalings / gradient / bounds stay -- and the next tick follows
+    the update path from there.  Checked against the oracle started from exactly that workspace (carry_from_workspace with the ENGINE's scalings of the last tick,
+    the injected x and y, z = A x): same iteration count, forces within the parity tolerance, on every robot; and the tick differs from what a cleared carry gives."""
+    n = 48
+    rng = np.random.default_rng(91)
+    sc = scen.config3_random_flat(nb=n, seed=9100)
+    seq = []
+    for t in range(4):
+        if t > 0:
+            sc["x0"][:, :12] += rng.normal(0, 2e-3, (n, 12))
+        seq.append({k: np.array(v) if isinstance(v, np.ndarray) else v for k, v in sc.items()})
+    pr = oracle_params(oracle, sc); st = oracle.default_settings(warm_start=1); h = 10; mu = sc["params"]["mu"]
+    with _engine(pkg, sc, n, warm_start=2) as eng:
+        for t in (0, 1, 2):
+            eng.solve(seq[t]["x0"], seq[t]["xref"], seq[t]["R"], seq[t]["foot"], seq[t]["contact"])
+        x, y, rho = eng.get_warm_start(n); D, E, c = eng.get_workspace_scaling(n)
+        xi = x * (1.0 + rng.normal(0, 0.02, x.shape)); yi = y * (1.0 + rng.normal(0, 0.02, y.shape)); ri = rho * 1.5    # the injected state: NOT what the last tick left
+        eng.set_warm_start(xi, yi, ri)
+        zi = eng.get_workspace_z(n)
+        f = xi.reshape(n, h, 4, 3)
+        zA = np.stack([f[..., 0] + mu * f[..., 2], f[..., 0] - mu * f[..., 2], f[..., 1] + mu * f[..., 2], f[..., 1] - mu * f[..., 2], f[..., 2]], axis=-1).reshape(n, 20 * h)
+        assert np.abs(zi - zA).max() < 1e-12     # z = A x (osqp_warm_start_x)
+        out = eng.solve(seq[3]["x0"], seq[3]["xref"], seq[3]["R"], seq[3]["foot"], seq[3]["contact"], want_u=True)
+        assert eng.last_warm_start_mode() == 2
+    worst = 0.0
+    for i in range(n):
+        P, g, _, l, u, _ = oracle.mpc_form(pr, seq[2]["x0"][i], seq[2]["xref"][i], seq[2]["R"][i], seq[2]["foot"][i], seq[2]["contact"][i])   # the previous tick's data stays in the workspace
+        carry = oracle.carry_from_workspace(h, xi[i], yi[i], zA[i], ri[i], D[i], E[i], c[i], P, g, l, u)
+        r = oracle.mpc_solve_update(pr, st, seq[3]["x0"][i], seq[3]["xref"][i], seq[3]["R"][i], seq[3]["foot"][i], seq[3]["contact"][i], carry)
+        assert out["iters"][i] == r["info"].iters and out["status"][i] == r["info"].status, (i, out["iters"][i], r["info"].iters)
+        worst = max(worst, float(np.abs(out["u"][i] - r["u"]).max()))
+    assert worst <= TOL_FORCE_N, worst
+    # ... and this is not what a cleared carry (a fresh set-up warm-started from the same x, y, rho: mode 1) would have returned
+    with _engine(pkg, sc, n, warm_start=1) as e1:
+        e1.set_warm_start(xi, yi, ri)
+        m1 = e1.solve(seq[3]["x0"], seq[3]["xref"], seq[3]["R"], seq[3]["foot"], seq[3]["contact"], want_u=True)
+    assert np.abs(m1["u"] - out["u"]).max() > 1e-6
+    print(f"injected warm start on the update path: {n} robots, worst |du| vs the oracle from the same workspace {worst:.2e} N")
 
 
 @pytest.mark.parametrize("n", [1, 200])
@@ -1251,3 +1297,27 @@ def test_ten_thousand_warm_started_ticks_batch_1(pkg, oracle, scen, mode):
     else:            # the update path: at most a handful of partings in 10 000 ticks, every other tick within the tolerance (by construction of the count)
         assert len(diverged) <= 10 and worst <= TOL_FORCE_N, (mode, diverged, int(errs.argmax()), worst)
         assert seeded is None or diverged[-1] == nt - 1
+
+
+@pytest.mark.parametrize("gen,n", [("config3_random_flat", 4096), ("config4_random_h16", 2560), ("config5_divergent", 2048)])
+def test_stage_cycles_through_the_abi(pkg, scen, gen, n):
+    """VERDICT r3 item 9 / SURVEY 5 (the reference's t1..t6 stopwatches, S/A1RobotControl.cpp:491-553): a1mpc_set_profiling runs the clock-stamped instantiation of the
+    persistent ADMM kernel -- bit-identical results -- and a1mpc_last_stage_cycles splits the solve stage into factor passes | iterations | residual checks."""
+    sc = getattr(scen, gen)(nb=n)
+    with _engine(pkg, sc, n, warm_start=0) as eng:
+        a = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+        assert eng.last_stage_cycles()["qps"] == 0          # not profiled
+        eng.set_profiling(True)
+        b = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+        cyc = eng.last_stage_cycles(); nf = eng.last_nfact(n)
+        eng.set_profiling(False)
+        c = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+        assert eng.last_stage_cycles()["qps"] == 0
+    for k in ("grf", "u", "iters", "status"):
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
+    assert cyc["qps"] == n and min(cyc["factor"], cyc["iterate"], cyc["check"]) > 0
+    tot = cyc["factor"] + cyc["iterate"] + cyc["check"]
+    per_it = cyc["iterate"] / float(a["iters"].sum()); per_f = cyc["factor"] / float(nf.sum())
+    print(f"{gen} x {n}: factor {cyc['factor'] / tot:.3f} | iterate {cyc['iterate'] / tot:.3f} | check {cyc['check'] / tot:.3f} of the solve stage; "
+          f"{per_it:.0f} cycles per iteration, {per_f:.0f} per factor pass (wave-mates' stalls included)")
+    assert 0.5 < cyc["iterate"] / tot < 0.95 and 0.03 < cyc["factor"] / tot < 0.45
