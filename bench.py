@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
-PMC_SUMMARY = "r03_pmc_summary.json"   # static rocprofv3 --pmc summary of this round (tools/collect_profiles.sh + summarize_profiles.py)
+PMC_SUMMARY = "r04_pmc_summary.json"   # static rocprofv3 --pmc summary of this round (tools/collect_profiles.sh + summarize_profiles.py)
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (AMD spec; = 1/2 of the 157.3 TF FP32 rate in MI355X_MICROARCH.md)
 BATCH = 4096
 HORIZON = 10
@@ -649,6 +649,20 @@ def main():
     gpu_grf0 = None
     step(0); torch.cuda.synchronize(); gpu_grf0 = grf.cpu().numpy().copy()
     it, stt = work[0][0], work[0][1]
+    # stage counters (the reference's t1..t6 stopwatches): set-up | solve by HIP events, the solve stage split into factor passes | iterations | residual checks by
+    # the clock-stamped instantiation of the ADMM kernel (a1mpc_set_profiling; the same results bit for bit) -- one extra solve of batch 0, outside every timed region
+    stage = None
+    try:
+        eng.set_profiling(True); step(0); torch.cuda.synchronize()
+        cyc = eng.last_stage_cycles(); sms = eng.last_stage_ms(); eng.set_profiling(False)
+        tot = cyc["factor"] + cyc["iterate"] + cyc["check"]
+        if cyc["qps"] == n and tot > 0:
+            stage = {"setup_ms": sms[0], "solve_ms": sms[1], "solve_split": {"factor_passes": cyc["factor"] / tot, "iterations": cyc["iterate"] / tot, "residual_checks": cyc["check"] / tot},
+                     "cycles_per_iteration": cyc["iterate"] / float(work[0][0].sum()), "cycles_per_factor_pass": cyc["factor"] / float(work[0][2].sum()),
+                     "source": "a1mpc_last_stage_ms (HIP events) + a1mpc_last_stage_cycles (shader-clock stamps in the profiling instantiation of the persistent ADMM kernel; a QP's cycles "
+                               "include its wave-mate's divergent stages)"}
+    except Exception as e:   # (a library without the profiling entry points)
+        stage = {"error": str(e)}
     pipe_same = bool(np.array_equal(pipe_out0[0], gpu_grf0) and np.array_equal(pipe_out0[1], it) and np.array_equal(pipe_out0[2], stt))
     # the same batches with the queue ordered by history (each batch re-solved right after itself) and in plain index order: reported beside `value`
     index_ms = hist_ms = None
@@ -698,7 +712,7 @@ def main():
                                            "solves_per_s": n / (single_ms * 1e-3),
                                            "executed_fp64_frac": (pmc["executed_fp64_flops_per_launch"] / (single_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if pmc.get("executed_fp64_flops_per_launch") else None,
                                            "what": "the same first solves through ONE handle on one stream, launches serialised: the sum of the three kernels' durations in a kernel trace "
-                                                   "(profiles/r03_kernel_stats_bench_depth1_batch4096_h10.csv)"},
+                                                   "(profiles/r04_kernel_stats_bench_depth1_batch4096_h10.csv)"},
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
                          "executed_fp64_flops_per_launch": pmc.get("executed_fp64_flops_per_launch"),
                          "executed_fp64_frac": (pmc["executed_fp64_flops_per_launch"] / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if pmc.get("executed_fp64_flops_per_launch") else None,
@@ -707,6 +721,7 @@ def main():
                                  "would execute; the structured Riccati solve executes 1.5x / 2.8x / 3.9x fewer flops at h = 10 / 16 / 20), `executed_fp64_frac` prices the FP64 flops "
                                  "the kernels really issue (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 x live lanes from the static PMC profile) -- the hardware fraction"},
         }
+        out["stage_counters"] = stage
         out["scheduling"] = {
             "mode": "value: first solves (no history; queue ordered by the set-up kernel's per-QP cost guess).  Beside it: plain index order, and "
                     "'history' = the same batch solved again right after itself with the queue in longest-first order of the previous solve "

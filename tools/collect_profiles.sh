@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel trace of the default bench + PMC passes of the hot kernels (counters in their own
 # runs, one group per pass, never combined with trace domains).  usage: tools/collect_profiles.sh [round tag, default r02]
 # Outputs under gpurun_out/prof_<tag>/ ; tools/summarize_profiles.py <tag> copies the summaries into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$TAG
@@ -27,7 +27,9 @@ done
 for shape in "65536,10" "8192,16" "32768,20"; do
   for set in "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE FETCH_SIZE WRITE_SIZE"; do
     tag=$(echo $set | cut -d' ' -f1)
-    A1_SHAPE=$shape timeout 200 rocprofv3 --pmc $set -d $O/shape_${shape/,/x}_$tag --output-format csv -- python tools/prof_target.py > /dev/null 2>&1
+    # h = 16: the executed-FP64 count comes from the one-wave kernels (24 live lanes in every instruction: exact; the CU-wide kernel runs the same arithmetic per QP)
+    A1MPC_CU_WIDE=0 A1_SHAPE=$shape timeout 200 rocprofv3 --pmc $set -d $O/shape_${shape/,/x}_$tag --output-format csv -- python tools/prof_target.py > /dev/null 2>&1
+    [ "$shape" = "8192,16" ] && A1_SHAPE=$shape timeout 200 rocprofv3 --pmc $set -d $O/shape_${shape/,/x}cu_$tag --output-format csv -- python tools/prof_target.py > /dev/null 2>&1
   done
   A1_SHAPE=$shape timeout 200 rocprofv3 --kernel-trace --stats -d $O/shape_${shape/,/x}_trace --output-format csv -- python tools/prof_target.py > $O/shape_${shape/,/x}_trace.log 2>&1
 done

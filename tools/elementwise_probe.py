@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""HBM roofline of the element-wise caller-side kernels (N2a update_plan, N3 joint torques, N2b contact/terrain) at 65536 robots:
-algorithmic bytes per robot / kernel time (HIP events inside the library, a1mpc_last_kernel_ms).  Prints one JSON line."""
+"""HBM roofline of the element-wise caller-side kernels (N2a update_plan, N3 joint torques, N2b contact/terrain, N4a / N4b / N4c): algorithmic bytes per robot / kernel time
+(HIP events inside the library, a1mpc_last_kernel_ms).  usage: elementwise_probe.py [robots, default 65536].  A working set inside the 256 MiB Infinity Cache measures
+cache bandwidth, not HBM (MI355X_MICROARCH.md: scale past L3 before reading a bandwidth): run with >= 524288 robots for the HBM figures (A1_SKIP_N2B=1 skips the
+70-tick N2b sequence, which tools/ubench/n2b_bench measures at that size).  Prints one JSON line."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -40,7 +42,8 @@ with pkg.Engine(cfg, n, 0) as eng:
         b = 8 * 22 + 4 + 8 * 14 + 4 + 384 + la * (64 + 32 + 24) + 120 + 16
         t = float(np.median(ms[-5:]))
         return {"kernel_ms": t, "robots": nn, "legs_in_contact_per_robot": la, "bytes_per_robot": b, "GB_per_s": nn * b / (t * 1e-3) / 1e9}
-    out["N2b contact_terrain (one fused kernel since round 3; random filter phases, windows full)"] = n2b(eng, n)
+    if os.environ.get("A1_SKIP_N2B") != "1":
+        out["N2b contact_terrain (one fused kernel since round 3; random filter phases, windows full)"] = n2b(eng, n)
     # N4b leg kinematics, N4a swing legs, N4c EKF
     q = rng.uniform(-1, 1, (n, 12)); qd = rng.normal(0, 2, (n, 12)); pos = rng.normal(0, 1, (n, 3)); vel = rng.normal(0, 1, (n, 3))
     ms = []
@@ -61,7 +64,10 @@ with pkg.Engine(cfg, n, 0) as eng:
     fl = 2 * (18 * 18 * 2 + 28 * 18 * 2 + 28 * 28 * 28 + 28 * 28 + 28 * 4 + 18 * 28 + 18 * 28 * 18 + 18 * 18 * 18)  # products + the in-place 28 x 28 inverse (round 3; the 47-wide tableau until then: 28 * 28 * 47) + S^-1 e, S^-1 C: flops per robot
     out["N4c ekf (init + update kernels)"] = {"kernel_ms": float(np.median(ms[2:])), "bytes_per_robot": b, "GB_per_s": n * b / (float(np.median(ms[2:])) * 1e-3) / 1e9,
                                               "flops_per_robot": fl, "TFLOP_per_s": n * fl / (float(np.median(ms[2:])) * 1e-3) / 1e12}
-if os.environ.get("A1_N2B_LARGE", "1") != "0":
+if os.environ.get("A1_N2B_LARGE", "1") != "0" and os.environ.get("A1_SKIP_N2B") != "1":
     with pkg.Engine(cfg, 8 * n, 0) as big:
         out["N2b contact_terrain, 8 x the robots"] = n2b(big, 8 * n)
-print(json.dumps({"robots": n, "peak_GB_per_s": 8000, "kernels": out}))
+for v in out.values():
+    v["frac_of_achievable_6300_GB_per_s"] = v["GB_per_s"] / 6300.0
+    v["working_set_MB"] = v["bytes_per_robot"] * (v.get("robots", n)) / 1e6
+print(json.dumps({"robots": n, "peak_GB_per_s": 8000, "achievable_GB_per_s": 6300, "infinity_cache_MB": 256, "kernels": out}))

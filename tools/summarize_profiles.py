@@ -38,7 +38,7 @@ def overlap_summary(trace_dir):
         return None
     rows = [r for r in csv.DictReader(open(f)) if "a1mpc" in r.get("Kernel_Name", "") and "noop" not in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    admm = [r for r in rows if "admm_kernel" in r["Kernel_Name"]]
+    admm = [r for r in rows if "a1mpc_admm" in r["Kernel_Name"]]
     setup = [r for r in rows if "setup_kernel" in r["Kernel_Name"]]
     if len(admm) < 12 or len(setup) < 12:
         return None
@@ -95,7 +95,7 @@ summ["executed_fp64_flops_per_launch"] = ex
 # the other shapes (collect_profiles.sh: A1_SHAPE passes of tools/prof_target.py): per kernel and launch, counters + kernel durations
 by_cfg, shapes = {}, {}
 for d in sorted(glob.glob(os.path.join(src, "shape_*_SQ_INSTS_VALU_FMA_F64"))) + sorted(glob.glob(os.path.join(src, "shape_*_SQ_LDS_BANK_CONFLICT"))):
-    shape = os.path.basename(d).split("_")[1]
+    shape = os.path.basename(d).split("_")[1]   # "8192x16", or "8192x16cu" = the same batch on the CU-wide kernel (collect_profiles.sh)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         a2 = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
@@ -106,8 +106,11 @@ for d in sorted(glob.glob(os.path.join(src, "shape_*_SQ_INSTS_VALU_FMA_F64"))) +
         for k, dd in a2.items():
             shapes.setdefault(shape, {}).setdefault(k, {}).update({c: sum(v) / len(v) for c, v in dd.items()})
 for shape, ks in shapes.items():
-    h_ = int(shape.split("x")[1])
-    lanes = {"setup_kernel": 48, "admm_kernel": 48 if h_ == 10 else 24}   # ADMM kernel: two QPs per wavefront at h = 10, one (a main / twin pair of rows) from h = 16 on
+    h_ = int("".join(ch for ch in shape.split("x")[1] if ch.isdigit()))
+    # ADMM kernel: two QPs per wavefront at h = 10, one (a main / twin pair of rows) from h = 16 on.  The executed-FP64 figure of 8192 x h16 is taken from the pass on the
+    # ONE-WAVE kernels (A1MPC_CU_WIDE=0: 24 live lanes in every instruction, exact); the CU-wide kernel ("..cu": five QPs on four wavefronts, wave 0 with 48 live lanes)
+    # executes the same arithmetic per QP bit for bit, with fewer wave-level instructions -- its own entry prices them at the time-averaged 30 lanes (an estimate)
+    lanes = {"setup_kernel": 48, "admm_kernel": 48 if h_ == 10 else (30 if shape.endswith("cu") else 24)}
     e_ = 0.0
     for k, ln_ in lanes.items():
         c = ks.get(k, {})
