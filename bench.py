@@ -592,8 +592,9 @@ def main():
         d = ds[k % NB]; o = outs[k % NB]
         return pipe.submit_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], o[0], None, o[1], o[2], fresh=True, after_stream=after)
 
-    spin_up = max(0, 8 - args.warmup)     # (untimed, like the warm-up steps: with fewer than ~8 launches behind it the first timed steps run on a GPU that has not clocked up yet -- measured
-                                          #  0.72 vs 0.68 ms per step with --warmup 3; reported as config.untimed_launches_before_timing)
+    spin_up = max(0, int(os.environ.get("A1_BENCH_SPIN_UP", "32")) - args.warmup)   # (untimed, like the warm-up steps, reported as config.untimed_launches_before_timing: the GPU
+                                          #  needs some ms of work to reach its steady clocks -- 0.72 ms per step with 3 launches behind the timed region, 0.65 with 8,
+                                          #  tools/pipe_start_probe.py; a property of the power management, not of a step)
 
     def region(steps):
         """`steps` batches through the pipeline exactly the way the timed region issues them: the first launch of every slot starts behind an event on `stream`, an
