@@ -289,6 +289,33 @@ __global__ void a1mpc_noop_kernel() {}
 // Element-wise and HBM-bound: ~0.5 KB in + 0.3 KB out per robot.  The four lanes of a robot read the same robot-level words
 // (one transaction) and write consecutive 24-byte segments.  No FMA contraction: the results are bit-identical to the reference's
 // C++ arithmetic (and to the oracle, which is compiled the same way).
+// Wave-private LDS stage for the kernels that run one lane per (robot, leg) (round 4).  A lane's results are 3-vectors at a stride of 24 bytes between lanes: stored
+// straight from the registers, every store instruction touches 12 cache lines for 512 bytes of data.  The 16 robots of a wavefront own one contiguous run of
+// every [robot][12] array (192 doubles), so the wave parks three such arrays at a time in 576 doubles of LDS and stores them back out with 64 consecutive doubles
+// per instruction.  Pure data movement: no arithmetic, no bit changes (leg kernel 2.9 -> 5.8 TB/s at 524 288 robots).
+struct WaveStage {
+    double* sg;          // 576 doubles of LDS owned by this wavefront
+    int lane;            // 0..63 = (robot of the wave) * 4 + leg
+    int robots;          // live robots of this wavefront (16, fewer in the last one)
+    int64_t first;       // first robot of this wavefront
+    __device__ static void sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+    // null output pointers are skipped
+    __device__ void flush3(const double (&x0)[3], const double (&x1)[3], const double (&x2)[3], double* o0, double* o1, double* o2) const {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { sg[3 * lane + r] = x0[r]; sg[192 + 3 * lane + r] = x1[r]; sg[384 + 3 * lane + r] = x2[r]; }
+        sync();
+        const int cnt = robots * 12;
+        double* outs[3] = {o0, o1, o2};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (outs[t] == nullptr) continue;
+            double* out = outs[t] + first * 12;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { const int e = lane + 64 * m; if (e < cnt) out[e] = sg[192 * t + e]; }
+        }
+        sync();
+    }
+};
 struct PlanArgs {
     a1mpc_gait_config g;
     int32_t n;
@@ -300,42 +327,48 @@ struct PlanArgs {
 };
 __global__ __launch_bounds__(256) void a1mpc_plan_kernel(const PlanArgs a) {
 #pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) double stage[4][576];
+    const int lane = static_cast<int>(threadIdx.x) & 63, wv = static_cast<int>(threadIdx.x) >> 6;
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     const int64_t b = gid >> 2;
     const int leg = static_cast<int>(gid & 3);
-    if (b >= a.n) return;
-    double gc = a.gait_counter[b * 4 + leg];
-    const double spd = a.gait_counter_speed[b * 4 + leg];
-    uint8_t pc;
-    if (!a.movement_mode[b]) {                                  // :150-153
-        pc = 1; gc = a.g.gait_counter_reset[leg];
-    } else {                                                    // :155-165
-        gc = gc + spd;
-        gc = fmod(gc, a.g.counter_per_gait);
-        pc = gc <= a.g.counter_per_swing ? 1 : 0;
-    }
-    a.gait_counter[b * 4 + leg] = gc;
-    a.plan_contacts[b * 4 + leg] = pc;
-    const double* Rz = a.Rz + b * 9; const double* Rw = a.Rw + b * 9;
-    const double* v = a.root_lin_vel + b * 3; const double* vd = a.root_lin_vel_d + b * 3; const double* pos = a.root_pos + b * 3;
-    const double vrx = Rz[0] * v[0] + Rz[3] * v[1] + Rz[6] * v[2];   // :168-169  Rz' v
-    const double vry = Rz[1] * v[0] + Rz[4] * v[1] + Rz[7] * v[2];
-    const double k = sqrt(fabs(a.g.default_foot_pos[2]) / 9.8);       // default_foot_pos(2): linear index 2 = z of leg 0
-    const double half_swing = ((a.g.counter_per_swing / spd) * a.g.control_dt) / 2.0;
-    double dx = k * (vrx - vd[0]) + half_swing * vd[0];              // :175-182
-    double dy = k * (vry - vd[1]) + half_swing * vd[1];
-    if (dx < -a.g.foot_delta_x_limit) dx = -a.g.foot_delta_x_limit;
-    if (dx > a.g.foot_delta_x_limit) dx = a.g.foot_delta_x_limit;
-    if (dy < -a.g.foot_delta_y_limit) dy = -a.g.foot_delta_y_limit;
-    if (dy > a.g.foot_delta_y_limit) dy = a.g.foot_delta_y_limit;
-    const double r0 = a.g.default_foot_pos[3 * leg + 0] + dx, r1 = a.g.default_foot_pos[3 * leg + 1] + dy, r2 = a.g.default_foot_pos[3 * leg + 2];
-    if (a.rel) { a.rel[b * 12 + 3 * leg + 0] = r0; a.rel[b * 12 + 3 * leg + 1] = r1; a.rel[b * 12 + 3 * leg + 2] = r2; }
+    const int64_t wave_first = (static_cast<int64_t>(blockIdx.x) * 256 + wv * 64) >> 2;
+    if (wave_first >= a.n) return;
+    const WaveStage ws{stage[wv], lane, static_cast<int>(a.n - wave_first < 16 ? a.n - wave_first : 16), wave_first};
+    double rel[3] = {0, 0, 0}, ab[3] = {0, 0, 0}, wo[3] = {0, 0, 0};
+    if (b < a.n) {
+        double gc = a.gait_counter[b * 4 + leg];
+        const double spd = a.gait_counter_speed[b * 4 + leg];
+        uint8_t pc;
+        if (!a.movement_mode[b]) {                                  // :150-153
+            pc = 1; gc = a.g.gait_counter_reset[leg];
+        } else {                                                    // :155-165
+            gc = gc + spd;
+            gc = fmod(gc, a.g.counter_per_gait);
+            pc = gc <= a.g.counter_per_swing ? 1 : 0;
+        }
+        a.gait_counter[b * 4 + leg] = gc;
+        a.plan_contacts[b * 4 + leg] = pc;
+        const double* Rz = a.Rz + b * 9; const double* Rw = a.Rw + b * 9;
+        const double* v = a.root_lin_vel + b * 3; const double* vd = a.root_lin_vel_d + b * 3; const double* pos = a.root_pos + b * 3;
+        const double vrx = Rz[0] * v[0] + Rz[3] * v[1] + Rz[6] * v[2];   // :168-169  Rz' v
+        const double vry = Rz[1] * v[0] + Rz[4] * v[1] + Rz[7] * v[2];
+        const double k = sqrt(fabs(a.g.default_foot_pos[2]) / 9.8);       // default_foot_pos(2): linear index 2 = z of leg 0
+        const double half_swing = ((a.g.counter_per_swing / spd) * a.g.control_dt) / 2.0;
+        double dx = k * (vrx - vd[0]) + half_swing * vd[0];              // :175-182
+        double dy = k * (vry - vd[1]) + half_swing * vd[1];
+        if (dx < -a.g.foot_delta_x_limit) dx = -a.g.foot_delta_x_limit;
+        if (dx > a.g.foot_delta_x_limit) dx = a.g.foot_delta_x_limit;
+        if (dy < -a.g.foot_delta_y_limit) dy = -a.g.foot_delta_y_limit;
+        if (dy > a.g.foot_delta_y_limit) dy = a.g.foot_delta_y_limit;
+        rel[0] = a.g.default_foot_pos[3 * leg + 0] + dx; rel[1] = a.g.default_foot_pos[3 * leg + 1] + dy; rel[2] = a.g.default_foot_pos[3 * leg + 2];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {                                    // :198-199
-        const double w = Rw[r * 3 + 0] * r0 + Rw[r * 3 + 1] * r1 + Rw[r * 3 + 2] * r2;
-        if (a.abs_) a.abs_[b * 12 + 3 * leg + r] = w;
-        if (a.world) a.world[b * 12 + 3 * leg + r] = w + pos[r];
+        for (int r = 0; r < 3; ++r) {                                    // :198-199
+            ab[r] = Rw[r * 3 + 0] * rel[0] + Rw[r * 3 + 1] * rel[1] + Rw[r * 3 + 2] * rel[2];
+            wo[r] = ab[r] + pos[r];
+        }
     }
+    ws.flush3(rel, ab, wo, a.rel, a.abs_, a.world);   // (the three [robot][12] outputs leave through the wave's LDS stage: WaveStage)
 }
 
 template <int H>
@@ -1227,47 +1260,54 @@ struct SwingArgs {
 };
 __global__ __launch_bounds__(256) void a1mpc_swing_kernel(const SwingArgs a) {
 #pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) double stage[4][576];
+    const int lane = static_cast<int>(threadIdx.x) & 63, wv = static_cast<int>(threadIdx.x) >> 6;
     const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     const int64_t b = gid >> 2;
     const int i = static_cast<int>(gid & 3);
-    if (b >= a.n) return;
-    const double* Rz = a.Rz + b * 9;
-    const double* fa = a.foot_pos_abs + b * 12 + 3 * i;
-    const int64_t o = b * 12 + 3 * i;
-    double cur[3];
+    const int64_t wave_first = (static_cast<int64_t>(blockIdx.x) * 256 + wv * 64) >> 2;
+    if (wave_first >= a.n) return;
+    const WaveStage ws{stage[wv], lane, static_cast<int>(a.n - wave_first < 16 ? a.n - wave_first : 16), wave_first};
+    double cur[3] = {0, 0, 0}, st[3] = {0, 0, 0}, tl[3] = {0, 0, 0}, kin[3] = {0, 0, 0};
+    if (b < a.n) {
+        const double* Rz = a.Rz + b * 9;
+        const double* fa = a.foot_pos_abs + b * 12 + 3 * i;
+        const int64_t o = b * 12 + 3 * i;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) cur[r] = Rz[0 * 3 + r] * fa[0] + Rz[1 * 3 + r] * fa[1] + Rz[2 * 3 + r] * fa[2];   // :224
-    const double gc = a.gait_counter[b * 4 + i];
-    float spline_time = 0.0f;
-    double st[3];
-    if (gc <= a.counter_per_swing) {                                                                                  // :227-232
+        for (int r = 0; r < 3; ++r) cur[r] = Rz[0 * 3 + r] * fa[0] + Rz[1 * 3 + r] * fa[1] + Rz[2 * 3 + r] * fa[2];   // :224
+        const double gc = a.gait_counter[b * 4 + i];
+        float spline_time = 0.0f;
+        if (gc <= a.counter_per_swing) {                                                                                  // :227-232  (foot_pos_start <- the current position)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { st[r] = cur[r]; a.start[o + r] = cur[r]; }
-    } else {                                                                                                          // :233-236
-        spline_time = static_cast<float>(gc - a.counter_per_swing) / static_cast<float>(a.counter_per_swing);
+            for (int r = 0; r < 3; ++r) st[r] = cur[r];
+        } else {                                                                                                          // :233-236  (foot_pos_start stays: written back as read)
+            spline_time = static_cast<float>(gc - a.counter_per_swing) / static_cast<float>(a.counter_per_swing);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) st[r] = a.start[o + r];
+            for (int r = 0; r < 3; ++r) st[r] = a.start[o + r];
+        }
+        const double t = spline_time, u = 1 - t;
+        const double t2 = t * t, t3 = t2 * t, t4 = t2 * t2, u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double fin = a.target_rel[o + r];
+            double P1 = st[r], P2 = fin;
+            if (r == 2) { P1 += 0.0f; P2 += 0.4f + 0.5 * 0.0; }                                                           // FOOT_SWING_CLEARANCE1 / 2
+            double y = 0;                                                                                                 // Utils.cpp:97-104
+            y += 1.0 * 1.0 * u4 * st[r];
+            y += 4.0 * t * u3 * P1;
+            y += 6.0 * t2 * u2 * P2;
+            y += 4.0 * t3 * u * fin;
+            y += 1.0 * t4 * 1.0 * fin;
+            const double vel_cur = (cur[r] - a.rel_last[o + r]) / a.dt;                                                   // :243-252
+            const double vel_tgt = (y - a.target_last[o + r]) / a.dt;
+            tl[r] = y;
+            kin[r] = (y - cur[r]) * a.kp[r] + (vel_tgt - vel_cur) * a.kd[r];
+        }
     }
-    const double t = spline_time, u = 1 - t;
-    const double t2 = t * t, t3 = t2 * t, t4 = t2 * t2, u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const double fin = a.target_rel[o + r];
-        double P1 = st[r], P2 = fin;
-        if (r == 2) { P1 += 0.0f; P2 += 0.4f + 0.5 * 0.0; }                                                           // FOOT_SWING_CLEARANCE1 / 2
-        double y = 0;                                                                                                 // Utils.cpp:97-104
-        y += 1.0 * 1.0 * u4 * st[r];
-        y += 4.0 * t * u3 * P1;
-        y += 6.0 * t2 * u2 * P2;
-        y += 4.0 * t3 * u * fin;
-        y += 1.0 * t4 * 1.0 * fin;
-        const double vel_cur = (cur[r] - a.rel_last[o + r]) / a.dt;                                                   // :243-252
-        a.rel_last[o + r] = cur[r];
-        const double vel_tgt = (y - a.target_last[o + r]) / a.dt;
-        a.target_last[o + r] = y;
-        a.kin_out[o + r] = (y - cur[r]) * a.kp[r] + (vel_tgt - vel_cur) * a.kd[r];
-        a.cur_out[o + r] = cur[r];
-    }
+    // start / rel_last / target_last are updated in place, and a staged store writes OTHER lanes' words of this wavefront's 16 robots: every load above has
+    // completed by then -- the values parked in LDS depend on them (one s_waitcnt for the whole wave) -- and no other wavefront touches these robots
+    ws.flush3(st, cur, tl, a.start, a.rel_last, a.target_last);   // foot_pos_start, foot_pos_rel_last_time <- cur, foot_pos_target_last_time <- y
+    ws.flush3(kin, cur, cur, a.kin_out, a.cur_out, nullptr);
 }
 
 a1mpc_status a1mpc_swing_legs_batch(a1mpc_handle h, int32_t n, double counter_per_swing, double dt, const double* R_z,
@@ -1322,10 +1362,8 @@ struct LegArgs {
     const double *q, *qd, *R, *pos, *vel;
     double *rel, *Jb, *vrel, *pabs, *vabs, *pworld, *vworld;
 };
-// Round 4: the outputs leave through a wave-private LDS stage.  A lane's results are 9 + 6 x 3 doubles at strides of 72 / 24 bytes between lanes: stored straight from the
-// registers every store instruction touched 36 / 12 cache lines for 512 bytes of data (2.9 TB/s at 524 288 robots, 46 % of the achievable HBM rate).  The 16 robots of a
-// wavefront own contiguous runs of every output array (576 doubles of J blocks, 192 of each 3-vector array), so the wave writes its values to LDS in array order and
-// stores them back out with 64 consecutive doubles per instruction.  Pure data movement: the arithmetic and its bits are unchanged.
+// Round 4: the outputs (9 + 6 x 3 doubles per lane at strides of 72 / 24 bytes between lanes) leave through the wave's LDS stage (WaveStage): 64 consecutive doubles per
+// store instruction instead of 36 / 12 cache lines touched for 512 bytes; 0.213 -> 0.106 ms at 524 288 robots, bit-identical.
 __global__ __launch_bounds__(256) void a1mpc_leg_kernel(const LegArgs a) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) double stage[4][576];
@@ -1357,37 +1395,21 @@ __global__ __launch_bounds__(256) void a1mpc_leg_kernel(const LegArgs a) {
             vw[r] = va[r] + a.vel[b * 3 + r];
         }
     }
+    const WaveStage ws{stage[wv], lane, wave_robots, wave_first};
     double* sg = stage[wv];
-    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     // J blocks: lane (robot, leg) holds doubles [9 lane, 9 lane + 9) of the wave's 576
 #pragma unroll
     for (int k = 0; k < 9; ++k) sg[9 * lane + k] = J[k];
-    wave_sync();
+    WaveStage::sync();
     {
         double* out = a.Jb + wave_first * 36;
         const int cnt = wave_robots * 36;
 #pragma unroll
         for (int m = 0; m < 9; ++m) { const int e = lane + 64 * m; if (e < cnt) out[e] = sg[e]; }
     }
-    wave_sync();
-    // the 3-vector arrays, three at a time: array t at [192 t, 192 t + 192), lane holds [3 lane, 3 lane + 3) of it
-    auto flush3 = [&](const double (&x0)[3], const double (&x1)[3], const double (&x2)[3], double* o0, double* o1, double* o2) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { sg[3 * lane + r] = x0[r]; sg[192 + 3 * lane + r] = x1[r]; sg[384 + 3 * lane + r] = x2[r]; }
-        wave_sync();
-        const int cnt = wave_robots * 12;
-        double* outs[3] = {o0, o1, o2};
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (outs[t] == nullptr) continue;
-            double* out = outs[t] + wave_first * 12;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) { const int e = lane + 64 * m; if (e < cnt) out[e] = sg[192 * t + e]; }
-        }
-        wave_sync();
-    };
-    flush3(p, v, pa, a.rel, a.vrel, a.pabs);
-    flush3(va, pw, vw, a.vabs, a.pworld, a.vworld);
+    WaveStage::sync();
+    ws.flush3(p, v, pa, a.rel, a.vrel, a.pabs);
+    ws.flush3(va, pw, vw, a.vabs, a.pworld, a.vworld);
 }
 
 a1mpc_status a1mpc_leg_state_batch(a1mpc_handle h, int32_t n, const double* joint_pos, const double* joint_vel, const double* R_world,
