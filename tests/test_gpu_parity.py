@@ -1321,3 +1321,37 @@ def test_stage_cycles_through_the_abi(pkg, scen, gen, n):
     print(f"{gen} x {n}: factor {cyc['factor'] / tot:.3f} | iterate {cyc['iterate'] / tot:.3f} | check {cyc['check'] / tot:.3f} of the solve stage; "
           f"{per_it:.0f} cycles per iteration, {per_f:.0f} per factor pass (wave-mates' stalls included)")
     assert 0.5 < cyc["iterate"] / tot < 0.95 and 0.03 < cyc["factor"] / tot < 0.45
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_warm_ticks_of_a_large_batch_take_the_fused_kernel_and_match_the_oracle(pkg, oracle, scen, mode):
+    """Round 4: second and later warm-started ticks of a batch size run the FUSED kernel up to 8192 QPs at h = 10 (solve_device_impl: nothing left for the queue to
+    balance when every QP takes ~25 iterations), the first tick and any tick after a1mpc_set_schedule the split pipeline.  4096 robots, four ticks with slowly moving
+    states, both warm-start semantics: every 16th robot is chained through the oracle the same way -- same iteration count and status, forces within the parity
+    tolerance on every tick -- and a1mpc_last_stage_ms tells which pipeline ran (the fused kernel has no set-up stage of its own)."""
+    n, ticks = 4096, 4
+    rng = np.random.default_rng(404)
+    sc = scen.config3_random_flat(nb=n, seed=4040)
+    pr = oracle_params(oracle, sc); st = oracle.default_settings(warm_start=1); h = 10
+    sub = np.arange(0, n, 16)
+    wx = {int(i): np.zeros(12 * h) for i in sub}; wy = {int(i): np.zeros(20 * h) for i in sub}; rho = {int(i): None for i in sub}
+    carry = {int(i): oracle.update_carry(h) for i in sub}
+    staged = []
+    with _engine(pkg, sc, n, warm_start=mode) as eng:
+        for t in range(ticks):
+            if t > 0:
+                sc["x0"][:, :12] += rng.normal(0, 2e-3, (n, 12))
+            out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
+            staged.append(eng.last_stage_ms()[0] > 0.0)
+            worst = 0.0
+            for i in sub:
+                i = int(i)
+                if mode == 1:
+                    r = oracle.mpc_solve(pr, st, sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i], warm_x=wx[i], warm_y=wy[i], warm_rho=rho[i])
+                    wx[i], wy[i], rho[i] = r["warm_x"], r["warm_y"], r["rho"]
+                else:
+                    r = oracle.mpc_solve_update(pr, st, sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i], carry[i])
+                assert out["iters"][i] == r["info"].iters and out["status"][i] == r["info"].status, (mode, t, i, out["iters"][i], r["info"].iters)
+                worst = max(worst, float(np.abs(out["u"][i] - r["u"]).max()))
+            assert worst <= TOL_FORCE_N, (mode, t, worst)
+    assert staged[0] and not any(staged[1:]), staged     # tick 0: split pipeline (set-up stage timed); ticks 1..: the fused kernel
