@@ -1355,3 +1355,41 @@ def test_warm_ticks_of_a_large_batch_take_the_fused_kernel_and_match_the_oracle(
                 worst = max(worst, float(np.abs(out["u"][i] - r["u"]).max()))
             assert worst <= TOL_FORCE_N, (mode, t, worst)
     assert staged[0] and not any(staged[1:]), staged     # tick 0: split pipeline (set-up stage timed); ticks 1..: the fused kernel
+
+
+@pytest.mark.parametrize("seed", [1071, 1217, 1160, 1501])
+def test_settings_above_the_parity_bar_are_the_checkers_own_rounding(pkg, oracle, scen, seed):
+    """the random-settings soak (tests/tools/soak_settings.py) has a handful of combinations -- scaling 0 / 2, sigma ~ 1e-7, rho re-adapted every 10
+    iterations, 60-iteration cut-offs -- on which engine and oracle stop at the same iteration with forces 1e-4 ... 1e-1 N apart: ADMM amplifies last-bit differences of
+    the two linear solves there (the oracle's own two back ends part by more).  Gated here with the x87 extended-precision build of the oracle as the yardstick: on the
+    three QPs of each such combination with the largest engine-vs-oracle difference all three runs stop at the same iteration, and the engine's distance to the
+    extended-precision answer is of the order of the double-precision oracle's own (<= 5 x; it is the closer one on most)."""
+    import x87
+    n = 256
+    rng = np.random.default_rng(seed)
+    H = int(rng.choice([10, 10, 16, 20]))     # (the draw sequence of tests/tools/soak_settings.py)
+    over = dict(scaling=int(rng.choice([0, 2, 10, 10, 15])), alpha=float(rng.choice([1.0, 1.6, 1.6, rng.uniform(1.05, 1.9)])), rho=float(10 ** rng.uniform(-2, 0.3)),
+                sigma=float(10 ** rng.uniform(-7, -4)), check_termination=int(rng.choice([5, 10, 25, 25, 40])), adaptive_rho=int(rng.choice([0, 1, 1, 1])),
+                adaptive_rho_interval=int(rng.choice([0, 10, 25, 35, 50, 100])), adaptive_rho_tolerance=float(rng.choice([1.5, 2.0, 5.0, 5.0])),
+                eps_abs=float(rng.choice([1e-3, 1e-3, 1e-4, 1e-5])), max_iter=int(rng.choice([60, 400, 4000, 4000])))
+    over["eps_rel"] = over["eps_abs"]
+    gen = {10: scen.config3_random_flat, 16: scen.config4_random_h16, 20: scen.config5_divergent}[H]
+    sc = gen(nb=n, seed=7000 + seed)
+    p = dict(sc["params"], mu=float(rng.choice([0.3, 0.3, 0.6, 0.15])), fz_min=float(rng.choice([0.0, 0.0, 0.0, 5.0])), fz_max=float(rng.choice([180.0, 180.0, 120.0, 60.0])))
+    with pkg.Engine(pkg.make_config(p, H, warm_start=0, **over), n, 0) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+    pr = oracle.mpc_params(H, p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"], p["inertia"])
+    ref = oracle.mpc_solve_batch(pr, oracle.default_settings(**over), sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+    assert (out["iters"] == ref["iters"]).all()
+    st_diff = int((out["status"] != ref["status"]).sum())     # (at the iteration limit OSQP's "solved inaccurate" test, 10 x the tolerances, can sit on the same knife edge)
+    assert st_diff <= n // 50, st_diff
+    dd = np.abs(out["grf"].reshape(n, 12) - ref["grf"].reshape(n, 12)).max(1)
+    xpr = x87.params(p, H); xst = x87.settings(**over)
+    rows = []
+    for i in np.argsort(-dd)[:3]:
+        xr = x87.mpc_solve(xpr, xst, sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i])
+        d_e = float(np.abs(out["grf"][i] - xr["grf"]).max()); d_o = float(np.abs(ref["grf"][i] - xr["grf"]).max())
+        rows.append((int(i), float(dd[i]), d_e, d_o))
+        assert xr["iters"] == out["iters"][i], (seed, i, xr["iters"], out["iters"][i])
+        assert d_e <= 5.0 * d_o + TOL_FORCE_N, (seed, rows)
+    print(f"settings seed {seed} (h = {H}, {over}): worst engine-vs-oracle {dd.max():.2e} N, {st_diff} status differences; (qp, engine-vs-oracle, engine-vs-x87, oracle-vs-x87): {rows}")

@@ -72,3 +72,13 @@ def mpc_solve_update(pr, st, x0, xref, Rw, foot, contact, carry):
     lib().orc_mpc_solve_update(C.byref(pr), C.byref(st), _ldp(X0), _ldp(XR), _ldp(RW), _ldp(FT), ct.ctypes.data_as(C.POINTER(C.c_uint8)), _ldp(grf), _ldp(u), _ldp(c),
                                C.byref(info))
     return dict(grf=grf.astype(np.float64), u=u.astype(np.float64), iters=int(info.iters), status=int(info.status))
+
+
+def mpc_solve(pr, st, x0, xref, Rw, foot, contact):
+    """one cold solve (orc_mpc_solve in extended precision): dict(grf, iters, status)"""
+    grf = np.zeros(12, np.longdouble); info = InfoX()
+    ct = np.ascontiguousarray(contact, dtype=np.uint8)
+    X0, XR, RW, FT = _ld(x0), _ld(xref), _ld(Rw), _ld(foot)
+    lib().orc_mpc_solve(C.byref(pr), C.byref(st), _ldp(X0), _ldp(XR), _ldp(RW), _ldp(FT), C.c_int(0), ct.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(0), _ldp(grf),
+                        None, None, None, None, C.byref(info))
+    return dict(grf=grf.astype(np.float64), iters=int(info.iters), status=int(info.status))
