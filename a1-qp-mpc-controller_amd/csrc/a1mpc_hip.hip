@@ -1500,7 +1500,7 @@ __device__ inline void ekf_c_row(int r, int& c0, double& s0, int& c1, double& s1
     else if (r < 24) { c0 = 3 + (r - 12) % 3; s0 = 1.0; }                    // vel
     else { c0 = 6 + (r - 24) * 3 + 2; s0 = 1.0; }                            // foot height
 }
-__global__ __launch_bounds__(64) void a1mpc_ekf_kernel(const EkfArgs a) {
+__global__ __launch_bounds__(64, 2) void a1mpc_ekf_kernel(const EkfArgs a) {   // (two waves per SIMD: 256 registers each -- left alone the FMA form of round 4 took 272 and halved the occupancy)
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) double lds[2][1280];
     const int g = static_cast<int>(threadIdx.x) >> 5, l = static_cast<int>(threadIdx.x) & 31;
@@ -1606,7 +1606,7 @@ __global__ __launch_bounds__(64) void a1mpc_ekf_kernel(const EkfArgs a) {
     double serr = 0.0;
     if (l < 28) {
         // S^-1 error_y (:134): dense product, inner index ascending
-        for (int c = 0; c < 28; ++c) serr += M[c] * zs[c];
+        for (int c = 0; c < 28; ++c) serr = __builtin_fma(M[c], zs[c], serr);   // (round 4: the four big dense products accumulate by FMA, here and in the oracle alike)
         // S^-1 C (:138): the dense product with C's exact zeros dropped (C[c][j] is 0 or +-1, a zero term leaves the running sum as it is): per column j the
         // rows c with an entry, ascending -- j < 3: c = j, 3 + j, 6 + j, 9 + j (-1); j = 3..5: c = 12 + (j - 3), 15 + .., 18 + .., 21 + .. (+1); j = 6 + m: c = m (+1)
         // and, for the z column of a foot, c = 24 + m / 3 (+1)
@@ -1627,11 +1627,11 @@ __global__ __launch_bounds__(64) void a1mpc_ekf_kernel(const EkfArgs a) {
             G1[r] = c1 >= 0 ? Pr[c0] * s0 + Pr[c1] * s1 : Pr[c0] * s0;
         }
         double acc_ = 0;
-        for (int r = 0; r < 28; ++r) acc_ += G1[r] * zs[r];
+        for (int r = 0; r < 28; ++r) acc_ = __builtin_fma(G1[r], zs[r], acc_);
         xs[l] = xb[l] + acc_;
         double G2[18];
-        for (int j = 0; j < 18; ++j) { double s = 0; for (int r = 0; r < 28; ++r) s += G1[r] * SC[r * 18 + j]; G2[j] = s; }
-        for (int j = 0; j < 18; ++j) { double s = 0; for (int k = 0; k < 18; ++k) s += G2[k] * Pb[k * 18 + j]; Tn[j] = Pr[j] - s; }
+        for (int j = 0; j < 18; ++j) { double s = 0; for (int r = 0; r < 28; ++r) s = __builtin_fma(G1[r], SC[r * 18 + j], s); G2[j] = s; }
+        for (int j = 0; j < 18; ++j) { double s = 0; for (int k = 0; k < 18; ++k) s = __builtin_fma(G2[k], Pb[k * 18 + j], s); Tn[j] = Pr[j] - s; }
     }
     half_sync();  // every lane is done reading Pbar: its region now stages the unsymmetrised update for the transposed read
     double* Pm = Pb;

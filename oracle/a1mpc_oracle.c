@@ -1268,17 +1268,19 @@ void orc_ekf_step(double *state, double dt, int assume_flat_ground, int movement
         }
     }
     for (int i = 0; i < EKF_NM * EKF_NM; ++i) M[i] = -M[i];
-    for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a += M[r * EKF_NM + c] * err[c]; Serr[r] = a; }                                    /* :134 */
+    /* (round 4: the four big dense products below accumulate by fma(), like the device kernel: half the FP64 instructions there; the reference's Eigen products
+     * contract or not as its compiler pleases, and the agreement with the reference stays where the two different solvers for S put it, 1e-9) */
+    for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a = fma(M[r * EKF_NM + c], err[c], a); Serr[r] = a; }                                    /* :134 */
     for (int r = 0; r < EKF_NM; ++r) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a += M[r * EKF_NM + c] * C[c * EKF_NS + j]; SC[r * EKF_NS + j] = a; }   /* :138 */
     double G1[EKF_NS * EKF_NM], G2[EKF_NS * EKF_NS];
     for (int a_ = 0; a_ < EKF_NS; ++a_) for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int k = 0; k < EKF_NS; ++k) a += Pbar[a_ * EKF_NS + k] * C[r * EKF_NS + k]; G1[a_ * EKF_NM + r] = a; }
     for (int a_ = 0; a_ < EKF_NS; ++a_) {                                                             /* :136 */
-        double a = 0; for (int r = 0; r < EKF_NM; ++r) a += G1[a_ * EKF_NM + r] * Serr[r];
+        double a = 0; for (int r = 0; r < EKF_NM; ++r) a = fma(G1[a_ * EKF_NM + r], Serr[r], a);
         x[a_] = xbar[a_] + a;
     }
-    for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int r = 0; r < EKF_NM; ++r) a += G1[a_ * EKF_NM + r] * SC[r * EKF_NS + j]; G2[a_ * EKF_NS + j] = a; }
+    for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int r = 0; r < EKF_NM; ++r) a = fma(G1[a_ * EKF_NM + r], SC[r * EKF_NS + j], a); G2[a_ * EKF_NS + j] = a; }
     for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) {                            /* :139 */
-        double a = 0; for (int k = 0; k < EKF_NS; ++k) a += G2[a_ * EKF_NS + k] * Pbar[k * EKF_NS + j];
+        double a = 0; for (int k = 0; k < EKF_NS; ++k) a = fma(G2[a_ * EKF_NS + k], Pbar[k * EKF_NS + j], a);
         T[a_ * EKF_NS + j] = Pbar[a_ * EKF_NS + j] - a;
     }
     for (int i = 0; i < EKF_NS; ++i) for (int j = 0; j < EKF_NS; ++j) P[i * EKF_NS + j] = 0.5 * (T[i * EKF_NS + j] + T[j * EKF_NS + i]);   /* :140 */
