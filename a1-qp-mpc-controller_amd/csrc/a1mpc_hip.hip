@@ -1,11 +1,12 @@
 // a1mpc_hip.hip -- gfx950 kernels + the C ABI of include/a1mpc.h (liba1mpc.so).
 //
-// One workgroup = one wavefront = ROWS QPs (one per 16-lane DPP row; ROWS = 2 by default, A1MPC_ROWS_PER_WG), dynamic LDS =
-// ROWS x Layout<H>::ROW_STRIDE doubles (20.4 KB per QP at H = 10 -> eight QPs = four workgroups per CU).  Three ways through a batch
-// (launch_mpc): the latency kernel (<= 256 QPs: the rows of a wave share one QP's set-up), the fused kernel (up to the resident rows:
-// one row = one QP from inputs to outputs) and the split pipeline (set-up kernel -> persistent ADMM rows that drain a queue in
-// longest-first order -> order kernel).  The QPs of a batch are independent; nothing is shared between workgroups except the read-only
-// (alpha/beta) table and the queue counter, so the blockIdx -> XCD mapping is irrelevant here (no L2 reuse to localise).
+// One workgroup = one wavefront = ROWS QPs (one per main / twin pair of 16-lane DPP rows; ROWS = 2 at H = 10, 1 at H >= 16), dynamic LDS =
+// ROWS x Layout<H>::ROW_STRIDE doubles (20.4 KB per QP at H = 10 -> eight QPs = four workgroups per CU); at H = 16 the persistent ADMM kernel is ONE
+// 256-thread workgroup per CU that carries five QPs (a1mpc_admm_cu_kernel).  Three ways through a batch (launch_mpc): the latency kernel (<= 256 QPs: the
+// rows of a wave share one QP's set-up), the fused kernel (up to the resident rows: one row pair = one QP from inputs to outputs; also warm-started ticks of a
+// known batch at H = 10) and the split pipeline (set-up kernel -> queue-order kernel -> persistent ADMM rows that drain the queue longest-first).  The QPs of a
+// batch are independent; nothing is shared between workgroups except the read-only (alpha/beta) table and the queue counter, so the blockIdx -> XCD mapping is
+// irrelevant here (no L2 reuse to localise).
 //
 // There is no CPU path in this file: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
@@ -2691,6 +2692,14 @@ a1mpc_status a1mpc_last_nfact(a1mpc_handle h, int32_t n, int32_t* nfact_out) {
 a1mpc_status a1mpc_kernel_info(a1mpc_handle h, int32_t* lds_bytes_per_workgroup, int32_t* qps_per_workgroup,
                                int32_t* threads_per_workgroup) {
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    // the geometry of the persistent ADMM kernel large batches run (the fused / latency kernels of small batches: one wavefront of rows_per_wg QPs)
+    if (cu_wide_qps(h->cfg.horizon) > 0 && cu_wide_enabled() && rows_per_wg(h->cfg.horizon) == default_rows_per_wg(h->cfg.horizon)) {   // h = 16: one CU-wide workgroup, five QPs
+        const int q = cu_wide_qps(h->cfg.horizon);
+        if (lds_bytes_per_workgroup) *lds_bytes_per_workgroup = static_cast<int32_t>(lds_bytes_of(h->cfg.horizon) / rows_per_wg(h->cfg.horizon) * q);
+        if (qps_per_workgroup) *qps_per_workgroup = q;
+        if (threads_per_workgroup) *threads_per_workgroup = 256;
+        return A1MPC_OK;
+    }
     if (lds_bytes_per_workgroup) *lds_bytes_per_workgroup = static_cast<int32_t>(lds_bytes_of(h->cfg.horizon));
     if (qps_per_workgroup) *qps_per_workgroup = rows_per_wg(h->cfg.horizon);
     if (threads_per_workgroup) *threads_per_workgroup = h->cfg.horizon > 1 && rows_per_wg(h->cfg.horizon) <= 2 ? 64 : 16 * rows_per_wg(h->cfg.horizon);  // (twin rows: a full wavefront)
