@@ -310,3 +310,20 @@ def test_update_path_restatement(oracle, scen):
         upd = oracle.mpc_solve_update(pr, st, x0, seq["xref"][0], seq["R"][0], seq["foot"][0], seq["contact"][0], carry)
         d.append(np.abs(fresh["grf"] - upd["grf"]).max()); same += fresh["info"].iters == upd["info"].iters
     assert d[0] == 0.0 and np.median(d) < 1.0 and max(d) < 20.0 and same >= 100, (np.median(d), max(d), same)
+
+
+def test_check_termination_reproduces_osqp_residuals(oracle, scen):
+    """orc_check_termination (round 4: OSQP's termination test on a GIVEN unscaled iterate, used by the GPU suite on the ticks where engine and oracle part) evaluated on
+    the oracle's OWN solution (x, y from the solve, z from orc_last_z) reproduces the residuals the solve itself reported and passes; a perturbed point fails."""
+    sc = scen.config3_random_flat(nb=6)
+    p = sc["params"]; pr = oracle.mpc_params(10, p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"], p["inertia"])
+    st = oracle.default_settings(warm_start=1)
+    for i in range(6):
+        P, g, _, _, _, csr = oracle.mpc_form(pr, sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i])
+        r = oracle.mpc_solve(pr, st, sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i], warm_x=np.zeros(120), warm_y=np.zeros(200))
+        z = oracle.last_z(200)
+        c = oracle.check_termination(P, g, csr, r["warm_x"], z, r["warm_y"])
+        assert r["info"].status == 1 and c["ok"]
+        assert abs(c["pri_res"] - r["info"].pri_res) <= 1e-12 * max(1.0, r["info"].pri_res) and abs(c["dua_res"] - r["info"].dua_res) <= 1e-12
+        bad = oracle.check_termination(P, g, csr, r["warm_x"] + 5.0, z, r["warm_y"])
+        assert not bad["ok"]
