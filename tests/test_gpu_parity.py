@@ -993,15 +993,17 @@ def _oracle_update_ticks(oracle, pr, st, scs, carries):
     return grf, it, stt
 
 
-@pytest.mark.parametrize("n", [1, 300, 2600])
-def test_update_path_warm_start_2_matches_oracle(pkg, oracle, scen, n):
-    """warm_start = 2: the reference's tick >= 2 UPDATE path on the latency kernel (n = 1), the fused kernel (300) and the split pipeline (2600 > the resident
-    rows) against the oracle's restatement of OSQP's update functions (orc_mpc_solve_update): every robot carries its own workspace through a sequence of
-    slowly moving states with a contact switch; same iteration count and status on every QP of every tick, forces within the parity tolerance."""
+@pytest.mark.parametrize("n,h", [(1, 10), (300, 10), (2600, 10), (8300, 10), (1300, 16), (1100, 20)])
+def test_update_path_warm_start_2_matches_oracle(pkg, oracle, scen, n, h):
+    """warm_start = 2: the reference's tick >= 2 UPDATE path on the latency kernel (n = 1), the fused kernel (300; since round 4 also the warm ticks of 2600 x h10),
+    and the split pipeline's update-path instantiations -- set-up kernel + persistent rows at h = 10 (8300 > the 8192 up to which warm ticks run fused), the CU-wide
+    kernel at h = 16 (1300), the one-wave kernel at h = 20 (1100) -- against the oracle's restatement of OSQP's update functions (orc_mpc_solve_update): every robot
+    carries its own workspace through a sequence of slowly moving states with a contact switch; same iteration count and status on every QP of every tick, forces
+    within the parity tolerance."""
     rng = np.random.default_rng(100 + n)
-    sc = scen.config3_random_flat(nb=n, seed=900 + n)
+    sc = scen.config3_random_flat(nb=n, seed=900 + n, horizon=h)
     pr = oracle_params(oracle, sc); st = oracle.default_settings(warm_start=1)
-    carries = [oracle.update_carry(10) for _ in range(n)]
+    carries = [oracle.update_carry(h) for _ in range(n)]
     ticks = 8 if n == 1 else (5 if n == 300 else 3)
     with _engine(pkg, sc, n, warm_start=2) as eng:
         for t in range(ticks):
