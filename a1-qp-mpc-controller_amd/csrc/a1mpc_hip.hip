@@ -120,13 +120,20 @@ constexpr bool admm_twin_rows(int h, int rows) { return twin_rows(h, kModeMpc, r
 // the update path existed (the allocation of the hot loop is sensitive to anything around it: a1mpc_solver.hpp, load_prepared)
 // UNI: contacts broadcast over the horizon (contact_stride = 0): one pair of bounds for every slot (RowSolver<.., UNI>; built for H >= 16, where the registers matter)
 // CLK: the profiling instantiation (a1mpc_set_profiling): shader-clock stamps around factor passes / iteration segments / residual checks, outside the hot loop
-template <int H, int ROWS, bool UPD = false, bool UNI = false, bool CLK = false>
+// QUAD: one QP per wavefront and a horizon that is a multiple of 4 (H = 20): rows 1 and 3 do not idle, the four rows split the per-lane state (RowSolver<.., QUAD>)
+constexpr bool quad_rows(int h, int rows) { return h == 20 && rows == 1 && admm_twin_rows(h, rows); }
+template <int H, int ROWS, bool UPD = false, bool UNI = false, bool CLK = false, bool QUAD = false>
 __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     // ROWS <= 2: the wavefront's other rows run as twins of the QP rows (rows r and r + 2 share a QP and its LDS image, see row_is_twin)
     constexpr bool kTwin = admm_twin_rows(H, ROWS);
     const int row = static_cast<int>(threadIdx.x) >> 4;
     if constexpr (kTwin) {
+        if constexpr (QUAD) {
+            static_assert(quad_rows(H, ROWS), "a quad of rows: the wavefront's only QP");
+            admm_rows<H, true, false, UPD, UNI, CLK, true>(a, prep, counter, a1mpc_lds);
+            return;
+        }
         if ((row & 1) >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
         admm_rows<H, true, false, UPD, UNI, CLK>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H>::ROW_STRIDE);
     } else {
@@ -140,11 +147,19 @@ __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, cons
 // Rows still refill from the queue independently and nothing is shared between the waves (no workgroup barrier anywhere in admm_rows): the only coupling is
 // that wave 0's two QPs wait for each other's factor passes, as every pair of H = 10 does.
 constexpr int cu_wide_qps(int h) { return h == 16 ? 5 : 0; }   // QPs of a CU-wide workgroup (0: this horizon has no such kernel -- H = 20: 40 KB per image, four per CU)
-template <int H, bool UPD = false, bool UNI = false, bool CLK = false>
+// QUAD: waves 1-3 (one QP each) run their four rows as a quad (RowSolver<.., QUAD>); wave 0 keeps its two twin pairs
+template <int H, bool UPD = false, bool UNI = false, bool CLK = false, bool QUAD = false>
 __global__ __launch_bounds__(256) void a1mpc_admm_cu_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     static_assert(cu_wide_qps(H) == 5 && admm_twin_rows(H, 1), "five images: two on wave 0, one on each of waves 1-3");
     const int wave = static_cast<int>(threadIdx.x) >> 6, row = (static_cast<int>(threadIdx.x) >> 4) & 3;
+    if constexpr (QUAD) {
+        static_assert(H % 4 == 0, "quads split the horizon in fours");
+        if (wave != 0) {
+            admm_rows<H, true, false, UPD, UNI, CLK, true>(a, prep, counter, a1mpc_lds + (wave + 1) * Layout<H>::ROW_STRIDE);
+            return;
+        }
+    }
     if (wave != 0 && (row & 1)) return;  // waves 1-3: rows 1 and 3 have no QP
     const int image = wave == 0 ? (row & 1) : wave + 1;
     admm_rows<H, true, false, UPD, UNI, CLK>(a, prep, counter, a1mpc_lds + image * Layout<H>::ROW_STRIDE);
@@ -482,6 +497,16 @@ static bool cu_wide_enabled() {
     static const bool on = [] { const char* e = getenv("A1MPC_CU_WIDE"); return !(e && !strcmp(e, "0")); }();
     return on;
 }
+// the quad-of-rows ADMM kernel (H = 20, broadcast contacts).  A1MPC_QUAD=0 falls back to the twin-pair kernel (A/B runs)
+static bool quad_enabled() {
+    static const bool on = [] { const char* e = getenv("A1MPC_QUAD"); return !(e && !strcmp(e, "0")); }();
+    return on;
+}
+// ... and the CU-wide kernel's waves 1-3 (H = 16).  A1MPC_CU_QUAD=0: twin pairs on every wave
+static bool cu_quad_enabled() {
+    static const bool on = [] { const char* e = getenv("A1MPC_CU_QUAD"); return !(e && !strcmp(e, "0")); }();
+    return on && quad_enabled();
+}
 template <int H>
 static a1mpc_status resident_cu_workgroups(int* out) {
     static int resident[64] = {};
@@ -561,6 +586,9 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
             } else if (a.carry != nullptr) {
                 if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, true>), ldsq); st != A1MPC_OK) return st;
                 hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
+            } else if (a.contact_stride == 0 && cu_quad_enabled()) {
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, true, false, true>), ldsq); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, true, false, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
             } else if (a.contact_stride == 0) {
                 if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, true>), ldsq); st != A1MPC_OK) return st;
                 hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
@@ -593,7 +621,15 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     constexpr bool kHasUni = H >= 16 && ROWS == default_rows_per_wg(H) && admm_twin_rows(H, ROWS);
     if constexpr (kHasUni) {
         uni_kernel = !upd_kernels && a.contact_stride == 0;
-        if (uni_kernel) {
+        bool quad = false;
+        if constexpr (quad_rows(H, ROWS)) quad = uni_kernel && quad_enabled();
+        if constexpr (quad_rows(H, ROWS)) {
+            if (quad) {
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, true, false, true>), lds2); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, true, false, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
+            }
+        }
+        if (uni_kernel && !quad) {
             if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, true>), lds2); st != A1MPC_OK) return st;
             hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
         }

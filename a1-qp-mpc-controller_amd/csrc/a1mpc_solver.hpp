@@ -325,8 +325,13 @@ struct Prep {
 // the hot loop loses its 8 scratch reloads and 14 of 72 AGPR moves per iteration (8192 x h16 first solve 3.93 -> 3.73 ms).  Same values, same bits.
 // CLK = true (persistent ADMM kernel, profiling instantiation: a1mpc_set_profiling): shader-clock stamps around the factor passes, the iteration segments and the
 // residual checks of a QP -- outside the hot loop; the numbers behind a1mpc_last_stage_cycles (the reference's t1..t6 stopwatches, S/A1RobotControl.cpp:491-553)
-template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false, bool TWIN = false, bool UNI = false, bool CLK = false>
+// QUAD = true (persistent ADMM kernel, one QP per wavefront, H a multiple of 4: h = 20): the four rows of the wavefront work on one QP -- rows 0 / 1 in the main role,
+// rows 2 / 3 as twins, rows 1 / 3 bit-identical copies of rows 0 / 2 through everything sequential -- and the per-lane state is split four ways: slot k = step 4k + own,
+// own = 0 / 1 / 2 / 3 on rows 0 / 2 / 1 / 3.  The chains, their operands and their order are the pair's: same bits; the element-wise part of an iteration, the residual
+// norms and the state's registers are halved again.
+template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false, bool TWIN = false, bool UNI = false, bool CLK = false, bool QUAD = false>
 struct RowSolver {
+    static_assert(!QUAD || (TWIN && !GEN && H % 4 == 0), "quads of rows: a twin pair doubled, horizon a multiple of 4");
     static_assert(!UNI || (!GEN && MODE == kModeMpc), "uniform bounds: the fast path with broadcast contacts");
     static_assert(!GEN || (MODE == kModeMpc && H > 1), "the general path is an MPC solve");
     static_assert(!TWIN || (MODE == kModeMpc && !SETUP_ONLY && H > 1), "twin rows: the iterations of an MPC solve");
@@ -339,15 +344,17 @@ struct RowSolver {
     int ln, quad, comp, ci, krow;
     int mofs[12];     // TWIN: element b of my backward-sweep read inside a step's slot -- K_t[b][ci] on a main row, entry (ci, b) of the packed S_t^-1 on a twin
     bool act, wl;
-    bool twin, wr;    // TWIN: second row of the pair / this lane stores what both rows hold (act && !twin)
-    int tw;           // 0 / 1: my steps are 2k + tw
+    bool twin, wr;    // TWIN: second row of the pair / this lane stores what both rows hold (act && !twin; QUAD: row 0 only)
+    int tw;           // 0 / 1: main / twin role
+    int own;          // my steps are NS k + own  (TWIN: own = tw; QUAD: own = tw + 2 (row & 1))
     double hm, gAm, gBm, gCm, gVm;  // TWIN: 1 (main) / 0 (twin) and the costate-seed multipliers masked by it (sweep_back_rhs_twin)
     const double* brow;
     double dt, mu;
     // per-lane constants of the problem
     double Bt[6];  // my column of B~ (force layout); zero on pad lanes
     static constexpr bool kBrowInRegs = ((H <= 10) || TWIN) && !GEN;  // beyond that the per-lane ADMM state alone (6H doubles; 3H for a twin pair) overflows the register file
-    static constexpr int HS = TWIN ? H / 2 : H;  // slots of the per-lane state: slot k = step k, or step 2k + tw of a twin pair
+    static constexpr int NS = TWIN ? (QUAD ? 4 : 2) : 1;  // rows that split the per-lane state of one QP
+    static constexpr int HS = H / NS;  // slots of the per-lane state: slot k = step NS k + own
     double Brw[12];  // my row of B~ (state layout; zeros on lanes without a wrench state): step-invariant, so it stays in registers --
                      // an LDS read costs the wave ~12 issue cycles whatever its width (tools/ubench/issue_cost_ubench.hip)
     double cy, sy, fA, fB, fC, fP, gA, gB, gC, gV, q2s, r2a;
@@ -384,7 +391,9 @@ struct RowSolver {
         act = comp < 3;
         twin = TWIN && row_is_twin();
         tw = twin ? 1 : 0;
+        own = tw;
         wr = act && !twin;
+        if constexpr (QUAD) { own = tw + 2 * row_sub(); wr = wr && row_sub() == 0; }
         hm = twin ? 0.0 : 1.0;
         ci = act ? 3 * quad + comp : 0;  // compact index (safe 0 on pad lanes)
         krow = ci * L::KSTR;
@@ -401,6 +410,8 @@ struct RowSolver {
         warm = false; first_special = false; eqmask = 0; careful = false; upd = false;
     }
 
+    // the one lane that speaks for this QP (scalar outputs, the work queue)
+    A1_DEV bool lead() const { return ln == 0 && own == 0; }
     // orders LDS traffic between the lanes that work on this QP: my row, or both rows of a twin pair
     A1_DEV void sync() const {
         if constexpr (TWIN) pair_sync();
@@ -1027,25 +1038,25 @@ struct RowSolver {
         [[maybe_unused]] const bool upd_ = UPD && (fl & 4) != 0;
         [[maybe_unused]] double cgk[HS];  // update path: the true c g of my steps, parked in the pad column of K_t until the first iteration is done
         if constexpr (TWIN) {
-            const int to = tw * 12;  // my step of slot k is 2k + tw: one record row further on the twin
+            const int to = own * 12;  // my step of slot k is NS k + own: `own` record rows further on
             static_for<HS>([&](auto K) {
                 constexpr int k = A1_CV(K);
-                rr0[k] = am * p[(PR::RR0 + 2 * k) * 12 + ci + to];
-                rr1[k] = two ? p[(PR::RR0 + 2 * k) * 12 + ci + to] : 0.0;
-                dI2[k] = p[(PR::DI2 + 2 * k) * 12 + ci + to];
-                xh[k] = warm ? am * p[(PR::XH + 2 * k) * 12 + ci + to] : 0.0;
-                const int t = 2 * k + tw;
+                rr0[k] = am * p[(PR::RR0 + NS * k) * 12 + ci + to];
+                rr1[k] = two ? p[(PR::RR0 + NS * k) * 12 + ci + to] : 0.0;
+                dI2[k] = p[(PR::DI2 + NS * k) * 12 + ci + to];
+                xh[k] = warm ? am * p[(PR::XH + NS * k) * 12 + ci + to] : 0.0;
+                const int t = NS * k + own;
                 wh0[k] = (warm && act) ? io.warm_y[t * 20 + 5 * quad + r0] : 0.0;  // park_warm_y()
                 wh1[k] = (warm && act && comp < 2) ? io.warm_y[t * 20 + 5 * quad + r1] : 0.0;
                 if constexpr (UPD && H > 1) {
-                    cgk[k] = p[(PR::CG + 2 * k) * 12 + ci + to];
+                    cgk[k] = p[(PR::CG + NS * k) * 12 + ci + to];
                     if (upd_) {  // update path: y^ and the first iteration's c g come from the set-up (see setup)
-                        wh0[k] = am * p[(PR::YW0 + 2 * k) * 12 + ci + to]; wh1[k] = am * p[(PR::YW1 + 2 * k) * 12 + ci + to];
-                        if (act) lds[L::CG + 2 * k * 12 + ci + to] = p[(PR::CGE + 2 * k) * 12 + ci + to];
+                        wh0[k] = am * p[(PR::YW0 + NS * k) * 12 + ci + to]; wh1[k] = am * p[(PR::YW1 + NS * k) * 12 + ci + to];
+                        if (act) lds[L::CG + NS * k * 12 + ci + to] = p[(PR::CGE + NS * k) * 12 + ci + to];
                     }
-                    if (act && !upd_) lds[L::CG + 2 * k * 12 + ci + to] = cgk[k];
+                    if (act && !upd_) lds[L::CG + NS * k * 12 + ci + to] = cgk[k];
                 } else {
-                    if (act) lds[L::CG + 2 * k * 12 + ci + to] = p[(PR::CG + 2 * k) * 12 + ci + to];
+                    if (act) lds[L::CG + NS * k * 12 + ci + to] = p[(PR::CG + NS * k) * 12 + ci + to];
                 }
             });
         } else {
@@ -1079,7 +1090,7 @@ struct RowSolver {
         rho = p[PR::RHO * 12 + ci];
         cmask = act ? static_cast<unsigned>(pk & 0xfffffu) : 0u;
 #pragma unroll
-        for (int k = 0; k < HS; ++k) { if constexpr (!GEN) slot_bounds(k, TWIN ? 2 * k + tw : k); }
+        for (int k = 0; k < HS; ++k) { if constexpr (!GEN) slot_bounds(k, NS * k + own); }
         lo_u = P.fz_min * (cmask & 1u ? 1.0 : 0.0); hi_u = P.fz_max * (cmask & 1u ? 1.0 : 0.0);
         lb0 = comp == 2 ? lo_u : 0.0; ub0 = comp == 2 ? hi_u : kInfty;
         eqmask = act ? static_cast<unsigned>((pk >> 20) & 0xfffffu) : 0u;
@@ -1101,7 +1112,7 @@ struct RowSolver {
                                   // After the sync: in the fused kernels the record is staged in the factor region, which holds the pad columns
                 if (act) {
 #pragma unroll
-                    for (int k = 0; k < HS; ++k) lds[L::FAC + (TWIN ? 2 * k + tw : k) * L::SLOT + ci * L::KSTR + L::GCOL] = cgk[k];
+                    for (int k = 0; k < HS; ++k) lds[L::FAC + (NS * k + own) * L::SLOT + ci * L::KSTR + L::GCOL] = cgk[k];
                 }
                 sync();
             }
@@ -1118,7 +1129,7 @@ struct RowSolver {
         if (act) {
 #pragma unroll
             for (int k = 0; k < HS; ++k) {
-                const int t = TWIN ? 2 * k + tw : k;
+                const int t = NS * k + own;
                 lds[L::CG + t * 12 + ci] = lds[L::FAC + t * L::SLOT + ci * L::KSTR + L::GCOL];
             }
         }
@@ -1140,7 +1151,7 @@ struct RowSolver {
             const double wd = act ? (comp == 2 ? base + a0 + mu * mu * (spx + spy) : base + sp) : 0.0;
             const double wo = comp < 2 ? mu * (a0 - a1) : 0.0;
             const double wox = quad_perm<0, 0, 0, 0>(wo), woy = quad_perm<1, 1, 1, 1>(wo);
-            double* w = lds + L::FAC + (TWIN ? 2 * A1_CV(T) + tw : A1_CV(T)) * L::SLOT + L::K_SZ + 3 * ln;  // staged in the S area of the slot (the K area's pad column carries G)
+            double* w = lds + L::FAC + (NS * A1_CV(T) + own) * L::SLOT + L::K_SZ + 3 * ln;  // staged in the S area of the slot (the K area's pad column carries G)
             w[0] = comp == 0 ? wd : (comp == 2 ? wox : 0.0);
             w[1] = comp == 1 ? wd : (comp == 2 ? woy : 0.0);
             w[2] = comp == 2 ? wd : wo;
@@ -1428,17 +1439,17 @@ struct RowSolver {
     }
     template <bool FIRST, bool CAREFUL>
     A1_DEV void admm_iteration_twin() {
-        static_assert(H % 2 == 0, "twin rows split the horizon steps in pairs");
+        static_assert(H % NS == 0, "twin rows split the horizon steps in pairs, quads in fours");
         const double sigma_l = row_opaque(P.sigma);
         const double al = P.alpha, oma = 1.0 - P.alpha;
         const double muz = comp == 2 ? mu : 0.0, mux = comp < 2 ? mu : 0.0;
-        const double* cgp = lds + L::CG + tw * 12 + ci;  // c g of my step of slot k: cgp[24 k]
+        const double* cgp = lds + L::CG + own * 12 + ci;  // c g of my step of slot k: cgp[12 NS k]
         double d[H];
         double pv = 0.0;  // costate p_{t+1}, state layout
         double M[12], Kq[12];
         double pbn = 0.0;  // gV ror8(p_{t+1}) on the main row, 0 on the twin
         issue_back_reads<H - 1>(M);
-        double cgv = cgp[24 * (HS - 1)];
+        double cgv = cgp[12 * NS * (HS - 1)];
         row_sched_fence();
 #ifdef A1X_CLK
         const long long c0_ = clock64();
@@ -1483,7 +1494,7 @@ struct RowSolver {
                 t0 = rr0[k] * (comp == 2 ? xh[k] : fma(mu, xz, xh[k])) - csc * yw0;
                 t1 = rr1[k] * fma(-mu, xz, xh[k]) - csc * yw1;
             } else {
-                const double z0 = clamp_f64(wh0[k], lbs<k>(2 * k + tw), ubs<k>(2 * k + tw)), z1 = min_f64(wh1[k], 0.0);
+                const double z0 = clamp_f64(wh0[k], lbs<k>(NS * k + own), ubs<k>(NS * k + own)), z1 = min_f64(wh1[k], 0.0);
                 t0 = rr0[k] * fma(2.0, z0, -wh0[k]);
                 t1 = rr1[k] * fma(2.0, z1, -wh1[k]);
             }
@@ -1491,10 +1502,19 @@ struct RowSolver {
             const double smx = quad_perm<0, 0, 0, 0>(sm), smy = quad_perm<1, 1, 1, 1>(sm);
             const double at = fma(muz, smx + smy, t0 + t1);
             double e = fma(sigma_l * dI2[k], xh[k], at - cgv);
-            if constexpr (k > 0) cgv = cgp[24 * (k > 0 ? k - 1 : 0)];
+            if constexpr (k > 0) cgv = cgp[12 * NS * (k > 0 ? k - 1 : 0)];
             const double eo = twin_exchange(e);  // e: step 2k (the main row's) on both rows, eo: step 2k + 1 (the twin's)
-            back_step(std::integral_constant<int, 2 * k + 1>{}, eo);
-            back_step(std::integral_constant<int, 2 * k>{}, e);
+            if constexpr (QUAD) {  // (rows 0, 2: steps 4k, 4k + 1; rows 1, 3: steps 4k + 2, 4k + 3 -- the halves' even and odd rows swap)
+                double eb = eo;
+                const double ec = quad_exchange(e), ed = quad_exchange(eb);
+                back_step(std::integral_constant<int, 4 * k + 3>{}, ed);
+                back_step(std::integral_constant<int, 4 * k + 2>{}, ec);
+                back_step(std::integral_constant<int, 4 * k + 1>{}, eb);
+                back_step(std::integral_constant<int, 4 * k>{}, e);
+            } else {
+                back_step(std::integral_constant<int, 2 * k + 1>{}, eo);
+                back_step(std::integral_constant<int, 2 * k>{}, e);
+            }
         });
 #ifdef A1X_CLK
         const long long c1_ = clock64();
@@ -1538,20 +1558,25 @@ struct RowSolver {
         };
         static_for<HS>([&](auto K) {
             constexpr int k = A1_CV(K);
-            const double va = fwd_step(std::integral_constant<int, 2 * k>{});
-            const double vb = fwd_step(std::integral_constant<int, 2 * k + 1>{});
-            const double v = twin ? vb : va;  // my step's v
+            const double va = fwd_step(std::integral_constant<int, NS * k>{});
+            const double vb = fwd_step(std::integral_constant<int, NS * k + 1>{});
+            double v = twin ? vb : va;  // my step's v
+            if constexpr (QUAD) {
+                const double vc = fwd_step(std::integral_constant<int, 4 * k + 2>{});
+                const double vd = fwd_step(std::integral_constant<int, 4 * k + 3>{});
+                if (own >= 2) v = twin ? vd : vc;
+            }
             // update_x / update_z / update_y of my step in the w form (see the single-row code)
             [[maybe_unused]] double xz_first = 0.0;
             if constexpr (FIRST) xz_first = quad_perm<2, 2, 2, 2>(xh[k]);
             const double xh_old = xh[k];
             [[maybe_unused]] double gt0 = 0.0, gt1 = 0.0;
             if constexpr (CAREFUL) {
-                const double zp0 = clamp_f64(wh0[k], lbs<k>(2 * k + tw), ubs<k>(2 * k + tw)), zp1 = min_f64(wh1[k], 0.0);
+                const double zp0 = clamp_f64(wh0[k], lbs<k>(NS * k + own), ubs<k>(NS * k + own)), zp1 = min_f64(wh1[k], 0.0);
                 gt0 = rr0[k] * fma(2.0, zp0, -wh0[k]);
                 gt1 = rr1[k] * fma(2.0, zp1, -wh1[k]);
             }
-            const double z0 = clamp_f64(wh0[k], lbs<k>(2 * k + tw), ubs<k>(2 * k + tw));
+            const double z0 = clamp_f64(wh0[k], lbs<k>(NS * k + own), ubs<k>(NS * k + own));
             xh[k] = fma(al, v, oma * xh[k]);
             const double vz = quad_perm<2, 2, 2, 2>(v);
             const double av0 = fma(mux, vz, v);
@@ -1562,7 +1587,7 @@ struct RowSolver {
                 const double sdx = quad_perm<0, 0, 0, 0>(sdm), sdy = quad_perm<1, 1, 1, 1>(sdm);
                 const double atd = fma(muz, sdx + sdy, d0 + d1);
                 const double T = fma(sigma_l * dI2[k], xh_old - v, atd);
-                double* G = lds + L::FAC + (2 * k + tw) * L::SLOT + ci * L::KSTR + L::GCOL;
+                double* G = lds + L::FAC + (NS * k + own) * L::SLOT + ci * L::KSTR + L::GCOL;
                 if (act) *G = fma(al, T, oma * *G);
             }
             if constexpr (FIRST) {
@@ -1594,6 +1619,10 @@ struct RowSolver {
         if constexpr (TWIN) {
             const double o = twin_exchange(v);
             v = max_f64(v, o);
+            if constexpr (QUAD) {
+                const double q = quad_exchange(v);
+                v = max_f64(v, q);
+            }
         }
         return v;
     }
@@ -1605,38 +1634,45 @@ struct RowSolver {
             // each keeps the (P u) of its own steps
             double sv[H];
             double s = row_dpp_ready(0.0);
+            auto Bx = [&](int t, double x_ready) {  // (B~_t x) on the wrench lanes
+                if constexpr (GEN) {
+                    double Br[12];
+                    const double* br = brow_at(t);
+#pragma unroll
+                    for (int b = 0; b < 12; ++b) Br[b] = br[b];
+                    return dot_bc<0>(Br, x_ready);
+                } else {
+                    return dot_bc<0>(Brw, x_ready);
+                }
+            };
             static_for<HS>([&](auto K) {
                 constexpr int k = A1_CV(K);
-                double xa = xh[k];
-                const double xb = twin_exchange(xa);  // xa: step 2k (the main row's) on both rows, xb: step 2k + 1
-                auto Bx = [&](int t, double x_ready) {  // (B~_t x) on the wrench lanes
-                    if constexpr (GEN) {
-                        double Br[12];
-                        const double* br = brow_at(t);
-#pragma unroll
-                        for (int b = 0; b < 12; ++b) Br[b] = br[b];
-                        return dot_bc<0>(Br, x_ready);
-                    } else {
-                        return dot_bc<0>(Brw, x_ready);
-                    }
-                };
-                s = row_dpp_ready(opA(s) + Bx(2 * k, row_dpp_ready(xa)));
-                sv[2 * k] = q2s * s;
-                s = row_dpp_ready(opA(s) + Bx(2 * k + 1, row_dpp_ready(xb)));
-                sv[2 * k + 1] = q2s * s;
+                double xs[NS];
+                xs[0] = xh[k];
+                xs[1] = twin_exchange(xs[0]);  // xs[0]: step 2k (the main row's) on both rows, xs[1]: step 2k + 1; a quad: rows 0, 2 hold steps 4k, 4k + 1, rows 1, 3 the next two
+                if constexpr (QUAD) { xs[2] = quad_exchange(xs[0]); xs[3] = quad_exchange(xs[1]); }
+                static_for<NS>([&](auto O) {
+                    constexpr int t = NS * k + A1_CV(O);
+                    s = row_dpp_ready(opA(s) + Bx(t, row_dpp_ready(xs[O])));
+                    sv[t] = q2s * s;
+                });
             });
             double lam = row_dpp_ready(0.0);
+            auto Btl_ = [&](int t, double lam_ready) {  // (B~_t' lambda) in force layout
+                if constexpr (GEN) { double Bq[6]; Bt_at(t, Bq); return dot_bc<6>(Bq, lam_ready); }
+                else return BtT(lam_ready);
+            };
             static_for<HS>([&](auto KK) {
                 constexpr int k = HS - 1 - A1_CV(KK);
-                auto Btl_ = [&](int t, double lam_ready) {  // (B~_t' lambda) in force layout
-                    if constexpr (GEN) { double Bq[6]; Bt_at(t, Bq); return dot_bc<6>(Bq, lam_ready); }
-                    else return BtT(lam_ready);
-                };
-                lam = row_dpp_ready(sv[2 * k + 1] + opAT(lam));
-                const double b1 = Btl_(2 * k + 1, lam);
-                lam = row_dpp_ready(sv[2 * k] + opAT(lam));
-                const double b0 = Btl_(2 * k, lam);
-                Pu[k] = fma(r2a, xh[k], twin ? b1 : b0);
+                double bs[NS];
+                static_for<NS>([&](auto OO) {
+                    constexpr int o = NS - 1 - A1_CV(OO);
+                    lam = row_dpp_ready(sv[NS * k + o] + opAT(lam));
+                    bs[o] = Btl_(NS * k + o, lam);
+                });
+                double bo = twin ? bs[1] : bs[0];
+                if constexpr (QUAD) { if (own >= 2) bo = twin ? bs[3] : bs[2]; }
+                Pu[k] = fma(r2a, xh[k], bo);
             });
         } else {   // P u = B_qp' Q (B_qp u) + R u : roll-out, then adjoint
             double sv[H];
@@ -1668,7 +1704,7 @@ struct RowSolver {
         const double irho = one_c / rho_c, irho_eq = one_c / (kRhoEqOverIneq * rho_c);
         static_for<HS>([&](auto T) {
             constexpr int k = A1_CV(T);            // slot
-            const int t = TWIN ? 2 * k + tw : k;   // its horizon step
+            const int t = NS * k + own;   // its horizon step
             const double uz = quad_perm<2, 2, 2, 2>(xh[k]);
             const double ax0 = comp == 2 ? xh[k] : fma(mu, uz, xh[k]);  // E^-1 (A_s x)
             const double ax1 = comp < 2 ? fma(-mu, uz, xh[k]) : 0.0;
@@ -1804,7 +1840,7 @@ struct RowSolver {
                         // y_s = rho E (wh - zh) is kept:  wh <- zh + (rho_old / rho_new) (wh - zh),  rr <- rr rho_new / rho_old
                         const double up = rn / rho, dn = rho / rn;
                         static_for<HS>([&](auto T) {
-                            const int t_ = TWIN ? 2 * A1_CV(T) + tw : A1_CV(T);
+                            const int t_ = NS * A1_CV(T) + own;
                             const double z0 = fmin(fmax(wh0[T], lbs<A1_CV(T)>(t_)), ubs<A1_CV(T)>(t_)), z1 = fmin(wh1[T], 0.0);
                             wh0[T] = fma(dn, wh0[T] - z0, z0);
                             wh1[T] = fma(dn, wh1[T] - z1, z1);
@@ -1853,7 +1889,7 @@ struct RowSolver {
         }
         static_for<HS>([&](auto T) {
             constexpr int k = A1_CV(T);
-            const int t = TWIN ? 2 * k + tw : k;  // (a twin pair: each row writes its own steps)
+            const int t = NS * k + own;  // (a twin pair / a quad: each row writes its own steps)
             if (act) {
                 const double xu = nanout ? nanv : xh[k];
                 if (io.u_full) io.u_full[t * 12 + ci] = xu;
@@ -1875,9 +1911,9 @@ struct RowSolver {
             }
         });
 #ifdef A1X_CLK
-        if (ln == 0 && !twin && io.u_full) { io.u_full[0] = double(clkB); io.u_full[12] = double(clkF); io.u_full[24] = double(clkT); io.u_full[36] = double(clkU); io.u_full[48] = double(clkX); }
+        if (lead() && io.u_full) { io.u_full[0] = double(clkB); io.u_full[12] = double(clkF); io.u_full[24] = double(clkT); io.u_full[36] = double(clkU); io.u_full[48] = double(clkX); }
 #endif
-        if (ln == 0 && !twin) {
+        if (lead()) {
             if (io.iters) *io.iters = iter;
             if (io.status) *io.status = status_out;
             if (io.nfact) *io.nfact = nfact;
@@ -1973,9 +2009,9 @@ A1_DEV void setup_row(const BatchArgs& a, const double* __restrict__ tab, int64_
 // split pipeline, kernel 2: a persistent row.  It pulls prepared QPs from a shared counter and advances them one
 // checkpoint-aligned segment per loop trip; a row whose QP has converged writes it out and pulls the next one at the next
 // trip, so the rows of a wave never wait for each other's iteration counts -- only for each other's (rare) re-factorisations.
-template <int H, bool TWIN = false, bool GEN = false, bool UPD = false, bool UNI = false, bool CLK = false>
+template <int H, bool TWIN = false, bool GEN = false, bool UPD = false, bool UNI = false, bool CLK = false, bool QUAD = false>
 A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* __restrict__ counter, double* __restrict__ lds) {
-    RowSolver<H, kModeMpc, false, GEN, TWIN, UNI, CLK> S(a.P, a.tab, lds);
+    RowSolver<H, kModeMpc, false, GEN, TWIN, UNI, CLK, QUAD> S(a.P, a.tab, lds);
     bool alive = true, need_new = true, have = false;
     int64_t cur = 0;
     while (alive) {
@@ -1983,16 +2019,17 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
             if (have) {
                 if constexpr (UPD) S.write_outputs(make_io<H, kModeMpc>(a, cur), carry_of<H>(a, cur));
                 else S.write_outputs(make_io<H, kModeMpc>(a, cur));
-                if (a.cost != nullptr && S.ln == 0 && !S.twin) a.cost[cur] = S.iter + 10 * S.nfact;  // ~ ADMM-iteration equivalents (a factor pass ~ 10)
-                if constexpr (CLK) { if (a.clk != nullptr && S.ln == 0 && !S.twin) { a.clk[cur * 3 + 0] = S.pfX; a.clk[cur * 3 + 1] = S.pfT; a.clk[cur * 3 + 2] = S.pfU; } }
+                if (a.cost != nullptr && S.lead()) a.cost[cur] = S.iter + 10 * S.nfact;  // ~ ADMM-iteration equivalents (a factor pass ~ 10)
+                if constexpr (CLK) { if (a.clk != nullptr && S.lead()) { a.clk[cur * 3 + 0] = S.pfX; a.clk[cur * 3 + 1] = S.pfT; a.clk[cur * 3 + 2] = S.pfU; } }
             }
             double v = 0.0;
-            if (S.ln == 0 && !S.twin) {
+            if (S.lead()) {
                 const int q = row_atomic_inc(counter);
                 v = static_cast<double>((q < a.n && a.order != nullptr) ? a.order[q] : q);
             }
             v = row_bcast<0>(v);
             if constexpr (TWIN) v = twin_from_main(v);  // the twin row works on its main row's QP
+            if constexpr (QUAD) (void)quad_exchange(v);  // ... and rows 1, 3 on row 0's
             cur = static_cast<int64_t>(v);
             if (cur >= a.n) {
                 alive = false;

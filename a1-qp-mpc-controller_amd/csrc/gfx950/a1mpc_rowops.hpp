@@ -437,6 +437,25 @@ A1_DEV double twin_from_main(double v) {
     return v;
 }
 
+// ---- quads of rows (persistent ADMM kernel, horizon a multiple of 4, one QP per wavefront) ------------------------------------------------
+// With one LDS image per wavefront all four rows work on the same QP: rows 0 / 1 in the main role, rows 2 / 3 as their twins, rows 1 and 3 bit-identical
+// copies of rows 0 and 2 through the sweeps -- and the per-lane ADMM state (x^, w, rho rows, D^-2 of a step) split four ways instead of two, so that the
+// element-wise third of an iteration is issued for four steps at once (RowSolver<.., QUAD>).
+A1_DEV int row_sub() { return (static_cast<int>(threadIdx.x) >> 4) & 1; }
+// a = [x | y] on the (even | odd) row of each half  ->  a = x on both, returns y: v_permlane16_swap (odd rows of vdst <-> even rows of src) on both dwords
+A1_DEV double quad_exchange(double& a) {
+    double c;
+    asm("v_mov_b64 %0, %1\n"
+        "s_nop 1\n" : "=v"(c) : "v"(a));
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, a), cbits = __builtin_bit_cast(unsigned long long, c);
+    const unsigned lo = static_cast<unsigned>(bits), hi = static_cast<unsigned>(bits >> 32);
+    const unsigned clo = static_cast<unsigned>(cbits), chi = static_cast<unsigned>(cbits >> 32);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(lo, clo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(hi, chi, false, false);
+    a = __builtin_bit_cast(double, static_cast<unsigned long long>(r0[0]) | (static_cast<unsigned long long>(r1[0]) << 32));
+    return __builtin_bit_cast(double, static_cast<unsigned long long>(r0[1]) | (static_cast<unsigned long long>(r1[1]) << 32));
+}
+
 // true if the predicate holds on any live lane of the wavefront (= any row that is still running)
 A1_DEV bool row_wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 

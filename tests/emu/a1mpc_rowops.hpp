@@ -87,6 +87,9 @@ inline double twin_exchange(double& a) { return emu_twin_exchange(a); }
 inline double twin_exchange_copied(double& a, double /*copy of a (the device block's hazard spacing)*/) { return emu_twin_exchange(a); }
 inline double twin_from_main(double v) { (void)emu_twin_exchange(v); return v; }
 inline void pair_sync() { double z = 0.0; (void)emu_twin_exchange(z); }  // both rows of the pair arrive before either goes on
+// quads of rows (RowSolver<.., QUAD>): device only -- the test double runs pairs
+inline int row_sub() { return 0; }
+inline double quad_exchange(double& a) { return a; }
 inline void coop_sync() { pair_sync(); }  // a set-up shared by the two rows of a pair (the four-row variant of the latency kernel is not emulated)
 inline void sweep_back_rhs_twin(double& r, double& pa, double& pb, double p, const double (&Bt)[6], double gA, double gB, double gC, double hm) {
     const double* P_ = emu_publish(p);

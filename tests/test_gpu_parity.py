@@ -1399,3 +1399,16 @@ def test_settings_above_the_parity_bar_are_the_checkers_own_rounding(pkg, oracle
         assert xr["iters"] == out["iters"][i], (seed, i, xr["iters"], out["iters"][i])
         assert d_e <= 5.0 * d_o + TOL_FORCE_N, (seed, rows)
     print(f"settings seed {seed} (h = {H}, {over}): worst engine-vs-oracle {dd.max():.2e} N, {st_diff} status differences; (qp, engine-vs-oracle, engine-vs-x87, oracle-vs-x87): {rows}")
+
+
+@pytest.mark.parametrize("h,n", [(20, 2100), (16, 2600)])
+def test_quad_of_rows_kernels_leave_the_twin_pairs_bits(pkg, h, n):
+    """h = 20 (one QP per wavefront) and waves 1-3 of the CU-wide kernel at h = 16 run the four rows of a wavefront as a QUAD on one QP (RowSolver<.., QUAD>): the per-lane state
+    split four ways, the chains untouched.  Against the twin-pair kernels of the same library (A1MPC_QUAD=0 in a child process): forces, the full solution, iteration counts and
+    statuses of first solves, solves in history order and three warm-started ticks -- the same bits."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_quad.py"), pkg.build.LIB_PATH, str(h), str(n), "1"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["bit_identical"] is True, r.stdout[-800:]
