@@ -2,7 +2,8 @@
 //
 // One workgroup = one wavefront = ROWS QPs (one per main / twin pair of 16-lane DPP rows; ROWS = 2 at H = 10, 1 at H >= 16), dynamic LDS =
 // ROWS x Layout<H>::ROW_STRIDE doubles (20.4 KB per QP at H = 10 -> eight QPs = four workgroups per CU); at H = 16 the persistent ADMM kernel is ONE
-// 256-thread workgroup per CU that carries five QPs (a1mpc_admm_cu_kernel).  Three ways through a batch (launch_mpc): the latency kernel (<= 256 QPs: the
+// 256-thread workgroup per CU that carries five QPs (a1mpc_admm_cu_kernel); a wavefront that holds ONE QP (H = 20, waves 1-3 of the H = 16 workgroup) runs its four
+// rows as a quad on it (RowSolver<.., QUAD>).  Three ways through a batch (launch_mpc): the latency kernel (<= 256 QPs: the
 // rows of a wave share one QP's set-up), the fused kernel (up to the resident rows: one row pair = one QP from inputs to outputs; also warm-started ticks of a
 // known batch at H = 10) and the split pipeline (set-up kernel -> queue-order kernel -> persistent ADMM rows that drain the queue longest-first).  The QPs of a
 // batch are independent; nothing is shared between workgroups except the read-only (alpha/beta) table and the queue counter, so the blockIdx -> XCD mapping is
@@ -482,10 +483,10 @@ static a1mpc_status resident_workgroups(int* out) {
     std::lock_guard<std::mutex> lock(g_cache_mu);
     if (!resident[dev]) {
         const size_t lds2 = lds_bytes<H>(ROWS);
-        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, false, false, quad_rows(H, ROWS)>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(lds2)));
         int per_cu = 0, cus = 0;
-        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS>), admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS, lds2));
+        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, false, false, quad_rows(H, ROWS)>), admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS, lds2));
         A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         resident[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
     }
@@ -516,9 +517,9 @@ static a1mpc_status resident_cu_workgroups(int* out) {
     std::lock_guard<std::mutex> lock(g_cache_mu);
     if (!resident[dev]) {
         const size_t lds2 = lds_bytes<H>(cu_wide_qps(H));
-        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2)));
+        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2)));
         int per_cu = 0, cus = 0;
-        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H>), 256, lds2));
+        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, false, false, true>), 256, lds2));
         A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         resident[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
     }
@@ -581,11 +582,11 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
             const int wantq = (a.n + Q - 1) / Q;
             const dim3 gridq(static_cast<unsigned>(wantq < resq ? wantq : resq)), blockq(256);
             if (a.clk != nullptr && a.carry == nullptr && a.contact_stride == 0) {   // profiling instantiation (of the kernel broadcast contacts run)
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, true, true>), ldsq); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, true, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, true, true, true>), ldsq); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, true, true, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
             } else if (a.carry != nullptr) {
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, true>), ldsq); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, true, false, false, true>), ldsq); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, true, false, false, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
             } else if (a.contact_stride == 0 && cu_quad_enabled()) {
                 if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, true, false, true>), ldsq); st != A1MPC_OK) return st;
                 hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, true, false, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
@@ -593,7 +594,7 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
                 if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, true>), ldsq); st != A1MPC_OK) return st;
                 hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
             } else {
-                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
+                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, false, false, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
             }
             A1_HIP(hipGetLastError());
             return A1MPC_OK;
@@ -603,16 +604,16 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
     const dim3 grid(static_cast<unsigned>(want < res ? want : res)), block(admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS);
     if constexpr (kHasUpd) {
         if (upd_kernels) {
-            if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, true>), lds2); st != A1MPC_OK) return st;
-            hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
+            if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, true, false, false, quad_rows(H, ROWS)>), lds2); st != A1MPC_OK) return st;
+            hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, true, false, false, quad_rows(H, ROWS)>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
         }
     }
     // profiling instantiation (a1mpc_set_profiling; H > 1, default rows, no update path, broadcast contacts): the kernel of the default batches with clock stamps
     if constexpr (H > 1 && ROWS == default_rows_per_wg(H) && admm_twin_rows(H, ROWS) && cu_wide_qps(H) == 0) {
         if (a.clk != nullptr && !upd_kernels && a.contact_stride == 0) {
             constexpr bool kUni = H >= 16;
-            if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, kUni, true>), lds2); st != A1MPC_OK) return st;
-            hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, kUni, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
+            if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, kUni, true, quad_rows(H, ROWS)>), lds2); st != A1MPC_OK) return st;
+            hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, kUni, true, quad_rows(H, ROWS)>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
             A1_HIP(hipGetLastError());
             return A1MPC_OK;
         }
@@ -634,7 +635,7 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
             hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
         }
     }
-    if (!upd_kernels && !uni_kernel) hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
+    if (!upd_kernels && !uni_kernel) hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, false, false, quad_rows(H, ROWS)>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
 }

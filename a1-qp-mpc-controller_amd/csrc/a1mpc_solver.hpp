@@ -1417,7 +1417,8 @@ struct RowSolver {
     }
 
     // ---------------------------------------------------------------- the same iteration for a main / twin pair of rows (TWIN)
-    // The pair splits (a) the per-lane state: slot k of xh / wh / rr / dI2 is horizon step 2k on the main row and 2k + 1 on the twin, so all
+    // (QUAD: the same for a quad of rows -- slot k is horizon step 4k + own, rows 1 / 3 repeat what rows 0 / 2 do in the sweeps and hold their own steps' state.)
+// The pair splits (a) the per-lane state: slot k of xh / wh / rr / dI2 is horizon step 2k on the main row and 2k + 1 on the twin, so all
     // element-wise work (projection, right-hand side, x / w update) is issued once per PAIR of steps and the register file holds half the
     // state; and (b) the two 12-term products of a backward step on the same right-hand side: one chain of v_fmac_f64_dpp and one LDS read
     // per term compute K_t' r on the main row and S_t^-1 r on the twin.  Everything that is sequential over the steps (the costate, the

@@ -321,8 +321,11 @@ def other_config_rooflines(pkg, local, steps=4):
         entry = {"config": name, "batch": n, "horizon": h, "avg_kernel_ms": avg, "solves_per_s": n / (avg * 1e-3), "bound": "fp64-valu", "achieved": ach,
                  "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "mean_iters": float(it.float().mean().item()),
                  "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n, "solved_frac": float((stt == 1).float().mean().item())}
-        entry["lanes_live"] = {10: "48 of 64 (two QPs per wavefront)", 16: "28.8 of 64 on average: a CU-wide workgroup of four wavefronts carries five QPs (wave 0 two = 48 lanes, waves 1-3 one = 24 lanes each)",
-                               20: "24 of 64 (one QP per wavefront: 40 KB of LDS per QP, four per CU)"}[h]
+        entry["lanes_live"] = {10: "48 of 64 (two QPs per wavefront)",
+                               16: "48 of 64: a CU-wide workgroup of four wavefronts carries five QPs (wave 0 two as twin pairs = 48 lanes; waves 1-3 one each as a quad of rows = 48 lanes "
+                                   "in the sweeps, whose rows 1 / 3 repeat rows 0 / 2, and 4 x 12 distinct lanes in the element-wise steps)",
+                               20: "48 of 64 (one QP per wavefront as a quad of rows: 40 KB of LDS per QP, four per CU; rows 1 / 3 repeat the sweeps of rows 0 / 2 and hold their own quarter of the "
+                                   "per-lane state -- executed_fp64_frac counts the work of ONE pair, from the twin-pair kernel's PMC pass)"}[h]
         ex = pmc.get(f"{n}x{h}")   # SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 x live lanes of a first solve of this batch (static: profiles/, rocprofv3 --pmc of tools/prof_shapes.py)
         if ex:
             entry["executed_fp64_flops_per_launch"] = ex; entry["executed_fp64_frac"] = ex / (avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS

@@ -681,7 +681,7 @@ def test_general_path_split_pipeline(pkg, oracle, scen, h, nb):
     assert worst <= TOL_FORCE_N, worst
 
 
-@pytest.mark.parametrize("h,nb", [(10, 4500), (10, 700), (10, 1), (16, 1200), (20, 2300)])
+@pytest.mark.parametrize("h,nb", [(10, 4500), (10, 700), (10, 1), (16, 1200), (16, 1500), (20, 2300)])
 def test_contact_schedule_alone_stays_on_the_fast_kernels(pkg, oracle, scen, h, nb):
     """a per-step contact schedule with step-invariant feet (contact_stride = 4, foot_stride = 0, no yaw_A): the fast kernels take it (set-up
     kernel + persistent twin rows, fused kernel, latency kernel by batch size) -- vs the oracle's strided formation on a sample, and vs the
