@@ -27,6 +27,8 @@ for shape in "65536,10" "8192,16" "32768,20"; do
     # rows run the same arithmetic per QP bit for bit; a quad's rows 1 / 3 repeat the sweeps of rows 0 / 2, which this figure leaves out (it counts work, not occupancy)
     A1MPC_CU_WIDE=0 A1MPC_QUAD=0 A1_SHAPE=$shape timeout 200 rocprofv3 --pmc $set -d $O/shape_${shape/,/x}_$tag --output-format csv -- python tools/prof_target.py > /dev/null 2>&1
     [ "$shape" = "8192,16" ] && A1_SHAPE=$shape timeout 200 rocprofv3 --pmc $set -d $O/shape_${shape/,/x}cu_$tag --output-format csv -- python tools/prof_target.py > /dev/null 2>&1
+    # ... and the quads as they run (48 live lanes; rows 1 / 3 repeat the sweeps of rows 0 / 2): what the FP64 pipe ISSUES, repeats included
+    [ "$shape" = "32768,20" ] && A1_SHAPE=$shape timeout 200 rocprofv3 --pmc $set -d $O/shape_${shape/,/x}q_$tag --output-format csv -- python tools/prof_target.py > /dev/null 2>&1
   done
   A1_SHAPE=$shape timeout 200 rocprofv3 --kernel-trace --stats -d $O/shape_${shape/,/x}_trace --output-format csv -- python tools/prof_target.py > $O/shape_${shape/,/x}_trace.log 2>&1
 done

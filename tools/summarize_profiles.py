@@ -110,7 +110,8 @@ for shape, ks in shapes.items():
     # ADMM kernel: two QPs per wavefront at h = 10, one (a main / twin pair of rows) from h = 16 on.  The executed-FP64 figure of 8192 x h16 is taken from the pass on the
     # ONE-WAVE kernels (A1MPC_CU_WIDE=0: 24 live lanes in every instruction, exact); the CU-wide kernel ("..cu": five QPs on four wavefronts, wave 0 with 48 live lanes)
     # executes the same arithmetic per QP bit for bit, with fewer wave-level instructions -- its own entry prices them at the time-averaged 30 lanes (an estimate)
-    lanes = {"setup_kernel": 48, "admm_kernel": 48 if h_ == 10 else (30 if shape.endswith("cu") else 24)}
+    # "..q": the quad-of-rows kernel as it runs (h = 20: 48 live lanes, rows 1 / 3 repeating the sweeps of rows 0 / 2) -- what the FP64 pipe issues, repeats included
+    lanes = {"setup_kernel": 48, "admm_kernel": 48 if (h_ == 10 or shape.endswith("q")) else (30 if shape.endswith("cu") else 24)}
     e_ = 0.0
     for k, ln_ in lanes.items():
         c = ks.get(k, {})
