@@ -68,3 +68,17 @@ def compare(out, ref, tol=TOL_FORCE_N, min_same=MIN_SAME_ITERS, resolve=None):
             assert d <= 3.0 * slack + tol, f"QP {i}: iterations {out['iters'][i]} vs {ref['iters'][i]}; {d:.3e} N from the exact optimum, the oracle's own default-mode slack is {slack:.3e} N"
             worst_ratio = max(worst_ratio, d / max(slack, 1e-300))
     return dict(same_frac=float(frac), du=float(du), dgrf=float(dg), resolved=int((~same).sum()), worst_resolved_ratio=float(worst_ratio))
+
+
+def noise_band(O, pr, sc, i, trials=40, seed=0, settings=None):
+    """what double precision leaves open on QP i of `sc`: (the oracle's result, median, max) of the change of the oracle's GRFs over `trials` one-ulp perturbations of one
+    word of x0.  On almost every QP this is ~1e-10 N; on the few where a small rho makes the x-update ill-conditioned it reaches 1e-5 N, and there a comparison between
+    two double-precision implementations of the same iterate sequence (engine, oracle, OSQP itself) cannot be held to less (tests/tools/outlier_noise_band.py)."""
+    st = settings if settings is not None else O.default_settings()
+    base = O.mpc_solve(pr, st, sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i])
+    rng = np.random.default_rng(seed); ds = []
+    for _ in range(trials):
+        x0 = sc["x0"][i].copy(); j = rng.integers(0, 12); x0[j] = np.nextafter(x0[j], x0[j] + (1.0 if rng.random() < 0.5 else -1.0))
+        r = O.mpc_solve(pr, st, x0, sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i])
+        ds.append(np.abs(r["grf"].ravel() - base["grf"].ravel()).max())
+    return base, float(np.median(ds)), float(max(ds))

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import TOL_FORCE_BALANCE_N, TOL_FORCE_N, compare, exact_resolver, oracle_batch, oracle_params, take
+from helpers import TOL_FORCE_BALANCE_N, TOL_FORCE_N, compare, exact_resolver, noise_band, oracle_batch, oracle_params, take
 
 pytestmark = pytest.mark.gpu
 
@@ -1412,3 +1412,23 @@ def test_quad_of_rows_kernels_leave_the_twin_pairs_bits(pkg, h, n):
     assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["bit_identical"] is True, r.stdout[-800:]
+
+
+def test_the_soak_tail_is_double_precisions_own_noise(pkg, oracle, scen):
+    """The one QP of this round's 819 200-QP soak (tests/tools/soak_parity.py 20000 200 10, profiles/r04_parity_soak_1M.txt) where engine and oracle part by more than the
+    1e-5 N bar: seed 20160, QP 0 -- 100 iterations, rho adapted down to 5e-4, same iteration count and status, 4.4e-5 N between the two.  On this QP the double-precision
+    oracle's own answer moves by up to 2.9e-5 N when one word of x0 moves by one ulp (the x87 build: 7e-9 N -- the QP is not ill-posed, double precision is noisy on it),
+    so no two double-precision implementations of the iterate sequence can be held to 1e-5 N here: the engine has to stay within 3 x that band, and its neighbours in
+    the batch within the usual bar."""
+    sc = scen.config3_random_flat(nb=4096, seed=20160, param_set="gazebo")
+    with _engine(pkg, sc, 4096, warm_start=0) as eng:
+        out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+    pr = oracle_params(oracle, sc)
+    base, med, mx = noise_band(oracle, pr, sc, 0)
+    assert out["iters"][0] == base["info"].iters and out["status"][0] == base["info"].status
+    d = np.abs(out["grf"][0] - base["grf"].ravel()).max()
+    assert mx > TOL_FORCE_N, (mx, "the oracle's noise band on this QP used to exceed the parity bar: has the oracle's arithmetic changed?")
+    assert d <= 3.0 * mx, (d, med, mx)
+    ref = oracle_batch(oracle, take(sc, 256), want_u=False)
+    same = out["iters"][1:256] == ref["iters"][1:256]
+    assert same.all() and np.abs(out["grf"][1:256] - ref["grf"][1:256]).max() <= TOL_FORCE_N

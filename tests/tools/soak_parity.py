@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, __graft_entry__ as g
 pkg = g.load_package(); orc = g.load_oracle()
-worst = 0; bad = 0; tot = 0
+worst = 0; bad = 0; tot = 0; over = 0
 lo = int(sys.argv[1]) if len(sys.argv) > 1 else 3000; cnt = int(sys.argv[2]) if len(sys.argv) > 2 else 12  # usage: soak_parity.py [first_seed [count [horizon]]]
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 gen = {10: pkg.scenarios.config3_random_flat, 16: pkg.scenarios.config4_random_h16, 20: pkg.scenarios.config5_divergent}[H]
@@ -18,6 +18,14 @@ for seed in range(lo, lo + cnt):
     ref = orc.mpc_solve_batch(pr, orc.default_settings(), sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
     dd = np.abs(out["grf"].reshape(n, 12) - ref["grf"].reshape(n, 12)).max(1)
     same = (out["iters"].ravel() == ref["iters"].ravel()); steq = (out["status"].ravel() == ref["status"].ravel())
-    worst = max(worst, dd.max()); bad += int((~same).sum() + (~steq).sum()); tot += n
+    worst = max(worst, dd.max()); bad += int((~same).sum() + (~steq).sum()); tot += n; over += int((dd > 1e-5).sum())
+    for i in np.flatnonzero(dd > 1e-6):   # the tail: which of the two is nearer the same iterate sequence in x87 extended precision (tests/x87.py), and the QP itself for a closer look
+        sys.path.insert(0, os.path.join(os.getcwd(), "tests")); import x87
+        rx = x87.mpc_solve(x87.params(p, H), x87.settings(), sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i])
+        de = np.abs(out["grf"][i] - rx["grf"]).max(); do = np.abs(ref["grf"][i].ravel() - rx["grf"]).max()
+        print("  outlier seed %d QP %d: engine vs oracle %.3e N, iterations %d (x87: %d); against x87: engine %.3e N, oracle %.3e N" % (seed, i, dd[i], out["iters"][i], rx["iters"], de, do), flush=True)
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.savez("gpurun_out/soak_outlier_h%d_seed%d_qp%d.npz" % (H, seed, i), x0=sc["x0"][i], xref=sc["xref"][i], R=sc["R"][i], foot=sc["foot"][i], contact=sc["contact"][i],
+                 grf_engine=out["grf"][i], grf_oracle=ref["grf"][i], iters=out["iters"][i], param_set=("gazebo", "hardware", "isaac")[seed % 3] if H == 10 else "gazebo")
     print(seed, "max %.2e same iters %.5f status eq %.5f" % (dd.max(), same.mean(), steq.mean()), flush=True)
-print("TOTAL h =", H, ":", tot, "QPs, worst %.3e N, mismatching iteration counts / statuses: %d" % (worst, bad))
+print("TOTAL h =", H, ":", tot, "QPs, worst %.3e N, QPs over the 1e-5 N bar: %d, mismatching iteration counts / statuses: %d" % (worst, over, bad))
