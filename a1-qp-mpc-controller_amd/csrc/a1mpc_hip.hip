@@ -41,12 +41,19 @@ using KernelArgs = BatchArgs;
 // The MPC kernels with at most two QPs per wavefront run the wavefront's other rows as twins of the QP rows: rows r and r + 2 share a QP and its
 // LDS image (row_is_twin(), RowSolver<.., TWIN>); the workgroup is then a full wavefront.
 constexpr bool twin_rows(int h, int mode, int rows) { return rows <= 2 && h > 1 && mode == kModeMpc; }
+// ... and where a wavefront holds ONE QP and the horizon is a multiple of 4, all four rows work on it as a quad (fused and latency kernels; the persistent rows: quad_rows below)
+constexpr bool fused_quad_rows(int h, int mode, int rows) { return rows == 1 && h > 1 && h % 4 == 0 && mode == kModeMpc; }
 // ROWS = QPs (DPP rows) per workgroup; the workgroup is one wavefront with 16*ROWS live lanes (64 with twin rows).
 // UPD: the instantiation that also serves warm_start = 2 (the reference's update path; built for the default ROWS of a horizon only)
 template <int H, int MODE, int ROWS, bool UPD = false>
 __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     constexpr bool kTwin = twin_rows(H, MODE, ROWS);
+    if constexpr (fused_quad_rows(H, MODE, ROWS)) {   // one QP per wavefront, horizon a multiple of 4: the four rows share it as a quad (RowSolver<.., QUAD>)
+        const int64_t bq = static_cast<int64_t>(blockIdx.x);
+        solve_row_with<H, MODE, false, true, UPD, true>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(bq)); }, a1mpc_lds);
+        return;
+    }
     const int row = kTwin ? (static_cast<int>(threadIdx.x) >> 4) & 1 : static_cast<int>(threadIdx.x) >> 4;
     if (kTwin && row >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
     const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
@@ -84,10 +91,11 @@ __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a
         row_sync();  // every row is done with the set-up scratch aliased into the factor region
         if (row == 0) S.template save_prepared<UPD>(a1mpc_lds + Layout<H>::FAC);
     }
-    if (row & 1) return;
+    constexpr bool kQuad = H % 4 == 0;   // the four rows go on as a quad; otherwise rows 1 and 3 retire
+    if constexpr (!kQuad) { if (row & 1) return; }
     // Rows 0 and 2 continue exactly like a main / twin pair of the split pipeline's second kernel: a fresh solver that reads the hand-off record
     // (here through LDS).  Carrying the set-up's registers into the ADMM loop instead costs that loop its spill-free allocation.
-    RowSolver<H, kModeMpc, false, false, true> S(a.P, a.tab, a1mpc_lds);
+    RowSolver<H, kModeMpc, false, false, true, false, false, kQuad> S(a.P, a.tab, a1mpc_lds);
     S.template load_prepared<UPD>(a1mpc_lds + Layout<H>::FAC, make_io<H, kModeMpc>(a, b));
     S.template solve<UPD>();
     if constexpr (UPD) S.write_outputs(make_io<H, kModeMpc>(a, b), carry_of<H>(a, b));

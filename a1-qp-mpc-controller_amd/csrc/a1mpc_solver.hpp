@@ -1417,14 +1417,14 @@ struct RowSolver {
     }
 
     // ---------------------------------------------------------------- the same iteration for a main / twin pair of rows (TWIN)
-    // (QUAD: the same for a quad of rows -- slot k is horizon step 4k + own, rows 1 / 3 repeat what rows 0 / 2 do in the sweeps and hold their own steps' state.)
-// The pair splits (a) the per-lane state: slot k of xh / wh / rr / dI2 is horizon step 2k on the main row and 2k + 1 on the twin, so all
+    // The pair splits (a) the per-lane state: slot k of xh / wh / rr / dI2 is horizon step 2k on the main row and 2k + 1 on the twin, so all
     // element-wise work (projection, right-hand side, x / w update) is issued once per PAIR of steps and the register file holds half the
     // state; and (b) the two 12-term products of a backward step on the same right-hand side: one chain of v_fmac_f64_dpp and one LDS read
     // per term compute K_t' r on the main row and S_t^-1 r on the twin.  Everything that is sequential over the steps (the costate, the
     // roll-out) is computed redundantly and bit-identically by both rows; twin_exchange() moves the per-step values the other row needs
     // (the right-hand-side data e_t, then p_t / d_t).  Every value is formed by the same operations in the same order as in the
     // single-row code above: the two kernels agree bit for bit.
+    // QUAD, a quad of rows on one QP: slot k is horizon step 4k + own, rows 1 / 3 repeat what rows 0 / 2 do in the sweeps and hold their own steps' state; the right-hand sides of a slot's four steps reach every row through one v_permlane32_swap and two v_permlane16_swap.
     // LDS reads are issued as soon as the block that consumed the previous step's has been issued (into the registers it frees): with one
     // wave per SIMD nothing else hides an LDS round trip.  (Measured and not kept: carrying the first reads of the next iteration across the
     // loop back-edge -- the loop-carried registers push loop invariants into scratch, 2.95 -> 3.56 us per iteration; double-buffering the
@@ -2054,9 +2054,10 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
 // TWIN: the calling row is one of a main / twin pair (rows r and r + 2 of the wavefront, see RowSolver<.., TWIN>): the main row sets the QP up alone,
 // both iterate.
 // UPD: the instantiation that also serves warm_start = 2 (the reference's update path); UPD = false is the code of every other mode, as it was before that path existed
-template <int H, int MODE, bool GEN = false, bool TWIN = false, bool UPD = false, class MakeIO>
+template <int H, int MODE, bool GEN = false, bool TWIN = false, bool UPD = false, bool QUAD = false, class MakeIO>
 A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab, MakeIO&& make_io_, double* __restrict__ lds) {
     static_assert(!TWIN || (MODE == kModeMpc && Prep<H>::STRIDE <= H * Layout<H>::SLOT), "twin rows: the MPC solve with the set-up | iteration hand-off");
+    static_assert(!QUAD || (TWIN && !GEN), "a quad of rows: a twin pair doubled, fast path");
     if constexpr (GEN) {
         // general path (per-step feet / contact schedules): the same set-up | iteration hand-off as below (its per-step tables live behind c*g
         // in the LDS image and survive it; the T*B~w table aliased into the factor region is dead once the Ruiz passes are done)
@@ -2081,12 +2082,13 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
         {   // (a main / twin pair shares the set-up: see the general path above)
             RowSolver<H, MODE> S0(P, tab, lds);
             if constexpr (TWIN) { S0.coop_id = row_is_twin() ? 1 : 0; S0.coop_n = 2; }
+            if constexpr (QUAD) { S0.coop_id = 2 * S0.coop_id + row_sub(); S0.coop_n = 4; }   // (a quad: the four rows, like the latency kernel's)
             S0.template setup<UPD>(make_io_());
             if constexpr (TWIN) pair_sync(); else row_sync();
-            if (!TWIN || !row_is_twin()) S0.template save_prepared<UPD>(lds + Layout<H>::FAC);
+            if ((!TWIN || !row_is_twin()) && (!QUAD || row_sub() == 0)) S0.template save_prepared<UPD>(lds + Layout<H>::FAC);
         }
         if constexpr (TWIN) pair_sync();  // the twin reads the hand-off record its main row wrote
-        RowSolver<H, MODE, false, false, TWIN> S(P, tab, lds);
+        RowSolver<H, MODE, false, false, TWIN, false, false, QUAD> S(P, tab, lds);
         S.template load_prepared<UPD>(lds + Layout<H>::FAC, make_io_());
         S.template solve<UPD>();
         if constexpr (UPD) { const ProblemIO& io_ = make_io_(); S.write_outputs(io_, io_.carry); }
