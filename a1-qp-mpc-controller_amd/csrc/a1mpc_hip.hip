@@ -866,7 +866,8 @@ static bool warm_fused_enabled() {
 static int warm_fused_max(int horizon) {
     static const int over = [] { const char* e = getenv("A1MPC_WARM_FUSED_MAX"); return e ? atoi(e) : 0; }();
     if (over > 0) return over;
-    return horizon == 10 ? 8192 : 0;
+    return horizon == 10 ? 8192 : (horizon == 20 ? 2048 : 0);   // (h = 16 / 20 with the fused kernel's quads of rows: profiles/r04_warm_ticks_h16_h20_fused_vs_split.txt -- 2048 x h20
+                                                                 // 0.72 -> 0.63 ms per tick; from 4096 on, and at h = 16 everywhere, the split pipeline's denser residency wins)
 }
 static constexpr int kScheduleMinBatch = 1024;  // below this every QP is resident at once and the order cannot matter
 

@@ -1325,13 +1325,13 @@ def test_stage_cycles_through_the_abi(pkg, scen, gen, n):
     assert 0.5 < cyc["iterate"] / tot < 0.95 and 0.03 < cyc["factor"] / tot < 0.45
 
 
-@pytest.mark.parametrize("mode,n,h", [(1, 4096, 10), (2, 4096, 10), (1, 1400, 16), (1, 1200, 20)])
+@pytest.mark.parametrize("mode,n,h", [(1, 4096, 10), (2, 4096, 10), (1, 1400, 16), (1, 1200, 20), (2, 1200, 20), (1, 2400, 20)])
 def test_warm_ticks_of_a_large_batch_take_the_fused_kernel_and_match_the_oracle(pkg, oracle, scen, mode, n, h):
     """Round 4: second and later warm-started ticks of a batch size run the FUSED kernel up to 8192 QPs at h = 10 (solve_device_impl: nothing left for the queue to
     balance when every QP takes ~25 iterations), the first tick and any tick after a1mpc_set_schedule the split pipeline.  4096 robots, four ticks with slowly moving
     states, both warm-start semantics: every 16th robot is chained through the oracle the same way -- same iteration count and status, forces within the parity
-    tolerance on every tick -- and a1mpc_last_stage_ms tells which pipeline ran (the fused kernel has no set-up stage of its own).  The h = 16 / 20 cases run the
-    warm-start hand-off of the split pipeline (the CU-wide kernel at h = 16) the same way."""
+    tolerance on every tick -- and a1mpc_last_stage_ms tells which pipeline ran (the fused kernel has no set-up stage of its own).  The h = 16 and the larger h = 20 cases
+    run the warm-start hand-off of the split pipeline (the CU-wide kernel at h = 16) the same way; h = 20 up to 2048 QPs takes the fused kernel's quads of rows."""
     ticks = 4
     rng = np.random.default_rng(404)
     sc = scen.config3_random_flat(nb=n, seed=4040, horizon=h)
@@ -1357,10 +1357,10 @@ def test_warm_ticks_of_a_large_batch_take_the_fused_kernel_and_match_the_oracle(
                 assert out["iters"][i] == r["info"].iters and out["status"][i] == r["info"].status, (mode, t, i, out["iters"][i], r["info"].iters)
                 worst = max(worst, float(np.abs(out["u"][i] - r["u"]).max()))
             assert worst <= TOL_FORCE_N, (mode, t, worst)
-    if h == 10:
-        assert staged[0] and not any(staged[1:]), staged     # tick 0: split pipeline (set-up stage timed); ticks 1..: the fused kernel
+    if h == 10 or (h == 20 and n <= 2048):
+        assert staged[0] and not any(staged[1:]), staged     # tick 0: split pipeline (set-up stage timed); ticks 1..: the fused kernel (h = 20: its quad of rows, up to 2048 QPs)
     else:
-        assert all(staged), staged                           # h = 16 / 20: warm ticks stay on the split pipeline (the CU-wide kernel at h = 16), where the fused kernel loses
+        assert all(staged), staged                           # h = 16, larger h = 20 batches: warm ticks stay on the split pipeline (the CU-wide kernel at h = 16), where the fused kernel loses
 
 
 @pytest.mark.parametrize("seed", [1071, 1217, 1160, 1501])
