@@ -14,7 +14,9 @@
 namespace a1mpc {
 
 struct EmuRow;
-extern thread_local int emu_lane;        // 0..15, or 0..31 when a main / twin pair of rows is emulated (16..31 = the twin)
+extern thread_local int emu_lane;        // 0..15, or 0..31 when a main / twin pair of rows is emulated (16..31 = the twin), or 0..63 for a quad (the device's lane order)
+extern thread_local int emu_lanes;       // 16 / 32 / 64
+double emu_quad_exchange(double& a);     // a = [x | y] on the (even | odd) row of each half of a quad -> a = x on both, returns y
 const double* emu_publish(double v);     // returns the 16 published values of MY row of this exchange
 double emu_twin_exchange(double& a);     // a = [x | y] on (main | twin) -> a = [x | x], returns [y | y]
 
@@ -82,15 +84,15 @@ inline void sweep_back_chains(double& d, double& pa, double& pb, double r, const
     d = da + db;
 }
 // ---- a main / twin pair of rows (RowSolver<.., TWIN>): the same operation order as the gfx950 blocks
-inline bool row_is_twin() { return emu_lane >= 16; }
+inline bool row_is_twin() { return emu_lanes == 64 ? (emu_lane & 32) != 0 : emu_lane >= 16; }
 inline double twin_exchange(double& a) { return emu_twin_exchange(a); }
 inline double twin_exchange_copied(double& a, double /*copy of a (the device block's hazard spacing)*/) { return emu_twin_exchange(a); }
 inline double twin_from_main(double v) { (void)emu_twin_exchange(v); return v; }
 inline void pair_sync() { double z = 0.0; (void)emu_twin_exchange(z); }  // both rows of the pair arrive before either goes on
-// quads of rows (RowSolver<.., QUAD>): device only -- the test double runs pairs
-inline int row_sub() { return 0; }
-inline double quad_exchange(double& a) { return a; }
-inline void coop_sync() { pair_sync(); }  // a set-up shared by the two rows of a pair (the four-row variant of the latency kernel is not emulated)
+// quads of rows (RowSolver<.., QUAD>): 64 fibers in the device's lane order
+inline int row_sub() { return emu_lanes == 64 ? (emu_lane >> 4) & 1 : 0; }
+inline double quad_exchange(double& a) { return emu_quad_exchange(a); }
+inline void coop_sync() { pair_sync(); }  // a set-up shared by the rows of a pair or a quad (the exchange waits for every emulated lane)
 inline void sweep_back_rhs_twin(double& r, double& pa, double& pb, double p, const double (&Bt)[6], double gA, double gB, double gC, double hm) {
     const double* P_ = emu_publish(p);
     double ra = r, rb = 0.0;

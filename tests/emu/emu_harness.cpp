@@ -15,9 +15,10 @@
 namespace a1mpc {
 
 thread_local int emu_lane = 0;
+thread_local int emu_lanes = 16;  // lanes of the emulated (part of a) wavefront: 16 = one row, 32 = a main / twin pair, 64 = a quad of rows in the device's lane order
 
 namespace {
-constexpr int kLanes = 32;  // a DPP row, or a main / twin pair of rows (lanes 16-31 = the twin: RowSolver<.., TWIN>)
+constexpr int kLanes = 64;  // a DPP row, a main / twin pair of rows (lanes 16-31 = the twin: RowSolver<.., TWIN>), or a quad (the wavefront: rows 2 / 3 = the twins, RowSolver<.., QUAD>)
 constexpr size_t kStack = 1 << 20;
 struct Sched {
     int lanes;
@@ -25,8 +26,8 @@ struct Sched {
     ucontext_t ctx[kLanes];
     char* stacks[kLanes];
     bool finished[kLanes];
-    double buf[2][kLanes], xbuf[2][kLanes];  // row-local exchanges / exchanges between the rows of a pair
-    long gen[kLanes], xgen[kLanes];          // how many of each this lane has published
+    double buf[2][kLanes], xbuf[2][kLanes], qbuf[2][kLanes];  // row-local exchanges / exchanges between the rows of a pair / between the even and odd row of each half of a quad
+    long gen[kLanes], xgen[kLanes], qgen[kLanes];            // how many of each this lane has published
     void (*fn)(void*);
     void* arg;
 };
@@ -71,9 +72,24 @@ double emu_twin_exchange(double& a) {
     const long g = ++s->xgen[l];
     const double mine = a;
     s->xbuf[g & 1][l] = a;
-    wait_for(s, l, s->xgen, g, 0, 32);
-    const double other = s->xbuf[g & 1][l ^ 16];
-    if (l < 16) return other;
+    const int half = s->lanes == 64 ? 32 : 16;   // (a quad runs in the device's lane order: the twins are rows 2 and 3)
+    wait_for(s, l, s->xgen, g, 0, s->lanes);
+    const double other = s->xbuf[g & 1][l ^ half];
+    if (!(l & half)) return other;
+    a = other;
+    return mine;
+}
+// a = [x | y] on the (even | odd) row of each half of a quad  ->  a = x on both, returns y   (v_permlane16_swap on the device)
+double emu_quad_exchange(double& a) {
+    Sched* s = g_s;
+    const int l = emu_lane;
+    if (s->lanes != 64) { fprintf(stderr, "emu: quad_exchange outside a quad of rows\n"); abort(); }
+    const long g = ++s->qgen[l];
+    const double mine = a;
+    s->qbuf[g & 1][l] = a;
+    wait_for(s, l, s->qgen, g, 0, 64);
+    const double other = s->qbuf[g & 1][l ^ 16];
+    if (!(l & 16)) return other;
     a = other;
     return mine;
 }
@@ -82,6 +98,7 @@ static void run_row(void (*fn)(void*), void* arg, int lanes = 16) {
     Sched s;
     memset(&s, 0, sizeof s);
     s.lanes = lanes;
+    emu_lanes = lanes;
     s.fn = fn;
     s.arg = arg;
     g_s = &s;
@@ -132,7 +149,15 @@ static void job_twin_entry(void* a) {  // the fused kernel on a main / twin pair
         else solve_row_with<H, kModeMpc, false, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
     }
 }
-static bool g_emu_twin = false;  // a1mpc_emu_set_twin(): the fused entry points run main / twin pairs
+template <int H>
+static void job_quad_entry(void* a) {  // the fused kernel on a quad of rows (one QP per wavefront, H a multiple of 4)
+    Job<H>* j = static_cast<Job<H>*>(a);
+    if constexpr (H > 1 && H % 4 == 0) {
+        if (j->io.carry) solve_row_with<H, kModeMpc, false, true, true, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+        else solve_row_with<H, kModeMpc, false, true, false, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+    }
+}
+static int g_emu_twin = 0;  // a1mpc_emu_set_twin(): the fused entry points run main / twin pairs (1) or quads of rows (2; H a multiple of 4)
 static double* g_emu_carry = nullptr;  // a1mpc_emu_set_carry(): n x Carry<H>::STRIDE doubles of the update path (warm_start = 2), or null
 static int g_emu_contact_stride = 0;  // a1mpc_emu_set_contact_stride(): 4 = `contact` is an n x 4H per-step schedule (fast path, feet step-invariant)
 template <int H>
@@ -164,13 +189,14 @@ static void run_batch(const DeviceParams* P, int n, const double* x0, const doub
         j.io.status = status ? status + b : nullptr;
         j.io.nfact = nfact ? nfact + b : nullptr;
         j.io.carry = g_emu_carry ? g_emu_carry + (size_t)b * Carry<H>::STRIDE : nullptr;
-        if (g_emu_twin && H > 1 && H % 2 == 0) run_row(job_twin_entry<H>, &j, 32);
+        if (g_emu_twin == 2 && H > 1 && H % 4 == 0) run_row(job_quad_entry<H>, &j, 64);
+        else if (g_emu_twin && H > 1 && H % 2 == 0) run_row(job_twin_entry<H>, &j, 32);
         else run_row(job_entry<H>, &j);
     }
 }
 
 }  // namespace a1mpc
-extern "C" void a1mpc_emu_set_twin(int on) { a1mpc::g_emu_twin = on != 0; }
+extern "C" void a1mpc_emu_set_twin(int on) { a1mpc::g_emu_twin = on; }
 extern "C" void a1mpc_emu_set_contact_stride(int stride) { a1mpc::g_emu_contact_stride = stride; }
 extern "C" void a1mpc_emu_set_carry(double* carry) { a1mpc::g_emu_carry = carry; }
 extern "C" int a1mpc_emu_carry_stride(int horizon) {
@@ -197,6 +223,15 @@ static void split_admm_twin_entry(void* p) {
     auto* j = static_cast<SplitJob<H>*>(p);
     if (j->a->carry) admm_rows<H, true, false, true>(*j->a, j->prep, j->counter, j->lds); else admm_rows<H, true>(*j->a, j->prep, j->counter, j->lds);
 }
+template <int H>
+static void split_admm_quad_entry(void* p) {   // (the device's instantiations: broadcast contacts run UNI, a schedule or the update path the plain one)
+    auto* j = static_cast<SplitJob<H>*>(p);
+    if constexpr (H > 1 && H % 4 == 0) {
+        if (j->a->carry) admm_rows<H, true, false, true, false, false, true>(*j->a, j->prep, j->counter, j->lds);
+        else if (j->a->contact_stride == 0) admm_rows<H, true, false, false, true, false, true>(*j->a, j->prep, j->counter, j->lds);
+        else admm_rows<H, true, false, false, false, false, true>(*j->a, j->prep, j->counter, j->lds);
+    }
+}
 // the split pipeline on host fibers: K1 for every QP, then `nrows` persistent rows draining the queue one after another
 template <int H>
 static void run_split(const BatchArgs& a, int nrows, bool twin = false) {
@@ -215,6 +250,7 @@ static void run_split(const BatchArgs& a, int nrows, bool twin = false) {
     for (int r = 0; r < nrows; ++r) {
         for (auto& v : lds2) v = NAN;
         j.lds = lds2.data();
+        if constexpr (H > 1 && H % 4 == 0) { if (twin && g_emu_twin == 2) { run_row(split_admm_quad_entry<H>, &j, 64); continue; } }
         if constexpr (H > 1) { if (twin) { run_row(split_admm_twin_entry<H>, &j, 32); continue; } }
         run_row(split_admm_entry<H>, &j);
     }

@@ -248,6 +248,54 @@ def test_emulated_contact_schedule_on_the_fast_path(oracle, scen, h, twin, split
     assert (gen["iters"] == out["iters"]).all() and np.abs(gen["u"] - out["u"]).max() < 1e-9
 
 
+# ---- quads of rows (RowSolver<.., QUAD>: the device kernels that hold ONE QP per wavefront -- H = 16 / 20) --------------------------------------
+@pytest.mark.parametrize("gen,kw,n", [("config4_random_h16", dict(nb=4), 3), ("config5_divergent", dict(nb=4), 2)])
+def test_emulated_quad_of_rows_matches_the_twin_pair_bit_for_bit(oracle, scen, gen, kw, n):
+    """64 fibers in the device's lane order: rows 0 / 1 in the main role, rows 2 / 3 as twins, the per-lane state split four ways (slot k = step 4k + own), a slot's four
+    right-hand sides handed round by twin_exchange + quad_exchange, the fused path's set-up shared by the four rows.  Same operations in the same order as the pair's:
+    the same bits -- on the fused path and through the set-up kernel + persistent rows (the instantiation broadcast contacts run, UNI)."""
+    sc = getattr(scen, gen)(**kw)
+    two = emu.solve(sc, n, twin=True)
+    four = emu.solve(sc, n, quad=True)
+    for k in ("u", "grf", "iters", "status", "nfact"):
+        assert np.array_equal(two[k], four[k]), k
+    split = emu.solve(sc, n, split_rows=1, quad=True)
+    for k in ("u", "grf", "iters", "status", "nfact"):
+        assert np.array_equal(two[k], split[k]), k
+    compare(four, oracle_batch(oracle, sc, n), tol=1e-8, min_same=1.0)
+
+
+def test_emulated_quad_of_rows_contact_schedule_warm_start_update_path_and_bad_input(oracle, scen):
+    """the other instantiations of the quad: a per-step contact schedule (per-slot bounds), warm-started ticks (the FIRST-iteration variant: y0 parked in the w registers
+    of the row that owns the step), the update path (warm_start = 2: carry written by the row that owns the step, c g restored after iteration 1), a NaN input -- each
+    against the twin pair's bits"""
+    rng = np.random.default_rng(720)
+    sc, foot, fs, contact, cs = _strided_case(scen, rng, 20, 2, False, True)
+    a = emu.solve(sc, 2, twin=True, split_rows=1, contact_schedule=contact); b = emu.solve(sc, 2, quad=True, split_rows=1, contact_schedule=contact)
+    c = emu.solve(sc, 2, quad=True, contact_schedule=contact)
+    for k in ("u", "grf", "iters", "status", "nfact"):
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
+    sc = scen.config3_random_flat(nb=1, horizon=16)
+    rng = np.random.default_rng(721)
+    for mode, split in ((1, 0), (1, 1), (2, 0), (2, 1)):
+        w2 = (np.zeros((1, 192)), np.zeros((1, 320)), np.zeros(1)); w4 = (np.zeros((1, 192)), np.zeros((1, 320)), np.zeros(1))
+        c2 = emu.carry_buffer(16, 1) if mode == 2 else None; c4 = emu.carry_buffer(16, 1) if mode == 2 else None
+        x0 = sc["x0"].copy()
+        for t in range(3):
+            one = dict(sc); one["x0"] = x0
+            two = emu.solve(one, 1, warm=w2, warm_start=mode, twin=True, split_rows=split, carry=c2)
+            four = emu.solve(one, 1, warm=w4, warm_start=mode, quad=True, split_rows=split, carry=c4)
+            for k in ("u", "grf", "iters", "status", "nfact"):
+                assert np.array_equal(two[k], four[k]), (mode, split, t, k)
+            assert np.array_equal(w2[0], w4[0]) and np.array_equal(w2[1], w4[1]) and np.array_equal(w2[2], w4[2])
+            if mode == 2: assert np.array_equal(c2, c4)
+            x0 = x0.copy(); x0[:, :12] += rng.normal(0, 2e-3, (1, 12))
+    sc = scen.config5_divergent(nb=2)
+    sc["x0"][0, 4] = np.nan
+    out = emu.solve(sc, 2, quad=True)
+    assert out["status"][0] == -7 and (out["grf"][0] == 0).all() and np.isnan(out["u"][0]).all() and out["status"][1] == 1
+
+
 # ---- the Ruiz sweep's early stop (RowSolver::setup, column loop) ------------------------------------------------------------------------------
 @pytest.mark.parametrize("gen,kw,n,split", [("config3_random_flat", dict(nb=8), 6, 0), ("config3_random_flat", dict(nb=8, param_set="hardware"), 4, 2),
                                             ("config5_divergent", dict(nb=4), 2, 1)])
@@ -336,25 +384,26 @@ def test_emulated_update_path_reinitialises_on_a_pattern_change(oracle, scen, pa
     assert seen == [0, 0, 1, 0, 1, 0]
 
 
-@pytest.mark.parametrize("gen,kw,n,twin,split", [("config3_random_flat", {}, 3, True, 0), ("config5_divergent", {"horizon": 10}, 4, True, 2)])
+@pytest.mark.parametrize("gen,kw,n,twin,split", [("config3_random_flat", {}, 3, True, 0), ("config5_divergent", {"horizon": 10}, 4, True, 2), ("config4_random_h16", {}, 1, "quad", 1)])
 def test_emulated_dont_care_lanes_are_dont_cares(scen, gen, kw, n, twin, split):
     """the hot loop no longer holds the fz lanes' (non-existent) second-row variable wh1 at zero, nor the pad lanes' state -- correctness rests on every
     reader masking them.  A build that overwrites them at every segment start (fz-lane wh1 = +-1e300, pad-lane xh / wh0 / wh1 = NaN; -DA1X_POISON) must return the
     same bits: forces, iteration counts, status, factor passes, and the carried warm start."""
     sc = getattr(scen, gen)(nb=n, **kw)
+    rows = dict(quad=True) if twin == "quad" else dict(twin=twin)   # (a quad of rows: the h = 16 / 20 kernels)
     for ws in (0, 1):
         warm = None
         if ws:
             h = sc["horizon"]
-            first = emu.solve(sc, n, warm=(np.zeros((n, 12 * h)), np.zeros((n, 20 * h)), np.zeros(n)), warm_start=1, twin=twin, split_rows=split)
+            first = emu.solve(sc, n, warm=(np.zeros((n, 12 * h)), np.zeros((n, 20 * h)), np.zeros(n)), warm_start=1, split_rows=split, **rows)
             assert (first["status"] == 1).all()
         def run():
             w = None
             if ws:
                 h = sc["horizon"]
                 w = (np.zeros((n, 12 * h)), np.zeros((n, 20 * h)), np.zeros(n))
-                emu.solve(sc, n, warm=w, warm_start=1, twin=twin, split_rows=split)      # tick 1 fills the workspace ...
-            out = emu.solve(sc, n, warm=w, warm_start=ws, twin=twin, split_rows=split)     # ... tick 2 starts from it (OSQP's first-iteration code path)
+                emu.solve(sc, n, warm=w, warm_start=1, split_rows=split, **rows)      # tick 1 fills the workspace ...
+            out = emu.solve(sc, n, warm=w, warm_start=ws, split_rows=split, **rows)     # ... tick 2 starts from it (OSQP's first-iteration code path)
             return out, w
         a, wa = run()
         with emu.using(emu.variant(["-DA1X_POISON"], "poison")):
