@@ -67,6 +67,11 @@ template <int H, int ROWS>
 __global__ __launch_bounds__(64) void a1mpc_solve_gen_kernel(const KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     static_assert(ROWS <= 2, "rows r and r + 2 of the wavefront share a QP (twin rows)");
+    if constexpr (fused_quad_rows(H, kModeMpc, ROWS)) {   // one QP per wavefront, horizon a multiple of 4: a quad of rows
+        const int64_t bq = static_cast<int64_t>(blockIdx.x);
+        solve_row_with<H, kModeMpc, true, true, false, true>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(bq)); }, a1mpc_lds);
+        return;
+    }
     const int row = (static_cast<int>(threadIdx.x) >> 4) & 1;
     if (row >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
     const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
@@ -191,6 +196,10 @@ template <int H, int ROWS>
 __global__ __launch_bounds__(64) void a1mpc_admm_gen_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     static_assert(ROWS <= 2, "rows r and r + 2 of the wavefront share a QP (twin rows)");
+    if constexpr (fused_quad_rows(H, kModeMpc, ROWS)) {   // one QP per wavefront, horizon a multiple of 4: a quad of rows
+        admm_rows<H, true, true, false, false, false, true>(a, prep, counter, a1mpc_lds);
+        return;
+    }
     const int row = static_cast<int>(threadIdx.x) >> 4;
     if ((row & 1) >= ROWS) return;
     admm_rows<H, true, true>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H, true>::ROW_STRIDE);

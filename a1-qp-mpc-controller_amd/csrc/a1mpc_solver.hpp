@@ -331,7 +331,7 @@ struct Prep {
 // norms and the state's registers are halved again.
 template <int H, int MODE = kModeMpc, bool SETUP_ONLY = false, bool GEN = false, bool TWIN = false, bool UNI = false, bool CLK = false, bool QUAD = false>
 struct RowSolver {
-    static_assert(!QUAD || (TWIN && !GEN && H % 4 == 0), "quads of rows: a twin pair doubled, horizon a multiple of 4");
+    static_assert(!QUAD || (TWIN && H % 4 == 0), "quads of rows: a twin pair doubled, horizon a multiple of 4");
     static_assert(!UNI || (!GEN && MODE == kModeMpc), "uniform bounds: the fast path with broadcast contacts");
     static_assert(!GEN || (MODE == kModeMpc && H > 1), "the general path is an MPC solve");
     static_assert(!TWIN || (MODE == kModeMpc && !SETUP_ONLY && H > 1), "twin rows: the iterations of an MPC solve");
@@ -2057,7 +2057,7 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
 template <int H, int MODE, bool GEN = false, bool TWIN = false, bool UPD = false, bool QUAD = false, class MakeIO>
 A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab, MakeIO&& make_io_, double* __restrict__ lds) {
     static_assert(!TWIN || (MODE == kModeMpc && Prep<H>::STRIDE <= H * Layout<H>::SLOT), "twin rows: the MPC solve with the set-up | iteration hand-off");
-    static_assert(!QUAD || (TWIN && !GEN), "a quad of rows: a twin pair doubled, fast path");
+    static_assert(!QUAD || TWIN, "a quad of rows: a twin pair doubled");
     if constexpr (GEN) {
         // general path (per-step feet / contact schedules): the same set-up | iteration hand-off as below (its per-step tables live behind c*g
         // in the LDS image and survive it; the T*B~w table aliased into the factor region is dead once the Ruiz passes are done)
@@ -2066,12 +2066,13 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
             // other horizon step of the D / E updates, everything else is computed redundantly (same values, same LDS image)
             RowSolver<H, MODE, false, true> S0(P, tab, lds);
             if constexpr (TWIN) { S0.coop_id = row_is_twin() ? 1 : 0; S0.coop_n = 2; }
+            if constexpr (QUAD) { S0.coop_id = 2 * S0.coop_id + row_sub(); S0.coop_n = 4; }   // (a quad: the four rows)
             S0.setup(make_io_());
             if constexpr (TWIN) pair_sync(); else row_sync();  // everybody is done with the set-up scratch aliased into the factor region
-            if (!TWIN || !row_is_twin()) S0.save_prepared(lds + Layout<H, true>::FAC);
+            if ((!TWIN || !row_is_twin()) && (!QUAD || row_sub() == 0)) S0.save_prepared(lds + Layout<H, true>::FAC);
         }
         if constexpr (TWIN) pair_sync();  // the twin reads the hand-off record and the per-step tables its main row wrote
-        RowSolver<H, MODE, false, true, TWIN> S(P, tab, lds);
+        RowSolver<H, MODE, false, true, TWIN, false, false, QUAD> S(P, tab, lds);
         S.load_prepared(lds + Layout<H, true>::FAC, make_io_());
         S.solve();
         S.write_outputs(make_io_());

@@ -138,7 +138,7 @@ def _solve(sc, n, h, P, grf, u, iters, status, nfact, wx, wy, rho, contact, spli
     return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
 
 
-def solve_gen(sc, foot, foot_stride, contact, contact_stride, n=None, settings=None, warm=None, twin=False, **over):
+def solve_gen(sc, foot, foot_stride, contact, contact_stride, n=None, settings=None, warm=None, twin=False, quad=False, **over):
     """the general path: foot (n, 12) or (n, 12h) with foot_stride 0 / 12; contact (n, 4) or (n, 4h) with contact_stride 0 / 4"""
     h = sc["horizon"]
     n = len(sc["x0"]) if n is None else n
@@ -149,7 +149,7 @@ def solve_gen(sc, foot, foot_stride, contact, contact_stride, n=None, settings=N
     wx = wy = rho = None
     if warm is not None:
         wx, wy, rho = warm
-    lib().a1mpc_emu_set_twin(1 if twin else 0)
+    lib().a1mpc_emu_set_twin(2 if quad else (1 if twin else 0))
     rc = lib().a1mpc_emu_solve_gen(C.byref(P), h, n, _p(sc["x0"]), _p(sc["xref"]), _p(sc["R"]), _p(foot), int(foot_stride), _p(contact, C.c_uint8),
                                    int(contact_stride), _p(grf), _p(u), _p(wx), _p(wy), _p(rho), _p(iters, C.c_int32), _p(status, C.c_int32),
                                    _p(nfact, C.c_int32))
@@ -158,7 +158,7 @@ def solve_gen(sc, foot, foot_stride, contact, contact_stride, n=None, settings=N
     return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
 
 
-def solve_gen_split(sc, foot, foot_stride, contact, contact_stride, rows=2, n=None, settings=None, **over):
+def solve_gen_split(sc, foot, foot_stride, contact, contact_stride, rows=2, n=None, settings=None, quad=False, **over):
     """the general path's split pipeline: its own set-up kernel, then `rows` persistent main / twin pairs draining the queue"""
     h = sc["horizon"]
     n = len(sc["x0"]) if n is None else n
@@ -166,8 +166,10 @@ def solve_gen_split(sc, foot, foot_stride, contact, contact_stride, rows=2, n=No
     foot = np.ascontiguousarray(foot, dtype=np.float64); contact = np.ascontiguousarray(contact, dtype=np.uint8)
     grf = np.zeros((n, 12)); u = np.zeros((n, 12 * h))
     iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32); nfact = np.zeros(n, np.int32)
+    lib().a1mpc_emu_set_twin(2 if quad else 0)
     rc = lib().a1mpc_emu_solve_gen_split(C.byref(P), h, n, int(rows), _p(sc["x0"]), _p(sc["xref"]), _p(sc["R"]), _p(foot), int(foot_stride), _p(contact, C.c_uint8),
                                          int(contact_stride), _p(grf), _p(u), _p(iters, C.c_int32), _p(status, C.c_int32), _p(nfact, C.c_int32))
+    lib().a1mpc_emu_set_twin(0)
     assert rc == 0
     return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
 

@@ -279,6 +279,11 @@ template <int H>
 static void split_setup_gen_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); setup_row<H, true>(*j->a, j->a->tab, j->b, j->lds, j->prep); }
 template <int H>
 static void split_admm_gen_entry(void* p) { auto* j = static_cast<SplitJob<H>*>(p); admm_rows<H, true, true>(*j->a, j->prep, j->counter, j->lds); }
+template <int H>
+static void split_admm_gen_quad_entry(void* p) {
+    auto* j = static_cast<SplitJob<H>*>(p);
+    if constexpr (H % 4 == 0) admm_rows<H, true, true, false, false, false, true>(*j->a, j->prep, j->counter, j->lds);
+}
 // the general path's split pipeline: its set-up kernel for every QP, then `nrows` persistent main / twin pairs
 template <int H>
 static void run_split_gen(const BatchArgs& a, int nrows) {
@@ -297,7 +302,8 @@ static void run_split_gen(const BatchArgs& a, int nrows) {
     for (int r = 0; r < nrows; ++r) {
         for (auto& v : lds2) v = NAN;
         j.lds = lds2.data();
-        run_row(split_admm_gen_entry<H>, &j, 32);
+        if (g_emu_twin == 2 && H % 4 == 0) run_row(split_admm_gen_quad_entry<H>, &j, 64);
+        else run_row(split_admm_gen_entry<H>, &j, 32);
     }
 }
 }  // namespace a1mpc
@@ -383,6 +389,11 @@ static void gen_twin_entry(void* a) {
     if constexpr (H % 2 == 0) solve_row_with<H, kModeMpc, true, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
 }
 template <int H>
+static void gen_quad_entry(void* a) {
+    Job<H>* j = static_cast<Job<H>*>(a);
+    if constexpr (H % 4 == 0) solve_row_with<H, kModeMpc, true, true, false, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+}
+template <int H>
 static void run_gen(const DeviceParams* P, int n, const double* x0, const double* xref, const double* R, const double* foot, int foot_stride,
                     const uint8_t* contact, int contact_stride, double* grf, double* u_full, double* warm_x, double* warm_y, double* rho,
                     int32_t* iters, int32_t* status, int32_t* nfact) {
@@ -401,7 +412,8 @@ static void run_gen(const DeviceParams* P, int n, const double* x0, const double
         j.io.warm_x = warm_x ? warm_x + (size_t)b * 12 * H : nullptr; j.io.warm_y = warm_y ? warm_y + (size_t)b * 20 * H : nullptr;
         j.io.rho_io = rho ? rho + b : nullptr;
         j.io.iters = iters ? iters + b : nullptr; j.io.status = status ? status + b : nullptr; j.io.nfact = nfact ? nfact + b : nullptr;
-        if (g_emu_twin && H % 2 == 0) run_row(gen_twin_entry<H>, &j, 32);
+        if (g_emu_twin == 2 && H % 4 == 0) run_row(gen_quad_entry<H>, &j, 64);
+        else if (g_emu_twin && H % 2 == 0) run_row(gen_twin_entry<H>, &j, 32);
         else run_row(gen_entry<H>, &j);
     }
 }

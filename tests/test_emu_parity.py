@@ -296,6 +296,19 @@ def test_emulated_quad_of_rows_contact_schedule_warm_start_update_path_and_bad_i
     assert out["status"][0] == -7 and (out["grf"][0] == 0).all() and np.isnan(out["u"][0]).all() and out["status"][1] == 1
 
 
+@pytest.mark.parametrize("h", [16, 20])
+def test_emulated_quad_of_rows_on_the_general_path(scen, h):
+    """per-step feet + per-step contacts (RowSolver<.., GEN>): B~_t and the bounds of a step come from the LDS tables by horizon step, so the quad's slot -> step map is all
+    that changes; the fused kernel's set-up is shared by the four rows.  Fused and split, against the twin pair's bits."""
+    rng = np.random.default_rng(730 + h)
+    sc, foot, fs, contact, cs = _strided_case(scen, rng, h, 2, True, True)
+    two = emu.solve_gen(sc, foot, fs, contact, cs, twin=True)
+    four = emu.solve_gen(sc, foot, fs, contact, cs, quad=True)
+    split = emu.solve_gen_split(sc, foot, fs, contact, cs, rows=1, quad=True)
+    for k in ("u", "grf", "iters", "status", "nfact"):
+        assert np.array_equal(two[k], four[k]) and np.array_equal(two[k], split[k]), k
+
+
 # ---- the Ruiz sweep's early stop (RowSolver::setup, column loop) ------------------------------------------------------------------------------
 @pytest.mark.parametrize("gen,kw,n,split", [("config3_random_flat", dict(nb=8), 6, 0), ("config3_random_flat", dict(nb=8, param_set="hardware"), 4, 2),
                                             ("config5_divergent", dict(nb=4), 2, 1)])
