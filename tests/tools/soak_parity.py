@@ -3,11 +3,12 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, __graft_entry__ as g
 pkg = g.load_package(); orc = g.load_oracle()
 worst = 0; bad = 0; tot = 0; over = 0
-lo = int(sys.argv[1]) if len(sys.argv) > 1 else 3000; cnt = int(sys.argv[2]) if len(sys.argv) > 2 else 12  # usage: soak_parity.py [first_seed [count [horizon]]]
+lo = int(sys.argv[1]) if len(sys.argv) > 1 else 3000; cnt = int(sys.argv[2]) if len(sys.argv) > 2 else 12  # usage: soak_parity.py [first_seed [count [horizon [qps_per_batch]]]]
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+N = int(sys.argv[4]) if len(sys.argv) > 4 else 4096   # QPs per batch (4096: the split pipeline; <= 256: the latency kernel; up to the resident rows: the fused kernel)
 gen = {10: pkg.scenarios.config3_random_flat, 16: pkg.scenarios.config4_random_h16, 20: pkg.scenarios.config5_divergent}[H]
 for seed in range(lo, lo + cnt):
-    n = 4096
+    n = N
     sc = gen(nb=n, seed=seed, param_set=("gazebo", "hardware", "isaac")[seed % 3]) if H == 10 else gen(nb=n, seed=seed); p = sc["params"]
     cfg = pkg.make_config(p, H, warm_start=0)
     with pkg.Engine(cfg, n, 0) as eng:
@@ -28,4 +29,4 @@ for seed in range(lo, lo + cnt):
         np.savez("gpurun_out/soak_outlier_h%d_seed%d_qp%d.npz" % (H, seed, i), x0=sc["x0"][i], xref=sc["xref"][i], R=sc["R"][i], foot=sc["foot"][i], contact=sc["contact"][i],
                  grf_engine=out["grf"][i], grf_oracle=ref["grf"][i], iters=out["iters"][i], param_set=("gazebo", "hardware", "isaac")[seed % 3] if H == 10 else "gazebo")
     print(seed, "max %.2e same iters %.5f status eq %.5f" % (dd.max(), same.mean(), steq.mean()), flush=True)
-print("TOTAL h =", H, ":", tot, "QPs, worst %.3e N, QPs over the 1e-5 N bar: %d, mismatching iteration counts / statuses: %d" % (worst, over, bad))
+print("TOTAL h =", H, "batches of", N, ":", tot, "QPs, worst %.3e N, QPs over the 1e-5 N bar: %d, mismatching iteration counts / statuses: %d" % (worst, over, bad))
