@@ -155,7 +155,8 @@ def test_size_independent_properties_full_batch(pkg, scen):
                                            ("config3_random_flat", 1500, True),   # fused kernel, two QPs per wave
                                            ("config3_random_flat", 3000, True),   # split pipeline, longest-first queue
                                            ("config3_random_flat", 3000, False),  # split pipeline, index-order queue
-                                           ("config4_random_h16", 700, True), ("config5_divergent", 300, True)])
+                                           ("config4_random_h16", 700, True), ("config5_divergent", 300, True),   # fused and latency kernels' quads of rows
+                                           ("config4_random_h16", 1500, True), ("config5_divergent", 1300, True)])   # persistent quads (CU-wide at h = 16) vs fused quads
 def test_result_does_not_depend_on_position_or_history(pkg, scen, gen, n, history):
     """Every kernel path: a QP's result is bit for bit the same wherever it sits in the batch, whatever its wave-mates are and
     whatever the row solved before (another batch in between).  A violated DPP read hazard or a stale LDS word shows up here."""
