@@ -329,7 +329,7 @@ def other_config_rooflines(pkg, local, steps=4):
         ex = pmc.get(f"{n}x{h}")   # SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 x live lanes of a first solve of this batch (static: profiles/, rocprofv3 --pmc of tools/prof_shapes.py)
         if ex:
             entry["executed_fp64_flops_per_launch"] = ex; entry["executed_fp64_frac"] = ex / (avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
-        exq = pmc.get(f"{n}x{h}q")   # the quad-of-rows kernel as it runs: rows 1 / 3 repeat the sweeps of rows 0 / 2 -- what the FP64 pipe issues, repeats included
+        exq = pmc.get(f"{n}x{h}q") or pmc.get(f"{n}x{h}cu")   # the quad-of-rows kernels as they run (h = 20; the CU-wide kernel at h = 16): rows 1 / 3 of a quad repeat the sweeps of rows 0 / 2 -- what the FP64 pipe issues, repeats included
         if exq:
             entry["issued_fp64_frac_repeats_included"] = exq / (avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
         if n <= 8192:   # a batch of this size leaves a tail: the same first solves with two batches in flight (a1mpc_pipeline; batches of tens of thousands fill the chip alone)

@@ -108,10 +108,11 @@ for d in sorted(glob.glob(os.path.join(src, "shape_*_SQ_INSTS_VALU_FMA_F64"))) +
 for shape, ks in shapes.items():
     h_ = int("".join(ch for ch in shape.split("x")[1] if ch.isdigit()))
     # ADMM kernel: two QPs per wavefront at h = 10, one (a main / twin pair of rows) from h = 16 on.  The executed-FP64 figure of 8192 x h16 is taken from the pass on the
-    # ONE-WAVE kernels (A1MPC_CU_WIDE=0: 24 live lanes in every instruction, exact); the CU-wide kernel ("..cu": five QPs on four wavefronts, wave 0 with 48 live lanes)
-    # executes the same arithmetic per QP bit for bit, with fewer wave-level instructions -- its own entry prices them at the time-averaged 30 lanes (an estimate)
+    # ONE-WAVE twin-pair kernels (A1MPC_CU_WIDE=0 A1MPC_QUAD=0: 24 live lanes in every instruction, exact); the CU-wide kernel ("..cu": five QPs on four wavefronts)
+    # executes the same arithmetic per QP bit for bit
     # "..q": the quad-of-rows kernel as it runs (h = 20: 48 live lanes, rows 1 / 3 repeating the sweeps of rows 0 / 2) -- what the FP64 pipe issues, repeats included
-    lanes = {"setup_kernel": 48, "admm_kernel": 48 if (h_ == 10 or shape.endswith("q")) else (30 if shape.endswith("cu") else 24)}
+    # "..cu" (h = 16, the CU-wide kernel as it runs since the quads: wave 0 two twin pairs, waves 1-3 a quad each -- 48 live lanes in every instruction): issued, repeats included
+    lanes = {"setup_kernel": 48, "admm_kernel": 48 if (h_ == 10 or shape.endswith("q") or shape.endswith("cu")) else 24}
     e_ = 0.0
     for k, ln_ in lanes.items():
         c = ks.get(k, {})
