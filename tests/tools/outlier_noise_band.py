@@ -2,7 +2,7 @@
 """CPU only.  The rounding-noise band of ONE QP: how far the double-precision oracle's answer moves when one input word moves by one ulp, beside the same
 experiment in x87 extended precision (tests/x87.py) and the oracle's own default-vs-exact slack.  For the tail of a parity soak: a QP where engine and oracle
 part by more than the 1e-5 N bar is judged against what double precision itself leaves open on it.
-usage: outlier_noise_band.py seed qp [param_set] [horizon]   (the soak's generator: scenarios.config3_random_flat(nb=4096, seed, param_set))"""
+usage: outlier_noise_band.py seed qp [param_set] [horizon]   (the soak's generators: scenarios.config3_random_flat(nb=4096, seed, param_set) at h = 10, config4_random_h16 / config5_divergent at 16 / 20)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,7 +17,8 @@ from helpers import noise_band
 if __name__ == "__main__":
     seed, qp = int(sys.argv[1]), int(sys.argv[2]); ps = sys.argv[3] if len(sys.argv) > 3 else ("gazebo", "hardware", "isaac")[seed % 3]; H = int(sys.argv[4]) if len(sys.argv) > 4 else 10
     pkg = g.load_package(); orc = g.load_oracle()
-    sc = pkg.scenarios.config3_random_flat(nb=4096, seed=seed, param_set=ps, horizon=H); p = sc["params"]
+    gen = {10: pkg.scenarios.config3_random_flat, 16: pkg.scenarios.config4_random_h16, 20: pkg.scenarios.config5_divergent}[H]   # (the soak's generators)
+    sc = gen(nb=4096, seed=seed, param_set=ps) if H == 10 else gen(nb=4096, seed=seed); p = sc["params"]
     pr = orc.mpc_params(H, p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"], p["inertia"])
     base, med, mx = noise_band(orc, pr, sc, qp)
     px = x87.params(p, H)
