@@ -134,7 +134,8 @@ constexpr bool admm_twin_rows(int h, int rows) { return twin_rows(h, kModeMpc, r
 // the update path existed (the allocation of the hot loop is sensitive to anything around it: a1mpc_solver.hpp, load_prepared)
 // UNI: contacts broadcast over the horizon (contact_stride = 0): one pair of bounds for every slot (RowSolver<.., UNI>; built for H >= 16, where the registers matter)
 // CLK: the profiling instantiation (a1mpc_set_profiling): shader-clock stamps around factor passes / iteration segments / residual checks, outside the hot loop
-// QUAD: one QP per wavefront and a horizon that is a multiple of 4 (H = 20): rows 1 and 3 do not idle, the four rows split the per-lane state (RowSolver<.., QUAD>)
+// QUAD: one QP per wavefront and a horizon that is a multiple of 4 (H = 20; waves 1-3 of the CU-wide H = 16 kernel below): rows 1 and 3 do not idle, the four rows split
+// the per-lane state (RowSolver<.., QUAD>)
 constexpr bool quad_rows(int h, int rows) { return h == 20 && rows == 1 && admm_twin_rows(h, rows); }
 template <int H, int ROWS, bool UPD = false, bool UNI = false, bool CLK = false, bool QUAD = false>
 __global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {

@@ -325,7 +325,8 @@ struct Prep {
 // the hot loop loses its 8 scratch reloads and 14 of 72 AGPR moves per iteration (8192 x h16 first solve 3.93 -> 3.73 ms).  Same values, same bits.
 // CLK = true (persistent ADMM kernel, profiling instantiation: a1mpc_set_profiling): shader-clock stamps around the factor passes, the iteration segments and the
 // residual checks of a QP -- outside the hot loop; the numbers behind a1mpc_last_stage_cycles (the reference's t1..t6 stopwatches, S/A1RobotControl.cpp:491-553)
-// QUAD = true (persistent ADMM kernel, one QP per wavefront, H a multiple of 4: h = 20): the four rows of the wavefront work on one QP -- rows 0 / 1 in the main role,
+// QUAD = true (every kernel that holds ONE QP per wavefront at a horizon that is a multiple of 4 -- h = 16 / 20: persistent rows, fused and latency kernels, fast and general
+// path): the four rows of the wavefront work on one QP -- rows 0 / 1 in the main role,
 // rows 2 / 3 as twins, rows 1 / 3 bit-identical copies of rows 0 / 2 through everything sequential -- and the per-lane state is split four ways: slot k = step 4k + own,
 // own = 0 / 1 / 2 / 3 on rows 0 / 2 / 1 / 3.  The chains, their operands and their order are the pair's: same bits; the element-wise part of an iteration, the residual
 // norms and the state's registers are halved again.

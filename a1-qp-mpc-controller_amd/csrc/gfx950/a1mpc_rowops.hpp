@@ -437,7 +437,7 @@ A1_DEV double twin_from_main(double v) {
     return v;
 }
 
-// ---- quads of rows (persistent ADMM kernel, horizon a multiple of 4, one QP per wavefront) ------------------------------------------------
+// ---- quads of rows (kernels with one QP per wavefront, horizon a multiple of 4) ----------------------------------------------------------------
 // With one LDS image per wavefront all four rows work on the same QP: rows 0 / 1 in the main role, rows 2 / 3 as their twins, rows 1 and 3 bit-identical
 // copies of rows 0 and 2 through the sweeps -- and the per-lane ADMM state (x^, w, rho rows, D^-2 of a step) split four ways instead of two, so that the
 // element-wise third of an iteration is issued for four steps at once (RowSolver<.., QUAD>).
