@@ -92,11 +92,12 @@ def carry_buffer(horizon, n):
     return np.zeros((n, int(lib().a1mpc_emu_carry_stride(int(horizon)))))
 
 
-def solve(sc, n=None, settings=None, warm=None, split_rows=0, twin=False, contact_schedule=None, carry=None, quad=False, **over):
+def solve(sc, n=None, settings=None, warm=None, split_rows=0, twin=False, contact_schedule=None, carry=None, quad=False, latency=False, **over):
     """split_rows > 0: run the two-kernel pipeline (set-up kernel, then `split_rows` persistent ADMM rows) instead of the fused path;
     twin: the iterations run on main / twin PAIRS of rows (RowSolver<.., TWIN>: what the device kernels do for H > 1);
     quad: ... on a QUAD of rows, 64 fibers in the device's lane order (RowSolver<.., QUAD>: the device kernels with one QP per wavefront, H = 16 / 20; the set-up of the
     fused path is shared by the four rows, like the latency kernel's);
+    latency: the latency kernel of batches <= 256 QPs -- the four rows share the set-up, then rows 0 / 2 solve as a pair (rows 1 / 3 retire) or, at H = 16 / 20, all four as a quad;
     contact_schedule: (n, 4h) per-step contacts on the FAST path (feet step-invariant) instead of sc["contact"]"""
     h = sc["horizon"]
     n = len(sc["x0"]) if n is None else n
@@ -113,12 +114,12 @@ def solve(sc, n=None, settings=None, warm=None, split_rows=0, twin=False, contac
     lib().a1mpc_emu_set_carry.argtypes = [C.c_void_p]
     lib().a1mpc_emu_set_carry(None if carry is None else carry.ctypes.data)   # update path (warm_start = 2): carried in place
     try:
-        return _solve(sc, n, h, P, grf, u, iters, status, nfact, wx, wy, rho, contact, split_rows, twin or quad, quad)
+        return _solve(sc, n, h, P, grf, u, iters, status, nfact, wx, wy, rho, contact, split_rows, twin or quad, quad, latency)
     finally:
         lib().a1mpc_emu_set_contact_stride(0); lib().a1mpc_emu_set_carry(None)
 
 
-def _solve(sc, n, h, P, grf, u, iters, status, nfact, wx, wy, rho, contact, split_rows, twin, quad=False):
+def _solve(sc, n, h, P, grf, u, iters, status, nfact, wx, wy, rho, contact, split_rows, twin, quad=False, latency=False):
     if split_rows:
         lib().a1mpc_emu_set_twin(2 if quad else 0)
         rc = lib().a1mpc_emu_solve_split(C.byref(P), h, n, -int(split_rows) if twin else int(split_rows), _p(sc["x0"]), _p(sc["xref"]), _p(sc["R"]), _p(sc["foot"]),
@@ -127,7 +128,7 @@ def _solve(sc, n, h, P, grf, u, iters, status, nfact, wx, wy, rho, contact, spli
         lib().a1mpc_emu_set_twin(0)
         assert rc == 0
         return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
-    lib().a1mpc_emu_set_twin(2 if quad else (1 if twin else 0))
+    lib().a1mpc_emu_set_twin(3 if latency else (2 if quad else (1 if twin else 0)))
     try:
         rc = lib().a1mpc_emu_solve(C.byref(P), h, n, _p(sc["x0"]), _p(sc["xref"]), _p(sc["R"]), _p(sc["foot"]),
                                    _p(contact, C.c_uint8), _p(grf), _p(u), _p(wx), _p(wy), _p(rho), _p(iters, C.c_int32),

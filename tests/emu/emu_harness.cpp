@@ -22,6 +22,7 @@ constexpr int kLanes = 64;  // a DPP row, a main / twin pair of rows (lanes 16-3
 constexpr size_t kStack = 1 << 20;
 struct Sched {
     int lanes;
+    bool retire_ok;  // rows may leave early (the latency kernel's rows 1 and 3 after the shared set-up): a finished lane counts as arrived
     ucontext_t main_ctx;
     ucontext_t ctx[kLanes];
     char* stacks[kLanes];
@@ -45,6 +46,7 @@ void wait_for(Sched* s, int l, const long* cnt, long g, int lo, int hi) {
     for (;;) {
         bool all = true;
         for (int x = lo; x < hi; ++x) {
+            if (s->finished[x] && s->retire_ok) continue;
             if (s->finished[x] && cnt[x] < g) { fprintf(stderr, "emu: divergent control flow (lane %d finished while lane %d waits for it)\n", x, l); abort(); }
             all = all && cnt[x] >= g;
         }
@@ -94,10 +96,11 @@ double emu_quad_exchange(double& a) {
     return mine;
 }
 
-static void run_row(void (*fn)(void*), void* arg, int lanes = 16) {
+static void run_row(void (*fn)(void*), void* arg, int lanes = 16, bool retire_ok = false) {
     Sched s;
     memset(&s, 0, sizeof s);
     s.lanes = lanes;
+    s.retire_ok = retire_ok;
     emu_lanes = lanes;
     s.fn = fn;
     s.arg = arg;
@@ -120,7 +123,7 @@ static void run_row(void (*fn)(void*), void* arg, int lanes = 16) {
         }
         if (!alive) break;
     }
-    for (int r = 0; r < lanes; r += 16)
+    for (int r = 0; r < lanes; r += 16)   // (rows that retire early stop counting together: still equal within a row)
         for (int l = r + 1; l < r + 16; ++l)
             if (s.gen[l] != s.gen[r]) { fprintf(stderr, "emu: the lanes of a row disagree on the number of cross-lane ops\n"); abort(); }
     for (int l = 0; l < lanes; ++l) free(s.stacks[l]);
@@ -157,7 +160,30 @@ static void job_quad_entry(void* a) {  // the fused kernel on a quad of rows (on
         else solve_row_with<H, kModeMpc, false, true, false, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
     }
 }
-static int g_emu_twin = 0;  // a1mpc_emu_set_twin(): the fused entry points run main / twin pairs (1) or quads of rows (2; H a multiple of 4)
+// the latency kernel (a1mpc_solve_coop_kernel, csrc/a1mpc_hip.hip) statement for statement: the four rows of a wavefront share ONE QP's set-up (each takes every fourth horizon
+// step of the Ruiz sweeps), row 0 leaves the hand-off record in the factor region, then rows 0 / 2 solve as a main / twin pair while rows 1 / 3 retire -- or, at a horizon
+// that is a multiple of 4, all four go on as a quad
+template <int H>
+static void latency_entry(void* a) {
+    Job<H>* j = static_cast<Job<H>*>(a);
+    if constexpr (H > 1 && H % 2 == 0) {
+        const int row = emu_lane >> 4;
+        const bool upd = j->io.carry != nullptr;
+        {
+            RowSolver<H, kModeMpc> S(*j->P, j->tab, j->lds);
+            S.coop_id = row; S.coop_n = 4;
+            if (upd) S.template setup<true>(j->io); else S.template setup<false>(j->io);
+            coop_sync();   // (the device's row_sync() orders the whole wavefront)
+            if (row == 0) { if (upd) S.template save_prepared<true>(j->lds + Layout<H>::FAC); else S.template save_prepared<false>(j->lds + Layout<H>::FAC); }
+        }
+        constexpr bool kQuad = H % 4 == 0;
+        if constexpr (!kQuad) { if (row & 1) return; }
+        RowSolver<H, kModeMpc, false, false, true, false, false, kQuad> S(*j->P, j->tab, j->lds);
+        if (upd) { S.template load_prepared<true>(j->lds + Layout<H>::FAC, j->io); S.template solve<true>(); S.write_outputs(j->io, j->io.carry); }
+        else { S.template load_prepared<false>(j->lds + Layout<H>::FAC, j->io); S.template solve<false>(); S.write_outputs(j->io); }
+    }
+}
+static int g_emu_twin = 0;  // a1mpc_emu_set_twin(): the fused entry points run main / twin pairs (1), quads of rows (2; H a multiple of 4) or the latency kernel (3)
 static double* g_emu_carry = nullptr;  // a1mpc_emu_set_carry(): n x Carry<H>::STRIDE doubles of the update path (warm_start = 2), or null
 static int g_emu_contact_stride = 0;  // a1mpc_emu_set_contact_stride(): 4 = `contact` is an n x 4H per-step schedule (fast path, feet step-invariant)
 template <int H>
@@ -189,7 +215,8 @@ static void run_batch(const DeviceParams* P, int n, const double* x0, const doub
         j.io.status = status ? status + b : nullptr;
         j.io.nfact = nfact ? nfact + b : nullptr;
         j.io.carry = g_emu_carry ? g_emu_carry + (size_t)b * Carry<H>::STRIDE : nullptr;
-        if (g_emu_twin == 2 && H > 1 && H % 4 == 0) run_row(job_quad_entry<H>, &j, 64);
+        if (g_emu_twin == 3 && H > 1 && H % 2 == 0) run_row(latency_entry<H>, &j, 64, true);
+        else if (g_emu_twin == 2 && H > 1 && H % 4 == 0) run_row(job_quad_entry<H>, &j, 64);
         else if (g_emu_twin && H > 1 && H % 2 == 0) run_row(job_twin_entry<H>, &j, 32);
         else run_row(job_entry<H>, &j);
     }

@@ -309,6 +309,33 @@ def test_emulated_quad_of_rows_on_the_general_path(scen, h):
         assert np.array_equal(two[k], four[k]) and np.array_equal(two[k], split[k]), k
 
 
+@pytest.mark.parametrize("gen,n", [("config3_random_flat", 3), ("config4_random_h16", 2), ("config5_divergent", 2)])
+def test_emulated_latency_kernel_matches_the_fused_path(scen, gen, n):
+    """the kernel of batches <= 256 QPs (a1mpc_solve_coop_kernel) statement for statement on 64 fibers: the four rows of a wavefront share ONE QP's set-up (each takes
+    every fourth horizon step of the Ruiz sweeps and of the D / E updates; the column maxima meet in LDS), row 0 leaves the hand-off record, rows 1 / 3 retire at h = 10
+    and rows 0 / 2 solve as a pair -- at h = 16 / 20 all four go on as a quad.  The same bits as the fused path: cold solves, and three ticks each of both warm-start
+    semantics (the update path's carry is read and written by the rows that stay)."""
+    sc = getattr(scen, gen)(nb=4)
+    h = sc["horizon"]
+    two = emu.solve(sc, n, twin=True)
+    lat = emu.solve(sc, n, latency=True)
+    for k in ("u", "grf", "iters", "status", "nfact"):
+        assert np.array_equal(two[k], lat[k]), k
+    rng = np.random.default_rng(740 + h)
+    one = {k: (sc[k][:1].copy() if k in ("x0", "xref", "R", "foot", "contact") else sc[k]) for k in sc}
+    for mode in (1, 2):
+        wa = (np.zeros((1, 12 * h)), np.zeros((1, 20 * h)), np.zeros(1)); wb = (np.zeros((1, 12 * h)), np.zeros((1, 20 * h)), np.zeros(1))
+        ca = emu.carry_buffer(h, 1) if mode == 2 else None; cb = emu.carry_buffer(h, 1) if mode == 2 else None
+        for t in range(3):
+            a = emu.solve(one, 1, warm=wa, warm_start=mode, twin=True, carry=ca)
+            b = emu.solve(one, 1, warm=wb, warm_start=mode, latency=True, carry=cb)
+            for k in ("u", "grf", "iters", "status", "nfact"):
+                assert np.array_equal(a[k], b[k]), (mode, t, k)
+            assert np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1]) and np.array_equal(wa[2], wb[2])
+            if mode == 2: assert np.array_equal(ca, cb)
+            one["x0"] = one["x0"].copy(); one["x0"][:, :12] += rng.normal(0, 2e-3, (1, 12))
+
+
 # ---- the Ruiz sweep's early stop (RowSolver::setup, column loop) ------------------------------------------------------------------------------
 @pytest.mark.parametrize("gen,kw,n,split", [("config3_random_flat", dict(nb=8), 6, 0), ("config3_random_flat", dict(nb=8, param_set="hardware"), 4, 2),
                                             ("config5_divergent", dict(nb=4), 2, 1)])
