@@ -45,20 +45,22 @@ constexpr bool twin_rows(int h, int mode, int rows) { return rows <= 2 && h > 1 
 constexpr bool fused_quad_rows(int h, int mode, int rows) { return rows == 1 && h > 1 && h % 4 == 0 && mode == kModeMpc; }
 // ROWS = QPs (DPP rows) per workgroup; the workgroup is one wavefront with 16*ROWS live lanes (64 with twin rows).
 // UPD: the instantiation that also serves warm_start = 2 (the reference's update path; built for the default ROWS of a horizon only)
-template <int H, int MODE, int ROWS, bool UPD = false>
+// CLK: the profiling instantiation (a1mpc_set_profiling): shader-clock stamps between the stages of a tick, a.clk = n x kTickStages cycles (a1mpc_last_tick_stage_cycles)
+template <int H, int MODE, int ROWS, bool UPD = false, bool CLK = false>
 __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     constexpr bool kTwin = twin_rows(H, MODE, ROWS);
     if constexpr (fused_quad_rows(H, MODE, ROWS)) {   // one QP per wavefront, horizon a multiple of 4: the four rows share it as a quad (RowSolver<.., QUAD>)
         const int64_t bq = static_cast<int64_t>(blockIdx.x);
-        solve_row_with<H, MODE, false, true, UPD, true>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(bq)); }, a1mpc_lds);
+        solve_row_with<H, MODE, false, true, UPD, true, CLK>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(bq)); }, a1mpc_lds, CLK ? a.clk + bq * kTickStages : nullptr);
         return;
     }
     const int row = kTwin ? (static_cast<int>(threadIdx.x) >> 4) & 1 : static_cast<int>(threadIdx.x) >> 4;
     if (kTwin && row >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
     const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
     if (b >= a.n) return;  // row-uniform (a twin leaves with its main row): the other rows of the wave keep all their DPP sources
-    solve_row_with<H, MODE, false, kTwin, UPD>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+    solve_row_with<H, MODE, false, kTwin, UPD, false, CLK>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE,
+                                                           CLK ? a.clk + b * kTickStages : nullptr);
 }
 
 // General path (per-step feet / per-step contact schedules: S/ConvexMpc.h:74 B_mat_d_list, S/test/test_mpc.cpp:106-122): the fused kernel
@@ -82,29 +84,35 @@ __global__ __launch_bounds__(64) void a1mpc_solve_gen_kernel(const KernelArgs a)
 // Latency variant of the fused kernel for a handful of QPs: the four rows of a wavefront work on ONE QP during set-up (each takes every fourth
 // horizon step of the Ruiz sweeps; everything else is computed redundantly and written to the one shared LDS image), then rows 1-3 retire
 // and row 0 solves.  Same results bit for bit (the column maxima are exact and order-free).
-template <int H, bool UPD = false>
+template <int H, bool UPD = false, bool CLK = false>
 __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     const int row = static_cast<int>(threadIdx.x) >> 4;
     const int64_t b = static_cast<int64_t>(blockIdx.x);
     const ProblemIO io = make_io_sched<H, kModeMpc>(a, b);
     static_assert(Prep<H>::STRIDE <= H * Layout<H>::SLOT, "the hand-off record fits the (still empty) factor region");
+    [[maybe_unused]] long long c0 = 0, cF = 0, cR = 0, c1 = 0, c2 = 0;
+    if constexpr (CLK) c0 = row_clock();
     {
-        RowSolver<H, kModeMpc> S(a.P, a.tab, a1mpc_lds);
+        RowSolver<H, kModeMpc, false, false, false, false, CLK> S(a.P, stage_table<H, Layout<H>>(a.tab, a1mpc_lds, row, 4), a1mpc_lds);
         S.coop_id = row; S.coop_n = 4;
         S.template setup<UPD>(io);
         row_sync();  // every row is done with the set-up scratch aliased into the factor region
         if (row == 0) S.template save_prepared<UPD>(a1mpc_lds + Layout<H>::FAC);
+        if constexpr (CLK) { cF = S.ckF; cR = S.ckR; }
     }
     constexpr bool kQuad = H % 4 == 0;   // the four rows go on as a quad; otherwise rows 1 and 3 retire
     if constexpr (!kQuad) { if (row & 1) return; }
     // Rows 0 and 2 continue exactly like a main / twin pair of the split pipeline's second kernel: a fresh solver that reads the hand-off record
     // (here through LDS).  Carrying the set-up's registers into the ADMM loop instead costs that loop its spill-free allocation.
-    RowSolver<H, kModeMpc, false, false, true, false, false, kQuad> S(a.P, a.tab, a1mpc_lds);
+    RowSolver<H, kModeMpc, false, false, true, false, CLK, kQuad> S(a.P, a.tab, a1mpc_lds);
     S.template load_prepared<UPD>(a1mpc_lds + Layout<H>::FAC, make_io<H, kModeMpc>(a, b));
+    if constexpr (CLK) c1 = row_clock();
     S.template solve<UPD>();
+    if constexpr (CLK) c2 = row_clock();
     if constexpr (UPD) S.write_outputs(make_io<H, kModeMpc>(a, b), carry_of<H>(a, b));
     else S.write_outputs(make_io<H, kModeMpc>(a, b));
+    if constexpr (CLK) S.store_tick_stages(a.clk ? a.clk + b * kTickStages : nullptr, c0, cF, cR, c1, c2, row_clock());
 }
 
 // ---- split pipeline (large batches) -----------------------------------------------------------------------------
@@ -564,6 +572,12 @@ static a1mpc_status resident_rows(int* out) {
     return st;
 }
 
+// Did the launch just issued run a profiling (CLK) instantiation?  Set by the launch functions, read by solve_device_impl right after them (same thread): only then does
+// the handle's stage record describe the solve (a fallback kernel without stamps must not leave a stale or uninitialised record behind as "profiled").
+thread_local bool g_clk_ran = false;
+// horizons whose fused / latency kernels have a profiling instantiation (the closed-loop tick and the batch-1 tick of the headline horizon; every further horizon costs a minute of compile time)
+constexpr bool tick_clk_horizon(int h) { return h == 10; }
+
 template <int H, int ROWS>
 static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* counter, hipStream_t stream, hipEvent_t mid) {
     const size_t lds2 = lds_bytes<H>(ROWS), lds1 = sizeof(double) * (4 * LayoutSetup<H>::ROW_STRIDE + 2 * H * H);
@@ -602,6 +616,7 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
             if (a.clk != nullptr && a.carry == nullptr && a.contact_stride == 0) {   // profiling instantiation (of the kernel broadcast contacts run)
                 if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, true, true, true>), ldsq); st != A1MPC_OK) return st;
                 hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, true, true, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
+                g_clk_ran = true;
             } else if (a.carry != nullptr) {
                 if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, true, false, false, true>), ldsq); st != A1MPC_OK) return st;
                 hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, true, false, false, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
@@ -633,6 +648,7 @@ static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* co
             if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, kUni, true, quad_rows(H, ROWS)>), lds2); st != A1MPC_OK) return st;
             hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, kUni, true, quad_rows(H, ROWS)>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
             A1_HIP(hipGetLastError());
+            g_clk_ran = true;
             return A1MPC_OK;
         }
     }
@@ -706,6 +722,21 @@ static a1mpc_status launch_rows(const KernelArgs& a, hipStream_t stream) {
         }
     }
     const unsigned grid = static_cast<unsigned>((a.n + ROWS - 1) / ROWS);
+    if constexpr (MODE == kModeMpc && tick_clk_horizon(H) && ROWS == default_rows_per_wg(H)) {
+        if (a.clk != nullptr && a.contact_stride == 0) {   // profiling instantiations (a1mpc_set_profiling): stage stamps of the whole tick, both warm-start semantics
+            const dim3 blk(twin_rows(H, MODE, ROWS) ? 64 : 16 * ROWS);
+            if (a.carry != nullptr) {
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE, ROWS, true, true>), lds_bytes<H>(ROWS)); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE, ROWS, true, true>), dim3(grid), blk, lds_bytes<H>(ROWS), stream, a);
+            } else {
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE, ROWS, false, true>), lds_bytes<H>(ROWS)); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE, ROWS, false, true>), dim3(grid), blk, lds_bytes<H>(ROWS), stream, a);
+            }
+            A1_HIP(hipGetLastError());
+            g_clk_ran = true;
+            return A1MPC_OK;
+        }
+    }
     if constexpr (MODE == kModeMpc && H > 1 && ROWS == default_rows_per_wg(H)) {
         if (a.carry != nullptr) {   // warm_start = 2: the update-path instantiation
             if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE, ROWS, true>), lds_bytes<H>(ROWS)); st != A1MPC_OK) return st;
@@ -840,6 +871,20 @@ static a1mpc_status launch_coop(const KernelArgs& a, hipStream_t stream) {
             attr_set[dev] = true;
         }
     }
+    if constexpr (tick_clk_horizon(H)) {
+        if (a.clk != nullptr && a.contact_stride == 0) {   // profiling instantiations (a1mpc_set_profiling)
+            if (a.carry != nullptr) {
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_coop_kernel<H, true, true>), lds_bytes<H>(1)); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_solve_coop_kernel<H, true, true>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds_bytes<H>(1), stream, a);
+            } else {
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_coop_kernel<H, false, true>), lds_bytes<H>(1)); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_solve_coop_kernel<H, false, true>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds_bytes<H>(1), stream, a);
+            }
+            A1_HIP(hipGetLastError());
+            g_clk_ran = true;
+            return A1MPC_OK;
+        }
+    }
     if (a.carry != nullptr) {   // warm_start = 2: the update-path instantiation
         if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_coop_kernel<H, true>), lds_bytes<H>(1)); st != A1MPC_OK) return st;
         hipLaunchKernelGGL((a1mpc_solve_coop_kernel<H, true>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds_bytes<H>(1), stream, a);
@@ -956,6 +1001,60 @@ static void to_device_params(const a1mpc_config& c, DeviceParams* p) {
     p->scaling_iters = c.scaling; p->warm_start = c.warm_start;
 }
 
+// Which configurations the engine accepts (a13).  OSQP validates its data and settings in osqp_setup (auxil.c validate_data: every l_i <= u_i;
+// validate_settings: rho, sigma > 0, 0 < alpha < 2, eps >= 0, max_iter > 0, scaling >= 0, adaptive_rho_tolerance >= 1, ...) and refuses to set up otherwise; the
+// reference never looks at the outcome (S/A1RobotControl.cpp:532,540) and then "solves" on an uninitialised workspace.  Here the same conditions are a loud
+// A1MPC_ERR_INVALID_ARGUMENT at a1mpc_create / a1mpc_update_config / a1mpc_balance_solve_batch.  On everything that passes, the QP family is feasible and bounded:
+//   * 0 <= mu, fz_min <= fz_max, fz_max >= 0: per leg and step (0, 0, max(fz_min, 0) c) satisfies the pyramid and the box (c = the contact flag) -- never primal infeasible;
+//   * the box and the pyramid bound every force by fz_max (1 + mu) -- the feasible set is compact, so the cost is bounded below whatever the weights: never dual infeasible;
+//   * q >= 0, r >= 0 (finite): P = B'QB + R is positive semi-definite -- never OSQP_NON_CVX from the data (the status remains for non-finite INPUTS).
+// Hence OSQP's statuses -3 / 3 (primal infeasible) and -4 / 4 (dual infeasible) have no exact certificate on any accepted configuration and the kernels do not evaluate
+// the approximate certificate tests (auxil.c is_primal_infeasible / is_dual_infeasible); the oracle does evaluate them, and over every QP the suites compare (> 2 M) it never reported one.
+static bool all_finite(const double* v, int n) {
+    for (int i = 0; i < n; ++i) if (!std::isfinite(v[i])) return false;
+    return true;
+}
+static const char* invalid_config(const a1mpc_config& c) {
+    if (!std::isfinite(c.dt) || !(c.dt > 0)) return "dt must be positive and finite";
+    if (!std::isfinite(c.mass) || !(c.mass > 0)) return "mass must be positive and finite";
+    if (!std::isfinite(c.mu) || c.mu < 0) return "mu must be >= 0 and finite (a negative friction coefficient collapses the pyramid to the zero force, and to the empty set -- primal infeasible -- when fz_min > 0)";
+    if (!std::isfinite(c.fz_min) || !std::isfinite(c.fz_max)) return "fz_min / fz_max must be finite";
+    if (c.fz_min > c.fz_max) return "fz_min > fz_max: OSQP's validate_data refuses l > u (the problem would be primal infeasible)";
+    if (c.fz_max < 0) return "fz_max < 0: a stance leg would need fz <= fz_max < 0 inside a pyramid that asks fz >= 0 (primal infeasible)";
+    if (!all_finite(c.q, A1MPC_STATE_DIM) || !all_finite(c.r, A1MPC_NUM_DOF)) return "q / r weights must be finite";
+    for (int i = 0; i < A1MPC_STATE_DIM; ++i) if (c.q[i] < 0) return "q weights must be >= 0 (a negative weight makes the Hessian indefinite: OSQP_NON_CVX)";
+    for (int i = 0; i < A1MPC_NUM_DOF; ++i) if (c.r[i] < 0) return "r weights must be >= 0 (a negative weight makes the Hessian indefinite: OSQP_NON_CVX)";
+    if (!all_finite(c.inertia_body, 9)) return "inertia_body must be finite";
+    {   // the body inertia is inverted (S/ConvexMpc.cpp:136-141): it must be invertible
+        const double* I = c.inertia_body;
+        const double det = I[0] * (I[4] * I[8] - I[5] * I[7]) - I[1] * (I[3] * I[8] - I[5] * I[6]) + I[2] * (I[3] * I[7] - I[4] * I[6]);
+        if (!(std::fabs(det) > 0)) return "inertia_body must be invertible";
+    }
+    // osqp auxil.c validate_settings
+    if (!std::isfinite(c.rho) || !(c.rho > 0)) return "rho must be positive";
+    if (!std::isfinite(c.sigma) || !(c.sigma > 0)) return "sigma must be positive";
+    if (!std::isfinite(c.alpha) || !(c.alpha > 0) || !(c.alpha < 2)) return "alpha must lie in (0, 2)";
+    if (!std::isfinite(c.eps_abs) || !std::isfinite(c.eps_rel) || c.eps_abs < 0 || c.eps_rel < 0) return "eps_abs / eps_rel must be >= 0 and finite";
+    if (c.eps_abs == 0 && c.eps_rel == 0) return "eps_abs and eps_rel must not both be zero";
+    if (c.max_iter <= 0) return "max_iter must be positive";
+    if (c.check_termination < 0) return "check_termination must be >= 0";
+    if (c.scaling < 0) return "scaling must be >= 0";
+    if (c.adaptive_rho != 0 && c.adaptive_rho != 1) return "adaptive_rho must be 0 or 1";
+    if (c.adaptive_rho_interval < 0) return "adaptive_rho_interval must be >= 0";
+    if (c.adaptive_rho && (!std::isfinite(c.adaptive_rho_tolerance) || c.adaptive_rho_tolerance < 1.0)) return "adaptive_rho_tolerance must be >= 1";
+    if (c.warm_start < 0 || c.warm_start > 2) return "warm_start must be 0, 1 or 2";
+    return nullptr;
+}
+static const char* invalid_balance_config(const a1mpc_balance_config& q) {
+    if (!all_finite(q.Q, 6) || !std::isfinite(q.R) || !std::isfinite(q.mu) || !std::isfinite(q.F_min) || !std::isfinite(q.F_max)) return "balance-QP constants must be finite";
+    for (int i = 0; i < 6; ++i) if (q.Q[i] < 0) return "balance-QP weights Q must be >= 0";
+    if (q.R < 0) return "balance-QP weight R must be >= 0";
+    if (q.mu < 0) return "balance-QP mu must be >= 0";
+    if (q.F_min > q.F_max) return "balance-QP F_min > F_max (primal infeasible; OSQP's validate_data refuses l > u)";
+    if (q.F_max < 0) return "balance-QP F_max < 0 (primal infeasible)";
+    return nullptr;
+}
+
 }  // namespace a1mpc
 
 using namespace a1mpc;
@@ -1001,8 +1100,9 @@ struct a1mpc_handle_s {
     uint8_t* d_aux_u8 = nullptr;
     int32_t hint_n = 0;  // batch size the order was built for (0 = none)
     bool profiling = false;        // a1mpc_set_profiling: split-pipeline solves run the clock-stamped instantiation of the ADMM kernel
-    long long* d_clk = nullptr;    // n x 3 cycles per QP (allocated on first use)
+    long long* d_clk = nullptr;    // n x kTickStages cycles per QP (allocated on first use)
     int32_t clk_n = 0;             // QPs of the last profiled solve (0: the last solve was not profiled)
+    bool clk_tick = false;         // ... and it ran the fused / latency kernel: every stage of the record is filled (a1mpc_last_tick_stage_cycles)
     int32_t last_ws_mode = -1;  // warm-start semantics the last MPC solve ran (a1mpc_last_warm_start_mode): the configured mode, or 1 where mode 2 does not exist
     int schedule = 1;    // 1 = history (default), 0 = index order
     // packed device blocks + pinned host mirrors of the host-pointer MPC entry (one copy each way per call)
@@ -2073,8 +2173,7 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     if (!cfg || !out || max_batch <= 0 || device < 0) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null config/out or bad batch/device");
     *out = nullptr;
     if (lds_bytes_of(cfg->horizon) == 0) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be 1, 10, 16 or 20");
-    if (!(cfg->dt > 0) || !(cfg->mass > 0) || cfg->max_iter <= 0 || !(cfg->rho > 0) || !(cfg->sigma > 0))
-        return fail(A1MPC_ERR_INVALID_ARGUMENT, "dt, mass, rho, sigma and max_iter must be positive");
+    if (const char* why = invalid_config(*cfg)) return fail(A1MPC_ERR_INVALID_ARGUMENT, why);   // (before any device query: a bad configuration is reported as such on every machine)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(A1MPC_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
     if (device >= ndev) return fail(A1MPC_ERR_NO_DEVICE, "device ordinal out of range");
@@ -2165,8 +2264,7 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
 a1mpc_status a1mpc_update_config(a1mpc_handle h, const a1mpc_config* cfg) {
     if (!h || !cfg) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle/config");
     if (cfg->horizon != h->cfg.horizon) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "the horizon of a handle is fixed at a1mpc_create");
-    if (!(cfg->dt > 0) || !(cfg->mass > 0) || cfg->max_iter <= 0 || !(cfg->rho > 0) || !(cfg->sigma > 0))
-        return fail(A1MPC_ERR_INVALID_ARGUMENT, "dt, mass, rho, sigma and max_iter must be positive");
+    if (const char* why = invalid_config(*cfg)) return fail(A1MPC_ERR_INVALID_ARGUMENT, why);   // (the handle keeps the configuration it had)
     // every constant travels to the kernels by value with each launch: nothing on the device has to change, launches already
     // queued keep the values they were issued with, the carried warm start stays
     if (cfg->warm_start != h->cfg.warm_start && h->d_carry) {
@@ -2240,10 +2338,24 @@ a1mpc_status a1mpc_last_stage_cycles(a1mpc_handle h, double* cycles3_out, int32_
     if (h->clk_n == 0 || !h->d_clk) return A1MPC_OK;
     A1_HIP(hipSetDevice(h->device));
     A1_ORDER(h, h->stream);
-    std::vector<long long> c(static_cast<size_t>(h->clk_n) * 3);
+    std::vector<long long> c(static_cast<size_t>(h->clk_n) * kTickStages);
     A1_HIP(hipMemcpyAsync(c.data(), h->d_clk, c.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
     A1_HIP(hipStreamSynchronize(h->stream));
-    for (int b = 0; b < h->clk_n; ++b) for (int k = 0; k < 3; ++k) cycles3_out[k] += static_cast<double>(c[static_cast<size_t>(b) * 3 + k]);
+    for (int b = 0; b < h->clk_n; ++b) for (int k = 0; k < 3; ++k) cycles3_out[k] += static_cast<double>(c[static_cast<size_t>(b) * kTickStages + kClkFactor + k]);
+    return A1MPC_OK;
+}
+a1mpc_status a1mpc_last_tick_stage_cycles(a1mpc_handle h, double* cycles8_out, int32_t* qps_out) {
+    if (!h || !cycles8_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle / output");
+    for (int k = 0; k < kTickStages; ++k) cycles8_out[k] = 0.0;
+    const int32_t nq = h->clk_tick ? h->clk_n : 0;
+    if (qps_out) *qps_out = nq;
+    if (nq == 0 || !h->d_clk) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    A1_ORDER(h, h->stream);
+    std::vector<long long> c(static_cast<size_t>(nq) * kTickStages);
+    A1_HIP(hipMemcpyAsync(c.data(), h->d_clk, c.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    A1_HIP(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < nq; ++b) for (int k = 0; k < kTickStages; ++k) cycles8_out[k] += static_cast<double>(c[static_cast<size_t>(b) * kTickStages + k]);
     return A1MPC_OK;
 }
 
@@ -2350,6 +2462,7 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     A1_HIP(hipSetDevice(h->device));
     hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->stream;
     A1_ORDER(h, s);
+    h->clk_n = 0; h->clk_tick = false;   // (set again below when this solve runs a profiling instantiation)
     KernelArgs a;
     std::memset(&a, 0, sizeof a);
     a.P = h->dp; a.tab = h->d_tab; a.n = n;
@@ -2417,13 +2530,16 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     a.predict = (hints && h->hint_n != n) ? 1 : 0;  // first solve of this batch size: order by the set-up kernel's guess instead
     A1_HIP(hipEventRecord(h->ev0, s));
     h->staged = split;
-    h->clk_n = 0;
-    if (h->profiling && split && h->cfg.horizon > 1 && a.carry == nullptr && a.contact_stride == 0) {
-        if (!h->d_clk) A1_HIP(hipMalloc(&h->d_clk, static_cast<size_t>(h->max_batch) * 3 * sizeof(long long)));
-        a.clk = h->d_clk; h->clk_n = n;
+    h->clk_n = 0; h->clk_tick = false;
+    if (h->profiling && h->cfg.horizon > 1 && a.contact_stride == 0) {
+        if (!h->d_clk) A1_HIP(hipMalloc(&h->d_clk, static_cast<size_t>(h->max_batch) * kTickStages * sizeof(long long)));
+        A1_HIP(hipMemsetAsync(h->d_clk, 0, static_cast<size_t>(n) * kTickStages * sizeof(long long), s));
+        a.clk = h->d_clk;
     }
+    g_clk_ran = false;
     a1mpc_status st = launch_mpc(h->cfg.horizon, a, h->d_prep, h->d_counter, s, split, h->ev_mid);
     if (st != A1MPC_OK) return st;
+    if (a.clk != nullptr && g_clk_ran) { h->clk_n = n; h->clk_tick = !split; }   // (a kernel without stamps ran: the record stays "not profiled")
     if (hints) h->hint_n = n;   // the cost buffer now holds this batch's costs: the next solve of this size is ordered by them (sorted in front of its ADMM kernel)
     A1_HIP(hipEventRecord(h->ev1, s));
     h->timed = true;
@@ -2669,6 +2785,7 @@ a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_confi
                                        const double* R_world, const double* R_z, const double* foot_abs, const uint8_t* contact,
                                        double* grf_body_out, double* f_world_out, int32_t* iters_out, int32_t* status_out) {
     if (!h || !qp) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle/config");
+    if (const char* why = invalid_balance_config(*qp)) return fail(A1MPC_ERR_INVALID_ARGUMENT, why);
     if (n < 0 || !root_acc || !R_world || !R_z || !foot_abs || !contact || !grf_body_out)
         return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
     if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
@@ -2829,6 +2946,8 @@ a1mpc_status a1mpc_sharded_create(const a1mpc_config* cfg, int32_t max_batch, co
                                   a1mpc_sharded* out) {
     if (!cfg || !out || max_batch <= 0 || (transport != 0 && transport != 1)) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null config/out, bad batch or transport");
     *out = nullptr;
+    if (lds_bytes_of(cfg->horizon) == 0) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be 1, 10, 16 or 20");
+    if (const char* why = invalid_config(*cfg)) return fail(A1MPC_ERR_INVALID_ARGUMENT, why);
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return fail(A1MPC_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
     a1mpc_sharded S = new (std::nothrow) a1mpc_sharded_s();

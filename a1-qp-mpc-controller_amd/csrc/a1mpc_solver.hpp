@@ -232,7 +232,11 @@ struct Layout {
     static constexpr int DL = 36;            // D table of the current Ruiz pass, [t][12]
     static constexpr int TBW = DL + 12 * H;  // GEN: [t][3][12] = T*B~_omega of step t
     static constexpr int COOP = TBW + (GEN ? 36 * H : 0);  // [row][s][16 lanes] partial column maxima of a set-up shared by several rows of a wave (RowSolver::coop_n)
-    static_assert(COOP + 8 * H * 16 <= H * SLOT || H == 1, "alias");  // + the D / E0 / E1 / m tables of the shared Ruiz update
+    static constexpr int E0X = COOP + 4 * H * 16;          // [t][16 lanes]: the rows of a shared set-up hand each other the E of their own horizon steps, once, behind the last Ruiz pass
+    static constexpr int TAB = E0X + H * 16;               // [s][t][2] = (alpha_st / beta_st, beta_st): the fused / latency kernels stage the batch's table here (stage_table), where a
+                                                           // column of it is one LDS round trip away instead of one global-memory round trip per column of every Ruiz sweep
+    static_assert(TAB + 2 * H * H <= COOP + 8 * H * 16, "the table fits behind the E hand-over");
+    static_assert(COOP + 8 * H * 16 <= H * SLOT || H == 1, "alias");
     // row stride mod 32 in {4,10,16,22,28}: the two QPs that share a 32-lane LDS phase then read the stride-13 rows of K_t
     // from disjoint banks; even, so that 16-byte alignment survives.  H = 10: 2544 doubles = 20,352 B per QP -> eight QPs
     // per CU (160 KiB): four workgroups of two rows.
@@ -253,7 +257,7 @@ struct LayoutSetup {
     static constexpr int TBL = 0;
     static constexpr int DL = 36;
     static constexpr int TBW = DL + 12 * H;                  // GEN: [t][3][12] = T*B~_omega of step t
-    static constexpr int COOP = 0;  // never used by the set-up kernels (one row per QP)
+    static constexpr int COOP = 0, E0X = 0, TAB = 0;  // never used by the set-up kernels (one row per QP; the kernel stages the table behind the rows' images itself)
     static constexpr int CUV = 0, LBT = 0, UBT = 0;          // (not written by a set-up-only solver)
     static constexpr int BL = TBW + (GEN ? 36 * H : 0);
     static constexpr int ZROW = 6;
@@ -323,8 +327,10 @@ struct Prep {
 // UNI = true (persistent ADMM kernel, H >= 16): the caller guarantees contacts broadcast over the horizon (contact_stride = 0, what the reference's controller
 // does, S/ConvexMpc.cpp:228-245), so ONE pair of bounds serves every slot and the per-slot pairs (2 HS doubles per lane) leave the register file -- at H = 16
 // the hot loop loses its 8 scratch reloads and 14 of 72 AGPR moves per iteration (8192 x h16 first solve 3.93 -> 3.73 ms).  Same values, same bits.
-// CLK = true (persistent ADMM kernel, profiling instantiation: a1mpc_set_profiling): shader-clock stamps around the factor passes, the iteration segments and the
-// residual checks of a QP -- outside the hot loop; the numbers behind a1mpc_last_stage_cycles (the reference's t1..t6 stopwatches, S/A1RobotControl.cpp:491-553)
+// CLK = true (profiling instantiations: a1mpc_set_profiling): shader-clock stamps around the factor passes, the iteration segments and the
+// residual checks of a QP -- outside the hot loop; the numbers behind a1mpc_last_stage_cycles (the reference's t1..t6 stopwatches, S/A1RobotControl.cpp:491-553).
+// Round 5: the fused and the latency kernel (what every warm-started closed-loop tick and every batch-1 tick runs) have such an instantiation too, with stamps behind
+// the formation and the Ruiz passes of the set-up as well (ckF, ckR; kTickStages below)
 // QUAD = true (every kernel that holds ONE QP per wavefront at a horizon that is a multiple of 4 -- h = 16 / 20: persistent rows, fused and latency kernels, fast and general
 // path): the four rows of the wavefront work on one QP -- rows 0 / 1 in the main role,
 // rows 2 / 3 as twins, rows 1 / 3 bit-identical copies of rows 0 / 2 through everything sequential -- and the per-lane state is split four ways: slot k = step 4k + own,
@@ -380,6 +386,7 @@ struct RowSolver {
     long long clkB = 0, clkF = 0, clkT = 0, clkU = 0, clkX = 0;
 #endif
     long long pfX = 0, pfT = 0, pfU = 0;  // CLK: shader-clock cycles this QP spent in factor passes / iteration segments / residual checks (wave-mates' stalls included)
+    long long ckF = 0, ckR = 0;           // CLK, set-up: shader clock behind the formation (inputs, B~, gradient, U / V) and behind the Ruiz passes (a1mpc_last_tick_stage_cycles)
     int pred_cost = 0;  // set-up's guess of this QP's cost (queue order of a first solve, see predict_cost)
     struct Info {
         double pri_res, dua_res, nEz, nEAx, nDq, nDAty, nDPx;  // unscaled
@@ -682,6 +689,7 @@ struct RowSolver {
             });
         }
 
+        if constexpr (CLK) ckF = row_clock();
         // ---------------------------------------------------------------- Ruiz equilibration (osqp scaling.c scale_data)
         // update path (warm_start = 2, a previous tick in the carry): osqp_update_P re-equilibrates while the workspace still holds the PREVIOUS tick's
         // gradient -- the only place the gradient enters scale_data is the cost normalisation below
@@ -712,7 +720,10 @@ struct RowSolver {
         double D[H], E0[H], E1[H];
         csc = 1.0;
 #pragma unroll
-        for (int t = 0; t < H; ++t) { D[t] = 1.0; E0[t] = act ? 1.0 : 0.0; E1[t] = (comp < 2) ? 1.0 : 0.0; }
+        for (int t = 0; t < H; ++t) { D[t] = 1.0; E0[t] = act ? 1.0 : 0.0; }
+        // E1 (the scaling of my second constraint row: fx / fy lanes only) is not iterated (round 5): the rows [f + mu fz] and [f - mu fz] have the same absolute entries, so
+        // every Ruiz pass would update E1 by the same operations on the same operands as E0 -- E1 == E0 bit for bit on the fx / fy lanes, 0 elsewhere (see Prep<H>) -- it
+        // is copied from E0 behind the passes.  One of three rsqrt chains per horizon step and pass, and a third of the tables a shared set-up hands around, go.
         if (P.scaling_iters > 0) {
             double m[H];
             // m[s] = max_{t,b} D_tb |P_(s,a),(t,b)|  for my rows (s, a): one pass over the implicit Hessian.
@@ -720,13 +731,8 @@ struct RowSolver {
             double Umax = 0.0, Vmax = 0.0;
 #pragma unroll
             for (int b = 0; b < 12; ++b) { Umax = fmax(Umax, fabs(U[b])); Vmax = fmax(Vmax, fabs(V[b])); }
+            // sweep: the caller has published the current D of every step in the DL table (and synchronised)
             auto sweep = [&](double(&mm)[H]) {
-                set_sync();
-                if (act) {
-#pragma unroll
-                    for (int t = 0; t < H; ++t) lds[L::DL + t * 12 + ci] = D[t];
-                }
-                set_sync();
                 // the largest D of the whole QP (pad lanes hold 1.0 and do not count)
                 double Dall = 0.0;
 #pragma unroll
@@ -816,43 +822,61 @@ struct RowSolver {
                         static_for<H>([&](auto S) { mm[S] = fmax(mm[S], lds[L::COOP + (r * H + A1_CV(S)) * 16 + ln]); });
                 }
             };
+            set_sync();
+            if (act) {   // D = 1: every row of a shared set-up writes the same words
+#pragma unroll
+                for (int t = 0; t < H; ++t) lds[L::DL + t * 12 + ci] = D[t];
+            }
+            set_sync();
             sweep(m);
 #pragma unroll 1
             for (int pass = 0; pass < P.scaling_iters; ++pass) {
                 // one Ruiz step of horizon step T (scaling.c scale_data: column norms of [P A'; A 0] -> D, row norms -> E)
-                auto ruiz_step = [&](double& Dt_, double& E0t, double& E1t, double mt) {
+                auto ruiz_step = [&](double& Dt_, double& E0t, double mt) {
                     const double Dz = quad_perm<2, 2, 2, 2>(Dt_);
-                    const double mE = fmax(E0t, E1t);
+                    const double mE = E0t;   // = max(E0, E1): my two rows share their scaling (above)
                     const double mEx = quad_perm<0, 0, 0, 0>(mE), mEy = quad_perm<1, 1, 1, 1>(mE);
                     const double colA = Dt_ * (comp == 2 ? fmax(mu * fmax(mEx, mEy), E0t) : mE);
                     const double colP = csc * Dt_ * mt;
                     const double dtmp = row_rsqrt(limit_scaling(fmax(colP, colA)));
                     const double rowf = comp == 2 ? Dt_ : fmax(Dt_, mu * Dz);
                     const double e0 = row_rsqrt(limit_scaling(E0t * rowf));
-                    const double e1 = row_rsqrt(limit_scaling(E1t * rowf));
-                    Dt_ *= dtmp; E0t *= e0; E1t *= e1;
+                    Dt_ *= dtmp; E0t *= e0;
                 };
-                if (coop_n > 1) {
-                    // latency variant: the rows of the wave take every coop_n-th horizon step; the tables meet in the shared LDS image
-                    double* tb = lds + L::COOP + 4 * H * 16;  // [4 tables: D, E0, E1, m][H][16 lanes]
-                    static_for<H>([&](auto T) {
-                        constexpr int t = A1_CV(T);
-                        if (coop_id == 0) { tb[(0 * H + t) * 16 + ln] = D[t]; tb[(1 * H + t) * 16 + ln] = E0[t]; tb[(2 * H + t) * 16 + ln] = E1[t]; tb[(3 * H + t) * 16 + ln] = m[t]; }
+                // Shared set-up (coop_n rows of the wave on one QP): row j OWNS the horizon steps t = coop_n k + j.  A step's E is only ever needed by that step's own
+                // update, so it stays in its owner's registers through all passes (handed around once, behind the last pass); the new D of a step goes straight into the
+                // DL table the next sweep reads anyway, and every row reads the whole table back (the cost normalisation sums over all steps in a fixed order).
+                // Round 5: until then the four tables (D, E0, E1, m) went through LDS twice per pass -- 105 LDS operations per pass at H = 10 against 25 now.
+                auto shared_pass = [&](auto NN) {
+                    constexpr int N = A1_CV(NN);
+                    static_for<(H + N - 1) / N>([&](auto K) {
+                        constexpr int k = A1_CV(K);
+                        double Dt_ = D[N * k], E0t = E0[N * k], mt = m[N * k];
+                        static_for<N - 1>([&](auto J) {
+                            constexpr int t = N * k + A1_CV(J) + 1;
+                            if constexpr (t < H) { if (coop_id == A1_CV(J) + 1) { Dt_ = D[t]; E0t = E0[t]; mt = m[t]; } }
+                        });
+                        ruiz_step(Dt_, E0t, mt);
+                        static_for<N>([&](auto J) {
+                            constexpr int t = N * k + A1_CV(J);
+                            if constexpr (t < H) { if (coop_id == A1_CV(J)) { E0[t] = E0t; if (act) lds[L::DL + t * 12 + ci] = Dt_; } }
+                        });
                     });
-                    set_sync();
-#pragma unroll 1
-                    for (int t = coop_id; t < H; t += coop_n) {
-                        double Dt_ = tb[(0 * H + t) * 16 + ln], E0t = tb[(1 * H + t) * 16 + ln], E1t = tb[(2 * H + t) * 16 + ln];
-                        ruiz_step(Dt_, E0t, E1t, tb[(3 * H + t) * 16 + ln]);
-                        tb[(0 * H + t) * 16 + ln] = Dt_; tb[(1 * H + t) * 16 + ln] = E0t; tb[(2 * H + t) * 16 + ln] = E1t;
+                };
+                set_sync();   // every row is done with the DL table of the sweep before
+                if (coop_n == 1) {
+                    static_for<H>([&](auto T) { ruiz_step(D[T], E0[T], m[T]); });
+                    if (act) {
+#pragma unroll
+                        for (int t = 0; t < H; ++t) lds[L::DL + t * 12 + ci] = D[t];
                     }
                     set_sync();
-                    static_for<H>([&](auto T) {
-                        constexpr int t = A1_CV(T);
-                        D[t] = tb[(0 * H + t) * 16 + ln]; E0[t] = tb[(1 * H + t) * 16 + ln]; E1[t] = tb[(2 * H + t) * 16 + ln];
-                    });
                 } else {
-                    static_for<H>([&](auto T) { ruiz_step(D[T], E0[T], E1[T], m[T]); });
+                    if (coop_n == 2) shared_pass(std::integral_constant<int, 2>{});
+                    else shared_pass(std::integral_constant<int, 4>{});
+                    set_sync();
+#pragma unroll
+                    for (int t = 0; t < H; ++t) D[t] = act ? lds[L::DL + t * 12 + ci] : 1.0;   // (pad lanes: D stays 1, as every pass leaves it there)
                 }
                 sweep(m);
                 double sum = 0.0, nq = 0.0;
@@ -868,8 +892,17 @@ struct RowSolver {
                 csc *= ct;
             }
         }
+        if (P.scaling_iters > 0 && coop_n > 1) {   // the E of the other rows' horizon steps (each row wrote its own steps' only)
+            set_sync();
+            static_for<H>([&](auto T) { if ((A1_CV(T) & (coop_n - 1)) == coop_id) lds[L::E0X + A1_CV(T) * 16 + ln] = E0[T]; });   // (coop_n: 2 or 4)
+            set_sync();
+            static_for<H>([&](auto T) { E0[T] = lds[L::E0X + A1_CV(T) * 16 + ln]; });
+        }
+#pragma unroll
+        for (int t = 0; t < H; ++t) E1[t] = comp < 2 ? E0[t] : 0.0;
         cinv = 1.0 / csc;
         qd = csc * q2s;
+        if constexpr (CLK) ckR = row_clock();
 
         // ---------------------------------------------------------------- hot state of the ADMM loop
         // The iteration is carried in UNSCALED variables so that the Ruiz factors drop out of the hot loop:
@@ -1922,6 +1955,13 @@ struct RowSolver {
             if (io.rho_io) *io.rho_io = rho;   // also after a failed solve: OSQP's cold_start() zeroes x, z, y and leaves the rho it had adapted in settings->rho (round 4; until then 0 = "settings.rho")
         }
     }
+    // profiling instantiations of the fused / latency kernels: this QP's stage record (kTickStages cycles, layout kClk*) from the driver's stamps --
+    // c0 entry | cF formation done | cR Ruiz passes done | c1 hot state + hand-off done | c2 solve() returned | c3 outputs written.  The iterations' share is what
+    // solve() spent outside factor passes and residual checks (OSQP's first iteration and the loop glue included).
+    A1_DEV void store_tick_stages(long long* __restrict__ clk, long long c0, long long cF, long long cR, long long c1, long long c2, long long c3) const {
+        if (clk == nullptr || !lead()) return;
+        clk[0] = cF - c0; clk[1] = cR - cF; clk[2] = c1 - cR; clk[3] = pfX; clk[4] = (c2 - c1) - pfX - pfU; clk[5] = pfU; clk[6] = c3 - c2; clk[7] = c3 - c0;
+    }
 };
 
 // arguments of a batch launch (device pointers; per-QP records are contiguous, QP b at base + b * record size)
@@ -1943,8 +1983,10 @@ struct BatchArgs {
     int32_t* cost;
     int32_t predict;  // the set-up kernel writes its cost guess to `cost` (first solve of a batch: no history to order the queue by)
     double* carry;    // warm_start = 2 (update path): n x Carry<H>::STRIDE, or null
-    long long* clk;   // profiling instantiation (a1mpc_set_profiling): n x 3 shader-clock cycles per QP [factor passes, iteration segments, residual checks], or null
+    long long* clk;   // profiling instantiations (a1mpc_set_profiling): n x kTickStages shader-clock cycles per QP (layout below), or null
 };
+// per-QP stage record of the profiling instantiations: the split pipeline's persistent rows fill FACTOR / ITER / CHECK, the fused and the latency kernel all of it
+enum : int { kClkForm = 0, kClkRuiz = 1, kClkHandoff = 2, kClkFactor = 3, kClkIter = 4, kClkCheck = 5, kClkOut = 6, kClkTotal = 7, kTickStages = 8 };
 template <int H, int MODE>
 A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
     ProblemIO io;
@@ -2022,7 +2064,7 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
                 if constexpr (UPD) S.write_outputs(make_io<H, kModeMpc>(a, cur), carry_of<H>(a, cur));
                 else S.write_outputs(make_io<H, kModeMpc>(a, cur));
                 if (a.cost != nullptr && S.lead()) a.cost[cur] = S.iter + 10 * S.nfact;  // ~ ADMM-iteration equivalents (a factor pass ~ 10)
-                if constexpr (CLK) { if (a.clk != nullptr && S.lead()) { a.clk[cur * 3 + 0] = S.pfX; a.clk[cur * 3 + 1] = S.pfT; a.clk[cur * 3 + 2] = S.pfU; } }
+                if constexpr (CLK) { if (a.clk != nullptr && S.lead()) { a.clk[cur * kTickStages + kClkFactor] = S.pfX; a.clk[cur * kTickStages + kClkIter] = S.pfT; a.clk[cur * kTickStages + kClkCheck] = S.pfU; } }
             }
             double v = 0.0;
             if (S.lead()) {
@@ -2049,14 +2091,31 @@ A1_DEV void admm_rows(const BatchArgs& a, const double* __restrict__ prep, int* 
     }
 }
 
+// The fused / latency kernels' copy of the batch's (alpha / beta, beta) table inside the QP's LDS image (Layout::TAB, in the still empty factor region): the Ruiz sweeps read
+// a column of it per visited block column, and from global memory that was one exposed round trip per column -- a lone wave per SIMD hides nothing (round 5: ~25 k of
+// the ~100 k cycles the ten passes took in a warm-started tick).  The `parts` rows that share the image split the copy; all loads are issued before the first store.
+template <int H, class LAY>
+A1_DEV const double* stage_table(const double* __restrict__ tab, double* __restrict__ lds, int part, int parts) {
+    constexpr int N2 = 2 * H * H, PER = (N2 + 15) / 16;
+    double v[PER];
+    const int l0 = row_lane() + 16 * part, step = 16 * parts;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int i = l0 + step * k; v[k] = (k * parts < PER && i < N2) ? tab[i] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int i = l0 + step * k; if (k * parts < PER && i < N2) lds[LAY::TAB + i] = v[k]; }
+    return lds + LAY::TAB;   // (the caller's first set_sync() orders the stores against the sweeps' reads)
+}
+
 // the fused path: one QP from inputs to outputs (small batches, the batch-1 latency path, the CPU test double).
 // make_io() is called where the pointers are needed (set-up, hand-off, outputs) instead of once: a ProblemIO of per-row pointers that
 // stays live across the ADMM loop costs that loop ~30 VGPRs it does not have.
 // TWIN: the calling row is one of a main / twin pair (rows r and r + 2 of the wavefront, see RowSolver<.., TWIN>): the main row sets the QP up alone,
 // both iterate.
 // UPD: the instantiation that also serves warm_start = 2 (the reference's update path); UPD = false is the code of every other mode, as it was before that path existed
-template <int H, int MODE, bool GEN = false, bool TWIN = false, bool UPD = false, bool QUAD = false, class MakeIO>
-A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab, MakeIO&& make_io_, double* __restrict__ lds) {
+// CLK (fast path, H > 1): the profiling instantiation -- `clk` = this QP's kTickStages stage record (a1mpc_last_tick_stage_cycles); same arithmetic, same bits
+template <int H, int MODE, bool GEN = false, bool TWIN = false, bool UPD = false, bool QUAD = false, bool CLK = false, class MakeIO>
+A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab, MakeIO&& make_io_, double* __restrict__ lds, [[maybe_unused]] long long* __restrict__ clk = nullptr) {
+    static_assert(!CLK || (!GEN && MODE == kModeMpc && Prep<H>::STRIDE <= H * Layout<H>::SLOT), "the profiling instantiation exists for the fast path's set-up | iteration hand-off");
     static_assert(!TWIN || (MODE == kModeMpc && Prep<H>::STRIDE <= H * Layout<H>::SLOT), "twin rows: the MPC solve with the set-up | iteration hand-off");
     static_assert(!QUAD || TWIN, "a quad of rows: a twin pair doubled");
     if constexpr (GEN) {
@@ -2065,9 +2124,11 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
         static_assert(Prep<H>::STRIDE <= H * Layout<H, true>::SLOT, "the hand-off record fits the (still empty) factor region");
         {   // a main / twin pair shares the set-up like the rows of the latency kernel do: each takes every other column of the Ruiz sweeps and every
             // other horizon step of the D / E updates, everything else is computed redundantly (same values, same LDS image)
-            RowSolver<H, MODE, false, true> S0(P, tab, lds);
-            if constexpr (TWIN) { S0.coop_id = row_is_twin() ? 1 : 0; S0.coop_n = 2; }
-            if constexpr (QUAD) { S0.coop_id = 2 * S0.coop_id + row_sub(); S0.coop_n = 4; }   // (a quad: the four rows)
+            int cid = 0, cn = 1;
+            if constexpr (TWIN) { cid = row_is_twin() ? 1 : 0; cn = 2; }
+            if constexpr (QUAD) { cid = 2 * cid + row_sub(); cn = 4; }   // (a quad: the four rows)
+            RowSolver<H, MODE, false, true> S0(P, stage_table<H, Layout<H, true>>(tab, lds, cid, cn), lds);
+            S0.coop_id = cid; S0.coop_n = cn;
             S0.setup(make_io_());
             if constexpr (TWIN) pair_sync(); else row_sync();  // everybody is done with the set-up scratch aliased into the factor region
             if ((!TWIN || !row_is_twin()) && (!QUAD || row_sub() == 0)) S0.save_prepared(lds + Layout<H, true>::FAC);
@@ -2081,20 +2142,28 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
         // Set-up and iteration are two solver objects joined by the hand-off record of the split pipeline, staged in the (still
         // empty) factor region: the ADMM loop then gets the register allocation of the persistent kernel instead of one that
         // also carries the set-up's live values (scratch reloads inside the loop).  ~0.5 us per solve.
+        [[maybe_unused]] long long c0 = 0, cF = 0, cR = 0, c1 = 0, c2 = 0;
+        if constexpr (CLK) c0 = row_clock();
         {   // (a main / twin pair shares the set-up: see the general path above)
-            RowSolver<H, MODE> S0(P, tab, lds);
-            if constexpr (TWIN) { S0.coop_id = row_is_twin() ? 1 : 0; S0.coop_n = 2; }
-            if constexpr (QUAD) { S0.coop_id = 2 * S0.coop_id + row_sub(); S0.coop_n = 4; }   // (a quad: the four rows, like the latency kernel's)
+            int cid = 0, cn = 1;
+            if constexpr (TWIN) { cid = row_is_twin() ? 1 : 0; cn = 2; }
+            if constexpr (QUAD) { cid = 2 * cid + row_sub(); cn = 4; }   // (a quad: the four rows, like the latency kernel's)
+            RowSolver<H, MODE, false, false, false, false, CLK> S0(P, stage_table<H, Layout<H>>(tab, lds, cid, cn), lds);
+            S0.coop_id = cid; S0.coop_n = cn;
             S0.template setup<UPD>(make_io_());
             if constexpr (TWIN) pair_sync(); else row_sync();
             if ((!TWIN || !row_is_twin()) && (!QUAD || row_sub() == 0)) S0.template save_prepared<UPD>(lds + Layout<H>::FAC);
+            if constexpr (CLK) { cF = S0.ckF; cR = S0.ckR; }
         }
         if constexpr (TWIN) pair_sync();  // the twin reads the hand-off record its main row wrote
-        RowSolver<H, MODE, false, false, TWIN, false, false, QUAD> S(P, tab, lds);
+        RowSolver<H, MODE, false, false, TWIN, false, CLK, QUAD> S(P, tab, lds);
         S.template load_prepared<UPD>(lds + Layout<H>::FAC, make_io_());
+        if constexpr (CLK) c1 = row_clock();
         S.template solve<UPD>();
+        if constexpr (CLK) c2 = row_clock();
         if constexpr (UPD) { const ProblemIO& io_ = make_io_(); S.write_outputs(io_, io_.carry); }
         else S.write_outputs(make_io_());
+        if constexpr (CLK) S.store_tick_stages(clk, c0, cF, cR, c1, c2, row_clock());
     } else {
         RowSolver<H, MODE> S(P, tab, lds);
         S.setup(make_io_());

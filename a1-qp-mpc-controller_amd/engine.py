@@ -40,7 +40,7 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
     _fields_ = [("counter_per_swing", C.c_double), ("foot_force_low", C.c_double), ("use_terrain_adapt", C.c_int32)]
 
 
-EXPORTS = ["a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_get_workspace_z", "a1mpc_get_workspace_scaling", "a1mpc_last_warm_start_mode", "a1mpc_set_profiling", "a1mpc_last_stage_cycles", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
+EXPORTS = ["a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_get_workspace_z", "a1mpc_get_workspace_scaling", "a1mpc_last_warm_start_mode", "a1mpc_set_profiling", "a1mpc_last_stage_cycles", "a1mpc_last_tick_stage_cycles", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error", "a1mpc_build_info", "a1mpc_pipeline_create", "a1mpc_pipeline_submit_device", "a1mpc_pipeline_submit",
@@ -119,6 +119,8 @@ def load_library(path=None):
     lib.a1mpc_set_profiling.argtypes = [vp, i32]; lib.a1mpc_set_profiling.restype = C.c_int
     lib.a1mpc_last_stage_cycles.argtypes = [vp, dp, C.POINTER(C.c_int32)]; lib.a1mpc_last_stage_cycles.restype = C.c_int
     lib.a1mpc_last_warm_start_mode.argtypes = [vp, C.POINTER(C.c_int32)]; lib.a1mpc_last_warm_start_mode.restype = C.c_int
+    if path == _build.LIB_PATH or hasattr(lib, "a1mpc_last_tick_stage_cycles"):  # (round 5; an older build bound by hand for an A/B may lack it)
+        lib.a1mpc_last_tick_stage_cycles.argtypes = [vp, dp, C.POINTER(C.c_int32)]; lib.a1mpc_last_tick_stage_cycles.restype = C.c_int
     lib.a1mpc_set_schedule.argtypes = [vp, i32]; lib.a1mpc_set_schedule.restype = C.c_int
     lib.a1mpc_reset_warm_start.argtypes = [vp]; lib.a1mpc_reset_warm_start.restype = C.c_int
     lib.a1mpc_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]; lib.a1mpc_last_kernel_ms.restype = C.c_int
@@ -270,6 +272,14 @@ class Engine:
         c = np.zeros(3); q = C.c_int32(0)
         _check(self.lib, self.lib.a1mpc_last_stage_cycles(self._h, _dp(c), C.byref(q)), "a1mpc_last_stage_cycles")
         return dict(factor=float(c[0]), iterate=float(c[1]), check=float(c[2]), qps=int(q.value))
+
+    TICK_STAGES = ("formation", "ruiz", "handoff", "factor", "iterate", "check", "outputs", "total")
+
+    def last_tick_stage_cycles(self):
+        """dict(stage -> shader-clock cycles summed over the QPs of the last profiled fused / latency tick; qps) -- a1mpc_last_tick_stage_cycles"""
+        c = np.zeros(8); q = C.c_int32(0)
+        _check(self.lib, self.lib.a1mpc_last_tick_stage_cycles(self._h, _dp(c), C.byref(q)), "a1mpc_last_tick_stage_cycles")
+        return dict(zip(self.TICK_STAGES, map(float, c)), qps=int(q.value))
 
     def last_warm_start_mode(self):
         m = C.c_int32(-9)

@@ -225,6 +225,45 @@ def warm_tick_probe(pkg, local, n=4096, ticks=12, mode=1):
             "ticks_per_s_x_robots": n / (float(np.median(ms[4:])) * 1e-3), "mean_iters_cold_first_tick": iters[0], "mean_iters_warm": float(np.mean(iters[4:]))}
 
 
+def warm_tick_stage_counters(pkg, local, n=4096, mode=1, ticks=8):
+    """where a warm-started tick spends its cycles -- the profiling instantiation of the fused (n > 256) / latency (n <= 256) kernel
+    (a1mpc_set_profiling + a1mpc_last_tick_stage_cycles: same arithmetic, same bits, shader-clock stamps between the stages), one profiled tick behind `ticks` plain ones.
+    Shares of the tick's cycles, cycles per QP and the plain kernel's ms per tick beside them."""
+    import torch
+    dev = torch.device("cuda", local); st = torch.cuda.Stream(device=dev)
+    a = pkg.scenarios.config3_random_flat(nb=n) if n > 1 else None
+    if n == 1:   # BASELINE configs[1]: the trot sequence, one robot
+        seq = pkg.scenarios.config2_trot_sequence(ticks + 2)
+        frames = [{k: np.ascontiguousarray(seq[k][t:t + 1]) for k in ("x0", "xref", "R", "foot", "contact")} for t in range(ticks + 2)]
+        params = seq["params"]
+    else:
+        rng = np.random.default_rng(5)
+        b = {k: a[k].copy() for k in ("x0", "xref", "R", "foot", "contact")}
+        b["x0"][:, :12] += rng.normal(0, 0.002, (n, 12)); b["foot"] += rng.normal(0, 0.001, (n, 12))
+        frames = [a if t % 2 == 0 else b for t in range(ticks + 2)]
+        params = a["params"]
+    cfg = pkg.make_config(params, HORIZON, warm_start=mode)
+    grf = torch.zeros((n, 12), dtype=torch.float64, device=dev); it = torch.zeros(n, dtype=torch.int32, device=dev); stt = torch.zeros(n, dtype=torch.int32, device=dev)
+    ms = []
+    with pkg.Engine(cfg, n, local) as eng:
+        def tick(t):
+            d = {k: torch.from_numpy(frames[t][k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")}
+            eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, it, stt, stream=st.cuda_stream)
+            return eng.last_kernel_ms()
+        for t in range(ticks):
+            ms.append(tick(t))
+        eng.set_profiling(True); prof_ms = tick(ticks); cyc = eng.last_tick_stage_cycles(); iters = float(it.float().mean().item()); eng.set_profiling(False)
+        ms.append(tick(ticks + 1))
+    if cyc["qps"] != n or cyc["total"] <= 0:
+        return {"error": f"the tick was not profiled (qps {cyc['qps']})"}
+    tot = cyc["total"]
+    return {"robots": n, "warm_start_mode": mode, "kernel": "latency (coop) kernel" if n <= 256 else "fused kernel",
+            "kernel_ms_per_tick": float(np.median(ms[3:])), "profiled_tick_ms": prof_ms, "mean_iters": iters,
+            "share": {k: cyc[k] / tot for k in pkg.Engine.TICK_STAGES[:-1]}, "cycles_per_qp": {k: cyc[k] / n for k in pkg.Engine.TICK_STAGES},
+            "stages": "[formation | Ruiz passes | hot state + hand-off | factor passes | iterations | residual checks | outputs + carry], shader-clock cycles of the "
+                      "wavefront summed over the QPs (a QP's cycles include its wave-mate's)"}
+
+
 def full_tick_probe(pkg, local, n=4096, ticks=10):
     """Extra information (not `value`): one whole control tick per robot chained on the GPU through the *_device entry points -- leg state,
     EKF, gait plan, swing legs, contacts / terrain, warm-started MPC (tick records), joint torques -- sensors resident in HBM, one stream."""

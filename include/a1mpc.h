@@ -59,6 +59,16 @@ typedef enum a1mpc_status {
 #define A1MPC_QP_SOLVED_INACCURATE 2
 #define A1MPC_QP_MAX_ITER_REACHED (-2)
 #define A1MPC_QP_NON_CVX (-7)
+/* OSQP's other outcomes -- PRIMAL_INFEASIBLE (-3), PRIMAL_INFEASIBLE_INACCURATE (3), DUAL_INFEASIBLE (-4), DUAL_INFEASIBLE_INACCURATE (4) -- are UNREACHABLE here by
+ * construction, and the kernels do not evaluate OSQP's infeasibility certificates (auxil.c is_primal_infeasible / is_dual_infeasible):
+ *   * every configuration on which they could fire is refused with A1MPC_ERR_INVALID_ARGUMENT by a1mpc_create / a1mpc_update_config / a1mpc_sharded_create /
+ *     a1mpc_pipeline_create (and the balance-QP constants by a1mpc_balance_solve_batch): mu < 0, fz_min > fz_max, fz_max < 0, a negative or non-finite weight,
+ *     mass / dt <= 0, a singular body inertia, and every OSQP setting osqp_setup itself refuses (auxil.c validate_settings: rho, sigma <= 0, alpha outside (0, 2),
+ *     negative tolerances, ...).  OSQP refuses the same data in osqp_setup (validate_data: l <= u); the reference ignores that return code
+ *     (S/A1RobotControl.cpp:532,540) and goes on to read an uninitialised solution (:559) -- a deliberate deviation: the bad configuration is reported where it is given.
+ *   * on every accepted configuration the per-problem inputs (states, feet, contacts) cannot make the QP infeasible or unbounded: the bounds come from the
+ *     configuration and the contact flags only, (0, 0, max(fz_min, 0) c) is always feasible, the feasible set is compact and P = B'QB + R is positive semi-definite.
+ * Non-finite INPUTS surface as A1MPC_QP_NON_CVX + zero forces (OSQP: a NaN residual ends the solve as OSQP_NON_CVX). */
 
 typedef struct a1mpc_config {
     int32_t horizon; /* PLAN_HORIZON (S/A1Params.h:26 fixes 10; a run-time value here) */
@@ -111,7 +121,8 @@ typedef struct a1mpc_handle_s* a1mpc_handle;
 void a1mpc_default_config(a1mpc_config* cfg);
 void a1mpc_default_balance_config(a1mpc_balance_config* cfg);
 
-/* device: HIP device ordinal (>= 0).  max_batch: largest n any later call will pass. */
+/* device: HIP device ordinal (>= 0).  max_batch: largest n any later call will pass.  The configuration is validated first (see the status
+ * values above for what is refused and why): A1MPC_ERR_INVALID_ARGUMENT + a1mpc_last_error() naming the field, whether or not a GPU is present. */
 a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t device, a1mpc_handle* out);
 void a1mpc_destroy(a1mpc_handle h);
 
@@ -385,6 +396,19 @@ a1mpc_status a1mpc_get_workspace_scaling(a1mpc_handle h, int32_t n, double* D_ou
  * ratio splits a1mpc_last_stage_ms' solve stage.  Host call; synchronises the handle's stream. */
 a1mpc_status a1mpc_set_profiling(a1mpc_handle h, int32_t on);
 a1mpc_status a1mpc_last_stage_cycles(a1mpc_handle h, double* cycles3_out, int32_t* qps_out);
+/* The same stopwatches for the tick the reference actually runs (round 5): with profiling on, a solve that goes through the fused or the latency kernel at horizon 10
+ * -- every warm-started closed-loop tick of a known batch up to 8192 robots, every batch of <= 256 QPs, i.e. the batch-1 control tick, in all three warm-start
+ * semantics -- runs a clock-stamped instantiation of that kernel (same arithmetic, same results bit for bit) and this call returns the shader-clock cycles summed over
+ * its QPs, in the order of the reference's tick (S/A1RobotControl.cpp:446-562):
+ *   [0] formation: inputs, B~, gradient roll-out + adjoint, the two 12x12 Hessian blocks        (calculate_A/B_mat_c .. calculate_qp_mats, :491-520)
+ *   [1] the Ruiz equilibration passes + cost scaling                                            (osqp_setup / osqp_update_P: scale_data)
+ *   [2] hot state (rho vector, warm-start iterates, update-path carry) + set-up -> solver hand-off
+ *   [3] Riccati factor passes   [4] ADMM iterations (OSQP's first iteration included)   [5] residual checks + rho updates        (solver.solve(), :540)
+ *   [6] outputs: R' f, the carried workspace (x, y, rho; update path: z, scalings)                (:555-561, store_solution)
+ *   [7] the whole tick, entry to exit (= the sum of [0..6])
+ * A wavefront's QPs share its instruction stream: a QP's cycles include its wave-mate's.  *qps_out = QPs summed (0: the last solve was not such a tick -- a
+ * split-pipeline solve reports through a1mpc_last_stage_cycles).  Host call; synchronises the handle's stream. */
+a1mpc_status a1mpc_last_tick_stage_cycles(a1mpc_handle h, double* cycles8_out, int32_t* qps_out);
 /* Which warm-start semantics the handle's last MPC solve actually ran: 0 (cold), 1 (fresh set-up + osqp_warm_start) or 2 (the reference's update path).
  * warm_start = 2 exists on the fast path at horizons 10 / 16 / 20; a solve through the general path (per-step feet, a separate A_c yaw) or at horizon 1
  * runs mode 1 instead (documented at a1mpc_config.warm_start) -- this call makes that visible to the caller.  -1 before the first solve. */
@@ -393,7 +417,7 @@ a1mpc_status a1mpc_last_warm_start_mode(a1mpc_handle h, int32_t* mode_out);
 /* Replace the configuration of a live handle -- everything except the horizon: dt (the reference uses the measured loop dt when
  * use_sim_time is "true", S/A1RobotControl.cpp:465), weights, mass / inertia, friction and force limits, OSQP settings.  The constants
  * travel to the kernels by value with every launch, so this costs nothing, keeps the carried warm start and takes effect with the
- * next call. */
+ * next call.  Validated like a1mpc_create; a refused configuration leaves the handle's configuration as it was. */
 a1mpc_status a1mpc_update_config(a1mpc_handle h, const a1mpc_config* cfg);
 
 /* instrumentation: duration of the last kernel launched through this handle (HIP events on its stream;

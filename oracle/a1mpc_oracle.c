@@ -382,7 +382,7 @@ static int update_rho_vec(work_t *w) {
 /* Per-thread scratch, reused from solve to solve.  Every solve used to calloc / malloc ~0.5 MB in pieces above glibc's mmap threshold: each one a fresh mapping,
  * page faults and the process-wide mmap lock -- the 128 OpenMP threads of the CPU baseline ran 9.8x one thread.  Buffers live as long as their thread. */
 typedef struct { void *p; size_t cap; } orc_scratch;
-static __thread orc_scratch tl_scratch[8];
+static __thread orc_scratch tl_scratch[9];   /* slot 8: orc_last_z() only (it used to share slot 2 with the formation's B_mat_d_list) */
 static void *scratch_get(int slot, size_t bytes, int zero) {
     orc_scratch *sc = &tl_scratch[slot];
     if (sc->cap < bytes) { free(sc->p); sc->p = malloc(bytes); sc->cap = sc->p ? bytes : 0; }
@@ -533,7 +533,7 @@ done:
     info->rho_final = w.rho;
     if (rho_io) *rho_io = w.rho;
     {   /* the unscaled z = Einv z_s of this solve, for orc_last_z() (tests: OSQP's termination test needs it beside x and y) */
-        double *lz = (double *)scratch_get(2, (size_t)(m + 1) * sizeof(double), 0);
+        double *lz = (double *)scratch_get(8, (size_t)(m + 1) * sizeof(double), 0);
         if (lz) { lz[0] = (double)m; for (int i = 0; i < m; ++i) lz[1 + i] = w.Einv[i] * w.z[i]; }
     }
     if (carry) {  /* what stays in the reference's workspace for the next tick's update calls */
@@ -568,7 +568,7 @@ int orc_osqp_solve_update_ex(int n, int m, const double *P, const double *q, con
 }
 /* unscaled z of the calling thread's most recent solve (m doubles); returns m, or -1 when there was none or the size differs */
 int orc_last_z(int m, double *z_out) {
-    const double *lz = (const double *)tl_scratch[2].p;
+    const double *lz = (const double *)tl_scratch[8].p;
     if (!lz || (int)lz[0] != m) return -1;
     for (int i = 0; i < m; ++i) z_out[i] = lz[1 + i];
     return m;
@@ -1178,9 +1178,14 @@ static void ekf_C(double *C) {                                       /* :10-17 *
         }
     for (int i = 0; i < NLEG; ++i) C[(NLEG * 6 + i) * EKF_NS + 6 + i * 3 + 2] = 1.0;
 }
-void orc_ekf_step(double *state, double dt, int assume_flat_ground, int movement_mode, const double *foot_force, const double *Rw,
-                  const double *imu_acc, const double *imu_ang_vel, const double *foot_pos_rel, const double *foot_vel_rel,
-                  double *root_pos, double *root_lin_vel, uint8_t *estimated_contacts_out) {
+/* use_fma = 0: the PINNED restatement -- every product of S/A1BasicEKF.cpp:70-164 as a multiply followed by an add, the arithmetic the reference's source
+ * states (compiled with -ffp-contract=off); tests/test_ref_pin.py holds THIS variant to the verbatim-compiled reference.
+ * use_fma = 1: the four big dense products (:134-139) accumulate by fma() -- the device kernel's arithmetic (round 4: half the FP64 instructions there).  It is
+ * not a second ground truth: tests hold it to the plain variant within a stated bound (the oracle must not follow the kernel). */
+static inline double ekf_acc(int use_fma, double x, double y, double a) { return use_fma ? fma(x, y, a) : a + x * y; }
+static void ekf_step_impl(int use_fma, double *state, double dt, int assume_flat_ground, int movement_mode, const double *foot_force, const double *Rw,
+                          const double *imu_acc, const double *imu_ang_vel, const double *foot_pos_rel, const double *foot_vel_rel,
+                          double *root_pos, double *root_lin_vel, uint8_t *estimated_contacts_out) {
     double *x = state, *P = state + EKF_NS, *inited = state + EKF_NS + EKF_NS * EKF_NS;
     if (*inited == 0.0) {                                            /* init_state :54-68 */
         for (int i = 0; i < EKF_NS * EKF_NS; ++i) P[i] = 0.0;
@@ -1268,19 +1273,18 @@ void orc_ekf_step(double *state, double dt, int assume_flat_ground, int movement
         }
     }
     for (int i = 0; i < EKF_NM * EKF_NM; ++i) M[i] = -M[i];
-    /* (round 4: the four big dense products below accumulate by fma(), like the device kernel: half the FP64 instructions there; the reference's Eigen products
-     * contract or not as its compiler pleases, and the agreement with the reference stays where the two different solvers for S put it, 1e-9) */
-    for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a = fma(M[r * EKF_NM + c], err[c], a); Serr[r] = a; }                                    /* :134 */
+    /* (the four big dense products below: multiply + add in the pinned variant, fma() in the device kernel's variant -- see ekf_step_impl's header) */
+    for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a = ekf_acc(use_fma, M[r * EKF_NM + c], err[c], a); Serr[r] = a; }                        /* :134 */
     for (int r = 0; r < EKF_NM; ++r) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a += M[r * EKF_NM + c] * C[c * EKF_NS + j]; SC[r * EKF_NS + j] = a; }   /* :138 */
     double G1[EKF_NS * EKF_NM], G2[EKF_NS * EKF_NS];
     for (int a_ = 0; a_ < EKF_NS; ++a_) for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int k = 0; k < EKF_NS; ++k) a += Pbar[a_ * EKF_NS + k] * C[r * EKF_NS + k]; G1[a_ * EKF_NM + r] = a; }
     for (int a_ = 0; a_ < EKF_NS; ++a_) {                                                             /* :136 */
-        double a = 0; for (int r = 0; r < EKF_NM; ++r) a = fma(G1[a_ * EKF_NM + r], Serr[r], a);
+        double a = 0; for (int r = 0; r < EKF_NM; ++r) a = ekf_acc(use_fma, G1[a_ * EKF_NM + r], Serr[r], a);
         x[a_] = xbar[a_] + a;
     }
-    for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int r = 0; r < EKF_NM; ++r) a = fma(G1[a_ * EKF_NM + r], SC[r * EKF_NS + j], a); G2[a_ * EKF_NS + j] = a; }
+    for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int r = 0; r < EKF_NM; ++r) a = ekf_acc(use_fma, G1[a_ * EKF_NM + r], SC[r * EKF_NS + j], a); G2[a_ * EKF_NS + j] = a; }
     for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) {                            /* :139 */
-        double a = 0; for (int k = 0; k < EKF_NS; ++k) a = fma(G2[a_ * EKF_NS + k], Pbar[k * EKF_NS + j], a);
+        double a = 0; for (int k = 0; k < EKF_NS; ++k) a = ekf_acc(use_fma, G2[a_ * EKF_NS + k], Pbar[k * EKF_NS + j], a);
         T[a_ * EKF_NS + j] = Pbar[a_ * EKF_NS + j] - a;
     }
     for (int i = 0; i < EKF_NS; ++i) for (int j = 0; j < EKF_NS; ++j) P[i * EKF_NS + j] = 0.5 * (T[i * EKF_NS + j] + T[j * EKF_NS + i]);   /* :140 */
@@ -1290,6 +1294,18 @@ void orc_ekf_step(double *state, double dt, int assume_flat_ground, int movement
     }
     for (int i = 0; i < NLEG; ++i) estimated_contacts_out[i] = ec[i] < 0.5 ? 0 : 1;                   /* :151-157 */
     for (int r = 0; r < 3; ++r) { root_pos[r] = x[r]; root_lin_vel[r] = x[3 + r]; }                   /* :159-163 */
+}
+/* the pinned restatement (multiply + add, as the reference's source states it) */
+void orc_ekf_step(double *state, double dt, int assume_flat_ground, int movement_mode, const double *foot_force, const double *Rw,
+                  const double *imu_acc, const double *imu_ang_vel, const double *foot_pos_rel, const double *foot_vel_rel,
+                  double *root_pos, double *root_lin_vel, uint8_t *estimated_contacts_out) {
+    ekf_step_impl(0, state, dt, assume_flat_ground, movement_mode, foot_force, Rw, imu_acc, imu_ang_vel, foot_pos_rel, foot_vel_rel, root_pos, root_lin_vel, estimated_contacts_out);
+}
+/* the device kernel's arithmetic (fma accumulation in the four dense products): bit-comparable with a1mpc_ekf_update_batch, held to orc_ekf_step by the tests */
+void orc_ekf_step_fma(double *state, double dt, int assume_flat_ground, int movement_mode, const double *foot_force, const double *Rw,
+                      const double *imu_acc, const double *imu_ang_vel, const double *foot_pos_rel, const double *foot_vel_rel,
+                      double *root_pos, double *root_lin_vel, uint8_t *estimated_contacts_out) {
+    ekf_step_impl(1, state, dt, assume_flat_ground, movement_mode, foot_force, Rw, imu_acc, imu_ang_vel, foot_pos_rel, foot_vel_rel, root_pos, root_lin_vel, estimated_contacts_out);
 }
 int orc_ekf_state_doubles(void) { return ORC_EKF_STATE; }
 

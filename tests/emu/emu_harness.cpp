@@ -170,7 +170,7 @@ static void latency_entry(void* a) {
         const int row = emu_lane >> 4;
         const bool upd = j->io.carry != nullptr;
         {
-            RowSolver<H, kModeMpc> S(*j->P, j->tab, j->lds);
+            RowSolver<H, kModeMpc> S(*j->P, stage_table<H, Layout<H>>(j->tab, j->lds, row, 4), j->lds);
             S.coop_id = row; S.coop_n = 4;
             if (upd) S.template setup<true>(j->io); else S.template setup<false>(j->io);
             coop_sync();   // (the device's row_sync() orders the whole wavefront)

@@ -49,6 +49,50 @@ def test_no_cpu_fallback(pkg, scen):
         pkg.Engine(bad, 1, 0)
 
 
+BAD_CONFIGS = [dict(p=dict(fz_min=200.0)), dict(p=dict(fz_max=-5.0, fz_min=-10.0)), dict(p=dict(mu=-0.3)), dict(p=dict(mu=float("nan"))), dict(p=dict(mass=0.0)),
+               dict(p=dict(dt=0.0)), dict(p=dict(dt=float("inf"))), dict(q0=-1.0), dict(r0=-1e-6), dict(q0=float("nan")), dict(p=dict(inertia=[0.0] * 9)),
+               dict(o=dict(rho=0.0)), dict(o=dict(sigma=-1e-6)), dict(o=dict(alpha=2.0)), dict(o=dict(alpha=0.0)), dict(o=dict(eps_abs=-1e-3)),
+               dict(o=dict(eps_abs=0.0, eps_rel=0.0)), dict(o=dict(max_iter=0)), dict(o=dict(check_termination=-1)), dict(o=dict(scaling=-1)),
+               dict(o=dict(adaptive_rho_tolerance=0.5)), dict(o=dict(adaptive_rho_interval=-25)), dict(o=dict(warm_start=3))]
+
+
+def bad_config(pkg, sc, case):
+    p = dict(sc["params"], **case.get("p", {}))
+    if "q0" in case:
+        p["q"] = [case["q0"]] + list(p["q"][1:])
+    if "r0" in case:
+        p["r"] = [case["r0"]] + list(p["r"][1:])
+    return pkg.make_config(p, 10, **case.get("o", {}))
+
+
+@pytest.mark.parametrize("case", BAD_CONFIGS, ids=[str(c) for c in BAD_CONFIGS])
+def test_bad_configurations_are_refused_before_any_device_query(pkg, scen, case):
+    """every configuration on which OSQP's PRIMAL / DUAL_INFEASIBLE or NON_CVX outcomes could be reached -- and every setting osqp_setup itself refuses
+    (auxil.c validate_data / validate_settings) -- is A1MPC_ERR_INVALID_ARGUMENT at a1mpc_create, with or without a GPU (the check comes before hipGetDeviceCount), and
+    a1mpc_last_error names the field.  include/a1mpc.h lists which OSQP statuses are unreachable as a consequence."""
+    lib = pkg.load_library()
+    cfg = bad_config(pkg, scen.scenario_T(), case)
+    h = C.c_void_p()
+    rc = lib.a1mpc_create(C.byref(cfg), 4, 0, C.byref(h))
+    assert rc == 1 and not h.value, (rc, lib.a1mpc_last_error())
+    assert len(lib.a1mpc_last_error()) > 10
+    qp = pkg.BalanceConfig(); lib.a1mpc_default_balance_config(C.byref(qp))
+    assert (qp.mu, qp.F_min, qp.F_max) == (0.7, 0.0, 180.0)
+
+
+def test_the_reference_configurations_pass_validation(pkg, scen):
+    """the three rosparam weight sets of the reference (config/*_a1_mpc.yaml) and the test program's (S/test/test_mpc.cpp) are accepted: without a GPU the call gets past the
+    validation and fails for want of a device (3 = A1MPC_ERR_NO_DEVICE / 4 = A1MPC_ERR_HIP), with one it succeeds"""
+    lib = pkg.load_library()
+    for name in ("gazebo", "hardware", "isaac"):
+        cfg = pkg.make_config(scen.PARAM_SETS[name] | scen.MPC_CONSTANTS, 10)
+        h = C.c_void_p()
+        rc = lib.a1mpc_create(C.byref(cfg), 4, 0, C.byref(h))
+        assert rc in (0, 3, 4), (name, rc, lib.a1mpc_last_error())
+        if rc == 0:
+            lib.a1mpc_destroy(h)
+
+
 def test_product_never_touches_the_oracle():
     """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/"""
     pk = os.path.join(ROOT, "a1-qp-mpc-controller_amd")

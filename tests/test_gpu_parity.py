@@ -1,4 +1,6 @@
 """-m gpu: the HIP path, called through the C ABI (liba1mpc.so), against the oracle on identical inputs."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -35,7 +37,8 @@ def test_randomized_configs_default_settings(pkg, oracle, scen, name, gen, n):
     with _engine(pkg, sc, n, warm_start=0) as eng:
         out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
     ref = oracle_batch(oracle, sc)
-    r = compare(out, ref, resolve=exact_resolver(oracle, sc))   # (a QP with another iteration count is checked against the exact-mode optimum, not dropped)
+    # (a QP with another iteration count is checked against the exact-mode optimum, not dropped)
+    r = compare(out, ref, resolve=exact_resolver(oracle, sc))
     print(name, r, "iters", np.unique(out["iters"], return_counts=True))
 
 
@@ -83,7 +86,8 @@ def test_all_contact_patterns(pkg, oracle, scen):
         out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
     compare(out, oracle_batch(oracle, sc), min_same=1.0)
     assert np.abs(out["grf"][0]).max() < 1e-3
-    assert (np.abs(out["u"].reshape(16, -1, 4, 3)[:, 0][sc["contact"] == 0]) < 0.1).all()  # OSQP-default accuracy on the swing-leg equalities
+    # OSQP-default accuracy on the swing-leg equalities
+    assert (np.abs(out["u"].reshape(16, -1, 4, 3)[:, 0][sc["contact"] == 0]) < 0.1).all()
 
 
 def test_warm_started_tick_sequence(pkg, oracle, scen):
@@ -155,8 +159,10 @@ def test_size_independent_properties_full_batch(pkg, scen):
                                            ("config3_random_flat", 1500, True),   # fused kernel, two QPs per wave
                                            ("config3_random_flat", 3000, True),   # split pipeline, longest-first queue
                                            ("config3_random_flat", 3000, False),  # split pipeline, index-order queue
-                                           ("config4_random_h16", 700, True), ("config5_divergent", 300, True),   # fused and latency kernels' quads of rows
-                                           ("config4_random_h16", 1500, True), ("config5_divergent", 1300, True)])   # persistent quads (CU-wide at h = 16) vs fused quads
+                                           # fused and latency kernels' quads of rows
+                                           ("config4_random_h16", 700, True), ("config5_divergent", 300, True),
+                                           # persistent quads (CU-wide at h = 16) vs fused quads
+                                           ("config4_random_h16", 1500, True), ("config5_divergent", 1300, True)])
 def test_result_does_not_depend_on_position_or_history(pkg, scen, gen, n, history):
     """Every kernel path: a QP's result is bit for bit the same wherever it sits in the batch, whatever its wave-mates are and
     whatever the row solved before (another batch in between).  A violated DPP read hazard or a stale LDS word shows up here."""
@@ -240,9 +246,11 @@ def test_device_pointer_entry_and_batched_warm_start(pkg, oracle, scen):
     from helpers import oracle_params
     pr = oracle_params(oracle, sc); so = oracle.default_settings(warm_start=1)
     for b in range(0, n, 7):
-        r1 = oracle.mpc_solve(pr, so, sc["x0"][b], sc["xref"][b], sc["R"][b], sc["foot"][b], sc["contact"][b], warm_x=np.zeros(120), warm_y=np.zeros(200))
+        r1 = oracle.mpc_solve(pr, so, sc["x0"][b], sc["xref"][b], sc["R"][b], sc["foot"][b], sc["contact"][b], warm_x=np.zeros(120),
+                warm_y=np.zeros(200))
         assert host1["iters"][b] == r1["info"].iters and np.abs(host1["u"][b] - r1["u"]).max() < TOL_FORCE_N
-        r2 = oracle.mpc_solve(pr, so, sc["x0"][b], sc["xref"][b], sc["R"][b], sc["foot"][b], sc["contact"][b], warm_x=r1["warm_x"], warm_y=r1["warm_y"],
+        r2 = oracle.mpc_solve(pr, so, sc["x0"][b], sc["xref"][b], sc["R"][b], sc["foot"][b], sc["contact"][b], warm_x=r1["warm_x"],
+                warm_y=r1["warm_y"],
                               warm_rho=r1["rho"])
         assert int(it[b]) == r2["info"].iters, (b, int(it[b]), r2["info"].iters)
         assert np.abs(u[b].cpu().numpy() - r2["u"]).max() < TOL_FORCE_N
@@ -250,7 +258,8 @@ def test_device_pointer_entry_and_batched_warm_start(pkg, oracle, scen):
 
 SETTINGS_CASES = [dict(scaling=0), dict(scaling=3), dict(alpha=1.0), dict(alpha=1.8), dict(rho=1.0), dict(rho=0.01, adaptive_rho=0),
                   dict(check_termination=10), dict(adaptive_rho_interval=50), dict(check_termination=10, adaptive_rho_interval=35),
-                  dict(max_iter=30), dict(sigma=1e-4), dict(adaptive_rho_interval=0), dict(adaptive_rho_interval=0, check_termination=10), dict(eps_abs=1e-5, eps_rel=1e-5), dict(adaptive_rho_tolerance=2.0)]
+                  dict(max_iter=30), dict(sigma=1e-4), dict(adaptive_rho_interval=0), dict(adaptive_rho_interval=0, check_termination=10),
+                          dict(eps_abs=1e-5, eps_rel=1e-5), dict(adaptive_rho_tolerance=2.0)]
 
 
 @pytest.mark.parametrize("over", SETTINGS_CASES, ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
@@ -265,22 +274,54 @@ def test_non_default_osqp_settings(pkg, oracle, scen, over):
 
 @pytest.mark.parametrize("seed", range(100, 112))
 def test_random_setting_combinations(pkg, oracle, scen, seed):
-    """several knobs away from their defaults at once (the draws of tests/tools/soak_settings.py, seeds 100-111: OSQP settings x friction / force limits x horizon),
-    64 QPs each: same iteration count and status on every QP, forces within the bar.  (The soak's 660 combinations are in profiles/r03_settings_soak*.txt; the handful
-    that exceed the bar are combinations on which the oracle's own two linear-system back ends part by more, profiles/r03_settings_soaks_second_round.txt.)"""
+    """several knobs away from their defaults at once (the draws of tests/tools/soak_settings.py, seeds 100-111: OSQP settings x friction /
+    force limits x horizon),
+    64 QPs each: same iteration count and status on every QP, forces within the bar.  (The soak's 660 combinations are in
+    profiles/r03_settings_soak*.txt; the handful
+    that exceed the bar are combinations on which the oracle's own two linear-system back ends part by more,
+    profiles/r03_settings_soaks_second_round.txt.)"""
     rng = np.random.default_rng(seed)
     H = int(rng.choice([10, 10, 16, 20]))
-    over = dict(scaling=int(rng.choice([0, 2, 10, 10, 15])), alpha=float(rng.choice([1.0, 1.6, 1.6, rng.uniform(1.05, 1.9)])), rho=float(10 ** rng.uniform(-2, 0.3)),
-                sigma=float(10 ** rng.uniform(-7, -4)), check_termination=int(rng.choice([5, 10, 25, 25, 40])), adaptive_rho=int(rng.choice([0, 1, 1, 1])),
-                adaptive_rho_interval=int(rng.choice([0, 10, 25, 35, 50, 100])), adaptive_rho_tolerance=float(rng.choice([1.5, 2.0, 5.0, 5.0])),
+    over = dict(scaling=int(rng.choice([0, 2, 10, 10, 15])), alpha=float(rng.choice([1.0, 1.6, 1.6, rng.uniform(1.05, 1.9)])),
+            rho=float(10 ** rng.uniform(-2, 0.3)),
+                sigma=float(10 ** rng.uniform(-7, -4)), check_termination=int(rng.choice([5, 10, 25, 25, 40])),
+                        adaptive_rho=int(rng.choice([0, 1, 1, 1])),
+                adaptive_rho_interval=int(rng.choice([0, 10, 25, 35, 50, 100])),
+                        adaptive_rho_tolerance=float(rng.choice([1.5, 2.0, 5.0, 5.0])),
                 eps_abs=float(rng.choice([1e-3, 1e-3, 1e-4, 1e-5])), max_iter=int(rng.choice([60, 400, 4000, 4000])))
     over["eps_rel"] = over["eps_abs"]
     gen = {10: scen.config3_random_flat, 16: scen.config4_random_h16, 20: scen.config5_divergent}[H]
     sc = gen(nb=64, seed=7000 + seed)
-    sc["params"] = dict(sc["params"], mu=float(rng.choice([0.3, 0.3, 0.6, 0.15])), fz_min=float(rng.choice([0.0, 0.0, 0.0, 5.0])), fz_max=float(rng.choice([180.0, 180.0, 120.0, 60.0])))
+    sc["params"] = dict(sc["params"], mu=float(rng.choice([0.3, 0.3, 0.6, 0.15])), fz_min=float(rng.choice([0.0, 0.0, 0.0, 5.0])),
+            fz_max=float(rng.choice([180.0, 180.0, 120.0, 60.0])))
     with _engine(pkg, sc, 64, warm_start=0, **over) as eng:
         out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
     compare(out, oracle_batch(oracle, sc, settings=oracle.default_settings(**over)), min_same=1.0)
+
+
+def test_infeasible_configuration_is_refused_where_osqp_would_report_primal_infeasibility(pkg, oracle, scen):
+    """fz_max < 0 puts every stance leg's fz <= fz_max < 0 against a pyramid that asks fz >= 0.  The oracle -- which evaluates OSQP's certificates
+    (auxil.c is_primal_infeasible) -- answers PRIMAL_INFEASIBLE (-3) and zero forces for every QP; the engine, which does not evaluate them, refuses the configuration
+    with A1MPC_ERR_INVALID_ARGUMENT at a1mpc_create and at a1mpc_update_config (include/a1mpc.h: the statuses -3 / -4 are unreachable on every accepted
+    configuration), and a refused update leaves the live handle exactly as it was."""
+    sc = scen.config3_random_flat(nb=16)
+    bad = dict(sc["params"], fz_min=-10.0, fz_max=-5.0)
+    pr = oracle.mpc_params(10, bad["dt"], bad["mu"], bad["fz_min"], bad["fz_max"], bad["q"], bad["r"], bad["mass"], bad["inertia"])
+    ref = oracle.mpc_solve_batch(pr, oracle.default_settings(), sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+    stance = sc["contact"].any(axis=1)
+    assert (ref["status"][stance] == -3).all() and not ref["grf"][stance].any()      # what the reference's OSQP would conclude
+    with pytest.raises(pkg.A1MpcError, match="fz_max"):
+        pkg.Engine(pkg.make_config(bad, 10), 16, 0)
+    with _engine(pkg, sc, 16, warm_start=0) as eng:
+        a = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+        for over in (dict(fz_min=-10.0, fz_max=-5.0), dict(fz_min=200.0), dict(mu=-0.3), dict(mass=float("nan"))):
+            with pytest.raises(pkg.A1MpcError):
+                eng.update_config(pkg.make_config(dict(sc["params"], **over), 10, warm_start=0))
+        b = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"]) and (b["status"] == 1).all()
+        qp = pkg.BalanceConfig(); eng.lib.a1mpc_default_balance_config(C.byref(qp)); qp.F_max = -1.0
+        with pytest.raises(pkg.A1MpcError):
+            eng.balance_solve(np.zeros((1, 6)), np.eye(3).reshape(1, 9), np.eye(3).reshape(1, 9), np.zeros((1, 12)), np.ones((1, 4), np.uint8), qp=qp)
 
 
 @pytest.mark.parametrize("mu,fz_min,fz_max", [(0.6, 0.0, 120.0), (0.3, 5.0, 180.0), (0.15, 0.0, 60.0)])
@@ -322,7 +363,8 @@ def test_update_plan_N2a_bit_exact(pkg, oracle, scen):
         assert (out["gait_counter"][b] == g2).all() and (out["plan_contacts"][b] == pc).all()
         assert (out["foot_pos_target_rel"][b] == rel).all() and (out["foot_pos_target_abs"][b] == ab).all()
         assert (out["foot_pos_target_world"][b] == wo).all()
-    assert (out["plan_contacts"][mm == 0] == 1).all() and (np.abs(out["foot_pos_target_rel"].reshape(n, 4, 3)[:, :, 0] - [0.17, 0.17, -0.17, -0.17]) <= 0.1 + 1e-15).all()
+    assert (out["plan_contacts"][mm == 0] == 1).all() and (np.abs(out["foot_pos_target_rel"].reshape(n, 4, 3)[:, :, 0] - [0.17, 0.17,
+            -0.17, -0.17]) <= 0.1 + 1e-15).all()
 
 
 def test_joint_torques_N3_bit_exact(pkg, oracle, scen):
@@ -344,7 +386,8 @@ def test_joint_torques_N3_bit_exact(pkg, oracle, scen):
         assert (tau[b] == ref).all(), b
     ref5 = oracle.joint_torques(1, c[5], Jb[5].reshape(36), grf[5], fk[5], km, tg[5], prev[5])
     assert (tau[act == 0] == 0).all() and np.array_equal(tau[5], ref5)
-    assert (tau[5, 3:5] == prev[5, 3:5]).all() and np.isinf(tau[5, 5])  # 0*inf = NaN is guarded (:314-317), the infinity is not -- like the reference
+    # 0*inf = NaN is guarded (:314-317), the infinity is not -- like the reference
+    assert (tau[5, 3:5] == prev[5, 3:5]).all() and np.isinf(tau[5, 5])
 
 
 def test_queue_order_does_not_change_results(pkg, scen):
@@ -363,7 +406,8 @@ def test_queue_order_does_not_change_results(pkg, scen):
 
 def test_random_batches_statistics(pkg, oracle, scen):
     """Arbitrary random batches (seeds that no other test uses): identical iteration counts and statuses, and the stated distribution of
-    ||u_gpu - u_oracle||_inf -- median at rounding level, 99.9 % below 1e-7 N, every QP below 1e-5 N.  These batches contain the QPs whose rho
+    ||u_gpu - u_oracle||_inf -- median at rounding level, 99.9 % below 1e-7 N, every QP below 1e-5 N.  These batches contain the QPs whose
+    rho
     estimate is taken at rho = RHO_MIN, where the dual residual must be carried through the x-update identity."""
     from helpers import TOL_FORCE_ANY_BATCH_N
     worst = 0.0
@@ -414,7 +458,8 @@ def test_contact_terrain_N2b_sequence(pkg, oracle, scen):
 
 
 def test_contact_terrain_N2b_partial_wavefront_and_spare_capacity(pkg, oracle, scen):
-    """N2b with n = 70 robots on a handle created for 200: the second wavefront of the launch stages 6 records (the record copy is cut at n, the ring regions start
+    """N2b with n = 70 robots on a handle created for 200: the second wavefront of the launch stages 6 records (the record copy is cut at
+    n, the ring regions start
     behind max_batch records) -- every robot against the oracle over a leg-window wrap."""
     rng = np.random.default_rng(77)
     n, cap, ticks = 70, 200, 90
@@ -451,7 +496,8 @@ def test_swing_legs_N4a_sequence(pkg, oracle, scen):
             for b in range(0, n, 11):
                 c_o, k_o = oracle.swing_legs(Rz[b], foot[b], gcs[b], tgt[b], st_o[0][b], st_o[1][b], st_o[2][b])
                 assert (cur[b] == c_o).all() and (st_g[0][b] == st_o[0][b]).all() and (st_g[1][b] == st_o[1][b]).all(), (t, b)
-                assert np.abs(st_g[2][b] - st_o[2][b]).max() <= 1e-15 and np.abs(kin[b] - k_o).max() <= 1e-9, (t, b, np.abs(kin[b] - k_o).max())
+                assert np.abs(st_g[2][b] - st_o[2][b]).max() <= 1e-15 and np.abs(kin[b] - k_o).max() <= 1e-9, (t, b,
+                        np.abs(kin[b] - k_o).max())
                 st_o[2][b] = st_g[2][b]  # keep the two state copies from drifting apart by the curve's ulp differences
 
 
@@ -463,19 +509,24 @@ def test_control_tick_chain(pkg, oracle, scen):
     n, ticks, h = 48, 16, 10
     P = scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS
     cfg = pkg.make_config(P, h, warm_start=0)
-    pr = oracle.mpc_params(h, P["dt"], P["mu"], P["fz_min"], P["fz_max"], P["q"], P["r"], P["mass"], P["inertia"]); st = oracle.default_settings()
+    pr = oracle.mpc_params(h, P["dt"], P["mu"], P["fz_min"], P["fz_max"], P["q"], P["r"], P["mass"],
+            P["inertia"]); st = oracle.default_settings()
     dfp = np.array([0.17, 0.15, -0.35, 0.17, -0.15, -0.35, -0.17, 0.15, -0.35, -0.17, -0.15, -0.35]); gp = oracle.gait_params(dfp)
     km = np.array([0.1, 0.1, 0.04])
-    G = dict(gc=np.tile([0.0, 120.0, 120.0, 0.0], (n, 1)), start=np.zeros((n, 12)), rl=np.tile(dfp, (n, 1)), tl=np.tile(dfp, (n, 1)), pitch=np.zeros(n), tau=np.zeros((n, 12)))
+    G = dict(gc=np.tile([0.0, 120.0, 120.0, 0.0], (n, 1)), start=np.zeros((n, 12)), rl=np.tile(dfp, (n, 1)), tl=np.tile(dfp, (n, 1)),
+            pitch=np.zeros(n), tau=np.zeros((n, 12)))
     O = dict(gc=G["gc"].copy(), start=np.zeros((n, 12)), rl=G["rl"].copy(), tl=G["tl"].copy(), pitch=np.zeros(n), tau=np.zeros((n, 12)),
              ct=[oracle.contact_state() for _ in range(n)])
     worst = 0.0
     with pkg.Engine(cfg, n, 0) as eng:
         for t in range(ticks):
             # synthetic sensors of this tick
-            eul = rng.normal(0, 0.05, (n, 3)); eul[:, 2] = rng.uniform(-1, 1, n); pos = np.c_[rng.normal(0, 1, (n, 2)), 0.3 + rng.normal(0, 0.01, n)]
-            w = rng.normal(0, 0.3, (n, 3)); v = rng.normal(0, 0.3, (n, 3)); vd = np.c_[rng.uniform(-0.5, 0.5, (n, 2)), np.zeros(n)]; wd = np.c_[np.zeros((n, 2)), rng.uniform(-0.5, 0.5, n)]
-            R = scen.rot_zyx(eul[:, 0], eul[:, 1], eul[:, 2]).reshape(n, 9); Rz = scen.rot_zyx(0 * eul[:, 0], 0 * eul[:, 0], eul[:, 2]).reshape(n, 9)
+            eul = rng.normal(0, 0.05, (n, 3)); eul[:, 2] = rng.uniform(-1, 1, n); pos = np.c_[rng.normal(0, 1, (n, 2)),
+                    0.3 + rng.normal(0, 0.01, n)]
+            w = rng.normal(0, 0.3, (n, 3)); v = rng.normal(0, 0.3, (n, 3)); vd = np.c_[rng.uniform(-0.5, 0.5, (n, 2)),
+                    np.zeros(n)]; wd = np.c_[np.zeros((n, 2)), rng.uniform(-0.5, 0.5, n)]
+            R = scen.rot_zyx(eul[:, 0], eul[:, 1], eul[:, 2]).reshape(n, 9); Rz = scen.rot_zyx(0 * eul[:, 0], 0 * eul[:, 0],
+                    eul[:, 2]).reshape(n, 9)
             foot_rel = dfp + rng.normal(0, 0.02, (n, 12))
             foot_abs = np.einsum("nij,nlj->nli", R.reshape(n, 3, 3), foot_rel.reshape(n, 4, 3)).reshape(n, 12)
             ff = rng.uniform(0, 80, (n, 4)); Jb = rng.normal(0, 0.2, (n, 36)); Jb[:, [0, 4, 8, 9, 13, 17, 18, 22, 26, 27, 31, 35]] += 0.3
@@ -483,7 +534,8 @@ def test_control_tick_chain(pkg, oracle, scen):
             # ---- device chain
             up = eng.update_plan(mm, G["gc"], spd, v, Rz, R, pos, vd); G["gc"] = up["gait_counter"]
             cur, kin = eng.swing_legs(Rz, foot_abs, G["gc"], up["foot_pos_target_rel"], G["start"], G["rl"], G["tl"])
-            ctr = eng.contact_terrain(G["gc"], up["plan_contacts"], ff, foot_abs, pos[:, 2], G["pitch"]); G["pitch"] = ctr["root_euler_d_pitch"]
+            ctr = eng.contact_terrain(G["gc"], up["plan_contacts"], ff, foot_abs, pos[:, 2],
+                    G["pitch"]); G["pitch"] = ctr["root_euler_d_pitch"]
             eul_d = np.c_[np.zeros(n), G["pitch"], eul[:, 2]]
             tick = scen.pack_tick(eul, pos, w, v, eul_d, vd, wd, np.full(n, 0.3))
             sol = eng.solve_ticks(tick, R, foot_abs, ctr["contacts"])
@@ -524,22 +576,33 @@ def test_leg_state_N4b(pkg, oracle, scen):
 
 def test_ekf_N4c_sequence(pkg, oracle, scen):
     """A1BasicEKF for 200 robots over 80 ticks, device-resident filter state vs the oracle's dense restatement
-    (S/A1BasicEKF.cpp:54-163).  Same operation order and no contraction: the estimates are compared bit for bit."""
+    (S/A1BasicEKF.cpp:54-163).  Two checks (the oracle must not move with the kernel): (i) against the PINNED restatement --
+    multiply + add, what
+    tests/test_ref_pin.py holds to the reference's compiled source -- within 1e-11: the kernel accumulates its four dense products by FMA,
+    a rounding per term
+    of 18- and 28-term dot products on a contracting filter (the CPU suite measures 1.1e-13 between the two arithmetics over 200 ticks);
+    (ii) bit for bit
+    against the oracle's FMA variant of the same products (same operation order: what pins the kernel's lane map and elimination)."""
     rng = np.random.default_rng(51)
     n, ticks = 200, 80
     cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
-    states = [oracle.ekf_state() for _ in range(n)]
+    states = [oracle.ekf_state() for _ in range(n)]; pinned = [oracle.ekf_state() for _ in range(n)]
     base = np.array([0.18, 0.13, -0.3, 0.18, -0.13, -0.3, -0.18, 0.13, -0.3, -0.18, -0.13, -0.3])
     with pkg.Engine(cfg, n, 0) as eng:
         for t in range(ticks):
             mm = np.where(rng.random(n) < 0.8, 1, 0).astype(np.uint8) if t > 3 else np.zeros(n, np.uint8)
             yaw = rng.uniform(-3, 3, n); eul = rng.normal(0, 0.05, (n, 2)); R = scen.rot_zyx(eul[:, 0], eul[:, 1], yaw).reshape(n, 9)
-            fk = base + rng.normal(0, 0.01, (n, 12)); fv = rng.normal(0, 0.3, (n, 12)); acc = np.array([0.0, 0.0, 9.81]) + rng.normal(0, 0.3, (n, 3))
+            fk = base + rng.normal(0, 0.01, (n, 12)); fv = rng.normal(0, 0.3, (n, 12)); acc = np.array([0.0, 0.0, 9.81]) + rng.normal(0,
+                    0.3, (n, 3))
             w = rng.normal(0, 0.3, (n, 3)); ff = rng.uniform(0, 160, (n, 4))
             pos, vel, ec = eng.ekf_update(0.0025, mm, ff, R, acc, w, fk, fv)
             for b in range(0, n, 3):
-                p_o, v_o, e_o = oracle.ekf_step(states[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b])
-                assert np.array_equal(pos[b], p_o) and np.array_equal(vel[b], v_o) and (ec[b] == e_o).all(), (t, b, pos[b] - p_o, vel[b] - v_o)
+                p_o, v_o, e_o = oracle.ekf_step(states[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b], fma=True)
+                assert np.array_equal(pos[b], p_o) and np.array_equal(vel[b], v_o) and (ec[b] == e_o).all(), (t, b, pos[b] - p_o,
+                        vel[b] - v_o)
+                p_p, v_p, e_p = oracle.ekf_step(pinned[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b])
+                assert max(np.abs(pos[b] - p_p).max(), np.abs(vel[b] - v_p).max()) <= 1e-11 and (ec[b] == e_p).all(), (t, b, pos[b] - p_p,
+                        vel[b] - v_p)
 
 
 def test_device_pointer_tick_matches_host_pointer_tick(pkg, scen):
@@ -555,54 +618,76 @@ def test_device_pointer_tick_matches_host_pointer_tick(pkg, scen):
     dev = torch.device("cuda", 0)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     ptr = lambda t: C.c_void_p(t.data_ptr())
-    km = np.array([0.1, 0.1, 0.04]); kp = np.array([300.0, 400.0, 400.0]); kd = np.array([8.0, 8.0, 8.0]); dp_ = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    km = np.array([0.1, 0.1, 0.04]); kp = np.array([300.0, 400.0, 400.0]); kd = np.array([8.0, 8.0,
+            8.0]); dp_ = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     with pkg.Engine(cfg, n, 0) as eh, pkg.Engine(cfg, n, 0) as ed:
-        gait = pkg.engine.GaitConfig(); ed.lib.a1mpc_default_gait_config(C.byref(gait)); ccfg = pkg.engine.ContactConfig(); ed.lib.a1mpc_default_contact_config(C.byref(ccfg))
+        gait = pkg.engine.GaitConfig(); ed.lib.a1mpc_default_gait_config(C.byref(gait)); ccfg = pkg.engine.ContactConfig(
+                ); ed.lib.a1mpc_default_contact_config(C.byref(ccfg))
         fix = np.ascontiguousarray(eh.A1_RHO_FIX); opt = np.zeros((4, 3))
-        st_h = dict(gc=np.tile([0.0, 120.0, 120.0, 0.0], (n, 1)), start=np.zeros((n, 12)), rl=np.zeros((n, 12)), tl=np.zeros((n, 12)), pitch=np.zeros(n), tau=np.zeros((n, 12)))
+        st_h = dict(gc=np.tile([0.0, 120.0, 120.0, 0.0], (n, 1)), start=np.zeros((n, 12)), rl=np.zeros((n, 12)), tl=np.zeros((n, 12)),
+                pitch=np.zeros(n), tau=np.zeros((n, 12)))
         st_d = {k: T(v) for k, v in st_h.items()}
         st = torch.cuda.Stream(device=dev); sp = C.c_void_p(st.cuda_stream)
         for t in range(3):
-            q = rng.uniform(-0.8, 0.8, (n, 12)); qd = rng.normal(0, 1, (n, 12)); eul = rng.normal(0, 0.05, (n, 3)); eul[:, 2] = rng.uniform(-1, 1, n)
-            R = scen.rot_zyx(eul[:, 0], eul[:, 1], eul[:, 2]).reshape(n, 9); Rz = scen.rot_zyx(0 * eul[:, 0], 0 * eul[:, 0], eul[:, 2]).reshape(n, 9)
-            acc = np.array([0, 0, 9.81]) + rng.normal(0, 0.2, (n, 3)); w = rng.normal(0, 0.2, (n, 3)); ff = rng.uniform(0, 120, (n, 4)); mm = np.ones(n, np.uint8)
-            vd = np.c_[rng.uniform(-0.4, 0.4, (n, 2)), np.zeros(n)]; wd = np.c_[np.zeros((n, 2)), rng.uniform(-0.4, 0.4, n)]; spd = np.full((n, 4), 2.0); tg = rng.normal(0, 0.5, (n, 12))
+            q = rng.uniform(-0.8, 0.8, (n, 12)); qd = rng.normal(0, 1, (n, 12)); eul = rng.normal(0, 0.05, (n, 3)); eul[:,
+                    2] = rng.uniform(-1, 1, n)
+            R = scen.rot_zyx(eul[:, 0], eul[:, 1], eul[:, 2]).reshape(n, 9); Rz = scen.rot_zyx(0 * eul[:, 0], 0 * eul[:, 0],
+                    eul[:, 2]).reshape(n, 9)
+            acc = np.array([0, 0, 9.81]) + rng.normal(0, 0.2, (n, 3)); w = rng.normal(0, 0.2, (n, 3)); ff = rng.uniform(0, 120,
+                    (n, 4)); mm = np.ones(n, np.uint8)
+            vd = np.c_[rng.uniform(-0.4, 0.4, (n, 2)), np.zeros(n)]; wd = np.c_[np.zeros((n, 2)),
+                    rng.uniform(-0.4, 0.4, n)]; spd = np.full((n, 4), 2.0); tg = rng.normal(0, 0.5, (n, 12))
             act = np.ones(n, np.uint8)
             # ---- host-pointer chain
             leg = eh.leg_state(q, qd, R, np.zeros((n, 3)), np.zeros((n, 3)))
             pos, vel, ec = eh.ekf_update(0.0025, mm, ff, R, acc, w, leg["foot_pos_rel"], leg["foot_vel_rel"])
             up = eh.update_plan(mm, st_h["gc"], spd, vel, Rz, R, pos, vd); st_h["gc"] = up["gait_counter"]
             cur, kin = eh.swing_legs(Rz, leg["foot_pos_abs"], st_h["gc"], up["foot_pos_target_rel"], st_h["start"], st_h["rl"], st_h["tl"])
-            ctr = eh.contact_terrain(st_h["gc"], up["plan_contacts"], ff, leg["foot_pos_abs"], pos[:, 2], st_h["pitch"]); st_h["pitch"] = ctr["root_euler_d_pitch"]
+            ctr = eh.contact_terrain(st_h["gc"], up["plan_contacts"], ff, leg["foot_pos_abs"], pos[:, 2],
+                    st_h["pitch"]); st_h["pitch"] = ctr["root_euler_d_pitch"]
             tick = scen.pack_tick(eul, pos, w, vel, np.c_[np.zeros(n), st_h["pitch"], eul[:, 2]], vd, wd, np.full(n, 0.3))
             sol = eh.solve_ticks(tick, R, leg["foot_pos_abs"], ctr["contacts"])
             st_h["tau"] = eh.joint_torques(act, ctr["contacts"], leg["Jb"], sol["grf"], kin, km, tg, st_h["tau"])
             # ---- device-pointer chain (same inputs uploaded once per tick, everything else stays on the GPU)
             with torch.cuda.stream(st):
-                d = {k: T(v) for k, v in dict(q=q, qd=qd, R=R, Rz=Rz, acc=acc, w=w, ff=ff, mm=mm, vd=vd, wd=wd, spd=spd, tg=tg, act=act, eul=eul, z0=np.zeros((n, 3))).items()}
-                o = {k: torch.zeros((n, m), dtype=torch.float64, device=dev) for k, m in dict(rel=12, Jb=36, vrel=12, pabs=12, vabs=12, pw=12, vw=12, pos=3, vel=3, trel=12, tabs=12,
-                                                                                             tworld=12, cur=12, kin=12, rec=12, grf=12).items()}
-                ec_d = torch.zeros((n, 4), dtype=torch.uint8, device=dev); pc_d = torch.zeros((n, 4), dtype=torch.uint8, device=dev); ct_d = torch.zeros((n, 4), dtype=torch.uint8, device=dev)
-                ta_d = torch.zeros(n, dtype=torch.float64, device=dev); it_d = torch.zeros(n, dtype=torch.int32, device=dev); stt_d = torch.zeros(n, dtype=torch.int32, device=dev)
+                d = {k: T(v) for k, v in dict(q=q, qd=qd, R=R, Rz=Rz, acc=acc, w=w, ff=ff, mm=mm, vd=vd, wd=wd, spd=spd, tg=tg, act=act,
+                        eul=eul, z0=np.zeros((n, 3))).items()}
+                o = {k: torch.zeros((n, m), dtype=torch.float64, device=dev) for k,
+                        m in dict(rel=12, Jb=36, vrel=12, pabs=12, vabs=12, pw=12, vw=12, pos=3, vel=3, trel=12, tabs=12,
+                                                                                             tworld=12, cur=12, kin=12, rec=12,
+                                                                                                     grf=12).items()}
+                ec_d = torch.zeros((n, 4), dtype=torch.uint8, device=dev); pc_d = torch.zeros((n, 4), dtype=torch.uint8,
+                        device=dev); ct_d = torch.zeros((n, 4), dtype=torch.uint8, device=dev)
+                ta_d = torch.zeros(n, dtype=torch.float64, device=dev); it_d = torch.zeros(n, dtype=torch.int32,
+                        device=dev); stt_d = torch.zeros(n, dtype=torch.int32, device=dev)
                 L = ed.lib
-                assert L.a1mpc_leg_state_batch_device(ed._h, n, ptr(d["q"]), ptr(d["qd"]), ptr(d["R"]), ptr(d["z0"]), ptr(d["z0"]), dp_(fix), dp_(opt), ptr(o["rel"]), ptr(o["Jb"]),
+                assert L.a1mpc_leg_state_batch_device(ed._h, n, ptr(d["q"]), ptr(d["qd"]), ptr(d["R"]), ptr(d["z0"]), ptr(d["z0"]),
+                        dp_(fix), dp_(opt), ptr(o["rel"]), ptr(o["Jb"]),
                                                       ptr(o["vrel"]), ptr(o["pabs"]), ptr(o["vabs"]), ptr(o["pw"]), ptr(o["vw"]), sp) == 0
-                assert L.a1mpc_ekf_update_batch_device(ed._h, n, 0.0025, 1, ptr(d["mm"]), ptr(d["ff"]), ptr(d["R"]), ptr(d["acc"]), ptr(d["w"]), ptr(o["rel"]), ptr(o["vrel"]),
+                assert L.a1mpc_ekf_update_batch_device(ed._h, n, 0.0025, 1, ptr(d["mm"]), ptr(d["ff"]), ptr(d["R"]), ptr(d["acc"]),
+                        ptr(d["w"]), ptr(o["rel"]), ptr(o["vrel"]),
                                                        ptr(o["pos"]), ptr(o["vel"]), ptr(ec_d), sp) == 0
-                assert L.a1mpc_update_plan_batch_device(ed._h, C.byref(gait), n, ptr(d["mm"]), ptr(st_d["gc"]), ptr(d["spd"]), ptr(o["vel"]), ptr(d["Rz"]), ptr(d["R"]), ptr(o["pos"]),
+                assert L.a1mpc_update_plan_batch_device(ed._h, C.byref(gait), n, ptr(d["mm"]), ptr(st_d["gc"]), ptr(d["spd"]),
+                        ptr(o["vel"]), ptr(d["Rz"]), ptr(d["R"]), ptr(o["pos"]),
                                                         ptr(d["vd"]), ptr(pc_d), ptr(o["trel"]), ptr(o["tabs"]), ptr(o["tworld"]), sp) == 0
-                assert L.a1mpc_swing_legs_batch_device(ed._h, n, 120.0, 0.0025, ptr(d["Rz"]), ptr(o["pabs"]), ptr(st_d["gc"]), ptr(o["trel"]), dp_(kp), dp_(kd), ptr(st_d["start"]),
+                assert L.a1mpc_swing_legs_batch_device(ed._h, n, 120.0, 0.0025, ptr(d["Rz"]), ptr(o["pabs"]), ptr(st_d["gc"]),
+                        ptr(o["trel"]), dp_(kp), dp_(kd), ptr(st_d["start"]),
                                                        ptr(st_d["rl"]), ptr(st_d["tl"]), ptr(o["cur"]), ptr(o["kin"]), sp) == 0
                 pz = o["pos"][:, 2].contiguous()
-                assert L.a1mpc_contact_terrain_batch_device(ed._h, C.byref(ccfg), n, ptr(st_d["gc"]), ptr(pc_d), ptr(d["ff"]), ptr(o["pabs"]), ptr(pz), ptr(st_d["pitch"]), ptr(ct_d),
+                assert L.a1mpc_contact_terrain_batch_device(ed._h, C.byref(ccfg), n, ptr(st_d["gc"]), ptr(pc_d), ptr(d["ff"]),
+                        ptr(o["pabs"]), ptr(pz), ptr(st_d["pitch"]), ptr(ct_d),
                                                             ptr(o["rec"]), ptr(ta_d), sp) == 0
                 zc = torch.zeros(n, dtype=torch.float64, device=dev)
-                tick_d = torch.cat([d["eul"], o["pos"], d["w"], o["vel"], torch.stack([zc, st_d["pitch"], d["eul"][:, 2]], 1), d["vd"], d["wd"], torch.full((n, 1), 0.3, dtype=torch.float64, device=dev)], 1).contiguous()
-                assert L.a1mpc_solve_batch_ticks_device(ed._h, n, ptr(tick_d), ptr(d["R"]), ptr(o["pabs"]), ptr(ct_d), ptr(o["grf"]), None, ptr(it_d), ptr(stt_d), sp) == 0
-                assert L.a1mpc_joint_torques_batch_device(ed._h, n, ptr(d["act"]), ptr(ct_d), ptr(o["Jb"]), ptr(o["grf"]), ptr(o["kin"]), dp_(km), ptr(d["tg"]), ptr(st_d["tau"]), sp) == 0
+                tick_d = torch.cat([d["eul"], o["pos"], d["w"], o["vel"], torch.stack([zc, st_d["pitch"], d["eul"][:, 2]], 1), d["vd"],
+                        d["wd"], torch.full((n, 1), 0.3, dtype=torch.float64, device=dev)], 1).contiguous()
+                assert L.a1mpc_solve_batch_ticks_device(ed._h, n, ptr(tick_d), ptr(d["R"]), ptr(o["pabs"]), ptr(ct_d), ptr(o["grf"]),
+                        None, ptr(it_d), ptr(stt_d), sp) == 0
+                assert L.a1mpc_joint_torques_batch_device(ed._h, n, ptr(d["act"]), ptr(ct_d), ptr(o["Jb"]), ptr(o["grf"]), ptr(o["kin"]),
+                        dp_(km), ptr(d["tg"]), ptr(st_d["tau"]), sp) == 0
             st.synchronize()
             assert np.array_equal(st_d["tau"].cpu().numpy(), st_h["tau"]), (t, np.abs(st_d["tau"].cpu().numpy() - st_h["tau"]).max())
-            assert np.array_equal(o["pos"].cpu().numpy(), pos) and np.array_equal(ct_d.cpu().numpy(), ctr["contacts"]) and np.array_equal(it_d.cpu().numpy(), sol["iters"])
+            assert np.array_equal(o["pos"].cpu().numpy(), pos) and np.array_equal(ct_d.cpu().numpy(),
+                    ctr["contacts"]) and np.array_equal(it_d.cpu().numpy(), sol["iters"])
 
 
 # ------------------------------------------------------------------------------------------------------------ round 2
@@ -633,11 +718,13 @@ def _strided_inputs(scen, rng, h, nb, feet, cont):
         foot = (sc["foot"].reshape(nb, 1, 4, 3) - vd * p["dt"] * np.arange(h).reshape(1, h, 1, 1) * 40.0).reshape(nb, h * 12); fs = 12
     if cont:
         sw = rng.integers(0, h + 1, (nb, 4)); first = rng.integers(0, 2, (nb, 4))
-        contact = np.where(np.arange(h).reshape(1, h, 1) < sw[:, None, :], first[:, None, :], 1 - first[:, None, :]).astype(np.uint8).reshape(nb, h * 4); cs = 4
+        contact = np.where(np.arange(h).reshape(1, h, 1) < sw[:, None, :], first[:, None, :],
+                1 - first[:, None, :]).astype(np.uint8).reshape(nb, h * 4); cs = 4
     return sc, np.ascontiguousarray(foot), fs, np.ascontiguousarray(contact), cs
 
 
-@pytest.mark.parametrize("h,nb,feet,cont", [(10, 300, True, True), (10, 128, True, False), (10, 128, False, True), (16, 96, True, True), (20, 64, True, True)])
+@pytest.mark.parametrize("h,nb,feet,cont", [(10, 300, True, True), (10, 128, True, False), (10, 128, False, True), (16, 96, True, True),
+        (20, 64, True, True)])
 def test_per_step_feet_and_contact_schedules(pkg, oracle, scen, h, nb, feet, cont):
     """b' (VERDICT r1): a1mpc_solve_batch_strided -- per-step B_d (S/ConvexMpc.h:74 B_mat_d_list, S/test/test_mpc.cpp:106-122) and per-step
     contact schedules -- vs the oracle's strided formation (which oracle/_ref pins to the reference's ConvexMpc for per-step feet)."""
@@ -648,7 +735,8 @@ def test_per_step_feet_and_contact_schedules(pkg, oracle, scen, h, nb, feet, con
         bc = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], sc["foot"], 0, sc["contact"], 0, want_u=True)
         fast = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
     assert np.array_equal(bc["u"], fast["u"]) and np.array_equal(bc["iters"], fast["iters"])   # (0, 0) is the fast path, bit for bit
-    pr = oracle.mpc_params(h, **{k: sc["params"][k] for k in ("dt", "mu", "fz_min", "fz_max", "q", "r", "mass", "inertia")}); st = oracle.default_settings()
+    pr = oracle.mpc_params(h, **{k: sc["params"][k] for k in ("dt", "mu", "fz_min", "fz_max", "q", "r", "mass",
+            "inertia")}); st = oracle.default_settings()
     worst = 0.0
     for b in range(0, nb, 3):
         r = oracle.mpc_solve(pr, st, sc["x0"][b], sc["xref"][b], sc["R"][b], foot[b], contact[b], foot_stride=fs, contact_stride=cs)
@@ -662,18 +750,23 @@ def test_per_step_feet_and_contact_schedules(pkg, oracle, scen, h, nb, feet, con
 
 @pytest.mark.parametrize("h,nb", [(10, 4000), (16, 2100), (20, 1700)])
 def test_general_path_split_pipeline(pkg, oracle, scen, h, nb):
-    """a general-path batch beyond its resident rows runs the general path's own set-up kernel + persistent main / twin pairs on a queue (the hand-off
-    record carries B~w_t of every step): bit for bit the fused general-path kernel (the first 200 QPs solved alone), the oracle's strided formation on a
+    """a general-path batch beyond its resident rows runs the general path's own set-up kernel + persistent main / twin pairs on a queue
+    (the hand-off
+    record carries B~w_t of every step): bit for bit the fused general-path kernel (the first 200 QPs solved alone), the oracle's strided
+    formation on a
     sample, and a re-solve in history order"""
     rng = np.random.default_rng(5000 + h)
     sc, foot, fs, contact, cs = _strided_inputs(scen, rng, h, nb, True, True)
     with _engine(pkg, sc, nb, warm_start=0) as eng:
         out = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, fs, contact, cs, want_u=True)
-        again = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, fs, contact, cs, want_u=True)   # queue now ordered by the first solve's costs
+        # queue now ordered by the first solve's costs
+        again = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, fs, contact, cs, want_u=True)
         small = eng.solve_strided(sc["x0"][:200], sc["xref"][:200], sc["R"][:200], foot[:200], fs, contact[:200], cs, want_u=True)
     assert np.array_equal(out["u"], again["u"]) and np.array_equal(out["iters"], again["iters"])
-    assert np.array_equal(out["u"][:200], small["u"]) and np.array_equal(out["iters"][:200], small["iters"]) and np.array_equal(out["grf"][:200], small["grf"])
-    pr = oracle.mpc_params(h, **{k: sc["params"][k] for k in ("dt", "mu", "fz_min", "fz_max", "q", "r", "mass", "inertia")}); st = oracle.default_settings()
+    assert np.array_equal(out["u"][:200], small["u"]) and np.array_equal(out["iters"][:200],
+            small["iters"]) and np.array_equal(out["grf"][:200], small["grf"])
+    pr = oracle.mpc_params(h, **{k: sc["params"][k] for k in ("dt", "mu", "fz_min", "fz_max", "q", "r", "mass",
+            "inertia")}); st = oracle.default_settings()
     worst = 0.0
     for b in range(0, nb, nb // 50):
         r = oracle.mpc_solve(pr, st, sc["x0"][b], sc["xref"][b], sc["R"][b], foot[b], contact[b], foot_stride=fs, contact_stride=cs)
@@ -684,7 +777,8 @@ def test_general_path_split_pipeline(pkg, oracle, scen, h, nb):
 
 @pytest.mark.parametrize("h,nb", [(10, 4500), (10, 700), (10, 1), (16, 1200), (16, 1500), (20, 2300)])
 def test_contact_schedule_alone_stays_on_the_fast_kernels(pkg, oracle, scen, h, nb):
-    """a per-step contact schedule with step-invariant feet (contact_stride = 4, foot_stride = 0, no yaw_A): the fast kernels take it (set-up
+    """a per-step contact schedule with step-invariant feet (contact_stride = 4, foot_stride = 0, no yaw_A): the fast kernels take it
+    (set-up
     kernel + persistent twin rows, fused kernel, latency kernel by batch size) -- vs the oracle's strided formation on a sample, and vs the
     general path on every QP (a yaw_A equal to the state's yaw forces the general path onto the same QP)."""
     rng = np.random.default_rng(4000 + h + nb)
@@ -694,7 +788,8 @@ def test_contact_schedule_alone_stays_on_the_fast_kernels(pkg, oracle, scen, h, 
         gen = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], sc["foot"], 0, contact, 4, want_u=True, yaw_A=sc["x0"][:, 2].copy())
         ms_fast = None
     assert (out["status"] == 1).all() and np.array_equal(out["iters"], gen["iters"]) and np.abs(out["u"] - gen["u"]).max() <= 1e-7
-    pr = oracle.mpc_params(h, **{k: sc["params"][k] for k in ("dt", "mu", "fz_min", "fz_max", "q", "r", "mass", "inertia")}); st = oracle.default_settings()
+    pr = oracle.mpc_params(h, **{k: sc["params"][k] for k in ("dt", "mu", "fz_min", "fz_max", "q", "r", "mass",
+            "inertia")}); st = oracle.default_settings()
     worst = 0.0
     for b in range(0, nb, max(1, nb // 40)):
         r = oracle.mpc_solve(pr, st, sc["x0"][b], sc["xref"][b], sc["R"][b], sc["foot"][b], contact[b], foot_stride=0, contact_stride=4)
@@ -720,12 +815,14 @@ def test_failed_tick_leaves_a_cold_start_behind(pkg, oracle, scen):
         assert (o1["status"][bad] == -7).all() and (o1["grf"][bad] == 0).all() and (o1["status"][~bad] == 1).all()
         wx, wy, rho = eng.get_warm_start(n)
         assert (wx[bad] == 0).all() and (wy[bad] == 0).all() and np.isfinite(wx).all() and np.isfinite(wy).all()
-        assert np.array_equal(rho[bad], rho0[bad]) and (rho0[bad] > 0).all()    # the failed solve never got to adapt: the rho it was started with stays
+        # the failed solve never got to adapt: the rho it was started with stays
+        assert np.array_equal(rho[bad], rho0[bad]) and (rho0[bad] > 0).all()
         o2 = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
     assert (o2["status"] == 1).all()
     pr = oracle_params(oracle, sc); st = oracle.default_settings(warm_start=1)
     for i in np.flatnonzero(bad):   # cold iterates + the carried rho: the oracle started the same way
-        r = oracle.mpc_solve(pr, st, sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i], warm_x=np.zeros(120), warm_y=np.zeros(200), warm_rho=rho[i])
+        r = oracle.mpc_solve(pr, st, sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i], warm_x=np.zeros(120),
+                warm_y=np.zeros(200), warm_rho=rho[i])
         assert o2["iters"][i] == r["info"].iters and np.abs(o2["u"][i] - r["u"]).max() <= TOL_FORCE_N, i
 
 
@@ -737,7 +834,8 @@ def test_update_config_dt_and_warm_start_io(pkg, oracle, scen):
     p2 = dict(sc["params"], dt=0.004, mass=13.0)
     xr2 = sc["xref"].copy()   # x_ref as the caller builds it with the other dt
     tk = sc["tick"]
-    xr2 = scen.build_reference(10, 0.004, tk[:, 0:3], tk[:, 3:6], sc["R"].reshape(n, 3, 3), tk[:, 12:15], tk[:, 15:18], tk[:, 18:21], tk[:, 21])
+    xr2 = scen.build_reference(10, 0.004, tk[:, 0:3], tk[:, 3:6], sc["R"].reshape(n, 3, 3), tk[:, 12:15], tk[:, 15:18], tk[:, 18:21],
+            tk[:, 21])
     with _engine(pkg, sc, n, warm_start=1) as eng:
         a = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
         wx, wy, rho = eng.get_warm_start(n)
@@ -746,7 +844,8 @@ def test_update_config_dt_and_warm_start_io(pkg, oracle, scen):
     pr = oracle.mpc_params(10, p2["dt"], p2["mu"], p2["fz_min"], p2["fz_max"], p2["q"], p2["r"], p2["mass"], p2["inertia"])
     st = oracle.default_settings(warm_start=1)
     for i in range(0, n, 4):
-        r = oracle.mpc_solve(pr, st, sc["x0"][i], xr2[i], sc["R"][i], sc["foot"][i], sc["contact"][i], warm_x=wx[i], warm_y=wy[i], warm_rho=rho[i])
+        r = oracle.mpc_solve(pr, st, sc["x0"][i], xr2[i], sc["R"][i], sc["foot"][i], sc["contact"][i], warm_x=wx[i], warm_y=wy[i],
+                warm_rho=rho[i])
         assert b["iters"][i] == r["info"].iters and np.abs(b["u"][i] - r["u"]).max() <= TOL_FORCE_N, i
     # a workspace written through the ABI is the one the next solve starts from
     with _engine(pkg, sc, n, warm_start=1) as eng:
@@ -782,7 +881,8 @@ def test_calls_on_different_streams_are_ordered(pkg, scen):
 
 @pytest.mark.parametrize("h", [10, 16, 20])
 def test_gpu_formed_dense_qp_equals_reference_ConvexMpc(pkg, oracle, scen, h):
-    """a1mpc_form_qp_batch (the GPU's implicit Hessian written out entry by entry) vs S/ConvexMpc.cpp compiled verbatim (oracle/_ref), and vs the
+    """a1mpc_form_qp_batch (the GPU's implicit Hessian written out entry by entry) vs S/ConvexMpc.cpp compiled verbatim (oracle/_ref), and
+    vs the
     oracle: P, g, l, u for broadcast and per-step feet / contacts.  This compares the engine's formation with the REFERENCE directly,
     not through iterates."""
     import ref as REF
@@ -800,25 +900,32 @@ def test_gpu_formed_dense_qp_equals_reference_ConvexMpc(pkg, oracle, scen, h):
     rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
     for b in range(nb):
         for out, f, fstr in ((bc, sc["foot"][b], 0), (ps, foot[b], 12)):
-            r = REF.convex_mpc_form(h, p["q"], p["r"], sc["x0"][b][:3], p["mass"], p["inertia"], sc["R"][b], f, sc["contact"][b], sc["x0"][b], sc["xref"][b], p["dt"],
+            r = REF.convex_mpc_form(h, p["q"], p["r"], sc["x0"][b][:3], p["mass"], p["inertia"], sc["R"][b], f, sc["contact"][b],
+                    sc["x0"][b], sc["xref"][b], p["dt"],
                                     foot_stride=fstr)
-            assert rel(out["P"][b], r["P"]) <= 1e-12 and rel(out["g"][b], r["g"]) <= 1e-10, (b, fstr, rel(out["P"][b], r["P"]), rel(out["g"][b], r["g"]))
+            assert rel(out["P"][b], r["P"]) <= 1e-12 and rel(out["g"][b], r["g"]) <= 1e-10, (b, fstr, rel(out["P"][b], r["P"]),
+                    rel(out["g"][b], r["g"]))
             assert np.array_equal(out["l"][b], r["l"]) and np.array_equal(out["u"][b], r["u"])
-        P, g, A, l, u, _ = oracle.mpc_form(pr, sc["x0"][b], sc["xref"][b], sc["R"][b], foot[b], contact[b], foot_stride=12, contact_stride=4)
-        assert rel(pc["P"][b], P) <= 1e-12 and rel(pc["g"][b], g) <= 1e-10 and np.array_equal(pc["l"][b], l) and np.array_equal(pc["u"][b], u)
+        P, g, A, l, u, _ = oracle.mpc_form(pr, sc["x0"][b], sc["xref"][b], sc["R"][b], foot[b], contact[b], foot_stride=12,
+                contact_stride=4)
+        assert rel(pc["P"][b], P) <= 1e-12 and rel(pc["g"][b], g) <= 1e-10 and np.array_equal(pc["l"][b],
+                l) and np.array_equal(pc["u"][b], u)
 
 
 def test_terrain_block_alone(pkg, oracle, scen):
-    """a1mpc_terrain_batch (the terrain block of compute_grf with the caller's foot_pos_recent_contact) vs the full N2b entry fed the same way."""
+    """a1mpc_terrain_batch (the terrain block of compute_grf with the caller's foot_pos_recent_contact)
+    vs the full N2b entry fed the same way."""
     rng = np.random.default_rng(3)
     n = 200
     cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
     base = np.outer([0.2, 0.2, -0.2, -0.2], [1.0, 0.0, 0.3]).reshape(12) + np.outer([1, -1, 1, -1], [0.0, 0.13, 0.0]).reshape(12)
     pitch_a = np.zeros(n); pitch_b = np.zeros(n)
-    gcs = np.tile([0.0, 0.0, 0.0, 0.0], (n, 1)); plan = np.ones((n, 4), np.uint8)     # all feet in contact: every recent-contact filter updates
+    # all feet in contact: every recent-contact filter updates
+    gcs = np.tile([0.0, 0.0, 0.0, 0.0], (n, 1)); plan = np.ones((n, 4), np.uint8)
     with pkg.Engine(cfg, n, 0) as full, pkg.Engine(cfg, n, 0) as only:
         for t in range(130):
-            foot = base + rng.normal(0, 0.03, (n, 12)) + np.tile([0.0, 0.0, -0.3], 4); z = np.where(rng.random(n) < 0.9, 0.3, 0.05); ff = rng.uniform(0, 80, (n, 4))
+            foot = base + rng.normal(0, 0.03, (n, 12)) + np.tile([0.0, 0.0, -0.3], 4); z = np.where(rng.random(n) < 0.9, 0.3,
+                    0.05); ff = rng.uniform(0, 80, (n, 4))
             o = full.contact_terrain(gcs, plan, ff, foot, z, pitch_a); pitch_a = o["root_euler_d_pitch"]
             pitch_b, ta = only.terrain(o["foot_pos_recent_contact"], z, pitch_b)
             assert np.array_equal(ta, o["terrain_angle"]) and np.array_equal(pitch_b, pitch_a), t
@@ -826,8 +933,10 @@ def test_terrain_block_alone(pkg, oracle, scen):
 
 
 def test_native_sharded_handle_two_shards_on_one_gpu(pkg, scen):
-    """a1mpc_sharded_* (SURVEY 8b device = -1, 8e): the batch cut into contiguous shards behind one handle.  The test box has one GPU, so the
-    pinned-copy transport runs two (three) shards on device 0 -- results must equal the single-handle solve bit for bit, ragged sizes included;
+    """a1mpc_sharded_* (SURVEY 8b device = -1, 8e): the batch cut into contiguous shards behind one handle.  The test box has one GPU, so
+    the
+    pinned-copy transport runs two (three) shards on device 0 -- results must equal the single-handle solve bit for bit, ragged sizes
+    included;
     the RCCL transport is created on the one device (communicator set-up, root staging; no peer to talk to)."""
     sc = scen.config3_random_flat(nb=4097)
     cfg = pkg.make_config(sc["params"], 10, warm_start=0)
@@ -838,7 +947,8 @@ def test_native_sharded_handle_two_shards_on_one_gpu(pkg, scen):
             assert sh.info()["n_shards"] == len(devs)
             for n in (4097, 5, 1):
                 out = sh.solve(sc["x0"][:n], sc["xref"][:n], sc["R"][:n], sc["foot"][:n], sc["contact"][:n])
-                assert np.array_equal(out["grf"], ref["grf"][:n]) and np.array_equal(out["iters"], ref["iters"][:n]) and np.array_equal(out["status"], ref["status"][:n]), (devs, n)
+                assert np.array_equal(out["grf"], ref["grf"][:n]) and np.array_equal(out["iters"],
+                        ref["iters"][:n]) and np.array_equal(out["status"], ref["status"][:n]), (devs, n)
     with pkg.ShardedEngine(cfg, 512, devices=None, transport=0) as sh:   # "all visible devices"
         out = sh.solve(sc["x0"][:512], sc["xref"][:512], sc["R"][:512], sc["foot"][:512], sc["contact"][:512])
         assert np.array_equal(out["grf"], ref["grf"][:512])
@@ -862,7 +972,8 @@ def test_stage_split_instrumentation(pkg, scen):
 
 
 def test_general_path_warm_started_sequence_and_device_pointers(pkg, oracle, scen):
-    """The general path carries the OSQP workspace like the fast path (warm-started ticks with per-step feet / contacts vs the oracle chained the
+    """The general path carries the OSQP workspace like the fast path (warm-started ticks with per-step feet / contacts vs the oracle
+    chained the
     same way), and its device-pointer entry gives the host entry's numbers."""
     import ctypes as C
     import torch
@@ -870,33 +981,39 @@ def test_general_path_warm_started_sequence_and_device_pointers(pkg, oracle, sce
     rng = np.random.default_rng(77)
     sc, foot, fs, contact, cs = _strided_inputs(scen, rng, h, nb, True, True)
     p = sc["params"]
-    pr = oracle.mpc_params(h, p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"], p["inertia"]); st = oracle.default_settings(warm_start=1)
+    pr = oracle.mpc_params(h, p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"],
+            p["inertia"]); st = oracle.default_settings(warm_start=1)
     wx = np.zeros((nb, 12 * h)); wy = np.zeros((nb, 20 * h)); rho = np.zeros(nb)
     with _engine(pkg, sc, nb, warm_start=1) as eng:
         for t in range(ticks):
             x0 = sc["x0"].copy(); x0[:, :12] += rng.normal(0, 0.002, (nb, 12)) * t
             out = eng.solve_strided(x0, sc["xref"], sc["R"], foot, fs, contact, cs, want_u=True)
             for b in range(0, nb, 5):
-                r = oracle.mpc_solve(pr, st, x0[b], sc["xref"][b], sc["R"][b], foot[b], contact[b], warm_x=wx[b], warm_y=wy[b], warm_rho=rho[b], foot_stride=fs, contact_stride=cs)
+                r = oracle.mpc_solve(pr, st, x0[b], sc["xref"][b], sc["R"][b], foot[b], contact[b], warm_x=wx[b], warm_y=wy[b],
+                        warm_rho=rho[b], foot_stride=fs, contact_stride=cs)
                 wx[b], wy[b], rho[b] = r["warm_x"], r["warm_y"], r["rho"]
                 assert out["iters"][b] == r["info"].iters, (t, b, out["iters"][b], r["info"].iters)
                 assert np.abs(out["u"][b] - r["u"]).max() <= TOL_FORCE_N
     dev = torch.device("cuda:0")
     T = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
     d = [T(sc["x0"]), T(sc["xref"]), T(sc["R"]), T(foot), T(contact, torch.uint8)]
-    g = torch.zeros(nb, 12, dtype=torch.float64, device=dev); it = torch.zeros(nb, dtype=torch.int32, device=dev); stt = torch.zeros(nb, dtype=torch.int32, device=dev)
+    g = torch.zeros(nb, 12, dtype=torch.float64, device=dev); it = torch.zeros(nb, dtype=torch.int32, device=dev); stt = torch.zeros(nb,
+            dtype=torch.int32, device=dev)
     ptr = lambda t: C.c_void_p(t.data_ptr())
     with _engine(pkg, sc, nb, warm_start=0) as eng:
         host = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, fs, contact, cs)
-        rc = eng.lib.a1mpc_solve_batch_strided_device(eng._h, nb, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), fs, ptr(d[4]), cs, None, ptr(g), None, ptr(it), ptr(stt), None)
+        rc = eng.lib.a1mpc_solve_batch_strided_device(eng._h, nb, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), fs, ptr(d[4]), cs, None,
+                ptr(g), None, ptr(it), ptr(stt), None)
         assert rc == 0
         torch.cuda.synchronize()
     assert np.array_equal(g.cpu().numpy(), host["grf"]) and np.array_equal(it.cpu().numpy(), host["iters"])
 
 
 def test_batch_pipeline_overlaps_batches_and_changes_no_bit(pkg, oracle, scen):
-    """a1mpc_pipeline_*: consecutive batches in flight on `depth` handles / HIP streams.  Every batch comes back bit-identical to a lone handle's
-    solve (and the first one is oracle-checked), slots go round-robin, a fixed slot keeps its warm start, wait / join deliver the outputs, and at
+    """a1mpc_pipeline_*: consecutive batches in flight on `depth` handles / HIP streams.  Every batch comes back bit-identical to a lone
+    handle's
+    solve (and the first one is oracle-checked), slots go round-robin, a fixed slot keeps its warm start, wait / join deliver the outputs,
+    and at
     4096 x h10 two batches in flight are faster per batch than one (the next batch runs in the tail of the one before)."""
     import time
     import torch
@@ -924,7 +1041,8 @@ def test_batch_pipeline_overlaps_batches_and_changes_no_bit(pkg, oracle, scen):
             assert slots == [k % depth for k in range(NB)]
             pipe.wait()
             for k in range(NB):
-                assert np.array_equal(outs[k][0].cpu().numpy(), ref[k][0]) and np.array_equal(outs[k][1].cpu().numpy(), ref[k][1]), (depth, k)
+                assert np.array_equal(outs[k][0].cpu().numpy(), ref[k][0]) and np.array_equal(outs[k][1].cpu().numpy(),
+                        ref[k][1]), (depth, k)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for k in range(steps):
                 pipe.submit_device(n, *ins[k % NB], outs[k % NB][0], None, outs[k % NB][1])
@@ -996,10 +1114,14 @@ def _oracle_update_ticks(oracle, pr, st, scs, carries):
 
 @pytest.mark.parametrize("n,h", [(1, 10), (300, 10), (2600, 10), (8300, 10), (1300, 16), (1100, 20)])
 def test_update_path_warm_start_2_matches_oracle(pkg, oracle, scen, n, h):
-    """warm_start = 2: the reference's tick >= 2 UPDATE path on the latency kernel (n = 1), the fused kernel (300; since round 4 also the warm ticks of 2600 x h10),
-    and the split pipeline's update-path instantiations -- set-up kernel + persistent rows at h = 10 (8300 > the 8192 up to which warm ticks run fused), the CU-wide
-    kernel at h = 16 (1300), the one-wave kernel at h = 20 (1100) -- against the oracle's restatement of OSQP's update functions (orc_mpc_solve_update): every robot
-    carries its own workspace through a sequence of slowly moving states with a contact switch; same iteration count and status on every QP of every tick, forces
+    """warm_start = 2: the reference's tick >= 2 UPDATE path on the latency kernel (n = 1), the fused kernel (300; since round 4 also the
+    warm ticks of 2600 x h10),
+    and the split pipeline's update-path instantiations -- set-up kernel + persistent rows at h = 10 (8300 > the 8192 up to which warm
+    ticks run fused), the CU-wide
+    kernel at h = 16 (1300), the one-wave kernel at h = 20 (1100) -- against the oracle's restatement of OSQP's update functions
+    (orc_mpc_solve_update): every robot
+    carries its own workspace through a sequence of slowly moving states with a contact switch; same iteration count and status on every QP
+    of every tick, forces
     within the parity tolerance."""
     rng = np.random.default_rng(100 + n)
     sc = scen.config3_random_flat(nb=n, seed=900 + n, horizon=h)
@@ -1011,7 +1133,8 @@ def test_update_path_warm_start_2_matches_oracle(pkg, oracle, scen, n, h):
             if t > 0:
                 sc["x0"][:, :12] += rng.normal(0, 2e-3, (n, 12)); sc["foot"] += rng.normal(0, 1e-3, (n, 12))
             if t == 2:
-                sc["contact"][:] = 1 - sc["contact"]      # every leg changes role: constraint types change, the carried z / y meet other bounds
+                # every leg changes role: constraint types change, the carried z / y meet other bounds
+                sc["contact"][:] = 1 - sc["contact"]
                 sc["contact"][sc["contact"].sum(1) == 0] = [1, 0, 0, 1]
             out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
             grf, it, stt = _oracle_update_ticks(oracle, pr, st, sc, carries)
@@ -1019,7 +1142,8 @@ def test_update_path_warm_start_2_matches_oracle(pkg, oracle, scen, n, h):
             assert np.abs(out["grf"] - grf).max() <= TOL_FORCE_N, (n, t, np.abs(out["grf"] - grf).max())
     # the first tick of a handle and the tick after a1mpc_reset_warm_start are cold solves whatever the mode
     with _engine(pkg, sc, n, warm_start=2) as eng, _engine(pkg, sc, n, warm_start=0) as cold:
-        a = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"]); c = cold.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
+        a = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"]); c = cold.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"],
+                sc["contact"])
         assert np.array_equal(a["grf"], c["grf"]) and np.array_equal(a["iters"], c["iters"])
         eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"]); eng.reset_warm_start()
         a = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
@@ -1027,8 +1151,10 @@ def test_update_path_warm_start_2_matches_oracle(pkg, oracle, scen, n, h):
 
 
 def test_pipeline_slots_carry_their_own_update_path_workspace(pkg, scen):
-    """two robot fleets on the two slots of a pipeline with warm_start = 2: each slot carries its own OSQP workspace (x, y, rho AND the update path's scalings /
-    gradient / z), so every tick of a fleet equals the tick of a lone handle that solved the same sequence -- bit for bit, while the two fleets' launches overlap."""
+    """two robot fleets on the two slots of a pipeline with warm_start = 2: each slot carries its own OSQP workspace (x, y, rho AND the
+    update path's scalings /
+    gradient / z), so every tick of a fleet equals the tick of a lone handle that solved the same sequence -- bit for bit, while the two
+    fleets' launches overlap."""
     import torch
     n = 2600
     dev = torch.device("cuda:0")
@@ -1042,20 +1168,24 @@ def test_pipeline_slots_carry_their_own_update_path_workspace(pkg, scen):
             for f in range(2):
                 if tick > 0:
                     fleets[f]["x0"][:, :12] += rng.normal(0, 2e-3, (n, 12))
-                ins.append([t(fleets[f]["x0"]), t(fleets[f]["xref"]), t(fleets[f]["R"]), t(fleets[f]["foot"]), t(fleets[f]["contact"], torch.uint8)])
+                ins.append([t(fleets[f]["x0"]), t(fleets[f]["xref"]), t(fleets[f]["R"]), t(fleets[f]["foot"]),
+                        t(fleets[f]["contact"], torch.uint8)])
             outs = [(torch.zeros(n, 12, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(4)]
             assert pipe.submit_device(n, *ins[0], outs[0][0], None, outs[0][1], slot=0, fresh=False) == 0
             assert pipe.submit_device(n, *ins[1], outs[1][0], None, outs[1][1], slot=1, fresh=False) == 1
             e0.solve_device(n, *ins[0], outs[2][0], None, outs[2][1]); e1.solve_device(n, *ins[1], outs[3][0], None, outs[3][1])
             pipe.wait(); torch.cuda.synchronize()
             for f in range(2):
-                assert np.array_equal(outs[f][0].cpu().numpy(), outs[2 + f][0].cpu().numpy()) and np.array_equal(outs[f][1].cpu().numpy(), outs[2 + f][1].cpu().numpy()), (tick, f)
+                assert np.array_equal(outs[f][0].cpu().numpy(), outs[2 + f][0].cpu().numpy()) and np.array_equal(outs[f][1].cpu().numpy(),
+                        outs[2 + f][1].cpu().numpy()), (tick, f)
         assert outs[0][1].float().mean().item() < 40   # warm ticks
 
 
 def test_host_pointer_pipeline_matches_the_synchronous_entry(pkg, scen):
-    """a1mpc_pipeline_submit / _wait: host arrays in, host arrays out (the reference's side of the boundary, S/A1RobotControl.h:44), two or three batches in flight.
-    The inputs are snapshotted before submit returns (they are overwritten right behind it here); every batch comes back bit-identical to a1mpc_solve_batch,
+    """a1mpc_pipeline_submit / _wait: host arrays in, host arrays out (the reference's side of the boundary, S/A1RobotControl.h:44), two or
+    three batches in flight.
+    The inputs are snapshotted before submit returns (they are overwritten right behind it here); every batch comes back bit-identical to
+    a1mpc_solve_batch,
     u_full / iters / status included; a slot that is resubmitted first delivers its previous batch; n = 0 and ragged sizes work."""
     n, NB = 3000, 5   # beyond the resident rows: the split pipeline
     scs = [scen.config3_random_flat(nb=n, seed=800 + k) for k in range(NB)]
@@ -1067,7 +1197,8 @@ def test_host_pointer_pipeline_matches_the_synchronous_entry(pkg, scen):
             ref.append(eng.solve(s["x0"], s["xref"], s["R"], s["foot"], s["contact"], want_u=True))
     for depth in (2, 3):
         with pkg.Pipeline(cfg, n, 0, depth=depth) as pipe:
-            outs = [dict(grf=np.full((n, 12), np.nan), u=np.full((n, 120), np.nan), iters=np.full(n, -1, np.int32), status=np.full(n, -99, np.int32)) for _ in range(NB)]
+            outs = [dict(grf=np.full((n, 12), np.nan), u=np.full((n, 120), np.nan), iters=np.full(n, -1, np.int32),
+                    status=np.full(n, -99, np.int32)) for _ in range(NB)]
             for k, s in enumerate(scs):
                 ins = [np.array(s[f]) for f in ("x0", "xref", "R", "foot", "contact")]
                 slot = pipe.submit(*ins, outs[k], fresh=True)   # round-robin: a slot that still holds batch k - depth delivers it first
@@ -1093,12 +1224,15 @@ def test_host_pointer_pipeline_matches_the_synchronous_entry(pkg, scen):
             pipe.submit(scs[1]["x0"][:0], scs[1]["xref"][:0], scs[1]["R"][:0], scs[1]["foot"][:0], scs[1]["contact"][:0], e, slot=1)
             pipe.wait()
             with pytest.raises(pkg.A1MpcError):
-                pipe.submit(np.zeros((n + 1, 13)), np.zeros((n + 1, 130)), np.zeros((n + 1, 9)), np.zeros((n + 1, 12)), np.zeros((n + 1, 4), np.uint8), dict(grf=np.zeros((n + 1, 12))))
+                pipe.submit(np.zeros((n + 1, 13)), np.zeros((n + 1, 130)), np.zeros((n + 1, 9)), np.zeros((n + 1, 12)),
+                        np.zeros((n + 1, 4), np.uint8), dict(grf=np.zeros((n + 1, 12))))
 
 
 def test_update_path_carry_is_dropped_by_ticks_that_do_not_refresh_it(pkg, oracle, scen):
-    """warm_start = 2: a general-path tick (per-step feet) and a stretch in warm_start = 1 rewrite the carried (x, y, rho) but not the update
-    path's carry.  The fast-path tick that follows must NOT pair the stale scalings / gradient / z with the fresh iterates: it is a fresh set-up warm-started
+    """warm_start = 2: a general-path tick (per-step feet) and a stretch in warm_start = 1 rewrite the carried (x, y, rho)
+    but not the update
+    path's carry.  The fast-path tick that follows must NOT pair the stale scalings / gradient / z with the fresh iterates: it is a fresh
+    set-up warm-started
     from (x, y, rho) -- exactly what a warm_start = 1 handle that saw the same sequence does, bit for bit."""
     n = 64
     rng = np.random.default_rng(77)
@@ -1117,11 +1251,13 @@ def test_update_path_carry_is_dropped_by_ticks_that_do_not_refresh_it(pkg, oracl
         # align the two handles' carried (x, y, rho), then a general-path tick on both
         x, y, rho = e2.get_warm_start(n)
         e1.set_warm_start(x, y, rho)
-        e2.set_warm_start(x, y, rho)   # (the same values it holds: a no-op on the iterates; the general-path tick below is what drops the carry)
+        # (the same values it holds: a no-op on the iterates; the general-path tick below is what drops the carry)
+        e2.set_warm_start(x, y, rho)
         a = e2.solve_strided(seq[2]["x0"], seq[2]["xref"], seq[2]["R"], f2, 12, c2, 4)
         b = e1.solve_strided(seq[2]["x0"], seq[2]["xref"], seq[2]["R"], f2, 12, c2, 4)
         assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"])
-        # a fast-path tick on the update path first (fills the carry again), then the general path, then the fast path: the last one must equal mode 1
+        # a fast-path tick on the update path first (fills the carry again), then the general path, then the fast path: the last one must
+        # equal mode 1
         a = e2.solve(seq[3]["x0"], seq[3]["xref"], seq[3]["R"], seq[3]["foot"], seq[3]["contact"])
         b = e1.solve(seq[3]["x0"], seq[3]["xref"], seq[3]["R"], seq[3]["foot"], seq[3]["contact"])
         assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"])   # (tick after a cleared carry = mode 1)
@@ -1131,7 +1267,8 @@ def test_update_path_carry_is_dropped_by_ticks_that_do_not_refresh_it(pkg, oracl
         assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"])
         a = e2.solve(seq[5]["x0"], seq[5]["xref"], seq[5]["R"], seq[5]["foot"], seq[5]["contact"])
         b = e1.solve(seq[5]["x0"], seq[5]["xref"], seq[5]["R"], seq[5]["foot"], seq[5]["contact"])
-        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"]), "stale update-path carry used after a general-path tick"
+        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"],
+                b["iters"]), "stale update-path carry used after a general-path tick"
     # the same through a1mpc_update_config: 2 -> 1 -> 2 leaves no stale carry behind
     with _engine(pkg, sc, n, warm_start=2) as e2, _engine(pkg, sc, n, warm_start=1) as e1:
         for t in (0, 1):
@@ -1145,14 +1282,19 @@ def test_update_path_carry_is_dropped_by_ticks_that_do_not_refresh_it(pkg, oracl
         e2.update_config(pkg.make_config(sc["params"], 10, warm_start=2))
         a = e2.solve(seq[4]["x0"], seq[4]["xref"], seq[4]["R"], seq[4]["foot"], seq[4]["contact"])
         b = e1.solve(seq[4]["x0"], seq[4]["xref"], seq[4]["R"], seq[4]["foot"], seq[4]["contact"])
-        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"]), "stale update-path carry used after a1mpc_update_config"
+        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"],
+                b["iters"]), "stale update-path carry used after a1mpc_update_config"
 
 
 def test_update_path_injected_warm_start_is_reexpressed_on_the_workspace(pkg, oracle, scen):
-    """with warm_start = 2 an a1mpc_warm_start(x, y, rho) no longer clears the update path's carry; it does what osqp_warm_start_x / _y do on the
-    reference's persistent solver -- x and y replace the iterates, z becomes A x, the previous tick's scalings / gradient / bounds stay -- and the next tick follows
-    the update path from there.  Checked against the oracle started from exactly that workspace (carry_from_workspace with the ENGINE's scalings of the last tick,
-    the injected x and y, z = A x): same iteration count, forces within the parity tolerance, on every robot; and the tick differs from what a cleared carry gives."""
+    """with warm_start = 2 an a1mpc_warm_start(x, y, rho) no longer clears the update path's carry; it does what
+    osqp_warm_start_x / _y do on the
+    reference's persistent solver -- x and y replace the iterates, z becomes A x, the previous tick's scalings / gradient / bounds stay --
+    and the next tick follows
+    the update path from there.  Checked against the oracle started from exactly that workspace (carry_from_workspace with the ENGINE's
+    scalings of the last tick,
+    the injected x and y, z = A x): same iteration count, forces within the parity tolerance, on every robot; and the tick differs from
+    what a cleared carry gives."""
     n = 48
     rng = np.random.default_rng(91)
     sc = scen.config3_random_flat(nb=n, seed=9100)
@@ -1166,19 +1308,23 @@ def test_update_path_injected_warm_start_is_reexpressed_on_the_workspace(pkg, or
         for t in (0, 1, 2):
             eng.solve(seq[t]["x0"], seq[t]["xref"], seq[t]["R"], seq[t]["foot"], seq[t]["contact"])
         x, y, rho = eng.get_warm_start(n); D, E, c = eng.get_workspace_scaling(n)
-        xi = x * (1.0 + rng.normal(0, 0.02, x.shape)); yi = y * (1.0 + rng.normal(0, 0.02, y.shape)); ri = rho * 1.5    # the injected state: NOT what the last tick left
+        # the injected state: NOT what the last tick left
+        xi = x * (1.0 + rng.normal(0, 0.02, x.shape)); yi = y * (1.0 + rng.normal(0, 0.02, y.shape)); ri = rho * 1.5
         eng.set_warm_start(xi, yi, ri)
         zi = eng.get_workspace_z(n)
         f = xi.reshape(n, h, 4, 3)
-        zA = np.stack([f[..., 0] + mu * f[..., 2], f[..., 0] - mu * f[..., 2], f[..., 1] + mu * f[..., 2], f[..., 1] - mu * f[..., 2], f[..., 2]], axis=-1).reshape(n, 20 * h)
+        zA = np.stack([f[..., 0] + mu * f[..., 2], f[..., 0] - mu * f[..., 2], f[..., 1] + mu * f[..., 2], f[..., 1] - mu * f[..., 2],
+                f[..., 2]], axis=-1).reshape(n, 20 * h)
         assert np.abs(zi - zA).max() < 1e-12     # z = A x (osqp_warm_start_x)
         out = eng.solve(seq[3]["x0"], seq[3]["xref"], seq[3]["R"], seq[3]["foot"], seq[3]["contact"], want_u=True)
         assert eng.last_warm_start_mode() == 2
     worst = 0.0
     for i in range(n):
-        P, g, _, l, u, _ = oracle.mpc_form(pr, seq[2]["x0"][i], seq[2]["xref"][i], seq[2]["R"][i], seq[2]["foot"][i], seq[2]["contact"][i])   # the previous tick's data stays in the workspace
+        # the previous tick's data stays in the workspace
+        P, g, _, l, u, _ = oracle.mpc_form(pr, seq[2]["x0"][i], seq[2]["xref"][i], seq[2]["R"][i], seq[2]["foot"][i], seq[2]["contact"][i])
         carry = oracle.carry_from_workspace(h, xi[i], yi[i], zA[i], ri[i], D[i], E[i], c[i], P, g, l, u)
-        r = oracle.mpc_solve_update(pr, st, seq[3]["x0"][i], seq[3]["xref"][i], seq[3]["R"][i], seq[3]["foot"][i], seq[3]["contact"][i], carry)
+        r = oracle.mpc_solve_update(pr, st, seq[3]["x0"][i], seq[3]["xref"][i], seq[3]["R"][i], seq[3]["foot"][i], seq[3]["contact"][i],
+                carry)
         assert out["iters"][i] == r["info"].iters and out["status"][i] == r["info"].status, (i, out["iters"][i], r["info"].iters)
         worst = max(worst, float(np.abs(out["u"][i] - r["u"]).max()))
     assert worst <= TOL_FORCE_N, worst
@@ -1192,10 +1338,14 @@ def test_update_path_injected_warm_start_is_reexpressed_on_the_workspace(pkg, or
 
 @pytest.mark.parametrize("n", [1, 200])
 def test_update_path_reinitialises_on_a_hessian_pattern_change(pkg, oracle, scen, n):
-    """warm_start = 2 and the OsqpEigen branch SURVEY 8(c) names: when exact zeros of the reference's dense Hessian appear or vanish (fixture T's weights: level <->
-    pitched), updateHessianMatrix re-initialises the solver (rho back to settings.rho, fresh scaling) and warm-starts it with the workspace's SCALED iterates
-    (S/A1RobotControl.cpp:533-538, S/ConvexMpc.cpp:211).  The kernels find the change in the zero patterns of U and V, the oracle in the dense P: same ticks re-initialise,
-    same iteration counts, forces within the parity tolerance.  Two re-initialisations only -- the oracle's own two linear-system back ends drift apart by 1000x per
+    """warm_start = 2 and the OsqpEigen branch SURVEY 8(c) names: when exact zeros of the reference's dense Hessian appear or vanish
+    (fixture T's weights: level <->
+    pitched), updateHessianMatrix re-initialises the solver (rho back to settings.rho, fresh scaling) and warm-starts it with the
+    workspace's SCALED iterates
+    (S/A1RobotControl.cpp:533-538, S/ConvexMpc.cpp:211).  The kernels find the change in the zero patterns of U and V, the oracle in the
+    dense P: same ticks re-initialise,
+    same iteration counts, forces within the parity tolerance.  Two re-initialisations only -- the oracle's own two linear-system back ends
+    drift apart by 1000x per
     re-initialised solve on this ill-conditioned QP (tests/test_emu_parity.py)."""
     T = scen.scenario_T(); p = T["params"]; h = 10
     pr = oracle_params(oracle, T); st = oracle.default_settings(warm_start=1)
@@ -1208,23 +1358,29 @@ def test_update_path_reinitialises_on_a_hessian_pattern_change(pkg, oracle, scen
             R = scen.rot_zyx(0.0, pitch, 0.0)
             foot = (R @ nominal.T).T.reshape(12) if pitch else nominal.reshape(12)
             x0 = np.tile(np.array([0.0, pitch, 0.0, 0.0, 0.0, 0.15 + 0.001 * t, 0, 0, 0, 0, 0, 0, -9.8]), (n, 1)); x0[:, 5] += dz
-            xref = np.stack([oracle.mpc_reference(h, p["dt"], x0[b, 0:3], x0[b, 3:6], R.reshape(9), np.zeros(3), np.zeros(3), np.zeros(3), 0.15) for b in range(n)])
-            sc = dict(x0=x0, xref=xref, R=np.tile(R.reshape(9), (n, 1)), foot=np.tile(foot, (n, 1)), contact=np.tile(np.array([1, 0, 1, 0], np.uint8), (n, 1)))
+            xref = np.stack([oracle.mpc_reference(h, p["dt"], x0[b, 0:3], x0[b, 3:6], R.reshape(9), np.zeros(3), np.zeros(3), np.zeros(3),
+                    0.15) for b in range(n)])
+            sc = dict(x0=x0, xref=xref, R=np.tile(R.reshape(9), (n, 1)), foot=np.tile(foot, (n, 1)),
+                    contact=np.tile(np.array([1, 0, 1, 0], np.uint8), (n, 1)))
             out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
             re = []
             for b in range(n):
                 o = oracle.mpc_solve_update(pr, st, x0[b], xref[b], sc["R"][b], sc["foot"][b], sc["contact"][b], carries[b])
                 re.append(o["info"].reinit)
-                assert out["iters"][b] == o["info"].iters and out["status"][b] == o["info"].status, (n, t, b, out["iters"][b], o["info"].iters)
+                assert out["iters"][b] == o["info"].iters and out["status"][b] == o["info"].status, (n, t, b, out["iters"][b],
+                        o["info"].iters)
                 assert np.abs(out["grf"][b] - o["grf"]).max() <= TOL_FORCE_N, (n, t, b)
             assert all(r == (1 if t in (2, 4) else 0) for r in re), (t, re[:8])
 
 
-# ------------------------------------------------------------------------------------------------------------ round 3: the big batches, gated
+# ------------------------------------------------------------------------------------------------------------ round 3: the big batches,
+# gated
 @pytest.mark.parametrize("gen,n,h", [("config5_divergent", 32768, 20), ("config3_random_flat", 65536, 10)])
 def test_full_size_batches_every_qp_vs_oracle(pkg, oracle, scen, gen, n, h):
-    """BASELINE configs[4] as ONE launch of 32768 x h20 (mixed contact patterns, 0.5 rad pitch) and BASELINE's upper batch, 65536 x h10, as one
-    launch -- EVERY QP against the oracle (all host threads): same iteration count and status on every QP, forces within the parity tolerance."""
+    """BASELINE configs[4] as ONE launch of 32768 x h20 (mixed contact patterns, 0.5 rad pitch) and BASELINE's upper
+    batch, 65536 x h10, as one
+    launch -- EVERY QP against the oracle (all host threads): same iteration count and status on every QP, forces within the parity
+    tolerance."""
     sc = getattr(scen, gen)(nb=n)
     with _engine(pkg, sc, n, warm_start=0) as eng:
         out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=False)
@@ -1236,19 +1392,30 @@ def test_full_size_batches_every_qp_vs_oracle(pkg, oracle, scen, gen, n, h):
 
 @pytest.mark.parametrize("mode", [1, 2])
 def test_ten_thousand_warm_started_ticks_batch_1(pkg, oracle, scen, mode):
-    """VERDICT r2 item 6 / BASELINE configs[1]: 10 000 sequential warm-started trot ticks of ONE robot (the reference's operating point, S/A1RobotControl.cpp:522-538)
-    through the host-pointer entry, in both warm-start semantics -- 1: fresh set-up + osqp_warm_start, 2: the reference's per-tick OSQP update path -- against the oracle
+    """VERDICT r2 item 6 / BASELINE configs[1]: 10 000 sequential warm-started trot ticks of ONE robot (the reference's operating point,
+    S/A1RobotControl.cpp:522-538)
+    through the host-pointer entry, in both warm-start semantics -- 1: fresh set-up + osqp_warm_start, 2: the reference's per-tick OSQP
+    update path -- against the oracle
     chained the same way.  Mode 1: the same iteration count and status and forces within the parity tolerance on EVERY tick.
-    Mode 2 asserts something on every tick as well.  The update path makes this tick sequence a chaotic map (independent 2 cm / 0.02 rad noise on
-    every tick: each solve starts from iterates scaled for another problem), so last-bit differences between two implementations grow from tick to tick until they
-    exceed the tolerance -- the oracle's OWN two back ends, Cholesky of the reduced system vs LDL' of the KKT matrix, are 0.5 N apart from tick 3354 on.  Between those
-    (counted, rare) PARTINGS every tick is within the parity tolerance with the same iteration count.  ON a parting tick the engine's answer is checked on its own:
-      (i)  OSQP's termination test (auxil.c check_termination: unscaled residuals against eps_abs + eps_rel x norms) evaluated on the ENGINE's (x, z, y) of that tick
+    Mode 2 asserts something on every tick as well.  The update path makes this tick sequence a chaotic map
+    (independent 2 cm / 0.02 rad noise on
+    every tick: each solve starts from iterates scaled for another problem), so last-bit differences between two implementations grow from
+    tick to tick until they
+    exceed the tolerance -- the oracle's OWN two back ends, Cholesky of the reduced system vs LDL' of the KKT matrix, are 0.5 N apart from
+    tick 3354 on.  Between those
+    (counted, rare) PARTINGS every tick is within the parity tolerance with the same iteration count.  ON a parting tick the engine's
+    answer is checked on its own:
+      (i)  OSQP's termination test (auxil.c check_termination: unscaled residuals against eps_abs + eps_rel x norms) evaluated on the
+      ENGINE's (x, z, y) of that tick
            passes -- the engine stopped at a point OSQP itself accepts;
-      (ii) the oracle is then RE-SEEDED from the engine's workspace (a1mpc_get_warm_start / _workspace_z / _workspace_scaling: everything the reference's persistent
-           solver carries) instead of both sides restarting cold, and the next tick -- engine, double-precision oracle and the x87 extended-precision build of the
-           oracle (tests/x87.py), all three from that one state -- must agree tick-for-tick again: engine vs oracle within 1e-7 N with the same iteration count (a
-           parting is accumulated chaos, not a per-tick discrepancy), and the engine no further from the extended-precision answer than the double oracle is (+ 1e-10 N)."""
+      (ii) the oracle is then RE-SEEDED from the engine's workspace (a1mpc_get_warm_start / _workspace_z / _workspace_scaling: everything
+      the reference's persistent
+           solver carries) instead of both sides restarting cold, and the next tick -- engine, double-precision oracle and the x87
+           extended-precision build of the
+           oracle (tests/x87.py), all three from that one state -- must agree tick-for-tick again: engine vs oracle within 1e-7 N with the
+           same iteration count (a
+           parting is accumulated chaos, not a per-tick discrepancy), and the engine no further from the extended-precision answer than the
+           double oracle is (+ 1e-10 N)."""
     import x87
     nt = 10000
     sc = scen.config2_trot_sequence(nt)
@@ -1263,7 +1430,8 @@ def test_ten_thousand_warm_started_ticks_batch_1(pkg, oracle, scen, mode):
         for t in range(nt):
             out = eng.solve(sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t])
             if mode == 1:
-                r = oracle.mpc_solve(pr, st, sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t], warm_x=wx, warm_y=wy, warm_rho=rho)
+                r = oracle.mpc_solve(pr, st, sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t], warm_x=wx,
+                        warm_y=wy, warm_rho=rho)
                 wx, wy, rho = r["warm_x"], r["warm_y"], r["rho"]
             else:
                 r = oracle.mpc_solve_update(pr, st, sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t], carry)
@@ -1273,11 +1441,14 @@ def test_ten_thousand_warm_started_ticks_batch_1(pkg, oracle, scen, mode):
                 assert same, (mode, t, out["iters"], r["info"].iters)
                 continue
             if seeded is not None:   # (ii) the tick after a parting: all three from ONE state
-                xr = x87.mpc_solve_update(xpr, x87.settings(warm_start=1), sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t], seeded)
+                xr = x87.mpc_solve_update(xpr, x87.settings(warm_start=1), sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t],
+                        sc["contact"][t], seeded)
                 d_eng = float(np.abs(out["grf"][0] - xr["grf"]).max()); d_orc = float(np.abs(r["grf"] - xr["grf"]).max())
-                partings[-1].update(next_tick=dict(iters=(int(out["iters"][0]), int(r["info"].iters), xr["iters"]), engine_vs_oracle_N=errs[t], engine_vs_x87_N=d_eng, oracle_vs_x87_N=d_orc))
+                partings[-1].update(next_tick=dict(iters=(int(out["iters"][0]), int(r["info"].iters), xr["iters"]),
+                        engine_vs_oracle_N=errs[t], engine_vs_x87_N=d_eng, oracle_vs_x87_N=d_orc))
                 assert same and errs[t] <= 1e-7, (t, partings[-1])
-                assert d_eng <= d_orc + 1e-10, (t, partings[-1])   # (observed: the engine is the CLOSER one on every parting, 1e-13 against 1e-11 N)
+                # (observed: the engine is the CLOSER one on every parting, 1e-13 against 1e-11 N)
+                assert d_eng <= d_orc + 1e-10, (t, partings[-1])
                 seeded = None
             if not same or errs[t] > TOL_FORCE_N:
                 assert eng.last_warm_start_mode() == 2
@@ -1285,27 +1456,35 @@ def test_ten_thousand_warm_started_ticks_batch_1(pkg, oracle, scen, mode):
                 P, g, _, l, u, csr = oracle.mpc_form(pr, sc["x0"][t], sc["xref"][t], sc["R"][t], sc["foot"][t], sc["contact"][t])
                 k = 10.0 if out["status"][0] == 2 else 1.0     # (SOLVED_INACCURATE: OSQP's approximate test, 10 x the tolerances)
                 ct = oracle.check_termination(P, g, csr, ex[0], ez[0], ey[0], eps_abs=k * st.eps_abs, eps_rel=k * st.eps_rel)
-                assert out["status"][0] in (1, 2) and ct["ok"], (t, int(out["status"][0]), ct)   # (i) a point OSQP's own termination test accepts
-                partings.append(dict(tick=t, iters=(int(out["iters"][0]), int(r["info"].iters)), engine_vs_oracle_N=errs[t], pri=(ct["pri_res"], ct["pri_tol"]), dua=(ct["dua_res"], ct["dua_tol"])))
+                # (i) a point OSQP's own termination test accepts
+                assert out["status"][0] in (1, 2) and ct["ok"], (t, int(out["status"][0]), ct)
+                partings.append(dict(tick=t, iters=(int(out["iters"][0]), int(r["info"].iters)), engine_vs_oracle_N=errs[t],
+                        pri=(ct["pri_res"], ct["pri_tol"]), dua=(ct["dua_res"], ct["dua_tol"])))
                 diverged.append(t); errs[t] = 0.0
-                carry = oracle.carry_from_workspace(h, ex[0], ey[0], ez[0], erho[0], eD[0], eE[0], ec[0], P, g, l, u)   # the oracle goes on from the ENGINE's workspace
+                # the oracle goes on from the ENGINE's workspace
+                carry = oracle.carry_from_workspace(h, ex[0], ey[0], ez[0], erho[0], eD[0], eE[0], ec[0], P, g, l, u)
                 seeded = carry.copy()
     worst = float(errs.max())
-    print(f"warm_start = {mode}: 10000 ticks, |dGRF| median {np.median(errs):.1e}, 99.9 % {np.quantile(errs, 0.999):.1e}, worst {worst:.2e} N (tick {int(errs.argmax())}), "
-          f"ticks above 1e-6 N: {int((errs > 1e-6).sum())}, partings (oracle re-seeded from the engine's workspace): {diverged}, mean iterations {its / nt:.1f}")
+    print(f"warm_start = {mode}: 10000 ticks, |dGRF| median {np.median(errs):.1e}, 99.9 % {np.quantile(errs, 0.999):.1e}, "
+          f"worst {worst:.2e} N (tick {int(errs.argmax())}), "
+          f"ticks above 1e-6 N: {int((errs > 1e-6).sum())}, "
+          f"partings (oracle re-seeded from the engine's workspace): {diverged}, mean iterations {its / nt:.1f}")
     for pt in partings:
         print("  parting", pt)
     if mode == 1:    # fresh set-up + osqp_warm_start: the parity tolerance on every one of the 10 000 ticks
         assert worst <= TOL_FORCE_N, (mode, int(errs.argmax()), worst)
-    else:            # the update path: at most a handful of partings in 10 000 ticks, every other tick within the tolerance (by construction of the count)
+    # the update path: at most a handful of partings in 10 000 ticks, every other tick within the tolerance (by construction of the count)
+    else:
         assert len(diverged) <= 10 and worst <= TOL_FORCE_N, (mode, diverged, int(errs.argmax()), worst)
         assert seeded is None or diverged[-1] == nt - 1
 
 
 @pytest.mark.parametrize("gen,n", [("config3_random_flat", 4096), ("config4_random_h16", 2560), ("config5_divergent", 2048)])
 def test_stage_cycles_through_the_abi(pkg, scen, gen, n):
-    """VERDICT r3 item 9 / SURVEY 5 (the reference's t1..t6 stopwatches, S/A1RobotControl.cpp:491-553): a1mpc_set_profiling runs the clock-stamped instantiation of the
-    persistent ADMM kernel -- bit-identical results -- and a1mpc_last_stage_cycles splits the solve stage into factor passes | iterations | residual checks."""
+    """VERDICT r3 item 9 / SURVEY 5 (the reference's t1..t6 stopwatches, S/A1RobotControl.cpp:491-553): a1mpc_set_profiling runs the
+    clock-stamped instantiation of the
+    persistent ADMM kernel -- bit-identical results -- and a1mpc_last_stage_cycles splits the solve stage into factor passes | iterations |
+    residual checks."""
     sc = getattr(scen, gen)(nb=n)
     with _engine(pkg, sc, n, warm_start=0) as eng:
         a = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
@@ -1321,18 +1500,24 @@ def test_stage_cycles_through_the_abi(pkg, scen, gen, n):
     assert cyc["qps"] == n and min(cyc["factor"], cyc["iterate"], cyc["check"]) > 0
     tot = cyc["factor"] + cyc["iterate"] + cyc["check"]
     per_it = cyc["iterate"] / float(a["iters"].sum()); per_f = cyc["factor"] / float(nf.sum())
-    print(f"{gen} x {n}: factor {cyc['factor'] / tot:.3f} | iterate {cyc['iterate'] / tot:.3f} | check {cyc['check'] / tot:.3f} of the solve stage; "
+    print(f"{gen} x {n}: factor {cyc['factor'] / tot:.3f} | iterate {cyc['iterate'] / tot:.3f} | "
+          f"check {cyc['check'] / tot:.3f} of the solve stage; "
           f"{per_it:.0f} cycles per iteration, {per_f:.0f} per factor pass (wave-mates' stalls included)")
     assert 0.5 < cyc["iterate"] / tot < 0.95 and 0.03 < cyc["factor"] / tot < 0.45
 
 
 @pytest.mark.parametrize("mode,n,h", [(1, 4096, 10), (2, 4096, 10), (1, 1400, 16), (1, 1200, 20), (2, 1200, 20), (1, 2400, 20)])
 def test_warm_ticks_of_a_large_batch_take_the_fused_kernel_and_match_the_oracle(pkg, oracle, scen, mode, n, h):
-    """Round 4: second and later warm-started ticks of a batch size run the FUSED kernel up to 8192 QPs at h = 10 (solve_device_impl: nothing left for the queue to
-    balance when every QP takes ~25 iterations), the first tick and any tick after a1mpc_set_schedule the split pipeline.  4096 robots, four ticks with slowly moving
-    states, both warm-start semantics: every 16th robot is chained through the oracle the same way -- same iteration count and status, forces within the parity
-    tolerance on every tick -- and a1mpc_last_stage_ms tells which pipeline ran (the fused kernel has no set-up stage of its own).  The h = 16 and the larger h = 20 cases
-    run the warm-start hand-off of the split pipeline (the CU-wide kernel at h = 16) the same way; h = 20 up to 2048 QPs takes the fused kernel's quads of rows."""
+    """Round 4: second and later warm-started ticks of a batch size run the FUSED kernel up to 8192 QPs at h = 10 (solve_device_impl:
+    nothing left for the queue to
+    balance when every QP takes ~25 iterations), the first tick and any tick after a1mpc_set_schedule the split pipeline.  4096 robots,
+    four ticks with slowly moving
+    states, both warm-start semantics: every 16th robot is chained through the oracle the same way -- same iteration count and status,
+    forces within the parity
+    tolerance on every tick -- and a1mpc_last_stage_ms tells which pipeline ran (the fused kernel has no set-up stage of its own).  The h =
+    16 and the larger h = 20 cases
+    run the warm-start hand-off of the split pipeline (the CU-wide kernel at h = 16) the same way; h = 20 up to 2048 QPs takes the fused
+    kernel's quads of rows."""
     ticks = 4
     rng = np.random.default_rng(404)
     sc = scen.config3_random_flat(nb=n, seed=4040, horizon=h)
@@ -1351,44 +1536,57 @@ def test_warm_ticks_of_a_large_batch_take_the_fused_kernel_and_match_the_oracle(
             for i in sub:
                 i = int(i)
                 if mode == 1:
-                    r = oracle.mpc_solve(pr, st, sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i], warm_x=wx[i], warm_y=wy[i], warm_rho=rho[i])
+                    r = oracle.mpc_solve(pr, st, sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i], warm_x=wx[i],
+                            warm_y=wy[i], warm_rho=rho[i])
                     wx[i], wy[i], rho[i] = r["warm_x"], r["warm_y"], r["rho"]
                 else:
                     r = oracle.mpc_solve_update(pr, st, sc["x0"][i], sc["xref"][i], sc["R"][i], sc["foot"][i], sc["contact"][i], carry[i])
-                assert out["iters"][i] == r["info"].iters and out["status"][i] == r["info"].status, (mode, t, i, out["iters"][i], r["info"].iters)
+                assert out["iters"][i] == r["info"].iters and out["status"][i] == r["info"].status, (mode, t, i, out["iters"][i],
+                        r["info"].iters)
                 worst = max(worst, float(np.abs(out["u"][i] - r["u"]).max()))
             assert worst <= TOL_FORCE_N, (mode, t, worst)
     if h == 10 or (h == 20 and n <= 2048):
-        assert staged[0] and not any(staged[1:]), staged     # tick 0: split pipeline (set-up stage timed); ticks 1..: the fused kernel (h = 20: its quad of rows, up to 2048 QPs)
+        # tick 0: split pipeline (set-up stage timed); ticks 1..: the fused kernel (h = 20: its quad of rows, up to 2048 QPs)
+        assert staged[0] and not any(staged[1:]), staged
     else:
-        assert all(staged), staged                           # h = 16, larger h = 20 batches: warm ticks stay on the split pipeline (the CU-wide kernel at h = 16), where the fused kernel loses
+        # h = 16, larger h = 20 batches: warm ticks stay on the split pipeline (the CU-wide kernel at h = 16), where the fused kernel loses
+        assert all(staged), staged
 
 
 @pytest.mark.parametrize("seed", [1071, 1217, 1160, 1501])
 def test_settings_above_the_parity_bar_are_the_checkers_own_rounding(pkg, oracle, scen, seed):
-    """the random-settings soak (tests/tools/soak_settings.py) has a handful of combinations -- scaling 0 / 2, sigma ~ 1e-7, rho re-adapted every 10
-    iterations, 60-iteration cut-offs -- on which engine and oracle stop at the same iteration with forces 1e-4 ... 1e-1 N apart: ADMM amplifies last-bit differences of
-    the two linear solves there (the oracle's own two back ends part by more).  Gated here with the x87 extended-precision build of the oracle as the yardstick: on the
-    three QPs of each such combination with the largest engine-vs-oracle difference all three runs stop at the same iteration, and the engine's distance to the
+    """the random-settings soak (tests/tools/soak_settings.py) has a handful of combinations -- scaling 0 / 2, sigma
+    ~ 1e-7, rho re-adapted every 10
+    iterations, 60-iteration cut-offs -- on which engine and oracle stop at the same iteration with forces 1e-4 ... 1e-1 N apart: ADMM
+    amplifies last-bit differences of
+    the two linear solves there (the oracle's own two back ends part by more).  Gated here with the x87 extended-precision build of the
+    oracle as the yardstick: on the
+    three QPs of each such combination with the largest engine-vs-oracle difference all three runs stop at the same iteration, and the
+    engine's distance to the
     extended-precision answer is of the order of the double-precision oracle's own (<= 5 x; it is the closer one on most)."""
     import x87
     n = 256
     rng = np.random.default_rng(seed)
     H = int(rng.choice([10, 10, 16, 20]))     # (the draw sequence of tests/tools/soak_settings.py)
-    over = dict(scaling=int(rng.choice([0, 2, 10, 10, 15])), alpha=float(rng.choice([1.0, 1.6, 1.6, rng.uniform(1.05, 1.9)])), rho=float(10 ** rng.uniform(-2, 0.3)),
-                sigma=float(10 ** rng.uniform(-7, -4)), check_termination=int(rng.choice([5, 10, 25, 25, 40])), adaptive_rho=int(rng.choice([0, 1, 1, 1])),
-                adaptive_rho_interval=int(rng.choice([0, 10, 25, 35, 50, 100])), adaptive_rho_tolerance=float(rng.choice([1.5, 2.0, 5.0, 5.0])),
+    over = dict(scaling=int(rng.choice([0, 2, 10, 10, 15])), alpha=float(rng.choice([1.0, 1.6, 1.6, rng.uniform(1.05, 1.9)])),
+            rho=float(10 ** rng.uniform(-2, 0.3)),
+                sigma=float(10 ** rng.uniform(-7, -4)), check_termination=int(rng.choice([5, 10, 25, 25, 40])),
+                        adaptive_rho=int(rng.choice([0, 1, 1, 1])),
+                adaptive_rho_interval=int(rng.choice([0, 10, 25, 35, 50, 100])),
+                        adaptive_rho_tolerance=float(rng.choice([1.5, 2.0, 5.0, 5.0])),
                 eps_abs=float(rng.choice([1e-3, 1e-3, 1e-4, 1e-5])), max_iter=int(rng.choice([60, 400, 4000, 4000])))
     over["eps_rel"] = over["eps_abs"]
     gen = {10: scen.config3_random_flat, 16: scen.config4_random_h16, 20: scen.config5_divergent}[H]
     sc = gen(nb=n, seed=7000 + seed)
-    p = dict(sc["params"], mu=float(rng.choice([0.3, 0.3, 0.6, 0.15])), fz_min=float(rng.choice([0.0, 0.0, 0.0, 5.0])), fz_max=float(rng.choice([180.0, 180.0, 120.0, 60.0])))
+    p = dict(sc["params"], mu=float(rng.choice([0.3, 0.3, 0.6, 0.15])), fz_min=float(rng.choice([0.0, 0.0, 0.0, 5.0])),
+            fz_max=float(rng.choice([180.0, 180.0, 120.0, 60.0])))
     with pkg.Engine(pkg.make_config(p, H, warm_start=0, **over), n, 0) as eng:
         out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
     pr = oracle.mpc_params(H, p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"], p["inertia"])
     ref = oracle.mpc_solve_batch(pr, oracle.default_settings(**over), sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"])
     assert (out["iters"] == ref["iters"]).all()
-    st_diff = int((out["status"] != ref["status"]).sum())     # (at the iteration limit OSQP's "solved inaccurate" test, 10 x the tolerances, can sit on the same knife edge)
+    # (at the iteration limit OSQP's "solved inaccurate" test, 10 x the tolerances, can sit on the same knife edge)
+    st_diff = int((out["status"] != ref["status"]).sum())
     assert st_diff <= n // 50, st_diff
     dd = np.abs(out["grf"].reshape(n, 12) - ref["grf"].reshape(n, 12)).max(1)
     xpr = x87.params(p, H); xst = x87.settings(**over)
@@ -1399,27 +1597,35 @@ def test_settings_above_the_parity_bar_are_the_checkers_own_rounding(pkg, oracle
         rows.append((int(i), float(dd[i]), d_e, d_o))
         assert xr["iters"] == out["iters"][i], (seed, i, xr["iters"], out["iters"][i])
         assert d_e <= 5.0 * d_o + TOL_FORCE_N, (seed, rows)
-    print(f"settings seed {seed} (h = {H}, {over}): worst engine-vs-oracle {dd.max():.2e} N, {st_diff} status differences; (qp, engine-vs-oracle, engine-vs-x87, oracle-vs-x87): {rows}")
+    print(f"settings seed {seed} (h = {H}, {over}): worst engine-vs-oracle {dd.max():.2e} N, {st_diff} status differences; "
+          f"(qp, engine-vs-oracle, engine-vs-x87, oracle-vs-x87): {rows}")
 
 
 @pytest.mark.parametrize("h,n", [(20, 2100), (16, 2600)])
 def test_quad_of_rows_kernels_leave_the_twin_pairs_bits(pkg, h, n):
-    """h = 20 (one QP per wavefront) and waves 1-3 of the CU-wide kernel at h = 16 run the four rows of a wavefront as a QUAD on one QP (RowSolver<.., QUAD>): the per-lane state
-    split four ways, the chains untouched.  Against the twin-pair kernels of the same library (A1MPC_QUAD=0 in a child process): forces, the full solution, iteration counts and
+    """h = 20 (one QP per wavefront) and waves 1-3 of the CU-wide kernel at h = 16 run the four rows of a wavefront as a QUAD on one QP
+    (RowSolver<.., QUAD>): the per-lane state
+    split four ways, the chains untouched.  Against the twin-pair kernels of the same library (A1MPC_QUAD=0 in a child process): forces,
+    the full solution, iteration counts and
     statuses of first solves, solves in history order and three warm-started ticks -- the same bits."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_quad.py"), pkg.build.LIB_PATH, str(h), str(n), "1"], capture_output=True, text=True, timeout=900, cwd=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_quad.py"), pkg.build.LIB_PATH, str(h), str(n), "1"],
+            capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["bit_identical"] is True, r.stdout[-800:]
 
 
 def test_the_soak_tail_is_double_precisions_own_noise(pkg, oracle, scen):
-    """The one QP of this round's 819 200-QP soak (tests/tools/soak_parity.py 20000 200 10, profiles/r04_parity_soak_1M.txt) where engine and oracle part by more than the
-    1e-5 N bar: seed 20160, QP 0 -- 100 iterations, rho adapted down to 5e-4, same iteration count and status, 4.4e-5 N between the two.  On this QP the double-precision
-    oracle's own answer moves by up to 2.9e-5 N when one word of x0 moves by one ulp (the x87 build: 7e-9 N -- the QP is not ill-posed, double precision is noisy on it),
-    so no two double-precision implementations of the iterate sequence can be held to 1e-5 N here: the engine has to stay within 3 x that band, and its neighbours in
+    """The one QP of this round's 819 200-QP soak (tests/tools/soak_parity.py 20000 200 10, profiles/r04_parity_soak_1M.txt) where engine
+    and oracle part by more than the
+    1e-5 N bar: seed 20160, QP 0 -- 100 iterations, rho adapted down to 5e-4, same iteration count and status, 4.4e-5 N between the two.
+    On this QP the double-precision
+    oracle's own answer moves by up to 2.9e-5 N when one word of x0 moves by one ulp (the x87 build: 7e-9 N -- the QP is not ill-posed,
+    double precision is noisy on it),
+    so no two double-precision implementations of the iterate sequence can be held to 1e-5 N here: the engine has to stay within 3 x that
+    band, and its neighbours in
     the batch within the usual bar."""
     sc = scen.config3_random_flat(nb=4096, seed=20160, param_set="gazebo")
     with _engine(pkg, sc, 4096, warm_start=0) as eng:

@@ -219,6 +219,26 @@ def test_leg_state_restatement(oracle):
         assert np.allclose(o["foot_vel_world"].reshape(4, 3), vr @ R.T + vel, atol=1e-13)
 
 
+def test_ekf_fma_variant_stays_within_rounding_of_the_pinned_restatement(oracle, scen):
+    """orc_ekf_step is the pinned restatement (multiply + add, held to the reference's compiled source by tests/test_ref_pin.py); orc_ekf_step_fma is the
+    device kernel's arithmetic (the four dense products of S/A1BasicEKF.cpp:134-139 accumulate by fma) and is no ground truth of its own: over 20 robots x 200
+    ticks it stays within 1e-11 m / m/s of the pinned one (measured 1.1e-13: one rounding per term of 18- and 28-term dot products, on a contracting filter)."""
+    rng = np.random.default_rng(51)
+    base = np.array([0.18, 0.13, -0.3, 0.18, -0.13, -0.3, -0.18, 0.13, -0.3, -0.18, -0.13, -0.3])
+    worst = 0.0
+    for rob in range(20):
+        s0 = oracle.ekf_state(); s1 = oracle.ekf_state()
+        for t in range(200):
+            mm = 1 if (t > 3 and rng.random() < 0.8) else 0
+            e = rng.normal(0, 0.05, 2); R = scen.rot_zyx(e[0], e[1], rng.uniform(-3, 3)).reshape(9)
+            fk = base + rng.normal(0, 0.01, 12); fv = rng.normal(0, 0.3, 12); acc = np.array([0, 0, 9.81]) + rng.normal(0, 0.3, 3); w = rng.normal(0, 0.3, 3); ff = rng.uniform(0, 160, 4)
+            p0, v0, e0 = oracle.ekf_step(s0, 0.0025, mm, ff, R, acc, w, fk, fv, assume_flat_ground=rob % 2)
+            p1, v1, e1 = oracle.ekf_step(s1, 0.0025, mm, ff, R, acc, w, fk, fv, assume_flat_ground=rob % 2, fma=True)
+            worst = max(worst, np.abs(p0 - p1).max(), np.abs(v0 - v1).max())
+            assert (e0 == e1).all()
+    assert 0.0 < worst <= 1e-11, worst   # (> 0: the two variants really are different arithmetics)
+
+
 def test_ekf_restatement(oracle):
     """N4c oracle vs an independent numpy Kalman update (numpy.linalg.solve for the two S^-1 products) over a 120-tick sequence"""
     rng = np.random.default_rng(13)
