@@ -51,14 +51,17 @@ __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     constexpr bool kTwin = twin_rows(H, MODE, ROWS);
     if constexpr (fused_quad_rows(H, MODE, ROWS)) {   // one QP per wavefront, horizon a multiple of 4: the four rows share it as a quad (RowSolver<.., QUAD>)
-        const int64_t bq = static_cast<int64_t>(blockIdx.x);
+        // a.order (warm-started ticks of a known batch, see solve_device_impl): workgroup k takes the QP that was k-th most expensive in the previous tick -- the chip
+        // runs a batch of 2 x the resident rows in two rounds, and a 50-iteration QP that starts in the second one is a tail of a whole 25-iteration segment
+        const int64_t bq = a.order ? static_cast<int64_t>(a.order[blockIdx.x]) : static_cast<int64_t>(blockIdx.x);
         solve_row_with<H, MODE, false, true, UPD, true, CLK>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(bq)); }, a1mpc_lds, CLK ? a.clk + bq * kTickStages : nullptr);
         return;
     }
     const int row = kTwin ? (static_cast<int>(threadIdx.x) >> 4) & 1 : static_cast<int>(threadIdx.x) >> 4;
     if (kTwin && row >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
-    const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
-    if (b >= a.n) return;  // row-uniform (a twin leaves with its main row): the other rows of the wave keep all their DPP sources
+    const int64_t slot = static_cast<int64_t>(blockIdx.x) * ROWS + row;
+    if (slot >= a.n) return;  // row-uniform (a twin leaves with its main row): the other rows of the wave keep all their DPP sources
+    const int64_t b = a.order ? static_cast<int64_t>(a.order[slot]) : slot;
     solve_row_with<H, MODE, false, kTwin, UPD, false, CLK>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE,
                                                            CLK ? a.clk + b * kTickStages : nullptr);
 }
@@ -110,8 +113,8 @@ __global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a
     if constexpr (CLK) c1 = row_clock();
     S.template solve<UPD>();
     if constexpr (CLK) c2 = row_clock();
-    if constexpr (UPD) S.write_outputs(make_io<H, kModeMpc>(a, b), carry_of<H>(a, b));
-    else S.write_outputs(make_io<H, kModeMpc>(a, b));
+    if constexpr (UPD) S.write_outputs(make_io_sched<H, kModeMpc>(a, b), carry_of<H>(a, b));   // (make_io_sched: the output stage's joint torques read the contacts)
+    else S.write_outputs(make_io_sched<H, kModeMpc>(a, b));
     if constexpr (CLK) S.store_tick_stages(a.clk ? a.clk + b * kTickStages : nullptr, c0, cF, cR, c1, c2, row_clock());
 }
 
@@ -327,6 +330,25 @@ __global__ __launch_bounds__(256) void a1mpc_form_kernel(const FormArgs a) {
 }
 
 __global__ void a1mpc_noop_kernel() {}
+
+// a1mpc_control_tick_device: the 22-number tick record of a1mpc_solve_batch_ticks assembled on the device from the arrays the stages before it left there
+// (S/A1RobotControl.cpp:452-456, :470-488 read exactly these fields of A1CtrlStates): one thread per robot, 22 coalesced-enough words in, 22 out
+struct PackArgs {
+    int32_t n;
+    const double *euler, *pos, *ang_vel, *lin_vel, *euler_d, *lin_vel_d, *ang_vel_d, *pos_d_z;
+    double* tick;
+};
+__global__ __launch_bounds__(256) void a1mpc_tick_pack_kernel(const PackArgs a) {
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (b >= a.n) return;
+    double* t = a.tick + b * 22;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        t[k] = a.euler[b * 3 + k]; t[3 + k] = a.pos[b * 3 + k]; t[6 + k] = a.ang_vel[b * 3 + k]; t[9 + k] = a.lin_vel[b * 3 + k];
+        t[12 + k] = a.euler_d[b * 3 + k]; t[15 + k] = a.lin_vel_d[b * 3 + k]; t[18 + k] = a.ang_vel_d[b * 3 + k];
+    }
+    t[21] = a.pos_d_z[b];
+}
 
 // ---- N2a: update_plan (S/A1RobotControl.cpp:148-202), one lane per (robot, leg) ------------------------------------------------
 // Element-wise and HBM-bound: ~0.5 KB in + 0.3 KB out per robot.  The four lanes of a robot read the same robot-level words
@@ -1081,6 +1103,9 @@ struct a1mpc_handle_s {
     double* d_carry = nullptr;     // warm_start = 2 (the reference's update path): n x Carry<H>::STRIDE, allocated on first use
     hipEvent_t ev_order = nullptr;
     hipEvent_t ev_mid = nullptr;   // between the set-up kernel and the persistent ADMM kernel of the split pipeline (a1mpc_last_stage_ms)
+    hipEvent_t ev_tick0 = nullptr, ev_tick1 = nullptr;   // around a1mpc_control_tick_device
+    bool tick_timed = false, tick_fused = false, tick_km_set = false;
+    double tick_km[3] = {0, 0, 0};
     bool staged = false;
     bool busy = false;
     // carried OSQP workspace (warm start)
@@ -1095,6 +1120,7 @@ struct a1mpc_handle_s {
     uint8_t* d_contact_steps = nullptr;  // general path: n x 4H per-step contacts
     double* d_ct_state = nullptr;  // N2b filter state of every robot (allocated on first use)
     double* d_ekf_state = nullptr;  // N4c Kalman filter state of every robot (allocated on first use)
+    double* d_tickrec = nullptr;    // a1mpc_control_tick_device: n x 22 tick records + 3 doubles (km_foot), allocated on first use
     // staging of the element-wise entry points (N2a, N2b, N3), allocated on first use: 64 / 96 doubles and 16 bytes per robot
     double *d_aux_in = nullptr, *d_aux_out = nullptr;
     uint8_t* d_aux_u8 = nullptr;
@@ -1172,6 +1198,7 @@ struct ContactArgs {
     const double *gait_counter, *foot_force, *foot_pos_abs, *root_pos_z;
     const uint8_t* plan_contacts;
     double* pitch_d;
+    int32_t z_stride, pitch_stride;   // doubles between two robots' root_pos_z / root_euler_d pitch (1: arrays of their own; 3: element 2 of root_pos / element 1 of root_euler_d, a1mpc_control_tick_device)
     uint8_t* contacts;
     double *recent_out, *terrain_out;
     const double* recent_in;  // terrain-only entry: foot_pos_recent_contact comes from the caller instead of the handle's contact state
@@ -1279,7 +1306,7 @@ __device__ __forceinline__ void contact_terrain_robot(const ContactArgs& a, cons
     for (int r = 0; r < 3; ++r) co[r] = P3[3 * r + 0] * rhs[0] + P3[3 * r + 1] * rhs[1] + P3[3 * r + 2] * rhs[2];
     const double s0 = co[1], s1 = co[2], s2 = -1.0;
     double terrain_angle = 0.0;                                                             // :339-352
-    if (a.root_pos_z[b] > 0.1) {
+    if (a.root_pos_z[b * a.z_stride] > 0.1) {
         const double angle_cos = fabs(0.0 * s0 + 0.0 * s1 + 1.0 * s2) / (sqrt(0.0 * 0.0 + 0.0 * 0.0 + 1.0 * 1.0) * sqrt(s0 * s0 + s1 * s1 + s2 * s2));
         const double v = acos(angle_cos);
         const int count = st->rb.count, head = st->rb.head;
@@ -1294,7 +1321,7 @@ __device__ __forceinline__ void contact_terrain_robot(const ContactArgs& a, cons
     if (terrain_angle > 0.5) terrain_angle = 0.5;
     if (terrain_angle < -0.5) terrain_angle = -0.5;
     const double F_R_diff = rc[2] + rc[5] - rc[8] - rc[11];                                // :355
-    if (a.use_terrain_adapt) a.pitch_d[b] = F_R_diff > 0.05 ? -terrain_angle : terrain_angle;  // :358-364
+    if (a.use_terrain_adapt) a.pitch_d[b * a.pitch_stride] = F_R_diff > 0.05 ? -terrain_angle : terrain_angle;  // :358-364
     a.terrain_out[b] = terrain_angle;
 }
 // One wavefront = 64 robots.  A lane that walks its own 384-byte record in HBM makes every load instruction touch 64 different lines (measured: 2.5 TB/s of algorithmic
@@ -1391,7 +1418,7 @@ a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_con
     A1_HIP(hipMemcpyAsync(d_pd, root_euler_d_pitch, N * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(d_pc, plan_contacts, N * 4, hipMemcpyHostToDevice, s));
     ContactArgs a;
-    a.recent_in = nullptr;
+    a.recent_in = nullptr; a.z_stride = 1; a.pitch_stride = 1;
     a.n = n; a.counter_per_swing = cfg->counter_per_swing; a.foot_force_low = cfg->foot_force_low; a.use_terrain_adapt = cfg->use_terrain_adapt;
     contact_state_pointers(h, a); a.gait_counter = d_gc; a.foot_force = d_ff; a.foot_pos_abs = d_fp; a.root_pos_z = d_z; a.plan_contacts = d_pc;
     a.pitch_d = d_pd; a.contacts = d_ct; a.recent_out = d_rec; a.terrain_out = d_ta;
@@ -1884,47 +1911,11 @@ __global__ __launch_bounds__(256) void a1mpc_torque_kernel(const TorqueArgs a) {
     if (b >= a.n) return;
     double* out = a.tau + b * 12 + 3 * leg;
     if (!a.active[b]) { out[0] = 0.0; out[1] = 0.0; out[2] = 0.0; return; }   // :294-295
-    const double* Jp = a.Jb + b * 36 + 9 * leg;
-    double J[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) J[k] = Jp[k];
-    double t0, t1, t2;
-    if (a.contacts[b * 4 + leg]) {                                             // :303  J' (-f)
-        const double f0 = -a.grf[b * 12 + 3 * leg + 0], f1 = -a.grf[b * 12 + 3 * leg + 1], f2 = -a.grf[b * 12 + 3 * leg + 2];
-        t0 = J[0] * f0 + J[1] * f1 + J[2] * f2;
-        t1 = J[3] * f0 + J[4] * f1 + J[5] * f2;
-        t2 = J[6] * f0 + J[7] * f1 + J[8] * f2;
-    } else {                                                                    // :306-307  PartialPivLU, Eigen's unblocked_lu order
-        double b0 = a.km[0] * a.fkin[b * 12 + 3 * leg + 0], b1 = a.km[1] * a.fkin[b * 12 + 3 * leg + 1], b2 = a.km[2] * a.fkin[b * 12 + 3 * leg + 2];
-        // k = 0: pivot = first largest |J(r,0)|
-        int r0 = 0; double big = fabs(J[0]);
-        if (fabs(J[1]) > big) { big = fabs(J[1]); r0 = 1; }
-        if (fabs(J[2]) > big) { big = fabs(J[2]); r0 = 2; }
-        if (big != 0.0) {
-            if (r0 == 1) { double t; t = J[0]; J[0] = J[1]; J[1] = t; t = J[3]; J[3] = J[4]; J[4] = t; t = J[6]; J[6] = J[7]; J[7] = t; }
-            if (r0 == 2) { double t; t = J[0]; J[0] = J[2]; J[2] = t; t = J[3]; J[3] = J[5]; J[5] = t; t = J[6]; J[6] = J[8]; J[8] = t; }
-            J[1] /= J[0]; J[2] /= J[0];
-        }
-        J[4] -= J[1] * J[3]; J[7] -= J[1] * J[6]; J[5] -= J[2] * J[3]; J[8] -= J[2] * J[6];
-        // k = 1
-        int r1 = 1; big = fabs(J[4]);
-        if (fabs(J[5]) > big) { big = fabs(J[5]); r1 = 2; }
-        if (big != 0.0) {
-            if (r1 == 2) { double t; t = J[1]; J[1] = J[2]; J[2] = t; t = J[4]; J[4] = J[5]; J[5] = t; t = J[7]; J[7] = J[8]; J[8] = t; }
-            J[5] /= J[4];
-        }
-        J[8] -= J[5] * J[7];
-        // P b, L y = P b, U x = y
-        if (r0 == 1) { const double t = b0; b0 = b1; b1 = t; }
-        if (r0 == 2) { const double t = b0; b0 = b2; b2 = t; }
-        if (r1 == 2) { const double t = b1; b1 = b2; b2 = t; }
-        b1 -= J[1] * b0;
-        b2 -= J[2] * b0 + J[5] * b1;
-        b2 /= J[8];
-        b1 -= J[7] * b2; b1 /= J[4];
-        b0 -= J[3] * b1 + J[6] * b2; b0 /= J[0];
-        t0 = b0; t1 = b1; t2 = b2;
-    }
+    const double* gr = a.grf + b * 12 + 3 * leg;
+    const double* fk = a.fkin + b * 12 + 3 * leg;
+    double t[3];
+    leg_joint_torque(a.Jb + b * 36 + 9 * leg, a.contacts[b * 4 + leg] != 0, gr[0], gr[1], gr[2], a.km[0] * fk[0], a.km[1] * fk[1], a.km[2] * fk[2], t);   // (a1mpc_solver.hpp: shared with the MPC kernels' output stage)
+    const double t0 = t[0], t1 = t[1], t2 = t[2];
     const double* g = a.tg + b * 12 + 3 * leg;
     const double v0 = t0 + g[0], v1 = t1 + g[1], v2 = t2 + g[2];                // :311
     if (!isnan(v0)) out[0] = v0;                                                // :314-317
@@ -2080,7 +2071,7 @@ a1mpc_status a1mpc_contact_terrain_batch_device(a1mpc_handle h, const a1mpc_cont
                     foot_pos_recent_contact_out && terrain_angle_out);
     if (a1mpc_status st = ensure_contact_state(h, s); st != A1MPC_OK) return st;
     ContactArgs a;
-    a.recent_in = nullptr;
+    a.recent_in = nullptr; a.z_stride = 1; a.pitch_stride = 1;
     a.n = n; a.counter_per_swing = cfg->counter_per_swing; a.foot_force_low = cfg->foot_force_low; a.use_terrain_adapt = cfg->use_terrain_adapt;
     contact_state_pointers(h, a); a.gait_counter = gait_counter; a.foot_force = foot_force; a.foot_pos_abs = foot_pos_abs; a.root_pos_z = root_pos_z;
     a.plan_contacts = plan_contacts; a.pitch_d = root_euler_d_pitch; a.contacts = contacts_out; a.recent_out = foot_pos_recent_contact_out; a.terrain_out = terrain_angle_out;
@@ -2157,7 +2148,7 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     void* ptrs[] = {h->d_tab, h->d_tab1, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_aux, h->d_Rz, h->d_contact, h->d_grf,
-                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_ekf_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8, h->d_foot_steps, h->d_contact_steps, h->d_prep_gen, h->d_carry, h->d_clk};
+                    h->d_u, h->d_iters, h->d_status, h->d_nfact, h->d_wx, h->d_wy, h->d_rho, h->d_prep, h->d_counter, h->d_in, h->d_out, h->d_order, h->d_cost, h->d_ct_state, h->d_ekf_state, h->d_aux_in, h->d_aux_out, h->d_aux_u8, h->d_foot_steps, h->d_contact_steps, h->d_prep_gen, h->d_carry, h->d_clk, h->d_tickrec};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
@@ -2165,6 +2156,8 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_order) (void)hipEventDestroy(h->ev_order);
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
+    if (h->ev_tick0) (void)hipEventDestroy(h->ev_tick0);
+    if (h->ev_tick1) (void)hipEventDestroy(h->ev_tick1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -2199,6 +2192,8 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     A1_TRY(hipEventCreate(&h->ev1));
     A1_TRY(hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming));
     A1_TRY(hipEventCreate(&h->ev_mid));
+    A1_TRY(hipEventCreate(&h->ev_tick0));
+    A1_TRY(hipEventCreate(&h->ev_tick1));
     std::vector<double> tab(2 * H * H), tab1(2);
     fill_gamma_beta_table(H, tab.data());
     fill_gamma_beta_table(1, tab1.data());
@@ -2450,10 +2445,26 @@ a1mpc_status a1mpc_set_schedule(a1mpc_handle h, int32_t history) {
     return A1MPC_OK;
 }
 
+// N3 in the MPC kernels' output stage (a1mpc_control_tick_device): the device arrays compute_joint_torques reads and writes; `fused` reports whether the launch that
+// solve_device_impl chose carries the stage (the fused / latency kernels do; the split pipeline's persistent rows do not -- the caller then launches the torque kernel)
+struct TorqueFuse {
+    const uint8_t* active;
+    const double *J, *fkin, *tg, *km;
+    double* tau;
+    bool fused;
+};
+// A1MPC_WARM_ORDER=1: launch the fused kernel of a warm-started tick in the order of the previous tick's per-QP cost (longest first).  OFF by default: measured and
+// lost (profiles/r05_warm_tick_order.txt: 4096 x h10 ticks 0.335 -> 0.348 ms, update path 0.362 -> 0.373) -- a warm tick has no tail worth ordering for (3 of 4096
+// QPs need a second 25-iteration segment and the two rounds of the resident rows absorb them), and the order kernel in front of the tick costs its ~12 us.
+static bool warm_order_enabled() {
+    static const bool on = [] { const char* e = getenv("A1MPC_WARM_ORDER"); return e && !strcmp(e, "1"); }();
+    return on;
+}
 static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d_tick, const double* d_x0, const double* d_x_ref,
                                       const double* d_R_world, const double* d_foot_abs, const uint8_t* d_contact,
                                       double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out,
-                                      void* hip_stream, int32_t foot_stride = 0, int32_t contact_stride = 0, const double* d_yaw_A = nullptr) {
+                                      void* hip_stream, int32_t foot_stride = 0, int32_t contact_stride = 0, const double* d_yaw_A = nullptr, TorqueFuse* tq = nullptr) {
+    if (tq) tq->fused = false;
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
     if (n < 0 || (!d_tick && (!d_x0 || !d_x_ref)) || !d_R_world || !d_foot_abs || !d_contact || !d_grf_body_out)
         return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
@@ -2523,12 +2534,25 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     // for the queue to balance, and the fused kernel -- set-up and solve in one launch, no hand-off through memory, no kernel boundary for the rows to idle at --
     // wins up to a few rounds of the resident rows (4096 x h10: 0.397 -> 0.350 ms per tick, 8192: 0.665 -> 0.652; profiles/r04_warm_ticks_fused_vs_split.txt).
     // Same results bit for bit (the pipelines are tested against each other).  A1MPC_WARM_FUSED=0 keeps the split pipeline (A/B runs).
-    if (split && h->cfg.warm_start != 0 && h->hint_n == n && pipeline_mode() == 0 && warm_fused_enabled() && n <= warm_fused_max(h->cfg.horizon)) split = false;
+    bool warm_fused = false;
+    if (split && h->cfg.warm_start != 0 && h->hint_n == n && pipeline_mode() == 0 && warm_fused_enabled() && n <= warm_fused_max(h->cfg.horizon)) { split = false; warm_fused = true; }
     const bool hints = h->schedule && split && n >= kScheduleMinBatch;
     a.order = hints ? h->d_order : nullptr;
     a.cost = hints ? h->d_cost : nullptr;
     a.predict = (hints && h->hint_n != n) ? 1 : 0;  // first solve of this batch size: order by the set-up kernel's guess instead
     A1_HIP(hipEventRecord(h->ev0, s));
+    // Round 5 trial (opt-in, see warm_order_enabled): the fused kernel of a warm-started tick launches its workgroups in the order of the previous tick's per-QP
+    // cost, longest first (the cost buffer holds it: hint_n == n; the fused kernel records this tick's).  Scheduling only: every result is bit-identical in any order.
+    if (warm_fused && h->schedule && n >= kScheduleMinBatch && n > kCoopMaxBatch && warm_order_enabled()) {
+        RoctxRange range("a1mpc order");
+        hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, s, static_cast<int>(n), static_cast<const int32_t*>(h->d_cost), h->d_order);
+        A1_HIP(hipGetLastError());
+        a.order = h->d_order; a.cost = h->d_cost;
+    }
+    if (tq != nullptr && !split && h->cfg.horizon > 1) {   // the fused / latency kernels write the joint torques in their output stage
+        a.tq_active = tq->active; a.tq_J = tq->J; a.tq_fkin = tq->fkin; a.tq_tg = tq->tg; a.tq_km = tq->km; a.tq_tau = tq->tau;
+        tq->fused = true;
+    }
     h->staged = split;
     h->clk_n = 0; h->clk_tick = false;
     if (h->profiling && h->cfg.horizon > 1 && a.contact_stride == 0) {
@@ -2560,6 +2584,128 @@ a1mpc_status a1mpc_solve_batch_ticks_device(a1mpc_handle h, int32_t n, const dou
     if (!d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
     return solve_device_impl(h, n, d_tick, nullptr, nullptr, d_R_world, d_foot_abs, d_contact, d_grf_body_out, d_u_full_out, d_iters_out,
                              d_status_out, hip_stream);
+}
+
+void a1mpc_default_tick_params(a1mpc_tick_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    a1mpc_default_gait_config(&p->gait);
+    a1mpc_default_contact_config(&p->contact);
+    p->control_dt = 0.0025; p->assume_flat_ground = 1;
+    const double kp[3] = {300.0, 400.0, 400.0}, kd[3] = {8.0, 8.0, 8.0}, km[3] = {0.1, 0.1, 0.04};   // kp_foot / kd_foot / km_foot of the Gazebo parameter set (config/gazebo_a1_mpc.yaml)
+    std::memcpy(p->kp_foot, kp, sizeof kp); std::memcpy(p->kd_foot, kd, sizeof kd); std::memcpy(p->km_foot, km, sizeof km);
+    const double ox = 0.1805, oy = 0.047, d = 0.0838, lt = 0.21, lc = 0.21;   // A1 leg geometry, S/GazeboA1ROS.cpp:20-50 (leg_offset_x/y, motor_offset, upper / lower leg length)
+    const double sx[4] = {1, 1, -1, -1}, sy[4] = {1, -1, 1, -1};
+    for (int i = 0; i < 4; ++i) { double* f = p->rho_fix + 5 * i; f[0] = sx[i] * ox; f[1] = sy[i] * oy; f[2] = sy[i] * d; f[3] = lt; f[4] = lc; }
+}
+
+// One control tick of n robots in ONE call, device-resident: the reference's chain  joint-state callback (leg FK / Jacobians, S/GazeboA1ROS.cpp:264-279)
+// -> A1BasicEKF::update_estimation (S/A1BasicEKF.cpp:70-163) -> update_plan (S/A1RobotControl.cpp:148-202) -> generate_swing_legs_ctrl (:204-287, with the contact logic and
+// the terrain fit of compute_grf :335-376) -> compute_grf (:446-562) -> compute_joint_torques (:289-319), as driven by S/MainGazebo.cpp:47-119 -- six kernels, the tick-record
+// pack and the MPC launch back to back on one stream, no host round trip, and N3 inside the MPC kernel's output stage whenever the tick runs the fused / latency kernel
+// (every warm-started tick of a known batch).  Bit-identical to chaining the seven *_device entry points.
+a1mpc_status a1mpc_control_tick_device(a1mpc_handle h, const a1mpc_tick_params* p, const a1mpc_tick_buffers* bf, int32_t n, void* hip_stream) {
+    if (!h || !p || !bf) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle / params / buffers");
+    if (n < 0) return fail(A1MPC_ERR_INVALID_ARGUMENT, "negative n");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (h->cfg.horizon < 2) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "tick records need horizon >= 2");
+    const void* need[] = {bf->joint_pos, bf->joint_vel, bf->R_world, bf->R_z, bf->root_euler, bf->root_ang_vel, bf->imu_acc, bf->imu_ang_vel, bf->foot_force, bf->movement_mode,
+                          bf->mpc_active, bf->root_lin_vel_d, bf->root_ang_vel_d, bf->root_pos_d_z, bf->gait_counter_speed, bf->torques_gravity, bf->gait_counter, bf->foot_pos_start,
+                          bf->foot_pos_rel_last_time, bf->foot_pos_target_last_time, bf->root_euler_d, bf->joint_torques, bf->root_pos, bf->root_lin_vel, bf->estimated_contacts,
+                          bf->plan_contacts, bf->contacts, bf->foot_pos_rel, bf->j_foot_blocks, bf->foot_vel_rel, bf->foot_pos_abs, bf->foot_pos_target_rel, bf->foot_pos_cur,
+                          bf->foot_forces_kin, bf->foot_pos_recent_contact, bf->terrain_angle, bf->grf};
+    for (const void* q : need) if (!q) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null device pointer in a1mpc_tick_buffers (only the optional outputs may be null)");
+    if (!(p->control_dt > 0)) return fail(A1MPC_ERR_INVALID_ARGUMENT, "control_dt <= 0");
+    if (n == 0) return A1MPC_OK;
+    A1_HIP(hipSetDevice(h->device));
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->stream;
+    A1_ORDER(h, s);
+    const size_t N = n;
+    if (!h->d_tickrec) A1_HIP(hipMalloc(&h->d_tickrec, (static_cast<size_t>(h->max_batch) * 22 + 3) * sizeof(double)));
+    if (!h->d_ekf_state) {
+        A1_HIP(hipMalloc(&h->d_ekf_state, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double)));
+        A1_HIP(hipMemsetAsync(h->d_ekf_state, 0, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double), s));
+    }
+    if (a1mpc_status st = ensure_contact_state(h, s); st != A1MPC_OK) return st;
+    A1_HIP(hipEventRecord(h->ev_tick0, s));   // (ev_tick0 .. ev_tick1 = the whole tick; ev0 .. ev1 = the MPC launch, as after every solve)
+    {   // 1. leg state (uses the previous estimate of root_pos / root_lin_vel for the world-frame outputs, like the reference's callback)
+        LegArgs a;
+        a.n = n;
+        std::memcpy(a.rho_fix, p->rho_fix, sizeof a.rho_fix); std::memcpy(a.rho_opt, p->rho_opt, sizeof a.rho_opt);
+        a.q = bf->joint_pos; a.qd = bf->joint_vel; a.R = bf->R_world; a.pos = bf->root_pos; a.vel = bf->root_lin_vel; a.rel = bf->foot_pos_rel; a.Jb = bf->j_foot_blocks;
+        a.vrel = bf->foot_vel_rel; a.pabs = bf->foot_pos_abs; a.vabs = bf->foot_vel_abs; a.pworld = bf->foot_pos_world; a.vworld = bf->foot_vel_world;
+        hipLaunchKernelGGL(a1mpc_leg_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    }
+    {   // 2. EKF
+        EkfArgs a;
+        a.n = n; a.dt = p->control_dt; a.flat = p->assume_flat_ground; a.state = h->d_ekf_state; a.mode = bf->movement_mode; a.ff = bf->foot_force; a.R = bf->R_world;
+        a.acc = bf->imu_acc; a.w = bf->imu_ang_vel; a.fk = bf->foot_pos_rel; a.fv = bf->foot_vel_rel; a.pos_out = bf->root_pos; a.vel_out = bf->root_lin_vel;
+        a.ec_out = bf->estimated_contacts;
+        hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((N + 1) / 2)), dim3(64), 0, s, a);
+    }
+    {   // 3. update_plan
+        PlanArgs a;
+        a.g = p->gait; a.n = n; a.movement_mode = bf->movement_mode; a.gait_counter = bf->gait_counter; a.gait_counter_speed = bf->gait_counter_speed;
+        a.root_lin_vel = bf->root_lin_vel; a.Rz = bf->R_z; a.Rw = bf->R_world; a.root_pos = bf->root_pos; a.root_lin_vel_d = bf->root_lin_vel_d;
+        a.plan_contacts = bf->plan_contacts; a.rel = bf->foot_pos_target_rel; a.abs_ = bf->foot_pos_target_abs; a.world = bf->foot_pos_target_world;
+        hipLaunchKernelGGL(a1mpc_plan_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    }
+    {   // 4. swing legs
+        SwingArgs a;
+        a.n = n; a.counter_per_swing = p->gait.counter_per_swing; a.dt = p->control_dt;
+        for (int k = 0; k < 3; ++k) { a.kp[k] = p->kp_foot[k]; a.kd[k] = p->kd_foot[k]; }
+        a.Rz = bf->R_z; a.foot_pos_abs = bf->foot_pos_abs; a.gait_counter = bf->gait_counter; a.target_rel = bf->foot_pos_target_rel; a.start = bf->foot_pos_start;
+        a.rel_last = bf->foot_pos_rel_last_time; a.target_last = bf->foot_pos_target_last_time; a.cur_out = bf->foot_pos_cur; a.kin_out = bf->foot_forces_kin;
+        hipLaunchKernelGGL(a1mpc_swing_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+    }
+    {   // 5. contacts / terrain: root_pos[2] and root_euler_d[1] are read / written in place (strides of 3)
+        ContactArgs a;
+        a.recent_in = nullptr; a.z_stride = 3; a.pitch_stride = 3;
+        a.n = n; a.counter_per_swing = p->contact.counter_per_swing; a.foot_force_low = p->contact.foot_force_low; a.use_terrain_adapt = p->contact.use_terrain_adapt;
+        contact_state_pointers(h, a); a.gait_counter = bf->gait_counter; a.foot_force = bf->foot_force; a.foot_pos_abs = bf->foot_pos_abs; a.root_pos_z = bf->root_pos + 2;
+        a.plan_contacts = bf->plan_contacts; a.pitch_d = bf->root_euler_d + 1; a.contacts = bf->contacts; a.recent_out = bf->foot_pos_recent_contact; a.terrain_out = bf->terrain_angle;
+        launch_contact_terrain(a, s);
+    }
+    {   // 6. the tick record
+        PackArgs a;
+        a.n = n; a.euler = bf->root_euler; a.pos = bf->root_pos; a.ang_vel = bf->root_ang_vel; a.lin_vel = bf->root_lin_vel; a.euler_d = bf->root_euler_d;
+        a.lin_vel_d = bf->root_lin_vel_d; a.ang_vel_d = bf->root_ang_vel_d; a.pos_d_z = bf->root_pos_d_z; a.tick = h->d_tickrec;
+        hipLaunchKernelGGL(a1mpc_tick_pack_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+    }
+    A1_HIP(hipGetLastError());
+    double* d_km = h->d_tickrec + static_cast<size_t>(h->max_batch) * 22;
+    if (std::memcmp(h->tick_km, p->km_foot, sizeof h->tick_km) != 0 || !h->tick_km_set) {   // km_foot travels once (and again when it changes): the output stage reads it from device memory
+        std::memcpy(h->tick_km, p->km_foot, sizeof h->tick_km); h->tick_km_set = true;
+        std::memcpy(h->h_pin, p->km_foot, 3 * sizeof(double));   // (a pinned source; the handle's pinned block is free: this entry point takes no host arrays)
+        A1_HIP(hipMemcpyAsync(d_km, h->h_pin, 3 * sizeof(double), hipMemcpyHostToDevice, s));
+        A1_HIP(hipStreamSynchronize(s));   // (once: the pinned words may be overwritten by a later host-pointer call)
+    }
+    // 7. MPC from the tick records + N3 in its output stage
+    TorqueFuse tq{bf->mpc_active, bf->j_foot_blocks, bf->foot_forces_kin, bf->torques_gravity, d_km, bf->joint_torques, false};
+    if (a1mpc_status st = solve_device_impl(h, n, h->d_tickrec, nullptr, nullptr, bf->R_world, bf->foot_pos_abs, bf->contacts, bf->grf, nullptr, bf->iters, bf->status, s, 0, 0, nullptr, &tq);
+        st != A1MPC_OK) return st;
+    if (!tq.fused) {   // the split pipeline solved this tick (a first tick, a batch beyond the fused kernel's range): N3 as its own launch
+        TorqueArgs a;
+        a.n = n; a.active = bf->mpc_active; a.contacts = bf->contacts; a.Jb = bf->j_foot_blocks; a.grf = bf->grf; a.fkin = bf->foot_forces_kin; a.tg = bf->torques_gravity; a.tau = bf->joint_torques;
+        a.km[0] = p->km_foot[0]; a.km[1] = p->km_foot[1]; a.km[2] = p->km_foot[2];
+        hipLaunchKernelGGL(a1mpc_torque_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+        A1_HIP(hipGetLastError());
+    }
+    h->tick_fused = tq.fused;
+    A1_HIP(hipEventRecord(h->ev_tick1, s));
+    h->tick_timed = true;
+    A1_MARK(h, s);
+    return A1MPC_OK;
+}
+a1mpc_status a1mpc_last_control_tick_ms(a1mpc_handle h, float* ms_out, int32_t* torques_fused_out) {
+    if (!h || !ms_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle/out");
+    if (!h->tick_timed) return fail(A1MPC_ERR_INVALID_ARGUMENT, "no control tick has been launched through this handle");
+    A1_HIP(hipSetDevice(h->device));
+    A1_HIP(hipEventSynchronize(h->ev_tick1));
+    A1_HIP(hipEventElapsedTime(ms_out, h->ev_tick0, h->ev_tick1));
+    if (torques_fused_out) *torques_fused_out = h->tick_fused ? 1 : 0;
+    return A1MPC_OK;
 }
 
 a1mpc_status a1mpc_solve_batch_ticks(a1mpc_handle h, int32_t n, const double* tick, const double* R_world, const double* foot_abs,
@@ -2674,7 +2820,7 @@ a1mpc_status a1mpc_terrain_batch(a1mpc_handle h, int32_t use_terrain_adapt, int3
     A1_HIP(hipMemcpyAsync(d_pd, root_euler_d_pitch, N * sizeof(double), hipMemcpyHostToDevice, s));
     ContactArgs a;
     std::memset(&a, 0, sizeof a);
-    a.n = n; a.use_terrain_adapt = use_terrain_adapt; contact_state_pointers(h, a); a.root_pos_z = d_z; a.pitch_d = d_pd;
+    a.n = n; a.use_terrain_adapt = use_terrain_adapt; contact_state_pointers(h, a); a.root_pos_z = d_z; a.pitch_d = d_pd; a.z_stride = 1; a.pitch_stride = 1;
     a.recent_in = d_rec; a.recent_out = nullptr; a.terrain_out = d_ta;
     launch_contact_terrain(a, s);
     A1_HIP(hipGetLastError());

@@ -86,7 +86,61 @@ struct ProblemIO {
     int32_t* status;         // out or null
     int32_t* nfact;          // out or null
     double* carry;           // Carry<H>::STRIDE in/out or null: what the reference's persistent OSQP workspace still holds of the previous tick (warm_start = 2, the UPDATE path)
+    int32_t* cost;           // fused kernel only, or null: this QP's cost record (iterations + 10 factor passes), the next tick's launch order (a1mpc_solve_kernel)
+    // N3 in the output stage (a1mpc_control_tick_device; fused / latency kernels only): compute_joint_torques (S/A1RobotControl.cpp:289-319) of this robot, or tq_tau = null
+    const uint8_t* tq_active;  // 1: 0 while the reference's mpc_init_counter < 10
+    const double* tq_J;        // 36: the four diagonal 3x3 blocks of j_foot, column-major each
+    const double* tq_fkin;     // 12: foot_forces_kin
+    const double* tq_tg;       // 12: torques_gravity
+    const double* tq_km;       // 3: km_foot (device copy inside the handle)
+    double* tq_tau;            // 12 in/out: joint_torques (NaN results keep the previous value)
 };
+
+// compute_joint_torques for ONE leg (S/A1RobotControl.cpp:297-311): stance: tau = J'(-f_grf); swing: tau = J^-1 (km .* f_kin) by partial-pivot LU in Eigen's operation
+// order (unblocked_lu).  No FMA contraction: bit-identical to the reference's C++ arithmetic (and to the oracle, which is compiled the same way).  Shared by the
+// stand-alone torque kernel and the MPC kernels' output stage.
+A1_DEV void leg_joint_torque(const double* __restrict__ Jp, bool contact, double g0, double g1, double g2, double k0, double k1, double k2, double (&t)[3]) {
+#pragma clang fp contract(off)
+    double J[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) J[k] = Jp[k];
+    if (contact) {                                                             // :303  J' (-f)
+        const double f0 = -g0, f1 = -g1, f2 = -g2;
+        t[0] = J[0] * f0 + J[1] * f1 + J[2] * f2;
+        t[1] = J[3] * f0 + J[4] * f1 + J[5] * f2;
+        t[2] = J[6] * f0 + J[7] * f1 + J[8] * f2;
+    } else {                                                                    // :306-307  PartialPivLU, Eigen's unblocked_lu order
+        double b0 = k0, b1 = k1, b2 = k2;
+        // k = 0: pivot = first largest |J(r,0)|
+        int r0 = 0; double big = fabs(J[0]);
+        if (fabs(J[1]) > big) { big = fabs(J[1]); r0 = 1; }
+        if (fabs(J[2]) > big) { big = fabs(J[2]); r0 = 2; }
+        if (big != 0.0) {
+            if (r0 == 1) { double x; x = J[0]; J[0] = J[1]; J[1] = x; x = J[3]; J[3] = J[4]; J[4] = x; x = J[6]; J[6] = J[7]; J[7] = x; }
+            if (r0 == 2) { double x; x = J[0]; J[0] = J[2]; J[2] = x; x = J[3]; J[3] = J[5]; J[5] = x; x = J[6]; J[6] = J[8]; J[8] = x; }
+            J[1] /= J[0]; J[2] /= J[0];
+        }
+        J[4] -= J[1] * J[3]; J[7] -= J[1] * J[6]; J[5] -= J[2] * J[3]; J[8] -= J[2] * J[6];
+        // k = 1
+        int r1 = 1; big = fabs(J[4]);
+        if (fabs(J[5]) > big) { big = fabs(J[5]); r1 = 2; }
+        if (big != 0.0) {
+            if (r1 == 2) { double x; x = J[1]; J[1] = J[2]; J[2] = x; x = J[4]; J[4] = J[5]; J[5] = x; x = J[7]; J[7] = J[8]; J[8] = x; }
+            J[5] /= J[4];
+        }
+        J[8] -= J[5] * J[7];
+        // P b, L y = P b, U x = y
+        if (r0 == 1) { const double x = b0; b0 = b1; b1 = x; }
+        if (r0 == 2) { const double x = b0; b0 = b2; b2 = x; }
+        if (r1 == 2) { const double x = b1; b1 = b2; b2 = x; }
+        b1 -= J[1] * b0;
+        b2 -= J[2] * b0 + J[5] * b1;
+        b2 /= J[8];
+        b1 -= J[7] * b2; b1 /= J[4];
+        b0 -= J[3] * b1 + J[6] * b2; b0 /= J[0];
+        t[0] = b0; t[1] = b1; t[2] = b2;
+    }
+}
 
 // ---- compile-time helpers ----------------------------------------------------------------------
 #define A1_CV(x) (std::remove_cv_t<std::remove_reference_t<decltype(x)>>::value)  // value of an integral_constant argument
@@ -949,10 +1003,11 @@ struct RowSolver {
                     // warm start (the code of warm_start = 1 below and in the first iteration) from those values
                     const double* cr = io.carry;
                     const double cp = cr[CR::C];
-                    const double Dp = act ? cr[CR::D + t * 12 + ci] : 1.0, E0p = act ? cr[CR::E0 + t * 12 + ci] : 1.0, E1p = (act && comp < 2) ? cr[CR::E1 + t * 12 + ci] : 1.0;
+                    const double Dp = act ? cr[CR::D + t * 12 + ci] : 1.0, E0p = act ? cr[CR::E0 + t * 12 + ci] : 1.0;   // (E1' == E0' on the fx / fy lanes: see the Ruiz passes)
                     xh[t] = act ? xh[t] / Dp : 0.0;
-                    wh0[t] = act ? (cp / E0p) * wh0[t] : 0.0;
-                    wh1[t] = (act && comp < 2) ? (cp / E1p) * wh1[t] : 0.0;
+                    const double ce = cp / E0p;
+                    wh0[t] = act ? ce * wh0[t] : 0.0;
+                    wh1[t] = (act && comp < 2) ? ce * wh1[t] : 0.0;
                     epsv[t] = 0.0;   // (they travel like the update path's y^: through the hand-off record, with an uncorrected c g)
                 } else if (upd) {
                     // The carried SCALED iterates (x_s, z_s, y_s) are used as they are, i.e. read in the NEW scaling:  x0 = D (x / D'), z0 = (E' / E) z,
@@ -963,12 +1018,14 @@ struct RowSolver {
                     // the true c g comes back after iteration 1, see load_prepared / advance).
                     const double* cr = io.carry;
                     const double cp = cr[CR::C];
-                    const double Dp = act ? cr[CR::D + t * 12 + ci] : 1.0, E0p = act ? cr[CR::E0 + t * 12 + ci] : 1.0, E1p = (act && comp < 2) ? cr[CR::E1 + t * 12 + ci] : 1.0;
+                    const double Dp = act ? cr[CR::D + t * 12 + ci] : 1.0, E0p = act ? cr[CR::E0 + t * 12 + ci] : 1.0;
                     const double zp0 = act ? cr[CR::Z0 + t * 12 + ci] : 0.0, zp1 = (act && comp < 2) ? cr[CR::Z1 + t * 12 + ci] : 0.0;
                     xh[t] = act ? D[t] * (xh[t] / Dp) : 0.0;
                     const double cr_c = cp / csc;
-                    const double y0 = act ? cr_c * (E0[t] / E0p) * wh0[t] : 0.0, y1 = (act && comp < 2) ? cr_c * (E1[t] / E1p) * wh1[t] : 0.0;
-                    const double zc0 = act ? (E0p / E0[t]) * zp0 : 0.0, zc1 = (act && comp < 2) ? (E1p / E1[t]) * zp1 : 0.0;
+                    // E1 == E0 and E1' == E0' bit for bit on the fx / fy lanes (my two rows share their scaling: see the Ruiz passes): one pair of quotients serves both rows
+                    const double eup = E0[t] / E0p, edn = E0p / E0[t];
+                    const double y0 = act ? cr_c * eup * wh0[t] : 0.0, y1 = (act && comp < 2) ? cr_c * eup * wh1[t] : 0.0;
+                    const double zc0 = act ? edn * zp0 : 0.0, zc1 = (act && comp < 2) ? edn * zp1 : 0.0;
                     const double xz = quad_perm<2, 2, 2, 2>(xh[t]);
                     const double z00 = comp == 2 ? xh[t] : fma(mu, xz, xh[t]), z01 = fma(-mu, xz, xh[t]);
                     const double d0 = act ? zc0 - z00 : 0.0, d1 = (act && comp < 2) ? zc1 - z01 : 0.0;
@@ -1917,9 +1974,31 @@ struct RowSolver {
             const double f = nanout ? nanv : xh[0];
             const double f0 = quad_perm<0, 0, 0, 0>(f), f1 = quad_perm<1, 1, 1, 1>(f), f2 = quad_perm<2, 2, 2, 2>(f);
             const bool bad = (f0 != f0) || (f1 != f1) || (f2 != f2);
+            double gout = 0.0;
             if (wr) {  // R' f (S/A1RobotControl.cpp:558-561); non-finite solution -> zeros + status
                 const double gb = io.R[0 * 3 + comp] * f0 + io.R[1 * 3 + comp] * f1 + io.R[2 * 3 + comp] * f2;
-                io.grf[3 * quad + comp] = bad ? 0.0 : gb;
+                gout = bad ? 0.0 : gb;
+                io.grf[3 * quad + comp] = gout;
+            }
+            if constexpr (MODE == kModeMpc && !GEN && H > 1) {
+                // N3 in the output stage (a1mpc_control_tick_device): the joint torques of my leg from the GRF this lane has just written -- the three lanes
+                // of a leg evaluate the leg's torque (each all of it, from the leg's three force components) and store their own component; a null tq_tau compiles to nothing
+                // in the persistent rows (make_io leaves it null) and is one uniform branch in the fused / latency kernels
+                if (io.tq_tau != nullptr) {
+                    const double g0 = quad_perm<0, 0, 0, 0>(gout), g1 = quad_perm<1, 1, 1, 1>(gout), g2 = quad_perm<2, 2, 2, 2>(gout);
+                    if (wr) {
+                        double* out = io.tq_tau + 3 * quad + comp;
+                        if (!*io.tq_active) {                                          // :294-295
+                            *out = 0.0;
+                        } else {
+                            double tq[3];
+                            const double* fk = io.tq_fkin + 3 * quad;
+                            leg_joint_torque(io.tq_J + 9 * quad, io.contact[quad] != 0, g0, g1, g2, io.tq_km[0] * fk[0], io.tq_km[1] * fk[1], io.tq_km[2] * fk[2], tq);
+                            const double v = tq[comp == 0 ? 0 : (comp == 1 ? 1 : 2)] + io.tq_tg[3 * quad + comp];   // :311
+                            if (!(v != v)) *out = v;                                   // :314-317 (a NaN keeps the previous value)
+                        }
+                    }
+                }
             }
         }
         static_for<HS>([&](auto T) {
@@ -1984,6 +2063,10 @@ struct BatchArgs {
     int32_t predict;  // the set-up kernel writes its cost guess to `cost` (first solve of a batch: no history to order the queue by)
     double* carry;    // warm_start = 2 (update path): n x Carry<H>::STRIDE, or null
     long long* clk;   // profiling instantiations (a1mpc_set_profiling): n x kTickStages shader-clock cycles per QP (layout below), or null
+    // N3 in the output stage of the fused / latency kernels (a1mpc_control_tick_device), or tq_tau = null: per-robot records like the arrays above
+    const uint8_t* tq_active;
+    const double *tq_J, *tq_fkin, *tq_tg, *tq_km;
+    double* tq_tau;
 };
 // per-QP stage record of the profiling instantiations: the split pipeline's persistent rows fill FACTOR / ITER / CHECK, the fused and the latency kernel all of it
 enum : int { kClkForm = 0, kClkRuiz = 1, kClkHandoff = 2, kClkFactor = 3, kClkIter = 4, kClkCheck = 5, kClkOut = 6, kClkTotal = 7, kTickStages = 8 };
@@ -2008,6 +2091,8 @@ A1_DEV ProblemIO make_io(const BatchArgs& a, int64_t b) {
     io.status = a.status ? a.status + b : nullptr;
     io.nfact = a.nfact ? a.nfact + b : nullptr;
     io.carry = nullptr;  // (set by make_io_sched for the set-ups; the ADMM side gets the pointer where it writes, see carry_of)
+    io.cost = nullptr; io.tq_tau = nullptr;   // (make_io_sched: the fused / latency kernels only -- the persistent rows keep the code they had)
+    io.tq_active = nullptr; io.tq_J = nullptr; io.tq_fkin = nullptr; io.tq_tg = nullptr; io.tq_km = nullptr;
     return io;
 }
 template <int H>
@@ -2021,6 +2106,10 @@ A1_DEV ProblemIO make_io_sched(const BatchArgs& a, int64_t b) {
     io.contact = a.contact + b * (a.contact_stride ? 4 * H : 4);
     io.foot_stride = 0; io.contact_stride = a.contact_stride; io.yaw_A = nullptr;
     io.carry = carry_of<H>(a, b);
+    io.cost = a.cost ? a.cost + b : nullptr;
+    if (a.tq_tau != nullptr) {
+        io.tq_tau = a.tq_tau + b * 12; io.tq_active = a.tq_active + b; io.tq_J = a.tq_J + b * 36; io.tq_fkin = a.tq_fkin + b * 12; io.tq_tg = a.tq_tg + b * 12; io.tq_km = a.tq_km;
+    }
     return io;
 }
 
@@ -2161,8 +2250,12 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
         if constexpr (CLK) c1 = row_clock();
         S.template solve<UPD>();
         if constexpr (CLK) c2 = row_clock();
-        if constexpr (UPD) { const ProblemIO& io_ = make_io_(); S.write_outputs(io_, io_.carry); }
-        else S.write_outputs(make_io_());
+        {
+            const ProblemIO& io_ = make_io_();
+            if constexpr (UPD) S.write_outputs(io_, io_.carry);
+            else S.write_outputs(io_);
+            if (io_.cost != nullptr && S.lead()) *io_.cost = S.iter + 10 * S.nfact;   // the next tick's launch order (longest first: a1mpc_solve_kernel)
+        }
         if constexpr (CLK) S.store_tick_stages(clk, c0, cF, cR, c1, c2, row_clock());
     } else {
         RowSolver<H, MODE> S(P, tab, lds);

@@ -40,7 +40,23 @@ class ContactConfig(C.Structure):  # a1mpc_contact_config
     _fields_ = [("counter_per_swing", C.c_double), ("foot_force_low", C.c_double), ("use_terrain_adapt", C.c_int32)]
 
 
-EXPORTS = ["a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_get_workspace_z", "a1mpc_get_workspace_scaling", "a1mpc_last_warm_start_mode", "a1mpc_set_profiling", "a1mpc_last_stage_cycles", "a1mpc_last_tick_stage_cycles", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
+class TickParams(C.Structure):  # a1mpc_tick_params
+    _fields_ = [("gait", GaitConfig), ("contact", ContactConfig), ("control_dt", C.c_double), ("assume_flat_ground", C.c_int32),
+                ("kp_foot", C.c_double * 3), ("kd_foot", C.c_double * 3), ("km_foot", C.c_double * 3), ("rho_fix", C.c_double * 20), ("rho_opt", C.c_double * 12)]
+
+
+TICK_BUFFER_FIELDS = ("joint_pos", "joint_vel", "R_world", "R_z", "root_euler", "root_ang_vel", "imu_acc", "imu_ang_vel", "foot_force", "movement_mode", "mpc_active",
+                      "root_lin_vel_d", "root_ang_vel_d", "root_pos_d_z", "gait_counter_speed", "torques_gravity", "gait_counter", "foot_pos_start", "foot_pos_rel_last_time",
+                      "foot_pos_target_last_time", "root_euler_d", "joint_torques", "root_pos", "root_lin_vel", "estimated_contacts", "plan_contacts", "contacts", "foot_pos_rel",
+                      "j_foot_blocks", "foot_vel_rel", "foot_pos_abs", "foot_vel_abs", "foot_pos_world", "foot_vel_world", "foot_pos_target_rel", "foot_pos_target_abs",
+                      "foot_pos_target_world", "foot_pos_cur", "foot_forces_kin", "foot_pos_recent_contact", "terrain_angle", "grf", "iters", "status")
+
+
+class TickBuffers(C.Structure):  # a1mpc_tick_buffers: device pointers, in the header's order
+    _fields_ = [(k, C.c_void_p) for k in TICK_BUFFER_FIELDS]
+
+
+EXPORTS = ["a1mpc_default_tick_params", "a1mpc_control_tick_device", "a1mpc_last_control_tick_ms", "a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_get_workspace_z", "a1mpc_get_workspace_scaling", "a1mpc_last_warm_start_mode", "a1mpc_set_profiling", "a1mpc_last_stage_cycles", "a1mpc_last_tick_stage_cycles", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error", "a1mpc_build_info", "a1mpc_pipeline_create", "a1mpc_pipeline_submit_device", "a1mpc_pipeline_submit",
@@ -119,6 +135,10 @@ def load_library(path=None):
     lib.a1mpc_set_profiling.argtypes = [vp, i32]; lib.a1mpc_set_profiling.restype = C.c_int
     lib.a1mpc_last_stage_cycles.argtypes = [vp, dp, C.POINTER(C.c_int32)]; lib.a1mpc_last_stage_cycles.restype = C.c_int
     lib.a1mpc_last_warm_start_mode.argtypes = [vp, C.POINTER(C.c_int32)]; lib.a1mpc_last_warm_start_mode.restype = C.c_int
+    if path == _build.LIB_PATH or hasattr(lib, "a1mpc_control_tick_device"):   # (round 5)
+        lib.a1mpc_default_tick_params.argtypes = [C.POINTER(TickParams)]; lib.a1mpc_default_tick_params.restype = None
+        lib.a1mpc_control_tick_device.argtypes = [vp, C.POINTER(TickParams), C.POINTER(TickBuffers), i32, vp]; lib.a1mpc_control_tick_device.restype = C.c_int
+        lib.a1mpc_last_control_tick_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]; lib.a1mpc_last_control_tick_ms.restype = C.c_int
     if path == _build.LIB_PATH or hasattr(lib, "a1mpc_last_tick_stage_cycles"):  # (round 5; an older build bound by hand for an A/B may lack it)
         lib.a1mpc_last_tick_stage_cycles.argtypes = [vp, dp, C.POINTER(C.c_int32)]; lib.a1mpc_last_tick_stage_cycles.restype = C.c_int
     lib.a1mpc_set_schedule.argtypes = [vp, i32]; lib.a1mpc_set_schedule.restype = C.c_int
@@ -272,6 +292,15 @@ class Engine:
         c = np.zeros(3); q = C.c_int32(0)
         _check(self.lib, self.lib.a1mpc_last_stage_cycles(self._h, _dp(c), C.byref(q)), "a1mpc_last_stage_cycles")
         return dict(factor=float(c[0]), iterate=float(c[1]), check=float(c[2]), qps=int(q.value))
+
+    def control_tick_device(self, params, buffers, n, stream=None):
+        """a1mpc_control_tick_device: one whole control tick of n robots (device pointers in a TickBuffers), asynchronous on `stream`"""
+        _check(self.lib, self.lib.a1mpc_control_tick_device(self._h, C.byref(params), C.byref(buffers), int(n), C.c_void_p(stream) if stream else None), "a1mpc_control_tick_device")
+
+    def last_control_tick_ms(self):
+        ms = C.c_float(0); fused = C.c_int32(0)
+        _check(self.lib, self.lib.a1mpc_last_control_tick_ms(self._h, C.byref(ms), C.byref(fused)), "a1mpc_last_control_tick_ms")
+        return float(ms.value), bool(fused.value)
 
     TICK_STAGES = ("formation", "ruiz", "handoff", "factor", "iterate", "check", "outputs", "total")
 

@@ -102,7 +102,7 @@ def cpu_baseline(pkg, sc, budget_s=15.0):
             "mean_iters": float(r["iters"].mean()), "single_thread_cold_solves_per_s": 1.0 / ts, "single_thread_warm_ticks": single}, r
 
 
-def latency_probe(pkg, nticks=1500, mode=1):
+def latency_probe(pkg, nticks=1500, mode=1, horizon=10, cpp_ticks=10000):
     """BASELINE configs[1]: batch 1, trot, warm-started sequential ticks through the host-pointer ABI (PCIe inclusive).  10 000 ticks from the
     C++ harness (tests/cpp/latency_harness, no Python in the loop) when it has been built; the Python loop below otherwise.
     mode 1: fresh set-up + osqp_warm_start every tick; mode 2: the reference's per-tick OSQP update path on its persistent solver (S/A1RobotControl.cpp:533-540:
@@ -112,12 +112,12 @@ def latency_probe(pkg, nticks=1500, mode=1):
     if os.path.exists(exe):
         try:
             env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("LOCAL_RANK", "0")) if os.environ.get("LOCAL_RANK") else None
-            r = subprocess.run([exe, "10000", "0", str(mode)], capture_output=True, text=True, timeout=120, env=env)
+            r = subprocess.run([exe, str(cpp_ticks), "0", str(mode), str(horizon)], capture_output=True, text=True, timeout=120, env=env)
             if r.returncode == 0:
                 return json.loads(r.stdout)
         except Exception:
             pass
-    sc = pkg.scenarios.config2_trot_sequence(nticks)
+    sc = pkg.scenarios.config2_trot_sequence(nticks, horizon=horizon)
     cfg = pkg.make_config(sc["params"], sc["horizon"], warm_start=mode)
     import gc
     lat = np.zeros(nticks)
@@ -131,7 +131,7 @@ def latency_probe(pkg, nticks=1500, mode=1):
         finally:
             gc.enable()
     lat = lat[50:] * 1e3
-    return {"warm_start": mode, "workload": "config2 trot, h=10, batch 1, warm start, host pointers in/out", "ticks": int(len(lat)),
+    return {"warm_start": mode, "workload": f"config2 trot, h={horizon}, batch 1, warm start, host pointers in/out", "horizon": horizon, "ticks": int(len(lat)),
             "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)), "max_ms": float(lat.max())}
 
 
@@ -181,7 +181,7 @@ def _pcie_inclusive(pkg, scs, cfg, n, local, steps, NB):
             "a1mpc_pipeline_submit_depth2": {"ms_per_batch": pipe_ms, "solves_per_s": n / pipe_ms * 1e3, "bit_identical_to_synchronous": bool(same)}}
 
 
-def batch_sweep(pkg, local, sizes=(1024, 16384, 65536)):
+def batch_sweep(pkg, local, sizes=(1, 16, 256, 1024, 4096, 16384, 65536)):
     """Extra information (not `value`): the same workload generator at other batch sizes of BASELINE's 1..65536 range."""
     import torch
     out = {}
@@ -198,8 +198,8 @@ def batch_sweep(pkg, local, sizes=(1024, 16384, 65536)):
             for _ in range(4):
                 eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, it, stt, stream=st.cuda_stream)
                 ms.append(eng.last_kernel_ms())
-        out[str(n)] = {"kernel_ms": float(np.median(ms[1:])), "solves_per_s": n / (float(np.median(ms[1:])) * 1e-3)}
-    return out
+        out[str(n)] = {"kernel_ms": float(np.median(ms[1:])), "solves_per_s": n / (float(np.median(ms[1:])) * 1e-3), "mean_iters": float(it.float().mean().item())}
+    return out   # (cold first solves through one handle on one stream: north_star's "batch 1 ... 65536")
 
 
 def warm_tick_probe(pkg, local, n=4096, ticks=12, mode=1):
@@ -265,68 +265,52 @@ def warm_tick_stage_counters(pkg, local, n=4096, mode=1, ticks=8):
 
 
 def full_tick_probe(pkg, local, n=4096, ticks=10):
-    """Extra information (not `value`): one whole control tick per robot chained on the GPU through the *_device entry points -- leg state,
-    EKF, gait plan, swing legs, contacts / terrain, warm-started MPC (tick records), joint torques -- sensors resident in HBM, one stream."""
+    """Extra information (not `value`): one whole control tick per robot in ONE C call (a1mpc_control_tick_device, round 5) -- leg state, EKF, gait plan, swing legs,
+    contacts / terrain, warm-started MPC from tick records, joint torques in the MPC kernel's output stage -- sensors resident in HBM, one stream, HIP events around
+    `ticks` ticks.  (Until round 4 the same stages were seven entry points chained from Python with the tick record assembled by torch: 0.577 ms.)"""
     import ctypes as C
     import torch
-    dev = torch.device("cuda", local); st = torch.cuda.Stream(device=dev); sp = C.c_void_p(st.cuda_stream)
-    rng = np.random.default_rng(7); scen = pkg.scenarios
+    dev = torch.device("cuda", local); st = torch.cuda.Stream(device=dev)
+    rng = np.random.default_rng(7); scen = pkg.scenarios; E = pkg.engine
     P = scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS
     cfg = pkg.make_config(P, HORIZON, warm_start=1)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    ptr = lambda t: C.c_void_p(t.data_ptr())
-    dp_ = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-    km = np.array([0.1, 0.1, 0.04]); kp = np.array([300.0, 400.0, 400.0]); kd = np.array([8.0, 8.0, 8.0]); opt = np.zeros((4, 3))
     eul = rng.normal(0, 0.03, (n, 3)); eul[:, 2] = rng.uniform(-1, 1, n)
-    q0 = np.tile([0.0, 0.8, -1.6], (n, 4)) + rng.normal(0, 0.05, (n, 12))
-    d = {k: T(v) for k, v in dict(q=q0, qd=rng.normal(0, 0.3, (n, 12)), R=scen.rot_zyx(eul[:, 0], eul[:, 1], eul[:, 2]).reshape(n, 9),
-                                  Rz=scen.rot_zyx(0 * eul[:, 0], 0 * eul[:, 0], eul[:, 2]).reshape(n, 9), acc=np.array([0, 0, 9.81]) + rng.normal(0, 0.1, (n, 3)),
-                                  w=rng.normal(0, 0.1, (n, 3)), ff=rng.uniform(20, 120, (n, 4)), mm=np.ones(n, np.uint8), vd=np.c_[rng.uniform(-0.3, 0.3, (n, 2)), np.zeros(n)],
-                                  wd=np.c_[np.zeros((n, 2)), rng.uniform(-0.3, 0.3, n)], spd=np.full((n, 4), 2.0), tg=rng.normal(0, 0.3, (n, 12)), act=np.ones(n, np.uint8),
-                                  eul=eul, z0=np.zeros((n, 3)), gc=np.tile([0.0, 120.0, 120.0, 0.0], (n, 1)), start=np.zeros((n, 12)), rl=np.zeros((n, 12)), tl=np.zeros((n, 12)),
-                                  pitch=np.zeros(n), tau=np.zeros((n, 12))).items()}
-    o = {k: torch.zeros((n, m), dtype=torch.float64, device=dev) for k, m in dict(rel=12, Jb=36, vrel=12, pabs=12, vabs=12, pw=12, vw=12, pos=3, vel=3, trel=12, tabs=12, tworld=12,
-                                                                                 cur=12, kin=12, rec=12, grf=12, tick=22).items()}
-    u8 = {k: torch.zeros((n, 4), dtype=torch.uint8, device=dev) for k in ("ec", "pc", "ct")}
-    ta = torch.zeros(n, dtype=torch.float64, device=dev); pz = torch.zeros(n, dtype=torch.float64, device=dev)
-    it = torch.zeros(n, dtype=torch.int32, device=dev); stt = torch.zeros(n, dtype=torch.int32, device=dev)
+    inp = dict(joint_pos=np.tile([0.0, 0.8, -1.6], (n, 4)) + rng.normal(0, 0.05, (n, 12)), joint_vel=rng.normal(0, 0.3, (n, 12)),
+               R_world=scen.rot_zyx(eul[:, 0], eul[:, 1], eul[:, 2]).reshape(n, 9), R_z=scen.rot_zyx(0 * eul[:, 0], 0 * eul[:, 0], eul[:, 2]).reshape(n, 9), root_euler=eul,
+               root_ang_vel=rng.normal(0, 0.1, (n, 3)), imu_acc=np.array([0, 0, 9.81]) + rng.normal(0, 0.1, (n, 3)), imu_ang_vel=rng.normal(0, 0.1, (n, 3)),
+               foot_force=rng.uniform(20, 120, (n, 4)), movement_mode=np.ones(n, np.uint8), mpc_active=np.ones(n, np.uint8),
+               root_lin_vel_d=np.c_[rng.uniform(-0.3, 0.3, (n, 2)), np.zeros(n)], root_ang_vel_d=np.c_[np.zeros((n, 2)), rng.uniform(-0.3, 0.3, n)], root_pos_d_z=np.full(n, 0.3),
+               gait_counter_speed=np.full((n, 4), 2.0), torques_gravity=rng.normal(0, 0.3, (n, 12)),
+               gait_counter=np.tile([0.0, 120.0, 120.0, 0.0], (n, 1)), root_euler_d=np.c_[np.zeros((n, 2)), eul[:, 2]])
+    f64 = dict(foot_pos_start=12, foot_pos_rel_last_time=12, foot_pos_target_last_time=12, joint_torques=12, root_pos=3, root_lin_vel=3, foot_pos_rel=12, j_foot_blocks=36,
+               foot_vel_rel=12, foot_pos_abs=12, foot_vel_abs=12, foot_pos_world=12, foot_vel_world=12, foot_pos_target_rel=12, foot_pos_target_abs=12, foot_pos_target_world=12,
+               foot_pos_cur=12, foot_forces_kin=12, foot_pos_recent_contact=12, terrain_angle=1, grf=12)
+    d = {k: T(v) for k, v in inp.items()}
+    d.update({k: torch.zeros((n, m), dtype=torch.float64, device=dev) for k, m in f64.items()})
+    d.update({k: torch.zeros((n, 4), dtype=torch.uint8, device=dev) for k in ("estimated_contacts", "plan_contacts", "contacts")})
+    d.update({k: torch.zeros(n, dtype=torch.int32, device=dev) for k in ("iters", "status")})
+    bf = E.TickBuffers()
+    for k in E.TICK_BUFFER_FIELDS:
+        setattr(bf, k, d[k].data_ptr())
     with pkg.Engine(cfg, n, local) as eng:
-        L, H_ = eng.lib, eng._h
-        gait = pkg.engine.GaitConfig(); L.a1mpc_default_gait_config(C.byref(gait)); cc = pkg.engine.ContactConfig(); L.a1mpc_default_contact_config(C.byref(cc))
-        fix = np.ascontiguousarray(eng.A1_RHO_FIX)
-
-        def tick():
-            rcs = [L.a1mpc_leg_state_batch_device(H_, n, ptr(d["q"]), ptr(d["qd"]), ptr(d["R"]), ptr(d["z0"]), ptr(d["z0"]), dp_(fix), dp_(opt), ptr(o["rel"]), ptr(o["Jb"]), ptr(o["vrel"]),
-                                                  ptr(o["pabs"]), ptr(o["vabs"]), ptr(o["pw"]), ptr(o["vw"]), sp),
-                   L.a1mpc_ekf_update_batch_device(H_, n, 0.0025, 1, ptr(d["mm"]), ptr(d["ff"]), ptr(d["R"]), ptr(d["acc"]), ptr(d["w"]), ptr(o["rel"]), ptr(o["vrel"]), ptr(o["pos"]),
-                                                   ptr(o["vel"]), ptr(u8["ec"]), sp),
-                   L.a1mpc_update_plan_batch_device(H_, C.byref(gait), n, ptr(d["mm"]), ptr(d["gc"]), ptr(d["spd"]), ptr(o["vel"]), ptr(d["Rz"]), ptr(d["R"]), ptr(o["pos"]), ptr(d["vd"]),
-                                                    ptr(u8["pc"]), ptr(o["trel"]), ptr(o["tabs"]), ptr(o["tworld"]), sp),
-                   L.a1mpc_swing_legs_batch_device(H_, n, 120.0, 0.0025, ptr(d["Rz"]), ptr(o["pabs"]), ptr(d["gc"]), ptr(o["trel"]), dp_(kp), dp_(kd), ptr(d["start"]), ptr(d["rl"]),
-                                                   ptr(d["tl"]), ptr(o["cur"]), ptr(o["kin"]), sp)]
-            with torch.cuda.stream(st):
-                pz.copy_(o["pos"][:, 2])
-            rcs.append(L.a1mpc_contact_terrain_batch_device(H_, C.byref(cc), n, ptr(d["gc"]), ptr(u8["pc"]), ptr(d["ff"]), ptr(o["pabs"]), ptr(pz), ptr(d["pitch"]), ptr(u8["ct"]),
-                                                            ptr(o["rec"]), ptr(ta), sp))
-            with torch.cuda.stream(st):  # the 22-number tick record of a1mpc_solve_batch_ticks, assembled on the device
-                o["tick"][:, 0:3] = d["eul"]; o["tick"][:, 3:6] = o["pos"]; o["tick"][:, 6:9] = d["w"]; o["tick"][:, 9:12] = o["vel"]
-                o["tick"][:, 12] = 0.0; o["tick"][:, 13] = d["pitch"]; o["tick"][:, 14] = d["eul"][:, 2]; o["tick"][:, 15:18] = d["vd"]; o["tick"][:, 18:21] = d["wd"]; o["tick"][:, 21] = 0.3
-            rcs.append(L.a1mpc_solve_batch_ticks_device(H_, n, ptr(o["tick"]), ptr(d["R"]), ptr(o["pabs"]), ptr(u8["ct"]), ptr(o["grf"]), None, ptr(it), ptr(stt), sp))
-            rcs.append(L.a1mpc_joint_torques_batch_device(H_, n, ptr(d["act"]), ptr(u8["ct"]), ptr(o["Jb"]), ptr(o["grf"]), ptr(o["kin"]), dp_(km), ptr(d["tg"]), ptr(d["tau"]), sp))
-            assert not any(rcs), rcs
-
+        prm = E.TickParams(); eng.lib.a1mpc_default_tick_params(C.byref(prm))
         for _ in range(4):
-            tick()
+            eng.control_tick_device(prm, bf, n, stream=st.cuda_stream)
         st.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record(st)
         for _ in range(ticks):
-            tick()
+            eng.control_tick_device(prm, bf, n, stream=st.cuda_stream)
         e1.record(st)
         st.synchronize()
         ms = e0.elapsed_time(e1) / ticks
-    return {"workload": "4096 robots: leg state + EKF + gait plan + swing legs + contacts/terrain + warm-started MPC (h=10) + joint torques per tick, device-resident",
-            "ms_per_tick": ms, "robot_ticks_per_s": n / (ms * 1e-3), "mean_mpc_iters": float(it.float().mean().item())}
+        last_ms, fused = eng.last_control_tick_ms()
+        mpc_ms = eng.last_kernel_ms()
+    return {"workload": f"{n} robots: leg state + EKF + gait plan + swing legs + contacts/terrain + warm-started MPC (h=10, tick records) + joint torques per tick, device-resident, "
+                        "ONE C call per tick (a1mpc_control_tick_device)", "ms_per_tick": ms, "robot_ticks_per_s": n / (ms * 1e-3), "last_tick_ms_by_its_own_events": last_ms,
+            "mpc_launch_ms_of_the_last_tick": mpc_ms, "joint_torques_in_the_mpc_output_stage": bool(fused), "mean_mpc_iters": float(d["iters"].float().mean().item()),
+            "solved_frac": float((d["status"] == 1).float().mean().item())}
 
 
 def other_config_rooflines(pkg, local, steps=4):
@@ -670,6 +654,14 @@ def main():
     elapsed = time.perf_counter() - t0
     pipe_ms = e0.elapsed_time(e1) / args.steps   # device time per batch with `depth` batches in flight
     pipe_out0 = tuple(t_.cpu().numpy().copy() for t_ in outs[0])   # what the timed region left for batch 0 (GRFs, iterations, status): the parity block checks THESE
+    # continuity with the round-3 protocol (ADVICE r4 / VERDICT r4 item 7): the same K steps behind only 8 untimed launches, the GPU idle for a second before them
+    # (round 3 timed exactly that; round 4 moved to 32 untimed launches, which is worth ~5 % through the clocks alone).  Reported beside `value`, never instead of it.
+    value8 = None
+    if world == 1 and os.environ.get("A1_BENCH_VALUE8", "1") != "0":
+        time.sleep(1.0)
+        region(8); pipe.wait(); torch.cuda.synchronize()
+        t8 = time.perf_counter(); region(args.steps); torch.cuda.synchronize()
+        value8 = n * args.steps / (time.perf_counter() - t8)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -768,6 +760,13 @@ def main():
                                  "the kernels really issue (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 x live lanes from the static PMC profile) -- the hardware fraction"},
         }
         out["stage_counters"] = stage
+        # ---- scalars a reader of this line needs first; repeated inside `roofline` and `config`, which the driver keeps whole
+        admm_ms = stage.get("solve_ms") if isinstance(stage, dict) else None   # the persistent ADMM kernel (+ the ~6 us order kernel) of one launch alone, by HIP events
+        admm_flops = flops_b[0] - n * float(pkg.algorithmic_flops(h, np.zeros(1, np.int64), np.zeros(1, np.int64))[0])   # F(h, iters, nfact) minus F_cond: what the ADMM kernel itself owes
+        scal = {"value_with_8_untimed_launches": value8, "single_stream_solves_per_s": n / (single_ms * 1e-3), "single_stream_frac": flops / (single_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "admm_kernel_ms": admm_ms, "admm_kernel_model_frac": (admm_flops / (admm_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if admm_ms else None,
+                "admm_kernel_executed_frac": (pmc["executed_fp64_flops_admm_kernel"] / (admm_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if (admm_ms and pmc.get("executed_fp64_flops_admm_kernel")) else None}
+        out.update(scal); out["roofline"]["scalars"] = dict(scal)
         out["scheduling"] = {
             "mode": "value: first solves (no history; queue ordered by the set-up kernel's per-QP cost guess).  Beside it: plain index order, and "
                     "'history' = the same batch solved again right after itself with the queue in longest-first order of the previous solve "
@@ -805,10 +804,24 @@ def main():
             out["pcie_inclusive"] = pcie_inclusive_probe(pkg, scs, cfg, n, local)
             out["latency"] = latency_probe(pkg)
             out["latency_update_path"] = latency_probe(pkg, mode=2)   # warm_start = 2: the reference's operating point (its persistent OsqpEigen solver, update calls + solve per tick)
+            out["latency_update_path_h16"] = latency_probe(pkg, mode=2, horizon=16, cpp_ticks=4000)
+            out["latency_update_path_h20"] = latency_probe(pkg, mode=2, horizon=20, cpp_ticks=4000)
             out["throughput_by_batch"] = batch_sweep(pkg, local)
             out["warm_start_ticks"] = warm_tick_probe(pkg, local)
             out["warm_start_ticks_update_path"] = warm_tick_probe(pkg, local, mode=2)
+            out["stage_counters_warm"] = {f"{n_}_robots_mode{m_}": warm_tick_stage_counters(pkg, local, n=n_, mode=m_) for n_ in (4096, 1) for m_ in (1, 2)}
             out["full_control_tick"] = full_tick_probe(pkg, local)
+            meas = {"latency_p50_ms": out["latency"].get("p50_ms"), "latency_p99_ms": out["latency"].get("p99_ms"),
+                    "latency_update_path_p50_ms": out["latency_update_path"].get("p50_ms"), "latency_update_path_p99_ms": out["latency_update_path"].get("p99_ms"),
+                    "latency_update_path_h16_p50_p99_ms": [out["latency_update_path_h16"].get("p50_ms"), out["latency_update_path_h16"].get("p99_ms")],
+                    "latency_update_path_h20_p50_p99_ms": [out["latency_update_path_h20"].get("p50_ms"), out["latency_update_path_h20"].get("p99_ms")],
+                    "warm_tick_kernel_ms_4096_robots": out["warm_start_ticks"]["kernel_ms_per_tick"],
+                    "warm_tick_update_path_kernel_ms_4096_robots": out["warm_start_ticks_update_path"]["kernel_ms_per_tick"],
+                    "full_control_tick_ms_4096_robots": out["full_control_tick"]["ms_per_tick"],
+                    "throughput_by_batch_solves_per_s": {k: v["solves_per_s"] for k, v in out["throughput_by_batch"].items()},
+                    "other_shapes": [{"config": e["config"], "solves_per_s": e["solves_per_s"], "model_frac": e["frac"], "executed_fp64_frac": e.get("executed_fp64_frac"),
+                                      "issued_fp64_frac": e.get("issued_fp64_frac_repeats_included")} for e in out.get("roofline_other_configs", [])]}
+            out["config"]["measured_beside_value"] = meas   # (inside `config`: the driver's record keeps this block whole)
         if not args.no_cpu_baseline:
             out["cpu_baseline"], ref = cpu_baseline(pkg, sc)
             # parity of the timed workload against the checker (same leg: the oracle is only ever the baseline / the checker)

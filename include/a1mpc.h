@@ -341,6 +341,65 @@ a1mpc_status a1mpc_joint_torques_batch_device(a1mpc_handle h, int32_t n, const u
                                               double* d_joint_torques, void* hip_stream);
 
 /*
+ * One control tick of n robots in ONE call, device-resident (round 5; SURVEY 8(f) N1-N4 chained): what the reference runs per robot every 2.5 ms --
+ *   joint-state callback: leg FK / Jacobians (S/GazeboA1ROS.cpp:264-279)  ->  A1BasicEKF::update_estimation (S/A1BasicEKF.cpp:70-163)  ->  update_plan
+ *   (S/A1RobotControl.cpp:148-202)  ->  generate_swing_legs_ctrl (:204-287; its contact logic together with the terrain fit of compute_grf, :335-376, :566-582)  ->
+ *   compute_grf (:446-562: state packing, reference trajectory, QP formation, OSQP)  ->  compute_joint_torques (:289-319), driven by S/MainGazebo.cpp:47-119
+ * -- as six element-wise / filter kernels, a tick-record pack and the MPC launch back to back on `hip_stream` (NULL = the handle's), no host round trip.
+ * compute_joint_torques (N3) runs INSIDE the MPC kernel's output stage whenever the tick goes through the fused / latency kernel (every warm-started tick of a
+ * known batch, every batch of <= 256 robots): the lanes that have just written a leg's GRF evaluate tau = J'(-f) (stance) or J^-1 (km .* f_kin) (swing) for that leg;
+ * otherwise (a first tick, a batch beyond the fused kernel's range) it is one more launch.  Results are bit-identical to chaining the seven *_device entry points
+ * (a1mpc_leg_state_batch_device, a1mpc_ekf_update_batch_device, a1mpc_update_plan_batch_device, a1mpc_swing_legs_batch_device, a1mpc_contact_terrain_batch_device,
+ * a1mpc_solve_batch_ticks_device, a1mpc_joint_torques_batch_device) with root_pos[.][2] as root_pos_z and root_euler_d[.][1] as the terrain pitch.
+ * The filter states (EKF, contact / terrain windows) and the carried OSQP workspace live in the handle, indexed by the robot's position in the batch.
+ */
+typedef struct a1mpc_tick_params {
+    a1mpc_gait_config gait;           /* update_plan + counter_per_swing of the swing legs */
+    a1mpc_contact_config contact;     /* contact logic, terrain adaptation */
+    double control_dt;                /* EKF dt and the swing legs' velocity dt (2.5 ms, S/A1CtrlStates.h:332) */
+    int32_t assume_flat_ground;       /* A1BasicEKF ctor argument, S/A1BasicEKF.cpp:42-53 */
+    double kp_foot[3], kd_foot[3];    /* swing-leg PD, per axis (S/A1CtrlStates.h: kp_foot / kd_foot) */
+    double km_foot[3];                /* S/A1CtrlStates.h: km_foot */
+    double rho_fix[20], rho_opt[12];  /* leg geometry: 4 x [ox, oy, d, lt, lc] and 4 x 3 (S/GazeboA1ROS.cpp:20-50) */
+} a1mpc_tick_params;
+typedef struct a1mpc_tick_buffers {   /* DEVICE pointers, n robots each; layouts as in the per-stage entry points above */
+    /* inputs of this tick: sensors, attitude (the reference takes it from the IMU / simulator), commands */
+    const double *joint_pos, *joint_vel;                 /* n x 12 */
+    const double *R_world, *R_z;                         /* n x 9 row-major: root_rot_mat, root_rot_mat_z */
+    const double *root_euler, *root_ang_vel;             /* n x 3 (world frame), the tick record's [0:3] and [6:9] */
+    const double *imu_acc, *imu_ang_vel;                 /* n x 3 (the EKF's inputs) */
+    const double* foot_force;                            /* n x 4 */
+    const uint8_t* movement_mode;                        /* n */
+    const uint8_t* mpc_active;                           /* n: 0 while the reference's mpc_init_counter < 10 (S/A1RobotControl.cpp:294) */
+    const double *root_lin_vel_d, *root_ang_vel_d;       /* n x 3: commanded velocities (lin: body frame, rotated at S/A1RobotControl.cpp:470) */
+    const double* root_pos_d_z;                          /* n: commanded body height, root_pos_d[2] */
+    const double* gait_counter_speed;                    /* n x 4 */
+    const double* torques_gravity;                       /* n x 12 */
+    /* state carried from tick to tick by the caller (in/out) */
+    double* gait_counter;                                /* n x 4 */
+    double *foot_pos_start, *foot_pos_rel_last_time, *foot_pos_target_last_time;   /* n x 12 */
+    double* root_euler_d;                                /* n x 3: [1] is overwritten with +-terrain_angle when use_terrain_adapt (S/A1RobotControl.cpp:358-364) */
+    double* joint_torques;                               /* n x 12: NaN results keep the previous value (:314-317) */
+    double *root_pos, *root_lin_vel;                     /* n x 3: the estimate (in: the previous tick's, read by the leg stage's world-frame outputs; out: this tick's) */
+    /* outputs */
+    uint8_t *estimated_contacts, *plan_contacts, *contacts;   /* n x 4 */
+    double *foot_pos_rel, *j_foot_blocks, *foot_vel_rel, *foot_pos_abs;   /* n x 12 / n x 36 / n x 12 / n x 12 */
+    double *foot_vel_abs, *foot_pos_world, *foot_vel_world;               /* n x 12, each may be NULL */
+    double* foot_pos_target_rel;                                          /* n x 12 */
+    double *foot_pos_target_abs, *foot_pos_target_world;                  /* n x 12, each may be NULL */
+    double *foot_pos_cur, *foot_forces_kin;              /* n x 12 */
+    double* foot_pos_recent_contact;                     /* n x 12 */
+    double* terrain_angle;                               /* n */
+    double* grf;                                         /* n x 12: foot_forces_grf, body frame */
+    int32_t *iters, *status;                             /* n each, or NULL */
+} a1mpc_tick_buffers;
+void a1mpc_default_tick_params(a1mpc_tick_params* p);   /* the reference's Gazebo parameter set and the A1's leg geometry */
+a1mpc_status a1mpc_control_tick_device(a1mpc_handle h, const a1mpc_tick_params* params, const a1mpc_tick_buffers* buffers, int32_t n, void* hip_stream);
+/* duration of the handle's last a1mpc_control_tick_device on the device (HIP events around the whole tick; synchronises it) and whether its joint torques were
+ * written by the MPC kernel's output stage (1) or by a launch of their own (0) */
+a1mpc_status a1mpc_last_control_tick_ms(a1mpc_handle h, float* ms_out, int32_t* torques_fused_out);
+
+/*
  * Debug / verification: the dense QP data the reference's ConvexMpc keeps in its public members after calculate_qp_mats
  * (hessian, gradient, lb, ub: S/ConvexMpc.h:84-93, S/ConvexMpc.cpp:158-245) for n problems, formed on the GPU from the same inputs as
  * a1mpc_solve_batch_strided.  P_out n x (12H)^2 (row-major, symmetric), g_out n x 12H, l_out / u_out n x 20H (the constraint matrix is

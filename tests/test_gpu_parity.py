@@ -690,6 +690,96 @@ def test_device_pointer_tick_matches_host_pointer_tick(pkg, scen):
                     ctr["contacts"]) and np.array_equal(it_d.cpu().numpy(), sol["iters"])
 
 
+def tick_inputs(scen, rng, n):
+    """random sensors / commands of one control tick (what test_device_pointer_tick_matches_host_pointer_tick feeds the chain)"""
+    eul = rng.normal(0, 0.05, (n, 3)); eul[:, 2] = rng.uniform(-1, 1, n)
+    return dict(joint_pos=np.tile([0.0, 0.8, -1.6], (n, 4)) + rng.normal(0, 0.1, (n, 12)), joint_vel=rng.normal(0, 1, (n, 12)),
+                R_world=scen.rot_zyx(eul[:, 0], eul[:, 1], eul[:, 2]).reshape(n, 9), R_z=scen.rot_zyx(0 * eul[:, 0], 0 * eul[:, 0], eul[:, 2]).reshape(n, 9),
+                root_euler=eul, root_ang_vel=rng.normal(0, 0.2, (n, 3)), imu_acc=np.array([0, 0, 9.81]) + rng.normal(0, 0.2, (n, 3)),
+                imu_ang_vel=rng.normal(0, 0.2, (n, 3)), foot_force=rng.uniform(0, 120, (n, 4)), movement_mode=np.ones(n, np.uint8),
+                mpc_active=(rng.random(n) < 0.9).astype(np.uint8), root_lin_vel_d=np.c_[rng.uniform(-0.4, 0.4, (n, 2)), np.zeros(n)],
+                root_ang_vel_d=np.c_[np.zeros((n, 2)), rng.uniform(-0.4, 0.4, n)], root_pos_d_z=np.full(n, 0.3), gait_counter_speed=np.full((n, 4), 2.0),
+                torques_gravity=rng.normal(0, 0.5, (n, 12)))
+
+
+TICK_STATE = dict(gait_counter=4, foot_pos_start=12, foot_pos_rel_last_time=12, foot_pos_target_last_time=12, root_euler_d=3, joint_torques=12, root_pos=3,
+                  root_lin_vel=3)
+TICK_OUT_F64 = dict(foot_pos_rel=12, j_foot_blocks=36, foot_vel_rel=12, foot_pos_abs=12, foot_vel_abs=12, foot_pos_world=12, foot_vel_world=12, foot_pos_target_rel=12,
+                    foot_pos_target_abs=12, foot_pos_target_world=12, foot_pos_cur=12, foot_forces_kin=12, foot_pos_recent_contact=12, terrain_angle=1, grf=12)
+
+
+@pytest.mark.parametrize("n,warm", [(300, 1), (64, 2), (4096, 1)])
+def test_control_tick_one_call_matches_the_seven_entry_chain(pkg, scen, n, warm):
+    """a1mpc_control_tick_device -- leg state, EKF, gait plan, swing legs, contacts / terrain, MPC from tick records and the joint torques in ONE C call,
+    N3 inside the MPC kernel's output stage -- against the seven *_device entry points chained by hand on a second handle: every output and every carried state bit for
+    bit, four ticks.  n = 300: the fused kernel from the first tick; 64: the latency kernel, update path; 4096: the split pipeline on the first tick (torques by their
+    own launch), then the fused kernel in the order of the previous tick's costs (torques in the output stage)."""
+    import torch
+    rng = np.random.default_rng(2025 + n)
+    P = scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS
+    cfg = pkg.make_config(P, 10, warm_start=warm)
+    dev = torch.device("cuda", 0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    dp_ = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    E = pkg.engine
+    with pkg.Engine(cfg, n, 0) as e1, pkg.Engine(cfg, n, 0) as e7:
+        prm = E.TickParams(); e1.lib.a1mpc_default_tick_params(C.byref(prm))
+        assert np.allclose(np.array(prm.rho_fix).reshape(4, 5), e1.A1_RHO_FIX) and list(prm.km_foot) == [0.1, 0.1, 0.04]
+        kp = np.array(prm.kp_foot); kd = np.array(prm.kd_foot); km = np.array(prm.km_foot); fix = np.array(prm.rho_fix); opt = np.array(prm.rho_opt)
+        st = torch.cuda.Stream(device=dev); sp = C.c_void_p(st.cuda_stream)
+        init = dict(gait_counter=np.tile([0.0, 120.0, 120.0, 0.0], (n, 1)), root_pos=np.tile([0.0, 0.0, 0.3], (n, 1)))
+        state = [{k: T(init.get(k, np.zeros((n, m)))) for k, m in TICK_STATE.items()} for _ in range(2)]
+        outs = [{k: torch.zeros((n, m) if m > 1 else (n,), dtype=torch.float64, device=dev) for k, m in TICK_OUT_F64.items()} for _ in range(2)]
+        u8 = [{k: torch.zeros((n, 4), dtype=torch.uint8, device=dev) for k in ("estimated_contacts", "plan_contacts", "contacts")} for _ in range(2)]
+        i32 = [{k: torch.zeros(n, dtype=torch.int32, device=dev) for k in ("iters", "status")} for _ in range(2)]
+        fused_seen = []
+        for t in range(4):
+            inp = {k: T(v) for k, v in tick_inputs(scen, rng, n).items()}
+            # ---- one call
+            bf = E.TickBuffers()
+            for k in E.TICK_BUFFER_FIELDS:
+                src = inp if k in inp else state[0] if k in state[0] else outs[0] if k in outs[0] else u8[0] if k in u8[0] else i32[0]
+                setattr(bf, k, src[k].data_ptr())
+            e1.control_tick_device(prm, bf, n, stream=st.cuda_stream)
+            fused_seen.append(e1.last_control_tick_ms()[1])
+            # ---- the chain
+            s7, o7, b7, j7, L, H_ = state[1], outs[1], u8[1], i32[1], e7.lib, e7._h
+            rcs = [L.a1mpc_leg_state_batch_device(H_, n, ptr(inp["joint_pos"]), ptr(inp["joint_vel"]), ptr(inp["R_world"]), ptr(s7["root_pos"]), ptr(s7["root_lin_vel"]), dp_(fix),
+                                                  dp_(opt), ptr(o7["foot_pos_rel"]), ptr(o7["j_foot_blocks"]), ptr(o7["foot_vel_rel"]), ptr(o7["foot_pos_abs"]),
+                                                  ptr(o7["foot_vel_abs"]), ptr(o7["foot_pos_world"]), ptr(o7["foot_vel_world"]), sp),
+                   L.a1mpc_ekf_update_batch_device(H_, n, prm.control_dt, 1, ptr(inp["movement_mode"]), ptr(inp["foot_force"]), ptr(inp["R_world"]), ptr(inp["imu_acc"]),
+                                                   ptr(inp["imu_ang_vel"]), ptr(o7["foot_pos_rel"]), ptr(o7["foot_vel_rel"]), ptr(s7["root_pos"]), ptr(s7["root_lin_vel"]),
+                                                   ptr(b7["estimated_contacts"]), sp),
+                   L.a1mpc_update_plan_batch_device(H_, C.byref(prm.gait), n, ptr(inp["movement_mode"]), ptr(s7["gait_counter"]), ptr(inp["gait_counter_speed"]),
+                                                    ptr(s7["root_lin_vel"]), ptr(inp["R_z"]), ptr(inp["R_world"]), ptr(s7["root_pos"]), ptr(inp["root_lin_vel_d"]),
+                                                    ptr(b7["plan_contacts"]), ptr(o7["foot_pos_target_rel"]), ptr(o7["foot_pos_target_abs"]), ptr(o7["foot_pos_target_world"]), sp),
+                   L.a1mpc_swing_legs_batch_device(H_, n, prm.gait.counter_per_swing, prm.control_dt, ptr(inp["R_z"]), ptr(o7["foot_pos_abs"]), ptr(s7["gait_counter"]),
+                                                   ptr(o7["foot_pos_target_rel"]), dp_(kp), dp_(kd), ptr(s7["foot_pos_start"]), ptr(s7["foot_pos_rel_last_time"]),
+                                                   ptr(s7["foot_pos_target_last_time"]), ptr(o7["foot_pos_cur"]), ptr(o7["foot_forces_kin"]), sp)]
+            with torch.cuda.stream(st):
+                pz = s7["root_pos"][:, 2].contiguous(); pitch = s7["root_euler_d"][:, 1].contiguous()
+            rcs.append(L.a1mpc_contact_terrain_batch_device(H_, C.byref(prm.contact), n, ptr(s7["gait_counter"]), ptr(b7["plan_contacts"]), ptr(inp["foot_force"]),
+                                                            ptr(o7["foot_pos_abs"]), ptr(pz), ptr(pitch), ptr(b7["contacts"]), ptr(o7["foot_pos_recent_contact"]),
+                                                            ptr(o7["terrain_angle"]), sp))
+            with torch.cuda.stream(st):
+                s7["root_euler_d"][:, 1] = pitch
+                tick = torch.cat([inp["root_euler"], s7["root_pos"], inp["root_ang_vel"], s7["root_lin_vel"], s7["root_euler_d"], inp["root_lin_vel_d"], inp["root_ang_vel_d"],
+                                  inp["root_pos_d_z"].reshape(n, 1)], 1).contiguous()
+            rcs.append(L.a1mpc_solve_batch_ticks_device(H_, n, ptr(tick), ptr(inp["R_world"]), ptr(o7["foot_pos_abs"]), ptr(b7["contacts"]), ptr(o7["grf"]), None,
+                                                        ptr(j7["iters"]), ptr(j7["status"]), sp))
+            rcs.append(L.a1mpc_joint_torques_batch_device(H_, n, ptr(inp["mpc_active"]), ptr(b7["contacts"]), ptr(o7["j_foot_blocks"]), ptr(o7["grf"]), ptr(o7["foot_forces_kin"]),
+                                                          dp_(km), ptr(inp["torques_gravity"]), ptr(s7["joint_torques"]), sp))
+            assert not any(rcs), rcs
+            st.synchronize()
+            for grp in (state, outs, u8, i32):
+                for k in grp[0]:
+                    a, b = grp[0][k].cpu().numpy(), grp[1][k].cpu().numpy()
+                    assert np.array_equal(a, b, equal_nan=True), (t, k, np.abs(a.astype(float) - b.astype(float)).max())
+            assert (i32[0]["status"].cpu().numpy() == 1).all() and np.abs(state[0]["joint_torques"].cpu().numpy()).max() > 0.1
+        assert fused_seen == ([True] * 4 if n <= 2048 else [False, True, True, True]), fused_seen
+
+
 # ------------------------------------------------------------------------------------------------------------ round 2
 def test_bench_batch_all_4096_qps_vs_oracle(pkg, oracle, scen):
     """VERDICT r1 task 2: EVERY QP of the bench configuration (BASELINE configs[2]: 4096 x h10, the bench seed) against the oracle."""
@@ -1375,12 +1465,11 @@ def test_update_path_reinitialises_on_a_hessian_pattern_change(pkg, oracle, scen
 
 # ------------------------------------------------------------------------------------------------------------ round 3: the big batches,
 # gated
-@pytest.mark.parametrize("gen,n,h", [("config5_divergent", 32768, 20), ("config3_random_flat", 65536, 10)])
+@pytest.mark.parametrize("gen,n,h", [("config5_divergent", 32768, 20), ("config3_random_flat", 65536, 10), ("config4_random_h16", 65536, 16)])
 def test_full_size_batches_every_qp_vs_oracle(pkg, oracle, scen, gen, n, h):
-    """BASELINE configs[4] as ONE launch of 32768 x h20 (mixed contact patterns, 0.5 rad pitch) and BASELINE's upper
-    batch, 65536 x h10, as one
-    launch -- EVERY QP against the oracle (all host threads): same iteration count and status on every QP, forces within the parity
-    tolerance."""
+    """BASELINE configs[4] as ONE launch of 32768 x h20 (mixed contact patterns, 0.5 rad pitch), BASELINE's upper batch, 65536 x h10, as one
+    launch, and the whole of BASELINE configs[3], 65536 x h16, on one GPU -- what `bench.py --config 4` solves at N = 1 -- EVERY QP against
+    the oracle (all host threads): same iteration count and status on every QP, forces within the parity tolerance."""
     sc = getattr(scen, gen)(nb=n)
     with _engine(pkg, sc, n, warm_start=0) as eng:
         out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=False)
