@@ -66,6 +66,49 @@ __global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
                                                            CLK ? a.clk + b * kTickStages : nullptr);
 }
 
+// Round 5 trial ("split-vs-fused with a queue in both"; A1MPC_FUSED_QUEUE=1): the fused kernel as PERSISTENT wavefronts on a work queue -- no set-up
+// kernel, no hand-off record through HBM, no grid-wide barrier between a batch's set-up and its iterations, so the wavefronts of the NEXT batch (another stream) can
+// start on every SIMD this batch's tail vacates.  A wavefront pulls ROWS queue slots at a time (both of its QPs are set up together: the set-up is wave-wide code)
+// and goes back to the queue when both have converged.  The queue order comes from a1mpc_predict_kernel (the set-up kernel's cost guess, evaluated from the inputs
+// alone) or from the previous solve's costs.  Same RowSolver code as a1mpc_solve_kernel: same bits.  Measured: profiles/r05_fused_queue_trial.txt.
+template <int H, int MODE, int ROWS>
+__global__ __launch_bounds__(64) void a1mpc_solve_queue_kernel(const KernelArgs a, int* __restrict__ counter) {
+    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
+    static_assert(twin_rows(H, MODE, ROWS) && ROWS == 2, "two QPs per wavefront, each on a main / twin pair of rows");
+    const int row = (static_cast<int>(threadIdx.x) >> 4) & 1;
+    while (true) {
+        int q0 = 0;
+        if (threadIdx.x == 0) q0 = atomicAdd(counter, ROWS);
+        q0 = __builtin_amdgcn_readfirstlane(q0);
+        if (q0 >= a.n) break;
+        const int slot = q0 + row;
+        if (slot < a.n) {   // row-uniform (a twin follows its main row)
+            const int64_t b = a.order ? static_cast<int64_t>(a.order[slot]) : static_cast<int64_t>(slot);
+            solve_row_with<H, MODE, false, true, false>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
+        }
+        row_sync();   // the images are free again
+    }
+}
+// the set-up kernel's cost guess (RowSolver::predict_cost) from the inputs alone, one thread per QP: the queue order of a first solve through a1mpc_solve_queue_kernel
+__global__ __launch_bounds__(256) void a1mpc_predict_kernel(const KernelArgs a, int H) {
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (b >= a.n) return;
+    double ev[3];
+    if (a.tick) {
+        const double* k = a.tick + b * 22; const double* R = a.R + b * 9;
+        const double vwx = R[0] * k[15] + R[1] * k[16] + R[2] * k[17], vwy = R[3] * k[15] + R[4] * k[16] + R[5] * k[17];
+        ev[0] = vwx - k[9]; ev[1] = vwy - k[10]; ev[2] = 0.0 - k[11];
+    } else {
+        const double* x0 = a.x0 + b * 13; const double* xr = a.xref + b * 13 * H;
+        for (int i = 0; i < 3; ++i) ev[i] = xr[9 + i] - x0[9 + i];
+    }
+    const uint8_t* c = a.contact + b * (a.contact_stride ? 4 * H : 4);
+    const bool all_stance = c[0] && c[1] && c[2] && c[3];
+    const double hard = 30.0 * ev[2] + 27.0 * sqrt(ev[0] * ev[0] + ev[1] * ev[1]) + (all_stance ? 10.0 : 0.0);
+    const double cc = 8.0 * hard + 400.0;
+    a.cost[b] = cc > 0.0 ? (cc < 2047.0 ? static_cast<int>(cc) : 2047) : 0;
+}
+
 // General path (per-step feet / per-step contact schedules: S/ConvexMpc.h:74 B_mat_d_list, S/test/test_mpc.cpp:106-122): the fused kernel
 // over RowSolver<.., GEN = true>, whose LDS image also holds B~_t and the bounds of every horizon step.
 template <int H, int ROWS>
@@ -331,24 +374,6 @@ __global__ __launch_bounds__(256) void a1mpc_form_kernel(const FormArgs a) {
 
 __global__ void a1mpc_noop_kernel() {}
 
-// a1mpc_control_tick_device: the 22-number tick record of a1mpc_solve_batch_ticks assembled on the device from the arrays the stages before it left there
-// (S/A1RobotControl.cpp:452-456, :470-488 read exactly these fields of A1CtrlStates): one thread per robot, 22 coalesced-enough words in, 22 out
-struct PackArgs {
-    int32_t n;
-    const double *euler, *pos, *ang_vel, *lin_vel, *euler_d, *lin_vel_d, *ang_vel_d, *pos_d_z;
-    double* tick;
-};
-__global__ __launch_bounds__(256) void a1mpc_tick_pack_kernel(const PackArgs a) {
-    const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (b >= a.n) return;
-    double* t = a.tick + b * 22;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        t[k] = a.euler[b * 3 + k]; t[3 + k] = a.pos[b * 3 + k]; t[6 + k] = a.ang_vel[b * 3 + k]; t[9 + k] = a.lin_vel[b * 3 + k];
-        t[12 + k] = a.euler_d[b * 3 + k]; t[15 + k] = a.lin_vel_d[b * 3 + k]; t[18 + k] = a.ang_vel_d[b * 3 + k];
-    }
-    t[21] = a.pos_d_z[b];
-}
 
 // ---- N2a: update_plan (S/A1RobotControl.cpp:148-202), one lane per (robot, leg) ------------------------------------------------
 // Element-wise and HBM-bound: ~0.5 KB in + 0.3 KB out per robot.  The four lanes of a robot read the same robot-level words
@@ -390,6 +415,40 @@ struct PlanArgs {
     uint8_t* plan_contacts;
     double *rel, *abs_, *world;
 };
+// one (robot, leg) of update_plan: the new gait counter (also stored), the planned contact and the three foothold vectors
+__device__ __forceinline__ void plan_lane(const PlanArgs& a, const int64_t b, const int leg, double& gc, double (&rel)[3], double (&ab)[3], double (&wo)[3]) {
+#pragma clang fp contract(off)
+    gc = a.gait_counter[b * 4 + leg];
+    const double spd = a.gait_counter_speed[b * 4 + leg];
+    uint8_t pc;
+    if (!a.movement_mode[b]) {                                  // :150-153
+        pc = 1; gc = a.g.gait_counter_reset[leg];
+    } else {                                                    // :155-165
+        gc = gc + spd;
+        gc = fmod(gc, a.g.counter_per_gait);
+        pc = gc <= a.g.counter_per_swing ? 1 : 0;
+    }
+    a.gait_counter[b * 4 + leg] = gc;
+    a.plan_contacts[b * 4 + leg] = pc;
+    const double* Rz = a.Rz + b * 9; const double* Rw = a.Rw + b * 9;
+    const double* v = a.root_lin_vel + b * 3; const double* vd = a.root_lin_vel_d + b * 3; const double* pos = a.root_pos + b * 3;
+    const double vrx = Rz[0] * v[0] + Rz[3] * v[1] + Rz[6] * v[2];   // :168-169  Rz' v
+    const double vry = Rz[1] * v[0] + Rz[4] * v[1] + Rz[7] * v[2];
+    const double k = sqrt(fabs(a.g.default_foot_pos[2]) / 9.8);       // default_foot_pos(2): linear index 2 = z of leg 0
+    const double half_swing = ((a.g.counter_per_swing / spd) * a.g.control_dt) / 2.0;
+    double dx = k * (vrx - vd[0]) + half_swing * vd[0];              // :175-182
+    double dy = k * (vry - vd[1]) + half_swing * vd[1];
+    if (dx < -a.g.foot_delta_x_limit) dx = -a.g.foot_delta_x_limit;
+    if (dx > a.g.foot_delta_x_limit) dx = a.g.foot_delta_x_limit;
+    if (dy < -a.g.foot_delta_y_limit) dy = -a.g.foot_delta_y_limit;
+    if (dy > a.g.foot_delta_y_limit) dy = a.g.foot_delta_y_limit;
+    rel[0] = a.g.default_foot_pos[3 * leg + 0] + dx; rel[1] = a.g.default_foot_pos[3 * leg + 1] + dy; rel[2] = a.g.default_foot_pos[3 * leg + 2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {                                    // :198-199
+        ab[r] = Rw[r * 3 + 0] * rel[0] + Rw[r * 3 + 1] * rel[1] + Rw[r * 3 + 2] * rel[2];
+        wo[r] = ab[r] + pos[r];
+    }
+}
 __global__ __launch_bounds__(256) void a1mpc_plan_kernel(const PlanArgs a) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) double stage[4][576];
@@ -400,39 +459,8 @@ __global__ __launch_bounds__(256) void a1mpc_plan_kernel(const PlanArgs a) {
     const int64_t wave_first = (static_cast<int64_t>(blockIdx.x) * 256 + wv * 64) >> 2;
     if (wave_first >= a.n) return;
     const WaveStage ws{stage[wv], lane, static_cast<int>(a.n - wave_first < 16 ? a.n - wave_first : 16), wave_first};
-    double rel[3] = {0, 0, 0}, ab[3] = {0, 0, 0}, wo[3] = {0, 0, 0};
-    if (b < a.n) {
-        double gc = a.gait_counter[b * 4 + leg];
-        const double spd = a.gait_counter_speed[b * 4 + leg];
-        uint8_t pc;
-        if (!a.movement_mode[b]) {                                  // :150-153
-            pc = 1; gc = a.g.gait_counter_reset[leg];
-        } else {                                                    // :155-165
-            gc = gc + spd;
-            gc = fmod(gc, a.g.counter_per_gait);
-            pc = gc <= a.g.counter_per_swing ? 1 : 0;
-        }
-        a.gait_counter[b * 4 + leg] = gc;
-        a.plan_contacts[b * 4 + leg] = pc;
-        const double* Rz = a.Rz + b * 9; const double* Rw = a.Rw + b * 9;
-        const double* v = a.root_lin_vel + b * 3; const double* vd = a.root_lin_vel_d + b * 3; const double* pos = a.root_pos + b * 3;
-        const double vrx = Rz[0] * v[0] + Rz[3] * v[1] + Rz[6] * v[2];   // :168-169  Rz' v
-        const double vry = Rz[1] * v[0] + Rz[4] * v[1] + Rz[7] * v[2];
-        const double k = sqrt(fabs(a.g.default_foot_pos[2]) / 9.8);       // default_foot_pos(2): linear index 2 = z of leg 0
-        const double half_swing = ((a.g.counter_per_swing / spd) * a.g.control_dt) / 2.0;
-        double dx = k * (vrx - vd[0]) + half_swing * vd[0];              // :175-182
-        double dy = k * (vry - vd[1]) + half_swing * vd[1];
-        if (dx < -a.g.foot_delta_x_limit) dx = -a.g.foot_delta_x_limit;
-        if (dx > a.g.foot_delta_x_limit) dx = a.g.foot_delta_x_limit;
-        if (dy < -a.g.foot_delta_y_limit) dy = -a.g.foot_delta_y_limit;
-        if (dy > a.g.foot_delta_y_limit) dy = a.g.foot_delta_y_limit;
-        rel[0] = a.g.default_foot_pos[3 * leg + 0] + dx; rel[1] = a.g.default_foot_pos[3 * leg + 1] + dy; rel[2] = a.g.default_foot_pos[3 * leg + 2];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {                                    // :198-199
-            ab[r] = Rw[r * 3 + 0] * rel[0] + Rw[r * 3 + 1] * rel[1] + Rw[r * 3 + 2] * rel[2];
-            wo[r] = ab[r] + pos[r];
-        }
-    }
+    double rel[3] = {0, 0, 0}, ab[3] = {0, 0, 0}, wo[3] = {0, 0, 0}, gc = 0.0;
+    if (b < a.n) plan_lane(a, b, leg, gc, rel, ab, wo);
     ws.flush3(rel, ab, wo, a.rel, a.abs_, a.world);   // (the three [robot][12] outputs leave through the wave's LDS stage: WaveStage)
 }
 
@@ -970,8 +998,34 @@ static a1mpc_status use_split_pipeline(int horizon, int n, bool have_prep, bool*
     return st;
 }
 
+static bool fused_queue_enabled() {
+    static const bool on = [] { const char* e = getenv("A1MPC_FUSED_QUEUE"); return e && !strcmp(e, "1"); }();
+    return on;
+}
+// the round-5 trial kernel (see a1mpc_solve_queue_kernel): h = 10, cold or warm_start = 1 batches beyond the resident rows, contacts broadcast
+static a1mpc_status launch_fused_queue(const KernelArgs& a, int* counter, hipStream_t stream) {
+    constexpr int H = 10, ROWS = 2;
+    int res = 0;
+    if (a1mpc_status st = resident_workgroups<H, ROWS>(&res); st != A1MPC_OK) return st;
+    if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_queue_kernel<H, kModeMpc, ROWS>), lds_bytes<H>(ROWS)); st != A1MPC_OK) return st;
+    A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
+    if (a.cost != nullptr && a.order != nullptr) {
+        if (a.predict) hipLaunchKernelGGL(a1mpc_predict_kernel, dim3(static_cast<unsigned>((a.n + 255) / 256)), dim3(256), 0, stream, a, H);
+        hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, static_cast<int>(a.n), static_cast<const int32_t*>(a.cost), const_cast<int32_t*>(a.order));
+    }
+    const int want = (a.n + ROWS - 1) / ROWS;
+    hipLaunchKernelGGL((a1mpc_solve_queue_kernel<H, kModeMpc, ROWS>), dim3(static_cast<unsigned>(want < res ? want : res)), dim3(64), lds_bytes<H>(ROWS), stream, a, counter);
+    A1_HIP(hipGetLastError());
+    return A1MPC_OK;
+}
 static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s, bool split, hipEvent_t mid) {
     RoctxRange range(split ? "a1mpc solve (split pipeline)" : "a1mpc solve (fused)");
+#ifndef A1MPC_DEV_SLIM
+    if (split && counter && horizon == 10 && fused_queue_enabled() && a.carry == nullptr && a.clk == nullptr) {
+        if (mid) A1_HIP(hipEventRecord(mid, s));
+        return launch_fused_queue(a, counter, s);
+    }
+#endif
     if (split && prep && counter) {
         switch (horizon) {
 #ifdef A1MPC_DEV_SLIM
@@ -1089,6 +1143,7 @@ struct a1mpc_handle_s {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool timing = true;   // a1mpc_set_timing: HIP events around the launches (a1mpc_last_kernel_ms / _stage_ms / _control_tick_ms); off = three to five event records less per tick
     double* d_tab = nullptr;      // (alpha/beta, beta) table of cfg.horizon
     double* d_tab1 = nullptr;     // the H = 1 table (balance QP)
     // device staging for the host-pointer entry points
@@ -1121,6 +1176,7 @@ struct a1mpc_handle_s {
     double* d_ct_state = nullptr;  // N2b filter state of every robot (allocated on first use)
     double* d_ekf_state = nullptr;  // N4c Kalman filter state of every robot (allocated on first use)
     double* d_tickrec = nullptr;    // a1mpc_control_tick_device: n x 22 tick records + 3 doubles (km_foot), allocated on first use
+    int32_t ekf_ready_n = 0;        // robots 0 .. ekf_ready_n - 1 have had their filter initialised (the init kernel is not launched for them again)
     // staging of the element-wise entry points (N2a, N2b, N3), allocated on first use: 64 / 96 doubles and 16 bytes per robot
     double *d_aux_in = nullptr, *d_aux_out = nullptr;
     uint8_t* d_aux_u8 = nullptr;
@@ -1134,6 +1190,7 @@ struct a1mpc_handle_s {
     // packed device blocks + pinned host mirrors of the host-pointer MPC entry (one copy each way per call)
     char *d_in = nullptr, *d_out = nullptr;
     char* h_pin = nullptr;
+    char* d_pin = nullptr;   // the pinned block as the device sees it (hipHostGetDevicePointer), or null: small batches read / write it directly (host_submit)
     size_t h_pin_bytes = 0, h_pin_in_bytes = 0;
 };
 
@@ -1199,6 +1256,10 @@ struct ContactArgs {
     const uint8_t* plan_contacts;
     double* pitch_d;
     int32_t z_stride, pitch_stride;   // doubles between two robots' root_pos_z / root_euler_d pitch (1: arrays of their own; 3: element 2 of root_pos / element 1 of root_euler_d, a1mpc_control_tick_device)
+    // a1mpc_control_tick_device: the lane that has just written a robot's terrain pitch also assembles its 22-number MPC tick record (a1mpc_tick_pack_kernel's job, one
+    // launch less per tick), or pk_tick = null
+    const double *pk_euler, *pk_pos, *pk_ang_vel, *pk_lin_vel, *pk_euler_d, *pk_lin_vel_d, *pk_ang_vel_d, *pk_pos_d_z;
+    double* pk_tick;
     uint8_t* contacts;
     double *recent_out, *terrain_out;
     const double* recent_in;  // terrain-only entry: foot_pos_recent_contact comes from the caller instead of the handle's contact state
@@ -1347,6 +1408,15 @@ __global__ __launch_bounds__(64) void a1mpc_contact_terrain_kernel(const Contact
     for (int i = 0; i < kCtUnits; ++i) { const int o = i * 64 + lane, r = o / kCtUnits, w = o - r * kCtUnits; *reinterpret_cast<uint4*>(img + r * kCtLdsStride + w * 16) = v[i]; }
     __syncthreads();
     if (b < a.n) contact_terrain_robot(a, b, reinterpret_cast<CtRecord*>(img + lane * kCtLdsStride));
+    if (b < a.n && a.pk_tick != nullptr) {   // (S/A1RobotControl.cpp:452-456, :470-488 read exactly these fields; root_euler_d[1] is the pitch this lane has just written)
+        double* t = a.pk_tick + b * 22;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            t[k] = a.pk_euler[b * 3 + k]; t[3 + k] = a.pk_pos[b * 3 + k]; t[6 + k] = a.pk_ang_vel[b * 3 + k]; t[9 + k] = a.pk_lin_vel[b * 3 + k];
+            t[12 + k] = a.pk_euler_d[b * 3 + k]; t[15 + k] = a.pk_lin_vel_d[b * 3 + k]; t[18 + k] = a.pk_ang_vel_d[b * 3 + k];
+        }
+        t[21] = a.pk_pos_d_z[b];
+    }
     __syncthreads();
     uint4* dst = reinterpret_cast<uint4*>(a.rec + base);
 #pragma unroll
@@ -1418,15 +1488,15 @@ a1mpc_status a1mpc_contact_terrain_batch(a1mpc_handle h, const a1mpc_contact_con
     A1_HIP(hipMemcpyAsync(d_pd, root_euler_d_pitch, N * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(d_pc, plan_contacts, N * 4, hipMemcpyHostToDevice, s));
     ContactArgs a;
-    a.recent_in = nullptr; a.z_stride = 1; a.pitch_stride = 1;
+    a.recent_in = nullptr; a.z_stride = 1; a.pitch_stride = 1; a.pk_tick = nullptr;
     a.n = n; a.counter_per_swing = cfg->counter_per_swing; a.foot_force_low = cfg->foot_force_low; a.use_terrain_adapt = cfg->use_terrain_adapt;
     contact_state_pointers(h, a); a.gait_counter = d_gc; a.foot_force = d_ff; a.foot_pos_abs = d_fp; a.root_pos_z = d_z; a.plan_contacts = d_pc;
     a.pitch_d = d_pd; a.contacts = d_ct; a.recent_out = d_rec; a.terrain_out = d_ta;
-    A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     launch_contact_terrain(a, s);
     A1_HIP(hipGetLastError());
-    A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true; A1_MARK(h, s);
+    if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = h->timing; A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(contacts_out, d_ct, N * 4, hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(foot_pos_recent_contact_out, d_rec, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(terrain_angle_out, d_ta, N * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1442,6 +1512,43 @@ struct SwingArgs {
     const double *Rz, *foot_pos_abs, *gait_counter, *target_rel;
     double *start, *rel_last, *target_last, *cur_out, *kin_out;
 };
+// one (robot, leg) of generate_swing_legs_ctrl's first block: gc = the leg's gait counter, target_rel = its foothold (both may come straight from plan_lane's registers)
+__device__ __forceinline__ void swing_lane(const SwingArgs& a, const int64_t b, const int i, const double gc, const double (&target_rel)[3], double (&cur)[3], double (&st)[3],
+                                           double (&tl)[3], double (&kin)[3]) {
+#pragma clang fp contract(off)
+    const double* Rz = a.Rz + b * 9;
+    const double* fa = a.foot_pos_abs + b * 12 + 3 * i;
+    const int64_t o = b * 12 + 3 * i;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cur[r] = Rz[0 * 3 + r] * fa[0] + Rz[1 * 3 + r] * fa[1] + Rz[2 * 3 + r] * fa[2];   // :224
+    float spline_time = 0.0f;
+    if (gc <= a.counter_per_swing) {                                                                                  // :227-232  (foot_pos_start <- the current position)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) st[r] = cur[r];
+    } else {                                                                                                          // :233-236  (foot_pos_start stays: written back as read)
+        spline_time = static_cast<float>(gc - a.counter_per_swing) / static_cast<float>(a.counter_per_swing);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) st[r] = a.start[o + r];
+    }
+    const double t = spline_time, u = 1 - t;
+    const double t2 = t * t, t3 = t2 * t, t4 = t2 * t2, u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double fin = target_rel[r];
+        double P1 = st[r], P2 = fin;
+        if (r == 2) { P1 += 0.0f; P2 += 0.4f + 0.5 * 0.0; }                                                           // FOOT_SWING_CLEARANCE1 / 2
+        double y = 0;                                                                                                 // Utils.cpp:97-104
+        y += 1.0 * 1.0 * u4 * st[r];
+        y += 4.0 * t * u3 * P1;
+        y += 6.0 * t2 * u2 * P2;
+        y += 4.0 * t3 * u * fin;
+        y += 1.0 * t4 * 1.0 * fin;
+        const double vel_cur = (cur[r] - a.rel_last[o + r]) / a.dt;                                                   // :243-252
+        const double vel_tgt = (y - a.target_last[o + r]) / a.dt;
+        tl[r] = y;
+        kin[r] = (y - cur[r]) * a.kp[r] + (vel_tgt - vel_cur) * a.kd[r];
+    }
+}
 __global__ __launch_bounds__(256) void a1mpc_swing_kernel(const SwingArgs a) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) double stage[4][576];
@@ -1454,44 +1561,38 @@ __global__ __launch_bounds__(256) void a1mpc_swing_kernel(const SwingArgs a) {
     const WaveStage ws{stage[wv], lane, static_cast<int>(a.n - wave_first < 16 ? a.n - wave_first : 16), wave_first};
     double cur[3] = {0, 0, 0}, st[3] = {0, 0, 0}, tl[3] = {0, 0, 0}, kin[3] = {0, 0, 0};
     if (b < a.n) {
-        const double* Rz = a.Rz + b * 9;
-        const double* fa = a.foot_pos_abs + b * 12 + 3 * i;
-        const int64_t o = b * 12 + 3 * i;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) cur[r] = Rz[0 * 3 + r] * fa[0] + Rz[1 * 3 + r] * fa[1] + Rz[2 * 3 + r] * fa[2];   // :224
-        const double gc = a.gait_counter[b * 4 + i];
-        float spline_time = 0.0f;
-        if (gc <= a.counter_per_swing) {                                                                                  // :227-232  (foot_pos_start <- the current position)
-#pragma unroll
-            for (int r = 0; r < 3; ++r) st[r] = cur[r];
-        } else {                                                                                                          // :233-236  (foot_pos_start stays: written back as read)
-            spline_time = static_cast<float>(gc - a.counter_per_swing) / static_cast<float>(a.counter_per_swing);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) st[r] = a.start[o + r];
-        }
-        const double t = spline_time, u = 1 - t;
-        const double t2 = t * t, t3 = t2 * t, t4 = t2 * t2, u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double fin = a.target_rel[o + r];
-            double P1 = st[r], P2 = fin;
-            if (r == 2) { P1 += 0.0f; P2 += 0.4f + 0.5 * 0.0; }                                                           // FOOT_SWING_CLEARANCE1 / 2
-            double y = 0;                                                                                                 // Utils.cpp:97-104
-            y += 1.0 * 1.0 * u4 * st[r];
-            y += 4.0 * t * u3 * P1;
-            y += 6.0 * t2 * u2 * P2;
-            y += 4.0 * t3 * u * fin;
-            y += 1.0 * t4 * 1.0 * fin;
-            const double vel_cur = (cur[r] - a.rel_last[o + r]) / a.dt;                                                   // :243-252
-            const double vel_tgt = (y - a.target_last[o + r]) / a.dt;
-            tl[r] = y;
-            kin[r] = (y - cur[r]) * a.kp[r] + (vel_tgt - vel_cur) * a.kd[r];
-        }
+        const double tr[3] = {a.target_rel[b * 12 + 3 * i], a.target_rel[b * 12 + 3 * i + 1], a.target_rel[b * 12 + 3 * i + 2]};
+        swing_lane(a, b, i, a.gait_counter[b * 4 + i], tr, cur, st, tl, kin);
     }
-    // start / rel_last / target_last are updated in place, and a staged store writes OTHER lanes' words of this wavefront's 16 robots: every load above has
-    // completed by then -- the values parked in LDS depend on them (one s_waitcnt for the whole wave) -- and no other wavefront touches these robots
+    // start / rel_last / target_last are updated in place, and a staged store writes OTHER lanes' words of this wavefront's 16 robots (no other wavefront touches
+    // these robots).  Every load above must have returned before the first such store: an explicit s_waitcnt vmcnt(0) -- rel_last / target_last only feed `kin`, which
+    // is parked in the SECOND flush, so the first flush's data dependences alone would not cover them
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
     ws.flush3(st, cur, tl, a.start, a.rel_last, a.target_last);   // foot_pos_start, foot_pos_rel_last_time <- cur, foot_pos_target_last_time <- y
     ws.flush3(kin, cur, cur, a.kin_out, a.cur_out, nullptr);
+}
+// a1mpc_control_tick_device: update_plan and the swing-leg block in ONE launch -- both run one lane per (robot, leg), and the swing block's inputs from the plan (the
+// leg's new gait counter and foothold) are the lane's own registers.  Same lane functions as the two kernels: same bits, one launch less per tick.
+__global__ __launch_bounds__(256) void a1mpc_plan_swing_kernel(const PlanArgs pa, const SwingArgs sa) {
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) double stage[4][576];
+    const int lane = static_cast<int>(threadIdx.x) & 63, wv = static_cast<int>(threadIdx.x) >> 6;
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t b = gid >> 2;
+    const int leg = static_cast<int>(gid & 3);
+    const int64_t wave_first = (static_cast<int64_t>(blockIdx.x) * 256 + wv * 64) >> 2;
+    if (wave_first >= pa.n) return;
+    const WaveStage ws{stage[wv], lane, static_cast<int>(pa.n - wave_first < 16 ? pa.n - wave_first : 16), wave_first};
+    double rel[3] = {0, 0, 0}, ab[3] = {0, 0, 0}, wo[3] = {0, 0, 0}, gc = 0.0;
+    double cur[3] = {0, 0, 0}, st[3] = {0, 0, 0}, tl[3] = {0, 0, 0}, kin[3] = {0, 0, 0};
+    if (b < pa.n) {
+        plan_lane(pa, b, leg, gc, rel, ab, wo);
+        swing_lane(sa, b, leg, gc, rel, cur, st, tl, kin);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): every load of the in-place arrays has returned before the staged stores write other lanes' words of them (see a1mpc_swing_kernel)
+    ws.flush3(rel, ab, wo, pa.rel, pa.abs_, pa.world);
+    ws.flush3(st, cur, tl, sa.start, sa.rel_last, sa.target_last);
+    ws.flush3(kin, cur, cur, sa.kin_out, sa.cur_out, nullptr);
 }
 
 a1mpc_status a1mpc_swing_legs_batch(a1mpc_handle h, int32_t n, double counter_per_swing, double dt, const double* R_z,
@@ -1525,11 +1626,11 @@ a1mpc_status a1mpc_swing_legs_batch(a1mpc_handle h, int32_t n, double counter_pe
     for (int k = 0; k < 3; ++k) { a.kp[k] = kp_foot[k]; a.kd[k] = kd_foot[k]; }
     a.Rz = d_Rz; a.foot_pos_abs = d_fa; a.gait_counter = d_gc; a.target_rel = d_tr; a.start = d_st; a.rel_last = d_rl; a.target_last = d_tl;
     a.cur_out = d_cur; a.kin_out = d_kin;
-    A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(a1mpc_swing_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
     A1_HIP(hipGetLastError());
-    A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true; A1_MARK(h, s);
+    if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = h->timing; A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(foot_pos_start, d_st, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(foot_pos_rel_last_time, d_rl, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(foot_pos_target_last_time, d_tl, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1624,11 +1725,11 @@ a1mpc_status a1mpc_leg_state_batch(a1mpc_handle h, int32_t n, const double* join
     a.q = d_q; a.qd = d_qd; a.R = d_R; a.pos = d_pos; a.vel = d_vel; a.rel = d_rel; a.Jb = d_Jb;
     a.vrel = foot_vel_rel_out ? d_vrel : nullptr; a.pabs = foot_pos_abs_out ? d_pabs : nullptr; a.vabs = foot_vel_abs_out ? d_vabs : nullptr;
     a.pworld = foot_pos_world_out ? d_pw : nullptr; a.vworld = foot_vel_world_out ? d_vw : nullptr;
-    A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(a1mpc_leg_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
     A1_HIP(hipGetLastError());
-    A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true; A1_MARK(h, s);
+    if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = h->timing; A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(foot_pos_rel_out, d_rel, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(j_foot_blocks_out, d_Jb, N * 36 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (foot_vel_rel_out) A1_HIP(hipMemcpyAsync(foot_vel_rel_out, d_vrel, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1847,6 +1948,7 @@ a1mpc_status a1mpc_reset_ekf_state(a1mpc_handle h) {
     A1_ORDER(h, h->stream);  // the memsets below must not overtake a launch still running on a caller's stream
     A1_HIP(hipMemsetAsync(h->d_ekf_state, 0, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double), h->stream));
     A1_HIP(hipStreamSynchronize(h->stream));
+    h->ekf_ready_n = 0;
     return A1MPC_OK;
 }
 a1mpc_status a1mpc_ekf_update_batch(a1mpc_handle h, int32_t n, double dt, int32_t assume_flat_ground, const uint8_t* movement_mode,
@@ -1882,12 +1984,15 @@ a1mpc_status a1mpc_ekf_update_batch(a1mpc_handle h, int32_t n, double dt, int32_
     EkfArgs a;
     a.n = n; a.dt = dt; a.flat = assume_flat_ground; a.state = h->d_ekf_state; a.mode = d_mm; a.ff = d_ff; a.R = d_R; a.acc = d_acc; a.w = d_w;
     a.fk = d_fk; a.fv = d_fv; a.pos_out = d_pos; a.vel_out = d_vel; a.ec_out = d_ec;
-    A1_HIP(hipEventRecord(h->ev0, s));
-    hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
+    if (n > h->ekf_ready_n) {   // (robots 0 .. ekf_ready_n - 1 have been through init_state: nothing for the init kernel to do -- one launch less per tick)
+        hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+        h->ekf_ready_n = n;
+    }
     hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((N + 1) / 2)), dim3(64), 0, s, a);
     A1_HIP(hipGetLastError());
-    A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true; A1_MARK(h, s);
+    if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = h->timing; A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(root_pos_out, d_pos, N * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(root_lin_vel_out, d_vel, N * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(estimated_contacts_out, d_ec, N * 4, hipMemcpyDeviceToHost, s));
@@ -1949,11 +2054,11 @@ a1mpc_status a1mpc_joint_torques_batch(a1mpc_handle h, int32_t n, const uint8_t*
     TorqueArgs a;
     a.n = n; a.active = d_act; a.contacts = d_c; a.Jb = d_J; a.grf = d_grf; a.fkin = d_fk; a.tg = d_tg; a.tau = d_tau;
     a.km[0] = km_foot[0]; a.km[1] = km_foot[1]; a.km[2] = km_foot[2];
-    A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(a1mpc_torque_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
     A1_HIP(hipGetLastError());
-    A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true; A1_MARK(h, s);
+    if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = h->timing; A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(joint_torques, d_tau, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipStreamSynchronize(s));
     return A1MPC_OK;
@@ -2002,11 +2107,11 @@ a1mpc_status a1mpc_update_plan_batch(a1mpc_handle h, const a1mpc_gait_config* ga
     PlanArgs a;
     a.g = *gait; a.n = n; a.movement_mode = d_mm; a.gait_counter = d_gc; a.gait_counter_speed = d_spd; a.root_lin_vel = d_v; a.Rz = d_Rz; a.Rw = d_Rw;
     a.root_pos = d_pos; a.root_lin_vel_d = d_vd; a.plan_contacts = d_pc; a.rel = d_rel; a.abs_ = d_abs; a.world = d_world;
-    A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(a1mpc_plan_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
     A1_HIP(hipGetLastError());
-    A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true; A1_MARK(h, s);
+    if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = h->timing; A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(gait_counter, d_gc, N * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
     A1_HIP(hipMemcpyAsync(plan_contacts_out, d_pc, N * 4, hipMemcpyDeviceToHost, s));
     if (rel_out) A1_HIP(hipMemcpyAsync(rel_out, d_rel, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -2031,8 +2136,8 @@ a1mpc_status a1mpc_update_plan_batch(a1mpc_handle h, const a1mpc_gait_config* ga
     (void)N
 #define A1_DEV_EPILOGUE()              \
     A1_HIP(hipGetLastError());         \
-    A1_HIP(hipEventRecord(h->ev1, s)); \
-    h->timed = true; A1_MARK(h, s); \
+    if (h->timing) A1_HIP(hipEventRecord(h->ev1, s)); \
+    h->timed = h->timing; A1_MARK(h, s); \
     return A1MPC_OK
 
 a1mpc_status a1mpc_update_plan_batch_device(a1mpc_handle h, const a1mpc_gait_config* gait, int32_t n, const uint8_t* movement_mode,
@@ -2044,7 +2149,7 @@ a1mpc_status a1mpc_update_plan_batch_device(a1mpc_handle h, const a1mpc_gait_con
     a.g = *gait; a.n = n; a.movement_mode = movement_mode; a.gait_counter = gait_counter; a.gait_counter_speed = gait_counter_speed; a.root_lin_vel = root_lin_vel;
     a.Rz = R_z; a.Rw = R_world; a.root_pos = root_pos; a.root_lin_vel_d = root_lin_vel_d; a.plan_contacts = plan_contacts_out; a.rel = rel_out; a.abs_ = abs_out;
     a.world = world_out;
-    A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(a1mpc_plan_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
     A1_DEV_EPILOGUE();
 }
@@ -2059,7 +2164,7 @@ a1mpc_status a1mpc_swing_legs_batch_device(a1mpc_handle h, int32_t n, double cou
     for (int k = 0; k < 3; ++k) { a.kp[k] = kp_foot_host[k]; a.kd[k] = kd_foot_host[k]; }
     a.Rz = R_z; a.foot_pos_abs = foot_pos_abs; a.gait_counter = gait_counter; a.target_rel = foot_pos_target_rel; a.start = foot_pos_start;
     a.rel_last = foot_pos_rel_last_time; a.target_last = foot_pos_target_last_time; a.cur_out = foot_pos_cur_out; a.kin_out = foot_forces_kin_out;
-    A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(a1mpc_swing_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
     A1_DEV_EPILOGUE();
 }
@@ -2071,11 +2176,11 @@ a1mpc_status a1mpc_contact_terrain_batch_device(a1mpc_handle h, const a1mpc_cont
                     foot_pos_recent_contact_out && terrain_angle_out);
     if (a1mpc_status st = ensure_contact_state(h, s); st != A1MPC_OK) return st;
     ContactArgs a;
-    a.recent_in = nullptr; a.z_stride = 1; a.pitch_stride = 1;
+    a.recent_in = nullptr; a.z_stride = 1; a.pitch_stride = 1; a.pk_tick = nullptr;
     a.n = n; a.counter_per_swing = cfg->counter_per_swing; a.foot_force_low = cfg->foot_force_low; a.use_terrain_adapt = cfg->use_terrain_adapt;
     contact_state_pointers(h, a); a.gait_counter = gait_counter; a.foot_force = foot_force; a.foot_pos_abs = foot_pos_abs; a.root_pos_z = root_pos_z;
     a.plan_contacts = plan_contacts; a.pitch_d = root_euler_d_pitch; a.contacts = contacts_out; a.recent_out = foot_pos_recent_contact_out; a.terrain_out = terrain_angle_out;
-    A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     launch_contact_terrain(a, s);
     A1_DEV_EPILOGUE();
 }
@@ -2089,7 +2194,7 @@ a1mpc_status a1mpc_leg_state_batch_device(a1mpc_handle h, int32_t n, const doubl
     std::memcpy(a.rho_fix, rho_fix_host, sizeof a.rho_fix); std::memcpy(a.rho_opt, rho_opt_host, sizeof a.rho_opt);
     a.q = joint_pos; a.qd = joint_vel; a.R = R_world; a.pos = root_pos; a.vel = root_lin_vel; a.rel = foot_pos_rel_out; a.Jb = j_foot_blocks_out;
     a.vrel = foot_vel_rel_out; a.pabs = foot_pos_abs_out; a.vabs = foot_vel_abs_out; a.pworld = foot_pos_world_out; a.vworld = foot_vel_world_out;
-    A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(a1mpc_leg_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
     A1_DEV_EPILOGUE();
 }
@@ -2106,8 +2211,11 @@ a1mpc_status a1mpc_ekf_update_batch_device(a1mpc_handle h, int32_t n, double dt,
     EkfArgs a;
     a.n = n; a.dt = dt; a.flat = assume_flat_ground; a.state = h->d_ekf_state; a.mode = movement_mode; a.ff = foot_force; a.R = R_world; a.acc = imu_acc;
     a.w = imu_ang_vel; a.fk = foot_pos_rel; a.fv = foot_vel_rel; a.pos_out = root_pos_out; a.vel_out = root_lin_vel_out; a.ec_out = estimated_contacts_out;
-    A1_HIP(hipEventRecord(h->ev0, s));
-    hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
+    if (n > h->ekf_ready_n) {   // (robots 0 .. ekf_ready_n - 1 have been through init_state: nothing for the init kernel to do -- one launch less per tick)
+        hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+        h->ekf_ready_n = n;
+    }
     hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((N + 1) / 2)), dim3(64), 0, s, a);
     A1_DEV_EPILOGUE();
 }
@@ -2118,7 +2226,7 @@ a1mpc_status a1mpc_joint_torques_batch_device(a1mpc_handle h, int32_t n, const u
     TorqueArgs a;
     a.n = n; a.active = active; a.contacts = contacts; a.Jb = j_foot_blocks; a.grf = grf; a.fkin = f_kin; a.tg = torques_gravity; a.tau = joint_torques;
     a.km[0] = km_foot_host[0]; a.km[1] = km_foot_host[1]; a.km[2] = km_foot_host[2];
-    A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     hipLaunchKernelGGL(a1mpc_torque_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
     A1_DEV_EPILOGUE();
 }
@@ -2231,6 +2339,7 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     A1_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_in), h->h_pin_in_bytes));
     A1_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_out), out_max));
     A1_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), h->h_pin_bytes, hipHostMallocDefault));
+    { void* dp = nullptr; if (hipHostGetDevicePointer(&dp, h->h_pin, 0) == hipSuccess) h->d_pin = static_cast<char*>(dp); else (void)hipGetLastError(); }
     // One-time, per process: the first launches / copies through a fresh HIP runtime cost milliseconds (code-object load, pool set-up);
     // a 400 Hz loop should not pay that on its first tick (measured 5 ms -> 0.4 ms), so the tick's operation mix is exercised here.
     static bool runtime_warmed_dev[64] = {};   // per device: a sharded handle (a1mpc_sharded_*) creates one engine handle on every GPU of the node
@@ -2321,6 +2430,12 @@ a1mpc_status a1mpc_get_warm_start(a1mpc_handle h, int32_t n, double* x_out, doub
     return A1MPC_OK;
 }
 
+a1mpc_status a1mpc_set_timing(a1mpc_handle h, int32_t on) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    h->timing = on != 0;
+    if (!h->timing) { h->timed = false; h->tick_timed = false; h->staged = false; }
+    return A1MPC_OK;
+}
 a1mpc_status a1mpc_set_profiling(a1mpc_handle h, int32_t on) {
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
     h->profiling = on != 0;
@@ -2512,16 +2627,16 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
         a.order = hints_gen ? h->d_order : nullptr;
         a.cost = hints_gen ? h->d_cost : nullptr;
         a.predict = (hints_gen && h->hint_n != -n) ? 1 : 0;  // (the history of a general-path batch is remembered as -n: never mixed up with a fast-path batch of the same size)
-        h->staged = split_gen;
-        A1_HIP(hipEventRecord(h->ev0, s));
+        h->staged = split_gen && h->timing;
+        if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
         if (split_gen) {
-            if (a1mpc_status stg = launch_gen_split(h->cfg.horizon, a, h->d_prep_gen, h->d_counter, s, h->ev_mid); stg != A1MPC_OK) return stg;
+            if (a1mpc_status stg = launch_gen_split(h->cfg.horizon, a, h->d_prep_gen, h->d_counter, s, h->timing ? h->ev_mid : nullptr); stg != A1MPC_OK) return stg;
             if (hints_gen) h->hint_n = -n;   // the cost buffer now holds this batch's costs: the next general-path solve of this size is ordered by them
         } else {
             if (a1mpc_status stg = launch_gen(h->cfg.horizon, a, s); stg != A1MPC_OK) return stg;
         }
-        A1_HIP(hipEventRecord(h->ev1, s));
-        h->timed = true;
+        if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
+        h->timed = h->timing;
         A1_MARK(h, s);
         return A1MPC_OK;
     }
@@ -2540,7 +2655,7 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     a.order = hints ? h->d_order : nullptr;
     a.cost = hints ? h->d_cost : nullptr;
     a.predict = (hints && h->hint_n != n) ? 1 : 0;  // first solve of this batch size: order by the set-up kernel's guess instead
-    A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     // Round 5 trial (opt-in, see warm_order_enabled): the fused kernel of a warm-started tick launches its workgroups in the order of the previous tick's per-QP
     // cost, longest first (the cost buffer holds it: hint_n == n; the fused kernel records this tick's).  Scheduling only: every result is bit-identical in any order.
     if (warm_fused && h->schedule && n >= kScheduleMinBatch && n > kCoopMaxBatch && warm_order_enabled()) {
@@ -2553,7 +2668,7 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
         a.tq_active = tq->active; a.tq_J = tq->J; a.tq_fkin = tq->fkin; a.tq_tg = tq->tg; a.tq_km = tq->km; a.tq_tau = tq->tau;
         tq->fused = true;
     }
-    h->staged = split;
+    h->staged = split && h->timing;
     h->clk_n = 0; h->clk_tick = false;
     if (h->profiling && h->cfg.horizon > 1 && a.contact_stride == 0) {
         if (!h->d_clk) A1_HIP(hipMalloc(&h->d_clk, static_cast<size_t>(h->max_batch) * kTickStages * sizeof(long long)));
@@ -2561,12 +2676,12 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
         a.clk = h->d_clk;
     }
     g_clk_ran = false;
-    a1mpc_status st = launch_mpc(h->cfg.horizon, a, h->d_prep, h->d_counter, s, split, h->ev_mid);
+    a1mpc_status st = launch_mpc(h->cfg.horizon, a, h->d_prep, h->d_counter, s, split, h->timing ? h->ev_mid : nullptr);
     if (st != A1MPC_OK) return st;
     if (a.clk != nullptr && g_clk_ran) { h->clk_n = n; h->clk_tick = !split; }   // (a kernel without stamps ran: the record stays "not profiled")
     if (hints) h->hint_n = n;   // the cost buffer now holds this batch's costs: the next solve of this size is ordered by them (sorted in front of its ADMM kernel)
-    A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true;
+    if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = h->timing;
     A1_MARK(h, s);
     return A1MPC_OK;
 }
@@ -2627,7 +2742,7 @@ a1mpc_status a1mpc_control_tick_device(a1mpc_handle h, const a1mpc_tick_params* 
         A1_HIP(hipMemsetAsync(h->d_ekf_state, 0, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double), s));
     }
     if (a1mpc_status st = ensure_contact_state(h, s); st != A1MPC_OK) return st;
-    A1_HIP(hipEventRecord(h->ev_tick0, s));   // (ev_tick0 .. ev_tick1 = the whole tick; ev0 .. ev1 = the MPC launch, as after every solve)
+    if (h->timing) A1_HIP(hipEventRecord(h->ev_tick0, s));   // (ev_tick0 .. ev_tick1 = the whole tick; ev0 .. ev1 = the MPC launch, as after every solve)
     {   // 1. leg state (uses the previous estimate of root_pos / root_lin_vel for the world-frame outputs, like the reference's callback)
         LegArgs a;
         a.n = n;
@@ -2641,37 +2756,35 @@ a1mpc_status a1mpc_control_tick_device(a1mpc_handle h, const a1mpc_tick_params* 
         a.n = n; a.dt = p->control_dt; a.flat = p->assume_flat_ground; a.state = h->d_ekf_state; a.mode = bf->movement_mode; a.ff = bf->foot_force; a.R = bf->R_world;
         a.acc = bf->imu_acc; a.w = bf->imu_ang_vel; a.fk = bf->foot_pos_rel; a.fv = bf->foot_vel_rel; a.pos_out = bf->root_pos; a.vel_out = bf->root_lin_vel;
         a.ec_out = bf->estimated_contacts;
-        hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+        if (n > h->ekf_ready_n) {   // (robots 0 .. ekf_ready_n - 1 have been through init_state: nothing for the init kernel to do -- one launch less per tick)
+            hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+            h->ekf_ready_n = n;
+        }
         hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((N + 1) / 2)), dim3(64), 0, s, a);
     }
-    {   // 3. update_plan
+    {   // 3. update_plan + 4. swing legs, one launch (a1mpc_plan_swing_kernel).  (Round 5 trial: the swing block as its own launch on a second stream beside stage 5 --
+        //    both only need the plan's outputs -- joined in front of the MPC launch: the two cross-stream event waits cost more than the 5 us kernel they hide,
+        //    0.490 -> 0.503 ms per tick at 4096 robots; profiles/r05_control_tick.txt)
         PlanArgs a;
         a.g = p->gait; a.n = n; a.movement_mode = bf->movement_mode; a.gait_counter = bf->gait_counter; a.gait_counter_speed = bf->gait_counter_speed;
         a.root_lin_vel = bf->root_lin_vel; a.Rz = bf->R_z; a.Rw = bf->R_world; a.root_pos = bf->root_pos; a.root_lin_vel_d = bf->root_lin_vel_d;
         a.plan_contacts = bf->plan_contacts; a.rel = bf->foot_pos_target_rel; a.abs_ = bf->foot_pos_target_abs; a.world = bf->foot_pos_target_world;
-        hipLaunchKernelGGL(a1mpc_plan_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
+        SwingArgs w;
+        w.n = n; w.counter_per_swing = p->gait.counter_per_swing; w.dt = p->control_dt;
+        for (int k = 0; k < 3; ++k) { w.kp[k] = p->kp_foot[k]; w.kd[k] = p->kd_foot[k]; }
+        w.Rz = bf->R_z; w.foot_pos_abs = bf->foot_pos_abs; w.gait_counter = bf->gait_counter; w.target_rel = bf->foot_pos_target_rel; w.start = bf->foot_pos_start;
+        w.rel_last = bf->foot_pos_rel_last_time; w.target_last = bf->foot_pos_target_last_time; w.cur_out = bf->foot_pos_cur; w.kin_out = bf->foot_forces_kin;
+        hipLaunchKernelGGL(a1mpc_plan_swing_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a, w);
     }
-    {   // 4. swing legs
-        SwingArgs a;
-        a.n = n; a.counter_per_swing = p->gait.counter_per_swing; a.dt = p->control_dt;
-        for (int k = 0; k < 3; ++k) { a.kp[k] = p->kp_foot[k]; a.kd[k] = p->kd_foot[k]; }
-        a.Rz = bf->R_z; a.foot_pos_abs = bf->foot_pos_abs; a.gait_counter = bf->gait_counter; a.target_rel = bf->foot_pos_target_rel; a.start = bf->foot_pos_start;
-        a.rel_last = bf->foot_pos_rel_last_time; a.target_last = bf->foot_pos_target_last_time; a.cur_out = bf->foot_pos_cur; a.kin_out = bf->foot_forces_kin;
-        hipLaunchKernelGGL(a1mpc_swing_kernel, dim3(static_cast<unsigned>((N * 4 + 255) / 256)), dim3(256), 0, s, a);
-    }
-    {   // 5. contacts / terrain: root_pos[2] and root_euler_d[1] are read / written in place (strides of 3)
+    {   // 5. contacts / terrain: root_pos[2] and root_euler_d[1] are read / written in place (strides of 3); 6. the tick record, by the same lanes
         ContactArgs a;
         a.recent_in = nullptr; a.z_stride = 3; a.pitch_stride = 3;
+        a.pk_euler = bf->root_euler; a.pk_pos = bf->root_pos; a.pk_ang_vel = bf->root_ang_vel; a.pk_lin_vel = bf->root_lin_vel; a.pk_euler_d = bf->root_euler_d;
+        a.pk_lin_vel_d = bf->root_lin_vel_d; a.pk_ang_vel_d = bf->root_ang_vel_d; a.pk_pos_d_z = bf->root_pos_d_z; a.pk_tick = h->d_tickrec;
         a.n = n; a.counter_per_swing = p->contact.counter_per_swing; a.foot_force_low = p->contact.foot_force_low; a.use_terrain_adapt = p->contact.use_terrain_adapt;
         contact_state_pointers(h, a); a.gait_counter = bf->gait_counter; a.foot_force = bf->foot_force; a.foot_pos_abs = bf->foot_pos_abs; a.root_pos_z = bf->root_pos + 2;
         a.plan_contacts = bf->plan_contacts; a.pitch_d = bf->root_euler_d + 1; a.contacts = bf->contacts; a.recent_out = bf->foot_pos_recent_contact; a.terrain_out = bf->terrain_angle;
         launch_contact_terrain(a, s);
-    }
-    {   // 6. the tick record
-        PackArgs a;
-        a.n = n; a.euler = bf->root_euler; a.pos = bf->root_pos; a.ang_vel = bf->root_ang_vel; a.lin_vel = bf->root_lin_vel; a.euler_d = bf->root_euler_d;
-        a.lin_vel_d = bf->root_lin_vel_d; a.ang_vel_d = bf->root_ang_vel_d; a.pos_d_z = bf->root_pos_d_z; a.tick = h->d_tickrec;
-        hipLaunchKernelGGL(a1mpc_tick_pack_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
     }
     A1_HIP(hipGetLastError());
     double* d_km = h->d_tickrec + static_cast<size_t>(h->max_batch) * 22;
@@ -2693,8 +2806,8 @@ a1mpc_status a1mpc_control_tick_device(a1mpc_handle h, const a1mpc_tick_params* 
         A1_HIP(hipGetLastError());
     }
     h->tick_fused = tq.fused;
-    A1_HIP(hipEventRecord(h->ev_tick1, s));
-    h->tick_timed = true;
+    if (h->timing) A1_HIP(hipEventRecord(h->ev_tick1, s));
+    h->tick_timed = h->timing;
     A1_MARK(h, s);
     return A1MPC_OK;
 }
@@ -2765,6 +2878,17 @@ static a1mpc_status host_submit(a1mpc_handle h, int32_t n, const double* x0, con
     std::memcpy(hin + o_c, contact, N * 4);
     hipStream_t s = h->stream;
     A1_ORDER(h, s);
+    // Round 5, the batch-1 control tick (BASELINE's latency metric): for a handful of QPs the kernel reads its inputs from, and writes its results to, the handle's
+    // PINNED block itself (device-mapped host memory: 1.3 KB in, ~100 B out per QP over PCIe, a few transactions) -- the two staging copies each cost more on the
+    // GPU's timeline than the bytes they move.  Same kernel, same bits.  A1MPC_ZERO_COPY_MAX (default 8 QPs; 0 = always stage through device memory).
+    static const int zero_copy_max = [] { const char* e = getenv("A1MPC_ZERO_COPY_MAX"); return e ? atoi(e) : 8; }();
+    if (n <= zero_copy_max && h->d_pin != nullptr) {
+        char* din = h->d_pin; char* dout = h->d_pin + h->h_pin_in_bytes;
+        return a1mpc_solve_batch_device(
+            h, n, reinterpret_cast<const double*>(din + o_x0), reinterpret_cast<const double*>(din + o_xr), reinterpret_cast<const double*>(din + o_R),
+            reinterpret_cast<const double*>(din + o_f), reinterpret_cast<const uint8_t*>(din + o_c), reinterpret_cast<double*>(dout + q.q_grf),
+            want_u ? reinterpret_cast<double*>(dout + q.q_u) : nullptr, reinterpret_cast<int32_t*>(dout + q.q_it), reinterpret_cast<int32_t*>(dout + q.q_st), s);
+    }
     A1_HIP(hipMemcpyAsync(h->d_in, hin, in_bytes, hipMemcpyHostToDevice, s));
     a1mpc_status st = a1mpc_solve_batch_device(
         h, n, reinterpret_cast<const double*>(h->d_in + o_x0), reinterpret_cast<const double*>(h->d_in + o_xr),
@@ -2820,7 +2944,7 @@ a1mpc_status a1mpc_terrain_batch(a1mpc_handle h, int32_t use_terrain_adapt, int3
     A1_HIP(hipMemcpyAsync(d_pd, root_euler_d_pitch, N * sizeof(double), hipMemcpyHostToDevice, s));
     ContactArgs a;
     std::memset(&a, 0, sizeof a);
-    a.n = n; a.use_terrain_adapt = use_terrain_adapt; contact_state_pointers(h, a); a.root_pos_z = d_z; a.pitch_d = d_pd; a.z_stride = 1; a.pitch_stride = 1;
+    a.n = n; a.use_terrain_adapt = use_terrain_adapt; contact_state_pointers(h, a); a.root_pos_z = d_z; a.pitch_d = d_pd; a.z_stride = 1; a.pitch_stride = 1; a.pk_tick = nullptr;
     a.recent_in = d_rec; a.recent_out = nullptr; a.terrain_out = d_ta;
     launch_contact_terrain(a, s);
     A1_HIP(hipGetLastError());
@@ -2956,7 +3080,7 @@ a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_confi
     a.tab = h->d_tab1; a.n = n;
     a.root_acc = h->d_aux; a.Rz = h->d_Rz; a.R = h->d_R; a.foot = h->d_foot; a.contact = h->d_contact;
     a.grf = h->d_grf; a.u_full = h->d_u; a.iters = h->d_iters; a.status = h->d_status; a.nfact = h->d_nfact;
-    A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
 #ifdef A1MPC_DEV_SLIM
     a1mpc_status st = fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "slim development build");
 #else
@@ -2964,8 +3088,8 @@ a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_confi
     a1mpc_status st = launch<1, kModeBalance>(a, s);
 #endif
     if (st != A1MPC_OK) return st;
-    A1_HIP(hipEventRecord(h->ev1, s));
-    h->timed = true;
+    if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
+    h->timed = h->timing;
     A1_MARK(h, s);
     A1_HIP(hipMemcpyAsync(grf_body_out, h->d_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (f_world_out) A1_HIP(hipMemcpyAsync(f_world_out, h->d_u, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -799,20 +799,23 @@ struct RowSolver {
                 });
                 if constexpr (GEN) {
 #pragma unroll 1
-                    for (int t = coop_id; t < H; t += coop_n) {  // every block is evaluated: a per-block pruning bound like the fast path's was tried and measured slower here
-                                                   // (3.11 -> 3.35 ms at 4096 x h10: per-lane skips do not skip at wave level and cost registers)
-                                                   // and so was the fast path's column loop (below) with the bound gamma (sum_c |cu_c| max|B~w_c| + ..) + ..:
-                                                   // the triangle inequality over the three omega rows is too loose to stop early (1.86 -> 1.80 M solves/s)
+                    for (int t = coop_id; t < H; t += coop_n) {  // every block is evaluated.  Tried and measured slower here: a per-block pruning bound like the fast path's
+                                                   // (round 2: 3.11 -> 3.35 ms at 4096 x h10, per-lane skips do not skip at wave level and cost registers); the fast path's
+                                                   // column loop with the bound gamma (sum_c |cu_c| max|B~w_c| + ..) + .. (round 2: too loose to stop, 1.86 -> 1.80 M solves/s);
+                                                   // and (round 5, profiles/r05_general_path_early_stop.txt) the same loop with the tighter, rounding-safe bound
+                                                   // max_b (sum_c |cu_c| max_t |B~w_t[c][b]|): exact, but the blocks of the last horizon steps (gamma_st = 0: they do not decay
+                                                   // with t) never tie with their bound the way the fast path's do, so no sweep stops -- the set-up got 18-25 % slower at h = 16 / 20
                         // entry (s,a),(t,b) = beta_st (y . B~w_t[:,b] + k_{b%3})  with  y = gamma_st dt^2 T'(q T B~w_s[:,a]) + q_w B~w_s[:,a]  and the
                         // velocity-row constants k: 3 FMAs per entry and one table (round 2; it was 6 FMAs and two tables)
+                        const int tc = t;
                         double gb[2 * H], Dt[12], Bwt[3][12];
 #pragma unroll
-                        for (int s2 = 0; s2 < H; ++s2) { gb[2 * s2] = tab[(s2 * H + t) * 2]; gb[2 * s2 + 1] = tab[(s2 * H + t) * 2 + 1]; }
+                        for (int s2 = 0; s2 < H; ++s2) { gb[2 * s2] = tab[(s2 * H + tc) * 2]; gb[2 * s2 + 1] = tab[(s2 * H + tc) * 2 + 1]; }
 #pragma unroll
                         for (int b = 0; b < 12; ++b) {
-                            Dt[b] = lds[L::DL + t * 12 + b];
+                            Dt[b] = lds[L::DL + tc * 12 + b];
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) Bwt[c][b] = lds[L::BW + (t * 3 + c) * 12 + b];
+                            for (int c = 0; c < 3; ++c) Bwt[c][b] = lds[L::BW + (tc * 3 + c) * 12 + b];
                         }
                         static_for<H>([&](auto S) {
                             constexpr int s = A1_CV(S);
@@ -976,6 +979,25 @@ struct RowSolver {
         first_special = warm || !(P.fz_min <= 0.0 && P.fz_max >= 0.0);
         eqmask = 0; cmask = 0;
         set_sync();  // the Ruiz D table (aliased into the factor region) is dead from here on
+        // Every global load of the hot state is issued HERE, back to back, ahead of the per-step arithmetic (round 5): the carried iterates and, on the update path, what the
+        // previous tick left in the workspace.  Inside the loop below they sat behind per-step branches (pattern change | update | plain), one exposed memory round trip per
+        // horizon step of a lone wavefront -- ~20 k of the 43 k cycles the update path's hot state + hand-off took (profiles/r05_tick_stages_*.json).
+        [[maybe_unused]] constexpr bool kUpdPath = UPD && MODE == kModeMpc && H > 1 && !GEN;
+        [[maybe_unused]] double cDp[kUpdPath ? H : 1], cE0p[kUpdPath ? H : 1], cZ0[kUpdPath ? H : 1], cZ1[kUpdPath ? H : 1], ccp = 0.0;
+        static_for<H>([&](auto T) {
+            constexpr int t = A1_CV(T);
+            xh[t] = (warm && act) ? io.warm_x[t * 12 + ci] : 0.0;  // x_s = D^-1 x  <=>  xh = x
+            park_warm_y(io, t);
+            if constexpr (kUpdPath) {
+                cDp[t] = 1.0; cE0p[t] = 1.0; cZ0[t] = 0.0; cZ1[t] = 0.0;
+                if (upd) {
+                    const double* cr = io.carry;
+                    cDp[t] = act ? cr[CR::D + t * 12 + ci] : 1.0; cE0p[t] = act ? cr[CR::E0 + t * 12 + ci] : 1.0;   // (E1' == E0' on the fx / fy lanes: see the Ruiz passes)
+                    cZ0[t] = act ? cr[CR::Z0 + t * 12 + ci] : 0.0; cZ1[t] = (act && comp < 2) ? cr[CR::Z1 + t * 12 + ci] : 0.0;
+                }
+            }
+        });
+        if constexpr (kUpdPath) { if (upd) ccp = io.carry[CR::C]; }
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
             // the step's contact flags (a per-step schedule when contact_stride = 4): bounds of my slot-0 row at step t
@@ -994,16 +1016,12 @@ struct RowSolver {
             rr1[t] = E1[t] * E1[t] * rho;
             const double di = 1.0 / D[t];
             dI2[t] = di * di;
-            xh[t] = (warm && act) ? io.warm_x[t * 12 + ci] : 0.0;  // x_s = D^-1 x  <=>  xh = x
-            park_warm_y(io, t);
             if (act) lds[L::CG + t * 12 + ci] = csc * g[t];          // D^-1 q_s = c g
             if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) {
                 if (upd && reinit) {
                     // pattern change: the previous solve's SCALED x_s = x / D', y_s = c' y / E' go through osqp_warm_start_x / _y as if they were unscaled -- a plain
                     // warm start (the code of warm_start = 1 below and in the first iteration) from those values
-                    const double* cr = io.carry;
-                    const double cp = cr[CR::C];
-                    const double Dp = act ? cr[CR::D + t * 12 + ci] : 1.0, E0p = act ? cr[CR::E0 + t * 12 + ci] : 1.0;   // (E1' == E0' on the fx / fy lanes: see the Ruiz passes)
+                    const double cp = ccp, Dp = cDp[t], E0p = cE0p[t];
                     xh[t] = act ? xh[t] / Dp : 0.0;
                     const double ce = cp / E0p;
                     wh0[t] = act ? ce * wh0[t] : 0.0;
@@ -1016,10 +1034,7 @@ struct RowSolver {
                     // (osqp_warm_start semantics); with delta = z0 - A x0 both are reproduced exactly by parking  y^ = y0 + (1 - alpha) rr delta / c  in the w
                     // registers and by handing the first iteration  c g - A'[(2 - alpha) rr delta]  in the slot of c g (admm_iteration<FIRST> is not touched;
                     // the true c g comes back after iteration 1, see load_prepared / advance).
-                    const double* cr = io.carry;
-                    const double cp = cr[CR::C];
-                    const double Dp = act ? cr[CR::D + t * 12 + ci] : 1.0, E0p = act ? cr[CR::E0 + t * 12 + ci] : 1.0;
-                    const double zp0 = act ? cr[CR::Z0 + t * 12 + ci] : 0.0, zp1 = (act && comp < 2) ? cr[CR::Z1 + t * 12 + ci] : 0.0;
+                    const double cp = ccp, Dp = cDp[t], E0p = cE0p[t], zp0 = cZ0[t], zp1 = cZ1[t];
                     xh[t] = act ? D[t] * (xh[t] / Dp) : 0.0;
                     const double cr_c = cp / csc;
                     // E1 == E0 and E1' == E0' bit for bit on the fx / fy lanes (my two rows share their scaling: see the Ruiz passes): one pair of quotients serves both rows

@@ -56,7 +56,7 @@ class TickBuffers(C.Structure):  # a1mpc_tick_buffers: device pointers, in the h
     _fields_ = [(k, C.c_void_p) for k in TICK_BUFFER_FIELDS]
 
 
-EXPORTS = ["a1mpc_default_tick_params", "a1mpc_control_tick_device", "a1mpc_last_control_tick_ms", "a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_get_workspace_z", "a1mpc_get_workspace_scaling", "a1mpc_last_warm_start_mode", "a1mpc_set_profiling", "a1mpc_last_stage_cycles", "a1mpc_last_tick_stage_cycles", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
+EXPORTS = ["a1mpc_set_timing", "a1mpc_default_tick_params", "a1mpc_control_tick_device", "a1mpc_last_control_tick_ms", "a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_get_workspace_z", "a1mpc_get_workspace_scaling", "a1mpc_last_warm_start_mode", "a1mpc_set_profiling", "a1mpc_last_stage_cycles", "a1mpc_last_tick_stage_cycles", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error", "a1mpc_build_info", "a1mpc_pipeline_create", "a1mpc_pipeline_submit_device", "a1mpc_pipeline_submit",
@@ -135,6 +135,8 @@ def load_library(path=None):
     lib.a1mpc_set_profiling.argtypes = [vp, i32]; lib.a1mpc_set_profiling.restype = C.c_int
     lib.a1mpc_last_stage_cycles.argtypes = [vp, dp, C.POINTER(C.c_int32)]; lib.a1mpc_last_stage_cycles.restype = C.c_int
     lib.a1mpc_last_warm_start_mode.argtypes = [vp, C.POINTER(C.c_int32)]; lib.a1mpc_last_warm_start_mode.restype = C.c_int
+    if path == _build.LIB_PATH or hasattr(lib, "a1mpc_set_timing"):   # (round 5)
+        lib.a1mpc_set_timing.argtypes = [vp, i32]; lib.a1mpc_set_timing.restype = C.c_int
     if path == _build.LIB_PATH or hasattr(lib, "a1mpc_control_tick_device"):   # (round 5)
         lib.a1mpc_default_tick_params.argtypes = [C.POINTER(TickParams)]; lib.a1mpc_default_tick_params.restype = None
         lib.a1mpc_control_tick_device.argtypes = [vp, C.POINTER(TickParams), C.POINTER(TickBuffers), i32, vp]; lib.a1mpc_control_tick_device.restype = C.c_int
@@ -283,6 +285,10 @@ class Engine:
         x = np.zeros((n, NU * h)); y = np.zeros((n, 20 * h)); rho = np.zeros(n)
         _check(self.lib, self.lib.a1mpc_get_warm_start(self._h, int(n), _dp(x), _dp(y), _dp(rho)), "a1mpc_get_warm_start")
         return x, y, rho
+
+    def set_timing(self, on=True):
+        """a1mpc_set_timing: the handle's HIP timing events on / off (off: last_kernel_ms & co. are unavailable, every tick is a few event records lighter)"""
+        _check(self.lib, self.lib.a1mpc_set_timing(self._h, 1 if on else 0), "a1mpc_set_timing")
 
     def set_profiling(self, on=True):
         _check(self.lib, self.lib.a1mpc_set_profiling(self._h, 1 if on else 0), "a1mpc_set_profiling")

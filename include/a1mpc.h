@@ -479,6 +479,12 @@ a1mpc_status a1mpc_last_warm_start_mode(a1mpc_handle h, int32_t* mode_out);
  * next call.  Validated like a1mpc_create; a refused configuration leaves the handle's configuration as it was. */
 a1mpc_status a1mpc_update_config(a1mpc_handle h, const a1mpc_config* cfg);
 
+/* The handle's HIP timing events (around every launch: a1mpc_last_kernel_ms, a1mpc_last_stage_ms, a1mpc_last_control_tick_ms read them) on (default) / off.  An event
+ * record is a packet of its own on the GPU's queue; a 400 Hz control loop that never reads the instrumentation can turn it off -- three records less per MPC tick, four
+ * per control tick (round 5: batch-1 p50 -5 us, a chained control tick -15 us at 4096 robots).  With timing off the three calls above return
+ * A1MPC_ERR_INVALID_ARGUMENT ("no kernel has been launched ...").  No result depends on it. */
+a1mpc_status a1mpc_set_timing(a1mpc_handle h, int32_t on);
+
 /* instrumentation: duration of the last kernel launched through this handle (HIP events on its stream;
  * synchronises that stream), bytes of dynamic LDS per workgroup and QPs per workgroup of the horizon's kernel */
 a1mpc_status a1mpc_last_kernel_ms(a1mpc_handle h, float* ms_out);

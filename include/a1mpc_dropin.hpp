@@ -293,7 +293,7 @@ class ComputeGrfGpu {
         for (int i = 0; i < A1MPC_NUM_DOF; ++i) c.r[i] = state.r_weights(i);
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c.inertia_body[i * 3 + j] = state.a1_trunk_inertia(i, j);
         c.mu = 0.3; c.fz_min = 0.0; c.fz_max = 180.0;   // S/ConvexMpc.cpp:8,223-224
-        if (!h_) check_status(a1mpc_create(&c, 1, device_, &h_), "a1mpc_create");
+        if (!h_) { check_status(a1mpc_create(&c, 1, device_, &h_), "a1mpc_create"); a1mpc_set_timing(h_, 0); }   // (the control loop never reads the handle's timing events)
         else check_status(a1mpc_update_config(h_, &c), "a1mpc_update_config");   // host-only, every tick
         cfg_ = c;
     }

@@ -1,7 +1,7 @@
 // tests/cpp/latency_harness.cpp -- batch-1 tick latency of the C ABI from C++ (no Python in the loop): BASELINE configs[1], SURVEY 8(d) config 2
 // = trot, horizon 10, 10 000 sequential warm-started ticks (S/A1Params.h:10: a tick every 2.5 ms; S/MainGazebo.cpp:57-68 is the caller).
 // Host pointers in and out (PCIe and launch included), one caller thread.  Prints one JSON object.
-//   latency_harness [ticks=10000] [pace_us=0] [warm_mode=1] [horizon=10]      pace_us > 0 sleeps between ticks like the reference's thread 1 does; horizon 10 / 16 / 20
+//   latency_harness [ticks=10000] [pace_us=0] [warm_mode=1] [horizon=10] [timing_events=0]      pace_us > 0 sleeps between ticks like the reference's thread 1 does; horizon 10 / 16 / 20
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -24,6 +24,7 @@ int main(int argc, char** argv) {
     const int warm_mode = argc > 3 ? atoi(argv[3]) : 1;   // 1 = fresh set-up + warm start, 2 = the reference's update path (a1mpc.h)
     const int H = argc > 4 ? atoi(argv[4]) : 10;          // PLAN_HORIZON (S/A1Params.h:26 fixes 10; BASELINE configs[3] / [4]: 16 / 20)
     if (H != 10 && H != 16 && H != 20) { std::fprintf(stderr, "horizon must be 10, 16 or 20\n"); return 1; }
+    const int timing = argc > 5 ? atoi(argv[5]) : 0;      // the handle's HIP timing events (a1mpc_set_timing): off by default here -- a control loop does not read them
     a1mpc_config cfg;
     a1mpc_default_config(&cfg);
     const double q[13] = {20, 10, 1, 0, 0, 420, .05, .05, .05, 30, 30, 10, 0};   // config/gazebo_a1_mpc.yaml:40-72
@@ -33,6 +34,7 @@ int main(int argc, char** argv) {
     cfg.horizon = H; cfg.warm_start = warm_mode;
     a1mpc_handle h = nullptr;
     if (a1mpc_create(&cfg, 1, 0, &h) != A1MPC_OK) { std::fprintf(stderr, "a1mpc_create: %s\n", a1mpc_last_error()); return 2; }
+    a1mpc_set_timing(h, timing);
     std::mt19937_64 rng(0xA1 + 2);
     std::normal_distribution<double> N01(0.0, 1.0);
     const double nominal[12] = {0.17, 0.15, -0.35, 0.17, -0.15, -0.35, -0.17, 0.15, -0.35, -0.17, -0.15, -0.35};
@@ -74,8 +76,8 @@ int main(int argc, char** argv) {
     int over = 0, worst_t = skip;
     for (int t = skip; t < ticks; ++t) { over += lat[t] > 2.5; if (lat[t] > lat[worst_t]) worst_t = t; }
     double mean_it = 0; for (int t = skip; t < ticks; ++t) mean_it += iters[t]; mean_it /= (ticks - skip);
-    std::printf("{\"warm_start\": %d, \"workload\": \"config2 trot, h=%d, batch 1, warm start, host pointers in/out, C++ caller, %s\", \"horizon\": %d, \"ticks\": %zu, \"p50_ms\": %.4f, \"p99_ms\": %.4f, "
+    std::printf("{\"warm_start\": %d, \"workload\": \"config2 trot, h=%d, batch 1, warm start, host pointers in/out, C++ caller, %s\", \"horizon\": %d, \"timing_events\": %d, \"ticks\": %zu, \"p50_ms\": %.4f, \"p99_ms\": %.4f, "
                 "\"p999_ms\": %.4f, \"max_ms\": %.4f, \"ticks_over_2p5_ms\": %d, \"worst_tick_index\": %d, \"worst_tick_iters\": %d, \"mean_iters\": %.1f, \"not_solved\": %d}\n",
-                warm_mode, H, pace_us > 0 ? "paced" : "back to back", H, v.size(), pct(0.50), pct(0.99), pct(0.999), s.back(), over, worst_t, iters[worst_t], mean_it, bad_status);
+                warm_mode, H, pace_us > 0 ? "paced" : "back to back", H, timing, v.size(), pct(0.50), pct(0.99), pct(0.999), s.back(), over, worst_t, iters[worst_t], mean_it, bad_status);
     return 0;
 }

@@ -27,7 +27,7 @@ extern "C" void n2b_tick(int n, int max_batch, void* state, double counter_per_s
     a.n = n; a.counter_per_swing = counter_per_swing; a.foot_force_low = foot_force_low; a.use_terrain_adapt = use_terrain_adapt;
     a.rec = reinterpret_cast<CtRecord*>(state); a.leg_ring = reinterpret_cast<double*>(a.rec + max_batch); a.terrain_ring = a.leg_ring + static_cast<size_t>(max_batch) * kCtLegRing; a.stride = max_batch;
     a.gait_counter = gc; a.foot_force = ff; a.foot_pos_abs = foot; a.root_pos_z = z; a.plan_contacts = plan; a.pitch_d = pitch; a.contacts = contacts;
-    a.recent_out = recent_out; a.terrain_out = terrain_out; a.recent_in = recent_in; a.z_stride = 1; a.pitch_stride = 1;
+    a.recent_out = recent_out; a.terrain_out = terrain_out; a.recent_in = recent_in; a.z_stride = 1; a.pitch_stride = 1; a.pk_tick = nullptr;
     for (int b = 0; b < n; ++b) contact_terrain_robot(a, b, a.rec + b);   // (the kernel proper adds the wavefront's LDS staging of the records around this)
 }
 '''

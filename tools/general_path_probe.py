@@ -28,5 +28,5 @@ for h, n in ((10, 4096), (10, 16384), (16, 8192), (20, 8192)):
                     schedule_only_kernel_ms=float(np.median(ms_s)), schedule_only_solves_per_s=n / (float(np.median(ms_s)) * 1e-3), mean_iters_schedule_only=float(c["iters"].mean()),
                     solved_schedule_only=float((c["status"] == 1).mean()), mean_iters_fast=float(a["iters"].mean()), mean_iters_general=float(b["iters"].mean()), solved_general=float((b["status"] == 1).mean())))
     print(out[-1], flush=True)
-os.makedirs("gpurun_out/r02", exist_ok=True)
-json.dump(out, open("gpurun_out/r02/general_path_probe.json", "w"), indent=1)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/general_path_probe.json", "w"), indent=1)

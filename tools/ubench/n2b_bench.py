@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(d_pd, 0, n * 8)); CK(hipMemcpy(d_z, z.data(), n * 8, hipMemcpyHostToDevice));
     ContactArgs a; a.n = n; a.counter_per_swing = 120; a.foot_force_low = 30; a.use_terrain_adapt = 1;
     a.rec = reinterpret_cast<CtRecord*>(st); a.leg_ring = reinterpret_cast<double*>(a.rec + n); a.terrain_ring = a.leg_ring + (size_t)n * kCtLegRing; a.stride = n;
-    a.gait_counter = d_gc; a.foot_force = d_ff; a.foot_pos_abs = d_fp; a.root_pos_z = d_z; a.plan_contacts = d_pc; a.pitch_d = d_pd; a.contacts = d_ct; a.recent_out = d_rec; a.terrain_out = d_ta; a.recent_in = nullptr; a.z_stride = 1; a.pitch_stride = 1;
+    a.gait_counter = d_gc; a.foot_force = d_ff; a.foot_pos_abs = d_fp; a.root_pos_z = d_z; a.plan_contacts = d_pc; a.pitch_d = d_pd; a.contacts = d_ct; a.recent_out = d_rec; a.terrain_out = d_ta; a.recent_in = nullptr; a.z_stride = 1; a.pitch_stride = 1; a.pk_tick = nullptr;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ms;
     for (int t = 0; t < ticks; ++t) {
