@@ -111,20 +111,21 @@ __global__ __launch_bounds__(256) void a1mpc_predict_kernel(const KernelArgs a, 
 
 // General path (per-step feet / per-step contact schedules: S/ConvexMpc.h:74 B_mat_d_list, S/test/test_mpc.cpp:106-122): the fused kernel
 // over RowSolver<.., GEN = true>, whose LDS image also holds B~_t and the bounds of every horizon step.
-template <int H, int ROWS>
+// UPD (round 5): the instantiation that also serves warm_start = 2, the reference's update path, on the general path (batches within the resident rows)
+template <int H, int ROWS, bool UPD = false>
 __global__ __launch_bounds__(64) void a1mpc_solve_gen_kernel(const KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
     static_assert(ROWS <= 2, "rows r and r + 2 of the wavefront share a QP (twin rows)");
     if constexpr (fused_quad_rows(H, kModeMpc, ROWS)) {   // one QP per wavefront, horizon a multiple of 4: a quad of rows
         const int64_t bq = static_cast<int64_t>(blockIdx.x);
-        solve_row_with<H, kModeMpc, true, true, false, true>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(bq)); }, a1mpc_lds);
+        solve_row_with<H, kModeMpc, true, true, UPD, true>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(bq)); }, a1mpc_lds);
         return;
     }
     const int row = (static_cast<int>(threadIdx.x) >> 4) & 1;
     if (row >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
     const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
     if (b >= a.n) return;
-    solve_row_with<H, kModeMpc, true, true>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H, true>::ROW_STRIDE);
+    solve_row_with<H, kModeMpc, true, true, UPD>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H, true>::ROW_STRIDE);
 }
 
 // Latency variant of the fused kernel for a handful of QPs: the four rows of a wavefront work on ONE QP during set-up (each takes every fourth
@@ -812,6 +813,12 @@ static a1mpc_status launch_gen_rows(const KernelArgs& a, hipStream_t stream) {
                                        static_cast<int>(lds)));
             attr_set[dev] = true;
         }
+    }
+    if (a.carry != nullptr) {   // warm_start = 2: the update-path instantiation
+        if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_gen_kernel<H, ROWS, true>), lds); st != A1MPC_OK) return st;
+        hipLaunchKernelGGL((a1mpc_solve_gen_kernel<H, ROWS, true>), dim3(static_cast<unsigned>((a.n + ROWS - 1) / ROWS)), dim3(64), lds, stream, a);
+        A1_HIP(hipGetLastError());
+        return A1MPC_OK;
     }
     hipLaunchKernelGGL((a1mpc_solve_gen_kernel<H, ROWS>), dim3(static_cast<unsigned>((a.n + ROWS - 1) / ROWS)), dim3(64), lds, stream, a);
     A1_HIP(hipGetLastError());
@@ -2603,23 +2610,25 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
         }
         a.carry = h->d_carry;
     }
-    h->last_ws_mode = (h->cfg.warm_start == 2 && (a.carry == nullptr || foot_stride != 0 || d_yaw_A != nullptr)) ? 1 : h->cfg.warm_start;
+    h->last_ws_mode = (h->cfg.warm_start == 2 && a.carry == nullptr) ? 1 : h->cfg.warm_start;   // (the general path's split pipeline revises this below)
     a.contact_stride = contact_stride;  // a per-step contact schedule alone (feet step-invariant) stays on the fast path: contacts only change bounds and equality rows
     if (foot_stride != 0 || d_yaw_A != nullptr) {  // general path: per-step B_d (and / or its own A_c yaw), with or without a contact schedule
         if (d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "per-step feet / contacts are not combined with tick records");
         a.foot_stride = foot_stride; a.contact_stride = contact_stride; a.yaw_A = d_yaw_A;
-        // The general kernels solve on warm_start = 1 semantics: they rewrite the carried (x, y, rho) of these problems but neither read nor refresh the update
-        // path's carry (previous scalings, gradient, z).  A carry left standing would pair tick k - 2's scalings with tick k - 1's iterates on the next
-        // fast-path tick: mark "no previous tick" (field C of every record) instead -- that tick is then a fresh set-up warm-started from (x, y, rho).
-        if (a.carry != nullptr) {
-            A1_HIP(hipMemset2DAsync(h->d_carry, carry_stride(h->cfg.horizon) * sizeof(double), 0, sizeof(double), static_cast<size_t>(n), s));
-            a.carry = nullptr;
-        }
         // a batch beyond the resident rows of the general path's ADMM kernel runs its split pipeline (set-up kernel + persistent rows on a queue, like the
         // fast path); its hand-off records (B~w_t of every step included) live in a buffer of their own, allocated on first use
         int rows_gen = 0;
         if (a1mpc_status st0 = resident_rows_gen(h->cfg.horizon, &rows_gen); st0 != A1MPC_OK) return st0;
         const bool split_gen = pipeline_mode() != 2 && rows_gen > 0 && (pipeline_mode() == 1 || n > rows_gen) && h->d_counter != nullptr;
+        // warm_start = 2 (round 5): the FUSED general kernels follow the update path like the fast path's (batches within the resident rows -- the control loop's
+        // batch 1 among them).  The general path's split pipeline solves on warm_start = 1 semantics: it rewrites the carried (x, y, rho) of these problems but neither
+        // reads nor refreshes the update path's carry (previous scalings, gradient, z).  A carry left standing would pair tick k - 2's scalings with tick k - 1's
+        // iterates on the next update-path tick: mark "no previous tick" (field C of every record) instead -- that tick is then a fresh set-up warm-started from (x, y, rho).
+        if (a.carry != nullptr && split_gen) {
+            A1_HIP(hipMemset2DAsync(h->d_carry, carry_stride(h->cfg.horizon) * sizeof(double), 0, sizeof(double), static_cast<size_t>(n), s));
+            a.carry = nullptr;
+            h->last_ws_mode = 1;
+        }
         if (split_gen && !h->d_prep_gen) {
             A1_HIP(hipMalloc(&h->d_prep_gen, static_cast<size_t>(h->max_batch) * prep_stride_gen(h->cfg.horizon) * sizeof(double)));
         }

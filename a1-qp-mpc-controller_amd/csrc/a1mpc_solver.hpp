@@ -749,7 +749,7 @@ struct RowSolver {
         // gradient -- the only place the gradient enters scale_data is the cost normalisation below
         using CR = Carry<H>;
         upd = false;
-        if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) upd = P.warm_start == 2 && io.carry != nullptr && io.warm_x != nullptr && io.warm_y != nullptr && io.carry[CR::C] > 0.0;
+        if constexpr (UPD && MODE == kModeMpc && H > 1) upd = P.warm_start == 2 && io.carry != nullptr && io.warm_x != nullptr && io.warm_y != nullptr && io.carry[CR::C] > 0.0;
         // Pattern change.  osqp-eigen's updateHessianMatrix takes osqp_update_P only while the upper-triangular triplets of hessian.sparseView() keep their pattern; when
         // exact zeros of the reference's dense B_qp'QB_qp appear or vanish it reads the workspace iterates, clears the solver, initialises it again (fresh scaling with
         // the CURRENT data, rho back to settings.rho) and warm-starts it with those iterates through osqp_warm_start_x / _y -- which scale what they are given, and
@@ -757,17 +757,36 @@ struct RowSolver {
         // alpha_st = 0 exactly where max(s,t) = H - 1, so the pattern of P is a function of the zero patterns of U and V: my rows' 24 flags are the signature.
         [[maybe_unused]] bool reinit = false;
         [[maybe_unused]] double sig = 0.0;
-        if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) {
-            unsigned bits = 0;
-            static_for<12>([&](auto B) { bits |= (U[B] != 0.0 ? 1u : 0u) << A1_CV(B); bits |= (V[B] != 0.0 ? 1u : 0u) << (12 + A1_CV(B)); });
-            sig = act ? static_cast<double>(bits) : 0.0;
+        if constexpr (UPD && MODE == kModeMpc && H > 1) {
+            if constexpr (GEN) {
+                // General path (round 5): every block (s,t) has its own U_st, V_st; an entry of the reference's dense Hessian is structurally zero exactly when the omega /
+                // rpy rows of B~w_s[:,a] and B~w_t[:,b] have no common non-zero (and the velocity / position rows do not match), so the pattern is a function of the zero
+                // patterns of my columns of the per-step tables B~w_s and T B~w_s: 6 flags per step and lane, folded into one exactly representable number (< 2^50).
+                // A change of these flags is a SUPERSET of the changes osqp-eigen sees (a flag can change under a zero weight without touching the Hessian's pattern);
+                // for inputs in general position neither ever changes.
+                unsigned long long hsh = 0;
+                static_for<H>([&](auto S) {
+                    unsigned v = 0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        v |= (act && lds[L::BW + (A1_CV(S) * 3 + c) * 12 + ci] != 0.0 ? 1u : 0u) << c;
+                        v |= (act && lds[L::TBW + (A1_CV(S) * 3 + c) * 12 + ci] != 0.0 ? 1u : 0u) << (3 + c);
+                    }
+                    hsh = (hsh * 67ull + v + 1ull) & ((1ull << 50) - 1ull);
+                });
+                sig = act ? static_cast<double>(hsh) : 0.0;
+            } else {
+                unsigned bits = 0;
+                static_for<12>([&](auto B) { bits |= (U[B] != 0.0 ? 1u : 0u) << A1_CV(B); bits |= (V[B] != 0.0 ? 1u : 0u) << (12 + A1_CV(B)); });
+                sig = act ? static_cast<double>(bits) : 0.0;
+            }
             if (upd) {
                 const double prev = act ? io.carry[CR::SIG + ci] : 0.0;
                 reinit = row_allmax(prev != sig ? 1.0 : 0.0) > 0.0;
             }
         }
-        [[maybe_unused]] double gq[(UPD && MODE == kModeMpc && H > 1 && !GEN) ? H : 1];   // the gradient the cost normalisation sees: the previous tick's on the update path
-        if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) {
+        [[maybe_unused]] double gq[(UPD && MODE == kModeMpc && H > 1) ? H : 1];   // the gradient the cost normalisation sees: the previous tick's on the update path
+        if constexpr (UPD && MODE == kModeMpc && H > 1) {
 #pragma unroll
             for (int t = 0; t < H; ++t) gq[t] = (upd && !reinit) ? (act ? io.carry[CR::G + t * 12 + ci] : 0.0) : g[t];
         }
@@ -940,7 +959,7 @@ struct RowSolver {
 #pragma unroll
                 for (int t = 0; t < H; ++t) {
                     sum += csc * D[t] * m[t];
-                    if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) nq = fmax(nq, fabs(csc * D[t] * gq[t]));
+                    if constexpr (UPD && MODE == kModeMpc && H > 1) nq = fmax(nq, fabs(csc * D[t] * gq[t]));
                     else nq = fmax(nq, fabs(csc * D[t] * g[t]));
                 }
                 const double mean = row_allsum(sum) / double(12 * H);
@@ -972,7 +991,7 @@ struct RowSolver {
         rho = P.rho0;
         warm = P.warm_start && io.warm_x != nullptr && io.warm_y != nullptr;
         if (warm && io.rho_io != nullptr && *io.rho_io > 0.0) rho = *io.rho_io;
-        if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) { if (reinit) rho = P.rho0; }   // a re-initialised solver starts from its settings' rho
+        if constexpr (UPD && MODE == kModeMpc && H > 1) { if (reinit) rho = P.rho0; }   // a re-initialised solver starts from its settings' rho
         rho = fmin(fmax(rho, kRhoMin), kRhoMax);
         // OSQP's first iteration starts from z0 = A x0 (not projected) and y0; with x0 = y0 = 0 and 0 inside the bounds it
         // coincides with the generic w-form iteration from w = 0
@@ -982,7 +1001,7 @@ struct RowSolver {
         // Every global load of the hot state is issued HERE, back to back, ahead of the per-step arithmetic (round 5): the carried iterates and, on the update path, what the
         // previous tick left in the workspace.  Inside the loop below they sat behind per-step branches (pattern change | update | plain), one exposed memory round trip per
         // horizon step of a lone wavefront -- ~20 k of the 43 k cycles the update path's hot state + hand-off took (profiles/r05_tick_stages_*.json).
-        [[maybe_unused]] constexpr bool kUpdPath = UPD && MODE == kModeMpc && H > 1 && !GEN;
+        [[maybe_unused]] constexpr bool kUpdPath = UPD && MODE == kModeMpc && H > 1;
         [[maybe_unused]] double cDp[kUpdPath ? H : 1], cE0p[kUpdPath ? H : 1], cZ0[kUpdPath ? H : 1], cZ1[kUpdPath ? H : 1], ccp = 0.0;
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
@@ -1017,7 +1036,7 @@ struct RowSolver {
             const double di = 1.0 / D[t];
             dI2[t] = di * di;
             if (act) lds[L::CG + t * 12 + ci] = csc * g[t];          // D^-1 q_s = c g
-            if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) {
+            if constexpr (UPD && MODE == kModeMpc && H > 1) {
                 if (upd && reinit) {
                     // pattern change: the previous solve's SCALED x_s = x / D', y_s = c' y / E' go through osqp_warm_start_x / _y as if they were unscaled -- a plain
                     // warm start (the code of warm_start = 1 below and in the first iteration) from those values
@@ -1055,7 +1074,7 @@ struct RowSolver {
             }
         });
         set_sync();
-        if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) {
+        if constexpr (UPD && MODE == kModeMpc && H > 1) {
             // what the next tick's update calls will find in the workspace: this tick's scalings and unscaled gradient (z follows in write_outputs).
             // Every row that shares this set-up holds the same values; the reads of the previous tick's fields above are complete (set_sync)
             if (P.warm_start == 2 && io.carry != nullptr && coop_id == 0) {
@@ -1213,7 +1232,7 @@ struct RowSolver {
             }
         }
         sync();
-        if constexpr (UPD && H > 1 && !GEN) {
+        if constexpr (UPD && H > 1) {
             if (first_special) {  // the true c g waits in the pad column of K_t until iteration 1 is done (restore_cg; the update path's first iteration runs on a corrected one).
                                   // After the sync: in the fused kernels the record is staged in the factor region, which holds the pad columns
                 if (act) {
@@ -1898,7 +1917,7 @@ struct RowSolver {
             if (P.adaptive_rho && P.adaptive_rho_every > 0) next = imin(next, (iter / P.adaptive_rho_every + 1) * P.adaptive_rho_every);
             if (iter == 0 && first_special) {
                 admm_iteration<true>(); iter = 1;
-                if constexpr (UPD && H > 1 && !GEN && !SETUP_ONLY && MODE == kModeMpc) restore_cg();  // (unconditional in the UPD instantiations: a flag would have to live across the ADMM loop)
+                if constexpr (UPD && H > 1 && !SETUP_ONLY && MODE == kModeMpc) restore_cg();  // (unconditional in the UPD instantiations: a flag would have to live across the ADMM loop)
             }
 #ifdef A1X_POISON  // test build (tests/test_emu_parity.py): the values nothing may depend on -- wh1 of the fz lanes (no second constraint row: any FINITE value), every
                    // per-step register of the pad lanes (anything) -- are overwritten at every segment start; not one output bit may change
@@ -2030,7 +2049,7 @@ struct RowSolver {
                     const double z0 = fmin(fmax(wh0[k], lbs<k>(t)), ubs<k>(t)), z1 = fmin(wh1[k], 0.0);
                     io.warm_y[t * 20 + 5 * quad + r0] = nanout ? 0.0 : cinv * rr0[k] * (wh0[k] - z0);
                     if (comp < 2) io.warm_y[t * 20 + 5 * quad + r1] = nanout ? 0.0 : cinv * rr1[k] * (wh1[k] - z1);
-                    if constexpr (H > 1 && MODE == kModeMpc && !GEN) {
+                    if constexpr (H > 1 && MODE == kModeMpc) {
                         if (carry) {  // z_s / E = Pi(w / E): what OSQP leaves in work->z (zeros after a failed solve: cold_start)
                             carry[Carry<H>::Z0 + t * 12 + ci] = nanout ? 0.0 : z0;
                             if (comp < 2) carry[Carry<H>::Z1 + t * 12 + ci] = nanout ? 0.0 : z1;
@@ -2137,6 +2156,7 @@ A1_DEV ProblemIO make_io_gen(const BatchArgs& a, int64_t b) {
     io.foot = a.foot + b * (a.foot_stride ? 12 * H : 12);
     io.contact = a.contact + b * (a.contact_stride ? 4 * H : 4);
     io.foot_stride = a.foot_stride; io.contact_stride = a.contact_stride; io.yaw_A = a.yaw_A ? a.yaw_A + b : nullptr;
+    io.carry = carry_of<H>(a, b);   // (warm_start = 2 on the general path: the fused general kernels, round 5)
     return io;
 }
 
@@ -2233,15 +2253,16 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
             if constexpr (QUAD) { cid = 2 * cid + row_sub(); cn = 4; }   // (a quad: the four rows)
             RowSolver<H, MODE, false, true> S0(P, stage_table<H, Layout<H, true>>(tab, lds, cid, cn), lds);
             S0.coop_id = cid; S0.coop_n = cn;
-            S0.setup(make_io_());
+            S0.template setup<UPD>(make_io_());
             if constexpr (TWIN) pair_sync(); else row_sync();  // everybody is done with the set-up scratch aliased into the factor region
-            if ((!TWIN || !row_is_twin()) && (!QUAD || row_sub() == 0)) S0.save_prepared(lds + Layout<H, true>::FAC);
+            if ((!TWIN || !row_is_twin()) && (!QUAD || row_sub() == 0)) S0.template save_prepared<UPD>(lds + Layout<H, true>::FAC);
         }
         if constexpr (TWIN) pair_sync();  // the twin reads the hand-off record and the per-step tables its main row wrote
         RowSolver<H, MODE, false, true, TWIN, false, false, QUAD> S(P, tab, lds);
-        S.load_prepared(lds + Layout<H, true>::FAC, make_io_());
-        S.solve();
-        S.write_outputs(make_io_());
+        S.template load_prepared<UPD>(lds + Layout<H, true>::FAC, make_io_());
+        S.template solve<UPD>();
+        if constexpr (UPD) { const ProblemIO& io_ = make_io_(); S.write_outputs(io_, io_.carry); }
+        else S.write_outputs(make_io_());
     } else if constexpr (MODE == kModeMpc && Prep<H>::STRIDE <= H * Layout<H>::SLOT) {
         // Set-up and iteration are two solver objects joined by the hand-off record of the split pipeline, staged in the (still
         // empty) factor region: the ADMM loop then gets the register allocation of the persistent kernel instead of one that

@@ -96,14 +96,18 @@ typedef struct a1mpc_config {
                                          update*Bound on the persistent OsqpEigen workspace, then solve()): OSQP re-equilibrates with the PREVIOUS tick's
                                          gradient still in the workspace and starts from the previous solve's SCALED (x, z, y) as they are.  The handle then
                                          also carries the previous scalings, gradient and z of every problem.  Restated from OSQP 0.6's update functions
-                                         (oracle: orc_mpc_solve_update); horizons 10 / 16 / 20, fast path (per-step feet and horizon 1 behave like 1:
-                                         a1mpc_last_warm_start_mode reports which semantics a solve actually ran).
+                                         (oracle: orc_mpc_solve_update); horizons 10 / 16 / 20: the fast path at every batch size and, since round 5, the general
+                                         path (per-step feet / contact schedules / its own A_c yaw: a1mpc_solve_batch_strided) for batches within the resident rows
+                                         of its fused kernel (1536 / 1024 / 768 QPs at h = 10 / 16 / 20 on an MI355X -- the control loop's batch 1 among them; its
+                                         pattern-change test reads the zero patterns of the per-step tables, a superset of the changes osqp-eigen sees).  Larger
+                                         general-path batches and horizon 1 (the balance QP, which the reference cold-starts anyway) behave like 1:
+                                         a1mpc_last_warm_start_mode reports which semantics a solve actually ran.
                                          When the sparsity pattern of the reference's Hessian (dense.sparseView(), S/ConvexMpc.cpp:211: exact zeros are not stored)
                                          changes from one tick to the next, osqp-eigen cannot take osqp_update_P: updateHessianMatrix clears the solver, initialises
                                          it again (rho back to cfg.rho, fresh scaling) and warm-starts it with the workspace's scaled iterates -- reproduced per
                                          problem (the pattern is a function of the zero patterns of the two 12x12 blocks the Hessian is made of).  A tick solved
-                                         in another mode or on the general path drops the carried workspace: the next tick is a fresh set-up warm-started from
-                                         (x, y, rho).  (An a1mpc_warm_start injection does NOT drop it since round 4: see there.) */
+                                         in another mode or through the general path's split pipeline drops the carried workspace: the next tick is a fresh set-up
+                                         warm-started from (x, y, rho).  (An a1mpc_warm_start injection does NOT drop it since round 4: see there.) */
 } a1mpc_config;
 
 /* balance-QP constants, A1RobotControl ctor S/A1RobotControl.cpp:11-15 */

@@ -782,13 +782,16 @@ int orc_mpc_solve(const orc_mpc_params *pr, const orc_settings *st, const double
 
 /* One MPC tick on the reference's UPDATE PATH (see osqp_solve_impl): carry = 2 + 2n + 4m doubles + 2 for the sparsity pattern of the previous tick's P
  * (osqp-eigen compares it in updateHessianMatrix), zero before the first tick of a robot. */
-int orc_mpc_solve_update(const orc_mpc_params *pr, const orc_settings *st, const double *x0, const double *xref, const double *Rw,
-                         const double *foot, const uint8_t *contact, double *grf_out, double *u_full, double *carry, orc_info *info) {
+/* the general case of the reference's INTERFACE on the update path (per-step B_d: S/ConvexMpc.h:74 B_mat_d_list; a per-step contact schedule; A_c from another yaw,
+ * S/test/test_mpc.cpp:94-122): the same persistent-solver semantics on the QP those inputs form */
+int orc_mpc_solve_update_strided(const orc_mpc_params *pr, const orc_settings *st, const double *x0, const double *xref, double yaw_A, const double *Rw,
+                                 const double *foot, int foot_stride, const uint8_t *contact, int contact_stride, double *grf_out, double *u_full, double *carry,
+                                 orc_info *info) {
     const int h = pr->horizon, n = NU * h, m = NC * h;
     double *P = (double *)scratch_get(6, sizeof(double) * ((size_t)n * n + n + 2 * m + 36 * h + n + m), 0);
     double *g = P + (size_t)n * n, *l = g + n, *u = l + m, *av = u + m, *x = av + 36 * h, *y = x + n;
     int32_t *rp = (int32_t *)scratch_get(7, sizeof(int32_t) * (m + 1 + 36 * h), 0), *ci = rp + m + 1;
-    orc_mpc_form(pr, x0, xref, x0[2], Rw, foot, 0, contact, 0, P, g, rp, ci, av, l, u);
+    orc_mpc_form(pr, x0, xref, yaw_A, Rw, foot, foot_stride, contact, contact_stride, P, g, rp, ci, av, l, u);
     memset(x, 0, sizeof(double) * n); memset(y, 0, sizeof(double) * m);
     double sig[2], *csig = carry + 2 + 2 * n + 4 * m;
     orc_pattern_signature(n, P, sig);
@@ -803,6 +806,11 @@ int orc_mpc_solve_update(const orc_mpc_params *pr, const orc_settings *st, const
     }
     if (u_full) memcpy(u_full, x, sizeof(double) * n);
     return rc;
+}
+
+int orc_mpc_solve_update(const orc_mpc_params *pr, const orc_settings *st, const double *x0, const double *xref, const double *Rw,
+                         const double *foot, const uint8_t *contact, double *grf_out, double *u_full, double *carry, orc_info *info) {
+    return orc_mpc_solve_update_strided(pr, st, x0, xref, x0[2], Rw, foot, 0, contact, 0, grf_out, u_full, carry, info);
 }
 
 /* batch driver (CPU baseline): one problem per OpenMP thread, static partition */

@@ -214,15 +214,17 @@ def carry_from_workspace(h, x, y, z, rho, D, E, c, P_prev, g_prev, l_prev, u_pre
     return carry
 
 
-def mpc_solve_update(pr, st, x0, xref, Rw, foot, contact, carry):
+def mpc_solve_update(pr, st, x0, xref, Rw, foot, contact, carry, foot_stride=0, contact_stride=0, yaw=None):
     """one tick on the reference's UPDATE PATH (updateHessianMatrix / updateGradient / update*Bound on a persistent OSQP workspace,
-    S/A1RobotControl.cpp:533-538; see osqp_solve_impl in a1mpc_oracle.c).  `carry` is updated in place."""
+    S/A1RobotControl.cpp:533-538; see osqp_solve_impl in a1mpc_oracle.c).  `carry` is updated in place.  foot_stride / contact_stride / yaw: the general case of the
+    reference's interface (per-step feet, a contact schedule, A_c from another yaw), as in mpc_solve."""
     h = pr.horizon
     grf = np.zeros(12); u = np.zeros(NU * h); info = Info()
     assert carry.dtype == np.float64 and carry.size == 4 + 2 * NU * h + 4 * NC * h and carry.flags.c_contiguous
-    lib().orc_mpc_solve_update(C.byref(pr), C.byref(st), _p(np.ascontiguousarray(x0, dtype=np.float64)), _p(np.ascontiguousarray(xref, dtype=np.float64)),
-                               _p(np.ascontiguousarray(Rw, dtype=np.float64)), _p(np.ascontiguousarray(foot, dtype=np.float64)),
-                               _p(np.ascontiguousarray(contact, dtype=np.uint8), C.c_uint8), _p(grf), _p(u), _p(carry), C.byref(info))
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    lib().orc_mpc_solve_update_strided(C.byref(pr), C.byref(st), _p(x0), _p(np.ascontiguousarray(xref, dtype=np.float64)), C.c_double(float(x0[2] if yaw is None else yaw)),
+                                       _p(np.ascontiguousarray(Rw, dtype=np.float64)), _p(np.ascontiguousarray(foot, dtype=np.float64)), C.c_int(int(foot_stride)),
+                                       _p(np.ascontiguousarray(contact, dtype=np.uint8), C.c_uint8), C.c_int(int(contact_stride)), _p(grf), _p(u), _p(carry), C.byref(info))
     return dict(grf=grf, u=u, info=info)
 
 

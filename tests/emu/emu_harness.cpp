@@ -413,12 +413,18 @@ static void gen_entry(void* a) {
 template <int H>
 static void gen_twin_entry(void* a) {
     Job<H>* j = static_cast<Job<H>*>(a);
-    if constexpr (H % 2 == 0) solve_row_with<H, kModeMpc, true, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+    if constexpr (H % 2 == 0) {
+        if (j->io.carry) solve_row_with<H, kModeMpc, true, true, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);   // (like the host: the update-path instantiation for warm_start = 2)
+        else solve_row_with<H, kModeMpc, true, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+    }
 }
 template <int H>
 static void gen_quad_entry(void* a) {
     Job<H>* j = static_cast<Job<H>*>(a);
-    if constexpr (H % 4 == 0) solve_row_with<H, kModeMpc, true, true, false, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+    if constexpr (H % 4 == 0) {
+        if (j->io.carry) solve_row_with<H, kModeMpc, true, true, true, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+        else solve_row_with<H, kModeMpc, true, true, false, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+    }
 }
 template <int H>
 static void run_gen(const DeviceParams* P, int n, const double* x0, const double* xref, const double* R, const double* foot, int foot_stride,
@@ -439,6 +445,7 @@ static void run_gen(const DeviceParams* P, int n, const double* x0, const double
         j.io.warm_x = warm_x ? warm_x + (size_t)b * 12 * H : nullptr; j.io.warm_y = warm_y ? warm_y + (size_t)b * 20 * H : nullptr;
         j.io.rho_io = rho ? rho + b : nullptr;
         j.io.iters = iters ? iters + b : nullptr; j.io.status = status ? status + b : nullptr; j.io.nfact = nfact ? nfact + b : nullptr;
+        if constexpr (H >= 10) j.io.carry = g_emu_carry ? g_emu_carry + (size_t)b * Carry<H>::STRIDE : nullptr;   // update path (a1mpc_emu_set_carry); twin / quad runs only
         if (g_emu_twin == 2 && H % 4 == 0) run_row(gen_quad_entry<H>, &j, 64);
         else if (g_emu_twin && H % 2 == 0) run_row(gen_twin_entry<H>, &j, 32);
         else run_row(gen_entry<H>, &j);

@@ -92,6 +92,8 @@ for k, lanes in live.items():
     g_ = lambda n: c.get(n, {}).get("mean_per_launch", 0.0)
     ex += lanes * (2.0 * g_("SQ_INSTS_VALU_FMA_F64") + g_("SQ_INSTS_VALU_ADD_F64") + g_("SQ_INSTS_VALU_MUL_F64"))
 summ["executed_fp64_flops_per_launch"] = ex
+_c = summ.get("admm_kernel", {}); _g = lambda n: _c.get(n, {}).get("mean_per_launch", 0.0)
+summ["executed_fp64_flops_admm_kernel"] = 48 * (2.0 * _g("SQ_INSTS_VALU_FMA_F64") + _g("SQ_INSTS_VALU_ADD_F64") + _g("SQ_INSTS_VALU_MUL_F64"))   # the persistent ADMM kernel alone (bench.py: admm_kernel_executed_frac)
 # the other shapes (collect_profiles.sh: A1_SHAPE passes of tools/prof_target.py): per kernel and launch, counters + kernel durations
 by_cfg, shapes = {}, {}
 for d in sorted(glob.glob(os.path.join(src, "shape_*_SQ_INSTS_VALU_FMA_F64"))) + sorted(glob.glob(os.path.join(src, "shape_*_SQ_LDS_BANK_CONFLICT"))):
