@@ -1792,16 +1792,24 @@ __device__ inline void ekf_c_row(int r, int& c0, double& s0, int& c1, double& s1
     else if (r < 24) { c0 = 3 + (r - 12) % 3; s0 = 1.0; }                    // vel
     else { c0 = 6 + (r - 24) * 3 + 2; s0 = 1.0; }                            // foot height
 }
-__global__ __launch_bounds__(64, 2) void a1mpc_ekf_kernel(const EkfArgs a) {   // (two waves per SIMD: 256 registers each -- left alone the FMA form of round 4 took 272 and halved the occupancy)
+// Two residencies of the same arithmetic (bit-identical: tools/ubench/ekf_bench.py prints a checksum of the filter states):
+//   LEAN = false  two wavefronts per SIMD (256 registers, 10 KB of LDS per robot): the fewest instructions per robot -- what a batch that fits the chip in one round wants
+//                 (4096 robots of a control tick: 47 us against 52)
+//   LEAN = true   (round 5) THREE wavefronts per SIMD (168 registers, 5.4 KB per robot) for batches of many rounds: 65 536 robots 0.542 -> 0.489 ms, 16 384: 0.156 -> 0.150 (profiles/r05_ekf_residency.txt).  What stood in the way
+//                 was LDS: the 28 x 29 staging of S for the symmetrisation is gone (a lane recomputes the transposed entry S[c][l] from Pbar in LDS with the operations lane c
+//                 used), S^-1 C reaches the measurement update in two halves of 14 rows through one 252-double buffer (the sums still run over r = 0 .. 27 in ascending
+//                 order), and the lane's row of Pbar is re-read from LDS where the measurement update needs it instead of living in registers through the 28 sweeps.
+extern "C++" {   // (this section sits inside the ABI's extern "C" block)
+template <bool LEAN>
+__device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __restrict__ lds_g, const int g, const int l) {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) double lds[2][1280];
-    const int g = static_cast<int>(threadIdx.x) >> 5, l = static_cast<int>(threadIdx.x) & 31;
     const int64_t b = static_cast<int64_t>(blockIdx.x) * 2 + g;
     if (b >= a.n) return;
     double* st = a.state + b * kEkfState;
     const double flag = st[18 + 324];
     if (flag != 1.0) { if (l == 0 && flag == 2.0) st[18 + 324] = 1.0; return; }
-    double *Pb = lds[g], *Sm = Pb + 324, *prow = Sm + 28 * 29, *xs = prow + 48, *xb = xs + 18, *zs = xb + 18;   // 324+812+48+18+18+28 = 1248 doubles = 10 KB per robot
+    // LEAN: 324 + 252 + 32 + 18 + 18 + 28 = 672 doubles = 5.4 KB per robot; otherwise 324 + 812 + 48 + 18 + 18 + 28 = 1248 doubles = 10 KB (SCh = the 28 x 29 staging of S, then S^-1 C)
+    double *Pb = lds_g, *SCh = Pb + 324, *prow = SCh + (LEAN ? 252 : 28 * 29), *xs = prow + (LEAN ? 32 : 48), *xb = xs + 18, *zs = xb + 18;
     const double dt = a.dt;
     const double* Pg = st + 18;  // P of the previous tick: every lane reads its own row(s) straight from global memory
     if (l < 18) xs[l] = st[l];
@@ -1859,14 +1867,28 @@ __global__ __launch_bounds__(64, 2) void a1mpc_ekf_kernel(const EkfArgs a) {   /
             ekf_c_row(c, d0, t0, d1, t1);
             const double v = d1 >= 0 ? CP[d0] * t0 + CP[d1] * t1 : CP[d0] * t0;
             M[c] = v + (c == r ? rd : 0.0);
-            Sm[r * 29 + c] = M[c];
+            if constexpr (!LEAN) SCh[r * 29 + c] = M[c];
         }
         err = y - yhat;
         zs[r] = err;   // error_y, read by every row in the product S^-1 error_y below
     }
     half_sync();
-    if (l < 28)
-        for (int c = 0; c < 28; ++c) M[c] = c == l ? 0.5 * (M[c] + M[c]) : (c > l ? 0.5 * (M[c] + Sm[c * 29 + l]) : 0.5 * (Sm[c * 29 + l] + M[c]));   // :131
+    if constexpr (!LEAN) {
+        if (l < 28)
+            for (int c = 0; c < 28; ++c) M[c] = c == l ? 0.5 * (M[c] + M[c]) : (c > l ? 0.5 * (M[c] + SCh[c * 29 + l]) : 0.5 * (SCh[c * 29 + l] + M[c]));   // :131
+    } else if (l < 28) {   // :131  S <- (S + S') / 2.  S[c][l], the entry lane c holds, is recomputed here from Pbar by lane c's own operations (C row of c times Pbar, then my C row)
+        int d0, d1; double t0, t1;
+        ekf_c_row(l, d0, t0, d1, t1);
+#pragma unroll
+        for (int c = 0; c < 28; ++c) {
+            int e0, e1; double u0, u1;
+            ekf_c_row(c, e0, u0, e1, u1);
+            const double cp0 = e1 >= 0 ? u0 * Pb[e0 * 18 + d0] + u1 * Pb[e1 * 18 + d0] : u0 * Pb[e0 * 18 + d0];
+            const double cp1 = d1 >= 0 ? (e1 >= 0 ? u0 * Pb[e0 * 18 + d1] + u1 * Pb[e1 * 18 + d1] : u0 * Pb[e0 * 18 + d1]) : 0.0;
+            const double tr = (d1 >= 0 ? cp0 * t0 + cp1 * t1 : cp0 * t0) + 0.0;   // (+ 0.0: lane c added its "not the diagonal" zero)
+            M[c] = c == l ? 0.5 * (M[c] + M[c]) : (c > l ? 0.5 * (M[c] + tr) : 0.5 * (tr + M[c]));
+        }
+    }
     // ---- S^-1 by the symmetric sweep operator (in-place Gauss-Jordan without pivoting; S is symmetric positive definite); the two solves (:134, :138) are then
     // products with it.  Sweep k, p = a_kk:  a_ij -= (a_ik / p) a_kj,  a_ik = a_ik / p,  a_kj = a_kj / p,  a_kk = -1 / p  -- the matrix stays symmetric and ends as -S^-1.
     // Lane i takes the pivot row from COLUMN k as the other lanes hold it (a_jk for a_kj): a sweep exchanges ONE word per lane (28 lanes write, everyone reads the 28
@@ -1894,36 +1916,77 @@ __global__ __launch_bounds__(64, 2) void a1mpc_ekf_kernel(const EkfArgs a) {   /
         for (int j = 0; j < 28; ++j) M[j] = -M[j];
     }
     half_sync();
-    double* SC = Sm;  // S is consumed: the region now holds S^-1 C (28 x 18)
-    double serr = 0.0;
+    double serr = 0.0, SC[18];   // my row of S^-1 C (28 x 18)
+#pragma unroll
+    for (int j = 0; j < 18; ++j) SC[j] = 0.0;
     if (l < 28) {
         // S^-1 error_y (:134): dense product, inner index ascending
         for (int c = 0; c < 28; ++c) serr = __builtin_fma(M[c], zs[c], serr);   // (round 4: the four big dense products accumulate by FMA, here and in the oracle alike)
         // S^-1 C (:138): the dense product with C's exact zeros dropped (C[c][j] is 0 or +-1, a zero term leaves the running sum as it is): per column j the
         // rows c with an entry, ascending -- j < 3: c = j, 3 + j, 6 + j, 9 + j (-1); j = 3..5: c = 12 + (j - 3), 15 + .., 18 + .., 21 + .. (+1); j = 6 + m: c = m (+1)
         // and, for the z column of a foot, c = 24 + m / 3 (+1)
-        for (int j = 0; j < 3; ++j) SC[l * 18 + j] = (((0.0 + M[j] * -1.0) + M[3 + j] * -1.0) + M[6 + j] * -1.0) + M[9 + j] * -1.0;
-        for (int j = 0; j < 3; ++j) SC[l * 18 + 3 + j] = (((0.0 + M[12 + j] * 1.0) + M[15 + j] * 1.0) + M[18 + j] * 1.0) + M[21 + j] * 1.0;
-        for (int m = 0; m < 12; ++m) SC[l * 18 + 6 + m] = m % 3 == 2 ? (0.0 + M[m] * 1.0) + M[24 + m / 3] * 1.0 : 0.0 + M[m] * 1.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) SC[j] = (((0.0 + M[j] * -1.0) + M[3 + j] * -1.0) + M[6 + j] * -1.0) + M[9 + j] * -1.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) SC[3 + j] = (((0.0 + M[12 + j] * 1.0) + M[15 + j] * 1.0) + M[18 + j] * 1.0) + M[21 + j] * 1.0;
+#pragma unroll
+        for (int m = 0; m < 12; ++m) SC[6 + m] = m % 3 == 2 ? (0.0 + M[m] * 1.0) + M[24 + m / 3] * 1.0 : 0.0 + M[m] * 1.0;
     }
     half_sync();   // every row has read error_y: its place now takes S^-1 error_y
     if (l < 28) zs[l] = serr;
     half_sync();
-    // ---- measurement update (:136-140)
-    double Tn[18];
+    // ---- measurement update (:136-140).  S^-1 C arrives in two halves of 14 rows (one 252-double buffer); every sum still runs over r = 0 .. 27 in ascending order
+    double Tn[18], G1[28], G2[18];
+    const double* Prow = LEAN ? Pb + (l < 18 ? l : 0) * 18 : Pr;   // my row of Pbar: LEAN re-reads it from LDS instead of holding it in registers through the 28 sweeps
     if (l < 18) {
-        double G1[28];
+#pragma unroll
         for (int r = 0; r < 28; ++r) {
             int c0, c1; double s0, s1;
             ekf_c_row(r, c0, s0, c1, s1);
-            G1[r] = c1 >= 0 ? Pr[c0] * s0 + Pr[c1] * s1 : Pr[c0] * s0;
+            G1[r] = c1 >= 0 ? Prow[c0] * s0 + Prow[c1] * s1 : Prow[c0] * s0;
         }
         double acc_ = 0;
+#pragma unroll
         for (int r = 0; r < 28; ++r) acc_ = __builtin_fma(G1[r], zs[r], acc_);
         xs[l] = xb[l] + acc_;
-        double G2[18];
-        for (int j = 0; j < 18; ++j) { double s = 0; for (int r = 0; r < 28; ++r) s = __builtin_fma(G1[r], SC[r * 18 + j], s); G2[j] = s; }
-        for (int j = 0; j < 18; ++j) { double s = 0; for (int k = 0; k < 18; ++k) s = __builtin_fma(G2[k], Pb[k * 18 + j], s); Tn[j] = Pr[j] - s; }
+#pragma unroll
+        for (int j = 0; j < 18; ++j) G2[j] = 0;
+    }
+    if constexpr (LEAN) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (l >= 14 * half && l < 14 * half + 14) {
+#pragma unroll
+                for (int j = 0; j < 18; ++j) SCh[(l - 14 * half) * 18 + j] = SC[j];
+            }
+            half_sync();
+            if (l < 18) {
+#pragma unroll
+                for (int j = 0; j < 18; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 14; ++r) G2[j] = __builtin_fma(G1[14 * half + r], SCh[r * 18 + j], G2[j]);
+                }
+            }
+            half_sync();
+        }
+    } else {   // (the staging of S is consumed: the region holds all of S^-1 C)
+        if (l < 28) {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) SCh[l * 18 + j] = SC[j];
+        }
+        half_sync();
+        if (l < 18) {
+#pragma unroll
+            for (int j = 0; j < 18; ++j) {
+#pragma unroll
+                for (int r = 0; r < 28; ++r) G2[j] = __builtin_fma(G1[r], SCh[r * 18 + j], G2[j]);
+            }
+        }
+        half_sync();
+    }
+    if (l < 18) {
+#pragma unroll
+        for (int j = 0; j < 18; ++j) { double s = 0; for (int k = 0; k < 18; ++k) s = __builtin_fma(G2[k], Pb[k * 18 + j], s); Tn[j] = Prow[j] - s; }
     }
     half_sync();  // every lane is done reading Pbar: its region now stages the unsymmetrised update for the transposed read
     double* Pm = Pb;
@@ -1947,6 +2010,25 @@ __global__ __launch_bounds__(64, 2) void a1mpc_ekf_kernel(const EkfArgs a) {   /
     }
     if (l < 4) a.ec_out[b * 4 + l] = ec[l] < 0.5 ? 0 : 1;                                                           // :151-157
 }
+}  // extern "C++"
+__global__ __launch_bounds__(64, 2) void a1mpc_ekf_kernel(const EkfArgs a) {
+    __shared__ __attribute__((aligned(16))) double lds[2][1280];
+    const int g = static_cast<int>(threadIdx.x) >> 5;
+    ekf_update_robot<false>(a, lds[g], g, static_cast<int>(threadIdx.x) & 31);
+}
+__global__ __launch_bounds__(64, 3) void a1mpc_ekf_lean_kernel(const EkfArgs a) {
+    __shared__ __attribute__((aligned(16))) double lds[2][680];
+    const int g = static_cast<int>(threadIdx.x) >> 5;
+    ekf_update_robot<true>(a, lds[g], g, static_cast<int>(threadIdx.x) & 31);
+}
+// batches of several rounds of the chip run the three-waves-per-SIMD residency (measured crossover between 4096 and 65 536 robots; A1MPC_EKF_LEAN=0 / 1 forces one)
+static void launch_ekf_update(const EkfArgs& a, hipStream_t s) {
+    static const int force = [] { const char* e = getenv("A1MPC_EKF_LEAN"); return e ? atoi(e) : -1; }();
+    const bool lean = force >= 0 ? force != 0 : a.n >= 16384;
+    if (lean) hipLaunchKernelGGL(a1mpc_ekf_lean_kernel, dim3(static_cast<unsigned>((a.n + 1) / 2)), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((a.n + 1) / 2)), dim3(64), 0, s, a);
+}
+#define EKF_LAUNCH(a) launch_ekf_update(a, 0)   // (tools/ubench/ekf_bench.py cuts this section into a stand-alone timing harness)
 
 a1mpc_status a1mpc_reset_ekf_state(a1mpc_handle h) {
     if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
@@ -1996,7 +2078,7 @@ a1mpc_status a1mpc_ekf_update_batch(a1mpc_handle h, int32_t n, double dt, int32_
         hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
         h->ekf_ready_n = n;
     }
-    hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((N + 1) / 2)), dim3(64), 0, s, a);
+    launch_ekf_update(a, s);
     A1_HIP(hipGetLastError());
     if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
     h->timed = h->timing; A1_MARK(h, s);
@@ -2223,7 +2305,7 @@ a1mpc_status a1mpc_ekf_update_batch_device(a1mpc_handle h, int32_t n, double dt,
         hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
         h->ekf_ready_n = n;
     }
-    hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((N + 1) / 2)), dim3(64), 0, s, a);
+    launch_ekf_update(a, s);
     A1_DEV_EPILOGUE();
 }
 a1mpc_status a1mpc_joint_torques_batch_device(a1mpc_handle h, int32_t n, const uint8_t* active, const uint8_t* contacts, const double* j_foot_blocks,
@@ -2769,7 +2851,7 @@ a1mpc_status a1mpc_control_tick_device(a1mpc_handle h, const a1mpc_tick_params* 
             hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
             h->ekf_ready_n = n;
         }
-        hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((N + 1) / 2)), dim3(64), 0, s, a);
+        launch_ekf_update(a, s);
     }
     {   // 3. update_plan + 4. swing legs, one launch (a1mpc_plan_swing_kernel).  (Round 5 trial: the swing block as its own launch on a second stream beside stage 5 --
         //    both only need the plan's outputs -- joined in front of the MPC launch: the two cross-stream event waits cost more than the 5 us kernel they hide,

@@ -605,6 +605,33 @@ def test_ekf_N4c_sequence(pkg, oracle, scen):
                         vel[b] - v_p)
 
 
+def test_ekf_large_batch_residency(pkg, oracle, scen):
+    """Batches of 16 384 robots and more run the EKF in its three-waves-per-SIMD residency (680 instead of 1280 LDS words per robot, the
+    same arithmetic in the same order).  16 385 robots (the last workgroup half empty), five ticks from the first-call initialisation on:
+    a spread of robots incl. the first and the last against the oracle's FMA variant bit for bit, and the robots of a 200-robot engine
+    (the other residency) against the same rows of the large batch bit for bit."""
+    rng = np.random.default_rng(52)
+    n, ticks, small = 16385, 5, 200
+    cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+    sample = sorted({0, 1, 2, small - 1, n // 2, n - 2, n - 1} | set(rng.integers(0, n, 40).tolist()))
+    states = {b: oracle.ekf_state() for b in sample}
+    base = np.array([0.18, 0.13, -0.3, 0.18, -0.13, -0.3, -0.18, 0.13, -0.3, -0.18, -0.13, -0.3])
+    with pkg.Engine(cfg, n, 0) as eng, pkg.Engine(cfg, small, 0) as eng_s:
+        for t in range(ticks):
+            mm = np.where(rng.random(n) < 0.8, 1, 0).astype(np.uint8) if t > 1 else np.zeros(n, np.uint8)
+            yaw = rng.uniform(-3, 3, n); eul = rng.normal(0, 0.05, (n, 2)); R = scen.rot_zyx(eul[:, 0], eul[:, 1], yaw).reshape(n, 9)
+            fk = base + rng.normal(0, 0.01, (n, 12)); fv = rng.normal(0, 0.3, (n, 12))
+            acc = np.array([0.0, 0.0, 9.81]) + rng.normal(0, 0.3, (n, 3))
+            w = rng.normal(0, 0.3, (n, 3)); ff = rng.uniform(0, 160, (n, 4))
+            pos, vel, ec = eng.ekf_update(0.0025, mm, ff, R, acc, w, fk, fv)
+            s = slice(0, small)
+            pos_s, vel_s, ec_s = eng_s.ekf_update(0.0025, mm[s], ff[s], R[s], acc[s], w[s], fk[s], fv[s])
+            assert np.array_equal(pos[s], pos_s) and np.array_equal(vel[s], vel_s) and np.array_equal(ec[s], ec_s), t
+            for b in sample:
+                p_o, v_o, e_o = oracle.ekf_step(states[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b], fma=True)
+                assert np.array_equal(pos[b], p_o) and np.array_equal(vel[b], v_o) and (ec[b] == e_o).all(), (t, b, pos[b] - p_o, vel[b] - v_o)
+
+
 def test_device_pointer_tick_matches_host_pointer_tick(pkg, scen):
     """The *_device variants of the caller-side entry points chained on the GPU (torch tensors, one stream, no host copies between the
     stages) give bit for bit what the host-pointer entries give: leg state -> EKF -> plan -> swing legs -> contacts / terrain -> MPC
