@@ -304,16 +304,16 @@ struct Layout {
 };
 
 // LDS image of the set-up kernel (formation + Ruiz only: no factor): 348 doubles per QP at H = 10; GEN (the general path's own set-up kernel): + the per-step
-// tables B~w_t and T B~w_t, 1068 doubles = 8.5 KB per QP at H = 10 (the per-step bounds are rebuilt from the contact bits by the ADMM kernel)
+// table B~w_t, 720 doubles = 5.8 KB per QP at H = 10 (the per-step bounds are rebuilt from the contact bits by the ADMM kernel)
 template <int H, bool GEN = false>
 struct LayoutSetup {
     static constexpr int KSTR = 13, K_SZ = 12 * KSTR, S_SZ = 78, SLOT = K_SZ + S_SZ, FAC = 0, GCOL = 12;  // unused by the set-up code paths
     static constexpr int TBL = 0;
     static constexpr int DL = 36;
-    static constexpr int TBW = DL + 12 * H;                  // GEN: [t][3][12] = T*B~_omega of step t
+    static constexpr int TBW = DL + 12 * H;                  // (GEN: T*B~_omega of step t lives in registers here, RowSolver::setup `tbwr`)
     static constexpr int COOP = 0, E0X = 0, TAB = 0;  // never used by the set-up kernels (one row per QP; the kernel stages the table behind the rows' images itself)
     static constexpr int CUV = 0, LBT = 0, UBT = 0;          // (not written by a set-up-only solver)
-    static constexpr int BL = TBW + (GEN ? 36 * H : 0);
+    static constexpr int BL = TBW;
     static constexpr int ZROW = 6;
     static constexpr int CG = BL + 84;
     static constexpr int BW = CG + 12 * H;                   // GEN: [t][3][12] = the omega rows of B~_t
@@ -625,9 +625,14 @@ struct RowSolver {
 #pragma unroll
             for (int k = 0; k < 3; ++k) lds[L::TBL + k * 12 + ci] = TB[k];
         }
+        // my column of T * B~w_t for every step: only ever read back by the lane that wrote it (the sweeps fold the rotation into the step-s factors cu), so the general
+        // path's set-up kernel keeps it in registers -- its LDS image loses 36 H doubles and twice (h = 16) / 1.5 times (h = 20) as many wavefronts fit a CU (round 5);
+        // the fused kernels park it in the not-yet-written factor region as before
+        [[maybe_unused]] double tbwr[(GEN && SETUP_ONLY) ? H : 1][3];
         if constexpr (GEN) {
             // per-step feet: the omega rows of B~_t = dt * Iw^-1 * skew(r_t) (S/ConvexMpc.cpp:138,151 with the step's foot_pos) and T * them
             static_for<H>([&](auto T) {
+#pragma clang fp contract(off)   // (the FMAs of this block are written out: see tb0 / tb1)
                 constexpr int t = A1_CV(T);
                 const double* fp = io.foot + static_cast<int64_t>(t) * io.foot_stride;
                 const double rx = fp[3 * quad + 0], ry = fp[3 * quad + 1], rz = fp[3 * quad + 2];
@@ -637,13 +642,18 @@ struct RowSolver {
                 double bw[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) bw[k] = (Ii[k * 3 + 0] * k0 + Ii[k * 3 + 1] * k1 + Ii[k * 3 + 2] * k2) * dt;
+                // (explicit FMAs: left to the compiler's contraction, the register and the LDS variant of this block were fused differently and the two pipelines parted by an ulp)
+                const double tb0 = fma(cy, bw[0], sy * bw[1]), tb1 = fma(-sy, bw[0], cy * bw[1]);
                 if (act) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) lds[L::BW + (t * 3 + k) * 12 + ci] = bw[k];
-                    lds[L::TBW + (t * 3 + 0) * 12 + ci] = cy * bw[0] + sy * bw[1];
-                    lds[L::TBW + (t * 3 + 1) * 12 + ci] = -sy * bw[0] + cy * bw[1];
-                    lds[L::TBW + (t * 3 + 2) * 12 + ci] = bw[2];
+                    if constexpr (!SETUP_ONLY) {
+                        lds[L::TBW + (t * 3 + 0) * 12 + ci] = tb0;
+                        lds[L::TBW + (t * 3 + 1) * 12 + ci] = tb1;
+                        lds[L::TBW + (t * 3 + 2) * 12 + ci] = bw[2];
+                    }
                 }
+                if constexpr (SETUP_ONLY) { tbwr[t][0] = row_opaque(act ? tb0 : 0.0); tbwr[t][1] = row_opaque(act ? tb1 : 0.0); tbwr[t][2] = row_opaque(act ? bw[2] : 0.0); }   // (opaque like a value read back from LDS)
             });
         }
         set_sync();
@@ -727,11 +737,14 @@ struct RowSolver {
                 Vcs[k] = (act && comp == k) ? P.q2[9 + k] * Bt[3 + k] * Bt[3 + k] : 0.0;
             }
             static_for<H>([&](auto S) {
+#pragma clang fp contract(off)   // (no contraction left to the compiler between the set-up kernel's and the fused kernels' copies of this block)
                 constexpr int s = A1_CV(S);
                 double ud = 0.0, vd = 0.0;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const double tb = act ? lds[L::TBW + (s * 3 + c) * 12 + ci] : 0.0, bwv = act ? lds[L::BW + (s * 3 + c) * 12 + ci] : 0.0;
+                    double tb;
+                    if constexpr (SETUP_ONLY) tb = tbwr[s][c]; else tb = act ? lds[L::TBW + (s * 3 + c) * 12 + ci] : 0.0;
+                    const double bwv = act ? lds[L::BW + (s * 3 + c) * 12 + ci] : 0.0;
                     cu[s][c] = P.q2[c] * tb; cv[s][c] = P.q2[6 + c] * bwv;
                     ud += cu[s][c] * tb; vd += cv[s][c] * bwv;
                     if (comp == c) { ud += Ucs[c]; vd += Vcs[c]; }
@@ -770,7 +783,8 @@ struct RowSolver {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         v |= (act && lds[L::BW + (A1_CV(S) * 3 + c) * 12 + ci] != 0.0 ? 1u : 0u) << c;
-                        v |= (act && lds[L::TBW + (A1_CV(S) * 3 + c) * 12 + ci] != 0.0 ? 1u : 0u) << (3 + c);
+                        if constexpr (SETUP_ONLY) v |= (tbwr[A1_CV(S)][c] != 0.0 ? 1u : 0u) << (3 + c);
+                        else v |= (act && lds[L::TBW + (A1_CV(S) * 3 + c) * 12 + ci] != 0.0 ? 1u : 0u) << (3 + c);
                     }
                     hsh = (hsh * 67ull + v + 1ull) & ((1ull << 50) - 1ull);
                 });

@@ -1382,12 +1382,12 @@ def test_host_pointer_pipeline_matches_the_synchronous_entry(pkg, scen):
 
 
 def test_update_path_carry_is_dropped_by_ticks_that_do_not_refresh_it(pkg, oracle, scen):
-    """warm_start = 2: a general-path tick (per-step feet) and a stretch in warm_start = 1 rewrite the carried (x, y, rho)
-    but not the update
-    path's carry.  The fast-path tick that follows must NOT pair the stale scalings / gradient / z with the fresh iterates: it is a fresh
-    set-up warm-started
+    """warm_start = 2: a general-path tick (per-step feet) through the general path's SPLIT pipeline (a batch beyond its
+    fused kernels' resident rows; within them the general path follows the update path itself since round 5:
+    test_update_path_on_the_general_path) and a stretch in warm_start = 1 rewrite the carried (x, y, rho) but not the update path's carry.  The
+    fast-path tick that follows must NOT pair the stale scalings / gradient / z with the fresh iterates: it is a fresh set-up warm-started
     from (x, y, rho) -- exactly what a warm_start = 1 handle that saw the same sequence does, bit for bit."""
-    n = 64
+    n = 2048   # (> 1536 = the resident rows of the general path's fused kernel at h = 10)
     rng = np.random.default_rng(77)
     sc = scen.config3_random_flat(nb=n, seed=4242)
     seq = []
@@ -1407,6 +1407,7 @@ def test_update_path_carry_is_dropped_by_ticks_that_do_not_refresh_it(pkg, oracl
         # (the same values it holds: a no-op on the iterates; the general-path tick below is what drops the carry)
         e2.set_warm_start(x, y, rho)
         a = e2.solve_strided(seq[2]["x0"], seq[2]["xref"], seq[2]["R"], f2, 12, c2, 4)
+        assert e2.last_warm_start_mode() == 1
         b = e1.solve_strided(seq[2]["x0"], seq[2]["xref"], seq[2]["R"], f2, 12, c2, 4)
         assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"])
         # a fast-path tick on the update path first (fills the carry again), then the general path, then the fast path: the last one must
