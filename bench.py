@@ -202,6 +202,30 @@ def batch_sweep(pkg, local, sizes=(1, 16, 256, 1024, 4096, 16384, 65536)):
     return out   # (cold first solves through one handle on one stream: north_star's "batch 1 ... 65536")
 
 
+def general_path_probe(pkg, local, shapes=((10, 4096), (16, 8192), (20, 8192))):
+    """Extra information (not `value`): the general path of the reference's interface -- per-step feet (S/ConvexMpc.h:74 B_mat_d_list) and per-step
+    contact schedules through a1mpc_solve_batch_strided -- on the states of the fast path's workload: first solves (queue by the set-up kernel's guess)
+    and the same batch again in history order (tools/general_path_probe.py is the same measurement with the fast path beside it)."""
+    out = {}
+    for h, n in shapes:
+        sc = pkg.scenarios.config3_random_flat(nb=n, horizon=h)
+        rng = np.random.default_rng(h)
+        vd = rng.uniform(-0.6, 0.6, (n, 1, 1, 3))
+        foot = np.ascontiguousarray((sc["foot"].reshape(n, 1, 4, 3) - vd * sc["params"]["dt"] * np.arange(h).reshape(1, h, 1, 1) * 40.0).reshape(n, h * 12))
+        sw = rng.integers(0, h + 1, (n, 4)); first = rng.integers(0, 2, (n, 4))
+        contact = np.ascontiguousarray(np.where(np.arange(h).reshape(1, h, 1) < sw[:, None, :], first[:, None, :], 1 - first[:, None, :]).astype(np.uint8).reshape(n, h * 4))
+        with pkg.Engine(pkg.make_config(sc["params"], h, warm_start=0), n, local) as eng:
+            first_ms, hist_ms = [], []
+            for _ in range(3):
+                eng.set_schedule(True)   # forgets the history: the next solve is a first solve
+                o = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, 12, contact, 4); first_ms.append(eng.last_kernel_ms())
+                eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, 12, contact, 4); hist_ms.append(eng.last_kernel_ms())
+        f, hh = float(np.median(first_ms)), float(np.median(hist_ms))
+        out[f"{n}xh{h}"] = {"first_solve_kernel_ms": f, "first_solve_solves_per_s": n / (f * 1e-3), "history_order_kernel_ms": hh, "history_order_solves_per_s": n / (hh * 1e-3),
+                            "mean_iters": float(o["iters"].mean()), "solved_frac": float((o["status"] == 1).mean())}
+    return out
+
+
 def warm_tick_probe(pkg, local, n=4096, ticks=12, mode=1):
     """Extra information (not `value`): the closed-loop regime -- the same n robots tick after tick with warm start (the carried OSQP
     workspace of the reference) and slowly moving states (two nearby batches alternate), queue order from the previous tick."""
@@ -817,6 +841,7 @@ def main():
             out["warm_start_ticks_update_path"] = warm_tick_probe(pkg, local, mode=2)
             out["stage_counters_warm"] = {f"{n_}_robots_mode{m_}": warm_tick_stage_counters(pkg, local, n=n_, mode=m_) for n_ in (4096, 1) for m_ in (1, 2)}
             out["full_control_tick"] = full_tick_probe(pkg, local)
+            out["general_path"] = general_path_probe(pkg, local)
             meas = {"latency_p50_ms": out["latency"].get("p50_ms"), "latency_p99_ms": out["latency"].get("p99_ms"),
                     "latency_update_path_p50_ms": out["latency_update_path"].get("p50_ms"), "latency_update_path_p99_ms": out["latency_update_path"].get("p99_ms"),
                     "latency_update_path_h16_p50_p99_ms": [out["latency_update_path_h16"].get("p50_ms"), out["latency_update_path_h16"].get("p99_ms")],
@@ -825,6 +850,7 @@ def main():
                     "warm_tick_update_path_kernel_ms_4096_robots": out["warm_start_ticks_update_path"]["kernel_ms_per_tick"],
                     "full_control_tick_ms_4096_robots": out["full_control_tick"]["ms_per_tick"],
                     "throughput_by_batch_solves_per_s": {k: v["solves_per_s"] for k, v in out["throughput_by_batch"].items()},
+                    "general_path_first_solves_per_s": {k: v["first_solve_solves_per_s"] for k, v in out["general_path"].items()},
                     "other_shapes": [{"config": e["config"], "solves_per_s": e["solves_per_s"], "model_frac": e["frac"], "executed_fp64_frac": e.get("executed_fp64_frac"),
                                       "issued_fp64_frac": e.get("issued_fp64_frac_repeats_included")} for e in out.get("roofline_other_configs", [])]}
             out["config"]["measured_beside_value"] = meas   # (inside `config`: the driver's record keeps this block whole)
