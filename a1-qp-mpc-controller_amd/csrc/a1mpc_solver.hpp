@@ -304,7 +304,7 @@ struct Layout {
 };
 
 // LDS image of the set-up kernel (formation + Ruiz only: no factor): 348 doubles per QP at H = 10; GEN (the general path's own set-up kernel): + the per-step
-// table B~w_t, 720 doubles = 5.8 KB per QP at H = 10 (the per-step bounds are rebuilt from the contact bits by the ADMM kernel)
+// table B~w_t, 600 doubles = 4.8 KB per QP at H = 10 (the per-step bounds are rebuilt from the contact bits by the ADMM kernel)
 template <int H, bool GEN = false>
 struct LayoutSetup {
     static constexpr int KSTR = 13, K_SZ = 12 * KSTR, S_SZ = 78, SLOT = K_SZ + S_SZ, FAC = 0, GCOL = 12;  // unused by the set-up code paths
@@ -316,7 +316,8 @@ struct LayoutSetup {
     static constexpr int BL = TBW;
     static constexpr int ZROW = 6;
     static constexpr int CG = BL + 84;
-    static constexpr int BW = CG + 12 * H;                   // GEN: [t][3][12] = the omega rows of B~_t
+    static constexpr int BW = CG + (GEN ? 0 : 12 * H);       // GEN: [t][3][12] = the omega rows of B~_t (and no CG table: c g goes from registers into the record, RowSolver::cgr -- four
+                                                             // four-QP workgroups of the general path's set-up kernel per CU at H = 20: 4 x 1080 doubles + the table = 40 KB each)
     static constexpr int RAW = BW + (GEN ? 36 * H : 0);
     static constexpr int ROW_STRIDE = RAW + (RAW % 2);
 };
@@ -442,6 +443,7 @@ struct RowSolver {
     long long pfX = 0, pfT = 0, pfU = 0;  // CLK: shader-clock cycles this QP spent in factor passes / iteration segments / residual checks (wave-mates' stalls included)
     long long ckF = 0, ckR = 0;           // CLK, set-up: shader clock behind the formation (inputs, B~, gradient, U / V) and behind the Ruiz passes (a1mpc_last_tick_stage_cycles)
     int pred_cost = 0;  // set-up's guess of this QP's cost (queue order of a first solve, see predict_cost)
+    [[maybe_unused]] double cgr[(SETUP_ONLY && GEN) ? H : 1];   // the general path's set-up kernel: c g of my lane per step on its way into the hand-off record (its LDS image has no CG table)
     struct Info {
         double pri_res, dua_res, nEz, nEAx, nDq, nDAty, nDPx;  // unscaled
         double s_pri, s_dua, s_z, s_Ax, s_q, s_Aty, s_Px;      // scaled (rho estimate)
@@ -1049,7 +1051,8 @@ struct RowSolver {
             rr1[t] = E1[t] * E1[t] * rho;
             const double di = 1.0 / D[t];
             dI2[t] = di * di;
-            if (act) lds[L::CG + t * 12 + ci] = csc * g[t];          // D^-1 q_s = c g
+            if constexpr (SETUP_ONLY && GEN) cgr[t] = csc * g[t];
+            else if (act) lds[L::CG + t * 12 + ci] = csc * g[t];     // D^-1 q_s = c g
             if constexpr (UPD && MODE == kModeMpc && H > 1) {
                 if (upd && reinit) {
                     // pattern change: the previous solve's SCALED x_s = x / D', y_s = c' y / E' go through osqp_warm_start_x / _y as if they were unscaled -- a plain
@@ -1140,9 +1143,10 @@ struct RowSolver {
             constexpr int t = A1_CV(T);
             p[(PR::RR0 + t) * 12 + ci] = rr0[t];   // (rr1: rr0 again on the fx / fy lanes, zero elsewhere -- see Prep)
             p[(PR::DI2 + t) * 12 + ci] = dI2[t];
-            p[(PR::CG + t) * 12 + ci] = lds[L::CG + t * 12 + ci];
+            if constexpr (SETUP_ONLY && GEN) p[(PR::CG + t) * 12 + ci] = cgr[t];
+            else p[(PR::CG + t) * 12 + ci] = lds[L::CG + t * 12 + ci];
             if (warm) p[(PR::XH + t) * 12 + ci] = xh[t];
-            if constexpr (UPD && H > 1 && !TWIN) {
+            if constexpr (UPD && H > 1 && !TWIN && !(SETUP_ONLY && GEN)) {
                 if (upd) {  // update path: y^ of my two rows and the first iteration's c g (see setup)
                     p[(PR::YW0 + t) * 12 + ci] = wh0[t]; p[(PR::YW1 + t) * 12 + ci] = wh1[t];
                     p[(PR::CGE + t) * 12 + ci] = lds[L::CG + t * 12 + ci] - epsv[t];
