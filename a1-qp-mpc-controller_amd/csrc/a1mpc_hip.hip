@@ -128,6 +128,14 @@ __global__ __launch_bounds__(64) void a1mpc_solve_gen_kernel(const KernelArgs a)
     solve_row_with<H, kModeMpc, true, true, UPD>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H, true>::ROW_STRIDE);
 }
 
+// Latency variant of the general path's fused kernel (H = 10; solve_latency_gen): one QP per wavefront, its four rows share the set-up, rows 0 / 2 solve
+template <int H, bool UPD = false>
+__global__ __launch_bounds__(64) void a1mpc_solve_gen_coop_kernel(const KernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
+    const int64_t b = static_cast<int64_t>(blockIdx.x);
+    solve_latency_gen<H, UPD>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(b)); }, a1mpc_lds);
+}
+
 // Latency variant of the fused kernel for a handful of QPs: the four rows of a wavefront work on ONE QP during set-up (each takes every fourth
 // horizon step of the Ruiz sweeps; everything else is computed redundantly and written to the one shared LDS image), then rows 1-3 retire
 // and row 0 solves.  Same results bit for bit (the column maxima are exact and order-free).
@@ -800,11 +808,30 @@ static a1mpc_status launch_rows(const KernelArgs& a, hipStream_t stream) {
     A1_HIP(hipGetLastError());
     return A1MPC_OK;
 }
+static constexpr int kCoopMaxBatch = 256;  // at most this many QPs: one wavefront per QP during set-up (the chip has 1024 SIMDs)
+static bool coop_setup_enabled() {   // A1MPC_COOP_SETUP=0: small batches through the fused kernels instead of the latency kernels (A/B runs)
+    static const bool on = [] { const char* e = getenv("A1MPC_COOP_SETUP"); return !(e && !strcmp(e, "0")); }();
+    return on;
+}
 template <int H, int ROWS>
 static a1mpc_status launch_gen_rows(const KernelArgs& a, hipStream_t stream) {
     static bool attr_set[64] = {};
     int dev = 0;
     A1_HIP(hipGetDevice(&dev));
+    if constexpr (H % 4 != 0) {   // a handful of QPs at H = 10: one wavefront per QP, its four rows share the set-up (a1mpc_solve_gen_coop_kernel)
+        if (a.n <= kCoopMaxBatch && coop_setup_enabled()) {
+            const size_t lds1 = sizeof(double) * Layout<H, true>::ROW_STRIDE;
+            if (a.carry != nullptr) {
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_gen_coop_kernel<H, true>), lds1); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_solve_gen_coop_kernel<H, true>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds1, stream, a);
+            } else {
+                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_gen_coop_kernel<H, false>), lds1); st != A1MPC_OK) return st;
+                hipLaunchKernelGGL((a1mpc_solve_gen_coop_kernel<H, false>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds1, stream, a);
+            }
+            A1_HIP(hipGetLastError());
+            return A1MPC_OK;
+        }
+    }
     const size_t lds = sizeof(double) * ROWS * Layout<H, true>::ROW_STRIDE;
     {
         std::lock_guard<std::mutex> lock(g_cache_mu);
@@ -914,7 +941,6 @@ static a1mpc_status launch_gen(int horizon, const KernelArgs& a, hipStream_t s) 
 #endif
     return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet / contact schedules need horizon 10, 16 or 20");
 }
-static constexpr int kCoopMaxBatch = 256;  // at most this many QPs: one wavefront per QP during set-up (the chip has 1024 SIMDs)
 template <int H>
 static a1mpc_status launch_coop(const KernelArgs& a, hipStream_t stream) {
     static bool attr_set[64] = {};
@@ -955,8 +981,7 @@ static a1mpc_status launch_coop(const KernelArgs& a, hipStream_t stream) {
 template <int H, int MODE>
 static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
     if constexpr (MODE == kModeMpc && H > 1) {
-        static const bool coop = [] { const char* e = getenv("A1MPC_COOP_SETUP"); return !(e && !strcmp(e, "0")); }();
-        if (coop && a.n <= kCoopMaxBatch) return launch_coop<H>(a, stream);
+        if (coop_setup_enabled() && a.n <= kCoopMaxBatch) return launch_coop<H>(a, stream);
     }
 #ifdef A1MPC_ALL_ROWS
     if (a.carry == nullptr) {   // (the update-path kernels exist for the default rows per workgroup only)

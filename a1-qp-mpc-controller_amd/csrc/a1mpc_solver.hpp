@@ -2318,6 +2318,31 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
         S.write_outputs(make_io_());
     }
 }
+// Latency variant of the general path's fused solve for a horizon at which a wavefront would hold two QPs (H = 10; round 5): a handful of QPs, one per wavefront, whose FOUR
+// rows share the set-up -- each takes every fourth block column of the general path's Ruiz sweeps (every column is visited there: the sweeps are most of a general-path tick's
+// set-up) and every fourth horizon step of the D / E updates; then rows 1 / 3 retire and rows 0 / 2 solve as a main / twin pair.  Same bits as the fused general kernel, whose
+// pairs share the set-up two ways (the column maxima are exact and order-free).  At H = 16 / 20 the fused kernel's quad of rows already is this arrangement.
+template <int H, bool UPD = false, class MakeIO>
+A1_DEV void solve_latency_gen(const DeviceParams& P, const double* __restrict__ tab, MakeIO&& make_io_, double* __restrict__ lds) {
+    static_assert(H % 2 == 0 && H % 4 != 0, "a main / twin pair per QP and no quad: H = 10");
+    using LG = Layout<H, true>;
+    static_assert(Prep<H>::STRIDE <= H * LG::SLOT, "the hand-off record fits the (still empty) factor region");
+    const int cid = 2 * (row_is_twin() ? 1 : 0) + row_sub();
+    {
+        RowSolver<H, kModeMpc, false, true> S0(P, stage_table<H, LG>(tab, lds, cid, 4), lds);
+        S0.coop_id = cid; S0.coop_n = 4;
+        S0.template setup<UPD>(make_io_());
+        coop_sync();   // everybody is done with the set-up scratch aliased into the factor region
+        if (cid == 0) S0.template save_prepared<UPD>(lds + LG::FAC);
+    }
+    if (row_sub()) return;   // rows 1 and 3 retire
+    pair_sync();             // the twin reads the hand-off record and the per-step tables row 0 wrote
+    RowSolver<H, kModeMpc, false, true, true> S(P, tab, lds);
+    S.template load_prepared<UPD>(lds + LG::FAC, make_io_());
+    S.template solve<UPD>();
+    if constexpr (UPD) { const ProblemIO& io_ = make_io_(); S.write_outputs(io_, io_.carry); }
+    else S.write_outputs(make_io_());
+}
 template <int H, int MODE = kModeMpc, bool GEN = false, bool UPD = false>
 A1_DEV void solve_row(const DeviceParams& P, const double* __restrict__ tab, const ProblemIO& io, double* __restrict__ lds) {
     solve_row_with<H, MODE, GEN, false, UPD>(P, tab, [&]() -> const ProblemIO& { return io; }, lds);

@@ -223,6 +223,19 @@ def general_path_probe(pkg, local, shapes=((10, 4096), (16, 8192), (20, 8192))):
         f, hh = float(np.median(first_ms)), float(np.median(hist_ms))
         out[f"{n}xh{h}"] = {"first_solve_kernel_ms": f, "first_solve_solves_per_s": n / (f * 1e-3), "history_order_kernel_ms": hh, "history_order_solves_per_s": n / (hh * 1e-3),
                             "mean_iters": float(o["iters"].mean()), "solved_frac": float((o["status"] == 1).mean())}
+        # batch 1 (the reference's own use of the interface, S/test/test_mpc.cpp:106-122: one QP with a B_d per step): the fused general kernel, 40 warm-started
+        # ticks of robot 0 with slowly moving state, kernel time by the handle's events, the fast path's latency kernel on the same ticks beside it
+        with pkg.Engine(pkg.make_config(sc["params"], h, warm_start=1), 1, local) as eng:
+            g_ms, f_ms, its = [], [], []
+            x0 = sc["x0"][:1].copy()
+            for k in range(40):
+                x0[:, :12] += np.random.default_rng(1000 + k).normal(0, 2e-3, (1, 12))
+                o1 = eng.solve_strided(x0, sc["xref"][:1], sc["R"][:1], foot[:1], 12, contact[:1], 4); g_ms.append(eng.last_kernel_ms()); its.append(int(o1["iters"][0]))
+            eng.reset_warm_start()
+            for k in range(40):
+                eng.solve(x0, sc["xref"][:1], sc["R"][:1], sc["foot"][:1], sc["contact"][:1]); f_ms.append(eng.last_kernel_ms())
+        out[f"{n}xh{h}"].update({"batch1_warm_tick_kernel_ms": float(np.median(g_ms[5:])), "batch1_warm_tick_mean_iters": float(np.mean(its[5:])),
+                                 "batch1_warm_tick_kernel_ms_fast_path": float(np.median(f_ms[5:]))})
     return out
 
 

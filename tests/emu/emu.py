@@ -139,7 +139,7 @@ def _solve(sc, n, h, P, grf, u, iters, status, nfact, wx, wy, rho, contact, spli
     return dict(grf=grf, u=u, iters=iters, status=status, nfact=nfact)
 
 
-def solve_gen(sc, foot, foot_stride, contact, contact_stride, n=None, settings=None, warm=None, twin=False, quad=False, carry=None, **over):
+def solve_gen(sc, foot, foot_stride, contact, contact_stride, n=None, settings=None, warm=None, twin=False, quad=False, carry=None, latency=False, **over):
     """the general path: foot (n, 12) or (n, 12h) with foot_stride 0 / 12; contact (n, 4) or (n, 4h) with contact_stride 0 / 4;
     carry: Carry<H> records (carry_buffer) for the update path, warm_start = 2 (twin / quad runs)"""
     h = sc["horizon"]
@@ -151,7 +151,7 @@ def solve_gen(sc, foot, foot_stride, contact, contact_stride, n=None, settings=N
     wx = wy = rho = None
     if warm is not None:
         wx, wy, rho = warm
-    lib().a1mpc_emu_set_twin(2 if quad else (1 if twin else 0))
+    lib().a1mpc_emu_set_twin(3 if latency else (2 if quad else (1 if twin else 0)))   # latency: the general path's latency kernel (h = 10)
     lib().a1mpc_emu_set_carry.argtypes = [C.c_void_p]
     lib().a1mpc_emu_set_carry(None if carry is None else carry.ctypes.data)
     rc = lib().a1mpc_emu_solve_gen(C.byref(P), h, n, _p(sc["x0"]), _p(sc["xref"]), _p(sc["R"]), _p(foot), int(foot_stride), _p(contact, C.c_uint8),

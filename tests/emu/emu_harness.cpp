@@ -426,6 +426,15 @@ static void gen_quad_entry(void* a) {
         else solve_row_with<H, kModeMpc, true, true, false, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
     }
 }
+// the general path's latency kernel (a1mpc_solve_gen_coop_kernel): the device function itself, on 64 fibers whose rows 1 / 3 retire behind the shared set-up
+template <int H>
+static void gen_latency_entry(void* a) {
+    Job<H>* j = static_cast<Job<H>*>(a);
+    if constexpr (H % 2 == 0 && H % 4 != 0 && H >= 10) {
+        if (j->io.carry) solve_latency_gen<H, true>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+        else solve_latency_gen<H, false>(*j->P, j->tab, [&]() -> const ProblemIO& { return j->io; }, j->lds);
+    }
+}
 template <int H>
 static void run_gen(const DeviceParams* P, int n, const double* x0, const double* xref, const double* R, const double* foot, int foot_stride,
                     const uint8_t* contact, int contact_stride, double* grf, double* u_full, double* warm_x, double* warm_y, double* rho,
@@ -446,7 +455,8 @@ static void run_gen(const DeviceParams* P, int n, const double* x0, const double
         j.io.rho_io = rho ? rho + b : nullptr;
         j.io.iters = iters ? iters + b : nullptr; j.io.status = status ? status + b : nullptr; j.io.nfact = nfact ? nfact + b : nullptr;
         if constexpr (H >= 10) j.io.carry = g_emu_carry ? g_emu_carry + (size_t)b * Carry<H>::STRIDE : nullptr;   // update path (a1mpc_emu_set_carry); twin / quad runs only
-        if (g_emu_twin == 2 && H % 4 == 0) run_row(gen_quad_entry<H>, &j, 64);
+        if (g_emu_twin == 3 && H % 2 == 0 && H % 4 != 0 && H >= 10) run_row(gen_latency_entry<H>, &j, 64, true);
+        else if (g_emu_twin == 2 && H % 4 == 0) run_row(gen_quad_entry<H>, &j, 64);
         else if (g_emu_twin && H % 2 == 0) run_row(gen_twin_entry<H>, &j, 32);
         else run_row(gen_entry<H>, &j);
     }

@@ -422,6 +422,41 @@ def test_emulated_update_path_on_the_general_path_matches_oracle(oracle, scen, h
     assert carry[0, 0] > 0.0          # the update path's carry was used (C = the cost scaling of the last tick)
 
 
+def test_emulated_latency_kernel_on_the_general_path(scen):
+    """Round 5: the general path's latency kernel at h = 10 (solve_latency_gen: the four rows of a wavefront share one QP's set-up, rows 0 / 2 solve) gives the bits of the
+    fused general kernel's main / twin pair -- cold solves with per-step feet and contact schedules, and a warm_start = 2 sequence through a contact switch."""
+    h, n = 10, 6
+    sc = scen.config3_random_flat(nb=n, horizon=h)
+    rng = np.random.default_rng(7)
+    vd = rng.uniform(-0.6, 0.6, (n, 1, 1, 3))
+    foot = (sc["foot"].reshape(n, 1, 4, 3) - vd * sc["params"]["dt"] * np.arange(h).reshape(1, h, 1, 1) * 40.0).reshape(n, h * 12)
+    sw = rng.integers(0, h + 1, (n, 4)); first = rng.integers(0, 2, (n, 4))
+    contact = np.where(np.arange(h).reshape(1, h, 1) < sw[:, None, :], first[:, None, :], 1 - first[:, None, :]).astype(np.uint8).reshape(n, h * 4)
+    a = emu.solve_gen(sc, foot, 12, contact, 4, twin=True)
+    b = emu.solve_gen(sc, foot, 12, contact, 4, latency=True)
+    assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["status"], b["status"]) and np.array_equal(a["nfact"], b["nfact"])
+    assert (a["status"] == 1).all()
+    seq = scen.config2_trot_sequence(70, horizon=h)
+    st = {}
+    for name in ("twin", "latency"):
+        st[name] = dict(wx=np.zeros((1, 12 * h)), wy=np.zeros((1, 20 * h)), rho=np.zeros(1), carry=emu.carry_buffer(h, 1))
+    dt = seq["params"]["dt"]
+    for k in list(range(0, 4)) + list(range(58, 62)):
+        vdk = np.array([0.3, 0.05 * np.sin(k), 0.0])
+        footk = (seq["foot"][k].reshape(1, 4, 3) - vdk * dt * np.arange(h).reshape(h, 1, 1)).reshape(1, 12 * h)
+        phase = (k + np.arange(h)) // 60 % 2 == 0
+        contk = np.where(phase[:, None], [1, 0, 0, 1], [0, 1, 1, 0]).astype(np.uint8).reshape(1, 4 * h)
+        one = {kk: (seq[kk][k:k + 1] if kk in ("x0", "xref", "R", "foot", "contact") else seq[kk]) for kk in seq}
+        outs = {}
+        for name in ("twin", "latency"):
+            w = st[name]
+            outs[name] = emu.solve_gen(one, footk, 12, contk, 4, n=1, warm=(w["wx"], w["wy"], w["rho"]), carry=w["carry"], twin=name == "twin", latency=name == "latency",
+                                       warm_start=2)
+        assert np.array_equal(outs["twin"]["u"], outs["latency"]["u"]) and outs["twin"]["iters"][0] == outs["latency"]["iters"][0], k
+        assert np.array_equal(st["twin"]["carry"], st["latency"]["carry"]) and np.array_equal(st["twin"]["wy"], st["latency"]["wy"]), k
+    assert st["latency"]["carry"][0, 0] > 0.0
+
+
 @pytest.mark.parametrize("path", ["fused_twin", "split_twin"])
 def test_emulated_update_path_reinitialises_on_a_pattern_change(oracle, scen, path):
     """warm_start = 2 when exact zeros of the reference's Hessian appear / vanish (fixture T's weights: level <-> pitched): osqp-eigen's updateHessianMatrix

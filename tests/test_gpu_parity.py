@@ -901,6 +901,35 @@ def test_update_path_on_the_general_path(pkg, oracle, scen, h, nb):
             assert eng.last_warm_start_mode() == 1
 
 
+def test_general_path_latency_kernel(pkg, oracle, scen):
+    """Round 5: a handful of general-path QPs at h = 10 (<= 256: the reference's own use of the interface is ONE, S/test/test_mpc.cpp:106-122) run one per wavefront with
+    the four rows sharing the set-up (a1mpc_solve_gen_coop_kernel).  Bit for bit what the same QPs give inside a batch of 300 (the fused general kernel: main / twin
+    pairs), the oracle's strided formation on every QP, and the same on the update path (warm_start = 2) over four ticks."""
+    h, nb, small = 10, 300, 9
+    rng = np.random.default_rng(4242)
+    sc, foot, fs, contact, cs = _strided_inputs(scen, rng, h, nb, True, True)
+    with _engine(pkg, sc, nb, warm_start=0) as eng:
+        big = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, fs, contact, cs, want_u=True)
+        lat = eng.solve_strided(sc["x0"][:small], sc["xref"][:small], sc["R"][:small], foot[:small], fs, contact[:small], cs, want_u=True)
+        one = eng.solve_strided(sc["x0"][:1], sc["xref"][:1], sc["R"][:1], foot[:1], fs, contact[:1], cs, want_u=True)
+    for k in ("u", "grf", "iters", "status"):
+        assert np.array_equal(big[k][:small], lat[k]) and np.array_equal(big[k][:1], one[k]), k
+    p = sc["params"]
+    pr = oracle.mpc_params(h, p["dt"], p["mu"], p["fz_min"], p["fz_max"], p["q"], p["r"], p["mass"], p["inertia"]); st = oracle.default_settings()
+    for b in range(small):
+        o = oracle.mpc_solve(pr, st, sc["x0"][b], sc["xref"][b], sc["R"][b], foot[b], contact[b], foot_stride=fs, contact_stride=cs)
+        assert o["info"].iters == lat["iters"][b] and o["info"].status == lat["status"][b] and np.abs(o["grf"] - lat["grf"][b]).max() < 1e-5, b
+    # update path: a batch of 300 (fused general kernel) and its first 9 robots alone (latency kernel) tick side by side
+    with _engine(pkg, sc, nb, warm_start=2) as e_big, _engine(pkg, sc, small, warm_start=2) as e_lat:
+        x0 = sc["x0"].copy()
+        for t in range(4):
+            x0[:, :12] += np.random.default_rng(t).normal(0, 2e-3, (nb, 12))
+            a = e_big.solve_strided(x0, sc["xref"], sc["R"], foot, fs, contact, cs, want_u=True)
+            b = e_lat.solve_strided(x0[:small], sc["xref"][:small], sc["R"][:small], foot[:small], fs, contact[:small], cs, want_u=True)
+            assert np.array_equal(a["u"][:small], b["u"]) and np.array_equal(a["iters"][:small], b["iters"]), t
+        assert e_lat.last_warm_start_mode() == 2 and e_big.last_warm_start_mode() == 2
+
+
 @pytest.mark.parametrize("h,nb", [(10, 4000), (16, 2100), (20, 1700)])
 def test_general_path_split_pipeline(pkg, oracle, scen, h, nb):
     """a general-path batch beyond its resident rows runs the general path's own set-up kernel + persistent main / twin pairs on a queue
