@@ -809,6 +809,10 @@ static a1mpc_status launch_rows(const KernelArgs& a, hipStream_t stream) {
     return A1MPC_OK;
 }
 static constexpr int kCoopMaxBatch = 256;  // at most this many QPs: one wavefront per QP during set-up (the chip has 1024 SIMDs)
+static int coop_max_batch() {   // A1MPC_COOP_MAX=n moves the limit (A/B runs: profiles/r05_latency_kernel_batch_limit.txt)
+    static const int v = [] { const char* e = getenv("A1MPC_COOP_MAX"); const int n = e ? atoi(e) : kCoopMaxBatch; return n > 0 ? n : kCoopMaxBatch; }();
+    return v;
+}
 static bool coop_setup_enabled() {   // A1MPC_COOP_SETUP=0: small batches through the fused kernels instead of the latency kernels (A/B runs)
     static const bool on = [] { const char* e = getenv("A1MPC_COOP_SETUP"); return !(e && !strcmp(e, "0")); }();
     return on;
@@ -819,7 +823,7 @@ static a1mpc_status launch_gen_rows(const KernelArgs& a, hipStream_t stream) {
     int dev = 0;
     A1_HIP(hipGetDevice(&dev));
     if constexpr (H % 4 != 0) {   // a handful of QPs at H = 10: one wavefront per QP, its four rows share the set-up (a1mpc_solve_gen_coop_kernel)
-        if (a.n <= kCoopMaxBatch && coop_setup_enabled()) {
+        if (a.n <= coop_max_batch() && coop_setup_enabled()) {
             const size_t lds1 = sizeof(double) * Layout<H, true>::ROW_STRIDE;
             if (a.carry != nullptr) {
                 if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_gen_coop_kernel<H, true>), lds1); st != A1MPC_OK) return st;
@@ -981,7 +985,7 @@ static a1mpc_status launch_coop(const KernelArgs& a, hipStream_t stream) {
 template <int H, int MODE>
 static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
     if constexpr (MODE == kModeMpc && H > 1) {
-        if (coop_setup_enabled() && a.n <= kCoopMaxBatch) return launch_coop<H>(a, stream);
+        if (coop_setup_enabled() && a.n <= coop_max_batch()) return launch_coop<H>(a, stream);
     }
 #ifdef A1MPC_ALL_ROWS
     if (a.carry == nullptr) {   // (the update-path kernels exist for the default rows per workgroup only)
@@ -2774,7 +2778,7 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     // Round 5 trial (opt-in, see warm_order_enabled): the fused kernel of a warm-started tick launches its workgroups in the order of the previous tick's per-QP
     // cost, longest first (the cost buffer holds it: hint_n == n; the fused kernel records this tick's).  Scheduling only: every result is bit-identical in any order.
-    if (warm_fused && h->schedule && n >= kScheduleMinBatch && n > kCoopMaxBatch && warm_order_enabled()) {
+    if (warm_fused && h->schedule && n >= kScheduleMinBatch && n > coop_max_batch() && warm_order_enabled()) {
         RoctxRange range("a1mpc order");
         hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, s, static_cast<int>(n), static_cast<const int32_t*>(h->d_cost), h->d_order);
         A1_HIP(hipGetLastError());
