@@ -473,8 +473,10 @@ a1mpc_status a1mpc_last_stage_cycles(a1mpc_handle h, double* cycles3_out, int32_
  * split-pipeline solve reports through a1mpc_last_stage_cycles).  Host call; synchronises the handle's stream. */
 a1mpc_status a1mpc_last_tick_stage_cycles(a1mpc_handle h, double* cycles8_out, int32_t* qps_out);
 /* Which warm-start semantics the handle's last MPC solve actually ran: 0 (cold), 1 (fresh set-up + osqp_warm_start) or 2 (the reference's update path).
- * warm_start = 2 exists on the fast path at horizons 10 / 16 / 20; a solve through the general path (per-step feet, a separate A_c yaw) or at horizon 1
- * runs mode 1 instead (documented at a1mpc_config.warm_start) -- this call makes that visible to the caller.  -1 before the first solve. */
+ * warm_start = 2 exists at horizons 10 / 16 / 20 on the fast path and (round 5) on the general path's latency and fused kernels (per-step feet, a separate A_c
+ * yaw: batches within those kernels' resident rows -- 1536 / 1024 / 768 QPs at h = 10 / 16 / 20 on an MI355X); a general-path batch beyond them (its split
+ * pipeline) or a solve at horizon 1 runs mode 1 instead (documented at a1mpc_config.warm_start) -- this call makes that visible to the caller.  -1 before the
+ * first solve. */
 a1mpc_status a1mpc_last_warm_start_mode(a1mpc_handle h, int32_t* mode_out);
 
 /* Replace the configuration of a live handle -- everything except the horizon: dt (the reference uses the measured loop dt when
