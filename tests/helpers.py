@@ -8,9 +8,10 @@ TOL_FORCE_N = 1e-5          # ||u_gpu - u_oracle||_inf, same settings, same iter
                             # 99.9 % < 5e-9, worst 1.4e-6 N (most of the worst-case gap is the double-precision oracle's own rounding: DESIGN.md 5)
 TOL_FORCE_ANY_BATCH_N = 1e-5   # the same bound for arbitrary random batches (seeds no other test uses)
 TOL_FORCE_BALANCE_N = 2e-4  # balance QP: P = 1e-3 I + M'QM, cond ~ 1e6 -- round-off is amplified more (observed <= 2e-5 N)
-MIN_SAME_ITERS = 0.995      # fraction of problems that must stop at the oracle's iteration (a termination test that
-                            # lands within round-off of its threshold may flip; those problems are compared through
-                            # the oracle's own default-vs-exact slack instead)
+MIN_SAME_ITERS = 1.0        # EVERY problem must stop at the oracle's iteration with the oracle's status (round 6, VERDICT r5 item 7: not one mismatch has been
+                            # observed in > 2 M fresh QPs at OSQP's default tolerances, so the gate is what is observed).  The only callers that pass a smaller
+                            # fraction are named exceptions with their reason beside them: test_exact_mode_h10 (eps 1e-10: the termination threshold itself
+                            # lies inside double-precision round-off of the residuals).  The exact-mode resolver below stays as a DIAGNOSTIC for those.
 
 
 def oracle_params(O, sc):

@@ -55,7 +55,9 @@ def test_exact_mode_h10(pkg, oracle, scen):
     with _engine(pkg, sc, 64, warm_start=0, eps_abs=1e-10, eps_rel=1e-10, max_iter=100000) as eng:
         out = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
     ref = oracle_batch(oracle, sc, settings=oracle.exact_settings())
-    compare(out, ref, min_same=0.9)
+    # named exception to MIN_SAME_ITERS = 1.0: at eps 1e-10 the termination threshold is inside the round-off of the residuals themselves (the residual of a converged
+    # QP is ~1e-11 +- 1e-12 of summation-order noise), so the checkpoint at which it passes may differ by one; the resolver holds such QPs to the exact optimum
+    compare(out, ref, min_same=0.9, resolve=exact_resolver(oracle, sc, settings=oracle.exact_settings()))
     # whatever the iteration count, both are the optimum
     assert np.abs(out["u"] - ref["u"]).max() < 1e-5
 
