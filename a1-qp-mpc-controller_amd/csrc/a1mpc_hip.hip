@@ -10,85 +10,18 @@
 // irrelevant here (no L2 reuse to localise).
 //
 // There is no CPU path in this file: without a HIP device every entry point fails.
-#include <hip/hip_runtime.h>
-#include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen()ed by a1mpc_sharded_create(transport = 1), never linked
 
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
 #include <new>
-#include <string>
-#include <utility>
-#include <vector>
 
-#include <a1mpc_rowops.hpp>
+#include "a1mpc_common.hpp"
 
-#include "../../include/a1mpc.h"
-#include "a1mpc_solver.hpp"
-#include "a1mpc_tables.hpp"
+extern "C" const char a1mpc_build_id_[];   // a1mpc_build_id.cpp: "sources <hash> arch gfx950"
 
-#ifdef A1MPC_DEV_SLIM
-#define A1_SLIM_H ((A1MPC_DEV_SLIM + 0) >= 10 ? (A1MPC_DEV_SLIM + 0) : 10)   // the one horizon a kernel-tuning build serves (split pipeline only)
-#endif
 namespace a1mpc {
 
-using KernelArgs = BatchArgs;
-
-
-// The MPC kernels with at most two QPs per wavefront run the wavefront's other rows as twins of the QP rows: rows r and r + 2 share a QP and its
-// LDS image (row_is_twin(), RowSolver<.., TWIN>); the workgroup is then a full wavefront.
-constexpr bool twin_rows(int h, int mode, int rows) { return rows <= 2 && h > 1 && mode == kModeMpc; }
-// ... and where a wavefront holds ONE QP and the horizon is a multiple of 4, all four rows work on it as a quad (fused and latency kernels; the persistent rows: quad_rows below)
-constexpr bool fused_quad_rows(int h, int mode, int rows) { return rows == 1 && h > 1 && h % 4 == 0 && mode == kModeMpc; }
-// ROWS = QPs (DPP rows) per workgroup; the workgroup is one wavefront with 16*ROWS live lanes (64 with twin rows).
-// UPD: the instantiation that also serves warm_start = 2 (the reference's update path; built for the default ROWS of a horizon only)
-// CLK: the profiling instantiation (a1mpc_set_profiling): shader-clock stamps between the stages of a tick, a.clk = n x kTickStages cycles (a1mpc_last_tick_stage_cycles)
-template <int H, int MODE, int ROWS, bool UPD = false, bool CLK = false>
-__global__ __launch_bounds__(64) void a1mpc_solve_kernel(const KernelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    constexpr bool kTwin = twin_rows(H, MODE, ROWS);
-    if constexpr (fused_quad_rows(H, MODE, ROWS)) {   // one QP per wavefront, horizon a multiple of 4: the four rows share it as a quad (RowSolver<.., QUAD>)
-        // a.order (warm-started ticks of a known batch, see solve_device_impl): workgroup k takes the QP that was k-th most expensive in the previous tick -- the chip
-        // runs a batch of 2 x the resident rows in two rounds, and a 50-iteration QP that starts in the second one is a tail of a whole 25-iteration segment
-        const int64_t bq = a.order ? static_cast<int64_t>(a.order[blockIdx.x]) : static_cast<int64_t>(blockIdx.x);
-        solve_row_with<H, MODE, false, true, UPD, true, CLK>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(bq)); }, a1mpc_lds, CLK ? a.clk + bq * kTickStages : nullptr);
-        return;
-    }
-    const int row = kTwin ? (static_cast<int>(threadIdx.x) >> 4) & 1 : static_cast<int>(threadIdx.x) >> 4;
-    if (kTwin && row >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
-    const int64_t slot = static_cast<int64_t>(blockIdx.x) * ROWS + row;
-    if (slot >= a.n) return;  // row-uniform (a twin leaves with its main row): the other rows of the wave keep all their DPP sources
-    const int64_t b = a.order ? static_cast<int64_t>(a.order[slot]) : slot;
-    solve_row_with<H, MODE, false, kTwin, UPD, false, CLK>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE,
-                                                           CLK ? a.clk + b * kTickStages : nullptr);
-}
-
-// Round 5 trial ("split-vs-fused with a queue in both"; A1MPC_FUSED_QUEUE=1): the fused kernel as PERSISTENT wavefronts on a work queue -- no set-up
-// kernel, no hand-off record through HBM, no grid-wide barrier between a batch's set-up and its iterations, so the wavefronts of the NEXT batch (another stream) can
-// start on every SIMD this batch's tail vacates.  A wavefront pulls ROWS queue slots at a time (both of its QPs are set up together: the set-up is wave-wide code)
-// and goes back to the queue when both have converged.  The queue order comes from a1mpc_predict_kernel (the set-up kernel's cost guess, evaluated from the inputs
-// alone) or from the previous solve's costs.  Same RowSolver code as a1mpc_solve_kernel: same bits.  Measured: profiles/r05_fused_queue_trial.txt.
-template <int H, int MODE, int ROWS>
-__global__ __launch_bounds__(64) void a1mpc_solve_queue_kernel(const KernelArgs a, int* __restrict__ counter) {
-    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    static_assert(twin_rows(H, MODE, ROWS) && ROWS == 2, "two QPs per wavefront, each on a main / twin pair of rows");
-    const int row = (static_cast<int>(threadIdx.x) >> 4) & 1;
-    while (true) {
-        int q0 = 0;
-        if (threadIdx.x == 0) q0 = atomicAdd(counter, ROWS);
-        q0 = __builtin_amdgcn_readfirstlane(q0);
-        if (q0 >= a.n) break;
-        const int slot = q0 + row;
-        if (slot < a.n) {   // row-uniform (a twin follows its main row)
-            const int64_t b = a.order ? static_cast<int64_t>(a.order[slot]) : static_cast<int64_t>(slot);
-            solve_row_with<H, MODE, false, true, false>(a.P, a.tab, [&]() { return make_io_sched<H, MODE>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
-        }
-        row_sync();   // the images are free again
-    }
-}
 // the set-up kernel's cost guess (RowSolver::predict_cost) from the inputs alone, one thread per QP: the queue order of a first solve through a1mpc_solve_queue_kernel
 __global__ __launch_bounds__(256) void a1mpc_predict_kernel(const KernelArgs a, int H) {
     const int64_t b = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -107,166 +40,6 @@ __global__ __launch_bounds__(256) void a1mpc_predict_kernel(const KernelArgs a, 
     const double hard = 30.0 * ev[2] + 27.0 * sqrt(ev[0] * ev[0] + ev[1] * ev[1]) + (all_stance ? 10.0 : 0.0);
     const double cc = 8.0 * hard + 400.0;
     a.cost[b] = cc > 0.0 ? (cc < 2047.0 ? static_cast<int>(cc) : 2047) : 0;
-}
-
-// General path (per-step feet / per-step contact schedules: S/ConvexMpc.h:74 B_mat_d_list, S/test/test_mpc.cpp:106-122): the fused kernel
-// over RowSolver<.., GEN = true>, whose LDS image also holds B~_t and the bounds of every horizon step.
-// UPD (round 5): the instantiation that also serves warm_start = 2, the reference's update path, on the general path (batches within the resident rows)
-template <int H, int ROWS, bool UPD = false>
-__global__ __launch_bounds__(64) void a1mpc_solve_gen_kernel(const KernelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    static_assert(ROWS <= 2, "rows r and r + 2 of the wavefront share a QP (twin rows)");
-    if constexpr (fused_quad_rows(H, kModeMpc, ROWS)) {   // one QP per wavefront, horizon a multiple of 4: a quad of rows
-        const int64_t bq = static_cast<int64_t>(blockIdx.x);
-        solve_row_with<H, kModeMpc, true, true, UPD, true>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(bq)); }, a1mpc_lds);
-        return;
-    }
-    const int row = (static_cast<int>(threadIdx.x) >> 4) & 1;
-    if (row >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
-    const int64_t b = static_cast<int64_t>(blockIdx.x) * ROWS + row;
-    if (b >= a.n) return;
-    solve_row_with<H, kModeMpc, true, true, UPD>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(b)); }, a1mpc_lds + row * Layout<H, true>::ROW_STRIDE);
-}
-
-// Latency variant of the general path's fused kernel (H = 10; solve_latency_gen): one QP per wavefront, its four rows share the set-up, rows 0 / 2 solve
-template <int H, bool UPD = false>
-__global__ __launch_bounds__(64) void a1mpc_solve_gen_coop_kernel(const KernelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    const int64_t b = static_cast<int64_t>(blockIdx.x);
-    solve_latency_gen<H, UPD>(a.P, a.tab, [&]() { return make_io_gen<H>(a, row_opaque(b)); }, a1mpc_lds);
-}
-
-// Latency variant of the fused kernel for a handful of QPs: the four rows of a wavefront work on ONE QP during set-up (each takes every fourth
-// horizon step of the Ruiz sweeps; everything else is computed redundantly and written to the one shared LDS image), then rows 1-3 retire
-// and row 0 solves.  Same results bit for bit (the column maxima are exact and order-free).
-template <int H, bool UPD = false, bool CLK = false>
-__global__ __launch_bounds__(64) void a1mpc_solve_coop_kernel(const KernelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    const int row = static_cast<int>(threadIdx.x) >> 4;
-    const int64_t b = static_cast<int64_t>(blockIdx.x);
-    const ProblemIO io = make_io_sched<H, kModeMpc>(a, b);
-    static_assert(Prep<H>::STRIDE <= H * Layout<H>::SLOT, "the hand-off record fits the (still empty) factor region");
-    [[maybe_unused]] long long c0 = 0, cF = 0, cR = 0, c1 = 0, c2 = 0;
-    if constexpr (CLK) c0 = row_clock();
-    {
-        RowSolver<H, kModeMpc, false, false, false, false, CLK> S(a.P, stage_table<H, Layout<H>>(a.tab, a1mpc_lds, row, 4), a1mpc_lds);
-        S.coop_id = row; S.coop_n = 4;
-        S.template setup<UPD>(io);
-        row_sync();  // every row is done with the set-up scratch aliased into the factor region
-        if (row == 0) S.template save_prepared<UPD>(a1mpc_lds + Layout<H>::FAC);
-        if constexpr (CLK) { cF = S.ckF; cR = S.ckR; }
-    }
-    constexpr bool kQuad = H % 4 == 0;   // the four rows go on as a quad; otherwise rows 1 and 3 retire
-    if constexpr (!kQuad) { if (row & 1) return; }
-    // Rows 0 and 2 continue exactly like a main / twin pair of the split pipeline's second kernel: a fresh solver that reads the hand-off record
-    // (here through LDS).  Carrying the set-up's registers into the ADMM loop instead costs that loop its spill-free allocation.
-    RowSolver<H, kModeMpc, false, false, true, false, CLK, kQuad> S(a.P, a.tab, a1mpc_lds);
-    S.template load_prepared<UPD>(a1mpc_lds + Layout<H>::FAC, make_io<H, kModeMpc>(a, b));
-    if constexpr (CLK) c1 = row_clock();
-    S.template solve<UPD>();
-    if constexpr (CLK) c2 = row_clock();
-    if constexpr (UPD) S.write_outputs(make_io_sched<H, kModeMpc>(a, b), carry_of<H>(a, b));   // (make_io_sched: the output stage's joint torques read the contacts)
-    else S.write_outputs(make_io_sched<H, kModeMpc>(a, b));
-    if constexpr (CLK) S.store_tick_stages(a.clk ? a.clk + b * kTickStages : nullptr, c0, cF, cR, c1, c2, row_clock());
-}
-
-// ---- split pipeline (large batches) -----------------------------------------------------------------------------
-// K1: formation + Ruiz, 4 QPs per wavefront, 2.8 KB of LDS per QP (H = 10), ONE wave per SIMD (WAVES = 1: all 512 registers, nothing spills).
-// Until the Ruiz sweep became a short column loop (RowSolver::setup) a second wave per SIMD (256 registers each, 35-137 doubles per lane spilled) paid off
-// for multi-round batches at H = 10 / 16; with the column loop it loses everywhere (65 536 x h10: 1.27 vs 1.16 ms, 32 768 x h16: 2.12 vs 1.25 ms,
-// 16 384 x h20: 2.14 vs 0.75 ms; profiles/r02_setup_waves_probe.txt) and is no longer built.
-template <int H, int WAVES, bool UPD = false>   // UPD: the instantiation that also serves warm_start = 2 (see a1mpc_admm_kernel)
-__global__ __launch_bounds__(64, WAVES) void a1mpc_setup_kernel(const KernelArgs a, double* __restrict__ prep) {
-    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    const int row = static_cast<int>(threadIdx.x) >> 4;
-    const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + row;
-    // the (alpha/beta, beta) table is read H times per Ruiz sweep: stage it in LDS behind the four rows' regions
-    double* tabl = a1mpc_lds + 4 * LayoutSetup<H>::ROW_STRIDE;
-    for (int i = static_cast<int>(threadIdx.x); i < 2 * H * H; i += 64) tabl[i] = a.tab[i];
-    __syncthreads();
-    if (b >= a.n) return;
-    setup_row<H, false, UPD>(a, tabl, b, a1mpc_lds + row * LayoutSetup<H>::ROW_STRIDE, prep);
-}
-// K2: persistent rows; grid = resident workgroups; every row drains the queue of prepared QPs.
-#ifdef A1X_NOTWIN
-constexpr bool admm_twin_rows(int, int) { return false; }
-#else
-constexpr bool admm_twin_rows(int h, int rows) { return twin_rows(h, kModeMpc, rows); }
-#endif  // the wavefront's spare rows run as twins (RowSolver<.., TWIN>)
-// UPD: the instantiation that also serves warm_start = 2 (the reference's update path); every other mode runs UPD = false, whose code is what it was before
-// the update path existed (the allocation of the hot loop is sensitive to anything around it: a1mpc_solver.hpp, load_prepared)
-// UNI: contacts broadcast over the horizon (contact_stride = 0): one pair of bounds for every slot (RowSolver<.., UNI>; built for H >= 16, where the registers matter)
-// CLK: the profiling instantiation (a1mpc_set_profiling): shader-clock stamps around factor passes / iteration segments / residual checks, outside the hot loop
-// QUAD: one QP per wavefront and a horizon that is a multiple of 4 (H = 20; waves 1-3 of the CU-wide H = 16 kernel below): rows 1 and 3 do not idle, the four rows split
-// the per-lane state (RowSolver<.., QUAD>)
-constexpr bool quad_rows(int h, int rows) { return h == 20 && rows == 1 && admm_twin_rows(h, rows); }
-template <int H, int ROWS, bool UPD = false, bool UNI = false, bool CLK = false, bool QUAD = false>
-__global__ __launch_bounds__(64) void a1mpc_admm_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
-    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    // ROWS <= 2: the wavefront's other rows run as twins of the QP rows (rows r and r + 2 share a QP and its LDS image, see row_is_twin)
-    constexpr bool kTwin = admm_twin_rows(H, ROWS);
-    const int row = static_cast<int>(threadIdx.x) >> 4;
-    if constexpr (kTwin) {
-        if constexpr (QUAD) {
-            static_assert(quad_rows(H, ROWS), "a quad of rows: the wavefront's only QP");
-            admm_rows<H, true, false, UPD, UNI, CLK, true>(a, prep, counter, a1mpc_lds);
-            return;
-        }
-        if ((row & 1) >= ROWS) return;  // ROWS = 1: rows 1 and 3 have no QP
-        admm_rows<H, true, false, UPD, UNI, CLK>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H>::ROW_STRIDE);
-    } else {
-        admm_rows<H, false, false, UPD, UNI, CLK>(a, prep, counter, a1mpc_lds + row * Layout<H>::ROW_STRIDE);
-    }
-}
-
-// K2, CU-wide (round 4): ONE workgroup of four wavefronts owns a CU's whole LDS.  At H = 16 an image is 32.2 KB: five fit in 160 KB, but an ADMM wave needs a
-// whole SIMD's register file, so with one-wave workgroups of one QP each the fifth image has no wave to serve it and rows 1 and 3 of every wave idle.  Here
-// wave 0 carries TWO QPs (main / twin pairs on rows (0,2) and (1,3), exactly the H = 10 arrangement) and waves 1-3 one each: five QPs per CU instead of four.
-// Rows still refill from the queue independently and nothing is shared between the waves (no workgroup barrier anywhere in admm_rows): the only coupling is
-// that wave 0's two QPs wait for each other's factor passes, as every pair of H = 10 does.
-constexpr int cu_wide_qps(int h) { return h == 16 ? 5 : 0; }   // QPs of a CU-wide workgroup (0: this horizon has no such kernel -- H = 20: 40 KB per image, four per CU)
-// QUAD: waves 1-3 (one QP each) run their four rows as a quad (RowSolver<.., QUAD>); wave 0 keeps its two twin pairs
-template <int H, bool UPD = false, bool UNI = false, bool CLK = false, bool QUAD = false>
-__global__ __launch_bounds__(256) void a1mpc_admm_cu_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
-    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    static_assert(cu_wide_qps(H) == 5 && admm_twin_rows(H, 1), "five images: two on wave 0, one on each of waves 1-3");
-    const int wave = static_cast<int>(threadIdx.x) >> 6, row = (static_cast<int>(threadIdx.x) >> 4) & 3;
-    if constexpr (QUAD) {
-        static_assert(H % 4 == 0, "quads split the horizon in fours");
-        if (wave != 0) {
-            admm_rows<H, true, false, UPD, UNI, CLK, true>(a, prep, counter, a1mpc_lds + (wave + 1) * Layout<H>::ROW_STRIDE);
-            return;
-        }
-    }
-    if (wave != 0 && (row & 1)) return;  // waves 1-3: rows 1 and 3 have no QP
-    const int image = wave == 0 ? (row & 1) : wave + 1;
-    admm_rows<H, true, false, UPD, UNI, CLK>(a, prep, counter, a1mpc_lds + image * Layout<H>::ROW_STRIDE);
-}
-
-// The general path's own split pipeline (round 2, last step): the same two kernels over RowSolver<.., GEN = true>.  K1 holds the per-step table B~w_t
-// of four QPs (5.8 KB each at H = 10; T B~w_t stays in the registers of the lanes that own its columns -- round 5: four instead of two wavefronts per CU at H = 16); its record carries B~w_t to K2, whose rows rebuild the per-step tables of their LDS image from it.
-template <int H>
-__global__ __launch_bounds__(64, 1) void a1mpc_setup_gen_kernel(const KernelArgs a, double* __restrict__ prep) {
-    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    const int row = static_cast<int>(threadIdx.x) >> 4;
-    const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + row;
-    double* tabl = a1mpc_lds + 4 * LayoutSetup<H, true>::ROW_STRIDE;
-    for (int i = static_cast<int>(threadIdx.x); i < 2 * H * H; i += 64) tabl[i] = a.tab[i];
-    __syncthreads();
-    if (b >= a.n) return;
-    setup_row<H, true>(a, tabl, b, a1mpc_lds + row * LayoutSetup<H, true>::ROW_STRIDE, prep);
-}
-template <int H, int ROWS>
-__global__ __launch_bounds__(64) void a1mpc_admm_gen_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
-    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    static_assert(ROWS <= 2, "rows r and r + 2 of the wavefront share a QP (twin rows)");
-    if constexpr (fused_quad_rows(H, kModeMpc, ROWS)) {   // one QP per wavefront, horizon a multiple of 4: a quad of rows
-        admm_rows<H, true, true, false, false, false, true>(a, prep, counter, a1mpc_lds);
-        return;
-    }
-    const int row = static_cast<int>(threadIdx.x) >> 4;
-    if ((row & 1) >= ROWS) return;
-    admm_rows<H, true, true>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H, true>::ROW_STRIDE);
 }
 
 // K3: the next solve's queue order = this solve's QPs by decreasing cost (counting sort, one workgroup).  A batch of 1-4x the resident
@@ -291,6 +64,9 @@ __global__ __launch_bounds__(1024) void a1mpc_order_kernel(int n, const int32_t*
         order[atomicAdd(&hist[c < 0 ? 0 : (c > 255 ? 255 : c)], 1)] = i;
     }
 }
+void launch_order_kernel(int n, const int32_t* cost, int32_t* order, hipStream_t stream) { hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, n, cost, order); }
+void launch_predict_kernel(const KernelArgs& a, int H, hipStream_t stream) { hipLaunchKernelGGL(a1mpc_predict_kernel, dim3(static_cast<unsigned>((a.n + 255) / 256)), dim3(256), 0, stream, a, H); }
+
 
 // ---- debug / verification: the dense QP data the reference's ConvexMpc holds in its public members (hessian, gradient, lb, ub --
 // S/ConvexMpc.h:84-93, filled by calculate_qp_mats, S/ConvexMpc.cpp:158-245) materialised from the same inputs, per-step feet and
@@ -473,81 +249,11 @@ __global__ __launch_bounds__(256) void a1mpc_plan_kernel(const PlanArgs a) {
     ws.flush3(rel, ab, wo, a.rel, a.abs_, a.world);   // (the three [robot][12] outputs leave through the wave's LDS stage: WaveStage)
 }
 
-template <int H>
-constexpr size_t lds_bytes(int rows) { return sizeof(double) * rows * Layout<H>::ROW_STRIDE; }
-
-// QPs per wavefront.  LDS (not wave slots) bounds residency at 8 QPs per CU (H = 10) whatever the split, and a wave costs the same
-// issue slots with 2 or 4 live rows, so 2 rows x 4 waves per CU loses nothing and each row waits for only one neighbour's
-// factorisation passes (measured: +5 % at 4096 QPs, +4 % at 32768).  From H = 16 on LDS allows four QPs per CU at most: one QP (a main / twin pair of rows) per
-// wavefront then puts them on four SIMDs instead of two -- no more QPs in flight, but no row waits for a wave-mate's hand-over or factor pass any more and the LDS
-// conflicts between the two images go (8192 x h16 first solve 4.62 -> 4.41 ms, 16 384 x h20 10.35 -> 10.04 ms).  A1MPC_ROWS_PER_WG = 1 | 2 | 4 overrides.
-constexpr int default_rows_per_wg(int horizon) { return horizon >= 16 ? 1 : 2; }
-// The shipped build instantiates the kernels for the default rows per workgroup only (the other two layouts were measured and lost, above; every extra layout of
-// the H = 16 / 20 kernels costs a minute of compile time): the override is honoured by -DA1MPC_ALL_ROWS tuning builds.
-static int rows_per_wg(int horizon) {
-#ifndef A1MPC_ALL_ROWS
-    return default_rows_per_wg(horizon);
-#endif
-    static int r = [] {
-        const char* e = getenv("A1MPC_ROWS_PER_WG");
-        const int v = e ? atoi(e) : 0;
-        return (v == 1 || v == 2 || v == 4) ? v : 0;
-    }();
-    return r ? r : default_rows_per_wg(horizon);
-}
-
 thread_local std::string g_last_error;
-static a1mpc_status fail(a1mpc_status s, const std::string& msg) { g_last_error = msg; return s; }
-#define A1_HIP(call)                                                                                          \
-    do {                                                                                                      \
-        hipError_t e_ = (call);                                                                               \
-        if (e_ != hipSuccess) return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-// Pipeline choice.  A batch that fits the resident rows of the ADMM kernel runs the fused kernel (set-up + solve in one launch: every QP
-// starts at once, nothing to queue; measured 6 % faster than the split pair for 64 <= n <= 2048 at H = 10, equal at n = 1); larger batches
-// run the split pipeline (set-up kernel + persistent rows, +30 % at 4096).  A1MPC_PIPELINE=fused|split forces one.  The balance QP is always fused.
-static int pipeline_mode() {  // 0 = auto, 1 = always split, 2 = always fused
-    static int m = [] {
-        const char* e = getenv("A1MPC_PIPELINE");
-        if (e && !strcmp(e, "fused")) return 2;
-        if (e && !strcmp(e, "split")) return 1;
-        return 0;
-    }();
-    return m;
-}
-
-// Profiler ranges (the reference brackets its tick with stopwatches t1..t6, S/A1RobotControl.cpp:491-553).  With A1MPC_ROCTX=1 the launches of a solve are
-// bracketed by roctx ranges ("a1mpc set-up", "a1mpc order", "a1mpc admm", "a1mpc solve (fused)"; rocprofv3 --marker-trace shows them beside the kernel trace).
-// The roctx library is dlopen()ed on first use, never linked; without the variable, or without the library, a range is a no-op.
-struct RoctxApi {
-    int (*push)(const char*) = nullptr;
-    int (*pop)() = nullptr;
-    RoctxApi() {
-        const char* e = getenv("A1MPC_ROCTX");
-        if (!(e && !strcmp(e, "1"))) return;
-        void* lib = nullptr;
-        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
-            if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
-        if (!lib) return;
-        push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
-        pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
-        if (!push || !pop) push = nullptr, pop = nullptr;
-    }
-};
-static const RoctxApi& roctx() { static const RoctxApi api; return api; }
-struct RoctxRange {
-    bool on;
-    explicit RoctxRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
-    ~RoctxRange() { if (on) roctx().pop(); }
-    RoctxRange(const RoctxRange&) = delete;
-    RoctxRange& operator=(const RoctxRange&) = delete;
-};
-
-// per-device caches below (occupancy, attribute-set flags) are shared by every handle of the process: handles of different threads are independent (a1mpc.h), so they are guarded
-static std::mutex g_cache_mu;
+std::mutex g_cache_mu;
+thread_local bool g_clk_ran = false;
 // dynamic-LDS limit of a kernel, once per device and kernel
-static a1mpc_status set_lds_attr(const void* fn, size_t bytes) {
+a1mpc_status set_lds_attr(const void* fn, size_t bytes) {
     static std::vector<std::pair<const void*, int>> done;
     static std::mutex mu;   // handles of different threads may launch at the same time
     std::lock_guard<std::mutex> lock(mu);
@@ -558,197 +264,7 @@ static a1mpc_status set_lds_attr(const void* fn, size_t bytes) {
     done.emplace_back(fn, dev);
     return A1MPC_OK;
 }
-// workgroups of the persistent ADMM kernel that are resident at once on the current device (occupancy query, cached per device)
-template <int H, int ROWS>
-static a1mpc_status resident_workgroups(int* out) {
-    static int resident[64] = {};
-    int dev = 0;
-    A1_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) { *out = 512; return A1MPC_OK; }
-    std::lock_guard<std::mutex> lock(g_cache_mu);
-    if (!resident[dev]) {
-        const size_t lds2 = lds_bytes<H>(ROWS);
-        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, false, false, quad_rows(H, ROWS)>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(lds2)));
-        int per_cu = 0, cus = 0;
-        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, false, false, quad_rows(H, ROWS)>), admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS, lds2));
-        A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        resident[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
-    }
-    *out = resident[dev];
-    return A1MPC_OK;
-}
-// the CU-wide ADMM kernel (a1mpc_admm_cu_kernel; H = 16): one workgroup of 256 threads and five images per CU.  A1MPC_CU_WIDE=0 falls back to the one-wave kernels (A/B runs)
-static bool cu_wide_enabled() {
-    static const bool on = [] { const char* e = getenv("A1MPC_CU_WIDE"); return !(e && !strcmp(e, "0")); }();
-    return on;
-}
-// the quad-of-rows ADMM kernel (H = 20, broadcast contacts).  A1MPC_QUAD=0 falls back to the twin-pair kernel (A/B runs)
-static bool quad_enabled() {
-    static const bool on = [] { const char* e = getenv("A1MPC_QUAD"); return !(e && !strcmp(e, "0")); }();
-    return on;
-}
-// ... and the CU-wide kernel's waves 1-3 (H = 16).  A1MPC_CU_QUAD=0: twin pairs on every wave
-static bool cu_quad_enabled() {
-    static const bool on = [] { const char* e = getenv("A1MPC_CU_QUAD"); return !(e && !strcmp(e, "0")); }();
-    return on && quad_enabled();
-}
-template <int H>
-static a1mpc_status resident_cu_workgroups(int* out) {
-    static int resident[64] = {};
-    int dev = 0;
-    A1_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) { *out = 256; return A1MPC_OK; }
-    std::lock_guard<std::mutex> lock(g_cache_mu);
-    if (!resident[dev]) {
-        const size_t lds2 = lds_bytes<H>(cu_wide_qps(H));
-        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds2)));
-        int per_cu = 0, cus = 0;
-        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, false, false, true>), 256, lds2));
-        A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        resident[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
-    }
-    *out = resident[dev];
-    return A1MPC_OK;
-}
-template <int H>
-static a1mpc_status resident_rows(int* out) {
-    int wg = 0;
-    a1mpc_status st;
-#ifdef A1MPC_DEV_SLIM
-    st = resident_workgroups<H, default_rows_per_wg(H)>(&wg); *out = default_rows_per_wg(H) * wg;
-#else
-#ifdef A1MPC_ALL_ROWS
-    switch (rows_per_wg(H)) {
-        case 1: st = resident_workgroups<H, 1>(&wg); *out = wg; return st;
-        case 2: st = resident_workgroups<H, 2>(&wg); *out = 2 * wg; return st;
-    }
-    st = resident_workgroups<H, 4>(&wg); *out = 4 * wg;
-#else
-    st = resident_workgroups<H, default_rows_per_wg(H)>(&wg); *out = default_rows_per_wg(H) * wg;
-#endif
-#endif
-    return st;
-}
 
-// Did the launch just issued run a profiling (CLK) instantiation?  Set by the launch functions, read by solve_device_impl right after them (same thread): only then does
-// the handle's stage record describe the solve (a fallback kernel without stamps must not leave a stale or uninitialised record behind as "profiled").
-thread_local bool g_clk_ran = false;
-// horizons whose fused / latency kernels have a profiling instantiation (the closed-loop tick and the batch-1 tick of the headline horizon; every further horizon costs a minute of compile time)
-constexpr bool tick_clk_horizon(int h) { return h == 10; }
-
-template <int H, int ROWS>
-static a1mpc_status launch_split_rows(const KernelArgs& a, double* prep, int* counter, hipStream_t stream, hipEvent_t mid) {
-    const size_t lds2 = lds_bytes<H>(ROWS), lds1 = sizeof(double) * (4 * LayoutSetup<H>::ROW_STRIDE + 2 * H * H);
-    int res = 0;
-    if (a1mpc_status st = resident_workgroups<H, ROWS>(&res); st != A1MPC_OK) return st;
-    A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
-    bool upd_kernels = false;   // warm_start = 2: the update-path instantiations of the two kernels (H > 1, default rows per workgroup; same resources, a few more instructions around set-up and iteration 1)
-    constexpr bool kHasUpd = H > 1 && ROWS == default_rows_per_wg(H);
-    if constexpr (kHasUpd) upd_kernels = a.carry != nullptr;
-    {
-        RoctxRange range("a1mpc set-up");
-        if constexpr (kHasUpd) { if (upd_kernels) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1, true>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep); }
-        if (!upd_kernels) hipLaunchKernelGGL((a1mpc_setup_kernel<H, 1>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
-    }
-    A1_HIP(hipGetLastError());
-    // queue order of THIS solve, longest first: by the set-up kernel's cost guesses (predict: no history) or by the cost each QP had in the handle's previous
-    // solve of this batch size (the cost buffer still holds it; the ADMM kernel below overwrites it with this solve's).  Sorted here, in front of the kernel
-    // that needs it, not behind the solve that produced the costs: a one-workgroup kernel of 1024 threads behind a persistent kernel waits for a free CU, and
-    // with a second batch in flight on another stream (a1mpc_pipeline) that wait was ~0.5 ms per launch (kernel trace, profiles/r02_kernel_trace_overlap.json)
-    if (a.cost != nullptr && a.order != nullptr) {
-        RoctxRange range("a1mpc order");
-        hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, static_cast<int>(a.n), static_cast<const int32_t*>(a.cost),
-                           const_cast<int32_t*>(a.order));
-        A1_HIP(hipGetLastError());
-    }
-    if (mid) A1_HIP(hipEventRecord(mid, stream));  // stage split: formation + Ruiz (+ queue order) | factor + iterate
-    RoctxRange range_admm("a1mpc admm");
-    if constexpr (cu_wide_qps(H) > 0 && ROWS == default_rows_per_wg(H)) {
-        if (cu_wide_enabled()) {   // five QPs per CU: one 256-thread workgroup per CU (a1mpc_admm_cu_kernel)
-            constexpr int Q = cu_wide_qps(H);
-            const size_t ldsq = lds_bytes<H>(Q);
-            int resq = 0;
-            if (a1mpc_status st = resident_cu_workgroups<H>(&resq); st != A1MPC_OK) return st;
-            const int wantq = (a.n + Q - 1) / Q;
-            const dim3 gridq(static_cast<unsigned>(wantq < resq ? wantq : resq)), blockq(256);
-            if (a.clk != nullptr && a.carry == nullptr && a.contact_stride == 0) {   // profiling instantiation (of the kernel broadcast contacts run)
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, true, true, true>), ldsq); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, true, true, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
-                g_clk_ran = true;
-            } else if (a.carry != nullptr) {
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, true, false, false, true>), ldsq); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, true, false, false, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
-            } else if (a.contact_stride == 0 && cu_quad_enabled()) {
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, true, false, true>), ldsq); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, true, false, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
-            } else if (a.contact_stride == 0) {
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_cu_kernel<H, false, true>), ldsq); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
-            } else {
-                hipLaunchKernelGGL((a1mpc_admm_cu_kernel<H, false, false, false, true>), gridq, blockq, ldsq, stream, a, static_cast<const double*>(prep), counter);
-            }
-            A1_HIP(hipGetLastError());
-            return A1MPC_OK;
-        }
-    }
-    const int want = (a.n + ROWS - 1) / ROWS;
-    const dim3 grid(static_cast<unsigned>(want < res ? want : res)), block(admm_twin_rows(H, ROWS) ? 64 : 16 * ROWS);
-    if constexpr (kHasUpd) {
-        if (upd_kernels) {
-            if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, true, false, false, quad_rows(H, ROWS)>), lds2); st != A1MPC_OK) return st;
-            hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, true, false, false, quad_rows(H, ROWS)>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
-        }
-    }
-    // profiling instantiation (a1mpc_set_profiling; H > 1, default rows, no update path, broadcast contacts): the kernel of the default batches with clock stamps
-    if constexpr (H > 1 && ROWS == default_rows_per_wg(H) && admm_twin_rows(H, ROWS) && cu_wide_qps(H) == 0) {
-        if (a.clk != nullptr && !upd_kernels && a.contact_stride == 0) {
-            constexpr bool kUni = H >= 16;
-            if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, kUni, true, quad_rows(H, ROWS)>), lds2); st != A1MPC_OK) return st;
-            hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, kUni, true, quad_rows(H, ROWS)>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
-            A1_HIP(hipGetLastError());
-            g_clk_ran = true;
-            return A1MPC_OK;
-        }
-    }
-    bool uni_kernel = false;   // broadcast contacts at H >= 16: the instantiation with one pair of bounds for all slots
-    constexpr bool kHasUni = H >= 16 && ROWS == default_rows_per_wg(H) && admm_twin_rows(H, ROWS);
-    if constexpr (kHasUni) {
-        uni_kernel = !upd_kernels && a.contact_stride == 0;
-        bool quad = false;
-        if constexpr (quad_rows(H, ROWS)) quad = uni_kernel && quad_enabled();
-        if constexpr (quad_rows(H, ROWS)) {
-            if (quad) {
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, true, false, true>), lds2); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, true, false, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
-            }
-        }
-        if (uni_kernel && !quad) {
-            if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_admm_kernel<H, ROWS, false, true>), lds2); st != A1MPC_OK) return st;
-            hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, true>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
-        }
-    }
-    if (!upd_kernels && !uni_kernel) hipLaunchKernelGGL((a1mpc_admm_kernel<H, ROWS, false, false, false, quad_rows(H, ROWS)>), grid, block, lds2, stream, a, static_cast<const double*>(prep), counter);
-    A1_HIP(hipGetLastError());
-    return A1MPC_OK;
-}
-template <int H>
-static a1mpc_status launch_split(const KernelArgs& a, double* prep, int* counter, hipStream_t stream, hipEvent_t mid) {
-#ifdef A1MPC_DEV_SLIM  // kernel-tuning builds: the split pipeline of ONE horizon (-DA1MPC_DEV_SLIM: 10; -DA1MPC_DEV_SLIM=16 / =20), a minute or two instead of five to compile
-    return launch_split_rows<H, default_rows_per_wg(H)>(a, prep, counter, stream, mid);
-#else
-#ifdef A1MPC_ALL_ROWS
-    if (a.carry == nullptr) {   // (the update-path kernels exist for the default rows per workgroup only)
-        switch (rows_per_wg(H)) {
-            case 1: return launch_split_rows<H, 1>(a, prep, counter, stream, mid);
-            case 2: return launch_split_rows<H, 2>(a, prep, counter, stream, mid);
-        }
-        return launch_split_rows<H, 4>(a, prep, counter, stream, mid);
-    }
-#endif
-    return launch_split_rows<H, default_rows_per_wg(H)>(a, prep, counter, stream, mid);
-#endif
-}
 static size_t carry_stride(int horizon) {
     switch (horizon) {
         case 10: return Carry<10>::STRIDE;
@@ -766,141 +282,6 @@ static size_t prep_stride(int horizon) {
     }
     return 0;
 }
-
-template <int H, int MODE, int ROWS>
-static a1mpc_status launch_rows(const KernelArgs& a, hipStream_t stream) {
-    static bool attr_set[64] = {};
-    int dev = 0;
-    A1_HIP(hipGetDevice(&dev));
-    {
-        std::lock_guard<std::mutex> lock(g_cache_mu);
-        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE, ROWS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes<H>(ROWS))));
-            attr_set[dev] = true;
-        }
-    }
-    const unsigned grid = static_cast<unsigned>((a.n + ROWS - 1) / ROWS);
-    if constexpr (MODE == kModeMpc && tick_clk_horizon(H) && ROWS == default_rows_per_wg(H)) {
-        if (a.clk != nullptr && a.contact_stride == 0) {   // profiling instantiations (a1mpc_set_profiling): stage stamps of the whole tick, both warm-start semantics
-            const dim3 blk(twin_rows(H, MODE, ROWS) ? 64 : 16 * ROWS);
-            if (a.carry != nullptr) {
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE, ROWS, true, true>), lds_bytes<H>(ROWS)); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE, ROWS, true, true>), dim3(grid), blk, lds_bytes<H>(ROWS), stream, a);
-            } else {
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE, ROWS, false, true>), lds_bytes<H>(ROWS)); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE, ROWS, false, true>), dim3(grid), blk, lds_bytes<H>(ROWS), stream, a);
-            }
-            A1_HIP(hipGetLastError());
-            g_clk_ran = true;
-            return A1MPC_OK;
-        }
-    }
-    if constexpr (MODE == kModeMpc && H > 1 && ROWS == default_rows_per_wg(H)) {
-        if (a.carry != nullptr) {   // warm_start = 2: the update-path instantiation
-            if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_kernel<H, MODE, ROWS, true>), lds_bytes<H>(ROWS)); st != A1MPC_OK) return st;
-            hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE, ROWS, true>), dim3(grid), dim3(twin_rows(H, MODE, ROWS) ? 64 : 16 * ROWS), lds_bytes<H>(ROWS), stream, a);
-            A1_HIP(hipGetLastError());
-            return A1MPC_OK;
-        }
-    }
-    hipLaunchKernelGGL((a1mpc_solve_kernel<H, MODE, ROWS>), dim3(grid), dim3(twin_rows(H, MODE, ROWS) ? 64 : 16 * ROWS), lds_bytes<H>(ROWS), stream, a);
-    A1_HIP(hipGetLastError());
-    return A1MPC_OK;
-}
-static constexpr int kCoopMaxBatch = 256;  // at most this many QPs: one wavefront per QP during set-up (the chip has 1024 SIMDs)
-static int coop_max_batch() {   // A1MPC_COOP_MAX=n moves the limit (A/B runs: profiles/r05_latency_kernel_batch_limit.txt)
-    static const int v = [] { const char* e = getenv("A1MPC_COOP_MAX"); const int n = e ? atoi(e) : kCoopMaxBatch; return n > 0 ? n : kCoopMaxBatch; }();
-    return v;
-}
-static bool coop_setup_enabled() {   // A1MPC_COOP_SETUP=0: small batches through the fused kernels instead of the latency kernels (A/B runs)
-    static const bool on = [] { const char* e = getenv("A1MPC_COOP_SETUP"); return !(e && !strcmp(e, "0")); }();
-    return on;
-}
-template <int H, int ROWS>
-static a1mpc_status launch_gen_rows(const KernelArgs& a, hipStream_t stream) {
-    static bool attr_set[64] = {};
-    int dev = 0;
-    A1_HIP(hipGetDevice(&dev));
-    if constexpr (H % 4 != 0) {   // a handful of QPs at H = 10: one wavefront per QP, its four rows share the set-up (a1mpc_solve_gen_coop_kernel)
-        if (a.n <= coop_max_batch() && coop_setup_enabled()) {
-            const size_t lds1 = sizeof(double) * Layout<H, true>::ROW_STRIDE;
-            if (a.carry != nullptr) {
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_gen_coop_kernel<H, true>), lds1); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_solve_gen_coop_kernel<H, true>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds1, stream, a);
-            } else {
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_gen_coop_kernel<H, false>), lds1); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_solve_gen_coop_kernel<H, false>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds1, stream, a);
-            }
-            A1_HIP(hipGetLastError());
-            return A1MPC_OK;
-        }
-    }
-    const size_t lds = sizeof(double) * ROWS * Layout<H, true>::ROW_STRIDE;
-    {
-        std::lock_guard<std::mutex> lock(g_cache_mu);
-        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_gen_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds)));
-            attr_set[dev] = true;
-        }
-    }
-    if (a.carry != nullptr) {   // warm_start = 2: the update-path instantiation
-        if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_gen_kernel<H, ROWS, true>), lds); st != A1MPC_OK) return st;
-        hipLaunchKernelGGL((a1mpc_solve_gen_kernel<H, ROWS, true>), dim3(static_cast<unsigned>((a.n + ROWS - 1) / ROWS)), dim3(64), lds, stream, a);
-        A1_HIP(hipGetLastError());
-        return A1MPC_OK;
-    }
-    hipLaunchKernelGGL((a1mpc_solve_gen_kernel<H, ROWS>), dim3(static_cast<unsigned>((a.n + ROWS - 1) / ROWS)), dim3(64), lds, stream, a);
-    A1_HIP(hipGetLastError());
-    return A1MPC_OK;
-}
-// resident workgroups of the general path's ADMM kernel (occupancy query, cached per device)
-template <int H, int ROWS>
-static a1mpc_status resident_workgroups_gen(int* out) {
-    static int resident[64] = {};
-    int dev = 0;
-    A1_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return fail(A1MPC_ERR_HIP, "device index out of range");
-    std::lock_guard<std::mutex> lock(g_cache_mu);
-    if (!resident[dev]) {
-        const size_t lds = sizeof(double) * ROWS * Layout<H, true>::ROW_STRIDE;
-        A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_gen_kernel<H, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        int per_cu = 0, cus = 0;
-        A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_gen_kernel<H, ROWS>), 64, lds));
-        A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        resident[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
-    }
-    *out = resident[dev];
-    return A1MPC_OK;
-}
-// a batch beyond the resident rows: the general path's set-up kernel, the queue-order kernel, its persistent ADMM kernel
-template <int H, int ROWS>
-static a1mpc_status launch_gen_split_rows(const KernelArgs& a, double* prep, int* counter, hipStream_t stream, hipEvent_t mid, int res) {
-    static bool attr_set[64] = {};
-    int dev = 0;
-    A1_HIP(hipGetDevice(&dev));
-    const size_t lds1 = sizeof(double) * (4 * LayoutSetup<H, true>::ROW_STRIDE + 2 * H * H), lds2 = sizeof(double) * ROWS * Layout<H, true>::ROW_STRIDE;
-    {
-        std::lock_guard<std::mutex> lock(g_cache_mu);
-        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_setup_gen_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds1)));
-            attr_set[dev] = true;
-        }
-    }
-    A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
-    hipLaunchKernelGGL((a1mpc_setup_gen_kernel<H>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
-    A1_HIP(hipGetLastError());
-    if (a.cost != nullptr && a.order != nullptr) {   // (predicted or the previous solve's costs: see launch_split_rows)
-        hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, static_cast<int>(a.n), static_cast<const int32_t*>(a.cost), const_cast<int32_t*>(a.order));
-        A1_HIP(hipGetLastError());
-    }
-    if (mid) A1_HIP(hipEventRecord(mid, stream));
-    const int want = (a.n + ROWS - 1) / ROWS;
-    hipLaunchKernelGGL((a1mpc_admm_gen_kernel<H, ROWS>), dim3(static_cast<unsigned>(want < res ? want : res)), dim3(64), lds2, stream, a, static_cast<const double*>(prep), counter);
-    A1_HIP(hipGetLastError());
-    return A1MPC_OK;
-}
 static size_t prep_stride_gen(int horizon) {
     switch (horizon) {
         case 10: return Prep<10>::STRIDE_GEN;
@@ -914,89 +295,30 @@ static a1mpc_status resident_rows_gen(int horizon, int* rows) {
     int wg = 0;
     a1mpc_status st = A1MPC_OK;
     *rows = 0;
-#ifndef A1MPC_DEV_SLIM
     switch (horizon) {
         case 10: st = resident_workgroups_gen<10, 2>(&wg); *rows = 2 * wg; break;
         case 16: st = resident_workgroups_gen<16, 1>(&wg); *rows = wg; break;
         case 20: st = resident_workgroups_gen<20, 1>(&wg); *rows = wg; break;
     }
-#endif
     return st;
 }
 static a1mpc_status launch_gen_split(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s, hipEvent_t mid) {
     int wg = 0;
-#ifndef A1MPC_DEV_SLIM
     switch (horizon) {
         case 10: if (a1mpc_status st = resident_workgroups_gen<10, 2>(&wg); st != A1MPC_OK) return st; return launch_gen_split_rows<10, 2>(a, prep, counter, s, mid, wg);
         case 16: if (a1mpc_status st = resident_workgroups_gen<16, 1>(&wg); st != A1MPC_OK) return st; return launch_gen_split_rows<16, 1>(a, prep, counter, s, mid, wg);
         case 20: if (a1mpc_status st = resident_workgroups_gen<20, 1>(&wg); st != A1MPC_OK) return st; return launch_gen_split_rows<20, 1>(a, prep, counter, s, mid, wg);
     }
-#endif
     return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet / contact schedules need horizon 10, 16 or 20");
 }
 // LDS per QP: 25.2 KB (H = 10: six QPs per CU), 39.9 KB (H = 16: four, one per wavefront like the fast path's), 49.7 KB (H = 20: three, one row per workgroup)
 static a1mpc_status launch_gen(int horizon, const KernelArgs& a, hipStream_t s) {
-#ifndef A1MPC_DEV_SLIM
     switch (horizon) {
         case 10: return launch_gen_rows<10, 2>(a, s);
         case 16: return launch_gen_rows<16, 1>(a, s);
         case 20: return launch_gen_rows<20, 1>(a, s);
     }
-#endif
     return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet / contact schedules need horizon 10, 16 or 20");
-}
-template <int H>
-static a1mpc_status launch_coop(const KernelArgs& a, hipStream_t stream) {
-    static bool attr_set[64] = {};
-    int dev = 0;
-    A1_HIP(hipGetDevice(&dev));
-    {
-        std::lock_guard<std::mutex> lock(g_cache_mu);
-        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_solve_coop_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds_bytes<H>(1))));
-            attr_set[dev] = true;
-        }
-    }
-    if constexpr (tick_clk_horizon(H)) {
-        if (a.clk != nullptr && a.contact_stride == 0) {   // profiling instantiations (a1mpc_set_profiling)
-            if (a.carry != nullptr) {
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_coop_kernel<H, true, true>), lds_bytes<H>(1)); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_solve_coop_kernel<H, true, true>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds_bytes<H>(1), stream, a);
-            } else {
-                if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_coop_kernel<H, false, true>), lds_bytes<H>(1)); st != A1MPC_OK) return st;
-                hipLaunchKernelGGL((a1mpc_solve_coop_kernel<H, false, true>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds_bytes<H>(1), stream, a);
-            }
-            A1_HIP(hipGetLastError());
-            g_clk_ran = true;
-            return A1MPC_OK;
-        }
-    }
-    if (a.carry != nullptr) {   // warm_start = 2: the update-path instantiation
-        if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_coop_kernel<H, true>), lds_bytes<H>(1)); st != A1MPC_OK) return st;
-        hipLaunchKernelGGL((a1mpc_solve_coop_kernel<H, true>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds_bytes<H>(1), stream, a);
-        A1_HIP(hipGetLastError());
-        return A1MPC_OK;
-    }
-    hipLaunchKernelGGL((a1mpc_solve_coop_kernel<H>), dim3(static_cast<unsigned>(a.n)), dim3(64), lds_bytes<H>(1), stream, a);
-    A1_HIP(hipGetLastError());
-    return A1MPC_OK;
-}
-template <int H, int MODE>
-static a1mpc_status launch(const KernelArgs& a, hipStream_t stream) {
-    if constexpr (MODE == kModeMpc && H > 1) {
-        if (coop_setup_enabled() && a.n <= coop_max_batch()) return launch_coop<H>(a, stream);
-    }
-#ifdef A1MPC_ALL_ROWS
-    if (a.carry == nullptr) {   // (the update-path kernels exist for the default rows per workgroup only)
-        switch (rows_per_wg(H)) {
-            case 1: return launch_rows<H, MODE, 1>(a, stream);
-            case 2: return launch_rows<H, MODE, 2>(a, stream);
-        }
-        return launch_rows<H, MODE, 4>(a, stream);
-    }
-#endif
-    return launch_rows<H, MODE, default_rows_per_wg(H)>(a, stream);
 }
 
 static bool warm_fused_enabled() {
@@ -1020,14 +342,10 @@ static a1mpc_status use_split_pipeline(int horizon, int n, bool have_prep, bool*
     int rows = 0;
     a1mpc_status st = A1MPC_OK;
     switch (horizon) {
-#ifdef A1MPC_DEV_SLIM
-        case A1_SLIM_H: st = resident_rows<A1_SLIM_H>(&rows); break;
-#else
         case 10: st = resident_rows<10>(&rows); break;
         case 1: st = resident_rows<1>(&rows); break;
         case 16: st = resident_rows<16>(&rows); break;
         case 20: st = resident_rows<20>(&rows); break;
-#endif
         default: return A1MPC_OK;
     }
     *split = n > rows;
@@ -1038,50 +356,26 @@ static bool fused_queue_enabled() {
     static const bool on = [] { const char* e = getenv("A1MPC_FUSED_QUEUE"); return e && !strcmp(e, "1"); }();
     return on;
 }
-// the round-5 trial kernel (see a1mpc_solve_queue_kernel): h = 10, cold or warm_start = 1 batches beyond the resident rows, contacts broadcast
-static a1mpc_status launch_fused_queue(const KernelArgs& a, int* counter, hipStream_t stream) {
-    constexpr int H = 10, ROWS = 2;
-    int res = 0;
-    if (a1mpc_status st = resident_workgroups<H, ROWS>(&res); st != A1MPC_OK) return st;
-    if (a1mpc_status st = set_lds_attr(reinterpret_cast<const void*>(&a1mpc_solve_queue_kernel<H, kModeMpc, ROWS>), lds_bytes<H>(ROWS)); st != A1MPC_OK) return st;
-    A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
-    if (a.cost != nullptr && a.order != nullptr) {
-        if (a.predict) hipLaunchKernelGGL(a1mpc_predict_kernel, dim3(static_cast<unsigned>((a.n + 255) / 256)), dim3(256), 0, stream, a, H);
-        hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, static_cast<int>(a.n), static_cast<const int32_t*>(a.cost), const_cast<int32_t*>(a.order));
-    }
-    const int want = (a.n + ROWS - 1) / ROWS;
-    hipLaunchKernelGGL((a1mpc_solve_queue_kernel<H, kModeMpc, ROWS>), dim3(static_cast<unsigned>(want < res ? want : res)), dim3(64), lds_bytes<H>(ROWS), stream, a, counter);
-    A1_HIP(hipGetLastError());
-    return A1MPC_OK;
-}
 static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s, bool split, hipEvent_t mid) {
     RoctxRange range(split ? "a1mpc solve (split pipeline)" : "a1mpc solve (fused)");
-#ifndef A1MPC_DEV_SLIM
     if (split && counter && horizon == 10 && fused_queue_enabled() && a.carry == nullptr && a.clk == nullptr) {
         if (mid) A1_HIP(hipEventRecord(mid, s));
         return launch_fused_queue(a, counter, s);
     }
-#endif
     if (split && prep && counter) {
         switch (horizon) {
-#ifdef A1MPC_DEV_SLIM
-            case A1_SLIM_H: return launch_split<A1_SLIM_H>(a, prep, counter, s, mid);
-#else
             case 10: return launch_split<10>(a, prep, counter, s, mid);
             case 1: return launch_split<1>(a, prep, counter, s, mid);
             case 16: return launch_split<16>(a, prep, counter, s, mid);
             case 20: return launch_split<20>(a, prep, counter, s, mid);
-#endif
         }
     }
-#ifndef A1MPC_DEV_SLIM
     switch (horizon) {
         case 1: return launch<1, kModeMpc>(a, s);
         case 10: return launch<10, kModeMpc>(a, s);
         case 16: return launch<16, kModeMpc>(a, s);
         case 20: return launch<20, kModeMpc>(a, s);
     }
-#endif
     return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be 1, 10, 16 or 20");
 }
 static size_t lds_bytes_of(int horizon) {
@@ -2364,11 +1658,9 @@ const char* a1mpc_status_string(a1mpc_status s) {
 }
 const char* a1mpc_last_error(void) { return g_last_error.c_str(); }
 
-#ifndef A1MPC_SOURCE_HASH
-#define A1MPC_SOURCE_HASH "unknown"
-#endif
-// which sources this library is the compilation of (build.py: sha256 over csrc/ + include/a1mpc.h) -- a shipped .so is matched against the sources beside it
-const char* a1mpc_build_info(void) { return "sources " A1MPC_SOURCE_HASH " arch gfx950"; }
+// which sources this library is the compilation of (build.py: sha256 over csrc/ + include/a1mpc.h) -- a shipped .so is matched against the sources beside it.
+// The string lives in a unit of its own (a1mpc_build_id.cpp, compiled in a second): a change of any source re-stamps the library without recompiling this file.
+const char* a1mpc_build_info(void) { return a1mpc_build_id_; }
 
 void a1mpc_destroy(a1mpc_handle h) {
     if (!h) return;
@@ -3201,12 +2493,8 @@ a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_confi
     a.root_acc = h->d_aux; a.Rz = h->d_Rz; a.R = h->d_R; a.foot = h->d_foot; a.contact = h->d_contact;
     a.grf = h->d_grf; a.u_full = h->d_u; a.iters = h->d_iters; a.status = h->d_status; a.nfact = h->d_nfact;
     if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
-#ifdef A1MPC_DEV_SLIM
-    a1mpc_status st = fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "slim development build");
-#else
     h->staged = false;
     a1mpc_status st = launch<1, kModeBalance>(a, s);
-#endif
     if (st != A1MPC_OK) return st;
     if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
     h->timed = h->timing;

@@ -168,11 +168,11 @@ def dpp_coverage(path):
     return {k: sum(1 for b in blocks for (_, _, op, _) in b["instrs"] if "_dpp" in op and op.startswith("v_fmac_f64")) for k, blocks in _parse(path, "").items()}
 
 
-def coverage_gaps(paths, expected=None):
-    """list of messages: expected kernels that were not parsed, or parsed with too few DPP instructions"""
+def coverage_gaps(paths, expected=None, coverage=None):
+    """list of messages: expected kernels that were not parsed, or parsed with too few DPP instructions (`coverage`: the merged dpp_coverage() of every unit's listing)"""
     expected = EXPECTED_DPP if expected is None else expected
-    cov = {}
-    for p in paths:
+    cov = dict(coverage or {})
+    for p in paths or []:
         cov.update(dpp_coverage(p))
     out = []
     for key, least in expected.items():
@@ -181,4 +181,61 @@ def coverage_gaps(paths, expected=None):
             out.append(f"hazard check saw no kernel matching {key} (listing format changed?)")
         elif min(hits) < least:
             out.append(f"hazard check inspected only {min(hits)} v_fmac_f64_dpp in {key} (expected >= {least})")
+    return out
+
+
+# ---- code-object resources (round 6): registers, spills, scratch and LDS of every kernel, from the .amdgpu_metadata notes of the listing ----------------
+def kernel_resources(path):
+    """{mangled kernel name: {vgpr, agpr, sgpr, vgpr_spill, sgpr_spill, scratch_bytes, lds_static_bytes, scratch_instrs, scratch_instrs_in_loops}} of one gfx950 listing"""
+    import yaml
+    txt = open(path).read()
+    out = {}
+    for m in re.finditer(r"\.amdgpu_metadata\n(.*?)\n\s*\.end_amdgpu_metadata", txt, re.S):
+        doc = yaml.safe_load(m.group(1).replace("---", "", 1).rsplit("...", 1)[0])
+        for k in (doc or {}).get("amdhsa.kernels", []):
+            out[k[".name"]] = {"vgpr": k.get(".vgpr_count"), "agpr": k.get(".agpr_count"), "sgpr": k.get(".sgpr_count"), "vgpr_spill": k.get(".vgpr_spill_count", 0),
+                               "sgpr_spill": k.get(".sgpr_spill_count", 0), "scratch_bytes": k.get(".private_segment_fixed_size", 0), "lds_static_bytes": k.get(".group_segment_fixed_size", 0),
+                               "max_flat_workgroup_size": k.get(".max_flat_workgroup_size")}
+    # scratch traffic, and how much of it sits inside a loop (a block that a later block branches back to)
+    for kernel, blocks in _parse(path, "").items():
+        if kernel not in out:
+            continue
+        by_label = {b["label"]: i for i, b in enumerate(blocks) if b["label"]}
+        in_loop = [False] * len(blocks)
+        for i, b in enumerate(blocks):
+            for t in b["targets"]:
+                j = by_label.get(t)
+                if j is not None and j <= i:
+                    for k in range(j, i + 1):
+                        in_loop[k] = True
+        tot = loop = 0
+        for i, b in enumerate(blocks):
+            n = sum(1 for (_, _, op, _) in b["instrs"] if op.startswith("scratch_"))
+            tot += n
+            loop += n if in_loop[i] else 0
+        out[kernel]["scratch_instrs"] = tot
+        out[kernel]["scratch_instrs_in_loops"] = loop
+    return out
+
+
+# Kernels that must not touch scratch memory (a VGPR spilled to scratch in one of these is a performance bug the build refuses; `vgpr_spill_count` > 0 with 0 B of
+# scratch is a value parked in the AGPR half of the register file, which costs a v_accvgpr move and is accepted): the kernels the BASELINE configs run on the fast
+# path -- and, round 6, every kernel of the general path.  The A/B fallback instantiations behind environment switches (one-wave h = 16 kernels, the non-quad h = 20 kernel)
+# and the update-path / contact-schedule variants at h = 16 / 20 are reported in kernel_resources.json but not gated.
+NO_SCRATCH = ("a1mpc_admm_kernelILi10ELi2E", "a1mpc_admm_kernelILi20ELi1ELb0ELb1ELb0ELb1E", "a1mpc_admm_cu_kernelILi16ELb0ELb1ELb0ELb1E", "a1mpc_setup_kernelILi10E",
+              "a1mpc_setup_kernelILi16ELi1ELb0E", "a1mpc_setup_kernelILi20ELi1ELb0E", "a1mpc_solve_kernelILi10E", "a1mpc_solve_kernelILi16E", "a1mpc_solve_kernelILi20E",
+              "a1mpc_solve_coop_kernelILi")
+
+
+def resource_gaps(resources, no_scratch=None):
+    """list of messages: a kernel of NO_SCRATCH with scratch memory, or no kernel at all for one of its patterns (no fail-open)"""
+    no_scratch = NO_SCRATCH if no_scratch is None else no_scratch
+    out = []
+    for key in no_scratch:
+        hits = {k: v for k, v in resources.items() if key in k}
+        if not hits:
+            out.append(f"resource gate saw no kernel matching {key} (listing format changed?)")
+        for k, v in hits.items():
+            if (v.get("scratch_bytes") or 0) > 0:
+                out.append(f"{k[:90]}: {v.get('vgpr_spill')} spilled VGPRs, {v.get('scratch_bytes')} B of scratch per lane ({v.get('scratch_instrs_in_loops')} scratch instructions inside loops)")
     return out
