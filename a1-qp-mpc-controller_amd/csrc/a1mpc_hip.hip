@@ -2426,6 +2426,34 @@ a1mpc_status a1mpc_solve_batch_strided_device(a1mpc_handle h, int32_t n, const d
     return solve_device_impl(h, n, nullptr, d_x0, d_x_ref, d_R_world, d_foot_abs, d_contact, d_grf_body_out, d_u_full_out, d_iters_out,
                              d_status_out, hip_stream, foot_stride, contact_stride, d_yaw_A);
 }
+// The host-pointer strided entry in two halves, like host_submit / host_collect (a pipeline slot leaves the batch in flight: a1mpc_pipeline_submit_strided).
+// strided_host_submit: the caller's arrays are snapshotted by pageable H2D copies on the handle's stream (synchronous w.r.t. the host buffers), the launches and ONE
+// D2H copy into the handle's pinned mirror are queued; host_collect hands the mirror to the caller's arrays once the stream has drained.
+static a1mpc_status strided_host_submit(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world, const double* foot_abs, int32_t foot_stride,
+                                        const uint8_t* contact, int32_t contact_stride, const double* yaw_A, bool want_u) {
+    A1_HIP(hipSetDevice(h->device));
+    const size_t N = n, H = h->cfg.horizon, nfoot = foot_stride ? 12 * H : 12, ncont = contact_stride ? 4 * H : 4;
+    hipStream_t s = h->stream;
+    A1_ORDER(h, s);
+    if (!h->d_foot_steps) {
+        A1_HIP(hipMalloc(&h->d_foot_steps, static_cast<size_t>(h->max_batch) * 12 * H * sizeof(double)));
+        A1_HIP(hipMalloc(&h->d_contact_steps, static_cast<size_t>(h->max_batch) * 4 * H));
+    }
+    A1_HIP(hipMemcpyAsync(h->d_x0, x0, N * 13 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_xref, x_ref, N * 13 * H * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_R, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_foot_steps, foot_abs, N * nfoot * sizeof(double), hipMemcpyHostToDevice, s));
+    A1_HIP(hipMemcpyAsync(h->d_contact_steps, contact, N * ncont, hipMemcpyHostToDevice, s));
+    if (yaw_A) A1_HIP(hipMemcpyAsync(h->d_aux, yaw_A, N * sizeof(double), hipMemcpyHostToDevice, s));  // d_aux: n x 6 doubles of balance-QP staging, free here
+    const HostOut q = host_out_layout(N);
+    const size_t out_bytes = want_u ? q.q_u + N * 12 * H * sizeof(double) : q.q_u;
+    a1mpc_status st = solve_device_impl(h, n, nullptr, h->d_x0, h->d_xref, h->d_R, h->d_foot_steps, h->d_contact_steps, reinterpret_cast<double*>(h->d_out + q.q_grf),
+                                        want_u ? reinterpret_cast<double*>(h->d_out + q.q_u) : nullptr, reinterpret_cast<int32_t*>(h->d_out + q.q_it),
+                                        reinterpret_cast<int32_t*>(h->d_out + q.q_st), s, foot_stride, contact_stride, yaw_A ? h->d_aux : nullptr);
+    if (st != A1MPC_OK) return st;
+    A1_HIP(hipMemcpyAsync(h->h_pin + h->h_pin_in_bytes, h->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    return A1MPC_OK;
+}
 a1mpc_status a1mpc_solve_batch_strided(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
                                        const double* foot_abs, int32_t foot_stride, const uint8_t* contact, int32_t contact_stride,
                                        const double* yaw_A, double* grf_body_out, double* u_full_out, int32_t* iters_out, int32_t* status_out) {
@@ -2437,32 +2465,11 @@ a1mpc_status a1mpc_solve_batch_strided(a1mpc_handle h, int32_t n, const double* 
         return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
     if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
     if (n == 0) return A1MPC_OK;
-    A1_HIP(hipSetDevice(h->device));
-    const size_t N = n, H = h->cfg.horizon, nfoot = foot_stride ? 12 * H : 12, ncont = contact_stride ? 4 * H : 4;
-    hipStream_t s = h->stream;
-    A1_ORDER(h, s);
-    if (!h->d_foot_steps) {
-        A1_HIP(hipMalloc(&h->d_foot_steps, static_cast<size_t>(h->max_batch) * 12 * H * sizeof(double)));
-        A1_HIP(hipMalloc(&h->d_contact_steps, static_cast<size_t>(h->max_batch) * 4 * H));
-    }
-    // pageable copies on the stream are synchronous w.r.t. the host buffers: the caller's arrays are snapshotted when each call returns
-    A1_HIP(hipMemcpyAsync(h->d_x0, x0, N * 13 * sizeof(double), hipMemcpyHostToDevice, s));
-    A1_HIP(hipMemcpyAsync(h->d_xref, x_ref, N * 13 * H * sizeof(double), hipMemcpyHostToDevice, s));
-    A1_HIP(hipMemcpyAsync(h->d_R, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
-    A1_HIP(hipMemcpyAsync(h->d_foot_steps, foot_abs, N * nfoot * sizeof(double), hipMemcpyHostToDevice, s));
-    A1_HIP(hipMemcpyAsync(h->d_contact_steps, contact, N * ncont, hipMemcpyHostToDevice, s));
-    if (yaw_A) A1_HIP(hipMemcpyAsync(h->d_aux, yaw_A, N * sizeof(double), hipMemcpyHostToDevice, s));  // d_aux: n x 6 doubles of balance-QP staging, free here
-    a1mpc_status st = solve_device_impl(h, n, nullptr, h->d_x0, h->d_xref, h->d_R, h->d_foot_steps, h->d_contact_steps, h->d_grf,
-                                        u_full_out ? h->d_u : nullptr, h->d_iters, h->d_status, s, foot_stride, contact_stride, yaw_A ? h->d_aux : nullptr);
-    if (st != A1MPC_OK) return st;
-    A1_HIP(hipMemcpyAsync(grf_body_out, h->d_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (u_full_out) A1_HIP(hipMemcpyAsync(u_full_out, h->d_u, N * 12 * H * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (iters_out) A1_HIP(hipMemcpyAsync(iters_out, h->d_iters, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (status_out) A1_HIP(hipMemcpyAsync(status_out, h->d_status, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    A1_HIP(hipStreamSynchronize(s));
+    if (a1mpc_status st = strided_host_submit(h, n, x0, x_ref, R_world, foot_abs, foot_stride, contact, contact_stride, yaw_A, u_full_out != nullptr); st != A1MPC_OK) return st;
+    A1_HIP(hipStreamSynchronize(h->stream));
+    host_collect(h, n, grf_body_out, u_full_out, iters_out, status_out);
     return A1MPC_OK;
 }
-
 a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_config* qp, int32_t n, const double* root_acc,
                                        const double* R_world, const double* R_z, const double* foot_abs, const uint8_t* contact,
                                        double* grf_body_out, double* f_world_out, int32_t* iters_out, int32_t* status_out) {
@@ -2914,6 +2921,77 @@ a1mpc_status a1mpc_pipeline_submit_device(a1mpc_pipeline p, int32_t slot, int32_
     p->used[k] = 1;
     if (slot < 0) p->next = (p->next + 1) % p->depth;
     if (slot_out) *slot_out = k;
+    return A1MPC_OK;
+}
+
+// Round 6: the general path -- per-step feet / contact schedules / its own A_c yaw (S/ConvexMpc.h:74, S/test/test_mpc.cpp:106-122) -- and the compact tick
+// records (S/A1RobotControl.cpp:452-488) with two batches in flight.  A first solve of the general path is PURELY tail-bound (its queue order is unpredictable:
+// profiles/r05_general_path_order.txt), which is exactly the loss a second batch in flight hides.  Same slots, same events; the solve is the lone handle's, bit for bit.
+static a1mpc_status pipeline_submit_device_impl(a1mpc_pipeline p, int32_t slot, int32_t fresh_batch, int32_t n, const double* d_tick, const double* d_x0, const double* d_x_ref,
+                                                const double* d_R_world, const double* d_foot_abs, int32_t foot_stride, const uint8_t* d_contact, int32_t contact_stride,
+                                                const double* d_yaw_A, double* d_grf_body_out, double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out,
+                                                void* inputs_ready_stream, int32_t* slot_out) {
+    if (!p) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (slot >= p->depth) return fail(A1MPC_ERR_INVALID_ARGUMENT, "slot out of range");
+    if (!d_tick && (!d_x0 || !d_x_ref)) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (!strides_ok(foot_stride, contact_stride)) return fail(A1MPC_ERR_INVALID_ARGUMENT, "foot_stride must be 0 or 12, contact_stride 0 or 4");
+    const int k = slot >= 0 ? slot : p->next;
+    a1mpc_handle h = p->h[k];
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_pipeline_create");
+    A1_HIP(hipSetDevice(p->device));
+    if (a1mpc_status sd = pipeline_deliver(p, k); sd != A1MPC_OK) return sd;
+    if (inputs_ready_stream) {   // the slot's stream starts after everything the caller has queued on that stream so far
+        A1_HIP(hipEventRecord(p->ready[k], static_cast<hipStream_t>(inputs_ready_stream)));
+        A1_HIP(hipStreamWaitEvent(h->stream, p->ready[k], 0));
+    }
+    if (fresh_batch) h->hint_n = 0;
+    if (a1mpc_status st = solve_device_impl(h, n, d_tick, d_x0, d_x_ref, d_R_world, d_foot_abs, d_contact, d_grf_body_out, d_u_full_out, d_iters_out,
+                                            d_status_out, h->stream, foot_stride, contact_stride, d_yaw_A); st != A1MPC_OK) return st;
+    A1_HIP(hipEventRecord(p->done[k], h->stream));
+    p->used[k] = 1;
+    if (slot < 0) p->next = (p->next + 1) % p->depth;
+    if (slot_out) *slot_out = k;
+    return A1MPC_OK;
+}
+a1mpc_status a1mpc_pipeline_submit_strided_device(a1mpc_pipeline p, int32_t slot, int32_t fresh_batch, int32_t n, const double* d_x0, const double* d_x_ref,
+                                                  const double* d_R_world, const double* d_foot_abs, int32_t foot_stride, const uint8_t* d_contact,
+                                                  int32_t contact_stride, const double* d_yaw_A, double* d_grf_body_out, double* d_u_full_out,
+                                                  int32_t* d_iters_out, int32_t* d_status_out, void* inputs_ready_stream, int32_t* slot_out) {
+    return pipeline_submit_device_impl(p, slot, fresh_batch, n, nullptr, d_x0, d_x_ref, d_R_world, d_foot_abs, foot_stride, d_contact, contact_stride, d_yaw_A, d_grf_body_out,
+                                       d_u_full_out, d_iters_out, d_status_out, inputs_ready_stream, slot_out);
+}
+a1mpc_status a1mpc_pipeline_submit_ticks_device(a1mpc_pipeline p, int32_t slot, int32_t fresh_batch, int32_t n, const double* d_tick, const double* d_R_world,
+                                                const double* d_foot_abs, const uint8_t* d_contact, double* d_grf_body_out, double* d_u_full_out,
+                                                int32_t* d_iters_out, int32_t* d_status_out, void* inputs_ready_stream, int32_t* slot_out) {
+    if (!d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    return pipeline_submit_device_impl(p, slot, fresh_batch, n, d_tick, nullptr, nullptr, d_R_world, d_foot_abs, 0, d_contact, 0, nullptr, d_grf_body_out,
+                                       d_u_full_out, d_iters_out, d_status_out, inputs_ready_stream, slot_out);
+}
+// ... and host arrays in / out (what a caller on the reference's side of the boundary holds): snapshot + launches queued on the slot's stream, outputs handed over by
+// a1mpc_pipeline_wait / the next submit to the slot
+a1mpc_status a1mpc_pipeline_submit_strided(a1mpc_pipeline p, int32_t slot, int32_t fresh_batch, int32_t n, const double* x0, const double* x_ref, const double* R_world,
+                                           const double* foot_abs, int32_t foot_stride, const uint8_t* contact, int32_t contact_stride, const double* yaw_A,
+                                           double* grf_body_out, double* u_full_out, int32_t* iters_out, int32_t* status_out, int32_t* slot_out) {
+    if (!strides_ok(foot_stride, contact_stride)) return fail(A1MPC_ERR_INVALID_ARGUMENT, "foot_stride must be 0 or 12, contact_stride 0 or 4");
+    if (foot_stride == 0 && contact_stride == 0 && !yaw_A)   // (0, 0, NULL) IS a1mpc_pipeline_submit
+        return a1mpc_pipeline_submit(p, slot, fresh_batch, n, x0, x_ref, R_world, foot_abs, contact, grf_body_out, u_full_out, iters_out, status_out, slot_out);
+    if (!p) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null pipeline");
+    if (slot >= p->depth) return fail(A1MPC_ERR_INVALID_ARGUMENT, "slot out of range");
+    if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !grf_body_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    const int k = slot >= 0 ? slot : p->next;
+    a1mpc_handle h = p->h[k];
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_pipeline_create");
+    A1_HIP(hipSetDevice(p->device));
+    if (a1mpc_status sd = pipeline_deliver(p, k); sd != A1MPC_OK) return sd;   // the slot's previous batch leaves its pinned mirror first
+    if (slot_out) *slot_out = k;
+    if (slot < 0) p->next = (p->next + 1) % p->depth;
+    if (n == 0) return A1MPC_OK;
+    if (fresh_batch) h->hint_n = 0;
+    if (a1mpc_status st = strided_host_submit(h, n, x0, x_ref, R_world, foot_abs, foot_stride, contact, contact_stride, yaw_A, u_full_out != nullptr); st != A1MPC_OK) return st;
+    A1_HIP(hipEventRecord(p->done[k], h->stream));
+    p->used[k] = 1;
+    a1mpc_pipeline_s::HostPending& q = p->pending[k];
+    q.n = n; q.grf = grf_body_out; q.u = u_full_out; q.iters = iters_out; q.status = status_out;
     return A1MPC_OK;
 }
 

@@ -197,15 +197,16 @@ __global__ __launch_bounds__(256) void a1mpc_admm_cu_kernel(const KernelArgs a, 
 // The general path's own split pipeline (round 2, last step): the same two kernels over RowSolver<.., GEN = true>.  K1 holds the per-step table B~w_t
 // of four QPs (5.8 KB each at H = 10; T B~w_t stays in the registers of the lanes that own its columns -- round 5: four instead of two wavefronts per CU at H = 16); its record carries B~w_t to K2, whose rows rebuild the per-step tables of their LDS image from it.
 template <int H>
-__global__ __launch_bounds__(64, 1) void a1mpc_setup_gen_kernel(const KernelArgs a, double* __restrict__ prep) {
+__global__ __launch_bounds__(64, 2) void a1mpc_setup_gen_kernel(const KernelArgs a, double* __restrict__ prep) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
-    const int row = static_cast<int>(threadIdx.x) >> 4;
-    const int64_t b = static_cast<int64_t>(blockIdx.x) * 4 + row;
-    double* tabl = a1mpc_lds + 4 * LayoutSetup<H, true>::ROW_STRIDE;
+    constexpr int QPW = 4 / setup_gen_rows(H);                // QPs per wavefront: 2 (rows q and q + 2 share QP q) or 1 (all four rows)
+    const int q = QPW == 2 ? (static_cast<int>(threadIdx.x) >> 4) & 1 : 0;
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * QPW + q;
+    double* tabl = a1mpc_lds + QPW * LayoutSetup<H, true>::ROW_STRIDE;
     for (int i = static_cast<int>(threadIdx.x); i < 2 * H * H; i += 64) tabl[i] = a.tab[i];
     __syncthreads();
-    if (b >= a.n) return;
-    setup_row<H, true>(a, tabl, b, a1mpc_lds + row * LayoutSetup<H, true>::ROW_STRIDE, prep);
+    if (b >= a.n) return;   // (both rows of the pair leave together)
+    setup_row<H, true>(a, tabl, b, a1mpc_lds + q * LayoutSetup<H, true>::ROW_STRIDE, prep);
 }
 template <int H, int ROWS>
 __global__ __launch_bounds__(64) void a1mpc_admm_gen_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
@@ -487,7 +488,8 @@ a1mpc_status launch_gen_split_rows(const KernelArgs& a, double* prep, int* count
     static bool attr_set[64] = {};
     int dev = 0;
     A1_HIP(hipGetDevice(&dev));
-    const size_t lds1 = sizeof(double) * (4 * LayoutSetup<H, true>::ROW_STRIDE + 2 * H * H), lds2 = sizeof(double) * ROWS * Layout<H, true>::ROW_STRIDE;
+    constexpr int QPW = 4 / setup_gen_rows(H);   // QPs per wavefront of the set-up kernel
+    const size_t lds1 = sizeof(double) * (QPW * LayoutSetup<H, true>::ROW_STRIDE + 2 * H * H), lds2 = sizeof(double) * ROWS * Layout<H, true>::ROW_STRIDE;
     {
         std::lock_guard<std::mutex> lock(g_cache_mu);
         if (dev >= 0 && dev < 64 && !attr_set[dev]) {
@@ -496,7 +498,7 @@ a1mpc_status launch_gen_split_rows(const KernelArgs& a, double* prep, int* count
         }
     }
     A1_HIP(hipMemsetAsync(counter, 0, sizeof(int), stream));
-    hipLaunchKernelGGL((a1mpc_setup_gen_kernel<H>), dim3(static_cast<unsigned>((a.n + 3) / 4)), dim3(64), lds1, stream, a, prep);
+    hipLaunchKernelGGL((a1mpc_setup_gen_kernel<H>), dim3(static_cast<unsigned>((a.n + QPW - 1) / QPW)), dim3(64), lds1, stream, a, prep);
     A1_HIP(hipGetLastError());
     if (a.cost != nullptr && a.order != nullptr) {   // (predicted or the previous solve's costs: see launch_split_rows)
         launch_order_kernel(static_cast<int>(a.n), static_cast<const int32_t*>(a.cost), const_cast<int32_t*>(a.order), stream);

@@ -284,12 +284,15 @@ struct Layout {
     // set-up-only aliases inside the factor region (the factor is written after Ruiz is finished)
     static constexpr int TBL = 0;            // T*B~_omega (3x12)
     static constexpr int DL = 36;            // D table of the current Ruiz pass, [t][12]
-    static constexpr int TBW = DL + 12 * H;  // GEN: [t][3][12] = T*B~_omega of step t
-    static constexpr int COOP = TBW + (GEN ? 36 * H : 0);  // [row][s][16 lanes] partial column maxima of a set-up shared by several rows of a wave (RowSolver::coop_n)
+    static constexpr int GQT = DL + 12 * H;  // GEN: [t][12] the gradient the cost normalisation of the Ruiz passes sees (this tick's; on the update path the previous tick's)
+    static constexpr int FT = GQT + (GEN ? 12 * H : 0);    // GEN: [t][12] the foot positions of step t (3 x 4, column-major like the input): the Ruiz sweeps evaluate a block entry as a cross product with them
+    static constexpr int COOP = FT + (GEN ? 12 * H : 0);   // [row][s][16 lanes] partial column maxima of a set-up shared by several rows of a wave (RowSolver::coop_n)
+    static constexpr int ML = COOP;          // GEN: [t][12] the column maxima m_t of a Ruiz pass, each written by the row that owns horizon step t (RowSolver::setup, general path)
     static constexpr int E0X = COOP + 4 * H * 16;          // [t][16 lanes]: the rows of a shared set-up hand each other the E of their own horizon steps, once, behind the last Ruiz pass
     static constexpr int TAB = E0X + H * 16;               // [s][t][2] = (alpha_st / beta_st, beta_st): the fused / latency kernels stage the batch's table here (stage_table), where a
                                                            // column of it is one LDS round trip away instead of one global-memory round trip per column of every Ruiz sweep
     static_assert(TAB + 2 * H * H <= COOP + 8 * H * 16, "the table fits behind the E hand-over");
+    static_assert(ML + 12 * H <= E0X, "the general path's column maxima sit in front of the E hand-over");
     static_assert(COOP + 8 * H * 16 <= H * SLOT || H == 1, "alias");
     // row stride mod 32 in {4,10,16,22,28}: the two QPs that share a 32-lane LDS phase then read the stride-13 rows of K_t
     // from disjoint banks; even, so that 16-byte alignment survives.  H = 10: 2544 doubles = 20,352 B per QP -> eight QPs
@@ -310,15 +313,17 @@ struct LayoutSetup {
     static constexpr int KSTR = 13, K_SZ = 12 * KSTR, S_SZ = 78, SLOT = K_SZ + S_SZ, FAC = 0, GCOL = 12;  // unused by the set-up code paths
     static constexpr int TBL = 0;
     static constexpr int DL = 36;
-    static constexpr int TBW = DL + 12 * H;                  // (GEN: T*B~_omega of step t lives in registers here, RowSolver::setup `tbwr`)
-    static constexpr int COOP = 0, E0X = 0, TAB = 0;  // never used by the set-up kernels (one row per QP; the kernel stages the table behind the rows' images itself)
+    static constexpr int FT = DL + 12 * H;                   // GEN: [t][12] the foot positions of step t (see Layout)
+    static constexpr int GQT = 0;                            // (the general path's set-up kernel has no update-path instantiation: never read)
+    static constexpr int ML = FT + (GEN ? 12 * H : 0);       // GEN: [t][12] the column maxima of a Ruiz pass, written by the row that owns step t
+    static constexpr int E0X = ML;                           // GEN: [t][16 lanes] the E hand-over behind the last pass (the maxima are dead by then)
+    static constexpr int COOP = 0, TAB = 0;           // never used by the set-up kernels (the fast path's: one row per QP; the kernels stage the table behind the rows' images themselves)
     static constexpr int CUV = 0, LBT = 0, UBT = 0;          // (not written by a set-up-only solver)
-    static constexpr int BL = TBW;
+    static constexpr int BL = ML + (GEN ? 16 * H : 0);
     static constexpr int ZROW = 6;
     static constexpr int CG = BL + 84;
-    static constexpr int BW = CG + (GEN ? 0 : 12 * H);       // GEN: [t][3][12] = the omega rows of B~_t (and no CG table: c g goes from registers into the record, RowSolver::cgr -- four
-                                                             // four-QP workgroups of the general path's set-up kernel per CU at H = 20: 4 x 1080 doubles + the table = 40 KB each)
-    static constexpr int RAW = BW + (GEN ? 36 * H : 0);
+    static constexpr int BW = 0;                             // (no table of the omega rows of B~_t: the general path's set-up kernel writes them into the record and recomputes them, RowSolver::setup)
+    static constexpr int RAW = CG + 12 * H;                  // GEN: 120 + 52 H doubles per QP (1160 = 9.3 KB at H = 20)
     static constexpr int ROW_STRIDE = RAW + (RAW % 2);
 };
 
@@ -443,7 +448,7 @@ struct RowSolver {
     long long pfX = 0, pfT = 0, pfU = 0;  // CLK: shader-clock cycles this QP spent in factor passes / iteration segments / residual checks (wave-mates' stalls included)
     long long ckF = 0, ckR = 0;           // CLK, set-up: shader clock behind the formation (inputs, B~, gradient, U / V) and behind the Ruiz passes (a1mpc_last_tick_stage_cycles)
     int pred_cost = 0;  // set-up's guess of this QP's cost (queue order of a first solve, see predict_cost)
-    [[maybe_unused]] double cgr[(SETUP_ONLY && GEN) ? H : 1];   // the general path's set-up kernel: c g of my lane per step on its way into the hand-off record (its LDS image has no CG table)
+    double* gen_rec = nullptr;   // general path, set-up kernel: this QP's hand-off record -- the per-step columns of B~w_t go straight into it (its LDS image has no table for them)
     struct Info {
         double pri_res, dua_res, nEz, nEAx, nDq, nDAty, nDPx;  // unscaled
         double s_pri, s_dua, s_z, s_Ax, s_q, s_Aty, s_Px;      // scaled (rho estimate)
@@ -542,6 +547,16 @@ struct RowSolver {
         if constexpr (GEN) return (wl && quad == 2) ? lds + L::BW + (t * 3 + (ci - 6)) * 12 : brow;
         else return brow;
     }
+    // my column (leg, comp) of the omega rows of B~ for a foot at r: dt * Iw^-1 * skew(r)[:, comp]  (S/ConvexMpc.cpp:138,151; Ii = Iw^-1 row-major).  No contraction left to the
+    // compiler: the general path evaluates this in several places and every copy must round alike
+    A1_DEV void bw_from_foot(const double (&Ii)[9], double rx, double ry, double rz, double (&o)[3]) const {
+#pragma clang fp contract(off)
+        const double k0 = comp == 0 ? 0.0 : (comp == 1 ? -rz : ry);   // column `comp` of skew(r) (S/utils/Utils.cpp:35-41)
+        const double k1 = comp == 0 ? rz : (comp == 1 ? 0.0 : -rx);
+        const double k2 = comp == 0 ? -ry : (comp == 1 ? rx : 0.0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] = (Ii[k * 3 + 0] * k0 + Ii[k * 3 + 1] * k1 + Ii[k * 3 + 2] * k2) * dt;
+    }
     A1_DEV void bounds_from_contact(double cf) {
         lo_u = P.fz_min * cf; hi_u = P.fz_max * cf;
         // physical bounds of my two rows: slot 0 = [fx+mu fz >= 0 | fy+mu fz >= 0 | fz in [lo,hi]], slot 1 = [.. <= 0]
@@ -551,7 +566,9 @@ struct RowSolver {
     // ================================================================================ set-up: formation + Ruiz + hot state
     // UPD = false: an instantiation without the update path (warm_start = 2 never reaches it) -- the split pipeline's set-up kernel of every other mode keeps the
     // code it had before the update path existed (with it in: +9 % on that kernel, measured)
-    template <bool UPD = false>
+    // COOP (general path): the number of rows of the wavefront that share this set-up, as a compile-time constant (== coop_n; 0 = not given: one row).  The rows of a shared
+    // general-path set-up split the ROWS of the Hessian -- horizon step s belongs to row s mod COOP -- so a lane carries the step-s factors of H / COOP steps only (round 6)
+    template <bool UPD = false, int COOP = 0>
     A1_DEV void setup(const ProblemIO& io) {
         double Rm[9];
 #pragma unroll
@@ -627,38 +644,45 @@ struct RowSolver {
 #pragma unroll
             for (int k = 0; k < 3; ++k) lds[L::TBL + k * 12 + ci] = TB[k];
         }
-        // my column of T * B~w_t for every step: only ever read back by the lane that wrote it (the sweeps fold the rotation into the step-s factors cu), so the general
-        // path's set-up kernel keeps it in registers -- its LDS image loses 36 H doubles and twice (h = 16) / 1.5 times (h = 20) as many wavefronts fit a CU (round 5);
-        // the fused kernels park it in the not-yet-written factor region as before
-        [[maybe_unused]] double tbwr[(GEN && SETUP_ONLY) ? H : 1][3];
         if constexpr (GEN) {
-            // per-step feet: the omega rows of B~_t = dt * Iw^-1 * skew(r_t) (S/ConvexMpc.cpp:138,151 with the step's foot_pos) and T * them
+            // per-step feet: the omega rows of B~_t = dt * Iw^-1 * skew(r_t) (S/ConvexMpc.cpp:138,151 with the step's foot_pos).  T * them (the rpy rows of B_d) is recomputed
+            // from this table where it is needed (my own column of a few steps: step_factors below) -- until round 6 it had a table (fused kernels) or 3 H registers (set-up kernel) of its own
+            // The set-up kernel of the general path's split pipeline (SETUP_ONLY) keeps no B~w table in LDS: the column goes straight into the hand-off record (gen_rec) and is
+            // recomputed from the foot table where the set-up needs it again (bw_at: the same expression, the same bits) -- 36 H doubles less per QP, eight instead of seven
+            // one-QP workgroups per CU at H = 20
             static_for<H>([&](auto T) {
-#pragma clang fp contract(off)   // (the FMAs of this block are written out: see tb0 / tb1)
                 constexpr int t = A1_CV(T);
                 const double* fp = io.foot + static_cast<int64_t>(t) * io.foot_stride;
                 const double rx = fp[3 * quad + 0], ry = fp[3 * quad + 1], rz = fp[3 * quad + 2];
-                const double k0 = comp == 0 ? 0.0 : (comp == 1 ? -rz : ry);
-                const double k1 = comp == 0 ? rz : (comp == 1 ? 0.0 : -rx);
-                const double k2 = comp == 0 ? -ry : (comp == 1 ? rx : 0.0);
                 double bw[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) bw[k] = (Ii[k * 3 + 0] * k0 + Ii[k * 3 + 1] * k1 + Ii[k * 3 + 2] * k2) * dt;
-                // (explicit FMAs: left to the compiler's contraction, the register and the LDS variant of this block were fused differently and the two pipelines parted by an ulp)
-                const double tb0 = fma(cy, bw[0], sy * bw[1]), tb1 = fma(-sy, bw[0], cy * bw[1]);
+                bw_from_foot(Ii, rx, ry, rz, bw);
                 if (act) {
+                    if constexpr (SETUP_ONLY) {
+                        if (gen_rec != nullptr && coop_id == 0) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) lds[L::BW + (t * 3 + k) * 12 + ci] = bw[k];
-                    if constexpr (!SETUP_ONLY) {
-                        lds[L::TBW + (t * 3 + 0) * 12 + ci] = tb0;
-                        lds[L::TBW + (t * 3 + 1) * 12 + ci] = tb1;
-                        lds[L::TBW + (t * 3 + 2) * 12 + ci] = bw[2];
+                            for (int k = 0; k < 3; ++k) gen_rec[(PR::BWF + 3 * t + k) * 12 + ci] = bw[k];
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) lds[L::BW + (t * 3 + k) * 12 + ci] = bw[k];
                     }
+                    lds[L::FT + t * 12 + ci] = comp == 0 ? rx : (comp == 1 ? ry : rz);
                 }
-                if constexpr (SETUP_ONLY) { tbwr[t][0] = row_opaque(act ? tb0 : 0.0); tbwr[t][1] = row_opaque(act ? tb1 : 0.0); tbwr[t][2] = row_opaque(act ? bw[2] : 0.0); }   // (opaque like a value read back from LDS)
             });
         }
         set_sync();
+        // my column of the omega rows of B~_t during the set-up (general path): from the LDS table, or -- set-up kernel -- again from the step's foot position
+        [[maybe_unused]] auto bw_at = [&](int t, double (&o)[3]) {
+            if constexpr (SETUP_ONLY) {
+                const double* ft = lds + L::FT + t * 12 + 3 * quad;
+                bw_from_foot(Ii, ft[0], ft[1], ft[2], o);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) o[k] = act ? o[k] : 0.0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) o[k] = act ? lds[L::BW + (t * 3 + k) * 12 + ci] : 0.0;
+            }
+        };
 
         // ---------------------------------------------------------------- gradient g = B_qp' Q (A_qp x0 - x_ref)
         double g[H];
@@ -710,7 +734,13 @@ struct RowSolver {
             static_for<H>([&](auto TT) {
                 constexpr int t = H - 1 - A1_CV(TT);
                 lam = row_dpp_ready(w[t] + opAT(lam));
-                if constexpr (GEN) { double Bq[6]; Bt_at(t, Bq); g[t] = dot_bc<6>(Bq, lam); }
+                if constexpr (GEN) {
+                    double Bq[6], bq3[3];
+                    bw_at(t, bq3);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { Bq[k] = bq3[k]; Bq[3 + k] = Bt[3 + k]; }
+                    g[t] = dot_bc<6>(Bq, lam);
+                }
                 else g[t] = BtT(lam);
             });
         }
@@ -729,8 +759,9 @@ struct RowSolver {
             if (act && ci == B) { Ud = U[B]; Vd = V[B]; }
         });
         // GEN: block (s,t) of B_qp'QB_qp is beta_st (gamma_st U_st + V_st) with U_st[a][b] = dt^2 (sum_c q_c TB_s[c][a] TB_t[c][b] + q_{3+k} (dt/m)^2 [k = comp_a = comp_b]),
-        // V_st[a][b] = sum_c q_{6+c} B~w_s[c][a] B~w_t[c][b] + q_{9+k} (dt/m)^2 [..]: my row's step-s factors live in registers, the step-t tables in LDS
-        [[maybe_unused]] double cu[GEN ? H : 1][3], cv[GEN ? H : 1][3], Udg[GEN ? H : 1], Vdg[GEN ? H : 1], Ucs[3], Vcs[3];
+        // V_st[a][b] = sum_c q_{6+c} B~w_s[c][a] B~w_t[c][b] + q_{9+k} (dt/m)^2 [..]: my row's step-s factors live in registers (for the steps s this row of the set-up owns), the
+        // step-t tables in LDS
+        [[maybe_unused]] double Ucs[3], Vcs[3];
         [[maybe_unused]] const double dt2 = dt * dt;
         if constexpr (GEN) {
 #pragma unroll
@@ -738,24 +769,6 @@ struct RowSolver {
                 Ucs[k] = (act && comp == k) ? P.q2[3 + k] * Bt[3 + k] * Bt[3 + k] : 0.0;
                 Vcs[k] = (act && comp == k) ? P.q2[9 + k] * Bt[3 + k] * Bt[3 + k] : 0.0;
             }
-            static_for<H>([&](auto S) {
-#pragma clang fp contract(off)   // (no contraction left to the compiler between the set-up kernel's and the fused kernels' copies of this block)
-                constexpr int s = A1_CV(S);
-                double ud = 0.0, vd = 0.0;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    double tb;
-                    if constexpr (SETUP_ONLY) tb = tbwr[s][c]; else tb = act ? lds[L::TBW + (s * 3 + c) * 12 + ci] : 0.0;
-                    const double bwv = act ? lds[L::BW + (s * 3 + c) * 12 + ci] : 0.0;
-                    cu[s][c] = P.q2[c] * tb; cv[s][c] = P.q2[6 + c] * bwv;
-                    ud += cu[s][c] * tb; vd += cv[s][c] * bwv;
-                    if (comp == c) { ud += Ucs[c]; vd += Vcs[c]; }
-                }
-                Udg[s] = ud * dt2; Vdg[s] = vd;
-                // T B~w_t = T (B~w_t): fold the yaw rotation into my step-s factors once, so that a sweep entry needs the B~w_t table only
-                const double c0 = cu[s][0], c1 = cu[s][1];
-                cu[s][0] = (c0 * cy - c1 * sy) * dt2; cu[s][1] = (c0 * sy + c1 * cy) * dt2; cu[s][2] *= dt2;
-            });
         }
 
         if constexpr (CLK) ckF = row_clock();
@@ -782,11 +795,13 @@ struct RowSolver {
                 unsigned long long hsh = 0;
                 static_for<H>([&](auto S) {
                     unsigned v = 0;
+                    double bwS[3];
+                    bw_at(A1_CV(S), bwS);
+                    const double tbS[3] = {fma(cy, bwS[0], sy * bwS[1]), fma(-sy, bwS[0], cy * bwS[1]), bwS[2]};   // my column of T B~w_s, as step_factors forms it
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        v |= (act && lds[L::BW + (A1_CV(S) * 3 + c) * 12 + ci] != 0.0 ? 1u : 0u) << c;
-                        if constexpr (SETUP_ONLY) v |= (tbwr[A1_CV(S)][c] != 0.0 ? 1u : 0u) << (3 + c);
-                        else v |= (act && lds[L::TBW + (A1_CV(S) * 3 + c) * 12 + ci] != 0.0 ? 1u : 0u) << (3 + c);
+                        v |= (bwS[c] != 0.0 ? 1u : 0u) << c;
+                        v |= (tbS[c] != 0.0 ? 1u : 0u) << (3 + c);
                     }
                     hsh = (hsh * 67ull + v + 1ull) & ((1ull << 50) - 1ull);
                 });
@@ -801,8 +816,8 @@ struct RowSolver {
                 reinit = row_allmax(prev != sig ? 1.0 : 0.0) > 0.0;
             }
         }
-        [[maybe_unused]] double gq[(UPD && MODE == kModeMpc && H > 1) ? H : 1];   // the gradient the cost normalisation sees: the previous tick's on the update path
-        if constexpr (UPD && MODE == kModeMpc && H > 1) {
+        [[maybe_unused]] double gq[(UPD && MODE == kModeMpc && H > 1 && !GEN) ? H : 1];   // the gradient the cost normalisation sees: the previous tick's on the update path
+        if constexpr (UPD && MODE == kModeMpc && H > 1 && !GEN) {
 #pragma unroll
             for (int t = 0; t < H; ++t) gq[t] = (upd && !reinit) ? (act ? io.carry[CR::G + t * 12 + ci] : 0.0) : g[t];
         }
@@ -810,10 +825,146 @@ struct RowSolver {
         csc = 1.0;
 #pragma unroll
         for (int t = 0; t < H; ++t) { D[t] = 1.0; E0[t] = act ? 1.0 : 0.0; }
+        if constexpr (GEN) {
+            // ================================================================ general path: Ruiz passes with the ROWS of the Hessian split over the rows of the set-up (round 6)
+            // Every block (s,t) of the implicit Hessian is evaluated in every sweep (no pruning bound holds on this path: see the measurements named at the old column loop,
+            // profiles/r05_general_path_early_stop.txt), so a lane needs its step-s factors (cu, cv: 6 doubles per step) for every s it evaluates.  Until round 6 a row
+            // evaluated EVERY s for the columns t it was given: 6 H doubles of factors + D, E, m for all H steps per lane -- 330-390 doubles at H = 16 / 20 in a 256-double
+            // register file, 390-750 VGPRs spilled to scratch and 145-500 scratch instructions inside the sweep loops.  Now row j of the N rows that share
+            // the set-up OWNS the horizon steps s = N k + j: it evaluates the block rows s it owns against every column t, keeps factors / D / E / m of those H / N steps
+            // only, and nothing is combined across rows any more (a column maximum m_s has ONE producer).  What all rows need of each other goes through three small LDS tables per
+            // pass: D (DL, read by every sweep anyway), m (ML) and -- once, behind the last pass -- E (E0X).  The gradient waits in LDS (CG / GQT) instead of H registers.
+            constexpr int N = COOP > 0 ? COOP : 1;
+            constexpr int HSN = (H + N - 1) / N;
+            const int cid = N > 1 ? coop_id : 0;
+            if (act) {
+#pragma unroll
+                for (int t = 0; t < H; ++t) {
+                    lds[L::CG + t * 12 + ci] = g[t];   // (raw; becomes c g below)
+                    if constexpr (UPD && H > 1) lds[L::GQT + t * 12 + ci] = (upd && !reinit) ? io.carry[CR::G + t * 12 + ci] : g[t];
+                    lds[L::DL + t * 12 + ci] = 1.0;    // (every row of a shared set-up writes the same words)
+                }
+            }
+            constexpr int GSRC = (UPD && H > 1) ? L::GQT : L::CG;   // the gradient the cost normalisation sees (the previous tick's on the update path)
+            if (P.scaling_iters > 0) {
+                int sk[HSN]; bool vk[HSN];
+                double zuS[HSN][3], zvS[HSN][3], dgS[HSN], Dk[HSN], E0k[HSN], mk[HSN];
+                set_sync();   // the per-step table B~w_t is complete
+                static_for<HSN>([&](auto K) {
+#pragma clang fp contract(off)   // (no contraction left to the compiler: every instantiation of this block -- set-up kernel, fused, latency -- must round alike; the FMAs are written out)
+                    constexpr int k = A1_CV(K);
+                    const int s = N * k + cid;
+                    vk[k] = s < H; sk[k] = vk[k] ? s : H - 1;
+                    double bw[3];
+                    bw_at(sk[k], bw);
+                    const double tb[3] = {fma(cy, bw[0], sy * bw[1]), fma(-sy, bw[0], cy * bw[1]), bw[2]};   // my column of T B~w_s
+                    double ud = 0.0, vd = 0.0, cu[3], cv[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        cu[c] = P.q2[c] * tb[c]; cv[c] = P.q2[6 + c] * bw[c];
+                        ud += cu[c] * tb[c]; vd += cv[c] * bw[c];
+                        if (comp == c) { ud += Ucs[c]; vd += Vcs[c]; }
+                    }
+                    // the true diagonal entry carries R: alpha_ss U_ss + beta_ss V_ss + R  (alpha_ss = sum_{i >= s} (i - s)^2, beta_ss = H - s: exact in a double)
+                    const int nn = H - sk[k];
+                    const double ad = static_cast<double>((nn - 1) * nn * (2 * nn - 1) / 6), bd = static_cast<double>(nn);
+                    dgS[k] = fma(ad, ud * dt2, fma(bd, vd, r2a));
+                    // Entry (s,a),(t,b) = beta_st (y . B~w_t[:,b] + k_{b%3})  with  y = gamma_st dt^2 T'(q T B~w_s[:,a]) + q_w B~w_s[:,a]  and the velocity-row constants k.
+                    // Column b = (leg, c) of B~w_t is dt Iw^-1 (r_t,leg x e_c), so  y . B~w_t[:,b] = (z x r_t,leg)_c  with  z = dt Iw^-T y = gamma_st zu + zv: the three entries
+                    // of a leg are ONE cross product with the step's foot position (2 FMAs per entry seeded with k; round 6 -- until then 3 FMAs per entry against the 3 x 12
+                    // table B~w_t) and a sweep reads 12 instead of 36 table words per column block
+                    const double yu[3] = {(cu[0] * cy - cu[1] * sy) * dt2, (cu[0] * sy + cu[1] * cy) * dt2, cu[2] * dt2};   // (T B~w_t = T (B~w_t): the yaw rotation folded into my step-s factors)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        zuS[k][j] = fma(Ii[6 + j], yu[2], fma(Ii[3 + j], yu[1], Ii[j] * yu[0])) * dt;
+                        zvS[k][j] = fma(Ii[6 + j], cv[2], fma(Ii[3 + j], cv[1], Ii[j] * cv[0])) * dt;
+                    }
+                    Dk[k] = 1.0; E0k[k] = act ? 1.0 : 0.0;
+                });
+                // m[s] = max_{t,b} D_tb |P_(s,a),(t,b)| for my rows (s, a), s owned: one pass over my block rows of the implicit Hessian
+                // entry (s,a),(t,b) = beta_st (y . B~w_t[:,b] + k_{b%3})  with  y = gamma_st dt^2 T'(q T B~w_s[:,a]) + q_w B~w_s[:,a]  and the velocity-row constants k: 3 FMAs
+                // per entry and one table.  Tried and measured slower here: per-block pruning bounds (round 2) and the fast path's column loop with a rounding-safe bound
+                // (round 5: the blocks of the last horizon steps never tie with their bound, no sweep stops)
+                auto sweep = [&]() {
+                    static_for<HSN>([&](auto K) { mk[K] = dgS[K] * Dk[K]; });
+#pragma unroll 1
+                    for (int t = 0; t < H; ++t) {
+                        double Dt[12], rt[12];
+#pragma unroll
+                        for (int b = 0; b < 12; ++b) { Dt[b] = lds[L::DL + t * 12 + b]; rt[b] = lds[L::FT + t * 12 + b]; }
+                        double gnx = tab[(sk[0] * H + t) * 2], bnx = tab[(sk[0] * H + t) * 2 + 1];   // (gamma_st, beta_st) of my next step: read one step ahead of its use
+                        static_for<HSN>([&](auto K) {
+                            constexpr int k = A1_CV(K);
+                            const double gam = gnx, bet = bnx;
+                            if constexpr (k + 1 < HSN) { gnx = tab[(sk[k + 1] * H + t) * 2]; bnx = tab[(sk[k + 1] * H + t) * 2 + 1]; }
+                            const double z0 = fma(gam, zuS[k][0], zvS[k][0]), z1 = fma(gam, zuS[k][1], zvS[k][1]), z2 = fma(gam, zuS[k][2], zvS[k][2]);
+                            const double gd = gam * dt2;
+                            const double k3[3] = {fma(gd, Ucs[0], Vcs[0]), fma(gd, Ucs[1], Vcs[1]), fma(gd, Ucs[2], Vcs[2])};
+                            double a0 = 0.0, a1 = 0.0;
+                            static_for<4>([&](auto Lg) {   // (z x r)_0 = z1 r2 - z2 r1, (z x r)_1 = z2 r0 - z0 r2, (z x r)_2 = z0 r1 - z1 r0
+                                constexpr int l = 3 * A1_CV(Lg);
+                                const double e0 = fma(z1, rt[l + 2], fma(-z2, rt[l + 1], k3[0]));
+                                const double e1 = fma(z2, rt[l + 0], fma(-z0, rt[l + 2], k3[1]));
+                                const double e2 = fma(z0, rt[l + 1], fma(-z1, rt[l + 0], k3[2]));
+                                if constexpr (A1_CV(Lg) % 2 == 0) max_abs3_f64(a0, a1, e0 * Dt[l], e1 * Dt[l + 1], e2 * Dt[l + 2]);   // a0 = max(a0, |x0|, |x2|), a1 = max(a1, |x1|)
+                                else max_abs3_f64(a1, a0, e2 * Dt[l + 2], e1 * Dt[l + 1], e0 * Dt[l]);
+                            });
+                            mk[k] = max_f64(mk[k], bet * max_f64(a0, a1));
+                        });
+                    }
+                };
+                // one Ruiz step of an owned horizon step (scaling.c scale_data: column norms of [P A'; A 0] -> D, row norms -> E); E1 == E0 on the fx / fy lanes: see the fast path below
+                auto ruiz_step = [&](double& Dt_, double& E0t, double mt) {
+                    const double Dz = quad_perm<2, 2, 2, 2>(Dt_);
+                    const double mE = E0t;
+                    const double mEx = quad_perm<0, 0, 0, 0>(mE), mEy = quad_perm<1, 1, 1, 1>(mE);
+                    const double colA = Dt_ * (comp == 2 ? fmax(mu * fmax(mEx, mEy), E0t) : mE);
+                    const double colP = csc * Dt_ * mt;
+                    const double dtmp = row_rsqrt(limit_scaling(fmax(colP, colA)));
+                    const double rowf = comp == 2 ? Dt_ : fmax(Dt_, mu * Dz);
+                    const double e0 = row_rsqrt(limit_scaling(E0t * rowf));
+                    Dt_ *= dtmp; E0t *= e0;
+                };
+                set_sync();   // the D = 1 table is complete
+                sweep();
+#pragma unroll 1
+                for (int pass = 0; pass < P.scaling_iters; ++pass) {
+                    static_for<HSN>([&](auto K) { ruiz_step(Dk[K], E0k[K], mk[K]); });
+                    set_sync();   // every row is done with the D table of the sweep before
+                    if (act) { static_for<HSN>([&](auto K) { if (vk[K]) lds[L::DL + sk[K] * 12 + ci] = Dk[K]; }); }
+                    set_sync();
+                    sweep();
+                    if (act) { static_for<HSN>([&](auto K) { if (vk[K]) lds[L::ML + sk[K] * 12 + ci] = mk[K]; }); }
+                    set_sync();
+                    // cost normalisation: the mean column norm of c P and the norm of c q over ALL steps, summed in the fixed order every row (and the oracle) uses
+                    double sum = 0.0, nq = 0.0;
+                    {
+#pragma clang fp contract(off)
+#pragma unroll
+                        for (int t = 0; t < H; ++t) {
+                            const double cd = csc * (act ? lds[L::DL + t * 12 + ci] : 1.0);
+                            sum += cd * (act ? lds[L::ML + t * 12 + ci] : 0.0);
+                            nq = fmax(nq, fabs(cd * (act ? lds[GSRC + t * 12 + ci] : 0.0)));
+                        }
+                    }
+                    const double mean = row_allsum(sum) / double(12 * H);
+                    nq = limit_scaling(row_allmax(nq));
+                    const double ct = 1.0 / limit_scaling(fmax(mean, nq));
+                    csc *= ct;
+                }
+                // the E of every step (each row iterated its own steps' only); the final D is in its table.  The hot-state loop below reads D_t, E_t and g_t of a step from these
+                // tables when it gets there (h20: as arrays they are 160 registers held across it)
+                set_sync();   // the last pass's reads of ML are done (E0X may alias it)
+                static_for<HSN>([&](auto K) { if (vk[K]) lds[L::E0X + sk[K] * 16 + ln] = E0k[K]; });
+            } else {
+#pragma unroll
+                for (int t = 0; t < H; ++t) lds[L::E0X + t * 16 + ln] = act ? 1.0 : 0.0;
+            }
+        }
         // E1 (the scaling of my second constraint row: fx / fy lanes only) is not iterated (round 5): the rows [f + mu fz] and [f - mu fz] have the same absolute entries, so
         // every Ruiz pass would update E1 by the same operations on the same operands as E0 -- E1 == E0 bit for bit on the fx / fy lanes, 0 elsewhere (see Prep<H>) -- it
         // is copied from E0 behind the passes.  One of three rsqrt chains per horizon step and pass, and a third of the tables a shared set-up hands around, go.
-        if (P.scaling_iters > 0) {
+        if constexpr (!GEN) { if (P.scaling_iters > 0) {
             double m[H];
             // m[s] = max_{t,b} D_tb |P_(s,a),(t,b)|  for my rows (s, a): one pass over the implicit Hessian.
             // Exact pruning (see the column loop below): starting from the diagonal entry, 60-75 % of the blocks provably cannot raise a maximum.
@@ -829,44 +980,8 @@ struct RowSolver {
                 Dall = row_allmax(act ? Dall : 0.0);
                 static_for<H>([&](auto S) {  // the true diagonal entry carries R
                     constexpr double ad = alpha_diag(A1_CV(S), H), bd = H - A1_CV(S);
-                    if constexpr (GEN) mm[S] = (ad * Udg[S] + bd * Vdg[S] + r2a) * D[S];
-                    else mm[S] = (ad * Ud + bd * Vd + r2a) * D[S];
+                    mm[S] = (ad * Ud + bd * Vd + r2a) * D[S];
                 });
-                if constexpr (GEN) {
-#pragma unroll 1
-                    for (int t = coop_id; t < H; t += coop_n) {  // every block is evaluated.  Tried and measured slower here: a per-block pruning bound like the fast path's
-                                                   // (round 2: 3.11 -> 3.35 ms at 4096 x h10, per-lane skips do not skip at wave level and cost registers); the fast path's
-                                                   // column loop with the bound gamma (sum_c |cu_c| max|B~w_c| + ..) + .. (round 2: too loose to stop, 1.86 -> 1.80 M solves/s);
-                                                   // and (round 5, profiles/r05_general_path_early_stop.txt) the same loop with the tighter, rounding-safe bound
-                                                   // max_b (sum_c |cu_c| max_t |B~w_t[c][b]|): exact, but the blocks of the last horizon steps (gamma_st = 0: they do not decay
-                                                   // with t) never tie with their bound the way the fast path's do, so no sweep stops -- the set-up got 18-25 % slower at h = 16 / 20
-                        // entry (s,a),(t,b) = beta_st (y . B~w_t[:,b] + k_{b%3})  with  y = gamma_st dt^2 T'(q T B~w_s[:,a]) + q_w B~w_s[:,a]  and the
-                        // velocity-row constants k: 3 FMAs per entry and one table (round 2; it was 6 FMAs and two tables)
-                        const int tc = t;
-                        double gb[2 * H], Dt[12], Bwt[3][12];
-#pragma unroll
-                        for (int s2 = 0; s2 < H; ++s2) { gb[2 * s2] = tab[(s2 * H + tc) * 2]; gb[2 * s2 + 1] = tab[(s2 * H + tc) * 2 + 1]; }
-#pragma unroll
-                        for (int b = 0; b < 12; ++b) {
-                            Dt[b] = lds[L::DL + tc * 12 + b];
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) Bwt[c][b] = lds[L::BW + (tc * 3 + c) * 12 + b];
-                        }
-                        static_for<H>([&](auto S) {
-                            constexpr int s = A1_CV(S);
-                            const double gam = gb[2 * s], bet = gb[2 * s + 1];
-                            const double y0 = fma(gam, cu[s][0], cv[s][0]), y1 = fma(gam, cu[s][1], cv[s][1]), y2 = fma(gam, cu[s][2], cv[s][2]);
-                            const double gd = gam * dt2;
-                            const double k3[3] = {fma(gd, Ucs[0], Vcs[0]), fma(gd, Ucs[1], Vcs[1]), fma(gd, Ucs[2], Vcs[2])};
-                            double a0 = 0.0;
-                            static_for<12>([&](auto B) {
-                                constexpr int b = A1_CV(B);
-                                a0 = fmax(a0, fabs(fma(y2, Bwt[2][b], fma(y1, Bwt[1][b], fma(y0, Bwt[0][b], k3[b % 3])))) * Dt[b]);
-                            });
-                            mm[S] = fmax(mm[S], bet * a0);
-                        });
-                    }
-                }
                 // Blocks are visited column by column (t ascending; a row of a shared set-up takes every coop_n-th) and only while some block still to
                 // come could raise a maximum.  Inside a column every s is evaluated, branch-free, on the column's pre-scaled rows u_b = U_ab D_tb,
                 // v_b = V_ab D_tb: entry = |fma(gamma_st, u_b, v_b)| beta_st, 2 instructions per entry.  The bound of block (s,t),
@@ -879,7 +994,7 @@ struct RowSolver {
                 static_assert(gamma_beta_monotone(H), "the column loop of the Ruiz sweep stops early on the strength of this");
                 const double UDall = Umax * Dall, VDall = Vmax * Dall;
                 {
-                    int t = GEN ? H : coop_id;
+                    int t = coop_id;
 #pragma unroll 1
                     while (true) {
                         const int tc = t < H ? t : H - 1;  // (rows of a shared set-up run out of columns at different times; they re-visit a real block, which is harmless)
@@ -983,15 +1098,17 @@ struct RowSolver {
                 const double ct = 1.0 / limit_scaling(fmax(mean, nq));
                 csc *= ct;
             }
-        }
-        if (P.scaling_iters > 0 && coop_n > 1) {   // the E of the other rows' horizon steps (each row wrote its own steps' only)
+        } }
+        if constexpr (!GEN) { if (P.scaling_iters > 0 && coop_n > 1) {   // the E of the other rows' horizon steps (each row wrote its own steps' only)
             set_sync();
             static_for<H>([&](auto T) { if ((A1_CV(T) & (coop_n - 1)) == coop_id) lds[L::E0X + A1_CV(T) * 16 + ln] = E0[T]; });   // (coop_n: 2 or 4)
             set_sync();
             static_for<H>([&](auto T) { E0[T] = lds[L::E0X + A1_CV(T) * 16 + ln]; });
-        }
+        } }
+        if constexpr (!GEN) {
 #pragma unroll
-        for (int t = 0; t < H; ++t) E1[t] = comp < 2 ? E0[t] : 0.0;
+            for (int t = 0; t < H; ++t) E1[t] = comp < 2 ? E0[t] : 0.0;
+        }
         cinv = 1.0 / csc;
         qd = csc * q2s;
         if constexpr (CLK) ckR = row_clock();
@@ -1035,6 +1152,11 @@ struct RowSolver {
         if constexpr (kUpdPath) { if (upd) ccp = io.carry[CR::C]; }
         static_for<H>([&](auto T) {
             constexpr int t = A1_CV(T);
+            // this step's scalings and gradient (general path: from the tables the Ruiz passes left in LDS)
+            double Dt_, E0t_, gt_;
+            if constexpr (GEN) { Dt_ = act ? lds[L::DL + t * 12 + ci] : 1.0; E0t_ = lds[L::E0X + t * 16 + ln]; gt_ = act ? lds[L::CG + t * 12 + ci] : 0.0; }
+            else { Dt_ = D[t]; E0t_ = E0[t]; gt_ = g[t]; }
+            const double E1t_ = comp < 2 ? E0t_ : 0.0;
             // the step's contact flags (a per-step schedule when contact_stride = 4): bounds of my slot-0 row at step t
             const bool ct = act && io.contact[static_cast<int64_t>(t) * io.contact_stride + quad];
             const double cf = ct ? 1.0 : 0.0;
@@ -1045,14 +1167,24 @@ struct RowSolver {
             } else if constexpr (!TWIN) {
                 lbk[t] = comp == 2 ? lo_t : 0.0; ubk[t] = comp == 2 ? hi_t : kInfty;
             }
-            const bool eq = comp == 2 && (E0[t] * hi_t - E0[t] * lo_t < kRhoTol);
+            const bool eq = comp == 2 && (E0t_ * hi_t - E0t_ * lo_t < kRhoTol);
             if (eq) eqmask |= 1u << t;
-            rr0[t] = E0[t] * E0[t] * (eq ? kRhoEqOverIneq * rho : rho);
-            rr1[t] = E1[t] * E1[t] * rho;
-            const double di = 1.0 / D[t];
+            rr0[t] = E0t_ * E0t_ * (eq ? kRhoEqOverIneq * rho : rho);
+            rr1[t] = E1t_ * E1t_ * rho;
+            const double di = 1.0 / Dt_;
             dI2[t] = di * di;
-            if constexpr (SETUP_ONLY && GEN) cgr[t] = csc * g[t];
-            else if (act) lds[L::CG + t * 12 + ci] = csc * g[t];     // D^-1 q_s = c g
+            // D^-1 q_s = c g.  General path: the table holds the raw gradient until here, so ONE row of a shared set-up turns it into c g (a second one would scale it twice
+            // wherever the rows are not in lock-step -- the CPU test double's fibers are not)
+            if (act && (!GEN || coop_id == 0)) lds[L::CG + t * 12 + ci] = csc * gt_;
+            if constexpr (GEN && UPD && MODE == kModeMpc && H > 1) {
+                // what the next tick's update calls will find in the workspace: this tick's scalings and unscaled gradient (the reads of the previous tick's fields of this step are
+                // above; every row that shares the set-up holds the same values, one writes)
+                if (P.warm_start == 2 && io.carry != nullptr && coop_id == 0 && act) {
+                    double* cw = io.carry;
+                    cw[CR::D + t * 12 + ci] = Dt_; cw[CR::E0 + t * 12 + ci] = E0t_; cw[CR::G + t * 12 + ci] = gt_;
+                    if (comp < 2) cw[CR::E1 + t * 12 + ci] = E1t_;
+                }
+            }
             if constexpr (UPD && MODE == kModeMpc && H > 1) {
                 if (upd && reinit) {
                     // pattern change: the previous solve's SCALED x_s = x / D', y_s = c' y / E' go through osqp_warm_start_x / _y as if they were unscaled -- a plain
@@ -1071,10 +1203,10 @@ struct RowSolver {
                     // registers and by handing the first iteration  c g - A'[(2 - alpha) rr delta]  in the slot of c g (admm_iteration<FIRST> is not touched;
                     // the true c g comes back after iteration 1, see load_prepared / advance).
                     const double cp = ccp, Dp = cDp[t], E0p = cE0p[t], zp0 = cZ0[t], zp1 = cZ1[t];
-                    xh[t] = act ? D[t] * (xh[t] / Dp) : 0.0;
+                    xh[t] = act ? Dt_ * (xh[t] / Dp) : 0.0;
                     const double cr_c = cp / csc;
                     // E1 == E0 and E1' == E0' bit for bit on the fx / fy lanes (my two rows share their scaling: see the Ruiz passes): one pair of quotients serves both rows
-                    const double eup = E0[t] / E0p, edn = E0p / E0[t];
+                    const double eup = E0t_ / E0p, edn = E0p / E0t_;
                     const double y0 = act ? cr_c * eup * wh0[t] : 0.0, y1 = (act && comp < 2) ? cr_c * eup * wh1[t] : 0.0;
                     const double zc0 = act ? edn * zp0 : 0.0, zc1 = (act && comp < 2) ? edn * zp1 : 0.0;
                     const double xz = quad_perm<2, 2, 2, 2>(xh[t]);
@@ -1097,11 +1229,13 @@ struct RowSolver {
             if (P.warm_start == 2 && io.carry != nullptr && coop_id == 0) {
                 double* cw = io.carry;
                 if (act) {
-                    static_for<H>([&](auto T) {
-                        constexpr int t = A1_CV(T);
-                        cw[CR::D + t * 12 + ci] = D[t]; cw[CR::E0 + t * 12 + ci] = E0[t]; cw[CR::G + t * 12 + ci] = g[t];
-                        if (comp < 2) cw[CR::E1 + t * 12 + ci] = E1[t];
-                    });
+                    if constexpr (!GEN) {   // (general path: written step by step in the loop above)
+                        static_for<H>([&](auto T) {
+                            constexpr int t = A1_CV(T);
+                            cw[CR::D + t * 12 + ci] = D[t]; cw[CR::E0 + t * 12 + ci] = E0[t]; cw[CR::G + t * 12 + ci] = g[t];
+                            if (comp < 2) cw[CR::E1 + t * 12 + ci] = E1[t];
+                        });
+                    }
                     cw[CR::SIG + ci] = sig;
                 }
                 if (ln == 0) cw[CR::C] = csc;
@@ -1143,8 +1277,7 @@ struct RowSolver {
             constexpr int t = A1_CV(T);
             p[(PR::RR0 + t) * 12 + ci] = rr0[t];   // (rr1: rr0 again on the fx / fy lanes, zero elsewhere -- see Prep)
             p[(PR::DI2 + t) * 12 + ci] = dI2[t];
-            if constexpr (SETUP_ONLY && GEN) p[(PR::CG + t) * 12 + ci] = cgr[t];
-            else p[(PR::CG + t) * 12 + ci] = lds[L::CG + t * 12 + ci];
+            p[(PR::CG + t) * 12 + ci] = lds[L::CG + t * 12 + ci];
             if (warm) p[(PR::XH + t) * 12 + ci] = xh[t];
             if constexpr (UPD && H > 1 && !TWIN && !(SETUP_ONLY && GEN)) {
                 if (upd) {  // update path: y^ of my two rows and the first iteration's c g (see setup)
@@ -1159,12 +1292,7 @@ struct RowSolver {
         unsigned fl = (warm ? 1u : 0u) + (first_special ? 2u : 0u);
         if constexpr (UPD) fl += upd ? 4u : 0u;
         p[PR::PK * 12 + ci] = static_cast<double>(static_cast<unsigned long long>(cmask) | static_cast<unsigned long long>(eqmask) << 20 | static_cast<unsigned long long>(fl) << 40);
-        if constexpr (GEN && SETUP_ONLY) {  // the general path's own set-up kernel: the per-step omega rows of B~_t travel with the record
-            static_for<H>([&](auto T) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) p[(PR::BWF + 3 * A1_CV(T) + c) * 12 + ci] = lds[L::BW + (A1_CV(T) * 3 + c) * 12 + ci];
-            });
-        }
+        // (general path, set-up kernel: the per-step omega rows of B~_t -- fields BWF -- were written by setup() itself: gen_rec)
     }
     // tables (GEN): the record comes from the general path's set-up kernel -- B~w_t and the per-step bounds are rebuilt in this LDS image (in the fused
     // kernel they are still where the set-up wrote them)
@@ -2179,12 +2307,19 @@ A1_DEV ProblemIO make_io_gen(const BatchArgs& a, int64_t b) {
 }
 
 // split pipeline, kernel 1: formation + Ruiz for QP b, prepared state to global memory
+// rows of a wavefront that share one QP in the general path's set-up kernel: 2 (two QPs per wavefront) at H = 10, 4 (one QP per wavefront) at H = 16 / 20 -- the per-lane state of
+// the Ruiz passes then fits 256 registers and two wavefronts share a SIMD (a lone wavefront issues an FP64 instruction every 2.13 ns, two every 1.84: tools/ubench/f64_rate_ubench.hip)
+constexpr int setup_gen_rows(int h) { return h >= 16 ? 4 : 2; }
 template <int H, bool GEN = false, bool UPD = false>
 A1_DEV void setup_row(const BatchArgs& a, const double* __restrict__ tab, int64_t b, double* __restrict__ lds, double* __restrict__ prep) {
     RowSolver<H, kModeMpc, true, GEN> S(a.P, tab, lds);  // tab: the (alpha/beta, beta) table, staged in LDS by the kernel
     if constexpr (GEN) {
-        S.template setup<false>(make_io_gen<H>(a, b));
-        S.template save_prepared<false>(prep + b * Prep<H>::STRIDE_GEN);
+        // general path: rows r and r + 2 of the wavefront (H = 10; all four rows at H = 16 / 20: setup_gen_rows) share this QP's set-up -- each owns every N-th horizon step of the Ruiz passes, RowSolver::setup
+        constexpr int N = setup_gen_rows(H);
+        S.coop_id = N == 4 ? 2 * (row_is_twin() ? 1 : 0) + row_sub() : (row_is_twin() ? 1 : 0); S.coop_n = N;
+        S.gen_rec = prep + b * Prep<H>::STRIDE_GEN;
+        S.template setup<false, N>(make_io_gen<H>(a, b));
+        if (S.coop_id == 0) S.template save_prepared<false>(prep + b * Prep<H>::STRIDE_GEN);
     } else {
         S.template setup<UPD>(make_io_sched<H, kModeMpc>(a, b));
         S.template save_prepared<UPD>(prep + b * Prep<H>::STRIDE);
@@ -2271,7 +2406,7 @@ A1_DEV void solve_row_with(const DeviceParams& P, const double* __restrict__ tab
             if constexpr (QUAD) { cid = 2 * cid + row_sub(); cn = 4; }   // (a quad: the four rows)
             RowSolver<H, MODE, false, true> S0(P, stage_table<H, Layout<H, true>>(tab, lds, cid, cn), lds);
             S0.coop_id = cid; S0.coop_n = cn;
-            S0.template setup<UPD>(make_io_());
+            S0.template setup<UPD, QUAD ? 4 : (TWIN ? 2 : 1)>(make_io_());
             if constexpr (TWIN) pair_sync(); else row_sync();  // everybody is done with the set-up scratch aliased into the factor region
             if ((!TWIN || !row_is_twin()) && (!QUAD || row_sub() == 0)) S0.template save_prepared<UPD>(lds + Layout<H, true>::FAC);
         }
@@ -2331,7 +2466,7 @@ A1_DEV void solve_latency_gen(const DeviceParams& P, const double* __restrict__ 
     {
         RowSolver<H, kModeMpc, false, true> S0(P, stage_table<H, LG>(tab, lds, cid, 4), lds);
         S0.coop_id = cid; S0.coop_n = 4;
-        S0.template setup<UPD>(make_io_());
+        S0.template setup<UPD, 4>(make_io_());
         coop_sync();   // everybody is done with the set-up scratch aliased into the factor region
         if (cid == 0) S0.template save_prepared<UPD>(lds + LG::FAC);
     }

@@ -87,6 +87,12 @@ A1_DEV double max_abs_f64(double a, double x) {
     asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(x));
     return r;
 }
+// a = max(a, |x0|, |x2|), b = max(b, |x1|) as ONE statement (hipcc pads every dependent pair of asm statements with an s_nop; VALU -> VALU needs none)
+A1_DEV void max_abs3_f64(double& a, double& b, double x0, double x1, double x2) {
+    asm("v_max_f64 %0, %0, |%2|\n"
+        "v_max_f64 %1, %1, |%3|\n"
+        "v_max_f64 %0, %0, |%4|" : "+v"(a), "+v"(b) : "v"(x0), "v"(x1), "v"(x2));
+}
 A1_DEV double min_f64(double a, double b) {
     double r;
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));

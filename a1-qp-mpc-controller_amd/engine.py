@@ -60,7 +60,7 @@ EXPORTS = ["a1mpc_set_timing", "a1mpc_default_tick_params", "a1mpc_control_tick_
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error", "a1mpc_build_info", "a1mpc_pipeline_create", "a1mpc_pipeline_submit_device", "a1mpc_pipeline_submit",
-           "a1mpc_pipeline_wait", "a1mpc_pipeline_join", "a1mpc_pipeline_handle", "a1mpc_pipeline_depth", "a1mpc_pipeline_destroy"]
+           "a1mpc_pipeline_submit_strided_device", "a1mpc_pipeline_submit_strided", "a1mpc_pipeline_submit_ticks_device", "a1mpc_pipeline_wait", "a1mpc_pipeline_join", "a1mpc_pipeline_handle", "a1mpc_pipeline_depth", "a1mpc_pipeline_destroy"]
 
 _lib = None
 
@@ -120,6 +120,10 @@ def load_library(path=None):
     lib.a1mpc_pipeline_submit_device.argtypes = [vp, i32, i32, i32] + [vp] * 9 + [vp, i32p]; lib.a1mpc_pipeline_submit_device.restype = C.c_int
     if path == _build.LIB_PATH or hasattr(lib, "a1mpc_pipeline_submit"):  # (an older build bound by hand for an A/B, tools/ab_probe.py, may lack the round-3 entries)
         lib.a1mpc_pipeline_submit.argtypes = [vp, i32, i32, i32, dp, dp, dp, dp, u8p, dp, dp, i32p, i32p, i32p]; lib.a1mpc_pipeline_submit.restype = C.c_int
+    if path == _build.LIB_PATH or hasattr(lib, "a1mpc_pipeline_submit_strided_device"):   # (round 6)
+        lib.a1mpc_pipeline_submit_strided_device.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i32p]; lib.a1mpc_pipeline_submit_strided_device.restype = C.c_int
+        lib.a1mpc_pipeline_submit_strided.argtypes = [vp, i32, i32, i32, dp, dp, dp, dp, i32, u8p, i32, dp, dp, dp, i32p, i32p, i32p]; lib.a1mpc_pipeline_submit_strided.restype = C.c_int
+        lib.a1mpc_pipeline_submit_ticks_device.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32p]; lib.a1mpc_pipeline_submit_ticks_device.restype = C.c_int
     lib.a1mpc_pipeline_wait.argtypes = [vp, i32]; lib.a1mpc_pipeline_wait.restype = C.c_int
     lib.a1mpc_pipeline_join.argtypes = [vp, i32, vp]; lib.a1mpc_pipeline_join.restype = C.c_int
     lib.a1mpc_pipeline_handle.argtypes = [vp, i32, C.POINTER(vp)]; lib.a1mpc_pipeline_handle.restype = C.c_int
@@ -525,6 +529,52 @@ class Pipeline:
                                             _dp(out["u"]) if out.get("u") is not None else None, _ip(out["iters"]) if out.get("iters") is not None else None,
                                             _ip(out["status"]) if out.get("status") is not None else None, C.byref(k))
         _check(self.lib, rc, "a1mpc_pipeline_submit")
+        self._keep = getattr(self, "_keep", {}); self._keep[int(k.value)] = out   # the output arrays must outlive the slot's batch
+        return int(k.value)
+
+    def submit_strided_device(self, n, d_x0, d_xref, d_R, d_foot, foot_stride, d_contact, contact_stride, d_grf, d_u=None, d_iters=None, d_status=None, d_yaw_A=None,
+                              slot=-1, fresh=True, after_stream=None):
+        """a1mpc_pipeline_submit_strided_device: per-step feet / contact schedules / an A_c yaw of its own (the general path) with batches in flight together"""
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+        k = C.c_int32(-1)
+        rc = self.lib.a1mpc_pipeline_submit_strided_device(self._p, int(slot), 1 if fresh else 0, int(n), ptr(d_x0), ptr(d_xref), ptr(d_R), ptr(d_foot), int(foot_stride),
+                                                           ptr(d_contact), int(contact_stride), ptr(d_yaw_A), ptr(d_grf), ptr(d_u), ptr(d_iters), ptr(d_status),
+                                                           C.c_void_p(int(after_stream)) if after_stream else None, C.byref(k))
+        _check(self.lib, rc, "a1mpc_pipeline_submit_strided_device")
+        return int(k.value)
+
+    def submit_ticks_device(self, n, d_tick, d_R, d_foot, d_contact, d_grf, d_u=None, d_iters=None, d_status=None, slot=-1, fresh=True, after_stream=None):
+        """a1mpc_pipeline_submit_ticks_device: the compact 22-number tick records (x0 / x_ref are built on the device) with batches in flight together"""
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+        k = C.c_int32(-1)
+        rc = self.lib.a1mpc_pipeline_submit_ticks_device(self._p, int(slot), 1 if fresh else 0, int(n), ptr(d_tick), ptr(d_R), ptr(d_foot), ptr(d_contact), ptr(d_grf), ptr(d_u),
+                                                         ptr(d_iters), ptr(d_status), C.c_void_p(int(after_stream)) if after_stream else None, C.byref(k))
+        _check(self.lib, rc, "a1mpc_pipeline_submit_ticks_device")
+        return int(k.value)
+
+    def submit_strided(self, x0, xref, R, foot, foot_stride, contact, contact_stride, out, yaw_A=None, slot=-1, fresh=True):
+        """a1mpc_pipeline_submit_strided: host arrays in (a1mpc_solve_batch_strided's layouts; snapshotted before the call returns), host arrays out like submit()"""
+        n = int(x0.shape[0])
+        x0 = np.ascontiguousarray(x0, np.float64); xref = np.ascontiguousarray(xref, np.float64); R = np.ascontiguousarray(R, np.float64)
+        foot = np.ascontiguousarray(foot, np.float64); contact = np.ascontiguousarray(contact, np.uint8)
+        ya = None if yaw_A is None else np.ascontiguousarray(yaw_A, np.float64)
+        assert foot.size == n * (NU * self.horizon if foot_stride else NU) and contact.size == n * (4 * self.horizon if contact_stride else 4)
+        need = {"grf": (np.float64, n * NU), "u": (np.float64, n * NU * self.horizon), "iters": (np.int32, n), "status": (np.int32, n)}
+        for k_, a_ in out.items():
+            if a_ is None:
+                continue
+            if k_ not in need:
+                raise ValueError(f"unknown output array {k_!r}")
+            dt_, size_ = need[k_]
+            if not (isinstance(a_, np.ndarray) and a_.flags["C_CONTIGUOUS"] and a_.dtype == dt_ and a_.size >= size_):
+                raise ValueError(f"output array {k_!r} must be a C-contiguous numpy array of {np.dtype(dt_).name} with at least {size_} elements")
+        if out.get("grf") is None:
+            raise ValueError("output array 'grf' is required")
+        k = C.c_int32(-1)
+        rc = self.lib.a1mpc_pipeline_submit_strided(self._p, int(slot), 1 if fresh else 0, n, _dp(x0), _dp(xref), _dp(R), _dp(foot), int(foot_stride), _u8p(contact), int(contact_stride),
+                                                    _dp(ya), _dp(out["grf"]), _dp(out["u"]) if out.get("u") is not None else None,
+                                                    _ip(out["iters"]) if out.get("iters") is not None else None, _ip(out["status"]) if out.get("status") is not None else None, C.byref(k))
+        _check(self.lib, rc, "a1mpc_pipeline_submit_strided")
         self._keep = getattr(self, "_keep", {}); self._keep[int(k.value)] = out   # the output arrays must outlive the slot's batch
         return int(k.value)
 

@@ -227,9 +227,42 @@ def general_path_probe(pkg, local, shapes=((10, 4096), (16, 8192), (20, 8192))):
                 eng.set_schedule(True)   # forgets the history: the next solve is a first solve
                 o = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, 12, contact, 4); first_ms.append(eng.last_kernel_ms())
                 eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, 12, contact, 4); hist_ms.append(eng.last_kernel_ms())
+                st_ms = eng.last_stage_ms()   # (set-up | ADMM of the last launch by the handle's events)
         f, hh = float(np.median(first_ms)), float(np.median(hist_ms))
         out[f"{n}xh{h}"] = {"first_solve_kernel_ms": f, "first_solve_solves_per_s": n / (f * 1e-3), "history_order_kernel_ms": hh, "history_order_solves_per_s": n / (hh * 1e-3),
-                            "mean_iters": float(o["iters"].mean()), "solved_frac": float((o["status"] == 1).mean())}
+                            "setup_kernel_ms": float(st_ms[0]), "mean_iters": float(o["iters"].mean()), "solved_frac": float((o["status"] == 1).mean())}
+        # two batches in flight (a1mpc_pipeline_submit_strided_device, round 6): first solves of three distinct resident batches, every launch fresh (no queue history)
+        try:
+            import torch
+            dev = torch.device("cuda", local)
+            tt = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+            NBG = 3
+            ins = []
+            for k in range(NBG):
+                sck = pkg.scenarios.config3_random_flat(nb=n, horizon=h, seed=4242 + 31 * k)
+                rk = np.random.default_rng(h + 100 * k)
+                vdk = rk.uniform(-0.6, 0.6, (n, 1, 1, 3))
+                fk = np.ascontiguousarray((sck["foot"].reshape(n, 1, 4, 3) - vdk * sck["params"]["dt"] * np.arange(h).reshape(1, h, 1, 1) * 40.0).reshape(n, h * 12))
+                swk = rk.integers(0, h + 1, (n, 4)); fik = rk.integers(0, 2, (n, 4))
+                ck = np.ascontiguousarray(np.where(np.arange(h).reshape(1, h, 1) < swk[:, None, :], fik[:, None, :], 1 - fik[:, None, :]).astype(np.uint8).reshape(n, h * 4))
+                ins.append([tt(sck["x0"]), tt(sck["xref"]), tt(sck["R"]), tt(fk), tt(ck, torch.uint8)])
+            outs_g = [(torch.zeros(n, 12, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(NBG)]
+            with pkg.Pipeline(pkg.make_config(sc["params"], h, warm_start=0), n, local, depth=2) as pipe:
+                def run(steps):
+                    for k in range(steps):
+                        if k >= NBG:
+                            pass   # (outputs of batch k % NBG were last written two submits ago on the other slot's stream or this one's: same slot order, no hazard that matters for timing)
+                        x0_, xr_, R_, f_, c_ = ins[k % NBG]; o_ = outs_g[k % NBG]
+                        pipe.submit_strided_device(n, x0_, xr_, R_, f_, 12, c_, 4, o_[0], None, o_[1], o_[2], fresh=True)
+                    pipe.wait()
+                run(4); torch.cuda.synchronize()
+                steps = 12
+                t0 = time.perf_counter(); run(steps); torch.cuda.synchronize()
+                pms = (time.perf_counter() - t0) / steps * 1e3
+            out[f"{n}xh{h}"].update({"pipelined_ms_per_batch": pms, "pipelined_first_solves_per_s": n / (pms * 1e-3), "pipelined_what": "a1mpc_pipeline_submit_strided_device, depth 2, "
+                                     "first solves of 3 distinct resident batches (fresh_batch = 1), host clock over 12 submits + wait"})
+        except Exception as e:
+            out[f"{n}xh{h}"]["pipelined_error"] = str(e)[:200]
         # batch 1 (the reference's own use of the interface, S/test/test_mpc.cpp:106-122: one QP with a B_d per step): the fused general kernel, 40 warm-started
         # ticks of robot 0 with slowly moving state, kernel time by the handle's events, the fast path's latency kernel on the same ticks beside it
         with pkg.Engine(pkg.make_config(sc["params"], h, warm_start=1), 1, local) as eng:

@@ -563,6 +563,25 @@ a1mpc_status a1mpc_pipeline_submit_device(a1mpc_pipeline p, int32_t slot, int32_
 a1mpc_status a1mpc_pipeline_submit(a1mpc_pipeline p, int32_t slot, int32_t fresh_batch, int32_t n, const double* x0, const double* x_ref,
                                    const double* R_world, const double* foot_abs, const uint8_t* contact, double* grf_body_out,
                                    double* u_full_out, int32_t* iters_out, int32_t* status_out, int32_t* slot_out);
+/* Round 6: the other two input forms of the MPC entry with batches in flight together -- per-step feet / contact schedules / an A_c yaw of its own (the general path of
+ * the reference's INTERFACE: B_mat_d_list, S/ConvexMpc.h:74, driven by S/test/test_mpc.cpp:106-122; arguments of a1mpc_solve_batch_strided(_device)) and the compact tick
+ * records (S/A1RobotControl.cpp:452-488; arguments of a1mpc_solve_batch_ticks_device).  A first solve of the general path is bounded by its longest QPs and no feature of
+ * the inputs predicts them (profiles/r05_general_path_order.txt): the tail is what a second batch in flight fills.  Slots, events, fresh_batch, inputs_ready_stream and
+ * the life time of the output arrays are those of a1mpc_pipeline_submit_device / a1mpc_pipeline_submit; results are bit-identical to the lone handle's entry points.
+ * (foot_stride, contact_stride, yaw_A) = (0, 0, NULL) IS a1mpc_pipeline_submit(_device). */
+a1mpc_status a1mpc_pipeline_submit_strided_device(a1mpc_pipeline p, int32_t slot, int32_t fresh_batch, int32_t n, const double* d_x0,
+                                                  const double* d_x_ref, const double* d_R_world, const double* d_foot_abs, int32_t foot_stride,
+                                                  const uint8_t* d_contact, int32_t contact_stride, const double* d_yaw_A, double* d_grf_body_out,
+                                                  double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out, void* inputs_ready_stream,
+                                                  int32_t* slot_out);
+a1mpc_status a1mpc_pipeline_submit_strided(a1mpc_pipeline p, int32_t slot, int32_t fresh_batch, int32_t n, const double* x0, const double* x_ref,
+                                           const double* R_world, const double* foot_abs, int32_t foot_stride, const uint8_t* contact,
+                                           int32_t contact_stride, const double* yaw_A, double* grf_body_out, double* u_full_out,
+                                           int32_t* iters_out, int32_t* status_out, int32_t* slot_out);
+a1mpc_status a1mpc_pipeline_submit_ticks_device(a1mpc_pipeline p, int32_t slot, int32_t fresh_batch, int32_t n, const double* d_tick,
+                                                const double* d_R_world, const double* d_foot_abs, const uint8_t* d_contact, double* d_grf_body_out,
+                                                double* d_u_full_out, int32_t* d_iters_out, int32_t* d_status_out, void* inputs_ready_stream,
+                                                int32_t* slot_out);
 a1mpc_status a1mpc_pipeline_wait(a1mpc_pipeline p, int32_t slot);
 a1mpc_status a1mpc_pipeline_join(a1mpc_pipeline p, int32_t slot, void* hip_stream);
 /* a1mpc_pipeline_handle: a host-pointer batch still in flight on the slot is waited for and handed to its caller's output arrays first (its results live in

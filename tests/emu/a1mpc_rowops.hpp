@@ -50,6 +50,7 @@ inline double max_f64(double a, double b) { return fmax(a, b); }
 inline double min_f64(double a, double b) { return fmin(a, b); }
 inline double clamp_f64(double w, double lb, double ub) { return fmin(fmax(w, lb), ub); }
 inline double max_abs_f64(double a, double x) { return fmax(a, fabs(x)); }
+inline void max_abs3_f64(double& a, double& b, double x0, double x1, double x2) { a = fmax(fmax(a, fabs(x0)), fabs(x2)); b = fmax(b, fabs(x1)); }
 inline double row_dpp_ready(double x) { return x; }
 inline void row_dpp_ready12(double (&)[12]) {}
 inline void row_sync() { (void)emu_publish(0.0); }

@@ -324,7 +324,7 @@ static void run_split_gen(const BatchArgs& a, int nrows) {
     for (int64_t b = 0; b < a.n; ++b) {
         for (auto& v : lds1) v = NAN;
         j.b = b; j.lds = lds1.data();
-        run_row(split_setup_gen_entry<H>, &j);
+        run_row(split_setup_gen_entry<H>, &j, 16 * setup_gen_rows(H));   // (the general path's set-up kernel: two or four rows per QP, setup_gen_rows)
     }
     for (int r = 0; r < nrows; ++r) {
         for (auto& v : lds2) v = NAN;

@@ -9,6 +9,12 @@ for h, n in ((10, 4096), (10, 16384), (16, 8192), (20, 8192)):
     foot = np.ascontiguousarray((sc["foot"].reshape(n, 1, 4, 3) - vd * sc["params"]["dt"] * np.arange(h).reshape(1, h, 1, 1) * 40.0).reshape(n, h * 12))
     sw = rng.integers(0, h + 1, (n, 4)); first = rng.integers(0, 2, (n, 4))
     contact = np.ascontiguousarray(np.where(np.arange(h).reshape(1, h, 1) < sw[:, None, :], first[:, None, :], 1 - first[:, None, :]).astype(np.uint8).reshape(n, h * 4))
+    if os.environ.get("A1_PROBE_NO_RUIZ"):   # what of the set-up kernel is NOT the Ruiz passes (formation, gradient, hot state, hand-off record): the same launch with scaling = 0
+        with pkg.Engine(pkg.make_config(sc["params"], h, warm_start=0, scaling=0, max_iter=25), n, 0) as eng:
+            st = []
+            for _ in range(4):
+                eng.set_schedule(True); eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, 12, contact, 4); st.append(eng.last_stage_ms())
+            print(h, n, "   scaling = 0 (no Ruiz passes): set-up %.3f ms" % np.median(np.array(st[1:]), axis=0)[0])
     with pkg.Engine(pkg.make_config(sc["params"], h, warm_start=0), n, 0) as eng:
         st = []
         for _ in range(4):
