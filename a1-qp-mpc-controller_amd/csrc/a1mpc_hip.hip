@@ -2608,6 +2608,7 @@ struct a1mpc_sharded_s {
     std::vector<ncclComm_t> comm;
     std::vector<hipEvent_t> ev;             // per shard: "my part of this call is finished"
     bool broken = false;                    // an error inside an open RCCL group: the communicators were aborted, the handle only accepts a1mpc_sharded_destroy
+    long long last_scatter_bytes = 0, last_gather_bytes = 0;   // what the last solve moved from the root to the other shards and back (a1mpc_sharded_last_transfer)
 };
 static void shard_range(int n, int g, int G, int* start, int* count) {
     const int base = n / G, rem = n % G;
@@ -2682,26 +2683,67 @@ a1mpc_status a1mpc_sharded_info(a1mpc_sharded S, int32_t* n_shards, int32_t* dev
     return A1MPC_OK;
 }
 
-a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double* x0, const double* x_ref, const double* R_world, const double* foot_abs,
-                                       const uint8_t* contact, double* grf_body_out, int32_t* iters_out, int32_t* status_out) {
+// One implementation behind the four entry points (round 6): inputs as (x0, x_ref) or as the compact tick records (S/A1RobotControl.cpp:452-488), in HOST
+// arrays (snapshotted into the pinned mirror first) or in DEVICE arrays resident on shard 0's GPU (the root: the fleet's state lives there, shards are fed over xGMI --
+// peer copies with transport 0, grouped ncclSend / ncclRecv with transport 1 -- and their results come back into the caller's arrays on the root).  Every shard's engine
+// handle carries its own warm start / update-path workspace: with cfg.warm_start = 1 | 2 and a constant n the closed loop of a1mpc_solve_batch* runs unchanged, shard by shard.
+struct ShardedIo {
+    bool device = false;                      // the arrays below live on shard 0's device (else: host)
+    const double *x0 = nullptr, *xref = nullptr, *tick = nullptr, *R = nullptr, *foot = nullptr;
+    const uint8_t* contact = nullptr;
+    double* grf = nullptr; int32_t *iters = nullptr, *status = nullptr;
+    void* stream = nullptr;                   // device form: the root-device stream the inputs were produced on (NULL: they are ready)
+};
+static a1mpc_status sharded_solve_impl(a1mpc_sharded S, int32_t n, const ShardedIo& io) {
     if (!S) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
-    if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !grf_body_out) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    const bool ticks = io.tick != nullptr;
+    if (n < 0 || (!ticks && (!io.x0 || !io.xref)) || !io.R || !io.foot || !io.contact || !io.grf) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
     if (n > S->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_sharded_create");
     if (S->broken) return fail(A1MPC_ERR_HIP, "an earlier call failed inside an RCCL group and the communicators were aborted: destroy this handle and create a new one");
+    if (ticks && S->horizon < 2) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "tick records need horizon >= 2");
     if (n == 0) return A1MPC_OK;
     const size_t N = n, H = S->horizon, G = S->ndev;
-    // pinned snapshot (the caller's program mutates its arrays concurrently, see a1mpc.h), field after field like the device layout
+    // the input fields of a QP: bytes per QP, where the whole batch lies (host forms: the pinned snapshot `pin` and, transport 1, the root staging `root`; device forms: the
+    // caller's array on the root device) and which staging buffer of a shard's engine handle receives a slice (tick records ride in the x_ref buffer: 13 H >= 22)
+    struct Field { size_t bytes; const char* pin; const char* root; int which; };
+    Field in[5]; int nin = 0;
     char* p = S->pin;
-    double* p_x0 = reinterpret_cast<double*>(p); p += N * 13 * sizeof(double);
-    double* p_xr = reinterpret_cast<double*>(p); p += N * 13 * H * sizeof(double);
-    double* p_R = reinterpret_cast<double*>(p); p += N * 9 * sizeof(double);
-    double* p_f = reinterpret_cast<double*>(p); p += N * 12 * sizeof(double);
-    double* p_grf = reinterpret_cast<double*>(p); p += N * 12 * sizeof(double);
-    int32_t* p_it = reinterpret_cast<int32_t*>(p); p += N * sizeof(int32_t);
-    int32_t* p_st = reinterpret_cast<int32_t*>(p); p += N * sizeof(int32_t);
-    uint8_t* p_c = reinterpret_cast<uint8_t*>(p);
-    std::memcpy(p_x0, x0, N * 13 * sizeof(double)); std::memcpy(p_xr, x_ref, N * 13 * H * sizeof(double)); std::memcpy(p_R, R_world, N * 9 * sizeof(double));
-    std::memcpy(p_f, foot_abs, N * 12 * sizeof(double)); std::memcpy(p_c, contact, N * 4);
+    auto take = [&](size_t bytes) { char* q = p; p += N * bytes; return q; };
+    char* p_a = take(ticks ? 22 * sizeof(double) : 13 * sizeof(double));
+    char* p_b = ticks ? nullptr : take(13 * H * sizeof(double));
+    char* p_R = take(9 * sizeof(double)); char* p_f = take(12 * sizeof(double));
+    double* p_grf = reinterpret_cast<double*>(take(12 * sizeof(double)));
+    int32_t* p_it = reinterpret_cast<int32_t*>(take(sizeof(int32_t))); int32_t* p_st = reinterpret_cast<int32_t*>(take(sizeof(int32_t)));
+    char* p_c = take(4);
+    if (io.device) {
+        if (ticks) in[nin++] = {22 * sizeof(double), nullptr, reinterpret_cast<const char*>(io.tick), 1};
+        else { in[nin++] = {13 * sizeof(double), nullptr, reinterpret_cast<const char*>(io.x0), 0}; in[nin++] = {13 * H * sizeof(double), nullptr, reinterpret_cast<const char*>(io.xref), 1}; }
+        in[nin++] = {9 * sizeof(double), nullptr, reinterpret_cast<const char*>(io.R), 2}; in[nin++] = {12 * sizeof(double), nullptr, reinterpret_cast<const char*>(io.foot), 3};
+        in[nin++] = {4, nullptr, reinterpret_cast<const char*>(io.contact), 4};
+    } else {
+        // pinned snapshot (the caller's program mutates its arrays concurrently, see a1mpc.h), field after field like the device layout
+        if (ticks) { std::memcpy(p_a, io.tick, N * 22 * sizeof(double)); in[nin++] = {22 * sizeof(double), p_a, reinterpret_cast<const char*>(S->r_xref), 1}; }
+        else {
+            std::memcpy(p_a, io.x0, N * 13 * sizeof(double)); std::memcpy(p_b, io.xref, N * 13 * H * sizeof(double));
+            in[nin++] = {13 * sizeof(double), p_a, reinterpret_cast<const char*>(S->r_x0), 0}; in[nin++] = {13 * H * sizeof(double), p_b, reinterpret_cast<const char*>(S->r_xref), 1};
+        }
+        std::memcpy(p_R, io.R, N * 9 * sizeof(double)); std::memcpy(p_f, io.foot, N * 12 * sizeof(double)); std::memcpy(p_c, io.contact, N * 4);
+        in[nin++] = {9 * sizeof(double), p_R, reinterpret_cast<const char*>(S->r_R), 2}; in[nin++] = {12 * sizeof(double), p_f, reinterpret_cast<const char*>(S->r_foot), 3};
+        in[nin++] = {4, p_c, reinterpret_cast<const char*>(S->r_contact), 4};
+    }
+    auto shard_buf = [](a1mpc_handle h, int which) -> char* {
+        switch (which) {
+            case 0: return reinterpret_cast<char*>(h->d_x0);
+            case 1: return reinterpret_cast<char*>(h->d_xref);
+            case 2: return reinterpret_cast<char*>(h->d_R);
+            case 3: return reinterpret_cast<char*>(h->d_foot);
+        }
+        return reinterpret_cast<char*>(h->d_contact);
+    };
+    // where the results of the whole batch are collected on the root device (device forms: the caller's arrays; host forms with transport 1: the root staging)
+    double* root_grf = io.device ? io.grf : S->r_grf;
+    int32_t* root_it = io.device ? io.iters : S->r_iters;
+    int32_t* root_st = io.device ? io.status : S->r_status;
     // Error handling of a multi-device call: nothing may be left behind -- an open RCCL group is closed and every shard's stream is drained (their async copies
     // target the shared pinned mirror, which the next call overwrites) before the status goes back to the caller.
     bool group_open = false;
@@ -2709,7 +2751,7 @@ a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double*
         if (group_open && g_rccl.GroupEnd) {
             // A failure between paired ncclSend / ncclRecv calls leaves point-to-point operations without their partner: GroupEnd submits them and a stream
             // synchronise would then wait for ever.  Close the group, ABORT every communicator -- that terminates the operations in flight -- and only
-            // then drain the streams; the handle is unusable afterwards (a1mpc_sharded_solve_batch refuses, a1mpc_sharded_destroy frees it).
+            // then drain the streams; the handle is unusable afterwards (the solve entries refuse, a1mpc_sharded_destroy frees it).
             (void)g_rccl.GroupEnd(); group_open = false;
             for (size_t g = 0; g < S->comm.size(); ++g)
                 if (S->comm[g]) { if (hipSetDevice(S->dev[g]) == hipSuccess) (void)g_rccl.CommAbort(S->comm[g]); S->comm[g] = nullptr; }
@@ -2719,6 +2761,28 @@ a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double*
     };
 #define A1_SH_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { drain(); return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
 #define A1_SH_ST(call) do { a1mpc_status s_ = (call); if (s_ != A1MPC_OK) { drain(); return s_; } } while (0)
+    a1mpc_handle h0 = S->h[0];
+    const int dev0 = h0->device;
+    S->last_scatter_bytes = S->last_gather_bytes = 0;
+    // device forms: every shard's stream starts behind what the caller has queued on `stream` (an event of the root device; cross-device waits are stream-ordered)
+    if (io.device && io.stream != nullptr) {
+        A1_SH_HIP(hipSetDevice(dev0));
+        A1_SH_HIP(hipEventRecord(S->ev[0], static_cast<hipStream_t>(io.stream)));
+        for (size_t g = 0; g < G; ++g) { A1_SH_HIP(hipSetDevice(S->h[g]->device)); A1_SH_HIP(hipStreamWaitEvent(S->h[g]->stream, S->ev[0], 0)); }
+    }
+    // the solve of shard g: on its handle's staging buffers, or -- shard 0 of the device forms and of transport 1 -- in place on the root arrays
+    auto solve_shard = [&](size_t g, int c, bool in_place, size_t o) -> a1mpc_status {
+        a1mpc_handle h = S->h[g];
+        if (in_place) {
+            const char* base[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+            for (int f = 0; f < nin; ++f) base[in[f].which] = in[f].root + o * in[f].bytes;
+            return solve_device_impl(h, c, ticks ? reinterpret_cast<const double*>(base[1]) : nullptr, ticks ? nullptr : reinterpret_cast<const double*>(base[0]),
+                                     ticks ? nullptr : reinterpret_cast<const double*>(base[1]), reinterpret_cast<const double*>(base[2]), reinterpret_cast<const double*>(base[3]),
+                                     reinterpret_cast<const uint8_t*>(base[4]), root_grf + o * 12, nullptr, root_it ? root_it + o : h->d_iters, root_st ? root_st + o : h->d_status, h->stream);
+        }
+        return solve_device_impl(h, c, ticks ? h->d_xref : nullptr, ticks ? nullptr : h->d_x0, ticks ? nullptr : h->d_xref, h->d_R, h->d_foot, h->d_contact, h->d_grf, nullptr,
+                                 h->d_iters, h->d_status, h->stream);
+    };
     if (S->transport == 0) {
         for (size_t g = 0; g < G; ++g) {   // everything asynchronous: the G devices copy and solve concurrently
             int s0 = 0, c = 0;
@@ -2729,31 +2793,42 @@ a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double*
             hipStream_t st = h->stream;
             A1_SH_ST(order_streams(h, st));
             const size_t o = s0, C = c;
-            A1_SH_HIP(hipMemcpyAsync(h->d_x0, p_x0 + o * 13, C * 13 * sizeof(double), hipMemcpyHostToDevice, st));
-            A1_SH_HIP(hipMemcpyAsync(h->d_xref, p_xr + o * 13 * H, C * 13 * H * sizeof(double), hipMemcpyHostToDevice, st));
-            A1_SH_HIP(hipMemcpyAsync(h->d_R, p_R + o * 9, C * 9 * sizeof(double), hipMemcpyHostToDevice, st));
-            A1_SH_HIP(hipMemcpyAsync(h->d_foot, p_f + o * 12, C * 12 * sizeof(double), hipMemcpyHostToDevice, st));
-            A1_SH_HIP(hipMemcpyAsync(h->d_contact, p_c + o * 4, C * 4, hipMemcpyHostToDevice, st));
-            A1_SH_ST(solve_device_impl(h, c, nullptr, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_contact, h->d_grf, nullptr, h->d_iters, h->d_status, st));
-            A1_SH_HIP(hipMemcpyAsync(p_grf + o * 12, h->d_grf, C * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
-            A1_SH_HIP(hipMemcpyAsync(p_it + o, h->d_iters, C * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            A1_SH_HIP(hipMemcpyAsync(p_st + o, h->d_status, C * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            const bool in_place = io.device && g == 0;   // shard 0 of a device-resident batch reads and writes the caller's arrays
+            if (!in_place) {
+                for (int f = 0; f < nin; ++f) {
+                    if (io.device && h->device != dev0) A1_SH_HIP(hipMemcpyPeerAsync(shard_buf(h, in[f].which), h->device, in[f].root + o * in[f].bytes, dev0, C * in[f].bytes, st));   // over xGMI
+                    else if (io.device) A1_SH_HIP(hipMemcpyAsync(shard_buf(h, in[f].which), in[f].root + o * in[f].bytes, C * in[f].bytes, hipMemcpyDeviceToDevice, st));   // (a second shard on the root's own GPU)
+                    else A1_SH_HIP(hipMemcpyAsync(shard_buf(h, in[f].which), in[f].pin + o * in[f].bytes, C * in[f].bytes, hipMemcpyHostToDevice, st));
+                    S->last_scatter_bytes += static_cast<long long>(C * in[f].bytes);
+                }
+            }
+            A1_SH_ST(solve_shard(g, c, in_place, o));
+            if (in_place) continue;
+            if (io.device && h->device != dev0) {
+                A1_SH_HIP(hipMemcpyPeerAsync(root_grf + o * 12, dev0, h->d_grf, h->device, C * 12 * sizeof(double), st));
+                if (root_it) A1_SH_HIP(hipMemcpyPeerAsync(root_it + o, dev0, h->d_iters, h->device, C * sizeof(int32_t), st));
+                if (root_st) A1_SH_HIP(hipMemcpyPeerAsync(root_st + o, dev0, h->d_status, h->device, C * sizeof(int32_t), st));
+            } else if (io.device) {
+                A1_SH_HIP(hipMemcpyAsync(root_grf + o * 12, h->d_grf, C * 12 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                if (root_it) A1_SH_HIP(hipMemcpyAsync(root_it + o, h->d_iters, C * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+                if (root_st) A1_SH_HIP(hipMemcpyAsync(root_st + o, h->d_status, C * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            } else {
+                A1_SH_HIP(hipMemcpyAsync(p_grf + o * 12, h->d_grf, C * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+                A1_SH_HIP(hipMemcpyAsync(p_it + o, h->d_iters, C * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                A1_SH_HIP(hipMemcpyAsync(p_st + o, h->d_status, C * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            }
+            S->last_gather_bytes += static_cast<long long>(C * (12 * sizeof(double) + 2 * sizeof(int32_t)));
         }
         for (size_t g = 0; g < G; ++g) { A1_SH_HIP(hipSetDevice(S->h[g]->device)); A1_SH_HIP(hipStreamSynchronize(S->h[g]->stream)); }
     } else {
         // every RCCL call is issued with the device of ITS communicator current (one thread drives all the communicators of ncclCommInitAll: the stream
         // handed to a call belongs to that device)
 #define A1_NCCL(dev, call) do { A1_SH_HIP(hipSetDevice(dev)); ncclResult_t r_ = (call); if (r_ != ncclSuccess) { drain(); return fail(A1MPC_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); } } while (0)
-        a1mpc_handle h0 = S->h[0];
-        const int dev0 = h0->device;
         A1_SH_HIP(hipSetDevice(dev0));
         hipStream_t s0 = h0->stream;
         A1_SH_ST(order_streams(h0, s0));
-        A1_SH_HIP(hipMemcpyAsync(S->r_x0, p_x0, N * 13 * sizeof(double), hipMemcpyHostToDevice, s0));
-        A1_SH_HIP(hipMemcpyAsync(S->r_xref, p_xr, N * 13 * H * sizeof(double), hipMemcpyHostToDevice, s0));
-        A1_SH_HIP(hipMemcpyAsync(S->r_R, p_R, N * 9 * sizeof(double), hipMemcpyHostToDevice, s0));
-        A1_SH_HIP(hipMemcpyAsync(S->r_foot, p_f, N * 12 * sizeof(double), hipMemcpyHostToDevice, s0));
-        A1_SH_HIP(hipMemcpyAsync(S->r_contact, p_c, N * 4, hipMemcpyHostToDevice, s0));
+        if (!io.device)   // host form: the whole batch to the root staging in one copy per field
+            for (int f = 0; f < nin; ++f) A1_SH_HIP(hipMemcpyAsync(const_cast<char*>(in[f].root), in[f].pin, N * in[f].bytes, hipMemcpyHostToDevice, s0));
         for (size_t g = 1; g < G; ++g) { A1_SH_HIP(hipSetDevice(S->h[g]->device)); A1_SH_ST(order_streams(S->h[g], S->h[g]->stream)); }
         // scatter: shard g > 0 receives its slice of every field from shard 0's device (root drives all its xGMI links concurrently)
         A1_NCCL(dev0, g_rccl.GroupStart()); group_open = true;
@@ -2764,16 +2839,11 @@ a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double*
             a1mpc_handle h = S->h[g];
             const size_t o = st0, C = c;
             const int gi = static_cast<int>(g);
-            A1_NCCL(dev0, g_rccl.Send(S->r_x0 + o * 13, C * 13, ncclFloat64, gi, S->comm[0], s0));
-            A1_NCCL(dev0, g_rccl.Send(S->r_xref + o * 13 * H, C * 13 * H, ncclFloat64, gi, S->comm[0], s0));
-            A1_NCCL(dev0, g_rccl.Send(S->r_R + o * 9, C * 9, ncclFloat64, gi, S->comm[0], s0));
-            A1_NCCL(dev0, g_rccl.Send(S->r_foot + o * 12, C * 12, ncclFloat64, gi, S->comm[0], s0));
-            A1_NCCL(dev0, g_rccl.Send(S->r_contact + o * 4, C * 4, ncclUint8, gi, S->comm[0], s0));
-            A1_NCCL(h->device, g_rccl.Recv(h->d_x0, C * 13, ncclFloat64, 0, S->comm[g], h->stream));
-            A1_NCCL(h->device, g_rccl.Recv(h->d_xref, C * 13 * H, ncclFloat64, 0, S->comm[g], h->stream));
-            A1_NCCL(h->device, g_rccl.Recv(h->d_R, C * 9, ncclFloat64, 0, S->comm[g], h->stream));
-            A1_NCCL(h->device, g_rccl.Recv(h->d_foot, C * 12, ncclFloat64, 0, S->comm[g], h->stream));
-            A1_NCCL(h->device, g_rccl.Recv(h->d_contact, C * 4, ncclUint8, 0, S->comm[g], h->stream));
+            for (int f = 0; f < nin; ++f) {
+                A1_NCCL(dev0, g_rccl.Send(in[f].root + o * in[f].bytes, C * in[f].bytes, ncclUint8, gi, S->comm[0], s0));
+                A1_NCCL(h->device, g_rccl.Recv(shard_buf(h, in[f].which), C * in[f].bytes, ncclUint8, 0, S->comm[g], h->stream));
+                S->last_scatter_bytes += static_cast<long long>(C * in[f].bytes);
+            }
         }
         group_open = false;
         A1_NCCL(dev0, g_rccl.GroupEnd());
@@ -2782,10 +2852,8 @@ a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double*
             int st0 = 0, c = 0;
             shard_range(n, static_cast<int>(g), static_cast<int>(G), &st0, &c);
             if (c == 0) continue;
-            a1mpc_handle h = S->h[g];
-            A1_SH_HIP(hipSetDevice(h->device));
-            if (g == 0) A1_SH_ST(solve_device_impl(h, c, nullptr, S->r_x0, S->r_xref, S->r_R, S->r_foot, S->r_contact, S->r_grf, nullptr, S->r_iters, S->r_status, h->stream));
-            else A1_SH_ST(solve_device_impl(h, c, nullptr, h->d_x0, h->d_xref, h->d_R, h->d_foot, h->d_contact, h->d_grf, nullptr, h->d_iters, h->d_status, h->stream));
+            A1_SH_HIP(hipSetDevice(S->h[g]->device));
+            A1_SH_ST(solve_shard(g, c, g == 0, static_cast<size_t>(st0)));
         }
         // gather: results of shard g > 0 back to their slice of the root buffers
         A1_NCCL(dev0, g_rccl.GroupStart()); group_open = true;
@@ -2797,28 +2865,70 @@ a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double*
             const size_t o = st0, C = c;
             const int gi = static_cast<int>(g);
             A1_NCCL(h->device, g_rccl.Send(h->d_grf, C * 12, ncclFloat64, 0, S->comm[g], h->stream));
-            A1_NCCL(h->device, g_rccl.Send(h->d_iters, C, ncclInt32, 0, S->comm[g], h->stream));
-            A1_NCCL(h->device, g_rccl.Send(h->d_status, C, ncclInt32, 0, S->comm[g], h->stream));
-            A1_NCCL(dev0, g_rccl.Recv(S->r_grf + o * 12, C * 12, ncclFloat64, gi, S->comm[0], s0));
-            A1_NCCL(dev0, g_rccl.Recv(S->r_iters + o, C, ncclInt32, gi, S->comm[0], s0));
-            A1_NCCL(dev0, g_rccl.Recv(S->r_status + o, C, ncclInt32, gi, S->comm[0], s0));
+            A1_NCCL(dev0, g_rccl.Recv(root_grf + o * 12, C * 12, ncclFloat64, gi, S->comm[0], s0));
+            if (root_it) { A1_NCCL(h->device, g_rccl.Send(h->d_iters, C, ncclInt32, 0, S->comm[g], h->stream)); A1_NCCL(dev0, g_rccl.Recv(root_it + o, C, ncclInt32, gi, S->comm[0], s0)); }
+            if (root_st) { A1_NCCL(h->device, g_rccl.Send(h->d_status, C, ncclInt32, 0, S->comm[g], h->stream)); A1_NCCL(dev0, g_rccl.Recv(root_st + o, C, ncclInt32, gi, S->comm[0], s0)); }
+            S->last_gather_bytes += static_cast<long long>(C * (12 * sizeof(double) + 2 * sizeof(int32_t)));
         }
         group_open = false;
         A1_NCCL(dev0, g_rccl.GroupEnd());
         // the RCCL operations ran on the handles' streams behind their solves: the handles' "last launch" events move with them
         for (size_t g = 0; g < G; ++g) { A1_SH_HIP(hipSetDevice(S->h[g]->device)); A1_SH_ST(mark_launched(S->h[g], S->h[g]->stream)); }
         A1_SH_HIP(hipSetDevice(dev0));
-        A1_SH_HIP(hipMemcpyAsync(p_grf, S->r_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s0));
-        A1_SH_HIP(hipMemcpyAsync(p_it, S->r_iters, N * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
-        A1_SH_HIP(hipMemcpyAsync(p_st, S->r_status, N * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
+        if (!io.device) {
+            A1_SH_HIP(hipMemcpyAsync(p_grf, S->r_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s0));
+            A1_SH_HIP(hipMemcpyAsync(p_it, S->r_iters, N * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
+            A1_SH_HIP(hipMemcpyAsync(p_st, S->r_status, N * sizeof(int32_t), hipMemcpyDeviceToHost, s0));
+        }
         for (size_t g = 0; g < G; ++g) { A1_SH_HIP(hipSetDevice(S->h[g]->device)); A1_SH_HIP(hipStreamSynchronize(S->h[g]->stream)); }
 #undef A1_NCCL
     }
 #undef A1_SH_HIP
 #undef A1_SH_ST
-    std::memcpy(grf_body_out, p_grf, N * 12 * sizeof(double));
-    if (iters_out) std::memcpy(iters_out, p_it, N * sizeof(int32_t));
-    if (status_out) std::memcpy(status_out, p_st, N * sizeof(int32_t));
+    if (!io.device) {
+        std::memcpy(io.grf, p_grf, N * 12 * sizeof(double));
+        if (io.iters) std::memcpy(io.iters, p_it, N * sizeof(int32_t));
+        if (io.status) std::memcpy(io.status, p_st, N * sizeof(int32_t));
+    }
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded S, int32_t n, const double* x0, const double* x_ref, const double* R_world, const double* foot_abs,
+                                       const uint8_t* contact, double* grf_body_out, int32_t* iters_out, int32_t* status_out) {
+    ShardedIo io; io.x0 = x0; io.xref = x_ref; io.R = R_world; io.foot = foot_abs; io.contact = contact; io.grf = grf_body_out; io.iters = iters_out; io.status = status_out;
+    if (!x0 || !x_ref) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    return sharded_solve_impl(S, n, io);
+}
+a1mpc_status a1mpc_sharded_solve_batch_ticks(a1mpc_sharded S, int32_t n, const double* tick, const double* R_world, const double* foot_abs, const uint8_t* contact,
+                                             double* grf_body_out, int32_t* iters_out, int32_t* status_out) {
+    ShardedIo io; io.tick = tick; io.R = R_world; io.foot = foot_abs; io.contact = contact; io.grf = grf_body_out; io.iters = iters_out; io.status = status_out;
+    if (!tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    return sharded_solve_impl(S, n, io);
+}
+a1mpc_status a1mpc_sharded_solve_batch_device(a1mpc_sharded S, int32_t n, const double* d_x0, const double* d_x_ref, const double* d_R_world, const double* d_foot_abs,
+                                              const uint8_t* d_contact, double* d_grf_body_out, int32_t* d_iters_out, int32_t* d_status_out, void* hip_stream) {
+    ShardedIo io; io.device = true; io.x0 = d_x0; io.xref = d_x_ref; io.R = d_R_world; io.foot = d_foot_abs; io.contact = d_contact; io.grf = d_grf_body_out;
+    io.iters = d_iters_out; io.status = d_status_out; io.stream = hip_stream;
+    if (!d_x0 || !d_x_ref) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    return sharded_solve_impl(S, n, io);
+}
+a1mpc_status a1mpc_sharded_solve_batch_ticks_device(a1mpc_sharded S, int32_t n, const double* d_tick, const double* d_R_world, const double* d_foot_abs,
+                                                    const uint8_t* d_contact, double* d_grf_body_out, int32_t* d_iters_out, int32_t* d_status_out, void* hip_stream) {
+    ShardedIo io; io.device = true; io.tick = d_tick; io.R = d_R_world; io.foot = d_foot_abs; io.contact = d_contact; io.grf = d_grf_body_out;
+    io.iters = d_iters_out; io.status = d_status_out; io.stream = hip_stream;
+    if (!d_tick) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    return sharded_solve_impl(S, n, io);
+}
+// shard g's engine handle (warm-start I/O, a1mpc_reset_warm_start, the instrumentation calls) and the bytes the last solve moved between the root and the other shards
+a1mpc_status a1mpc_sharded_handle(a1mpc_sharded S, int32_t shard, a1mpc_handle* out) {
+    if (!S || !out || shard < 0 || shard >= S->ndev) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle/out or shard out of range");
+    *out = S->h[shard];
+    return A1MPC_OK;
+}
+a1mpc_status a1mpc_sharded_last_transfer(a1mpc_sharded S, int64_t* scatter_bytes, int64_t* gather_bytes) {
+    if (!S) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (scatter_bytes) *scatter_bytes = S->last_scatter_bytes;
+    if (gather_bytes) *gather_bytes = S->last_gather_bytes;
     return A1MPC_OK;
 }
 

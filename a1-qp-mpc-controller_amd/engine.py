@@ -56,7 +56,8 @@ class TickBuffers(C.Structure):  # a1mpc_tick_buffers: device pointers, in the h
     _fields_ = [(k, C.c_void_p) for k in TICK_BUFFER_FIELDS]
 
 
-EXPORTS = ["a1mpc_set_timing", "a1mpc_default_tick_params", "a1mpc_control_tick_device", "a1mpc_last_control_tick_ms", "a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_get_workspace_z", "a1mpc_get_workspace_scaling", "a1mpc_last_warm_start_mode", "a1mpc_set_profiling", "a1mpc_last_stage_cycles", "a1mpc_last_tick_stage_cycles", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
+EXPORTS = ["a1mpc_set_timing", "a1mpc_default_tick_params", "a1mpc_control_tick_device", "a1mpc_last_control_tick_ms", "a1mpc_last_stage_ms", "a1mpc_sharded_create", "a1mpc_sharded_solve_batch", "a1mpc_sharded_solve_batch_ticks", "a1mpc_sharded_solve_batch_device", "a1mpc_sharded_solve_batch_ticks_device", "a1mpc_sharded_handle",
+           "a1mpc_sharded_last_transfer", "a1mpc_sharded_info", "a1mpc_sharded_destroy", "a1mpc_terrain_batch", "a1mpc_form_qp_batch", "a1mpc_solve_batch_strided", "a1mpc_solve_batch_strided_device", "a1mpc_update_config", "a1mpc_warm_start", "a1mpc_get_warm_start", "a1mpc_get_workspace_z", "a1mpc_get_workspace_scaling", "a1mpc_last_warm_start_mode", "a1mpc_set_profiling", "a1mpc_last_stage_cycles", "a1mpc_last_tick_stage_cycles", "a1mpc_update_plan_batch_device", "a1mpc_swing_legs_batch_device", "a1mpc_contact_terrain_batch_device", "a1mpc_leg_state_batch_device",
            "a1mpc_ekf_update_batch_device", "a1mpc_joint_torques_batch_device", "a1mpc_ekf_update_batch", "a1mpc_reset_ekf_state", "a1mpc_leg_state_batch", "a1mpc_swing_legs_batch", "a1mpc_default_contact_config", "a1mpc_contact_terrain_batch", "a1mpc_reset_contact_state", "a1mpc_default_gait_config", "a1mpc_update_plan_batch", "a1mpc_joint_torques_batch", "a1mpc_set_schedule", "a1mpc_default_config", "a1mpc_default_balance_config", "a1mpc_create", "a1mpc_destroy", "a1mpc_solve_batch",
            "a1mpc_solve_batch_device", "a1mpc_solve_batch_ticks", "a1mpc_solve_batch_ticks_device", "a1mpc_balance_solve_batch", "a1mpc_reset_warm_start", "a1mpc_last_kernel_ms",
            "a1mpc_kernel_info", "a1mpc_last_nfact", "a1mpc_status_string", "a1mpc_last_error", "a1mpc_build_info", "a1mpc_pipeline_create", "a1mpc_pipeline_submit_device", "a1mpc_pipeline_submit",
@@ -115,6 +116,12 @@ def load_library(path=None):
     lib.a1mpc_sharded_create.argtypes = [C.POINTER(Config), i32, i32p, i32, i32, C.POINTER(vp)]; lib.a1mpc_sharded_create.restype = C.c_int
     lib.a1mpc_sharded_solve_batch.argtypes = [vp, i32, dp, dp, dp, dp, u8p, dp, i32p, i32p]; lib.a1mpc_sharded_solve_batch.restype = C.c_int
     lib.a1mpc_sharded_info.argtypes = [vp, i32p, i32p, i32p]; lib.a1mpc_sharded_info.restype = C.c_int
+    if path == _build.LIB_PATH or hasattr(lib, "a1mpc_sharded_solve_batch_ticks"):   # (round 6)
+        lib.a1mpc_sharded_solve_batch_ticks.argtypes = [vp, i32, dp, dp, dp, u8p, dp, i32p, i32p]; lib.a1mpc_sharded_solve_batch_ticks.restype = C.c_int
+        lib.a1mpc_sharded_solve_batch_device.argtypes = [vp, i32] + [vp] * 9; lib.a1mpc_sharded_solve_batch_device.restype = C.c_int
+        lib.a1mpc_sharded_solve_batch_ticks_device.argtypes = [vp, i32] + [vp] * 8; lib.a1mpc_sharded_solve_batch_ticks_device.restype = C.c_int
+        lib.a1mpc_sharded_handle.argtypes = [vp, i32, C.POINTER(vp)]; lib.a1mpc_sharded_handle.restype = C.c_int
+        lib.a1mpc_sharded_last_transfer.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]; lib.a1mpc_sharded_last_transfer.restype = C.c_int
     lib.a1mpc_sharded_destroy.argtypes = [vp]; lib.a1mpc_sharded_destroy.restype = None
     lib.a1mpc_pipeline_create.argtypes = [C.POINTER(Config), i32, i32, i32, C.POINTER(vp)]; lib.a1mpc_pipeline_create.restype = C.c_int
     lib.a1mpc_pipeline_submit_device.argtypes = [vp, i32, i32, i32] + [vp] * 9 + [vp, i32p]; lib.a1mpc_pipeline_submit_device.restype = C.c_int
@@ -633,6 +640,43 @@ class ShardedEngine:
         rc = self.lib.a1mpc_sharded_solve_batch(self._h, n, _dp(x0), _dp(xref), _dp(R), _dp(foot), contact.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(grf), _ip(iters), _ip(status))
         _check(self.lib, rc, "a1mpc_sharded_solve_batch")
         return dict(grf=grf, iters=iters, status=status)
+
+    def solve_ticks(self, tick, R, foot, contact):
+        """a1mpc_sharded_solve_batch_ticks: the compact 22-number tick records, host arrays"""
+        tick = _f64(tick, (-1, 22)); n = tick.shape[0]
+        R = _f64(R, (n, 9)); foot = _f64(foot, (n, 12)); contact = np.ascontiguousarray(contact, dtype=np.uint8).reshape(n, 4)
+        grf = np.zeros((n, 12)); iters = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
+        rc = self.lib.a1mpc_sharded_solve_batch_ticks(self._h, n, _dp(tick), _dp(R), _dp(foot), contact.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(grf), _ip(iters), _ip(status))
+        _check(self.lib, rc, "a1mpc_sharded_solve_batch_ticks")
+        return dict(grf=grf, iters=iters, status=status)
+
+    def solve_device(self, n, d_x0, d_xref, d_R, d_foot, d_contact, d_grf, d_iters=None, d_status=None, stream=None):
+        """a1mpc_sharded_solve_batch_device: the batch resident on shard 0's GPU (torch tensors of that device)"""
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+        rc = self.lib.a1mpc_sharded_solve_batch_device(self._h, int(n), ptr(d_x0), ptr(d_xref), ptr(d_R), ptr(d_foot), ptr(d_contact), ptr(d_grf), ptr(d_iters), ptr(d_status),
+                                                       C.c_void_p(int(stream)) if stream else None)
+        _check(self.lib, rc, "a1mpc_sharded_solve_batch_device")
+
+    def solve_ticks_device(self, n, d_tick, d_R, d_foot, d_contact, d_grf, d_iters=None, d_status=None, stream=None):
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+        rc = self.lib.a1mpc_sharded_solve_batch_ticks_device(self._h, int(n), ptr(d_tick), ptr(d_R), ptr(d_foot), ptr(d_contact), ptr(d_grf), ptr(d_iters), ptr(d_status),
+                                                             C.c_void_p(int(stream)) if stream else None)
+        _check(self.lib, rc, "a1mpc_sharded_solve_batch_ticks_device")
+
+    def last_transfer(self):
+        a = C.c_int64(); b = C.c_int64()
+        _check(self.lib, self.lib.a1mpc_sharded_last_transfer(self._h, C.byref(a), C.byref(b)), "a1mpc_sharded_last_transfer")
+        return dict(scatter_bytes=int(a.value), gather_bytes=int(b.value))
+
+    def shard_handle(self, g):
+        h = C.c_void_p()
+        _check(self.lib, self.lib.a1mpc_sharded_handle(self._h, int(g), C.byref(h)), "a1mpc_sharded_handle")
+        return h
+
+    def reset_warm_start(self):
+        n = self.info()["n_shards"]
+        for g in range(n):
+            _check(self.lib, self.lib.a1mpc_reset_warm_start(self.shard_handle(g)), "a1mpc_reset_warm_start")
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -525,6 +525,24 @@ a1mpc_status a1mpc_sharded_create(const a1mpc_config* cfg, int32_t max_batch, co
 a1mpc_status a1mpc_sharded_solve_batch(a1mpc_sharded s, int32_t n, const double* x0, const double* x_ref, const double* R_world,
                                        const double* foot_abs, const uint8_t* contact, double* grf_body_out, int32_t* iters_out,
                                        int32_t* status_out);
+/* Round 6: the closed loop on all GPUs.  The same sharded solve for the compact tick records (a1mpc_solve_batch_ticks: S/A1RobotControl.cpp:452-488 on the device), and for a batch that
+ * is RESIDENT ON SHARD 0's GPU (device pointers of that device; layouts of a1mpc_solve_batch_device / _ticks_device): the root feeds the other shards over xGMI -- peer copies
+ * with transport 0, grouped ncclSend / ncclRecv with transport 1 -- solves its own shard in place and collects every shard's GRFs / iterations / status in the caller's output
+ * arrays on the root ("RCCL over xGMI only to scatter inputs / gather GRFs", the north_star).  hip_stream: a stream of the root device the inputs were produced on (the shards
+ * start behind it; NULL: the inputs are ready).  The calls return when the outputs are complete.  Every shard's engine handle carries its own warm start: with
+ * cfg.warm_start = 1 or 2 and a constant n, tick after tick through any of these entries is the closed loop of the single-GPU handle, shard by shard (a1mpc_sharded_handle
+ * gives a shard's handle for a1mpc_reset_warm_start / a1mpc_get_warm_start / the instrumentation calls).  a1mpc_sharded_last_transfer: the bytes the last solve moved from the
+ * root to the other shards and back (1968 B + 104 B per QP at h = 16). */
+a1mpc_status a1mpc_sharded_solve_batch_ticks(a1mpc_sharded s, int32_t n, const double* tick, const double* R_world, const double* foot_abs,
+                                             const uint8_t* contact, double* grf_body_out, int32_t* iters_out, int32_t* status_out);
+a1mpc_status a1mpc_sharded_solve_batch_device(a1mpc_sharded s, int32_t n, const double* d_x0, const double* d_x_ref, const double* d_R_world,
+                                              const double* d_foot_abs, const uint8_t* d_contact, double* d_grf_body_out, int32_t* d_iters_out,
+                                              int32_t* d_status_out, void* hip_stream);
+a1mpc_status a1mpc_sharded_solve_batch_ticks_device(a1mpc_sharded s, int32_t n, const double* d_tick, const double* d_R_world, const double* d_foot_abs,
+                                                    const uint8_t* d_contact, double* d_grf_body_out, int32_t* d_iters_out, int32_t* d_status_out,
+                                                    void* hip_stream);
+a1mpc_status a1mpc_sharded_handle(a1mpc_sharded s, int32_t shard, a1mpc_handle* out);
+a1mpc_status a1mpc_sharded_last_transfer(a1mpc_sharded s, int64_t* scatter_bytes, int64_t* gather_bytes);
 a1mpc_status a1mpc_sharded_info(a1mpc_sharded s, int32_t* n_shards, int32_t* devices_out, int32_t* transport);
 void a1mpc_sharded_destroy(a1mpc_sharded s);
 
