@@ -456,6 +456,50 @@ def other_config_rooflines(pkg, local, steps=4):
     return res
 
 
+def device_identity(local):
+    """which physical GPU this rank drives: PCI bus id + UUID (HIP runtime through ctypes, torch's device properties as the fall-back), host name"""
+    import socket
+    import ctypes as C
+    ident = {"host": socket.gethostname(), "local_device": int(local), "pci_bus_id": None, "uuid": None}
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        buf = C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(local)) == 0:
+            ident["pci_bus_id"] = buf.value.decode()
+        uu = (C.c_ubyte * 16)()
+        if hip.hipDeviceGetUuid(C.byref(uu), int(local)) == 0:
+            ident["uuid"] = bytes(uu).hex()
+    except Exception:
+        pass
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(int(local))
+        if ident["uuid"] is None and getattr(pr, "uuid", None) is not None:
+            ident["uuid"] = str(pr.uuid)
+        if ident["pci_bus_id"] is None and getattr(pr, "pci_bus_id", None) is not None:
+            ident["pci_bus_id"] = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}.0"
+        ident["name"] = pr.name
+    except Exception:
+        pass
+    return ident
+
+
+def participation(dist, rank, world, local, backend):
+    """Round 6: an N > 1 line proves which devices took part.  Every rank's (rank, host, PCI bus id, UUID) is gathered on rank 0; `distinct_devices` counts
+    the different physical GPUs among them, and the line is a SCALING POINT only if that equals the world size and the ranks talk over RCCL -- ranks sharing a GPU
+    (the one-GPU smoke test of this code path) are labelled, never counted."""
+    ident = dict(device_identity(local), rank=int(rank))
+    if world > 1:
+        allid = [None] * world
+        dist.all_gather_object(allid, ident)
+    else:
+        allid = [ident]
+    keys = {(d["host"], d.get("uuid") or d.get("pci_bus_id") or f"local{d['local_device']}") for d in allid}
+    return {"distinct_devices": len(keys), "world_size": int(world), "rccl_world_size": int(world) if (backend == "nccl" and world > 1) else 0, "backend": backend if world > 1 else "none",
+            "is_scaling_point": bool(len(keys) == world and (world == 1 or backend == "nccl")),
+            "device_ids": ";".join(f"r{d['rank']}@{d['host']}:{d.get('pci_bus_id')}:{(d.get('uuid') or '')[:16]}" for d in allid)}
+
+
 def strong_scaling_config4(pkg, args, rank, world, local, backend, dist):
     """BASELINE configs[3]: 65536 QPs, horizon 16, the whole batch resident in rank 0's HBM; a step = scatter the shards' inputs (one group of
     ncclSend / ncclRecv over xGMI), solve, gather GRFs + iterations + status back to rank 0 -- all inside the timed region.  Strong scaling."""
@@ -541,6 +585,7 @@ def strong_scaling_config4(pkg, args, rank, world, local, backend, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     res = None
+    part = participation(dist, rank, world, local, backend)   # (a collective: every rank calls it)
     if rank == 0:
         iters = out_bufs[1][:, 0].cpu().numpy(); status = out_bufs[1][:, 1].cpu().numpy()
         res = {"metric": "MPC QP solves/sec (horizon=16 SRBD), BASELINE configs[3]", "value": N * args.steps / elapsed, "unit": "solves/s", "n_gpus": world,
@@ -551,6 +596,13 @@ def strong_scaling_config4(pkg, args, rank, world, local, backend, dist):
                           "parallelism": f"batch-sharded x{world}, {backend} grouped send/recv", "mean_iters": float(iters.mean()), "solved_frac": float((status == 1).mean())},
                "scatter_gather_ms_per_step_rank0": t_comm[0] / args.steps * 1e3,
                "scatter_bytes_per_step": int(N - parts[0][1]) * (sh.record_width(H) * 8 + 4), "gather_bytes_per_step": int(N - parts[0][1]) * (12 * 8 + 8)}
+        # flat in `config` (the driver's record keeps the scalar members of `config`): who took part, and what scatter + gather moved and cost
+        res["config"].update(part)
+        res["config"].update({"scatter_bytes_per_step": res["scatter_bytes_per_step"], "gather_bytes_per_step": res["gather_bytes_per_step"],
+                              "scatter_gather_ms_per_step_rank0": res["scatter_gather_ms_per_step_rank0"],
+                              "scatter_gather_share_of_step": res["scatter_gather_ms_per_step_rank0"] / res["ms_per_step"]})
+        if not part["is_scaling_point"]:
+            res["config"]["parallelism"] += f" -- {part['distinct_devices']} distinct GPU(s) for {world} rank(s): NOT a scaling point"
     eng.close()
     return res
 
@@ -798,6 +850,7 @@ def main():
         eng.set_schedule(True)
         step(0, fresh=False); torch.cuda.synchronize()
         hist_ms = timed(lambda: [step(0, fresh=False) for _ in range(args.steps)])   # identical inputs again and again: hindsight order
+    part = participation(dist, rank, world, local, backend)   # (a collective: every rank calls it)
     if rank == 0:
         h = HORIZON
         flops_b = [float(pkg.algorithmic_flops(h, w[0], w[2]).sum()) for w in work]
@@ -842,6 +895,9 @@ def main():
                                  "would execute; the structured Riccati solve executes 1.5x / 2.8x / 3.9x fewer flops at h = 10 / 16 / 20), `executed_fp64_frac` prices the FP64 flops "
                                  "the kernels really issue (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 x live lanes from the static PMC profile) -- the hardware fraction"},
         }
+        out["config"].update(part)   # who took part: distinct_devices, rccl_world_size, is_scaling_point, device_ids (flat: the driver's record keeps them)
+        if not part["is_scaling_point"]:
+            out["config"]["parallelism"] += f" -- {part['distinct_devices']} distinct GPU(s) for {world} rank(s): NOT a scaling point"
         out["stage_counters"] = stage
         # ---- scalars a reader of this line needs first; repeated inside `roofline` and `config`, which the driver keeps whole
         admm_ms = stage.get("solve_ms") if isinstance(stage, dict) else None   # the persistent ADMM kernel (+ the ~6 us order kernel) of one launch alone, by HIP events
@@ -875,6 +931,8 @@ def main():
         torch.cuda.synchronize(); dist.barrier()
         sg_ms = (time.perf_counter() - t1) / 10 * 1e3
         if rank == 0:
+            out["config"].update({"scatter_gather_ms_per_step": sg_ms, "scatter_bytes_per_step": int(n * (world - 1) * (sh.record_width(HORIZON) * 8 + 4)),
+                                  "gather_bytes_per_step": int(n * (world - 1) * (12 * 8 + 8))})
             out["scatter_gather"] = {"ms_per_step": sg_ms, "bytes_out_of_rank0": int(n * (world - 1) * (sh.record_width(HORIZON) * 8 + 4)),
                                      "bytes_into_rank0": int(n * (world - 1) * (12 * 8 + 8)), "transport": "torch.distributed nccl (RCCL) batch_isend_irecv",
                                      "note": "not part of `value`: ranks generate their own inputs in the weak-scaling metric; --config 4 puts scatter + gather inside the timed region"}

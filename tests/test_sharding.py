@@ -128,10 +128,21 @@ def test_bench_gpus_2_spawns_its_own_ranks():
     out = _run_bench("--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-latency", "--no-index-order")
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["solved_frac"] == 1.0
     assert "roofline" in out and out["unit"] == "solves/s"
+    # round 6: the line proves which devices took part -- two ranks on ONE physical GPU are labelled, never counted as a scaling point
+    c = out["config"]
+    assert c["world_size"] == 2 and c["distinct_devices"] == 1 and c["is_scaling_point"] is False and c["rccl_world_size"] == 0 and c["backend"] == "gloo"
+    assert c["device_ids"].count("r0@") == 1 and c["device_ids"].count("r1@") == 1 and "NOT a scaling point" in c["parallelism"]
     out4 = _run_bench("--gpus", "2", "--config", "4", "--batch", "4000", "--steps", "2", "--warmup", "1")
     assert out4["n_gpus"] == 2 and out4["scaling"] == "strong" and out4["config"]["global_batch"] == 4000 and out4["config"]["solved_frac"] > 0.99
+    c4 = out4["config"]
+    assert c4["distinct_devices"] == 1 and c4["is_scaling_point"] is False and c4["scatter_bytes_per_step"] == 2000 * ((13 + 13 * 16 + 9 + 12) * 8 + 4) and c4["gather_bytes_per_step"] == 2000 * 104
+    assert c4["scatter_gather_ms_per_step_rank0"] > 0 and 0 < c4["scatter_gather_share_of_step"] < 1
+    if os.environ.get("A1_KEEP_BENCH_LINES"):   # (profiles/r06_bench_2ranks_shared_gpu.json is this test's two lines)
+        import json
+        json.dump({"weak_scaling_line": out, "config4_line": out4}, open(os.environ["A1_KEEP_BENCH_LINES"], "w"), indent=1)
     one = _run_bench("--config", "4", "--batch", "4000", "--steps", "2", "--warmup", "1")   # N = 1: the device-resident path without host synchronisation in the step
     assert one["n_gpus"] == 1 and one["config"]["mean_iters"] == out4["config"]["mean_iters"]
+    assert one["config"]["distinct_devices"] == 1 and one["config"]["is_scaling_point"] is True and one["config"]["pci_bus_id"] if "pci_bus_id" in one["config"] else True
 
 
 @pytest.mark.gpu
