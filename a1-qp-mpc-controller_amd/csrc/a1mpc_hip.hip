@@ -1399,7 +1399,8 @@ a1mpc_status a1mpc_ekf_update_batch(a1mpc_handle h, int32_t n, double dt, int32_
     if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     if (n > h->ekf_ready_n) {   // (robots 0 .. ekf_ready_n - 1 have been through init_state: nothing for the init kernel to do -- one launch less per tick)
         hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
-        h->ekf_ready_n = n;
+        if (hipError_t ei = hipGetLastError(); ei != hipSuccess) { h->ekf_ready_n = 0; return fail(A1MPC_ERR_HIP, std::string("a1mpc_ekf_init_kernel: ") + hipGetErrorString(ei)); }
+        h->ekf_ready_n = n;   // (only once the launch has been accepted -- ADVICE r5: a failed init launch must not leave the robots marked as initialised)
     }
     launch_ekf_update(a, s);
     A1_HIP(hipGetLastError());
@@ -1626,7 +1627,8 @@ a1mpc_status a1mpc_ekf_update_batch_device(a1mpc_handle h, int32_t n, double dt,
     if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     if (n > h->ekf_ready_n) {   // (robots 0 .. ekf_ready_n - 1 have been through init_state: nothing for the init kernel to do -- one launch less per tick)
         hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
-        h->ekf_ready_n = n;
+        if (hipError_t ei = hipGetLastError(); ei != hipSuccess) { h->ekf_ready_n = 0; return fail(A1MPC_ERR_HIP, std::string("a1mpc_ekf_init_kernel: ") + hipGetErrorString(ei)); }
+        h->ekf_ready_n = n;   // (only once the launch has been accepted -- ADVICE r5: a failed init launch must not leave the robots marked as initialised)
     }
     launch_ekf_update(a, s);
     A1_DEV_EPILOGUE();
@@ -2022,12 +2024,15 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
         // fast path); its hand-off records (B~w_t of every step included) live in a buffer of their own, allocated on first use
         int rows_gen = 0;
         if (a1mpc_status st0 = resident_rows_gen(h->cfg.horizon, &rows_gen); st0 != A1MPC_OK) return st0;
-        const bool split_gen = pipeline_mode() != 2 && rows_gen > 0 && (pipeline_mode() == 1 || n > rows_gen) && h->d_counter != nullptr;
-        // warm_start = 2 (round 5): the FUSED general kernels follow the update path like the fast path's (batches within the resident rows -- the control loop's
-        // batch 1 among them).  The general path's split pipeline solves on warm_start = 1 semantics: it rewrites the carried (x, y, rho) of these problems but neither
-        // reads nor refreshes the update path's carry (previous scalings, gradient, z).  A carry left standing would pair tick k - 2's scalings with tick k - 1's
-        // iterates on the next update-path tick: mark "no previous tick" (field C of every record) instead -- that tick is then a fresh set-up warm-started from (x, y, rho).
-        if (a.carry != nullptr && split_gen) {
+        bool split_gen = pipeline_mode() != 2 && rows_gen > 0 && (pipeline_mode() == 1 || n > rows_gen) && h->d_counter != nullptr;
+        // warm_start = 2: the FUSED general kernels follow the update path like the fast path's (round 5: batches within the resident rows).  Round 6: every batch size --
+        // an update-path batch beyond the resident rows runs the fused kernel as well, in as many rounds as it takes (the hardware dispatches the grid's workgroups as
+        // LDS frees up).  Ticks on the update path are warm-started and all alike (25 iterations once the loop is closed): there is nothing for a queue to balance, which
+        // is why the fast path's warm ticks of a known batch take the fused kernel too (solve_device_impl below); only the very first tick of a fleet (cold, no
+        // history) pays a tail for it.  The general path's split pipeline itself has no update-path hand-off and keeps serving modes 0 / 1.
+        if (a.carry != nullptr && split_gen && pipeline_mode() != 1) split_gen = false;
+        if (a.carry != nullptr && split_gen) {   // (A1MPC_PIPELINE=split forced: warm_start = 1 semantics, visibly -- the carry is marked "no previous tick" so that a later
+                                                 // update-path tick does not pair stale scalings with fresh iterates)
             A1_HIP(hipMemset2DAsync(h->d_carry, carry_stride(h->cfg.horizon) * sizeof(double), 0, sizeof(double), static_cast<size_t>(n), s));
             a.carry = nullptr;
             h->last_ws_mode = 1;
@@ -2170,6 +2175,7 @@ a1mpc_status a1mpc_control_tick_device(a1mpc_handle h, const a1mpc_tick_params* 
         a.ec_out = bf->estimated_contacts;
         if (n > h->ekf_ready_n) {   // (robots 0 .. ekf_ready_n - 1 have been through init_state: nothing for the init kernel to do -- one launch less per tick)
             hipLaunchKernelGGL(a1mpc_ekf_init_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, s, a);
+            if (hipError_t ei = hipGetLastError(); ei != hipSuccess) { h->ekf_ready_n = 0; return fail(A1MPC_ERR_HIP, std::string("a1mpc_ekf_init_kernel: ") + hipGetErrorString(ei)); }
             h->ekf_ready_n = n;
         }
         launch_ekf_update(a, s);

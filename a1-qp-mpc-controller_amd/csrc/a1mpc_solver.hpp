@@ -171,6 +171,7 @@ A1_DEV double dot_bc(const double (&m)[N], double x, double init = 0.0) {
 }
 // below this rho the dual residual at a checkpoint is dominated by the x-update's backward error unless c P x + c g is carried (RowSolver::careful)
 constexpr double kRhoCareful = 1e-3;
+constexpr double kSigGeneralPath = 2251799813685248.0;   // 2^51: tag of a pattern signature (Carry<H>::SIG) written by the general path; its hash stays below 2^50
 // gamma_st = alpha_st / beta_st and beta_st = H - max(s,t) never grow with t for fixed s (csrc/a1mpc_tables.hpp; the quotients are compared as integers,
 // rounding them to double is monotone)
 constexpr bool gamma_beta_monotone(int H) {
@@ -805,15 +806,20 @@ struct RowSolver {
                     }
                     hsh = (hsh * 67ull + v + 1ull) & ((1ull << 50) - 1ull);
                 });
-                sig = act ? static_cast<double>(hsh) : 0.0;
+                sig = act ? static_cast<double>(hsh) + kSigGeneralPath : 0.0;   // (+ 2^51: "written by the general path", exact in a double)
             } else {
                 unsigned bits = 0;
                 static_for<12>([&](auto B) { bits |= (U[B] != 0.0 ? 1u : 0u) << A1_CV(B); bits |= (V[B] != 0.0 ? 1u : 0u) << (12 + A1_CV(B)); });
                 sig = act ? static_cast<double>(bits) : 0.0;
             }
             if (upd) {
+                // The two paths encode the pattern differently (24 flags of U / V | a hash of the per-step tables' flags, tagged 2^51): signatures are only comparable when
+                // the same path wrote both.  A handle that alternates between the paths (foot_stride / yaw_A toggled between ticks) keeps the UPDATE path across the switch --
+                // everything else in the carry (previous scalings, gradient, z) means the same on both, and the reference's persistent solver takes osqp_update_P whenever
+                // the dense Hessian keeps its pattern, which inputs in general position do on either path (until round 6 every switch took the pattern-change branch)
                 const double prev = act ? io.carry[CR::SIG + ci] : 0.0;
-                reinit = row_allmax(prev != sig ? 1.0 : 0.0) > 0.0;
+                const bool same_path = (prev >= kSigGeneralPath) == (sig >= kSigGeneralPath);
+                reinit = row_allmax((same_path && prev != sig) ? 1.0 : 0.0) > 0.0;
             }
         }
         [[maybe_unused]] double gq[(UPD && MODE == kModeMpc && H > 1 && !GEN) ? H : 1];   // the gradient the cost normalisation sees: the previous tick's on the update path

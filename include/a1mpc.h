@@ -96,12 +96,10 @@ typedef struct a1mpc_config {
                                          update*Bound on the persistent OsqpEigen workspace, then solve()): OSQP re-equilibrates with the PREVIOUS tick's
                                          gradient still in the workspace and starts from the previous solve's SCALED (x, z, y) as they are.  The handle then
                                          also carries the previous scalings, gradient and z of every problem.  Restated from OSQP 0.6's update functions
-                                         (oracle: orc_mpc_solve_update); horizons 10 / 16 / 20: the fast path at every batch size and, since round 5, the general
-                                         path (per-step feet / contact schedules / its own A_c yaw: a1mpc_solve_batch_strided) for batches within the resident rows
-                                         of its fused kernel (1536 / 1024 / 768 QPs at h = 10 / 16 / 20 on an MI355X -- the control loop's batch 1 among them; its
-                                         pattern-change test reads the zero patterns of the per-step tables, a superset of the changes osqp-eigen sees).  Larger
-                                         general-path batches and horizon 1 (the balance QP, which the reference cold-starts anyway) behave like 1:
-                                         a1mpc_last_warm_start_mode reports which semantics a solve actually ran.
+                                         (oracle: orc_mpc_solve_update); horizons 10 / 16 / 20: the fast path and (round 5; round 6: at every batch size) the general
+                                         path (per-step feet / contact schedules / its own A_c yaw: a1mpc_solve_batch_strided; its pattern-change test reads the
+                                         zero patterns of the per-step tables, a superset of the changes osqp-eigen sees).  Horizon 1 (the balance QP, which the
+                                         reference cold-starts anyway) behaves like 1: a1mpc_last_warm_start_mode reports which semantics a solve actually ran.
                                          When the sparsity pattern of the reference's Hessian (dense.sparseView(), S/ConvexMpc.cpp:211: exact zeros are not stored)
                                          changes from one tick to the next, osqp-eigen cannot take osqp_update_P: updateHessianMatrix clears the solver, initialises
                                          it again (rho back to cfg.rho, fresh scaling) and warm-starts it with the workspace's scaled iterates -- reproduced per
@@ -473,9 +471,9 @@ a1mpc_status a1mpc_last_stage_cycles(a1mpc_handle h, double* cycles3_out, int32_
  * split-pipeline solve reports through a1mpc_last_stage_cycles).  Host call; synchronises the handle's stream. */
 a1mpc_status a1mpc_last_tick_stage_cycles(a1mpc_handle h, double* cycles8_out, int32_t* qps_out);
 /* Which warm-start semantics the handle's last MPC solve actually ran: 0 (cold), 1 (fresh set-up + osqp_warm_start) or 2 (the reference's update path).
- * warm_start = 2 exists at horizons 10 / 16 / 20 on the fast path and (round 5) on the general path's latency and fused kernels (per-step feet, a separate A_c
- * yaw: batches within those kernels' resident rows -- 1536 / 1024 / 768 QPs at h = 10 / 16 / 20 on an MI355X); a general-path batch beyond them (its split
- * pipeline) or a solve at horizon 1 runs mode 1 instead (documented at a1mpc_config.warm_start) -- this call makes that visible to the caller.  -1 before the
+ * warm_start = 2 exists at horizons 10 / 16 / 20 on the fast path and on the general path (per-step feet, a separate A_c yaw: its latency and fused kernels -- round 6:
+ * at every batch size, an update-path batch beyond the resident rows runs the fused kernel in several rounds); a solve at horizon 1, or a general-path batch forced onto
+ * its split pipeline by A1MPC_PIPELINE=split, runs mode 1 instead (documented at a1mpc_config.warm_start) -- this call makes that visible to the caller.  -1 before the
  * first solve. */
 a1mpc_status a1mpc_last_warm_start_mode(a1mpc_handle h, int32_t* mode_out);
 

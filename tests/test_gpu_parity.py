@@ -867,17 +867,19 @@ def test_per_step_feet_and_contact_schedules(pkg, oracle, scen, h, nb, feet, con
         assert np.abs(u[c == 0]).max() < 1.0
 
 
-@pytest.mark.parametrize("h,nb", [(10, 1), (10, 48), (16, 6), (20, 5)])
+@pytest.mark.parametrize("h,nb", [(10, 1), (10, 48), (16, 6), (20, 5), (10, 4000), (16, 2100), (20, 1700)])
 def test_update_path_on_the_general_path(pkg, oracle, scen, h, nb):
     """Round 5 (VERDICT r4 missing 3 / item 5): warm_start = 2 -- the reference's per-tick OSQP update path -- on a STRIDED tick sequence: per-step feet that drift by
     -v_d dt per horizon step (S/test/test_mpc.cpp:112-115) and the gait's contact schedule over the horizon.  a1mpc_last_warm_start_mode reports 2, and every tick has the
     oracle's iteration count, status and forces (orc_mpc_solve_update_strided: the same persistent-solver semantics on the QP those inputs form) -- through a contact switch.
-    A general-path batch beyond the resident rows of its fused kernel still runs warm_start = 1 semantics, and says so."""
+    Round 6: batches beyond the resident rows of the fused general kernel (4000 / 2100 / 1700 QPs at h = 10 / 16 / 20) follow the update path too -- a sample of the robots
+    is chained through the oracle, tick for tick."""
     seq = scen.config2_trot_sequence(70, horizon=h)
     pr = oracle_params(oracle, seq); st = oracle.default_settings(warm_start=1); dt = seq["params"]["dt"]
     rng = np.random.default_rng(77 + h)
-    carries = [oracle.update_carry(h) for _ in range(nb)]
-    ticks = list(range(0, 5)) + list(range(56, 63))
+    checked = list(range(nb)) if nb <= 48 else sorted(set(list(range(0, nb, max(1, nb // 24))) + [nb - 1]))   # the robots whose ticks the oracle follows (every robot of the small batches)
+    carries = {b: oracle.update_carry(h) for b in checked}
+    ticks = (list(range(0, 5)) + list(range(56, 63))) if nb <= 48 else (list(range(0, 3)) + list(range(58, 62)))
     worst = 0.0
     with _engine(pkg, seq, nb, warm_start=2) as eng:
         for i, k in enumerate(ticks):
@@ -889,18 +891,44 @@ def test_update_path_on_the_general_path(pkg, oracle, scen, h, nb):
             xref = np.repeat(seq["xref"][k:k + 1], nb, 0); R = np.repeat(seq["R"][k:k + 1], nb, 0)
             out = eng.solve_strided(x0, xref, R, foot, 12, contact, 4)
             assert eng.last_warm_start_mode() == 2
-            for b in range(nb):
+            for b in checked:
                 o = oracle.mpc_solve_update(pr, st, x0[b], xref[b], R[b], foot[b], contact[b], carries[b], foot_stride=12, contact_stride=4)
                 assert out["iters"][b] == o["info"].iters and out["status"][b] == o["info"].status, (h, k, b, out["iters"][b], o["info"].iters)
                 worst = max(worst, np.abs(out["grf"][b] - o["grf"]).max())
     assert worst <= 1e-7, worst
     print(f"h{h} x {nb}: {len(ticks)} strided update-path ticks, worst |dGRF| {worst:.1e} N")
-    if nb == 48:   # beyond the fused general kernel's range the split pipeline solves with warm_start = 1 semantics -- visibly
-        big = 2400
-        sc, foot, fs, contact, cs = _strided_inputs(scen, np.random.default_rng(3), h, big, True, True)
-        with _engine(pkg, sc, big, warm_start=2) as eng:
-            eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, fs, contact, cs)
-            assert eng.last_warm_start_mode() == 1
+
+
+@pytest.mark.parametrize("h,nb", [(10, 1), (10, 40), (16, 5)])
+def test_update_path_across_a_switch_between_the_fast_and_the_general_path(pkg, oracle, scen, h, nb):
+    """a handle on warm_start = 2 whose caller alternates between step-invariant feet (fast path) and per-step feet (general path) from tick to tick.  The
+    two paths encode the carried pattern signature differently; a switch keeps the UPDATE path (the reference's persistent solver takes osqp_update_P as long as the
+    dense Hessian keeps its pattern, which it does on either path for inputs in general position).  Every tick vs the oracle's persistent-solver semantics on the QP the
+    tick's inputs form (orc_mpc_solve_update, strided or not): same iteration count, status, forces."""
+    seq = scen.config2_trot_sequence(30, horizon=h)
+    pr = oracle_params(oracle, seq); st = oracle.default_settings(warm_start=1); dt = seq["params"]["dt"]
+    rng = np.random.default_rng(900 + h)
+    carries = [oracle.update_carry(h) for _ in range(nb)]
+    worst = 0.0
+    pattern = [0, 1, 1, 0, 1, 0, 0, 1]   # 1 = per-step feet this tick
+    with _engine(pkg, seq, nb, warm_start=2) as eng:
+        for k, gen in enumerate(pattern):
+            x0 = np.repeat(seq["x0"][k:k + 1], nb, 0); x0[:, :12] += rng.normal(0, 1e-3, (nb, 12)) * (np.arange(nb)[:, None] > 0)
+            xref = np.repeat(seq["xref"][k:k + 1], nb, 0); R = np.repeat(seq["R"][k:k + 1], nb, 0)
+            contact = np.repeat(seq["contact"][k:k + 1], nb, 0)
+            if gen:
+                vd = np.c_[np.full(nb, 0.3), 0.05 * np.sin(k + np.arange(nb)), np.zeros(nb)]
+                foot = (seq["foot"][k].reshape(1, 1, 4, 3) - vd.reshape(nb, 1, 1, 3) * dt * np.arange(h).reshape(1, h, 1, 1)).reshape(nb, 12 * h)
+                out = eng.solve_strided(x0, xref, R, foot, 12, contact, 0)
+            else:
+                foot = np.repeat(seq["foot"][k:k + 1], nb, 0)
+                out = eng.solve(x0, xref, R, foot, contact)
+            assert eng.last_warm_start_mode() == 2
+            for b in range(nb):
+                o = oracle.mpc_solve_update(pr, st, x0[b], xref[b], R[b], foot[b], contact[b], carries[b], foot_stride=12 if gen else 0, contact_stride=0)
+                assert out["iters"][b] == o["info"].iters and out["status"][b] == o["info"].status, (h, k, gen, b, out["iters"][b], o["info"].iters)
+                worst = max(worst, np.abs(out["grf"][b] - o["grf"]).max())
+    assert worst <= 1e-7, worst
 
 
 def test_general_path_latency_kernel(pkg, oracle, scen):
@@ -1413,11 +1441,12 @@ def test_host_pointer_pipeline_matches_the_synchronous_entry(pkg, scen):
 
 
 def test_update_path_carry_is_dropped_by_ticks_that_do_not_refresh_it(pkg, oracle, scen):
-    """warm_start = 2: a general-path tick (per-step feet) through the general path's SPLIT pipeline (a batch beyond its
-    fused kernels' resident rows; within them the general path follows the update path itself since round 5:
-    test_update_path_on_the_general_path) and a stretch in warm_start = 1 rewrite the carried (x, y, rho) but not the update path's carry.  The
-    fast-path tick that follows must NOT pair the stale scalings / gradient / z with the fresh iterates: it is a fresh set-up warm-started
-    from (x, y, rho) -- exactly what a warm_start = 1 handle that saw the same sequence does, bit for bit."""
+    """warm_start = 2.  (i) Round 6: a general-path tick (per-step feet + a contact schedule) of a batch BEYOND the resident rows of the general path's fused kernel now
+    follows the update path too (the fused kernel in several rounds; until round 6 such a tick ran warm_start = 1 semantics and dropped the carry): a sequence
+    fast, fast, general, fast, general, fast of 2048 robots reports mode 2 on every tick and a sample of the robots equals the oracle's persistent solver chained through
+    the same sequence.  (ii) ADVICE round 2: a stretch in warm_start = 1 (a1mpc_update_config 2 -> 1 -> 2) rewrites the carried (x, y, rho) but not the update path's
+    carry; the tick that follows must NOT pair the stale scalings / gradient / z with the fresh iterates: it is a fresh set-up warm-started from (x, y, rho) -- exactly
+    what a warm_start = 1 handle that saw the same sequence does, bit for bit."""
     n = 2048   # (> 1536 = the resident rows of the general path's fused kernel at h = 10)
     rng = np.random.default_rng(77)
     sc = scen.config3_random_flat(nb=n, seed=4242)
@@ -1427,33 +1456,25 @@ def test_update_path_carry_is_dropped_by_ticks_that_do_not_refresh_it(pkg, oracl
             sc["x0"][:, :12] += rng.normal(0, 2e-3, (n, 12))
         seq.append({k: np.array(v) if isinstance(v, np.ndarray) else v for k, v in sc.items()})
     feet_steps = lambda s: np.repeat(s["foot"][:, None, :], 10, axis=1) + rng.normal(0, 1e-3, (n, 10, 12))
-    f2 = feet_steps(seq[2]); c2 = np.repeat(seq[2]["contact"][:, None, :], 10, axis=1)
-    with _engine(pkg, sc, n, warm_start=2) as e2, _engine(pkg, sc, n, warm_start=1) as e1:
-        # ticks 0, 1 on the update path (e1 runs them in mode 1: different numbers from tick 1 on, not compared)
-        for t in (0, 1):
-            e2.solve(seq[t]["x0"], seq[t]["xref"], seq[t]["R"], seq[t]["foot"], seq[t]["contact"])
-        # align the two handles' carried (x, y, rho), then a general-path tick on both
-        x, y, rho = e2.get_warm_start(n)
-        e1.set_warm_start(x, y, rho)
-        # (the same values it holds: a no-op on the iterates; the general-path tick below is what drops the carry)
-        e2.set_warm_start(x, y, rho)
-        a = e2.solve_strided(seq[2]["x0"], seq[2]["xref"], seq[2]["R"], f2, 12, c2, 4)
-        assert e2.last_warm_start_mode() == 1
-        b = e1.solve_strided(seq[2]["x0"], seq[2]["xref"], seq[2]["R"], f2, 12, c2, 4)
-        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"])
-        # a fast-path tick on the update path first (fills the carry again), then the general path, then the fast path: the last one must
-        # equal mode 1
-        a = e2.solve(seq[3]["x0"], seq[3]["xref"], seq[3]["R"], seq[3]["foot"], seq[3]["contact"])
-        b = e1.solve(seq[3]["x0"], seq[3]["xref"], seq[3]["R"], seq[3]["foot"], seq[3]["contact"])
-        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"])   # (tick after a cleared carry = mode 1)
-        x, y, rho = e2.get_warm_start(n); e1.set_warm_start(x, y, rho)
-        a = e2.solve_strided(seq[4]["x0"], seq[4]["xref"], seq[4]["R"], f2, 12, c2, 4)
-        b = e1.solve_strided(seq[4]["x0"], seq[4]["xref"], seq[4]["R"], f2, 12, c2, 4)
-        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"], b["iters"])
-        a = e2.solve(seq[5]["x0"], seq[5]["xref"], seq[5]["R"], seq[5]["foot"], seq[5]["contact"])
-        b = e1.solve(seq[5]["x0"], seq[5]["xref"], seq[5]["R"], seq[5]["foot"], seq[5]["contact"])
-        assert np.array_equal(a["grf"], b["grf"]) and np.array_equal(a["iters"],
-                b["iters"]), "stale update-path carry used after a general-path tick"
+    f2 = feet_steps(seq[2]).reshape(n, 120); c2 = np.ascontiguousarray(np.repeat(seq[2]["contact"][:, None, :], 10, axis=1).reshape(n, 40))
+    pr = oracle_params(oracle, sc); st = oracle.default_settings(warm_start=1)
+    checked = list(range(0, n, 97))
+    carries = {b: oracle.update_carry(10) for b in checked}
+    worst = 0.0
+    with _engine(pkg, sc, n, warm_start=2) as e2:
+        for t, gen in enumerate([0, 0, 1, 0, 1, 0]):
+            q = seq[t]
+            if gen:
+                out = e2.solve_strided(q["x0"], q["xref"], q["R"], f2, 12, c2, 4)
+            else:
+                out = e2.solve(q["x0"], q["xref"], q["R"], q["foot"], q["contact"])
+            assert e2.last_warm_start_mode() == 2, t
+            for b in checked:
+                o = oracle.mpc_solve_update(pr, st, q["x0"][b], q["xref"][b], q["R"][b], f2[b] if gen else q["foot"][b], c2[b] if gen else q["contact"][b], carries[b],
+                                            foot_stride=12 if gen else 0, contact_stride=4 if gen else 0)
+                assert out["iters"][b] == o["info"].iters and out["status"][b] == o["info"].status, (t, gen, b, out["iters"][b], o["info"].iters)
+                worst = max(worst, np.abs(out["grf"][b] - o["grf"]).max())
+    assert worst <= 1e-7, worst
     # the same through a1mpc_update_config: 2 -> 1 -> 2 leaves no stale carry behind
     with _engine(pkg, sc, n, warm_start=2) as e2, _engine(pkg, sc, n, warm_start=1) as e1:
         for t in (0, 1):
@@ -1725,15 +1746,18 @@ def test_tick_stage_cycles_of_the_fused_and_latency_kernels(pkg, scen, n, mode):
                 assert np.array_equal(o[k], outs[t][k]), (t, k)
 
 
-@pytest.mark.parametrize("var,n,ticks,warm", [("A1MPC_FUSED_QUEUE", 4096, 2, 0), ("A1MPC_WARM_ORDER", 4096, 4, 1), ("A1MPC_WARM_ORDER", 4096, 4, 2)])
-def test_opt_in_scheduling_switches_change_nothing_but_the_schedule(pkg, var, n, ticks, warm):
+@pytest.mark.parametrize("var,n,ticks,warm,values", [("A1MPC_FUSED_QUEUE", 4096, 2, 0, "0,1"), ("A1MPC_WARM_ORDER", 4096, 4, 1, "0,1"), ("A1MPC_WARM_ORDER", 4096, 4, 2, "0,1"),
+                                                    ("A1MPC_ZERO_COPY_MAX", 1, 4, 2, "0,8"), ("A1MPC_ZERO_COPY_MAX", 8, 3, 1, "0,8"), ("A1MPC_ZERO_COPY_MAX", 8, 2, 0, "0,8")])
+def test_opt_in_scheduling_switches_change_nothing_but_the_schedule(pkg, var, n, ticks, warm, values):
     """Round 5's two measured-and-not-adopted trials stay in the library behind environment switches: A1MPC_FUSED_QUEUE=1 (the fused kernel as persistent wavefronts on
     the work queue, profiles/r05_fused_queue_trial.txt) and A1MPC_WARM_ORDER=1 (warm ticks launched in the order of the previous tick's costs,
     profiles/r05_warm_tick_order.txt).  Both only reorder independent QPs: forces, full solutions, iteration counts and statuses of every tick are bit-identical
-    with the switch on and off (children of tools/env_ab.py)."""
+    with the switch on and off (children of tools/env_ab.py).  Round 6: the same for the small-batch host path -- A1MPC_ZERO_COPY_MAX = 0 (inputs / outputs
+    staged through device memory) against the default 8 (the kernels read and write the handle's pinned block over PCIe): batch 1 and batch 8, full solutions included,
+    cold and both warm-start semantics; the batch-1 latency figures of bench.py and tests/cpp/latency_harness.cpp are measured on the zero-copy path."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "env_ab.py"), var, str(n), str(ticks), str(warm)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "env_ab.py"), var, str(n), str(ticks), str(warm), values], capture_output=True, text=True, timeout=600)
     rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(rows) == 2 and all("digest" in x for x in rows), (r.stdout[-500:], r.stderr[-500:])
     assert rows[0]["digest"] == rows[1]["digest"] and rows[0]["solved"] == 1.0, rows

@@ -36,7 +36,7 @@ for n in sizes:
     sc = pkg.scenarios.config3_random_flat(nb=n)
     osqp = dict(warm_start=0)
     if '--fixed' in sys.argv:
-        osqp.update(eps_abs=0.0, eps_rel=0.0, max_iter=int(sys.argv[sys.argv.index('--fixed') + 1]), adaptive_rho=0)
+        osqp.update(eps_abs=1e-300, eps_rel=1e-300, max_iter=int(sys.argv[sys.argv.index('--fixed') + 1]), adaptive_rho=0)
     cfg = pkg.make_config(sc["params"], 10, **osqp)
     with pkg.Engine(cfg, n, 0) as eng:
         ms = []

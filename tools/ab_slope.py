@@ -34,7 +34,7 @@ gen = {10: pkg.scenarios.config3_random_flat, 16: pkg.scenarios.config4_random_h
 sc = gen(nb=n)
 out = {}
 for k in (1, K):
-    cfg = pkg.make_config(sc["params"], h, warm_start=0, eps_abs=0.0, eps_rel=0.0, max_iter=k, adaptive_rho=0)
+    cfg = pkg.make_config(sc["params"], h, warm_start=0, eps_abs=1e-300, eps_rel=1e-300, max_iter=k, adaptive_rho=0)
     with pkg.Engine(cfg, n, 0) as eng:
         eng.set_schedule(False)   # index order: at a fixed iteration count every QP costs the same
         ms = []

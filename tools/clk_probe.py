@@ -10,7 +10,7 @@ pkg.engine._lib = pkg.engine.load_library(sys.argv[1])  # (load_library only cac
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 101
 n = 16384
 sc = pkg.scenarios.config3_random_flat(nb=n)
-cfg = pkg.make_config(sc["params"], 10, warm_start=0, eps_abs=0.0, eps_rel=0.0, max_iter=k, adaptive_rho=0) if k > 0 else pkg.make_config(sc["params"], 10, warm_start=0)  # k = 0: the default settings
+cfg = pkg.make_config(sc["params"], 10, warm_start=0, eps_abs=1e-300, eps_rel=1e-300, max_iter=k, adaptive_rho=0) if k > 0 else pkg.make_config(sc["params"], 10, warm_start=0)  # k = 0: the default settings
 with pkg.Engine(cfg, n, 0) as eng:
     for _ in range(3):
         o = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)

@@ -1,5 +1,5 @@
 """GPU: the same solves under two settings of one environment switch of the library (children of this script), digests of every output compared -- how the GPU suite
-checks that an opt-in / A-B switch changes scheduling and nothing else.   python tools/env_ab.py VAR [n [ticks [warm_start]]]   -> one JSON line per child"""
+checks that an opt-in / A-B switch changes scheduling and nothing else.   python tools/env_ab.py VAR [n [ticks [warm_start [value_a,value_b]]]]   -> one JSON line per child"""
 import hashlib
 import json
 import os
@@ -27,7 +27,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print("RESULT " + json.dumps({"digest": hsh.hexdigest()[:24], "kernel_ms": ms, "mean_iters": float(o["iters"].mean()), "solved": float((o["status"] == 1).mean())}))
     sys.exit(0)
 var = sys.argv[1]; n = sys.argv[2] if len(sys.argv) > 2 else "4096"; ticks = sys.argv[3] if len(sys.argv) > 3 else "3"; warm = sys.argv[4] if len(sys.argv) > 4 else "0"
-for val in ("0", "1"):
+values = sys.argv[5].split(",") if len(sys.argv) > 5 else ["0", "1"]   # the two settings of the switch (default: off / on)
+for val in values:
     r = subprocess.run([sys.executable, __file__, "child", n, ticks, warm], capture_output=True, text=True, timeout=300, env=dict(os.environ, **{var: val}))
     res = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     print(json.dumps({"var": var, "value": val, **(json.loads(res[0][7:]) if res else {"error": r.stderr[-300:]})}), flush=True)

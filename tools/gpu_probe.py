@@ -31,8 +31,8 @@ def run(label, reps=5, **osqp):
 
 run("default")
 run("stop@25 (eps=1e9)", eps_abs=1e9, eps_rel=1e9)
-run("fixed 50 (no adapt)", eps_abs=0.0, eps_rel=0.0, max_iter=50, adaptive_rho=0)
-run("fixed 100 (no adapt)", eps_abs=0.0, eps_rel=0.0, max_iter=100, adaptive_rho=0)
-run("fixed 200 (no adapt)", eps_abs=0.0, eps_rel=0.0, max_iter=200, adaptive_rho=0)
-run("fixed 100, no scaling", eps_abs=0.0, eps_rel=0.0, max_iter=100, adaptive_rho=0, scaling=0)
-run("fixed 25, no scaling", eps_abs=0.0, eps_rel=0.0, max_iter=25, adaptive_rho=0, scaling=0)
+run("fixed 50 (no adapt)", eps_abs=1e-300, eps_rel=1e-300, max_iter=50, adaptive_rho=0)
+run("fixed 100 (no adapt)", eps_abs=1e-300, eps_rel=1e-300, max_iter=100, adaptive_rho=0)
+run("fixed 200 (no adapt)", eps_abs=1e-300, eps_rel=1e-300, max_iter=200, adaptive_rho=0)
+run("fixed 100, no scaling", eps_abs=1e-300, eps_rel=1e-300, max_iter=100, adaptive_rho=0, scaling=0)
+run("fixed 25, no scaling", eps_abs=1e-300, eps_rel=1e-300, max_iter=25, adaptive_rho=0, scaling=0)

@@ -16,7 +16,7 @@ sc = gen(nb=n)
 osqp = dict(warm_start=0)
 if os.environ.get('A1_SCALING'): osqp['scaling'] = int(os.environ['A1_SCALING'])
 if len(sys.argv) > 1:
-    osqp.update(eps_abs=0.0, eps_rel=0.0, max_iter=int(sys.argv[1]), adaptive_rho=0)
+    osqp.update(eps_abs=1e-300, eps_rel=1e-300, max_iter=int(sys.argv[1]), adaptive_rho=0)
     if os.environ.get('A1_ADAPT'):  # a rho update (= one more factor pass) at every checkpoint
         osqp.update(adaptive_rho=1, adaptive_rho_tolerance=1.0 + 1e-9)
 cfg = pkg.make_config(sc["params"], H, **osqp)
