@@ -473,6 +473,7 @@ struct a1mpc_handle_s {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    hipEvent_t ev_mark = nullptr;   // marker_at(): a no-timing event recorded where a timing event would be (A1MPC_TICK_MARKERS, profiles/r06_control_tick_timeline.md)
     bool timing = true;   // a1mpc_set_timing: HIP events around the launches (a1mpc_last_kernel_ms / _stage_ms / _control_tick_ms); off = three to five event records less per tick
     double* d_tab = nullptr;      // (alpha/beta, beta) table of cfg.horizon
     double* d_tab1 = nullptr;     // the H = 1 table (balance QP)
@@ -1675,6 +1676,7 @@ void a1mpc_destroy(a1mpc_handle h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_order) (void)hipEventDestroy(h->ev_order);
+    if (h->ev_mark) (void)hipEventDestroy(h->ev_mark);
     if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     if (h->ev_tick0) (void)hipEventDestroy(h->ev_tick0);
     if (h->ev_tick1) (void)hipEventDestroy(h->ev_tick1);
@@ -1711,6 +1713,7 @@ a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t de
     A1_TRY(hipEventCreate(&h->ev0));
     A1_TRY(hipEventCreate(&h->ev1));
     A1_TRY(hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming));
+    A1_TRY(hipEventCreateWithFlags(&h->ev_mark, hipEventDisableTiming));
     A1_TRY(hipEventCreate(&h->ev_mid));
     A1_TRY(hipEventCreate(&h->ev_tick0));
     A1_TRY(hipEventCreate(&h->ev_tick1));
@@ -1983,6 +1986,12 @@ struct TorqueFuse {
 // A1MPC_WARM_ORDER=1: launch the fused kernel of a warm-started tick in the order of the previous tick's per-QP cost (longest first).  OFF by default: measured and
 // lost (profiles/r05_warm_tick_order.txt: 4096 x h10 ticks 0.335 -> 0.348 ms, update path 0.362 -> 0.373) -- a warm tick has no tail worth ordering for (3 of 4096
 // QPs need a second 25-iteration segment and the two rounds of the resident rows absorb them), and the order kernel in front of the tick costs its ~12 us.
+// Round 6 experiment switch (profiles/r06_control_tick_timeline.md): with the handle's timing events OFF, record a no-timing marker event where a timing event would have been
+// -- bit 0: in front of the MPC launch (ev0), bit 1: at the start of a control tick (ev_tick0), bit 2: behind the MPC launch (ev1), bit 3: at the end of a tick (ev_tick1)
+static int tick_markers() {
+    static const int m = [] { const char* e = getenv("A1MPC_TICK_MARKERS"); return e ? atoi(e) : 0; }();
+    return m;
+}
 static bool warm_order_enabled() {
     static const bool on = [] { const char* e = getenv("A1MPC_WARM_ORDER"); return e && !strcmp(e, "1"); }();
     return on;
@@ -2072,7 +2081,7 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     a.order = hints ? h->d_order : nullptr;
     a.cost = hints ? h->d_cost : nullptr;
     a.predict = (hints && h->hint_n != n) ? 1 : 0;  // first solve of this batch size: order by the set-up kernel's guess instead
-    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev0, s)); else if (tick_markers() & 1) A1_HIP(hipEventRecord(h->ev_mark, s));
     // Round 5 trial (opt-in, see warm_order_enabled): the fused kernel of a warm-started tick launches its workgroups in the order of the previous tick's per-QP
     // cost, longest first (the cost buffer holds it: hint_n == n; the fused kernel records this tick's).  Scheduling only: every result is bit-identical in any order.
     if (warm_fused && h->schedule && n >= kScheduleMinBatch && n > coop_max_batch() && warm_order_enabled()) {
@@ -2097,7 +2106,7 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     if (st != A1MPC_OK) return st;
     if (a.clk != nullptr && g_clk_ran) { h->clk_n = n; h->clk_tick = !split; }   // (a kernel without stamps ran: the record stays "not profiled")
     if (hints) h->hint_n = n;   // the cost buffer now holds this batch's costs: the next solve of this size is ordered by them (sorted in front of its ADMM kernel)
-    if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev1, s)); else if (tick_markers() & 4) A1_HIP(hipEventRecord(h->ev_mark, s));
     h->timed = h->timing;
     A1_MARK(h, s);
     return A1MPC_OK;
@@ -2159,6 +2168,7 @@ a1mpc_status a1mpc_control_tick_device(a1mpc_handle h, const a1mpc_tick_params* 
         A1_HIP(hipMemsetAsync(h->d_ekf_state, 0, static_cast<size_t>(h->max_batch) * kEkfState * sizeof(double), s));
     }
     if (a1mpc_status st = ensure_contact_state(h, s); st != A1MPC_OK) return st;
+    if (!h->timing && (tick_markers() & 2)) A1_HIP(hipEventRecord(h->ev_mark, s));
     if (h->timing) A1_HIP(hipEventRecord(h->ev_tick0, s));   // (ev_tick0 .. ev_tick1 = the whole tick; ev0 .. ev1 = the MPC launch, as after every solve)
     {   // 1. leg state (uses the previous estimate of root_pos / root_lin_vel for the world-frame outputs, like the reference's callback)
         LegArgs a;
@@ -2224,7 +2234,7 @@ a1mpc_status a1mpc_control_tick_device(a1mpc_handle h, const a1mpc_tick_params* 
         A1_HIP(hipGetLastError());
     }
     h->tick_fused = tq.fused;
-    if (h->timing) A1_HIP(hipEventRecord(h->ev_tick1, s));
+    if (h->timing) A1_HIP(hipEventRecord(h->ev_tick1, s)); else if (tick_markers() & 8) A1_HIP(hipEventRecord(h->ev_mark, s));
     h->tick_timed = h->timing;
     A1_MARK(h, s);
     return A1MPC_OK;

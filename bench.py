@@ -341,7 +341,7 @@ def warm_tick_stage_counters(pkg, local, n=4096, mode=1, ticks=8):
                       "wavefront summed over the QPs (a QP's cycles include its wave-mate's)"}
 
 
-def full_tick_probe(pkg, local, n=4096, ticks=10):
+def full_tick_probe(pkg, local, n=4096, ticks=10, only=None):
     """Extra information (not `value`): one whole control tick per robot in ONE C call (a1mpc_control_tick_device, round 5) -- leg state, EKF, gait plan, swing legs,
     contacts / terrain, warm-started MPC from tick records, joint torques in the MPC kernel's output stage -- sensors resident in HBM, one stream, HIP events around
     `ticks` ticks.  (Until round 4 the same stages were seven entry points chained from Python with the tick record assembled by torch: 0.577 ms.)"""
@@ -386,12 +386,28 @@ def full_tick_probe(pkg, local, n=4096, ticks=10):
             e1.record(st)
             st.synchronize()
             return e0.elapsed_time(e1) / ticks
-        r = [(run(False), run(True)) for _ in range(3)]   # alternating: box clocks drift by a few per cent over a run
-        ms_off = float(np.median([a for a, _ in r])); ms = float(np.median([b for _, b in r]))   # `ms_per_tick`: the handle as a1mpc_create leaves it (timing events on)
+        if only is not None and not isinstance(only, (list, tuple)):   # (tools/control_tick_timeline.py: ONE setting of a1mpc_set_timing, for a kernel / HIP trace of exactly these ticks)
+            return {"timing_events": bool(only), "ms_per_tick": [run(bool(only)) for _ in range(3)]}
+        if only is not None:   # (tools/control_tick_markers.py: an explicit sequence of settings, e.g. [1, 0, 1, 0, 1, 0] -- the position of a run in the sequence matters, see there)
+            return {"sequence": list(only), "ms_per_tick": [run(bool(x)) for x in only]}
+        # Round 6 (profiles/r06_control_tick_timeline.md): what a run of ten ticks (4 ms of work behind a synchronisation) measures is decided by its POSITION in the sequence of runs
+        # -- the part's clocks ramp: 0.47 / 0.43 / 0.55 / 0.38 / 0.38 / 0.45 ms per tick for six identical runs -- not by the setting; round 5's (off, on) x 3 protocol therefore
+        # reported "timing off is 7 % slower", an artefact.  The figures are now taken from runs of `long_ticks` ticks (steady clocks) in on / off / off / on order; the
+        # ten-tick runs are kept beside them, six in a row with the default setting.
+        long_ticks = 100
+        ticks_short = ticks
+        ticks = long_ticks
+        r = [(x, run(bool(x))) for x in (1, 0, 0, 1)]
+        ms = float(np.mean([v for x, v in r if x])); ms_off = float(np.mean([v for x, v in r if not x]))   # `ms_per_tick`: the handle as a1mpc_create leaves it (timing events on)
+        ticks = ticks_short
+        short_runs = [run(True) for _ in range(6)]
         last_ms, fused = eng.last_control_tick_ms()
         mpc_ms = eng.last_kernel_ms()
     return {"workload": f"{n} robots: leg state + EKF + gait plan + swing legs + contacts/terrain + warm-started MPC (h=10, tick records) + joint torques per tick, device-resident, "
-                        "ONE C call per tick (a1mpc_control_tick_device)", "ms_per_tick": ms, "robot_ticks_per_s": n / (ms * 1e-3), "ms_per_tick_with_a1mpc_set_timing_off": ms_off, "last_tick_ms_by_its_own_events": last_ms,
+                        "ONE C call per tick (a1mpc_control_tick_device)", "ms_per_tick": ms, "robot_ticks_per_s": n / (ms * 1e-3), "ms_per_tick_with_a1mpc_set_timing_off": ms_off,
+            "protocol": f"runs of {long_ticks} back-to-back ticks between HIP events on the caller's stream, timing events on / off / off / on, means; `ms_per_tick` = on (the library's default)",
+            "ms_per_tick_runs_of_10_ticks_in_sequence": short_runs, "runs_of_10_ticks_note": "six identical runs (timing on): the figure follows the position in the sequence (clock ramp after "
+            "each synchronisation), which is what round 5's alternating ten-tick protocol mistook for an effect of the timing events", "last_tick_ms_by_its_own_events": last_ms,
             "mpc_launch_ms_of_the_last_tick": mpc_ms, "joint_torques_in_the_mpc_output_stage": bool(fused), "mean_mpc_iters": float(d["iters"].float().mean().item()),
             "solved_frac": float((d["status"] == 1).float().mean().item())}
 

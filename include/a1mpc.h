@@ -485,8 +485,9 @@ a1mpc_status a1mpc_update_config(a1mpc_handle h, const a1mpc_config* cfg);
 
 /* The handle's HIP timing events (around every launch: a1mpc_last_kernel_ms, a1mpc_last_stage_ms, a1mpc_last_control_tick_ms read them) on (default) / off.  An event
  * record is a packet of its own on the GPU's queue; a 400 Hz control loop that never reads the instrumentation can turn it off -- three records less per MPC tick, four
- * per control tick (round 5: batch-1 p50 -5 us, a chained control tick -15 us at 4096 robots).  With timing off the three calls above return
- * A1MPC_ERR_INVALID_ARGUMENT ("no kernel has been launched ...").  No result depends on it. */
+ * per control tick (batch-1 p50 -5 us; a chained control tick -15..-18 us at 4096 robots: each record is a marker packet in front of which the command processor drains
+ * the queue, 5-6 us -- kernel trace and the round-5 "timing off is slower" artefact explained in profiles/r06_control_tick_timeline.md).  With timing off the three calls
+ * above return A1MPC_ERR_INVALID_ARGUMENT ("no kernel has been launched ...").  No result depends on it. */
 a1mpc_status a1mpc_set_timing(a1mpc_handle h, int32_t on);
 
 /* instrumentation: duration of the last kernel launched through this handle (HIP events on its stream;
