@@ -740,7 +740,8 @@ struct RowSolver {
                     bw_at(t, bq3);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) { Bq[k] = bq3[k]; Bq[3 + k] = Bt[3 + k]; }
-                    g[t] = dot_bc<6>(Bq, lam);
+                    const double gt = dot_bc<6>(Bq, lam);
+                    if (act) lds[L::CG + t * 12 + ci] = gt;   // (general path: the gradient waits in its LDS table -- raw here, c g behind the Ruiz passes -- not in H registers)
                 }
                 else g[t] = BtT(lam);
             });
@@ -843,11 +844,10 @@ struct RowSolver {
             constexpr int N = COOP > 0 ? COOP : 1;
             constexpr int HSN = (H + N - 1) / N;
             const int cid = N > 1 ? coop_id : 0;
-            if (act) {
+            if (act) {   // (the raw gradient is in the CG table already: written by the adjoint sweep above, by every row of a shared set-up alike)
 #pragma unroll
                 for (int t = 0; t < H; ++t) {
-                    lds[L::CG + t * 12 + ci] = g[t];   // (raw; becomes c g below)
-                    if constexpr (UPD && H > 1) lds[L::GQT + t * 12 + ci] = (upd && !reinit) ? io.carry[CR::G + t * 12 + ci] : g[t];
+                    if constexpr (UPD && H > 1) lds[L::GQT + t * 12 + ci] = (upd && !reinit) ? io.carry[CR::G + t * 12 + ci] : lds[L::CG + t * 12 + ci];
                     lds[L::DL + t * 12 + ci] = 1.0;    // (every row of a shared set-up writes the same words)
                 }
             }

@@ -224,7 +224,11 @@ def kernel_resources(path):
 # and the update-path / contact-schedule variants at h = 16 / 20 are reported in kernel_resources.json but not gated.
 NO_SCRATCH = ("a1mpc_admm_kernelILi10ELi2E", "a1mpc_admm_kernelILi20ELi1ELb0ELb1ELb0ELb1E", "a1mpc_admm_cu_kernelILi16ELb0ELb1ELb0ELb1E", "a1mpc_setup_kernelILi10E",
               "a1mpc_setup_kernelILi16ELi1ELb0E", "a1mpc_setup_kernelILi20ELi1ELb0E", "a1mpc_solve_kernelILi10E", "a1mpc_solve_kernelILi16E", "a1mpc_solve_kernelILi20E",
-              "a1mpc_solve_coop_kernelILi")
+              "a1mpc_solve_coop_kernelILi",
+              # round 6: the general path (per-step feet / contact schedules) -- until then 87-754 spilled VGPRs per kernel, 145-503 scratch instructions inside loops
+              "a1mpc_solve_gen_kernelILi", "a1mpc_solve_gen_coop_kernelILi", "a1mpc_admm_gen_kernelILi", "a1mpc_setup_gen_kernelILi10E", "a1mpc_setup_gen_kernelILi16E")
+# ... and kernels that may park a few long-lived values (pointers, the rotation) in scratch ACROSS their loops but not inside them: (pattern, scratch bytes, scratch instructions in loops)
+BOUNDED_SCRATCH = (("a1mpc_setup_gen_kernelILi20E", 128, 8),)
 
 
 def resource_gaps(resources, no_scratch=None):
@@ -238,4 +242,12 @@ def resource_gaps(resources, no_scratch=None):
         for k, v in hits.items():
             if (v.get("scratch_bytes") or 0) > 0:
                 out.append(f"{k[:90]}: {v.get('vgpr_spill')} spilled VGPRs, {v.get('scratch_bytes')} B of scratch per lane ({v.get('scratch_instrs_in_loops')} scratch instructions inside loops)")
+    if no_scratch is NO_SCRATCH:
+        for key, max_bytes, max_in_loops in BOUNDED_SCRATCH:
+            hits = {k: v for k, v in resources.items() if key in k}
+            if not hits:
+                out.append(f"resource gate saw no kernel matching {key} (listing format changed?)")
+            for k, v in hits.items():
+                if (v.get("scratch_bytes") or 0) > max_bytes or (v.get("scratch_instrs_in_loops") or 0) > max_in_loops:
+                    out.append(f"{k[:90]}: {v.get('scratch_bytes')} B of scratch per lane (allowed {max_bytes}), {v.get('scratch_instrs_in_loops')} scratch instructions inside loops (allowed {max_in_loops})")
     return out
