@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
-PMC_SUMMARY = "r05_pmc_summary.json"   # static rocprofv3 --pmc summary of this round (tools/collect_profiles.sh + summarize_profiles.py)
+PMC_SUMMARY = "r06_pmc_summary.json"   # static rocprofv3 --pmc summary of this round (tools/collect_profiles.sh + summarize_profiles.py)
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 vector = matrix peak (AMD spec; = 1/2 of the 157.3 TF FP32 rate in MI355X_MICROARCH.md)
 BATCH = 4096
 HORIZON = 10
@@ -902,7 +902,7 @@ def main():
                                            "solves_per_s": n / (single_ms * 1e-3),
                                            "executed_fp64_frac": (pmc["executed_fp64_flops_per_launch"] / (single_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if pmc.get("executed_fp64_flops_per_launch") else None,
                                            "what": "the same first solves through ONE handle on one stream, launches serialised: the sum of the three kernels' durations in a kernel trace "
-                                                   "(profiles/r05_kernel_stats_bench_depth1_batch4096_h10.csv)"},
+                                                   "(profiles/r06_kernel_stats_bench_depth1_batch4096_h10.csv)"},
                          "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": pkg.algorithmic_bytes(h) * n,
                          "executed_fp64_flops_per_launch": pmc.get("executed_fp64_flops_per_launch"),
                          "executed_fp64_frac": (pmc["executed_fp64_flops_per_launch"] / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if pmc.get("executed_fp64_flops_per_launch") else None,

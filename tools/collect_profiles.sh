@@ -32,4 +32,6 @@ for shape in "65536,10" "8192,16" "32768,20"; do
   done
   A1_SHAPE=$shape timeout 200 rocprofv3 --kernel-trace --stats -d $O/shape_${shape/,/x}_trace --output-format csv -- python tools/prof_target.py > $O/shape_${shape/,/x}_trace.log 2>&1
 done
+# round 6: the general path (per-step feet + contact schedules): set-up | ADMM kernels of its split pipeline at 4096 / 16 384 x h10, 8192 x h16, 8192 x h20
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/general_trace --output-format csv -- python tools/general_path_stage_probe.py > $O/general_trace.log 2>&1
 find $O -name "*kernel_stats.csv" -exec head -6 {} \;

@@ -20,6 +20,9 @@ if os.path.exists(log):
     lines = [l for l in open(log) if l.startswith("{")]
     if lines:
         open(os.path.join(dst, TAG + "_bench_under_rocprof.json"), "w").write(lines[-1])
+f = newest(os.path.join(src, "general_trace", "**", "*kernel_stats.csv"))
+if f:
+    shutil.copy(f, os.path.join(dst, TAG + "_kernel_stats_general_path.csv"))
 f = newest(os.path.join(src, "trace_depth1", "**", "*kernel_stats.csv"))
 if f:
     shutil.copy(f, os.path.join(dst, TAG + "_kernel_stats_bench_depth1_batch4096_h10.csv"))
