@@ -763,13 +763,14 @@ struct RowSolver {
         // GEN: block (s,t) of B_qp'QB_qp is beta_st (gamma_st U_st + V_st) with U_st[a][b] = dt^2 (sum_c q_c TB_s[c][a] TB_t[c][b] + q_{3+k} (dt/m)^2 [k = comp_a = comp_b]),
         // V_st[a][b] = sum_c q_{6+c} B~w_s[c][a] B~w_t[c][b] + q_{9+k} (dt/m)^2 [..]: my row's step-s factors live in registers (for the steps s this row of the set-up owns), the
         // step-t tables in LDS
-        [[maybe_unused]] double Ucs[3], Vcs[3];
+        [[maybe_unused]] double Ucs[3], Vcs[3], Ucd[3];
         [[maybe_unused]] const double dt2 = dt * dt;
         if constexpr (GEN) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 Ucs[k] = (act && comp == k) ? P.q2[3 + k] * Bt[3 + k] * Bt[3 + k] : 0.0;
                 Vcs[k] = (act && comp == k) ? P.q2[9 + k] * Bt[3 + k] * Bt[3 + k] : 0.0;
+                Ucd[k] = Ucs[k] * dt2;
             }
         }
 
@@ -904,15 +905,17 @@ struct RowSolver {
                             const double gam = gnx, bet = bnx;
                             if constexpr (k + 1 < HSN) { gnx = tab[(sk[k + 1] * H + t) * 2]; bnx = tab[(sk[k + 1] * H + t) * 2 + 1]; }
                             const double z0 = fma(gam, zuS[k][0], zvS[k][0]), z1 = fma(gam, zuS[k][1], zvS[k][1]), z2 = fma(gam, zuS[k][2], zvS[k][2]);
-                            const double gd = gam * dt2;
-                            const double k3[3] = {fma(gd, Ucs[0], Vcs[0]), fma(gd, Ucs[1], Vcs[1]), fma(gd, Ucs[2], Vcs[2])};
-                            double a0 = 0.0, a1 = 0.0;
+                            const double k3[3] = {fma(gam, Ucd[0], Vcs[0]), fma(gam, Ucd[1], Vcs[1]), fma(gam, Ucd[2], Vcs[2])};   // (Ucd = dt^2 Ucs: the velocity-row constants of U)
+                            double a0, a1;
                             static_for<4>([&](auto Lg) {   // (z x r)_0 = z1 r2 - z2 r1, (z x r)_1 = z2 r0 - z0 r2, (z x r)_2 = z0 r1 - z1 r0
                                 constexpr int l = 3 * A1_CV(Lg);
                                 const double e0 = fma(z1, rt[l + 2], fma(-z2, rt[l + 1], k3[0]));
                                 const double e1 = fma(z2, rt[l + 0], fma(-z0, rt[l + 2], k3[1]));
                                 const double e2 = fma(z0, rt[l + 1], fma(-z1, rt[l + 0], k3[2]));
-                                if constexpr (A1_CV(Lg) % 2 == 0) max_abs3_f64(a0, a1, e0 * Dt[l], e1 * Dt[l + 1], e2 * Dt[l + 2]);   // a0 = max(a0, |x0|, |x2|), a1 = max(a1, |x1|)
+                                if constexpr (A1_CV(Lg) == 0) {   // the first leg seeds the two running maxima (|x| rides on the multiply's source modifiers: no move, no max)
+                                    a0 = fabs(e0) * Dt[l]; a1 = fabs(e1) * Dt[l + 1];
+                                    a0 = max_abs_f64(a0, e2 * Dt[l + 2]);
+                                } else if constexpr (A1_CV(Lg) % 2 == 0) max_abs3_f64(a0, a1, e0 * Dt[l], e1 * Dt[l + 1], e2 * Dt[l + 2]);   // a0 = max(a0, |x0|, |x2|), a1 = max(a1, |x1|)
                                 else max_abs3_f64(a1, a0, e2 * Dt[l + 2], e1 * Dt[l + 1], e0 * Dt[l]);
                             });
                             mk[k] = max_f64(mk[k], bet * max_f64(a0, a1));

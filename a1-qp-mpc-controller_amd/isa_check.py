@@ -226,9 +226,9 @@ NO_SCRATCH = ("a1mpc_admm_kernelILi10ELi2E", "a1mpc_admm_kernelILi20ELi1ELb0ELb1
               "a1mpc_setup_kernelILi16ELi1ELb0E", "a1mpc_setup_kernelILi20ELi1ELb0E", "a1mpc_solve_kernelILi10E", "a1mpc_solve_kernelILi16E", "a1mpc_solve_kernelILi20E",
               "a1mpc_solve_coop_kernelILi",
               # round 6: the general path (per-step feet / contact schedules) -- until then 87-754 spilled VGPRs per kernel, 145-503 scratch instructions inside loops
-              "a1mpc_solve_gen_kernelILi", "a1mpc_solve_gen_coop_kernelILi", "a1mpc_admm_gen_kernelILi", "a1mpc_setup_gen_kernelILi10E", "a1mpc_setup_gen_kernelILi16E")
+              "a1mpc_solve_gen_kernelILi", "a1mpc_solve_gen_coop_kernelILi", "a1mpc_admm_gen_kernelILi", "a1mpc_setup_gen_kernelILi10E")
 # ... and kernels that may park a few long-lived values (pointers, the rotation) in scratch ACROSS their loops but not inside them: (pattern, scratch bytes, scratch instructions in loops)
-BOUNDED_SCRATCH = (("a1mpc_setup_gen_kernelILi20E", 128, 8),)
+BOUNDED_SCRATCH = (("a1mpc_setup_gen_kernelILi16E", 64, 0), ("a1mpc_setup_gen_kernelILi20E", 128, 8))   # (two wavefronts per SIMD: 256 registers; a dozen long-lived values wait in scratch while the Ruiz passes run)
 
 
 def resource_gaps(resources, no_scratch=None):
