@@ -203,7 +203,15 @@ __global__ __launch_bounds__(64, 2) void a1mpc_setup_gen_kernel(const KernelArgs
     const int q = QPW == 2 ? (static_cast<int>(threadIdx.x) >> 4) & 1 : 0;
     const int64_t b = static_cast<int64_t>(blockIdx.x) * QPW + q;
     double* tabl = a1mpc_lds + QPW * LayoutSetup<H, true>::ROW_STRIDE;
-    for (int i = static_cast<int>(threadIdx.x); i < 2 * H * H; i += 64) tabl[i] = a.tab[i];
+    {   // the (gamma, beta) table: every load in flight before the first store (one L2 round trip per workgroup instead of one per 64 words; round 6: at one QP per workgroup the
+        // staging is paid per QP)
+        constexpr int N2 = 2 * H * H, PER = (N2 + 63) / 64;
+        double v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const int i = static_cast<int>(threadIdx.x) + 64 * k; v[k] = i < N2 ? a.tab[i] : 0.0; }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const int i = static_cast<int>(threadIdx.x) + 64 * k; if (i < N2) tabl[i] = v[k]; }
+    }
     __syncthreads();
     if (b >= a.n) return;   // (both rows of the pair leave together)
     setup_row<H, true>(a, tabl, b, a1mpc_lds + q * LayoutSetup<H, true>::ROW_STRIDE, prep);
