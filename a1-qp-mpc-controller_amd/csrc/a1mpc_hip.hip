@@ -1,13 +1,12 @@
-// a1mpc_hip.hip -- gfx950 kernels + the C ABI of include/a1mpc.h (liba1mpc.so).
+// a1mpc_hip.hip -- the C ABI of include/a1mpc.h (liba1mpc.so) and the caller-side kernels (gait plan, contacts / terrain, swing legs, leg kinematics, EKF, joint torques,
+// the dense-QP formation entry, the queue-order kernel).
 //
-// One workgroup = one wavefront = ROWS QPs (one per main / twin pair of 16-lane DPP rows; ROWS = 2 at H = 10, 1 at H >= 16), dynamic LDS =
-// ROWS x Layout<H>::ROW_STRIDE doubles (20.4 KB per QP at H = 10 -> eight QPs = four workgroups per CU); at H = 16 the persistent ADMM kernel is ONE
-// 256-thread workgroup per CU that carries five QPs (a1mpc_admm_cu_kernel); a wavefront that holds ONE QP (H = 20, waves 1-3 of the H = 16 workgroup) runs its four
-// rows as a quad on it (RowSolver<.., QUAD>).  Three ways through a batch (launch_mpc): the latency kernel (<= 256 QPs: the
-// rows of a wave share one QP's set-up), the fused kernel (up to the resident rows: one row pair = one QP from inputs to outputs; also warm-started ticks of a
-// known batch at H = 10) and the split pipeline (set-up kernel -> queue-order kernel -> persistent ADMM rows that drain the queue longest-first).  The QPs of a
-// batch are independent; nothing is shared between workgroups except the read-only (alpha/beta) table and the queue counter, so the blockIdx -> XCD mapping is
-// irrelevant here (no L2 reuse to localise).
+// The solver's kernels live in csrc/a1mpc_kernels.hpp and are compiled as one translation unit per (horizon, pipeline): csrc/a1mpc_k_*.hip (round 6; build.py compiles the
+// units in parallel).  This unit sees only the DECLARATIONS of their launch entry points (csrc/a1mpc_common.hpp) and decides which way a batch goes (launch_mpc,
+// solve_device_impl): the latency kernel (<= 256 QPs: the rows of a wave share one QP's set-up), the fused kernel (up to the resident rows: one row pair = one QP from
+// inputs to outputs; also warm-started ticks of a known batch) or the split pipeline (set-up kernel -> queue-order kernel -> persistent ADMM rows that drain the queue
+// longest-first); the general path (per-step feet / contact schedules) has the same three.  The QPs of a batch are independent; nothing is shared between workgroups except the
+// read-only (alpha/beta) table and the queue counter, so the blockIdx -> XCD mapping is irrelevant here (no L2 reuse to localise).
 //
 // There is no CPU path in this file: without a HIP device every entry point fails.
 #include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen()ed by a1mpc_sharded_create(transport = 1), never linked

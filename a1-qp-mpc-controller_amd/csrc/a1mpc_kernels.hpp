@@ -194,8 +194,10 @@ __global__ __launch_bounds__(256) void a1mpc_admm_cu_kernel(const KernelArgs a, 
     admm_rows<H, true, false, UPD, UNI, CLK>(a, prep, counter, a1mpc_lds + image * Layout<H>::ROW_STRIDE);
 }
 
-// The general path's own split pipeline (round 2, last step): the same two kernels over RowSolver<.., GEN = true>.  K1 holds the per-step table B~w_t
-// of four QPs (5.8 KB each at H = 10; T B~w_t stays in the registers of the lanes that own its columns -- round 5: four instead of two wavefronts per CU at H = 16); its record carries B~w_t to K2, whose rows rebuild the per-step tables of their LDS image from it.
+// The general path's own split pipeline (round 2, last step): the same two kernels over RowSolver<.., GEN = true>.  K1 (round 6): the rows of a wavefront that share a QP --
+// two at H = 10 (two QPs per wavefront), all four at H = 16 / 20 (setup_gen_rows) -- split the ROWS of the Hessian in the Ruiz passes (RowSolver::setup, general path); its LDS
+// image holds the foot table and the D / m / E hand-over tables of the passes but no B~w_t table (120 + 52 H doubles per QP): the per-step columns go straight into the record,
+// which carries them to K2, whose rows rebuild the per-step tables of their LDS image from it.  256 registers: two wavefronts per SIMD.
 template <int H>
 __global__ __launch_bounds__(64, 2) void a1mpc_setup_gen_kernel(const KernelArgs a, double* __restrict__ prep) {
     extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
