@@ -60,6 +60,39 @@ def test_scatter_solve_gather_world2(n):
     assert seen == ([(n + 1) // 2] if n > 0 else [])
 
 
+def _participation_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    part = bench.participation(dist, rank, world, 0, "gloo")     # (a collective: every rank calls it; no GPU here -- the identity falls back to host + local ordinal)
+    if rank == 0:
+        q.put(part)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_participation_gather_world2():
+    """round 6: the N > 1 bench line says which devices took part.  Two gloo ranks on this (GPU-less) host both claim local device 0: one distinct device, not a scaling point,
+    both ranks listed."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_participation_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    part = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert part["world_size"] == 2 and part["distinct_devices"] == 1 and part["is_scaling_point"] is False and part["rccl_world_size"] == 0 and part["backend"] == "gloo"
+    assert part["device_ids"].count("r0@") == 1 and part["device_ids"].count("r1@") == 1
+    import bench
+    one = bench.participation(None, 0, 1, 0, "nccl")              # N = 1: trivially a scaling point, no collective
+    assert one["distinct_devices"] == 1 and one["is_scaling_point"] is True and one["rccl_world_size"] == 0
+
+
 def test_partition(pkg):
     P = pkg.sharding.partition
     assert P(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
