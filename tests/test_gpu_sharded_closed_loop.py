@@ -117,3 +117,46 @@ def test_sharded_rccl_transport_one_rank_device_forms(pkg, scen):
             assert np.array_equal(o["grf"], ref[t]["grf"]) and np.array_equal(o["iters"], ref[t]["iters"]), t
         with pytest.raises(pkg.A1MpcError):
             sh.solve_ticks_device(n, None, t_(seq[0]["R"]), t_(seq[0]["foot"]), t_(seq[0]["contact"], torch.uint8), grf)
+
+
+def test_sharded_and_pipeline_argument_errors(pkg, scen):
+    """the new entries refuse what the old ones refuse: null pointers, a batch beyond max_batch, tick records at horizon 1, bad strides -- with a status, never a crash"""
+    import ctypes as C
+    import torch
+    n = 64
+    sc = scen.config3_random_flat(nb=n)
+    lib = pkg.load_library()
+    dev = torch.device("cuda:0")
+    t_ = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    cfg = pkg.make_config(sc["params"], 10, warm_start=1)
+    with pkg.ShardedEngine(cfg, n, devices=[0, 0], transport=0) as sh:
+        grf = torch.zeros(n, 12, dtype=torch.float64, device=dev)
+        with pytest.raises(pkg.A1MpcError):
+            sh.solve_ticks_device(n + 1, t_(sc["tick"]), t_(sc["R"]), t_(sc["foot"]), t_(sc["contact"], torch.uint8), grf)     # n > max_batch
+        with pytest.raises(pkg.A1MpcError):
+            sh.solve_device(n, None, t_(sc["xref"]), t_(sc["R"]), t_(sc["foot"]), t_(sc["contact"], torch.uint8), grf)          # null x0
+        with pytest.raises(pkg.A1MpcError):
+            sh.solve_ticks_device(n, t_(sc["tick"]), t_(sc["R"]), t_(sc["foot"]), t_(sc["contact"], torch.uint8), None)         # null output
+        h = C.c_void_p()
+        assert lib.a1mpc_sharded_handle(sh._h, 2, C.byref(h)) != 0 and lib.a1mpc_sharded_handle(sh._h, -1, C.byref(h)) != 0     # shard out of range
+        assert lib.a1mpc_sharded_handle(sh._h, 1, C.byref(h)) == 0 and h.value
+        assert lib.a1mpc_sharded_last_transfer(None, None, None) != 0
+        o = sh.solve_ticks(sc["tick"][:0], sc["R"][:0], sc["foot"][:0], sc["contact"][:0])                                      # n = 0: nothing to do
+        assert o["grf"].shape == (0, 12)
+    cfg1 = pkg.make_config(sc["params"], 1, warm_start=0)
+    with pkg.ShardedEngine(cfg1, n, devices=[0], transport=0) as sh1:
+        with pytest.raises(pkg.A1MpcError):
+            sh1.solve_ticks(sc["tick"], sc["R"], sc["foot"], sc["contact"])                                                      # tick records need horizon >= 2
+    with pkg.Pipeline(cfg, n, 0, depth=2) as pipe:
+        ins = [t_(sc["x0"]), t_(sc["xref"]), t_(sc["R"]), t_(sc["foot"]), t_(sc["contact"], torch.uint8)]
+        grf = torch.zeros(n, 12, dtype=torch.float64, device=dev)
+        with pytest.raises(pkg.A1MpcError):
+            pipe.submit_strided_device(n, ins[0], ins[1], ins[2], ins[3], 0, ins[4], 3, grf)                                    # contact_stride must be 0 or 4
+        with pytest.raises(pkg.A1MpcError):
+            pipe.submit_ticks_device(n, None, ins[2], ins[3], ins[4], grf)                                                      # null tick records
+        with pytest.raises(pkg.A1MpcError):
+            pipe.submit_strided_device(n + 1, *ins[:4], 0, ins[4], 0, grf)                                                       # n > max_batch
+        k = pipe.submit_strided_device(n, *ins[:4], 0, ins[4], 0, grf, slot=1)                                                   # a fixed slot; (0, 0, NULL): the plain entry
+        assert k == 1
+        pipe.wait()
+        assert float(grf.abs().max()) > 1.0
