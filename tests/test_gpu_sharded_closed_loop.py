@@ -1,6 +1,6 @@
 """GPU, through the C ABI: the round-6 entries of the sharded handle -- tick records, device-resident batches, per-shard warm starts (cfg.warm_start = 1 and 2).  The
 test box has ONE GPU: two / three shards on device 0 (transport 0: the peer copies degenerate to copies inside the device) and the RCCL transport with one rank.  Bar:
-bit-identical to ONE engine handle ticking the same robots -- whose ticks the oracle checks in tests/test_gpu_parity.py -- shard by shard (a shard's handle sees its slice
+bit-identical to ONE engine handle ticking the same robots -- whose ticks the oracle checks in tests/test_gpu_update_path.py -- shard by shard (a shard's handle sees its slice
 of the batch as batch positions 0 .. c-1, exactly like a lone handle given that slice)."""
 import numpy as np
 import pytest

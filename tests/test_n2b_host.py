@@ -1,6 +1,6 @@
 """N2b on the CPU: the product's contact / terrain kernel text compiled for the host (tests/emu/n2b_host.py) stepped against the oracle -- the shipped
 arithmetic AND the shipped state layout (records + sector-sized ring slots), window wrap of both filter lengths included.  The same sequence runs on the
-GPU in tests/test_gpu_parity.py::test_contact_terrain_N2b_sequence."""
+GPU in tests/test_gpu_caller_side.py::test_contact_terrain_N2b_sequence."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))

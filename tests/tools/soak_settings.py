@@ -1,5 +1,5 @@
 """Random COMBINATIONS of OSQP settings, friction / force limits, weight sets and horizons against the oracle (GPU): the single-setting cases of
-tests/test_gpu_parity.py::test_non_default_osqp_settings draw one knob at a time.  usage: soak_settings.py [first_seed [count [qps_per_case]]]"""
+tests/test_gpu_settings.py::test_non_default_osqp_settings draw one knob at a time.  usage: soak_settings.py [first_seed [count [qps_per_case]]]"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, __graft_entry__ as g
