@@ -21,20 +21,52 @@ class DeviceParams(C.Structure):  # mirrors a1mpc::DeviceParams (csrc/a1mpc_solv
                 ("scaling_iters", C.c_int32), ("warm_start", C.c_int32)]
 
 
+KNOWN_VARIANTS = {"fullsweep": ["-DA1X_FULL_SWEEP"], "poison": ["-DA1X_POISON"]}   # the extra builds tests/test_emu_parity.py asks for (variant())
+
+
+def _sources():
+    return [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_HERE, "a1mpc_rowops.hpp"), os.path.join(_CSRC, "a1mpc_solver.hpp"), os.path.join(_CSRC, "a1mpc_tables.hpp")]
+
+
+def _stale(path):
+    return not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in _sources())
+
+
+def _variant_path(tag):
+    return os.path.join(_HERE, f"liba1mpc_emu_{tag}.so")
+
+
+def _build_all(force=False, extra=None):
+    """Compiles every stale library of the test double -- the default build and the known variants -- IN PARALLEL (one g++ each: ~4 minutes of template instantiation per build,
+    three builds in a row were 11 minutes of the CPU suite) under one file lock: pytest-xdist workers that arrive later wait and find everything fresh.  A build is written to a
+    temporary name and renamed, so a reader never maps a half-written library."""
+    import fcntl
+    jobs = {}
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        want = {_LIB: os.environ.get("A1_EMU_FLAGS", "").split()}
+        want.update({_variant_path(t): list(f) for t, f in KNOWN_VARIANTS.items()})
+        want.update(extra or {})
+        for path, flags in want.items():
+            if force or _stale(path):
+                tmp = f"{path}.tmp{os.getpid()}"
+                jobs[path] = (tmp, subprocess.Popen(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", _HERE, "-I", _CSRC, _sources()[0], "-o", tmp] + flags))
+        for path, (tmp, proc) in jobs.items():
+            if proc.wait() != 0:
+                raise RuntimeError(f"g++ failed on the CPU test double ({os.path.basename(path)})")
+            os.replace(tmp, path)
+    return list(jobs)
+
+
 def build(force=False):
-    srcs = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_HERE, "a1mpc_rowops.hpp"),
-            os.path.join(_CSRC, "a1mpc_solver.hpp"), os.path.join(_CSRC, "a1mpc_tables.hpp")]
-    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", _HERE, "-I", _CSRC, srcs[0], "-o", _LIB] + os.environ.get("A1_EMU_FLAGS", "").split())
+    _build_all(force)
     return _LIB
 
 
 def variant(flags, tag):
     """a second build of the test double with extra compiler flags (e.g. -DA1X_FULL_SWEEP), as its own library; use it with `using()`"""
-    path = os.path.join(_HERE, f"liba1mpc_emu_{tag}.so")
-    srcs = [os.path.join(_HERE, "emu_harness.cpp"), os.path.join(_HERE, "a1mpc_rowops.hpp"), os.path.join(_CSRC, "a1mpc_solver.hpp"), os.path.join(_CSRC, "a1mpc_tables.hpp")]
-    if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", _HERE, "-I", _CSRC, srcs[0], "-o", path] + list(flags))
+    path = _variant_path(tag)
+    _build_all(extra=None if KNOWN_VARIANTS.get(tag) == list(flags) else {path: list(flags)})
     v = C.CDLL(path)
     assert v.a1mpc_emu_sizeof_params() == C.sizeof(DeviceParams)
     return v
