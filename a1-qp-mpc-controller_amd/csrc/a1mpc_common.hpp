@@ -111,6 +111,11 @@ inline bool cu_wide_enabled() {
     static const bool on = [] { const char* e = getenv("A1MPC_CU_WIDE"); return !(e && !strcmp(e, "0")); }();
     return on;
 }
+// the general path's CU-wide persistent kernel (a1mpc_admm_gen_cu_kernel; H = 10: seven QPs per CU).  A1MPC_GEN_CU_WIDE=0 falls back to the one-wave kernel, six per CU (A/B runs)
+inline bool gen_cu_wide_enabled() {
+    static const bool on = [] { const char* e = getenv("A1MPC_GEN_CU_WIDE"); return !(e && !strcmp(e, "0")); }();
+    return on;
+}
 // the quad-of-rows ADMM kernel (H = 20, broadcast contacts).  A1MPC_QUAD=0 falls back to the twin-pair kernel (A/B runs)
 inline bool quad_enabled() {
     static const bool on = [] { const char* e = getenv("A1MPC_QUAD"); return !(e && !strcmp(e, "0")); }();

@@ -231,6 +231,20 @@ __global__ __launch_bounds__(64) void a1mpc_admm_gen_kernel(const KernelArgs a, 
     admm_rows<H, true, true>(a, prep, counter, a1mpc_lds + (row & 1) * Layout<H, true>::ROW_STRIDE);
 }
 
+// The general path's persistent kernel, CU-wide (round 6; H = 10): ONE workgroup of four wavefronts owns a CU's whole LDS.  With the per-step bounds in registers an image of the
+// general path is 23.3 KB at H = 10: seven fit in 160 KB where one-wave workgroups of two QPs place six.  Waves 0-2 carry two QPs each (main / twin pairs on rows (0,2) and (1,3)),
+// wave 3 one; rows refill from the queue independently and nothing is shared between the waves (no workgroup barrier in admm_rows): the same bits as a1mpc_admm_gen_kernel.
+constexpr int cu_wide_gen_qps(int h) { return h == 10 ? 7 : 0; }
+template <int H>
+__global__ __launch_bounds__(256) void a1mpc_admm_gen_cu_kernel(const KernelArgs a, const double* __restrict__ prep, int* __restrict__ counter) {
+    extern __shared__ __attribute__((aligned(16))) double a1mpc_lds[];
+    static_assert(cu_wide_gen_qps(H) == 7 && !fused_quad_rows(H, kModeMpc, 1), "seven images: two on each of waves 0-2, one on wave 3; main / twin pairs of rows");
+    const int wave = static_cast<int>(threadIdx.x) >> 6, row = (static_cast<int>(threadIdx.x) >> 4) & 3;
+    if (wave == 3 && (row & 1)) return;   // wave 3: rows 1 and 3 have no QP
+    const int image = 2 * wave + (wave == 3 ? 0 : (row & 1));
+    admm_rows<H, true, true>(a, prep, counter, a1mpc_lds + image * Layout<H, true>::ROW_STRIDE);
+}
+
 
 // workgroups of the persistent ADMM kernel that are resident at once on the current device (occupancy query, cached per device)
 template <int H, int ROWS>
@@ -515,6 +529,29 @@ a1mpc_status launch_gen_split_rows(const KernelArgs& a, double* prep, int* count
         A1_HIP(hipGetLastError());
     }
     if (mid) A1_HIP(hipEventRecord(mid, stream));
+    if constexpr (cu_wide_gen_qps(H) > 0) {
+        if (gen_cu_wide_enabled()) {   // seven QPs per CU: one 256-thread workgroup per CU (a1mpc_admm_gen_cu_kernel)
+            constexpr int Q = cu_wide_gen_qps(H);
+            const size_t ldsq = sizeof(double) * Q * Layout<H, true>::ROW_STRIDE;
+            static int resq_dev[64] = {};
+            int resq = 0;
+            {
+                std::lock_guard<std::mutex> lock(g_cache_mu);
+                if (dev >= 0 && dev < 64 && !resq_dev[dev]) {
+                    A1_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&a1mpc_admm_gen_cu_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ldsq)));
+                    int per_cu = 0, cus = 0;
+                    A1_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&a1mpc_admm_gen_cu_kernel<H>), 256, ldsq));
+                    A1_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+                    resq_dev[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+                }
+                resq = (dev >= 0 && dev < 64) ? resq_dev[dev] : 256;
+            }
+            const int wantq = (a.n + Q - 1) / Q;
+            hipLaunchKernelGGL((a1mpc_admm_gen_cu_kernel<H>), dim3(static_cast<unsigned>(wantq < resq ? wantq : resq)), dim3(256), ldsq, stream, a, static_cast<const double*>(prep), counter);
+            A1_HIP(hipGetLastError());
+            return A1MPC_OK;
+        }
+    }
     const int want = (a.n + ROWS - 1) / ROWS;
     hipLaunchKernelGGL((a1mpc_admm_gen_kernel<H, ROWS>), dim3(static_cast<unsigned>(want < res ? want : res)), dim3(64), lds2, stream, a, static_cast<const double*>(prep), counter);
     A1_HIP(hipGetLastError());

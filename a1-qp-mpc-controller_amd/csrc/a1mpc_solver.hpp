@@ -279,9 +279,8 @@ struct Layout {
     static constexpr int ZROW = 6;           // a seventh, all-zero row of B~: the row of every lane that owns no wrench state
     static constexpr int CG = BL + 84;       // c*g = D^-1 q_s, [t][12]
     static constexpr int BW = CG + 12 * H;   // GEN: [t][3][12] = dt*Iw^-1*skew(r_t), the omega rows of B~_t (rows 3-5 of B~ are step-invariant)
-    static constexpr int LBT = BW + (GEN ? 36 * H : 0);   // GEN: [t][12] lower bound of my slot-0 row at step t
-    static constexpr int UBT = LBT + (GEN ? 12 * H : 0);  // GEN: [t][12] upper bound
-    static constexpr int RAW = UBT + (GEN ? 12 * H : 0);
+    static constexpr int RAW = BW + (GEN ? 36 * H : 0);   // (round 6: the per-step bounds of the general path live in registers like the fast path's -- slot_bounds from the contact bits --
+                                                          // not in two more tables: 24 H doubles less per image, seven instead of six QPs per CU at H = 10 in the CU-wide workgroup)
     // set-up-only aliases inside the factor region (the factor is written after Ruiz is finished)
     static constexpr int TBL = 0;            // T*B~_omega (3x12)
     static constexpr int DL = 36;            // D table of the current Ruiz pass, [t][12]
@@ -319,7 +318,7 @@ struct LayoutSetup {
     static constexpr int ML = FT + (GEN ? 12 * H : 0);       // GEN: [t][12] the column maxima of a Ruiz pass, written by the row that owns step t
     static constexpr int E0X = ML;                           // GEN: [t][16 lanes] the E hand-over behind the last pass (the maxima are dead by then)
     static constexpr int COOP = 0, TAB = 0;           // never used by the set-up kernels (the fast path's: one row per QP; the kernels stage the table behind the rows' images themselves)
-    static constexpr int CUV = 0, LBT = 0, UBT = 0;          // (not written by a set-up-only solver)
+    static constexpr int CUV = 0;                            // (not written by a set-up-only solver)
     static constexpr int BL = ML + (GEN ? 16 * H : 0);
     static constexpr int ZROW = 6;
     static constexpr int CG = BL + 84;
@@ -427,7 +426,7 @@ struct RowSolver {
                      // an LDS read costs the wave ~12 issue cycles whatever its width (tools/ubench/issue_cost_ubench.hip)
     double cy, sy, fA, fB, fC, fP, gA, gB, gC, gV, q2s, r2a;
     double csc, cinv, qd, lo_u, hi_u, lb0, ub0;   // (lo_u .. ub0: step 0's)
-    double lbk[HS], ubk[HS];  // bounds of my slot-0 row per slot: contacts may follow a per-step schedule (contact_stride = 4); the general path keeps them in LDS
+    double lbk[HS], ubk[HS];  // bounds of my slot-0 row per slot: contacts may follow a per-step schedule (contact_stride = 4)
     unsigned eqmask;  // bit t: my slot-0 row at step t is an equality row (swing leg: l = u = 0; auxil.c set_rho_vec)
     unsigned cmask;   // bit t: my leg is in contact at step t
     int r0, r1;       // reference row numbers of my two rows inside a (step, leg) block
@@ -525,12 +524,10 @@ struct RowSolver {
         return dot_bc<0>(Br, u);  // lanes without a wrench state read the zero row
     }
     // ---- per-step accessors (GEN: tables in LDS; otherwise the step-invariant registers)
-    A1_DEV double lb_at(int t) const { if constexpr (GEN) return lds[L::LBT + t * 12 + ci]; else return lb0; }  // (GEN callers only)
-    A1_DEV double ub_at(int t) const { if constexpr (GEN) return lds[L::UBT + t * 12 + ci]; else return ub0; }
     template <int K>
-    A1_DEV double lbs(int t) const { if constexpr (GEN) return lds[L::LBT + t * 12 + ci]; else return lbk[UNI ? 0 : K]; }  // slot K = horizon step t
+    A1_DEV double lbs(int) const { return lbk[UNI ? 0 : K]; }  // slot K = horizon step t
     template <int K>
-    A1_DEV double ubs(int t) const { if constexpr (GEN) return lds[L::UBT + t * 12 + ci]; else return ubk[UNI ? 0 : K]; }
+    A1_DEV double ubs(int) const { return ubk[UNI ? 0 : K]; }
     A1_DEV void slot_bounds(int k, int t) {  // from the contact bit of step t
         const double cf = (cmask >> t) & 1u ? 1.0 : 0.0;
         lbk[k] = comp == 2 ? P.fz_min * cf : 0.0;
@@ -1171,9 +1168,7 @@ struct RowSolver {
             const double cf = ct ? 1.0 : 0.0;
             const double lo_t = P.fz_min * cf, hi_t = P.fz_max * cf;
             if (ct) cmask |= 1u << t;
-            if constexpr (GEN) {
-                if constexpr (!SETUP_ONLY) { if (act) { lds[L::LBT + t * 12 + ci] = comp == 2 ? lo_t : 0.0; lds[L::UBT + t * 12 + ci] = comp == 2 ? hi_t : kInfty; } }  // (the ADMM kernel of the split pipeline rebuilds them from the contact bits)
-            } else if constexpr (!TWIN) {
+            if constexpr (!TWIN) {   // (the solve object of every kernel rebuilds its slots' bounds from the contact bits of the hand-off record: load_prepared)
                 lbk[t] = comp == 2 ? lo_t : 0.0; ubk[t] = comp == 2 ? hi_t : kInfty;
             }
             const bool eq = comp == 2 && (E0t_ * hi_t - E0t_ * lo_t < kRhoTol);
@@ -1370,7 +1365,7 @@ struct RowSolver {
         rho = p[PR::RHO * 12 + ci];
         cmask = act ? static_cast<unsigned>(pk & 0xfffffu) : 0u;
 #pragma unroll
-        for (int k = 0; k < HS; ++k) { if constexpr (!GEN) slot_bounds(k, NS * k + own); }
+        for (int k = 0; k < HS; ++k) slot_bounds(k, NS * k + own);
         lo_u = P.fz_min * (cmask & 1u ? 1.0 : 0.0); hi_u = P.fz_max * (cmask & 1u ? 1.0 : 0.0);
         lb0 = comp == 2 ? lo_u : 0.0; ub0 = comp == 2 ? hi_u : kInfty;
         eqmask = act ? static_cast<unsigned>((pk >> 20) & 0xfffffu) : 0u;
@@ -1380,9 +1375,6 @@ struct RowSolver {
                     constexpr int t = A1_CV(T);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) lds[L::BW + (t * 3 + c) * 12 + ci] = p[(PR::BWF + 3 * t + c) * 12 + ci];
-                    const double cf = (cmask >> t) & 1u ? 1.0 : 0.0;
-                    lds[L::LBT + t * 12 + ci] = comp == 2 ? P.fz_min * cf : 0.0;
-                    lds[L::UBT + t * 12 + ci] = comp == 2 ? P.fz_max * cf : kInfty;
                 });
             }
         }

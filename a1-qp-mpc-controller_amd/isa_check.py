@@ -159,7 +159,7 @@ def dpp_hazards(path, key=""):
 # The check must not fail OPEN: if a change of listing format, name mangling or block labels made _parse() find nothing, dpp_hazards() would
 # return [] and every build would pass.  build() therefore also demands that the kernels made of inline-asm DPP chains were found and that a
 # plausible number of v_fmac_f64_dpp instructions was inspected in each.
-EXPECTED_DPP = {"a1mpc_admm_kernelILi10E": 1500, "a1mpc_admm_kernelILi16E": 2500, "a1mpc_admm_kernelILi20E": 3000, "a1mpc_admm_cu_kernelILi16E": 2500, "a1mpc_setup_kernelILi10E": 60,
+EXPECTED_DPP = {"a1mpc_admm_gen_cu_kernelILi10E": 1500, "a1mpc_admm_kernelILi10E": 1500, "a1mpc_admm_kernelILi16E": 2500, "a1mpc_admm_kernelILi20E": 3000, "a1mpc_admm_cu_kernelILi16E": 2500, "a1mpc_setup_kernelILi10E": 60,
                 "a1mpc_solve_kernelILi10E": 1500, "a1mpc_solve_coop_kernelILi10E": 1500, "a1mpc_solve_gen_kernelILi10E": 1500}
 
 
@@ -226,7 +226,7 @@ NO_SCRATCH = ("a1mpc_admm_kernelILi10ELi2E", "a1mpc_admm_kernelILi20ELi1ELb0ELb1
               "a1mpc_setup_kernelILi16ELi1ELb0E", "a1mpc_setup_kernelILi20ELi1ELb0E", "a1mpc_solve_kernelILi10E", "a1mpc_solve_kernelILi16E", "a1mpc_solve_kernelILi20E",
               "a1mpc_solve_coop_kernelILi",
               # round 6: the general path (per-step feet / contact schedules) -- until then 87-754 spilled VGPRs per kernel, 145-503 scratch instructions inside loops
-              "a1mpc_solve_gen_kernelILi", "a1mpc_solve_gen_coop_kernelILi", "a1mpc_admm_gen_kernelILi", "a1mpc_setup_gen_kernelILi10E")
+              "a1mpc_solve_gen_kernelILi", "a1mpc_solve_gen_coop_kernelILi", "a1mpc_admm_gen_kernelILi", "a1mpc_admm_gen_cu_kernelILi", "a1mpc_setup_gen_kernelILi10E")
 # ... and kernels that may park a few long-lived values (pointers, the rotation) in scratch ACROSS their loops but not inside them: (pattern, scratch bytes, scratch instructions in loops)
 BOUNDED_SCRATCH = (("a1mpc_setup_gen_kernelILi16E", 64, 0), ("a1mpc_setup_gen_kernelILi20E", 128, 8))   # (two wavefronts per SIMD: 256 registers; a dozen long-lived values wait in scratch while the Ruiz passes run)
 
