@@ -310,7 +310,9 @@ static a1mpc_status launch_gen_split(int horizon, const KernelArgs& a, double* p
     }
     return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet / contact schedules need horizon 10, 16 or 20");
 }
-// LDS per QP: 25.2 KB (H = 10: six QPs per CU), 39.9 KB (H = 16: four, one per wavefront like the fast path's), 49.7 KB (H = 20: three, one row per workgroup)
+// LDS per QP (round 6: the per-step bounds left the image): 22.7 KB (H = 10: six QPs per CU in one-wave workgroups, seven in the CU-wide persistent kernel), 35.9 KB (H = 16: four,
+// one per wavefront like the fast path's), 44.7 KB (H = 20: three, one row per workgroup) -- which also leaves 13 / 26 KB of a CU's LDS free at H = 16 / 20: the set-up kernel of a
+// second batch in flight (11.7 / 15.7 KB per workgroup) now runs BESIDE the persistent kernel instead of behind it (profiles/r06_general_pipeline.md)
 static a1mpc_status launch_gen(int horizon, const KernelArgs& a, hipStream_t s) {
     switch (horizon) {
         case 10: return launch_gen_rows<10, 2>(a, s);
