@@ -39,6 +39,17 @@ constexpr size_t lds_bytes(int rows) { return sizeof(double) * rows * Layout<H>:
 // wavefront then puts them on four SIMDs instead of two -- no more QPs in flight, but no row waits for a wave-mate's hand-over or factor pass any more and the LDS
 // conflicts between the two images go (8192 x h16 first solve 4.62 -> 4.41 ms, 16 384 x h20 10.35 -> 10.04 ms).  A1MPC_ROWS_PER_WG = 1 | 2 | 4 overrides.
 constexpr int default_rows_per_wg(int horizon) { return horizon >= 16 ? 1 : 2; }
+// Horizons compiled in (the reference fixes PLAN_HORIZON = 10 at compile time, S/A1Params.h:26; a run-time value here).  1 / 10 / 16 / 20 are the tuned ones (the
+// balance-QP analogue, the reference's horizon, BASELINE configs[3] / [4]): fast path AND general path, every kernel variant.  The other even horizons up to 14 run the
+// fast path's kernel family as it instantiates for them -- a main / twin pair of rows per QP, two QPs per wavefront, split and fused pipelines, latency kernel, all three
+// warm-start modes, contact schedules, tick records; no scratch in any of their kernels (the resource gate covers them) -- so that a controller built with another
+// PLAN_HORIZON still finds its QP.  Odd horizons do not exist (a twin pair splits the steps by parity), 18 would spill (one QP per wavefront without the quads of
+// rows that make 16 and 20 fit: 194-257 spilled registers, measured) and 2 is left out because its fused kernel and its split pipeline part by one unit in the last
+// place (2.6e-13 N: a contraction the backend places differently in the two instantiations, DESIGN 8 item 5 -- every offered horizon is bit-identical across
+// its pipelines, tools/cross_pipeline_bits.py); per-step feet (the general path) exist at 10 / 16 / 20 only.
+#define A1MPC_FAST_HORIZONS(X) X(1) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(20)
+#define A1MPC_MULTI_STEP_HORIZONS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(20)   // ... with an update path (warm_start = 2): every one of them but 1
+#define A1MPC_HORIZON_LIST "1, 4, 6, 8, 10, 12, 14, 16 or 20"
 // The shipped build instantiates the kernels for the default rows per workgroup only (the other two layouts were measured and lost, above; every extra layout of
 // the H = 16 / 20 kernels costs a minute of compile time): the override is honoured by -DA1MPC_ALL_ROWS tuning builds.
 static int rows_per_wg(int horizon) {

@@ -266,18 +266,17 @@ a1mpc_status set_lds_attr(const void* fn, size_t bytes) {
 
 static size_t carry_stride(int horizon) {
     switch (horizon) {
-        case 10: return Carry<10>::STRIDE;
-        case 16: return Carry<16>::STRIDE;
-        case 20: return Carry<20>::STRIDE;
+#define A1_CASE(H) case H: return Carry<H>::STRIDE;
+        A1MPC_MULTI_STEP_HORIZONS(A1_CASE)
+#undef A1_CASE
     }
     return 0;  // (horizon 1: the update path does not apply -- warm_start = 2 behaves like 1)
 }
 static size_t prep_stride(int horizon) {
     switch (horizon) {
-        case 1: return Prep<1>::STRIDE;
-        case 10: return Prep<10>::STRIDE;
-        case 16: return Prep<16>::STRIDE;
-        case 20: return Prep<20>::STRIDE;
+#define A1_CASE(H) case H: return Prep<H>::STRIDE;
+        A1MPC_FAST_HORIZONS(A1_CASE)
+#undef A1_CASE
     }
     return 0;
 }
@@ -308,7 +307,7 @@ static a1mpc_status launch_gen_split(int horizon, const KernelArgs& a, double* p
         case 16: if (a1mpc_status st = resident_workgroups_gen<16, 1>(&wg); st != A1MPC_OK) return st; return launch_gen_split_rows<16, 1>(a, prep, counter, s, mid, wg);
         case 20: if (a1mpc_status st = resident_workgroups_gen<20, 1>(&wg); st != A1MPC_OK) return st; return launch_gen_split_rows<20, 1>(a, prep, counter, s, mid, wg);
     }
-    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet / contact schedules need horizon 10, 16 or 20");
+    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet (foot_stride = 12) and a separate A_c yaw need horizon 10, 16 or 20");
 }
 // LDS per QP (round 6: the per-step bounds left the image): 22.7 KB (H = 10: six QPs per CU in one-wave workgroups, seven in the CU-wide persistent kernel), 35.9 KB (H = 16: four,
 // one per wavefront like the fast path's), 44.7 KB (H = 20: three, one row per workgroup) -- which also leaves 13 / 26 KB of a CU's LDS free at H = 16 / 20: the set-up kernel of a
@@ -319,7 +318,7 @@ static a1mpc_status launch_gen(int horizon, const KernelArgs& a, hipStream_t s) 
         case 16: return launch_gen_rows<16, 1>(a, s);
         case 20: return launch_gen_rows<20, 1>(a, s);
     }
-    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet / contact schedules need horizon 10, 16 or 20");
+    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet (foot_stride = 12) and a separate A_c yaw need horizon 10, 16 or 20");
 }
 
 static bool warm_fused_enabled() {
@@ -343,10 +342,9 @@ static a1mpc_status use_split_pipeline(int horizon, int n, bool have_prep, bool*
     int rows = 0;
     a1mpc_status st = A1MPC_OK;
     switch (horizon) {
-        case 10: st = resident_rows<10>(&rows); break;
-        case 1: st = resident_rows<1>(&rows); break;
-        case 16: st = resident_rows<16>(&rows); break;
-        case 20: st = resident_rows<20>(&rows); break;
+#define A1_CASE(H) case H: st = resident_rows<H>(&rows); break;
+        A1MPC_FAST_HORIZONS(A1_CASE)
+#undef A1_CASE
         default: return A1MPC_OK;
     }
     *split = n > rows;
@@ -365,27 +363,24 @@ static a1mpc_status launch_mpc(int horizon, const KernelArgs& a, double* prep, i
     }
     if (split && prep && counter) {
         switch (horizon) {
-            case 10: return launch_split<10>(a, prep, counter, s, mid);
-            case 1: return launch_split<1>(a, prep, counter, s, mid);
-            case 16: return launch_split<16>(a, prep, counter, s, mid);
-            case 20: return launch_split<20>(a, prep, counter, s, mid);
+#define A1_CASE(H) case H: return launch_split<H>(a, prep, counter, s, mid);
+            A1MPC_FAST_HORIZONS(A1_CASE)
+#undef A1_CASE
         }
     }
     switch (horizon) {
-        case 1: return launch<1, kModeMpc>(a, s);
-        case 10: return launch<10, kModeMpc>(a, s);
-        case 16: return launch<16, kModeMpc>(a, s);
-        case 20: return launch<20, kModeMpc>(a, s);
+#define A1_CASE(H) case H: return launch<H, kModeMpc>(a, s);
+        A1MPC_FAST_HORIZONS(A1_CASE)
+#undef A1_CASE
     }
-    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be 1, 10, 16 or 20");
+    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be " A1MPC_HORIZON_LIST);
 }
 static size_t lds_bytes_of(int horizon) {
     const int r = rows_per_wg(horizon);
     switch (horizon) {
-        case 1: return lds_bytes<1>(r);
-        case 10: return lds_bytes<10>(r);
-        case 16: return lds_bytes<16>(r);
-        case 20: return lds_bytes<20>(r);
+#define A1_CASE(H) case H: return lds_bytes<H>(r);
+        A1MPC_FAST_HORIZONS(A1_CASE)
+#undef A1_CASE
     }
     return 0;
 }
@@ -1688,7 +1683,7 @@ void a1mpc_destroy(a1mpc_handle h) {
 a1mpc_status a1mpc_create(const a1mpc_config* cfg, int32_t max_batch, int32_t device, a1mpc_handle* out) {
     if (!cfg || !out || max_batch <= 0 || device < 0) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null config/out or bad batch/device");
     *out = nullptr;
-    if (lds_bytes_of(cfg->horizon) == 0) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be 1, 10, 16 or 20");
+    if (lds_bytes_of(cfg->horizon) == 0) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be " A1MPC_HORIZON_LIST);
     if (const char* why = invalid_config(*cfg)) return fail(A1MPC_ERR_INVALID_ARGUMENT, why);   // (before any device query: a bad configuration is reported as such on every machine)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(A1MPC_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
@@ -2649,7 +2644,7 @@ a1mpc_status a1mpc_sharded_create(const a1mpc_config* cfg, int32_t max_batch, co
                                   a1mpc_sharded* out) {
     if (!cfg || !out || max_batch <= 0 || (transport != 0 && transport != 1)) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null config/out, bad batch or transport");
     *out = nullptr;
-    if (lds_bytes_of(cfg->horizon) == 0) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be 1, 10, 16 or 20");
+    if (lds_bytes_of(cfg->horizon) == 0) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "horizon must be " A1MPC_HORIZON_LIST);
     if (const char* why = invalid_config(*cfg)) return fail(A1MPC_ERR_INVALID_ARGUMENT, why);
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return fail(A1MPC_ERR_NO_DEVICE, "hipGetDeviceCount found no device");

@@ -227,7 +227,7 @@ extern "C" void a1mpc_emu_set_twin(int on) { a1mpc::g_emu_twin = on; }
 extern "C" void a1mpc_emu_set_contact_stride(int stride) { a1mpc::g_emu_contact_stride = stride; }
 extern "C" void a1mpc_emu_set_carry(double* carry) { a1mpc::g_emu_carry = carry; }
 extern "C" int a1mpc_emu_carry_stride(int horizon) {
-    switch (horizon) { case 10: return a1mpc::Carry<10>::STRIDE; case 16: return a1mpc::Carry<16>::STRIDE; case 20: return a1mpc::Carry<20>::STRIDE; case 4: return a1mpc::Carry<4>::STRIDE; }
+    switch (horizon) { case 10: return a1mpc::Carry<10>::STRIDE; case 16: return a1mpc::Carry<16>::STRIDE; case 20: return a1mpc::Carry<20>::STRIDE; case 4: return a1mpc::Carry<4>::STRIDE; case 12: return a1mpc::Carry<12>::STRIDE; }
     return 0;
 }
 
@@ -298,6 +298,8 @@ extern "C" int a1mpc_emu_solve_split(const a1mpc::DeviceParams* P, int horizon, 
         case 10: a1mpc::run_split<10>(a, nrows, twin); return 0;
         case 16: a1mpc::run_split<16>(a, nrows, twin); return 0;
         case 20: a1mpc::run_split<20>(a, nrows, twin); return 0;
+        case 4: a1mpc::run_split<4>(a, nrows, twin); return 0;     // two of the extended horizons (csrc/a1mpc_common.hpp, A1MPC_FAST_HORIZONS): the shortest, and one beyond 10
+        case 12: a1mpc::run_split<12>(a, nrows, twin); return 0;
     }
     return -1;
 }
@@ -372,6 +374,7 @@ extern "C" int a1mpc_emu_solve(const a1mpc::DeviceParams* P, int horizon, int n,
     switch (horizon) {
         case 1: a1mpc::run_batch<1>(P, n, x0, xref, R, foot, contact, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
         case 4: a1mpc::run_batch<4>(P, n, x0, xref, R, foot, contact, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
+        case 12: a1mpc::run_batch<12>(P, n, x0, xref, R, foot, contact, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
         case 10: a1mpc::run_batch<10>(P, n, x0, xref, R, foot, contact, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
         case 16: a1mpc::run_batch<16>(P, n, x0, xref, R, foot, contact, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;
         case 20: a1mpc::run_batch<20>(P, n, x0, xref, R, foot, contact, grf, u_full, warm_x, warm_y, rho, iters, status, nfact); return 0;

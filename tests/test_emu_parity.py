@@ -61,7 +61,8 @@ def test_emulated_all_swing_and_max_iter(oracle, scen):
     assert out["iters"][0] == 30 and out["status"][0] == ref["status"][0] and np.abs(out["u"] - ref["u"]).max() < 1e-8
 
 
-@pytest.mark.parametrize("gen,kw,n,rows", [("config3_random_flat", dict(nb=8), 7, 2), ("config4_random_h16", dict(nb=4), 3, 1)])
+@pytest.mark.parametrize("gen,kw,n,rows", [("config3_random_flat", dict(nb=8), 7, 2), ("config4_random_h16", dict(nb=4), 3, 1),
+                                            ("config3_random_flat", dict(nb=4, horizon=4), 3, 2), ("config3_random_flat", dict(nb=4, horizon=12), 3, 2)])
 def test_emulated_split_pipeline(oracle, scen, gen, kw, n, rows):
     """set-up kernel -> prepared state in memory -> persistent ADMM rows pulling QPs from the shared counter"""
     sc = getattr(scen, gen)(**kw)
@@ -182,7 +183,8 @@ def test_emulated_failed_tick_does_not_poison_warm_start(oracle, scen):
 
 
 # ---- main / twin pairs of rows (RowSolver<.., TWIN>: what every device kernel with H > 1 runs) ------------------------------------------------
-@pytest.mark.parametrize("gen,kw,n", [("config3_random_flat", dict(nb=8), 5), ("config4_random_h16", dict(nb=4), 2), ("config5_divergent", dict(nb=4), 2)])
+@pytest.mark.parametrize("gen,kw,n", [("config3_random_flat", dict(nb=8), 5), ("config4_random_h16", dict(nb=4), 2), ("config5_divergent", dict(nb=4), 2),
+                                       ("config3_random_flat", dict(nb=4, horizon=4), 4), ("config5_divergent", dict(nb=4, horizon=12), 2)])   # (two of the extended horizons)
 def test_emulated_twin_rows_match_the_single_row_code_bit_for_bit(oracle, scen, gen, kw, n):
     """the pair splits the per-lane state by horizon step and the two products of a backward step, and swaps values between the rows
     (twin_exchange); every value is formed by the same operations in the same order as in the single-row code"""
@@ -364,16 +366,16 @@ def test_emulated_general_path_split_pipeline(scen, h, feet, cont, rows):
     assert (fused["iters"] == split["iters"]).all() and (fused["status"] == split["status"]).all() and (fused["nfact"] == split["nfact"]).all()
 
 
-@pytest.mark.parametrize("path", ["fused_twin", "split_twin", "single_row"])
-def test_emulated_update_path_matches_oracle(oracle, scen, path):
+@pytest.mark.parametrize("path,h", [("fused_twin", 10), ("split_twin", 10), ("single_row", 10), ("fused_twin", 4), ("split_twin", 12)])   # (h = 4, 12: two of the extended horizons)
+def test_emulated_update_path_matches_oracle(oracle, scen, path, h):
     """warm_start = 2, the reference's tick >= 2 UPDATE path (S/A1RobotControl.cpp:533-538): previous gradient in the Ruiz cost normalisation, carried iterates
     read in the new scaling, first iteration from the carried z -- the solver source, lane for lane, against the oracle's restatement of OSQP's update
     functions (orc_mpc_solve_update): same iteration count every tick, forces to 1e-8 N (1e-7 N after the failed tick), through a contact switch and a failed tick."""
-    seq = scen.config2_trot_sequence(70)
+    seq = scen.config2_trot_sequence(70, horizon=h)
     pr = oracle_params(oracle, seq); st = oracle.default_settings(warm_start=1)
     kw = dict(fused_twin=dict(twin=True), split_twin=dict(split_rows=1, twin=True), single_row=dict())[path]
-    carry_o = oracle.update_carry(10)
-    wx = np.zeros((1, 120)); wy = np.zeros((1, 200)); rho = np.zeros(1); carry = emu.carry_buffer(10, 1)
+    carry_o = oracle.update_carry(h)
+    wx = np.zeros((1, 12 * h)); wy = np.zeros((1, 20 * h)); rho = np.zeros(1); carry = emu.carry_buffer(h, 1)
     ticks = list(range(0, 6)) + list(range(57, 64))      # (the contacts switch 1001 -> 0110 at tick 60; jumping from tick 5 to 57 is one more big change of the state)
     for i, k in enumerate(ticks):
         x0 = seq["x0"][k].copy()
