@@ -43,27 +43,32 @@ __global__ __launch_bounds__(256) void a1mpc_predict_kernel(const KernelArgs a, 
 
 // K3: the next solve's queue order = this solve's QPs by decreasing cost (counting sort, one workgroup).  A batch of 1-4x the resident
 // rows is otherwise finished by whichever long QP happened to start last; longest-first makes the makespan max(longest, total / rows).
-__global__ __launch_bounds__(1024) void a1mpc_order_kernel(int n, const int32_t* __restrict__ cost, int32_t* __restrict__ order) {
-    __shared__ int hist[256];
+// 256 threads, 24 registers, 512 B of LDS (round 6): ONE wavefront per SIMD, which fits BESIDE a resident persistent wavefront (424 of 512 registers, 1 KB of a CU's LDS
+// left at H = 10).  As a 1024-thread workgroup (four wavefronts per SIMD) it had to wait for a CU with no persistent wavefront at all: 6 us behind its own batch's set-up
+// with two batches in flight, but 0.4-0.5 ms per launch as soon as a third slot lets a batch's set-up run ahead of its turn (kernel trace, profiles/r06_setup_ahead.md).
+// The costs (0 .. 2047) are bucketed by 16 instead of 8 (128 buckets): scheduling only
+constexpr int kOrderThreads = 256, kOrderBins = 128, kOrderShift = 4;
+__global__ __launch_bounds__(kOrderThreads) void a1mpc_order_kernel(int n, const int32_t* __restrict__ cost, int32_t* __restrict__ order) {
+    __shared__ int hist[kOrderBins];
     const int tid = static_cast<int>(threadIdx.x);
-    if (tid < 256) hist[tid] = 0;
+    if (tid < kOrderBins) hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const int c = cost[i] >> 3;
-        atomicAdd(&hist[c < 0 ? 0 : (c > 255 ? 255 : c)], 1);
+    for (int i = tid; i < n; i += kOrderThreads) {
+        const int c = cost[i] >> kOrderShift;
+        atomicAdd(&hist[c < 0 ? 0 : (c > kOrderBins - 1 ? kOrderBins - 1 : c)], 1);
     }
     __syncthreads();
     if (tid == 0) {
         int run = 0;
-        for (int b = 255; b >= 0; --b) { const int c = hist[b]; hist[b] = run; run += c; }
+        for (int b = kOrderBins - 1; b >= 0; --b) { const int c = hist[b]; hist[b] = run; run += c; }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const int c = cost[i] >> 3;
-        order[atomicAdd(&hist[c < 0 ? 0 : (c > 255 ? 255 : c)], 1)] = i;
+    for (int i = tid; i < n; i += kOrderThreads) {
+        const int c = cost[i] >> kOrderShift;
+        order[atomicAdd(&hist[c < 0 ? 0 : (c > kOrderBins - 1 ? kOrderBins - 1 : c)], 1)] = i;
     }
 }
-void launch_order_kernel(int n, const int32_t* cost, int32_t* order, hipStream_t stream) { hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, stream, n, cost, order); }
+void launch_order_kernel(int n, const int32_t* cost, int32_t* order, hipStream_t stream) { hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, n, cost, order); }
 void launch_predict_kernel(const KernelArgs& a, int H, hipStream_t stream) { hipLaunchKernelGGL(a1mpc_predict_kernel, dim3(static_cast<unsigned>((a.n + 255) / 256)), dim3(256), 0, stream, a, H); }
 
 
@@ -2082,7 +2087,7 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
     // cost, longest first (the cost buffer holds it: hint_n == n; the fused kernel records this tick's).  Scheduling only: every result is bit-identical in any order.
     if (warm_fused && h->schedule && n >= kScheduleMinBatch && n > coop_max_batch() && warm_order_enabled()) {
         RoctxRange range("a1mpc order");
-        hipLaunchKernelGGL(a1mpc_order_kernel, dim3(1), dim3(1024), 0, s, static_cast<int>(n), static_cast<const int32_t*>(h->d_cost), h->d_order);
+        launch_order_kernel(static_cast<int>(n), static_cast<const int32_t*>(h->d_cost), h->d_order, s);
         A1_HIP(hipGetLastError());
         a.order = h->d_order; a.cost = h->d_cost;
     }
