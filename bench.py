@@ -209,6 +209,27 @@ def batch_sweep(pkg, local, sizes=(1, 16, 256, 1024, 4096, 16384, 65536)):
     return out   # (cold first solves through one handle on one stream: north_star's "batch 1 ... 65536")
 
 
+def horizon_sweep(pkg, local, n=4096, horizons=(4, 6, 8, 10, 12, 14, 16, 20)):
+    """Extra information (not `value`): cold first solves of the same workload generator at every MPC horizon compiled in (PLAN_HORIZON is a run-time value of the
+    C ABI; 4 / 6 / 8 / 12 / 14 are the extended horizons: the kernel family as it instantiates for them), one handle, one stream."""
+    import torch
+    out = {}
+    dev = torch.device("cuda", local); st = torch.cuda.Stream(device=dev)
+    for h in horizons:
+        sc = pkg.scenarios.config3_random_flat(nb=n, horizon=h)
+        d = {k: torch.from_numpy(sc[k]).to(dev) for k in ("x0", "xref", "R", "foot", "contact")}
+        grf = torch.zeros((n, 12), dtype=torch.float64, device=dev); it = torch.zeros(n, dtype=torch.int32, device=dev); stt = torch.zeros(n, dtype=torch.int32, device=dev)
+        with pkg.Engine(pkg.make_config(sc["params"], h, warm_start=0), n, local) as eng:
+            ms = []
+            for _ in range(4):
+                eng.set_schedule(True)
+                eng.solve_device(n, d["x0"], d["xref"], d["R"], d["foot"], d["contact"], grf, None, it, stt, stream=st.cuda_stream)
+                ms.append(eng.last_kernel_ms())
+        out[f"h{h}"] = {"kernel_ms": float(np.median(ms[1:])), "solves_per_s": n / (float(np.median(ms[1:])) * 1e-3), "mean_iters": float(it.float().mean().item()),
+                        "solved": int((stt == 1).sum().item())}
+    return out
+
+
 def general_path_probe(pkg, local, shapes=((10, 4096), (16, 8192), (20, 8192))):
     """Extra information (not `value`): the general path of the reference's interface -- per-step feet (S/ConvexMpc.h:74 B_mat_d_list) and per-step
     contact schedules through a1mpc_solve_batch_strided -- on the states of the fast path's workload: first solves (queue by the set-up kernel's guess)
@@ -964,6 +985,7 @@ def main():
             out["latency_update_path_h16"] = latency_probe(pkg, mode=2, horizon=16, cpp_ticks=4000)
             out["latency_update_path_h20"] = latency_probe(pkg, mode=2, horizon=20, cpp_ticks=4000)
             out["throughput_by_batch"] = batch_sweep(pkg, local)
+            out["throughput_by_horizon_4096"] = horizon_sweep(pkg, local)
             out["warm_start_ticks"] = warm_tick_probe(pkg, local)
             out["warm_start_ticks_update_path"] = warm_tick_probe(pkg, local, mode=2)
             out["stage_counters_warm"] = {f"{n_}_robots_mode{m_}": warm_tick_stage_counters(pkg, local, n=n_, mode=m_) for n_ in (4096, 1) for m_ in (1, 2)}
