@@ -43,11 +43,11 @@ __global__ __launch_bounds__(256) void a1mpc_predict_kernel(const KernelArgs a, 
 
 // K3: the next solve's queue order = this solve's QPs by decreasing cost (counting sort, one workgroup).  A batch of 1-4x the resident
 // rows is otherwise finished by whichever long QP happened to start last; longest-first makes the makespan max(longest, total / rows).
-// 256 threads, 24 registers, 512 B of LDS (round 6): ONE wavefront per SIMD, which fits BESIDE a resident persistent wavefront (424 of 512 registers, 1 KB of a CU's LDS
-// left at H = 10).  As a 1024-thread workgroup (four wavefronts per SIMD) it had to wait for a CU with no persistent wavefront at all: 6 us behind its own batch's set-up
-// with two batches in flight, but 0.4-0.5 ms per launch as soon as a third slot lets a batch's set-up run ahead of its turn (kernel trace, profiles/r06_setup_ahead.md).
-// The costs (0 .. 2047) are bucketed by 16 instead of 8 (128 buckets): scheduling only
-constexpr int kOrderThreads = 256, kOrderBins = 128, kOrderShift = 4;
+// Round 6: 8 registers per wavefront and 516 B of LDS, so that the workgroup's four wavefronts per SIMD fit BESIDE a resident persistent wavefront (424 of 512 registers,
+// 1 KB of a CU's LDS left at H = 10).  At 24 registers (a serial loop over the buckets on one thread) it had to wait for a CU with no persistent wavefront at all: 6 us
+// behind its own batch's set-up with two batches in flight, but 0.4-0.5 ms per launch as soon as a third slot lets a batch's set-up run ahead of its turn (kernel
+// trace, profiles/r06_setup_ahead.md); the build's resource gate keeps it at <= 16 (isa_check.MAX_VGPR_BESIDE_PERSISTENT).  The costs (0 .. 2047) are bucketed by 16: scheduling only
+constexpr int kOrderThreads = 1024, kOrderBins = 128, kOrderShift = 4;
 __global__ __launch_bounds__(kOrderThreads) void a1mpc_order_kernel(int n, const int32_t* __restrict__ cost, int32_t* __restrict__ order) {
     __shared__ int hist[kOrderBins];
     const int tid = static_cast<int>(threadIdx.x);
@@ -58,10 +58,21 @@ __global__ __launch_bounds__(kOrderThreads) void a1mpc_order_kernel(int n, const
         atomicAdd(&hist[c < 0 ? 0 : (c > kOrderBins - 1 ? kOrderBins - 1 : c)], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int b = kOrderBins - 1; b >= 0; --b) { const int c = hist[b]; hist[b] = run; run += c; }
+    // first queue position of every bucket, most expensive bucket first: an exclusive scan over the buckets in descending order -- thread t < 128 takes bucket 127 - t,
+    // wave-level shuffles inside each of the two wavefronts, one word of LDS across them (a serial loop over the buckets on one thread was half of the kernel's 10 us)
+    static_assert(kOrderBins == 128 && kOrderThreads >= 128, "two wavefronts scan the buckets");
+    __shared__ int carry;
+    int mine = 0, incl = 0;
+    if (tid < kOrderBins) {
+        mine = hist[kOrderBins - 1 - tid]; incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if ((tid & 63) >= off) incl += up;
+        }
+        if (tid == 63) carry = incl;   // buckets 127 .. 64 in total
     }
+    __syncthreads();
+    if (tid < kOrderBins) hist[kOrderBins - 1 - tid] = incl - mine + (tid >= 64 ? carry : 0);
     __syncthreads();
     for (int i = tid; i < n; i += kOrderThreads) {
         const int c = cost[i] >> kOrderShift;

@@ -233,6 +233,12 @@ NO_SCRATCH = ("a1mpc_admm_kernelILi10ELi2E", "a1mpc_admm_kernelILi20ELi1ELb0ELb1
 BOUNDED_SCRATCH = (("a1mpc_setup_gen_kernelILi16E", 64, 0), ("a1mpc_setup_gen_kernelILi20E", 128, 8))   # (two wavefronts per SIMD: 256 registers; a dozen long-lived values wait in scratch while the Ruiz passes run)
 
 
+# ... and kernels that have to fit BESIDE a resident persistent wavefront (424 of a SIMD's 512 registers are taken, 88 are left): (pattern, registers per wavefront, wavefronts
+# per SIMD of one workgroup).  The queue-order kernel is one 1024-thread workgroup = four wavefronts per SIMD: at 24 registers it had to wait for a CU without any persistent
+# wavefront (0.4-0.5 ms behind a batch in flight, profiles/r06_setup_ahead.md); at 8 it starts at once
+MAX_VGPR_BESIDE_PERSISTENT = (("a1mpc_order_kernel", 16, 4),)
+
+
 def resource_gaps(resources, no_scratch=None):
     """list of messages: a kernel of NO_SCRATCH with scratch memory, or no kernel at all for one of its patterns (no fail-open)"""
     no_scratch = NO_SCRATCH if no_scratch is None else no_scratch
@@ -245,6 +251,13 @@ def resource_gaps(resources, no_scratch=None):
             if (v.get("scratch_bytes") or 0) > 0:
                 out.append(f"{k[:90]}: {v.get('vgpr_spill')} spilled VGPRs, {v.get('scratch_bytes')} B of scratch per lane ({v.get('scratch_instrs_in_loops')} scratch instructions inside loops)")
     if no_scratch is NO_SCRATCH:
+        for key, max_vgpr, waves in MAX_VGPR_BESIDE_PERSISTENT:
+            hits = {k: v for k, v in resources.items() if key in k}
+            if not hits:
+                out.append(f"resource gate saw no kernel matching {key} (listing format changed?)")
+            for k, v in hits.items():
+                if (v.get("vgpr") or 0) > max_vgpr:
+                    out.append(f"{k[:90]}: {v.get('vgpr')} registers per wavefront x {waves} wavefronts per SIMD no longer fit beside a persistent wavefront (allowed {max_vgpr})")
         for key, max_bytes, max_in_loops in BOUNDED_SCRATCH:
             hits = {k: v for k, v in resources.items() if key in k}
             if not hits:

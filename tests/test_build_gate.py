@@ -18,6 +18,8 @@ def _clean(isa):
         r["_ZN5a1mpc" + key + "EEvNS_9BatchArgsE"] = dict(vgpr=400, agpr=144, vgpr_spill=4, scratch_bytes=0, scratch_instrs=0, scratch_instrs_in_loops=0)
     for key, b, l in isa.BOUNDED_SCRATCH:
         r["_ZN5a1mpc" + key + "EEvNS_9BatchArgsEPd"] = dict(vgpr=256, agpr=0, vgpr_spill=26, scratch_bytes=b, scratch_instrs=30, scratch_instrs_in_loops=l)
+    for key, v, w in isa.MAX_VGPR_BESIDE_PERSISTENT:
+        r["_ZN5a1mpc18" + key + "EiPKiPi"] = dict(vgpr=v, agpr=0, vgpr_spill=0, scratch_bytes=0, scratch_instrs=0, scratch_instrs_in_loops=0)
     return r
 
 
@@ -41,6 +43,12 @@ def test_gate_does_not_fail_open():
     k = next(k for k in r if "a1mpc_setup_gen_kernelILi20E" in k)
     r[k] = dict(r[k], scratch_instrs_in_loops=19)
     assert any("inside loops (allowed 8)" in m for m in isa.resource_gaps(r))
+    r = _clean(isa)
+    k = next(k for k in r if "a1mpc_order_kernel" in k)
+    r[k] = dict(r[k], vgpr=24)   # (the queue-order kernel as it was until round 6: four wavefronts per SIMD x 24 registers wait for a CU without a persistent wavefront)
+    assert any("no longer fit beside a persistent wavefront" in m for m in isa.resource_gaps(r))
+    del r[k]
+    assert any("saw no kernel matching a1mpc_order_kernel" in m for m in isa.resource_gaps(r))
 
 
 def test_the_library_built_here_passes_the_gate():
