@@ -350,8 +350,8 @@ def test_device_pointer_tick_matches_host_pointer_tick(pkg, scen):
                     ctr["contacts"]) and np.array_equal(it_d.cpu().numpy(), sol["iters"])
 
 
-@pytest.mark.parametrize("n,warm", [(300, 1), (64, 2), (4096, 1)])
-def test_control_tick_one_call_matches_the_seven_entry_chain(pkg, scen, n, warm):
+@pytest.mark.parametrize("n,warm,h", [(300, 1, 10), (64, 2, 10), (4096, 1, 10), (300, 2, 12), (64, 1, 6)])   # (h = 12, 6: two of the extended horizons)
+def test_control_tick_one_call_matches_the_seven_entry_chain(pkg, scen, n, warm, h):
     """a1mpc_control_tick_device -- leg state, EKF, gait plan, swing legs, contacts / terrain, MPC from tick records and the joint torques in ONE C call,
     N3 inside the MPC kernel's output stage -- against the seven *_device entry points chained by hand on a second handle: every output and every carried state bit for
     bit, four ticks.  n = 300: the fused kernel from the first tick; 64: the latency kernel, update path; 4096: the split pipeline on the first tick (torques by their
@@ -359,7 +359,7 @@ def test_control_tick_one_call_matches_the_seven_entry_chain(pkg, scen, n, warm)
     import torch
     rng = np.random.default_rng(2025 + n)
     P = scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS
-    cfg = pkg.make_config(P, 10, warm_start=warm)
+    cfg = pkg.make_config(P, h, warm_start=warm)
     dev = torch.device("cuda", 0)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     ptr = lambda t: C.c_void_p(t.data_ptr())

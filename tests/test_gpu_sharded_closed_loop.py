@@ -8,9 +8,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _ticks(scen, n, nticks, seed=77):
+def _ticks(scen, n, nticks, seed=77, horizon=10):
     """`nticks` consecutive ticks of the same n robots: slowly moving states, tick records and (x0, x_ref) of the same ticks"""
-    base = scen.config3_random_flat(nb=n, seed=seed)
+    base = scen.config3_random_flat(nb=n, seed=seed, horizon=horizon)
     rng = np.random.default_rng(seed)
     out = []
     x0 = base["x0"].copy(); tick = base["tick"].copy()
@@ -48,11 +48,11 @@ def _ranges(n, G):
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("n,devs", [(601, [0, 0]), (3001, [0, 0, 0])])
-def test_sharded_closed_loop_equals_lone_handles(pkg, scen, mode, n, devs):
+@pytest.mark.parametrize("n,devs,h", [(601, [0, 0], 10), (3001, [0, 0, 0], 10), (601, [0, 0], 8)])   # (h = 8: one of the extended horizons)
+def test_sharded_closed_loop_equals_lone_handles(pkg, scen, mode, n, devs, h):
     import torch
-    seq = _ticks(scen, n, 4)
-    cfg = pkg.make_config(seq[0]["params"], 10, warm_start=mode)
+    seq = _ticks(scen, n, 4, horizon=h)
+    cfg = pkg.make_config(seq[0]["params"], h, warm_start=mode)
     splits = _ranges(n, len(devs))
     ref_x = _lone_reference(pkg, cfg, seq, n, splits, use_ticks=False)
     ref_t = _lone_reference(pkg, cfg, seq, n, splits, use_ticks=True)
@@ -68,7 +68,7 @@ def test_sharded_closed_loop_equals_lone_handles(pkg, scen, mode, n, devs):
                 assert np.array_equal(o[k], ref_x[t][k]), ("host x0/xref", t, k)
         tr = sh.last_transfer()
         moved = n   # transport 0 with host arrays: every shard is fed from the pinned mirror
-        assert tr["scatter_bytes"] == moved * ((13 + 130 + 9 + 12) * 8 + 4) and tr["gather_bytes"] == moved * (96 + 8)
+        assert tr["scatter_bytes"] == moved * ((13 + 13 * h + 9 + 12) * 8 + 4) and tr["gather_bytes"] == moved * (96 + 8)
         # host arrays, tick records (a fresh closed loop: the shards' warm starts are dropped first)
         sh.reset_warm_start()
         for t, sc in enumerate(seq):
@@ -91,7 +91,7 @@ def test_sharded_closed_loop_equals_lone_handles(pkg, scen, mode, n, devs):
                 assert np.array_equal(grf.cpu().numpy(), ref[t]["grf"]) and np.array_equal(it.cpu().numpy(), ref[t]["iters"]) and np.array_equal(st.cpu().numpy(), ref[t]["status"]), (form, t)
             tr = sh.last_transfer()
             moved = n - splits[0][1]   # the root's own shard is solved in place
-            per_qp = ((13 + 130) if form == "x" else 22) * 8 + (9 + 12) * 8 + 4
+            per_qp = ((13 + 13 * h) if form == "x" else 22) * 8 + (9 + 12) * 8 + 4
             assert tr["scatter_bytes"] == moved * per_qp and tr["gather_bytes"] == moved * (96 + 8), (form, tr)
 
 
