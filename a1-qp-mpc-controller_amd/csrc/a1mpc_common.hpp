@@ -141,6 +141,12 @@ inline bool cu_quad_enabled() {
 // Did the launch just issued run a profiling (CLK) instantiation?  Set by the launch functions, read by solve_device_impl right after them (same thread): only then does
 // the handle's stage record describe the solve (a fallback kernel without stamps must not leave a stale or uninitialised record behind as "profiled").
 extern thread_local bool g_clk_ran;   // (a1mpc_hip.hip)
+// The general path at H = 10 has two persistent kernels: the CU-wide one (seven QPs per CU, 158.9 of 160 KB of LDS) and the one-wave workgroups (six per CU, 24 KB left).
+// A lone handle wants the seventh QP (4096 x h10 first solves 2.87 against 2.76 M/s).  A slot of a TWO-slot pipeline wants the 24 KB: the other slot's set-up workgroups
+// (11.8 KB each) then run BESIDE its persistent rows instead of waiting for them to retire -- 3.57-3.62 against 3.37-3.41 M/s with two batches in flight, reproducibly
+// (profiles/r06_general_pipeline.md); with three slots the CU-wide kernel is ahead again by 1.4 %.  Set by solve_device_impl from the handle's pipeline depth for the duration
+// of a launch, read by launch_gen_split_rows (same thread).  Scheduling only: the two kernels agree bit for bit (tested).  A1MPC_GEN_PIPE_ONE_WAVE=0 ignores the hint (A/B runs)
+extern thread_local bool g_gen_prefer_one_wave;   // (a1mpc_hip.hip)
 // horizons whose fused / latency kernels have a profiling instantiation (the closed-loop tick and the batch-1 tick of the headline horizon; every further horizon costs a minute of compile time)
 constexpr bool tick_clk_horizon(int h) { return h == 10; }
 

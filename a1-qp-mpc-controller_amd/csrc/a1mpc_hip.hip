@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void a1mpc_plan_kernel(const PlanArgs a) {
 thread_local std::string g_last_error;
 std::mutex g_cache_mu;
 thread_local bool g_clk_ran = false;
+thread_local bool g_gen_prefer_one_wave = false;
 // dynamic-LDS limit of a kernel, once per device and kernel
 a1mpc_status set_lds_attr(const void* fn, size_t bytes) {
     static std::vector<std::pair<const void*, int>> done;
@@ -506,6 +507,7 @@ struct a1mpc_handle_s {
     double tick_km[3] = {0, 0, 0};
     bool staged = false;
     bool busy = false;
+    int pipeline_depth = 0;      // > 0: this handle is a slot of an a1mpc_pipeline with that many slots (g_gen_prefer_one_wave)
     // carried OSQP workspace (warm start)
     double *d_wx = nullptr, *d_wy = nullptr, *d_rho = nullptr;
     // split pipeline: prepared state of every QP (set-up kernel -> ADMM kernel) and the work-queue counter
@@ -2068,7 +2070,11 @@ static a1mpc_status solve_device_impl(a1mpc_handle h, int32_t n, const double* d
         h->staged = split_gen && h->timing;
         if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
         if (split_gen) {
-            if (a1mpc_status stg = launch_gen_split(h->cfg.horizon, a, h->d_prep_gen, h->d_counter, s, h->timing ? h->ev_mid : nullptr); stg != A1MPC_OK) return stg;
+            static const bool pipe_hint = [] { const char* e = getenv("A1MPC_GEN_PIPE_ONE_WAVE"); return !(e && !strcmp(e, "0")); }();
+            g_gen_prefer_one_wave = pipe_hint && h->pipeline_depth == 2;
+            const a1mpc_status stg = launch_gen_split(h->cfg.horizon, a, h->d_prep_gen, h->d_counter, s, h->timing ? h->ev_mid : nullptr);
+            g_gen_prefer_one_wave = false;
+            if (stg != A1MPC_OK) return stg;
             if (hints_gen) h->hint_n = -n;   // the cost buffer now holds this batch's costs: the next general-path solve of this size is ordered by them
         } else {
             if (a1mpc_status stg = launch_gen(h->cfg.horizon, a, s); stg != A1MPC_OK) return stg;
@@ -3007,6 +3013,7 @@ a1mpc_status a1mpc_pipeline_create(const a1mpc_config* cfg, int32_t max_batch, i
         a1mpc_handle hk = nullptr;
         const a1mpc_status st = a1mpc_create(cfg, max_batch, device, &hk);
         if (st != A1MPC_OK) { a1mpc_pipeline_destroy(p); return st; }
+        hk->pipeline_depth = p->depth;
         p->h.push_back(hk);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {

@@ -530,7 +530,7 @@ a1mpc_status launch_gen_split_rows(const KernelArgs& a, double* prep, int* count
     }
     if (mid) A1_HIP(hipEventRecord(mid, stream));
     if constexpr (cu_wide_gen_qps(H) > 0) {
-        if (gen_cu_wide_enabled()) {   // seven QPs per CU: one 256-thread workgroup per CU (a1mpc_admm_gen_cu_kernel)
+        if (gen_cu_wide_enabled() && !g_gen_prefer_one_wave) {   // seven QPs per CU: one 256-thread workgroup per CU (a1mpc_admm_gen_cu_kernel); a slot of a two-slot pipeline keeps the one-wave workgroups
             constexpr int Q = cu_wide_gen_qps(H);
             const size_t ldsq = sizeof(double) * Q * Layout<H, true>::ROW_STRIDE;
             static int resq_dev[64] = {};

@@ -169,7 +169,7 @@ a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d
  * horizon with step-invariant feet, the case a controller with a contact plan has -- also runs the fast kernels at their speed: contacts only
  * change the bounds and which rows are equalities (any horizon a1mpc_create accepts).  Per-step feet and / or a yaw_A run the general kernels:
  * same OSQP iterates as the reference's formation with those inputs, with a bigger LDS image per QP (B~_t of every step), i.e.
- * fewer QPs in flight -- 1.7-2.5x slower by design (round 6; with two batches in flight 3.4 M / 1.5 M / 1.07 M first solves/s at 4096 x h10 / 8192 x h16 / 8192 x h20).
+ * fewer QPs in flight -- 1.7-2.5x slower by design (round 6; with two batches in flight 3.6 M / 1.5 M / 1.07 M first solves/s at 4096 x h10 / 8192 x h16 / 8192 x h20).
  * Horizons 10, 16, 20.
  */
 a1mpc_status a1mpc_solve_batch_strided(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
