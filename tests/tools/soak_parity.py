@@ -6,7 +6,9 @@ worst = 0; bad = 0; tot = 0; over = 0
 lo = int(sys.argv[1]) if len(sys.argv) > 1 else 3000; cnt = int(sys.argv[2]) if len(sys.argv) > 2 else 12  # usage: soak_parity.py [first_seed [count [horizon [qps_per_batch]]]]
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 4096   # QPs per batch (4096: the split pipeline; <= 256: the latency kernel; up to the resident rows: the fused kernel)
-gen = {10: pkg.scenarios.config3_random_flat, 16: pkg.scenarios.config4_random_h16, 20: pkg.scenarios.config5_divergent}[H]
+gen = {10: pkg.scenarios.config3_random_flat, 16: pkg.scenarios.config4_random_h16, 20: pkg.scenarios.config5_divergent}.get(H)
+if gen is None:   # the extended horizons (4, 6, 8, 12, 14): BASELINE configs[2]'s generator and, on odd seeds, configs[4]'s (all contact patterns, 0.5 rad pitch) at that horizon
+    gen = lambda nb, seed: (pkg.scenarios.config5_divergent if seed % 2 else pkg.scenarios.config3_random_flat)(nb=nb, seed=seed, horizon=H)
 for seed in range(lo, lo + cnt):
     n = N
     sc = gen(nb=n, seed=seed, param_set=("gazebo", "hardware", "isaac")[seed % 3]) if H == 10 else gen(nb=n, seed=seed); p = sc["params"]
