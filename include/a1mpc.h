@@ -559,6 +559,11 @@ void a1mpc_sharded_destroy(a1mpc_sharded s);
  * solves of distinct batches (profiles/r03_bench_default_run.json, r03_bench_depth1_run.json): 4096 x h10 4.2-5.0 M -> 6.35-6.44 M solves/s,
  * 8192 x h16 2.23 -> 2.47 M; depth 3 no longer pays (profiles/r03_pcie_probe_4096_h10.json); 16 384 x h10 neutral; a batch of 65 536 QPs
  * fills the chip on its own and loses 7 % when pipelined -- submit those through a plain handle.
+ * Round 6 (kernel traces of the slots, profiles/r06_setup_ahead.md): what is left between two slots and one 65 536-QP launch (0.60-0.61 against 0.57-0.58 ms per 4096 x h10
+ * batch) is the chain set-up kernel -> queue-order kernel -> persistent kernel of every batch, each of which finds the chip full; a third slot is worth 3-4 % when the
+ * caller submits in a free-running loop and loses 11-19 % when it starts its slots behind one event, so the default stays two.  A slot of a two-slot pipeline runs the
+ * general path's one-wave persistent kernel at horizon 10 (six QPs per CU) instead of the CU-wide one (seven): the other slot's set-up then runs beside it (+6 % at
+ * 4096 QPs, +12 % at 2560; same bits).
  *   submit   device pointers, layouts of a1mpc_solve_batch_device.  slot = -1: next slot round-robin (returned in *slot_out), or a fixed
  *            slot (a robot population that is warm-started must stay on its slot: the carried OSQP workspace lives there).
  *            fresh_batch != 0: these QPs are new to the slot, order its queue by the set-up kernel's cost guess instead of the slot's
