@@ -29,7 +29,7 @@ RESOURCES_PATH = os.path.join(_HERE, "build", "kernel_resources.json")
 HEADERS = ["a1mpc_common.hpp", "a1mpc_kernels.hpp", "a1mpc_solver.hpp", "a1mpc_tables.hpp", os.path.join("gfx950", "a1mpc_rowops.hpp")]
 EXTENDED_HORIZONS = (14, 12, 8, 6, 4)   # the fast path's kernel family at the other even horizons (csrc/a1mpc_common.hpp, A1MPC_FAST_HORIZONS): 16-47 s per unit
 KERNEL_UNITS = ([f"a1mpc_k_h{h}_{p}.hip" for h in (20, 16, 10) for p in ("split", "fused")] + [f"a1mpc_k_gen{h}_{p}.hip" for h in (20, 16, 10) for p in ("split", "fused")]
-                + [f"a1mpc_k_h{h}_{p}.hip" for h in EXTENDED_HORIZONS for p in ("split", "fused")] + ["a1mpc_k_h1.hip"])
+                + [f"a1mpc_k_h{h}_{p}.hip" for h in EXTENDED_HORIZONS for p in ("split", "fused")] + [f"a1mpc_k_gen{h}.hip" for h in EXTENDED_HORIZONS] + ["a1mpc_k_h1.hip"])
 MAIN_UNIT = "a1mpc_hip.hip"
 ID_UNIT = "a1mpc_build_id.cpp"
 UNITS = KERNEL_UNITS + [MAIN_UNIT]       # (slowest first: the pool starts them in this order)

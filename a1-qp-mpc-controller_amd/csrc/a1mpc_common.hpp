@@ -41,14 +41,16 @@ constexpr size_t lds_bytes(int rows) { return sizeof(double) * rows * Layout<H>:
 constexpr int default_rows_per_wg(int horizon) { return horizon >= 16 ? 1 : 2; }
 // Horizons compiled in (the reference fixes PLAN_HORIZON = 10 at compile time, S/A1Params.h:26; a run-time value here).  1 / 10 / 16 / 20 are the tuned ones (the
 // balance-QP analogue, the reference's horizon, BASELINE configs[3] / [4]): fast path AND general path, every kernel variant.  The other even horizons up to 14 run the
-// fast path's kernel family as it instantiates for them -- a main / twin pair of rows per QP, two QPs per wavefront, split and fused pipelines, latency kernel, all three
-// warm-start modes, contact schedules, tick records; no scratch in any of their kernels (the resource gate covers them) -- so that a controller built with another
-// PLAN_HORIZON still finds its QP.  Odd horizons do not exist (a twin pair splits the steps by parity), 18 would spill (one QP per wavefront without the quads of
+// kernel families of BOTH paths as they instantiate for them -- a main / twin pair of rows per QP, two QPs per wavefront, split and fused pipelines, latency kernel, all three
+// warm-start modes, contact schedules, tick records, per-step feet; no scratch in any of their solve kernels (the resource gate covers them) -- so that a controller built
+// with another PLAN_HORIZON still finds its QP.  Odd horizons do not exist (a twin pair splits the steps by parity), 18 would spill (one QP per wavefront without the quads of
 // rows that make 16 and 20 fit: 194-257 spilled registers, measured) and 2 is left out because its fused kernel and its split pipeline part by one unit in the last
 // place (2.6e-13 N: a contraction the backend places differently in the two instantiations, DESIGN 8 item 5 -- every offered horizon is bit-identical across
-// its pipelines, tools/cross_pipeline_bits.py); per-step feet (the general path) exist at 10 / 16 / 20 only.
+// its pipelines, tools/cross_pipeline_bits.py).
 #define A1MPC_FAST_HORIZONS(X) X(1) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(20)
 #define A1MPC_MULTI_STEP_HORIZONS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(20)   // ... with an update path (warm_start = 2): every one of them but 1
+// (H, QPs per wavefront of the general path's kernels): every multi-step horizon
+#define A1MPC_GEN_HORIZONS(X) X(4, 2) X(6, 2) X(8, 2) X(10, 2) X(12, 2) X(14, 2) X(16, 1) X(20, 1)
 #define A1MPC_HORIZON_LIST "1, 4, 6, 8, 10, 12, 14, 16 or 20"
 // The shipped build instantiates the kernels for the default rows per workgroup only (the other two layouts were measured and lost, above; every extra layout of
 // the H = 16 / 20 kernels costs a minute of compile time): the override is honoured by -DA1MPC_ALL_ROWS tuning builds.

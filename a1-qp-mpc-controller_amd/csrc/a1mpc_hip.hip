@@ -299,9 +299,9 @@ static size_t prep_stride(int horizon) {
 }
 static size_t prep_stride_gen(int horizon) {
     switch (horizon) {
-        case 10: return Prep<10>::STRIDE_GEN;
-        case 16: return Prep<16>::STRIDE_GEN;
-        case 20: return Prep<20>::STRIDE_GEN;
+#define A1_CASE(H, R) case H: return Prep<H>::STRIDE_GEN;
+        A1MPC_GEN_HORIZONS(A1_CASE)
+#undef A1_CASE
     }
     return 0;
 }
@@ -311,31 +311,31 @@ static a1mpc_status resident_rows_gen(int horizon, int* rows) {
     a1mpc_status st = A1MPC_OK;
     *rows = 0;
     switch (horizon) {
-        case 10: st = resident_workgroups_gen<10, 2>(&wg); *rows = 2 * wg; break;
-        case 16: st = resident_workgroups_gen<16, 1>(&wg); *rows = wg; break;
-        case 20: st = resident_workgroups_gen<20, 1>(&wg); *rows = wg; break;
+#define A1_CASE(H, R) case H: st = resident_workgroups_gen<H, R>(&wg); *rows = R * wg; break;
+        A1MPC_GEN_HORIZONS(A1_CASE)
+#undef A1_CASE
     }
     return st;
 }
 static a1mpc_status launch_gen_split(int horizon, const KernelArgs& a, double* prep, int* counter, hipStream_t s, hipEvent_t mid) {
     int wg = 0;
     switch (horizon) {
-        case 10: if (a1mpc_status st = resident_workgroups_gen<10, 2>(&wg); st != A1MPC_OK) return st; return launch_gen_split_rows<10, 2>(a, prep, counter, s, mid, wg);
-        case 16: if (a1mpc_status st = resident_workgroups_gen<16, 1>(&wg); st != A1MPC_OK) return st; return launch_gen_split_rows<16, 1>(a, prep, counter, s, mid, wg);
-        case 20: if (a1mpc_status st = resident_workgroups_gen<20, 1>(&wg); st != A1MPC_OK) return st; return launch_gen_split_rows<20, 1>(a, prep, counter, s, mid, wg);
+#define A1_CASE(H, R) case H: if (a1mpc_status st = resident_workgroups_gen<H, R>(&wg); st != A1MPC_OK) return st; return launch_gen_split_rows<H, R>(a, prep, counter, s, mid, wg);
+        A1MPC_GEN_HORIZONS(A1_CASE)
+#undef A1_CASE
     }
-    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet (foot_stride = 12) and a separate A_c yaw need horizon 10, 16 or 20");
+    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet (foot_stride = 12) and a separate A_c yaw need a horizon > 1");
 }
 // LDS per QP (round 6: the per-step bounds left the image): 22.7 KB (H = 10: six QPs per CU in one-wave workgroups, seven in the CU-wide persistent kernel), 35.9 KB (H = 16: four,
 // one per wavefront like the fast path's), 44.7 KB (H = 20: three, one row per workgroup) -- which also leaves 13 / 26 KB of a CU's LDS free at H = 16 / 20: the set-up kernel of a
 // second batch in flight (11.7 / 15.7 KB per workgroup) now runs BESIDE the persistent kernel instead of behind it (profiles/r06_general_pipeline.md)
 static a1mpc_status launch_gen(int horizon, const KernelArgs& a, hipStream_t s) {
     switch (horizon) {
-        case 10: return launch_gen_rows<10, 2>(a, s);
-        case 16: return launch_gen_rows<16, 1>(a, s);
-        case 20: return launch_gen_rows<20, 1>(a, s);
+#define A1_CASE(H, R) case H: return launch_gen_rows<H, R>(a, s);
+        A1MPC_GEN_HORIZONS(A1_CASE)
+#undef A1_CASE
     }
-    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet (foot_stride = 12) and a separate A_c yaw need horizon 10, 16 or 20");
+    return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "per-step feet (foot_stride = 12) and a separate A_c yaw need a horizon > 1");
 }
 
 static bool warm_fused_enabled() {

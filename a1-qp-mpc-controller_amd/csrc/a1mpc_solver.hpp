@@ -2310,7 +2310,7 @@ A1_DEV ProblemIO make_io_gen(const BatchArgs& a, int64_t b) {
 // split pipeline, kernel 1: formation + Ruiz for QP b, prepared state to global memory
 // rows of a wavefront that share one QP in the general path's set-up kernel: 2 (two QPs per wavefront) at H = 10, 4 (one QP per wavefront) at H = 16 / 20 -- the per-lane state of
 // the Ruiz passes then fits 256 registers and two wavefronts share a SIMD (a lone wavefront issues an FP64 instruction every 2.13 ns, two every 1.84: tools/ubench/f64_rate_ubench.hip)
-constexpr int setup_gen_rows(int h) { return h >= 16 ? 4 : 2; }
+constexpr int setup_gen_rows(int h) { return h >= 12 ? 4 : 2; }   // (12, 14: the extended horizons -- with two rows their set-up kernels spill, 84 / 196 B)
 template <int H, bool GEN = false, bool UPD = false>
 A1_DEV void setup_row(const BatchArgs& a, const double* __restrict__ tab, int64_t b, double* __restrict__ lds, double* __restrict__ prep) {
     RowSolver<H, kModeMpc, true, GEN> S(a.P, tab, lds);  // tab: the (alpha/beta, beta) table, staged in LDS by the kernel

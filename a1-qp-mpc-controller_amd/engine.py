@@ -14,7 +14,7 @@ from . import build as _build
 
 NS, NU, NC = 13, 12, 20
 STATUS_NAMES = {1: "solved", 2: "solved_inaccurate", -2: "max_iter_reached", -7: "non_cvx", -10: "unsolved"}
-SUPPORTED_HORIZONS = (1, 4, 6, 8, 10, 12, 14, 16, 20)   # (per-step feet -- the general path -- at 10 / 16 / 20 only)
+SUPPORTED_HORIZONS = (1, 4, 6, 8, 10, 12, 14, 16, 20)   # (1, 10, 16, 20: tuned; the others: the kernel families as they instantiate)
 
 
 class Config(C.Structure):  # a1mpc_config, include/a1mpc.h

@@ -228,9 +228,9 @@ NO_SCRATCH = ("a1mpc_admm_kernelILi10ELi2E", "a1mpc_admm_kernelILi20ELi1ELb0ELb1
               # round 6: the general path (per-step feet / contact schedules) -- until then 87-754 spilled VGPRs per kernel, 145-503 scratch instructions inside loops
               "a1mpc_solve_gen_kernelILi", "a1mpc_solve_gen_coop_kernelILi", "a1mpc_admm_gen_kernelILi", "a1mpc_admm_gen_cu_kernelILi", "a1mpc_setup_gen_kernelILi10E"
               # ... and every kernel of the extended horizons (4, 6, 8, 12, 14: the fast path's family as it instantiates there -- a horizon whose kernels would spill is not offered)
-              ) + tuple(f"a1mpc_{k}_kernelILi{h}E" for h in (4, 6, 8, 12, 14) for k in ("admm", "setup", "solve"))
+              ) + tuple(f"a1mpc_{k}_kernelILi{h}E" for h in (4, 6, 8, 12, 14) for k in ("admm", "setup", "solve")) + tuple(f"a1mpc_setup_gen_kernelILi{h}E" for h in (4, 6, 8, 12))
 # ... and kernels that may park a few long-lived values (pointers, the rotation) in scratch ACROSS their loops but not inside them: (pattern, scratch bytes, scratch instructions in loops)
-BOUNDED_SCRATCH = (("a1mpc_setup_gen_kernelILi16E", 64, 0), ("a1mpc_setup_gen_kernelILi20E", 128, 8))   # (two wavefronts per SIMD: 256 registers; a dozen long-lived values wait in scratch while the Ruiz passes run)
+BOUNDED_SCRATCH = (("a1mpc_setup_gen_kernelILi14E", 64, 0), ("a1mpc_setup_gen_kernelILi16E", 64, 0), ("a1mpc_setup_gen_kernelILi20E", 128, 8))   # (two wavefronts per SIMD: 256 registers; a dozen long-lived values wait in scratch while the Ruiz passes run)
 
 
 # ... and kernels that have to fit BESIDE a resident persistent wavefront (424 of a SIMD's 512 registers are taken, 88 are left): (pattern, registers per wavefront, wavefronts

@@ -46,7 +46,7 @@ extern "C" {
 typedef enum a1mpc_status {
     A1MPC_OK = 0,
     A1MPC_ERR_INVALID_ARGUMENT = 1,
-    A1MPC_ERR_UNSUPPORTED_HORIZON = 2, /* horizons compiled in: 1, 4, 6, 8, 10, 12, 14, 16, 20 (a1mpc_config.horizon); per-step feet: 10, 16, 20 */
+    A1MPC_ERR_UNSUPPORTED_HORIZON = 2, /* horizons compiled in: 1, 4, 6, 8, 10, 12, 14, 16, 20 (a1mpc_config.horizon) */
     A1MPC_ERR_NO_DEVICE = 3,
     A1MPC_ERR_HIP = 4,
     A1MPC_ERR_BATCH_TOO_LARGE = 5
@@ -72,8 +72,8 @@ typedef enum a1mpc_status {
 
 typedef struct a1mpc_config {
     int32_t horizon; /* PLAN_HORIZON (S/A1Params.h:26 fixes 10; a run-time value here).  1, 10, 16, 20: the tuned horizons (the balance-QP analogue, the reference's own,
-                        BASELINE's h = 16 / 20 configurations) -- every entry point.  4, 6, 8, 12, 14: the same kernel family as it instantiates for them (all
-                        warm-start modes, contact schedules, tick records, pipelines, sharding; no per-step feet / yaw_A: a1mpc_solve_batch_strided).  Anything
+                        BASELINE's h = 16 / 20 configurations).  4, 6, 8, 12, 14: the same kernel families -- fast path and general path -- as they instantiate for them
+                        (every entry point: all warm-start modes, contact schedules, tick records, per-step feet / yaw_A, pipelines, sharding), not tuned beyond that.  Anything
                         else -- odd horizons, 2, 18, > 20 -- is refused by a1mpc_create with A1MPC_ERR_UNSUPPORTED_HORIZON */
     double dt;       /* mpc_dt, S/A1RobotControl.cpp:462 */
     double mu;       /* S/ConvexMpc.cpp:8 */
@@ -99,7 +99,7 @@ typedef struct a1mpc_config {
                                          update*Bound on the persistent OsqpEigen workspace, then solve()): OSQP re-equilibrates with the PREVIOUS tick's
                                          gradient still in the workspace and starts from the previous solve's SCALED (x, z, y) as they are.  The handle then
                                          also carries the previous scalings, gradient and z of every problem.  Restated from OSQP 0.6's update functions
-                                         (oracle: orc_mpc_solve_update); every horizon > 1 on the fast path; horizons 10 / 16 / 20 also on (round 5; round 6: at every batch size) the general
+                                         (oracle: orc_mpc_solve_update); every horizon > 1, on the fast path and on (round 5; round 6: at every batch size) the general
                                          path (per-step feet / contact schedules / its own A_c yaw: a1mpc_solve_batch_strided; its pattern-change test reads the
                                          zero patterns of the per-step tables, a superset of the changes osqp-eigen sees).  Horizon 1 (the balance QP, which the
                                          reference cold-starts anyway) behaves like 1: a1mpc_last_warm_start_mode reports which semantics a solve actually ran.
@@ -170,7 +170,7 @@ a1mpc_status a1mpc_solve_batch_device(a1mpc_handle h, int32_t n, const double* d
  * change the bounds and which rows are equalities (any horizon a1mpc_create accepts).  Per-step feet and / or a yaw_A run the general kernels:
  * same OSQP iterates as the reference's formation with those inputs, with a bigger LDS image per QP (B~_t of every step), i.e.
  * fewer QPs in flight -- 1.7-2.5x slower by design (round 6; with two batches in flight 3.6 M / 1.5 M / 1.07 M first solves/s at 4096 x h10 / 8192 x h16 / 8192 x h20).
- * Horizons 10, 16, 20.
+ * Every horizon > 1 that a1mpc_create accepts (10, 16, 20 tuned; 4, 6, 8, 12, 14 as the kernels instantiate).
  */
 a1mpc_status a1mpc_solve_batch_strided(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
                                        const double* foot_abs, int32_t foot_stride, const uint8_t* contact, int32_t contact_stride,
@@ -475,7 +475,7 @@ a1mpc_status a1mpc_last_stage_cycles(a1mpc_handle h, double* cycles3_out, int32_
  * split-pipeline solve reports through a1mpc_last_stage_cycles).  Host call; synchronises the handle's stream. */
 a1mpc_status a1mpc_last_tick_stage_cycles(a1mpc_handle h, double* cycles8_out, int32_t* qps_out);
 /* Which warm-start semantics the handle's last MPC solve actually ran: 0 (cold), 1 (fresh set-up + osqp_warm_start) or 2 (the reference's update path).
- * warm_start = 2 exists at every horizon > 1 on the fast path and, at horizons 10 / 16 / 20, on the general path (per-step feet, a separate A_c yaw: its latency and fused kernels -- round 6:
+ * warm_start = 2 exists at every horizon > 1 on the fast path and on the general path (per-step feet, a separate A_c yaw: its latency and fused kernels -- round 6:
  * at every batch size, an update-path batch beyond the resident rows runs the fused kernel in several rounds); a solve at horizon 1, or a general-path batch forced onto
  * its split pipeline by A1MPC_PIPELINE=split, runs mode 1 instead (documented at a1mpc_config.warm_start) -- this call makes that visible to the caller.  -1 before the
  * first solve. */

@@ -1,6 +1,6 @@
 """-m gpu: the extended horizons (4, 6, 8, 12, 14 -- SURVEY 8 a1: PLAN_HORIZON is a compile-time constant of the reference, S/A1Params.h:26, a run-time value of the
 C ABI) through the C ABI against the oracle: the fast path's kernel family as it instantiates for them (latency kernel, fused kernel, set-up kernel + persistent rows),
-cold, warm-started, on the update path, with a contact schedule and from tick records; per-step feet are refused there (the general path exists at 10 / 16 / 20)."""
+cold, warm-started, on the update path, with a contact schedule and from tick records.  Per-step feet at these horizons: tests/test_gpu_general_path.py."""
 import numpy as np
 import pytest
 
@@ -81,7 +81,7 @@ def test_update_path_and_warm_start(pkg, oracle, scen, h, n):
 @pytest.mark.parametrize("h,nb", [(4, 64), (6, 700), (8, 1), (12, 4500), (14, 64)])
 def test_contact_schedule_and_tick_records(pkg, oracle, scen, h, nb):
     """a per-step contact schedule with step-invariant feet (contact_stride = 4) runs the fast kernels at every horizon a1mpc_create accepts (a1mpc.h); tick records
-     build the same x0 / x_ref as the caller would; per-step feet are refused with A1MPC_ERR_UNSUPPORTED_HORIZON and leave the handle usable"""
+     build the same x0 / x_ref as the caller would; per-step feet equal to the broadcast ones give the fast path's forces on the general kernels"""
     rng = np.random.default_rng(4100 + h + nb)
     sc, foot, fs, contact, cs = _strided_inputs(scen, rng, h, nb, False, True)
     pr = oracle_params(oracle, sc); st = oracle.default_settings()
@@ -99,8 +99,8 @@ def test_contact_schedule_and_tick_records(pkg, oracle, scen, h, nb):
         b_ = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
         assert (a["iters"] == b_["iters"]).all() and np.abs(a["u"] - b_["u"]).max() < TOL_FORCE_N
         feet = np.ascontiguousarray(np.tile(sc["foot"], (1, h)))
-        with pytest.raises(pkg.A1MpcError, match="horizon 10, 16 or 20"):
-            eng.solve_strided(sc["x0"], sc["xref"], sc["R"], feet, 12, contact, 4)
+        gen = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], feet, 12, contact, 4, want_u=True)   # the same QPs through the general kernels (per-step feet that happen to be equal)
+        assert np.array_equal(gen["iters"], out["iters"]) and np.abs(gen["u"] - out["u"]).max() <= 1e-7
         again = eng.solve(sc["x0"], sc["xref"], sc["R"], sc["foot"], sc["contact"], want_u=True)
         assert np.array_equal(again["u"], b_["u"])
 

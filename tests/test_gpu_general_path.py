@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("h,nb,feet,cont", [(10, 300, True, True), (10, 128, True, False), (10, 128, False, True), (16, 96, True, True),
-        (20, 64, True, True)])
+        (20, 64, True, True), (4, 200, True, True), (6, 200, True, False), (8, 300, True, True), (12, 300, True, True), (14, 200, True, True), (12, 7, True, True),
+        (6, 5, True, True)])   # (4 .. 14: the extended horizons; 7 / 5 QPs: their small-batch kernels)
 def test_per_step_feet_and_contact_schedules(pkg, oracle, scen, h, nb, feet, cont):
     """b' (VERDICT r1): a1mpc_solve_batch_strided -- per-step B_d (S/ConvexMpc.h:74 B_mat_d_list, S/test/test_mpc.cpp:106-122) and per-step
     contact schedules -- vs the oracle's strided formation (which oracle/_ref pins to the reference's ConvexMpc for per-step feet)."""
@@ -36,7 +37,7 @@ def test_per_step_feet_and_contact_schedules(pkg, oracle, scen, h, nb, feet, con
         assert np.abs(u[c == 0]).max() < 1.0
 
 
-@pytest.mark.parametrize("h,nb", [(10, 1), (10, 48), (16, 6), (20, 5), (10, 4000), (16, 2100), (20, 1700)])
+@pytest.mark.parametrize("h,nb", [(10, 1), (10, 48), (16, 6), (20, 5), (10, 4000), (16, 2100), (20, 1700), (8, 1), (12, 40), (14, 3), (6, 30), (12, 2600)])
 def test_update_path_on_the_general_path(pkg, oracle, scen, h, nb):
     """Round 5 (VERDICT r4 missing 3 / item 5): warm_start = 2 -- the reference's per-tick OSQP update path -- on a STRIDED tick sequence: per-step feet that drift by
     -v_d dt per horizon step (S/test/test_mpc.cpp:112-115) and the gait's contact schedule over the horizon.  a1mpc_last_warm_start_mode reports 2, and every tick has the
@@ -64,7 +65,7 @@ def test_update_path_on_the_general_path(pkg, oracle, scen, h, nb):
                 o = oracle.mpc_solve_update(pr, st, x0[b], xref[b], R[b], foot[b], contact[b], carries[b], foot_stride=12, contact_stride=4)
                 assert out["iters"][b] == o["info"].iters and out["status"][b] == o["info"].status, (h, k, b, out["iters"][b], o["info"].iters)
                 worst = max(worst, np.abs(out["grf"][b] - o["grf"]).max())
-    assert worst <= 1e-7, worst
+    assert worst <= (1e-7 if h in (10, 16, 20) else 1e-6), worst   # (what is observed, two decades under the parity bar TOL_FORCE_N = 1e-5 N; h = 6: 1.3e-7 N with every iteration count equal)
     print(f"h{h} x {nb}: {len(ticks)} strided update-path ticks, worst |dGRF| {worst:.1e} N")
 
 
@@ -100,12 +101,13 @@ def test_update_path_across_a_switch_between_the_fast_and_the_general_path(pkg, 
     assert worst <= 1e-7, worst
 
 
-def test_general_path_latency_kernel(pkg, oracle, scen):
+@pytest.mark.parametrize("h", [10, 6, 14, 8])   # (6, 14: extended horizons with a latency kernel of their own; 8: a multiple of 4 -- small batches run the fused general kernel)
+def test_general_path_latency_kernel(pkg, oracle, scen, h):
     """Round 5: a handful of general-path QPs at h = 10 (<= 256: the reference's own use of the interface is ONE, S/test/test_mpc.cpp:106-122) run one per wavefront with
     the four rows sharing the set-up (a1mpc_solve_gen_coop_kernel).  Bit for bit what the same QPs give inside a batch of 300 (the fused general kernel: main / twin
     pairs), the oracle's strided formation on every QP, and the same on the update path (warm_start = 2) over four ticks."""
-    h, nb, small = 10, 300, 9
-    rng = np.random.default_rng(4242)
+    nb, small = 300, 9
+    rng = np.random.default_rng(4242 + h)
     sc, foot, fs, contact, cs = _strided_inputs(scen, rng, h, nb, True, True)
     with _engine(pkg, sc, nb, warm_start=0) as eng:
         big = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, fs, contact, cs, want_u=True)
@@ -129,7 +131,7 @@ def test_general_path_latency_kernel(pkg, oracle, scen):
         assert e_lat.last_warm_start_mode() == 2 and e_big.last_warm_start_mode() == 2
 
 
-@pytest.mark.parametrize("h,nb", [(10, 4000), (16, 2100), (20, 1700)])
+@pytest.mark.parametrize("h,nb", [(10, 4000), (16, 2100), (20, 1700), (4, 5000), (6, 5000), (8, 4000), (12, 3000), (14, 2500)])
 def test_general_path_split_pipeline(pkg, oracle, scen, h, nb):
     """a general-path batch beyond its resident rows runs the general path's own set-up kernel + persistent main / twin pairs on a queue
     (the hand-off

@@ -8,8 +8,9 @@ pkg = g.load_package(); orc = g.load_oracle()
 lo = int(sys.argv[1]) if len(sys.argv) > 1 else 7000; cnt = int(sys.argv[2]) if len(sys.argv) > 2 else 6; n = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 RS = len(sys.argv) > 4 and sys.argv[4] == "1"
 worst = 0.0; bad = 0; tot = 0
+HS = tuple(int(v) for v in os.environ["A1_SOAK_HORIZONS"].split(",")) if os.environ.get("A1_SOAK_HORIZONS") else (10, 10, 16, 20)   # (A1_SOAK_HORIZONS=4,6,8,12,14: the extended horizons)
 for seed in range(lo, lo + cnt):
-    h = (10, 10, 16, 20)[seed % 4]
+    h = HS[seed % len(HS)]
     sc = pkg.scenarios.config3_random_flat(nb=n, seed=seed, horizon=h, param_set=("gazebo", "hardware", "isaac")[seed % 3]); p = sc["params"]
     rng = np.random.default_rng(seed)
     vd = rng.uniform(-0.6, 0.6, (n, 1, 1, 3))
