@@ -1130,15 +1130,52 @@ __device__ inline void ekf_c_row(int r, int& c0, double& s0, int& c1, double& s1
     else if (r < 24) { c0 = 3 + (r - 12) % 3; s0 = 1.0; }                    // vel
     else { c0 = 6 + (r - 24) * 3 + 2; s0 = 1.0; }                            // foot height
 }
-// Two residencies of the same arithmetic (bit-identical: tools/ubench/ekf_bench.py prints a checksum of the filter states):
-//   LEAN = false  two wavefronts per SIMD (256 registers, 10 KB of LDS per robot): the fewest instructions per robot -- what a batch that fits the chip in one round wants
-//                 (4096 robots of a control tick: 47 us against 52)
-//   LEAN = true   (round 5) THREE wavefronts per SIMD (168 registers, 5.4 KB per robot) for batches of many rounds: 65 536 robots 0.542 -> 0.489 ms, 16 384: 0.156 -> 0.150 (profiles/r05_ekf_residency.txt).  What stood in the way
-//                 was LDS: the 28 x 29 staging of S for the symmetrisation is gone (a lane recomputes the transposed entry S[c][l] from Pbar in LDS with the operations lane c
-//                 used), S^-1 C reaches the measurement update in two halves of 14 rows through one 252-double buffer (the sums still run over r = 0 .. 27 in ascending
-//                 order), and the lane's row of Pbar is re-read from LDS where the measurement update needs it instead of living in registers through the 28 sweeps.
+// ONE arithmetic, round 6: the measurement update never forms S^-1.  S = L D L' by forward elimination without pivoting (S is symmetric positive definite), the
+// right-hand sides [C Pbar | error_y] ride along, and with Y = L^-1 [C Pbar | error_y]
+//     x = xbar + Y_P' D^-1 y_e,      P = Pbar - Y_P' D^-1 Y_P                                                                  (:134-139)
+// -- nothing is solved backwards, and the four dense products behind the explicit inverse (S^-1 error_y, S^-1 C, Pbar C' (S^-1 C), (..) Pbar) are one 28-term
+// rank update.  A third of the inverse's arithmetic, and closer to an 80-bit evaluation of the filter than the explicit inverse is (state 7.6e-15 against 7.3e-14,
+// covariance 1.0e-15 against 1.0e-12 per tick: tests/test_oracle.py).  Until round 6: in-place Gauss-Jordan sweeps to -S^-1 (2 x 28^3 multiply-adds per robot) with the
+// pivot column exchanged through LDS, two residencies of it (profiles/r05_ekf_residency.txt).
+// No LDS in the elimination.  A robot is two DPP rows of 16 lanes; lane i holds ROW i of S (M[28]) and COLUMN i of the right-hand sides (B[28]: column c < 18 of C Pbar,
+// column 18 = error_y).  Step k, p = a_kk:  f_i = a_ik / p,  a_ij -= f_i a_jk (j > k),  b_ic -= f_i b_kc (i > k).  a_jk lives in lane j, f_i in lane i: both reach the lane
+// that needs them as the DPP source of a v_fmac_f64_dpp (row_newbcast), after one v_permlane16_swap pair has put each 16-lane half of the column on both rows of the
+// robot (ekf_rows).  The pivot row is taken from COLUMN k as the other lanes hold it (a_jk for a_kj): only entries of the lower triangle ever feed another entry, so this
+// is the standard right-looking L D L' and the upper triangle a lane drags along is never read.  Rows / columns that are done keep executing the updates on dead
+// registers (no branch inside a step).  The rank update reads y_rb from lane b the same way.  (First cut of this round: rows of Y published to LDS by the pivot lane,
+// 10 masked 16-byte stores per step -- 40 % fewer VALU instructions than the inverse and SLOWER, 0.59 ms per 65 536 robots against 0.49: every multiply-add took a fresh
+// broadcast operand from LDS and the CU's one LDS served four SIMDs, profiles/r06_ekf_ldl.md.)  oracle/a1mpc_oracle.c ekf_step_impl(device = 1) is the same
+// arithmetic in the same order.
 extern "C++" {   // (this section sits inside the ABI's extern "C" block)
-template <bool LEAN>
+template <int I, int N, class F>
+__device__ __forceinline__ void ekf_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); ekf_for<I + 1, N>(f); }
+}
+// (ua, ub) <- x:  ua = the lanes of the robot's EVEN row of x on both of its rows, ub = the odd row's (v_permlane16_swap: odd rows of vdst <-> even rows of src)
+__device__ __forceinline__ void ekf_rows(double x, double& ua, double& ub) {
+    double c0, c1;
+    asm("v_mov_b64 %0, %2\n"
+        "v_mov_b64 %1, %2\n"
+        "s_nop 1" : "=&v"(c0), "=&v"(c1) : "v"(x));   // (VALU write -> v_permlane16_swap read: 2 wait states, which hipcc cannot see behind an asm statement)
+    const unsigned long long b0 = __builtin_bit_cast(unsigned long long, c0), b1 = __builtin_bit_cast(unsigned long long, c1);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(b0), static_cast<unsigned>(b1), false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(static_cast<unsigned>(b0 >> 32), static_cast<unsigned>(b1 >> 32), false, false);
+    ua = __builtin_bit_cast(double, static_cast<unsigned long long>(r0[0]) | (static_cast<unsigned long long>(r1[0]) << 32));
+    ub = __builtin_bit_cast(double, static_cast<unsigned long long>(r0[1]) | (static_cast<unsigned long long>(r1[1]) << 32));
+    asm volatile("s_nop 1" : "+v"(ua), "+v"(ub));     // (VALU write -> DPP read: 2 wait states; the DPP reads below sit inside asm statements)
+}
+template <int L>
+__device__ __forceinline__ double ekf_bcast(double v) { return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + L, 0xF, 0xF, true); }   // row_newbcast:L
+// acc += m * (lane L of my row's x)  /  acc -= ..  as ONE instruction (v_fmac_f64 is the only FP64 arithmetic with a DPP form)
+template <int L>
+__device__ __forceinline__ void ekf_fma(double& acc, double m, double x) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(L));
+}
+template <int L>
+__device__ __forceinline__ void ekf_fnma(double& acc, double m, double x) {
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(L));
+}
+constexpr int kEkfLds = 324 + 16 + 18 + 18 + 28;   // doubles per robot: Pbar (+ 16 words that idle lanes read past it), x, xbar, error_y: 3.2 KB
 __device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __restrict__ lds_g, const int g, const int l) {
 #pragma clang fp contract(off)
     const int64_t b = static_cast<int64_t>(blockIdx.x) * 2 + g;
@@ -1146,8 +1183,7 @@ __device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __res
     double* st = a.state + b * kEkfState;
     const double flag = st[18 + 324];
     if (flag != 1.0) { if (l == 0 && flag == 2.0) st[18 + 324] = 1.0; return; }
-    // LEAN: 324 + 252 + 32 + 18 + 18 + 28 = 672 doubles = 5.4 KB per robot; otherwise 324 + 812 + 48 + 18 + 18 + 28 = 1248 doubles = 10 KB (SCh = the 28 x 29 staging of S, then S^-1 C)
-    double *Pb = lds_g, *SCh = Pb + 324, *prow = SCh + (LEAN ? 252 : 28 * 29), *xs = prow + (LEAN ? 32 : 48), *xb = xs + 18, *zs = xb + 18;
+    double *Pb = lds_g, *xs = Pb + 324 + 16, *xb = xs + 18, *zs = xb + 18;
     const double dt = a.dt;
     const double* Pg = st + 18;  // P of the previous tick: every lane reads its own row(s) straight from global memory
     if (l < 18) xs[l] = st[l];
@@ -1157,9 +1193,8 @@ __device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __res
     const double PIMU = 0.01, VIMU = 0.01, PFOOT = 0.01, S_PIMU_REL = 0.001, S_VIMU_REL = 0.1, S_ZFOOT = 0.001;       // A1BasicEKF.h:15-20
     half_sync();
     // ---- process update (:72-112): xbar = A x + B u, Pbar = A P A' + Q; lane i < 18 owns row i
-    double Pr[18];
+    double xbv = 0.0;
     if (l < 18) {
-        double xbv;
         if (l < 3) xbv = (xs[l] + dt * xs[3 + l]) + 0.0;
         else if (l < 6) { const int c = l - 3; const double u = (R[3 * c] * acc[0] + R[3 * c + 1] * acc[1] + R[3 * c + 2] * acc[2]) + (c == 2 ? -9.81 : 0.0); xbv = xs[l] + dt * u; }
         else xbv = xs[l] + 0.0;
@@ -1168,12 +1203,13 @@ __device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __res
         for (int j = 0; j < 18; ++j) T[j] = l < 3 ? Pg[l * 18 + j] + dt * Pg[(3 + l) * 18 + j] : Pg[l * 18 + j];
         double q;
         if (l < 3) q = PIMU * dt / 20.0; else if (l < 6) q = VIMU * dt * 9.8 / 20.0; else q = (1 + (1 - ec[(l - 6) / 3]) * 1e3) * dt * PFOOT;
-        for (int j = 0; j < 18; ++j) { Pr[j] = (j < 3 ? T[j] + T[3 + j] * dt : T[j]) + (j == l ? q : 0.0); Pb[l * 18 + j] = Pr[j]; }
+        for (int j = 0; j < 18; ++j) Pb[l * 18 + j] = (j < 3 ? T[j] + T[3 + j] * dt : T[j]) + (j == l ? q : 0.0);
     }
     half_sync();
-    // ---- innovation (:115-131): lane r < 28 owns row r of S (and its error_y entry)
+    // ---- innovation (:115-131): lane r < 28 owns row r of S and its error_y entry
     double M[28];
-    double err = 0.0;
+#pragma unroll
+    for (int c = 0; c < 28; ++c) M[c] = 0.0;
     if (l < 28) {
         const int r = l;
         int c0, c1; double s0, s1;
@@ -1198,133 +1234,75 @@ __device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __res
             y = (1.0 - ec[i]) * (xs[2] + fk[3 * i + 2]) + ec[i] * 0;
             rd = a.flat ? (1 + (1 - ec[i]) * 1e3) * S_ZFOOT : 1e5;
         }
-        double CP[18];
+        double CP[18];   // my row of C Pbar
+#pragma unroll
         for (int j = 0; j < 18; ++j) CP[j] = c1 >= 0 ? s0 * Pb[c0 * 18 + j] + s1 * Pb[c1 * 18 + j] : s0 * Pb[c0 * 18 + j];
+#pragma unroll
         for (int c = 0; c < 28; ++c) {
             int d0, d1; double t0, t1;
             ekf_c_row(c, d0, t0, d1, t1);
             const double v = d1 >= 0 ? CP[d0] * t0 + CP[d1] * t1 : CP[d0] * t0;
             M[c] = v + (c == r ? rd : 0.0);
-            if constexpr (!LEAN) SCh[r * 29 + c] = M[c];
         }
-        err = y - yhat;
-        zs[r] = err;   // error_y, read by every row in the product S^-1 error_y below
-    }
-    half_sync();
-    if constexpr (!LEAN) {
-        if (l < 28)
-            for (int c = 0; c < 28; ++c) M[c] = c == l ? 0.5 * (M[c] + M[c]) : (c > l ? 0.5 * (M[c] + SCh[c * 29 + l]) : 0.5 * (SCh[c * 29 + l] + M[c]));   // :131
-    } else if (l < 28) {   // :131  S <- (S + S') / 2.  S[c][l], the entry lane c holds, is recomputed here from Pbar by lane c's own operations (C row of c times Pbar, then my C row)
-        int d0, d1; double t0, t1;
-        ekf_c_row(l, d0, t0, d1, t1);
+        zs[r] = y - yhat;   // error_y: column 18 of the right-hand sides, which lane 18 collects below
+        // :131  S <- (S + S') / 2.  S[c][l], the entry lane c holds, is recomputed here from Pbar by lane c's own operations (C row of c times Pbar, then my C row)
 #pragma unroll
         for (int c = 0; c < 28; ++c) {
             int e0, e1; double u0, u1;
             ekf_c_row(c, e0, u0, e1, u1);
-            const double cp0 = e1 >= 0 ? u0 * Pb[e0 * 18 + d0] + u1 * Pb[e1 * 18 + d0] : u0 * Pb[e0 * 18 + d0];
-            const double cp1 = d1 >= 0 ? (e1 >= 0 ? u0 * Pb[e0 * 18 + d1] + u1 * Pb[e1 * 18 + d1] : u0 * Pb[e0 * 18 + d1]) : 0.0;
-            const double tr = (d1 >= 0 ? cp0 * t0 + cp1 * t1 : cp0 * t0) + 0.0;   // (+ 0.0: lane c added its "not the diagonal" zero)
+            const double cp0 = e1 >= 0 ? u0 * Pb[e0 * 18 + c0] + u1 * Pb[e1 * 18 + c0] : u0 * Pb[e0 * 18 + c0];
+            const double cp1 = c1 >= 0 ? (e1 >= 0 ? u0 * Pb[e0 * 18 + c1] + u1 * Pb[e1 * 18 + c1] : u0 * Pb[e0 * 18 + c1]) : 0.0;
+            const double tr = (c1 >= 0 ? cp0 * s0 + cp1 * s1 : cp0 * s0) + 0.0;   // (+ 0.0: lane c added its "not the diagonal" zero)
             M[c] = c == l ? 0.5 * (M[c] + M[c]) : (c > l ? 0.5 * (M[c] + tr) : 0.5 * (tr + M[c]));
         }
     }
-    // ---- S^-1 by the symmetric sweep operator (in-place Gauss-Jordan without pivoting; S is symmetric positive definite); the two solves (:134, :138) are then
-    // products with it.  Sweep k, p = a_kk:  a_ij -= (a_ik / p) a_kj,  a_ik = a_ik / p,  a_kj = a_kj / p,  a_kk = -1 / p  -- the matrix stays symmetric and ends as -S^-1.
-    // Lane i takes the pivot row from COLUMN k as the other lanes hold it (a_jk for a_kj): a sweep exchanges ONE word per lane (28 lanes write, everyone reads the 28
-    // back).  Exact, because the update is fma(-(a_ik a_jk), 1/p, a_ij): the product commutes, lanes i and j compute the same bits for a_ij and a_ji.  (Until round 3
-    // lane k scaled its row first and published all of it: 28 LDS writes with one lane of 32 active per sweep.  oracle/a1mpc_oracle.c does the same.)
-#pragma unroll
-    for (int k = 0; k < 28; ++k) {
-        half_sync();   // the previous sweep's reads of the column are complete
-        if (l < 28) prow[l] = M[k];
-        half_sync();
-        if (l < 28) {
-            const double pinv = 1.0 / prow[k];
-            if (l == k) {
-#pragma unroll
-                for (int j = 0; j < 28; ++j) M[j] = j == k ? -pinv : M[j] * pinv;
-            } else {
-                const double aik = M[k];
-#pragma unroll
-                for (int j = 0; j < 28; ++j) M[j] = j == k ? aik * pinv : __builtin_fma(-(aik * prow[j]), pinv, M[j]);
-            }
-        }
-    }
-    if (l < 28) {
-#pragma unroll
-        for (int j = 0; j < 28; ++j) M[j] = -M[j];
-    }
     half_sync();
-    double serr = 0.0, SC[18];   // my row of S^-1 C (28 x 18)
+    // the right-hand sides, a COLUMN per lane: B[r] = (C Pbar)[r][l] for l < 18 (row r of C has one or two entries: known at compile time), error_y[r] on lane 18
+    double B[28];
+    ekf_for<0, 28>([&](auto Rr) {
+        constexpr int r = decltype(Rr)::value;
+        constexpr int c0 = r < 12 ? r % 3 : (r < 24 ? 3 + (r - 12) % 3 : 6 + (r - 24) * 3 + 2);   // (ekf_c_row, as constants)
+        double v;
+        if constexpr (r < 12) v = -1.0 * Pb[c0 * 18 + l] + 1.0 * Pb[(6 + r) * 18 + l];
+        else v = 1.0 * Pb[c0 * 18 + l];
+        B[r] = l < 18 ? v : (l == 18 ? zs[r] : 0.0);
+    });
+    // ---- L D L' with the right-hand sides riding along (see the header of this section); every lane of the robot executes every instruction
+    double D = 0.0;   // 1 / d_r on lane r
+    ekf_for<0, 28>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        double ua, ub;
+        ekf_rows(M[k], ua, ub);                                    // column k of the trailing matrix: a_jk on lane j
+        const double pinv = 1.0 / ekf_bcast<k % 16>(k < 16 ? ua : ub);
+        D = l == k ? pinv : D;
+        if constexpr (k < 27) {
+            const double f = M[k] * pinv;
+            double ga, gb;
+            ekf_rows(f, ga, gb);
+            ekf_for<k + 1, 28>([&](auto J) { constexpr int j = decltype(J)::value; ekf_fnma<j % 16>(M[j], f, j < 16 ? ua : ub); });
+            ekf_for<k + 1, 28>([&](auto I) { constexpr int i = decltype(I)::value; ekf_fnma<i % 16>(B[i], B[k], i < 16 ? ga : gb); });
+        }
+    });
+    // ---- measurement update (:134-140): lane a < 18 owns row a of  Y_P' D^-1 [Y_P | y_e]  (the sums run over r = 0 .. 27 in ascending order); y_rb comes from lane b
+    double G[19];
 #pragma unroll
-    for (int j = 0; j < 18; ++j) SC[j] = 0.0;
-    if (l < 28) {
-        // S^-1 error_y (:134): dense product, inner index ascending
-        for (int c = 0; c < 28; ++c) serr = __builtin_fma(M[c], zs[c], serr);   // (round 4: the four big dense products accumulate by FMA, here and in the oracle alike)
-        // S^-1 C (:138): the dense product with C's exact zeros dropped (C[c][j] is 0 or +-1, a zero term leaves the running sum as it is): per column j the
-        // rows c with an entry, ascending -- j < 3: c = j, 3 + j, 6 + j, 9 + j (-1); j = 3..5: c = 12 + (j - 3), 15 + .., 18 + .., 21 + .. (+1); j = 6 + m: c = m (+1)
-        // and, for the z column of a foot, c = 24 + m / 3 (+1)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) SC[j] = (((0.0 + M[j] * -1.0) + M[3 + j] * -1.0) + M[6 + j] * -1.0) + M[9 + j] * -1.0;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) SC[3 + j] = (((0.0 + M[12 + j] * 1.0) + M[15 + j] * 1.0) + M[18 + j] * 1.0) + M[21 + j] * 1.0;
-#pragma unroll
-        for (int m = 0; m < 12; ++m) SC[6 + m] = m % 3 == 2 ? (0.0 + M[m] * 1.0) + M[24 + m / 3] * 1.0 : 0.0 + M[m] * 1.0;
+    for (int j = 0; j < 19; ++j) G[j] = 0.0;
+    {
+        double da, db;
+        ekf_rows(D, da, db);
+        ekf_for<0, 28>([&](auto Rr) {
+            constexpr int r = decltype(Rr)::value;
+            const double wr = B[r] * ekf_bcast<r % 16>(r < 16 ? da : db);
+            double va, vb;
+            ekf_rows(B[r], va, vb);
+            ekf_for<0, 19>([&](auto Cc) { constexpr int c = decltype(Cc)::value; ekf_fma<c % 16>(G[c], wr, c < 16 ? va : vb); });
+        });
     }
-    half_sync();   // every row has read error_y: its place now takes S^-1 error_y
-    if (l < 28) zs[l] = serr;
-    half_sync();
-    // ---- measurement update (:136-140).  S^-1 C arrives in two halves of 14 rows (one 252-double buffer); every sum still runs over r = 0 .. 27 in ascending order
-    double Tn[18], G1[28], G2[18];
-    const double* Prow = LEAN ? Pb + (l < 18 ? l : 0) * 18 : Pr;   // my row of Pbar: LEAN re-reads it from LDS instead of holding it in registers through the 28 sweeps
+    double Tn[18], xnew = 0.0;
     if (l < 18) {
+        xnew = xbv + G[18];
 #pragma unroll
-        for (int r = 0; r < 28; ++r) {
-            int c0, c1; double s0, s1;
-            ekf_c_row(r, c0, s0, c1, s1);
-            G1[r] = c1 >= 0 ? Prow[c0] * s0 + Prow[c1] * s1 : Prow[c0] * s0;
-        }
-        double acc_ = 0;
-#pragma unroll
-        for (int r = 0; r < 28; ++r) acc_ = __builtin_fma(G1[r], zs[r], acc_);
-        xs[l] = xb[l] + acc_;
-#pragma unroll
-        for (int j = 0; j < 18; ++j) G2[j] = 0;
-    }
-    if constexpr (LEAN) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (l >= 14 * half && l < 14 * half + 14) {
-#pragma unroll
-                for (int j = 0; j < 18; ++j) SCh[(l - 14 * half) * 18 + j] = SC[j];
-            }
-            half_sync();
-            if (l < 18) {
-#pragma unroll
-                for (int j = 0; j < 18; ++j) {
-#pragma unroll
-                    for (int r = 0; r < 14; ++r) G2[j] = __builtin_fma(G1[14 * half + r], SCh[r * 18 + j], G2[j]);
-                }
-            }
-            half_sync();
-        }
-    } else {   // (the staging of S is consumed: the region holds all of S^-1 C)
-        if (l < 28) {
-#pragma unroll
-            for (int j = 0; j < 18; ++j) SCh[l * 18 + j] = SC[j];
-        }
-        half_sync();
-        if (l < 18) {
-#pragma unroll
-            for (int j = 0; j < 18; ++j) {
-#pragma unroll
-                for (int r = 0; r < 28; ++r) G2[j] = __builtin_fma(G1[r], SCh[r * 18 + j], G2[j]);
-            }
-        }
-        half_sync();
-    }
-    if (l < 18) {
-#pragma unroll
-        for (int j = 0; j < 18; ++j) { double s = 0; for (int k = 0; k < 18; ++k) s = __builtin_fma(G2[k], Pb[k * 18 + j], s); Tn[j] = Prow[j] - s; }
+        for (int j = 0; j < 18; ++j) Tn[j] = Pb[l * 18 + j] - G[j];
     }
     half_sync();  // every lane is done reading Pbar: its region now stages the unsymmetrised update for the transposed read
     double* Pm = Pb;
@@ -1343,28 +1321,19 @@ __device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __res
             }
         }
         for (int j = 0; j < 18; ++j) st[18 + l * 18 + j] = Pn[j];
-        st[l] = xs[l];
-        if (l < 3) a.pos_out[b * 3 + l] = xs[l]; else if (l < 6) a.vel_out[b * 3 + l - 3] = xs[l];
+        st[l] = xnew;
+        if (l < 3) a.pos_out[b * 3 + l] = xnew; else if (l < 6) a.vel_out[b * 3 + l - 3] = xnew;
     }
     if (l < 4) a.ec_out[b * 4 + l] = ec[l] < 0.5 ? 0 : 1;                                                           // :151-157
 }
 }  // extern "C++"
-__global__ __launch_bounds__(64, 2) void a1mpc_ekf_kernel(const EkfArgs a) {
-    __shared__ __attribute__((aligned(16))) double lds[2][1280];
+__global__ __launch_bounds__(64, 3) void a1mpc_ekf_kernel(const EkfArgs a) {
+    __shared__ __attribute__((aligned(16))) double lds[2][kEkfLds];
     const int g = static_cast<int>(threadIdx.x) >> 5;
-    ekf_update_robot<false>(a, lds[g], g, static_cast<int>(threadIdx.x) & 31);
+    ekf_update_robot(a, lds[g], g, static_cast<int>(threadIdx.x) & 31);
 }
-__global__ __launch_bounds__(64, 3) void a1mpc_ekf_lean_kernel(const EkfArgs a) {
-    __shared__ __attribute__((aligned(16))) double lds[2][680];
-    const int g = static_cast<int>(threadIdx.x) >> 5;
-    ekf_update_robot<true>(a, lds[g], g, static_cast<int>(threadIdx.x) & 31);
-}
-// batches of several rounds of the chip run the three-waves-per-SIMD residency (measured crossover between 4096 and 65 536 robots; A1MPC_EKF_LEAN=0 / 1 forces one)
 static void launch_ekf_update(const EkfArgs& a, hipStream_t s) {
-    static const int force = [] { const char* e = getenv("A1MPC_EKF_LEAN"); return e ? atoi(e) : -1; }();
-    const bool lean = force >= 0 ? force != 0 : a.n >= 16384;
-    if (lean) hipLaunchKernelGGL(a1mpc_ekf_lean_kernel, dim3(static_cast<unsigned>((a.n + 1) / 2)), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((a.n + 1) / 2)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3(static_cast<unsigned>((a.n + 1) / 2)), dim3(64), 0, s, a);
 }
 #define EKF_LAUNCH(a) launch_ekf_update(a, 0)   // (tools/ubench/ekf_bench.py cuts this section into a stand-alone timing harness)
 

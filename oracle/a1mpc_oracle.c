@@ -1186,12 +1186,13 @@ static void ekf_C(double *C) {                                       /* :10-17 *
         }
     for (int i = 0; i < NLEG; ++i) C[(NLEG * 6 + i) * EKF_NS + 6 + i * 3 + 2] = 1.0;
 }
-/* use_fma = 0: the PINNED restatement -- every product of S/A1BasicEKF.cpp:70-164 as a multiply followed by an add, the arithmetic the reference's source
- * states (compiled with -ffp-contract=off); tests/test_ref_pin.py holds THIS variant to the verbatim-compiled reference.
- * use_fma = 1: the four big dense products (:134-139) accumulate by fma() -- the device kernel's arithmetic (round 4: half the FP64 instructions there).  It is
- * not a second ground truth: tests hold it to the plain variant within a stated bound (the oracle must not follow the kernel). */
-static inline double ekf_acc(int use_fma, double x, double y, double a) { return use_fma ? fma(x, y, a) : a + x * y; }
-static void ekf_step_impl(int use_fma, double *state, double dt, int assume_flat_ground, int movement_mode, const double *foot_force, const double *Rw,
+/* device = 0: the PINNED restatement -- every product of S/A1BasicEKF.cpp:70-164 as a multiply followed by an add, the arithmetic the reference's source
+ * states (compiled with -ffp-contract=off), the two solves as products with an explicit S^-1; tests/test_ref_pin.py holds THIS variant to the verbatim-compiled
+ * reference.
+ * device = 1: the device kernel's arithmetic for :134-139 (round 6: L D L' of S with the right-hand sides [C Pbar | error_y] riding along, see below; until then
+ * the same explicit inverse with fma() accumulation in the four dense products).  It is not a second ground truth: tests hold it to the pinned variant within a
+ * stated bound (the oracle must not follow the kernel). */
+static void ekf_step_impl(int device, double *state, double dt, int assume_flat_ground, int movement_mode, const double *foot_force, const double *Rw,
                           const double *imu_acc, const double *imu_ang_vel, const double *foot_pos_rel, const double *foot_vel_rel,
                           double *root_pos, double *root_lin_vel, uint8_t *estimated_contacts_out) {
     double *x = state, *P = state + EKF_NS, *inited = state + EKF_NS + EKF_NS * EKF_NS;
@@ -1264,36 +1265,68 @@ static void ekf_step_impl(int use_fma, double *state, double dt, int assume_flat
         const double v = 0.5 * (M[r * EKF_NM + c] + M[c * EKF_NM + r]); M[r * EKF_NM + c] = v; M[c * EKF_NM + r] = v;
     }
     for (int r = 0; r < EKF_NM; ++r) { M[r * EKF_NM + r] = 0.5 * (M[r * EKF_NM + r] + M[r * EKF_NM + r]); err[r] = y[r] - yhat[r]; }   /* :133 */
-    /* S^-1 by the symmetric sweep operator (in-place Gauss-Jordan without pivoting; S is symmetric positive definite); the two solves (:134, :138) are then
-     * products with it.  Sweep k with p = a_kk:  a_ij -= (a_ik / p) a_kj,  a_ik = a_ik / p,  a_kj = a_kj / p,  a_kk = -1 / p; the matrix stays symmetric and ends
-     * as -S^-1.  Row i takes the pivot row from COLUMN k as the other rows hold it (a_jk for a_kj): on the device row i lives in lane i, and one word per lane is
-     * all a sweep has to exchange.  That is exact because the update is evaluated as fma(-(a_ik a_jk), 1/p, a_ij): the product commutes, rows i and j compute
-     * the same bits for a_ij and a_ji, and the matrix stays symmetric to the last bit.  (With f = a_ik / p first -- one operation fewer -- a_ij and a_ji drift
-     * apart by a rounding per sweep and the inverse loses a digit and a half componentwise: tried, 8.6e-13 against 2.8e-14 on the filter's graded S.) */
-    for (int k = 0; k < EKF_NM; ++k) {
-        double col[EKF_NM];
-        for (int j = 0; j < EKF_NM; ++j) col[j] = M[j * EKF_NM + k];
-        const double pinv = 1.0 / col[k];
-        for (int i = 0; i < EKF_NM; ++i) {
-            if (i == k) { for (int j = 0; j < EKF_NM; ++j) M[k * EKF_NM + j] = j == k ? -pinv : M[k * EKF_NM + j] * pinv; continue; }
-            const double aik = M[i * EKF_NM + k];
-            for (int j = 0; j < EKF_NM; ++j) M[i * EKF_NM + j] = j == k ? aik * pinv : fma(-(aik * col[j]), pinv, M[i * EKF_NM + j]);
+    if (device) {
+        /* The device kernel's arithmetic (round 6).  K = Pbar C' S^-1 never appears: with S = L D L' (forward elimination without pivoting; S is symmetric positive
+         * definite) and Y = L^-1 [C Pbar | error_y] -- the right-hand sides ride along in the elimination -- the two updates (:136, :139) are
+         *     x = xbar + Y_P' D^-1 y_e,      P = Pbar - Y_P' D^-1 Y_P
+         * and nothing is solved backwards.  Step k, p = a_kk:  f_i = a_ik / p,  a_ij -= f_i a_jk (j > k),  b_ic -= f_i b_kc  for the rows i > k.  Row i takes the pivot row
+         * from COLUMN k as the other rows hold it (a_jk for a_kj: on the device row i lives in lane i and one word per lane is what a step exchanges); only entries of the
+         * lower triangle ever feed another entry, so this IS the standard right-looking L D L' -- the upper triangle a lane drags along is never read.  A third of the
+         * explicit inverse's arithmetic (28^3 / 3 + 28^2 19 / 2 multiply-adds against 2 28^3) and four dense products fewer behind it. */
+        double Bm[EKF_NM][EKF_NS + 1], dinv[EKF_NM];
+        for (int r = 0; r < EKF_NM; ++r) { for (int c = 0; c < EKF_NS; ++c) Bm[r][c] = CP[r * EKF_NS + c]; Bm[r][EKF_NS] = err[r]; }
+        for (int k = 0; k < EKF_NM; ++k) {
+            double col[EKF_NM];
+            for (int j = 0; j < EKF_NM; ++j) col[j] = M[j * EKF_NM + k];
+            const double pinv = 1.0 / col[k];
+            dinv[k] = pinv;
+            for (int i = k + 1; i < EKF_NM; ++i) {
+                const double f = col[i] * pinv;
+                for (int j = k + 1; j < EKF_NM; ++j) M[i * EKF_NM + j] = fma(-f, col[j], M[i * EKF_NM + j]);
+                for (int c = 0; c <= EKF_NS; ++c) Bm[i][c] = fma(-f, Bm[k][c], Bm[i][c]);
+            }
         }
-    }
-    for (int i = 0; i < EKF_NM * EKF_NM; ++i) M[i] = -M[i];
-    /* (the four big dense products below: multiply + add in the pinned variant, fma() in the device kernel's variant -- see ekf_step_impl's header) */
-    for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a = ekf_acc(use_fma, M[r * EKF_NM + c], err[c], a); Serr[r] = a; }                        /* :134 */
-    for (int r = 0; r < EKF_NM; ++r) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a += M[r * EKF_NM + c] * C[c * EKF_NS + j]; SC[r * EKF_NS + j] = a; }   /* :138 */
-    double G1[EKF_NS * EKF_NM], G2[EKF_NS * EKF_NS];
-    for (int a_ = 0; a_ < EKF_NS; ++a_) for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int k = 0; k < EKF_NS; ++k) a += Pbar[a_ * EKF_NS + k] * C[r * EKF_NS + k]; G1[a_ * EKF_NM + r] = a; }
-    for (int a_ = 0; a_ < EKF_NS; ++a_) {                                                             /* :136 */
-        double a = 0; for (int r = 0; r < EKF_NM; ++r) a = ekf_acc(use_fma, G1[a_ * EKF_NM + r], Serr[r], a);
-        x[a_] = xbar[a_] + a;
-    }
-    for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int r = 0; r < EKF_NM; ++r) a = ekf_acc(use_fma, G1[a_ * EKF_NM + r], SC[r * EKF_NS + j], a); G2[a_ * EKF_NS + j] = a; }
-    for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) {                            /* :139 */
-        double a = 0; for (int k = 0; k < EKF_NS; ++k) a = ekf_acc(use_fma, G2[a_ * EKF_NS + k], Pbar[k * EKF_NS + j], a);
-        T[a_ * EKF_NS + j] = Pbar[a_ * EKF_NS + j] - a;
+        for (int a_ = 0; a_ < EKF_NS; ++a_) {                                                         /* :136, :139 */
+            double acc = 0, G[EKF_NS] = {0};
+            for (int r = 0; r < EKF_NM; ++r) {
+                const double w = Bm[r][a_] * dinv[r];
+                acc = fma(w, Bm[r][EKF_NS], acc);
+                for (int j = 0; j < EKF_NS; ++j) G[j] = fma(w, Bm[r][j], G[j]);
+            }
+            x[a_] = xbar[a_] + acc;
+            for (int j = 0; j < EKF_NS; ++j) T[a_ * EKF_NS + j] = Pbar[a_ * EKF_NS + j] - G[j];
+        }
+    } else {
+        /* S^-1 by the symmetric sweep operator (in-place Gauss-Jordan without pivoting; S is symmetric positive definite); the two solves (:134, :138) are then
+         * products with it.  Sweep k with p = a_kk:  a_ij -= (a_ik / p) a_kj,  a_ik = a_ik / p,  a_kj = a_kj / p,  a_kk = -1 / p; the matrix stays symmetric and ends
+         * as -S^-1.  Row i takes the pivot row from COLUMN k as the other rows hold it (a_jk for a_kj): on the device row i lives in lane i, and one word per lane is
+         * all a sweep has to exchange.  That is exact because the update is evaluated as fma(-(a_ik a_jk), 1/p, a_ij): the product commutes, rows i and j compute
+         * the same bits for a_ij and a_ji, and the matrix stays symmetric to the last bit.  (With f = a_ik / p first -- one operation fewer -- a_ij and a_ji drift
+         * apart by a rounding per sweep and the inverse loses a digit and a half componentwise: tried, 8.6e-13 against 2.8e-14 on the filter's graded S.) */
+        for (int k = 0; k < EKF_NM; ++k) {
+            double col[EKF_NM];
+            for (int j = 0; j < EKF_NM; ++j) col[j] = M[j * EKF_NM + k];
+            const double pinv = 1.0 / col[k];
+            for (int i = 0; i < EKF_NM; ++i) {
+                if (i == k) { for (int j = 0; j < EKF_NM; ++j) M[k * EKF_NM + j] = j == k ? -pinv : M[k * EKF_NM + j] * pinv; continue; }
+                const double aik = M[i * EKF_NM + k];
+                for (int j = 0; j < EKF_NM; ++j) M[i * EKF_NM + j] = j == k ? aik * pinv : fma(-(aik * col[j]), pinv, M[i * EKF_NM + j]);
+            }
+        }
+        for (int i = 0; i < EKF_NM * EKF_NM; ++i) M[i] = -M[i];
+        for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a += M[r * EKF_NM + c] * err[c]; Serr[r] = a; }                        /* :134 */
+        for (int r = 0; r < EKF_NM; ++r) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int c = 0; c < EKF_NM; ++c) a += M[r * EKF_NM + c] * C[c * EKF_NS + j]; SC[r * EKF_NS + j] = a; }   /* :138 */
+        double G1[EKF_NS * EKF_NM], G2[EKF_NS * EKF_NS];
+        for (int a_ = 0; a_ < EKF_NS; ++a_) for (int r = 0; r < EKF_NM; ++r) { double a = 0; for (int k = 0; k < EKF_NS; ++k) a += Pbar[a_ * EKF_NS + k] * C[r * EKF_NS + k]; G1[a_ * EKF_NM + r] = a; }
+        for (int a_ = 0; a_ < EKF_NS; ++a_) {                                                             /* :136 */
+            double a = 0; for (int r = 0; r < EKF_NM; ++r) a += G1[a_ * EKF_NM + r] * Serr[r];
+            x[a_] = xbar[a_] + a;
+        }
+        for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) { double a = 0; for (int r = 0; r < EKF_NM; ++r) a += G1[a_ * EKF_NM + r] * SC[r * EKF_NS + j]; G2[a_ * EKF_NS + j] = a; }
+        for (int a_ = 0; a_ < EKF_NS; ++a_) for (int j = 0; j < EKF_NS; ++j) {                            /* :139 */
+            double a = 0; for (int k = 0; k < EKF_NS; ++k) a += G2[a_ * EKF_NS + k] * Pbar[k * EKF_NS + j];
+            T[a_ * EKF_NS + j] = Pbar[a_ * EKF_NS + j] - a;
+        }
     }
     for (int i = 0; i < EKF_NS; ++i) for (int j = 0; j < EKF_NS; ++j) P[i * EKF_NS + j] = 0.5 * (T[i * EKF_NS + j] + T[j * EKF_NS + i]);   /* :140 */
     if (P[0] * P[EKF_NS + 1] - P[1] * P[EKF_NS] > 1e-6) {                                             /* :143-147 */
@@ -1309,7 +1342,7 @@ void orc_ekf_step(double *state, double dt, int assume_flat_ground, int movement
                   double *root_pos, double *root_lin_vel, uint8_t *estimated_contacts_out) {
     ekf_step_impl(0, state, dt, assume_flat_ground, movement_mode, foot_force, Rw, imu_acc, imu_ang_vel, foot_pos_rel, foot_vel_rel, root_pos, root_lin_vel, estimated_contacts_out);
 }
-/* the device kernel's arithmetic (fma accumulation in the four dense products): bit-comparable with a1mpc_ekf_update_batch, held to orc_ekf_step by the tests */
+/* the device kernel's arithmetic (L D L' with the right-hand sides riding along, no explicit S^-1): bit-comparable with a1mpc_ekf_update_batch, held to orc_ekf_step by the tests */
 void orc_ekf_step_fma(double *state, double dt, int assume_flat_ground, int movement_mode, const double *foot_force, const double *Rw,
                       const double *imu_acc, const double *imu_ang_vel, const double *foot_pos_rel, const double *foot_vel_rel,
                       double *root_pos, double *root_lin_vel, uint8_t *estimated_contacts_out) {

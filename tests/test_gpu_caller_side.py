@@ -210,12 +210,11 @@ def test_leg_state_N4b(pkg, oracle, scen):
 def test_ekf_N4c_sequence(pkg, oracle, scen):
     """A1BasicEKF for 200 robots over 80 ticks, device-resident filter state vs the oracle's dense restatement
     (S/A1BasicEKF.cpp:54-163).  Two checks (the oracle must not move with the kernel): (i) against the PINNED restatement --
-    multiply + add, what
-    tests/test_ref_pin.py holds to the reference's compiled source -- within 1e-11: the kernel accumulates its four dense products by FMA,
-    a rounding per term
-    of 18- and 28-term dot products on a contracting filter (the CPU suite measures 1.1e-13 between the two arithmetics over 200 ticks);
-    (ii) bit for bit
-    against the oracle's FMA variant of the same products (same operation order: what pins the kernel's lane map and elimination)."""
+    multiply + add, the two solves as products with an explicit S^-1, what tests/test_ref_pin.py holds to the reference's compiled source --
+    within 1e-10: the kernel (round 6) eliminates [S | C Pbar | error_y] to L D L' form and never forms S^-1; the CPU suite measures 2.2e-11
+    between the two arithmetics over 200 ticks and shows, against an 80-bit evaluation, that it is the explicit inverse's rounding
+    (tests/test_oracle.py); (ii) bit for bit against the oracle's device variant (same operations in the same order: what pins the kernel's
+    lane map and elimination)."""
     rng = np.random.default_rng(51)
     n, ticks = 200, 80
     cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
@@ -234,15 +233,14 @@ def test_ekf_N4c_sequence(pkg, oracle, scen):
                 assert np.array_equal(pos[b], p_o) and np.array_equal(vel[b], v_o) and (ec[b] == e_o).all(), (t, b, pos[b] - p_o,
                         vel[b] - v_o)
                 p_p, v_p, e_p = oracle.ekf_step(pinned[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b])
-                assert max(np.abs(pos[b] - p_p).max(), np.abs(vel[b] - v_p).max()) <= 1e-11 and (ec[b] == e_p).all(), (t, b, pos[b] - p_p,
+                assert max(np.abs(pos[b] - p_p).max(), np.abs(vel[b] - v_p).max()) <= 1e-10 and (ec[b] == e_p).all(), (t, b, pos[b] - p_p,
                         vel[b] - v_p)
 
 
 def test_ekf_large_batch_residency(pkg, oracle, scen):
-    """Batches of 16 384 robots and more run the EKF in its three-waves-per-SIMD residency (680 instead of 1280 LDS words per robot, the
-    same arithmetic in the same order).  16 385 robots (the last workgroup half empty), five ticks from the first-call initialisation on:
-    a spread of robots incl. the first and the last against the oracle's FMA variant bit for bit, and the robots of a 200-robot engine
-    (the other residency) against the same rows of the large batch bit for bit."""
+    """A batch of several rounds of the chip (16 385 robots: the last workgroup half empty), five ticks from the first-call
+    initialisation on: a spread of robots incl. the first and the last against the oracle's device variant bit for bit, and the robots of a
+    200-robot engine against the same rows of the large batch bit for bit (a robot's result does not depend on the batch it rides in)."""
     rng = np.random.default_rng(52)
     n, ticks, small = 16385, 5, 200
     cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)

@@ -4,7 +4,7 @@ usage: ekf_bench.py build [extra hipcc flags]  ->  tools/ubench/ekf_bench  (GPU 
 state after the last tick -- equal checksums = the same bits)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-s = open(os.path.join(ROOT, "a1-qp-mpc-controller_amd", "csrc", "a1mpc_hip.hip")).read()
+s = open(os.environ.get("EKF_SRC") or os.path.join(ROOT, "a1-qp-mpc-controller_amd", "csrc", "a1mpc_hip.hip")).read()   # (EKF_SRC: another revision of the source, for A/B)
 sec = s[s.index("// ---- N4c: A1BasicEKF"):s.index("a1mpc_status a1mpc_reset_ekf_state")]
 DRV = r'''
 #include <hip/hip_runtime.h>
@@ -56,6 +56,9 @@ int main(int argc, char** argv) {
 launch = '#define EKF_LAUNCH(a) hipLaunchKernelGGL(a1mpc_ekf_kernel, dim3((a.n + 1) / 2), dim3(64), 0, 0, a)\n'
 if "EKF_LAUNCH" in sec: launch = ""
 src = DRV.replace("@SECTION@", launch + sec)
+if os.environ.get("EKF_WAVES"):   # A/B of the residency: waves per SIMD the kernel is compiled for
+    sec = sec.replace("__launch_bounds__(64, 3) void a1mpc_ekf_kernel", "__launch_bounds__(64, %d) void a1mpc_ekf_kernel" % int(os.environ["EKF_WAVES"]))
+    src = DRV.replace("@SECTION@", launch + sec)
 tag = os.environ.get("EKF_TAG", "")
 out = os.path.join(ROOT, "tools", "ubench", "ekf_bench" + ("_" + tag if tag else ""))
 cpp = "/tmp/ekf_bench.hip"; open(cpp, "w").write(src)
