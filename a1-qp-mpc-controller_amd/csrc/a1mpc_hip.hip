@@ -1181,28 +1181,47 @@ __device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __res
     const int64_t b = static_cast<int64_t>(blockIdx.x) * 2 + g;
     if (b >= a.n) return;
     double* st = a.state + b * kEkfState;
-    const double flag = st[18 + 324];
-    if (flag != 1.0) { if (l == 0 && flag == 2.0) st[18 + 324] = 1.0; return; }
     double *Pb = lds_g, *xs = Pb + 324 + 16, *xb = xs + 18, *zs = xb + 18;
     const double dt = a.dt;
-    const double* Pg = st + 18;  // P of the previous tick: every lane reads its own row(s) straight from global memory
-    if (l < 18) xs[l] = st[l];
-    const double* R = a.R + b * 9; const double *fk = a.fk + b * 12, *fv = a.fv + b * 12, *acc = a.acc + b * 3, *w = a.w + b * 3;
+    // Every global load of the tick is issued here, before the first use of any of them: ONE exposure to the memory latency per robot.  (Until round 6 the loads sat where
+    // they were used, behind the lane-dependent branches of the process update and of the measurement vector -- 18 pairs of row loads each waited for on its own, the
+    // contact inputs behind the flag: half of a wavefront's life was spent parked at s_waitcnt, SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.49, profiles/r06_ekf_ldl.md.)
+    const double* Pg = st + 18;  // P of the previous tick: lane i < 18 reads row i (and row 3 + i for i < 3: A P) straight from global memory
+    const int rowA = l < 18 ? l : 0, rowB = l < 3 ? 3 + l : rowA;
+    const int r = l < 28 ? l : 27;                                       // my row of S / C (lanes 28 - 31 idle along on row 27's inputs)
+    const int leg = r < 24 ? (r % 12) / 3 : r - 24, cr = l % 3;         // the leg my measurement row belongs to; my component (process rows 3 - 5 and measurement rows alike)
+    const double flag = st[18 + 324];
+    double Pa[18], Pc[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) { Pa[j] = Pg[rowA * 18 + j]; Pc[j] = Pg[rowB * 18 + j]; }
+    const double xl = st[rowA];
+    const int mode = a.mode[b];
+    double ffv[4], accv[3], wv[3], Rc[3], f[3], v[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ffv[i] = a.ff[b * 4 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { accv[i] = a.acc[b * 3 + i]; wv[i] = a.w[b * 3 + i]; Rc[i] = a.R[b * 9 + 3 * cr + i]; f[i] = a.fk[b * 12 + 3 * leg + i]; v[i] = a.fv[b * 12 + 3 * leg + i]; }
+    // (a robot whose filter was initialised in THIS call -- flag 2 -- or never -- flag 0 -- runs through the arithmetic on whatever its state holds and stores nothing: the
+    // flag is looked at where the results leave, so its load is not a round trip of its own ahead of the others)
+    if (l < 18) xs[l] = xl;
     double ec[4];
-    for (int i = 0; i < 4; ++i) ec[i] = a.mode[b] == 0 ? 1.0 : fmin(fmax(a.ff[b * 4 + i] / (100.0 - 0.0), 0.0), 1.0);   // :79-86
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ec[i] = mode == 0 ? 1.0 : fmin(fmax(ffv[i] / (100.0 - 0.0), 0.0), 1.0);   // :79-86
     const double PIMU = 0.01, VIMU = 0.01, PFOOT = 0.01, S_PIMU_REL = 0.001, S_VIMU_REL = 0.1, S_ZFOOT = 0.001;       // A1BasicEKF.h:15-20
     half_sync();
     // ---- process update (:72-112): xbar = A x + B u, Pbar = A P A' + Q; lane i < 18 owns row i
     double xbv = 0.0;
     if (l < 18) {
-        if (l < 3) xbv = (xs[l] + dt * xs[3 + l]) + 0.0;
-        else if (l < 6) { const int c = l - 3; const double u = (R[3 * c] * acc[0] + R[3 * c + 1] * acc[1] + R[3 * c + 2] * acc[2]) + (c == 2 ? -9.81 : 0.0); xbv = xs[l] + dt * u; }
-        else xbv = xs[l] + 0.0;
+        if (l < 3) xbv = (xl + dt * xs[3 + l]) + 0.0;
+        else if (l < 6) { const double u = (Rc[0] * accv[0] + Rc[1] * accv[1] + Rc[2] * accv[2]) + (cr == 2 ? -9.81 : 0.0); xbv = xl + dt * u; }
+        else xbv = xl + 0.0;
         xb[l] = xbv;
         double T[18];
-        for (int j = 0; j < 18; ++j) T[j] = l < 3 ? Pg[l * 18 + j] + dt * Pg[(3 + l) * 18 + j] : Pg[l * 18 + j];
+#pragma unroll
+        for (int j = 0; j < 18; ++j) T[j] = l < 3 ? Pa[j] + dt * Pc[j] : Pa[j];
         double q;
         if (l < 3) q = PIMU * dt / 20.0; else if (l < 6) q = VIMU * dt * 9.8 / 20.0; else q = (1 + (1 - ec[(l - 6) / 3]) * 1e3) * dt * PFOOT;
+#pragma unroll
         for (int j = 0; j < 18; ++j) Pb[l * 18 + j] = (j < 3 ? T[j] + T[3 + j] * dt : T[j]) + (j == l ? q : 0.0);
     }
     half_sync();
@@ -1211,29 +1230,21 @@ __device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __res
 #pragma unroll
     for (int c = 0; c < 28; ++c) M[c] = 0.0;
     if (l < 28) {
-        const int r = l;
         int c0, c1; double s0, s1;
         ekf_c_row(r, c0, s0, c1, s1);
         const double yhat = c1 >= 0 ? s0 * xb[c0] + s1 * xb[c1] : s0 * xb[c0];
-        double y, rd;
-        if (r < 24) {
-            const int i = (r % 12) / 3, c = r % 3;
-            const double* f = fk + 3 * i;
-            const double wgt = 1 + (1 - ec[i]) * 1e3;
-            if (r < 12) { y = R[3 * c] * f[0] + R[3 * c + 1] * f[1] + R[3 * c + 2] * f[2]; rd = wgt * S_PIMU_REL; }
-            else {
-                const double* v = fv + 3 * i;
-                const double wx = w[0], wy = w[1], wz = w[2];
-                const double sk0 = 0.0 * f[0] + -wz * f[1] + wy * f[2], sk1 = wz * f[0] + 0.0 * f[1] + -wx * f[2], sk2 = -wy * f[0] + wx * f[1] + 0.0 * f[2];
-                const double lv0 = -v[0] - sk0, lv1 = -v[1] - sk1, lv2 = -v[2] - sk2;
-                const double rl = R[3 * c] * lv0 + R[3 * c + 1] * lv1 + R[3 * c + 2] * lv2;
-                y = (1.0 - ec[i]) * xs[3 + c] + ec[i] * rl; rd = wgt * S_VIMU_REL;
-            }
-        } else {
-            const int i = r - 24;
-            y = (1.0 - ec[i]) * (xs[2] + fk[3 * i + 2]) + ec[i] * 0;
-            rd = a.flat ? (1 + (1 - ec[i]) * 1e3) * S_ZFOOT : 1e5;
-        }
+        // the three kinds of measurement rows, each evaluated by every lane on its own leg / component and selected (the same operations as a branch per kind would do)
+        const double ecl = leg == 0 ? ec[0] : (leg == 1 ? ec[1] : (leg == 2 ? ec[2] : ec[3]));
+        const double wgt = 1 + (1 - ecl) * 1e3;
+        const double y_pos = Rc[0] * f[0] + Rc[1] * f[1] + Rc[2] * f[2];
+        const double wx = wv[0], wy = wv[1], wz = wv[2];
+        const double sk0 = 0.0 * f[0] + -wz * f[1] + wy * f[2], sk1 = wz * f[0] + 0.0 * f[1] + -wx * f[2], sk2 = -wy * f[0] + wx * f[1] + 0.0 * f[2];
+        const double lv0 = -v[0] - sk0, lv1 = -v[1] - sk1, lv2 = -v[2] - sk2;
+        const double rl = Rc[0] * lv0 + Rc[1] * lv1 + Rc[2] * lv2;
+        const double y_vel = (1.0 - ecl) * xs[3 + cr] + ecl * rl;
+        const double y_z = (1.0 - ecl) * (xs[2] + f[2]) + ecl * 0;
+        const double y = r < 12 ? y_pos : (r < 24 ? y_vel : y_z);
+        const double rd = r < 12 ? wgt * S_PIMU_REL : (r < 24 ? wgt * S_VIMU_REL : (a.flat ? (1 + (1 - ecl) * 1e3) * S_ZFOOT : 1e5));
         double CP[18];   // my row of C Pbar
 #pragma unroll
         for (int j = 0; j < 18; ++j) CP[j] = c1 >= 0 ? s0 * Pb[c0 * 18 + j] + s1 * Pb[c1 * 18 + j] : s0 * Pb[c0 * 18 + j];
@@ -1241,8 +1252,8 @@ __device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __res
         for (int c = 0; c < 28; ++c) {
             int d0, d1; double t0, t1;
             ekf_c_row(c, d0, t0, d1, t1);
-            const double v = d1 >= 0 ? CP[d0] * t0 + CP[d1] * t1 : CP[d0] * t0;
-            M[c] = v + (c == r ? rd : 0.0);
+            const double vv = d1 >= 0 ? CP[d0] * t0 + CP[d1] * t1 : CP[d0] * t0;
+            M[c] = vv + (c == r ? rd : 0.0);
         }
         zs[r] = y - yhat;   // error_y: column 18 of the right-hand sides, which lane 18 collects below
         // :131  S <- (S + S') / 2.  S[c][l], the entry lane c holds, is recomputed here from Pbar by lane c's own operations (C row of c times Pbar, then my C row)
@@ -1309,7 +1320,9 @@ __device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __res
     if (l < 18)
         for (int j = 0; j < 18; ++j) Pm[l * 18 + j] = Tn[j];
     half_sync();
-    if (l < 18) {
+    const bool live = flag == 1.0;
+    if (l == 0 && flag == 2.0) st[18 + 324] = 1.0;   // initialised in this call: an ordinary robot from the next tick on
+    if (l < 18 && live) {
         double Pn[18];
         for (int j = 0; j < 18; ++j) Pn[j] = 0.5 * (Tn[j] + Pm[j * 18 + l]);                                       // :140
         const double p00 = 0.5 * (Pm[0] + Pm[0]), p01 = 0.5 * (Pm[1] + Pm[18]), p10 = 0.5 * (Pm[18] + Pm[1]), p11 = 0.5 * (Pm[19] + Pm[19]);
@@ -1324,7 +1337,7 @@ __device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __res
         st[l] = xnew;
         if (l < 3) a.pos_out[b * 3 + l] = xnew; else if (l < 6) a.vel_out[b * 3 + l - 3] = xnew;
     }
-    if (l < 4) a.ec_out[b * 4 + l] = ec[l] < 0.5 ? 0 : 1;                                                           // :151-157
+    if (l < 4 && live) a.ec_out[b * 4 + l] = ec[l] < 0.5 ? 0 : 1;                                                   // :151-157
 }
 }  // extern "C++"
 __global__ __launch_bounds__(64, 3) void a1mpc_ekf_kernel(const EkfArgs a) {
