@@ -1138,9 +1138,9 @@ __device__ inline void ekf_c_row(int r, int& c0, double& s0, int& c1, double& s1
 // covariance 1.0e-15 against 1.0e-12 per tick: tests/test_oracle.py).  Until round 6: in-place Gauss-Jordan sweeps to -S^-1 (2 x 28^3 multiply-adds per robot) with the
 // pivot column exchanged through LDS, two residencies of it (profiles/r05_ekf_residency.txt).
 // No LDS in the elimination.  A robot is two DPP rows of 16 lanes; lane i holds ROW i of S (M[28]) and COLUMN i of the right-hand sides (B[28]: column c < 18 of C Pbar,
-// column 18 = error_y).  Step k, p = a_kk:  f_i = a_ik / p,  a_ij -= f_i a_jk (j > k),  b_ic -= f_i b_kc (i > k).  a_jk lives in lane j, f_i in lane i: both reach the lane
-// that needs them as the DPP source of a v_fmac_f64_dpp (row_newbcast), after one v_permlane16_swap pair has put each 16-lane half of the column on both rows of the
-// robot (ekf_rows).  The pivot row is taken from COLUMN k as the other lanes hold it (a_jk for a_kj): only entries of the lower triangle ever feed another entry, so this
+// column 18 = error_y).  Step k, p = a_kk:  f_i = a_ik / p,  a_ij -= f_i a_jk (j > k);  t_c = b_kc / p,  b_ic -= a_ik t_c (i > k).  a_jk and a_ik live in lanes j and i: the column reaches
+// the lane that needs it as the DPP source of a v_fmac_f64_dpp (row_newbcast), after one v_permlane16_swap pair has put each 16-lane half of it on both rows of the
+// robot (ekf_rows) -- one exchange per step serves both updates.  The pivot row is taken from COLUMN k as the other lanes hold it (a_jk for a_kj): only entries of the lower triangle ever feed another entry, so this
 // is the standard right-looking L D L' and the upper triangle a lane drags along is never read.  Rows / columns that are done keep executing the updates on dead
 // registers (no branch inside a step).  The rank update reads y_rb from lane b the same way.  (First cut of this round: rows of Y published to LDS by the pivot lane,
 // 10 masked 16-byte stores per step -- 40 % fewer VALU instructions than the inverse and SLOWER, 0.59 ms per 65 536 robots against 0.49: every multiply-add took a fresh
@@ -1287,11 +1287,9 @@ __device__ __forceinline__ void ekf_update_robot(const EkfArgs& a, double* __res
         const double pinv = 1.0 / ekf_bcast<k % 16>(k < 16 ? ua : ub);
         D = l == k ? pinv : D;
         if constexpr (k < 27) {
-            const double f = M[k] * pinv;
-            double ga, gb;
-            ekf_rows(f, ga, gb);
-            ekf_for<k + 1, 28>([&](auto J) { constexpr int j = decltype(J)::value; ekf_fnma<j % 16>(M[j], f, j < 16 ? ua : ub); });
-            ekf_for<k + 1, 28>([&](auto I) { constexpr int i = decltype(I)::value; ekf_fnma<i % 16>(B[i], B[k], i < 16 ? ga : gb); });
+            const double f = M[k] * pinv, t = B[k] * pinv;   // f_i = a_ik / p on lane i (my row's multiplier);  t_c = b_kc / p on lane c (my column of the scaled pivot row)
+            ekf_for<k + 1, 28>([&](auto J) { constexpr int j = decltype(J)::value; ekf_fnma<j % 16>(M[j], f, j < 16 ? ua : ub); });   // a_ij -= f_i a_jk
+            ekf_for<k + 1, 28>([&](auto I) { constexpr int i = decltype(I)::value; ekf_fnma<i % 16>(B[i], t, i < 16 ? ua : ub); });   // b_ic -= a_ik t_c: the column serves both updates
         }
     });
     // ---- measurement update (:134-140): lane a < 18 owns row a of  Y_P' D^-1 [Y_P | y_e]  (the sums run over r = 0 .. 27 in ascending order); y_rb comes from lane b

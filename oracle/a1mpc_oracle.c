@@ -1269,7 +1269,7 @@ static void ekf_step_impl(int device, double *state, double dt, int assume_flat_
         /* The device kernel's arithmetic (round 6).  K = Pbar C' S^-1 never appears: with S = L D L' (forward elimination without pivoting; S is symmetric positive
          * definite) and Y = L^-1 [C Pbar | error_y] -- the right-hand sides ride along in the elimination -- the two updates (:136, :139) are
          *     x = xbar + Y_P' D^-1 y_e,      P = Pbar - Y_P' D^-1 Y_P
-         * and nothing is solved backwards.  Step k, p = a_kk:  f_i = a_ik / p,  a_ij -= f_i a_jk (j > k),  b_ic -= f_i b_kc  for the rows i > k.  Row i takes the pivot row
+         * and nothing is solved backwards.  Step k, p = a_kk:  f_i = a_ik / p,  a_ij -= f_i a_jk (j > k);  t_c = b_kc / p,  b_ic -= a_ik t_c  for the rows i > k.  Row i takes the pivot row
          * from COLUMN k as the other rows hold it (a_jk for a_kj: on the device row i lives in lane i and one word per lane is what a step exchanges); only entries of the
          * lower triangle ever feed another entry, so this IS the standard right-looking L D L' -- the upper triangle a lane drags along is never read.  A third of the
          * explicit inverse's arithmetic (28^3 / 3 + 28^2 19 / 2 multiply-adds against 2 28^3) and four dense products fewer behind it. */
@@ -1280,10 +1280,12 @@ static void ekf_step_impl(int device, double *state, double dt, int assume_flat_
             for (int j = 0; j < EKF_NM; ++j) col[j] = M[j * EKF_NM + k];
             const double pinv = 1.0 / col[k];
             dinv[k] = pinv;
+            double t[EKF_NS + 1];
+            for (int c = 0; c <= EKF_NS; ++c) t[c] = Bm[k][c] * pinv;
             for (int i = k + 1; i < EKF_NM; ++i) {
                 const double f = col[i] * pinv;
                 for (int j = k + 1; j < EKF_NM; ++j) M[i * EKF_NM + j] = fma(-f, col[j], M[i * EKF_NM + j]);
-                for (int c = 0; c <= EKF_NS; ++c) Bm[i][c] = fma(-f, Bm[k][c], Bm[i][c]);
+                for (int c = 0; c <= EKF_NS; ++c) Bm[i][c] = fma(-col[i], t[c], Bm[i][c]);
             }
         }
         for (int a_ = 0; a_ < EKF_NS; ++a_) {                                                         /* :136, :139 */
