@@ -645,22 +645,42 @@ __device__ inline void sym3_pinv(const double* m, double* out) {  // pseudo-inve
         for (int j = 0; j < 3; ++j)
             out[3 * i + j] = v[3 * i + 0] * inv[0] * v[3 * j + 0] + v[3 * i + 1] * inv[1] * v[3 * j + 1] + v[3 * i + 2] * inv[2] * v[3 * j + 2];
 }
+// a robot's inputs of one tick: loaded BEFORE its record is staged, so that they travel with the record instead of after it (round 6: until then they were loaded behind the
+// staging barrier, the ring sectors behind them, root_pos_z behind the plane fit and the terrain ring's word behind that -- five exposures to the memory latency per robot, now two)
+struct CtInputs { double gc[4], ff[4], fp[12], rz; uint8_t plan[4]; };
+__device__ __forceinline__ CtInputs contact_terrain_inputs(const ContactArgs& a, const int64_t b) {
+    CtInputs in;
+    in.rz = a.root_pos_z[b * a.z_stride];
+    if (!a.recent_in) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { in.gc[i] = a.gait_counter[b * 4 + i]; in.ff[i] = a.foot_force[b * 4 + i]; in.plan[i] = a.plan_contacts[b * 4 + i]; }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) in.fp[k] = a.foot_pos_abs[b * 12 + k];
+    }
+    return in;
+}
 // one robot's tick on its record `st` (the kernel hands in the record's LDS image; the terrain-only entry and the host-compiled test double the record itself)
-__device__ __forceinline__ void contact_terrain_robot(const ContactArgs& a, const int64_t b, CtRecord* st) {
+__device__ __forceinline__ void contact_terrain_robot_in(const ContactArgs& a, const int64_t b, CtRecord* st, const CtInputs& in) {
 #pragma clang fp contract(off)
     double rc[12];
+    // the terrain-angle filter's word under its cursor is read here, with the leg rings' sectors: everything a tick reads in place is in flight before anything is computed
+    const bool standing = in.rz > 0.1;
+    const int tcount = st->rb.count, thead = st->rb.head;
+    double* tr = a.terrain_ring + thead * a.stride + b;
+    const double tr_old = (standing && tcount >= kTerrainWindow) ? *tr : 0.0;
     if (a.recent_in) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) rc[k] = a.recent_in[b * 12 + k];
     } else {
         CtLeg L[4];
-        double slot[4][3], gc[4], ff[4], fp[12];
-        uint8_t plan[4];
+        double slot[4][3];
+        const double (&gc)[4] = in.gc, (&ff)[4] = in.ff, (&fp)[12] = in.fp;
+        const uint8_t (&plan)[4] = in.plan;
         bool c[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { L[i] = st->leg[i]; gc[i] = a.gait_counter[b * 4 + i]; ff[i] = a.foot_force[b * 4 + i]; plan[i] = a.plan_contacts[b * 4 + i]; }
+        for (int i = 0; i < 4; ++i) L[i] = st->leg[i];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) { rc[k] = st->rb.recent[k]; fp[k] = a.foot_pos_abs[b * 12 + k]; }
+        for (int k = 0; k < 12; ++k) rc[k] = st->rb.recent[k];
         double* ring = a.leg_ring + b * kCtLegRing;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -712,16 +732,14 @@ __device__ __forceinline__ void contact_terrain_robot(const ContactArgs& a, cons
     for (int r = 0; r < 3; ++r) co[r] = P3[3 * r + 0] * rhs[0] + P3[3 * r + 1] * rhs[1] + P3[3 * r + 2] * rhs[2];
     const double s0 = co[1], s1 = co[2], s2 = -1.0;
     double terrain_angle = 0.0;                                                             // :339-352
-    if (a.root_pos_z[b * a.z_stride] > 0.1) {
+    if (standing) {
         const double angle_cos = fabs(0.0 * s0 + 0.0 * s1 + 1.0 * s2) / (sqrt(0.0 * 0.0 + 0.0 * 0.0 + 1.0 * 1.0) * sqrt(s0 * s0 + s1 * s1 + s2 * s2));
         const double v = acos(angle_cos);
-        const int count = st->rb.count, head = st->rb.head;
         Neumaier f{st->rb.sum, st->rb.corr};
-        double* tr = a.terrain_ring + head * a.stride + b;
-        if (count >= kTerrainWindow) f.add(-*tr); else st->rb.count = count + 1;
+        if (tcount >= kTerrainWindow) f.add(-tr_old); else st->rb.count = tcount + 1;
         f.add(v);
         *tr = v;
-        st->rb.head = (head + 1) % kTerrainWindow; st->rb.sum = f.sum; st->rb.corr = f.corr;
+        st->rb.head = (thead + 1) % kTerrainWindow; st->rb.sum = f.sum; st->rb.corr = f.corr;
         terrain_angle = (f.sum + f.corr) / static_cast<double>(kTerrainWindow);
     }
     if (terrain_angle > 0.5) terrain_angle = 0.5;
@@ -730,6 +748,8 @@ __device__ __forceinline__ void contact_terrain_robot(const ContactArgs& a, cons
     if (a.use_terrain_adapt) a.pitch_d[b * a.pitch_stride] = F_R_diff > 0.05 ? -terrain_angle : terrain_angle;  // :358-364
     a.terrain_out[b] = terrain_angle;
 }
+// (a name of its own, not an overload: this section sits inside the ABI's extern "C" block, where two functions of one name are ONE symbol)
+__device__ __forceinline__ void contact_terrain_robot(const ContactArgs& a, const int64_t b, CtRecord* st) { contact_terrain_robot_in(a, b, st, contact_terrain_inputs(a, b)); }
 // One wavefront = 64 robots.  A lane that walks its own 384-byte record in HBM makes every load instruction touch 64 different lines (measured: 2.5 TB/s of algorithmic
 // bytes at 524 288 robots whether the plane fit runs or not).  The wavefront therefore moves its 24 KB of records as 24 fully coalesced 16-byte-per-lane loads into LDS,
 // every lane works on the LDS image of its record (stride 400 B = 25 x 16 B: the 16 lanes of a ds_read_b128 phase hit 16 different quad-banks), and the image goes back
@@ -745,6 +765,7 @@ __global__ __launch_bounds__(64) void a1mpc_contact_terrain_kernel(const Contact
     }
     __shared__ __attribute__((aligned(16))) unsigned char img[64 * kCtLdsStride];
     const int cnt = a.n - base < 64 ? static_cast<int>(a.n - base) : 64;
+    const CtInputs in = contact_terrain_inputs(a, b < a.n ? b : a.n - 1);   // (in flight together with the record)
     const uint4* src = reinterpret_cast<const uint4*>(a.rec + base);
     uint4 v[kCtUnits];
 #pragma unroll
@@ -752,15 +773,18 @@ __global__ __launch_bounds__(64) void a1mpc_contact_terrain_kernel(const Contact
 #pragma unroll
     for (int i = 0; i < kCtUnits; ++i) { const int o = i * 64 + lane, r = o / kCtUnits, w = o - r * kCtUnits; *reinterpret_cast<uint4*>(img + r * kCtLdsStride + w * 16) = v[i]; }
     __syncthreads();
-    if (b < a.n) contact_terrain_robot(a, b, reinterpret_cast<CtRecord*>(img + lane * kCtLdsStride));
+    if (b < a.n) contact_terrain_robot_in(a, b, reinterpret_cast<CtRecord*>(img + lane * kCtLdsStride), in);
     if (b < a.n && a.pk_tick != nullptr) {   // (S/A1RobotControl.cpp:452-456, :470-488 read exactly these fields; root_euler_d[1] is the pitch this lane has just written)
         double* t = a.pk_tick + b * 22;
+        double tv[22];   // (every load before the first store: written field by field each load waited for the store before it -- the compiler cannot know that t[] and the sources are apart)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            t[k] = a.pk_euler[b * 3 + k]; t[3 + k] = a.pk_pos[b * 3 + k]; t[6 + k] = a.pk_ang_vel[b * 3 + k]; t[9 + k] = a.pk_lin_vel[b * 3 + k];
-            t[12 + k] = a.pk_euler_d[b * 3 + k]; t[15 + k] = a.pk_lin_vel_d[b * 3 + k]; t[18 + k] = a.pk_ang_vel_d[b * 3 + k];
+            tv[k] = a.pk_euler[b * 3 + k]; tv[3 + k] = a.pk_pos[b * 3 + k]; tv[6 + k] = a.pk_ang_vel[b * 3 + k]; tv[9 + k] = a.pk_lin_vel[b * 3 + k];
+            tv[12 + k] = a.pk_euler_d[b * 3 + k]; tv[15 + k] = a.pk_lin_vel_d[b * 3 + k]; tv[18 + k] = a.pk_ang_vel_d[b * 3 + k];
         }
-        t[21] = a.pk_pos_d_z[b];
+        tv[21] = a.pk_pos_d_z[b];
+#pragma unroll
+        for (int k = 0; k < 22; ++k) t[k] = tv[k];
     }
     __syncthreads();
     uint4* dst = reinterpret_cast<uint4*>(a.rec + base);

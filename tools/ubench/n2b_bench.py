@@ -4,7 +4,7 @@ with hipcc in seconds -- kernel experiments without the three-minute library bui
 tools/ubench/n2b_bench [robots [ticks]])"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-s = open(os.path.join(ROOT, "a1-qp-mpc-controller_amd", "csrc", "a1mpc_hip.hip")).read()
+s = open(os.environ.get("N2B_SRC") or os.path.join(ROOT, "a1-qp-mpc-controller_amd", "csrc", "a1mpc_hip.hip")).read()   # (N2B_SRC: another revision of the source, for A/B)
 sec = s[s.index("// ---- N2b: contact logic"):s.index("// the handle's contact state: records")]
 DRV = r'''
 #include <hip/hip_runtime.h>
@@ -64,15 +64,16 @@ for v in variant.split("+"):
         sub("sym3_pinv(M, P3);", "for (int k = 0; k < 9; ++k) P3[k] = M[k];")
     if v == "noring":  # no ring traffic (wrong results): what the scattered sectors cost
         sub("slot[i][k] = full ? sl[k] : 0.0;", "slot[i][k] = 0.0;")
+        sub("const double tr_old = (standing && tcount >= kTerrainWindow) ? *tr : 0.0;", "const double tr_old = 0.0;")
         sub("sl[k] = fp[3 * i + k];", "")
-        sub("if (count >= kTerrainWindow) f.add(-*tr); else st->rb.count = count + 1;", "st->rb.count = count + 1;")
+        sub("if (tcount >= kTerrainWindow) f.add(-tr_old); else st->rb.count = tcount + 1;", "st->rb.count = tcount + 1;")
         sub("*tr = v;", "")
     if v == "norecout":
         sub("if (a.recent_out) {", "if (false) {")
     if v == "stageonly":  # records in and out only
-        sub("if (b < a.n) contact_terrain_robot(a, b, reinterpret_cast<CtRecord*>(img + lane * kCtLdsStride));", "if (b < a.n) a.terrain_out[b] = reinterpret_cast<CtRecord*>(img + lane * kCtLdsStride)->rb.sum;")
+        sub("if (b < a.n) contact_terrain_robot_in(a, b, reinterpret_cast<CtRecord*>(img + lane * kCtLdsStride), in);", "if (b < a.n) a.terrain_out[b] = reinterpret_cast<CtRecord*>(img + lane * kCtLdsStride)->rb.sum;")
 src = DRV.replace('@SECTION@', launch + sec)
-out = os.path.join(ROOT, "tools", "ubench", "n2b_bench" + ("_" + variant if variant else ""))
+out = os.path.join(ROOT, "tools", "ubench", "n2b_bench" + ("_" + variant if variant else "") + ("_" + os.environ["N2B_TAG"] if os.environ.get("N2B_TAG") else ""))
 cpp = "/tmp/n2b_bench.hip"; open(cpp, "w").write(src)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", cpp, "-o", out] + sys.argv[2:], check=True)
 print("built", out)
