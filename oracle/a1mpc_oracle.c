@@ -1345,7 +1345,7 @@ void orc_ekf_step(double *state, double dt, int assume_flat_ground, int movement
     ekf_step_impl(0, state, dt, assume_flat_ground, movement_mode, foot_force, Rw, imu_acc, imu_ang_vel, foot_pos_rel, foot_vel_rel, root_pos, root_lin_vel, estimated_contacts_out);
 }
 /* the device kernel's arithmetic (L D L' with the right-hand sides riding along, no explicit S^-1): bit-comparable with a1mpc_ekf_update_batch, held to orc_ekf_step by the tests */
-void orc_ekf_step_fma(double *state, double dt, int assume_flat_ground, int movement_mode, const double *foot_force, const double *Rw,
+void orc_ekf_step_device(double *state, double dt, int assume_flat_ground, int movement_mode, const double *foot_force, const double *Rw,
                       const double *imu_acc, const double *imu_ang_vel, const double *foot_pos_rel, const double *foot_vel_rel,
                       double *root_pos, double *root_lin_vel, uint8_t *estimated_contacts_out) {
     ekf_step_impl(1, state, dt, assume_flat_ground, movement_mode, foot_force, Rw, imu_acc, imu_ang_vel, foot_pos_rel, foot_vel_rel, root_pos, root_lin_vel, estimated_contacts_out);

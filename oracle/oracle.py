@@ -348,13 +348,14 @@ def ekf_state():
     return np.zeros(lib().orc_ekf_state_doubles())
 
 
-def ekf_step(state, dt, movement_mode, foot_force, Rw, imu_acc, imu_ang_vel, foot_pos_rel, foot_vel_rel, assume_flat_ground=1, fma=False):
+def ekf_step(state, dt, movement_mode, foot_force, Rw, imu_acc, imu_ang_vel, foot_pos_rel, foot_vel_rel, assume_flat_ground=1, device=False):
     """S/A1BasicEKF.cpp: init_state on the first call of a state, update_estimation afterwards.  returns (root_pos, root_lin_vel, estimated_contacts).
-    fma=False: the pinned restatement (multiply + add, what tests/test_ref_pin.py holds to the reference's compiled source); fma=True: the device kernel's
-    arithmetic (fma accumulation in the four dense products) -- bit-comparable with a1mpc_ekf_update_batch, itself held to the pinned variant by the tests."""
+    device=False: the pinned restatement (multiply + add, the two solves as products with an explicit S^-1: what tests/test_ref_pin.py holds to the reference's compiled
+    source); device=True: the device kernel's arithmetic (L D L' of S with [C Pbar | error_y] riding along) -- bit-comparable with a1mpc_ekf_update_batch, itself held to the
+    pinned variant and to an 80-bit evaluation by the tests."""
     a = lambda v: _p(np.ascontiguousarray(v, dtype=np.float64))
     pos = np.zeros(3); vel = np.zeros(3); ec = np.zeros(4, np.uint8)
-    (lib().orc_ekf_step_fma if fma else lib().orc_ekf_step)(_p(state), C.c_double(dt), C.c_int(int(assume_flat_ground)), C.c_int(int(movement_mode)), a(foot_force), a(Rw), a(imu_acc),
+    (lib().orc_ekf_step_device if device else lib().orc_ekf_step)(_p(state), C.c_double(dt), C.c_int(int(assume_flat_ground)), C.c_int(int(movement_mode)), a(foot_force), a(Rw), a(imu_acc),
                        a(imu_ang_vel), a(foot_pos_rel), a(foot_vel_rel), _p(pos), _p(vel), _p(ec, C.c_uint8))
     return pos, vel, ec
 

@@ -229,7 +229,7 @@ def test_ekf_N4c_sequence(pkg, oracle, scen):
             w = rng.normal(0, 0.3, (n, 3)); ff = rng.uniform(0, 160, (n, 4))
             pos, vel, ec = eng.ekf_update(0.0025, mm, ff, R, acc, w, fk, fv)
             for b in range(0, n, 3):
-                p_o, v_o, e_o = oracle.ekf_step(states[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b], fma=True)
+                p_o, v_o, e_o = oracle.ekf_step(states[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b], device=True)
                 assert np.array_equal(pos[b], p_o) and np.array_equal(vel[b], v_o) and (ec[b] == e_o).all(), (t, b, pos[b] - p_o,
                         vel[b] - v_o)
                 p_p, v_p, e_p = oracle.ekf_step(pinned[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b])
@@ -259,7 +259,7 @@ def test_ekf_large_batch_residency(pkg, oracle, scen):
             pos_s, vel_s, ec_s = eng_s.ekf_update(0.0025, mm[s], ff[s], R[s], acc[s], w[s], fk[s], fv[s])
             assert np.array_equal(pos[s], pos_s) and np.array_equal(vel[s], vel_s) and np.array_equal(ec[s], ec_s), t
             for b in sample:
-                p_o, v_o, e_o = oracle.ekf_step(states[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b], fma=True)
+                p_o, v_o, e_o = oracle.ekf_step(states[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b], device=True)
                 assert np.array_equal(pos[b], p_o) and np.array_equal(vel[b], v_o) and (ec[b] == e_o).all(), (t, b, pos[b] - p_o, vel[b] - v_o)
 
 

@@ -256,7 +256,7 @@ def _ekf_tick_80bit(state, dt, mm, ff, R, acc, w, fk, fv, flat):
 
 def test_ekf_device_variant_vs_the_pinned_restatement_and_an_80_bit_evaluation(oracle, scen):
     """orc_ekf_step is the pinned restatement (multiply + add, the two solves as products with an explicit S^-1; held to the reference's compiled source by
-    tests/test_ref_pin.py); orc_ekf_step_fma is the device kernel's arithmetic (round 6: L D L' of S with [C Pbar | error_y] riding along, no S^-1) and is no ground
+    tests/test_ref_pin.py); orc_ekf_step_device is the device kernel's arithmetic (round 6: L D L' of S with [C Pbar | error_y] riding along, no S^-1) and is no ground
     truth of its own.  Two bounds:
       (i)  over 20 robots x 200 ticks the two stay within 1e-10 m / m/s of each other (measured 2.2e-11);
       (ii) tick by tick from the same state, against an 80-bit evaluation of the reference's formulas, the device arithmetic is the CLOSER of the two: state within
@@ -276,9 +276,9 @@ def test_ekf_device_variant_vs_the_pinned_restatement_and_an_80_bit_evaluation(o
             if yard:   # both arithmetics from ONE state (the pinned sequence's), against the 80-bit tick
                 xt, Pt = _ekf_tick_80bit(s0, 0.0025, mm, ff, R, acc, w, fk, fv, rob % 2)
                 sd = s0.copy()
-                oracle.ekf_step(sd, 0.0025, mm, ff, R, acc, w, fk, fv, assume_flat_ground=rob % 2, fma=True)
+                oracle.ekf_step(sd, 0.0025, mm, ff, R, acc, w, fk, fv, assume_flat_ground=rob % 2, device=True)
             p0, v0, e0 = oracle.ekf_step(s0, 0.0025, mm, ff, R, acc, w, fk, fv, assume_flat_ground=rob % 2)
-            p1, v1, e1 = oracle.ekf_step(s1, 0.0025, mm, ff, R, acc, w, fk, fv, assume_flat_ground=rob % 2, fma=True)
+            p1, v1, e1 = oracle.ekf_step(s1, 0.0025, mm, ff, R, acc, w, fk, fv, assume_flat_ground=rob % 2, device=True)
             if yard:
                 for i, s_ in enumerate((s0, sd)):
                     ex[i] = max(ex[i], float(np.abs(s_[:18] - xt).max())); eP[i] = max(eP[i], float(np.abs(s_[18:342].reshape(18, 18) - Pt).max()))
