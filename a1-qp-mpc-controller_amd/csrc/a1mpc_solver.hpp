@@ -648,24 +648,39 @@ struct RowSolver {
             // The set-up kernel of the general path's split pipeline (SETUP_ONLY) keeps no B~w table in LDS: the column goes straight into the hand-off record (gen_rec) and is
             // recomputed from the foot table where the set-up needs it again (bw_at: the same expression, the same bits) -- 36 H doubles less per QP, eight instead of seven
             // one-QP workgroups per CU at H = 20
-            static_for<H>([&](auto T) {
-                constexpr int t = A1_CV(T);
-                const double* fp = io.foot + static_cast<int64_t>(t) * io.foot_stride;
-                const double rx = fp[3 * quad + 0], ry = fp[3 * quad + 1], rz = fp[3 * quad + 2];
-                double bw[3];
-                bw_from_foot(Ii, rx, ry, rz, bw);
-                if (act) {
-                    if constexpr (SETUP_ONLY) {
-                        if (gen_rec != nullptr && coop_id == 0) {
+            // Every step's foot position is loaded before the first column is stored (round 6, last session): written step by step, the set-up kernel's loop was load -> wait ->
+            // compute -> three stores to the hand-off record -> wait for the stores (this part counts loads and stores in ONE vmcnt, and the compiler must assume that the record
+            // and the feet overlap) -> next load: 2 H exposures to the memory latency per QP, a fifth of the kernel's wave cycles parked at s_waitcnt
+            // (profiles/r06_general_setup_counters.txt).
+            // (In chunks of at most eight steps: at H = 16 the 96 registers of all the feet pushed a spill of the set-up kernel into its Ruiz loops.)
+            constexpr int CH = H <= 12 ? H : 8, NCH = (H + CH - 1) / CH;
+            static_for<NCH>([&](auto C_) {
+                constexpr int t0 = A1_CV(C_) * CH, tn = (t0 + CH < H ? t0 + CH : H) - t0;
+                double rf[3 * CH];
+                static_for<tn>([&](auto T) {
+                    constexpr int t = t0 + A1_CV(T);
+                    const double* fp = io.foot + static_cast<int64_t>(t) * io.foot_stride;
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) gen_rec[(PR::BWF + 3 * t + k) * 12 + ci] = bw[k];
+                    for (int k = 0; k < 3; ++k) rf[3 * A1_CV(T) + k] = fp[3 * quad + k];
+                });
+                static_for<tn>([&](auto T) {
+                    constexpr int t = t0 + A1_CV(T);
+                    const double rx = rf[3 * A1_CV(T) + 0], ry = rf[3 * A1_CV(T) + 1], rz = rf[3 * A1_CV(T) + 2];
+                    double bw[3];
+                    bw_from_foot(Ii, rx, ry, rz, bw);
+                    if (act) {
+                        if constexpr (SETUP_ONLY) {
+                            if (gen_rec != nullptr && coop_id == 0) {
+#pragma unroll
+                                for (int k = 0; k < 3; ++k) gen_rec[(PR::BWF + 3 * t + k) * 12 + ci] = bw[k];
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) lds[L::BW + (t * 3 + k) * 12 + ci] = bw[k];
                         }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) lds[L::BW + (t * 3 + k) * 12 + ci] = bw[k];
+                        lds[L::FT + t * 12 + ci] = comp == 0 ? rx : (comp == 1 ? ry : rz);
                     }
-                    lds[L::FT + t * 12 + ci] = comp == 0 ? rx : (comp == 1 ? ry : rz);
-                }
+                });
             });
         }
         set_sync();
