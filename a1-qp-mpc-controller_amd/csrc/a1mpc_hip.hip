@@ -1158,7 +1158,7 @@ __device__ inline void ekf_c_row(int r, int& c0, double& s0, int& c1, double& s1
 // right-hand sides [C Pbar | error_y] ride along, and with Y = L^-1 [C Pbar | error_y]
 //     x = xbar + Y_P' D^-1 y_e,      P = Pbar - Y_P' D^-1 Y_P                                                                  (:134-139)
 // -- nothing is solved backwards, and the four dense products behind the explicit inverse (S^-1 error_y, S^-1 C, Pbar C' (S^-1 C), (..) Pbar) are one 28-term
-// rank update.  A third of the inverse's arithmetic, and closer to an 80-bit evaluation of the filter than the explicit inverse is (state 7.6e-15 against 7.3e-14,
+// rank update.  A third of the inverse's arithmetic, and closer to an 80-bit evaluation of the filter than the explicit inverse is (state 9.8e-15 against 7.3e-14,
 // covariance 1.0e-15 against 1.0e-12 per tick: the CPU suite measures it).  Until round 6: in-place Gauss-Jordan sweeps to -S^-1 (2 x 28^3 multiply-adds per robot) with the
 // pivot column exchanged through LDS, two residencies of it (profiles/r05_ekf_residency.txt).
 // No LDS in the elimination.  A robot is two DPP rows of 16 lanes; lane i holds ROW i of S (M[28]) and COLUMN i of the right-hand sides (B[28]: column c < 18 of C Pbar,
