@@ -32,7 +32,7 @@ def _parse(path, key):
     cur = None
     with open(path) as f:
         for ln, l in enumerate(f, 1):
-            m = re.match(r"^(_Z\w+):", l)
+            m = re.match(r"^(_Z\w+|a1mpc_\w+):", l)   # (mangled names, and the extern "C" kernels of a1mpc_hip.hip: the EKF kernel has DPP chains of its own since round 6)
             if m:
                 kernel = m.group(1) if key in m.group(1) else None
                 if kernel:
@@ -160,7 +160,8 @@ def dpp_hazards(path, key=""):
 # return [] and every build would pass.  build() therefore also demands that the kernels made of inline-asm DPP chains were found and that a
 # plausible number of v_fmac_f64_dpp instructions was inspected in each.
 EXPECTED_DPP = {"a1mpc_admm_gen_cu_kernelILi10E": 1500, "a1mpc_admm_kernelILi10E": 1500, "a1mpc_admm_kernelILi16E": 2500, "a1mpc_admm_kernelILi20E": 3000, "a1mpc_admm_cu_kernelILi16E": 2500, "a1mpc_setup_kernelILi10E": 60,
-                "a1mpc_solve_kernelILi10E": 1500, "a1mpc_solve_coop_kernelILi10E": 1500, "a1mpc_solve_gen_kernelILi10E": 1500}
+                "a1mpc_solve_kernelILi10E": 1500, "a1mpc_solve_coop_kernelILi10E": 1500, "a1mpc_solve_gen_kernelILi10E": 1500,
+                "a1mpc_ekf_kernel": 1200}   # (the EKF: 1288 = 2 x 378 in the elimination + 28 x 19 in the rank update)
 
 
 def dpp_coverage(path):

@@ -64,3 +64,25 @@ def test_the_library_built_here_passes_the_gate():
     assert isa.resource_gaps(res) == []
     gen = {k: v for k, v in res.items() if "gen_kernel" in k or "gen_coop" in k}
     assert len(gen) >= 14 and all((v["scratch_instrs_in_loops"] or 0) <= 8 for v in gen.values())
+
+
+def test_hazard_check_sees_the_extern_c_kernels(tmp_path):
+    """The EKF kernel (extern "C": an unmangled label) carries inline-asm DPP chains since round 6: the DPP hazard check must parse it like the mangled kernels, find a
+    hazard in it, and the coverage gate must miss it when it is gone (no fail-open)."""
+    isa = _isa()
+    body = lambda gap: f"""
+a1mpc_ekf_kernel:                       ; @a1mpc_ekf_kernel
+; %bb.0:
+	v_mul_f64 v[2:3], v[4:5], v[6:7]
+{gap}	v_fmac_f64_dpp v[8:9], -v[2:3], v[10:11] row_newbcast:3 row_mask:0xf bank_mask:0xf
+	s_endpgm
+.Lfunc_end0:
+"""
+    bad = tmp_path / "bad.s"; bad.write_text(body(""))
+    good = tmp_path / "good.s"; good.write_text(body("\ts_nop 1\n"))
+    assert len(isa.dpp_hazards(str(bad))) == 1 and "a1mpc_ekf_kernel" in isa.dpp_hazards(str(bad))[0]
+    assert isa.dpp_hazards(str(good)) == []
+    assert isa.dpp_coverage(str(good)) == {"a1mpc_ekf_kernel": 1}
+    assert "a1mpc_ekf_kernel" in isa.EXPECTED_DPP
+    gaps = isa.coverage_gaps(None, coverage={k: v for k, v in isa.EXPECTED_DPP.items() if k != "a1mpc_ekf_kernel"})
+    assert any("a1mpc_ekf_kernel" in m for m in gaps), gaps
