@@ -441,3 +441,29 @@ def test_terrain_block_alone(pkg, oracle, scen):
             pitch_b, ta = only.terrain(o["foot_pos_recent_contact"], z, pitch_b)
             assert np.array_equal(ta, o["terrain_angle"]) and np.array_equal(pitch_b, pitch_a), t
     assert np.abs(pitch_a).max() > 0.05
+
+
+@pytest.mark.gpu
+def test_ekf_fleet_that_grows_and_is_reset(pkg, oracle, scen):
+    """The EKF kernel looks at a robot's initialised-flag where its results leave (round 6: every load of the tick is in flight before anything is computed), so a robot
+    whose filter is new in THIS call walks through the arithmetic and must store nothing but its flag.  A fleet of 100 robots that grows to 301 after three ticks (the
+    newcomers are initialised in the call that first sees them, the veterans keep filtering), shrinks back to 37, and is reset in the middle: every robot of every
+    tick bit for bit against the oracle's device variant, each oracle state started in the tick its robot first appeared."""
+    rng = np.random.default_rng(77)
+    cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+    base = np.array([0.18, 0.13, -0.3, 0.18, -0.13, -0.3, -0.18, 0.13, -0.3, -0.18, -0.13, -0.3])
+    nmax = 301
+    states = [oracle.ekf_state() for _ in range(nmax)]
+    sizes = [100, 100, 100, 301, 301, 301, 37, 37, 301, 301, 200, 200]
+    with pkg.Engine(cfg, nmax, 0) as eng:
+        for t, n in enumerate(sizes):
+            if t == 8:
+                eng.reset_ekf_state(); states = [oracle.ekf_state() for _ in range(nmax)]
+            mm = np.where(rng.random(n) < 0.8, 1, 0).astype(np.uint8)
+            yaw = rng.uniform(-3, 3, n); eul = rng.normal(0, 0.05, (n, 2)); R = scen.rot_zyx(eul[:, 0], eul[:, 1], yaw).reshape(n, 9)
+            fk = base + rng.normal(0, 0.01, (n, 12)); fv = rng.normal(0, 0.3, (n, 12)); acc = np.array([0.0, 0.0, 9.81]) + rng.normal(0, 0.3, (n, 3))
+            w = rng.normal(0, 0.3, (n, 3)); ff = rng.uniform(0, 160, (n, 4))
+            pos, vel, ec = eng.ekf_update(0.0025, mm, ff, R, acc, w, fk, fv)
+            for b in range(n):
+                p_o, v_o, e_o = oracle.ekf_step(states[b], 0.0025, mm[b], ff[b], R[b], acc[b], w[b], fk[b], fv[b], device=True)
+                assert np.array_equal(pos[b], p_o) and np.array_equal(vel[b], v_o) and (ec[b] == e_o).all(), (t, n, b, pos[b] - p_o, vel[b] - v_o)
