@@ -11,6 +11,7 @@
 // There is no CPU path in this file: without a HIP device every entry point fails.
 #include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen()ed by a1mpc_sharded_create(transport = 1), never linked
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <new>
@@ -507,6 +508,7 @@ struct a1mpc_handle_s {
     double tick_km[3] = {0, 0, 0};
     bool staged = false;
     bool busy = false;
+    size_t zc_poll_bytes = 0;   // > 0: host_submit launched a kernel that writes its outputs into the pinned block itself and filled that many bytes of it with the in-flight pattern (a1mpc_solve_batch polls them)
     int pipeline_depth = 0;      // > 0: this handle is a slot of an a1mpc_pipeline with that many slots (g_gen_prefer_one_wave)
     // carried OSQP workspace (warm start)
     double *d_wx = nullptr, *d_wy = nullptr, *d_rho = nullptr;
@@ -2305,6 +2307,7 @@ a1mpc_status a1mpc_solve_batch_ticks(a1mpc_handle h, int32_t n, const double* ti
 //                 block, one H2D copy, the launches, one D2H copy into the pinned mirror -- all queued on the handle's stream, nothing waited for
 //                 (a tick is one H2D copy, one memset, two launches and one D2H copy -- API calls, not bytes, set batch-1 latency);
 //   host_collect  (after the stream has drained) the pinned mirror into the caller's output arrays.
+constexpr unsigned long long kInFlightWord = 0x7ff85a5a7ff85a5aull;   // what a1mpc_solve_batch leaves in every output word of the pinned block until the kernel has written it (host_submit)
 struct HostOut { size_t q_grf, q_it, q_st, q_u; };
 static HostOut host_out_layout(size_t N) {
     HostOut o;
@@ -2332,8 +2335,23 @@ static a1mpc_status host_submit(a1mpc_handle h, int32_t n, const double* x0, con
     // PINNED block itself (device-mapped host memory: 1.3 KB in, ~100 B out per QP over PCIe, a few transactions) -- the two staging copies each cost more on the
     // GPU's timeline than the bytes they move.  Same kernel, same bits.  A1MPC_ZERO_COPY_MAX (default 8 QPs; 0 = always stage through device memory).
     static const int zero_copy_max = [] { const char* e = getenv("A1MPC_ZERO_COPY_MAX"); return e ? atoi(e) : 8; }();
+    h->zc_poll_bytes = 0;
     if (n <= zero_copy_max && h->d_pin != nullptr) {
         char* din = h->d_pin; char* dout = h->d_pin + h->h_pin_in_bytes;
+        // Round 6: every output word doubles as its own completion flag.  The block the kernel is about to write is filled with a bit pattern no result has (a quiet NaN
+        // with a payload as a double -- forces are finite or exactly zero, a failed solve's u is the payload-free NaN --, 0x7ff85a5a as an int32: no iteration count, no
+        // status), and a1mpc_solve_batch polls until no word holds it any more instead of hipStreamSynchronize(): the host is awake 5 us earlier (p99: 9 us;
+        // tools/ubench/completion_wake_ubench.hip).  No ordering between the kernel's stores is assumed: a first version that polled `status` alone, stored last behind a
+        // system-scope release, saw the forces arrive AFTER it on 2 of 10 000 ticks (posted writes over PCIe with relaxed ordering).
+        static const bool poll = [] { const char* e = getenv("A1MPC_POLL_COMPLETION"); return e ? atoi(e) != 0 : true; }();
+        if (poll) {
+            static_assert(sizeof(unsigned long long) == 8, "");
+            unsigned long long* w = reinterpret_cast<unsigned long long*>(hout);
+            const size_t words = (out_bytes + 7) / 8;
+            for (size_t i = 0; i < words; ++i) w[i] = kInFlightWord;
+            std::atomic_thread_fence(std::memory_order_release);
+            h->zc_poll_bytes = out_bytes;
+        }
         return a1mpc_solve_batch_device(
             h, n, reinterpret_cast<const double*>(din + o_x0), reinterpret_cast<const double*>(din + o_xr), reinterpret_cast<const double*>(din + o_R),
             reinterpret_cast<const double*>(din + o_f), reinterpret_cast<const uint8_t*>(din + o_c), reinterpret_cast<double*>(dout + q.q_grf),
@@ -2368,8 +2386,28 @@ a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, cons
         return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
     if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
     if (n == 0) return A1MPC_OK;
-    if (a1mpc_status st = host_submit(h, n, x0, x_ref, R_world, foot_abs, contact, u_full_out != nullptr); st != A1MPC_OK) return st;
-    A1_HIP(hipStreamSynchronize(h->stream));
+    if (a1mpc_status st = host_submit(h, n, x0, x_ref, R_world, foot_abs, contact, u_full_out != nullptr); st != A1MPC_OK) { h->zc_poll_bytes = 0; return st; }
+    bool done = false;
+    if (h->zc_poll_bytes) {   // the kernel writes into the pinned block itself: poll its output words (and the stream now and then: a launch that failed never writes them)
+        const HostOut q = host_out_layout(static_cast<size_t>(n));
+        const char* hout = h->h_pin + h->h_pin_in_bytes;
+        const volatile unsigned long long* w64 = reinterpret_cast<const volatile unsigned long long*>(hout);
+        const volatile uint32_t* w32 = reinterpret_cast<const volatile uint32_t*>(hout);
+        const uint32_t lo = static_cast<uint32_t>(kInFlightWord);
+        const size_t i32_first = q.q_it / 4, i32_end = q.q_u / 4, d_end = h->zc_poll_bytes / 8;   // [grf doubles | iters, status int32 | u doubles]
+        for (unsigned spin = 1; !done; ++spin) {
+            done = true;
+            for (size_t i = i32_first; i < i32_end && done; ++i) done = w32[i] != lo;                  // (written last by the kernel: the cheap test first)
+            for (size_t i = 0; i < q.q_it / 8 && done; ++i) done = w64[i] != kInFlightWord;
+            for (size_t i = (q.q_u + 7) / 8; i < d_end && done; ++i) done = w64[i] != kInFlightWord;
+            if (done) break;
+            if ((spin & 0x3ff) == 0 && hipStreamQuery(h->stream) != hipErrorNotReady) break;   // finished (the words arrive with it) or failed: the synchronisation below reports which
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        h->zc_poll_bytes = 0;
+    }
+    if (!done) A1_HIP(hipStreamSynchronize(h->stream));
     host_collect(h, n, grf_body_out, u_full_out, iters_out, status_out);
     return A1MPC_OK;
 }

@@ -144,6 +144,9 @@ void a1mpc_destroy(a1mpc_handle h);
  *   iters_out, status_out  n each, or NULL
  * With cfg.warm_start the handle keeps (x, y, rho) of problem i between calls, like the reference's
  * persistent OSQP workspace.
+ * A handful of QPs (n <= 8: the reference's own call is n = 1) are read from and written to the handle's pinned block by the
+ * kernel itself, and the call returns as soon as the last output word has arrived (polled; round 6) -- the handle's stream may
+ * still be retiring the launch for a few microseconds, which later calls and every a1mpc_last_* query order themselves behind.
  */
 a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
                                const double* foot_abs, const uint8_t* contact, double* grf_body_out, double* u_full_out,
