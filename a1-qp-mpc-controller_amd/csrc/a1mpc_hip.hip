@@ -2401,7 +2401,7 @@ a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, cons
             for (size_t i = 0; i < q.q_it / 8 && done; ++i) done = w64[i] != kInFlightWord;
             for (size_t i = (q.q_u + 7) / 8; i < d_end && done; ++i) done = w64[i] != kInFlightWord;
             if (done) break;
-            if ((spin & 0x3ff) == 0 && hipStreamQuery(h->stream) != hipErrorNotReady) break;   // finished (the words arrive with it) or failed: the synchronisation below reports which
+            if ((spin & 0xffff) == 0 && hipStreamQuery(h->stream) != hipErrorNotReady) break;   // (about once a millisecond) finished -- the words arrive with it -- or failed: the synchronisation below reports which
             __builtin_ia32_pause();
         }
         std::atomic_thread_fence(std::memory_order_acquire);
