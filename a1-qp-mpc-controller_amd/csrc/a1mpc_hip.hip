@@ -2273,6 +2273,8 @@ a1mpc_status a1mpc_last_control_tick_ms(a1mpc_handle h, float* ms_out, int32_t* 
     return A1MPC_OK;
 }
 
+static a1mpc_status ticks_small_batch(a1mpc_handle h, int32_t n, const double* tick, const double* R_world, const double* foot_abs, const uint8_t* contact, double* grf_body_out,
+                                      double* u_full_out, int32_t* iters_out, int32_t* status_out, bool* taken);
 a1mpc_status a1mpc_solve_batch_ticks(a1mpc_handle h, int32_t n, const double* tick, const double* R_world, const double* foot_abs,
                                      const uint8_t* contact, double* grf_body_out, double* u_full_out, int32_t* iters_out,
                                      int32_t* status_out) {
@@ -2282,11 +2284,16 @@ a1mpc_status a1mpc_solve_batch_ticks(a1mpc_handle h, int32_t n, const double* ti
     if (n == 0) return A1MPC_OK;
     A1_HIP(hipSetDevice(h->device));
     const size_t N = n, H = h->cfg.horizon;
+    if (H < 2) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "tick records need horizon >= 2");
+    {   // a handful of ticks (the drop-in's compute_grf is n = 1): the kernel reads the handle's pinned block itself, the host polls the outputs (ticks_small_batch)
+        bool taken = false;
+        const a1mpc_status stz = ticks_small_batch(h, n, tick, R_world, foot_abs, contact, grf_body_out, u_full_out, iters_out, status_out, &taken);
+        if (taken) return stz;
+    }
     hipStream_t s = h->stream;
     A1_ORDER(h, s);
     // 22 + 9 + 12 doubles + 4 bytes per QP: the tick record rides in the x_ref staging buffer (13H >= 22 for H >= 2; H = 1 has its own room: 13 + 13)
     double* d_tick = (H >= 2) ? h->d_xref : h->d_x0;
-    if (H < 2) return fail(A1MPC_ERR_UNSUPPORTED_HORIZON, "tick records need horizon >= 2");
     A1_HIP(hipMemcpyAsync(d_tick, tick, N * 22 * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(h->d_R, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
     A1_HIP(hipMemcpyAsync(h->d_foot, foot_abs, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
@@ -2378,15 +2385,9 @@ static void host_collect(a1mpc_handle h, int32_t n, double* grf_body_out, double
     if (status_out) std::memcpy(status_out, hout + q.q_st, N * sizeof(int32_t));
 }
 
-a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
-                               const double* foot_abs, const uint8_t* contact, double* grf_body_out, double* u_full_out,
-                               int32_t* iters_out, int32_t* status_out) {
-    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
-    if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !grf_body_out)
-        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
-    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
-    if (n == 0) return A1MPC_OK;
-    if (a1mpc_status st = host_submit(h, n, x0, x_ref, R_world, foot_abs, contact, u_full_out != nullptr); st != A1MPC_OK) { h->zc_poll_bytes = 0; return st; }
+// Waits for the outputs of the launch host_submit / ticks_small_batch has just queued: polls the pinned block's output words when the kernel writes them itself
+// (zc_poll_bytes, see host_submit), synchronises the stream otherwise.
+static a1mpc_status host_wait_outputs(a1mpc_handle h, int32_t n) {
     bool done = false;
     if (h->zc_poll_bytes) {   // the kernel writes into the pinned block itself: poll its output words (and the stream now and then: a launch that failed never writes them)
         const HostOut q = host_out_layout(static_cast<size_t>(n));
@@ -2408,6 +2409,56 @@ a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, cons
         h->zc_poll_bytes = 0;
     }
     if (!done) A1_HIP(hipStreamSynchronize(h->stream));
+    return A1MPC_OK;
+}
+// a1mpc_solve_batch_ticks for a handful of robots -- what the drop-in's compute_grf calls with n = 1 (include/a1mpc_dropin.hpp) -- the way host_submit serves a1mpc_solve_batch: the
+// tick records, R, feet and contacts are snapshotted into the pinned block, the kernel reads and writes that block itself, the host polls the output words.  (Until round 6's
+// last session this entry always took four pageable host-to-device copies, the launch and up to four copies back.)
+static a1mpc_status ticks_small_batch(a1mpc_handle h, int32_t n, const double* tick, const double* R_world, const double* foot_abs, const uint8_t* contact, double* grf_body_out,
+                                      double* u_full_out, int32_t* iters_out, int32_t* status_out, bool* taken) {
+    static const int zero_copy_max = [] { const char* e = getenv("A1MPC_ZERO_COPY_MAX"); return e ? atoi(e) : 8; }();
+    *taken = false;
+    if (n > zero_copy_max || h->d_pin == nullptr) return A1MPC_OK;
+    *taken = true;
+    const size_t N = n, H = h->cfg.horizon;
+    const size_t o_t = 0, o_R = o_t + N * 22 * sizeof(double), o_f = o_R + N * 9 * sizeof(double), o_c = o_f + N * 12 * sizeof(double);   // (< h_pin_in_bytes: 43 doubles + 4 bytes per QP)
+    const HostOut q = host_out_layout(N);
+    const bool want_u = u_full_out != nullptr;
+    const size_t out_bytes = want_u ? q.q_u + N * 12 * H * sizeof(double) : q.q_u;
+    char* hin = h->h_pin; char* hout = h->h_pin + h->h_pin_in_bytes;
+    std::memcpy(hin + o_t, tick, N * 22 * sizeof(double));
+    std::memcpy(hin + o_R, R_world, N * 9 * sizeof(double));
+    std::memcpy(hin + o_f, foot_abs, N * 12 * sizeof(double));
+    std::memcpy(hin + o_c, contact, N * 4);
+    h->zc_poll_bytes = 0;
+    static const bool poll = [] { const char* e = getenv("A1MPC_POLL_COMPLETION"); return e ? atoi(e) != 0 : true; }();
+    if (poll) {
+        unsigned long long* w = reinterpret_cast<unsigned long long*>(hout);
+        for (size_t i = 0; i < (out_bytes + 7) / 8; ++i) w[i] = kInFlightWord;
+        std::atomic_thread_fence(std::memory_order_release);
+        h->zc_poll_bytes = out_bytes;
+    }
+    char* din = h->d_pin; char* dout = h->d_pin + h->h_pin_in_bytes;
+    const a1mpc_status st = a1mpc_solve_batch_ticks_device(
+        h, n, reinterpret_cast<const double*>(din + o_t), reinterpret_cast<const double*>(din + o_R), reinterpret_cast<const double*>(din + o_f),
+        reinterpret_cast<const uint8_t*>(din + o_c), reinterpret_cast<double*>(dout + q.q_grf), want_u ? reinterpret_cast<double*>(dout + q.q_u) : nullptr,
+        reinterpret_cast<int32_t*>(dout + q.q_it), reinterpret_cast<int32_t*>(dout + q.q_st), h->stream);
+    if (st != A1MPC_OK) { h->zc_poll_bytes = 0; return st; }
+    if (a1mpc_status sw = host_wait_outputs(h, n); sw != A1MPC_OK) return sw;
+    host_collect(h, n, grf_body_out, u_full_out, iters_out, status_out);
+    return A1MPC_OK;
+}
+
+a1mpc_status a1mpc_solve_batch(a1mpc_handle h, int32_t n, const double* x0, const double* x_ref, const double* R_world,
+                               const double* foot_abs, const uint8_t* contact, double* grf_body_out, double* u_full_out,
+                               int32_t* iters_out, int32_t* status_out) {
+    if (!h) return fail(A1MPC_ERR_INVALID_ARGUMENT, "null handle");
+    if (n < 0 || !x0 || !x_ref || !R_world || !foot_abs || !contact || !grf_body_out)
+        return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
+    if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
+    if (n == 0) return A1MPC_OK;
+    if (a1mpc_status st = host_submit(h, n, x0, x_ref, R_world, foot_abs, contact, u_full_out != nullptr); st != A1MPC_OK) { h->zc_poll_bytes = 0; return st; }
+    if (a1mpc_status st = host_wait_outputs(h, n); st != A1MPC_OK) return st;
     host_collect(h, n, grf_body_out, u_full_out, iters_out, status_out);
     return A1MPC_OK;
 }

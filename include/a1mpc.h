@@ -191,6 +191,7 @@ a1mpc_status a1mpc_solve_batch_strided_device(a1mpc_handle h, int32_t n, const d
  *   [0:3] root_euler  [3:6] root_pos  [6:9] root_ang_vel  [9:12] root_lin_vel          (world frame, as in mpc_states)
  *   [12:15] root_euler_d  [15:18] root_lin_vel_d (BODY frame; rotated by R_world as at :470)  [18:21] root_ang_vel_d  [21] root_pos_d[2]
  * Input per QP drops from (13 + 13H) to 22 doubles.  Host pointers; a1mpc_solve_batch_ticks_device takes device pointers + a stream.
+ * A handful of ticks (n <= 8; the drop-in's compute_grf is n = 1) take the pinned-block path of a1mpc_solve_batch (see there).
  */
 a1mpc_status a1mpc_solve_batch_ticks(a1mpc_handle h, int32_t n, const double* tick, const double* R_world, const double* foot_abs,
                                      const uint8_t* contact, double* grf_body_out, double* u_full_out, int32_t* iters_out,

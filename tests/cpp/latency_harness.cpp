@@ -2,6 +2,7 @@
 // = trot, horizon 10, 10 000 sequential warm-started ticks (S/A1Params.h:10: a tick every 2.5 ms; S/MainGazebo.cpp:57-68 is the caller).
 // Host pointers in and out (PCIe and launch included), one caller thread.  Prints one JSON object.
 //   latency_harness [ticks=10000] [pace_us=0] [warm_mode=1] [horizon=10] [timing_events=0]      pace_us > 0 sleeps between ticks like the reference's thread 1 does; horizon 10 / 16 / 20
+//                   [entry=0]   1 = the same ticks as 22-number tick records through a1mpc_solve_batch_ticks -- the entry the drop-in's compute_grf calls (include/a1mpc_dropin.hpp)
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -24,6 +25,7 @@ int main(int argc, char** argv) {
     const int warm_mode = argc > 3 ? atoi(argv[3]) : 1;   // 1 = fresh set-up + warm start, 2 = the reference's update path (a1mpc.h)
     const int H = argc > 4 ? atoi(argv[4]) : 10;          // PLAN_HORIZON (S/A1Params.h:26 fixes 10; BASELINE configs[3] / [4]: 16 / 20)
     if (H != 10 && H != 16 && H != 20) { std::fprintf(stderr, "horizon must be 10, 16 or 20\n"); return 1; }
+    const int entry = argc > 6 ? atoi(argv[6]) : 0;       // 0 = a1mpc_solve_batch (x0 / x_ref), 1 = a1mpc_solve_batch_ticks (the tick record x0 / x_ref are built from on the device)
     const int timing = argc > 5 ? atoi(argv[5]) : 0;      // the handle's HIP timing events (a1mpc_set_timing): off by default here -- a control loop does not read them
     a1mpc_config cfg;
     a1mpc_default_config(&cfg);
@@ -60,7 +62,10 @@ int main(int argc, char** argv) {
         contact[0] = ph; contact[1] = !ph; contact[2] = !ph; contact[3] = ph;
         int32_t it = 0, st = 0;
         const auto a = std::chrono::steady_clock::now();
-        const a1mpc_status rc = a1mpc_solve_batch(h, 1, x0, xref, R, foot, contact, grf, nullptr, &it, &st);
+        // the tick record of the same tick: [euler, pos, ang_vel, lin_vel | euler_d, lin_vel_d (body), ang_vel_d, pos_z_d] (include/a1mpc.h)
+        const double tick[22] = {x0[0], x0[1], x0[2], x0[3], x0[4], x0[5], x0[6], x0[7], x0[8], x0[9], x0[10], x0[11], 0, 0, 0, 0.3, 0, 0, 0, 0, 0, 0.3};
+        const a1mpc_status rc = entry == 1 ? a1mpc_solve_batch_ticks(h, 1, tick, R, foot, contact, grf, nullptr, &it, &st)
+                                           : a1mpc_solve_batch(h, 1, x0, xref, R, foot, contact, grf, nullptr, &it, &st);
         const auto b = std::chrono::steady_clock::now();
         if (rc != A1MPC_OK) { std::fprintf(stderr, "a1mpc_solve_batch: %s\n", a1mpc_last_error()); return 3; }
         lat[t] = std::chrono::duration<double, std::milli>(b - a).count();
@@ -76,8 +81,8 @@ int main(int argc, char** argv) {
     int over = 0, worst_t = skip;
     for (int t = skip; t < ticks; ++t) { over += lat[t] > 2.5; if (lat[t] > lat[worst_t]) worst_t = t; }
     double mean_it = 0; for (int t = skip; t < ticks; ++t) mean_it += iters[t]; mean_it /= (ticks - skip);
-    std::printf("{\"warm_start\": %d, \"workload\": \"config2 trot, h=%d, batch 1, warm start, host pointers in/out, C++ caller, %s\", \"horizon\": %d, \"timing_events\": %d, \"ticks\": %zu, \"p50_ms\": %.4f, \"p99_ms\": %.4f, "
+    std::printf("{\"warm_start\": %d, \"workload\": \"config2 trot, h=%d, batch 1, warm start, host pointers in/out (%s), C++ caller, %s\", \"horizon\": %d, \"timing_events\": %d, \"ticks\": %zu, \"p50_ms\": %.4f, \"p99_ms\": %.4f, "
                 "\"p999_ms\": %.4f, \"max_ms\": %.4f, \"ticks_over_2p5_ms\": %d, \"worst_tick_index\": %d, \"worst_tick_iters\": %d, \"mean_iters\": %.1f, \"not_solved\": %d}\n",
-                warm_mode, H, pace_us > 0 ? "paced" : "back to back", H, timing, v.size(), pct(0.50), pct(0.99), pct(0.999), s.back(), over, worst_t, iters[worst_t], mean_it, bad_status);
+                warm_mode, H, entry == 1 ? "tick records: a1mpc_solve_batch_ticks" : "x0 / x_ref: a1mpc_solve_batch", pace_us > 0 ? "paced" : "back to back", H, timing, v.size(), pct(0.50), pct(0.99), pct(0.999), s.back(), over, worst_t, iters[worst_t], mean_it, bad_status);
     return 0;
 }

@@ -203,6 +203,40 @@ def test_tick_records_N1(pkg, oracle, scen):
         compare({k: v[:32] if v is not None else None for k, v in a.items()}, oracle_batch(oracle, take(sc, 32)), min_same=1.0)
 
 
+def test_small_host_batches_of_tick_records_take_the_pinned_block(pkg, oracle, scen):
+    """Round 6: a1mpc_solve_batch_ticks with a handful of robots (the drop-in's compute_grf is n = 1) lets the kernel read and write the handle's pinned block and polls the
+    output words, like a1mpc_solve_batch; larger batches keep the staged copies.  The same robots through both (n = 1, 3, 8 against the first rows of an n = 9 call; cold
+    solves, so nothing depends on history), with and without the inputs' copy out: bit for bit, every QP at the oracle's iteration count -- and 300 warm-started
+    batch-1 ticks of one robot equal the same ticks taken from the device-pointer entry."""
+    sc = scen.config3_random_flat(nb=9, seed=4242)
+    with _engine(pkg, sc, 16, warm_start=0) as eng:
+        big = eng.solve_ticks(sc["tick"], sc["R"], sc["foot"], sc["contact"], want_u=True)           # n = 9: staged
+        compare(big, oracle_batch(oracle, sc), min_same=1.0)
+        for n in (1, 3, 8):
+            for want_u in (True, False):
+                s = take(sc, n)
+                a = eng.solve_ticks(sc["tick"][:n], s["R"], s["foot"], s["contact"], want_u=want_u)   # n <= 8: the pinned block, polled
+                assert np.array_equal(a["grf"], big["grf"][:n]) and np.array_equal(a["iters"], big["iters"][:n]) and np.array_equal(a["status"], big["status"][:n]), (n, want_u)
+                if want_u: assert np.array_equal(a["u"], big["u"][:n]), n
+                b = eng.solve(s["x0"], s["xref"], s["R"], s["foot"], s["contact"], want_u=want_u)      # the x0 / x_ref entry's small-batch path
+                assert (a["iters"] == b["iters"]).all() and np.abs(a["grf"] - b["grf"]).max() < TOL_FORCE_N
+    seq = scen.config2_trot_sequence(300)
+    import torch
+    dev = torch.device("cuda", 0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tick = np.zeros((300, 22)); tick[:, 0:12] = seq["x0"][:, 0:12]; tick[:, 12:15] = seq["x0"][:, 0:3]; tick[:, 15] = 0.2; tick[:, 21] = 0.3
+    cfg = pkg.make_config(seq["params"], 10, warm_start=1)
+    with pkg.Engine(cfg, 4, 0) as e1, pkg.Engine(cfg, 4, 0) as e2:
+        g = torch.zeros(1, 12, dtype=torch.float64, device=dev); it = torch.zeros(1, dtype=torch.int32, device=dev); stt = torch.zeros(1, dtype=torch.int32, device=dev)
+        for t in range(300):
+            a = e1.solve_ticks(tick[t], seq["R"][t], seq["foot"][t], seq["contact"][t])
+            ins = [T(tick[t:t + 1]), T(seq["R"][t:t + 1]), T(seq["foot"][t:t + 1]), T(seq["contact"][t:t + 1].astype(np.uint8))]
+            rc = e2.lib.a1mpc_solve_batch_ticks_device(e2._h, 1, *[C.c_void_p(x.data_ptr()) for x in ins], C.c_void_p(g.data_ptr()), None, C.c_void_p(it.data_ptr()), C.c_void_p(stt.data_ptr()), None)
+            assert rc == 0
+            nf = (C.c_int32 * 1)(); assert e2.lib.a1mpc_last_nfact(e2._h, 1, nf) == 0   # (synchronises the handle's stream, which the launch went to)
+            assert np.array_equal(a["grf"][0], g.cpu().numpy()[0]) and a["iters"][0] == int(it[0]) and a["status"][0] == int(stt[0]), t
+
+
 def test_device_pointer_entry_and_batched_warm_start(pkg, oracle, scen):
     """a1mpc_solve_batch_device (asynchronous, caller's stream, torch tensors in HBM) == the host-pointer entry; and a batch of
     300 robots ticked twice with warm start matches 300 sequentially warm-started oracle solvers"""
