@@ -121,6 +121,11 @@ def latency_probe(pkg, nticks=1500, mode=1, horizon=10, cpp_ticks=10000):
                     if r2.returncode == 0:
                         j2 = json.loads(r2.stdout)
                         res["timing_events_on"] = {k: j2.get(k) for k in ("p50_ms", "p99_ms", "max_ms", "ticks_over_2p5_ms")}
+                    # ... and the same ticks as 22-number tick records through a1mpc_solve_batch_ticks: the entry the drop-in's compute_grf calls (include/a1mpc_dropin.hpp)
+                    r3 = subprocess.run([exe, str(cpp_ticks), "0", str(mode), str(horizon), "0", "1"], capture_output=True, text=True, timeout=120, env=env)
+                    if r3.returncode == 0:
+                        j3 = json.loads(r3.stdout)
+                        res["tick_record_entry"] = {k: j3.get(k) for k in ("p50_ms", "p99_ms", "max_ms", "ticks_over_2p5_ms", "mean_iters")}
                 return res
         except Exception:
             pass
@@ -1017,6 +1022,7 @@ def main():
                     "latency_p50_ms": r3(out["latency"].get("p50_ms")), "latency_p99_ms": r3(out["latency"].get("p99_ms")), "latency_max_ms": r3(out["latency"].get("max_ms")),
                     "latency_mode2_p50_ms": r3(out["latency_update_path"].get("p50_ms")), "latency_mode2_p99_ms": r3(out["latency_update_path"].get("p99_ms")),
                     "latency_timing_events_on_p50_ms": r3(out["latency"].get("timing_events_on", {}).get("p50_ms")), "latency_timing_events_on_p99_ms": r3(out["latency"].get("timing_events_on", {}).get("p99_ms")),
+                    "latency_tick_record_entry_p50_ms": r3(out["latency"].get("tick_record_entry", {}).get("p50_ms")), "latency_tick_record_entry_p99_ms": r3(out["latency"].get("tick_record_entry", {}).get("p99_ms")),
                     "latency_h16_mode2_p50_ms": r3(out["latency_update_path_h16"].get("p50_ms")), "latency_h16_mode2_p99_ms": r3(out["latency_update_path_h16"].get("p99_ms")),
                     "latency_h20_mode2_p50_ms": r3(out["latency_update_path_h20"].get("p50_ms")), "latency_h20_mode2_p99_ms": r3(out["latency_update_path_h20"].get("p99_ms")),
                     "latency_budget_ms": 2.5, "single_stream_solves_per_s": r3(out.get("single_stream_solves_per_s"), 0), "value_with_8_untimed_launches": r3(out.get("value_with_8_untimed_launches"), 0),
