@@ -2610,12 +2610,33 @@ a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_confi
     const size_t N = n;
     hipStream_t s = h->stream;
     A1_ORDER(h, s);
-    // the transfers are small (344 B per QP); pageable copies on the stream are synchronous w.r.t. the host buffer
-    A1_HIP(hipMemcpyAsync(h->d_aux, root_acc, N * 6 * sizeof(double), hipMemcpyHostToDevice, s));
-    A1_HIP(hipMemcpyAsync(h->d_R, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
-    A1_HIP(hipMemcpyAsync(h->d_Rz, R_z, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
-    A1_HIP(hipMemcpyAsync(h->d_foot, foot_abs, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
-    A1_HIP(hipMemcpyAsync(h->d_contact, contact, N * 4, hipMemcpyHostToDevice, s));
+    // A handful of QPs (the drop-in's compute_grf with stance_leg_control_type = 0 is n = 1): inputs and outputs in the handle's pinned block, read and written by the kernel
+    // itself, the output words polled -- the small-batch path of a1mpc_solve_batch (host_submit).  Larger batches: the transfers are small (344 B per QP); pageable copies on
+    // the stream are synchronous w.r.t. the host buffer
+    static const int zero_copy_max = [] { const char* e = getenv("A1MPC_ZERO_COPY_MAX"); return e ? atoi(e) : 8; }();
+    static const bool poll = [] { const char* e = getenv("A1MPC_POLL_COMPLETION"); return e ? atoi(e) != 0 : true; }();
+    const bool small = n <= zero_copy_max && h->d_pin != nullptr;
+    const size_t o_a = 0, o_R = o_a + N * 6 * sizeof(double), o_Rz = o_R + N * 9 * sizeof(double), o_f = o_Rz + N * 9 * sizeof(double), o_c = o_f + N * 12 * sizeof(double);
+    const HostOut q = host_out_layout(N);
+    const size_t out_bytes = f_world_out ? q.q_u + N * 12 * sizeof(double) : q.q_u;
+    h->zc_poll_bytes = 0;
+    if (small) {
+        char* hin = h->h_pin; char* hout = h->h_pin + h->h_pin_in_bytes;
+        std::memcpy(hin + o_a, root_acc, N * 6 * sizeof(double)); std::memcpy(hin + o_R, R_world, N * 9 * sizeof(double)); std::memcpy(hin + o_Rz, R_z, N * 9 * sizeof(double));
+        std::memcpy(hin + o_f, foot_abs, N * 12 * sizeof(double)); std::memcpy(hin + o_c, contact, N * 4);
+        if (poll) {
+            unsigned long long* w = reinterpret_cast<unsigned long long*>(hout);
+            for (size_t i = 0; i < (out_bytes + 7) / 8; ++i) w[i] = kInFlightWord;
+            std::atomic_thread_fence(std::memory_order_release);
+            h->zc_poll_bytes = out_bytes;
+        }
+    } else {
+        A1_HIP(hipMemcpyAsync(h->d_aux, root_acc, N * 6 * sizeof(double), hipMemcpyHostToDevice, s));
+        A1_HIP(hipMemcpyAsync(h->d_R, R_world, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+        A1_HIP(hipMemcpyAsync(h->d_Rz, R_z, N * 9 * sizeof(double), hipMemcpyHostToDevice, s));
+        A1_HIP(hipMemcpyAsync(h->d_foot, foot_abs, N * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+        A1_HIP(hipMemcpyAsync(h->d_contact, contact, N * 4, hipMemcpyHostToDevice, s));
+    }
     KernelArgs a;
     std::memset(&a, 0, sizeof a);
     a.P = h->dp;
@@ -2626,13 +2647,29 @@ a1mpc_status a1mpc_balance_solve_batch(a1mpc_handle h, const a1mpc_balance_confi
     a.tab = h->d_tab1; a.n = n;
     a.root_acc = h->d_aux; a.Rz = h->d_Rz; a.R = h->d_R; a.foot = h->d_foot; a.contact = h->d_contact;
     a.grf = h->d_grf; a.u_full = h->d_u; a.iters = h->d_iters; a.status = h->d_status; a.nfact = h->d_nfact;
+    if (small) {
+        const char* din = h->d_pin; char* dout = h->d_pin + h->h_pin_in_bytes;
+        a.root_acc = reinterpret_cast<const double*>(din + o_a); a.R = reinterpret_cast<const double*>(din + o_R); a.Rz = reinterpret_cast<const double*>(din + o_Rz);
+        a.foot = reinterpret_cast<const double*>(din + o_f); a.contact = reinterpret_cast<const uint8_t*>(din + o_c);
+        a.grf = reinterpret_cast<double*>(dout + q.q_grf); a.u_full = f_world_out ? reinterpret_cast<double*>(dout + q.q_u) : nullptr;
+        a.iters = reinterpret_cast<int32_t*>(dout + q.q_it); a.status = reinterpret_cast<int32_t*>(dout + q.q_st);
+    }
     if (h->timing) A1_HIP(hipEventRecord(h->ev0, s));
     h->staged = false;
     a1mpc_status st = launch<1, kModeBalance>(a, s);
-    if (st != A1MPC_OK) return st;
+    if (st != A1MPC_OK) { h->zc_poll_bytes = 0; return st; }
     if (h->timing) A1_HIP(hipEventRecord(h->ev1, s));
     h->timed = h->timing;
     A1_MARK(h, s);
+    if (small) {
+        if (a1mpc_status sw = host_wait_outputs(h, n); sw != A1MPC_OK) return sw;
+        const char* hout = h->h_pin + h->h_pin_in_bytes;
+        std::memcpy(grf_body_out, hout + q.q_grf, N * 12 * sizeof(double));
+        if (f_world_out) std::memcpy(f_world_out, hout + q.q_u, N * 12 * sizeof(double));
+        if (iters_out) std::memcpy(iters_out, hout + q.q_it, N * sizeof(int32_t));
+        if (status_out) std::memcpy(status_out, hout + q.q_st, N * sizeof(int32_t));
+        return A1MPC_OK;
+    }
     A1_HIP(hipMemcpyAsync(grf_body_out, h->d_grf, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (f_world_out) A1_HIP(hipMemcpyAsync(f_world_out, h->d_u, N * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (iters_out) A1_HIP(hipMemcpyAsync(iters_out, h->d_iters, N * sizeof(int32_t), hipMemcpyDeviceToHost, s));

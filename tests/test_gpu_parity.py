@@ -108,6 +108,24 @@ def test_balance_qp(pkg, oracle, scen):
         assert np.allclose(o1["grf"].reshape(4, 3)[:, 2], 12.0 * 9.8 / 4, atol=0.02)  # ~ m g / 4 per leg
 
 
+def test_small_balance_batches_take_the_pinned_block(pkg, oracle, scen):
+    """Round 6: a1mpc_balance_solve_batch with a handful of QPs (the drop-in's compute_grf with stance_leg_control_type = 0 is n = 1) reads and writes the handle's pinned block and
+    polls the output words; larger batches keep the staged copies.  n = 1, 4, 8 against the first rows of an n = 9 call bit for bit, every QP at the oracle's iteration count."""
+    sc = scen.balance_random(9)
+    cfg = pkg.make_config(scen.PARAM_SETS["gazebo"] | scen.MPC_CONSTANTS, 10)
+    qp, st = oracle.default_qp_params(), oracle.default_settings()
+    with pkg.Engine(cfg, 16, 0) as eng:
+        big = eng.balance_solve(sc["root_acc"], sc["R"], sc["Rz"], sc["foot"], sc["contact"])            # staged
+        for b in range(9):
+            r = oracle.balance_solve(qp, st, sc["root_acc"][b], sc["R"][b], sc["Rz"][b], sc["foot"][b], sc["contact"][b])
+            assert big["iters"][b] == r["info"].iters and big["status"][b] == r["info"].status and np.abs(big["grf"][b] - r["grf"]).max() < TOL_FORCE_BALANCE_N
+        for n in (1, 4, 8):
+            for rep in range(3):   # (the block is reused call after call)
+                a = eng.balance_solve(sc["root_acc"][:n], sc["R"][:n], sc["Rz"][:n], sc["foot"][:n], sc["contact"][:n])   # the pinned block, polled
+                for k in ("grf", "f_world", "iters", "status"):
+                    assert np.array_equal(a[k], big[k][:n]), (n, rep, k)
+
+
 def test_size_independent_properties_full_batch(pkg, scen):
     """BASELINE config 3 at its full size (4096, h=10): properties that need no oracle."""
     sc = scen.config3_random_flat()
