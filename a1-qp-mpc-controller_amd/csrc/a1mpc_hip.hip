@@ -539,6 +539,8 @@ struct a1mpc_handle_s {
     char* h_pin = nullptr;
     char* d_pin = nullptr;   // the pinned block as the device sees it (hipHostGetDevicePointer), or null: small batches read / write it directly (host_submit)
     size_t h_pin_bytes = 0, h_pin_in_bytes = 0;
+    char *h_pin_gen = nullptr, *d_pin_gen = nullptr;   // a small pinned block for the general path's inputs of <= 8 QPs (per-step feet / contacts do not fit the block above), allocated on first use
+    size_t h_pin_gen_bytes = 0;
 };
 
 static a1mpc_status order_streams(a1mpc_handle h, hipStream_t s) {
@@ -1693,6 +1695,7 @@ void a1mpc_destroy(a1mpc_handle h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->h_pin_gen) (void)hipHostFree(h->h_pin_gen);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_order) (void)hipEventDestroy(h->ev_order);
@@ -2592,6 +2595,50 @@ a1mpc_status a1mpc_solve_batch_strided(a1mpc_handle h, int32_t n, const double* 
         return fail(A1MPC_ERR_INVALID_ARGUMENT, "null input/output pointer");
     if (n > h->max_batch) return fail(A1MPC_ERR_BATCH_TOO_LARGE, "n > max_batch given to a1mpc_create");
     if (n == 0) return A1MPC_OK;
+    {   // A handful of QPs on the general path (the drop-in's ConvexMpc-level call is n = 1): the small-batch path of a1mpc_solve_batch -- inputs in a pinned block the kernel
+        // reads itself (one of its own: per-step feet / contacts do not fit the handle's), outputs in the handle's pinned block, the output words polled.  Until round 6's last
+        // session: five or six pageable copies in, one back, a synchronisation.
+        static const int zero_copy_max = [] { const char* e = getenv("A1MPC_ZERO_COPY_MAX"); return e ? atoi(e) : 8; }();
+        static const bool poll = [] { const char* e = getenv("A1MPC_POLL_COMPLETION"); return e ? atoi(e) != 0 : true; }();
+        if (n <= zero_copy_max && zero_copy_max <= 64 && h->d_pin != nullptr) {
+            A1_HIP(hipSetDevice(h->device));
+            const size_t N = n, H = h->cfg.horizon, M = static_cast<size_t>(zero_copy_max);
+            if (!h->h_pin_gen) {
+                h->h_pin_gen_bytes = M * ((13 + 13 * H + 9 + 12 * H + 1) * sizeof(double) + 4 * H + 8);
+                A1_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_pin_gen), h->h_pin_gen_bytes, hipHostMallocDefault));
+                void* dp = nullptr;
+                if (hipHostGetDevicePointer(&dp, h->h_pin_gen, 0) == hipSuccess) h->d_pin_gen = static_cast<char*>(dp); else (void)hipGetLastError();
+            }
+            if (h->d_pin_gen != nullptr) {
+                const size_t nfoot = foot_stride ? 12 * H : 12, ncont = contact_stride ? 4 * H : 4;
+                const size_t o_x0 = 0, o_xr = o_x0 + N * 13 * sizeof(double), o_R = o_xr + N * 13 * H * sizeof(double), o_f = o_R + N * 9 * sizeof(double),
+                             o_y = o_f + N * nfoot * sizeof(double), o_c = o_y + N * sizeof(double);
+                const HostOut q = host_out_layout(N);
+                const bool want_u = u_full_out != nullptr;
+                const size_t out_bytes = want_u ? q.q_u + N * 12 * H * sizeof(double) : q.q_u;
+                char* hin = h->h_pin_gen; char* hout = h->h_pin + h->h_pin_in_bytes;
+                std::memcpy(hin + o_x0, x0, N * 13 * sizeof(double)); std::memcpy(hin + o_xr, x_ref, N * 13 * H * sizeof(double)); std::memcpy(hin + o_R, R_world, N * 9 * sizeof(double));
+                std::memcpy(hin + o_f, foot_abs, N * nfoot * sizeof(double)); if (yaw_A) std::memcpy(hin + o_y, yaw_A, N * sizeof(double)); std::memcpy(hin + o_c, contact, N * ncont);
+                h->zc_poll_bytes = 0;
+                if (poll) {
+                    unsigned long long* w = reinterpret_cast<unsigned long long*>(hout);
+                    for (size_t i = 0; i < (out_bytes + 7) / 8; ++i) w[i] = kInFlightWord;
+                    std::atomic_thread_fence(std::memory_order_release);
+                    h->zc_poll_bytes = out_bytes;
+                }
+                const char* din = h->d_pin_gen; char* dout = h->d_pin + h->h_pin_in_bytes;
+                const a1mpc_status st = solve_device_impl(
+                    h, n, nullptr, reinterpret_cast<const double*>(din + o_x0), reinterpret_cast<const double*>(din + o_xr), reinterpret_cast<const double*>(din + o_R),
+                    reinterpret_cast<const double*>(din + o_f), reinterpret_cast<const uint8_t*>(din + o_c), reinterpret_cast<double*>(dout + q.q_grf),
+                    want_u ? reinterpret_cast<double*>(dout + q.q_u) : nullptr, reinterpret_cast<int32_t*>(dout + q.q_it), reinterpret_cast<int32_t*>(dout + q.q_st), h->stream,
+                    foot_stride, contact_stride, yaw_A ? reinterpret_cast<const double*>(din + o_y) : nullptr);
+                if (st != A1MPC_OK) { h->zc_poll_bytes = 0; return st; }
+                if (a1mpc_status sw = host_wait_outputs(h, n); sw != A1MPC_OK) return sw;
+                host_collect(h, n, grf_body_out, u_full_out, iters_out, status_out);
+                return A1MPC_OK;
+            }
+        }
+    }
     if (a1mpc_status st = strided_host_submit(h, n, x0, x_ref, R_world, foot_abs, foot_stride, contact, contact_stride, yaw_A, u_full_out != nullptr); st != A1MPC_OK) return st;
     A1_HIP(hipStreamSynchronize(h->stream));
     host_collect(h, n, grf_body_out, u_full_out, iters_out, status_out);

@@ -219,3 +219,21 @@ def test_general_path_warm_started_sequence_and_device_pointers(pkg, oracle, sce
         assert rc == 0
         torch.cuda.synchronize()
     assert np.array_equal(g.cpu().numpy(), host["grf"]) and np.array_equal(it.cpu().numpy(), host["iters"])
+
+
+@pytest.mark.parametrize("h", (10, 16))
+def test_small_general_path_batches_take_a_pinned_block(pkg, oracle, scen, h):
+    """Round 6: a1mpc_solve_batch_strided with a handful of QPs (the drop-in's ConvexMpc-level call is n = 1) packs its inputs into a small pinned block the kernel reads itself and
+    polls the output words; larger batches keep the staged copies.  Per-step feet + schedules, per-step feet alone, and a separate A_c yaw: n = 1, 3, 8 against the first rows
+    of an n = 9 call bit for bit (cold solves), with and without the inputs' copy out."""
+    rng = np.random.default_rng(600 + h)
+    for feet, cont, yaw in ((True, True, False), (True, False, True), (False, True, True)):
+        sc, foot, fs, contact, cs = _strided_inputs(scen, rng, h, 9, feet, cont)
+        yaw_A = (sc["x0"][:, 2] + rng.normal(0, 0.05, 9)) if yaw else None
+        with _engine(pkg, sc, 16, warm_start=0) as eng:
+            big = eng.solve_strided(sc["x0"], sc["xref"], sc["R"], foot, fs, contact, cs, want_u=True, yaw_A=yaw_A)                  # n = 9: staged
+            for n in (1, 3, 8):
+                for want_u in (True, False):
+                    a = eng.solve_strided(sc["x0"][:n], sc["xref"][:n], sc["R"][:n], foot[:n], fs, contact[:n], cs, want_u=want_u, yaw_A=None if yaw_A is None else yaw_A[:n])
+                    assert np.array_equal(a["grf"], big["grf"][:n]) and np.array_equal(a["iters"], big["iters"][:n]) and np.array_equal(a["status"], big["status"][:n]), (feet, cont, yaw, n, want_u)
+                    if want_u: assert np.array_equal(a["u"], big["u"][:n]), (feet, cont, yaw, n)
